@@ -1,0 +1,10 @@
+"""flowgger_amd -- MI355X (gfx950) bulk log-line decoder behind flowgger's Decoder/Record interface.
+
+Scope: the per-line ``Decoder::decode()`` hot path (RFC5424, LTSV, GELF) of awslabs/flowgger,
+rebuilt as hand-written HIP kernels behind a C ABI (include/fg_hip.h).  See DESIGN.md.
+"""
+from .record import DecodeError, Record, SDValue, StructuredData  # noqa: F401
+from .decoder import Decoder, GelfDecoder, LTSVDecoder, RFC5424Decoder, pack_lines  # noqa: F401
+
+__all__ = ["Decoder", "RFC5424Decoder", "LTSVDecoder", "GelfDecoder", "Record", "StructuredData",
+           "SDValue", "DecodeError", "pack_lines"]

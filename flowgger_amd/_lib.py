@@ -1,0 +1,101 @@
+"""ctypes binding of libfg_hip.so (include/fg_hip.h).  Fails loudly: no library -> ImportError-like
+RuntimeError, no gfx950 device -> FgError(FG_ERR_NO_DEVICE).  There is no CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libfg_hip.so"
+
+FG_RFC5424, FG_LTSV, FG_GELF = 0, 1, 2
+FG_OK, FG_ERR_ARG, FG_ERR_HIP, FG_ERR_NO_DEVICE, FG_ERR_ENT_OVERFLOW, FG_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
+FG_NONE = 0xFFFFFFFF
+FG_T_STRING, FG_T_BOOL, FG_T_F64, FG_T_I64, FG_T_U64, FG_T_NULL, FG_T_SDID = range(7)
+FG_TABLE_ARRAYS = 15
+_ERRNAMES = {-1: "FG_ERR_ARG", -2: "FG_ERR_HIP", -3: "FG_ERR_NO_DEVICE (no gfx950 GPU; there is no CPU fallback)",
+             -4: "FG_ERR_ENT_OVERFLOW", -5: "FG_ERR_UNSUPPORTED"}
+
+
+class FgError(RuntimeError):
+    def __init__(self, code: int, what: str = ""):
+        self.code = code
+        super().__init__(f"{what}: {_ERRNAMES.get(code, code)}")
+
+
+class fg_span(C.Structure):
+    _fields_ = [("off", C.c_uint32), ("len", C.c_uint32)]
+
+
+class fg_tables(C.Structure):
+    _fields_ = [
+        ("n", C.c_uint64), ("ent_cap", C.c_uint64),
+        ("meta", C.c_void_p), ("ts", C.c_void_p),
+        ("hostname", C.c_void_p), ("appname", C.c_void_p), ("procid", C.c_void_p),
+        ("msgid", C.c_void_p), ("msg", C.c_void_p), ("full_msg", C.c_void_p),
+        ("ent_first", C.c_void_p), ("ent_count", C.c_void_p),
+        ("ent_name", C.c_void_p), ("ent_val", C.c_void_p),
+        ("ent_type", C.c_void_p), ("ent_flags", C.c_void_p), ("ent_used", C.c_void_p),
+    ]
+
+
+TABLE_FIELDS = ["meta", "ts", "hostname", "appname", "procid", "msgid", "msg", "full_msg", "ent_first",
+                "ent_count", "ent_name", "ent_val", "ent_type", "ent_flags", "ent_used"]
+
+
+class fg_cfg(C.Structure):
+    _fields_ = [
+        ("n_schema", C.c_uint32),
+        ("schema_names", C.POINTER(C.c_char_p)),
+        ("schema_types", C.POINTER(C.c_uint8)),
+        ("suffix_bool", C.c_char_p), ("suffix_f64", C.c_char_p),
+        ("suffix_i64", C.c_char_p), ("suffix_u64", C.c_char_p),
+    ]
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libfg_hip.so (after torch, when torch is importable, so both share one HIP runtime)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m flowgger_amd.build` "
+            "(hipcc --offload-arch=gfx950). The decoders have no CPU fallback.")
+    try:  # make torch's HIP runtime the process-wide one before ours is resolved
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional for the library itself
+        pass
+    L = C.CDLL(str(LIB_PATH))
+    vp, u64, u32 = C.c_void_p, C.c_uint64, C.c_uint32
+    L.fg_abi_version.restype = C.c_int
+    L.fg_create.argtypes = [C.c_int, C.POINTER(fg_cfg), C.POINTER(vp)]
+    L.fg_clone.argtypes = [vp, C.POINTER(vp)]
+    L.fg_destroy.argtypes = [vp]
+    L.fg_destroy.restype = None
+    L.fg_last_hip_error.argtypes = [vp]
+    L.fg_tables_layout.argtypes = [u64, u64, C.POINTER(u64)]
+    L.fg_decode_batch_device.argtypes = [vp, C.c_int, vp, u64, vp, u64, C.POINTER(fg_tables), vp]
+    L.fg_decode_batch.argtypes = [vp, C.c_int, vp, u64, vp, u64, C.POINTER(fg_tables)]
+    L.fg_error_string.argtypes = [C.c_int, C.c_uint8]
+    L.fg_error_string.restype = C.c_char_p
+    L.fg_tables_serialize.argtypes = [C.c_int, C.POINTER(fg_cfg), vp, vp, C.POINTER(fg_tables), u64, u64, vp, u64, vp]
+    L.fg_tables_serialize.restype = C.c_int64
+    L.fg_shard_plan.argtypes = [vp, u64, u32, vp]
+    L.fg_set_timing.argtypes = [vp, C.c_int]
+    L.fg_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    for name in ("fg_frame_lines_device", "fg_frame_lines"):
+        if hasattr(L, name):
+            getattr(L, name).restype = C.c_int
+    if L.fg_abi_version() != 1:
+        raise RuntimeError("libfg_hip.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise FgError(rc, what)

@@ -1,0 +1,98 @@
+"""Build libfg_hip.so (the gfx950 decode kernels + the C ABI of include/fg_hip.h) in-tree.
+
+hipcc cross-compiles for gfx950 without a GPU.  The link step is done by hand so that the
+library's DT_NEEDED entry for the HIP runtime is the unversioned ``libamdhip64.so``: inside a
+Python process that has imported PyTorch-ROCm, that name resolves to the runtime torch already
+loaded (torch ships ``libamdhip64.so`` without a SONAME), so device pointers and streams created
+by torch are valid in our kernels; in a standalone host process it resolves through ldconfig to
+/opt/rocm.  Two HIP runtimes in one process would not share allocations.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+CSRC = ROOT / "csrc"
+LIB = ROOT / "libfg_hip.so"
+ARCH = "gfx950"
+
+HIP_SOURCES = ["fg_rfc5424.hip", "fg_ltsv.hip", "fg_gelf.hip", "fg_frame.hip"]
+HIP_HOST_SOURCES = ["fg_capi.cpp"]  # host code that needs the HIP headers / launch syntax
+CXX_SOURCES = ["fg_materialize.cpp", "fg_host.cpp"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found: libfg_hip cannot be built (there is no CPU fallback)")
+
+
+def _hip_runtime_dir() -> str:
+    """Directory holding a libamdhip64.so WITHOUT a versioned SONAME (torch's), else /opt/rocm."""
+    try:
+        import importlib.util
+
+        spec = importlib.util.find_spec("torch")
+        if spec and spec.origin:
+            d = Path(spec.origin).parent / "lib"
+            if (d / "libamdhip64.so").exists():
+                return str(d)
+    except Exception:
+        pass
+    return "/opt/rocm/lib"
+
+
+def _run(cmd: list[str]) -> None:
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(" ".join(cmd) + "\n" + r.stdout + r.stderr)
+        raise RuntimeError(f"command failed: {' '.join(cmd[:3])} ...")
+
+
+def _stale(target: Path, deps: list[Path]) -> bool:
+    if not target.exists():
+        return True
+    t = target.stat().st_mtime
+    return any(d.exists() and d.stat().st_mtime > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    hipcc = _hipcc()
+    objdir = ROOT / "build"
+    objdir.mkdir(exist_ok=True)
+    headers = list(CSRC.glob("*.hpp")) + [ROOT.parent / "include" / "fg_hip.h", Path(__file__)]
+    common = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-fast-math",
+              "-ffp-contract=off", f"-I{ROOT.parent / 'include'}"]
+    objs: list[Path] = []
+    for name in HIP_SOURCES + HIP_HOST_SOURCES + CXX_SOURCES:
+        src = CSRC / name
+        if not src.exists():
+            continue
+        obj = objdir / (name + ".o")
+        objs.append(obj)
+        if not force and not _stale(obj, [src] + headers):
+            continue
+        if name in CXX_SOURCES:
+            cmd = ["g++", *common, "-c", str(src), "-o", str(obj)]
+        else:
+            cmd = [hipcc, f"--offload-arch={ARCH}", "-x", "hip", *common, "-c", str(src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd))
+        _run(cmd)
+    if force or _stale(LIB, objs):
+        rt = _hip_runtime_dir()
+        cmd = ["g++", "-shared", "-o", str(LIB), *map(str, objs), f"-L{rt}", "-lamdhip64",
+               "-Wl,--no-undefined", "-lpthread"]
+        if verbose:
+            print(" ".join(cmd))
+        _run(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

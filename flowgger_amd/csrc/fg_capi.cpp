@@ -1,0 +1,426 @@
+// fg_capi.cpp -- host side of the C ABI declared in include/fg_hip.h.
+//
+// Owns: device selection (gfx950 only, no CPU fallback), the per-ctx HIP stream, staging
+// buffers for the host-buffer entry point, HIP-event timing of the decode kernels.
+// It mirrors what XDecoder::new(&Config) + Box<dyn Decoder+Send>::clone do in the reference
+// (src/flowgger/mod.rs:413-422, src/flowgger/decoder/mod.rs:23-36): a ctx is built once from the
+// configuration and cloned per connection thread.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/fg_hip.h"
+#include "fg_device.hpp"
+
+extern "C" int fg_launch_rfc5424(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n,
+                                 const fg::DevTables* t, uint32_t tile_cap, hipStream_t stream);
+
+struct fg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int last_hip = 0;
+    bool timing = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_valid = false;
+    // LTSV configuration (owned copies)
+    std::vector<std::string> schema_names;
+    std::vector<uint8_t> schema_types;
+    std::string suffix[4];
+    bool has_suffix[4] = {false, false, false, false};
+    // staging for fg_decode_batch
+    uint8_t* d_bytes = nullptr;
+    uint64_t d_bytes_cap = 0;
+    uint64_t* d_offsets = nullptr;
+    uint64_t d_offsets_cap = 0;
+    uint8_t* d_tab = nullptr;  // one device allocation carved into the table arrays
+    uint64_t d_tab_cap = 0;
+    uint8_t* h_tab = nullptr;  // pinned host mirror
+    uint64_t h_tab_cap = 0;
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+#define FG_HIP(ctx, call)                         \
+    do {                                          \
+        hipError_t e_ = (call);                   \
+        if (e_ != hipSuccess) {                   \
+            (ctx)->last_hip = (int)e_;            \
+            return FG_ERR_HIP;                    \
+        }                                         \
+    } while (0)
+
+inline uint64_t up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+// carve `base` into the arrays of an fg_tables (256-byte aligned pieces)
+void carve(uint8_t* base, uint64_t n, uint64_t ent_cap, fg_tables* t, uint64_t* total) {
+    uint64_t sizes[FG_TABLE_ARRAYS];
+    fg_tables_layout(n, ent_cap, sizes);
+    uint64_t off = 0;
+    uint8_t* p[FG_TABLE_ARRAYS];
+    for (int k = 0; k < FG_TABLE_ARRAYS; ++k) {
+        p[k] = base ? base + off : nullptr;
+        off += up(sizes[k], 256);
+    }
+    if (total) *total = off;
+    if (!t) return;
+    t->n = n;
+    t->ent_cap = ent_cap;
+    t->meta = (uint32_t*)p[0];
+    t->ts = (double*)p[1];
+    t->hostname = (fg_span*)p[2];
+    t->appname = (fg_span*)p[3];
+    t->procid = (fg_span*)p[4];
+    t->msgid = (fg_span*)p[5];
+    t->msg = (fg_span*)p[6];
+    t->full_msg = (fg_span*)p[7];
+    t->ent_first = (uint32_t*)p[8];
+    t->ent_count = (uint32_t*)p[9];
+    t->ent_name = (fg_span*)p[10];
+    t->ent_val = (uint64_t*)p[11];
+    t->ent_type = (uint8_t*)p[12];
+    t->ent_flags = (uint8_t*)p[13];
+    t->ent_used = (uint64_t*)p[14];
+}
+
+fg::DevTables to_dev(const fg_tables& t) {
+    fg::DevTables d;
+    d.n = t.n;
+    d.ent_cap = t.ent_cap;
+    d.meta = t.meta;
+    d.ts = t.ts;
+    d.span[0] = t.hostname;
+    d.span[1] = t.appname;
+    d.span[2] = t.procid;
+    d.span[3] = t.msgid;
+    d.span[4] = t.msg;
+    d.span[5] = t.full_msg;
+    d.ent_first = t.ent_first;
+    d.ent_count = t.ent_count;
+    d.ent_name = t.ent_name;
+    d.ent_val = t.ent_val;
+    d.ent_type = t.ent_type;
+    d.ent_flags = t.ent_flags;
+    d.ent_used = (unsigned long long*)t.ent_used;
+    return d;
+}
+
+// LDS tile per 64-line wave: room for 64 average lines + 25 % + one KiB, 4..64 KiB.
+uint32_t pick_tile_cap(uint64_t nbytes, uint64_t n) {
+    uint64_t avg = n ? (nbytes + n - 1) / n : 0;
+    uint64_t want = up(64 * avg * 5 / 4 + 1024, 1024);
+    if (want < 4096) want = 4096;
+    if (want > 65536) want = 65536;
+    return (uint32_t)want;
+}
+
+const char* const kErr5424[] = {
+    "",
+    "Unsupported BOM",
+    "The priority should be inside brackets",
+    "Invalid priority",
+    "Missing version",
+    "Unsupported version",
+    "Missing timestamp",
+    "Unable to parse the date from RFC3339 to Unix time in RFC5424 decoder",
+    "Missing hostname",
+    "Missing application name",
+    "Missing process id",
+    "Missing message id",
+    "Missing message data",
+    "Missing log message",
+    "Malformated RFC5424 message",
+    "Missing structured data",
+    "Format error in the structured data",
+    "Missing ] after structured data",
+};
+const char* const kErrLtsv[] = {
+    "",
+    "Invalid severity level",
+    "Severity level should be <= 7",
+    "Type error; boolean was expected",
+    "Type error; f64 was expected",
+    "Type error; i64 was expected",
+    "Type error; u64 was expected",
+    "Missing timestamp",
+    "Missing hostname",
+    "Unable to parse the English to Unix timestamp in LTSV decoder",
+};
+const char* const kErrGelf[] = {
+    "",
+    "Invalid GELF input, unable to parse as a JSON object",
+    "Empty GELF input",
+    "Invalid GELF timestamp",
+    "GELF host name must be a string",
+    "GELF short message must be a string",
+    "GELF full message must be a string",
+    "GELF version must be a string",
+    "Unsupported GELF version",
+    "Invalid severity level",
+    "Invalid severity level (too high)",
+    "Invalid value type in structured data",
+    "Missing hostname",
+};
+
+int grow_dev(fg_ctx* ctx, void** p, uint64_t* cap, uint64_t need) {
+    if (need <= *cap) return FG_OK;
+    if (*p) FG_HIP(ctx, hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    uint64_t want = up(need + need / 4, 1 << 20);
+    FG_HIP(ctx, hipMalloc(p, want));
+    *cap = want;
+    return FG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fg_abi_version(void) { return FG_ABI_VERSION; }
+
+int fg_tables_layout(uint64_t n, uint64_t ent_cap, uint64_t sizes[FG_TABLE_ARRAYS]) {
+    if (!sizes) return FG_ERR_ARG;
+    sizes[0] = n * 4;
+    sizes[1] = n * 8;
+    for (int k = 2; k < 8; ++k) sizes[k] = n * 8;
+    sizes[8] = n * 4;
+    sizes[9] = n * 4;
+    sizes[10] = ent_cap * 8;
+    sizes[11] = ent_cap * 8;
+    sizes[12] = ent_cap;
+    sizes[13] = ent_cap;
+    sizes[14] = 8;
+    return FG_OK;
+}
+
+int fg_create(int device, const fg_cfg* cfg, fg_ctx** out) {
+    if (!out) return FG_ERR_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return FG_ERR_NO_DEVICE;
+    if (device < 0 || device >= count) return FG_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return FG_ERR_NO_DEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return FG_ERR_NO_DEVICE;  // kernels are gfx950-only
+    fg_ctx* ctx = new (std::nothrow) fg_ctx();
+    if (!ctx) return FG_ERR_ARG;
+    ctx->device = device;
+    if (cfg) {
+        for (uint32_t i = 0; i < cfg->n_schema; ++i) {
+            ctx->schema_names.emplace_back(cfg->schema_names[i]);
+            ctx->schema_types.push_back(cfg->schema_types[i]);
+        }
+        const char* s[4] = {cfg->suffix_bool, cfg->suffix_f64, cfg->suffix_i64, cfg->suffix_u64};
+        for (int k = 0; k < 4; ++k)
+            if (s[k]) {
+                ctx->suffix[k] = s[k];
+                ctx->has_suffix[k] = true;
+            }
+    }
+    DeviceGuard g(device);
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return FG_ERR_HIP;
+    }
+    *out = ctx;
+    return FG_OK;
+}
+
+int fg_clone(const fg_ctx* src, fg_ctx** out) {
+    if (!src || !out) return FG_ERR_ARG;
+    fg_ctx* ctx = new (std::nothrow) fg_ctx();
+    if (!ctx) return FG_ERR_ARG;
+    ctx->device = src->device;
+    ctx->schema_names = src->schema_names;
+    ctx->schema_types = src->schema_types;
+    for (int k = 0; k < 4; ++k) {
+        ctx->suffix[k] = src->suffix[k];
+        ctx->has_suffix[k] = src->has_suffix[k];
+    }
+    DeviceGuard g(ctx->device);
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return FG_ERR_HIP;
+    }
+    *out = ctx;
+    return FG_OK;
+}
+
+void fg_destroy(fg_ctx* ctx) {
+    if (!ctx) return;
+    DeviceGuard g(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->d_bytes) (void)hipFree(ctx->d_bytes);
+    if (ctx->d_offsets) (void)hipFree(ctx->d_offsets);
+    if (ctx->d_tab) (void)hipFree(ctx->d_tab);
+    if (ctx->h_tab) (void)hipHostFree(ctx->h_tab);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int fg_last_hip_error(const fg_ctx* ctx) { return ctx ? ctx->last_hip : 0; }
+
+int fg_set_timing(fg_ctx* ctx, int enabled) {
+    if (!ctx) return FG_ERR_ARG;
+    DeviceGuard g(ctx->device);
+    if (enabled && !ctx->ev0) {
+        FG_HIP(ctx, hipEventCreate(&ctx->ev0));
+        FG_HIP(ctx, hipEventCreate(&ctx->ev1));
+    }
+    ctx->timing = enabled != 0;
+    ctx->ev_valid = false;
+    return FG_OK;
+}
+
+int fg_last_kernel_ms(fg_ctx* ctx, float* ms) {
+    if (!ctx || !ms) return FG_ERR_ARG;
+    *ms = 0.f;
+    if (!ctx->timing || !ctx->ev_valid) return FG_OK;
+    DeviceGuard g(ctx->device);
+    FG_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    FG_HIP(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return FG_OK;
+}
+
+int fg_decode_batch_device(fg_ctx* ctx, fg_format fmt, const uint8_t* d_bytes, uint64_t nbytes,
+                           const uint64_t* d_offsets, uint64_t n, const fg_tables* tables, void* stream) {
+    if (!ctx || !tables || (n && (!d_offsets || !tables->meta))) return FG_ERR_ARG;
+    if (nbytes && !d_bytes) return FG_ERR_ARG;
+    if (((uintptr_t)d_bytes & 15u) != 0) return FG_ERR_ARG;
+    if (tables->n < n) return FG_ERR_ARG;
+    if (tables->ent_cap > 0xFFFFFFFFull) return FG_ERR_ARG;
+    DeviceGuard g(ctx->device);
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    fg::DevTables dt = to_dev(*tables);
+    if (dt.ent_used) FG_HIP(ctx, hipMemsetAsync(dt.ent_used, 0, 8, s));
+    if (n == 0) return FG_OK;
+    if (ctx->timing) FG_HIP(ctx, hipEventRecord(ctx->ev0, s));
+    int rc;
+    switch (fmt) {
+        case FG_RFC5424:
+            rc = fg_launch_rfc5424(d_bytes, d_offsets, n, &dt, pick_tile_cap(nbytes, n), s);
+            break;
+        default:
+            return FG_ERR_UNSUPPORTED;
+    }
+    if (rc != 0) {
+        ctx->last_hip = rc;
+        return FG_ERR_HIP;
+    }
+    if (ctx->timing) {
+        FG_HIP(ctx, hipEventRecord(ctx->ev1, s));
+        ctx->ev_valid = true;
+    }
+    return FG_OK;
+}
+
+int fg_decode_batch(fg_ctx* ctx, fg_format fmt, const uint8_t* bytes, uint64_t nbytes, const uint64_t* offsets,
+                    uint64_t n, fg_tables* out) {
+    if (!ctx || !out || (n && !offsets) || (nbytes && !bytes)) return FG_ERR_ARG;
+    if (n && (offsets[n] > nbytes || offsets[0] > offsets[n])) return FG_ERR_ARG;
+    DeviceGuard g(ctx->device);
+    hipStream_t s = ctx->stream;
+    int rc;
+    if ((rc = grow_dev(ctx, (void**)&ctx->d_bytes, &ctx->d_bytes_cap, up(nbytes, 16) + 16)) != FG_OK) return rc;
+    if ((rc = grow_dev(ctx, (void**)&ctx->d_offsets, &ctx->d_offsets_cap, (n + 1) * 8)) != FG_OK) return rc;
+    if (nbytes) FG_HIP(ctx, hipMemcpyAsync(ctx->d_bytes, bytes, nbytes, hipMemcpyHostToDevice, s));
+    if (n) FG_HIP(ctx, hipMemcpyAsync(ctx->d_offsets, offsets, (n + 1) * 8, hipMemcpyHostToDevice, s));
+    // entry capacity: start from one entry per 16 input bytes, grow x4 on overflow
+    uint64_t ent_cap = fmt == FG_RFC5424 ? nbytes / 16 + 1024 : nbytes / 8 + 1024;
+    for (;;) {
+        if (ent_cap > 0xFFFFFFF0ull) ent_cap = 0xFFFFFFF0ull;
+        uint64_t total = 0;
+        carve(nullptr, n, ent_cap, nullptr, &total);
+        if ((rc = grow_dev(ctx, (void**)&ctx->d_tab, &ctx->d_tab_cap, total)) != FG_OK) return rc;
+        if (total > ctx->h_tab_cap) {
+            if (ctx->h_tab) FG_HIP(ctx, hipHostFree(ctx->h_tab));
+            ctx->h_tab = nullptr;
+            ctx->h_tab_cap = 0;
+            uint64_t want = up(total + total / 4, 1 << 20);
+            FG_HIP(ctx, hipHostMalloc((void**)&ctx->h_tab, want, hipHostMallocDefault));
+            ctx->h_tab_cap = want;
+        }
+        fg_tables dt;
+        carve(ctx->d_tab, n, ent_cap, &dt, nullptr);
+        rc = fg_decode_batch_device(ctx, fmt, ctx->d_bytes, nbytes, ctx->d_offsets, n, &dt, s);
+        if (rc != FG_OK) return rc;
+        uint64_t used = 0;
+        FG_HIP(ctx, hipMemcpyAsync(&used, dt.ent_used, 8, hipMemcpyDeviceToHost, s));
+        FG_HIP(ctx, hipStreamSynchronize(s));
+        if (used > ent_cap) {
+            if (ent_cap >= 0xFFFFFFF0ull) return FG_ERR_ENT_OVERFLOW;
+            ent_cap = used + used / 8 + 1024;
+            continue;
+        }
+        // copy back: fixed columns in full, entry columns only up to `used`
+        fg_tables ht;
+        carve(ctx->h_tab, n, ent_cap, &ht, nullptr);
+        uint64_t sizes[FG_TABLE_ARRAYS];
+        fg_tables_layout(n, used, sizes);
+        void* dsts[FG_TABLE_ARRAYS] = {ht.meta, ht.ts, ht.hostname, ht.appname, ht.procid, ht.msgid, ht.msg, ht.full_msg,
+                                       ht.ent_first, ht.ent_count, ht.ent_name, ht.ent_val, ht.ent_type, ht.ent_flags, ht.ent_used};
+        void* srcs[FG_TABLE_ARRAYS] = {dt.meta, dt.ts, dt.hostname, dt.appname, dt.procid, dt.msgid, dt.msg, dt.full_msg,
+                                       dt.ent_first, dt.ent_count, dt.ent_name, dt.ent_val, dt.ent_type, dt.ent_flags, dt.ent_used};
+        for (int k = 0; k < FG_TABLE_ARRAYS; ++k)
+            if (sizes[k]) FG_HIP(ctx, hipMemcpyAsync(dsts[k], srcs[k], sizes[k], hipMemcpyDeviceToHost, s));
+        FG_HIP(ctx, hipStreamSynchronize(s));
+        *out = ht;
+        return FG_OK;
+    }
+}
+
+const char* fg_error_string(fg_format fmt, uint8_t status) {
+    switch (fmt) {
+        case FG_RFC5424:
+            return status < sizeof(kErr5424) / sizeof(*kErr5424) ? kErr5424[status] : nullptr;
+        case FG_LTSV:
+            return status < sizeof(kErrLtsv) / sizeof(*kErrLtsv) ? kErrLtsv[status] : nullptr;
+        case FG_GELF:
+            return status < sizeof(kErrGelf) / sizeof(*kErrGelf) ? kErrGelf[status] : nullptr;
+    }
+    return nullptr;
+}
+
+int fg_shard_plan(const uint64_t* offsets, uint64_t n, uint32_t g, uint64_t* line_starts) {
+    if (!line_starts || g == 0 || (n && !offsets)) return FG_ERR_ARG;
+    line_starts[0] = 0;
+    line_starts[g] = n;
+    if (n == 0) {
+        for (uint32_t k = 1; k < g; ++k) line_starts[k] = 0;
+        return FG_OK;
+    }
+    const uint64_t b0 = offsets[0], total = offsets[n] - b0;
+    uint64_t lo = 0;
+    for (uint32_t k = 1; k < g; ++k) {
+        // first line whose start is >= k/g of the bytes (binary search; offsets is non-decreasing)
+        uint64_t target = b0 + (uint64_t)((__uint128_t)total * k / g);
+        uint64_t a = lo, b = n;
+        while (a < b) {
+            uint64_t m = a + (b - a) / 2;
+            if (offsets[m] < target) a = m + 1;
+            else b = m;
+        }
+        line_starts[k] = a;
+        lo = a;
+    }
+    return FG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,181 @@
+"""Decoders -- host-side mirror of flowgger's `Decoder` trait for the GPU bulk-parse stage.
+
+Reference interface (src/flowgger/decoder/mod.rs:23-46):
+
+    pub trait Decoder: CloneBoxedDecoder {
+        fn decode(&self, line: &str) -> Result<Record, &'static str>;
+    }
+
+Same names, same argument meaning, same error strings: ``decode(line)`` returns a
+:class:`~flowgger_amd.record.Record` or raises :class:`~flowgger_amd.record.DecodeError` whose
+message is the reference's ``&'static str``.  What is new is ``decode_batch`` / ``decode_packed``:
+the batching framer hands over N framed lines at once and ONE call runs the gfx950 kernels
+(the per-line loop it replaces: src/flowgger/splitter/line_splitter.rs:17,44-54).
+
+Every call goes through the C ABI of libfg_hip.so; there is no CPU implementation here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterable, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from . import _lib as L
+from .record import DecodeError, Record, parse_canonical
+from .tables import DeviceTables, HostTables
+
+_TYPE_IDS = {"string": L.FG_T_STRING, "bool": L.FG_T_BOOL, "f64": L.FG_T_F64, "i64": L.FG_T_I64, "u64": L.FG_T_U64}
+
+
+def pack_lines(lines: Iterable[Union[str, bytes]]) -> Tuple[np.ndarray, np.ndarray]:
+    """The batching framer's container: framed lines -> (packed bytes, offsets[n+1] uint64)."""
+    bl = [ln.encode("utf-8", "surrogateescape") if isinstance(ln, str) else bytes(ln) for ln in lines]
+    offsets = np.zeros(len(bl) + 1, np.uint64)
+    if bl:
+        offsets[1:] = np.cumsum([len(b) for b in bl], dtype=np.uint64)
+    data = np.frombuffer(b"".join(bl), np.uint8).copy() if bl else np.zeros(0, np.uint8)
+    return data, offsets
+
+
+class Decoder:
+    """Base: owns an fg_ctx (the analogue of Box<dyn Decoder + Send>)."""
+
+    fmt: int = -1
+
+    def __init__(self, config: Optional[dict] = None, device: int = 0):
+        self._cfg = self._make_cfg(config)
+        self._ctx = C.c_void_p()
+        self.device = device
+        L.check(L.lib().fg_create(device, C.byref(self._cfg) if self._cfg is not None else None,
+                                  C.byref(self._ctx)), "fg_create")
+
+    # -- configuration hook (only LTSV has one) ------------------------------------------
+    def _make_cfg(self, config: Optional[dict]):
+        return None
+
+    def clone_boxed(self) -> "Decoder":  # decoder/mod.rs:29-36
+        other = object.__new__(type(self))
+        other._cfg = self._cfg
+        other._keep = getattr(self, "_keep", None)
+        other.device = self.device
+        other._ctx = C.c_void_p()
+        L.check(L.lib().fg_clone(self._ctx, C.byref(other._ctx)), "fg_clone")
+        return other
+
+    def close(self) -> None:
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            L.lib().fg_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- the reference interface ------------------------------------------------------------
+    def decode(self, line: Union[str, bytes]) -> Record:
+        res = self.decode_batch([line])[0]
+        if isinstance(res, DecodeError):
+            raise res
+        return res
+
+    # -- bulk interface -----------------------------------------------------------------------
+    def decode_packed(self, data: np.ndarray, offsets: np.ndarray) -> HostTables:
+        """Host buffers in, host tables out (H2D + kernels + D2H inside the library)."""
+        data = np.ascontiguousarray(data, np.uint8)
+        offsets = np.ascontiguousarray(offsets, np.uint64)
+        n = len(offsets) - 1
+        st = L.fg_tables()
+        L.check(L.lib().fg_decode_batch(self._ctx, self.fmt, data.ctypes.data, data.size,
+                                        offsets.ctypes.data, n, C.byref(st)), "fg_decode_batch")
+        return HostTables.from_struct(st)
+
+    def decode_batch(self, lines: Sequence[Union[str, bytes]]) -> List[Union[Record, DecodeError]]:
+        data, offsets = pack_lines(lines)
+        tab = self.decode_packed(data, offsets)
+        blob, offs = tab.serialize(self.fmt, data, offsets, cfg=self._cfg)
+        raw = blob.tobytes()
+        return [parse_canonical(raw[int(offs[i]):int(offs[i + 1])]) for i in range(len(lines))]
+
+    def decode_device(self, d_bytes, d_offsets, tables: DeviceTables, stream=None) -> None:
+        """Device-resident hot path: torch uint8 / int64|uint64 tensors already in HBM.
+        Asynchronous on `stream` (a torch.cuda.Stream; default = torch's current stream)."""
+        import torch
+
+        if stream is None:
+            stream = torch.cuda.current_stream(d_bytes.device)
+        n = d_offsets.numel() - 1
+        L.check(L.lib().fg_decode_batch_device(self._ctx, self.fmt, d_bytes.data_ptr(), d_bytes.numel(),
+                                               d_offsets.data_ptr(), n, C.byref(tables.struct),
+                                               C.c_void_p(stream.cuda_stream)), "fg_decode_batch_device")
+
+    def set_timing(self, enabled: bool = True) -> None:
+        L.check(L.lib().fg_set_timing(self._ctx, int(enabled)), "fg_set_timing")
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float()
+        L.check(L.lib().fg_last_kernel_ms(self._ctx, C.byref(ms)), "fg_last_kernel_ms")
+        return float(ms.value)
+
+    def error_string(self, status: int) -> Optional[str]:
+        s = L.lib().fg_error_string(self.fmt, status)
+        return None if s is None else s.decode()
+
+
+class RFC5424Decoder(Decoder):
+    """src/flowgger/decoder/rfc5424_decoder.rs:8-50 (stateless; config ignored, :12-14)."""
+    fmt = L.FG_RFC5424
+
+
+class GelfDecoder(Decoder):
+    """src/flowgger/decoder/gelf_decoder.rs:10-125 (config ignored, :16-18)."""
+    fmt = L.FG_GELF
+
+
+class LTSVDecoder(Decoder):
+    """src/flowgger/decoder/ltsv_decoder.rs:17-221.  `config` mirrors the TOML tables
+    ``input.ltsv_schema`` (name -> "string|bool|f64|i64|u64", case-insensitive, :33-45) and
+    ``input.ltsv_suffixes`` (type -> suffix, :57-81): {"input": {"ltsv_schema": {...},
+    "ltsv_suffixes": {...}}}."""
+    fmt = L.FG_LTSV
+
+    def _make_cfg(self, config: Optional[dict]):
+        inp = (config or {}).get("input", {})
+        schema = inp.get("ltsv_schema")
+        suffixes = inp.get("ltsv_suffixes")
+        cfg = L.fg_cfg()
+        keep = []
+        names, types = [], []
+        if schema is not None:
+            if not isinstance(schema, dict):
+                raise ValueError("input.ltsv_schema must be a list of key/type pairs")
+            for name, sdtype in schema.items():
+                if not isinstance(sdtype, str):
+                    raise ValueError("input.ltsv_schema types must be strings")
+                t = _TYPE_IDS.get(sdtype.lower())
+                if t is None:
+                    raise ValueError(f"Unsupported type in input.ltsv_schema for name [{name}]")
+                names.append(name.encode())
+                types.append(t)
+        cfg.n_schema = len(names)
+        arr_n = (C.c_char_p * max(len(names), 1))(*names)
+        arr_t = (C.c_uint8 * max(len(types), 1))(*types)
+        cfg.schema_names = C.cast(arr_n, C.POINTER(C.c_char_p))
+        cfg.schema_types = C.cast(arr_t, C.POINTER(C.c_uint8))
+        keep += [arr_n, arr_t, names]
+        if suffixes is not None:
+            if not isinstance(suffixes, dict):
+                raise ValueError("input.ltsv_suffixes must be a list of type/suffixes pairs")
+            for sdtype, suffix in suffixes.items():
+                if not isinstance(suffix, str):
+                    raise ValueError("input.ltsv_suffixes suffixes must be strings")
+                t = sdtype.lower()
+                if t == "string":
+                    raise ValueError("Strings cannot be suffixed")
+                if t not in ("bool", "f64", "i64", "u64"):
+                    raise ValueError(f"Unsupported type in input.ltsv_suffixes for type [{sdtype}]")
+                setattr(cfg, "suffix_" + t, suffix.encode())
+        self._keep = keep
+        return cfg

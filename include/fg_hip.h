@@ -1,0 +1,186 @@
+/*
+ * fg_hip.h -- C ABI of libfg_hip: the MI355X (gfx950) bulk log-line decoder that replaces
+ * flowgger's per-line Decoder::decode() hot path.
+ *
+ * Reference interface replaced (paths relative to the flowgger source tree):
+ *   trait Decoder { fn decode(&self, line:&str) -> Result<Record,&'static str> }
+ *                                                   src/flowgger/decoder/mod.rs:44-46
+ *   RFC5424Decoder::decode                          src/flowgger/decoder/rfc5424_decoder.rs:17-50
+ *   LTSVDecoder::new / decode                       src/flowgger/decoder/ltsv_decoder.rs:23-221
+ *   GelfDecoder::decode                             src/flowgger/decoder/gelf_decoder.rs:34-125
+ *   Record / StructuredData / SDValue               src/flowgger/record.rs:3-82
+ *   the per-line call site the batching framer replaces
+ *                                                   src/flowgger/splitter/line_splitter.rs:44-54
+ *
+ * Model: the framer packs N framed lines (valid UTF-8, framing bytes already stripped exactly
+ * as BufRead::lines()/split(0)/syslen do) into one byte buffer + an offset array and makes ONE
+ * call; hand-written HIP kernels tokenise every line and emit field-offset TABLES (struct of
+ * arrays below).  A `Record` identical to the reference decoder's is materialised from a table
+ * row + the line bytes (fg_tables_serialize / the Rust shim in INTEGRATION.md).  Errors are
+ * part of the result: status[i] != 0 indexes the reference's exact &'static str.
+ *
+ * Plain C, plain pointers and sizes; no torch / C++ types.  All functions return 0 on success
+ * or a negative FG_ERR_* (never throw, never abort).
+ */
+#ifndef FG_HIP_H
+#define FG_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FG_ABI_VERSION 1
+
+typedef enum fg_format { FG_RFC5424 = 0, FG_LTSV = 1, FG_GELF = 2 } fg_format;
+
+/* return codes */
+enum {
+    FG_OK = 0,
+    FG_ERR_ARG = -1,       /* NULL / inconsistent arguments */
+    FG_ERR_HIP = -2,       /* a HIP runtime call failed (fg_last_hip_error has the code) */
+    FG_ERR_NO_DEVICE = -3, /* no gfx950 device / kernels not loadable: there is NO CPU fallback */
+    FG_ERR_ENT_OVERFLOW = -4, /* entry table too small; tables are valid except status==FG_ST_OVERFLOW rows */
+    FG_ERR_UNSUPPORTED = -5
+};
+
+/* SDValue discriminants (record.rs:3-11) + the SD-element marker used in the entry table */
+enum {
+    FG_T_STRING = 0, FG_T_BOOL = 1, FG_T_F64 = 2, FG_T_I64 = 3, FG_T_U64 = 4, FG_T_NULL = 5,
+    FG_T_SDID = 6 /* entry opens a new StructuredData element; name = its sd_id */
+};
+
+/* A byte span inside ONE line: off is relative to the line's first byte (offsets[i]).
+ * len == FG_NONE means Option::None. */
+#define FG_NONE 0xFFFFFFFFu
+typedef struct fg_span { uint32_t off; uint32_t len; } fg_span;
+
+/* meta word: status | facility<<8 | severity<<16 | flags<<24
+ *   status   0 = Ok, else the format's error index (fg_error_string)
+ *   facility / severity  0xFF = None
+ *   flags    FG_F_* */
+#define FG_META_STATUS(m)   ((uint8_t)((m) & 0xFF))
+#define FG_META_FACILITY(m) ((uint8_t)(((m) >> 8) & 0xFF))
+#define FG_META_SEVERITY(m) ((uint8_t)(((m) >> 16) & 0xFF))
+#define FG_META_FLAGS(m)    ((uint8_t)(((m) >> 24) & 0xFF))
+enum {
+    FG_F_TS_NOW = 1,        /* GELF without "timestamp": Record.ts = wall clock at materialisation (gelf_decoder.rs:109) */
+    FG_F_HOST_ESC = 2,      /* GELF: hostname span holds JSON escapes (decode when materialising) */
+    FG_F_MSG_ESC = 4,       /* GELF: short_message span holds JSON escapes */
+    FG_F_FULLMSG_ESC = 8,   /* GELF: full_message span holds JSON escapes */
+    FG_F_BOM = 16           /* RFC5424: line started with U+FEFF (spans already skip it) */
+};
+#define FG_ST_OVERFLOW 0xFE /* status: the line's entries did not fit in ent_cap (re-run with more) */
+
+/* entry flags */
+enum {
+    FG_EF_VAL_ESC = 1,   /* value span needs unescaping: RFC5424 \" \\ \] (rfc5424_decoder.rs:105-125) or JSON escapes (GELF) */
+    FG_EF_NAME_ESC = 2,  /* GELF: key span holds JSON escapes */
+    FG_EF_SUFFIX = 4     /* LTSV: append the configured type suffix to the name (ltsv_decoder.rs:131-136) */
+};
+
+/* One entry = one (name, SDValue) pair or one SD-element header, 18 bytes as SoA:
+ *   ent_name[k]  span of the name WITHOUT the leading '_' the decoders add (sd_id for FG_T_SDID)
+ *   ent_val[k]   String: span packed as off | (uint64)len<<32 ; Bool: 0/1 ; F64: IEEE bits ;
+ *                I64: two's complement ; U64: value ; Null/SDID: 0
+ *   ent_type[k]  FG_T_*      ent_flags[k]  FG_EF_*
+ * Line i owns entries [ent_first[i], ent_first[i]+ent_count[i]) in decoder order.  Slices of
+ * different lines may appear in any order inside the entry table (wave-level allocation). */
+typedef struct fg_tables {
+    uint64_t n;          /* rows (lines) */
+    uint64_t ent_cap;    /* capacity of the ent_* arrays, in entries */
+    uint32_t* meta;      /* [n] */
+    double*   ts;        /* [n] Record.ts, bit-exact (utils/mod.rs:23-28) */
+    fg_span*  hostname;  /* [n] */
+    fg_span*  appname;   /* [n] */
+    fg_span*  procid;    /* [n] */
+    fg_span*  msgid;     /* [n] */
+    fg_span*  msg;       /* [n] */
+    fg_span*  full_msg;  /* [n] */
+    uint32_t* ent_first; /* [n] */
+    uint32_t* ent_count; /* [n] */
+    fg_span*  ent_name;  /* [ent_cap] */
+    uint64_t* ent_val;   /* [ent_cap] */
+    uint8_t*  ent_type;  /* [ent_cap] */
+    uint8_t*  ent_flags; /* [ent_cap] */
+    uint64_t* ent_used;  /* [1] entries allocated by the call (may exceed ent_cap on overflow) */
+} fg_tables;
+
+/* Fixed table bytes written per line (meta 4 + ts 8 + 6 spans 48 + ent_first/count 8). */
+#define FG_ROW_BYTES 68u
+#define FG_ENT_BYTES 18u
+
+/* LTSVDecoder::new configuration (input.ltsv_schema / input.ltsv_suffixes, ltsv_decoder.rs:24-84).
+ * Names are matched byte-exactly; types are FG_T_STRING..FG_T_U64. */
+typedef struct fg_cfg {
+    uint32_t n_schema;
+    const char* const* schema_names;
+    const uint8_t* schema_types;
+    const char* suffix_bool; /* NULL = None */
+    const char* suffix_f64;
+    const char* suffix_i64;
+    const char* suffix_u64;
+} fg_cfg;
+
+typedef struct fg_ctx fg_ctx;
+
+int fg_abi_version(void);
+
+/* Create a decoder context on HIP device `device` (replaces XDecoder::new(&Config),
+ * flowgger/mod.rs:413-422).  cfg may be NULL (RFC5424 / GELF take no configuration).
+ * Fails with FG_ERR_NO_DEVICE when no gfx950 GPU is usable -- there is no CPU fallback.
+ * A ctx is cheap to clone per connection thread (decoder/mod.rs:23-36): fg_clone shares the
+ * device-side configuration and gets its own stream + staging buffers. */
+int fg_create(int device, const fg_cfg* cfg, fg_ctx** out);
+int fg_clone(const fg_ctx* ctx, fg_ctx** out);
+void fg_destroy(fg_ctx* ctx);
+int fg_last_hip_error(const fg_ctx* ctx);
+
+/* Bytes of device scratch fg_decode_batch_device needs in `tables` are all caller-provided;
+ * this helper returns the byte size of every array of an fg_tables for (n, ent_cap) so that a
+ * caller can carve one allocation: sizes[k] for k = meta, ts, hostname, appname, procid, msgid,
+ * msg, full_msg, ent_first, ent_count, ent_name, ent_val, ent_type, ent_flags, ent_used. */
+#define FG_TABLE_ARRAYS 15
+int fg_tables_layout(uint64_t n, uint64_t ent_cap, uint64_t sizes[FG_TABLE_ARRAYS]);
+
+/* DEVICE-RESIDENT decode (the hot path): every pointer is a device pointer on ctx's device.
+ *   d_bytes    packed lines; must be 16-byte aligned and readable up to nbytes rounded up to 16
+ *   d_offsets  n+1 entries, offsets[0] >= 0, offsets[n] <= nbytes, non-decreasing
+ *   tables     struct (host memory) of DEVICE array pointers, n rows, ent_cap entries
+ *   stream     hipStream_t (NULL = the ctx's own stream); the call is asynchronous on it.
+ * replaces: `for line { decoder.decode(line) }` (line_splitter.rs:17,50). */
+int fg_decode_batch_device(fg_ctx* ctx, fg_format fmt, const uint8_t* d_bytes, uint64_t nbytes,
+                           const uint64_t* d_offsets, uint64_t n, const fg_tables* tables,
+                           void* stream);
+
+/* HOST-BUFFER decode: copies the batch to the GPU, decodes, copies the tables back into
+ * ctx-owned pinned host memory (`out` is filled with host pointers valid until the next call
+ * on this ctx or fg_destroy).  Synchronous.  Entry-table capacity grows automatically. */
+int fg_decode_batch(fg_ctx* ctx, fg_format fmt, const uint8_t* bytes, uint64_t nbytes,
+                    const uint64_t* offsets, uint64_t n, fg_tables* out);
+
+/* The reference's exact &'static str for a status code of a format (0 -> "", unknown -> NULL). */
+const char* fg_error_string(fg_format fmt, uint8_t status);
+
+/* Materialise rows [i0, i1) of HOST-visible tables into the canonical Record serialisation
+ * (format documented in INTEGRATION.md; identical to what oracle/ emits for the reference
+ * semantics).  out may be NULL to size; out_offsets (i1-i0+1 entries) may be NULL.
+ * cfg supplies the LTSV suffixes (NULL otherwise).  Returns total bytes, or negative FG_ERR_*. */
+int64_t fg_tables_serialize(fg_format fmt, const fg_cfg* cfg, const uint8_t* bytes,
+                            const uint64_t* offsets, const fg_tables* tables, uint64_t i0,
+                            uint64_t i1, uint8_t* out, uint64_t cap, uint64_t* out_offsets);
+
+/* Multi-GPU sharding plan (host): split n lines into g contiguous ranges balanced by BYTES;
+ * line_starts receives g+1 line indices (line_starts[0] = 0, line_starts[g] = n). */
+int fg_shard_plan(const uint64_t* offsets, uint64_t n, uint32_t g, uint64_t* line_starts);
+
+/* Duration in milliseconds of the most recent decode kernel launch(es) of this ctx measured
+ * with HIP events on the launch stream (0 when timing is disabled). fg_set_timing(ctx, 1)
+ * enables event recording around every launch. */
+int fg_set_timing(fg_ctx* ctx, int enabled);
+int fg_last_kernel_ms(fg_ctx* ctx, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FG_HIP_H */

@@ -1,0 +1,1239 @@
+// fg_oracle.cpp -- CPU ORACLE for the flowgger decode hot path.  TEST INFRASTRUCTURE ONLY.
+//
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+// library; the product (flowgger_amd/, include/) never links, imports or calls it.
+//
+// What it restates (all paths relative to /root/reference):
+//   src/flowgger/decoder/rfc5424_decoder.rs:17-242   RFC5424Decoder::decode and helpers
+//   src/flowgger/decoder/ltsv_decoder.rs:86-267      LTSVDecoder::decode, parse_ts chain
+//   src/flowgger/decoder/gelf_decoder.rs:34-125      GelfDecoder::decode
+//   src/flowgger/record.rs:3-82                      Record / StructuredData / SDValue
+//   src/flowgger/utils/mod.rs:23-28                  PreciseTimestamp::from_offset_datetime
+// plus the Rust std semantics those use (str::splitn/split/trim/trim_end, {u8,u64,i64,bool,
+// f64}::from_str) and two third-party crates that are NOT under /root/reference (no
+// Cargo.lock, nothing vendored, no rustc in this image, so the reference cannot be built):
+//   time = "0.3"  (Cargo.toml:54)  -- Rfc3339 well-known parser and the format-description
+//                                     parser for the LTSV "English" time form
+//   serde_json = "~0.8" (Cargo.toml:51) -- JSON DOM parse (BTreeMap object, u64-significand
+//                                     number algorithm, string escapes)
+// Their published algorithms are restated below from knowledge of the upstream sources.
+//
+// PARITY PINNING: the oracle reproduces every known-answer vector the reference's own tests
+// hold for this path (rfc5424_decoder.rs:244-314, ltsv_decoder.rs:269-487,
+// gelf_decoder.rs:133-205; see tests/test_oracle_golden.py).  Behaviour at the two
+// third-party boundaries that no reference test pins (UTC offsets beyond Z/-0700/-0000, leap
+// seconds, offset range, JSON exponent/overflow numbers, as_u64 on negatives, nesting depth)
+// is "parity unpinned": each such choice is marked UNPINNED below and listed in DESIGN.md.
+//
+// Build: make -C oracle   (g++ -O2 -std=c++17 -shared -fPIC, no other dependencies)
+
+#include "fg_oracle.h"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <optional>
+#include <string>
+#include <string_view>
+#include <thread>
+#include <utility>
+#include <vector>
+
+namespace {
+
+using sv = std::string_view;
+
+// ---------------------------------------------------------------------------------------
+// Record model (record.rs:3-11, 23-27, 70-82)
+// ---------------------------------------------------------------------------------------
+struct SDValue {
+    uint8_t type = FGO_T_NULL;
+    std::string s;      // String
+    uint64_t bits = 0;  // Bool (0/1), F64 (IEEE bits), I64 (two's complement), U64
+};
+struct StructuredData {
+    std::optional<std::string> sd_id;
+    std::vector<std::pair<std::string, SDValue>> pairs;
+};
+struct Record {
+    bool ts_now = false;  // gelf_decoder.rs:109 (timestamp absent -> wall clock)
+    double ts = 0.0;
+    std::string hostname;
+    std::optional<uint8_t> facility, severity;
+    std::optional<std::string> appname, procid, msgid, msg, full_msg;
+    std::optional<std::vector<StructuredData>> sd;
+};
+struct Result {
+    const char* err = nullptr;  // nullptr = Ok
+    Record rec;
+};
+
+// ---------------------------------------------------------------------------------------
+// Rust std restatements
+// ---------------------------------------------------------------------------------------
+
+// char::is_whitespace == Unicode White_Space: U+0009..000D, 0020, 0085, 00A0, 1680,
+// 2000..200A, 2028, 2029, 202F, 205F, 3000.
+inline bool is_ws_cp(uint32_t c) {
+    return (c >= 9 && c <= 13) || c == 0x20 || c == 0x85 || c == 0xA0 || c == 0x1680 ||
+           (c >= 0x2000 && c <= 0x200A) || c == 0x2028 || c == 0x2029 || c == 0x202F ||
+           c == 0x205F || c == 0x3000;
+}
+// Decode the UTF-8 scalar that starts at s[i] (input is valid UTF-8 by precondition,
+// line_splitter.rs:17-25); returns its byte length.
+inline int utf8_next(sv s, size_t i, uint32_t* cp) {
+    uint8_t b = (uint8_t)s[i];
+    if (b < 0x80) { *cp = b; return 1; }
+    if (b < 0xE0 && i + 1 < s.size()) { *cp = ((b & 0x1F) << 6) | ((uint8_t)s[i + 1] & 0x3F); return 2; }
+    if (b < 0xF0 && i + 2 < s.size()) {
+        *cp = ((b & 0x0F) << 12) | (((uint8_t)s[i + 1] & 0x3F) << 6) | ((uint8_t)s[i + 2] & 0x3F);
+        return 3;
+    }
+    if (i + 3 < s.size()) {
+        *cp = ((b & 0x07) << 18) | (((uint8_t)s[i + 1] & 0x3F) << 12) |
+              (((uint8_t)s[i + 2] & 0x3F) << 6) | ((uint8_t)s[i + 3] & 0x3F);
+        return 4;
+    }
+    *cp = 0xFFFD;  // truncated sequence: not whitespace; cannot happen on valid UTF-8
+    return 1;
+}
+sv trim_end(sv s) {  // str::trim_end
+    size_t e = s.size();
+    while (e > 0) {
+        size_t b = e - 1;
+        while (b > 0 && ((uint8_t)s[b] & 0xC0) == 0x80 && e - b < 4) --b;  // walk to the lead byte
+        uint32_t cp;
+        int n = utf8_next(s.substr(0, e), b, &cp);
+        if ((size_t)n != e - b || !is_ws_cp(cp)) break;
+        e = b;
+    }
+    return s.substr(0, e);
+}
+sv trim_start(sv s) {
+    size_t i = 0;
+    while (i < s.size()) {
+        uint32_t cp;
+        int n = utf8_next(s, i, &cp);
+        if (!is_ws_cp(cp)) break;
+        i += n;
+    }
+    return s.substr(i);
+}
+sv trim(sv s) { return trim_end(trim_start(s)); }  // str::trim
+
+// {u8,u64,usize}::from_str: optional '+', >=1 ASCII digits, overflow -> Err, nothing else.
+bool rust_parse_unsigned(sv s, uint64_t max, uint64_t* out) {
+    size_t i = 0;
+    if (s.empty()) return false;
+    if (s[0] == '+') i = 1;  // a lone "+" is an error; '-' is InvalidDigit for unsigned
+    if (i >= s.size()) return false;
+    uint64_t v = 0;
+    for (; i < s.size(); ++i) {
+        unsigned d = (unsigned char)s[i] - '0';
+        if (d > 9) return false;
+        if (v > (max - d) / 10) return false;  // v*10+d > max
+        v = v * 10 + d;
+    }
+    *out = v;
+    return true;
+}
+// i64::from_str: optional '+' or '-', >=1 digits, overflow -> Err.
+bool rust_parse_i64(sv s, int64_t* out) {
+    if (s.empty()) return false;
+    bool neg = false;
+    size_t i = 0;
+    if (s[0] == '+') i = 1;
+    else if (s[0] == '-') { neg = true; i = 1; }
+    if (i >= s.size()) return false;
+    uint64_t lim = neg ? (uint64_t)1 << 63 : ((uint64_t)1 << 63) - 1;
+    uint64_t v = 0;
+    for (; i < s.size(); ++i) {
+        unsigned d = (unsigned char)s[i] - '0';
+        if (d > 9) return false;
+        if (v > (lim - d) / 10) return false;
+        v = v * 10 + d;
+    }
+    *out = neg ? (int64_t)(0 - v) : (int64_t)v;
+    return true;
+}
+inline bool ieq(sv a, const char* b) {
+    size_t n = strlen(b);
+    if (a.size() != n) return false;
+    for (size_t i = 0; i < n; ++i)
+        if ((a[i] | 0x20) != b[i]) return false;
+    return true;
+}
+// f64::from_str (core::num::dec2flt): [+-]? ( inf | infinity | nan  (ASCII case-insensitive)
+//   | digits [. digits*] | . digits ) ( [eE] [+-]? digits )? ; correctly rounded.
+// glibc strtod is correctly rounded, so after validating Rust's (narrower) grammar we
+// delegate the conversion to it.
+bool rust_parse_f64(sv s, double* out) {
+    if (s.empty()) return false;
+    size_t i = 0;
+    bool neg = false;
+    if (s[0] == '+' || s[0] == '-') { neg = s[0] == '-'; i = 1; }
+    sv rest = s.substr(i);
+    if (rest.empty()) return false;
+    if (ieq(rest, "inf") || ieq(rest, "infinity")) { *out = neg ? -INFINITY : INFINITY; return true; }
+    if (ieq(rest, "nan")) {
+        uint64_t b = 0x7ff8000000000000ull | (neg ? 0x8000000000000000ull : 0);
+        memcpy(out, &b, 8);
+        return true;
+    }
+    size_t j = 0, nd_int = 0, nd_frac = 0;
+    while (j < rest.size() && (unsigned)(rest[j] - '0') <= 9) { ++j; ++nd_int; }
+    if (j < rest.size() && rest[j] == '.') {
+        ++j;
+        while (j < rest.size() && (unsigned)(rest[j] - '0') <= 9) { ++j; ++nd_frac; }
+    }
+    if (nd_int + nd_frac == 0) return false;
+    if (j < rest.size() && (rest[j] == 'e' || rest[j] == 'E')) {
+        ++j;
+        if (j < rest.size() && (rest[j] == '+' || rest[j] == '-')) ++j;
+        size_t nd = 0;
+        while (j < rest.size() && (unsigned)(rest[j] - '0') <= 9) { ++j; ++nd; }
+        if (nd == 0) return false;
+    }
+    if (j != rest.size()) return false;
+    std::string z(s);
+    *out = strtod(z.c_str(), nullptr);
+    return true;
+}
+
+// splitn(n, c): at most n pieces, last holds the remainder, empty pieces preserved.
+struct SplitN {
+    sv rest;
+    int left;
+    char c;
+    bool done = false;
+    SplitN(sv s, int n, char ch) : rest(s), left(n), c(ch) {}
+    bool next(sv* out) {
+        if (done || left == 0) return false;
+        if (left == 1) { *out = rest; done = true; return true; }
+        size_t p = rest.find(c);
+        if (p == sv::npos) { *out = rest; done = true; return true; }
+        *out = rest.substr(0, p);
+        rest = rest.substr(p + 1);
+        --left;
+        return true;
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// time 0.3 restatement
+// ---------------------------------------------------------------------------------------
+inline bool is_leap(int y) { return (y % 4 == 0) && (y % 100 != 0 || y % 400 == 0); }
+inline int days_in_month(int y, int m) {
+    static const int d[12] = {31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31};
+    return (m == 2 && is_leap(y)) ? 29 : d[m - 1];
+}
+// days since 1970-01-01 of the proleptic Gregorian date (valid for negative years too).
+inline int64_t days_from_civil(int64_t y, int m, int d) {
+    y -= m <= 2;
+    int64_t era = (y >= 0 ? y : y - 399) / 400;
+    int64_t yoe = y - era * 400;
+    int64_t doy = (153 * (m + (m > 2 ? -3 : 9)) + 2) / 5 + d - 1;
+    int64_t doe = yoe * 365 + yoe / 4 - yoe / 100 + doy;
+    return era * 146097 + doe - 719468;
+}
+inline void civil_from_days(int64_t z, int* y, int* m, int* d) {
+    z += 719468;
+    int64_t era = (z >= 0 ? z : z - 146096) / 146097;
+    int64_t doe = z - era * 146097;
+    int64_t yoe = (doe - doe / 1460 + doe / 36524 - doe / 146096) / 365;
+    int64_t yy = yoe + era * 400;
+    int64_t doy = doe - (365 * yoe + yoe / 4 - yoe / 100);
+    int64_t mp = (5 * doy + 2) / 153;
+    *d = (int)(doy - (153 * mp + 2) / 5 + 1);
+    *m = (int)(mp < 10 ? mp + 3 : mp - 9);
+    *y = (int)(yy + (*m <= 2));
+}
+struct DateTimeParts {
+    int year, month, day, hour, minute, second;
+    uint32_t nano;
+    int off_sign;  // +1 / -1
+    int off_h, off_m;
+};
+// Date::from_calendar_date + Time::from_hms_nano + UtcOffset::from_hms + assume_offset +
+// unix_timestamp_nanos() as f64 / 1e9 (utils/mod.rs:23-28).  `leap` = the RFC3339 parser's
+// second==60 stand-in (23:59:59.999999999, must be the last second of a month in UTC).
+bool datetime_to_unix(const DateTimeParts& p, bool allow_leap, double* out) {
+    int second = p.second;
+    uint32_t nano = p.nano;
+    bool leap = false;
+    if (second == 60 && allow_leap) { second = 59; nano = 999999999u; leap = true; }
+    if (p.month < 1 || p.month > 12) return false;
+    if (p.year < -9999 || p.year > 9999) return false;
+    if (p.day < 1 || p.day > days_in_month(p.year, p.month)) return false;
+    if (p.hour > 23 || p.minute > 59 || second > 59) return false;
+    // UNPINNED: time >= 0.3.21 accepts offsets up to +-25:59; older 0.3.x +-23:59.
+    if (p.off_h > 25 || p.off_m > 59) return false;
+    int64_t off = p.off_sign * (p.off_h * 3600 + p.off_m * 60);
+    int64_t secs = days_from_civil(p.year, p.month, p.day) * 86400 + p.hour * 3600 + p.minute * 60 + second - off;
+    if (leap) {
+        // UNPINNED: OffsetDateTime::is_valid_leap_second_stand_in (time >= 0.3.10).
+        int64_t days = secs >= 0 ? secs / 86400 : -((-secs + 86399) / 86400);
+        int64_t sod = secs - days * 86400;
+        int y, m, d;
+        civil_from_days(days, &y, &m, &d);
+        if (sod != 86399 || d != days_in_month(y, m)) return false;
+    }
+    __int128 nanos = (__int128)secs * 1000000000 + (__int128)nano;  // unix_timestamp_nanos(): i128
+    *out = (double)nanos / 1e9;  // `as f64` is round-to-nearest-even; then one IEEE divide
+    return true;
+}
+inline bool take_digits(sv s, size_t* i, int n, int* out) {
+    if (*i + n > s.size()) return false;
+    int v = 0;
+    for (int k = 0; k < n; ++k) {
+        unsigned d = (unsigned char)s[*i + k] - '0';
+        if (d > 9) return false;
+        v = v * 10 + d;
+    }
+    *i += n;
+    *out = v;
+    return true;
+}
+// subsecond, digits:OneOrMore -- >=1 digit; the first nine are kept, the rest consumed.
+inline bool take_subsecond(sv s, size_t* i, uint32_t* nano) {
+    if (*i >= s.size() || (unsigned)(s[*i] - '0') > 9) return false;
+    uint32_t v = (uint32_t)(s[*i] - '0') * 100000000u;
+    uint32_t mult = 10000000u;
+    ++*i;
+    while (*i < s.size() && (unsigned)(s[*i] - '0') <= 9) {
+        v += (uint32_t)(s[*i] - '0') * mult;
+        mult /= 10;
+        ++*i;
+    }
+    *nano = v;
+    return true;
+}
+// time::OffsetDateTime::parse(s, &Rfc3339)  (rfc5424_decoder.rs:95, ltsv_decoder.rs:225):
+// YYYY-MM-DD [Tt] HH:MM:SS [.d+] ( [Zz] | [+-]HH:MM ), whole input consumed.
+bool rfc3339_to_unix(sv s, double* out) {
+    DateTimeParts p{};
+    size_t i = 0;
+    if (!take_digits(s, &i, 4, &p.year)) return false;
+    if (i >= s.size() || s[i++] != '-') return false;
+    if (!take_digits(s, &i, 2, &p.month)) return false;
+    if (i >= s.size() || s[i++] != '-') return false;
+    if (!take_digits(s, &i, 2, &p.day)) return false;
+    if (i >= s.size() || (s[i] != 'T' && s[i] != 't')) return false;
+    ++i;
+    if (!take_digits(s, &i, 2, &p.hour)) return false;
+    if (i >= s.size() || s[i++] != ':') return false;
+    if (!take_digits(s, &i, 2, &p.minute)) return false;
+    if (i >= s.size() || s[i++] != ':') return false;
+    if (!take_digits(s, &i, 2, &p.second)) return false;
+    p.nano = 0;
+    if (i < s.size() && s[i] == '.') {
+        ++i;
+        if (!take_subsecond(s, &i, &p.nano)) return false;
+    }
+    p.off_sign = 1;
+    if (i < s.size() && (s[i] == 'Z' || s[i] == 'z')) {
+        ++i;
+    } else {
+        if (i >= s.size() || (s[i] != '+' && s[i] != '-')) return false;
+        p.off_sign = s[i] == '-' ? -1 : 1;
+        ++i;
+        if (!take_digits(s, &i, 2, &p.off_h)) return false;
+        if (i >= s.size() || s[i++] != ':') return false;
+        if (!take_digits(s, &i, 2, &p.off_m)) return false;
+    }
+    if (i != s.size()) return false;  // UnexpectedTrailingCharacters
+    return datetime_to_unix(p, /*allow_leap=*/true, out);
+}
+// "[day padding:none]/[month repr:short]/[year]:[hour]:[minute]:[second](.[subsecond])?
+//  [offset_hour sign:mandatory][offset_minute]"  (ltsv_decoder.rs:236-254)
+bool english_one(sv s, bool with_subsecond, double* out) {
+    static const char* mon[12] = {"Jan", "Feb", "Mar", "Apr", "May", "Jun", "Jul", "Aug", "Sep", "Oct", "Nov", "Dec"};
+    DateTimeParts p{};
+    size_t i = 0;
+    // [day padding:none] -> 1..2 digits, greedy
+    if (i >= s.size() || (unsigned)(s[i] - '0') > 9) return false;
+    p.day = s[i++] - '0';
+    if (i < s.size() && (unsigned)(s[i] - '0') <= 9) p.day = p.day * 10 + (s[i++] - '0');
+    if (i >= s.size() || s[i++] != '/') return false;
+    p.month = 0;
+    for (int m = 0; m < 12; ++m)
+        if (s.substr(i, 3) == mon[m]) { p.month = m + 1; break; }  // case-sensitive
+    if (!p.month) return false;
+    i += 3;
+    if (i >= s.size() || s[i++] != '/') return false;
+    // [year]: optional sign, exactly 4 digits (UNPINNED: sign handling)
+    int ysign = 1;
+    if (i < s.size() && (s[i] == '+' || s[i] == '-')) { ysign = s[i] == '-' ? -1 : 1; ++i; }
+    if (!take_digits(s, &i, 4, &p.year)) return false;
+    p.year *= ysign;
+    if (i >= s.size() || s[i++] != ':') return false;
+    if (!take_digits(s, &i, 2, &p.hour)) return false;
+    if (i >= s.size() || s[i++] != ':') return false;
+    if (!take_digits(s, &i, 2, &p.minute)) return false;
+    if (i >= s.size() || s[i++] != ':') return false;
+    if (!take_digits(s, &i, 2, &p.second)) return false;
+    p.nano = 0;
+    if (with_subsecond) {
+        if (i >= s.size() || s[i++] != '.') return false;
+        if (!take_subsecond(s, &i, &p.nano)) return false;
+    }
+    if (i >= s.size() || s[i++] != ' ') return false;
+    if (i >= s.size() || (s[i] != '+' && s[i] != '-')) return false;  // sign:mandatory
+    p.off_sign = s[i] == '-' ? -1 : 1;  // UNPINNED for "-00MM" (older time drops the sign)
+    ++i;
+    if (!take_digits(s, &i, 2, &p.off_h)) return false;
+    if (!take_digits(s, &i, 2, &p.off_m)) return false;
+    if (i != s.size()) return false;
+    return datetime_to_unix(p, /*allow_leap=*/false, out);
+}
+bool english_time_to_unix(sv s, double* out) {  // ltsv_decoder.rs:231-234
+    return english_one(s, false, out) || english_one(s, true, out);
+}
+
+// ---------------------------------------------------------------------------------------
+// RFC5424  (rfc5424_decoder.rs)
+// ---------------------------------------------------------------------------------------
+const char* E5424_BOM = "Unsupported BOM";
+const char* E5424_BRACKETS = "The priority should be inside brackets";
+const char* E5424_INVPRI = "Invalid priority";
+const char* E5424_NOVER = "Missing version";
+const char* E5424_BADVER = "Unsupported version";
+const char* E5424_NOTS = "Missing timestamp";
+const char* E5424_BADTS = "Unable to parse the date from RFC3339 to Unix time in RFC5424 decoder";
+const char* E5424_NOHOST = "Missing hostname";
+const char* E5424_NOAPP = "Missing application name";
+const char* E5424_NOPROC = "Missing process id";
+const char* E5424_NOMSGID = "Missing message id";
+const char* E5424_NODATA = "Missing message data";
+const char* E5424_NOMSG = "Missing log message";
+const char* E5424_MALFORMED = "Malformated RFC5424 message";
+const char* E5424_NOSD = "Missing structured data";
+const char* E5424_SDFMT = "Format error in the structured data";
+const char* E5424_NOBRACKET = "Missing ] after structured data";
+
+std::string unescape_sd_value(sv value) {  // :105-125
+    std::string res;
+    bool esc = false;
+    for (char c : value) {  // byte-wise == char-wise: every branch key is ASCII
+        if (!esc) {
+            if (c == '\\') esc = true;
+            else res.push_back(c);
+        } else {
+            if (c == '"' || c == '\\' || c == ']') res.push_back(c);
+            else { res.push_back('\\'); res.push_back(c); }
+            esc = false;
+        }
+    }
+    return res;
+}
+std::optional<std::string> parse_msg(sv line, size_t offset) {  // :163-172
+    if (offset > line.size()) return std::nullopt;
+    sv m = trim(line.substr(offset));
+    if (m.empty()) return std::nullopt;
+    return std::string(m);
+}
+// :174-242.  Returns error or (sd, leftover = the text after "sd_id ", offset just past ']').
+const char* parse_sd_data(sv line, size_t offset, StructuredData* sd_res, sv* leftover, size_t* after) {
+    sv tail = line.substr(offset);
+    size_t sp = tail.find(' ');
+    if (sp == sv::npos) return E5424_NOSD;  // :177 (":176" is unreachable)
+    sd_res->sd_id = std::string(tail.substr(0, sp));
+    sv sd = tail.substr(sp + 1);
+    bool in_name = false, in_value = false, esc = false, have_name = false;
+    size_t name_start = 0, value_start = 0;
+    sv name;
+    std::optional<size_t> after_sd;
+    // The reference iterates chars; every decision below depends only on ASCII bytes and on
+    // "code point > 126" which holds for each byte of a multi-byte sequence, so iterating
+    // bytes visits the same states.
+    for (size_t i = 0; i < sd.size(); ++i) {
+        unsigned char c = (unsigned char)sd[i];
+        bool is_sd_name = c >= 33 && c <= 126 && c != 34 && c != 61 && c != 93;  // :188-192
+        if (c == ' ' && !esc && !in_name && !have_name) {                          // :194
+        } else if (c == ']' && !esc && !in_name && !have_name) {                   // :197
+            after_sd = i + 1;
+            break;
+        } else if (!esc && is_sd_name && !in_name && !have_name) {                 // :201
+            in_name = true;
+            name_start = i;
+        } else if (is_sd_name && in_name && !have_name) {                          // :205
+        } else if (c == '=' && !esc && in_name) {                                  // :208
+            name = sd.substr(name_start, i - name_start);
+            have_name = true;
+            in_name = false;
+        } else if (c == '"' && !esc && have_name && !in_value) {                   // :212
+            in_value = true;
+            value_start = i + 1;
+        } else if (c == '\\' && !esc && in_value) {                                // :216
+            esc = true;
+        } else if (c == '"' && !esc && in_value) {                                 // :217
+            in_value = false;
+            SDValue v;
+            v.type = FGO_T_STRING;
+            v.s = unescape_sd_value(sd.substr(value_start, i - value_start));
+            sd_res->pairs.emplace_back("_" + std::string(name), std::move(v));
+            have_name = false;
+        } else if (in_value) {                                                     // :231
+            esc = false;
+        } else if (c == '"' && !esc && !in_name && !have_name) {                   // :232
+        } else {
+            return E5424_SDFMT;                                                    // :235
+        }
+    }
+    if (!after_sd) return E5424_NOBRACKET;  // :239
+    *leftover = sd;
+    *after = *after_sd;
+    return nullptr;
+}
+const char* parse_data(sv line, std::vector<StructuredData>* sd_vec, std::optional<std::string>* msg) {  // :127-161
+    if (line.empty()) return E5424_NOMSG;
+    if (line[0] == '-') { *msg = parse_msg(line, 1); return nullptr; }
+    if (line[0] != '[') return E5424_MALFORMED;
+    sv leftover = line;
+    size_t offset = 0;
+    for (;;) {
+        StructuredData sd;
+        sv nl;
+        size_t noff;
+        if (const char* e = parse_sd_data(leftover, offset + 1, &sd, &nl, &noff)) return e;
+        leftover = nl;
+        offset = noff;
+        sd_vec->push_back(std::move(sd));
+        if (offset >= leftover.size()) return E5424_NOMSG;  // :148
+        char c = leftover[offset];
+        if (c == '[') continue;
+        if (c == ' ') { *msg = parse_msg(leftover, offset); return nullptr; }
+        return E5424_MALFORMED;  // :154 (a multi-byte char here is also "other")
+    }
+}
+Result decode_rfc5424(sv line) {  // :18-49
+    Result r;
+    // BOM::parse :62-72
+    if (line.size() >= 3 && (uint8_t)line[0] == 0xEF && (uint8_t)line[1] == 0xBB && (uint8_t)line[2] == 0xBF)
+        line = line.substr(3);
+    else if (line.empty() || line[0] != '<') { r.err = E5424_BOM; return r; }
+    SplitN parts(line, 7, ' ');
+    sv part;
+    parts.next(&part);  // always yields ("Missing priority and version" :24 is unreachable)
+    // parse_pri_version :74-92
+    if (part.empty() || part[0] != '<') { r.err = E5424_BRACKETS; return r; }
+    {
+        SplitN pv(part.substr(1), 2, '>');
+        sv pri_s, ver;
+        pv.next(&pri_s);
+        uint64_t pri;
+        if (!rust_parse_unsigned(pri_s, 255, &pri)) { r.err = E5424_INVPRI; return r; }
+        if (!pv.next(&ver)) { r.err = E5424_NOVER; return r; }
+        if (ver != "1") { r.err = E5424_BADVER; return r; }
+        r.rec.facility = (uint8_t)(pri >> 3);
+        r.rec.severity = (uint8_t)(pri & 7);
+    }
+    if (!parts.next(&part)) { r.err = E5424_NOTS; return r; }
+    if (!rfc3339_to_unix(part, &r.rec.ts)) { r.err = E5424_BADTS; return r; }
+    if (!parts.next(&part)) { r.err = E5424_NOHOST; return r; }
+    r.rec.hostname = std::string(part);
+    if (!parts.next(&part)) { r.err = E5424_NOAPP; return r; }
+    r.rec.appname = std::string(part);
+    if (!parts.next(&part)) { r.err = E5424_NOPROC; return r; }
+    r.rec.procid = std::string(part);
+    if (!parts.next(&part)) { r.err = E5424_NOMSGID; return r; }
+    r.rec.msgid = std::string(part);
+    if (!parts.next(&part)) { r.err = E5424_NODATA; return r; }
+    std::vector<StructuredData> sd_vec;
+    if (const char* e = parse_data(part, &sd_vec, &r.rec.msg)) { r.err = e; return r; }
+    if (!sd_vec.empty()) r.rec.sd = std::move(sd_vec);
+    r.rec.full_msg = std::string(trim_end(line));  // :46 (the BOM-stripped line)
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------
+// LTSV  (ltsv_decoder.rs)
+// ---------------------------------------------------------------------------------------
+const char* ELTSV_LEVEL = "Invalid severity level";
+const char* ELTSV_LEVEL7 = "Severity level should be <= 7";
+const char* ELTSV_BOOL = "Type error; boolean was expected";
+const char* ELTSV_F64 = "Type error; f64 was expected";
+const char* ELTSV_I64 = "Type error; i64 was expected";
+const char* ELTSV_U64 = "Type error; u64 was expected";
+const char* ELTSV_NOTS = "Missing timestamp";
+const char* ELTSV_NOHOST = "Missing hostname";
+const char* ELTSV_ENGLISH = "Unable to parse the English to Unix timestamp in LTSV decoder";
+// Note on ltsv_decoder.rs:105-106: `&value[1..value.len()-1]` cannot panic -- a 1-byte value
+// cannot both start with '[' and end with ']'; "[]" yields the empty string.
+
+struct LtsvCfg {
+    std::map<std::string, uint8_t, std::less<>> schema;
+    std::optional<std::string> s_bool, s_f64, s_i64, s_u64;
+};
+LtsvCfg make_cfg(const fgo_ltsv_cfg* c) {
+    LtsvCfg r;
+    if (!c) return r;
+    for (uint32_t i = 0; i < c->n_schema; ++i) r.schema[c->schema_names[i]] = c->schema_types[i];
+    if (c->suffix_bool) r.s_bool = c->suffix_bool;
+    if (c->suffix_f64) r.s_f64 = c->suffix_f64;
+    if (c->suffix_i64) r.s_i64 = c->suffix_i64;
+    if (c->suffix_u64) r.s_u64 = c->suffix_u64;
+    return r;
+}
+inline bool ends_with(sv s, sv suf) { return s.size() >= suf.size() && s.substr(s.size() - suf.size()) == suf; }
+std::string final_name(sv name, const std::optional<std::string>& suffix) {  // :131-136
+    std::string r = "_";
+    r += name;
+    if (suffix && !ends_with(name, *suffix)) r += *suffix;
+    return r;
+}
+bool ltsv_parse_ts(sv s, double* out, const char** err) {  // :263-267
+    if (rust_parse_f64(s, out)) return true;
+    if (rfc3339_to_unix(s, out)) return true;
+    if (english_time_to_unix(s, out)) return true;
+    *err = ELTSV_ENGLISH;
+    return false;
+}
+Result decode_ltsv(sv line, const LtsvCfg& cfg) {  // :87-221
+    Result r;
+    StructuredData sd;
+    std::optional<double> ts;
+    std::optional<std::string> hostname;
+    size_t pos = 0;
+    for (;;) {  // line.split('\t')
+        size_t tab = line.find('\t', pos);
+        sv part = line.substr(pos, tab == sv::npos ? sv::npos : tab - pos);
+        size_t colon = part.find(':');
+        if (colon == sv::npos) {
+            // :99 println!("Missing value for name '{}'") -- stdout side effect only
+        } else {
+            sv name = part.substr(0, colon), value = part.substr(colon + 1);
+            if (name == "time") {
+                sv ts_s = value;
+                if (!value.empty() && value.front() == '[' && value.back() == ']' && value.size() >= 2)
+                    ts_s = value.substr(1, value.size() - 2);
+                double t;
+                if (!ltsv_parse_ts(ts_s, &t, &r.err)) return r;
+                ts = t;
+            } else if (name == "host") {
+                hostname = std::string(value);
+            } else if (name == "message") {
+                r.rec.msg = std::string(value);
+            } else if (name == "level") {
+                uint64_t lv;
+                if (!rust_parse_unsigned(value, 255, &lv)) { r.err = ELTSV_LEVEL; return r; }
+                if (lv > 7) { r.err = ELTSV_LEVEL7; return r; }
+                r.rec.severity = (uint8_t)lv;
+            } else {
+                SDValue v;
+                std::string fname;
+                auto it = cfg.schema.find(name);
+                uint8_t t = it == cfg.schema.end() ? (uint8_t)FGO_T_STRING : it->second;
+                switch (t) {
+                    case FGO_T_BOOL:
+                        fname = final_name(name, cfg.s_bool);
+                        if (value == "true") v.bits = 1;
+                        else if (value == "false") v.bits = 0;
+                        else { r.err = ELTSV_BOOL; return r; }
+                        break;
+                    case FGO_T_F64: {
+                        fname = final_name(name, cfg.s_f64);
+                        double d;
+                        if (!rust_parse_f64(value, &d)) { r.err = ELTSV_F64; return r; }
+                        memcpy(&v.bits, &d, 8);
+                        break;
+                    }
+                    case FGO_T_I64: {
+                        fname = final_name(name, cfg.s_i64);
+                        int64_t x;
+                        if (!rust_parse_i64(value, &x)) { r.err = ELTSV_I64; return r; }
+                        v.bits = (uint64_t)x;
+                        break;
+                    }
+                    case FGO_T_U64: {
+                        fname = final_name(name, cfg.s_u64);
+                        uint64_t x;
+                        if (!rust_parse_unsigned(value, UINT64_MAX, &x)) { r.err = ELTSV_U64; return r; }
+                        v.bits = x;
+                        break;
+                    }
+                    default:
+                        fname = final_name(name, std::nullopt);
+                        v.s = std::string(value);
+                        t = FGO_T_STRING;
+                }
+                v.type = t;
+                sd.pairs.emplace_back(std::move(fname), std::move(v));
+            }
+        }
+        if (tab == sv::npos) break;
+        pos = tab + 1;
+    }
+    if (!ts) { r.err = ELTSV_NOTS; return r; }
+    if (!hostname) { r.err = ELTSV_NOHOST; return r; }
+    r.rec.ts = *ts;
+    r.rec.hostname = std::move(*hostname);
+    if (!sd.pairs.empty()) {
+        std::vector<StructuredData> v;
+        v.push_back(std::move(sd));
+        r.rec.sd = std::move(v);
+    }
+    r.rec.full_msg = std::string(line);
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------
+// serde_json 0.8 restatement (DOM parse into Value; Object = BTreeMap, last duplicate wins)
+// ---------------------------------------------------------------------------------------
+struct JValue {
+    enum Kind : uint8_t { Null, Bool, I64, U64, F64, String, Array, Object } kind = Null;
+    uint64_t bits = 0;
+    std::string s;
+    std::map<std::string, JValue> obj;  // BTreeMap<String, Value>: byte-ordered keys
+};
+enum JErr { J_OK = 0, J_SYNTAX, J_INVALID_UNICODE_CODE_POINT };
+
+const double POW10[309] = {
+#define P8(a) 1e##a##0, 1e##a##1, 1e##a##2, 1e##a##3, 1e##a##4, 1e##a##5, 1e##a##6, 1e##a##7, 1e##a##8, 1e##a##9
+    1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  P8(1), P8(2), P8(3), P8(4), P8(5), P8(6), P8(7), P8(8), P8(9),
+    P8(10), P8(11), P8(12), P8(13), P8(14), P8(15), P8(16), P8(17), P8(18), P8(19), P8(20), P8(21), P8(22), P8(23), P8(24),
+    P8(25), P8(26), P8(27), P8(28), P8(29), 1e300, 1e301, 1e302, 1e303, 1e304, 1e305, 1e306, 1e307, 1e308
+#undef P8
+};
+
+struct JParser {
+    sv in;
+    size_t i = 0;
+    int depth = 0;
+    bool eof() const { return i >= in.size(); }
+    uint8_t peek_or_null() const { return eof() ? 0 : (uint8_t)in[i]; }
+    void ws() { while (!eof() && (in[i] == ' ' || in[i] == '\n' || in[i] == '\t' || in[i] == '\r')) ++i; }
+
+    static bool overflow_u64(uint64_t a, uint64_t b) { return a >= UINT64_MAX / 10 && (a > UINT64_MAX / 10 || b > UINT64_MAX % 10); }
+
+    JErr f64_from_parts(bool pos, uint64_t significand, int32_t exponent, JValue* v) {
+        double f = (double)significand;
+        for (;;) {
+            uint32_t a = exponent < 0 ? (uint32_t)(-(int64_t)exponent) : (uint32_t)exponent;
+            if (a <= 308) {
+                if (exponent >= 0) {
+                    f *= POW10[a];
+                    if (std::isinf(f)) return J_SYNTAX;  // NumberOutOfRange
+                } else {
+                    f /= POW10[a];
+                }
+                break;
+            }
+            // UNPINNED (|exp| > 308): serde_json >= 0.8.4 loop form
+            if (f == 0.0) break;
+            if (exponent >= 0) return J_SYNTAX;
+            f /= 1e308;
+            exponent += 308;
+        }
+        v->kind = JValue::F64;
+        double r = pos ? f : -f;
+        memcpy(&v->bits, &r, 8);
+        return J_OK;
+    }
+    JErr parse_exponent(bool pos, uint64_t significand, int32_t starting_exp, JValue* v) {
+        ++i;  // 'e'
+        bool pos_exp = true;
+        if (peek_or_null() == '+') ++i;
+        else if (peek_or_null() == '-') { ++i; pos_exp = false; }
+        if (eof() || (unsigned)(in[i] - '0') > 9) return J_SYNTAX;
+        int32_t exp = in[i++] - '0';
+        while (!eof() && (unsigned)(in[i] - '0') <= 9) {
+            int32_t digit = in[i++] - '0';
+            if (exp >= INT32_MAX / 10 && (exp > INT32_MAX / 10 || digit > INT32_MAX % 10)) {
+                // parse_exponent_overflow: zero significand or negative exp -> +-0.0, else error
+                if (significand != 0 && pos_exp) return J_SYNTAX;
+                while (!eof() && (unsigned)(in[i] - '0') <= 9) ++i;
+                v->kind = JValue::F64;
+                double z = pos ? 0.0 : -0.0;
+                memcpy(&v->bits, &z, 8);
+                return J_OK;
+            }
+            exp = exp * 10 + digit;
+        }
+        int64_t fe = pos_exp ? (int64_t)starting_exp + exp : (int64_t)starting_exp - exp;  // saturating
+        fe = std::max<int64_t>(INT32_MIN, std::min<int64_t>(INT32_MAX, fe));
+        return f64_from_parts(pos, significand, (int32_t)fe, v);
+    }
+    JErr parse_decimal(bool pos, uint64_t significand, int32_t exponent, JValue* v) {
+        ++i;  // '.'
+        bool at_least_one_digit = false;
+        while (!eof() && (unsigned)(in[i] - '0') <= 9) {
+            uint64_t digit = in[i++] - '0';
+            at_least_one_digit = true;
+            if (overflow_u64(significand, digit)) {
+                while (!eof() && (unsigned)(in[i] - '0') <= 9) ++i;  // ignore further digits
+                break;
+            }
+            significand = significand * 10 + digit;
+            exponent -= 1;
+        }
+        if (!at_least_one_digit) return J_SYNTAX;
+        uint8_t c = peek_or_null();
+        if (c == 'e' || c == 'E') return parse_exponent(pos, significand, exponent, v);
+        return f64_from_parts(pos, significand, exponent, v);
+    }
+    JErr parse_number(bool pos, uint64_t significand, JValue* v) {
+        uint8_t c = peek_or_null();
+        if (c == '.') return parse_decimal(pos, significand, 0, v);
+        if (c == 'e' || c == 'E') return parse_exponent(pos, significand, 0, v);
+        if (pos) { v->kind = JValue::U64; v->bits = significand; return J_OK; }
+        int64_t neg = (int64_t)(0 - significand);  // (significand as i64).wrapping_neg()
+        if (neg > 0) {  // underflow -> float
+            v->kind = JValue::F64;
+            double d = -(double)significand;
+            memcpy(&v->bits, &d, 8);
+        } else if (neg < 0) {
+            v->kind = JValue::I64;
+            v->bits = (uint64_t)neg;
+        } else {  // Value visitor: visit_i64(0) -> U64(0)
+            v->kind = JValue::U64;
+            v->bits = 0;
+        }
+        return J_OK;
+    }
+    JErr parse_long_integer(bool pos, uint64_t significand, int32_t exponent, JValue* v) {
+        for (;;) {
+            uint8_t c = peek_or_null();
+            if ((unsigned)(c - '0') <= 9 && !eof()) { ++i; exponent += 1; }
+            else if (c == '.') return parse_decimal(pos, significand, exponent, v);
+            else if (c == 'e' || c == 'E') return parse_exponent(pos, significand, exponent, v);
+            else return f64_from_parts(pos, significand, exponent, v);
+        }
+    }
+    JErr parse_integer(bool pos, JValue* v) {
+        if (eof()) return J_SYNTAX;
+        uint8_t c = (uint8_t)in[i++];
+        if (c == '0') {
+            uint8_t n = peek_or_null();
+            if (!eof() && (unsigned)(n - '0') <= 9) return J_SYNTAX;  // one leading 0 only
+            return parse_number(pos, 0, v);
+        }
+        if (c >= '1' && c <= '9') {
+            uint64_t res = c - '0';
+            for (;;) {
+                uint8_t d = peek_or_null();
+                if (!eof() && (unsigned)(d - '0') <= 9) {
+                    ++i;
+                    uint64_t digit = d - '0';
+                    if (overflow_u64(res, digit)) return parse_long_integer(pos, res, 1, v);
+                    res = res * 10 + digit;
+                } else {
+                    return parse_number(pos, res, v);
+                }
+            }
+        }
+        return J_SYNTAX;
+    }
+    static int hexv(uint8_t c) {
+        if (c >= '0' && c <= '9') return c - '0';
+        if (c >= 'a' && c <= 'f') return c - 'a' + 10;
+        if (c >= 'A' && c <= 'F') return c - 'A' + 10;
+        return -1;
+    }
+    JErr hex4(uint32_t* out) {
+        uint32_t n = 0;
+        for (int k = 0; k < 4; ++k) {
+            if (eof()) return J_SYNTAX;
+            int h = hexv((uint8_t)in[i++]);
+            if (h < 0) return J_SYNTAX;
+            n = n * 16 + h;
+        }
+        *out = n;
+        return J_OK;
+    }
+    static void push_utf8(std::string* s, uint32_t c) {
+        if (c < 0x80) s->push_back((char)c);
+        else if (c < 0x800) { s->push_back((char)(0xC0 | (c >> 6))); s->push_back((char)(0x80 | (c & 0x3F))); }
+        else if (c < 0x10000) {
+            s->push_back((char)(0xE0 | (c >> 12))); s->push_back((char)(0x80 | ((c >> 6) & 0x3F))); s->push_back((char)(0x80 | (c & 0x3F)));
+        } else {
+            s->push_back((char)(0xF0 | (c >> 18))); s->push_back((char)(0x80 | ((c >> 12) & 0x3F)));
+            s->push_back((char)(0x80 | ((c >> 6) & 0x3F))); s->push_back((char)(0x80 | (c & 0x3F)));
+        }
+    }
+    JErr parse_str(std::string* out) {  // opening quote already consumed
+        out->clear();
+        for (;;) {
+            if (eof()) return J_SYNTAX;  // EOFWhileParsingString
+            uint8_t c = (uint8_t)in[i];
+            if (c == '"') { ++i; return J_OK; }
+            if (c == '\\') {
+                ++i;
+                if (eof()) return J_SYNTAX;
+                uint8_t e = (uint8_t)in[i++];
+                switch (e) {
+                    case '"': out->push_back('"'); break;
+                    case '\\': out->push_back('\\'); break;
+                    case '/': out->push_back('/'); break;
+                    case 'b': out->push_back('\x08'); break;
+                    case 'f': out->push_back('\x0c'); break;
+                    case 'n': out->push_back('\n'); break;
+                    case 'r': out->push_back('\r'); break;
+                    case 't': out->push_back('\t'); break;
+                    case 'u': {
+                        uint32_t n1;
+                        if (hex4(&n1)) return J_SYNTAX;
+                        if (n1 >= 0xDC00 && n1 <= 0xDFFF) return J_SYNTAX;  // LoneLeadingSurrogateInHexEscape
+                        if (n1 >= 0xD800 && n1 <= 0xDBFF) {
+                            if (i + 1 >= in.size()) return J_SYNTAX;
+                            if (in[i] != '\\' || in[i + 1] != 'u') return J_SYNTAX;  // UnexpectedEndOfHexEscape
+                            i += 2;
+                            uint32_t n2;
+                            if (hex4(&n2)) return J_SYNTAX;
+                            if (n2 < 0xDC00 || n2 > 0xDFFF) return J_SYNTAX;
+                            n1 = (((n1 - 0xD800) << 10) | (n2 - 0xDC00)) + 0x10000;
+                        }
+                        push_utf8(out, n1);
+                        break;
+                    }
+                    default: return J_SYNTAX;  // InvalidEscape
+                }
+            } else if (c < 0x20) {
+                return J_INVALID_UNICODE_CODE_POINT;  // raw control character inside a string
+            } else {
+                out->push_back((char)c);
+                ++i;
+            }
+        }
+    }
+    bool ident(const char* rest) {
+        size_t n = strlen(rest);
+        if (in.substr(i, n) != sv(rest, n)) return false;
+        i += n;
+        return true;
+    }
+    JErr parse_value(JValue* v) {
+        ws();
+        if (eof()) return J_SYNTAX;
+        uint8_t c = (uint8_t)in[i];
+        switch (c) {
+            case 'n': ++i; if (!ident("ull")) return J_SYNTAX; v->kind = JValue::Null; return J_OK;
+            case 't': ++i; if (!ident("rue")) return J_SYNTAX; v->kind = JValue::Bool; v->bits = 1; return J_OK;
+            case 'f': ++i; if (!ident("alse")) return J_SYNTAX; v->kind = JValue::Bool; v->bits = 0; return J_OK;
+            case '-': ++i; return parse_integer(false, v);
+            case '"': ++i; v->kind = JValue::String; return parse_str(&v->s);
+            case '[': {
+                ++i;
+                v->kind = JValue::Array;
+                if (++depth > 512) return J_SYNTAX;  // UNPINNED: 0.8 has no depth limit (stack overflow)
+                bool first = true;
+                for (;;) {
+                    ws();
+                    if (eof()) return J_SYNTAX;
+                    if (in[i] == ']') { ++i; break; }
+                    if (!first) {
+                        if (in[i] != ',') return J_SYNTAX;
+                        ++i;
+                    }
+                    first = false;
+                    JValue e;
+                    if (JErr r = parse_value(&e)) return r;
+                }
+                --depth;
+                return J_OK;
+            }
+            case '{': {
+                ++i;
+                v->kind = JValue::Object;
+                if (++depth > 512) return J_SYNTAX;
+                bool first = true;
+                for (;;) {
+                    ws();
+                    if (eof()) return J_SYNTAX;
+                    if (in[i] == '}') { ++i; break; }
+                    if (!first) {
+                        if (in[i] != ',') return J_SYNTAX;
+                        ++i;
+                        ws();
+                    }
+                    first = false;
+                    if (eof() || in[i] != '"') return J_SYNTAX;  // KeyMustBeAString
+                    ++i;
+                    std::string key;
+                    if (JErr r = parse_str(&key)) return r;
+                    ws();
+                    if (eof() || in[i] != ':') return J_SYNTAX;
+                    ++i;
+                    JValue e;
+                    if (JErr r = parse_value(&e)) return r;
+                    v->obj[std::move(key)] = std::move(e);  // BTreeMap::insert: last wins
+                }
+                --depth;
+                return J_OK;
+            }
+            default:
+                if (c >= '0' && c <= '9') return parse_integer(true, v);
+                return J_SYNTAX;  // ExpectedSomeValue
+        }
+    }
+    JErr parse_document(JValue* v) {  // de::from_str
+        if (JErr r = parse_value(v)) return r;
+        ws();
+        return eof() ? J_OK : J_SYNTAX;  // TrailingCharacters
+    }
+};
+// Array elements above are parsed and dropped: the decoder only needs to know "it is an
+// array" (gelf_decoder.rs:97) -- but a nested error must still surface in parse order.
+
+// ---------------------------------------------------------------------------------------
+// GELF  (gelf_decoder.rs)
+// ---------------------------------------------------------------------------------------
+const char* EGELF_JSON = "Invalid GELF input, unable to parse as a JSON object";
+const char* EGELF_EMPTY = "Empty GELF input";
+const char* EGELF_TS = "Invalid GELF timestamp";
+const char* EGELF_HOST = "GELF host name must be a string";
+const char* EGELF_SHORT = "GELF short message must be a string";
+const char* EGELF_FULL = "GELF full message must be a string";
+const char* EGELF_VERSTR = "GELF version must be a string";
+const char* EGELF_VER = "Unsupported GELF version";
+const char* EGELF_LEVEL = "Invalid severity level";
+const char* EGELF_LEVEL7 = "Invalid severity level (too high)";
+const char* EGELF_SDTYPE = "Invalid value type in structured data";
+const char* EGELF_NOHOST = "Missing hostname";
+
+Result decode_gelf(sv line) {  // :34-125
+    Result r;
+    JValue doc;
+    JParser p{line};
+    JErr e = p.parse_document(&doc);
+    std::string replaced;
+    if (e == J_INVALID_UNICODE_CODE_POINT) {  // :44-46 retry with every '\n' -> "\\n"
+        for (char c : line) {
+            if (c == '\n') replaced += "\\n";
+            else replaced.push_back(c);
+        }
+        doc = JValue();
+        JParser p2{replaced};
+        e = p2.parse_document(&doc);
+    }
+    if (e != J_OK) { r.err = EGELF_JSON; return r; }
+    if (doc.kind != JValue::Object) { r.err = EGELF_EMPTY; return r; }
+    StructuredData sd;
+    std::optional<double> ts;
+    std::optional<std::string> hostname;
+    for (auto& kv : doc.obj) {  // sorted key order
+        const std::string& key = kv.first;
+        JValue& v = kv.second;
+        if (key == "timestamp") {  // Value::as_f64 (NumCast)
+            if (v.kind == JValue::F64) { double d; memcpy(&d, &v.bits, 8); ts = d; }
+            else if (v.kind == JValue::U64) ts = (double)v.bits;
+            else if (v.kind == JValue::I64) ts = (double)(int64_t)v.bits;
+            else { r.err = EGELF_TS; return r; }
+        } else if (key == "host") {
+            if (v.kind != JValue::String) { r.err = EGELF_HOST; return r; }
+            hostname = v.s;
+        } else if (key == "short_message") {
+            if (v.kind != JValue::String) { r.err = EGELF_SHORT; return r; }
+            r.rec.msg = v.s;
+        } else if (key == "full_message") {
+            if (v.kind != JValue::String) { r.err = EGELF_FULL; return r; }
+            r.rec.full_msg = v.s;
+        } else if (key == "version") {
+            if (v.kind != JValue::String) { r.err = EGELF_VERSTR; return r; }
+            if (v.s != "1.0" && v.s != "1.1") { r.err = EGELF_VER; return r; }
+        } else if (key == "level") {
+            // Value::as_u64 -- UNPINNED for negative I64 (0.8 uses NumCast -> None)
+            if (v.kind != JValue::U64) { r.err = EGELF_LEVEL; return r; }
+            if (v.bits > 7) { r.err = EGELF_LEVEL7; return r; }
+            r.rec.severity = (uint8_t)v.bits;
+        } else {
+            SDValue s;
+            switch (v.kind) {
+                case JValue::String: s.type = FGO_T_STRING; s.s = v.s; break;
+                case JValue::Bool: s.type = FGO_T_BOOL; s.bits = v.bits; break;
+                case JValue::F64: s.type = FGO_T_F64; s.bits = v.bits; break;
+                case JValue::I64: s.type = FGO_T_I64; s.bits = v.bits; break;
+                case JValue::U64: s.type = FGO_T_U64; s.bits = v.bits; break;
+                case JValue::Null: s.type = FGO_T_NULL; break;
+                default: r.err = EGELF_SDTYPE; return r;
+            }
+            std::string name = (!key.empty() && key[0] == '_') ? key : "_" + key;
+            sd.pairs.emplace_back(std::move(name), std::move(s));
+        }
+    }
+    if (ts) r.rec.ts = *ts;
+    else r.rec.ts_now = true;  // :109 -- ts is evaluated before the hostname check; no error either way
+    if (!hostname) { r.err = EGELF_NOHOST; return r; }
+    r.rec.hostname = std::move(*hostname);
+    if (!sd.pairs.empty()) {
+        std::vector<StructuredData> v;
+        v.push_back(std::move(sd));
+        r.rec.sd = std::move(v);
+    }
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------
+// canonical serialisation
+// ---------------------------------------------------------------------------------------
+struct Sink {
+    uint8_t* out;
+    uint64_t cap;
+    uint64_t n = 0;
+    void put(const void* p, size_t len) {
+        if (out && n + len <= cap) memcpy(out + n, p, len);
+        n += len;
+    }
+    void u8(uint8_t v) { put(&v, 1); }
+    void u32(uint32_t v) { put(&v, 4); }
+    void u64(uint64_t v) { put(&v, 8); }
+    void str(sv s) { u32((uint32_t)s.size()); put(s.data(), s.size()); }
+    void optstr(const std::optional<std::string>& s) {
+        if (!s) { u8(0); return; }
+        u8(1);
+        str(*s);
+    }
+};
+void serialise(const Result& r, Sink* k) {
+    if (r.err) {
+        k->u8(1);
+        k->str(r.err);
+        return;
+    }
+    const Record& rec = r.rec;
+    k->u8(0);
+    k->u8(rec.ts_now ? 1 : 0);
+    uint64_t tb = 0;
+    if (!rec.ts_now) memcpy(&tb, &rec.ts, 8);
+    k->u64(tb);
+    k->u8(rec.facility ? *rec.facility : 0xFF);
+    k->u8(rec.severity ? *rec.severity : 0xFF);
+    k->u8(1);
+    k->str(rec.hostname);
+    k->optstr(rec.appname);
+    k->optstr(rec.procid);
+    k->optstr(rec.msgid);
+    k->optstr(rec.msg);
+    k->optstr(rec.full_msg);
+    if (!rec.sd) { k->u8(0); return; }
+    k->u8(1);
+    k->u32((uint32_t)rec.sd->size());
+    for (const auto& sd : *rec.sd) {
+        k->optstr(sd.sd_id);
+        k->u32((uint32_t)sd.pairs.size());
+        for (const auto& kv : sd.pairs) {
+            k->str(kv.first);
+            k->u8(kv.second.type);
+            switch (kv.second.type) {
+                case FGO_T_STRING: k->str(kv.second.s); break;
+                case FGO_T_BOOL: k->u8((uint8_t)kv.second.bits); break;
+                case FGO_T_NULL: break;
+                default: k->u64(kv.second.bits);
+            }
+        }
+    }
+}
+Result decode_any(int fmt, const LtsvCfg& cfg, sv line) {
+    switch (fmt) {
+        case FGO_RFC5424: return decode_rfc5424(line);
+        case FGO_LTSV: return decode_ltsv(line, cfg);
+        default: return decode_gelf(line);
+    }
+}
+uint64_t record_checksum(const Result& r) {
+    if (r.err) return (uint64_t)(uintptr_t)r.err & 0xFF;
+    uint64_t h = 0;
+    memcpy(&h, &r.rec.ts, 8);
+    h ^= r.rec.hostname.size() * 0x9E3779B97F4A7C15ull;
+    if (r.rec.msg) h += r.rec.msg->size();
+    if (r.rec.full_msg) h += (uint8_t)r.rec.full_msg->back();
+    if (r.rec.sd) for (auto& s : *r.rec.sd) h += s.pairs.size() * 31;
+    return h;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t fgo_decode(int fmt, const fgo_ltsv_cfg* cfg, const uint8_t* line, uint64_t len, uint8_t* out, uint64_t cap) {
+    if (fmt < 0 || fmt > 2) return -1;
+    LtsvCfg c = make_cfg(cfg);
+    Result r = decode_any(fmt, c, sv((const char*)line, len));
+    Sink k{out, cap};
+    serialise(r, &k);
+    return (int64_t)k.n;
+}
+
+int64_t fgo_decode_batch(int fmt, const fgo_ltsv_cfg* cfg, const uint8_t* bytes, const uint64_t* offsets, uint64_t n,
+                         uint8_t* out, uint64_t cap, uint64_t* out_offsets, int threads) {
+    if (fmt < 0 || fmt > 2) return -1;
+    LtsvCfg c = make_cfg(cfg);
+    if (threads <= 0) threads = 1;
+    // pass 1: sizes (parallel), pass 2: write at the prefix-summed offsets (parallel)
+    std::vector<uint64_t> sizes(n + 1, 0);
+    auto run = [&](bool write) {
+        std::vector<std::thread> th;
+        for (int t = 0; t < threads; ++t) {
+            th.emplace_back([&, t]() {
+                uint64_t lo = n * t / threads, hi = n * (t + 1) / threads;
+                for (uint64_t i = lo; i < hi; ++i) {
+                    Result r = decode_any(fmt, c, sv((const char*)bytes + offsets[i], offsets[i + 1] - offsets[i]));
+                    if (!write) {
+                        Sink k{nullptr, 0};
+                        serialise(r, &k);
+                        sizes[i + 1] = k.n;
+                    } else {
+                        uint64_t o = sizes[i];
+                        Sink k{out + o, cap > o ? cap - o : 0};
+                        serialise(r, &k);
+                    }
+                }
+            });
+        }
+        for (auto& x : th) x.join();
+    };
+    run(false);
+    for (uint64_t i = 0; i < n; ++i) sizes[i + 1] += sizes[i];
+    if (out_offsets) memcpy(out_offsets, sizes.data(), (n + 1) * 8);
+    if (out && sizes[n] <= cap) run(true);
+    return (int64_t)sizes[n];
+}
+
+double fgo_bench_decode(int fmt, const fgo_ltsv_cfg* cfg, const uint8_t* bytes, const uint64_t* offsets, uint64_t n,
+                        int threads, uint64_t* checksum, uint64_t* n_ok) {
+    if (fmt < 0 || fmt > 2) return -1.0;
+    LtsvCfg c = make_cfg(cfg);
+    if (threads <= 0) threads = 1;
+    std::vector<uint64_t> sums(threads, 0), oks(threads, 0);
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; ++t) {
+        th.emplace_back([&, t]() {
+            uint64_t lo = n * t / threads, hi = n * (t + 1) / threads, s = 0, ok = 0;
+            for (uint64_t i = lo; i < hi; ++i) {
+                Result r = decode_any(fmt, c, sv((const char*)bytes + offsets[i], offsets[i + 1] - offsets[i]));
+                s += record_checksum(r);
+                ok += r.err == nullptr;
+            }
+            sums[t] = s;
+            oks[t] = ok;
+        });
+    }
+    for (auto& x : th) x.join();
+    double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    uint64_t s = 0, ok = 0;
+    for (int t = 0; t < threads; ++t) { s += sums[t]; ok += oks[t]; }
+    if (checksum) *checksum = s;
+    if (n_ok) *n_ok = ok;
+    return secs;
+}
+
+int fgo_rfc3339_to_unix(const uint8_t* s, uint64_t len, double* out) { return rfc3339_to_unix(sv((const char*)s, len), out); }
+int fgo_rust_parse_f64(const uint8_t* s, uint64_t len, double* out) { return rust_parse_f64(sv((const char*)s, len), out); }
+int fgo_english_time_to_unix(const uint8_t* s, uint64_t len, double* out) { return english_time_to_unix(sv((const char*)s, len), out); }
+int fgo_json_number(const uint8_t* s, uint64_t len, int* kind, uint64_t* bits) {
+    JValue v;
+    JParser p{sv((const char*)s, len)};
+    if (p.parse_document(&v) != J_OK) return 0;
+    if (v.kind != JValue::F64 && v.kind != JValue::I64 && v.kind != JValue::U64) return 0;
+    *kind = v.kind == JValue::F64 ? FGO_T_F64 : v.kind == JValue::I64 ? FGO_T_I64 : FGO_T_U64;
+    *bits = v.bits;
+    return 1;
+}
+
+}  // extern "C"

@@ -1,0 +1,82 @@
+/*
+ * fg_oracle.h -- C interface of the CPU ORACLE (test infrastructure, NOT product).
+ *
+ * The oracle is a behaviour-for-behaviour CPU restatement of flowgger's three
+ * per-line decoders (reference: src/flowgger/decoder/{rfc5424,ltsv,gelf}_decoder.rs,
+ * src/flowgger/record.rs, src/flowgger/utils/mod.rs:23-28).  It exists only to judge
+ * the HIP path: tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load it; nothing under flowgger_amd/ may.
+ *
+ * Every decode result is returned in the CANONICAL SERIALISATION (one byte string per
+ * line) that the product's table->Record materialiser also emits, so "bit-exact" is a
+ * plain byte comparison:
+ *
+ *   Ok  : 0x00
+ *         u8  ts_kind   (0 = value follows, 1 = "wall clock now" -- GELF without timestamp,
+ *                         gelf_decoder.rs:109; the 8 ts bytes are then zero)
+ *         f64 ts        (8 raw IEEE-754 bytes, little endian)
+ *         u8  facility  (0xFF = None)      u8 severity (0xFF = None)
+ *         optstr hostname, appname, procid, msgid, msg, full_msg
+ *              optstr := u8 present [, u32 len LE, bytes]      (hostname is always present)
+ *         u8  sd_present (0 = None, 1 = Some(vec))
+ *         [ u32 n_sd ; per element: optstr sd_id ; u32 n_pairs ;
+ *           per pair: u32 klen, key bytes, u8 type (0 String 1 Bool 2 F64 3 I64 4 U64 5 Null),
+ *                     String: u32 len, bytes | Bool: u8 | F64/I64/U64: 8 bytes LE | Null: - ]
+ *   Err : 0x01, u32 len LE, the exact &'static str of the reference
+ *
+ * Order of SD elements and pairs is significant (Vec, record.rs:26,81).
+ */
+#ifndef FG_ORACLE_H
+#define FG_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { FGO_RFC5424 = 0, FGO_LTSV = 1, FGO_GELF = 2 };
+enum { FGO_T_STRING = 0, FGO_T_BOOL = 1, FGO_T_F64 = 2, FGO_T_I64 = 3, FGO_T_U64 = 4, FGO_T_NULL = 5 };
+
+/* LTSV decoder configuration (input.ltsv_schema / input.ltsv_suffixes, ltsv_decoder.rs:24-84).
+ * n_schema == 0 behaves like "no schema" (every unknown key is a String pair). Suffix
+ * pointers may be NULL (= None). */
+typedef struct fgo_ltsv_cfg {
+    const char* const* schema_names; /* n_schema NUL-terminated names */
+    const uint8_t* schema_types;     /* n_schema FGO_T_* (STRING..U64) */
+    uint32_t n_schema;
+    const char* suffix_bool;
+    const char* suffix_f64;
+    const char* suffix_i64;
+    const char* suffix_u64;
+} fgo_ltsv_cfg;
+
+/* Decode one line; writes the canonical serialisation to out (capacity cap).
+ * Returns the serialised size (even when > cap; nothing is written past cap), <0 on bad args. */
+int64_t fgo_decode(int fmt, const fgo_ltsv_cfg* cfg, const uint8_t* line, uint64_t len,
+                   uint8_t* out, uint64_t cap);
+
+/* Decode n packed lines (line i = bytes[offsets[i] .. offsets[i+1])).  out_offsets has n+1
+ * entries.  Call with out == NULL to size.  Returns total serialised bytes. threads <= 0
+ * means 1. */
+int64_t fgo_decode_batch(int fmt, const fgo_ltsv_cfg* cfg, const uint8_t* bytes,
+                         const uint64_t* offsets, uint64_t n, uint8_t* out, uint64_t cap,
+                         uint64_t* out_offsets, int threads);
+
+/* CPU-baseline timing leg: decode n lines into owned Record objects (one heap string per
+ * field, like the reference) with `threads` std::threads; returns wall seconds for ONE pass.
+ * *checksum receives a value that depends on every record (defeats dead-code elimination);
+ * *n_ok the number of Ok results. */
+double fgo_bench_decode(int fmt, const fgo_ltsv_cfg* cfg, const uint8_t* bytes,
+                        const uint64_t* offsets, uint64_t n, int threads, uint64_t* checksum,
+                        uint64_t* n_ok);
+
+/* Exposed pieces, for unit tests of the restated std/third-party semantics. */
+int fgo_rfc3339_to_unix(const uint8_t* s, uint64_t len, double* out);  /* 1 = ok */
+int fgo_rust_parse_f64(const uint8_t* s, uint64_t len, double* out);  /* 1 = ok */
+int fgo_json_number(const uint8_t* s, uint64_t len, int* kind, uint64_t* bits); /* serde_json 0.8 */
+int fgo_english_time_to_unix(const uint8_t* s, uint64_t len, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,116 @@
+"""ctypes binding of oracle/libfg_oracle.so -- the CPU oracle (test infrastructure only)."""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+ORACLE_DIR = ROOT / "oracle"
+LIB = ORACLE_DIR / "libfg_oracle.so"
+RFC5424, LTSV, GELF = 0, 1, 2
+_TYPE_IDS = {"string": 0, "bool": 1, "f64": 2, "i64": 3, "u64": 4}
+
+
+class fgo_ltsv_cfg(C.Structure):
+    _fields_ = [("schema_names", C.POINTER(C.c_char_p)), ("schema_types", C.POINTER(C.c_uint8)),
+                ("n_schema", C.c_uint32), ("suffix_bool", C.c_char_p), ("suffix_f64", C.c_char_p),
+                ("suffix_i64", C.c_char_p), ("suffix_u64", C.c_char_p)]
+
+
+def build_oracle() -> Path:
+    src = ORACLE_DIR / "fg_oracle.cpp"
+    if not LIB.exists() or LIB.stat().st_mtime < max(src.stat().st_mtime, (ORACLE_DIR / "fg_oracle.h").stat().st_mtime):
+        subprocess.run(["make", "-C", str(ORACLE_DIR)], check=True, capture_output=True)
+    return LIB
+
+
+class Oracle:
+    def __init__(self):
+        self.lib = C.CDLL(str(build_oracle()))
+        L = self.lib
+        vp, u64 = C.c_void_p, C.c_uint64
+        L.fgo_decode.restype = C.c_int64
+        L.fgo_decode.argtypes = [C.c_int, vp, vp, u64, vp, u64]
+        L.fgo_decode_batch.restype = C.c_int64
+        L.fgo_decode_batch.argtypes = [C.c_int, vp, vp, vp, u64, vp, u64, vp, C.c_int]
+        L.fgo_bench_decode.restype = C.c_double
+        L.fgo_bench_decode.argtypes = [C.c_int, vp, vp, vp, u64, C.c_int, vp, vp]
+        for f in (L.fgo_rfc3339_to_unix, L.fgo_rust_parse_f64, L.fgo_english_time_to_unix):
+            f.argtypes = [vp, u64, C.POINTER(C.c_double)]
+        L.fgo_json_number.argtypes = [vp, u64, C.POINTER(C.c_int), C.POINTER(u64)]
+
+    @staticmethod
+    def make_cfg(config):
+        """config: same dict shape as flowgger_amd.LTSVDecoder; returns (struct|None, keepalive)."""
+        if not config:
+            return None, None
+        inp = config.get("input", {})
+        schema = inp.get("ltsv_schema") or {}
+        suffixes = inp.get("ltsv_suffixes") or {}
+        names = [k.encode() for k in schema]
+        types = [_TYPE_IDS[v.lower()] for v in schema.values()]
+        cfg = fgo_ltsv_cfg()
+        an = (C.c_char_p * max(len(names), 1))(*names)
+        at = (C.c_uint8 * max(len(types), 1))(*types)
+        cfg.schema_names = C.cast(an, C.POINTER(C.c_char_p))
+        cfg.schema_types = C.cast(at, C.POINTER(C.c_uint8))
+        cfg.n_schema = len(names)
+        for k, v in suffixes.items():
+            setattr(cfg, "suffix_" + k.lower(), v.encode())
+        return cfg, (an, at, names)
+
+    def decode(self, fmt: int, line, config=None) -> bytes:
+        b = line.encode("utf-8", "surrogateescape") if isinstance(line, str) else bytes(line)
+        cfg, keep = self.make_cfg(config)
+        cfgp = C.byref(cfg) if cfg is not None else None
+        buf = C.create_string_buffer(len(b) * 3 + 4096)
+        n = self.lib.fgo_decode(fmt, cfgp, b, len(b), buf, len(buf))
+        assert 0 <= n <= len(buf)
+        return buf.raw[:n]
+
+    def decode_batch(self, fmt: int, data: np.ndarray, offsets: np.ndarray, config=None, threads: int = 8):
+        data = np.ascontiguousarray(data, np.uint8)
+        offsets = np.ascontiguousarray(offsets, np.uint64)
+        n = len(offsets) - 1
+        cfg, keep = self.make_cfg(config)
+        cfgp = C.byref(cfg) if cfg is not None else None
+        offs = np.zeros(n + 1, np.uint64)
+        total = self.lib.fgo_decode_batch(fmt, cfgp, data.ctypes.data, offsets.ctypes.data, n, None, 0,
+                                          offs.ctypes.data, threads)
+        blob = np.zeros(max(total, 1), np.uint8)
+        self.lib.fgo_decode_batch(fmt, cfgp, data.ctypes.data, offsets.ctypes.data, n, blob.ctypes.data, total,
+                                  offs.ctypes.data, threads)
+        return blob[:total], offs
+
+    def bench(self, fmt: int, data: np.ndarray, offsets: np.ndarray, threads: int, config=None):
+        cfg, keep = self.make_cfg(config)
+        cfgp = C.byref(cfg) if cfg is not None else None
+        chk, nok = C.c_uint64(), C.c_uint64()
+        secs = self.lib.fgo_bench_decode(fmt, cfgp, data.ctypes.data, offsets.ctypes.data, len(offsets) - 1, threads,
+                                         C.byref(chk), C.byref(nok))
+        return secs, nok.value
+
+    def rfc3339(self, s: str):
+        out = C.c_double()
+        b = s.encode()
+        return out.value if self.lib.fgo_rfc3339_to_unix(b, len(b), C.byref(out)) else None
+
+    def parse_f64(self, s: str):
+        out = C.c_double()
+        b = s.encode()
+        return out.value if self.lib.fgo_rust_parse_f64(b, len(b), C.byref(out)) else None
+
+    def english(self, s: str):
+        out = C.c_double()
+        b = s.encode()
+        return out.value if self.lib.fgo_english_time_to_unix(b, len(b), C.byref(out)) else None
+
+    def json_number(self, s: str):
+        kind, bits = C.c_int(), C.c_uint64()
+        b = s.encode()
+        if not self.lib.fgo_json_number(b, len(b), C.byref(kind), C.byref(bits)):
+            return None
+        return kind.value, bits.value
