@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric: RFC5424 log lines/s on N x MI355X + achieved HBM GB/s.
+
+Workload (N=1 and per GPU at N>1, weak scaling): BASELINE config[1] -- RFC5424 without structured
+data, 100 M lines @ ~256 B (a deterministic 1 M-line tile, seed 0x54240002, replicated x100 in
+HBM with rebased offsets, 1 % invalid lines).  A "step" = ONE pass of the hot path
+(fg_decode_batch_device through the C ABI) over the whole resident batch: every line tokenised,
+every table row written.  Inputs are resident in HBM when the timed region starts.
+
+One JSON line on stdout (rank 0).  `roofline.achieved` = algorithmic bytes per launch (DESIGN.md:
+line bytes + 8 B offset read, 68 B table row written, + 18 B per SD entry) / mean kernel time
+measured with HIP events on the launch stream.  `cpu_baseline` = the C++ oracle (a restatement of
+the reference's CPU decoders, "port") timed on this box's host cores on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--tile-lines", type=int, default=1_000_000)
+    ap.add_argument("--reps", type=int, default=100, help="tile replicas resident per GPU")
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(data, offsets, n_lines):
+    """Oracle timing leg (the ONLY place bench.py touches oracle/)."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import oracle_binding
+
+    o = oracle_binding.Oracle()
+    cores = os.cpu_count() or 1
+    passes, secs, n_ok = 0, 0.0, 0
+    t_end = time.time() + 4.0
+    while passes < 2 or (time.time() < t_end and passes < 8):
+        s, n_ok = o.bench(0, data, offsets, cores)
+        secs += s
+        passes += 1
+    return {
+        "value": n_lines * passes / secs, "unit": "lines/s", "cores": cores, "kind": "port",
+        "sample": f"{passes} passes over the {n_lines}-line tile of the same workload, {cores} threads, "
+                  "owned Record per line (C++ restatement of the Rust decoders; the Rust build is unavailable)",
+    }, n_ok
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    from flowgger_amd import RFC5424Decoder, synth
+    from flowgger_amd.tables import DeviceTables
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the decode path has no CPU fallback")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    # ---- synthetic batch, resident in HBM -------------------------------------------------
+    sd = args.workload == "cfg4"
+    lines = synth.rfc5424_lines(args.tile_lines, cfg=4 if sd else 2, sd=sd)
+    data, offsets = synth.pack(lines)
+    n_tile, tile_bytes = len(lines), int(offsets[-1])
+    del lines
+    reps = args.reps
+    n = n_tile * reps
+    raw = torch.from_numpy(data[:tile_bytes]).to(dev)
+    d_bytes = torch.cat([raw.repeat(reps), torch.zeros(32, dtype=torch.uint8, device=dev)])
+    o = torch.from_numpy(offsets[:-1].astype(np.int64)).to(dev)
+    base = torch.arange(reps, device=dev, dtype=torch.int64).repeat_interleave(n_tile) * tile_bytes
+    d_offsets = torch.cat([o.repeat(reps) + base, torch.tensor([tile_bytes * reps], device=dev, dtype=torch.int64)])
+    del base, o, raw
+    ent_cap = (tile_bytes * reps // 10 if sd else 0) + 4096
+    tables = DeviceTables(n, ent_cap, dev)
+    dec = RFC5424Decoder(device=local)
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        dec.decode_device(d_bytes, d_offsets, tables, stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record(stream)
+        step()
+        b.record(stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    # ---- validity: every row was produced (status histogram of replica 0 == every replica) ----
+    meta = tables.column("meta").view(torch.int32).view(reps, n_tile)
+    status = meta & 0xFF
+    n_ok_tile = int((status[0] == 0).sum().item())
+    assert bool((status == status[0:1]).all()), "replicas disagree: work was skipped or corrupted"
+    used = int(tables.column("ent_used").view(torch.int64)[0].item())
+    assert used <= ent_cap, "entry table overflow"
+
+    if rank == 0:
+        alg_read = tile_bytes * reps + 8 * (n + 1)
+        alg_written = 68 * n + 18 * used
+        achieved = (alg_read + alg_written) / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "log lines/sec (RFC5424, 256B avg) at 1/2/4/8 MI355X; achieved HBM GB/s",
+            "value": n * world * args.steps / elapsed,
+            "unit": "lines/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {
+                "workload": ("BASELINE configs[1]: RFC5424 no structured data" if not sd else
+                             "BASELINE configs[3] shape: RFC5424 with structured data") +
+                            f", {n} lines/GPU @ {tile_bytes / n_tile:.0f} B avg ({n_tile}-line tile x{reps} resident in HBM), "
+                            "1% invalid lines",
+                "lines_per_gpu": n, "bytes_per_gpu": tile_bytes * reps,
+                "parallelism": f"lines sharded {world}-way, no data-path collective",
+                "ok_lines_per_tile": n_ok_tile,
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "kernel": "fg::k_rfc5424", "kernel_ms": kernel_ms,
+                "algorithmic_bytes_per_launch": alg_read + alg_written,
+                "read_only_frac": alg_read / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            },
+        }
+        tr = ROOT / "profiles" / "traffic.json"
+        if tr.exists():
+            try:
+                t = json.loads(tr.read_text()).get(args.workload)
+                if t:
+                    out["roofline"]["traffic"] = t["hbm_bytes_per_line"] * n
+            except Exception:
+                pass
+        if world == 1 and not args.no_cpu_baseline:
+            cb, n_ok_cpu = cpu_baseline(data, offsets, n_tile)
+            assert n_ok_cpu == n_ok_tile, f"GPU Ok count {n_ok_tile} != oracle Ok count {n_ok_cpu}"
+            out["cpu_baseline"] = cb
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

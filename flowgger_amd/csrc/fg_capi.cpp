@@ -307,7 +307,7 @@ int fg_decode_batch_device(fg_ctx* ctx, fg_format fmt, const uint8_t* d_bytes, u
     if (tables->n < n) return FG_ERR_ARG;
     if (tables->ent_cap > 0xFFFFFFFFull) return FG_ERR_ARG;
     DeviceGuard g(ctx->device);
-    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    hipStream_t s = stream == FG_STREAM_OWN ? ctx->stream : (hipStream_t)stream;
     fg::DevTables dt = to_dev(*tables);
     if (dt.ent_used) FG_HIP(ctx, hipMemsetAsync(dt.ent_used, 0, 8, s));
     if (n == 0) return FG_OK;
@@ -359,7 +359,7 @@ int fg_decode_batch(fg_ctx* ctx, fg_format fmt, const uint8_t* bytes, uint64_t n
         }
         fg_tables dt;
         carve(ctx->d_tab, n, ent_cap, &dt, nullptr);
-        rc = fg_decode_batch_device(ctx, fmt, ctx->d_bytes, nbytes, ctx->d_offsets, n, &dt, s);
+        rc = fg_decode_batch_device(ctx, fmt, ctx->d_bytes, nbytes, ctx->d_offsets, n, &dt, FG_STREAM_OWN);
         if (rc != FG_OK) return rc;
         uint64_t used = 0;
         FG_HIP(ctx, hipMemcpyAsync(&used, dt.ent_used, 8, hipMemcpyDeviceToHost, s));

@@ -123,6 +123,7 @@ typedef struct fg_cfg {
 } fg_cfg;
 
 typedef struct fg_ctx fg_ctx;
+#define FG_STREAM_OWN ((void*)(intptr_t)-1)
 
 int fg_abi_version(void);
 
@@ -147,7 +148,9 @@ int fg_tables_layout(uint64_t n, uint64_t ent_cap, uint64_t sizes[FG_TABLE_ARRAY
  *   d_bytes    packed lines; must be 16-byte aligned and readable up to nbytes rounded up to 16
  *   d_offsets  n+1 entries, offsets[0] >= 0, offsets[n] <= nbytes, non-decreasing
  *   tables     struct (host memory) of DEVICE array pointers, n rows, ent_cap entries
- *   stream     hipStream_t (NULL = the ctx's own stream); the call is asynchronous on it.
+ *   stream     a hipStream_t passed through verbatim (NULL = HIP's default/null stream, which is
+ *              what PyTorch's default current stream is), or FG_STREAM_OWN = the ctx's own
+ *              non-blocking stream; the call is asynchronous on it.
  * replaces: `for line { decoder.decode(line) }` (line_splitter.rs:17,50). */
 int fg_decode_batch_device(fg_ctx* ctx, fg_format fmt, const uint8_t* d_bytes, uint64_t nbytes,
                            const uint64_t* d_offsets, uint64_t n, const fg_tables* tables,

@@ -1,0 +1,124 @@
+"""CPU: the C-ABI library loads, exports every symbol include/fg_hip.h declares, refuses to run
+without a gfx950 GPU (no CPU fallback), and its pure-host entry points behave."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from flowgger_amd import _lib as L
+from flowgger_amd.record import DecodeError, parse_canonical
+from flowgger_amd.tables import HostTables, layout
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def declared_functions():
+    hdr = (ROOT / "include" / "fg_hip.h").read_text()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(fg_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = L.lib()
+    names = declared_functions()
+    assert len(names) >= 12
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in include/fg_hip.h but not exported"
+    assert lib.fg_abi_version() == 1
+
+
+def test_product_never_touches_the_oracle():
+    for p in list((ROOT / "flowgger_amd").rglob("*.py")) + list((ROOT / "flowgger_amd" / "csrc").glob("*")) + \
+            list((ROOT / "include").glob("*")):
+        if p.is_file() and p.suffix in (".py", ".cpp", ".hip", ".hpp", ".h"):
+            txt = p.read_text(errors="replace")
+            assert "fg_oracle" not in txt and "libfg_oracle" not in txt and "oracle_binding" not in txt, p
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    ctx = C.c_void_p()
+    assert L.lib().fg_create(0, None, C.byref(ctx)) == L.FG_ERR_NO_DEVICE
+    from flowgger_amd import RFC5424Decoder
+
+    with pytest.raises(L.FgError):
+        RFC5424Decoder()
+
+
+def test_error_strings_match_oracle_strings(oracle):
+    lib = L.lib()
+    # every reachable RFC5424 error of the synthetic invalid tail maps to a table entry
+    from flowgger_amd import synth
+
+    table = {lib.fg_error_string(0, i).decode() for i in range(1, 18)}
+    for line in synth.rfc5424_invalid_lines():
+        res = parse_canonical(oracle.decode(0, line))
+        assert isinstance(res, DecodeError) and str(res) in table, line
+    assert lib.fg_error_string(0, 0) == b"" and lib.fg_error_string(0, 200) is None
+    assert lib.fg_error_string(1, 9) == b"Unable to parse the English to Unix timestamp in LTSV decoder"
+    assert lib.fg_error_string(2, 12) == b"Missing hostname"
+
+
+def test_layout_and_shard_plan():
+    offs, total = layout(1000, 500)
+    assert [s for _, s in offs] == [4000, 8000] + [8000] * 6 + [4000, 4000, 4000, 4000, 500, 500, 8]
+    assert all(o % 256 == 0 for o, _ in offs) and total >= sum(s for _, s in offs)
+    lens = np.random.default_rng(1).integers(0, 700, 10000)
+    offsets = np.zeros(10001, np.uint64)
+    offsets[1:] = np.cumsum(lens)
+    for g in (1, 2, 3, 8):
+        starts = np.zeros(g + 1, np.uint64)
+        assert L.lib().fg_shard_plan(offsets.ctypes.data, 10000, g, starts.ctypes.data) == 0
+        assert starts[0] == 0 and starts[g] == 10000 and np.all(np.diff(starts.astype(np.int64)) >= 0)
+        per = np.diff(offsets[starts.astype(np.int64)].astype(np.int64))
+        assert per.max() - per.min() <= 2 * 700  # byte-balanced to within a line or two
+
+
+def _host_tables(n, ents):
+    offs, _ = layout(n, max(ents, 1))
+    dt = {"meta": np.uint32, "ts": np.float64, "ent_val": np.uint64, "ent_type": np.uint8, "ent_flags": np.uint8,
+          "ent_used": np.uint64}
+    arrays = {}
+    for name, (_, size) in zip(L.TABLE_FIELDS, offs):
+        d = np.dtype(dt.get(name, np.uint32))
+        arrays[name] = np.zeros(max(size // d.itemsize, 1), d)
+    return HostTables(n, max(ents, 1), arrays)
+
+
+def test_serialize_hand_built_rows(oracle):
+    """fg_tables_serialize on rows written by hand == the oracle's canonical bytes for the line."""
+    line = rb'<23>1 2015-08-05T15:53:45.637824Z testhostname appname 69 42 [origin@123 software="te\st sc\"ript" swVersion="0.0.1"] test message'
+    data = np.frombuffer(line, np.uint8).copy()
+    offsets = np.array([0, len(line)], np.uint64)
+    t = _host_tables(1, 3)
+    a = t.a
+    a["meta"][0] = 0 | (2 << 8) | (7 << 16)
+    a["ts"][0] = 1438790025.637824
+
+    def span(col, s):
+        o = line.index(s)
+        a[col].reshape(-1, 2)[0] = (o, len(s))
+
+    span("hostname", b"testhostname"); span("appname", b"appname"); span("procid", b"69"); span("msgid", b"42")
+    span("msg", b"test message")
+    a["full_msg"].reshape(-1, 2)[0] = (0, len(line))
+    a["ent_first"][0], a["ent_count"][0] = 0, 3
+    names = a["ent_name"].reshape(-1, 2)
+    for k, (nm, val, ty, fl) in enumerate([(b"origin@123", None, 6, 0), (b"software", rb'te\st sc\"ript', 0, 1),
+                                           (b"swVersion", b"0.0.1", 0, 0)]):
+        names[k] = (line.index(nm), len(nm))
+        if val is not None:
+            a["ent_val"][k] = line.index(val) | (len(val) << 32)
+        a["ent_type"][k], a["ent_flags"][k] = ty, fl
+    a["ent_used"][0] = 3
+    blob, offs = t.serialize(0, data, offsets)
+    assert blob.tobytes() == oracle.decode(0, line)
+    # an error row
+    a["meta"][0] = 13
+    blob, _ = t.serialize(0, data, offsets)
+    assert str(parse_canonical(blob.tobytes())) == "Missing log message"
