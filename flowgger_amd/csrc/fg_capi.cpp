@@ -119,12 +119,17 @@ fg::DevTables to_dev(const fg_tables& t) {
     return d;
 }
 
-// LDS tile per 64-line wave: room for 64 average lines + 25 % + one KiB, 4..64 KiB.
+// LDS tile per 64-line wave: room for 64 average lines + 12.5 % + 512 B, 4..56 KiB (the kernel
+// adds the space bitmap, 1/8 of the tile, on top).  FG_TILE_CAP overrides (bytes), for tuning.
 uint32_t pick_tile_cap(uint64_t nbytes, uint64_t n) {
+    if (const char* e = getenv("FG_TILE_CAP")) {
+        uint64_t v = strtoull(e, nullptr, 10);
+        if (v >= 1024 && v <= 57344) return (uint32_t)up(v, 1024);
+    }
     uint64_t avg = n ? (nbytes + n - 1) / n : 0;
-    uint64_t want = up(64 * avg * 5 / 4 + 1024, 1024);
+    uint64_t want = up(64 * avg * 9 / 8 + 512, 1024);
     if (want < 4096) want = 4096;
-    if (want > 65536) want = 65536;
+    if (want > 57344) want = 57344;
     return (uint32_t)want;
 }
 

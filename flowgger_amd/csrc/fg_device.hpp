@@ -257,7 +257,7 @@ __device__ __forceinline__ bool take_subsecond(R& rd, uint32_t& q, uint32_t len,
 // time::OffsetDateTime::parse(s, &Rfc3339) over rd[q..end): YYYY-MM-DD[Tt]HH:MM:SS[.d+]([Zz]|[+-]HH:MM),
 // whole [q,end) consumed.  (rfc5424_decoder.rs:94-99, ltsv_decoder.rs:224-229)
 template <class R>
-__device__ bool parse_rfc3339(R& rd, uint32_t q, uint32_t end, double* out) {
+__device__ __forceinline__ bool parse_rfc3339(R& rd, uint32_t q, uint32_t end, double* out) {
     DateTimeParts p;
     if (!take_digits(rd, q, end, 4, &p.year)) return false;
     if (q >= end || rd.byte(q) != '-') return false;
