@@ -16,8 +16,25 @@
 #include "../../include/fg_hip.h"
 #include "fg_device.hpp"
 
+namespace fg {
+// device view of input.ltsv_schema / input.ltsv_suffixes (must match fg_ltsv.hip)
+struct LtsvDevCfg {
+    uint32_t n_schema;
+    const uint8_t* blob;
+    const uint32_t* name_off;
+    const uint8_t* types;
+    uint32_t suf_off[4];
+    uint32_t suf_len[4];
+    uint32_t has_suf[4];
+};
+}  // namespace fg
+
 extern "C" int fg_launch_rfc5424(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n,
                                  const fg::DevTables* t, uint32_t tile_cap, hipStream_t stream);
+extern "C" int fg_launch_ltsv(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
+                              const fg::LtsvDevCfg* cfg, uint32_t tile_cap, hipStream_t stream);
+extern "C" int fg_launch_gelf(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
+                              uint32_t tile_cap, hipStream_t stream);
 
 struct fg_ctx {
     int device = 0;
@@ -31,6 +48,8 @@ struct fg_ctx {
     std::vector<uint8_t> schema_types;
     std::string suffix[4];
     bool has_suffix[4] = {false, false, false, false};
+    uint8_t* d_cfg = nullptr;  // device copy of the LTSV configuration (blob | name_off | types)
+    fg::LtsvDevCfg ltsv{};
     // staging for fg_decode_batch
     uint8_t* d_bytes = nullptr;
     uint64_t d_bytes_cap = 0;
@@ -121,15 +140,15 @@ fg::DevTables to_dev(const fg_tables& t) {
 
 // LDS tile per 64-line wave: room for 64 average lines + 12.5 % + 512 B, 4..56 KiB (the kernel
 // adds the space bitmap, 1/8 of the tile, on top).  FG_TILE_CAP overrides (bytes), for tuning.
-uint32_t pick_tile_cap(uint64_t nbytes, uint64_t n) {
+uint32_t pick_tile_cap(uint64_t nbytes, uint64_t n, uint64_t max_cap) {
     if (const char* e = getenv("FG_TILE_CAP")) {
         uint64_t v = strtoull(e, nullptr, 10);
-        if (v >= 1024 && v <= 57344) return (uint32_t)up(v, 1024);
+        if (v >= 1024 && v <= max_cap) return (uint32_t)up(v, 1024);
     }
     uint64_t avg = n ? (nbytes + n - 1) / n : 0;
     uint64_t want = up(64 * avg * 9 / 8 + 512, 1024);
     if (want < 4096) want = 4096;
-    if (want > 57344) want = 57344;
+    if (want > max_cap) want = max_cap;
     return (uint32_t)want;
 }
 
@@ -180,6 +199,37 @@ const char* const kErrGelf[] = {
     "Invalid value type in structured data",
     "Missing hostname",
 };
+
+// Upload the LTSV schema / suffixes once per ctx (LTSVDecoder::new, ltsv_decoder.rs:24-84).
+int upload_ltsv_cfg(fg_ctx* ctx) {
+    std::vector<uint8_t> blob;
+    std::vector<uint32_t> off;
+    for (const auto& nme : ctx->schema_names) {
+        off.push_back((uint32_t)blob.size());
+        blob.insert(blob.end(), nme.begin(), nme.end());
+    }
+    off.push_back((uint32_t)blob.size());
+    fg::LtsvDevCfg c{};
+    c.n_schema = (uint32_t)ctx->schema_names.size();
+    for (int k = 0; k < 4; ++k) {
+        c.suf_off[k] = (uint32_t)blob.size();
+        c.suf_len[k] = (uint32_t)ctx->suffix[k].size();
+        c.has_suf[k] = ctx->has_suffix[k] ? 1u : 0u;
+        blob.insert(blob.end(), ctx->suffix[k].begin(), ctx->suffix[k].end());
+    }
+    const uint64_t blob_sz = up(blob.size() + 1, 16), off_sz = up(off.size() * 4, 16), ty_sz = up(ctx->schema_types.size() + 1, 16);
+    FG_HIP(ctx, hipMalloc((void**)&ctx->d_cfg, blob_sz + off_sz + ty_sz));
+    std::vector<uint8_t> host(blob_sz + off_sz + ty_sz, 0);
+    if (!blob.empty()) memcpy(host.data(), blob.data(), blob.size());
+    memcpy(host.data() + blob_sz, off.data(), off.size() * 4);
+    if (!ctx->schema_types.empty()) memcpy(host.data() + blob_sz + off_sz, ctx->schema_types.data(), ctx->schema_types.size());
+    FG_HIP(ctx, hipMemcpy(ctx->d_cfg, host.data(), host.size(), hipMemcpyHostToDevice));
+    c.blob = ctx->d_cfg;
+    c.name_off = (const uint32_t*)(ctx->d_cfg + blob_sz);
+    c.types = ctx->d_cfg + blob_sz + off_sz;
+    ctx->ltsv = c;
+    return FG_OK;
+}
 
 int grow_dev(fg_ctx* ctx, void** p, uint64_t* cap, uint64_t need) {
     if (need <= *cap) return FG_OK;
@@ -242,6 +292,10 @@ int fg_create(int device, const fg_cfg* cfg, fg_ctx** out) {
         delete ctx;
         return FG_ERR_HIP;
     }
+    if (upload_ltsv_cfg(ctx) != FG_OK) {
+        fg_destroy(ctx);
+        return FG_ERR_HIP;
+    }
     *out = ctx;
     return FG_OK;
 }
@@ -262,6 +316,10 @@ int fg_clone(const fg_ctx* src, fg_ctx** out) {
         delete ctx;
         return FG_ERR_HIP;
     }
+    if (upload_ltsv_cfg(ctx) != FG_OK) {
+        fg_destroy(ctx);
+        return FG_ERR_HIP;
+    }
     *out = ctx;
     return FG_OK;
 }
@@ -275,6 +333,7 @@ void fg_destroy(fg_ctx* ctx) {
     if (ctx->d_bytes) (void)hipFree(ctx->d_bytes);
     if (ctx->d_offsets) (void)hipFree(ctx->d_offsets);
     if (ctx->d_tab) (void)hipFree(ctx->d_tab);
+    if (ctx->d_cfg) (void)hipFree(ctx->d_cfg);
     if (ctx->h_tab) (void)hipHostFree(ctx->h_tab);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -320,7 +379,13 @@ int fg_decode_batch_device(fg_ctx* ctx, fg_format fmt, const uint8_t* d_bytes, u
     int rc;
     switch (fmt) {
         case FG_RFC5424:
-            rc = fg_launch_rfc5424(d_bytes, d_offsets, n, &dt, pick_tile_cap(nbytes, n), s);
+            rc = fg_launch_rfc5424(d_bytes, d_offsets, n, &dt, pick_tile_cap(nbytes, n, 57344), s);
+            break;
+        case FG_LTSV:
+            rc = fg_launch_ltsv(d_bytes, d_offsets, n, &dt, &ctx->ltsv, pick_tile_cap(nbytes, n, 63488), s);
+            break;
+        case FG_GELF:
+            rc = fg_launch_gelf(d_bytes, d_offsets, n, &dt, pick_tile_cap(nbytes, n, 52224), s);
             break;
         default:
             return FG_ERR_UNSUPPORTED;

@@ -300,6 +300,28 @@ __device__ __forceinline__ bool parse_rfc3339(R& rd, uint32_t q, uint32_t end, d
     return datetime_to_unix(p, true, out);
 }
 
+// Stream [a0, a0+span) of the packed buffer into the wave's LDS tile: 16 B per lane, 1 KiB per
+// wave-instruction, 8 loads in flight per lane (a0 and span are multiples of 16).
+__device__ __forceinline__ void stage_tile(const uint8_t* __restrict__ bytes, uint64_t a0, uint32_t span, uint8_t* smem) {
+    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(bytes + a0);
+    uint4* dst = reinterpret_cast<uint4*>(smem);
+    const uint32_t nchunk = span >> 4;
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t c0 = 0; c0 < nchunk; c0 += kWave * 8) {
+        uint4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            uint32_t idx = c0 + k * kWave + lane;
+            if (idx < nchunk) v[k] = src[idx];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            uint32_t idx = c0 + k * kWave + lane;
+            if (idx < nchunk) dst[idx] = v[k];
+        }
+    }
+}
+
 // wave-wide exclusive prefix sum of a 32-bit value; *total receives the wave sum.
 __device__ __forceinline__ uint32_t wave_exclusive_sum(uint32_t v, uint32_t* total) {
     uint32_t lane = __lane_id();

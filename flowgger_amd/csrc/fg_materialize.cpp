@@ -58,7 +58,7 @@ void push_utf8(std::string* s, uint32_t c) {
     }
 }
 // JSON escapes of an already-validated string body (the kernel rejected malformed ones).
-void json_unescape(const uint8_t* p, uint32_t len, std::string* out) {
+void json_unescape(const uint8_t* p, uint32_t len, std::string* out, bool retry = false) {
     out->clear();
     for (uint32_t i = 0; i < len;) {
         uint8_t c = p[i];
@@ -69,6 +69,11 @@ void json_unescape(const uint8_t* p, uint32_t len, std::string* out) {
         }
         uint8_t e = p[i + 1];
         i += 2;
+        if (retry && e == '\n') {  // the reference replaced LF by "\\n": escaped backslash, then 'n'
+            out->push_back('\\');
+            out->push_back('n');
+            continue;
+        }
         switch (e) {
             case 'b': out->push_back('\x08'); break;
             case 'f': out->push_back('\x0c'); break;
@@ -150,7 +155,7 @@ extern "C" int64_t fg_tables_serialize(fg_format fmt, const fg_cfg* cfg, const u
             }
             k.u8(1);
             if (fmt == FG_GELF && (flags & esc_flag[c])) {
-                json_unescape(line + s.off, s.len, &tmp);
+                json_unescape(line + s.off, s.len, &tmp, (flags & FG_F_GELF_RETRY) != 0);
                 k.u32((uint32_t)tmp.size());
                 k.put(tmp.data(), tmp.size());
             } else {
@@ -194,7 +199,7 @@ extern "C" int64_t fg_tables_serialize(fg_format fmt, const fg_cfg* cfg, const u
             uint32_t nl = nm.len;
             std::string key;
             if (ef & FG_EF_NAME_ESC) {
-                json_unescape(np, nl, &tmp);
+                json_unescape(np, nl, &tmp, (flags & FG_F_GELF_RETRY) != 0);
                 key = tmp;
             } else {
                 key.assign((const char*)np, nl);
@@ -210,7 +215,7 @@ extern "C" int64_t fg_tables_serialize(fg_format fmt, const fg_cfg* cfg, const u
                     const uint32_t vo = (uint32_t)v, vl = (uint32_t)(v >> 32);
                     if (ef & FG_EF_VAL_ESC) {
                         if (fmt == FG_RFC5424) sd_unescape(line + vo, vl, &tmp);
-                        else json_unescape(line + vo, vl, &tmp);
+                        else json_unescape(line + vo, vl, &tmp, (flags & FG_F_GELF_RETRY) != 0);
                         k.u32((uint32_t)tmp.size());
                         k.put(tmp.data(), tmp.size());
                     } else {

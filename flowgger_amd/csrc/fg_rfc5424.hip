@@ -21,6 +21,8 @@
 // Fixed-width results go to struct-of-array tables (one coalesced store per column);
 // structured-data entries get their slots from ONE wave-aggregated atomic (count pass -> wave
 // prefix sum -> fill pass, both out of LDS).
+#include <cstdlib>
+
 #include "fg_device.hpp"
 
 namespace fg {
@@ -571,6 +573,7 @@ __device__ __forceinline__ bool parse_line_fast(const Tile& T, uint32_t base, ui
 }
 
 // One wave per 64-line group.  Dynamic LDS: [tile_cap + 64 bytes of data][bitmap: 2 B per 16 B].
+template <int BATCH>
 __global__ __launch_bounds__(kWave) void k_rfc5424(const uint8_t* __restrict__ bytes,
                                                   const uint64_t* __restrict__ offsets, uint64_t n,
                                                   DevTables t, uint32_t tile_cap) {
@@ -594,15 +597,15 @@ __global__ __launch_bounds__(kWave) void k_rfc5424(const uint8_t* __restrict__ b
         const uint4* __restrict__ src = reinterpret_cast<const uint4*>(bytes + a0);
         uint4* dst = reinterpret_cast<uint4*>(smem);
         const uint32_t nchunk = span >> 4;
-        for (uint32_t c0 = 0; c0 < nchunk; c0 += kWave * 16) {
-            uint4 v[16];
+        for (uint32_t c0 = 0; c0 < nchunk; c0 += kWave * BATCH) {
+            uint4 v[BATCH];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
+            for (int k = 0; k < BATCH; ++k) {
                 uint32_t idx = c0 + k * kWave + lane;
                 if (idx < nchunk) v[k] = src[idx];
             }
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
+            for (int k = 0; k < BATCH; ++k) {
                 uint32_t idx = c0 + k * kWave + lane;
                 if (idx < nchunk) {
                     dst[idx] = v[k];
@@ -693,7 +696,18 @@ extern "C" int fg_launch_rfc5424(const uint8_t* d_bytes, const uint64_t* d_offse
     uint64_t groups = (n + fg::kWave - 1) / fg::kWave;
     if (groups > 0x7FFFFFFFull) return -1;
     uint32_t lds = tile_cap + 64u + (tile_cap / 16u + 16u) * 2u;
-    hipLaunchKernelGGL(fg::k_rfc5424, dim3((uint32_t)groups), dim3(fg::kWave), lds, stream, d_bytes, d_offsets, n,
-                       *t, tile_cap);
+    // loads in flight per lane during stage A (tuning knob; 16 B each)
+    static int batch = [] {
+        const char* e = getenv("FG_BATCH");
+        return e ? atoi(e) : 8;
+    }();
+    dim3 grid((uint32_t)groups), block(fg::kWave);
+    switch (batch) {
+        case 4: hipLaunchKernelGGL(fg::k_rfc5424<4>, grid, block, lds, stream, d_bytes, d_offsets, n, *t, tile_cap); break;
+        case 12: hipLaunchKernelGGL(fg::k_rfc5424<12>, grid, block, lds, stream, d_bytes, d_offsets, n, *t, tile_cap); break;
+        case 16: hipLaunchKernelGGL(fg::k_rfc5424<16>, grid, block, lds, stream, d_bytes, d_offsets, n, *t, tile_cap); break;
+        case 20: hipLaunchKernelGGL(fg::k_rfc5424<20>, grid, block, lds, stream, d_bytes, d_offsets, n, *t, tile_cap); break;
+        default: hipLaunchKernelGGL(fg::k_rfc5424<8>, grid, block, lds, stream, d_bytes, d_offsets, n, *t, tile_cap); break;
+    }
     return (int)hipGetLastError();
 }

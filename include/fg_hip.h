@@ -68,7 +68,9 @@ enum {
     FG_F_HOST_ESC = 2,      /* GELF: hostname span holds JSON escapes (decode when materialising) */
     FG_F_MSG_ESC = 4,       /* GELF: short_message span holds JSON escapes */
     FG_F_FULLMSG_ESC = 8,   /* GELF: full_message span holds JSON escapes */
-    FG_F_BOM = 16           /* RFC5424: line started with U+FEFF (spans already skip it) */
+    FG_F_BOM = 16,          /* RFC5424: line started with U+FEFF (spans already skip it) */
+    FG_F_GELF_RETRY = 32    /* GELF: accepted via the '\n' -> "\\n" retry (gelf_decoder.rs:44-46); when decoding
+                               escapes a backslash followed by a raw LF means backslash + 'n' */
 };
 #define FG_ST_OVERFLOW 0xFE /* status: the line's entries did not fit in ent_cap (re-run with more) */
 

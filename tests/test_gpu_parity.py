@@ -180,3 +180,141 @@ def test_full_size_replicas_are_identical(rfc, oracle):
     oblob, ooffs = oracle.decode_batch(RFC5424, data, offsets)
     blob, offs = tables.to_host().serialize(RFC5424, data, offsets, 0, n)
     assert_same(blob, offs, oblob, ooffs, lines)
+
+
+# ------------------------------------------------------------------------------------- LTSV
+def test_ltsv_corpus_matches_oracle(oracle):
+    dec = LTSVDecoder(synth.LTSV_CONFIG)
+    lines = synth.ltsv_lines(60_000)
+    data, offsets = synth.pack(lines)
+    oblob, ooffs = oracle.decode_batch(LTSV, data, offsets, synth.LTSV_CONFIG)
+    (blob, offs), tab = host_path_blob(dec, data, offsets)
+    assert_same(blob, offs, oblob, ooffs, lines)
+    assert set(np.unique(tab.status).tolist()) == set(range(0, 10))
+    both_paths(dec, oracle, synth.ltsv_lines(5000, long_tail=True), synth.LTSV_CONFIG)
+
+
+def test_ltsv_semantics(oracle):
+    cfg = {"input": {"ltsv_schema": {"n": "u64", "b": "bool", "f": "f64", "i": "i64", "s": "string", "x_f64": "F64"},
+                     "ltsv_suffixes": {"f64": "_f64", "bool": "", "i64": "_i"}}}
+    dec = LTSVDecoder(cfg)
+    lines = [
+        "time:1\thost:h\tnovalue\t\t_x:y\tn:7", "host:h", "time:1", "time:x\thost:h", "time:1\thost:h\tlevel:8",
+        "time:1\thost:h\tlevel:x", "time:1\thost:h\tb:True", "time:1\thost:h\tf:x", "time:1\thost:h\ti:1.0",
+        "time:1\thost:h\tn:-1", "level:9\ttime:x", "time:[1]\thost:h", "time:nan\thost:h", "time:-inf\thost:h",
+        "time:1\ttime:2\thost:a\thost:b", "", "\t\t", ":", "time:1\thost:", "time:[]\thost:h", "time:[\thost:h",
+        "time:1\thost:h\tf:1e400\tf:-0\tf:.5\tf:5.\tf:+1E-3\tf:0x1", "time:1\thost:h\tx_f64:2.5\tf:2.5\ti:-9223372036854775808",
+        "time:1\thost:h\ti:9223372036854775808", "time:1\thost:h\tn:18446744073709551615\tn:18446744073709551616",
+        "time:1\thost:h\tb:false\tb:true\ts:str\tunknown:v\ta:b:c\tlevel:+007",
+        "time:[2015-08-05T15:53:45.637824+01:30]\thost:h", "time:[10/Oct/2000:13:55:36 -0700]\thost:h",
+        "time:10/Oct/2000:13:55:36.123456789123 +0530\thost:h", "time:[31/Feb/2000:13:55:36 -0700]\thost:h",
+        "time:[10/oct/2000:13:55:36 -0700]\thost:h", "time:[10/Oct/2000:13:55:60 -0700]\thost:h",
+        "time:[1/Jan/+2000:00:00:00 +0000]\thost:h", "time:[01/Jan/-0001:00:00:00 -0030]\thost:h",
+        "time:1438790025.99\thost:h", "time:1.7976931348623159e308\thost:h", "time:9007199254740993\thost:h",
+        "time:0.1000000000000000055511151231257827021181583404541015625\thost:h",
+        "time:123456789012345678901234567890e-10\thost:h",
+        "time:2.47032822920623272088284396434110686182529901307162382212792841250337753635104375932649918180817996189"
+        "898282347722858865463328355177969898199387398005390939063150356595155702263922908583924491051844359318028499"
+        "365361525003193704576782492193656236698636584807570015857692699037063119282795585513329278343384093519780155"
+        "312465972635795746227664652728272200563740064854999770965994704540208281662262378573934507363390079677619305"
+        "775067401763246736009689513405355374585166611342237666786041621596804619144672918403005300575308490487653917"
+        "113865916462395249126236538818796362393732804238910186723484976682350898633885879256283027559956575244555072"
+        "551893136908362547791869486679949683240497058210285131854513962138377228261454376934125320985913276672363281"
+        "25e-324\thost:h",
+    ]
+    both_paths(dec, oracle, lines, cfg)
+    r = dec.decode("time:1\thost:h\tx_f64:2.5\tf:2.5\tb:true\ti:3")
+    assert [(k, v.kind) for k, v in r.sd[0].pairs] == [("_x_f64", "F64"), ("_f_f64", "F64"), ("_b", "Bool"), ("_i_i", "I64")]
+
+
+def test_ltsv_f64_rounding_fuzz(oracle):
+    """Typed f64 values through all three dec2flt stages on the GPU (incl. forced Decimal path)."""
+    from decimal import Decimal, getcontext
+    from fractions import Fraction
+    import struct
+
+    getcontext().prec = 1200
+    rng = np.random.default_rng(17)
+    cfg = {"input": {"ltsv_schema": {"f": "f64"}}}
+    dec = LTSVDecoder(cfg)
+    lines = []
+    for i in range(4000):
+        e = int(rng.integers(1, 2046)) if i % 10 else 0
+        m = int(rng.integers(0, 1 << 52))
+        x = struct.unpack("<d", struct.pack("<Q", (e << 52) | m))[0]
+        y = struct.unpack("<d", struct.pack("<Q", ((e << 52) | m) + 1))[0]
+        if y == float("inf"):
+            continue
+        mid = (Fraction(x) + Fraction(y)) / 2
+        d = Decimal(mid.numerator) / Decimal(mid.denominator)
+        s = format(d, "e")
+        nd = int(rng.integers(1, 40))
+        rnd = "".join(str(int(v)) for v in rng.integers(0, 10, nd)) + "e" + str(int(rng.integers(-340, 310)))
+        lines.append(f"time:{s}\thost:h\tf:{s.replace('e', '1e')}\tf:{rnd}\tf:{repr(x)}")
+    both_paths(dec, oracle, lines, cfg)
+
+
+# ------------------------------------------------------------------------------------- GELF
+def test_gelf_corpus_matches_oracle(oracle):
+    dec = GelfDecoder()
+    lines = synth.gelf_lines(60_000)
+    data, offsets = synth.pack(lines)
+    oblob, ooffs = oracle.decode_batch(GELF, data, offsets)
+    (blob, offs), tab = host_path_blob(dec, data, offsets)
+    assert_same(blob, offs, oblob, ooffs, lines)
+    assert len(set(np.unique(tab.status).tolist())) >= 10
+
+
+def test_gelf_semantics(oracle):
+    dec = GelfDecoder()
+    many = "{" + ",".join(f'"k{(i * 7919) % 100:03d}":{i}' for i in range(100)) + ',"host":"h"}'
+    deep_ok = '{"host":"h","a":' + "[" * 510 + "]" * 510 + "}"
+    deep_bad = '{"host":"h","a":' + "[" * 512 + "]" * 512 + "}"
+    lines = [
+        '{"host":"h","b":1,"a":2,"_c":null,"B":true,"a":-3}', "[1,2]", '{"host":"h"} x', '{"a":1}', '{"host":1}',
+        '{"host":"h","level":-1}', '{"host":"h","level":1.0}', '{"host":"h","version":1}', '{"host":"h","short_message":1}',
+        '{"host":"h","full_message":null}', '{"host":"h","x":{"y":1}}', '{"host":"h\\u00e9\\n\\ud83d\\ude00","timestamp":1}',
+        '{"host":"a\nb","timestamp":1}', '{"host":"a\tb"}', '{"host":1,"_x":[]}', "", " ", "null", "true", '"str"', "12", "-",
+        "{}", "{ }", '{"host":"h",}', '{,"host":"h"}', '{"host" "h"}', '{"host":"h"', '{"host":"h"}}', "[", "[1,]", "[,1]",
+        '{"host":"h","a":[1,{"b":[true,false,null,"x",-1.5e3]}],"c":1}', '{"host":"h","a":[1 2]}', '{"host":"h","a":{"b":1,}}',
+        '{"host":"h","a":tru}', '{"host":"h","a":nul}', '{"host":"h","a":falsE}', '{"host":"h","a":01}', '{"host":"h","a":1.}',
+        '{"host":"h","a":-}', '{"host":"h","a":1e}', '{"host":"h","a":1e999}', '{"host":"h","a":-1e999}', '{"host":"h","a":1e-999}',
+        '{"host":"h","a":18446744073709551615,"b":18446744073709551616,"c":-9223372036854775808,"d":-9223372036854775809}',
+        '{"host":"h","a":0.1,"b":1385053862.3072,"c":123456789012345678901234567890.5e-5,"d":-0,"e":-0.0,"f":1E+2}',
+        '{"host":"h","timestamp":-5}', '{"host":"h","timestamp":18446744073709551615}', '{"host":"h","timestamp":true}',
+        '{"h\\u006fst":"escaped key","_a\\"b":"q","_a\\u0022b":"dup wins","a\\\\b":1,"a\\/b":2,"a\\tb":3}',
+        '{"host":"h","s":"\\ud83d"}', '{"host":"h","s":"\\ud83d\\u0041"}', '{"host":"h","s":"\\udc00"}', '{"host":"h","s":"\\u12g4"}',
+        '{"host":"h","s":"\\x"}', '{"host":"h","s":"abc', '{"host":"h","s":"\\', '{"host":"h","s":"\\u00"}', '{"host":"h","s":"\\u0000"}',
+        '{"host":"h","version":"1.0"}', '{"host":"h","version":"1.\\u0031"}', '{"host":"h","version":"1.2"}', '{"host":"h","level":7}',
+        '{"host":"h","level":8}', '{"host":"h","level":"1"}', '{"_":1,"__":2,"":3,"host":"h"}',
+        '{"host":"line1\nline2\nline3","short_message":"with\nnewline","_k\ney":"v"}',  # retry accepted
+        '{"host":"a\nb",\n"x":1}',  # retry turns the structural newline into a syntax error
+        '{"host":"a\\\nb"}',  # backslash + raw LF: escaped backslash then n (retry)
+        '{"host":"a\nb\\\nc","k\\\n":"v\\\n"}', '{"host":"a\nb","s":"\\ud83d\n\\ude00"}', '{"host":"a\rb"}', '{"host":"a\x00b"}',
+        '\n{"host":"h"}\n', '{"host":"h","a":"x\x7fy"}', '{"host":"h","a":"caf\u00e9 \u4e2d\u6587 \U0001F600"}',
+        many, deep_ok, deep_bad, '{"host":"h","big":' + "9" * 400 + "}", '{"host":"h","big":0.' + "9" * 400 + "}",
+        '{"host":"h","e":1e2147483648}', '{"host":"h","e":0e2147483648}', '{"host":"h","e":1e-2147483649}',
+        '{"zz":[],"host":5}', '{"timestamp":"x","level":99,"host":"h"}', '{"version":"9","timestamp":"x","host":"h"}',
+    ]
+    both_paths(dec, oracle, lines)
+    r = dec.decode('{"host":"h","b":1,"a":2,"_c":null,"B":true,"a":-3}')
+    assert [(k, v.kind, v.value) for k, v in r.sd[0].pairs] == [
+        ("_B", "Bool", True), ("_c", "Null", None), ("_a", "I64", -3), ("_b", "U64", 1)]
+
+
+def test_gelf_fuzz_mutations_match_oracle(oracle):
+    dec = GelfDecoder()
+    rng = np.random.default_rng(808)
+    base = synth.gelf_lines(6000, invalid_frac=0)
+    alphabet = [b'"', b"\\", b",", b":", b"{", b"}", b"[", b"]", b" ", b"\n", b"\t", b"0", b"-", b".", b"e", b"u", b"n",
+                b"true", b"null", b"", b"\\u00e9", b"\\n", "é".encode(), b"\x01", b"_"]
+    lines = []
+    for ln in base:
+        b = bytearray(ln)
+        for _ in range(int(rng.integers(1, 4))):
+            pos = int(rng.integers(0, len(b)))
+            if b[pos] >= 0x80:
+                continue
+            b[pos:pos + 1] = alphabet[int(rng.integers(0, len(alphabet)))]
+        lines.append(bytes(b))
+    both_paths(dec, oracle, lines)
