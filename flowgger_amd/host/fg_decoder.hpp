@@ -1,0 +1,353 @@
+// fg_decoder.hpp -- C++ host-side mirror of flowgger's Decoder trait, Record model and line
+// splitters on top of the C ABI (include/fg_hip.h).  Header-only; link with -lfg_hip -lamdhip64.
+//
+// Reference interface mirrored (paths relative to the flowgger source tree):
+//   trait Decoder { fn decode(&self, &str) -> Result<Record,&'static str> }   decoder/mod.rs:44-46
+//   CloneBoxedDecoder::clone_boxed                                            decoder/mod.rs:23-36
+//   Record / StructuredData / SDValue                                         record.rs:3-82
+//   LineSplitter / NulSplitter / SyslenSplitter ::run                         splitter/*_splitter.rs
+// New: decode_batch() -- N framed lines, ONE call into the gfx950 kernels.  There is no CPU decode
+// path in here: construction throws std::runtime_error when no gfx950 device is usable.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <istream>
+#include <memory>
+#include <optional>
+#include <ostream>
+#include <stdexcept>
+#include <string>
+#include <string_view>
+#include <utility>
+#include <vector>
+
+#include "../../include/fg_hip.h"
+
+namespace fg {
+
+struct SDValue {  // record.rs:3-11
+    enum Kind : uint8_t { String = 0, Bool = 1, F64 = 2, I64 = 3, U64 = 4, Null = 5 } kind = Null;
+    std::string s;
+    uint64_t bits = 0;  // Bool 0/1, F64 IEEE bits, I64 two's complement, U64
+};
+struct StructuredData {  // record.rs:23-27
+    std::optional<std::string> sd_id;
+    std::vector<std::pair<std::string, SDValue>> pairs;
+};
+struct Record {  // record.rs:70-82
+    double ts = 0.0;
+    bool ts_now = false;  // GELF without "timestamp": caller substitutes the wall clock (gelf_decoder.rs:109)
+    std::string hostname;
+    std::optional<uint8_t> facility, severity;
+    std::optional<std::string> appname, procid, msgid, msg, full_msg;
+    std::optional<std::vector<StructuredData>> sd;
+};
+// Result<Record, &'static str>
+struct DecodeResult {
+    const char* err = nullptr;  // points into libfg_hip's static error table
+    Record record;
+    bool ok() const { return err == nullptr; }
+};
+
+struct LtsvConfig {  // input.ltsv_schema / input.ltsv_suffixes (ltsv_decoder.rs:24-84)
+    std::vector<std::pair<std::string, uint8_t>> schema;  // name -> FG_T_STRING..FG_T_U64
+    std::optional<std::string> suffix_bool, suffix_f64, suffix_i64, suffix_u64;
+};
+
+namespace detail {
+struct Cursor {
+    const uint8_t* p;
+    uint8_t u8() { return *p++; }
+    uint32_t u32() { uint32_t v; memcpy(&v, p, 4); p += 4; return v; }
+    uint64_t u64() { uint64_t v; memcpy(&v, p, 8); p += 8; return v; }
+    std::string str() { uint32_t n = u32(); std::string s((const char*)p, n); p += n; return s; }
+    std::optional<std::string> optstr() { if (!u8()) return std::nullopt; return str(); }
+};
+// canonical serialisation -> Record
+inline DecodeResult from_canonical(const uint8_t* b, fg_format fmt, uint8_t status) {
+    DecodeResult r;
+    Cursor c{b};
+    if (c.u8() == 1) {
+        r.err = fg_error_string(fmt, status);
+        if (!r.err) r.err = "<libfg_hip: internal status>";
+        return r;
+    }
+    r.record.ts_now = c.u8() != 0;
+    uint64_t tb = c.u64();
+    memcpy(&r.record.ts, &tb, 8);
+    uint8_t fac = c.u8(), sev = c.u8();
+    if (fac != 0xFF) r.record.facility = fac;
+    if (sev != 0xFF) r.record.severity = sev;
+    r.record.hostname = c.optstr().value_or("");
+    r.record.appname = c.optstr();
+    r.record.procid = c.optstr();
+    r.record.msgid = c.optstr();
+    r.record.msg = c.optstr();
+    r.record.full_msg = c.optstr();
+    if (c.u8()) {
+        std::vector<StructuredData> v(c.u32());
+        for (auto& sd : v) {
+            sd.sd_id = c.optstr();
+            sd.pairs.resize(c.u32());
+            for (auto& kv : sd.pairs) {
+                kv.first = c.str();
+                kv.second.kind = (SDValue::Kind)c.u8();
+                switch (kv.second.kind) {
+                    case SDValue::String: kv.second.s = c.str(); break;
+                    case SDValue::Bool: kv.second.bits = c.u8(); break;
+                    case SDValue::Null: break;
+                    default: kv.second.bits = c.u64();
+                }
+            }
+        }
+        r.record.sd = std::move(v);
+    }
+    return r;
+}
+}  // namespace detail
+
+// Record -> canonical serialisation (used by tests to compare with the oracle byte for byte)
+inline std::string to_canonical(const DecodeResult& r) {
+    std::string o;
+    auto u8 = [&](uint8_t v) { o.push_back((char)v); };
+    auto u32 = [&](uint32_t v) { o.append((const char*)&v, 4); };
+    auto u64 = [&](uint64_t v) { o.append((const char*)&v, 8); };
+    auto str = [&](const std::string& s) { u32((uint32_t)s.size()); o += s; };
+    auto opt = [&](const std::optional<std::string>& s) { if (!s) { u8(0); return; } u8(1); str(*s); };
+    if (!r.ok()) { u8(1); str(r.err); return o; }
+    const Record& x = r.record;
+    u8(0); u8(x.ts_now ? 1 : 0);
+    uint64_t tb = 0;
+    if (!x.ts_now) memcpy(&tb, &x.ts, 8);
+    u64(tb);
+    u8(x.facility.value_or(0xFF)); u8(x.severity.value_or(0xFF));
+    u8(1); str(x.hostname);
+    opt(x.appname); opt(x.procid); opt(x.msgid); opt(x.msg); opt(x.full_msg);
+    if (!x.sd) { u8(0); return o; }
+    u8(1); u32((uint32_t)x.sd->size());
+    for (const auto& sd : *x.sd) {
+        opt(sd.sd_id);
+        u32((uint32_t)sd.pairs.size());
+        for (const auto& kv : sd.pairs) {
+            str(kv.first); u8(kv.second.kind);
+            switch (kv.second.kind) {
+                case SDValue::String: str(kv.second.s); break;
+                case SDValue::Bool: u8((uint8_t)kv.second.bits); break;
+                case SDValue::Null: break;
+                default: u64(kv.second.bits);
+            }
+        }
+    }
+    return o;
+}
+
+class Decoder {
+  public:
+    virtual ~Decoder() { if (ctx_) fg_destroy(ctx_); }
+    Decoder(const Decoder&) = delete;
+    Decoder& operator=(const Decoder&) = delete;
+
+    // the reference's trait method
+    DecodeResult decode(std::string_view line) const {
+        uint64_t offs[2] = {0, line.size()};
+        return std::move(decode_batch((const uint8_t*)line.data(), line.size(), offs, 1)[0]);
+    }
+    // N framed lines packed back to back; line i = bytes[offsets[i] .. offsets[i+1])
+    std::vector<DecodeResult> decode_batch(const uint8_t* bytes, uint64_t nbytes, const uint64_t* offsets, uint64_t n) const {
+        fg_tables t{};
+        int rc = fg_decode_batch(ctx_, fmt_, bytes, nbytes, offsets, n, &t);
+        if (rc != FG_OK) throw std::runtime_error("fg_decode_batch failed: " + std::to_string(rc));
+        std::vector<uint64_t> offs(n + 1);
+        int64_t total = fg_tables_serialize(fmt_, cfgp(), bytes, offsets, &t, 0, n, nullptr, 0, offs.data());
+        if (total < 0) throw std::runtime_error("fg_tables_serialize failed");
+        std::vector<uint8_t> blob((size_t)total + 1);
+        fg_tables_serialize(fmt_, cfgp(), bytes, offsets, &t, 0, n, blob.data(), (uint64_t)total, offs.data());
+        std::vector<DecodeResult> out;
+        out.reserve(n);
+        for (uint64_t i = 0; i < n; ++i) out.push_back(detail::from_canonical(blob.data() + offs[i], fmt_, FG_META_STATUS(t.meta[i])));
+        return out;
+    }
+    virtual std::unique_ptr<Decoder> clone_boxed() const = 0;  // decoder/mod.rs:29-36
+    fg_ctx* ctx() const { return ctx_; }
+    fg_format format() const { return fmt_; }
+
+  protected:
+    Decoder(fg_format fmt, int device, const LtsvConfig* cfg) : fmt_(fmt) {
+        if (cfg) set_cfg(*cfg);
+        int rc = fg_create(device, cfgp(), &ctx_);
+        if (rc != FG_OK) throw std::runtime_error(rc == FG_ERR_NO_DEVICE ? "libfg_hip: no gfx950 GPU (there is no CPU fallback)"
+                                                                         : "fg_create failed: " + std::to_string(rc));
+    }
+    Decoder(const Decoder& o, int /*clone*/) : fmt_(o.fmt_), lcfg_(o.lcfg_) {
+        if (o.has_cfg_) set_cfg(lcfg_);
+        if (fg_clone(o.ctx_, &ctx_) != FG_OK) throw std::runtime_error("fg_clone failed");
+    }
+    const fg_cfg* cfgp() const { return has_cfg_ ? &cfg_ : nullptr; }
+    void set_cfg(const LtsvConfig& c) {
+        lcfg_ = c;
+        names_.clear();
+        types_.clear();
+        for (auto& kv : lcfg_.schema) { names_.push_back(kv.first.c_str()); types_.push_back(kv.second); }
+        cfg_.n_schema = (uint32_t)names_.size();
+        cfg_.schema_names = names_.data();
+        cfg_.schema_types = types_.data();
+        cfg_.suffix_bool = lcfg_.suffix_bool ? lcfg_.suffix_bool->c_str() : nullptr;
+        cfg_.suffix_f64 = lcfg_.suffix_f64 ? lcfg_.suffix_f64->c_str() : nullptr;
+        cfg_.suffix_i64 = lcfg_.suffix_i64 ? lcfg_.suffix_i64->c_str() : nullptr;
+        cfg_.suffix_u64 = lcfg_.suffix_u64 ? lcfg_.suffix_u64->c_str() : nullptr;
+        has_cfg_ = true;
+    }
+    fg_format fmt_;
+    fg_ctx* ctx_ = nullptr;
+    LtsvConfig lcfg_;
+    std::vector<const char*> names_;
+    std::vector<uint8_t> types_;
+    fg_cfg cfg_{};
+    bool has_cfg_ = false;
+};
+
+class RFC5424Decoder : public Decoder {  // decoder/rfc5424_decoder.rs:8-50
+  public:
+    explicit RFC5424Decoder(int device = 0) : Decoder(FG_RFC5424, device, nullptr) {}
+    std::unique_ptr<Decoder> clone_boxed() const override { return std::unique_ptr<Decoder>(new RFC5424Decoder(*this, 0)); }
+  private:
+    RFC5424Decoder(const RFC5424Decoder& o, int) : Decoder(o, 0) {}
+};
+class GelfDecoder : public Decoder {  // decoder/gelf_decoder.rs:10-125
+  public:
+    explicit GelfDecoder(int device = 0) : Decoder(FG_GELF, device, nullptr) {}
+    std::unique_ptr<Decoder> clone_boxed() const override { return std::unique_ptr<Decoder>(new GelfDecoder(*this, 0)); }
+  private:
+    GelfDecoder(const GelfDecoder& o, int) : Decoder(o, 0) {}
+};
+class LTSVDecoder : public Decoder {  // decoder/ltsv_decoder.rs:17-221
+  public:
+    explicit LTSVDecoder(const LtsvConfig& cfg, int device = 0) : Decoder(FG_LTSV, device, &cfg) {}
+    std::unique_ptr<Decoder> clone_boxed() const override { return std::unique_ptr<Decoder>(new LTSVDecoder(*this, 0)); }
+  private:
+    LTSVDecoder(const LTSVDecoder& o, int) : Decoder(o, 0) {}
+};
+
+// ---------------------------------------------------------------------------------------------
+// Batching framers: same framing and error reporting as the reference splitters, one
+// decode_batch per `max_lines` / `max_bytes` instead of one decode per line.
+// ---------------------------------------------------------------------------------------------
+namespace detail {
+inline bool valid_utf8(const uint8_t* s, size_t n) {  // std::str::from_utf8
+    size_t i = 0;
+    while (i < n) {
+        uint8_t c = s[i];
+        if (c < 0x80) { ++i; continue; }
+        size_t len; uint32_t cp;
+        if (c >= 0xC2 && c <= 0xDF) { len = 2; cp = c & 0x1F; }
+        else if (c >= 0xE0 && c <= 0xEF) { len = 3; cp = c & 0x0F; }
+        else if (c >= 0xF0 && c <= 0xF4) { len = 4; cp = c & 0x07; }
+        else return false;
+        if (i + len > n) return false;
+        for (size_t k = 1; k < len; ++k) { if ((s[i + k] & 0xC0) != 0x80) return false; cp = (cp << 6) | (s[i + k] & 0x3F); }
+        if ((len == 3 && cp < 0x800) || (len == 4 && (cp < 0x10000 || cp > 0x10FFFF)) || (cp >= 0xD800 && cp <= 0xDFFF)) return false;
+        i += len;
+    }
+    return true;
+}
+inline bool is_ws_cp(uint32_t c) {
+    return (c >= 9 && c <= 13) || c == 0x20 || c == 0x85 || c == 0xA0 || c == 0x1680 || (c >= 0x2000 && c <= 0x200A) ||
+           c == 0x2028 || c == 0x2029 || c == 0x202F || c == 0x205F || c == 0x3000;
+}
+inline std::string_view trim(std::string_view s) {  // str::trim on valid UTF-8
+    auto dec = [&](size_t i, uint32_t* cp) -> size_t {
+        uint8_t b = (uint8_t)s[i];
+        if (b < 0x80) { *cp = b; return 1; }
+        size_t len = b < 0xE0 ? 2 : b < 0xF0 ? 3 : 4;
+        uint32_t v = b & (0xFF >> (len + 1));
+        for (size_t k = 1; k < len && i + k < s.size(); ++k) v = (v << 6) | ((uint8_t)s[i + k] & 0x3F);
+        *cp = v;
+        return len;
+    };
+    size_t b = 0, e = s.size();
+    while (b < e) { uint32_t cp; size_t n = dec(b, &cp); if (!is_ws_cp(cp)) break; b += n; }
+    while (e > b) {
+        size_t p = e - 1;
+        while (p > b && ((uint8_t)s[p] & 0xC0) == 0x80) --p;
+        uint32_t cp; dec(p, &cp);
+        if (!is_ws_cp(cp)) break;
+        e = p;
+    }
+    return s.substr(b, e - b);
+}
+}  // namespace detail
+
+using RecordSink = std::function<void(Record&&)>;  // stands in for encoder.encode(record) -> tx.send(bytes)
+
+class BatchingSplitter {
+  public:
+    enum Framing { Line, Nul, Syslen };
+    BatchingSplitter(Framing f, size_t max_lines = 1 << 16, size_t max_bytes = 32u << 20) : f_(f), max_lines_(max_lines), max_bytes_(max_bytes) {}
+
+    // Mirrors LineSplitter/NulSplitter/SyslenSplitter::run: frames `in`, decodes in batches, hands Ok records to
+    // `sink` in input order, reports errors on `err` exactly like the reference.
+    void run(std::istream& in, const Decoder& decoder, const RecordSink& sink, std::ostream& err) {
+        bytes_.clear();
+        offsets_.assign(1, 0);
+        std::string line;
+        if (f_ == Syslen) {
+            for (;;) {  // syslen_splitter.rs:42-57: "<len> " then exactly len bytes
+                std::string num;
+                int c;
+                while ((c = in.get()) != EOF && c != ' ') num.push_back((char)c);
+                if (c == EOF || num.empty()) { flush(decoder, sink, err); err << "Can't read message's length\n"; break; }  // :20-25
+                size_t len = 0;
+                bool ok = true;
+                size_t k = num[0] == '+' ? 1 : 0;
+                if (k >= num.size()) ok = false;
+                for (; k < num.size() && ok; ++k) { if (num[k] < '0' || num[k] > '9') ok = false; else len = len * 10 + (num[k] - '0'); }
+                if (!ok) { flush(decoder, sink, err); err << "Can't read message's length\n"; break; }
+                line.resize(len);
+                in.read(&line[0], (std::streamsize)len);
+                if ((size_t)in.gcount() != len) break;
+                push(line, decoder, sink, err);
+            }
+        } else {
+            const char delim = f_ == Line ? '\n' : '\0';
+            while (std::getline(in, line, delim)) {
+                if (f_ == Line && !line.empty() && line.back() == '\r') line.pop_back();  // BufRead::lines()
+                push(line, decoder, sink, err);
+            }
+        }
+        flush(decoder, sink, err);
+    }
+
+  private:
+    void push(const std::string& line, const Decoder& d, const RecordSink& sink, std::ostream& err) {
+        if (!detail::valid_utf8((const uint8_t*)line.data(), line.size())) {
+            flush(d, sink, err);  // keep stderr/record order
+            err << "Invalid UTF-8 input\n";  // line_splitter.rs:22-25, nul_splitter.rs:35-38
+            return;
+        }
+        bytes_.insert(bytes_.end(), line.begin(), line.end());
+        offsets_.push_back(bytes_.size());
+        if (offsets_.size() - 1 >= max_lines_ || bytes_.size() >= max_bytes_) flush(d, sink, err);
+    }
+    void flush(const Decoder& d, const RecordSink& sink, std::ostream& err) {
+        const uint64_t n = offsets_.size() - 1;
+        if (n == 0) return;
+        bytes_.resize(bytes_.size() + 16);  // readable slack (the data itself is not touched)
+        auto res = d.decode_batch(bytes_.data(), offsets_.back(), offsets_.data(), n);
+        for (uint64_t i = 0; i < n; ++i) {
+            if (res[i].ok()) { sink(std::move(res[i].record)); continue; }
+            std::string_view ln((const char*)bytes_.data() + offsets_[i], offsets_[i + 1] - offsets_[i]);
+            std::string_view t = detail::trim(ln);
+            if (f_ == Nul && t.empty()) continue;  // nul_splitter.rs:41-46
+            err << res[i].err << ": [" << t << "]\n";  // line_splitter.rs:37-39
+        }
+        bytes_.clear();
+        offsets_.assign(1, 0);
+    }
+    Framing f_;
+    size_t max_lines_, max_bytes_;
+    std::vector<uint8_t> bytes_;
+    std::vector<uint64_t> offsets_;
+};
+
+}  // namespace fg

@@ -318,3 +318,92 @@ def test_gelf_fuzz_mutations_match_oracle(oracle):
             b[pos:pos + 1] = alphabet[int(rng.integers(0, len(alphabet)))]
         lines.append(bytes(b))
     both_paths(dec, oracle, lines)
+
+
+# -------------------------------------------------------------------------- sharding (N > 1 path)
+def test_sharded_decode_equals_oracle(rfc, oracle):
+    """Byte-balanced 8-way shard plan, each shard decoded on its own, ordered host gather."""
+    from flowgger_amd import shard
+
+    lines = synth.rfc5424_lines(40_000, cfg=4, sd=True)
+    data, offsets = synth.pack(lines)
+    tab = shard.decode_sharded(lambda d, o, k: rfc.decode_packed(np.ascontiguousarray(d), o), data, offsets, 8)
+    blob, offs = tab.serialize(RFC5424, data, offsets)
+    oblob, ooffs = oracle.decode_batch(RFC5424, data, offsets)
+    assert_same(blob, offs, oblob, ooffs, lines)
+
+
+def test_cfg5_mixed_formats_ordered_merge(rfc, oracle):
+    from flowgger_amd import shard
+
+    ltsv = LTSVDecoder(synth.LTSV_CONFIG)
+    a = synth.rfc5424_lines(3000, cfg=5, sd=True, long_tail=True)
+    b = synth.ltsv_lines(2000, long_tail=True)
+    rng = np.random.default_rng(55)
+    tag = rng.permutation(np.array([0] * len(a) + [1] * len(b)))
+    parts = []
+    for t, dec, lines in ((0, rfc, a), (1, ltsv, b)):
+        d, o = synth.pack(lines)
+        (blob, offs), _ = host_path_blob(dec, d, o)
+        parts.append((np.nonzero(tag == t)[0], blob, offs))
+    blob, offs = shard.ordered_merge(parts)
+    it = {0: iter(a), 1: iter(b)}
+    for i, t in enumerate(tag):
+        want = oracle.decode(int(t), next(it[int(t)]), synth.LTSV_CONFIG if t else None)
+        assert blob[int(offs[i]):int(offs[i + 1])].tobytes() == want, i
+
+
+# ---------------------------------------------------------------------- C++ host mirror + framers
+@pytest.mark.parametrize("fmt,framing", [("rfc5424", "line"), ("gelf", "nul"), ("ltsv", "syslen")])
+def test_cpp_host_mirror_and_batching_splitters(tmp_path, oracle, fmt, framing):
+    """fg::Decoder / fg::BatchingSplitter (C++ mirror of the trait and of the three splitters):
+    Ok records in input order == oracle, error lines formatted like line_splitter.rs:37-39."""
+    import subprocess
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    exe = tmp_path / "host_mirror_test"
+    subprocess.run(["g++", "-std=c++17", "-O1", str(root / "tests/native/host_mirror_test.cpp"), "-o", str(exe),
+                    f"-L{root / 'flowgger_amd'}", "-lfg_hip", f"-Wl,-rpath,{root / 'flowgger_amd'}",
+                    "-L/opt/rocm/lib", "-lamdhip64"], check=True)
+    code = {"rfc5424": RFC5424, "ltsv": LTSV, "gelf": GELF}[fmt]
+    cfg = synth.LTSV_CONFIG if fmt == "ltsv" else None
+    lines = {"rfc5424": lambda: synth.rfc5424_lines(3000, cfg=4, sd=True), "gelf": lambda: synth.gelf_lines(3000),
+             "ltsv": lambda: synth.ltsv_lines(3000)}[fmt]()
+    lines = [ln for ln in lines if b"\n" not in ln and b"\0" not in ln]
+    lines[7] = lines[7] + b"  "
+    raw = bytearray()
+    expect_lines = []
+    for i, ln in enumerate(lines):
+        if framing == "line":
+            raw += ln + (b"\r\n" if i % 5 == 0 else b"\n")
+        elif framing == "nul":
+            raw += ln + b"\0"
+        else:
+            raw += str(len(ln)).encode() + b" " + ln
+        expect_lines.append(ln)
+    bad_utf8 = b"<13>1 2015-08-05T15:53:45Z h a p m - \xff\xfe"
+    if framing != "syslen":  # the reference unwrap()-panics on invalid UTF-8 under syslen framing
+        raw += bad_utf8 + (b"\n" if framing == "line" else b"\0")
+    f = tmp_path / "in.bin"
+    f.write_bytes(bytes(raw))
+    p = subprocess.run([str(exe), fmt, framing, str(f), "257"], capture_output=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    got_ok = [bytes.fromhex(x) for x in p.stdout.decode().split()]
+    got_err = p.stderr.decode("utf-8", "replace").splitlines()
+    want_ok, want_err = [], []
+    for ln in expect_lines:
+        c = oracle.decode(code, ln, cfg)
+        if c[0] == 0:
+            want_ok.append(c)
+        else:
+            msg = c[5:].decode()
+            t = ln.decode("utf-8", "replace").strip()
+            if not (framing == "nul" and t == ""):
+                want_err.append(f"{msg}: [{t}]")
+    if framing != "syslen":
+        want_err.append("Invalid UTF-8 input")
+    else:
+        want_err.append("Can't read message's length")
+    assert got_ok == want_ok
+    assert got_err == want_err
