@@ -11,6 +11,7 @@
 #include <stdint.h>
 
 #include "../../include/fg_hip.h"
+#include "fg_timeconv.hpp"
 
 namespace fg {
 
@@ -123,105 +124,7 @@ __device__ __forceinline__ uint32_t trim_start(R& rd, uint32_t s, uint32_t e) {
     return s;
 }
 
-// ---------------------------------------------------------------------------------------------
-// Calendar + timestamp arithmetic (time 0.3: Date::from_calendar_date, Time::from_hms_nano,
-// UtcOffset::from_hms, OffsetDateTime::unix_timestamp_nanos).
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool is_leap_year(int y) { return (y % 4 == 0) && (y % 100 != 0 || y % 400 == 0); }
-__device__ __forceinline__ int days_in_month(int y, int m) {
-    // 31 28 31 30 31 30 31 31 30 31 30 31 packed 2 bits each above 28
-    int d = 28 + ((0xEEFBB3 >> ((m - 1) * 2)) & 3);  // Jan..Dec extra days: 3 0 3 2 3 2 3 3 2 3 2 3
-    return (m == 2 && is_leap_year(y)) ? 29 : d;
-}
-__device__ __forceinline__ int64_t days_from_civil(int y, int m, int d) {
-    y -= m <= 2;
-    int era = (y >= 0 ? y : y - 399) / 400;
-    int yoe = y - era * 400;
-    int doy = (153 * (m + (m > 2 ? -3 : 9)) + 2) / 5 + d - 1;
-    int doe = yoe * 365 + yoe / 4 - yoe / 100 + doy;
-    return (int64_t)era * 146097 + doe - 719468;
-}
-__device__ __forceinline__ void civil_from_days(int64_t z, int* y, int* m, int* d) {
-    z += 719468;
-    int64_t era = (z >= 0 ? z : z - 146096) / 146097;
-    int doe = (int)(z - era * 146097);
-    int yoe = (doe - doe / 1460 + doe / 36524 - doe / 146096) / 365;
-    int yy = yoe + (int)era * 400;
-    int doy = doe - (365 * yoe + yoe / 4 - yoe / 100);
-    int mp = (5 * doy + 2) / 153;
-    *d = doy - (153 * mp + 2) / 5 + 1;
-    *m = mp < 10 ? mp + 3 : mp - 9;
-    *y = yy + (*m <= 2);
-}
-// (secs * 1e9 + nano) as i128 -> f64 (RNE) -> / 1e9, without __int128 runtime support.
-__device__ __forceinline__ double unix_nanos_to_f64(int64_t secs, uint32_t nano) {
-    // total = secs*1e9 + nano ; nano in [0, 1e9).  Work on the magnitude.
-    bool neg = secs < 0;
-    uint64_t lo, hi;
-    if (!neg) {
-        uint64_t a = (uint64_t)secs;
-        lo = a * 1000000000ull;
-        hi = __umul64hi(a, 1000000000ull);
-        uint64_t l2 = lo + nano;
-        hi += l2 < lo;
-        lo = l2;
-    } else {
-        // |total| = (-secs)*1e9 - nano   (secs <= -1 so this is > 0)
-        uint64_t a = (uint64_t)(-secs);
-        lo = a * 1000000000ull;
-        hi = __umul64hi(a, 1000000000ull);
-        uint64_t l2 = lo - nano;
-        hi -= l2 > lo;
-        lo = l2;
-    }
-    double mag;
-    if (hi == 0) {
-        mag = (double)lo;  // u64 -> f64 is correctly rounded (RNE)
-    } else {
-        // keep 64 significant bits, fold the shifted-out bits into a sticky LSB: rounding a
-        // 64-bit integer to 53 bits then sees exactly the same round/sticky information.
-        int s = 64 - __clzll((long long)hi);  // 1..64; here hi < 2^5
-        uint64_t m = (hi << (64 - s)) | (lo >> s);
-        uint64_t lost = lo & ((1ull << s) - 1ull);
-        m |= (lost != 0);
-        mag = ldexp((double)m, s);  // exact scaling
-    }
-    double f = neg ? -mag : mag;
-    return f / 1e9;  // IEEE-754 correctly rounded division (no fast-math)
-}
-
-struct DateTimeParts {
-    int year, month, day, hour, minute, second;
-    uint32_t nano;
-    int off_sign, off_h, off_m;
-};
-// Validation + conversion; allow_leap = the Rfc3339 parser's second==60 stand-in.
-__device__ __forceinline__ bool datetime_to_unix(const DateTimeParts& p, bool allow_leap, double* out) {
-    int second = p.second;
-    uint32_t nano = p.nano;
-    bool leap = false;
-    if (second == 60 && allow_leap) {
-        second = 59;
-        nano = 999999999u;
-        leap = true;
-    }
-    if (p.month < 1 || p.month > 12) return false;
-    if (p.year < -9999 || p.year > 9999) return false;
-    if (p.day < 1 || p.day > days_in_month(p.year, p.month)) return false;
-    if (p.hour > 23 || p.minute > 59 || second > 59) return false;
-    if (p.off_h > 25 || p.off_m > 59) return false;
-    int off = p.off_sign * (p.off_h * 3600 + p.off_m * 60);
-    int64_t secs = days_from_civil(p.year, p.month, p.day) * 86400 + (p.hour * 3600 + p.minute * 60 + second - off);
-    if (leap) {
-        int64_t days = secs >= 0 ? secs / 86400 : -((-secs + 86399) / 86400);
-        int64_t sod = secs - days * 86400;
-        int y, m, d;
-        civil_from_days(days, &y, &m, &d);
-        if (sod != 86399 || d != days_in_month(y, m)) return false;
-    }
-    *out = unix_nanos_to_f64(secs, nano);
-    return true;
-}
+// Calendar + timestamp arithmetic: fg_timeconv.hpp (host-testable).
 
 // n ASCII digits at rd[q..q+n) (all inside [0,len)); advances q.
 template <class R>

@@ -21,11 +21,14 @@
 // Fixed-width results go to struct-of-array tables (one coalesced store per column);
 // structured-data entries get their slots from ONE wave-aggregated atomic (count pass -> wave
 // prefix sum -> fill pass, both out of LDS).
+#include <cstdio>
 #include <cstdlib>
 
 #include "fg_device.hpp"
 
 namespace fg {
+
+using u32x4 = unsigned int __attribute__((ext_vector_type(4)));
 
 // status codes == index into the reference's error strings (fg_error_string)
 enum : uint32_t {
@@ -337,10 +340,28 @@ __device__ __forceinline__ uint32_t digits4(uint32_t x) {
     return (t & 0xFFu) * 100u + (t >> 16);
 }
 
-// RFC3339 from registers.  [t0, t0+L) is the timestamp part (line-relative).  Returns
-// 1 = ok (*out set), 0 = invalid, 2 = undecided (caller falls back to the byte-wise parser).
-__device__ __forceinline__ int fast_rfc3339(const Tile& T, uint32_t base, uint32_t t0, uint32_t L, double* out) {
-    if (L < 20u) return 0;
+// What the straight-line fast path could not finish; each bit sends the lane through one rare,
+// branchy piece of the generic parser afterwards.
+enum : uint32_t {
+    R_GENERIC = 1,  // not "<ddd>1 " shaped, header beyond the 128-byte window: whole line -> parse_line_generic
+    R_TS_SLOW = 2,  // leap second, >= 16 fraction digits, result before 1970 / beyond 2^34 s: byte-wise RFC3339
+    R_TAIL = 4,     // part 7 does not start with '-': structured data or garbage -> parse_tail
+    R_TRIM = 8      // whitespace (possibly multi-byte) at the trim points -> trim_end / trim_start
+};
+
+struct Fast {
+    uint32_t route;
+    uint32_t no_ts;    // "<PRI>1" is the whole line                                    :25
+    uint32_t ts_ok;    // timestamp converted on the fast path
+    uint32_t rest;     // status of everything after the timestamp (E_OK / E_NOHOST.. / E_NOMSG)
+    uint32_t t0, te;   // timestamp part [t0, te)
+    uint32_t d0;       // index of part 7
+    uint32_t e, s;     // message end / start after the cheap trims
+};
+
+// RFC3339 from registers, branch-free: [t0, t0+L) is the timestamp part.  Returns 1 = converted,
+// 0 = invalid, 2 = undecided (the caller runs the byte-wise parser).
+__device__ __forceinline__ uint32_t fast_rfc3339(const Tile& T, uint32_t base, uint32_t t0, uint32_t L, double* out) {
     const uint32_t a = base + t0;
     const uint32_t d = a >> 2, s = a & 3u;
     uint32_t w[10];
@@ -350,14 +371,14 @@ __device__ __forceinline__ int fast_rfc3339(const Tile& T, uint32_t base, uint32
 #pragma unroll
     for (int k = 0; k < 9; ++k) r[k] = __builtin_amdgcn_alignbyte(w[k + 1], w[k], s);
     // bytes 0..18 = "YYYY-MM-DDtHH:MM:SS" ; XOR with the pattern: digits -> 0..9, literals -> 0
-    uint32_t x0 = r[0] ^ 0x30303030u;                         // Y Y Y Y
-    uint32_t x1 = r[1] ^ 0x2D30302Du;                         // - M M -
-    uint32_t x2 = (r[2] | 0x00200000u) ^ 0x30743030u;         // D D t H   ('T'|0x20 == 't')
-    uint32_t x3 = r[3] ^ 0x30303A30u;                         // H : M M
-    uint32_t x4 = (r[4] & 0x00FFFFFFu) ^ 0x0030303Au;         // : S S (byte 19 cleared)
+    const uint32_t x0 = r[0] ^ 0x30303030u;                         // Y Y Y Y
+    const uint32_t x1 = r[1] ^ 0x2D30302Du;                         // - M M -
+    const uint32_t x2 = (r[2] | 0x00200000u) ^ 0x30743030u;         // D D t H   ('T'|0x20 == 't')
+    const uint32_t x3 = r[3] ^ 0x30303A30u;                         // H : M M
+    const uint32_t x4 = (r[4] & 0x00FFFFFFu) ^ 0x0030303Au;         // : S S (byte 19 cleared)
     uint32_t bad = swar_exceeds(x0, 0x76767676u) | swar_exceeds(x1, 0x7F76767Fu) | swar_exceeds(x2, 0x767F7676u) |
                    swar_exceeds(x3, 0x76767F76u) | swar_exceeds(x4, 0x7F76767Fu);
-    if (bad) return 0;
+    bad |= L < 20u ? 1u : 0u;
     DateTimeParts p;
     p.year = (int)digits4(x0);
     p.month = (int)(((x1 >> 8) & 0xFFu) * 10u + ((x1 >> 16) & 0xFFu));
@@ -365,258 +386,184 @@ __device__ __forceinline__ int fast_rfc3339(const Tile& T, uint32_t base, uint32
     p.hour = (int)((x2 >> 24) * 10u + (x3 & 0xFFu));
     p.minute = (int)(((x3 >> 16) & 0xFFu) * 10u + (x3 >> 24));
     p.second = (int)(((x4 >> 8) & 0xFFu) * 10u + ((x4 >> 16) & 0xFFu));
-    p.nano = 0;
-    uint32_t pos = 19;  // index of the time-zone designator
-    if ((r[4] >> 24) == '.') {
-        // fraction digits live in bytes 20..35 = r[5..8]; count the leading digits (clamped to L)
-        uint32_t f0 = r[5] ^ 0x30303030u, f1 = r[6] ^ 0x30303030u, f2 = r[7] ^ 0x30303030u, f3 = r[8] ^ 0x30303030u;
-        uint32_t n0 = swar_exceeds(f0, 0x76767676u), n1 = swar_exceeds(f1, 0x76767676u);
-        uint32_t n2 = swar_exceeds(f2, 0x76767676u), n3 = swar_exceeds(f3, 0x76767676u);
-        uint32_t nd = n0 ? (uint32_t)__builtin_ctz(n0) >> 3
-                         : n1 ? 4u + ((uint32_t)__builtin_ctz(n1) >> 3)
-                              : n2 ? 8u + ((uint32_t)__builtin_ctz(n2) >> 3)
-                                   : n3 ? 12u + ((uint32_t)__builtin_ctz(n3) >> 3) : 16u;
-        uint32_t room = L - 20u;
-        if (nd > room) nd = room;
-        if (nd == 0) return 0;
-        if (nd >= 16u) return 2;  // very long fraction: let the byte-wise parser decide
-        // keep the first min(nd,9) digits, zero the rest => nine digits with trailing zeros
-        uint32_t keep = nd < 9u ? nd : 9u;
-        uint32_t k0 = keep >= 4u ? 0xFFFFFFFFu : (1u << (8u * keep)) - 1u;
-        uint32_t k1 = keep >= 8u ? 0xFFFFFFFFu : keep <= 4u ? 0u : (1u << (8u * (keep - 4u))) - 1u;
-        uint32_t d8 = keep >= 9u ? (f2 & 0xFFu) : 0u;
-        p.nano = (digits4(f0 & k0) * 10000u + digits4(f1 & k1)) * 10u + d8;
-        pos = 20u + nd;
-    }
-    if (pos >= L) return 0;
+    // optional fraction: digits live in bytes 20..35 = r[5..8]; count the leading digits
+    const bool has_frac = (r[4] >> 24) == '.';
+    const uint32_t f0 = r[5] ^ 0x30303030u, f1 = r[6] ^ 0x30303030u, f2 = r[7] ^ 0x30303030u, f3 = r[8] ^ 0x30303030u;
+    const uint32_t n0 = swar_exceeds(f0, 0x76767676u), n1 = swar_exceeds(f1, 0x76767676u);
+    const uint32_t n2 = swar_exceeds(f2, 0x76767676u), n3 = swar_exceeds(f3, 0x76767676u);
+    uint32_t nd = n0 ? (uint32_t)__builtin_ctz(n0) >> 3
+                     : n1 ? 4u + ((uint32_t)__builtin_ctz(n1) >> 3)
+                          : n2 ? 8u + ((uint32_t)__builtin_ctz(n2) >> 3)
+                               : n3 ? 12u + ((uint32_t)__builtin_ctz(n3) >> 3) : 16u;
+    const uint32_t room = L - 20u;  // (garbage when L < 20: `bad` is already set)
+    nd = nd > room ? room : nd;
+    bad |= (has_frac && nd == 0u) ? 1u : 0u;
+    const bool undecided = has_frac && nd >= 16u;  // very long fraction: the byte-wise parser decides
+    // keep the first min(nd,9) digits, zero the rest => nine digits with trailing zeros
+    const uint32_t keep = nd < 9u ? nd : 9u;
+    const uint32_t k0 = keep >= 4u ? 0xFFFFFFFFu : (1u << (8u * keep)) - 1u;
+    const uint32_t k1 = keep >= 8u ? 0xFFFFFFFFu : keep <= 4u ? 0u : (1u << (8u * (keep - 4u))) - 1u;
+    const uint32_t d8 = keep >= 9u ? (f2 & 0xFFu) : 0u;
+    const uint32_t nano = (digits4(f0 & k0) * 10000u + digits4(f1 & k1)) * 10u + d8;
+    p.nano = has_frac ? nano : 0u;
+    const uint32_t pos = has_frac ? 20u + nd : 19u;  // index of the time-zone designator
+    uint32_t bad_tz = pos >= L ? 1u : 0u;            // (judged only when the fraction was decided here)
     // time-zone designator: re-read 8 bytes at its (data-dependent) position
     uint32_t z0, z1;
     load8(T, a + pos, &z0, &z1);
-    uint32_t c = z0 & 0xFFu;
-    p.off_sign = 1;
-    p.off_h = 0;
-    p.off_m = 0;
-    if ((c | 0x20u) == 'z') {
-        if (pos + 1u != L) return 0;
-    } else if (c == '+' || c == '-') {
-        if (pos + 6u != L) return 0;
-        // bytes 1..5 = H H : M M
-        uint32_t y0 = (z0 >> 8) ^ 0x003A3030u;   // H H :   (3 bytes)
-        uint32_t y1 = (z1 & 0xFFFFu) ^ 0x3030u;  // M M
-        if (swar_exceeds(y0, 0x7F7F7676u) | swar_exceeds(y1, 0x7F7F7676u)) return 0;
-        p.off_sign = c == '-' ? -1 : 1;
-        p.off_h = (int)((y0 & 0xFFu) * 10u + ((y0 >> 8) & 0xFFu));
-        p.off_m = (int)((y1 & 0xFFu) * 10u + ((y1 >> 8) & 0xFFu));
-    } else {
-        return 0;
-    }
-    return datetime_to_unix(p, true, out) ? 1 : 0;
+    const uint32_t c = z0 & 0xFFu;
+    const bool is_z = (c | 0x20u) == 'z';
+    const bool is_off = c == '+' || c == '-';
+    // bytes 1..5 = H H : M M
+    const uint32_t y0 = (z0 >> 8) ^ 0x003A3030u;   // H H :   (3 bytes)
+    const uint32_t y1 = (z1 & 0xFFFFu) ^ 0x3030u;  // M M
+    const uint32_t off_bad = swar_exceeds(y0, 0x7F7F7676u) | swar_exceeds(y1, 0x7F7F7676u);
+    bad_tz |= is_z ? (pos + 1u != L ? 1u : 0u) : is_off ? ((pos + 6u != L ? 1u : 0u) | off_bad) : 1u;
+    p.off_sign = c == '-' ? -1 : 1;
+    p.off_h = is_off ? (int)((y0 & 0xFFu) * 10u + ((y0 >> 8) & 0xFFu)) : 0;
+    p.off_m = is_off ? (int)((y1 & 0xFFu) * 10u + ((y1 >> 8) & 0xFFu)) : 0;
+    const uint32_t conv = (uint32_t)datetime_to_unix_fast(p, out);
+    return bad ? 0u : undecided ? 2u : bad_tz ? 0u : conv;
 }
 
-// Fast path of decode() for a line that lives in the LDS tile.  Returns false when the line's
-// shape is outside what the fast path recognises (caller then runs parse_line_generic).
-__device__ __forceinline__ bool parse_line_fast(const Tile& T, uint32_t base, uint32_t len, Row& r,
-                                                const DevTables& t) {
-    if (len < 5u) return false;
-    // ---- "<" 1-3 digits ">" "1" then ' ' or end of line ------------------------- :62-92
-    uint32_t h0, h1;
+// Lowest set bit of the 128-bit window (lo, hi) -> its index, cleared from the window; `none`
+// when the window is empty (then *found stays as it is).
+__device__ __forceinline__ uint32_t take_space(uint64_t& lo, uint64_t& hi, uint32_t none, uint32_t& found) {
+    const bool in_lo = lo != 0, in_hi = hi != 0;
+    const uint32_t p = in_lo ? (uint32_t)__builtin_ctzll(lo) : in_hi ? 64u + (uint32_t)__builtin_ctzll(hi) : none;
+    const uint64_t lo2 = lo & (lo - 1ull), hi2 = hi & (hi - 1ull);
+    hi = in_lo ? hi : hi2;
+    lo = lo2;  // (0 & anything == 0: no select needed)
+    found += (in_lo || in_hi) ? 1u : 0u;
+    return p;
+}
+
+// Fast path of decode() for a line that lives in the LDS tile: ONE straight-line block for the
+// common shape `<PRI>1 TS HOST APP PROC MSGID - MSG` (every independent LDS read issued up front,
+// everything else selects), so that lanes with valid, invalid-but-simple and oddly shaped lines
+// stay converged; what it cannot decide is reported in Fast::route.
+__device__ __forceinline__ Fast parse_line_fast(const Tile& T, uint32_t base, uint32_t len, Row& r) {
+    Fast f;
+    // ---- independent LDS reads: first 8 bytes, last byte, 160 bits of the space bitmap --------
+    uint32_t h0, h1, l0, l1;
     load8(T, base, &h0, &h1);
-    if ((h0 & 0xFFu) != '<') return false;
-    uint32_t c1 = ((h0 >> 8) & 0xFFu) - '0', c2 = ((h0 >> 16) & 0xFFu) - '0', c3 = (h0 >> 24) - '0';
-    if (c1 > 9u) return false;
-    uint32_t nd = 1, pri = c1;
-    if (c2 <= 9u) {
-        nd = 2;
-        pri = pri * 10u + c2;
-        if (c3 <= 9u) {
-            nd = 3;
-            pri = pri * 10u + c3;
-        }
-    }
-    if (pri > 255u) return false;
+    load8(T, base + (len ? len - 1u : 0u), &l0, &l1);
+    const uint32_t q = base >> 5, sh = base & 31u;
+    const uint32_t b0 = T.bm[q], b1 = T.bm[q + 1], b2 = T.bm[q + 2], b3 = T.bm[q + 3], b4 = T.bm[q + 4];
+
+    // ---- "<" 1-3 digits ">" "1" then ' ' or end of line ------------------------- :62-92
+    const uint32_t c1 = ((h0 >> 8) & 0xFFu) - '0', c2 = ((h0 >> 16) & 0xFFu) - '0', c3 = (h0 >> 24) - '0';
+    const bool d2 = c2 <= 9u, d3 = d2 && c3 <= 9u;
+    const uint32_t nd = 1u + (d2 ? 1u : 0u) + (d3 ? 1u : 0u);
+    uint32_t pri = c1;
+    pri = d2 ? pri * 10u + c2 : pri;
+    pri = d3 ? pri * 10u + c3 : pri;
     // bytes at 1+nd, 2+nd, 3+nd must be '>', '1', (' ' | end)
-    uint64_t hh = (((uint64_t)h1 << 32) | h0) >> (8u * (1u + nd));
-    if ((uint32_t)(hh & 0xFFFFu) != (('1' << 8) | '>')) return false;
+    const uint64_t hh = (((uint64_t)h1 << 32) | h0) >> (8u * (1u + nd));
     const uint32_t sp0 = 3u + nd;
-    if (sp0 > len) return false;
+    const bool shape = (h0 & 0xFFu) == '<' && c1 <= 9u && pri <= 255u && (uint32_t)(hh & 0xFFFFu) == (('1' << 8) | '>') &&
+                       sp0 <= len;
+    f.no_ts = sp0 == len ? 1u : 0u;
+    // "<13>1x": the generic path reports it
+    f.route = (!shape || (sp0 < len && (uint32_t)((hh >> 16) & 0xFFu) != ' ')) ? R_GENERIC : 0u;
     r.facility = pri >> 3;
     r.severity = pri & 7u;
-    if (sp0 == len) {
-        r.status = E_NOTS;
-        return true;
-    }
-    if ((uint32_t)((hh >> 16) & 0xFFu) != ' ') return false;  // "<13>1x": generic path reports it
 
-    // ---- splitn(7, ' '): positions of the first six spaces from the bitmap ----------- :23
-    uint32_t sp[6];
-    uint32_t nsp;
+    // ---- splitn(7, ' '): the five spaces after the one that follows "<PRI>1" ----------- :23
+    uint64_t lo = (uint64_t)__builtin_amdgcn_alignbit(b1, b0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(b2, b1, sh) << 32);
+    uint64_t hi = (uint64_t)__builtin_amdgcn_alignbit(b3, b2, sh) | ((uint64_t)__builtin_amdgcn_alignbit(b4, b3, sh) << 32);
     {
-        const uint32_t q = base >> 5, sh = base & 31u;
-        uint32_t b0 = T.bm[q], b1 = T.bm[q + 1], b2 = T.bm[q + 2], b3 = T.bm[q + 3], b4 = T.bm[q + 4];
-        uint64_t lo = (uint64_t)__builtin_amdgcn_alignbit(b1, b0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(b2, b1, sh) << 32);
-        uint64_t hi = (uint64_t)__builtin_amdgcn_alignbit(b3, b2, sh) | ((uint64_t)__builtin_amdgcn_alignbit(b4, b3, sh) << 32);
-        if (len < 64u) {
-            lo &= (1ull << len) - 1ull;
-            hi = 0;
-        } else if (len < 128u) {
-            hi &= (1ull << (len - 64u)) - 1ull;
-        }
-        nsp = 0;
-        uint32_t from = 128u;  // where a continuation beyond the window would resume
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            uint32_t pos = len;
-            if (lo) {
-                pos = (uint32_t)__builtin_ctzll(lo);
-                lo &= lo - 1ull;
-                nsp = k + 1;
-            } else if (hi) {
-                pos = 64u + (uint32_t)__builtin_ctzll(hi);
-                hi &= hi - 1ull;
-                nsp = k + 1;
-            }
-            sp[k] = pos;
-        }
-        if (nsp < 6u && len > 128u) {
-            // header longer than the window: continue on the bitmap in LDS (static indices only,
-            // so that sp[] stays in registers)
-            bool more = true;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                if (more && (uint32_t)k >= nsp) {
-                    uint32_t pos = find_space_bm(T, base, from, len);
-                    if (pos >= len) {
-                        more = false;
-                    } else {
-                        sp[k] = pos;
-                        nsp = k + 1;
-                        from = pos + 1u;
-                    }
-                }
-            }
-        }
+        const uint64_t lo_keep = len < 64u ? (1ull << (len & 63u)) - 1ull : ~0ull;
+        const uint64_t hi_keep = len < 64u ? 0ull : len < 128u ? (1ull << ((len - 64u) & 63u)) - 1ull : ~0ull;
+        lo &= lo_keep & ~((2ull << sp0) - 1ull);  // no space can precede sp0 in "<ddd>1"; sp0 itself is known
+        hi &= hi_keep;
     }
-    // sp[0] is the space right after "<PRI>1" by construction (no space can precede it)
+    uint32_t found = 0;
+    const uint32_t s1 = take_space(lo, hi, len, found);
+    const uint32_t s2 = take_space(lo, hi, len, found);
+    const uint32_t s3 = take_space(lo, hi, len, found);
+    const uint32_t s4 = take_space(lo, hi, len, found);
+    const uint32_t s5 = take_space(lo, hi, len, found);
+    // header longer than the window: let the generic parser walk it
+    f.route |= (found < 5u && len > 128u) ? R_GENERIC : 0u;
 
     // ---- timestamp ------------------------------------------------------------------- :25
+    f.t0 = sp0 + 1u;
+    f.te = s1;
     {
-        const uint32_t t0 = sp0 + 1u;
-        const uint32_t te = nsp >= 2u ? sp[1] : len;
-        int ok = fast_rfc3339(T, base, t0, te - t0, &r.ts);
-        if (ok == 2) {
-            LdsReader rd(T.w, base);
-            ok = parse_rfc3339(rd, t0, te, &r.ts) ? 1 : 0;
-        }
-        if (!ok) {
-            r.status = E_BADTS;
-            return true;
-        }
+        const uint32_t ok = fast_rfc3339(T, base, f.t0, s1 - f.t0, &r.ts);
+        f.ts_ok = ok == 1u ? 1u : 0u;
+        f.route |= ok == 2u ? R_TS_SLOW : 0u;
     }
-    // ---- hostname / appname / procid / msgid ------------------------------------- :26-30
-    if (nsp < 6u) {
-        r.status = E_NOHOST + (nsp - 1u);  // 1 space -> hostname missing ... 5 -> message data missing
-        return true;
-    }
-    // field k lies between spaces k+1 and k+2 (hostname between the 2nd and 3rd space)
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        r.off[k] = sp[k + 1] + 1u;
-        r.len[k] = sp[k + 2] - sp[k + 1] - 1u;
-    }
-    const uint32_t d0 = sp[5] + 1u;
-    if (d0 >= len) {
-        r.status = E_NOMSG;
-        return true;
-    }
+    // ---- hostname / appname / procid / msgid (verbatim) ------------------------- :26-30
+    r.off[S_HOST] = s1 + 1u;
+    r.len[S_HOST] = s2 - s1 - 1u;
+    r.off[S_APP] = s2 + 1u;
+    r.len[S_APP] = s3 - s2 - 1u;
+    r.off[S_PROC] = s3 + 1u;
+    r.len[S_PROC] = s4 - s3 - 1u;
+    r.off[S_MSGID] = s4 + 1u;
+    r.len[S_MSGID] = s5 - s4 - 1u;
+    const uint32_t d0 = s5 + 1u;
+    f.d0 = d0;
+    // found = spaces after the first: 0 -> hostname missing ... 4 -> message data missing
+    f.rest = found < 5u ? E_NOHOST + found : d0 >= len ? E_NOMSG : E_OK;
+
     // ---- part 7 ------------------------------------------------------------------ :127-161
     uint32_t m0, m1;
-    load8(T, base + d0, &m0, &m1);
+    load8(T, base + (d0 < len ? d0 : 0u), &m0, &m1);
     const uint32_t c = m0 & 0xFFu;
-    if (c != '-') {
-        // structured data or garbage: generic tail (byte-walking FSM)
-        LdsReader rd(T.w, base);
-        parse_tail(rd, d0, 0u, len, r, t);
-        return true;
-    }
-    r.data0 = d0;
+    const bool live = !f.no_ts && f.rest == E_OK;  // (the timestamp verdict may still come later)
+    f.route |= (live && c != '-') ? R_TAIL : 0u;
     // trim_end of the whole line: common case = last byte is a non-whitespace ASCII char
-    uint32_t e = len;
-    {
-        uint32_t l0, l1;
-        load8(T, base + len - 1u, &l0, &l1);
-        uint32_t last = l0 & 0xFFu;
-        if (!(last > 0x20u && last < 0x80u)) {
-            LdsReader rd(T.w, base);
-            e = trim_end(rd, 0u, len);
-        }
-    }
-    r.off[S_FULL] = 0;
-    r.len[S_FULL] = e;
-    // trim_start after the '-': common case = one ' ' then a non-whitespace ASCII char
-    uint32_t s = d0 + 1u;
-    {
-        uint32_t cA = (m0 >> 8) & 0xFFu, cB = (m0 >> 16) & 0xFFu;
-        if (s + 1u < len && cA == ' ' && cB > 0x20u && cB < 0x80u) {
-            s += 1u;
-        } else if (s < len && cA > 0x20u && cA < 0x80u) {
-            // "-x": message starts right after the dash
-        } else {
-            LdsReader rd(T.w, base);
-            s = trim_start(rd, s, len);
-        }
-    }
-    if (e > s) {
-        r.off[S_MSG] = s;
-        r.len[S_MSG] = e - s;
-    }
-    return true;
+    const uint32_t last = l0 & 0xFFu;
+    const bool end_plain = last > 0x20u && last < 0x80u;
+    f.e = len;
+    // trim_start after the '-': common case = one ' ' then a non-whitespace ASCII char, or "-x"
+    const uint32_t cA = (m0 >> 8) & 0xFFu, cB = (m0 >> 16) & 0xFFu;
+    const uint32_t s = d0 + 1u;
+    const bool one_sp = s + 1u < len && cA == ' ' && cB > 0x20u && cB < 0x80u;
+    const bool no_sp = s < len && cA > 0x20u && cA < 0x80u;
+    f.s = one_sp ? s + 1u : s;
+    f.route |= (live && c == '-' && !(end_plain && (one_sp || no_sp))) ? R_TRIM : 0u;
+    return f;
 }
 
-// One wave per 64-line group.  Dynamic LDS: [tile_cap + 64 bytes of data][bitmap: 2 B per 16 B].
-template <int BATCH>
-__global__ __launch_bounds__(kWave) void k_rfc5424(const uint8_t* __restrict__ bytes,
-                                                  const uint64_t* __restrict__ offsets, uint64_t n,
-                                                  DevTables t, uint32_t tile_cap) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint16_t* bm16 = reinterpret_cast<uint16_t*>(smem + tile_cap + 64u);
+// 16-bit mask (bit i = byte i of v equals 0x20) via exact SWAR zero-byte test + v_dot4_u32_u8 as
+// the bit gather: flags are 0x80 per matching byte, the weights 1,2,4,8 / 16..128 place them.
+__device__ __forceinline__ uint32_t eq20_flags(uint32_t x) {
+    uint32_t s = ((x & 0x7F7F7F7Fu) ^ 0x20202020u) + 0x7F7F7F7Fu;  // bit7 set <=> low 7 bits != 0x20
+    return ~(s | x) & 0x80808080u;                                   // bit7 set <=> byte == 0x20
+}
+__device__ __forceinline__ uint32_t space_mask16_dot(const uint4& v) {
+    uint32_t lo = __builtin_amdgcn_udot4(eq20_flags(v.y), 0x80402010u,
+                                         __builtin_amdgcn_udot4(eq20_flags(v.x), 0x08040201u, 0u, false), false);
+    uint32_t hi = __builtin_amdgcn_udot4(eq20_flags(v.w), 0x80402010u,
+                                         __builtin_amdgcn_udot4(eq20_flags(v.z), 0x08040201u, 0u, false), false);
+    return (lo >> 7) | (hi << 1);
+}
+
+// Stage B + SD entries + table row for ONE line group whose tile is in LDS (shared by both
+// kernels).  o0/o1 = this lane's line [o0, o1) in the packed buffer, a0 = packed-buffer address
+// of tile byte 0, span = tile bytes staged.
+struct RowOut {
+    uint32_t meta;
+    double ts;
+    fg_span span[6];
+    uint32_t first, count;
+};
+__device__ __forceinline__ void store_row(const DevTables& t, uint64_t li, const RowOut& o) {
+    t.meta[li] = o.meta;
+    t.ts[li] = o.ts;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) t.span[k][li] = o.span[k];
+    t.ent_first[li] = o.first;
+    t.ent_count[li] = o.count;
+}
+__device__ __forceinline__ RowOut decode_group(const uint8_t* __restrict__ bytes, const uint8_t* smem,
+                                               const uint16_t* bm16, uint64_t o0, uint64_t o1, uint64_t a0,
+                                               uint32_t span, bool valid, const DevTables& t) {
     const uint32_t lane = threadIdx.x;
-    const uint64_t l0 = (uint64_t)blockIdx.x * kWave;
-    const uint64_t li = l0 + lane;
-    const bool valid = li < n;
-    const uint64_t last = (l0 + kWave < n) ? l0 + kWave : n;
-    const uint64_t o0 = offsets[valid ? li : last];
-    const uint64_t o1 = offsets[valid ? li + 1 : last];
-    const uint64_t lo = __shfl(o0, 0, kWave);
-    const uint64_t hi = __shfl(o1, (int)(last - l0 - 1), kWave);
-    const uint64_t a0 = lo & ~15ull;
-    const uint64_t want = hi - a0;
-    const uint32_t span = want > tile_cap ? tile_cap : (uint32_t)((want + 15ull) & ~15ull);
-
-    // ---- stage A: stream [a0, a0+span) through registers into LDS, classify on the way ----
-    {
-        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(bytes + a0);
-        uint4* dst = reinterpret_cast<uint4*>(smem);
-        const uint32_t nchunk = span >> 4;
-        for (uint32_t c0 = 0; c0 < nchunk; c0 += kWave * BATCH) {
-            uint4 v[BATCH];
-#pragma unroll
-            for (int k = 0; k < BATCH; ++k) {
-                uint32_t idx = c0 + k * kWave + lane;
-                if (idx < nchunk) v[k] = src[idx];
-            }
-#pragma unroll
-            for (int k = 0; k < BATCH; ++k) {
-                uint32_t idx = c0 + k * kWave + lane;
-                if (idx < nchunk) {
-                    dst[idx] = v[k];
-                    bm16[idx] = (uint16_t)space_mask16(v[k]);
-                }
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- stage B: lane-per-line tokenisation ------------------------------------------------
     Row r;
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
@@ -628,10 +575,39 @@ __global__ __launch_bounds__(kWave) void k_rfc5424(const uint8_t* __restrict__ b
     const uint32_t base = (uint32_t)(o0 - a0);
     Tile T{reinterpret_cast<const uint32_t*>(smem), reinterpret_cast<const uint32_t*>(bm16)};
     if (valid) {
-        bool done = false;
-        if (in_tile) done = parse_line_fast(T, base, len, r, t);
-        if (!done) {
-            // reset whatever the fast path touched before giving up
+        uint32_t route = R_GENERIC;
+        if (in_tile) {
+            const Fast f = parse_line_fast(T, base, len, r);
+            route = f.route;
+            if (!(route & R_GENERIC)) {
+                if (route & R_TS_SLOW) {  // rare
+                    LdsReader rd(T.w, base);
+                    bool ok = parse_rfc3339(rd, f.t0, f.te, &r.ts);
+                    r.status = f.no_ts ? E_NOTS : ok ? f.rest : E_BADTS;
+                } else {
+                    r.status = f.no_ts ? E_NOTS : f.ts_ok ? f.rest : E_BADTS;
+                }
+                if (r.status == E_OK) {
+                    if (route & R_TAIL) {  // structured data (every line of an SD corpus) or garbage
+                        LdsReader rd(T.w, base);
+                        parse_tail(rd, f.d0, 0u, len, r, t);
+                    } else {
+                        uint32_t e = f.e, s0 = f.s;
+                        if (route & R_TRIM) {  // rare
+                            LdsReader rd(T.w, base);
+                            e = trim_end(rd, 0u, len);
+                            s0 = trim_start(rd, f.d0 + 1u, len);
+                        }
+                        r.data0 = f.d0;
+                        r.off[S_FULL] = 0;
+                        r.len[S_FULL] = e;
+                        r.off[S_MSG] = e > s0 ? s0 : 0u;
+                        r.len[S_MSG] = e > s0 ? e - s0 : FG_NONE;
+                    }
+                }
+            }
+        }
+        if (route & R_GENERIC) {  // rare: anything the fast path does not recognise, or a line outside the tile
             r = Row();
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
@@ -675,39 +651,321 @@ __global__ __launch_bounds__(kWave) void k_rfc5424(const uint8_t* __restrict__ b
         }
     }
 
-    // ---- table row: one coalesced store per column ------------------------------------------
-    if (valid) {
-        const bool ok = r.status == E_OK;
-        t.meta[li] = r.status | (r.facility << 8) | (r.severity << 16) | (r.flags << 24);
-        t.ts[li] = ok ? r.ts : 0.0;
+    // ---- table row (stored by the caller: one coalesced store per column) --------------------
+    RowOut o;
+    const bool ok = r.status == E_OK;
+    o.meta = r.status | (r.facility << 8) | (r.severity << 16) | (r.flags << 24);
+    o.ts = ok ? r.ts : 0.0;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) t.span[k][li] = ok ? fg_span{r.off[k], r.len[k]} : fg_span{0, FG_NONE};
-        t.ent_first[li] = first;
-        t.ent_count[li] = r.n_ent;
+    for (int k = 0; k < 6; ++k) o.span[k] = ok ? fg_span{r.off[k], r.len[k]} : fg_span{0, FG_NONE};
+    o.first = first;
+    o.count = r.n_ent;
+    return o;
+}
+
+// v2: one wave per 64-line group, one group per wave (kept for A/B and as the simple form).
+// Dynamic LDS: [tile_cap + 64 bytes of data][bitmap: 2 B per 16 B].
+template <int BATCH>
+__global__ __launch_bounds__(kWave) void k_rfc5424(const uint8_t* __restrict__ bytes,
+                                                  const uint64_t* __restrict__ offsets, uint64_t n,
+                                                  DevTables t, uint32_t tile_cap) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint16_t* bm16 = reinterpret_cast<uint16_t*>(smem + tile_cap + 64u);
+    const uint32_t lane = threadIdx.x;
+    const uint64_t l0 = (uint64_t)blockIdx.x * kWave;
+    const uint64_t li = l0 + lane;
+    const bool valid = li < n;
+    const uint64_t last = (l0 + kWave < n) ? l0 + kWave : n;
+    const uint64_t o0 = offsets[valid ? li : last];
+    const uint64_t o1 = offsets[valid ? li + 1 : last];
+    const uint64_t lo = __shfl(o0, 0, kWave);
+    const uint64_t hi = __shfl(o1, (int)(last - l0 - 1), kWave);
+    const uint64_t a0 = lo & ~15ull;
+    const uint64_t want = hi - a0;
+    const uint32_t span = want > tile_cap ? tile_cap : (uint32_t)((want + 15ull) & ~15ull);
+
+    // ---- stage A: stream [a0, a0+span) through registers into LDS, classify on the way ----
+    {
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(bytes + a0);
+        uint4* dst = reinterpret_cast<uint4*>(smem);
+        const uint32_t nchunk = span >> 4;
+        for (uint32_t c0 = 0; c0 < nchunk; c0 += kWave * BATCH) {
+            uint4 v[BATCH];
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k) {
+                uint32_t idx = c0 + k * kWave + lane;
+                if (idx < nchunk) v[k] = src[idx];
+            }
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k) {
+                uint32_t idx = c0 + k * kWave + lane;
+                if (idx < nchunk) {
+                    dst[idx] = v[k];
+                    bm16[idx] = (uint16_t)space_mask16(v[k]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    RowOut o = decode_group(bytes, smem, bm16, o0, o1, a0, span, valid, t);
+    if (valid) store_row(t, li, o);
+}
+
+// v3 (default): PERSISTENT waves with a register-resident prefetch window.
+//   Each wave walks line groups g = blockIdx.x, +gridDim.x, ...  (L lines per group, L = 64 for
+//   ~256-byte lines, smaller powers of two for longer lines so that a group's bytes fit the tile).
+//   While the lanes tokenise group g out of LDS (stage B), the bytes of group g+G are already on
+//   their way from HBM into NB x 16 B of VGPRs per lane (NB KiB per wave) and the offsets of
+//   group g+2G behind them, so every resident wave keeps ~NB KiB of HBM reads in flight all the
+//   time -- the VGPR file (512 KiB/CU, almost unused by this integer kernel) is the second buffer,
+//   LDS holds one tile per wave.  Bytes beyond the NB KiB window (rare: the window is sized for
+//   the average group + 12.5 %) are staged by a plain tail loop.
+//   PROF = true is a measurement build of the same kernel: s_memtime stamps at the phase
+//   boundaries, summed per wave and added to prof[0..4] = {wait-for-window, stage A, stores +
+//   prefetch issue, stage B, iterations} (FG_PROF=1, see the launcher).  Never the product path.
+template <int NB, bool PROF>
+__global__ __launch_bounds__(kWave, 2) void k_rfc5424_p(const uint8_t* __restrict__ bytes,
+                                                    const uint64_t* __restrict__ offsets, uint64_t n,
+                                                    DevTables t, uint32_t tile_cap, uint32_t L,
+                                                    uint64_t groups, unsigned long long* prof) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint16_t* bm16 = reinterpret_cast<uint16_t*>(smem + tile_cap + 64u);
+    uint4* dst = reinterpret_cast<uint4*>(smem);
+    const uint32_t lane = threadIdx.x;
+    const uint64_t G = gridDim.x;
+
+    // group geometry from the lanes' offsets, as SCALARS: tile start (16-byte aligned) + staged span
+    auto geometry = [&](uint64_t g, uint64_t o0, uint64_t o1, uint64_t* a0, uint32_t* span) {
+        const uint64_t l0 = g * L;
+        const uint32_t nl = (uint32_t)((l0 + L <= n) ? L : n - l0);
+        // (the builtins return int: widen through uint32_t or bit 31 sign-extends into the high word)
+        const uint32_t last = (uint32_t)__builtin_amdgcn_readfirstlane((int)(nl - 1u));
+        const uint32_t lo_l = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)o0);
+        const uint32_t lo_h = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(o0 >> 32));
+        const uint32_t hi_l = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)o1, (int)last);
+        const uint32_t hi_h = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(o1 >> 32), (int)last);
+        const uint64_t lo = (uint64_t)lo_l | ((uint64_t)lo_h << 32);
+        const uint64_t hi = (uint64_t)hi_l | ((uint64_t)hi_h << 32);
+        *a0 = lo & ~15ull;
+        const uint64_t want = hi - *a0;
+        *span = want > tile_cap ? tile_cap : (uint32_t)((want + 15ull) & ~15ull);
+    };
+    auto load_offsets = [&](uint64_t g, uint64_t* o0, uint64_t* o1) {
+        const uint64_t l0 = g * L;
+        uint64_t li = l0 + lane;
+        const uint64_t last = (l0 + L < n) ? l0 + L : n;
+        const bool valid = lane < L && li < n;
+        *o0 = offsets[valid ? li : last];
+        *o1 = offsets[valid ? li + 1 : last];
+    };
+    // the register window: NB buffer loads of 16 B per lane; the buffer descriptor bounds the
+    // tile, so rows past `span` fetch nothing and return zeros -- no per-row predication.  The
+    // row offset goes into the VGPR/immediate offset (the part the hardware range-checks; the
+    // scalar offset is not checked).
+    auto load_window = [&](uint64_t a0, uint32_t span, u32x4* v) {
+        __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(bytes + a0), (short)0, (int)span, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(lane * 16u + k * 1024u), 0, 0);
+    };
+
+    uint64_t g = blockIdx.x;
+    if (g >= groups) return;
+    uint64_t o0, o1, a0;
+    uint32_t span;
+    load_offsets(g, &o0, &o1);
+    geometry(g, o0, o1, &a0, &span);
+    u32x4 v[NB];
+    load_window(a0, span, v);
+    uint64_t no0 = 0, no1 = 0;
+    if (g + G < groups) load_offsets(g + G, &no0, &no1);
+    // The table row of a group is stored one iteration LATE (after the next group's stage A,
+    // before the prefetch after that is issued): vmcnt retires in order, so stores issued
+    // behind the window loads would have to be waited for at the top of every iteration.
+    RowOut pend{};
+    uint64_t pend_li = 0;
+    bool pend_valid = false;
+    uint64_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0, iters = 0, tm0 = 0, tm1 = 0, tm2 = 0, tm3 = 0;
+    // measurement build only: prof[5] = ablation flags (1 = no table stores, 2 = no stage B)
+    const uint32_t ablate = PROF ? (uint32_t)prof[5] : 0u;
+
+    for (;;) {
+        if (PROF) {
+            tm0 = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the window has landed
+            tm1 = __builtin_amdgcn_s_memtime();
+        }
+        // ---- stage A for group g: registers -> LDS, classify on the way ----------------------
+        const uint32_t nchunk = span >> 4;
+        const uint32_t nrow = (nchunk + kWave - 1u) / kWave;  // wave-uniform
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            if ((uint32_t)k < nrow) {  // scalar branch; lanes past the span store zeros inside the tile
+                uint32_t idx = k * kWave + lane;
+                uint4 q = make_uint4(v[k][0], v[k][1], v[k][2], v[k][3]);
+                dst[idx] = q;
+                bm16[idx] = (uint16_t)space_mask16_dot(q);
+            }
+        }
+        if (nrow > (uint32_t)NB) {  // rare: bytes beyond the register window
+            const uint4* __restrict__ src = reinterpret_cast<const uint4*>(bytes + a0);
+            for (uint32_t c0 = NB * kWave; c0 < nchunk; c0 += kWave * 4) {
+                uint4 w[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    uint32_t idx = c0 + k * kWave + lane;
+                    if (idx < nchunk) w[k] = src[idx];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    uint32_t idx = c0 + k * kWave + lane;
+                    if (idx < nchunk) {
+                        dst[idx] = w[k];
+                        bm16[idx] = (uint16_t)space_mask16_dot(w[k]);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the old window dead before the new one is loaded
+        if (PROF) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): LDS writes retired
+            tm2 = __builtin_amdgcn_s_memtime();
+        }
+        if (pend_valid && !(ablate & 1u)) store_row(t, pend_li, pend);
+        // ---- prefetch: offsets of g+2G first (they must not queue behind the data), then the
+        //      bytes of g+G into the register window ------------------------------------------
+        const uint64_t gn = g + G;
+        const bool more = gn < groups;  // wave-uniform
+        uint64_t po0 = no0, po1 = no1, pa0 = 0;
+        uint32_t pspan = 0;
+        if (more) {
+            if (gn + G < groups) load_offsets(gn + G, &no0, &no1);
+            geometry(gn, po0, po1, &pa0, &pspan);
+            load_window(pa0, pspan, v);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (PROF) tm3 = __builtin_amdgcn_s_memtime();
+        __syncthreads();  // single-wave workgroup: orders the LDS writes before stage B's reads
+        // ---- stage B for group g ------------------------------------------------------------
+        if (!(ablate & 2u)) {
+            const uint64_t li = g * L + lane;
+            const bool valid = lane < L && li < n;
+            pend = decode_group(bytes, smem, bm16, o0, o1, a0, span, valid, t);
+            pend_li = li;
+            pend_valid = valid;
+        }
+        if (PROF) {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            uint64_t tm4 = __builtin_amdgcn_s_memtime();
+            acc0 += tm1 - tm0;
+            acc1 += tm2 - tm1;
+            acc2 += tm3 - tm2;
+            acc3 += tm4 - tm3;
+            iters += 1;
+        }
+        if (!more) break;
+        __syncthreads();  // stage B's LDS reads are done before the next tile overwrites them
+        g = gn;
+        o0 = po0;
+        o1 = po1;
+        a0 = pa0;
+        span = pspan;
+    }
+    if (pend_valid && !(ablate & 1u)) store_row(t, pend_li, pend);
+    if (PROF && lane == 0) {
+        atomicAdd(&prof[0], (unsigned long long)acc0);
+        atomicAdd(&prof[1], (unsigned long long)acc1);
+        atomicAdd(&prof[2], (unsigned long long)acc2);
+        atomicAdd(&prof[3], (unsigned long long)acc3);
+        atomicAdd(&prof[4], (unsigned long long)iters);
     }
 }
 
 }  // namespace fg
 
 // host-side launcher (called from fg_capi.cpp).  tile_cap: multiple of 1024.
+//   FG_RFC5424_KERNEL=v2 selects the one-group-per-wave kernel (A/B); default = persistent v3.
+namespace {
+constexpr int kWindowKiB = 20;  // register prefetch window per wave (NB): 80 VGPRs
+struct PersistPlan {
+    int blocks_per_cu = 0;
+    int cus = 0;
+};
+}  // namespace
+
 extern "C" int fg_launch_rfc5424(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n,
                                  const fg::DevTables* t, uint32_t tile_cap, hipStream_t stream) {
     if (n == 0) return 0;
-    uint64_t groups = (n + fg::kWave - 1) / fg::kWave;
-    if (groups > 0x7FFFFFFFull) return -1;
-    uint32_t lds = tile_cap + 64u + (tile_cap / 16u + 16u) * 2u;
-    // loads in flight per lane during stage A (tuning knob; 16 B each)
-    static int batch = [] {
-        const char* e = getenv("FG_BATCH");
-        return e ? atoi(e) : 8;
-    }();
-    dim3 grid((uint32_t)groups), block(fg::kWave);
-    switch (batch) {
-        case 4: hipLaunchKernelGGL(fg::k_rfc5424<4>, grid, block, lds, stream, d_bytes, d_offsets, n, *t, tile_cap); break;
-        case 12: hipLaunchKernelGGL(fg::k_rfc5424<12>, grid, block, lds, stream, d_bytes, d_offsets, n, *t, tile_cap); break;
-        case 16: hipLaunchKernelGGL(fg::k_rfc5424<16>, grid, block, lds, stream, d_bytes, d_offsets, n, *t, tile_cap); break;
-        case 20: hipLaunchKernelGGL(fg::k_rfc5424<20>, grid, block, lds, stream, d_bytes, d_offsets, n, *t, tile_cap); break;
-        default: hipLaunchKernelGGL(fg::k_rfc5424<8>, grid, block, lds, stream, d_bytes, d_offsets, n, *t, tile_cap); break;
+    // tuning / A-B knobs are read per launch (getenv is nanoseconds next to a launch) so that the
+    // parity tests can sweep them inside one process
+    const char* e_ver = getenv("FG_RFC5424_KERNEL");
+    const int kernel_ver = (e_ver && e_ver[0] == 'v' && e_ver[1] == '2') ? 2 : 3;
+    dim3 block(fg::kWave);
+    if (kernel_ver == 2) {
+        uint64_t groups = (n + fg::kWave - 1) / fg::kWave;
+        if (groups > 0x7FFFFFFFull) return -1;
+        uint32_t lds = tile_cap + 64u + (tile_cap / 16u + 16u) * 2u;
+        dim3 grid((uint32_t)groups);
+        hipLaunchKernelGGL(fg::k_rfc5424<8>, grid, block, lds, stream, d_bytes, d_offsets, n, *t, tile_cap);
+        return (int)hipGetLastError();
     }
+    // lines per group: the host sized tile_cap for 64 average lines (+12.5 %), capped by LDS; when
+    // that cap bit (long lines) halve L until a group's expected bytes fit the register window.
+    // tile_cap encodes the average: avg ~= (tile_cap - 512) * 8 / 9 / 64 unless capped.
+    uint32_t L = 64;
+    uint32_t tile = tile_cap;
+    {
+        const char* e_l = getenv("FG_LINES_PER_GROUP");
+        const uint32_t forced = e_l ? (uint32_t)atoi(e_l) : 0u;
+        while (tile > (uint32_t)kWindowKiB * 1024u && L > 1) {
+            L >>= 1;
+            tile = ((tile / 2u + 1023u) / 1024u) * 1024u;
+        }
+        if (tile < 4096u) tile = 4096u;
+        if (forced >= 1 && forced <= 64 && (forced & (forced - 1)) == 0) {
+            L = forced;
+            tile = tile_cap;
+        }
+    }
+    const uint64_t groups = (n + L - 1) / L;
+    const uint32_t lds = tile + 64u + (tile / 16u + 16u) * 2u;
+    auto kern = fg::k_rfc5424_p<kWindowKiB, false>;
+    static int cus = 0;
+    int dev = 0;
+    if (cus == 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+        cus = prop.multiProcessorCount;
+    }
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, fg::kWave, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    const char* e_w = getenv("FG_WAVES_PER_CU");
+    const int waves_cap = e_w ? atoi(e_w) : 0;
+    if (waves_cap > 0 && per_cu > waves_cap) per_cu = waves_cap;
+    uint64_t nblocks = (uint64_t)per_cu * (uint64_t)cus;
+    if (nblocks > groups) nblocks = groups;
+    dim3 grid((uint32_t)nblocks);
+    if (getenv("FG_PROF")) {
+        // measurement build: synchronous, prints the per-phase cycle split to stderr
+        unsigned long long* d_prof = nullptr;
+        unsigned long long h[6] = {0, 0, 0, 0, 0, 0};
+        if (const char* e_a = getenv("FG_ABLATE")) h[5] = (unsigned long long)atoi(e_a);
+        if (hipMalloc((void**)&d_prof, sizeof(h)) != hipSuccess) return -1;
+        (void)hipMemcpyAsync(d_prof, h, sizeof(h), hipMemcpyHostToDevice, stream);
+        hipLaunchKernelGGL((fg::k_rfc5424_p<kWindowKiB, true>), grid, block, lds, stream, d_bytes, d_offsets, n, *t, tile, L,
+                           groups, d_prof);
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost);
+        (void)hipFree(d_prof);
+        const double it = h[4] ? (double)h[4] : 1.0;
+        fprintf(stderr,
+                "[fg prof] rfc5424 v3: grid %u x64, L %u, tile %u, iters/wave %.1f | cycles per iteration: wait %.0f, "
+                "stageA %.0f, stores+prefetch-issue %.0f, stageB %.0f\n",
+                (unsigned)nblocks, L, tile, it / (double)nblocks, h[0] / it, h[1] / it, h[2] / it, h[3] / it);
+        return (int)hipGetLastError();
+    }
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, d_bytes, d_offsets, n, *t, tile, L, groups,
+                       (unsigned long long*)nullptr);
     return (int)hipGetLastError();
 }

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: scripts_prof.sh <tag> [bench args...]  -- kernel trace + PMC passes of bench.py under rocprofv3;
+# usage: tools/prof.sh <tag> [bench args...]  -- kernel trace + PMC passes of bench.py under rocprofv3;
 # leaves only a condensed summary (gpurun_out/prof_<tag>.json) -- raw traces are deleted.
 TAG=$1; shift
 ROOT=$(pwd)
