@@ -36,13 +36,27 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--tile-lines", type=int, default=1_000_000)
     ap.add_argument("--reps", type=int, default=100, help="tile replicas resident per GPU")
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4"])
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5", "ltsv"],
+                    help="cfg2 = the BASELINE metric's configuration (default); the others time the remaining "
+                         "kernels on their parity-test corpora (not bench lines, see DESIGN.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--line-len", type=int, nargs=2, default=None, metavar=("LO", "HI"),
+                    help="cfg2 only: uniform line-length range instead of 192..320 (tuning experiments)")
     ap.add_argument("--invalid-frac", type=float, default=0.01, help="share of invalid lines in the tile (SURVEY 8d: 1 %%)")
     return ap.parse_args()
 
 
-def cpu_baseline(data, offsets, n_lines):
+WORKLOADS = {
+    # name: (format id, description)
+    "cfg2": (0, "BASELINE configs[1]: RFC5424 no structured data"),
+    "cfg4": (0, "BASELINE configs[3] shape: RFC5424 with structured data (~12 pairs)"),
+    "cfg5": (0, "BASELINE configs[4] shape: RFC5424, log-uniform 64 B..8 KiB lines with structured data"),
+    "cfg3": (2, "BASELINE configs[2]: GELF/JSON, 8 flat extra fields"),
+    "ltsv": (1, "LTSV, typed schema (the LTSV half of BASELINE configs[4])"),
+}
+
+
+def cpu_baseline(fmt, data, offsets, n_lines, cfg=None):
     """Oracle timing leg (the ONLY place bench.py touches oracle/)."""
     sys.path.insert(0, str(ROOT / "tests"))
     import oracle_binding
@@ -52,7 +66,7 @@ def cpu_baseline(data, offsets, n_lines):
     passes, secs, n_ok = 0, 0.0, 0
     t_end = time.time() + 4.0
     while passes < 2 or (time.time() < t_end and passes < 8):
-        s, n_ok = o.bench(0, data, offsets, cores)
+        s, n_ok = o.bench(fmt, data, offsets, cores, cfg)
         secs += s
         passes += 1
     return {
@@ -67,7 +81,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from flowgger_amd import RFC5424Decoder, synth
+    from flowgger_amd import GelfDecoder, LTSVDecoder, RFC5424Decoder, synth
     from flowgger_amd.tables import DeviceTables
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -83,8 +97,18 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     # ---- synthetic batch, resident in HBM -------------------------------------------------
-    sd = args.workload == "cfg4"
-    lines = synth.rfc5424_lines(args.tile_lines, cfg=4 if sd else 2, sd=sd, invalid_frac=args.invalid_frac)
+    wl = args.workload
+    fmt, wl_desc = WORKLOADS[wl]
+    sd = wl in ("cfg4", "cfg5")
+    if wl == "cfg3":
+        lines = synth.gelf_lines(args.tile_lines, invalid_frac=args.invalid_frac)
+    elif wl == "ltsv":
+        lines = synth.ltsv_lines(args.tile_lines, invalid_frac=args.invalid_frac)
+    elif wl == "cfg5":
+        lines = synth.rfc5424_lines(args.tile_lines, cfg=5, sd=True, invalid_frac=args.invalid_frac, long_tail=True)
+    else:
+        kw = {"lo": args.line_len[0], "hi": args.line_len[1]} if (args.line_len and not sd) else {}
+        lines = synth.rfc5424_lines(args.tile_lines, cfg=4 if sd else 2, sd=sd, invalid_frac=args.invalid_frac, **kw)
     data, offsets = synth.pack(lines)
     n_tile, tile_bytes = len(lines), int(offsets[-1])
     del lines
@@ -96,9 +120,10 @@ def main():
     base = torch.arange(reps, device=dev, dtype=torch.int64).repeat_interleave(n_tile) * tile_bytes
     d_offsets = torch.cat([o.repeat(reps) + base, torch.tensor([tile_bytes * reps], device=dev, dtype=torch.int64)])
     del base, o, raw
-    ent_cap = (tile_bytes * reps // 10 if sd else 0) + 4096
+    ent_cap = (tile_bytes * reps // 8 if wl != "cfg2" else 0) + 4096
     tables = DeviceTables(n, ent_cap, dev)
-    dec = RFC5424Decoder(device=local)
+    dec = (GelfDecoder(device=local) if fmt == 2 else LTSVDecoder(synth.LTSV_CONFIG, device=local) if fmt == 1
+           else RFC5424Decoder(device=local))
     stream = torch.cuda.current_stream(dev)
 
     def step():
@@ -147,8 +172,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {
-                "workload": ("BASELINE configs[1]: RFC5424 no structured data" if not sd else
-                             "BASELINE configs[3] shape: RFC5424 with structured data") +
+                "workload": wl_desc +
                             f", {n} lines/GPU @ {tile_bytes / n_tile:.0f} B avg ({n_tile}-line tile x{reps} resident in HBM), "
                             f"{args.invalid_frac * 100:g}% invalid lines",
                 "lines_per_gpu": n, "bytes_per_gpu": tile_bytes * reps,
@@ -158,7 +182,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                "kernel": "fg::k_rfc5424", "kernel_ms": kernel_ms,
+                "kernel": ("fg::k_rfc5424_p", "fg::k_ltsv", "fg::k_gelf")[fmt], "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_launch": alg_read + alg_written,
                 "read_only_frac": alg_read / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             },
@@ -172,7 +196,7 @@ def main():
             except Exception:
                 pass
         if world == 1 and not args.no_cpu_baseline:
-            cb, n_ok_cpu = cpu_baseline(data, offsets, n_tile)
+            cb, n_ok_cpu = cpu_baseline(fmt, data, offsets, n_tile, synth.LTSV_CONFIG if fmt == 1 else None)
             assert n_ok_cpu == n_ok_tile, f"GPU Ok count {n_ok_tile} != oracle Ok count {n_ok_cpu}"
             out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)

@@ -30,7 +30,9 @@ struct LtsvDevCfg {
 }  // namespace fg
 
 extern "C" int fg_launch_rfc5424(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n,
-                                 const fg::DevTables* t, uint32_t tile_cap, hipStream_t stream);
+                                 const fg::DevTables* t, uint32_t tile_cap, hipStream_t stream, uint64_t* stash,
+                                 uint32_t stash_blocks);
+extern "C" uint64_t fg_rfc5424_stash_bytes(uint32_t blocks);
 extern "C" int fg_launch_ltsv(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
                               const fg::LtsvDevCfg* cfg, uint32_t tile_cap, hipStream_t stream);
 extern "C" int fg_launch_gelf(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
@@ -49,6 +51,10 @@ struct fg_ctx {
     std::string suffix[4];
     bool has_suffix[4] = {false, false, false, false};
     uint8_t* d_cfg = nullptr;  // device copy of the LTSV configuration (blob | name_off | types)
+    // RFC5424: per-wave scratch where structured-data entries are parked between the parse and the
+    // copy into the entry table (allocated on the first RFC5424 call; sized for 8 waves on every CU)
+    uint64_t* d_stash = nullptr;
+    uint32_t stash_blocks = 0;
     fg::LtsvDevCfg ltsv{};
     // staging for fg_decode_batch
     uint8_t* d_bytes = nullptr;
@@ -334,6 +340,7 @@ void fg_destroy(fg_ctx* ctx) {
     if (ctx->d_offsets) (void)hipFree(ctx->d_offsets);
     if (ctx->d_tab) (void)hipFree(ctx->d_tab);
     if (ctx->d_cfg) (void)hipFree(ctx->d_cfg);
+    if (ctx->d_stash) (void)hipFree(ctx->d_stash);
     if (ctx->h_tab) (void)hipHostFree(ctx->h_tab);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -379,7 +386,15 @@ int fg_decode_batch_device(fg_ctx* ctx, fg_format fmt, const uint8_t* d_bytes, u
     int rc;
     switch (fmt) {
         case FG_RFC5424:
-            rc = fg_launch_rfc5424(d_bytes, d_offsets, n, &dt, pick_tile_cap(nbytes, n, 57344), s);
+            if (!ctx->d_stash) {
+                hipDeviceProp_t prop;
+                FG_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+                uint32_t blocks = 8u * (uint32_t)prop.multiProcessorCount;
+                FG_HIP(ctx, hipMalloc((void**)&ctx->d_stash, fg_rfc5424_stash_bytes(blocks)));
+                ctx->stash_blocks = blocks;
+            }
+            rc = fg_launch_rfc5424(d_bytes, d_offsets, n, &dt, pick_tile_cap(nbytes, n, 57344), s, ctx->d_stash,
+                                   ctx->stash_blocks);
             break;
         case FG_LTSV:
             rc = fg_launch_ltsv(d_bytes, d_offsets, n, &dt, &ctx->ltsv, pick_tile_cap(nbytes, n, 63488), s);

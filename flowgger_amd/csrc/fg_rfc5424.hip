@@ -356,6 +356,7 @@ struct Fast {
     uint32_t rest;     // status of everything after the timestamp (E_OK / E_NOHOST.. / E_NOMSG)
     uint32_t t0, te;   // timestamp part [t0, te)
     uint32_t d0;       // index of part 7
+    uint32_t c7;       // its first byte
     uint32_t e, s;     // message end / start after the cheap trims
 };
 
@@ -513,6 +514,7 @@ __device__ __forceinline__ Fast parse_line_fast(const Tile& T, uint32_t base, ui
     uint32_t m0, m1;
     load8(T, base + (d0 < len ? d0 : 0u), &m0, &m1);
     const uint32_t c = m0 & 0xFFu;
+    f.c7 = c;
     const bool live = !f.no_ts && f.rest == E_OK;  // (the timestamp verdict may still come later)
     f.route |= (live && c != '-') ? R_TAIL : 0u;
     // trim_end of the whole line: common case = last byte is a non-whitespace ASCII char
@@ -543,6 +545,282 @@ __device__ __forceinline__ uint32_t space_mask16_dot(const uint4& v) {
     return (lo >> 7) | (hi << 1);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Structured data out of the tile (the hot form; the byte-walking sd_walk above stays for lines
+// outside the tile and for the generic route).
+//
+// Most SD bytes are VALUE bytes, and inside a value only '"' and '\' matter
+// (rfc5424_decoder.rs:206-219).  When a group contains SD lines the wave turns the space bitmap
+// -- the fast path is finished with it by then -- into a bitmap of those two characters, and the
+// per-lane walker jumps over every value with one bit scan instead of walking it byte by byte;
+// names, '=' and separators (a handful of bytes per pair) are still walked.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t eq_flags(uint32_t x, uint32_t pat) {  // bit7 of each byte: byte == pat's byte (pat < 0x80)
+    uint32_t s = ((x & 0x7F7F7F7Fu) ^ pat) + 0x7F7F7F7Fu;
+    return ~(s | x) & 0x80808080u;
+}
+__device__ __forceinline__ uint32_t quote_mask16(const uint4& v) {
+    const uint32_t Q = 0x22222222u, B = 0x5C5C5C5Cu;
+    uint32_t f0 = eq_flags(v.x, Q) | eq_flags(v.x, B), f1 = eq_flags(v.y, Q) | eq_flags(v.y, B);
+    uint32_t f2 = eq_flags(v.z, Q) | eq_flags(v.z, B), f3 = eq_flags(v.w, Q) | eq_flags(v.w, B);
+    uint32_t lo = __builtin_amdgcn_udot4(f1, 0x80402010u, __builtin_amdgcn_udot4(f0, 0x08040201u, 0u, false), false);
+    uint32_t hi = __builtin_amdgcn_udot4(f3, 0x80402010u, __builtin_amdgcn_udot4(f2, 0x08040201u, 0u, false), false);
+    return (lo >> 7) | (hi << 1);
+}
+// wave-cooperative: bm16[c] = quote/backslash mask of tile chunk c for c < nchunk (overwrites the
+// space bitmap).  Caller brackets it with wave barriers.
+__device__ __forceinline__ void build_quote_bitmap(const uint8_t* smem, uint16_t* bm16, uint32_t nchunk) {
+    const uint4* src = reinterpret_cast<const uint4*>(smem);
+    for (uint32_t c = threadIdx.x; c < nchunk; c += kWave) bm16[c] = (uint16_t)quote_mask16(src[c]);
+}
+// first set bit of the tile bitmap at line index >= q, or len
+__device__ __forceinline__ uint32_t find_bit(const uint32_t* bm, uint32_t base, uint32_t q, uint32_t len) {
+    while (q < len) {
+        uint32_t a = base + q;
+        uint32_t w = bm[a >> 5] >> (a & 31u);
+        if (w) {
+            uint32_t r = q + (uint32_t)__builtin_ctz(w);
+            return r < len ? r : len;
+        }
+        q += 32u - (a & 31u);
+    }
+    return len;
+}
+__device__ __forceinline__ bool is_sd_name_char(uint32_t c) {  // :188-192
+    return (c - 33u) <= 93u && c != '"' && c != '=' && c != ']';
+}
+// 16-bit class masks of a 16-byte window (bit i <=> byte i), from exact SWAR byte tests gathered
+// with v_dot4_u32_u8.
+struct WinMasks {
+    uint32_t space; // ' '
+    uint32_t skip;  // ' ' or '"'   (the OUT state's ignorable characters, :194,:232)
+    uint32_t name;  // 33..=126 minus '"' '=' ']'                                   :188-192
+    uint32_t eq, quote, rb;
+};
+__device__ __forceinline__ uint32_t gather16(uint32_t f0, uint32_t f1, uint32_t f2, uint32_t f3) {
+    uint32_t lo = __builtin_amdgcn_udot4(f1, 0x80402010u, __builtin_amdgcn_udot4(f0, 0x08040201u, 0u, false), false);
+    uint32_t hi = __builtin_amdgcn_udot4(f3, 0x80402010u, __builtin_amdgcn_udot4(f2, 0x08040201u, 0u, false), false);
+    return (lo >> 7) | (hi << 1);
+}
+// bit7 of each byte set <=> 33 <= byte <= 126
+__device__ __forceinline__ uint32_t range_flags(uint32_t x) {
+    uint32_t l = x & 0x7F7F7F7Fu;
+    uint32_t ge33 = l + 0x5F5F5F5Fu;  // bit7 set <=> low7 >= 33
+    uint32_t le126 = l + 0x01010101u; // bit7 set <=> low7 == 127
+    return ge33 & ~le126 & ~x & 0x80808080u;
+}
+__device__ __forceinline__ WinMasks window_masks(const uint32_t w[4]) {
+    uint32_t sp[4], qu[4], eq[4], rb[4], rg[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        sp[k] = eq_flags(w[k], 0x20202020u);
+        qu[k] = eq_flags(w[k], 0x22222222u);
+        eq[k] = eq_flags(w[k], 0x3D3D3D3Du);
+        rb[k] = eq_flags(w[k], 0x5D5D5D5Du);
+        rg[k] = range_flags(w[k]);
+    }
+    WinMasks m;
+    m.quote = gather16(qu[0], qu[1], qu[2], qu[3]);
+    m.eq = gather16(eq[0], eq[1], eq[2], eq[3]);
+    m.rb = gather16(rb[0], rb[1], rb[2], rb[3]);
+    m.space = gather16(sp[0], sp[1], sp[2], sp[3]);
+    m.skip = m.space | m.quote;
+    m.name = gather16(rg[0], rg[1], rg[2], rg[3]) & ~(m.quote | m.eq | m.rb);
+    return m;
+}
+// 16 bytes of the tile starting at byte address a (unaligned)
+__device__ __forceinline__ void load16(const Tile& T, uint32_t a, uint32_t w[4]) {
+    const uint32_t d = a >> 2, s = a & 3u;
+    uint32_t r0 = T.w[d], r1 = T.w[d + 1], r2 = T.w[d + 2], r3 = T.w[d + 3], r4 = T.w[d + 4];
+    w[0] = __builtin_amdgcn_alignbyte(r1, r0, s);
+    w[1] = __builtin_amdgcn_alignbyte(r2, r1, s);
+    w[2] = __builtin_amdgcn_alignbyte(r3, r2, s);
+    w[3] = __builtin_amdgcn_alignbyte(r4, r3, s);
+}
+
+// Same contract as sd_walk, for a line in the tile whose group has the quote/backslash bitmap
+// (T.bm) built.  Lane-per-line, but token- instead of byte-granular: a serial byte walk on a GPU
+// costs one dependent LDS round trip (hundreds of cycles) per byte; here ONE pair costs two:
+//   round 1  bit scan of the quote bitmap from the value's first byte -> p (closing '"' or a '\');
+//   round 2  a 16-byte window AT p: byte 0 says which of the two it is, bytes 1.. hold the next
+//            pair's "<spaces>name=\"" prefix, resolved in registers from SWAR class masks.
+//
+// MODE  SD_COUNT  count entries only
+//       SD_EMIT   write them to the entry table starting at `slot`
+//       SD_STASH  count AND park a compact 64-bit record per entry in the wave's scratch
+//                 (stash[k * 64 + lane], k < kStashEntries): once the wave has its slots, the
+//                 entries are copied out of the stash instead of parsing every line a second time.
+enum { SD_COUNT = 0, SD_EMIT = 1, SD_STASH = 2 };
+constexpr uint32_t kStashEntries = 48;  // per line; lines with more fall back to the second parse
+// record: name_s | name_len << 16 | val_len << 32 | esc << 48 | is_sdid << 49   (val_s = name_s + name_len + 2)
+__device__ __forceinline__ uint64_t stash_pack(uint32_t name_s, uint32_t name_len, uint32_t val_len, uint32_t esc, uint32_t sdid) {
+    return (uint64_t)name_s | ((uint64_t)name_len << 16) | ((uint64_t)val_len << 32) | ((uint64_t)esc << 48) | ((uint64_t)sdid << 49);
+}
+template <int MODE>
+__device__ __forceinline__ uint32_t sd_walk_tile(const Tile& T, uint32_t base, uint32_t pos, uint32_t len, uint32_t* msg_at,
+                                                 uint32_t* n_ent, const DevTables& t, uint32_t slot, uint64_t* stash = nullptr) {
+    constexpr bool EMIT = MODE == SD_EMIT;
+    LdsReader rd(T.w, base);
+    uint32_t cnt = 0;
+    for (;;) {
+        // sd_id = bytes after '[' up to the first ' ' (anything allowed)            :175-177
+        const uint32_t s = pos + 1;
+        uint32_t sp = s;
+        for (;;) {  // 16 bytes per step
+            if (sp >= len) return E_NOSD;
+            uint32_t w[4];
+            load16(T, base + sp, w);
+            const uint32_t avail = len - sp < 16u ? len - sp : 16u;
+            const uint32_t hit = gather16(eq_flags(w[0], 0x20202020u), eq_flags(w[1], 0x20202020u), eq_flags(w[2], 0x20202020u),
+                                          eq_flags(w[3], 0x20202020u)) & ((1u << avail) - 1u);
+            if (hit) {
+                sp += (uint32_t)__builtin_ctz(hit);
+                break;
+            }
+            sp += avail;
+        }
+        if (EMIT) {
+            t.ent_name[slot + cnt] = fg_span{s, sp - s};
+            t.ent_val[slot + cnt] = 0;
+            t.ent_type[slot + cnt] = FG_T_SDID;
+            t.ent_flags[slot + cnt] = 0;
+        }
+        if (MODE == SD_STASH && cnt < kStashEntries) stash[cnt * kWave + threadIdx.x] = stash_pack(s, sp - s, 0, 0, 1);
+        ++cnt;
+        uint32_t status = E_OK;
+        uint32_t i = sp + 1;       // OUT state: next unread byte
+        bool in_value = false;     // true: [val_s, ...) is an open value, `cur` = where to look for its end
+        uint32_t name_s = 0, name_e = 0, val_s = 0, cur = 0, esc_seen = 0;
+        uint32_t close_at = 0;     // index of the element's ']'
+        for (;;) {
+            uint32_t w0 = i, start = 0;
+            if (in_value) {
+                const uint32_t p = find_bit(T.bm, base, cur, len);
+                if (p >= len) {
+                    status = E_NOBRACKET;  // input exhausted inside a value                  :239
+                    break;
+                }
+                w0 = p;
+                start = 1;
+            } else if (i >= len) {
+                status = E_NOBRACKET;
+                break;
+            }
+            uint32_t w[4];
+            load16(T, base + w0, w);
+            if (in_value) {
+                if ((w[0] & 0xFFu) == '\\') {  // escapes the next char, whatever it is   :207-213
+                    esc_seen = 1;
+                    cur = w0 + 2;
+                    continue;
+                }
+                // closing quote: the pair is complete                                      :214-228
+                if (EMIT) {
+                    t.ent_name[slot + cnt] = fg_span{name_s, name_e - name_s};
+                    t.ent_val[slot + cnt] = (uint64_t)val_s | ((uint64_t)(w0 - val_s) << 32);
+                    t.ent_type[slot + cnt] = FG_T_STRING;
+                    t.ent_flags[slot + cnt] = esc_seen ? FG_EF_VAL_ESC : 0;
+                }
+                if (MODE == SD_STASH && cnt < kStashEntries)
+                    stash[cnt * kWave + threadIdx.x] = stash_pack(name_s, name_e - name_s, w0 - val_s, esc_seen, 0);
+                ++cnt;
+                in_value = false;
+            }
+            // ---- OUT state at window offset `start`: <skip chars> then ']' | name '=' '"' -----
+            const uint32_t avail = len - w0 < 16u ? len - w0 : 16u;  // window bytes inside the line (>= 1)
+            const uint32_t inside = (1u << avail) - 1u;                // avail <= 16
+            const WinMasks m = window_masks(w);
+            const uint32_t from = ~((1u << start) - 1u);
+            const uint32_t stop = ~m.skip & from & inside;             // first byte that is not ' ' / '"'
+            if (stop == 0) {                                           // only ignorable bytes in view
+                i = w0 + avail;
+                continue;                                              // (i >= len is caught at the top)
+            }
+            const uint32_t i0 = (uint32_t)__builtin_ctz(stop);
+            if ((m.rb >> i0) & 1u) {
+                close_at = w0 + i0;                                    // unescaped ']' outside name/value :197
+                break;
+            }
+            if (!((m.name >> i0) & 1u)) {
+                status = E_SDFMT;                                      //                                   :235
+                break;
+            }
+            // name = run of name chars from i0; then '=' and '"' must follow, all inside the view
+            const uint32_t after_name = ~m.name & ~((1u << i0) - 1u) & 0xFFFFu;
+            const uint32_t e0 = after_name ? (uint32_t)__builtin_ctz(after_name) : 16u;
+            if (e0 + 1u < avail) {
+                if (!((m.eq >> e0) & 1u) || !((m.quote >> (e0 + 1u)) & 1u)) {
+                    status = E_SDFMT;
+                    break;
+                }
+                name_s = w0 + i0;
+                name_e = w0 + e0;
+                val_s = name_e + 2u;
+            } else if (i0 != 0) {
+                i = w0 + i0;                                           // re-window with the name at offset 0
+                continue;
+            } else {
+                // a name of 14+ bytes (or the line ends inside this prefix): byte-wise
+                uint32_t q = w0, c = 0;
+                do {
+                    ++q;
+                    c = q < len ? rd.byte(q) : 0x100u;
+                } while (is_sd_name_char(c));
+                if (q >= len || q + 1u >= len) {
+                    // exhausted in IN_NAME / HAVE_NAME (a non-'=' / non-'"' byte there is a format error first)
+                    status = (q < len && c != '=') ? E_SDFMT : E_NOBRACKET;
+                    break;
+                }
+                if (c != '=' || rd.byte(q + 1u) != '"') {
+                    status = E_SDFMT;
+                    break;
+                }
+                name_s = w0;
+                name_e = q;
+                val_s = q + 2u;
+            }
+            in_value = true;
+            esc_seen = 0;
+            cur = val_s;
+        }
+        if (status != E_OK) return status;
+        const uint32_t after = close_at + 1;
+        if (after >= len) return E_NOMSG;  // :148
+        const uint32_t c = rd.byte(after);
+        if (c == '[') {
+            pos = after;
+            continue;
+        }
+        if (c != ' ') return E_MALFORMED;  // :154
+        *msg_at = after;
+        *n_ent = cnt;
+        return E_OK;
+    }
+}
+// parse_tail for a line in the tile whose part 7 starts with '[' and whose group has the
+// quote bitmap built.
+__device__ __forceinline__ void parse_tail_sd_tile(const Tile& T, uint32_t base, uint32_t q, uint32_t len, Row& r,
+                                                   const DevTables& t, uint64_t* stash) {
+    r.data0 = q;
+    uint32_t msg_at = 0;
+    uint32_t st = stash ? sd_walk_tile<SD_STASH>(T, base, q, len, &msg_at, &r.n_ent, t, 0, stash)
+                        : sd_walk_tile<SD_COUNT>(T, base, q, len, &msg_at, &r.n_ent, t, 0);
+    if (st != E_OK) {
+        r.status = st;
+        r.n_ent = 0;
+        return;
+    }
+    LdsReader rd(T.w, base);
+    uint32_t e = trim_end(rd, 0u, len);
+    r.off[S_FULL] = 0;
+    r.len[S_FULL] = e;
+    uint32_t s = trim_start(rd, msg_at, len);
+    if (e > s) {
+        r.off[S_MSG] = s;
+        r.len[S_MSG] = e - s;
+    }
+}
+
 // Stage B + SD entries + table row for ONE line group whose tile is in LDS (shared by both
 // kernels).  o0/o1 = this lane's line [o0, o1) in the packed buffer, a0 = packed-buffer address
 // of tile byte 0, span = tile bytes staged.
@@ -562,7 +840,8 @@ __device__ __forceinline__ void store_row(const DevTables& t, uint64_t li, const
 }
 __device__ __forceinline__ RowOut decode_group(const uint8_t* __restrict__ bytes, const uint8_t* smem,
                                                const uint16_t* bm16, uint64_t o0, uint64_t o1, uint64_t a0,
-                                               uint32_t span, bool valid, const DevTables& t) {
+                                               uint32_t span, bool valid, const DevTables& t, uint32_t ablate = 0,
+                                               uint64_t* stash = nullptr) {
     const uint32_t lane = threadIdx.x;
     Row r;
 #pragma unroll
@@ -574,10 +853,13 @@ __device__ __forceinline__ RowOut decode_group(const uint8_t* __restrict__ bytes
     const bool in_tile = (o1 - a0) <= (uint64_t)span;
     const uint32_t base = (uint32_t)(o0 - a0);
     Tile T{reinterpret_cast<const uint32_t*>(smem), reinterpret_cast<const uint32_t*>(bm16)};
+    // ---- 1. straight-line fast path for every line of the tile --------------------------------
+    uint32_t route = 0;
+    Fast f{};
     if (valid) {
-        uint32_t route = R_GENERIC;
+        route = R_GENERIC;
         if (in_tile) {
-            const Fast f = parse_line_fast(T, base, len, r);
+            f = parse_line_fast(T, base, len, r);
             route = f.route;
             if (!(route & R_GENERIC)) {
                 if (route & R_TS_SLOW) {  // rare
@@ -587,27 +869,42 @@ __device__ __forceinline__ RowOut decode_group(const uint8_t* __restrict__ bytes
                 } else {
                     r.status = f.no_ts ? E_NOTS : f.ts_ok ? f.rest : E_BADTS;
                 }
-                if (r.status == E_OK) {
-                    if (route & R_TAIL) {  // structured data (every line of an SD corpus) or garbage
-                        LdsReader rd(T.w, base);
-                        parse_tail(rd, f.d0, 0u, len, r, t);
-                    } else {
-                        uint32_t e = f.e, s0 = f.s;
-                        if (route & R_TRIM) {  // rare
-                            LdsReader rd(T.w, base);
-                            e = trim_end(rd, 0u, len);
-                            s0 = trim_start(rd, f.d0 + 1u, len);
-                        }
-                        r.data0 = f.d0;
-                        r.off[S_FULL] = 0;
-                        r.len[S_FULL] = e;
-                        r.off[S_MSG] = e > s0 ? s0 : 0u;
-                        r.len[S_MSG] = e > s0 ? e - s0 : FG_NONE;
-                    }
-                }
             }
         }
-        if (route & R_GENERIC) {  // rare: anything the fast path does not recognise, or a line outside the tile
+    }
+    // ---- 2. structured data in this group?  Then the space bitmap (no longer needed) becomes the
+    //         quote/backslash bitmap, built by the whole wave -------------------------------------
+    const bool sd_lane = valid && !(route & R_GENERIC) && (route & R_TAIL) && r.status == E_OK && f.c7 == '[';
+    const bool group_has_sd = __any(sd_lane);  // wave-uniform
+    if (group_has_sd) {
+        __syncthreads();
+        build_quote_bitmap(smem, const_cast<uint16_t*>(bm16), span >> 4);
+        __syncthreads();
+    }
+    // ---- 3. the rare / heavy routes ------------------------------------------------------------
+    if (valid) {
+        if (!(route & R_GENERIC)) {
+            if (r.status == E_OK) {
+                if (sd_lane) {
+                    parse_tail_sd_tile(T, base, f.d0, len, r, t, stash);
+                } else if (route & R_TAIL) {  // garbage instead of '-' / '['
+                    LdsReader rd(T.w, base);
+                    parse_tail(rd, f.d0, 0u, len, r, t);
+                } else {
+                    uint32_t e = f.e, s0 = f.s;
+                    if (route & R_TRIM) {  // rare
+                        LdsReader rd(T.w, base);
+                        e = trim_end(rd, 0u, len);
+                        s0 = trim_start(rd, f.d0 + 1u, len);
+                    }
+                    r.data0 = f.d0;
+                    r.off[S_FULL] = 0;
+                    r.len[S_FULL] = e;
+                    r.off[S_MSG] = e > s0 ? s0 : 0u;
+                    r.len[S_MSG] = e > s0 ? e - s0 : FG_NONE;
+                }
+            }
+        } else {  // rare: anything the fast path does not recognise, or a line outside the tile
             r = Row();
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
@@ -640,7 +937,22 @@ __device__ __forceinline__ RowOut decode_group(const uint8_t* __restrict__ bytes
             } else {
                 first = (uint32_t)mine;
                 uint32_t msg_at, cnt;
-                if (in_tile) {
+                if (ablate & 4u) {
+                } else if (sd_lane && stash && r.n_ent <= kStashEntries) {
+                    // copy the parked records out (k-major in the stash: coalesced reads)
+                    for (uint32_t k = 0; k < r.n_ent; ++k) {
+                        const uint64_t rec = stash[k * kWave + lane];
+                        const uint32_t name_s = (uint32_t)rec & 0xFFFFu, name_len = (uint32_t)(rec >> 16) & 0xFFFFu;
+                        const uint32_t val_len = (uint32_t)(rec >> 32) & 0xFFFFu;
+                        const bool sdid = (rec >> 49) & 1u;
+                        t.ent_name[first + k] = fg_span{name_s, name_len};
+                        t.ent_val[first + k] = sdid ? 0ull : ((uint64_t)(name_s + name_len + 2u) | ((uint64_t)val_len << 32));
+                        t.ent_type[first + k] = sdid ? FG_T_SDID : FG_T_STRING;
+                        t.ent_flags[first + k] = ((rec >> 48) & 1u) ? FG_EF_VAL_ESC : 0;
+                    }
+                } else if (sd_lane) {
+                    sd_walk_tile<SD_EMIT>(T, base, r.data0, len, &msg_at, &cnt, t, first);
+                } else if (in_tile) {
                     LdsReader rd(T.w, base);
                     sd_walk<true>(rd, r.data0, len, &msg_at, &cnt, t, first);
                 } else {
@@ -727,12 +1039,13 @@ template <int NB, bool PROF>
 __global__ __launch_bounds__(kWave, 2) void k_rfc5424_p(const uint8_t* __restrict__ bytes,
                                                     const uint64_t* __restrict__ offsets, uint64_t n,
                                                     DevTables t, uint32_t tile_cap, uint32_t L,
-                                                    uint64_t groups, unsigned long long* prof) {
+                                                    uint64_t groups, unsigned long long* prof, uint64_t* stash_base) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint16_t* bm16 = reinterpret_cast<uint16_t*>(smem + tile_cap + 64u);
     uint4* dst = reinterpret_cast<uint4*>(smem);
     const uint32_t lane = threadIdx.x;
     const uint64_t G = gridDim.x;
+    uint64_t* stash = stash_base ? stash_base + (uint64_t)blockIdx.x * (kStashEntries * kWave) : nullptr;
 
     // group geometry from the lanes' offsets, as SCALARS: tile start (16-byte aligned) + staged span
     auto geometry = [&](uint64_t g, uint64_t o0, uint64_t o1, uint64_t* a0, uint32_t* span) {
@@ -850,7 +1163,7 @@ __global__ __launch_bounds__(kWave, 2) void k_rfc5424_p(const uint8_t* __restric
         if (!(ablate & 2u)) {
             const uint64_t li = g * L + lane;
             const bool valid = lane < L && li < n;
-            pend = decode_group(bytes, smem, bm16, o0, o1, a0, span, valid, t);
+            pend = decode_group(bytes, smem, bm16, o0, o1, a0, span, valid, t, ablate, (ablate & 8u) ? nullptr : stash);
             pend_li = li;
             pend_valid = valid;
         }
@@ -894,8 +1207,15 @@ struct PersistPlan {
 };
 }  // namespace
 
+extern "C" uint64_t fg_rfc5424_stash_bytes(uint32_t blocks) {
+    return (uint64_t)blocks * fg::kStashEntries * fg::kWave * sizeof(uint64_t);
+}
+
+// stash: device scratch of fg_rfc5424_stash_bytes(stash_blocks) bytes (or NULL: SD lines are then
+// parsed twice); the persistent grid is capped at stash_blocks.
 extern "C" int fg_launch_rfc5424(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n,
-                                 const fg::DevTables* t, uint32_t tile_cap, hipStream_t stream) {
+                                 const fg::DevTables* t, uint32_t tile_cap, hipStream_t stream, uint64_t* stash,
+                                 uint32_t stash_blocks) {
     if (n == 0) return 0;
     // tuning / A-B knobs are read per launch (getenv is nanoseconds next to a launch) so that the
     // parity tests can sweep them inside one process
@@ -945,6 +1265,8 @@ extern "C" int fg_launch_rfc5424(const uint8_t* d_bytes, const uint64_t* d_offse
     if (waves_cap > 0 && per_cu > waves_cap) per_cu = waves_cap;
     uint64_t nblocks = (uint64_t)per_cu * (uint64_t)cus;
     if (nblocks > groups) nblocks = groups;
+    if (stash && nblocks > stash_blocks) nblocks = stash_blocks;
+    if (stash_blocks == 0) stash = nullptr;
     dim3 grid((uint32_t)nblocks);
     if (getenv("FG_PROF")) {
         // measurement build: synchronous, prints the per-phase cycle split to stderr
@@ -954,7 +1276,7 @@ extern "C" int fg_launch_rfc5424(const uint8_t* d_bytes, const uint64_t* d_offse
         if (hipMalloc((void**)&d_prof, sizeof(h)) != hipSuccess) return -1;
         (void)hipMemcpyAsync(d_prof, h, sizeof(h), hipMemcpyHostToDevice, stream);
         hipLaunchKernelGGL((fg::k_rfc5424_p<kWindowKiB, true>), grid, block, lds, stream, d_bytes, d_offsets, n, *t, tile, L,
-                           groups, d_prof);
+                           groups, d_prof, stash);
         (void)hipStreamSynchronize(stream);
         (void)hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost);
         (void)hipFree(d_prof);
@@ -966,6 +1288,6 @@ extern "C" int fg_launch_rfc5424(const uint8_t* d_bytes, const uint64_t* d_offse
         return (int)hipGetLastError();
     }
     hipLaunchKernelGGL(kern, grid, block, lds, stream, d_bytes, d_offsets, n, *t, tile, L, groups,
-                       (unsigned long long*)nullptr);
+                       (unsigned long long*)nullptr, stash);
     return (int)hipGetLastError();
 }
