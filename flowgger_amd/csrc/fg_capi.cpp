@@ -29,14 +29,14 @@ struct LtsvDevCfg {
 };
 }  // namespace fg
 
-extern "C" int fg_launch_rfc5424(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n,
-                                 const fg::DevTables* t, uint32_t tile_cap, hipStream_t stream, uint64_t* stash,
-                                 uint32_t stash_blocks);
-extern "C" uint64_t fg_rfc5424_stash_bytes(uint32_t blocks);
+extern "C" int fg_launch_rfc5424(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
+                                 uint64_t avg_len, hipStream_t stream, uint64_t* stash, uint32_t stash_blocks);
+extern "C" uint64_t fg_stash_bytes(uint32_t blocks);
 extern "C" int fg_launch_ltsv(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
-                              const fg::LtsvDevCfg* cfg, uint32_t tile_cap, hipStream_t stream);
+                              const fg::LtsvDevCfg* cfg, uint64_t avg_len, hipStream_t stream, uint64_t* stash,
+                              uint32_t stash_blocks);
 extern "C" int fg_launch_gelf(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
-                              uint32_t tile_cap, hipStream_t stream);
+                              uint64_t avg_len, hipStream_t stream, uint64_t* stash, uint32_t stash_blocks);
 
 struct fg_ctx {
     int device = 0;
@@ -51,8 +51,8 @@ struct fg_ctx {
     std::string suffix[4];
     bool has_suffix[4] = {false, false, false, false};
     uint8_t* d_cfg = nullptr;  // device copy of the LTSV configuration (blob | name_off | types)
-    // RFC5424: per-wave scratch where structured-data entries are parked between the parse and the
-    // copy into the entry table (allocated on the first RFC5424 call; sized for 8 waves on every CU)
+    // per-wave scratch where entries (SD pairs / LTSV pairs / GELF extras) are parked between the
+    // parse and the copy into the entry table (allocated on the first decode; 8 waves on every CU)
     uint64_t* d_stash = nullptr;
     uint32_t stash_blocks = 0;
     fg::LtsvDevCfg ltsv{};
@@ -382,25 +382,24 @@ int fg_decode_batch_device(fg_ctx* ctx, fg_format fmt, const uint8_t* d_bytes, u
     fg::DevTables dt = to_dev(*tables);
     if (dt.ent_used) FG_HIP(ctx, hipMemsetAsync(dt.ent_used, 0, 8, s));
     if (n == 0) return FG_OK;
+    if (!ctx->d_stash) {
+        hipDeviceProp_t prop;
+        FG_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+        uint32_t blocks = 8u * (uint32_t)prop.multiProcessorCount;
+        FG_HIP(ctx, hipMalloc((void**)&ctx->d_stash, fg_stash_bytes(blocks)));
+        ctx->stash_blocks = blocks;
+    }
     if (ctx->timing) FG_HIP(ctx, hipEventRecord(ctx->ev0, s));
     int rc;
     switch (fmt) {
         case FG_RFC5424:
-            if (!ctx->d_stash) {
-                hipDeviceProp_t prop;
-                FG_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
-                uint32_t blocks = 8u * (uint32_t)prop.multiProcessorCount;
-                FG_HIP(ctx, hipMalloc((void**)&ctx->d_stash, fg_rfc5424_stash_bytes(blocks)));
-                ctx->stash_blocks = blocks;
-            }
-            rc = fg_launch_rfc5424(d_bytes, d_offsets, n, &dt, pick_tile_cap(nbytes, n, 57344), s, ctx->d_stash,
-                                   ctx->stash_blocks);
+            rc = fg_launch_rfc5424(d_bytes, d_offsets, n, &dt, (nbytes + n - 1) / n, s, ctx->d_stash, ctx->stash_blocks);
             break;
         case FG_LTSV:
-            rc = fg_launch_ltsv(d_bytes, d_offsets, n, &dt, &ctx->ltsv, pick_tile_cap(nbytes, n, 63488), s);
+            rc = fg_launch_ltsv(d_bytes, d_offsets, n, &dt, &ctx->ltsv, (nbytes + n - 1) / n, s, ctx->d_stash, ctx->stash_blocks);
             break;
         case FG_GELF:
-            rc = fg_launch_gelf(d_bytes, d_offsets, n, &dt, pick_tile_cap(nbytes, n, 52224), s);
+            rc = fg_launch_gelf(d_bytes, d_offsets, n, &dt, (nbytes + n - 1) / n, s, ctx->d_stash, ctx->stash_blocks);
             break;
         default:
             return FG_ERR_UNSUPPORTED;

@@ -1,8 +1,21 @@
 // fg_gelf.hip -- gfx950 kernel for GelfDecoder::decode
 // (reference: src/flowgger/decoder/gelf_decoder.rs:34-125; JSON semantics = serde_json 0.8).
 //
-// One wave per 64 lines; the group's bytes are streamed HBM -> LDS (coalesced 16 B/lane) and each
-// lane parses ITS line out of LDS:
+// Runs on the streaming pipeline of fg_pipeline.hpp (persistent waves, register prefetch window,
+// LDS tile per line group, at most 32 lines per group -- the per-lane member arrays live in LDS).
+//
+// FAST FORM (GelfFormat::fast_walk, the bottom half of this file): a flat object of at most 16
+// members whose keys hold no escapes -- every GELF producer's output.  Stage A builds the bitmap
+// of { '"', '\', bytes < 0x20 }; a lane walks its line member by member: strings are skipped with
+// one bit scan of that bitmap per segment (escapes are validated in place), the punctuation
+// between tokens is resolved in 16-byte register windows, numbers use serde_json 0.8's
+// algorithm.  Every member becomes a 64-bit record + a sort key (first 7 key bytes, big endian,
+// then the member index) in the lane's LDS array; the keys are ranked in registers (BTreeMap
+// order, last duplicate wins), gelf_decoder.rs:51-106 is dispatched in that order, and the
+// extras are copied to the entry table in the same order.  Anything else (nesting, escaped
+// keys, raw control characters = the '\n' retry, syntax errors, 17+ members, two different keys
+// sharing their first 7 bytes) leaves the fast form BEFORE any output and takes the exact
+// general form below -- which is the original three-pass byte-walking implementation:
 //   pass 1  strict JSON validation in document order (serde_json's grammar: whitespace set,
 //           one leading zero, escapes, \uXXXX surrogate pairing, raw control characters in
 //           strings = InvalidUnicodeCodePoint, arbitrary nesting with an explicit LDS bit-stack),
@@ -17,7 +30,7 @@
 //   pass 3  extras are written to the entry table in sorted order (count -> wave-aggregated
 //           atomic -> fill).
 // Numbers use serde_json 0.8's own (not correctly rounded) algorithm, see fg_numparse.hpp.
-#include "fg_device.hpp"
+#include "fg_pipeline.hpp"
 #include "fg_numparse.hpp"
 
 namespace fg {
@@ -547,91 +560,458 @@ __device__ void gelf_line(R& rd, uint32_t len, uint32_t* keypos, uint32_t* stack
     if (!r.have_host) r.status = G_NOHOST;   // :110
 }
 
-__global__ __launch_bounds__(kWave) void k_gelf(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets,
-                                               uint64_t n, DevTables t, uint32_t tile_cap) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t lane = threadIdx.x;
-    uint32_t* keypos = reinterpret_cast<uint32_t*>(smem + tile_cap + 64u) + lane * kMaxStored;
-    uint32_t* stack = reinterpret_cast<uint32_t*>(smem + tile_cap + 64u + kWave * kMaxStored * 4u) + lane * (kMaxDepth / 32u);
-    const uint64_t l0 = (uint64_t)blockIdx.x * kWave;
-    const uint64_t li = l0 + lane;
-    const bool valid = li < n;
-    const uint64_t last = (l0 + kWave < n) ? l0 + kWave : n;
-    const uint64_t o0 = offsets[valid ? li : last];
-    const uint64_t o1 = offsets[valid ? li + 1 : last];
-    const uint64_t lo = __shfl(o0, 0, kWave);
-    const uint64_t hi = __shfl(o1, (int)(last - l0 - 1), kWave);
-    const uint64_t a0 = lo & ~15ull;
-    const uint64_t want = hi - a0;
-    const uint32_t span = want > tile_cap ? tile_cap : (uint32_t)((want + 15ull) & ~15ull);
-    stage_tile(bytes, a0, span, smem);
-    __syncthreads();
+// =============================================================================================
+// The fast form
+// =============================================================================================
+constexpr uint32_t kGelfLines = 32;       // lines per group (cap): the member arrays below are per lane
+constexpr uint32_t kFastMembers = 16;
+// per lane: 16 sort keys (u64) | 16 records (u64) | 16 order bytes  = 272 bytes; the general
+// form's keypos[32] + nesting stack alias the first 192 bytes of the same block
+constexpr uint32_t kLaneBlock = kFastMembers * 16u + 16u;
+constexpr uint32_t kGelfExtraLds = kGelfLines * kLaneBlock;
+static_assert(kMaxStored * 4u + kMaxDepth / 8u <= kLaneBlock, "general-form arrays must fit the lane block");
 
-    GRow r;
-    const uint32_t len = (uint32_t)(o1 - o0);
-    const bool in_tile = (o1 - a0) <= (uint64_t)span;
-    const uint32_t base = (uint32_t)(o0 - a0);
-    if (valid) {
-        if (in_tile) {
-            LdsReader rd(reinterpret_cast<const uint32_t*>(smem), base);
-            gelf_line(rd, len, keypos, stack, r, t);
-        } else {
-            GlobalReader rd(reinterpret_cast<const uint32_t*>(bytes), o0);
-            gelf_line(rd, len, keypos, stack, r, t);
-        }
-        if (r.status != G_OK) r.n_ent = 0;
+enum : uint32_t { K_TS = 0, K_HOST = 1, K_SHORT = 2, K_FULL = 3, K_VERSION = 4, K_LEVEL = 5, K_OTHER = 6 };
+
+// record: key_b | key_len << 16 | v_b << 32 | kind << 48 | v_esc << 52 ; strings: v_len in the
+// stash word, numbers / bool: the value bits in the stash word
+__device__ __forceinline__ uint64_t rec_pack(uint32_t key_b, uint32_t key_len, uint32_t v_b, uint32_t kind, uint32_t v_esc) {
+    return (uint64_t)key_b | ((uint64_t)key_len << 16) | ((uint64_t)v_b << 32) | ((uint64_t)kind << 48) | ((uint64_t)v_esc << 52);
+}
+
+struct GelfFormat {
+    uint8_t* lane_blocks;  // LDS: kGelfLines x kLaneBlock
+
+    // stage A: '"' | '\\' | control characters
+    static __device__ __forceinline__ uint32_t mask16(const uint4& v) {
+        const uint32_t Q = 0x22222222u, B = 0x5C5C5C5Cu;
+        return gather16(eq_flags(v.x, Q) | eq_flags(v.x, B) | ctrl_flags(v.x), eq_flags(v.y, Q) | eq_flags(v.y, B) | ctrl_flags(v.y),
+                        eq_flags(v.z, Q) | eq_flags(v.z, B) | ctrl_flags(v.z), eq_flags(v.w, Q) | eq_flags(v.w, B) | ctrl_flags(v.w));
     }
-    uint32_t total;
-    uint32_t ex = wave_exclusive_sum(r.n_ent, &total);
-    uint32_t first = 0;
-    if (total != 0) {
-        unsigned long long slot0 = 0;
-        if (lane == 0) slot0 = atomicAdd(t.ent_used, (unsigned long long)total);
-        slot0 = __shfl(slot0, 0, kWave);
-        unsigned long long mine = slot0 + ex;
-        if (r.n_ent != 0) {
-            if (mine + r.n_ent > t.ent_cap) {
-                r.status = FG_ST_OVERFLOW;
-                r.n_ent = 0;
+
+    // A 16-byte register window consumed byte by byte.
+    struct Win {
+        uint64_t lo, hi;
+        uint32_t left;  // bytes still in view
+        __device__ __forceinline__ uint32_t peek() const { return (uint32_t)lo & 0xFFu; }
+        __device__ __forceinline__ void pop() {
+            lo = (lo >> 8) | (hi << 56);
+            hi >>= 8;
+            --left;
+        }
+    };
+    static __device__ __forceinline__ Win window(const Tile& T, uint32_t base, uint32_t p, uint32_t len) {
+        uint32_t w[4];
+        load16(T, base + p, w);
+        Win x;
+        x.lo = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+        x.hi = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+        const uint32_t avail = p < len ? len - p : 0u;
+        x.left = avail < 16u ? avail : 16u;
+        return x;
+    }
+    static __device__ __forceinline__ bool ws(uint32_t c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n'; }
+    // skip whitespace inside the window; false = the view ran out (caller leaves the fast form)
+    static __device__ __forceinline__ bool skip(Win& x, uint32_t& p) {
+        while (x.left && ws(x.peek())) {
+            x.pop();
+            ++p;
+        }
+        return x.left != 0;
+    }
+    static __device__ __forceinline__ bool hex4_ok(uint32_t v) {  // four ASCII hex digits in a dword
+        // per byte: '0'..'9' or ((c|0x20) in 'a'..'f')
+        const uint32_t d = v ^ 0x30303030u;                                   // digits -> 0..9
+        const uint32_t dig_bad = (d | ((d & 0x7F7F7F7Fu) + 0x76767676u)) & 0x80808080u;
+        const uint32_t l = (v | 0x20202020u) ^ 0x60606060u;                   // a..f -> 1..6
+        const uint32_t let_hi = (l | ((l & 0x7F7F7F7Fu) + 0x79797979u)) & 0x80808080u;  // > 6
+        const uint32_t let_zero = ~(((l & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | l) & 0x80808080u;  // == 0
+        return ((dig_bad & (let_hi | let_zero)) == 0u);
+    }
+
+    // String body from p (just past the opening quote): *end = index of the closing quote.
+    // false = leave the fast form (raw control character, bad / unusual escape, end of line).
+    static __device__ __forceinline__ bool skip_string(const Tile& T, LdsReader& rd, uint32_t base, uint32_t p, uint32_t len,
+                                                       uint32_t* end, uint32_t* esc) {
+        uint32_t has_esc = 0;
+        for (;;) {
+            const uint32_t h = find_bit(T.bm, base, p, len);
+            if (h >= len) return false;
+            uint32_t b0, b1;
+            load8(T, base + h, &b0, &b1);
+            const uint32_t c = b0 & 0xFFu;
+            if (c == '"') {
+                *end = h;
+                *esc = has_esc;
+                return true;
+            }
+            if (c != '\\') return false;  // raw control character: the general form handles the retry
+            has_esc = 1;
+            const uint32_t e = (b0 >> 8) & 0xFFu;
+            if (h + 1u >= len) return false;
+            if (e == '"' || e == '\\' || e == '/' || e == 'b' || e == 'f' || e == 'n' || e == 'r' || e == 't') {
+                p = h + 2u;
+                continue;
+            }
+            if (e != 'u' || h + 6u > len) return false;
+            // \uXXXX: bytes 2..5 of the view
+            const uint32_t hx = (b0 >> 16) | (b1 << 16);
+            if (!hex4_ok(hx)) return false;
+            const uint32_t d0 = hx & 0xFFu, d1 = (hx >> 8) & 0xFFu;
+            const bool is_d = (d0 | 0x20u) == 'd';
+            const uint32_t d1l = d1 | 0x20u;
+            const bool high = is_d && (d1 == '8' || d1 == '9' || d1l == 'a' || d1l == 'b');
+            const bool low = is_d && (d1l >= 'c' && d1l <= 'f');
+            if (low) return false;  // lone low surrogate
+            if (high) {             // must be followed by \uDC00..\uDFFF
+                if (h + 12u > len) return false;
+                uint32_t c0, c1;
+                load8(T, base + h + 6u, &c0, &c1);
+                if ((c0 & 0xFFFFu) != (('u' << 8) | '\\')) return false;
+                const uint32_t hx2 = (c0 >> 16) | (c1 << 16);
+                if (!hex4_ok(hx2)) return false;
+                const uint32_t e0 = hx2 & 0xFFu, e1 = ((hx2 >> 8) & 0xFFu) | 0x20u;
+                if (!((e0 | 0x20u) == 'd' && e1 >= 'c' && e1 <= 'f')) return false;
+                p = h + 12u;
             } else {
-                first = (uint32_t)mine;
+                p = h + 6u;
+            }
+        }
+    }
+
+    static __device__ __forceinline__ uint32_t known_key(uint32_t n, const uint32_t w[4]) {
+        // keys compared as (length, little-endian dwords of the first 16 bytes)
+        if (n == 9u && w[0] == 0x656D6974u && w[1] == 0x6D617473u && (w[2] & 0xFFu) == 'p') return K_TS;                  // timestamp
+        if (n == 4u && w[0] == 0x74736F68u) return K_HOST;                                                                // host
+        if (n == 13u && w[0] == 0x726F6873u && w[1] == 0x656D5F74u && w[2] == 0x67617373u && (w[3] & 0xFFu) == 'e') return K_SHORT;  // short_message
+        if (n == 12u && w[0] == 0x6C6C7566u && w[1] == 0x73656D5Fu && w[2] == 0x65676173u) return K_FULL;                 // full_message
+        if (n == 7u && w[0] == 0x73726576u && (w[1] & 0xFFFFFFu) == 0x6E6F69u) return K_VERSION;                          // version
+        if (n == 5u && w[0] == 0x6576656Cu && (w[1] & 0xFFu) == 'l') return K_LEVEL;                                      // level
+        return K_OTHER;
+    }
+
+    // Walk the line; members -> keys[] / recs[] (LDS, this lane) + the value word in the stash.
+    // Returns the member count, or 0xFFFFFFFF = not the fast form.
+    __device__ __forceinline__ uint32_t fast_walk(const Tile& T, uint32_t base, uint32_t len, uint64_t* keys, uint64_t* recs,
+                                                  uint64_t* stash) const {
+        constexpr uint32_t BAIL = 0xFFFFFFFFu;
+        LdsReader rd(T.w, base);
+        uint32_t p = 0;
+        Win x = window(T, base, p, len);
+        if (!skip(x, p) || x.peek() != '{') return BAIL;
+        x.pop();
+        ++p;
+        uint32_t n = 0;
+        bool first = true;
+        for (;;) {
+            // ---- [ws] '}' | [','] [ws] '"' -----------------------------------------------------
+            if (!skip(x, p)) {
+                if (p >= len) return BAIL;
+                x = window(T, base, p, len);
+                if (!skip(x, p)) return BAIL;
+            }
+            uint32_t c = x.peek();
+            if (c == '}') {
+                x.pop();
+                ++p;
+                break;
+            }
+            if (!first) {
+                if (c != ',') return BAIL;
+                x.pop();
+                ++p;
+                if (!skip(x, p)) {
+                    if (p >= len) return BAIL;
+                    x = window(T, base, p, len);
+                    if (!skip(x, p)) return BAIL;
+                }
+                c = x.peek();
+            }
+            first = false;
+            if (c != '"' || n >= kFastMembers) return BAIL;
+            // ---- key: no escapes, no control characters ------------------------------------------
+            const uint32_t key_b = p + 1u;
+            const uint32_t key_e = find_bit(T.bm, base, key_b, len);
+            if (key_e >= len || rd.byte(key_e) != '"') return BAIL;
+            // ---- [ws] ':' [ws] value -------------------------------------------------------------
+            p = key_e + 1u;
+            x = window(T, base, p, len);
+            if (!skip(x, p) || x.peek() != ':') return BAIL;
+            x.pop();
+            ++p;
+            if (!skip(x, p)) {
+                if (p >= len) return BAIL;
+                x = window(T, base, p, len);
+                if (!skip(x, p)) return BAIL;
+            }
+            if (x.left < 6u && len - p > x.left) x = window(T, base, p, len);  // room for a literal
+            c = x.peek();
+            uint32_t kind, v_b = p, v_esc = 0, vend;
+            uint64_t word = 0;
+            if (c == '"') {
+                kind = V_STRING;
+                v_b = p + 1u;
+                uint32_t e;
+                if (!skip_string(T, rd, base, v_b, len, &e, &v_esc)) return BAIL;
+                word = e - v_b;
+                vend = e + 1u;
+            } else if (c == '-' || (c - '0') <= 9u) {
+                uint32_t k2;
+                if (!num::json_number(rd, p, len, &vend, &k2, &word)) return BAIL;
+                kind = k2;
+            } else if (c == 't') {
+                if (!((uint32_t)x.lo == 0x65757274u && x.left >= 4u)) return BAIL;  // "true"
+                kind = V_BOOL;
+                word = 1;
+                vend = p + 4u;
+            } else if (c == 'f') {
+                if (!((uint32_t)x.lo == 0x736C6166u && ((uint32_t)(x.lo >> 32) & 0xFFu) == 'e' && x.left >= 5u)) return BAIL;  // "false"
+                kind = V_BOOL;
+                word = 0;
+                vend = p + 5u;
+            } else if (c == 'n') {
+                if (!((uint32_t)x.lo == 0x6C6C756Eu && x.left >= 4u)) return BAIL;  // "null"
+                kind = V_NULL;
+                vend = p + 4u;
+            } else {
+                return BAIL;  // nested value or garbage
+            }
+            // ---- record + sort key ---------------------------------------------------------------
+            {
+                uint32_t k0, k1;
+                load8(T, base + key_b, &k0, &k1);
+                const uint32_t kl = key_e - key_b;
+                uint64_t pre = (uint64_t)k0 | ((uint64_t)k1 << 32);
+                if (kl < 8u) pre &= kl == 0u ? 0ull : (~0ull >> (64u - 8u * kl));
+                // big-endian first 7 bytes in bits 63..8, member index in bits 7..0
+                const uint64_t be = __builtin_bswap64(pre);
+                keys[n] = (be & ~0xFFull) | n;
+                recs[n] = rec_pack(key_b, kl, v_b, kind, v_esc);
+                stash[n * kWave + threadIdx.x] = word;
+            }
+            ++n;
+            p = vend;
+            x = window(T, base, p, len);
+        }
+        // trailing whitespace only
+        for (;;) {
+            if (skip(x, p)) return BAIL;  // a non-whitespace byte after the object
+            if (p >= len) break;
+            x = window(T, base, p, len);
+        }
+        return n;
+    }
+
+    __device__ __forceinline__ RowOut decode(const GroupCtx& c, const DevTables& t) const {
+        const uint32_t lane = threadIdx.x;
+        const uint32_t len = (uint32_t)(c.o1 - c.o0);
+        const bool in_tile = (c.o1 - c.a0) <= (uint64_t)c.span;
+        const uint32_t base = (uint32_t)(c.o0 - c.a0);
+        Tile T{reinterpret_cast<const uint32_t*>(c.smem), reinterpret_cast<const uint32_t*>(c.bm16)};
+        uint8_t* blk = lane_blocks + (lane < kGelfLines ? lane : 0u) * kLaneBlock;
+        uint64_t* keys = reinterpret_cast<uint64_t*>(blk);
+        uint64_t* recs = keys + kFastMembers;
+        uint8_t* order = blk + kFastMembers * 16u;
+        uint32_t* keypos = reinterpret_cast<uint32_t*>(blk);              // general form (aliases keys)
+        uint32_t* stack = reinterpret_cast<uint32_t*>(blk + kMaxStored * 4u);
+
+        GRow r;
+        uint32_t nm = 0xFFFFFFFFu;  // members found by the fast form
+        if (c.valid && in_tile && len < 65536u && c.stash) nm = fast_walk(T, base, len, keys, recs, c.stash);
+        bool fast = c.valid && nm != 0xFFFFFFFFu;
+        uint32_t sorted_n = 0;
+        if (fast) {
+            // ---- rank the keys in registers (BTreeMap order; equal keys: later member last) ------
+            uint64_t k[kFastMembers];
+#pragma unroll
+            for (uint32_t i = 0; i < kFastMembers; ++i) k[i] = i < nm ? keys[i] : ~0ull;
+#pragma unroll
+            for (uint32_t i = 0; i < kFastMembers; ++i) {
+                uint32_t rank = 0;
+#pragma unroll
+                for (uint32_t j = 0; j < kFastMembers; ++j) rank += (j != i && k[j] < k[i]) ? 1u : 0u;
+                if (i < nm) order[rank] = (uint8_t)i;
+            }
+            // ---- duplicates / unresolved order: adjacent keys with the same 7-byte prefix ---------
+            LdsReader rd(T.w, base);
+            for (uint32_t s = 0; s + 1u < nm && fast; ++s) {
+                const uint32_t i = order[s], j = order[s + 1u];
+                if ((keys[i] >> 8) != (keys[j] >> 8)) continue;
+                const uint64_t ri = recs[i], rj = recs[j];
+                const uint32_t li = (uint32_t)(ri >> 16) & 0xFFFFu, lj = (uint32_t)(rj >> 16) & 0xFFFFu;
+                bool same = li == lj;
+                for (uint32_t q = 7; q < li && same; ++q) same = rd.byte(((uint32_t)ri & 0xFFFFu) + q) == rd.byte(((uint32_t)rj & 0xFFFFu) + q);
+                if (!same) fast = false;  // two different keys share 7 bytes: the general form orders them
+                else order[s] = 0xFFu;    // earlier duplicate: skipped (the last one wins, BTreeMap::insert)
+            }
+            sorted_n = nm;
+        }
+        if (fast) {
+            // ---- gelf_decoder.rs:51-106 in sorted key order -------------------------------------------
+            uint32_t cnt = 0;
+            for (uint32_t s = 0; s < sorted_n; ++s) {
+                const uint32_t i = order[s];
+                if (i == 0xFFu) continue;
+                const uint64_t rec = recs[i];
+                const uint32_t key_b = (uint32_t)rec & 0xFFFFu, kl = (uint32_t)(rec >> 16) & 0xFFFFu;
+                const uint32_t v_b = (uint32_t)(rec >> 32) & 0xFFFFu, kind = (uint32_t)(rec >> 48) & 0xFu, v_esc = (uint32_t)(rec >> 52) & 1u;
+                uint32_t w[4];
+                load16(T, base + key_b, w);
+                const uint32_t which = known_key(kl, w);
+                if (which == K_OTHER) {
+                    ++cnt;  // (nested values never reach the fast form)
+                    continue;
+                }
+                const uint64_t word = c.stash[i * kWave + lane];
+                uint32_t st = G_OK;
+                if (which == K_TS) {
+                    if (kind == V_F64) r.ts = num::bits_to_f64(word);
+                    else if (kind == V_U64) r.ts = (double)word;
+                    else if (kind == V_I64) r.ts = (double)(int64_t)word;
+                    else st = G_TS;
+                    r.have_ts = 1;
+                } else if (which == K_HOST) {
+                    if (kind != V_STRING) st = G_HOST;
+                    r.host_off = v_b;
+                    r.host_len = (uint32_t)word;
+                    r.have_host = 1;
+                    if (v_esc) r.flags |= FG_F_HOST_ESC;
+                } else if (which == K_SHORT) {
+                    if (kind != V_STRING) st = G_SHORT;
+                    r.msg_off = v_b;
+                    r.msg_len = (uint32_t)word;
+                    if (v_esc) r.flags |= FG_F_MSG_ESC;
+                } else if (which == K_FULL) {
+                    if (kind != V_STRING) st = G_FULL;
+                    r.full_off = v_b;
+                    r.full_len = (uint32_t)word;
+                    if (v_esc) r.flags |= FG_F_FULLMSG_ESC;
+                } else if (which == K_VERSION) {
+                    if (kind != V_STRING) st = G_VERSTR;
+                    else {
+                        // "1.0" / "1.1" -- by DECODED value: an escaped spelling goes through the general form
+                        if (v_esc) {
+                            fast = false;
+                            break;
+                        }
+                        uint32_t v0, v1;
+                        load8(T, base + v_b, &v0, &v1);
+                        const uint32_t three = v0 & 0xFFFFFFu;
+                        if (!((uint32_t)word == 3u && (three == 0x302E31u || three == 0x312E31u))) st = G_VER;
+                    }
+                } else {  // level
+                    if (kind != V_U64) st = G_LEVEL;  // Value::as_u64 (NumCast): floats and negatives -> None
+                    else if (word > 7) st = G_LEVEL7;
+                    else r.severity = (uint32_t)word;
+                }
+                if (st != G_OK) {
+                    r.status = st;
+                    break;
+                }
+            }
+            if (fast && r.status == G_OK) {
+                if (!r.have_ts) r.flags |= FG_F_TS_NOW;  // :109
+                if (!r.have_host) r.status = G_NOHOST;   // :110
+                r.n_ent = r.status == G_OK ? cnt : 0u;
+            }
+        }
+        const bool general = c.valid && !fast;
+        if (general) {  // the exact general form (rare)
+            r = GRow();
+            if (in_tile) {
+                LdsReader rd(T.w, base);
+                gelf_line(rd, len, keypos, stack, r, t);
+            } else {
+                GlobalReader rd(reinterpret_cast<const uint32_t*>(c.bytes), c.o0);
+                gelf_line(rd, len, keypos, stack, r, t);
+            }
+            if (r.status != G_OK) r.n_ent = 0;
+        }
+        bool overflow;
+        const uint32_t first = alloc_entries(t, r.n_ent, &overflow);
+        if (overflow) {
+            r.status = FG_ST_OVERFLOW;
+            r.n_ent = 0;
+        }
+        if (r.n_ent != 0) {
+            if (!general) {
+                uint32_t k = first;
+                for (uint32_t s = 0; s < sorted_n; ++s) {
+                    const uint32_t i = order[s];
+                    if (i == 0xFFu) continue;
+                    const uint64_t rec = recs[i];
+                    const uint32_t key_b = (uint32_t)rec & 0xFFFFu, kl = (uint32_t)(rec >> 16) & 0xFFFFu;
+                    uint32_t w[4];
+                    load16(T, base + key_b, w);
+                    if (known_key(kl, w) != K_OTHER) continue;
+                    const uint32_t v_b = (uint32_t)(rec >> 32) & 0xFFFFu, kind = (uint32_t)(rec >> 48) & 0xFu, v_esc = (uint32_t)(rec >> 52) & 1u;
+                    const uint64_t word = c.stash[i * kWave + lane];
+                    t.ent_name[k] = fg_span{key_b, kl};
+                    t.ent_type[k] = (uint8_t)kind;
+                    t.ent_val[k] = kind == V_STRING ? ((uint64_t)v_b | (word << 32)) : kind == V_NULL ? 0ull : word;
+                    t.ent_flags[k] = (uint8_t)((kind == V_STRING && v_esc) ? FG_EF_VAL_ESC : 0);
+                    ++k;
+                }
+            } else {
                 GRow tmp = r;
                 if (in_tile) {
-                    LdsReader rd(reinterpret_cast<const uint32_t*>(smem), base);
+                    LdsReader rd(T.w, base);
                     Gelf<LdsReader> g{rd, len, (r.flags & FG_F_GELF_RETRY) != 0, stack};
                     gelf_sorted_dispatch<true>(g, keypos, tmp, t, first);
                 } else {
-                    GlobalReader rd(reinterpret_cast<const uint32_t*>(bytes), o0);
+                    GlobalReader rd(reinterpret_cast<const uint32_t*>(c.bytes), c.o0);
                     Gelf<GlobalReader> g{rd, len, (r.flags & FG_F_GELF_RETRY) != 0, stack};
                     gelf_sorted_dispatch<true>(g, keypos, tmp, t, first);
                 }
             }
         }
-    }
-    if (valid) {
+        RowOut o;
         const bool ok = r.status == G_OK;
         const fg_span none{0, FG_NONE};
-        t.meta[li] = r.status | (0xFFu << 8) | ((ok ? r.severity : 0xFFu) << 16) | ((ok ? r.flags : 0u) << 24);
-        t.ts[li] = (ok && r.have_ts) ? r.ts : 0.0;
-        t.span[S_HOST][li] = ok ? fg_span{r.host_off, r.host_len} : none;
-        t.span[S_APP][li] = none;
-        t.span[S_PROC][li] = none;
-        t.span[S_MSGID][li] = none;
-        t.span[S_MSG][li] = ok ? fg_span{r.msg_off, r.msg_len} : none;
-        t.span[S_FULL][li] = ok ? fg_span{r.full_off, r.full_len} : none;
-        t.ent_first[li] = first;
-        t.ent_count[li] = r.n_ent;
+        o.meta = r.status | (0xFFu << 8) | ((ok ? r.severity : 0xFFu) << 16) | ((ok ? r.flags : 0u) << 24);
+        o.ts = (ok && r.have_ts) ? r.ts : 0.0;
+        o.span[S_HOST] = ok ? fg_span{r.host_off, r.host_len} : none;
+        o.span[S_APP] = none;
+        o.span[S_PROC] = none;
+        o.span[S_MSGID] = none;
+        o.span[S_MSG] = ok ? fg_span{r.msg_off, r.msg_len} : none;
+        o.span[S_FULL] = ok ? fg_span{r.full_off, r.full_len} : none;
+        o.first = first;
+        o.count = r.n_ent;
+        return o;
     }
+};
+
+template <int NB, bool PROF>
+__global__ __launch_bounds__(kWave, 2) void k_gelf(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets,
+                                                  uint64_t n, DevTables t, uint32_t tile_cap, uint32_t L, uint64_t groups,
+                                                  unsigned long long* prof, uint64_t* stash_base) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    GelfFormat fmt{smem + tile_cap + 64u + (tile_cap / 16u + 16u) * 2u};
+    persistent_loop<NB, PROF>(bytes, offsets, n, t, tile_cap, L, groups, prof, stash_base, fmt);
 }
 
 }  // namespace fg
 
 extern "C" int fg_launch_gelf(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
-                              uint32_t tile_cap, hipStream_t stream) {
+                              uint64_t avg_len, hipStream_t stream, uint64_t* stash, uint32_t stash_blocks) {
     if (n == 0) return 0;
-    uint64_t groups = (n + fg::kWave - 1) / fg::kWave;
-    if (groups > 0x7FFFFFFFull) return -1;
-    uint32_t lds = tile_cap + 64u + fg::kWave * fg::kMaxStored * 4u + fg::kWave * (fg::kMaxDepth / 8u);
-    hipLaunchKernelGGL(fg::k_gelf, dim3((uint32_t)groups), dim3(fg::kWave), lds, stream, d_bytes, d_offsets, n, *t, tile_cap);
+    fg::LaunchPlan p;
+    // at most kGelfLines lines per group: plan with twice the average length (L <= 32 follows), then
+    // size the tile for the real one
+    if (fg::plan_launch(fg::k_gelf<fg::kWindowKiB, false>, n, avg_len, fg::kGelfExtraLds, 57344u, stash ? stash_blocks : 0u, &p, fg::kGelfLines))
+        return -1;
+    if (stash_blocks == 0) stash = nullptr;
+    dim3 grid(p.blocks), block(fg::kWave);
+    if (getenv("FG_PROF")) {
+        fg::ProfRun pr;
+        if (!pr.begin(stream)) return -1;
+        hipLaunchKernelGGL((fg::k_gelf<fg::kWindowKiB, true>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L,
+                           p.groups, pr.d, stash);
+        pr.end(stream, "gelf", p);
+        return (int)hipGetLastError();
+    }
+    hipLaunchKernelGGL((fg::k_gelf<fg::kWindowKiB, false>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L,
+                       p.groups, (unsigned long long*)nullptr, stash);
     return (int)hipGetLastError();
 }

@@ -1,14 +1,17 @@
 // fg_ltsv.hip -- gfx950 kernel for LTSVDecoder::decode
 // (reference: src/flowgger/decoder/ltsv_decoder.rs:86-267).
 //
-// Same decomposition as the RFC5424 kernel: one wave per 64 lines, the group's byte range is
-// streamed HBM -> LDS with coalesced 16 B/lane loads, then every lane walks ITS line out of LDS.
-// LTSV is "split on TAB, then on the first ':'", so the walk is a single forward pass; typed
-// values (input.ltsv_schema) are converted on the GPU with the exact Rust semantics of
-// fg_numparse.hpp (f64::from_str is correctly rounded; its rare Decimal slow path runs one lane
-// at a time over a per-wave LDS digit buffer).
-// Pairs go to the shared entry table: count pass -> one wave-aggregated atomic -> fill pass.
-#include "fg_device.hpp"
+// Runs on the streaming pipeline of fg_pipeline.hpp (persistent waves, register prefetch window,
+// LDS tile per line group); stage A builds the TAB bitmap.  LTSV is "split on TAB, then on the
+// first ':'": every lane walks ITS line part by part -- one bit scan of the TAB bitmap for the
+// part's end, one 16-byte window at the part's start for the name, its ':' and the key match --
+// instead of byte by byte.  Typed values (input.ltsv_schema) are converted on the GPU with the
+// exact Rust semantics of fg_numparse.hpp (f64::from_str is correctly rounded; its rare Decimal
+// slow path runs one lane at a time over a per-wave LDS digit buffer); the schema lives in LDS.
+// Pairs are parked in the wave's stash while the line is parsed and copied to the entry table
+// once the wave has its slots (single parse); the byte-walking two-pass form below stays for
+// lines outside the tile and lines with more than kStashEntries pairs.
+#include "fg_pipeline.hpp"
 #include "fg_numparse.hpp"
 
 namespace fg {
@@ -277,89 +280,293 @@ __device__ void ltsv_walk(R& rd, uint32_t len, const LtsvDevCfg& cfg, uint8_t* l
     }
 }
 
-__global__ __launch_bounds__(kWave) void k_ltsv(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets,
-                                               uint64_t n, DevTables t, LtsvDevCfg cfg, uint32_t tile_cap) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t* lds_digits = smem + tile_cap + 64u;  // 768-byte digit buffer for dec2flt's slow path
-    const uint32_t lane = threadIdx.x;
-    const uint64_t l0 = (uint64_t)blockIdx.x * kWave;
-    const uint64_t li = l0 + lane;
-    const bool valid = li < n;
-    const uint64_t last = (l0 + kWave < n) ? l0 + kWave : n;
-    const uint64_t o0 = offsets[valid ? li : last];
-    const uint64_t o1 = offsets[valid ? li + 1 : last];
-    const uint64_t lo = __shfl(o0, 0, kWave);
-    const uint64_t hi = __shfl(o1, (int)(last - l0 - 1), kWave);
-    const uint64_t a0 = lo & ~15ull;
-    const uint64_t want = hi - a0;
-    const uint32_t span = want > tile_cap ? tile_cap : (uint32_t)((want + 15ull) & ~15ull);
-    stage_tile(bytes, a0, span, smem);
-    __syncthreads();
+// ---------------------------------------------------------------------------------------------
+// The tile form
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kSchemaLds = 32;    // schema entries mirrored in LDS (more: matched from global memory)
+struct SchemaEnt {                      // 24 bytes
+    uint32_t len;
+    uint32_t type;
+    uint32_t name[4];                   // first 16 bytes of the name, zero padded
+};
+constexpr uint32_t kLtsvExtraLds = 768u + kSchemaLds * sizeof(SchemaEnt);
 
-    LRow r;
-    const uint32_t len = (uint32_t)(o1 - o0);
-    const bool in_tile = (o1 - a0) <= (uint64_t)span;
-    const uint32_t base = (uint32_t)(o0 - a0);
-    if (valid) {
-        if (in_tile) {
-            LdsReader rd(reinterpret_cast<const uint32_t*>(smem), base);
-            ltsv_walk<false>(rd, len, cfg, lds_digits, r, t, 0);
-        } else {
-            GlobalReader rd(reinterpret_cast<const uint32_t*>(bytes), o0);
-            ltsv_walk<false>(rd, len, cfg, lds_digits, r, t, 0);
+struct LtsvFormat {
+    LtsvDevCfg cfg;
+    uint8_t* lds_digits;        // 768-byte digit buffer for dec2flt's slow path
+    const SchemaEnt* schema;    // LDS mirror of the first kSchemaLds schema entries
+
+    static __device__ __forceinline__ uint32_t mask16(const uint4& v) { return mask16_eq(v, 0x09090909u); }
+
+    // schema lookup (HashMap::get, ltsv_decoder.rs:126): exact byte match of the name [nb, nb+nl)
+    // whose first 16 bytes are in w[] (zero padded)
+    __device__ __forceinline__ uint32_t lookup(LdsReader& rd, uint32_t nb, uint32_t nl, const uint32_t w[4]) const {
+        const uint32_t ns = cfg.n_schema < kSchemaLds ? cfg.n_schema : kSchemaLds;
+        for (uint32_t k = 0; k < ns; ++k) {
+            const SchemaEnt& e = schema[k];
+            if (e.len != nl) continue;
+            if (e.name[0] != w[0] || e.name[1] != w[1] || e.name[2] != w[2] || e.name[3] != w[3]) continue;
+            bool eq = true;
+            if (nl > 16u) {
+                const uint32_t o = cfg.name_off[k];
+                for (uint32_t i = 16; i < nl && eq; ++i) eq = rd.byte(nb + i) == cfg.blob[o + i];
+            }
+            if (eq) return e.type;
         }
-        if (r.status != L_OK) r.n_ent = 0;
+        for (uint32_t k = kSchemaLds; k < cfg.n_schema; ++k) {
+            uint32_t o = cfg.name_off[k], l = cfg.name_off[k + 1] - o;
+            if (l != nl) continue;
+            bool eq = true;
+            for (uint32_t i = 0; i < l && eq; ++i) eq = rd.byte(nb + i) == cfg.blob[o + i];
+            if (eq) return cfg.types[k];
+        }
+        return FG_T_STRING;
     }
-    uint32_t total;
-    uint32_t ex = wave_exclusive_sum(r.n_ent, &total);
-    uint32_t first = 0;
-    if (total != 0) {
-        unsigned long long slot0 = 0;
-        if (lane == 0) slot0 = atomicAdd(t.ent_used, (unsigned long long)total);
-        slot0 = __shfl(slot0, 0, kWave);
-        unsigned long long mine = slot0 + ex;
-        if (r.n_ent != 0) {
-            if (mine + r.n_ent > t.ent_cap) {
-                r.status = FG_ST_OVERFLOW;
-                r.n_ent = 0;
+
+    // One forward pass over a line in the tile; pairs go to the stash (or, STASH = false, are
+    // only counted -- a line with more than kStashEntries pairs is re-walked by ltsv_walk<true>).
+    __device__ __forceinline__ void walk_tile(const Tile& T, uint32_t base, uint32_t len, LRow& r, uint64_t* stash) const {
+        LdsReader rd(T.w, base);
+        uint32_t cnt = 0;
+        uint32_t ps = 0;
+        for (;;) {  // line.split('\t')
+            const uint32_t pe = find_bit(T.bm, base, ps, len);
+            uint32_t w[4];
+            load16(T, base + ps, w);
+            // first ':' of the part: in the 16-byte window, else (long name) byte-wise
+            const uint32_t plen = pe - ps;
+            const uint32_t in_part = plen >= 16u ? 0xFFFFu : (1u << plen) - 1u;
+            uint32_t cm = gather16(eq_flags(w[0], 0x3A3A3A3Au), eq_flags(w[1], 0x3A3A3A3Au), eq_flags(w[2], 0x3A3A3A3Au),
+                                   eq_flags(w[3], 0x3A3A3A3Au)) & in_part;
+            uint32_t colon = 0xFFFFFFFFu;
+            if (cm) {
+                colon = ps + (uint32_t)__builtin_ctz(cm);
+            } else if (plen > 16u) {
+                uint32_t q = ps + 16u;
+                while (q < pe && rd.byte(q) != ':') ++q;
+                if (q < pe) colon = q;
+            }
+            if (colon != 0xFFFFFFFFu) {  // else: println!("Missing value for name ...") :99, no effect on the Record
+                const uint32_t nb = ps, ne = colon, nl = colon - ps, vb = colon + 1, ve = pe;
+                // the name's first 16 bytes, zero padded (for the key matches)
+                uint32_t k[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t lo = 4u * j;
+                    k[j] = nl >= lo + 4u ? w[j] : nl <= lo ? 0u : (w[j] & ((1u << (8u * (nl - lo))) - 1u));
+                }
+                const bool short4 = k[1] == 0u && k[2] == 0u && k[3] == 0u;
+                if (nl == 4u && short4 && k[0] == 0x656D6974u) {           // "time"
+                    uint32_t b = vb, e = ve;
+                    if (e > b && rd.byte(b) == '[' && rd.byte(e - 1) == ']' && e - b >= 2) {
+                        ++b;
+                        --e;
+                    }
+                    double ts;
+                    if (!ltsv_parse_ts(rd, b, e, lds_digits, &ts)) {
+                        r.status = L_ENGLISH;
+                        return;
+                    }
+                    r.ts = ts;
+                    r.have_ts = 1;
+                } else if (nl == 4u && short4 && k[0] == 0x74736F68u) {    // "host"
+                    r.host_off = vb;
+                    r.host_len = ve - vb;
+                    r.have_host = 1;
+                } else if (nl == 7u && k[0] == 0x7373656Du && k[1] == 0x00656761u && k[2] == 0u && k[3] == 0u) {  // "message"
+                    r.msg_off = vb;
+                    r.msg_len = ve - vb;
+                } else if (nl == 5u && k[0] == 0x6576656Cu && k[1] == 0x0000006Cu && k[2] == 0u && k[3] == 0u) {  // "level"
+                    uint64_t lv;
+                    if (!num::parse_unsigned(rd, vb, ve, 255, &lv)) {
+                        r.status = L_LEVEL;
+                        return;
+                    }
+                    if (lv > 7) {
+                        r.status = L_LEVEL7;
+                        return;
+                    }
+                    r.severity = (uint32_t)lv;
+                } else {
+                    const uint32_t ty = lookup(rd, nb, nl, k);
+                    uint64_t val = (uint64_t)vb | ((uint64_t)(ve - vb) << 32);
+                    uint32_t flags = 0;
+                    if (ty != FG_T_STRING) {
+                        if (ty == FG_T_BOOL) {
+                            if (key_is(rd, vb, ve, "true", 4)) val = 1;
+                            else if (key_is(rd, vb, ve, "false", 5)) val = 0;
+                            else {
+                                r.status = L_BOOL;
+                                return;
+                            }
+                        } else if (ty == FG_T_F64) {
+                            double d;
+                            if (!parse_f64_wave(rd, vb, ve, lds_digits, &d)) {
+                                r.status = L_F64;
+                                return;
+                            }
+                            val = num::f64_to_bits(d);
+                        } else if (ty == FG_T_I64) {
+                            int64_t x;
+                            if (!num::parse_i64(rd, vb, ve, &x)) {
+                                r.status = L_I64;
+                                return;
+                            }
+                            val = (uint64_t)x;
+                        } else {
+                            uint64_t x;
+                            if (!num::parse_unsigned(rd, vb, ve, 0xFFFFFFFFFFFFFFFFull, &x)) {
+                                r.status = L_U64;
+                                return;
+                            }
+                            val = x;
+                        }
+                        // suffix: appended unless the name already ends with it (:131-136)
+                        const uint32_t si = ty - FG_T_BOOL;
+                        if (cfg.has_suf[si]) {
+                            uint32_t sl = cfg.suf_len[si], so = cfg.suf_off[si];
+                            bool ends = nl >= sl;
+                            for (uint32_t i = 0; i < sl && ends; ++i) ends = rd.byte(ne - sl + i) == cfg.blob[so + i];
+                            if (!ends) flags |= FG_EF_SUFFIX;
+                        }
+                    }
+                    if (stash && cnt < kStashEntries) {
+                        stash[(cnt * 2u) * kWave + threadIdx.x] =
+                            (uint64_t)nb | ((uint64_t)nl << 16) | ((uint64_t)ty << 32) | ((uint64_t)flags << 40);
+                        stash[(cnt * 2u + 1u) * kWave + threadIdx.x] = val;
+                    }
+                    ++cnt;
+                }
+            }
+            if (pe >= len) break;
+            ps = pe + 1;
+        }
+        if (!r.have_ts) {
+            r.status = L_NOTS;
+            return;
+        }
+        if (!r.have_host) {
+            r.status = L_NOHOST;
+            return;
+        }
+        r.n_ent = cnt;
+    }
+
+    __device__ __forceinline__ RowOut decode(const GroupCtx& c, const DevTables& t) const {
+        const uint32_t lane = threadIdx.x;
+        const uint32_t len = (uint32_t)(c.o1 - c.o0);
+        const bool in_tile = (c.o1 - c.a0) <= (uint64_t)c.span;
+        const uint32_t base = (uint32_t)(c.o0 - c.a0);
+        Tile T{reinterpret_cast<const uint32_t*>(c.smem), reinterpret_cast<const uint32_t*>(c.bm16)};
+        LRow r;
+        const bool name_fits = len < 65536u;  // stash records keep 16-bit name offsets
+        const bool tile_lane = c.valid && in_tile && name_fits;
+        if (c.valid) {
+            if (tile_lane) {
+                walk_tile(T, base, len, r, c.stash);
+            } else if (in_tile) {
+                LdsReader rd(T.w, base);
+                ltsv_walk<false>(rd, len, cfg, lds_digits, r, t, 0);
             } else {
-                first = (uint32_t)mine;
+                GlobalReader rd(reinterpret_cast<const uint32_t*>(c.bytes), c.o0);
+                ltsv_walk<false>(rd, len, cfg, lds_digits, r, t, 0);
+            }
+            if (r.status != L_OK) r.n_ent = 0;
+        }
+        bool overflow;
+        const uint32_t first = alloc_entries(t, r.n_ent, &overflow);
+        if (overflow) {
+            r.status = FG_ST_OVERFLOW;
+            r.n_ent = 0;
+        }
+        if (r.n_ent != 0) {
+            if (tile_lane && c.stash && r.n_ent <= kStashEntries) {
+                for (uint32_t k = 0; k < r.n_ent; ++k) {  // k-major in the stash: coalesced reads
+                    const uint64_t rec = c.stash[(k * 2u) * kWave + lane];
+                    const uint64_t val = c.stash[(k * 2u + 1u) * kWave + lane];
+                    t.ent_name[first + k] = fg_span{(uint32_t)rec & 0xFFFFu, (uint32_t)(rec >> 16) & 0xFFFFu};
+                    t.ent_val[first + k] = val;
+                    t.ent_type[first + k] = (uint8_t)((rec >> 32) & 0xFFu);
+                    t.ent_flags[first + k] = (uint8_t)((rec >> 40) & 0xFFu);
+                }
+            } else {
                 LRow scratch = r;
                 if (in_tile) {
-                    LdsReader rd(reinterpret_cast<const uint32_t*>(smem), base);
+                    LdsReader rd(T.w, base);
                     ltsv_walk<true>(rd, len, cfg, lds_digits, scratch, t, first);
                 } else {
-                    GlobalReader rd(reinterpret_cast<const uint32_t*>(bytes), o0);
+                    GlobalReader rd(reinterpret_cast<const uint32_t*>(c.bytes), c.o0);
                     ltsv_walk<true>(rd, len, cfg, lds_digits, scratch, t, first);
                 }
             }
         }
-    }
-    if (valid) {
+        RowOut o;
         const bool ok = r.status == L_OK;
         const fg_span none{0, FG_NONE};
-        t.meta[li] = r.status | (0xFFu << 8) | ((ok ? r.severity : 0xFFu) << 16);
-        t.ts[li] = ok ? r.ts : 0.0;
-        t.span[S_HOST][li] = ok ? fg_span{r.host_off, r.host_len} : none;
-        t.span[S_APP][li] = none;
-        t.span[S_PROC][li] = none;
-        t.span[S_MSGID][li] = none;
-        t.span[S_MSG][li] = ok ? fg_span{r.msg_off, r.msg_len} : none;
-        t.span[S_FULL][li] = ok ? fg_span{0, len} : none;  // full_msg = Some(line), untrimmed :218
-        t.ent_first[li] = first;
-        t.ent_count[li] = r.n_ent;
+        o.meta = r.status | (0xFFu << 8) | ((ok ? r.severity : 0xFFu) << 16);
+        o.ts = ok ? r.ts : 0.0;
+        o.span[S_HOST] = ok ? fg_span{r.host_off, r.host_len} : none;
+        o.span[S_APP] = none;
+        o.span[S_PROC] = none;
+        o.span[S_MSGID] = none;
+        o.span[S_MSG] = ok ? fg_span{r.msg_off, r.msg_len} : none;
+        o.span[S_FULL] = ok ? fg_span{0, len} : none;  // full_msg = Some(line), untrimmed :218
+        o.first = first;
+        o.count = r.n_ent;
+        return o;
     }
+};
+
+template <int NB, bool PROF>
+__global__ __launch_bounds__(kWave, 2) void k_ltsv(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets,
+                                                  uint64_t n, DevTables t, LtsvDevCfg cfg, uint32_t tile_cap, uint32_t L,
+                                                  uint64_t groups, unsigned long long* prof, uint64_t* stash_base) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t* extra = smem + tile_cap + 64u + (tile_cap / 16u + 16u) * 2u;
+    SchemaEnt* schema = reinterpret_cast<SchemaEnt*>(extra + 768u);
+    // mirror the schema into LDS once per wave (names zero padded to 16 bytes)
+    const uint32_t ns = cfg.n_schema < kSchemaLds ? cfg.n_schema : kSchemaLds;
+    for (uint32_t k = threadIdx.x; k < ns; k += kWave) {
+        const uint32_t o = cfg.name_off[k], l = cfg.name_off[k + 1] - o;
+        SchemaEnt e;
+        e.len = l;
+        e.type = cfg.types[k];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint32_t v = 0;
+            for (uint32_t i = 0; i < 4; ++i) {
+                const uint32_t idx = 4u * j + i;
+                if (idx < l) v |= (uint32_t)cfg.blob[o + idx] << (8u * i);
+            }
+            e.name[j] = v;
+        }
+        schema[k] = e;
+    }
+    __syncthreads();
+    LtsvFormat fmt{cfg, extra, schema};
+    persistent_loop<NB, PROF>(bytes, offsets, n, t, tile_cap, L, groups, prof, stash_base, fmt);
 }
 
 }  // namespace fg
 
 extern "C" int fg_launch_ltsv(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
-                              const fg::LtsvDevCfg* cfg, uint32_t tile_cap, hipStream_t stream) {
+                              const fg::LtsvDevCfg* cfg, uint64_t avg_len, hipStream_t stream, uint64_t* stash,
+                              uint32_t stash_blocks) {
     if (n == 0) return 0;
-    uint64_t groups = (n + fg::kWave - 1) / fg::kWave;
-    if (groups > 0x7FFFFFFFull) return -1;
-    uint32_t lds = tile_cap + 64u + 768u;
-    hipLaunchKernelGGL(fg::k_ltsv, dim3((uint32_t)groups), dim3(fg::kWave), lds, stream, d_bytes, d_offsets, n, *t, *cfg,
-                       tile_cap);
+    fg::LaunchPlan p;
+    if (fg::plan_launch(fg::k_ltsv<fg::kWindowKiB, false>, n, avg_len, fg::kLtsvExtraLds, 57344u, stash ? stash_blocks : 0u, &p))
+        return -1;
+    if (stash_blocks == 0) stash = nullptr;
+    dim3 grid(p.blocks), block(fg::kWave);
+    if (getenv("FG_PROF")) {
+        fg::ProfRun pr;
+        if (!pr.begin(stream)) return -1;
+        hipLaunchKernelGGL((fg::k_ltsv<fg::kWindowKiB, true>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, *cfg, p.tile,
+                           p.L, p.groups, pr.d, stash);
+        pr.end(stream, "ltsv", p);
+        return (int)hipGetLastError();
+    }
+    hipLaunchKernelGGL((fg::k_ltsv<fg::kWindowKiB, false>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, *cfg, p.tile,
+                       p.L, p.groups, (unsigned long long*)nullptr, stash);
     return (int)hipGetLastError();
 }

@@ -1,0 +1,401 @@
+// fg_pipeline.hpp -- the HBM -> VGPR -> LDS streaming skeleton shared by the three decode kernels,
+// plus the byte-class / bitmap / window primitives their lane-per-line tokenisers are built from.
+//
+// Execution model (gfx950, 64-lane waves, one wave per workgroup, PERSISTENT grid):
+//   * a wave walks line groups g = blockIdx.x, +gridDim.x, ... ; a group = L consecutive lines
+//     (L = 64 for ~256-byte lines, smaller powers of two for longer lines) = one contiguous byte
+//     range of the packed buffer;
+//   * stage A: the group's bytes arrive in NB x 16 B of VGPRs per lane (a register prefetch
+//     window filled by bounds-checked buffer loads while the PREVIOUS group was being tokenised),
+//     are classified while they sit in registers (one 16-bit mask per 16-byte chunk -> a bitmap
+//     of the format's delimiter) and written to the wave's LDS tile;
+//   * stage B: every lane tokenises ITS line out of LDS (format-specific, F::decode);
+//   * the table row of a group is stored one iteration late (see the comment in the loop).
+// HBM sees only coalesced 1 KiB-per-wave-instruction reads, each byte once.
+#pragma once
+#include "fg_device.hpp"
+
+namespace fg {
+
+using u32x4 = unsigned int __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------
+// SWAR byte classes -> 16-bit masks
+// ---------------------------------------------------------------------------------------------
+// bit7 of each byte set <=> byte == pat's byte (pat bytes < 0x80); exact, no borrow artefacts
+__device__ __forceinline__ uint32_t eq_flags(uint32_t x, uint32_t pat) {
+    uint32_t s = ((x & 0x7F7F7F7Fu) ^ pat) + 0x7F7F7F7Fu;  // bit7 set <=> low 7 bits != pat
+    return ~(s | x) & 0x80808080u;
+}
+// bit7 of each byte set <=> 33 <= byte <= 126
+__device__ __forceinline__ uint32_t range_flags(uint32_t x) {
+    uint32_t l = x & 0x7F7F7F7Fu;
+    uint32_t ge33 = l + 0x5F5F5F5Fu;   // bit7 set <=> low7 >= 33
+    uint32_t le126 = l + 0x01010101u;  // bit7 set <=> low7 == 127
+    return ge33 & ~le126 & ~x & 0x80808080u;
+}
+// bit7 of each byte set <=> byte < 0x20 (control characters)
+__device__ __forceinline__ uint32_t ctrl_flags(uint32_t x) {
+    uint32_t ge32 = (x & 0x7F7F7F7Fu) + 0x60606060u;  // bit7 set <=> low7 >= 32
+    return ~(ge32 | x) & 0x80808080u;
+}
+// four dwords of byte flags (0x80 per hit) -> 16-bit mask, v_dot4_u32_u8 as the bit gather
+__device__ __forceinline__ uint32_t gather16(uint32_t f0, uint32_t f1, uint32_t f2, uint32_t f3) {
+    uint32_t lo = __builtin_amdgcn_udot4(f1, 0x80402010u, __builtin_amdgcn_udot4(f0, 0x08040201u, 0u, false), false);
+    uint32_t hi = __builtin_amdgcn_udot4(f3, 0x80402010u, __builtin_amdgcn_udot4(f2, 0x08040201u, 0u, false), false);
+    return (lo >> 7) | (hi << 1);
+}
+__device__ __forceinline__ uint32_t mask16_eq(const uint4& v, uint32_t pat) {
+    return gather16(eq_flags(v.x, pat), eq_flags(v.y, pat), eq_flags(v.z, pat), eq_flags(v.w, pat));
+}
+
+// ---------------------------------------------------------------------------------------------
+// The wave's LDS tile: bytes (as dwords) + one bitmap (bit i <=> tile byte i is in the class)
+// ---------------------------------------------------------------------------------------------
+struct Tile {
+    const uint32_t* w;
+    const uint32_t* bm;
+};
+// 8 / 16 consecutive bytes starting at tile byte `a` (unaligned) as little-endian dwords
+__device__ __forceinline__ void load8(const Tile& T, uint32_t a, uint32_t* lo, uint32_t* hi) {
+    uint32_t d = a >> 2, s = a & 3u;
+    uint32_t w0 = T.w[d], w1 = T.w[d + 1], w2 = T.w[d + 2];
+    *lo = __builtin_amdgcn_alignbyte(w1, w0, s);
+    *hi = __builtin_amdgcn_alignbyte(w2, w1, s);
+}
+__device__ __forceinline__ void load16(const Tile& T, uint32_t a, uint32_t w[4]) {
+    const uint32_t d = a >> 2, s = a & 3u;
+    uint32_t r0 = T.w[d], r1 = T.w[d + 1], r2 = T.w[d + 2], r3 = T.w[d + 3], r4 = T.w[d + 4];
+    w[0] = __builtin_amdgcn_alignbyte(r1, r0, s);
+    w[1] = __builtin_amdgcn_alignbyte(r2, r1, s);
+    w[2] = __builtin_amdgcn_alignbyte(r3, r2, s);
+    w[3] = __builtin_amdgcn_alignbyte(r4, r3, s);
+}
+// first set bit of a tile bitmap at line index >= q (tile byte base+q), or len; 32 bytes per step
+__device__ __forceinline__ uint32_t find_bit(const uint32_t* bm, uint32_t base, uint32_t q, uint32_t len) {
+    while (q < len) {
+        uint32_t a = base + q;
+        uint32_t w = bm[a >> 5] >> (a & 31u);
+        if (w) {
+            uint32_t r = q + (uint32_t)__builtin_ctz(w);
+            return r < len ? r : len;
+        }
+        q += 32u - (a & 31u);
+    }
+    return len;
+}
+// wave-cooperative: rebuild the bitmap of the staged tile for another byte class (M::mask16)
+template <class M>
+__device__ __forceinline__ void rebuild_bitmap(const uint8_t* smem, uint16_t* bm16, uint32_t nchunk) {
+    const uint4* src = reinterpret_cast<const uint4*>(smem);
+    for (uint32_t c = threadIdx.x; c < nchunk; c += kWave) bm16[c] = (uint16_t)M::mask16(src[c]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Output row (the fixed 68 bytes of a line) and the per-wave entry stash
+// ---------------------------------------------------------------------------------------------
+struct RowOut {
+    uint32_t meta;
+    double ts;
+    fg_span span[6];
+    uint32_t first, count;
+};
+__device__ __forceinline__ void store_row(const DevTables& t, uint64_t li, const RowOut& o) {
+    t.meta[li] = o.meta;
+    t.ts[li] = o.ts;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) t.span[k][li] = o.span[k];
+    t.ent_first[li] = o.first;
+    t.ent_count[li] = o.count;
+}
+// Entries found while a line is parsed are parked in the wave's scratch (stash[k * 64 + lane],
+// k < kStashEntries, two u64 per entry in the GELF/LTSV kernels, one in the RFC5424 kernel) and
+// copied into the entry table once the wave has its slots -- instead of parsing every line twice.
+constexpr uint32_t kStashEntries = 48;
+constexpr uint32_t kStashWords = 2;  // u64 words per stashed entry (scratch is sized for this)
+
+// Wave-aggregated allocation of entry slots: returns this lane's first slot, or sets *overflow.
+__device__ __forceinline__ uint32_t alloc_entries(const DevTables& t, uint32_t n_ent, bool* overflow) {
+    uint32_t total;
+    uint32_t ex = wave_exclusive_sum(n_ent, &total);
+    *overflow = false;
+    if (total == 0) return 0;  // wave-uniform
+    unsigned long long slot0 = 0;
+    if (threadIdx.x == 0) slot0 = atomicAdd(t.ent_used, (unsigned long long)total);
+    slot0 = __shfl(slot0, 0, kWave);
+    unsigned long long mine = slot0 + ex;
+    if (n_ent != 0 && mine + n_ent > t.ent_cap) {
+        *overflow = true;
+        return 0;
+    }
+    return (uint32_t)mine;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The persistent streaming loop.  F supplies
+//     static uint32_t F::mask16(const uint4&)                  stage-A byte class
+//     RowOut F::decode(const GroupCtx&)  (member, may use its own state)
+// ---------------------------------------------------------------------------------------------
+struct GroupCtx {
+    const uint8_t* bytes;   // packed buffer (global)
+    const uint8_t* smem;    // tile bytes
+    uint16_t* bm16;         // tile bitmap (stage A's class; a decoder may rebuild it)
+    uint64_t o0, o1;        // this lane's line [o0, o1) in the packed buffer
+    uint64_t a0;            // packed-buffer address of tile byte 0
+    uint32_t span;          // tile bytes staged
+    bool valid;             // this lane owns a line
+    uint64_t* stash;        // the wave's entry stash (or null)
+    uint32_t ablate;        // measurement build only
+};
+
+template <int NB, bool PROF, class F>
+__device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets,
+                                                uint64_t n, const DevTables& t, uint32_t tile_cap, uint32_t L, uint64_t groups,
+                                                unsigned long long* prof, uint64_t* stash_base, F& fmt) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint16_t* bm16 = reinterpret_cast<uint16_t*>(smem + tile_cap + 64u);
+    uint4* dst = reinterpret_cast<uint4*>(smem);
+    const uint32_t lane = threadIdx.x;
+    const uint64_t G = gridDim.x;
+    uint64_t* stash = stash_base ? stash_base + (uint64_t)blockIdx.x * (kStashEntries * kStashWords * kWave) : nullptr;
+
+    // group geometry from the lanes' offsets, as SCALARS: tile start (16-byte aligned) + staged span
+    auto geometry = [&](uint64_t g, uint64_t o0, uint64_t o1, uint64_t* a0, uint32_t* span) {
+        const uint64_t l0 = g * L;
+        const uint32_t nl = (uint32_t)((l0 + L <= n) ? L : n - l0);
+        // (the builtins return int: widen through uint32_t or bit 31 sign-extends into the high word)
+        const uint32_t last = (uint32_t)__builtin_amdgcn_readfirstlane((int)(nl - 1u));
+        const uint32_t lo_l = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)o0);
+        const uint32_t lo_h = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(o0 >> 32));
+        const uint32_t hi_l = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)o1, (int)last);
+        const uint32_t hi_h = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(o1 >> 32), (int)last);
+        const uint64_t lo = (uint64_t)lo_l | ((uint64_t)lo_h << 32);
+        const uint64_t hi = (uint64_t)hi_l | ((uint64_t)hi_h << 32);
+        *a0 = lo & ~15ull;
+        const uint64_t want = hi - *a0;
+        *span = want > tile_cap ? tile_cap : (uint32_t)((want + 15ull) & ~15ull);
+    };
+    auto load_offsets = [&](uint64_t g, uint64_t* o0, uint64_t* o1) {
+        const uint64_t l0 = g * L;
+        uint64_t li = l0 + lane;
+        const uint64_t last = (l0 + L < n) ? l0 + L : n;
+        const bool valid = lane < L && li < n;
+        *o0 = offsets[valid ? li : last];
+        *o1 = offsets[valid ? li + 1 : last];
+    };
+    // the register window: NB buffer loads of 16 B per lane; the buffer descriptor bounds the
+    // tile, so rows past `span` fetch nothing and return zeros -- no per-row predication.  The
+    // row offset goes into the VGPR/immediate offset (the part the hardware range-checks; the
+    // scalar offset is not checked).
+    auto load_window = [&](uint64_t a0, uint32_t span, u32x4* v) {
+        __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(bytes + a0), (short)0, (int)span, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(lane * 16u + k * 1024u), 0, 0);
+    };
+
+    uint64_t g = blockIdx.x;
+    if (g >= groups) return;
+    uint64_t o0, o1, a0;
+    uint32_t span;
+    load_offsets(g, &o0, &o1);
+    geometry(g, o0, o1, &a0, &span);
+    u32x4 v[NB];
+    load_window(a0, span, v);
+    uint64_t no0 = 0, no1 = 0;
+    if (g + G < groups) load_offsets(g + G, &no0, &no1);
+    // The table row of a group is stored one iteration LATE (after the next group's stage A,
+    // before the prefetch after that is issued): vmcnt retires in order, so stores issued
+    // behind the window loads would have to be waited for at the top of every iteration.
+    RowOut pend{};
+    uint64_t pend_li = 0;
+    bool pend_valid = false;
+    uint64_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0, iters = 0, tm0 = 0, tm1 = 0, tm2 = 0, tm3 = 0;
+    // measurement build only: prof[5] = ablation flags (1 = no table stores, 2 = no stage B,
+    // 4 / 8 = format-specific, see the decoders)
+    const uint32_t ablate = PROF ? (uint32_t)prof[5] : 0u;
+
+    for (;;) {
+        if (PROF) {
+            tm0 = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the window has landed
+            tm1 = __builtin_amdgcn_s_memtime();
+        }
+        // ---- stage A for group g: registers -> LDS, classify on the way ----------------------
+        const uint32_t nchunk = span >> 4;
+        const uint32_t nrow = (nchunk + kWave - 1u) / kWave;  // wave-uniform
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            if ((uint32_t)k < nrow) {  // scalar branch; lanes past the span store zeros inside the tile
+                uint32_t idx = k * kWave + lane;
+                uint4 q = make_uint4(v[k][0], v[k][1], v[k][2], v[k][3]);
+                dst[idx] = q;
+                bm16[idx] = (uint16_t)F::mask16(q);
+            }
+        }
+        if (nrow > (uint32_t)NB) {  // rare: bytes beyond the register window
+            const uint4* __restrict__ src = reinterpret_cast<const uint4*>(bytes + a0);
+            for (uint32_t c0 = NB * kWave; c0 < nchunk; c0 += kWave * 4) {
+                uint4 w[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    uint32_t idx = c0 + k * kWave + lane;
+                    if (idx < nchunk) w[k] = src[idx];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    uint32_t idx = c0 + k * kWave + lane;
+                    if (idx < nchunk) {
+                        dst[idx] = w[k];
+                        bm16[idx] = (uint16_t)F::mask16(w[k]);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the old window dead before the new one is loaded
+        if (PROF) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): LDS writes retired
+            tm2 = __builtin_amdgcn_s_memtime();
+        }
+        if (pend_valid && !(ablate & 1u)) store_row(t, pend_li, pend);
+        // ---- prefetch: offsets of g+2G first (they must not queue behind the data), then the
+        //      bytes of g+G into the register window ------------------------------------------
+        const uint64_t gn = g + G;
+        const bool more = gn < groups;  // wave-uniform
+        uint64_t po0 = no0, po1 = no1, pa0 = 0;
+        uint32_t pspan = 0;
+        if (more) {
+            if (gn + G < groups) load_offsets(gn + G, &no0, &no1);
+            geometry(gn, po0, po1, &pa0, &pspan);
+            load_window(pa0, pspan, v);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (PROF) tm3 = __builtin_amdgcn_s_memtime();
+        __syncthreads();  // single-wave workgroup: orders the LDS writes before stage B's reads
+        // ---- stage B for group g ------------------------------------------------------------
+        if (!(ablate & 2u)) {
+            const uint64_t li = g * L + lane;
+            const bool valid = lane < L && li < n;
+            GroupCtx c{bytes, smem, bm16, o0, o1, a0, span, valid, (ablate & 8u) ? nullptr : stash, ablate};
+            pend = fmt.decode(c, t);
+            pend_li = li;
+            pend_valid = valid;
+        }
+        if (PROF) {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            uint64_t tm4 = __builtin_amdgcn_s_memtime();
+            acc0 += tm1 - tm0;
+            acc1 += tm2 - tm1;
+            acc2 += tm3 - tm2;
+            acc3 += tm4 - tm3;
+            iters += 1;
+        }
+        if (!more) break;
+        __syncthreads();  // stage B's LDS reads are done before the next tile overwrites them
+        g = gn;
+        o0 = po0;
+        o1 = po1;
+        a0 = pa0;
+        span = pspan;
+    }
+    if (pend_valid && !(ablate & 1u)) store_row(t, pend_li, pend);
+    if (PROF && lane == 0) {
+        atomicAdd(&prof[0], (unsigned long long)acc0);
+        atomicAdd(&prof[1], (unsigned long long)acc1);
+        atomicAdd(&prof[2], (unsigned long long)acc2);
+        atomicAdd(&prof[3], (unsigned long long)acc3);
+        atomicAdd(&prof[4], (unsigned long long)iters);
+    }
+}
+
+}  // namespace fg
+
+// ---------------------------------------------------------------------------------------------
+// Host side: launch geometry shared by the three launchers
+// ---------------------------------------------------------------------------------------------
+#include <cstdio>
+#include <cstdlib>
+
+namespace fg {
+constexpr int kWindowKiB = 20;  // register prefetch window per wave (NB): 80 VGPRs
+
+struct LaunchPlan {
+    uint32_t L = 64;      // lines per group
+    uint32_t tile = 0;    // LDS tile bytes (multiple of 1024)
+    uint32_t lds = 0;     // dynamic LDS bytes per workgroup = tile + 64 + bitmap + extra
+    uint64_t groups = 0;
+    uint32_t blocks = 0;  // persistent grid
+};
+
+// Lines per group L and the LDS tile: the largest power of two L <= 64 whose average group
+// (+12.5 % + 512 B) fits the register prefetch window, so that a whole group is prefetched.
+// Lines longer than the window get L = 1 and a tile of up to `max_tile` (the part beyond the
+// window is staged by the tail loop); anything that still does not fit is parsed from global
+// memory.  FG_TILE_CAP / FG_LINES_PER_GROUP / FG_WAVES_PER_CU override (tuning, parity sweeps).
+template <class K>
+inline int plan_launch(K kernel, uint64_t n, uint64_t avg_len, uint32_t extra_lds, uint32_t max_tile, uint32_t stash_blocks,
+                       LaunchPlan* p, uint32_t max_lines = 64) {
+    const uint64_t window = (uint64_t)kWindowKiB * 1024u;
+    auto tile_for = [&](uint32_t l) { return (((uint64_t)l * avg_len * 9u / 8u + 512u) + 1023u) / 1024u * 1024u; };
+    auto clamp = [&](uint64_t v) { return (uint32_t)(v < 4096u ? 4096u : v > max_tile ? max_tile : v); };
+    uint32_t L = max_lines;
+    while (L > 1 && tile_for(L) > window) L >>= 1;
+    uint32_t tile = clamp(tile_for(L));
+    if (const char* e = getenv("FG_LINES_PER_GROUP")) {
+        uint32_t forced = (uint32_t)atoi(e);
+        if (forced >= 1 && forced <= max_lines) {
+            L = forced;
+            tile = clamp(tile_for(L));
+        }
+    }
+    if (const char* e = getenv("FG_TILE_CAP")) {
+        uint64_t v = strtoull(e, nullptr, 10);
+        if (v >= 1024 && v <= max_tile) tile = (uint32_t)((v + 1023u) / 1024u * 1024u);
+    }
+    p->L = L;
+    p->tile = tile;
+    p->lds = tile + 64u + (tile / 16u + 16u) * 2u + extra_lds;
+    p->groups = (n + L - 1) / L;
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+        cus = prop.multiProcessorCount;
+    }
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kWave, p->lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (const char* e = getenv("FG_WAVES_PER_CU")) {
+        int cap = atoi(e);
+        if (cap > 0 && per_cu > cap) per_cu = cap;
+    }
+    uint64_t blocks = (uint64_t)per_cu * (uint64_t)cus;
+    if (blocks > p->groups) blocks = p->groups;
+    if (stash_blocks && blocks > stash_blocks) blocks = stash_blocks;
+    p->blocks = (uint32_t)blocks;
+    return 0;
+}
+
+// FG_PROF=1: run the measurement build of a kernel synchronously and print the per-phase split.
+struct ProfRun {
+    unsigned long long* d = nullptr;
+    unsigned long long h[6] = {0, 0, 0, 0, 0, 0};
+    bool begin(hipStream_t stream) {
+        if (const char* e = getenv("FG_ABLATE")) h[5] = (unsigned long long)atoi(e);
+        if (hipMalloc((void**)&d, sizeof(h)) != hipSuccess) return false;
+        (void)hipMemcpyAsync(d, h, sizeof(h), hipMemcpyHostToDevice, stream);
+        return true;
+    }
+    void end(hipStream_t stream, const char* name, const LaunchPlan& p) {
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+        (void)hipFree(d);
+        const double it = h[4] ? (double)h[4] : 1.0;
+        fprintf(stderr,
+                "[fg prof] %s: grid %u x64, L %u, tile %u, iters/wave %.1f | cycles per iteration: wait %.0f, stageA %.0f, "
+                "stores+prefetch-issue %.0f, stageB %.0f\n",
+                name, p.blocks, p.L, p.tile, it / (double)(p.blocks ? p.blocks : 1), h[0] / it, h[1] / it, h[2] / it, h[3] / it);
+    }
+};
+}  // namespace fg

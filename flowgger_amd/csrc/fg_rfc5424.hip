@@ -24,11 +24,9 @@
 #include <cstdio>
 #include <cstdlib>
 
-#include "fg_device.hpp"
+#include "fg_pipeline.hpp"
 
 namespace fg {
-
-using u32x4 = unsigned int __attribute__((ext_vector_type(4)));
 
 // status codes == index into the reference's error strings (fg_error_string)
 enum : uint32_t {
@@ -286,36 +284,9 @@ __device__ __forceinline__ void parse_line_generic(R& rd, uint32_t len, Row& r, 
 }
 
 // =============================================================================================
-// Stage A: SWAR byte classification
-// =============================================================================================
-
-// 4-bit mask (bit i = byte i of x equals 0x20), exact (no borrow artefacts).
-__device__ __forceinline__ uint32_t space_nibble(uint32_t x) {
-    uint32_t y = x ^ 0x20202020u;                                          // zero byte <=> space
-    uint32_t t = ((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y;                    // bit7 set <=> byte != 0
-    t = ~t & 0x80808080u;                                                  // bit7 set <=> byte == 0
-    return ((t >> 7) * 0x00204081u) >> 21 & 0xFu;                          // gather bits 0,8,16,24
-}
-__device__ __forceinline__ uint32_t space_mask16(const uint4& v) {
-    return space_nibble(v.x) | (space_nibble(v.y) << 4) | (space_nibble(v.z) << 8) | (space_nibble(v.w) << 12);
-}
-
-// =============================================================================================
 // Stage B: register-resident fast path
 // =============================================================================================
 
-struct Tile {
-    const uint32_t* w;   // tile bytes as dwords (LDS)
-    const uint32_t* bm;  // space bitmap, bit i <=> tile byte i == ' ' (LDS)
-};
-
-// 8 consecutive bytes starting at tile byte `a` (unaligned) as two little-endian dwords
-__device__ __forceinline__ void load8(const Tile& T, uint32_t a, uint32_t* lo, uint32_t* hi) {
-    uint32_t d = a >> 2, s = a & 3u;
-    uint32_t w0 = T.w[d], w1 = T.w[d + 1], w2 = T.w[d + 2];
-    *lo = __builtin_amdgcn_alignbyte(w1, w0, s);
-    *hi = __builtin_amdgcn_alignbyte(w2, w1, s);
-}
 // first space at line index >= q (tile byte base+q), or len.  Bitmap walk, 32 bytes per step.
 __device__ __forceinline__ uint32_t find_space_bm(const Tile& T, uint32_t base, uint32_t q, uint32_t len) {
     while (q < len) {
@@ -531,20 +502,6 @@ __device__ __forceinline__ Fast parse_line_fast(const Tile& T, uint32_t base, ui
     return f;
 }
 
-// 16-bit mask (bit i = byte i of v equals 0x20) via exact SWAR zero-byte test + v_dot4_u32_u8 as
-// the bit gather: flags are 0x80 per matching byte, the weights 1,2,4,8 / 16..128 place them.
-__device__ __forceinline__ uint32_t eq20_flags(uint32_t x) {
-    uint32_t s = ((x & 0x7F7F7F7Fu) ^ 0x20202020u) + 0x7F7F7F7Fu;  // bit7 set <=> low 7 bits != 0x20
-    return ~(s | x) & 0x80808080u;                                   // bit7 set <=> byte == 0x20
-}
-__device__ __forceinline__ uint32_t space_mask16_dot(const uint4& v) {
-    uint32_t lo = __builtin_amdgcn_udot4(eq20_flags(v.y), 0x80402010u,
-                                         __builtin_amdgcn_udot4(eq20_flags(v.x), 0x08040201u, 0u, false), false);
-    uint32_t hi = __builtin_amdgcn_udot4(eq20_flags(v.w), 0x80402010u,
-                                         __builtin_amdgcn_udot4(eq20_flags(v.z), 0x08040201u, 0u, false), false);
-    return (lo >> 7) | (hi << 1);
-}
-
 // ---------------------------------------------------------------------------------------------
 // Structured data out of the tile (the hot form; the byte-walking sd_walk above stays for lines
 // outside the tile and for the generic route).
@@ -555,37 +512,13 @@ __device__ __forceinline__ uint32_t space_mask16_dot(const uint4& v) {
 // per-lane walker jumps over every value with one bit scan instead of walking it byte by byte;
 // names, '=' and separators (a handful of bytes per pair) are still walked.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t eq_flags(uint32_t x, uint32_t pat) {  // bit7 of each byte: byte == pat's byte (pat < 0x80)
-    uint32_t s = ((x & 0x7F7F7F7Fu) ^ pat) + 0x7F7F7F7Fu;
-    return ~(s | x) & 0x80808080u;
-}
-__device__ __forceinline__ uint32_t quote_mask16(const uint4& v) {
-    const uint32_t Q = 0x22222222u, B = 0x5C5C5C5Cu;
-    uint32_t f0 = eq_flags(v.x, Q) | eq_flags(v.x, B), f1 = eq_flags(v.y, Q) | eq_flags(v.y, B);
-    uint32_t f2 = eq_flags(v.z, Q) | eq_flags(v.z, B), f3 = eq_flags(v.w, Q) | eq_flags(v.w, B);
-    uint32_t lo = __builtin_amdgcn_udot4(f1, 0x80402010u, __builtin_amdgcn_udot4(f0, 0x08040201u, 0u, false), false);
-    uint32_t hi = __builtin_amdgcn_udot4(f3, 0x80402010u, __builtin_amdgcn_udot4(f2, 0x08040201u, 0u, false), false);
-    return (lo >> 7) | (hi << 1);
-}
-// wave-cooperative: bm16[c] = quote/backslash mask of tile chunk c for c < nchunk (overwrites the
-// space bitmap).  Caller brackets it with wave barriers.
-__device__ __forceinline__ void build_quote_bitmap(const uint8_t* smem, uint16_t* bm16, uint32_t nchunk) {
-    const uint4* src = reinterpret_cast<const uint4*>(smem);
-    for (uint32_t c = threadIdx.x; c < nchunk; c += kWave) bm16[c] = (uint16_t)quote_mask16(src[c]);
-}
-// first set bit of the tile bitmap at line index >= q, or len
-__device__ __forceinline__ uint32_t find_bit(const uint32_t* bm, uint32_t base, uint32_t q, uint32_t len) {
-    while (q < len) {
-        uint32_t a = base + q;
-        uint32_t w = bm[a >> 5] >> (a & 31u);
-        if (w) {
-            uint32_t r = q + (uint32_t)__builtin_ctz(w);
-            return r < len ? r : len;
-        }
-        q += 32u - (a & 31u);
+struct QuoteClass {  // '"' or '\\'
+    static __device__ __forceinline__ uint32_t mask16(const uint4& v) {
+        const uint32_t Q = 0x22222222u, B = 0x5C5C5C5Cu;
+        return gather16(eq_flags(v.x, Q) | eq_flags(v.x, B), eq_flags(v.y, Q) | eq_flags(v.y, B),
+                        eq_flags(v.z, Q) | eq_flags(v.z, B), eq_flags(v.w, Q) | eq_flags(v.w, B));
     }
-    return len;
-}
+};
 __device__ __forceinline__ bool is_sd_name_char(uint32_t c) {  // :188-192
     return (c - 33u) <= 93u && c != '"' && c != '=' && c != ']';
 }
@@ -597,18 +530,6 @@ struct WinMasks {
     uint32_t name;  // 33..=126 minus '"' '=' ']'                                   :188-192
     uint32_t eq, quote, rb;
 };
-__device__ __forceinline__ uint32_t gather16(uint32_t f0, uint32_t f1, uint32_t f2, uint32_t f3) {
-    uint32_t lo = __builtin_amdgcn_udot4(f1, 0x80402010u, __builtin_amdgcn_udot4(f0, 0x08040201u, 0u, false), false);
-    uint32_t hi = __builtin_amdgcn_udot4(f3, 0x80402010u, __builtin_amdgcn_udot4(f2, 0x08040201u, 0u, false), false);
-    return (lo >> 7) | (hi << 1);
-}
-// bit7 of each byte set <=> 33 <= byte <= 126
-__device__ __forceinline__ uint32_t range_flags(uint32_t x) {
-    uint32_t l = x & 0x7F7F7F7Fu;
-    uint32_t ge33 = l + 0x5F5F5F5Fu;  // bit7 set <=> low7 >= 33
-    uint32_t le126 = l + 0x01010101u; // bit7 set <=> low7 == 127
-    return ge33 & ~le126 & ~x & 0x80808080u;
-}
 __device__ __forceinline__ WinMasks window_masks(const uint32_t w[4]) {
     uint32_t sp[4], qu[4], eq[4], rb[4], rg[4];
 #pragma unroll
@@ -628,15 +549,6 @@ __device__ __forceinline__ WinMasks window_masks(const uint32_t w[4]) {
     m.name = gather16(rg[0], rg[1], rg[2], rg[3]) & ~(m.quote | m.eq | m.rb);
     return m;
 }
-// 16 bytes of the tile starting at byte address a (unaligned)
-__device__ __forceinline__ void load16(const Tile& T, uint32_t a, uint32_t w[4]) {
-    const uint32_t d = a >> 2, s = a & 3u;
-    uint32_t r0 = T.w[d], r1 = T.w[d + 1], r2 = T.w[d + 2], r3 = T.w[d + 3], r4 = T.w[d + 4];
-    w[0] = __builtin_amdgcn_alignbyte(r1, r0, s);
-    w[1] = __builtin_amdgcn_alignbyte(r2, r1, s);
-    w[2] = __builtin_amdgcn_alignbyte(r3, r2, s);
-    w[3] = __builtin_amdgcn_alignbyte(r4, r3, s);
-}
 
 // Same contract as sd_walk, for a line in the tile whose group has the quote/backslash bitmap
 // (T.bm) built.  Lane-per-line, but token- instead of byte-granular: a serial byte walk on a GPU
@@ -651,7 +563,6 @@ __device__ __forceinline__ void load16(const Tile& T, uint32_t a, uint32_t w[4])
 //                 (stash[k * 64 + lane], k < kStashEntries): once the wave has its slots, the
 //                 entries are copied out of the stash instead of parsing every line a second time.
 enum { SD_COUNT = 0, SD_EMIT = 1, SD_STASH = 2 };
-constexpr uint32_t kStashEntries = 48;  // per line; lines with more fall back to the second parse
 // record: name_s | name_len << 16 | val_len << 32 | esc << 48 | is_sdid << 49   (val_s = name_s + name_len + 2)
 __device__ __forceinline__ uint64_t stash_pack(uint32_t name_s, uint32_t name_len, uint32_t val_len, uint32_t esc, uint32_t sdid) {
     return (uint64_t)name_s | ((uint64_t)name_len << 16) | ((uint64_t)val_len << 32) | ((uint64_t)esc << 48) | ((uint64_t)sdid << 49);
@@ -821,27 +732,19 @@ __device__ __forceinline__ void parse_tail_sd_tile(const Tile& T, uint32_t base,
     }
 }
 
-// Stage B + SD entries + table row for ONE line group whose tile is in LDS (shared by both
-// kernels).  o0/o1 = this lane's line [o0, o1) in the packed buffer, a0 = packed-buffer address
-// of tile byte 0, span = tile bytes staged.
-struct RowOut {
-    uint32_t meta;
-    double ts;
-    fg_span span[6];
-    uint32_t first, count;
-};
-__device__ __forceinline__ void store_row(const DevTables& t, uint64_t li, const RowOut& o) {
-    t.meta[li] = o.meta;
-    t.ts[li] = o.ts;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) t.span[k][li] = o.span[k];
-    t.ent_first[li] = o.first;
-    t.ent_count[li] = o.count;
-}
-__device__ __forceinline__ RowOut decode_group(const uint8_t* __restrict__ bytes, const uint8_t* smem,
-                                               const uint16_t* bm16, uint64_t o0, uint64_t o1, uint64_t a0,
-                                               uint32_t span, bool valid, const DevTables& t, uint32_t ablate = 0,
-                                               uint64_t* stash = nullptr) {
+// The format policy of the streaming pipeline (fg_pipeline.hpp): stage A builds the SPACE bitmap;
+// decode() = stage B + SD entries + the table row for ONE line group whose tile is in LDS.
+struct Rfc5424Format {
+    static __device__ __forceinline__ uint32_t mask16(const uint4& v) { return mask16_eq(v, 0x20202020u); }
+
+    __device__ __forceinline__ RowOut decode(const GroupCtx& c, const DevTables& t) const {
+    const uint8_t* __restrict__ bytes = c.bytes;
+    const uint8_t* smem = c.smem;
+    uint16_t* bm16 = c.bm16;
+    const uint64_t o0 = c.o0, o1 = c.o1, a0 = c.a0;
+    const uint32_t span = c.span, ablate = c.ablate;
+    const bool valid = c.valid;
+    uint64_t* stash = c.stash;
     const uint32_t lane = threadIdx.x;
     Row r;
 #pragma unroll
@@ -878,7 +781,7 @@ __device__ __forceinline__ RowOut decode_group(const uint8_t* __restrict__ bytes
     const bool group_has_sd = __any(sd_lane);  // wave-uniform
     if (group_has_sd) {
         __syncthreads();
-        build_quote_bitmap(smem, const_cast<uint16_t*>(bm16), span >> 4);
+        rebuild_bitmap<QuoteClass>(smem, bm16, span >> 4);
         __syncthreads();
     }
     // ---- 3. the rare / heavy routes ------------------------------------------------------------
@@ -973,321 +876,45 @@ __device__ __forceinline__ RowOut decode_group(const uint8_t* __restrict__ bytes
     o.first = first;
     o.count = r.n_ent;
     return o;
-}
-
-// v2: one wave per 64-line group, one group per wave (kept for A/B and as the simple form).
-// Dynamic LDS: [tile_cap + 64 bytes of data][bitmap: 2 B per 16 B].
-template <int BATCH>
-__global__ __launch_bounds__(kWave) void k_rfc5424(const uint8_t* __restrict__ bytes,
-                                                  const uint64_t* __restrict__ offsets, uint64_t n,
-                                                  DevTables t, uint32_t tile_cap) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint16_t* bm16 = reinterpret_cast<uint16_t*>(smem + tile_cap + 64u);
-    const uint32_t lane = threadIdx.x;
-    const uint64_t l0 = (uint64_t)blockIdx.x * kWave;
-    const uint64_t li = l0 + lane;
-    const bool valid = li < n;
-    const uint64_t last = (l0 + kWave < n) ? l0 + kWave : n;
-    const uint64_t o0 = offsets[valid ? li : last];
-    const uint64_t o1 = offsets[valid ? li + 1 : last];
-    const uint64_t lo = __shfl(o0, 0, kWave);
-    const uint64_t hi = __shfl(o1, (int)(last - l0 - 1), kWave);
-    const uint64_t a0 = lo & ~15ull;
-    const uint64_t want = hi - a0;
-    const uint32_t span = want > tile_cap ? tile_cap : (uint32_t)((want + 15ull) & ~15ull);
-
-    // ---- stage A: stream [a0, a0+span) through registers into LDS, classify on the way ----
-    {
-        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(bytes + a0);
-        uint4* dst = reinterpret_cast<uint4*>(smem);
-        const uint32_t nchunk = span >> 4;
-        for (uint32_t c0 = 0; c0 < nchunk; c0 += kWave * BATCH) {
-            uint4 v[BATCH];
-#pragma unroll
-            for (int k = 0; k < BATCH; ++k) {
-                uint32_t idx = c0 + k * kWave + lane;
-                if (idx < nchunk) v[k] = src[idx];
-            }
-#pragma unroll
-            for (int k = 0; k < BATCH; ++k) {
-                uint32_t idx = c0 + k * kWave + lane;
-                if (idx < nchunk) {
-                    dst[idx] = v[k];
-                    bm16[idx] = (uint16_t)space_mask16(v[k]);
-                }
-            }
-        }
     }
-    __syncthreads();
-    RowOut o = decode_group(bytes, smem, bm16, o0, o1, a0, span, valid, t);
-    if (valid) store_row(t, li, o);
-}
+};
 
-// v3 (default): PERSISTENT waves with a register-resident prefetch window.
-//   Each wave walks line groups g = blockIdx.x, +gridDim.x, ...  (L lines per group, L = 64 for
-//   ~256-byte lines, smaller powers of two for longer lines so that a group's bytes fit the tile).
-//   While the lanes tokenise group g out of LDS (stage B), the bytes of group g+G are already on
-//   their way from HBM into NB x 16 B of VGPRs per lane (NB KiB per wave) and the offsets of
-//   group g+2G behind them, so every resident wave keeps ~NB KiB of HBM reads in flight all the
-//   time -- the VGPR file (512 KiB/CU, almost unused by this integer kernel) is the second buffer,
-//   LDS holds one tile per wave.  Bytes beyond the NB KiB window (rare: the window is sized for
-//   the average group + 12.5 %) are staged by a plain tail loop.
-//   PROF = true is a measurement build of the same kernel: s_memtime stamps at the phase
-//   boundaries, summed per wave and added to prof[0..4] = {wait-for-window, stage A, stores +
-//   prefetch issue, stage B, iterations} (FG_PROF=1, see the launcher).  Never the product path.
+// PROF = true is a measurement build of the same kernel (s_memtime stamps at the phase boundaries,
+// FG_PROF=1 / FG_ABLATE, see fg_pipeline.hpp); never the product path.
 template <int NB, bool PROF>
-__global__ __launch_bounds__(kWave, 2) void k_rfc5424_p(const uint8_t* __restrict__ bytes,
-                                                    const uint64_t* __restrict__ offsets, uint64_t n,
-                                                    DevTables t, uint32_t tile_cap, uint32_t L,
-                                                    uint64_t groups, unsigned long long* prof, uint64_t* stash_base) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint16_t* bm16 = reinterpret_cast<uint16_t*>(smem + tile_cap + 64u);
-    uint4* dst = reinterpret_cast<uint4*>(smem);
-    const uint32_t lane = threadIdx.x;
-    const uint64_t G = gridDim.x;
-    uint64_t* stash = stash_base ? stash_base + (uint64_t)blockIdx.x * (kStashEntries * kWave) : nullptr;
-
-    // group geometry from the lanes' offsets, as SCALARS: tile start (16-byte aligned) + staged span
-    auto geometry = [&](uint64_t g, uint64_t o0, uint64_t o1, uint64_t* a0, uint32_t* span) {
-        const uint64_t l0 = g * L;
-        const uint32_t nl = (uint32_t)((l0 + L <= n) ? L : n - l0);
-        // (the builtins return int: widen through uint32_t or bit 31 sign-extends into the high word)
-        const uint32_t last = (uint32_t)__builtin_amdgcn_readfirstlane((int)(nl - 1u));
-        const uint32_t lo_l = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)o0);
-        const uint32_t lo_h = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(o0 >> 32));
-        const uint32_t hi_l = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)o1, (int)last);
-        const uint32_t hi_h = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(o1 >> 32), (int)last);
-        const uint64_t lo = (uint64_t)lo_l | ((uint64_t)lo_h << 32);
-        const uint64_t hi = (uint64_t)hi_l | ((uint64_t)hi_h << 32);
-        *a0 = lo & ~15ull;
-        const uint64_t want = hi - *a0;
-        *span = want > tile_cap ? tile_cap : (uint32_t)((want + 15ull) & ~15ull);
-    };
-    auto load_offsets = [&](uint64_t g, uint64_t* o0, uint64_t* o1) {
-        const uint64_t l0 = g * L;
-        uint64_t li = l0 + lane;
-        const uint64_t last = (l0 + L < n) ? l0 + L : n;
-        const bool valid = lane < L && li < n;
-        *o0 = offsets[valid ? li : last];
-        *o1 = offsets[valid ? li + 1 : last];
-    };
-    // the register window: NB buffer loads of 16 B per lane; the buffer descriptor bounds the
-    // tile, so rows past `span` fetch nothing and return zeros -- no per-row predication.  The
-    // row offset goes into the VGPR/immediate offset (the part the hardware range-checks; the
-    // scalar offset is not checked).
-    auto load_window = [&](uint64_t a0, uint32_t span, u32x4* v) {
-        __amdgpu_buffer_rsrc_t rsrc =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(bytes + a0), (short)0, (int)span, 0x00020000);
-#pragma unroll
-        for (int k = 0; k < NB; ++k) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(lane * 16u + k * 1024u), 0, 0);
-    };
-
-    uint64_t g = blockIdx.x;
-    if (g >= groups) return;
-    uint64_t o0, o1, a0;
-    uint32_t span;
-    load_offsets(g, &o0, &o1);
-    geometry(g, o0, o1, &a0, &span);
-    u32x4 v[NB];
-    load_window(a0, span, v);
-    uint64_t no0 = 0, no1 = 0;
-    if (g + G < groups) load_offsets(g + G, &no0, &no1);
-    // The table row of a group is stored one iteration LATE (after the next group's stage A,
-    // before the prefetch after that is issued): vmcnt retires in order, so stores issued
-    // behind the window loads would have to be waited for at the top of every iteration.
-    RowOut pend{};
-    uint64_t pend_li = 0;
-    bool pend_valid = false;
-    uint64_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0, iters = 0, tm0 = 0, tm1 = 0, tm2 = 0, tm3 = 0;
-    // measurement build only: prof[5] = ablation flags (1 = no table stores, 2 = no stage B)
-    const uint32_t ablate = PROF ? (uint32_t)prof[5] : 0u;
-
-    for (;;) {
-        if (PROF) {
-            tm0 = __builtin_amdgcn_s_memtime();
-            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the window has landed
-            tm1 = __builtin_amdgcn_s_memtime();
-        }
-        // ---- stage A for group g: registers -> LDS, classify on the way ----------------------
-        const uint32_t nchunk = span >> 4;
-        const uint32_t nrow = (nchunk + kWave - 1u) / kWave;  // wave-uniform
-#pragma unroll
-        for (int k = 0; k < NB; ++k) {
-            if ((uint32_t)k < nrow) {  // scalar branch; lanes past the span store zeros inside the tile
-                uint32_t idx = k * kWave + lane;
-                uint4 q = make_uint4(v[k][0], v[k][1], v[k][2], v[k][3]);
-                dst[idx] = q;
-                bm16[idx] = (uint16_t)space_mask16_dot(q);
-            }
-        }
-        if (nrow > (uint32_t)NB) {  // rare: bytes beyond the register window
-            const uint4* __restrict__ src = reinterpret_cast<const uint4*>(bytes + a0);
-            for (uint32_t c0 = NB * kWave; c0 < nchunk; c0 += kWave * 4) {
-                uint4 w[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    uint32_t idx = c0 + k * kWave + lane;
-                    if (idx < nchunk) w[k] = src[idx];
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    uint32_t idx = c0 + k * kWave + lane;
-                    if (idx < nchunk) {
-                        dst[idx] = w[k];
-                        bm16[idx] = (uint16_t)space_mask16_dot(w[k]);
-                    }
-                }
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);  // keep the old window dead before the new one is loaded
-        if (PROF) {
-            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): LDS writes retired
-            tm2 = __builtin_amdgcn_s_memtime();
-        }
-        if (pend_valid && !(ablate & 1u)) store_row(t, pend_li, pend);
-        // ---- prefetch: offsets of g+2G first (they must not queue behind the data), then the
-        //      bytes of g+G into the register window ------------------------------------------
-        const uint64_t gn = g + G;
-        const bool more = gn < groups;  // wave-uniform
-        uint64_t po0 = no0, po1 = no1, pa0 = 0;
-        uint32_t pspan = 0;
-        if (more) {
-            if (gn + G < groups) load_offsets(gn + G, &no0, &no1);
-            geometry(gn, po0, po1, &pa0, &pspan);
-            load_window(pa0, pspan, v);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (PROF) tm3 = __builtin_amdgcn_s_memtime();
-        __syncthreads();  // single-wave workgroup: orders the LDS writes before stage B's reads
-        // ---- stage B for group g ------------------------------------------------------------
-        if (!(ablate & 2u)) {
-            const uint64_t li = g * L + lane;
-            const bool valid = lane < L && li < n;
-            pend = decode_group(bytes, smem, bm16, o0, o1, a0, span, valid, t, ablate, (ablate & 8u) ? nullptr : stash);
-            pend_li = li;
-            pend_valid = valid;
-        }
-        if (PROF) {
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_waitcnt(0xC07F);
-            uint64_t tm4 = __builtin_amdgcn_s_memtime();
-            acc0 += tm1 - tm0;
-            acc1 += tm2 - tm1;
-            acc2 += tm3 - tm2;
-            acc3 += tm4 - tm3;
-            iters += 1;
-        }
-        if (!more) break;
-        __syncthreads();  // stage B's LDS reads are done before the next tile overwrites them
-        g = gn;
-        o0 = po0;
-        o1 = po1;
-        a0 = pa0;
-        span = pspan;
-    }
-    if (pend_valid && !(ablate & 1u)) store_row(t, pend_li, pend);
-    if (PROF && lane == 0) {
-        atomicAdd(&prof[0], (unsigned long long)acc0);
-        atomicAdd(&prof[1], (unsigned long long)acc1);
-        atomicAdd(&prof[2], (unsigned long long)acc2);
-        atomicAdd(&prof[3], (unsigned long long)acc3);
-        atomicAdd(&prof[4], (unsigned long long)iters);
-    }
+__global__ __launch_bounds__(kWave, 2) void k_rfc5424(const uint8_t* __restrict__ bytes,
+                                                     const uint64_t* __restrict__ offsets, uint64_t n, DevTables t,
+                                                     uint32_t tile_cap, uint32_t L, uint64_t groups,
+                                                     unsigned long long* prof, uint64_t* stash_base) {
+    Rfc5424Format fmt;
+    persistent_loop<NB, PROF>(bytes, offsets, n, t, tile_cap, L, groups, prof, stash_base, fmt);
 }
 
 }  // namespace fg
 
-// host-side launcher (called from fg_capi.cpp).  tile_cap: multiple of 1024.
-//   FG_RFC5424_KERNEL=v2 selects the one-group-per-wave kernel (A/B); default = persistent v3.
-namespace {
-constexpr int kWindowKiB = 20;  // register prefetch window per wave (NB): 80 VGPRs
-struct PersistPlan {
-    int blocks_per_cu = 0;
-    int cus = 0;
-};
-}  // namespace
-
-extern "C" uint64_t fg_rfc5424_stash_bytes(uint32_t blocks) {
-    return (uint64_t)blocks * fg::kStashEntries * fg::kWave * sizeof(uint64_t);
+extern "C" uint64_t fg_stash_bytes(uint32_t blocks) {
+    return (uint64_t)blocks * fg::kStashEntries * fg::kStashWords * fg::kWave * sizeof(uint64_t);
 }
 
-// stash: device scratch of fg_rfc5424_stash_bytes(stash_blocks) bytes (or NULL: SD lines are then
-// parsed twice); the persistent grid is capped at stash_blocks.
-extern "C" int fg_launch_rfc5424(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n,
-                                 const fg::DevTables* t, uint32_t tile_cap, hipStream_t stream, uint64_t* stash,
-                                 uint32_t stash_blocks) {
+// host-side launcher (called from fg_capi.cpp).  stash: device scratch of fg_stash_bytes(stash_blocks)
+// bytes (or NULL: SD lines are then parsed twice); the persistent grid is capped at stash_blocks.
+extern "C" int fg_launch_rfc5424(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
+                                 uint64_t avg_len, hipStream_t stream, uint64_t* stash, uint32_t stash_blocks) {
     if (n == 0) return 0;
-    // tuning / A-B knobs are read per launch (getenv is nanoseconds next to a launch) so that the
-    // parity tests can sweep them inside one process
-    const char* e_ver = getenv("FG_RFC5424_KERNEL");
-    const int kernel_ver = (e_ver && e_ver[0] == 'v' && e_ver[1] == '2') ? 2 : 3;
-    dim3 block(fg::kWave);
-    if (kernel_ver == 2) {
-        uint64_t groups = (n + fg::kWave - 1) / fg::kWave;
-        if (groups > 0x7FFFFFFFull) return -1;
-        uint32_t lds = tile_cap + 64u + (tile_cap / 16u + 16u) * 2u;
-        dim3 grid((uint32_t)groups);
-        hipLaunchKernelGGL(fg::k_rfc5424<8>, grid, block, lds, stream, d_bytes, d_offsets, n, *t, tile_cap);
-        return (int)hipGetLastError();
-    }
-    // lines per group: the host sized tile_cap for 64 average lines (+12.5 %), capped by LDS; when
-    // that cap bit (long lines) halve L until a group's expected bytes fit the register window.
-    // tile_cap encodes the average: avg ~= (tile_cap - 512) * 8 / 9 / 64 unless capped.
-    uint32_t L = 64;
-    uint32_t tile = tile_cap;
-    {
-        const char* e_l = getenv("FG_LINES_PER_GROUP");
-        const uint32_t forced = e_l ? (uint32_t)atoi(e_l) : 0u;
-        while (tile > (uint32_t)kWindowKiB * 1024u && L > 1) {
-            L >>= 1;
-            tile = ((tile / 2u + 1023u) / 1024u) * 1024u;
-        }
-        if (tile < 4096u) tile = 4096u;
-        if (forced >= 1 && forced <= 64 && (forced & (forced - 1)) == 0) {
-            L = forced;
-            tile = tile_cap;
-        }
-    }
-    const uint64_t groups = (n + L - 1) / L;
-    const uint32_t lds = tile + 64u + (tile / 16u + 16u) * 2u;
-    auto kern = fg::k_rfc5424_p<kWindowKiB, false>;
-    static int cus = 0;
-    int dev = 0;
-    if (cus == 0) {
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
-        cus = prop.multiProcessorCount;
-    }
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, fg::kWave, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-    const char* e_w = getenv("FG_WAVES_PER_CU");
-    const int waves_cap = e_w ? atoi(e_w) : 0;
-    if (waves_cap > 0 && per_cu > waves_cap) per_cu = waves_cap;
-    uint64_t nblocks = (uint64_t)per_cu * (uint64_t)cus;
-    if (nblocks > groups) nblocks = groups;
-    if (stash && nblocks > stash_blocks) nblocks = stash_blocks;
+    fg::LaunchPlan p;
+    if (fg::plan_launch(fg::k_rfc5424<fg::kWindowKiB, false>, n, avg_len, 0u, 57344u, stash ? stash_blocks : 0u, &p)) return -1;
     if (stash_blocks == 0) stash = nullptr;
-    dim3 grid((uint32_t)nblocks);
+    dim3 grid(p.blocks), block(fg::kWave);
     if (getenv("FG_PROF")) {
-        // measurement build: synchronous, prints the per-phase cycle split to stderr
-        unsigned long long* d_prof = nullptr;
-        unsigned long long h[6] = {0, 0, 0, 0, 0, 0};
-        if (const char* e_a = getenv("FG_ABLATE")) h[5] = (unsigned long long)atoi(e_a);
-        if (hipMalloc((void**)&d_prof, sizeof(h)) != hipSuccess) return -1;
-        (void)hipMemcpyAsync(d_prof, h, sizeof(h), hipMemcpyHostToDevice, stream);
-        hipLaunchKernelGGL((fg::k_rfc5424_p<kWindowKiB, true>), grid, block, lds, stream, d_bytes, d_offsets, n, *t, tile, L,
-                           groups, d_prof, stash);
-        (void)hipStreamSynchronize(stream);
-        (void)hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost);
-        (void)hipFree(d_prof);
-        const double it = h[4] ? (double)h[4] : 1.0;
-        fprintf(stderr,
-                "[fg prof] rfc5424 v3: grid %u x64, L %u, tile %u, iters/wave %.1f | cycles per iteration: wait %.0f, "
-                "stageA %.0f, stores+prefetch-issue %.0f, stageB %.0f\n",
-                (unsigned)nblocks, L, tile, it / (double)nblocks, h[0] / it, h[1] / it, h[2] / it, h[3] / it);
+        fg::ProfRun pr;
+        if (!pr.begin(stream)) return -1;
+        hipLaunchKernelGGL((fg::k_rfc5424<fg::kWindowKiB, true>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile,
+                           p.L, p.groups, pr.d, stash);
+        pr.end(stream, "rfc5424", p);
         return (int)hipGetLastError();
     }
-    hipLaunchKernelGGL(kern, grid, block, lds, stream, d_bytes, d_offsets, n, *t, tile, L, groups,
-                       (unsigned long long*)nullptr, stash);
+    hipLaunchKernelGGL((fg::k_rfc5424<fg::kWindowKiB, false>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L,
+                       p.groups, (unsigned long long*)nullptr, stash);
     return (int)hipGetLastError();
 }
+

@@ -136,13 +136,12 @@ def test_long_tail_lengths_match_oracle(rfc, oracle):
 
 
 @pytest.mark.parametrize("knobs", [
-    {"FG_RFC5424_KERNEL": "v2"},
     {"FG_LINES_PER_GROUP": "64"}, {"FG_LINES_PER_GROUP": "32"}, {"FG_LINES_PER_GROUP": "8"},
-    {"FG_LINES_PER_GROUP": "1"}, {"FG_WAVES_PER_CU": "1"}, {"FG_TILE_CAP": "4096"},
+    {"FG_LINES_PER_GROUP": "1"}, {"FG_LINES_PER_GROUP": "48"}, {"FG_WAVES_PER_CU": "1"}, {"FG_TILE_CAP": "4096"},
     {"FG_TILE_CAP": "40960", "FG_LINES_PER_GROUP": "64"},
 ], ids=lambda k: ",".join(f"{a[3:]}={b}" for a, b in k.items()))
 def test_kernel_variants_are_bit_identical(rfc, oracle, knobs, monkeypatch):
-    """Every launch shape of the RFC5424 kernel (one-group-per-wave v2, persistent v3 with 64..1 lines
+    """Every launch shape of the RFC5424 kernel (64..1 lines
     per group, one wave per CU, tiles smaller than a group so that lines fall back to the global
     reader, tiles larger than the register window so that the tail loop runs) gives the oracle's
     bytes on all three corpora shapes."""
