@@ -289,12 +289,18 @@ struct SchemaEnt {                      // 24 bytes
     uint32_t type;
     uint32_t name[4];                   // first 16 bytes of the name, zero padded
 };
-constexpr uint32_t kLtsvExtraLds = 768u + kSchemaLds * sizeof(SchemaEnt);
+struct SuffixEnt {                      // 16 bytes: the four configured suffixes (bool, f64, i64, u64)
+    uint32_t len;                       // 0xFFFFFFFF = not configured
+    uint32_t pad;
+    uint64_t bytes;                     // first 8 bytes, zero padded
+};
+constexpr uint32_t kLtsvExtraLds = 768u + kSchemaLds * sizeof(SchemaEnt) + 4u * sizeof(SuffixEnt);
 
 struct LtsvFormat {
     LtsvDevCfg cfg;
     uint8_t* lds_digits;        // 768-byte digit buffer for dec2flt's slow path
     const SchemaEnt* schema;    // LDS mirror of the first kSchemaLds schema entries
+    const SuffixEnt* suffix;    // LDS mirror of the four suffixes
 
     static __device__ __forceinline__ uint32_t mask16(const uint4& v) { return mask16_eq(v, 0x09090909u); }
 
@@ -327,6 +333,7 @@ struct LtsvFormat {
     // only counted -- a line with more than kStashEntries pairs is re-walked by ltsv_walk<true>).
     __device__ __forceinline__ void walk_tile(const Tile& T, uint32_t base, uint32_t len, LRow& r, uint64_t* stash) const {
         LdsReader rd(T.w, base);
+        WinReader wr(T, base);  // numbers / timestamps: 16 bytes per LDS round trip
         uint32_t cnt = 0;
         uint32_t ps = 0;
         for (;;) {  // line.split('\t')
@@ -358,12 +365,12 @@ struct LtsvFormat {
                 const bool short4 = k[1] == 0u && k[2] == 0u && k[3] == 0u;
                 if (nl == 4u && short4 && k[0] == 0x656D6974u) {           // "time"
                     uint32_t b = vb, e = ve;
-                    if (e > b && rd.byte(b) == '[' && rd.byte(e - 1) == ']' && e - b >= 2) {
+                    if (e > b && wr.byte(b) == '[' && rd.byte(e - 1) == ']' && e - b >= 2) {
                         ++b;
                         --e;
                     }
                     double ts;
-                    if (!ltsv_parse_ts(rd, b, e, lds_digits, &ts)) {
+                    if (!ltsv_parse_ts(wr, b, e, lds_digits, &ts)) {
                         r.status = L_ENGLISH;
                         return;
                     }
@@ -378,7 +385,7 @@ struct LtsvFormat {
                     r.msg_len = ve - vb;
                 } else if (nl == 5u && k[0] == 0x6576656Cu && k[1] == 0x0000006Cu && k[2] == 0u && k[3] == 0u) {  // "level"
                     uint64_t lv;
-                    if (!num::parse_unsigned(rd, vb, ve, 255, &lv)) {
+                    if (!num::parse_unsigned(wr, vb, ve, 255, &lv)) {
                         r.status = L_LEVEL;
                         return;
                     }
@@ -401,32 +408,42 @@ struct LtsvFormat {
                             }
                         } else if (ty == FG_T_F64) {
                             double d;
-                            if (!parse_f64_wave(rd, vb, ve, lds_digits, &d)) {
+                            if (!parse_f64_wave(wr, vb, ve, lds_digits, &d)) {
                                 r.status = L_F64;
                                 return;
                             }
                             val = num::f64_to_bits(d);
                         } else if (ty == FG_T_I64) {
                             int64_t x;
-                            if (!num::parse_i64(rd, vb, ve, &x)) {
+                            if (!num::parse_i64(wr, vb, ve, &x)) {
                                 r.status = L_I64;
                                 return;
                             }
                             val = (uint64_t)x;
                         } else {
                             uint64_t x;
-                            if (!num::parse_unsigned(rd, vb, ve, 0xFFFFFFFFFFFFFFFFull, &x)) {
+                            if (!num::parse_unsigned(wr, vb, ve, 0xFFFFFFFFFFFFFFFFull, &x)) {
                                 r.status = L_U64;
                                 return;
                             }
                             val = x;
                         }
                         // suffix: appended unless the name already ends with it (:131-136)
-                        const uint32_t si = ty - FG_T_BOOL;
-                        if (cfg.has_suf[si]) {
-                            uint32_t sl = cfg.suf_len[si], so = cfg.suf_off[si];
-                            bool ends = nl >= sl;
-                            for (uint32_t i = 0; i < sl && ends; ++i) ends = rd.byte(ne - sl + i) == cfg.blob[so + i];
+                        const SuffixEnt sf = suffix[ty - FG_T_BOOL];
+                        if (sf.len != 0xFFFFFFFFu) {
+                            bool ends = nl >= sf.len;
+                            if (ends && sf.len != 0u) {
+                                if (sf.len <= 8u) {
+                                    uint32_t t0, t1;
+                                    load8(T, base + ne - sf.len, &t0, &t1);
+                                    uint64_t tail = (uint64_t)t0 | ((uint64_t)t1 << 32);
+                                    if (sf.len < 8u) tail &= ~0ull >> (64u - 8u * sf.len);
+                                    ends = tail == sf.bytes;
+                                } else {
+                                    const uint32_t so = cfg.suf_off[ty - FG_T_BOOL];
+                                    for (uint32_t i = 0; i < sf.len && ends; ++i) ends = rd.byte(ne - sf.len + i) == cfg.blob[so + i];
+                                }
+                            }
                             if (!ends) flags |= FG_EF_SUFFIX;
                         }
                     }
@@ -542,8 +559,19 @@ __global__ __launch_bounds__(kWave, 2) void k_ltsv(const uint8_t* __restrict__ b
         }
         schema[k] = e;
     }
+    SuffixEnt* suffix = reinterpret_cast<SuffixEnt*>(extra + 768u + kSchemaLds * sizeof(SchemaEnt));
+    if (threadIdx.x < 4u) {
+        const uint32_t k = threadIdx.x;
+        SuffixEnt e;
+        e.len = cfg.has_suf[k] ? cfg.suf_len[k] : 0xFFFFFFFFu;
+        e.pad = 0;
+        e.bytes = 0;
+        if (cfg.has_suf[k])
+            for (uint32_t i = 0; i < cfg.suf_len[k] && i < 8u; ++i) e.bytes |= (uint64_t)cfg.blob[cfg.suf_off[k] + i] << (8u * i);
+        suffix[k] = e;
+    }
     __syncthreads();
-    LtsvFormat fmt{cfg, extra, schema};
+    LtsvFormat fmt{cfg, extra, schema, suffix};
     persistent_loop<NB, PROF>(bytes, offsets, n, t, tile_cap, L, groups, prof, stash_base, fmt);
 }
 

@@ -71,6 +71,30 @@ __device__ __forceinline__ void load16(const Tile& T, uint32_t a, uint32_t w[4])
     w[2] = __builtin_amdgcn_alignbyte(r3, r2, s);
     w[3] = __builtin_amdgcn_alignbyte(r4, r3, s);
 }
+// Byte reader over a line in the tile that keeps 16 bytes in registers: a short forward walk
+// (a number, a timestamp) pays ONE LDS round trip instead of one per dword.  Same interface as
+// LdsReader (byte(i), i = line-relative index).
+struct WinReader {
+    const Tile& T;
+    uint32_t base;
+    uint32_t w0 = 0x80000000u;  // line index of the window's first byte (initially: no index is within 16 of it)
+    uint64_t lo = 0, hi = 0;
+    __device__ __forceinline__ WinReader(const Tile& t, uint32_t b) : T(t), base(b) {}
+    __device__ __forceinline__ uint32_t byte(uint32_t i) {
+        uint32_t off = i - w0;
+        if (off >= 16u) {
+            uint32_t w[4];
+            load16(T, base + i, w);
+            lo = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+            hi = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+            w0 = i;
+            off = 0;
+        }
+        const uint64_t v = off < 8u ? lo : hi;
+        return (uint32_t)(v >> (8u * (off & 7u))) & 0xFFu;
+    }
+};
+
 // first set bit of a tile bitmap at line index >= q (tile byte base+q), or len; 32 bytes per step
 __device__ __forceinline__ uint32_t find_bit(const uint32_t* bm, uint32_t base, uint32_t q, uint32_t len) {
     while (q < len) {
