@@ -9,6 +9,8 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libfg_hip.so"
 
 FG_RFC5424, FG_LTSV, FG_GELF = 0, 1, 2
+FG_FRAME_NONE, FG_FRAME_LINE, FG_FRAME_NUL = 0, 1, 2
+FG_ST_OVERFLOW, FG_ST_BAD_UTF8 = 0xFE, 0xFD
 FG_OK, FG_ERR_ARG, FG_ERR_HIP, FG_ERR_NO_DEVICE, FG_ERR_ENT_OVERFLOW, FG_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 FG_NONE = 0xFFFFFFFF
 FG_T_STRING, FG_T_BOOL, FG_T_F64, FG_T_I64, FG_T_U64, FG_T_NULL, FG_T_SDID = range(7)
@@ -87,9 +89,8 @@ def lib() -> C.CDLL:
     L.fg_shard_plan.argtypes = [vp, u64, u32, vp]
     L.fg_set_timing.argtypes = [vp, C.c_int]
     L.fg_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
-    for name in ("fg_frame_lines_device", "fg_frame_lines"):
-        if hasattr(L, name):
-            getattr(L, name).restype = C.c_int
+    L.fg_frame_device.argtypes = [vp, C.c_int, vp, u64, vp, vp, u64, C.POINTER(u64), vp]
+    L.fg_decode_frames_device.argtypes = [vp, C.c_int, C.c_int, vp, u64, vp, u64, vp, C.POINTER(fg_tables), vp]
     if L.fg_abi_version() != 1:
         raise RuntimeError("libfg_hip.so ABI version mismatch")
     _lib = L

@@ -30,13 +30,18 @@ struct LtsvDevCfg {
 }  // namespace fg
 
 extern "C" int fg_launch_rfc5424(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
-                                 uint64_t avg_len, hipStream_t stream, uint64_t* stash, uint32_t stash_blocks);
+                                 uint64_t avg_len, hipStream_t stream, uint64_t* stash, uint32_t stash_blocks, uint32_t strip,
+                                 const uint8_t* line_bad);
 extern "C" uint64_t fg_stash_bytes(uint32_t blocks);
+extern "C" uint64_t fg_frame_scratch_bytes(uint64_t nbytes);
+extern "C" int fg_launch_frame(const uint8_t* d_bytes, uint64_t nbytes, uint32_t delim, uint8_t* scratch, uint64_t* d_offsets,
+                               uint8_t* d_bad, uint64_t cap, uint64_t** d_total_out, hipStream_t stream);
 extern "C" int fg_launch_ltsv(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
                               const fg::LtsvDevCfg* cfg, uint64_t avg_len, hipStream_t stream, uint64_t* stash,
-                              uint32_t stash_blocks);
+                              uint32_t stash_blocks, uint32_t strip, const uint8_t* line_bad);
 extern "C" int fg_launch_gelf(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
-                              uint64_t avg_len, hipStream_t stream, uint64_t* stash, uint32_t stash_blocks);
+                              uint64_t avg_len, hipStream_t stream, uint64_t* stash, uint32_t stash_blocks, uint32_t strip,
+                              const uint8_t* line_bad);
 
 struct fg_ctx {
     int device = 0;
@@ -55,6 +60,8 @@ struct fg_ctx {
     // parse and the copy into the entry table (allocated on the first decode; 8 waves on every CU)
     uint64_t* d_stash = nullptr;
     uint32_t stash_blocks = 0;
+    uint8_t* d_frame = nullptr;  // fg_frame_device scratch (delimiter / UTF-8 masks, block counts)
+    uint64_t d_frame_cap = 0;
     fg::LtsvDevCfg ltsv{};
     // staging for fg_decode_batch
     uint8_t* d_bytes = nullptr;
@@ -341,6 +348,7 @@ void fg_destroy(fg_ctx* ctx) {
     if (ctx->d_tab) (void)hipFree(ctx->d_tab);
     if (ctx->d_cfg) (void)hipFree(ctx->d_cfg);
     if (ctx->d_stash) (void)hipFree(ctx->d_stash);
+    if (ctx->d_frame) (void)hipFree(ctx->d_frame);
     if (ctx->h_tab) (void)hipHostFree(ctx->h_tab);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -372,6 +380,46 @@ int fg_last_kernel_ms(fg_ctx* ctx, float* ms) {
 
 int fg_decode_batch_device(fg_ctx* ctx, fg_format fmt, const uint8_t* d_bytes, uint64_t nbytes,
                            const uint64_t* d_offsets, uint64_t n, const fg_tables* tables, void* stream) {
+    return fg_decode_frames_device(ctx, fmt, FG_FRAME_NONE, d_bytes, nbytes, d_offsets, n, nullptr, tables, stream);
+}
+
+int fg_frame_device(fg_ctx* ctx, fg_framing framing, const uint8_t* d_bytes, uint64_t nbytes, uint64_t* d_offsets,
+                    uint8_t* d_bad_utf8, uint64_t cap_frames, uint64_t* n_frames, void* stream) {
+    if (!ctx || !d_offsets || !d_bad_utf8 || !n_frames || (nbytes && !d_bytes)) return FG_ERR_ARG;
+    if (framing != FG_FRAME_LINE && framing != FG_FRAME_NUL) return FG_ERR_UNSUPPORTED;
+    if (((uintptr_t)d_bytes & 15u) != 0) return FG_ERR_ARG;
+    DeviceGuard g(ctx->device);
+    hipStream_t s = stream == FG_STREAM_OWN ? ctx->stream : (hipStream_t)stream;
+    *n_frames = 0;
+    if (nbytes == 0) return FG_OK;
+    int rc;
+    if ((rc = grow_dev(ctx, (void**)&ctx->d_frame, &ctx->d_frame_cap, fg_frame_scratch_bytes(nbytes))) != FG_OK) return rc;
+    uint64_t* d_total = nullptr;
+    int lrc = fg_launch_frame(d_bytes, nbytes, framing == FG_FRAME_LINE ? 0x0Au : 0x00u, ctx->d_frame, d_offsets, d_bad_utf8,
+                              cap_frames, &d_total, s);
+    if (lrc != 0) {
+        ctx->last_hip = lrc;
+        return FG_ERR_HIP;
+    }
+    // frames = delimiters (+1 when the stream does not end with one)
+    uint64_t total = 0;
+    FG_HIP(ctx, hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, s));
+    FG_HIP(ctx, hipStreamSynchronize(s));
+    if (total + 1 > cap_frames) {
+        *n_frames = total + 1;
+        return FG_ERR_ENT_OVERFLOW;
+    }
+    uint64_t last_end = 0;
+    FG_HIP(ctx, hipMemcpyAsync(&last_end, d_offsets + total, 8, hipMemcpyDeviceToHost, s));
+    FG_HIP(ctx, hipStreamSynchronize(s));
+    *n_frames = last_end == nbytes ? total : total + 1;
+    return FG_OK;
+}
+
+int fg_decode_frames_device(fg_ctx* ctx, fg_format fmt, fg_framing framing, const uint8_t* d_bytes, uint64_t nbytes,
+                            const uint64_t* d_offsets, uint64_t n, const uint8_t* d_bad_utf8, const fg_tables* tables,
+                            void* stream) {
+    if ((int)framing < 0 || (int)framing > 2) return FG_ERR_ARG;
     if (!ctx || !tables || (n && (!d_offsets || !tables->meta))) return FG_ERR_ARG;
     if (nbytes && !d_bytes) return FG_ERR_ARG;
     if (((uintptr_t)d_bytes & 15u) != 0) return FG_ERR_ARG;
@@ -393,13 +441,16 @@ int fg_decode_batch_device(fg_ctx* ctx, fg_format fmt, const uint8_t* d_bytes, u
     int rc;
     switch (fmt) {
         case FG_RFC5424:
-            rc = fg_launch_rfc5424(d_bytes, d_offsets, n, &dt, (nbytes + n - 1) / n, s, ctx->d_stash, ctx->stash_blocks);
+            rc = fg_launch_rfc5424(d_bytes, d_offsets, n, &dt, (nbytes + n - 1) / n, s, ctx->d_stash, ctx->stash_blocks, (uint32_t)framing,
+                                   d_bad_utf8);
             break;
         case FG_LTSV:
-            rc = fg_launch_ltsv(d_bytes, d_offsets, n, &dt, &ctx->ltsv, (nbytes + n - 1) / n, s, ctx->d_stash, ctx->stash_blocks);
+            rc = fg_launch_ltsv(d_bytes, d_offsets, n, &dt, &ctx->ltsv, (nbytes + n - 1) / n, s, ctx->d_stash, ctx->stash_blocks,
+                                (uint32_t)framing, d_bad_utf8);
             break;
         case FG_GELF:
-            rc = fg_launch_gelf(d_bytes, d_offsets, n, &dt, (nbytes + n - 1) / n, s, ctx->d_stash, ctx->stash_blocks);
+            rc = fg_launch_gelf(d_bytes, d_offsets, n, &dt, (nbytes + n - 1) / n, s, ctx->d_stash, ctx->stash_blocks,
+                                (uint32_t)framing, d_bad_utf8);
             break;
         default:
             return FG_ERR_UNSUPPORTED;
@@ -471,6 +522,7 @@ int fg_decode_batch(fg_ctx* ctx, fg_format fmt, const uint8_t* bytes, uint64_t n
 }
 
 const char* fg_error_string(fg_format fmt, uint8_t status) {
+    if (status == FG_ST_BAD_UTF8) return "Invalid UTF-8 input";  // line_splitter.rs:23, nul_splitter.rs:36
     switch (fmt) {
         case FG_RFC5424:
             return status < sizeof(kErr5424) / sizeof(*kErr5424) ? kErr5424[status] : nullptr;

@@ -985,16 +985,17 @@ struct GelfFormat {
 template <int NB, bool PROF>
 __global__ __launch_bounds__(kWave, 2) void k_gelf(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets,
                                                   uint64_t n, DevTables t, uint32_t tile_cap, uint32_t L, uint64_t groups,
-                                                  unsigned long long* prof, uint64_t* stash_base) {
+                                                  unsigned long long* prof, uint64_t* stash_base, FrameArgs fr) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     GelfFormat fmt{smem + tile_cap + 64u + (tile_cap / 16u + 16u) * 2u};
-    persistent_loop<NB, PROF>(bytes, offsets, n, t, tile_cap, L, groups, prof, stash_base, fmt);
+    persistent_loop<NB, PROF>(bytes, offsets, n, t, tile_cap, L, groups, prof, stash_base, fmt, fr);
 }
 
 }  // namespace fg
 
 extern "C" int fg_launch_gelf(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
-                              uint64_t avg_len, hipStream_t stream, uint64_t* stash, uint32_t stash_blocks) {
+                              uint64_t avg_len, hipStream_t stream, uint64_t* stash, uint32_t stash_blocks, uint32_t strip,
+                              const uint8_t* line_bad) {
     if (n == 0) return 0;
     fg::LaunchPlan p;
     // at most kGelfLines lines per group: plan with twice the average length (L <= 32 follows), then
@@ -1007,11 +1008,11 @@ extern "C" int fg_launch_gelf(const uint8_t* d_bytes, const uint64_t* d_offsets,
         fg::ProfRun pr;
         if (!pr.begin(stream)) return -1;
         hipLaunchKernelGGL((fg::k_gelf<fg::kWindowKiB, true>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L,
-                           p.groups, pr.d, stash);
+                           p.groups, pr.d, stash, fg::FrameArgs{strip, line_bad});
         pr.end(stream, "gelf", p);
         return (int)hipGetLastError();
     }
     hipLaunchKernelGGL((fg::k_gelf<fg::kWindowKiB, false>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L,
-                       p.groups, (unsigned long long*)nullptr, stash);
+                       p.groups, (unsigned long long*)nullptr, stash, fg::FrameArgs{strip, line_bad});
     return (int)hipGetLastError();
 }

@@ -537,7 +537,7 @@ struct LtsvFormat {
 template <int NB, bool PROF>
 __global__ __launch_bounds__(kWave, 2) void k_ltsv(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets,
                                                   uint64_t n, DevTables t, LtsvDevCfg cfg, uint32_t tile_cap, uint32_t L,
-                                                  uint64_t groups, unsigned long long* prof, uint64_t* stash_base) {
+                                                  uint64_t groups, unsigned long long* prof, uint64_t* stash_base, FrameArgs fr) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t* extra = smem + tile_cap + 64u + (tile_cap / 16u + 16u) * 2u;
     SchemaEnt* schema = reinterpret_cast<SchemaEnt*>(extra + 768u);
@@ -572,14 +572,14 @@ __global__ __launch_bounds__(kWave, 2) void k_ltsv(const uint8_t* __restrict__ b
     }
     __syncthreads();
     LtsvFormat fmt{cfg, extra, schema, suffix};
-    persistent_loop<NB, PROF>(bytes, offsets, n, t, tile_cap, L, groups, prof, stash_base, fmt);
+    persistent_loop<NB, PROF>(bytes, offsets, n, t, tile_cap, L, groups, prof, stash_base, fmt, fr);
 }
 
 }  // namespace fg
 
 extern "C" int fg_launch_ltsv(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
                               const fg::LtsvDevCfg* cfg, uint64_t avg_len, hipStream_t stream, uint64_t* stash,
-                              uint32_t stash_blocks) {
+                              uint32_t stash_blocks, uint32_t strip, const uint8_t* line_bad) {
     if (n == 0) return 0;
     fg::LaunchPlan p;
     if (fg::plan_launch(fg::k_ltsv<fg::kWindowKiB, false>, n, avg_len, fg::kLtsvExtraLds, 57344u, stash ? stash_blocks : 0u, &p))
@@ -590,11 +590,11 @@ extern "C" int fg_launch_ltsv(const uint8_t* d_bytes, const uint64_t* d_offsets,
         fg::ProfRun pr;
         if (!pr.begin(stream)) return -1;
         hipLaunchKernelGGL((fg::k_ltsv<fg::kWindowKiB, true>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, *cfg, p.tile,
-                           p.L, p.groups, pr.d, stash);
+                           p.L, p.groups, pr.d, stash, fg::FrameArgs{strip, line_bad});
         pr.end(stream, "ltsv", p);
         return (int)hipGetLastError();
     }
     hipLaunchKernelGGL((fg::k_ltsv<fg::kWindowKiB, false>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, *cfg, p.tile,
-                       p.L, p.groups, (unsigned long long*)nullptr, stash);
+                       p.L, p.groups, (unsigned long long*)nullptr, stash, fg::FrameArgs{strip, line_bad});
     return (int)hipGetLastError();
 }

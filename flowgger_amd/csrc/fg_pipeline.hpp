@@ -172,10 +172,17 @@ struct GroupCtx {
     uint32_t ablate;        // measurement build only
 };
 
+// Framing of the frames handed to the decoders (fg_decode_frames_device): what to strip from the
+// end of [offsets[i], offsets[i+1]) before decoding, and which frames to reject as invalid UTF-8.
+struct FrameArgs {
+    uint32_t strip;           // FG_FRAME_NONE / _LINE ("\n", then one "\r") / _NUL ("\0")
+    const uint8_t* line_bad;  // [n] 1 = not valid UTF-8 (or null)
+};
+
 template <int NB, bool PROF, class F>
 __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets,
                                                 uint64_t n, const DevTables& t, uint32_t tile_cap, uint32_t L, uint64_t groups,
-                                                unsigned long long* prof, uint64_t* stash_base, F& fmt) {
+                                                unsigned long long* prof, uint64_t* stash_base, F& fmt, FrameArgs fr) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint16_t* bm16 = reinterpret_cast<uint16_t*>(smem + tile_cap + 64u);
     uint4* dst = reinterpret_cast<uint4*>(smem);
@@ -300,8 +307,31 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
         if (!(ablate & 2u)) {
             const uint64_t li = g * L + lane;
             const bool valid = lane < L && li < n;
-            GroupCtx c{bytes, smem, bm16, o0, o1, a0, span, valid, (ablate & 8u) ? nullptr : stash, ablate};
+            // terminator stripping (BufRead::lines / split(0) semantics, see fg_frame.hip)
+            uint64_t e1 = o1;
+            if (fr.strip != FG_FRAME_NONE && valid && e1 > o0) {
+                auto byte_at = [&](uint64_t p) -> uint32_t {
+                    return (p - a0) < (uint64_t)span ? (uint32_t)smem[p - a0] : (uint32_t)bytes[p];
+                };
+                const uint32_t b1 = byte_at(e1 - 1);
+                if (fr.strip == FG_FRAME_LINE) {
+                    if (b1 == '\n') {
+                        --e1;
+                        if (e1 > o0 && byte_at(e1 - 1) == '\r') --e1;
+                    }
+                } else if (b1 == 0u) {
+                    --e1;
+                }
+            }
+            GroupCtx c{bytes, smem, bm16, o0, e1, a0, span, valid, (ablate & 8u) ? nullptr : stash, ablate};
             pend = fmt.decode(c, t);
+            if (fr.line_bad && valid && fr.line_bad[li]) {  // "Invalid UTF-8 input": the frame never reaches decode()
+                pend.meta = FG_ST_BAD_UTF8 | (0xFFu << 8) | (0xFFu << 16);
+                pend.ts = 0.0;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) pend.span[k] = fg_span{0, FG_NONE};
+                pend.count = 0;
+            }
             pend_li = li;
             pend_valid = valid;
         }

@@ -885,9 +885,9 @@ template <int NB, bool PROF>
 __global__ __launch_bounds__(kWave, 2) void k_rfc5424(const uint8_t* __restrict__ bytes,
                                                      const uint64_t* __restrict__ offsets, uint64_t n, DevTables t,
                                                      uint32_t tile_cap, uint32_t L, uint64_t groups,
-                                                     unsigned long long* prof, uint64_t* stash_base) {
+                                                     unsigned long long* prof, uint64_t* stash_base, FrameArgs fr) {
     Rfc5424Format fmt;
-    persistent_loop<NB, PROF>(bytes, offsets, n, t, tile_cap, L, groups, prof, stash_base, fmt);
+    persistent_loop<NB, PROF>(bytes, offsets, n, t, tile_cap, L, groups, prof, stash_base, fmt, fr);
 }
 
 }  // namespace fg
@@ -899,7 +899,8 @@ extern "C" uint64_t fg_stash_bytes(uint32_t blocks) {
 // host-side launcher (called from fg_capi.cpp).  stash: device scratch of fg_stash_bytes(stash_blocks)
 // bytes (or NULL: SD lines are then parsed twice); the persistent grid is capped at stash_blocks.
 extern "C" int fg_launch_rfc5424(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
-                                 uint64_t avg_len, hipStream_t stream, uint64_t* stash, uint32_t stash_blocks) {
+                                 uint64_t avg_len, hipStream_t stream, uint64_t* stash, uint32_t stash_blocks, uint32_t strip,
+                              const uint8_t* line_bad) {
     if (n == 0) return 0;
     fg::LaunchPlan p;
     if (fg::plan_launch(fg::k_rfc5424<fg::kWindowKiB, false>, n, avg_len, 0u, 57344u, stash ? stash_blocks : 0u, &p)) return -1;
@@ -909,12 +910,12 @@ extern "C" int fg_launch_rfc5424(const uint8_t* d_bytes, const uint64_t* d_offse
         fg::ProfRun pr;
         if (!pr.begin(stream)) return -1;
         hipLaunchKernelGGL((fg::k_rfc5424<fg::kWindowKiB, true>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile,
-                           p.L, p.groups, pr.d, stash);
+                           p.L, p.groups, pr.d, stash, fg::FrameArgs{strip, line_bad});
         pr.end(stream, "rfc5424", p);
         return (int)hipGetLastError();
     }
     hipLaunchKernelGGL((fg::k_rfc5424<fg::kWindowKiB, false>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L,
-                       p.groups, (unsigned long long*)nullptr, stash);
+                       p.groups, (unsigned long long*)nullptr, stash, fg::FrameArgs{strip, line_bad});
     return (int)hipGetLastError();
 }
 

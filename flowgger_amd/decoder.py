@@ -111,6 +111,43 @@ class Decoder:
                                                d_offsets.data_ptr(), n, C.byref(tables.struct),
                                                C.c_void_p(stream.cuda_stream)), "fg_decode_batch_device")
 
+    # -- GPU framing (the splitter side) -------------------------------------------
+    def frame_device(self, d_bytes, framing: int, cap_frames: Optional[int] = None, stream=None):
+        """Frame a raw byte stream resident in HBM: `buf_reader.lines()` (framing = FG_FRAME_LINE) or
+        `buf_reader.split(0)` (FG_FRAME_NUL) plus the per-frame `str::from_utf8` check
+        (splitter/line_splitter.rs:17-25, nul_splitter.rs:18-40).  Returns (d_offsets, d_bad_utf8, n):
+        frame i = d_bytes[offsets[i]:offsets[i+1]] INCLUDING its terminator."""
+        import torch
+
+        if stream is None:
+            stream = torch.cuda.current_stream(d_bytes.device)
+        nbytes = d_bytes.numel()
+        cap = cap_frames if cap_frames is not None else nbytes // 16 + 16
+        while True:
+            d_offsets = torch.empty(cap + 2, dtype=torch.int64, device=d_bytes.device)
+            d_bad = torch.empty(cap + 1, dtype=torch.uint8, device=d_bytes.device)
+            n = C.c_uint64()
+            rc = L.lib().fg_frame_device(self._ctx, framing, d_bytes.data_ptr(), nbytes, d_offsets.data_ptr(),
+                                         d_bad.data_ptr(), cap, C.byref(n), C.c_void_p(stream.cuda_stream))
+            if rc == L.FG_ERR_ENT_OVERFLOW:
+                cap = int(n.value) + 16
+                continue
+            L.check(rc, "fg_frame_device")
+            return d_offsets, d_bad, int(n.value)
+
+    def decode_frames_device(self, d_bytes, d_offsets, n: int, tables: DeviceTables, framing: int, d_bad=None,
+                             stream=None) -> None:
+        """Decode frames produced by frame_device (terminators are stripped inside the kernels; frames
+        flagged in d_bad get status FG_ST_BAD_UTF8 = the reference's "Invalid UTF-8 input")."""
+        import torch
+
+        if stream is None:
+            stream = torch.cuda.current_stream(d_bytes.device)
+        L.check(L.lib().fg_decode_frames_device(self._ctx, self.fmt, framing, d_bytes.data_ptr(), d_bytes.numel(),
+                                                d_offsets.data_ptr(), n, d_bad.data_ptr() if d_bad is not None else None,
+                                                C.byref(tables.struct), C.c_void_p(stream.cuda_stream)),
+                "fg_decode_frames_device")
+
     def set_timing(self, enabled: bool = True) -> None:
         L.check(L.lib().fg_set_timing(self._ctx, int(enabled)), "fg_set_timing")
 

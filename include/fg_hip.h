@@ -73,6 +73,15 @@ enum {
                                escapes a backslash followed by a raw LF means backslash + 'n' */
 };
 #define FG_ST_OVERFLOW 0xFE /* status: the line's entries did not fit in ent_cap (re-run with more) */
+#define FG_ST_BAD_UTF8 0xFD /* status: the frame is not valid UTF-8; the reference never decodes it, it prints
+                               "Invalid UTF-8 input" and drops it (line_splitter.rs:22-25, nul_splitter.rs:34-40) */
+
+/* How the frames handed to the decoders are delimited inside the byte buffer. */
+typedef enum fg_framing {
+    FG_FRAME_NONE = 0, /* offsets delimit bare lines (framing bytes already stripped by the caller) */
+    FG_FRAME_LINE = 1, /* BufRead::lines(): "\n" terminated, the "\n" and one preceding "\r" are not part of the line */
+    FG_FRAME_NUL = 2   /* BufRead::split(0): "\0" terminated */
+} fg_framing;
 
 /* entry flags */
 enum {
@@ -157,6 +166,27 @@ int fg_tables_layout(uint64_t n, uint64_t ent_cap, uint64_t sizes[FG_TABLE_ARRAY
 int fg_decode_batch_device(fg_ctx* ctx, fg_format fmt, const uint8_t* d_bytes, uint64_t nbytes,
                            const uint64_t* d_offsets, uint64_t n, const fg_tables* tables,
                            void* stream);
+
+/* GPU FRAMING + UTF-8 VALIDATION of a raw byte stream (replaces `buf_reader.lines()` /
+ * `buf_reader.split(0)` + `str::from_utf8`, splitter/line_splitter.rs:17-25, nul_splitter.rs:18-40):
+ *   d_bytes     raw stream chunk (device), 16-byte aligned, readable up to nbytes rounded up to 16
+ *   d_offsets   out, cap_frames + 2 entries: frame i = [offsets[i], offsets[i+1]) INCLUDING its
+ *               terminator; a final unterminated piece is a frame if it is non-empty
+ *   d_bad_utf8  out, cap_frames + 1 bytes: 1 = the frame is not valid UTF-8
+ *   n_frames    out (host): number of frames; the call synchronises the stream to read it
+ * Returns FG_ERR_ENT_OVERFLOW when cap_frames is too small (*n_frames then holds the need).
+ * framing must be FG_FRAME_LINE or FG_FRAME_NUL.  (syslen framing is a sequential prefix chain
+ * per connection and stays on the host: flowgger_amd/host/fg_decoder.hpp.) */
+int fg_frame_device(fg_ctx* ctx, fg_framing framing, const uint8_t* d_bytes, uint64_t nbytes,
+                    uint64_t* d_offsets, uint8_t* d_bad_utf8, uint64_t cap_frames, uint64_t* n_frames,
+                    void* stream);
+
+/* Decode frames as produced by fg_frame_device: the kernels strip the terminators themselves, and
+ * frames flagged in d_bad_utf8 (may be NULL) get status FG_ST_BAD_UTF8 instead of a decode.
+ * fg_decode_batch_device(...) == fg_decode_frames_device(..., FG_FRAME_NONE, ..., NULL, ...). */
+int fg_decode_frames_device(fg_ctx* ctx, fg_format fmt, fg_framing framing, const uint8_t* d_bytes,
+                            uint64_t nbytes, const uint64_t* d_offsets, uint64_t n,
+                            const uint8_t* d_bad_utf8, const fg_tables* tables, void* stream);
 
 /* HOST-BUFFER decode: copies the batch to the GPU, decodes, copies the tables back into
  * ctx-owned pinned host memory (`out` is filled with host pointers valid until the next call

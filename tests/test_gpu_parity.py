@@ -428,3 +428,116 @@ def test_cpp_host_mirror_and_batching_splitters(tmp_path, oracle, fmt, framing):
         want_err.append("Can't read message's length")
     assert got_ok == want_ok
     assert got_err == want_err
+
+
+# ---------------------------------------------------------------------------------------------
+# GPU framing + UTF-8 validation: BufRead::lines() / split(0) + str::from_utf8
+# ---------------------------------------------------------------------------------------------
+def _frames_reference(raw: bytes, framing: str):
+    """The reference splitters' framing, restated with the standard library: list of
+    (start, end_with_terminator, line_bytes_without_terminator, is_valid_utf8)."""
+    delim = b"\n" if framing == "line" else b"\0"
+    out, pos = [], 0
+    while pos < len(raw):
+        k = raw.find(delim, pos)
+        end = len(raw) if k < 0 else k + 1
+        body = raw[pos:end]
+        if k >= 0:
+            body = body[:-1]
+            if framing == "line" and body.endswith(b"\r"):  # lines(): strips "\n", then one "\r"
+                body = body[:-1]
+        try:
+            body.decode("utf-8")
+            ok = True
+        except UnicodeDecodeError:
+            ok = False
+        out.append((pos, end, body, ok))
+        pos = end
+    return out
+
+
+def _utf8_torture():
+    good = ["plain ascii", "caf\u00e9", "\u20ac euro", "\U0001F600 smile", "\u07ff\u0800\uffff\U00010000\U0010ffff", ""]
+    bad = [b"\xff", b"\xc0\xaf", b"\xc1\xbf", b"\xe0\x80\x80", b"\xe0\x9f\xbf", b"\xed\xa0\x80", b"\xed\xbf\xbf", b"\xf0\x80\x80\x80",
+           b"\xf0\x8f\xbf\xbf", b"\xf4\x90\x80\x80", b"\xf5\x80\x80\x80", b"\x80", b"\xbf", b"a\x80b", b"\xc2", b"\xe2\x82", b"\xf0\x9f\x98",
+           b"\xc2\x41", b"\xe2\x28\xa1", b"\xe2\x82\x28", b"\xf0\x28\x8c\xbc", b"\xf0\x90\x28\xbc", b"\xf0\x28\x8c\x28", b"\xf8\x88\x80\x80\x80",
+           b"ok\xe2\x82\xac then \xe2\x82 cut"]
+    return [g.encode() for g in good] + bad
+
+
+@pytest.mark.parametrize("framing", ["line", "nul"])
+def test_gpu_framing_and_utf8_match_the_splitters(rfc, oracle, framing):
+    import torch
+    from flowgger_amd import _lib as L
+    from flowgger_amd.tables import DeviceTables
+
+    rng = np.random.default_rng(0x8f1)
+    lines = synth.rfc5424_lines(40_000, cfg=2) + synth.rfc5424_lines(2_000, cfg=5, sd=True, long_tail=True)
+    tort = _utf8_torture()
+    delim = b"\n" if framing == "line" else b"\0"
+    pieces = []
+    for i, ln in enumerate(lines):
+        if i % 7 == 3:
+            ln = ln + b" " + tort[(i // 7) % len(tort)]
+        if i % 11 == 5:
+            ln = tort[(i // 11) % len(tort)] + b" " + ln  # the decoder then sees an unsupported BOM / garbage
+        if framing == "line" and i % 5 == 1:
+            ln = ln + b"\r"
+        if i % 97 == 0:
+            ln = b""  # empty frames are frames
+        pieces.append(ln + delim)
+    for tail in (b"", b"unterminated tail \xe2\x82", b"plain tail", b"\r"):
+        raw = b"".join(pieces) + tail
+        ref = _frames_reference(raw, framing)
+        dev = torch.device("cuda", rfc.device)
+        d_bytes = torch.cat([torch.frombuffer(bytearray(raw), dtype=torch.uint8), torch.zeros(32, dtype=torch.uint8)]).to(dev)[:len(raw) + 32]
+        d_raw = d_bytes[:len(raw)]
+        fr = L.FG_FRAME_LINE if framing == "line" else L.FG_FRAME_NUL
+        # cap too small first: must report the need, not overflow
+        d_offsets, d_bad, n = rfc.frame_device(d_raw, fr, cap_frames=8)
+        assert n == len(ref)
+        offs = d_offsets[:n + 1].cpu().numpy().astype(np.uint64)
+        bad = d_bad[:n].cpu().numpy()
+        assert np.array_equal(offs[:-1], np.array([r[0] for r in ref], np.uint64))
+        assert int(offs[-1]) == len(raw)
+        want_bad = np.array([0 if r[3] else 1 for r in ref], np.uint8)
+        assert np.array_equal(bad, want_bad), f"first UTF-8 verdict mismatch at frame {int(np.flatnonzero(bad != want_bad)[0])}"
+        # decode the frames in place (terminators stripped in-kernel) == oracle on the bare lines
+        tables = DeviceTables(n, len(raw) // 8 + 1024, dev)
+        rfc.decode_frames_device(d_raw, d_offsets, n, tables, fr, d_bad)
+        torch.cuda.synchronize(dev)
+        host = tables.to_host()
+        st = host.status
+        assert np.array_equal(st == L.FG_ST_BAD_UTF8, want_bad == 1)
+        good = [r[2] for r in ref if r[3]]
+        gdata, goffs = synth.pack(good)
+        oblob, ooffs = oracle.decode_batch(RFC5424, gdata, goffs)
+        idx = np.flatnonzero(want_bad == 0)
+        # serialise the good rows one by one against the framed buffer (spans are line-relative)
+        raw_np = np.frombuffer(raw, np.uint8)
+        blob, boffs = host.serialize(RFC5424, raw_np, offs)
+        for j, i in enumerate(idx[:: max(1, len(idx) // 4000)]):
+            jj = int(np.searchsorted(idx, i))
+            a = blob[int(boffs[i]):int(boffs[i + 1])].tobytes()
+            b = oblob[int(ooffs[jj]):int(ooffs[jj + 1])].tobytes()
+            assert a == b, (int(i), ref[int(i)][2][:80])
+
+
+def test_gpu_framing_block_boundaries(rfc):
+    """Streams whose length is 0, 1, a multiple of the 16 KiB scan block, and sequences that
+    straddle chunk / row / block boundaries."""
+    import torch
+    from flowgger_amd import _lib as L
+
+    dev = torch.device("cuda", rfc.device)
+    cases = [b"\n", b"x", b"\xe2\x82\xac\n" * 5461 + b"ab", (b"a" * 16383 + b"\n"), (b"a" * 16382 + b"\xc3\xa9" * 8192 + b"\n"),
+             b"a" * 16383 + b"\xc3", b"a" * 16381 + b"\xe2\x82\xac" + b"\xe2\x82\xac\n", b"a" * 1023 + b"\xf0\x9f\x98\x80" * 5000,
+             b"\n" * 40000, b"a" * 32768]
+    for raw in cases:
+        ref = _frames_reference(raw, "line")
+        d_bytes = torch.cat([torch.frombuffer(bytearray(raw), dtype=torch.uint8), torch.zeros(32, dtype=torch.uint8)]).to(dev)
+        d_offsets, d_bad, n = rfc.frame_device(d_bytes[:len(raw)], L.FG_FRAME_LINE)
+        assert n == len(ref), (raw[:20], n, len(ref))
+        offs = d_offsets[:n + 1].cpu().numpy()
+        assert [int(x) for x in offs[:-1]] == [r[0] for r in ref] and int(offs[-1]) == len(raw)
+        assert d_bad[:n].cpu().numpy().tolist() == [0 if r[3] else 1 for r in ref], raw[:20]
