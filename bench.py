@@ -36,7 +36,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--tile-lines", type=int, default=1_000_000)
     ap.add_argument("--reps", type=int, default=100, help="tile replicas resident per GPU")
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5", "ltsv"],
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5", "ltsv", "frame"],
                     help="cfg2 = the BASELINE metric's configuration (default); the others time the remaining "
                          "kernels on their parity-test corpora (not bench lines, see DESIGN.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -53,6 +53,7 @@ WORKLOADS = {
     "cfg5": (0, "BASELINE configs[4] shape: RFC5424, log-uniform 64 B..8 KiB lines with structured data"),
     "cfg3": (2, "BASELINE configs[2]: GELF/JSON, 8 flat extra fields"),
     "ltsv": (1, "LTSV, typed schema (the LTSV half of BASELINE configs[4])"),
+    "frame": (0, "GPU framing + UTF-8 validation of the newline-terminated cfg2 stream (SURVEY 8f-1), then decode of the frames"),
 }
 
 
@@ -104,6 +105,8 @@ def main():
         lines = synth.gelf_lines(args.tile_lines, invalid_frac=args.invalid_frac)
     elif wl == "ltsv":
         lines = synth.ltsv_lines(args.tile_lines, invalid_frac=args.invalid_frac)
+    elif wl == "frame":
+        lines = [ln + b"\n" for ln in synth.rfc5424_lines(args.tile_lines, cfg=2, invalid_frac=args.invalid_frac)]
     elif wl == "cfg5":
         lines = synth.rfc5424_lines(args.tile_lines, cfg=5, sd=True, invalid_frac=args.invalid_frac, long_tail=True)
     else:
@@ -126,8 +129,26 @@ def main():
            else RFC5424Decoder(device=local))
     stream = torch.cuda.current_stream(dev)
 
+    frame_ms = None
+    if wl == "frame":
+        from flowgger_amd import _lib as FL
+
+        raw_stream = d_bytes[:tile_bytes * reps]
+        f_off, f_bad, f_n = dec.frame_device(raw_stream, FL.FG_FRAME_LINE, cap_frames=n + 16)  # warm-up + result
+        assert f_n == n and bool((f_off[:n + 1] == d_offsets).all()), "GPU framing disagrees with the generator's offsets"
+        evf = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        evf[0].record(stream)
+        for _ in range(3):
+            dec.frame_device(raw_stream, FL.FG_FRAME_LINE, cap_frames=n + 16)
+        evf[1].record(stream)
+        torch.cuda.synchronize(dev)
+        frame_ms = evf[0].elapsed_time(evf[1]) / 3
+
     def step():
-        dec.decode_device(d_bytes, d_offsets, tables, stream)
+        if wl == "frame":
+            dec.decode_frames_device(raw_stream, f_off, n, tables, FL.FG_FRAME_LINE, f_bad, stream)
+        else:
+            dec.decode_device(d_bytes, d_offsets, tables, stream)
 
     def barrier():
         if world > 1:
@@ -187,6 +208,9 @@ def main():
                 "read_only_frac": alg_read / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             },
         }
+        if frame_ms is not None:
+            out["framing"] = {"ms": frame_ms, "GBps": tile_bytes * reps / (frame_ms * 1e-3) / 1e9,
+                              "note": "fg_frame_device: scan + prefix + emit kernels incl. the host sync that returns the frame count"}
         tr = ROOT / "profiles" / "traffic.json"
         if tr.exists():
             try:

@@ -1000,19 +1000,19 @@ extern "C" int fg_launch_gelf(const uint8_t* d_bytes, const uint64_t* d_offsets,
     fg::LaunchPlan p;
     // at most kGelfLines lines per group: plan with twice the average length (L <= 32 follows), then
     // size the tile for the real one
-    if (fg::plan_launch(fg::k_gelf<fg::kWindowKiB, false>, n, avg_len, fg::kGelfExtraLds, 57344u, stash ? stash_blocks : 0u, &p, fg::kGelfLines))
+    if (fg::plan_launch(fg::k_gelf<fg::kComputeBoundWindow, false>, n, avg_len, fg::kGelfExtraLds, 57344u, stash ? stash_blocks : 0u, &p, fg::kGelfLines))
         return -1;
     if (stash_blocks == 0) stash = nullptr;
     dim3 grid(p.blocks), block(fg::kWave);
     if (getenv("FG_PROF")) {
         fg::ProfRun pr;
         if (!pr.begin(stream)) return -1;
-        hipLaunchKernelGGL((fg::k_gelf<fg::kWindowKiB, true>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L,
+        hipLaunchKernelGGL((fg::k_gelf<fg::kComputeBoundWindow, true>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L,
                            p.groups, pr.d, stash, fg::FrameArgs{strip, line_bad});
         pr.end(stream, "gelf", p);
         return (int)hipGetLastError();
     }
-    hipLaunchKernelGGL((fg::k_gelf<fg::kWindowKiB, false>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L,
+    hipLaunchKernelGGL((fg::k_gelf<fg::kComputeBoundWindow, false>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L,
                        p.groups, (unsigned long long*)nullptr, stash, fg::FrameArgs{strip, line_bad});
     return (int)hipGetLastError();
 }

@@ -582,19 +582,19 @@ extern "C" int fg_launch_ltsv(const uint8_t* d_bytes, const uint64_t* d_offsets,
                               uint32_t stash_blocks, uint32_t strip, const uint8_t* line_bad) {
     if (n == 0) return 0;
     fg::LaunchPlan p;
-    if (fg::plan_launch(fg::k_ltsv<fg::kWindowKiB, false>, n, avg_len, fg::kLtsvExtraLds, 57344u, stash ? stash_blocks : 0u, &p))
+    if (fg::plan_launch(fg::k_ltsv<fg::kComputeBoundWindow, false>, n, avg_len, fg::kLtsvExtraLds, 57344u, stash ? stash_blocks : 0u, &p))
         return -1;
     if (stash_blocks == 0) stash = nullptr;
     dim3 grid(p.blocks), block(fg::kWave);
     if (getenv("FG_PROF")) {
         fg::ProfRun pr;
         if (!pr.begin(stream)) return -1;
-        hipLaunchKernelGGL((fg::k_ltsv<fg::kWindowKiB, true>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, *cfg, p.tile,
+        hipLaunchKernelGGL((fg::k_ltsv<fg::kComputeBoundWindow, true>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, *cfg, p.tile,
                            p.L, p.groups, pr.d, stash, fg::FrameArgs{strip, line_bad});
         pr.end(stream, "ltsv", p);
         return (int)hipGetLastError();
     }
-    hipLaunchKernelGGL((fg::k_ltsv<fg::kWindowKiB, false>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, *cfg, p.tile,
+    hipLaunchKernelGGL((fg::k_ltsv<fg::kComputeBoundWindow, false>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, *cfg, p.tile,
                        p.L, p.groups, (unsigned long long*)nullptr, stash, fg::FrameArgs{strip, line_bad});
     return (int)hipGetLastError();
 }

@@ -267,7 +267,7 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
         if (nrow > (uint32_t)NB) {  // rare: bytes beyond the register window
             const uint4* __restrict__ src = reinterpret_cast<const uint4*>(bytes + a0);
             for (uint32_t c0 = NB * kWave; c0 < nchunk; c0 += kWave * 4) {
-                uint4 w[4];
+                uint4 w[4];  // (the window registers are dead here)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     uint32_t idx = c0 + k * kWave + lane;
@@ -323,8 +323,58 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
                     --e1;
                 }
             }
-            GroupCtx c{bytes, smem, bm16, o0, e1, a0, span, valid, (ablate & 8u) ? nullptr : stash, ablate};
-            pend = fmt.decode(c, t);
+            // Lines are tokenised out of the tile.  The tile was sized for the AVERAGE group; when
+            // this group is longer, the lines that did not fit are done in further passes over a tile
+            // restaged from the first of them (plain loads: rare, so not prefetched).  Only a single
+            // line longer than the whole tile is parsed straight from global memory.
+            uint64_t ta0 = a0;
+            uint32_t tspan = span;
+            bool todo = valid;
+            for (;;) {
+                const bool fits = todo && (o1 - ta0) <= (uint64_t)tspan;
+                const unsigned long long fit_m = __ballot(fits), todo_m = __ballot(todo);
+                if (todo_m == 0ull) break;  // wave-uniform
+                bool now = fits;
+                if (fit_m == 0ull) now = todo && lane == (uint32_t)__builtin_ctzll(todo_m);  // longer than the tile: alone, from global
+                GroupCtx c{bytes, smem, bm16, o0, e1, ta0, tspan, now, (ablate & 8u) ? nullptr : stash, ablate};
+                const RowOut r = fmt.decode(c, t);
+                if (now) pend = r;
+                todo = todo && !now;
+                const unsigned long long left_m = __ballot(todo);
+                if (left_m == 0ull) break;
+                // restage: tile starts at the first unfinished line
+                const uint32_t j = (uint32_t)__builtin_ctzll(left_m);
+                const uint32_t nl = (uint32_t)((g * L + L <= n) ? L : n - g * L);
+                const uint64_t lo = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)o0, (int)j) |
+                                    ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(o0 >> 32), (int)j) << 32);
+                const uint64_t hi = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)o1, (int)(nl - 1u)) |
+                                    ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(o1 >> 32), (int)(nl - 1u)) << 32);
+                ta0 = lo & ~15ull;
+                const uint64_t want = hi - ta0;
+                tspan = want > tile_cap ? tile_cap : (uint32_t)((want + 15ull) & ~15ull);
+                __syncthreads();  // every lane is done reading the old tile
+                {
+                    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(bytes + ta0);
+                    const uint32_t nch = tspan >> 4;
+                    for (uint32_t c0 = 0; c0 < nch; c0 += kWave * 2) {  // (few registers: the prefetch window is live)
+                        uint4 w[2];
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            uint32_t idx = c0 + k * kWave + lane;
+                            if (idx < nch) w[k] = src[idx];
+                        }
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            uint32_t idx = c0 + k * kWave + lane;
+                            if (idx < nch) {
+                                dst[idx] = w[k];
+                                bm16[idx] = (uint16_t)F::mask16(w[k]);
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
             if (fr.line_bad && valid && fr.line_bad[li]) {  // "Invalid UTF-8 input": the frame never reaches decode()
                 pend.meta = FG_ST_BAD_UTF8 | (0xFFu << 8) | (0xFFu << 16);
                 pend.ts = 0.0;
@@ -373,6 +423,10 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
 
 namespace fg {
 constexpr int kWindowKiB = 20;  // register prefetch window per wave (NB): 80 VGPRs
+// The LTSV / GELF tokenisers are compute-bound (hundreds of instructions per line) and register
+// hungry: they keep only a token window (the rest of a group is staged by the plain tail loop,
+// ~2 us of exposed latency against a group time of tens of us) and get the registers instead.
+constexpr int kComputeBoundWindow = 2;
 
 struct LaunchPlan {
     uint32_t L = 64;      // lines per group
