@@ -690,94 +690,170 @@ struct GelfFormat {
         return K_OTHER;
     }
 
+    // serde_json 0.8 number scanning (fg_numparse.hpp json_number) for the everyday shape -- optional
+    // '-', 1..18 digits with at most one '.', no exponent -- done on registers, 16 bytes per LDS
+    // round trip.  Returns true = parsed (*kind / *bits as json_number would give, *end = index past
+    // the token), false = not this shape (the caller runs json_number, which owns every error).
+    static __device__ __forceinline__ bool fast_decimal(const Tile& T, uint32_t base, uint32_t p, uint32_t len, uint32_t* kind,
+                                                        uint64_t* bits, uint32_t* end) {
+        Win x = window(T, base, p, len);
+        bool neg = false;
+        if (x.left && x.peek() == '-') {
+            neg = true;
+            x.pop();
+            ++p;
+        }
+        uint64_t sig = 0;
+        uint32_t nd = 0, nf = 0, first = 0x100u, c = 0x100u;
+        bool dot = false;
+        for (;;) {
+            if (x.left == 0) {
+                if (p >= len) break;  // (c stays "end of line")
+                x = window(T, base, p, len);
+            }
+            c = x.peek();
+            const uint32_t d = c - '0';
+            if (d <= 9u) {
+                if (nd == 0) first = d;
+                sig = sig * 10u + d;
+                ++nd;
+                nf += dot ? 1u : 0u;
+            } else if (c == '.' && !dot && nd != 0) {
+                dot = true;
+            } else {
+                break;
+            }
+            x.pop();
+            ++p;
+            c = 0x100u;
+        }
+        if (c == 'e' || c == 'E' || c == '.' || nd == 0 || nd > 18u) return false;
+        if (dot && nf == 0) return false;                 // "1." is an error: json_number reports it
+        if (first == 0u && (nd - nf) > 1u) return false;  // leading zero rule: ditto
+        *end = p;
+        if (dot) {
+            *kind = V_F64;
+            return num::json_f64_from_parts(!neg, sig, -(int32_t)nf, bits);
+        }
+        if (!neg || sig == 0) {
+            *kind = V_U64;  // "-0" -> visit_i64(0) -> U64(0)
+            *bits = sig;
+        } else {
+            *kind = V_I64;
+            *bits = 0ull - sig;
+        }
+        return true;
+    }
+
+    // 8 bytes at line index p as a u64 + the mask (8 bits) of the bytes that are NOT a space; bytes
+    // past the end of the line read as spaces.  Only ' ' counts as inter-token whitespace on the fast
+    // form: TAB / CR / LF between tokens fail the "expected character" tests and leave it.
+    static __device__ __forceinline__ uint64_t punct8(const Tile& T, uint32_t base, uint32_t p, uint32_t len, uint32_t* nonspace) {
+        uint32_t lo, hi;
+        load8(T, base + p, &lo, &hi);
+        const uint32_t sp = (__builtin_amdgcn_udot4(eq_flags(lo, 0x20202020u), 0x08040201u, 0u, false) +
+                             __builtin_amdgcn_udot4(eq_flags(hi, 0x20202020u), 0x80402010u, 0u, false)) >> 7;
+        const uint32_t avail = p < len ? len - p : 0u;
+        const uint32_t inside = avail >= 8u ? 0xFFu : (1u << avail) - 1u;
+        *nonspace = ~sp & inside;
+        return (uint64_t)lo | ((uint64_t)hi << 32);
+    }
+    static __device__ __forceinline__ uint32_t byte_of(uint64_t v, uint32_t i) { return (uint32_t)(v >> (8u * i)) & 0xFFu; }
+
     // Walk the line; members -> keys[] / recs[] (LDS, this lane) + the value word in the stash.
-    // Returns the member count, or 0xFFFFFFFF = not the fast form.
+    // Returns the member count, or 0xFFFFFFFF = not the fast form.  Mostly straight-line: per member
+    // one bit scan for the key's closing quote, one 8-byte register window for `[sp]:[sp]<value>`,
+    // the value (bit scan / register decimal / literal compare), one window for `[sp],[sp]"` | `[sp]}`.
     __device__ __forceinline__ uint32_t fast_walk(const Tile& T, uint32_t base, uint32_t len, uint64_t* keys, uint64_t* recs,
                                                   uint64_t* stash) const {
         constexpr uint32_t BAIL = 0xFFFFFFFFu;
         LdsReader rd(T.w, base);
-        uint32_t p = 0;
-        Win x = window(T, base, p, len);
-        if (!skip(x, p) || x.peek() != '{') return BAIL;
-        x.pop();
-        ++p;
-        uint32_t n = 0;
-        bool first = true;
-        for (;;) {
-            // ---- [ws] '}' | [','] [ws] '"' -----------------------------------------------------
-            if (!skip(x, p)) {
-                if (p >= len) return BAIL;
-                x = window(T, base, p, len);
-                if (!skip(x, p)) return BAIL;
-            }
-            uint32_t c = x.peek();
+        uint32_t ns;
+        uint64_t w = punct8(T, base, 0, len, &ns);
+        if (ns == 0) return BAIL;
+        uint32_t i = (uint32_t)__builtin_ctz(ns);
+        if (byte_of(w, i) != '{') return BAIL;
+        ns &= ns - 1u;
+        uint32_t p;        // index of the next key's opening quote
+        bool closed = false;
+        uint32_t after = 0;  // index just past the closing '}'
+        if (ns == 0) {
+            // "{" then 7+ spaces, or a short line: look again from there
+            w = punct8(T, base, i + 1u, len, &ns);
+            if (ns == 0) return BAIL;
+            const uint32_t j = (uint32_t)__builtin_ctz(ns);
+            const uint32_t c = byte_of(w, j);
             if (c == '}') {
-                x.pop();
-                ++p;
-                break;
+                closed = true;
+                after = i + 1u + j + 1u;
+            } else if (c != '"') {
+                return BAIL;
             }
-            if (!first) {
-                if (c != ',') return BAIL;
-                x.pop();
-                ++p;
-                if (!skip(x, p)) {
-                    if (p >= len) return BAIL;
-                    x = window(T, base, p, len);
-                    if (!skip(x, p)) return BAIL;
-                }
-                c = x.peek();
+            p = i + 1u + j;
+        } else {
+            const uint32_t j = (uint32_t)__builtin_ctz(ns);
+            const uint32_t c = byte_of(w, j);
+            if (c == '}') {
+                closed = true;
+                after = j + 1u;
+            } else if (c != '"') {
+                return BAIL;
             }
-            first = false;
-            if (c != '"' || n >= kFastMembers) return BAIL;
+            p = j;
+        }
+        // One member per iteration.  Written as predicated straight-line code with a sticky `ok`
+        // instead of early returns: on this hardware every divergent exit costs a dozen scalar
+        // instructions of exec-mask bookkeeping, and there would be twenty of them per member.
+        uint32_t n = 0;
+        bool ok = true;
+        while (ok && !closed) {
+            ok = n < kFastMembers;
             // ---- key: no escapes, no control characters ------------------------------------------
             const uint32_t key_b = p + 1u;
             const uint32_t key_e = find_bit(T.bm, base, key_b, len);
-            if (key_e >= len || rd.byte(key_e) != '"') return BAIL;
-            // ---- [ws] ':' [ws] value -------------------------------------------------------------
-            p = key_e + 1u;
-            x = window(T, base, p, len);
-            if (!skip(x, p) || x.peek() != ':') return BAIL;
-            x.pop();
-            ++p;
-            if (!skip(x, p)) {
-                if (p >= len) return BAIL;
-                x = window(T, base, p, len);
-                if (!skip(x, p)) return BAIL;
-            }
-            if (x.left < 6u && len - p > x.left) x = window(T, base, p, len);  // room for a literal
-            c = x.peek();
-            uint32_t kind, v_b = p, v_esc = 0, vend;
+            ok = ok && key_e < len;
+            // ---- '"' [sp] ':' [sp] value-start, all inside 8 bytes ---------------------------------
+            w = punct8(T, base, key_e, len, &ns);
+            ok = ok && (uint32_t)(w & 0xFFu) == '"';  // else the hit was a '\\' or a control character
+            ns &= ~1u;                               // the quote itself
+            const uint32_t i1 = ns ? (uint32_t)__builtin_ctz(ns) : 0u;
+            ok = ok && ns != 0u && byte_of(w, i1) == ':';
+            ns &= ns - 1u;
+            const uint32_t i2 = ns ? (uint32_t)__builtin_ctz(ns) : 0u;
+            ok = ok && ns != 0u;
+            const uint32_t c = byte_of(w, i2);
+            const uint32_t v = key_e + i2;
+            uint32_t kind = V_NULL, v_b = v, v_esc = 0, vend = v;
             uint64_t word = 0;
-            if (c == '"') {
+            const bool is_str = c == '"', is_num = c == '-' || (c - '0') <= 9u;
+            if (ok && is_str) {
                 kind = V_STRING;
-                v_b = p + 1u;
-                uint32_t e;
-                if (!skip_string(T, rd, base, v_b, len, &e, &v_esc)) return BAIL;
+                v_b = v + 1u;
+                uint32_t e = 0;
+                ok = skip_string(T, rd, base, v_b, len, &e, &v_esc);
                 word = e - v_b;
                 vend = e + 1u;
-            } else if (c == '-' || (c - '0') <= 9u) {
-                uint32_t k2;
-                if (!num::json_number(rd, p, len, &vend, &k2, &word)) return BAIL;
+            }
+            if (ok && is_num) {
+                uint32_t k2 = 0;
+                bool good = fast_decimal(T, base, v, len, &k2, &word, &vend);
+                if (!good) good = num::json_number(rd, v, len, &vend, &k2, &word);
+                ok = good;
                 kind = k2;
-            } else if (c == 't') {
-                if (!((uint32_t)x.lo == 0x65757274u && x.left >= 4u)) return BAIL;  // "true"
-                kind = V_BOOL;
-                word = 1;
-                vend = p + 4u;
-            } else if (c == 'f') {
-                if (!((uint32_t)x.lo == 0x736C6166u && ((uint32_t)(x.lo >> 32) & 0xFFu) == 'e' && x.left >= 5u)) return BAIL;  // "false"
-                kind = V_BOOL;
-                word = 0;
-                vend = p + 5u;
-            } else if (c == 'n') {
-                if (!((uint32_t)x.lo == 0x6C6C756Eu && x.left >= 4u)) return BAIL;  // "null"
-                kind = V_NULL;
-                vend = p + 4u;
-            } else {
-                return BAIL;  // nested value or garbage
+            }
+            if (!is_str && !is_num) {
+                uint32_t l0, l1;
+                load8(T, base + v, &l0, &l1);
+                const bool t = c == 't' && l0 == 0x65757274u && v + 4u <= len;                           // "true"
+                const bool f = c == 'f' && l0 == 0x736C6166u && (l1 & 0xFFu) == 'e' && v + 5u <= len;    // "false"
+                const bool nl = c == 'n' && l0 == 0x6C6C756Eu && v + 4u <= len;                          // "null"
+                ok = ok && (t || f || nl);  // else: nested value or garbage
+                kind = nl ? V_NULL : V_BOOL;
+                word = t ? 1u : 0u;
+                vend = v + (f ? 5u : 4u);
             }
             // ---- record + sort key ---------------------------------------------------------------
-            {
+            if (ok) {
                 uint32_t k0, k1;
                 load8(T, base + key_b, &k0, &k1);
                 const uint32_t kl = key_e - key_b;
@@ -790,14 +866,24 @@ struct GelfFormat {
                 stash[n * kWave + threadIdx.x] = word;
             }
             ++n;
-            p = vend;
-            x = window(T, base, p, len);
+            // ---- [sp] ',' [sp] '"'   |   [sp] '}' ---------------------------------------------------
+            w = punct8(T, base, vend, len, &ns);
+            const uint32_t j1 = ns ? (uint32_t)__builtin_ctz(ns) : 0u;
+            const uint32_t d = byte_of(w, j1);
+            ok = ok && ns != 0u && (d == '}' || d == ',');
+            closed = d == '}';
+            after = vend + j1 + 1u;
+            ns &= ns - 1u;
+            const uint32_t j2 = ns ? (uint32_t)__builtin_ctz(ns) : 0u;
+            ok = ok && (closed || (ns != 0u && byte_of(w, j2) == '"'));
+            p = vend + j2;
         }
-        // trailing whitespace only
-        for (;;) {
-            if (skip(x, p)) return BAIL;  // a non-whitespace byte after the object
-            if (p >= len) break;
-            x = window(T, base, p, len);
+        if (!ok) return BAIL;
+        // trailing spaces only (anything else, incl. other whitespace: general form decides)
+        while (after < len) {
+            w = punct8(T, base, after, len, &ns);
+            if (ns != 0) return BAIL;
+            after += 8u;
         }
         return n;
     }
@@ -819,18 +905,28 @@ struct GelfFormat {
         uint32_t nm = 0xFFFFFFFFu;  // members found by the fast form
         if (c.valid && in_tile && len < 65536u && c.stash) nm = fast_walk(T, base, len, keys, recs, c.stash);
         bool fast = c.valid && nm != 0xFFFFFFFFu;
+        if (c.ablate & 16u) {  // measurement only: the walk alone
+            RowOut z{};
+            z.meta = nm;
+            return z;
+        }
         uint32_t sorted_n = 0;
+        if (c.ablate & 32u) {  // measurement only: (same point as 16 since numbers are converted in the walk)
+            RowOut z{};
+            z.meta = nm + (fast ? 1u : 0u);
+            return z;
+        }
         if (fast) {
             // ---- rank the keys in registers (BTreeMap order; equal keys: later member last) ------
             uint64_t k[kFastMembers];
 #pragma unroll
-            for (uint32_t i = 0; i < kFastMembers; ++i) k[i] = i < nm ? keys[i] : ~0ull;
-#pragma unroll
-            for (uint32_t i = 0; i < kFastMembers; ++i) {
+            for (uint32_t j = 0; j < kFastMembers; ++j) k[j] = j < nm ? keys[j] : ~0ull;
+            for (uint32_t i = 0; i < nm; ++i) {  // (k[] stays in registers: only the inner loop is unrolled)
+                const uint64_t ki = keys[i];
                 uint32_t rank = 0;
 #pragma unroll
-                for (uint32_t j = 0; j < kFastMembers; ++j) rank += (j != i && k[j] < k[i]) ? 1u : 0u;
-                if (i < nm) order[rank] = (uint8_t)i;
+                for (uint32_t j = 0; j < kFastMembers; ++j) rank += k[j] < ki ? 1u : 0u;
+                order[rank] = (uint8_t)i;
             }
             // ---- duplicates / unresolved order: adjacent keys with the same 7-byte prefix ---------
             LdsReader rd(T.w, base);
@@ -845,6 +941,11 @@ struct GelfFormat {
                 else order[s] = 0xFFu;    // earlier duplicate: skipped (the last one wins, BTreeMap::insert)
             }
             sorted_n = nm;
+        }
+        if (c.ablate & 64u) {  // measurement only: walk + numbers + ranking
+            RowOut z{};
+            z.meta = nm + sorted_n + (fast ? 1u : 0u) + order[0];
+            return z;
         }
         if (fast) {
             // ---- gelf_decoder.rs:51-106 in sorted key order -------------------------------------------

@@ -203,6 +203,48 @@ def test_full_size_replicas_are_identical(rfc, oracle):
     assert_same(blob, offs, oblob, ooffs, lines)
 
 
+@pytest.mark.parametrize("shape", ["cfg3_gelf", "cfg4_sd", "cfg5_long_tail", "ltsv"])
+def test_entry_workloads_at_scale_replicas_and_checksums(rfc, oracle, shape):
+    """The entry-producing configurations at millions of lines: R back-to-back replicas of a tile
+    decode to R identical fixed-column blocks and identical per-line entry counts, the entry table
+    holds exactly R x the tile's entries (a checksum of checksums over names / values / types that
+    does not depend on slot placement), and replica 0 materialises to the oracle's bytes."""
+    import torch
+
+    if shape == "cfg3_gelf":
+        dec, fmt, cfg, lines = GelfDecoder(), GELF, None, synth.gelf_lines(120_000)
+    elif shape == "ltsv":
+        dec, fmt, cfg, lines = LTSVDecoder(synth.LTSV_CONFIG), LTSV, synth.LTSV_CONFIG, synth.ltsv_lines(120_000)
+    elif shape == "cfg4_sd":
+        dec, fmt, cfg, lines = rfc, RFC5424, None, synth.rfc5424_lines(120_000, cfg=4, sd=True)
+    else:
+        dec, fmt, cfg, lines = rfc, RFC5424, None, synth.rfc5424_lines(40_000, cfg=5, sd=True, long_tail=True)
+    data, offsets = synth.pack(lines)
+    reps = 16
+    tables, _, _ = device_path(dec, data, offsets, reps=reps)
+    n = len(lines)
+    for name in ("meta", "ts", "hostname", "appname", "procid", "msgid", "msg", "full_msg", "ent_count"):
+        col = tables.column(name).view(reps, -1)
+        assert bool((col == col[0:1]).all()), name
+    # entries: placement differs between replicas, content must not
+    used = int(tables.column("ent_used").view(torch.int64)[0].item())
+    cnt = tables.column("ent_count").view(torch.int32).view(reps, n)
+    per_rep = int(cnt[0].sum().item())
+    assert used == per_rep * reps and per_rep > 0
+    first = tables.column("ent_first").view(torch.int32).view(reps, n).to(torch.int64)
+    name = tables.column("ent_name").view(torch.int64)[:used]
+    val = tables.column("ent_val").view(torch.int64)[:used]
+    typ = tables.column("ent_type")[:used].to(torch.int64)
+    flg = tables.column("ent_flags")[:used].to(torch.int64)
+    h = (name * 0x9E3779B1 + val * 0x85EBCA77 + typ * 0xC2B2AE3D + flg * 0x27D4EB2F)  # wraps mod 2^64
+    csum = torch.cumsum(torch.cat([torch.zeros(1, dtype=torch.int64, device=h.device), h]), 0)
+    line_sum = csum[first + cnt.to(torch.int64)] - csum[first]   # per line, per replica
+    assert bool((line_sum == line_sum[0:1]).all()), "entry content differs between replicas"
+    oblob, ooffs = oracle.decode_batch(fmt, data, offsets, cfg)
+    blob, offs = tables.to_host().serialize(fmt, data, offsets, 0, n, cfg=dec._cfg)
+    assert_same(blob, offs, oblob, ooffs, lines)
+
+
 # ------------------------------------------------------------------------------------- LTSV
 def test_ltsv_corpus_matches_oracle(oracle):
     dec = LTSVDecoder(synth.LTSV_CONFIG)
