@@ -89,6 +89,9 @@ def lib() -> C.CDLL:
     L.fg_shard_plan.argtypes = [vp, u64, u32, vp]
     L.fg_set_timing.argtypes = [vp, C.c_int]
     L.fg_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.fg_alloc_pinned.argtypes = [u64, C.POINTER(vp)]
+    L.fg_free_pinned.argtypes = [vp]
+    L.fg_free_pinned.restype = None
     L.fg_frame_device.argtypes = [vp, C.c_int, vp, u64, vp, vp, u64, C.POINTER(u64), vp]
     L.fg_decode_frames_device.argtypes = [vp, C.c_int, C.c_int, vp, u64, vp, u64, vp, C.POINTER(fg_tables), vp]
     if L.fg_abi_version() != 1:

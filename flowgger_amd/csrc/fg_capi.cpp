@@ -46,6 +46,8 @@ extern "C" int fg_launch_gelf(const uint8_t* d_bytes, const uint64_t* d_offsets,
 struct fg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;  // second lane of the pipelined host path (created on first use)
+    hipEvent_t ev_ready = nullptr;
     int last_hip = 0;
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -350,6 +352,9 @@ void fg_destroy(fg_ctx* ctx) {
     if (ctx->d_stash) (void)hipFree(ctx->d_stash);
     if (ctx->d_frame) (void)hipFree(ctx->d_frame);
     if (ctx->h_tab) (void)hipHostFree(ctx->h_tab);
+    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    if (ctx->ev_ready) (void)hipEventDestroy(ctx->ev_ready);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -416,9 +421,21 @@ int fg_frame_device(fg_ctx* ctx, fg_framing framing, const uint8_t* d_bytes, uin
     return FG_OK;
 }
 
+static int decode_frames_impl(fg_ctx* ctx, fg_format fmt, fg_framing framing, const uint8_t* d_bytes, uint64_t nbytes,
+                              const uint64_t* d_offsets, uint64_t n, const uint8_t* d_bad_utf8, const fg_tables* tables,
+                              void* stream, bool reset_counter);
+
 int fg_decode_frames_device(fg_ctx* ctx, fg_format fmt, fg_framing framing, const uint8_t* d_bytes, uint64_t nbytes,
                             const uint64_t* d_offsets, uint64_t n, const uint8_t* d_bad_utf8, const fg_tables* tables,
                             void* stream) {
+    return decode_frames_impl(ctx, fmt, framing, d_bytes, nbytes, d_offsets, n, d_bad_utf8, tables, stream, true);
+}
+
+// reset_counter = false: a further slice of a batch whose entry counter is already live (the
+// pipelined host path decodes one batch as several slices on two streams)
+static int decode_frames_impl(fg_ctx* ctx, fg_format fmt, fg_framing framing, const uint8_t* d_bytes, uint64_t nbytes,
+                              const uint64_t* d_offsets, uint64_t n, const uint8_t* d_bad_utf8, const fg_tables* tables,
+                              void* stream, bool reset_counter) {
     if ((int)framing < 0 || (int)framing > 2) return FG_ERR_ARG;
     if (!ctx || !tables || (n && (!d_offsets || !tables->meta))) return FG_ERR_ARG;
     if (nbytes && !d_bytes) return FG_ERR_ARG;
@@ -428,7 +445,7 @@ int fg_decode_frames_device(fg_ctx* ctx, fg_format fmt, fg_framing framing, cons
     DeviceGuard g(ctx->device);
     hipStream_t s = stream == FG_STREAM_OWN ? ctx->stream : (hipStream_t)stream;
     fg::DevTables dt = to_dev(*tables);
-    if (dt.ent_used) FG_HIP(ctx, hipMemsetAsync(dt.ent_used, 0, 8, s));
+    if (dt.ent_used && reset_counter) FG_HIP(ctx, hipMemsetAsync(dt.ent_used, 0, 8, s));
     if (n == 0) return FG_OK;
     if (!ctx->d_stash) {
         hipDeviceProp_t prop;
@@ -466,18 +483,39 @@ int fg_decode_frames_device(fg_ctx* ctx, fg_format fmt, fg_framing framing, cons
     return FG_OK;
 }
 
+int fg_alloc_pinned(uint64_t bytes, void** out) {
+    if (!out) return FG_ERR_ARG;
+    *out = nullptr;
+    return hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? FG_OK : FG_ERR_HIP;
+}
+void fg_free_pinned(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
 int fg_decode_batch(fg_ctx* ctx, fg_format fmt, const uint8_t* bytes, uint64_t nbytes, const uint64_t* offsets,
                     uint64_t n, fg_tables* out) {
     if (!ctx || !out || (n && !offsets) || (nbytes && !bytes)) return FG_ERR_ARG;
     if (n && (offsets[n] > nbytes || offsets[0] > offsets[n])) return FG_ERR_ARG;
     DeviceGuard g(ctx->device);
-    hipStream_t s = ctx->stream;
     int rc;
+    if (!ctx->stream2) {
+        FG_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+        FG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming));
+    }
     if ((rc = grow_dev(ctx, (void**)&ctx->d_bytes, &ctx->d_bytes_cap, up(nbytes, 16) + 16)) != FG_OK) return rc;
     if ((rc = grow_dev(ctx, (void**)&ctx->d_offsets, &ctx->d_offsets_cap, (n + 1) * 8)) != FG_OK) return rc;
-    if (nbytes) FG_HIP(ctx, hipMemcpyAsync(ctx->d_bytes, bytes, nbytes, hipMemcpyHostToDevice, s));
-    if (n) FG_HIP(ctx, hipMemcpyAsync(ctx->d_offsets, offsets, (n + 1) * 8, hipMemcpyHostToDevice, s));
-    // entry capacity: start from one entry per 16 input bytes, grow x4 on overflow
+    // Slices of ~32 MiB of line bytes, alternating between two streams: the H2D copy of slice k+1
+    // overlaps the kernel and the D2H copy of slice k's rows (PCIe is full duplex; the kernels are
+    // two orders of magnitude faster than the link).  Rows land at their final position, entries
+    // share one counter, so the result is the same as one monolithic launch.
+    uint32_t slices = (uint32_t)(nbytes / (32ull << 20));
+    if (slices < 1) slices = 1;
+    if (slices > 16) slices = 16;
+    if (n < slices) slices = n ? (uint32_t)n : 1;
+    std::vector<uint64_t> cut(slices + 1);
+    if (fg_shard_plan(offsets, n, slices, cut.data()) != FG_OK) return FG_ERR_ARG;
+    hipStream_t lanes[2] = {ctx->stream, ctx->stream2};
+    // entry capacity: start from one entry per 16 (RFC5424) / 8 input bytes, grow on overflow
     uint64_t ent_cap = fmt == FG_RFC5424 ? nbytes / 16 + 1024 : nbytes / 8 + 1024;
     for (;;) {
         if (ent_cap > 0xFFFFFFF0ull) ent_cap = 0xFFFFFFF0ull;
@@ -492,29 +530,64 @@ int fg_decode_batch(fg_ctx* ctx, fg_format fmt, const uint8_t* bytes, uint64_t n
             FG_HIP(ctx, hipHostMalloc((void**)&ctx->h_tab, want, hipHostMallocDefault));
             ctx->h_tab_cap = want;
         }
-        fg_tables dt;
+        fg_tables dt, ht;
         carve(ctx->d_tab, n, ent_cap, &dt, nullptr);
-        rc = fg_decode_batch_device(ctx, fmt, ctx->d_bytes, nbytes, ctx->d_offsets, n, &dt, FG_STREAM_OWN);
-        if (rc != FG_OK) return rc;
+        carve(ctx->h_tab, n, ent_cap, &ht, nullptr);
+        // offsets + the entry counter first (lane 0); lane 1 waits for them
+        if (n) FG_HIP(ctx, hipMemcpyAsync(ctx->d_offsets, offsets, (n + 1) * 8, hipMemcpyHostToDevice, lanes[0]));
+        FG_HIP(ctx, hipMemsetAsync(dt.ent_used, 0, 8, lanes[0]));
+        FG_HIP(ctx, hipEventRecord(ctx->ev_ready, lanes[0]));
+        FG_HIP(ctx, hipStreamWaitEvent(lanes[1], ctx->ev_ready, 0));
+        for (uint32_t k = 0; k < slices && n; ++k) {
+            hipStream_t s = lanes[k & 1u];
+            const uint64_t l0 = cut[k], l1 = cut[k + 1];
+            if (l1 == l0) continue;
+            // bytes of the slice, copied on 16-byte boundaries (the neighbouring bytes are the same data)
+            const uint64_t b0 = offsets[l0] & ~15ull, b1 = offsets[l1];
+            if (b1 > b0) FG_HIP(ctx, hipMemcpyAsync(ctx->d_bytes + b0, bytes + b0, b1 - b0, hipMemcpyHostToDevice, s));
+            fg_tables sl = dt;  // the slice's rows: same arrays, shifted by l0
+            sl.n = l1 - l0;
+            sl.meta += l0;
+            sl.ts += l0;
+            sl.hostname += l0;
+            sl.appname += l0;
+            sl.procid += l0;
+            sl.msgid += l0;
+            sl.msg += l0;
+            sl.full_msg += l0;
+            sl.ent_first += l0;
+            sl.ent_count += l0;
+            rc = decode_frames_impl(ctx, fmt, FG_FRAME_NONE, ctx->d_bytes, nbytes, ctx->d_offsets + l0, l1 - l0, nullptr, &sl,
+                                    (void*)s, false);
+            if (rc != FG_OK) return rc;
+            const uint64_t rows = l1 - l0;
+            FG_HIP(ctx, hipMemcpyAsync(ht.meta + l0, dt.meta + l0, rows * 4, hipMemcpyDeviceToHost, s));
+            FG_HIP(ctx, hipMemcpyAsync(ht.ts + l0, dt.ts + l0, rows * 8, hipMemcpyDeviceToHost, s));
+            fg_span* hs[6] = {ht.hostname, ht.appname, ht.procid, ht.msgid, ht.msg, ht.full_msg};
+            fg_span* ds[6] = {dt.hostname, dt.appname, dt.procid, dt.msgid, dt.msg, dt.full_msg};
+            for (int j = 0; j < 6; ++j) FG_HIP(ctx, hipMemcpyAsync(hs[j] + l0, ds[j] + l0, rows * 8, hipMemcpyDeviceToHost, s));
+            FG_HIP(ctx, hipMemcpyAsync(ht.ent_first + l0, dt.ent_first + l0, rows * 4, hipMemcpyDeviceToHost, s));
+            FG_HIP(ctx, hipMemcpyAsync(ht.ent_count + l0, dt.ent_count + l0, rows * 4, hipMemcpyDeviceToHost, s));
+        }
+        FG_HIP(ctx, hipStreamSynchronize(lanes[1]));
         uint64_t used = 0;
-        FG_HIP(ctx, hipMemcpyAsync(&used, dt.ent_used, 8, hipMemcpyDeviceToHost, s));
-        FG_HIP(ctx, hipStreamSynchronize(s));
+        FG_HIP(ctx, hipMemcpyAsync(&used, dt.ent_used, 8, hipMemcpyDeviceToHost, lanes[0]));
+        FG_HIP(ctx, hipStreamSynchronize(lanes[0]));
         if (used > ent_cap) {
             if (ent_cap >= 0xFFFFFFF0ull) return FG_ERR_ENT_OVERFLOW;
             ent_cap = used + used / 8 + 1024;
             continue;
         }
-        // copy back: fixed columns in full, entry columns only up to `used`
-        fg_tables ht;
-        carve(ctx->h_tab, n, ent_cap, &ht, nullptr);
-        uint64_t sizes[FG_TABLE_ARRAYS];
-        fg_tables_layout(n, used, sizes);
-        void* dsts[FG_TABLE_ARRAYS] = {ht.meta, ht.ts, ht.hostname, ht.appname, ht.procid, ht.msgid, ht.msg, ht.full_msg,
-                                       ht.ent_first, ht.ent_count, ht.ent_name, ht.ent_val, ht.ent_type, ht.ent_flags, ht.ent_used};
-        void* srcs[FG_TABLE_ARRAYS] = {dt.meta, dt.ts, dt.hostname, dt.appname, dt.procid, dt.msgid, dt.msg, dt.full_msg,
-                                       dt.ent_first, dt.ent_count, dt.ent_name, dt.ent_val, dt.ent_type, dt.ent_flags, dt.ent_used};
-        for (int k = 0; k < FG_TABLE_ARRAYS; ++k)
-            if (sizes[k]) FG_HIP(ctx, hipMemcpyAsync(dsts[k], srcs[k], sizes[k], hipMemcpyDeviceToHost, s));
+        // the entry columns, up to `used`
+        hipStream_t s = lanes[0];
+        if (used) {
+            FG_HIP(ctx, hipMemcpyAsync(ht.ent_name, dt.ent_name, used * 8, hipMemcpyDeviceToHost, s));
+            FG_HIP(ctx, hipMemcpyAsync(ht.ent_val, dt.ent_val, used * 8, hipMemcpyDeviceToHost, lanes[1]));
+            FG_HIP(ctx, hipMemcpyAsync(ht.ent_type, dt.ent_type, used, hipMemcpyDeviceToHost, s));
+            FG_HIP(ctx, hipMemcpyAsync(ht.ent_flags, dt.ent_flags, used, hipMemcpyDeviceToHost, lanes[1]));
+        }
+        *ht.ent_used = used;
+        FG_HIP(ctx, hipStreamSynchronize(lanes[1]));
         FG_HIP(ctx, hipStreamSynchronize(s));
         *out = ht;
         return FG_OK;

@@ -190,9 +190,16 @@ int fg_decode_frames_device(fg_ctx* ctx, fg_format fmt, fg_framing framing, cons
 
 /* HOST-BUFFER decode: copies the batch to the GPU, decodes, copies the tables back into
  * ctx-owned pinned host memory (`out` is filled with host pointers valid until the next call
- * on this ctx or fg_destroy).  Synchronous.  Entry-table capacity grows automatically. */
+ * on this ctx or fg_destroy).  Synchronous.  Entry-table capacity grows automatically.
+ * The batch is processed as ~32 MiB slices on two streams so that H2D, kernels and D2H overlap;
+ * it runs at link speed when `bytes` / `offsets` live in pinned memory (fg_alloc_pinned: the
+ * batching framer accumulates lines there), at the runtime's staged-copy speed otherwise. */
 int fg_decode_batch(fg_ctx* ctx, fg_format fmt, const uint8_t* bytes, uint64_t nbytes,
                     const uint64_t* offsets, uint64_t n, fg_tables* out);
+
+/* Page-locked host memory for the framer's batch buffers (bytes, offsets). */
+int fg_alloc_pinned(uint64_t bytes, void** out);
+void fg_free_pinned(void* p);
 
 /* The reference's exact &'static str for a status code of a format (0 -> "", unknown -> NULL). */
 const char* fg_error_string(fg_format fmt, uint8_t status);

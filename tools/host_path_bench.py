@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rate of the host-buffer entry point fg_decode_batch (H2D + kernel + D2H of the tables).
+Never the bench metric (bench.py times HBM-resident batches); reported in DESIGN.md next to it."""
+import sys
+import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from flowgger_amd import RFC5424Decoder, synth  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+lines = synth.rfc5424_lines(n, cfg=2)
+data, offsets = synth.pack(lines)
+import ctypes as C
+
+import numpy as np
+
+from flowgger_amd import _lib as L  # noqa: E402
+
+
+def pinned_copy(a):
+    p = C.c_void_p()
+    L.check(L.lib().fg_alloc_pinned(a.nbytes, C.byref(p)), "fg_alloc_pinned")
+    buf = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (a.nbytes,)).view(a.dtype)
+    buf[:] = a
+    return buf
+
+
+dec = RFC5424Decoder()
+dec.decode_packed(data[: 1 << 20], offsets[:1000])  # warm-up (context, stash, staging buffers)
+best = 1e9
+for _ in range(3):
+    t0 = time.perf_counter()
+    tab = dec.decode_packed(data, offsets)
+    best = min(best, time.perf_counter() - t0)
+print(f"fg_decode_batch (pageable source): {n} lines, {data.size / 1e6:.0f} MB in {best * 1e3:.1f} ms = {n / best / 1e6:.1f} M lines/s, "
+      f"{data.size / best / 1e9:.2f} GB/s of input (includes the Python-side copy of the tables)")
+
+pdata, poffs = pinned_copy(data), pinned_copy(offsets)
+best = 1e9
+for _ in range(3):
+    t0 = time.perf_counter()
+    st = L.fg_tables()
+    L.check(L.lib().fg_decode_batch(dec._ctx, dec.fmt, pdata.ctypes.data, pdata.size, poffs.ctypes.data, n, C.byref(st)), "fg_decode_batch")
+    best = min(best, time.perf_counter() - t0)
+print(f"fg_decode_batch (pinned source, tables left in the ctx's pinned buffer): {best * 1e3:.1f} ms = {n / best / 1e6:.1f} M lines/s, "
+      f"{data.size / best / 1e9:.2f} GB/s of input")
