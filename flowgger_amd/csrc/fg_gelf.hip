@@ -580,6 +580,7 @@ __device__ __forceinline__ uint64_t rec_pack(uint32_t key_b, uint32_t key_len, u
 }
 
 struct GelfFormat {
+    static constexpr bool kStageABitmap = true;
     uint8_t* lane_blocks;  // LDS: kGelfLines x kLaneBlock
 
     // stage A: '"' | '\\' | control characters

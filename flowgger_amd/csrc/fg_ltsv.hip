@@ -297,6 +297,7 @@ struct SuffixEnt {                      // 16 bytes: the four configured suffixe
 constexpr uint32_t kLtsvExtraLds = 768u + kSchemaLds * sizeof(SchemaEnt) + 4u * sizeof(SuffixEnt);
 
 struct LtsvFormat {
+    static constexpr bool kStageABitmap = true;
     LtsvDevCfg cfg;
     uint8_t* lds_digits;        // 768-byte digit buffer for dec2flt's slow path
     const SchemaEnt* schema;    // LDS mirror of the first kSchemaLds schema entries

@@ -140,10 +140,10 @@ constexpr uint32_t kStashWords = 2;  // u64 words per stashed entry (scratch is 
 
 // Wave-aggregated allocation of entry slots: returns this lane's first slot, or sets *overflow.
 __device__ __forceinline__ uint32_t alloc_entries(const DevTables& t, uint32_t n_ent, bool* overflow) {
+    *overflow = false;
+    if (!__any(n_ent != 0u)) return 0;  // wave-uniform; the common case of the no-SD corpus skips the scan
     uint32_t total;
     uint32_t ex = wave_exclusive_sum(n_ent, &total);
-    *overflow = false;
-    if (total == 0) return 0;  // wave-uniform
     unsigned long long slot0 = 0;
     if (threadIdx.x == 0) slot0 = atomicAdd(t.ent_used, (unsigned long long)total);
     slot0 = __shfl(slot0, 0, kWave);
@@ -261,7 +261,7 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
                 uint32_t idx = k * kWave + lane;
                 uint4 q = make_uint4(v[k][0], v[k][1], v[k][2], v[k][3]);
                 dst[idx] = q;
-                bm16[idx] = (uint16_t)F::mask16(q);
+                if (F::kStageABitmap) bm16[idx] = (uint16_t)F::mask16(q);
             }
         }
         if (nrow > (uint32_t)NB) {  // rare: bytes beyond the register window
@@ -278,7 +278,7 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
                     uint32_t idx = c0 + k * kWave + lane;
                     if (idx < nchunk) {
                         dst[idx] = w[k];
-                        bm16[idx] = (uint16_t)F::mask16(w[k]);
+                        if (F::kStageABitmap) bm16[idx] = (uint16_t)F::mask16(w[k]);
                     }
                 }
             }
@@ -326,54 +326,61 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
             // Lines are tokenised out of the tile.  The tile was sized for the AVERAGE group; when
             // this group is longer, the lines that did not fit are done in further passes over a tile
             // restaged from the first of them (plain loads: rare, so not prefetched).  Only a single
-            // line longer than the whole tile is parsed straight from global memory.
-            uint64_t ta0 = a0;
-            uint32_t tspan = span;
-            bool todo = valid;
-            for (;;) {
-                const bool fits = todo && (o1 - ta0) <= (uint64_t)tspan;
-                const unsigned long long fit_m = __ballot(fits), todo_m = __ballot(todo);
-                if (todo_m == 0ull) break;  // wave-uniform
-                bool now = fits;
-                if (fit_m == 0ull) now = todo && lane == (uint32_t)__builtin_ctzll(todo_m);  // longer than the tile: alone, from global
-                GroupCtx c{bytes, smem, bm16, o0, e1, ta0, tspan, now, (ablate & 8u) ? nullptr : stash, ablate};
-                const RowOut r = fmt.decode(c, t);
-                if (now) pend = r;
-                todo = todo && !now;
-                const unsigned long long left_m = __ballot(todo);
-                if (left_m == 0ull) break;
-                // restage: tile starts at the first unfinished line
-                const uint32_t j = (uint32_t)__builtin_ctzll(left_m);
-                const uint32_t nl = (uint32_t)((g * L + L <= n) ? L : n - g * L);
-                const uint64_t lo = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)o0, (int)j) |
-                                    ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(o0 >> 32), (int)j) << 32);
-                const uint64_t hi = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)o1, (int)(nl - 1u)) |
-                                    ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(o1 >> 32), (int)(nl - 1u)) << 32);
-                ta0 = lo & ~15ull;
-                const uint64_t want = hi - ta0;
-                tspan = want > tile_cap ? tile_cap : (uint32_t)((want + 15ull) & ~15ull);
-                __syncthreads();  // every lane is done reading the old tile
-                {
-                    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(bytes + ta0);
-                    const uint32_t nch = tspan >> 4;
-                    for (uint32_t c0 = 0; c0 < nch; c0 += kWave * 2) {  // (few registers: the prefetch window is live)
-                        uint4 w[2];
+            // line longer than the whole tile is parsed straight from global memory.  The common
+            // case -- everything fits -- is kept apart so that it pays nothing for the loop.
+            const bool fits0 = valid && (o1 - a0) <= (uint64_t)span;
+            if (__ballot(valid && !fits0) == 0ull) {  // wave-uniform
+                GroupCtx c{bytes, smem, bm16, o0, e1, a0, span, valid, (ablate & 8u) ? nullptr : stash, ablate};
+                pend = fmt.decode(c, t);
+            } else {
+                uint64_t ta0 = a0;
+                uint32_t tspan = span;
+                bool todo = valid;
+                for (;;) {
+                    const bool fits = todo && (o1 - ta0) <= (uint64_t)tspan;
+                    const unsigned long long fit_m = __ballot(fits), todo_m = __ballot(todo);
+                    if (todo_m == 0ull) break;  // wave-uniform
+                    bool now = fits;
+                    if (fit_m == 0ull) now = todo && lane == (uint32_t)__builtin_ctzll(todo_m);  // longer than the tile: alone, from global
+                    GroupCtx c{bytes, smem, bm16, o0, e1, ta0, tspan, now, (ablate & 8u) ? nullptr : stash, ablate};
+                    const RowOut r = fmt.decode(c, t);
+                    if (now) pend = r;
+                    todo = todo && !now;
+                    const unsigned long long left_m = __ballot(todo);
+                    if (left_m == 0ull) break;
+                    // restage: tile starts at the first unfinished line
+                    const uint32_t j = (uint32_t)__builtin_ctzll(left_m);
+                    const uint32_t nl = (uint32_t)((g * L + L <= n) ? L : n - g * L);
+                    const uint64_t lo = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)o0, (int)j) |
+                                        ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(o0 >> 32), (int)j) << 32);
+                    const uint64_t hi = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)o1, (int)(nl - 1u)) |
+                                        ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(o1 >> 32), (int)(nl - 1u)) << 32);
+                    ta0 = lo & ~15ull;
+                    const uint64_t want = hi - ta0;
+                    tspan = want > tile_cap ? tile_cap : (uint32_t)((want + 15ull) & ~15ull);
+                    __syncthreads();  // every lane is done reading the old tile
+                    {
+                        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(bytes + ta0);
+                        const uint32_t nch = tspan >> 4;
+                        for (uint32_t c0 = 0; c0 < nch; c0 += kWave * 2) {  // (few registers: the prefetch window is live)
+                            uint4 w[2];
 #pragma unroll
-                        for (int k = 0; k < 2; ++k) {
-                            uint32_t idx = c0 + k * kWave + lane;
-                            if (idx < nch) w[k] = src[idx];
-                        }
+                            for (int k = 0; k < 2; ++k) {
+                                uint32_t idx = c0 + k * kWave + lane;
+                                if (idx < nch) w[k] = src[idx];
+                            }
 #pragma unroll
-                        for (int k = 0; k < 2; ++k) {
-                            uint32_t idx = c0 + k * kWave + lane;
-                            if (idx < nch) {
-                                dst[idx] = w[k];
-                                bm16[idx] = (uint16_t)F::mask16(w[k]);
+                            for (int k = 0; k < 2; ++k) {
+                                uint32_t idx = c0 + k * kWave + lane;
+                                if (idx < nch) {
+                                    dst[idx] = w[k];
+                                    if (F::kStageABitmap) bm16[idx] = (uint16_t)F::mask16(w[k]);
+                                }
                             }
                         }
                     }
+                    __syncthreads();
                 }
-                __syncthreads();
             }
             if (fr.line_bad && valid && fr.line_bad[li]) {  // "Invalid UTF-8 input": the frame never reaches decode()
                 pend.meta = FG_ST_BAD_UTF8 | (0xFFu << 8) | (0xFFu << 16);
@@ -467,13 +474,10 @@ inline int plan_launch(K kernel, uint64_t n, uint64_t avg_len, uint32_t extra_ld
     p->tile = tile;
     p->lds = tile + 64u + (tile / 16u + 16u) * 2u + extra_lds;
     p->groups = (n + L - 1) / L;
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
-        cus = prop.multiProcessorCount;
-    }
+    int dev = 0, cus = 0;  // (per call: a process may drive several devices)
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+        return -1;
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kWave, p->lds) != hipSuccess || per_cu < 1) per_cu = 1;
     if (const char* e = getenv("FG_WAVES_PER_CU")) {

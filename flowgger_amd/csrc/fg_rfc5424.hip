@@ -287,19 +287,6 @@ __device__ __forceinline__ void parse_line_generic(R& rd, uint32_t len, Row& r, 
 // Stage B: register-resident fast path
 // =============================================================================================
 
-// first space at line index >= q (tile byte base+q), or len.  Bitmap walk, 32 bytes per step.
-__device__ __forceinline__ uint32_t find_space_bm(const Tile& T, uint32_t base, uint32_t q, uint32_t len) {
-    while (q < len) {
-        uint32_t a = base + q;
-        uint32_t w = T.bm[a >> 5] >> (a & 31u);
-        if (w) {
-            uint32_t r = q + (uint32_t)__builtin_ctz(w);
-            return r < len ? r : len;
-        }
-        q += 32u - (a & 31u);
-    }
-    return len;
-}
 // every byte of x (already XORed with the expected pattern) must be <= its limit, where
 // add = 0x7F - limit per byte: returns nonzero iff some byte exceeds its limit.
 __device__ __forceinline__ uint32_t swar_exceeds(uint32_t x, uint32_t add) {
@@ -333,15 +320,15 @@ struct Fast {
 
 // RFC3339 from registers, branch-free: [t0, t0+L) is the timestamp part.  Returns 1 = converted,
 // 0 = invalid, 2 = undecided (the caller runs the byte-wise parser).
-__device__ __forceinline__ uint32_t fast_rfc3339(const Tile& T, uint32_t base, uint32_t t0, uint32_t L, double* out) {
+// `hdr` = the line's first 132 bytes as line-aligned dwords (already in registers): the timestamp
+// starts at t0 in 5..7, i.e. always inside hdr[1].
+__device__ __forceinline__ uint32_t fast_rfc3339(const Tile& T, uint32_t base, const uint32_t* hdr, uint32_t t0, uint32_t L,
+                                                 double* out) {
     const uint32_t a = base + t0;
-    const uint32_t d = a >> 2, s = a & 3u;
-    uint32_t w[10];
-#pragma unroll
-    for (int k = 0; k < 10; ++k) w[k] = T.w[d + k];
+    const uint32_t s = t0 - 4u;  // 1..3
     uint32_t r[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) r[k] = __builtin_amdgcn_alignbyte(w[k + 1], w[k], s);
+    for (int k = 0; k < 9; ++k) r[k] = __builtin_amdgcn_alignbyte(hdr[k + 2], hdr[k + 1], s);
     // bytes 0..18 = "YYYY-MM-DDtHH:MM:SS" ; XOR with the pattern: digits -> 0..9, literals -> 0
     const uint32_t x0 = r[0] ^ 0x30303030u;                         // Y Y Y Y
     const uint32_t x1 = r[1] ^ 0x2D30302Du;                         // - M M -
@@ -416,12 +403,22 @@ __device__ __forceinline__ uint32_t take_space(uint64_t& lo, uint64_t& hi, uint3
 // stay converged; what it cannot decide is reported in Fast::route.
 __device__ __forceinline__ Fast parse_line_fast(const Tile& T, uint32_t base, uint32_t len, Row& r) {
     Fast f;
-    // ---- independent LDS reads: first 8 bytes, last byte, 160 bits of the space bitmap --------
-    uint32_t h0, h1, l0, l1;
-    load8(T, base, &h0, &h1);
+    // ---- independent LDS reads: the line's first 132 bytes (line-aligned dwords) and its last byte.
+    //      The space mask of the header is derived HERE, per line, from those registers: classifying
+    //      only the ~128 header bytes of each line costs fewer wave-instructions than classifying
+    //      every byte of the tile in stage A (most bytes of a log line are message text).
+    uint32_t l0, l1;
     load8(T, base + (len ? len - 1u : 0u), &l0, &l1);
-    const uint32_t q = base >> 5, sh = base & 31u;
-    const uint32_t b0 = T.bm[q], b1 = T.bm[q + 1], b2 = T.bm[q + 2], b3 = T.bm[q + 3], b4 = T.bm[q + 4];
+    uint32_t hdr[33];
+    {
+        const uint32_t d = base >> 2, sft = base & 3u;
+        uint32_t raw[34];
+#pragma unroll
+        for (int k = 0; k < 34; ++k) raw[k] = T.w[d + k];
+#pragma unroll
+        for (int k = 0; k < 33; ++k) hdr[k] = __builtin_amdgcn_alignbyte(raw[k + 1], raw[k], sft);
+    }
+    const uint32_t h0 = hdr[0], h1 = hdr[1];
 
     // ---- "<" 1-3 digits ">" "1" then ' ' or end of line ------------------------- :62-92
     const uint32_t c1 = ((h0 >> 8) & 0xFFu) - '0', c2 = ((h0 >> 16) & 0xFFu) - '0', c3 = (h0 >> 24) - '0';
@@ -442,8 +439,16 @@ __device__ __forceinline__ Fast parse_line_fast(const Tile& T, uint32_t base, ui
     r.severity = pri & 7u;
 
     // ---- splitn(7, ' '): the five spaces after the one that follows "<PRI>1" ----------- :23
-    uint64_t lo = (uint64_t)__builtin_amdgcn_alignbit(b1, b0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(b2, b1, sh) << 32);
-    uint64_t hi = (uint64_t)__builtin_amdgcn_alignbit(b3, b2, sh) | ((uint64_t)__builtin_amdgcn_alignbit(b4, b3, sh) << 32);
+    uint64_t lo, hi;
+    {
+        uint32_t m[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            m[k] = gather16(eq_flags(hdr[4 * k], 0x20202020u), eq_flags(hdr[4 * k + 1], 0x20202020u),
+                            eq_flags(hdr[4 * k + 2], 0x20202020u), eq_flags(hdr[4 * k + 3], 0x20202020u));
+        lo = (uint64_t)(m[0] | (m[1] << 16)) | ((uint64_t)(m[2] | (m[3] << 16)) << 32);
+        hi = (uint64_t)(m[4] | (m[5] << 16)) | ((uint64_t)(m[6] | (m[7] << 16)) << 32);
+    }
     {
         const uint64_t lo_keep = len < 64u ? (1ull << (len & 63u)) - 1ull : ~0ull;
         const uint64_t hi_keep = len < 64u ? 0ull : len < 128u ? (1ull << ((len - 64u) & 63u)) - 1ull : ~0ull;
@@ -463,7 +468,7 @@ __device__ __forceinline__ Fast parse_line_fast(const Tile& T, uint32_t base, ui
     f.t0 = sp0 + 1u;
     f.te = s1;
     {
-        const uint32_t ok = fast_rfc3339(T, base, f.t0, s1 - f.t0, &r.ts);
+        const uint32_t ok = fast_rfc3339(T, base, hdr, f.t0, s1 - f.t0, &r.ts);
         f.ts_ok = ok == 1u ? 1u : 0u;
         f.route |= ok == 2u ? R_TS_SLOW : 0u;
     }
@@ -735,7 +740,10 @@ __device__ __forceinline__ void parse_tail_sd_tile(const Tile& T, uint32_t base,
 // The format policy of the streaming pipeline (fg_pipeline.hpp): stage A builds the SPACE bitmap;
 // decode() = stage B + SD entries + the table row for ONE line group whose tile is in LDS.
 struct Rfc5424Format {
-    static __device__ __forceinline__ uint32_t mask16(const uint4& v) { return mask16_eq(v, 0x20202020u); }
+    // no stage-A bitmap: the fast path classifies the header bytes itself, the SD walker's
+    // quote bitmap is built on demand (rebuild_bitmap) for groups that hold SD lines
+    static constexpr bool kStageABitmap = false;
+    static __device__ __forceinline__ uint32_t mask16(const uint4&) { return 0u; }
 
     __device__ __forceinline__ RowOut decode(const GroupCtx& c, const DevTables& t) const {
     const uint8_t* __restrict__ bytes = c.bytes;
@@ -825,19 +833,16 @@ struct Rfc5424Format {
     }
 
     // ---- structured-data entries: wave prefix sum + one atomic per wave ---------------------
-    uint32_t total;
-    uint32_t ex = wave_exclusive_sum(r.n_ent, &total);
     uint32_t first = 0;
-    if (total != 0) {  // wave-uniform
-        unsigned long long slot0 = 0;
-        if (lane == 0) slot0 = atomicAdd(t.ent_used, (unsigned long long)total);
-        slot0 = __shfl(slot0, 0, kWave);
-        unsigned long long mine = slot0 + ex;
+    {
+        bool overflow;
+        const uint32_t mine = alloc_entries(t, r.n_ent, &overflow);
+        if (overflow) {
+            r.status = FG_ST_OVERFLOW;
+            r.n_ent = 0;
+        }
         if (r.n_ent != 0) {
-            if (mine + r.n_ent > t.ent_cap) {
-                r.status = FG_ST_OVERFLOW;
-                r.n_ent = 0;
-            } else {
+            {
                 first = (uint32_t)mine;
                 uint32_t msg_at, cnt;
                 if (ablate & 4u) {
