@@ -36,7 +36,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--tile-lines", type=int, default=1_000_000)
     ap.add_argument("--reps", type=int, default=100, help="tile replicas resident per GPU")
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5", "ltsv", "frame"],
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5", "ltsv", "ltsv5", "frame"],
                     help="cfg2 = the BASELINE metric's configuration (default); the others time the remaining "
                          "kernels on their parity-test corpora (not bench lines, see DESIGN.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -53,6 +53,7 @@ WORKLOADS = {
     "cfg5": (0, "BASELINE configs[4] shape: RFC5424, log-uniform 64 B..8 KiB lines with structured data"),
     "cfg3": (2, "BASELINE configs[2]: GELF/JSON, 8 flat extra fields"),
     "ltsv": (1, "LTSV, typed schema (the LTSV half of BASELINE configs[4])"),
+    "ltsv5": (1, "BASELINE configs[4] shape, LTSV half: log-uniform 64 B..8 KiB lines"),
     "frame": (0, "GPU framing + UTF-8 validation of the newline-terminated cfg2 stream (SURVEY 8f-1), then decode of the frames"),
 }
 
@@ -103,8 +104,8 @@ def main():
     sd = wl in ("cfg4", "cfg5")
     if wl == "cfg3":
         lines = synth.gelf_lines(args.tile_lines, invalid_frac=args.invalid_frac)
-    elif wl == "ltsv":
-        lines = synth.ltsv_lines(args.tile_lines, invalid_frac=args.invalid_frac)
+    elif wl in ("ltsv", "ltsv5"):
+        lines = synth.ltsv_lines(args.tile_lines, invalid_frac=args.invalid_frac, long_tail=wl == "ltsv5")
     elif wl == "frame":
         lines = [ln + b"\n" for ln in synth.rfc5424_lines(args.tile_lines, cfg=2, invalid_frac=args.invalid_frac)]
     elif wl == "cfg5":

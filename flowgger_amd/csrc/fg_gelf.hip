@@ -636,7 +636,7 @@ struct GelfFormat {
                                                        uint32_t* end, uint32_t* esc) {
         uint32_t has_esc = 0;
         for (;;) {
-            const uint32_t h = find_bit(T.bm, base, p, len);
+            const uint32_t h = find_bit_long(T.bm, base, p, len);
             if (h >= len) return false;
             uint32_t b0, b1;
             load8(T, base + h, &b0, &b1);

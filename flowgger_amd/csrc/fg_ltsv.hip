@@ -338,7 +338,7 @@ struct LtsvFormat {
         uint32_t cnt = 0;
         uint32_t ps = 0;
         for (;;) {  // line.split('\t')
-            const uint32_t pe = find_bit(T.bm, base, ps, len);
+            const uint32_t pe = find_bit_long(T.bm, base, ps, len);
             uint32_t w[4];
             load16(T, base + ps, w);
             // first ':' of the part: in the 16-byte window, else (long name) byte-wise

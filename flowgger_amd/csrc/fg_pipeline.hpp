@@ -96,6 +96,7 @@ struct WinReader {
 };
 
 // first set bit of a tile bitmap at line index >= q (tile byte base+q), or len; 32 bytes per step
+// (compact: for short fields -- names, keys, SD values)
 __device__ __forceinline__ uint32_t find_bit(const uint32_t* bm, uint32_t base, uint32_t q, uint32_t len) {
     while (q < len) {
         uint32_t a = base + q;
@@ -105,6 +106,44 @@ __device__ __forceinline__ uint32_t find_bit(const uint32_t* bm, uint32_t base, 
             return r < len ? r : len;
         }
         q += 32u - (a & 31u);
+    }
+    return len;
+}
+// The same for spans that may be long (an 8 KiB message, a JSON text field): the first word is
+// handled alone (the usual hit), a long run without the class is then crossed 256 bytes per
+// step, eight independent LDS reads per round trip.
+__device__ __forceinline__ uint32_t find_bit_long(const uint32_t* bm, uint32_t base, uint32_t q, uint32_t len) {
+    if (q >= len) return len;
+    {
+        const uint32_t a = base + q;
+        const uint32_t w = bm[a >> 5] >> (a & 31u);
+        if (w) {
+            const uint32_t r = q + (uint32_t)__builtin_ctz(w);
+            return r < len ? r : len;
+        }
+        q += 32u - (a & 31u);
+    }
+    while (q + 256u <= len) {  // base + q is a multiple of 32 from here on
+        const uint32_t i = (base + q) >> 5;
+        uint32_t w[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) w[k] = bm[i + k];
+        if ((w[0] | w[1] | w[2] | w[3] | w[4] | w[5] | w[6] | w[7]) != 0u) {
+            uint32_t r = len;
+#pragma unroll
+            for (int k = 7; k >= 0; --k)
+                if (w[k]) r = q + 32u * k + (uint32_t)__builtin_ctz(w[k]);
+            return r < len ? r : len;
+        }
+        q += 256u;
+    }
+    while (q < len) {
+        const uint32_t w = bm[(base + q) >> 5];
+        if (w) {
+            const uint32_t r = q + (uint32_t)__builtin_ctz(w);
+            return r < len ? r : len;
+        }
+        q += 32u;
     }
     return len;
 }

@@ -245,6 +245,18 @@ def test_entry_workloads_at_scale_replicas_and_checksums(rfc, oracle, shape):
     assert_same(blob, offs, oblob, ooffs, lines)
 
 
+def test_host_path_slices_and_entries(rfc, oracle):
+    """fg_decode_batch on a batch large enough to be cut into several ~32 MiB slices on two streams
+    (rows land at their final position, entries share one counter): same bytes as the oracle."""
+    lines = synth.rfc5424_lines(160_000, cfg=4, sd=True) + synth.rfc5424_lines(150_000, cfg=2)
+    data, offsets = synth.pack(lines)
+    assert data.size > 3 * (32 << 20)
+    oblob, ooffs = oracle.decode_batch(RFC5424, data, offsets)
+    (blob, offs), tab = host_path_blob(rfc, data, offsets)
+    assert_same(blob, offs, oblob, ooffs, lines)
+    assert tab.ent_used == int(tab.a["ent_count"].sum())
+
+
 # ------------------------------------------------------------------------------------- LTSV
 def test_ltsv_corpus_matches_oracle(oracle):
     dec = LTSVDecoder(synth.LTSV_CONFIG)
