@@ -204,7 +204,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                "kernel": ("fg::k_rfc5424_p", "fg::k_ltsv", "fg::k_gelf")[fmt], "kernel_ms": kernel_ms,
+                "kernel": ("fg::k_rfc5424", "fg::k_ltsv", "fg::k_gelf")[fmt], "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_launch": alg_read + alg_written,
                 "read_only_frac": alg_read / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             },
