@@ -89,6 +89,8 @@ def lib() -> C.CDLL:
     L.fg_shard_plan.argtypes = [vp, u64, u32, vp]
     L.fg_set_timing.argtypes = [vp, C.c_int]
     L.fg_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.fg_frame_decode_batch.argtypes = [vp, C.c_int, C.c_int, vp, u64, C.c_int, C.POINTER(fg_tables), C.POINTER(vp),
+                                        C.POINTER(u64), C.POINTER(u64)]
     L.fg_alloc_pinned.argtypes = [u64, C.POINTER(vp)]
     L.fg_free_pinned.argtypes = [vp]
     L.fg_free_pinned.restype = None

@@ -64,6 +64,10 @@ struct fg_ctx {
     uint32_t stash_blocks = 0;
     uint8_t* d_frame = nullptr;  // fg_frame_device scratch (delimiter / UTF-8 masks, block counts)
     uint64_t d_frame_cap = 0;
+    uint8_t* d_bad = nullptr;    // fg_frame_decode_batch: per-frame UTF-8 verdicts
+    uint64_t d_bad_cap = 0;
+    uint64_t* h_off = nullptr;   // fg_frame_decode_batch: pinned host copy of the frame offsets
+    uint64_t h_off_cap = 0;
     fg::LtsvDevCfg ltsv{};
     // staging for fg_decode_batch
     uint8_t* d_bytes = nullptr;
@@ -351,6 +355,8 @@ void fg_destroy(fg_ctx* ctx) {
     if (ctx->d_cfg) (void)hipFree(ctx->d_cfg);
     if (ctx->d_stash) (void)hipFree(ctx->d_stash);
     if (ctx->d_frame) (void)hipFree(ctx->d_frame);
+    if (ctx->d_bad) (void)hipFree(ctx->d_bad);
+    if (ctx->h_off) (void)hipHostFree(ctx->h_off);
     if (ctx->h_tab) (void)hipHostFree(ctx->h_tab);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
@@ -588,6 +594,104 @@ int fg_decode_batch(fg_ctx* ctx, fg_format fmt, const uint8_t* bytes, uint64_t n
         }
         *ht.ent_used = used;
         FG_HIP(ctx, hipStreamSynchronize(lanes[1]));
+        FG_HIP(ctx, hipStreamSynchronize(s));
+        *out = ht;
+        return FG_OK;
+    }
+}
+
+int fg_frame_decode_batch(fg_ctx* ctx, fg_format fmt, fg_framing framing, const uint8_t* bytes, uint64_t nbytes, int final,
+                          fg_tables* out, const uint64_t** out_offsets, uint64_t* n_frames, uint64_t* consumed) {
+    if (!ctx || !out || !out_offsets || !n_frames || !consumed || (nbytes && !bytes)) return FG_ERR_ARG;
+    if (framing != FG_FRAME_LINE && framing != FG_FRAME_NUL) return FG_ERR_UNSUPPORTED;
+    *n_frames = 0;
+    *consumed = 0;
+    *out_offsets = nullptr;
+    if (nbytes == 0) return FG_OK;
+    DeviceGuard g(ctx->device);
+    hipStream_t s = ctx->stream;
+    int rc;
+    if ((rc = grow_dev(ctx, (void**)&ctx->d_bytes, &ctx->d_bytes_cap, up(nbytes, 16) + 16)) != FG_OK) return rc;
+    FG_HIP(ctx, hipMemcpyAsync(ctx->d_bytes, bytes, nbytes, hipMemcpyHostToDevice, s));
+    FG_HIP(ctx, hipMemsetAsync(ctx->d_bytes + nbytes, 0, up(nbytes, 16) + 16 - nbytes, s));
+    // 1. frame: offsets + UTF-8 verdicts (capacity: one frame per 32 bytes to start with, exact on retry)
+    uint64_t cap = nbytes / 32 + 1024, total = 0, last_end = 0;
+    for (;;) {
+        if ((rc = grow_dev(ctx, (void**)&ctx->d_offsets, &ctx->d_offsets_cap, (cap + 2) * 8)) != FG_OK) return rc;
+        if ((rc = grow_dev(ctx, (void**)&ctx->d_bad, &ctx->d_bad_cap, cap + 1)) != FG_OK) return rc;
+        if ((rc = grow_dev(ctx, (void**)&ctx->d_frame, &ctx->d_frame_cap, fg_frame_scratch_bytes(nbytes))) != FG_OK) return rc;
+        uint64_t* d_total = nullptr;
+        int lrc = fg_launch_frame(ctx->d_bytes, nbytes, framing == FG_FRAME_LINE ? 0x0Au : 0x00u, ctx->d_frame, ctx->d_offsets,
+                                  ctx->d_bad, cap, &d_total, s);
+        if (lrc != 0) {
+            ctx->last_hip = lrc;
+            return FG_ERR_HIP;
+        }
+        FG_HIP(ctx, hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, s));
+        FG_HIP(ctx, hipStreamSynchronize(s));
+        if (total + 1 <= cap) break;
+        cap = total + 16;
+    }
+    FG_HIP(ctx, hipMemcpyAsync(&last_end, ctx->d_offsets + total, 8, hipMemcpyDeviceToHost, s));
+    FG_HIP(ctx, hipStreamSynchronize(s));
+    // terminated frames = total; a trailing unterminated piece is a frame only at the end of the stream
+    const bool tail = last_end != nbytes;
+    const uint64_t n = total + ((tail && final) ? 1 : 0);
+    *consumed = (tail && !final) ? last_end : nbytes;
+    *n_frames = n;
+    if ((n + 1) * 8 > ctx->h_off_cap) {
+        if (ctx->h_off) FG_HIP(ctx, hipHostFree(ctx->h_off));
+        ctx->h_off = nullptr;
+        ctx->h_off_cap = 0;
+        uint64_t want = up((n + 1) * 8 + (n + 1) * 2, 1 << 16);
+        FG_HIP(ctx, hipHostMalloc((void**)&ctx->h_off, want, hipHostMallocDefault));
+        ctx->h_off_cap = want;
+    }
+    FG_HIP(ctx, hipMemcpyAsync(ctx->h_off, ctx->d_offsets, (n + 1) * 8, hipMemcpyDeviceToHost, s));
+    *out_offsets = ctx->h_off;
+    if (n == 0) {
+        FG_HIP(ctx, hipStreamSynchronize(s));
+        fg_tables empty{};
+        *out = empty;
+        return FG_OK;
+    }
+    // 2. decode the frames in place (terminators stripped in-kernel, invalid UTF-8 -> FG_ST_BAD_UTF8)
+    const uint64_t used_bytes = *consumed;
+    uint64_t ent_cap = fmt == FG_RFC5424 ? used_bytes / 16 + 1024 : used_bytes / 8 + 1024;
+    for (;;) {
+        if (ent_cap > 0xFFFFFFF0ull) ent_cap = 0xFFFFFFF0ull;
+        uint64_t bytes_total = 0;
+        carve(nullptr, n, ent_cap, nullptr, &bytes_total);
+        if ((rc = grow_dev(ctx, (void**)&ctx->d_tab, &ctx->d_tab_cap, bytes_total)) != FG_OK) return rc;
+        if (bytes_total > ctx->h_tab_cap) {
+            if (ctx->h_tab) FG_HIP(ctx, hipHostFree(ctx->h_tab));
+            ctx->h_tab = nullptr;
+            ctx->h_tab_cap = 0;
+            uint64_t want = up(bytes_total + bytes_total / 4, 1 << 20);
+            FG_HIP(ctx, hipHostMalloc((void**)&ctx->h_tab, want, hipHostMallocDefault));
+            ctx->h_tab_cap = want;
+        }
+        fg_tables dt, ht;
+        carve(ctx->d_tab, n, ent_cap, &dt, nullptr);
+        carve(ctx->h_tab, n, ent_cap, &ht, nullptr);
+        rc = fg_decode_frames_device(ctx, fmt, framing, ctx->d_bytes, used_bytes, ctx->d_offsets, n, ctx->d_bad, &dt, FG_STREAM_OWN);
+        if (rc != FG_OK) return rc;
+        uint64_t used = 0;
+        FG_HIP(ctx, hipMemcpyAsync(&used, dt.ent_used, 8, hipMemcpyDeviceToHost, s));
+        FG_HIP(ctx, hipStreamSynchronize(s));
+        if (used > ent_cap) {
+            if (ent_cap >= 0xFFFFFFF0ull) return FG_ERR_ENT_OVERFLOW;
+            ent_cap = used + used / 8 + 1024;
+            continue;
+        }
+        uint64_t sizes[FG_TABLE_ARRAYS];
+        fg_tables_layout(n, used, sizes);
+        void* dsts[FG_TABLE_ARRAYS] = {ht.meta, ht.ts, ht.hostname, ht.appname, ht.procid, ht.msgid, ht.msg, ht.full_msg,
+                                       ht.ent_first, ht.ent_count, ht.ent_name, ht.ent_val, ht.ent_type, ht.ent_flags, ht.ent_used};
+        void* srcs[FG_TABLE_ARRAYS] = {dt.meta, dt.ts, dt.hostname, dt.appname, dt.procid, dt.msgid, dt.msg, dt.full_msg,
+                                       dt.ent_first, dt.ent_count, dt.ent_name, dt.ent_val, dt.ent_type, dt.ent_flags, dt.ent_used};
+        for (int k = 0; k < FG_TABLE_ARRAYS; ++k)
+            if (sizes[k]) FG_HIP(ctx, hipMemcpyAsync(dsts[k], srcs[k], sizes[k], hipMemcpyDeviceToHost, s));
         FG_HIP(ctx, hipStreamSynchronize(s));
         *out = ht;
         return FG_OK;

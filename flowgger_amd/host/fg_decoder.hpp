@@ -170,6 +170,7 @@ class Decoder {
     }
     virtual std::unique_ptr<Decoder> clone_boxed() const = 0;  // decoder/mod.rs:29-36
     fg_ctx* ctx() const { return ctx_; }
+    const fg_cfg* cfg_ptr() const { return cfgp(); }
     fg_format format() const { return fmt_; }
 
   protected:
@@ -348,6 +349,81 @@ class BatchingSplitter {
     size_t max_lines_, max_bytes_;
     std::vector<uint8_t> bytes_;
     std::vector<uint64_t> offsets_;
+};
+
+
+// LineSplitter / NulSplitter with the framing itself on the GPU: raw chunks of the stream go to
+// fg_frame_decode_batch (framing + UTF-8 validation + decode in one call); the host only carries an
+// unterminated tail over to the next chunk and reports like the reference.
+class GpuFramingSplitter {
+  public:
+    enum Framing { Line, Nul };
+    explicit GpuFramingSplitter(Framing f, size_t chunk_bytes = 8u << 20) : f_(f), chunk_(chunk_bytes) {}
+
+    void run(std::istream& in, const Decoder& d, const RecordSink& sink, std::ostream& err) {
+        std::vector<uint8_t> buf;
+        bool eof = false;
+        while (!eof || !buf.empty()) {
+            const size_t have = buf.size();
+            if (!eof) {
+                buf.resize(have + chunk_);
+                in.read((char*)buf.data() + have, (std::streamsize)chunk_);
+                const size_t got = (size_t)in.gcount();
+                buf.resize(have + got);
+                eof = got < chunk_;
+            }
+            if (buf.empty()) break;
+            fg_tables t{};
+            const uint64_t* off = nullptr;
+            uint64_t n = 0, consumed = 0;
+            buf.resize(buf.size() + 16);  // readable slack
+            const uint64_t nbytes = buf.size() - 16;
+            int rc = fg_frame_decode_batch(d.ctx(), d.format(), f_ == Line ? FG_FRAME_LINE : FG_FRAME_NUL, buf.data(), nbytes,
+                                           eof ? 1 : 0, &t, &off, &n, &consumed);
+            if (rc != FG_OK) throw std::runtime_error("fg_frame_decode_batch failed: " + std::to_string(rc));
+            if (n) emit(d, buf.data(), off, n, t, sink, err);
+            buf.resize(nbytes);
+            if (consumed == 0 && !eof && n == 0) {  // one frame longer than the chunk: read more
+                chunk_ *= 2;
+                continue;
+            }
+            buf.erase(buf.begin(), buf.begin() + (std::ptrdiff_t)consumed);
+        }
+    }
+
+  private:
+    void emit(const Decoder& d, const uint8_t* bytes, const uint64_t* off, uint64_t n, const fg_tables& t, const RecordSink& sink,
+              std::ostream& err) {
+        std::vector<uint64_t> so(n + 1);
+        int64_t total = fg_tables_serialize(d.format(), d.cfg_ptr(), bytes, off, &t, 0, n, nullptr, 0, so.data());
+        if (total < 0) throw std::runtime_error("fg_tables_serialize failed");
+        std::vector<uint8_t> blob((size_t)total + 1);
+        fg_tables_serialize(d.format(), d.cfg_ptr(), bytes, off, &t, 0, n, blob.data(), (uint64_t)total, so.data());
+        for (uint64_t i = 0; i < n; ++i) {
+            const uint8_t st = FG_META_STATUS(t.meta[i]);
+            if (st == FG_ST_BAD_UTF8) {
+                err << "Invalid UTF-8 input\n";  // line_splitter.rs:22-25, nul_splitter.rs:35-38
+                continue;
+            }
+            DecodeResult r = detail::from_canonical(blob.data() + so[i], d.format(), st);
+            if (r.ok()) {
+                sink(std::move(r.record));
+                continue;
+            }
+            // the line as the reference saw it: without its terminator
+            uint64_t b = off[i], e = off[i + 1];
+            if (f_ == Line) {
+                if (e > b && bytes[e - 1] == '\n') { --e; if (e > b && bytes[e - 1] == '\r') --e; }
+            } else if (e > b && bytes[e - 1] == 0) {
+                --e;
+            }
+            std::string_view tl = detail::trim(std::string_view((const char*)bytes + b, e - b));
+            if (f_ == Nul && tl.empty()) continue;  // nul_splitter.rs:41-46
+            err << r.err << ": [" << tl << "]\n";   // line_splitter.rs:37-39
+        }
+    }
+    Framing f_;
+    size_t chunk_;
 };
 
 }  // namespace fg

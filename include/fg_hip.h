@@ -197,6 +197,21 @@ int fg_decode_frames_device(fg_ctx* ctx, fg_format fmt, fg_framing framing, cons
 int fg_decode_batch(fg_ctx* ctx, fg_format fmt, const uint8_t* bytes, uint64_t nbytes,
                     const uint64_t* offsets, uint64_t n, fg_tables* out);
 
+/* HOST-BUFFER RAW-STREAM decode: one call frames a chunk of the raw byte stream on the GPU
+ * (FG_FRAME_LINE / FG_FRAME_NUL), validates UTF-8 per frame and decodes every frame -- what
+ * LineSplitter::run / NulSplitter::run do per line (line_splitter.rs:17-54, nul_splitter.rs:18-60).
+ *   final        nonzero: the stream ends with this chunk, so a trailing unterminated piece is a
+ *                frame (BufRead semantics); zero: it is left for the next chunk
+ *   out          tables in ctx-owned pinned host memory (as fg_decode_batch), *n_frames rows; a frame
+ *                that is not valid UTF-8 has status FG_ST_BAD_UTF8
+ *   out_offsets  ctx-owned host array, *n_frames + 1 entries: frame i = bytes[off[i] .. off[i+1])
+ *                INCLUDING its terminator; spans in `out` are relative to off[i]
+ *   consumed     bytes covered by the returned frames: carry bytes[consumed .. nbytes) over
+ * Everything returned stays valid until the next call on this ctx. */
+int fg_frame_decode_batch(fg_ctx* ctx, fg_format fmt, fg_framing framing, const uint8_t* bytes,
+                          uint64_t nbytes, int final, fg_tables* out, const uint64_t** out_offsets,
+                          uint64_t* n_frames, uint64_t* consumed);
+
 /* Page-locked host memory for the framer's batch buffers (bytes, offsets). */
 int fg_alloc_pinned(uint64_t bytes, void** out);
 void fg_free_pinned(void* p);

@@ -21,6 +21,20 @@ int main(int argc, char** argv) {
         dec.reset(new fg::LTSVDecoder(c));
     }
     auto clone = dec->clone_boxed();  // per-connection clone, like tcp_input.rs:39-47
+    auto hex_sink = [](fg::Record&& r) {
+        fg::DecodeResult d;
+        d.record = std::move(r);
+        std::string c = fg::to_canonical(d);
+        for (unsigned char ch : c) printf("%02x", ch);
+        printf("\n");
+    };
+    if (fr == "gpu-line" || fr == "gpu-nul") {  // framing + UTF-8 validation on the GPU as well
+        fg::GpuFramingSplitter gsp(fr == "gpu-line" ? fg::GpuFramingSplitter::Line : fg::GpuFramingSplitter::Nul,
+                                   argc > 4 ? (size_t)atoi(argv[4]) : (8u << 20));
+        std::ifstream gin(argv[3], std::ios::binary);
+        gsp.run(gin, *clone, hex_sink, std::cerr);
+        return 0;
+    }
     fg::BatchingSplitter sp(fr == "line" ? fg::BatchingSplitter::Line : fr == "nul" ? fg::BatchingSplitter::Nul : fg::BatchingSplitter::Syslen,
                             argc > 4 ? (size_t)atoi(argv[4]) : 1000);
     std::ifstream in(argv[3], std::ios::binary);

@@ -429,7 +429,8 @@ def test_cfg5_mixed_formats_ordered_merge(rfc, oracle):
 
 
 # ---------------------------------------------------------------------- C++ host mirror + framers
-@pytest.mark.parametrize("fmt,framing", [("rfc5424", "line"), ("gelf", "nul"), ("ltsv", "syslen")])
+@pytest.mark.parametrize("fmt,framing", [("rfc5424", "line"), ("gelf", "nul"), ("ltsv", "syslen"), ("rfc5424", "gpu-line"),
+                                         ("ltsv", "gpu-line"), ("gelf", "gpu-nul")])
 def test_cpp_host_mirror_and_batching_splitters(tmp_path, oracle, fmt, framing):
     """fg::Decoder / fg::BatchingSplitter (C++ mirror of the trait and of the three splitters):
     Ok records in input order == oracle, error lines formatted like line_splitter.rs:37-39."""
@@ -450,19 +451,24 @@ def test_cpp_host_mirror_and_batching_splitters(tmp_path, oracle, fmt, framing):
     raw = bytearray()
     expect_lines = []
     for i, ln in enumerate(lines):
-        if framing == "line":
+        if framing in ("line", "gpu-line"):
             raw += ln + (b"\r\n" if i % 5 == 0 else b"\n")
-        elif framing == "nul":
+        elif framing in ("nul", "gpu-nul"):
             raw += ln + b"\0"
         else:
             raw += str(len(ln)).encode() + b" " + ln
         expect_lines.append(ln)
     bad_utf8 = b"<13>1 2015-08-05T15:53:45Z h a p m - \xff\xfe"
     if framing != "syslen":  # the reference unwrap()-panics on invalid UTF-8 under syslen framing
-        raw += bad_utf8 + (b"\n" if framing == "line" else b"\0")
+        raw += bad_utf8 + (b"\n" if framing in ("line", "gpu-line") else b"\0")
+    if framing.startswith("gpu-"):
+        raw += lines[11]  # an unterminated last frame is a frame
+        expect_lines.append(lines[11])
     f = tmp_path / "in.bin"
     f.write_bytes(bytes(raw))
-    p = subprocess.run([str(exe), fmt, framing, str(f), "257"], capture_output=True)
+    # batch size (lines) for the host framers, chunk size (bytes) for the GPU-framing splitter: small,
+    # so that frames straddle chunks and the carry-over logic is exercised
+    p = subprocess.run([str(exe), fmt, framing, str(f), "257" if not framing.startswith("gpu-") else "20011"], capture_output=True)
     assert p.returncode == 0, p.stderr[-2000:]
     got_ok = [bytes.fromhex(x) for x in p.stdout.decode().split()]
     got_err = p.stderr.decode("utf-8", "replace").splitlines()
@@ -474,9 +480,13 @@ def test_cpp_host_mirror_and_batching_splitters(tmp_path, oracle, fmt, framing):
         else:
             msg = c[5:].decode()
             t = ln.decode("utf-8", "replace").strip()
-            if not (framing == "nul" and t == ""):
+            if not (framing in ("nul", "gpu-nul") and t == ""):
                 want_err.append(f"{msg}: [{t}]")
-    if framing != "syslen":
+    if framing.startswith("gpu-"):
+        # the invalid frame sits before the unterminated last line
+        tail_errs = want_err[-1:] if oracle.decode(code, lines[11], cfg)[0] != 0 else []
+        want_err = want_err[:len(want_err) - len(tail_errs)] + ["Invalid UTF-8 input"] + tail_errs
+    elif framing != "syslen":
         want_err.append("Invalid UTF-8 input")
     else:
         want_err.append("Can't read message's length")
