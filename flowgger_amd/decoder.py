@@ -148,6 +148,25 @@ class Decoder:
                                                 C.byref(tables.struct), C.c_void_p(stream.cuda_stream)),
                 "fg_decode_frames_device")
 
+    def frame_decode_batch(self, raw: Union[bytes, np.ndarray], framing: int, final: bool = True):
+        """Raw chunk of the byte stream in, tables out: GPU framing + UTF-8 validation + decode in one
+        call (fg_frame_decode_batch; the body of LineSplitter::run / NulSplitter::run).  Returns
+        (HostTables, offsets uint64[n+1], consumed): frame i = raw[offsets[i]:offsets[i+1]] including
+        its terminator; raw[consumed:] is an unterminated tail to carry over (empty when `final`)."""
+        buf = np.frombuffer(raw, np.uint8) if not isinstance(raw, np.ndarray) else np.ascontiguousarray(raw, np.uint8)
+        padded = np.zeros(buf.size + 16, np.uint8)
+        padded[:buf.size] = buf
+        st = L.fg_tables()
+        off = C.c_void_p()
+        n, used = C.c_uint64(), C.c_uint64()
+        L.check(L.lib().fg_frame_decode_batch(self._ctx, self.fmt, framing, padded.ctypes.data, buf.size, int(final),
+                                              C.byref(st), C.byref(off), C.byref(n), C.byref(used)), "fg_frame_decode_batch")
+        nf = int(n.value)
+        if nf == 0:
+            return None, np.zeros(1, np.uint64), int(used.value)
+        offsets = np.ctypeslib.as_array(C.cast(off, C.POINTER(C.c_uint64)), (nf + 1,)).copy()
+        return HostTables.from_struct(st), offsets, int(used.value)
+
     def set_timing(self, enabled: bool = True) -> None:
         L.check(L.lib().fg_set_timing(self._ctx, int(enabled)), "fg_set_timing")
 

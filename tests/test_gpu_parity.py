@@ -605,3 +605,44 @@ def test_gpu_framing_block_boundaries(rfc):
         offs = d_offsets[:n + 1].cpu().numpy()
         assert [int(x) for x in offs[:-1]] == [r[0] for r in ref] and int(offs[-1]) == len(raw)
         assert d_bad[:n].cpu().numpy().tolist() == [0 if r[3] else 1 for r in ref], raw[:20]
+
+
+def test_frame_decode_batch_chunked_stream(rfc, oracle):
+    """fg_frame_decode_batch over a stream cut into arbitrary chunks: the carried-over tails and the
+    per-chunk results concatenate to exactly the frames of the whole stream."""
+    from flowgger_amd import _lib as L
+
+    lines = synth.rfc5424_lines(5_000, cfg=2) + synth.rfc5424_lines(1_500, cfg=4, sd=True)
+    tort = _utf8_torture()
+    raw = b"".join((ln + (b" " + tort[i % len(tort)] if i % 9 == 4 else b"")) + (b"\r\n" if i % 4 == 0 else b"\n")
+                   for i, ln in enumerate(lines)) + b"last line without terminator"
+    ref = _frames_reference(raw, "line")
+    rng = np.random.default_rng(3)
+    got = []  # (status, canonical bytes)
+    pos, carry = 0, b""
+    while pos < len(raw) or carry:
+        step = int(rng.integers(1, 200_000))
+        chunk = carry + raw[pos:pos + step]
+        pos += step
+        final = pos >= len(raw)
+        tab, offs, used = rfc.frame_decode_batch(chunk, L.FG_FRAME_LINE, final=final)
+        if tab is not None:
+            blob, boffs = tab.serialize(RFC5424, np.frombuffer(chunk + b"\0" * 16, np.uint8), offs)
+            st = tab.status
+            for i in range(len(offs) - 1):
+                got.append((int(st[i]), blob[int(boffs[i]):int(boffs[i + 1])].tobytes()))
+        carry = chunk[used:]
+        if final:
+            assert carry == b""
+            break
+    assert len(got) == len(ref)
+    good = [r[2] for r in ref if r[3]]
+    gdata, goffs = synth.pack(good)
+    oblob, ooffs = oracle.decode_batch(RFC5424, gdata, goffs)
+    j = 0
+    for (st, blob), r in zip(got, ref):
+        if not r[3]:
+            assert st == L.FG_ST_BAD_UTF8
+            continue
+        assert blob == oblob[int(ooffs[j]):int(ooffs[j + 1])].tobytes(), r[2][:60]
+        j += 1
