@@ -1146,6 +1146,373 @@ uint64_t record_checksum(const Result& r) {
     return h;
 }
 
+
+// =========================================================================================
+// GELF encoder: GelfEncoder::encode, src/flowgger/encoder/gelf_encoder.rs:59-115,
+// + what it calls in serde_json 0.8: Value::Object = BTreeMap<String, Value> (keys in byte order,
+// a later insert replaces an earlier one), compact `to_vec`, `escape_str`, itoa for integers and
+// the `dtoa` crate (a port of rapidjson's Grisu2 with its `Prettify`) for f64; non-finite -> null.
+// PINNED by the reference's tests gelf_encoder.rs:125-244 (four vectors; the only floats they hold
+// are 1385053862.3072 and 123.456).  UNPINNED: every other f64 rendering (Grisu2 is not always the
+// shortest digit string; the `index < 9` guard of DigitGen is the one of the dtoa crate 0.2/0.4).
+// =========================================================================================
+struct DiyFp {
+    uint64_t f;
+    int e;
+};
+inline DiyFp diy_mul(DiyFp a, DiyFp b) {
+    unsigned __int128 p = (unsigned __int128)a.f * b.f;
+    uint64_t h = (uint64_t)(p >> 64), l = (uint64_t)p;
+    if (l & (1ull << 63)) ++h;  // round
+    return DiyFp{h, a.e + b.e + 64};
+}
+inline DiyFp diy_normalize(DiyFp a) {
+    int s = __builtin_clzll(a.f);
+    return DiyFp{a.f << s, a.e - s};
+}
+const DiyFp kCachedPowers[87] = {
+    {0xfa8fd5a0081c0288ull, -1220},
+    {0xbaaee17fa23ebf76ull, -1193},
+    {0x8b16fb203055ac76ull, -1166},
+    {0xcf42894a5dce35eaull, -1140},
+    {0x9a6bb0aa55653b2dull, -1113},
+    {0xe61acf033d1a45dfull, -1087},
+    {0xab70fe17c79ac6caull, -1060},
+    {0xff77b1fcbebcdc4full, -1034},
+    {0xbe5691ef416bd60cull, -1007},
+    {0x8dd01fad907ffc3cull, -980},
+    {0xd3515c2831559a83ull, -954},
+    {0x9d71ac8fada6c9b5ull, -927},
+    {0xea9c227723ee8bcbull, -901},
+    {0xaecc49914078536dull, -874},
+    {0x823c12795db6ce57ull, -847},
+    {0xc21094364dfb5637ull, -821},
+    {0x9096ea6f3848984full, -794},
+    {0xd77485cb25823ac7ull, -768},
+    {0xa086cfcd97bf97f4ull, -741},
+    {0xef340a98172aace5ull, -715},
+    {0xb23867fb2a35b28eull, -688},
+    {0x84c8d4dfd2c63f3bull, -661},
+    {0xc5dd44271ad3cdbaull, -635},
+    {0x936b9fcebb25c996ull, -608},
+    {0xdbac6c247d62a584ull, -582},
+    {0xa3ab66580d5fdaf6ull, -555},
+    {0xf3e2f893dec3f126ull, -529},
+    {0xb5b5ada8aaff80b8ull, -502},
+    {0x87625f056c7c4a8bull, -475},
+    {0xc9bcff6034c13053ull, -449},
+    {0x964e858c91ba2655ull, -422},
+    {0xdff9772470297ebdull, -396},
+    {0xa6dfbd9fb8e5b88full, -369},
+    {0xf8a95fcf88747d94ull, -343},
+    {0xb94470938fa89bcfull, -316},
+    {0x8a08f0f8bf0f156bull, -289},
+    {0xcdb02555653131b6ull, -263},
+    {0x993fe2c6d07b7facull, -236},
+    {0xe45c10c42a2b3b06ull, -210},
+    {0xaa242499697392d3ull, -183},
+    {0xfd87b5f28300ca0eull, -157},
+    {0xbce5086492111aebull, -130},
+    {0x8cbccc096f5088ccull, -103},
+    {0xd1b71758e219652cull, -77},
+    {0x9c40000000000000ull, -50},
+    {0xe8d4a51000000000ull, -24},
+    {0xad78ebc5ac620000ull, 3},
+    {0x813f3978f8940984ull, 30},
+    {0xc097ce7bc90715b3ull, 56},
+    {0x8f7e32ce7bea5c70ull, 83},
+    {0xd5d238a4abe98068ull, 109},
+    {0x9f4f2726179a2245ull, 136},
+    {0xed63a231d4c4fb27ull, 162},
+    {0xb0de65388cc8ada8ull, 189},
+    {0x83c7088e1aab65dbull, 216},
+    {0xc45d1df942711d9aull, 242},
+    {0x924d692ca61be758ull, 269},
+    {0xda01ee641a708deaull, 295},
+    {0xa26da3999aef774aull, 322},
+    {0xf209787bb47d6b85ull, 348},
+    {0xb454e4a179dd1877ull, 375},
+    {0x865b86925b9bc5c2ull, 402},
+    {0xc83553c5c8965d3dull, 428},
+    {0x952ab45cfa97a0b3ull, 455},
+    {0xde469fbd99a05fe3ull, 481},
+    {0xa59bc234db398c25ull, 508},
+    {0xf6c69a72a3989f5cull, 534},
+    {0xb7dcbf5354e9beceull, 561},
+    {0x88fcf317f22241e2ull, 588},
+    {0xcc20ce9bd35c78a5ull, 614},
+    {0x98165af37b2153dfull, 641},
+    {0xe2a0b5dc971f303aull, 667},
+    {0xa8d9d1535ce3b396ull, 694},
+    {0xfb9b7cd9a4a7443cull, 720},
+    {0xbb764c4ca7a44410ull, 747},
+    {0x8bab8eefb6409c1aull, 774},
+    {0xd01fef10a657842cull, 800},
+    {0x9b10a4e5e9913129ull, 827},
+    {0xe7109bfba19c0c9dull, 853},
+    {0xac2820d9623bf429ull, 880},
+    {0x80444b5e7aa7cf85ull, 907},
+    {0xbf21e44003acdd2dull, 933},
+    {0x8e679c2f5e44ff8full, 960},
+    {0xd433179d9c8cb841ull, 986},
+    {0x9e19db92b4e31ba9ull, 1013},
+    {0xeb96bf6ebadf77d9ull, 1039},
+    {0xaf87023b9bf0ee6bull, 1066}
+};
+inline DiyFp cached_power(int e, int* K) {
+    double dk = (-61 - e) * 0.30102999566398114 + 347;
+    int k = (int)dk;
+    if (dk - k > 0.0) ++k;
+    unsigned index = (unsigned)((k >> 3) + 1);
+    *K = -(-348 + (int)(index << 3));
+    return kCachedPowers[index];
+}
+inline void grisu_round(char* buf, int len, uint64_t delta, uint64_t rest, uint64_t ten_kappa, uint64_t wp_w) {
+    while (rest < wp_w && delta - rest >= ten_kappa && (rest + ten_kappa < wp_w || wp_w - rest > rest + ten_kappa - wp_w)) {
+        --buf[len - 1];
+        rest += ten_kappa;
+    }
+}
+inline int count_digits32(uint32_t n) {
+    if (n < 10) return 1;
+    if (n < 100) return 2;
+    if (n < 1000) return 3;
+    if (n < 10000) return 4;
+    if (n < 100000) return 5;
+    if (n < 1000000) return 6;
+    if (n < 10000000) return 7;
+    if (n < 100000000) return 8;
+    if (n < 1000000000) return 9;
+    return 10;
+}
+const uint32_t kPow10[10] = {1, 10, 100, 1000, 10000, 100000, 1000000, 10000000, 100000000, 1000000000};
+inline void digit_gen(DiyFp W, DiyFp Mp, uint64_t delta, char* buf, int* len, int* K) {
+    const DiyFp one{1ull << -Mp.e, Mp.e};
+    const uint64_t wp_w = Mp.f - W.f;
+    uint32_t p1 = (uint32_t)(Mp.f >> -one.e);
+    uint64_t p2 = Mp.f & (one.f - 1);
+    int kappa = count_digits32(p1);
+    *len = 0;
+    while (kappa > 0) {
+        uint32_t d = p1 / kPow10[kappa - 1];
+        p1 %= kPow10[kappa - 1];
+        if (d || *len) buf[(*len)++] = (char)('0' + d);
+        --kappa;
+        uint64_t tmp = ((uint64_t)p1 << -one.e) + p2;
+        if (tmp <= delta) {
+            *K += kappa;
+            grisu_round(buf, *len, delta, tmp, (uint64_t)kPow10[kappa] << -one.e, wp_w);
+            return;
+        }
+    }
+    for (;;) {
+        p2 *= 10;
+        delta *= 10;
+        char d = (char)(p2 >> -one.e);
+        if (d || *len) buf[(*len)++] = (char)('0' + d);
+        p2 &= one.f - 1;
+        --kappa;
+        if (p2 < delta) {
+            *K += kappa;
+            int index = -kappa;
+            grisu_round(buf, *len, delta, p2, one.f, wp_w * (index < 9 ? kPow10[index] : 0));
+            return;
+        }
+    }
+}
+inline void grisu2(double value, char* buf, int* len, int* K) {
+    uint64_t u;
+    memcpy(&u, &value, 8);
+    const int biased = (int)((u >> 52) & 0x7FF);
+    const uint64_t frac = u & ((1ull << 52) - 1);
+    DiyFp v = biased ? DiyFp{frac + (1ull << 52), biased - 1075} : DiyFp{frac, -1074};
+    // normalized boundaries
+    DiyFp pl{(v.f << 1) + 1, v.e - 1};
+    while (!(pl.f & (1ull << 53))) {
+        pl.f <<= 1;
+        --pl.e;
+    }
+    pl.f <<= 10;
+    pl.e -= 10;
+    DiyFp mi = (v.f == (1ull << 52)) ? DiyFp{(v.f << 2) - 1, v.e - 2} : DiyFp{(v.f << 1) - 1, v.e - 1};
+    mi.f <<= mi.e - pl.e;
+    mi.e = pl.e;
+    const DiyFp c_mk = cached_power(pl.e, K);
+    const DiyFp W = diy_mul(diy_normalize(v), c_mk);
+    DiyFp Wp = diy_mul(pl, c_mk);
+    DiyFp Wm = diy_mul(mi, c_mk);
+    ++Wm.f;
+    --Wp.f;
+    digit_gen(W, Wp, Wp.f - Wm.f, buf, len, K);
+}
+// dtoa::write: returns the text
+std::string dtoa_text(double value) {
+    if (value == 0.0) return std::signbit(value) ? "-0.0" : "0.0";
+    std::string out;
+    if (value < 0) {
+        out.push_back('-');
+        value = -value;
+    }
+    char d[32];
+    int len = 0, k = 0;
+    grisu2(value, d, &len, &k);
+    const int kk = len + k;  // 10^(kk-1) <= v < 10^kk
+    std::string digits(d, (size_t)len);
+    auto write_exp = [&](int K) {
+        if (K < 0) {
+            out.push_back('-');
+            K = -K;
+        }
+        out += std::to_string(K);
+    };
+    if (0 <= k && kk <= 21) {  // 1234e7 -> 12340000000.0
+        out += digits;
+        out.append((size_t)k, '0');
+        out += ".0";
+    } else if (0 < kk && kk <= 21) {  // 1234e-2 -> 12.34
+        out += digits.substr(0, (size_t)kk);
+        out.push_back('.');
+        out += digits.substr((size_t)kk);
+    } else if (-6 < kk && kk <= 0) {  // 1234e-6 -> 0.001234
+        out += "0.";
+        out.append((size_t)(-kk), '0');
+        out += digits;
+    } else if (len == 1) {  // 1e30
+        out += digits;
+        out.push_back('e');
+        write_exp(kk - 1);
+    } else {  // 1234e30 -> 1.234e33
+        out.push_back(digits[0]);
+        out.push_back('.');
+        out += digits.substr(1);
+        out.push_back('e');
+        write_exp(kk - 1);
+    }
+    return out;
+}
+
+// serde_json 0.8 escape_str
+void json_escape(sv s, std::string* out) {
+    static const char hex[] = "0123456789abcdef";
+    out->push_back('"');
+    for (unsigned char c : s) {
+        switch (c) {
+            case '"': *out += "\\\""; break;
+            case '\\': *out += "\\\\"; break;
+            case '\b': *out += "\\b"; break;
+            case '\f': *out += "\\f"; break;
+            case '\n': *out += "\\n"; break;
+            case '\r': *out += "\\r"; break;
+            case '\t': *out += "\\t"; break;
+            default:
+                if (c < 0x20) {
+                    *out += "\\u00";
+                    out->push_back(hex[c >> 4]);
+                    out->push_back(hex[c & 15]);
+                } else {
+                    out->push_back((char)c);
+                }
+        }
+    }
+    out->push_back('"');
+}
+struct JsonOut {
+    uint8_t type;  // FGO_T_*
+    std::string s;
+    uint64_t bits;
+};
+// gelf_encoder.rs:59-115
+std::string gelf_encode(const Record& r, const std::vector<std::pair<std::string, std::string>>& extra) {
+    std::map<std::string, JsonOut> m;
+    auto put_s = [&](const std::string& k, const std::string& v) { m[k] = JsonOut{FGO_T_STRING, v, 0}; };
+    put_s("version", "1.1");
+    put_s("host", r.hostname.empty() ? "unknown" : r.hostname);
+    put_s("short_message", r.msg ? *r.msg : "-");
+    {
+        uint64_t b;
+        memcpy(&b, &r.ts, 8);
+        m["timestamp"] = JsonOut{FGO_T_F64, "", b};
+    }
+    if (r.severity) m["level"] = JsonOut{FGO_T_U64, "", *r.severity};
+    if (r.full_msg) put_s("full_message", *r.full_msg);
+    if (r.appname) put_s("application_name", *r.appname);
+    if (r.procid) put_s("process_id", *r.procid);
+    if (r.sd) {
+        for (const auto& sd : *r.sd) {
+            if (sd.sd_id) put_s("sd_id", *sd.sd_id);
+            for (const auto& kv : sd.pairs) m[kv.first] = JsonOut{kv.second.type, kv.second.s, kv.second.bits};
+        }
+    }
+    for (const auto& kv : extra) put_s(kv.first, kv.second);
+    std::string out = "{";
+    bool first = true;
+    for (const auto& kv : m) {
+        if (!first) out.push_back(',');
+        first = false;
+        json_escape(kv.first, &out);
+        out.push_back(':');
+        const JsonOut& v = kv.second;
+        switch (v.type) {
+            case FGO_T_STRING: json_escape(v.s, &out); break;
+            case FGO_T_BOOL: out += v.bits ? "true" : "false"; break;
+            case FGO_T_NULL: out += "null"; break;
+            case FGO_T_U64: out += std::to_string(v.bits); break;
+            case FGO_T_I64: out += std::to_string((int64_t)v.bits); break;
+            default: {
+                double d;
+                memcpy(&d, &v.bits, 8);
+                if (std::isnan(d) || std::isinf(d)) out += "null";
+                else out += dtoa_text(d);
+            }
+        }
+    }
+    out.push_back('}');
+    return out;
+}
+// canonical serialisation -> Record (Ok results only)
+bool parse_canonical(const uint8_t* p, uint64_t n, Record* r) {
+    uint64_t i = 0;
+    auto u8 = [&]() -> uint32_t { return i < n ? p[i++] : 0; };
+    auto u32 = [&]() -> uint32_t { uint32_t v = 0; if (i + 4 <= n) memcpy(&v, p + i, 4); i += 4; return v; };
+    auto u64 = [&]() -> uint64_t { uint64_t v = 0; if (i + 8 <= n) memcpy(&v, p + i, 8); i += 8; return v; };
+    auto str = [&]() -> std::string { uint32_t l = u32(); std::string s; if (i + l <= n) s.assign((const char*)p + i, l); i += l; return s; };
+    auto opt = [&]() -> std::optional<std::string> { if (!u8()) return std::nullopt; return str(); };
+    if (u8() != 0) return false;
+    r->ts_now = u8() != 0;
+    uint64_t tb = u64();
+    memcpy(&r->ts, &tb, 8);
+    uint32_t fac = u8(), sev = u8();
+    if (fac != 0xFF) r->facility = (uint8_t)fac;
+    if (sev != 0xFF) r->severity = (uint8_t)sev;
+    u8();
+    r->hostname = str();
+    r->appname = opt();
+    r->procid = opt();
+    r->msgid = opt();
+    r->msg = opt();
+    r->full_msg = opt();
+    if (!u8()) return i <= n;
+    std::vector<StructuredData> v(u32());
+    for (auto& sd : v) {
+        sd.sd_id = opt();
+        uint32_t np = u32();
+        for (uint32_t k = 0; k < np; ++k) {
+            std::string key = str();
+            SDValue val;
+            val.type = (uint8_t)u8();
+            switch (val.type) {
+                case FGO_T_STRING: val.s = str(); break;
+                case FGO_T_BOOL: val.bits = u8(); break;
+                case FGO_T_NULL: break;
+                default: val.bits = u64();
+            }
+            sd.pairs.emplace_back(std::move(key), std::move(val));
+        }
+    }
+    r->sd = std::move(v);
+    return i <= n;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1234,6 +1601,47 @@ int fgo_json_number(const uint8_t* s, uint64_t len, int* kind, uint64_t* bits) {
     *kind = v.kind == JValue::F64 ? FGO_T_F64 : v.kind == JValue::I64 ? FGO_T_I64 : FGO_T_U64;
     *bits = v.bits;
     return 1;
+}
+
+
+// GELF encoder: canonical Record (an Ok result of fgo_decode) -> GELF JSON.  extra_* = the
+// output.gelf_extra table.  Returns the JSON length (even when > cap), -1 = not an Ok record.
+int64_t fgo_gelf_encode(const uint8_t* canonical, uint64_t len, const char* const* extra_keys, const char* const* extra_vals,
+                        uint32_t n_extra, uint8_t* out, uint64_t cap) {
+    Record r;
+    if (!parse_canonical(canonical, len, &r)) return -1;
+    std::vector<std::pair<std::string, std::string>> extra;
+    for (uint32_t i = 0; i < n_extra; ++i) extra.emplace_back(extra_keys[i], extra_vals[i]);
+    std::string j = gelf_encode(r, extra);
+    if (out && j.size() <= cap) memcpy(out, j.data(), j.size());
+    return (int64_t)j.size();
+}
+// decode + encode n packed lines (the BASELINE configs[0] pipeline: decoder -> GELF encoder); lines
+// that fail to decode produce an empty output.  out_offsets has n+1 entries; out == NULL sizes.
+int64_t fgo_decode_encode_gelf_batch(int fmt, const fgo_ltsv_cfg* cfg, const uint8_t* bytes, const uint64_t* offsets, uint64_t n,
+                                     const char* const* extra_keys, const char* const* extra_vals, uint32_t n_extra,
+                                     uint8_t* out, uint64_t cap, uint64_t* out_offsets) {
+    if (fmt < 0 || fmt > 2) return -1;
+    LtsvCfg c = make_cfg(cfg);
+    std::vector<std::pair<std::string, std::string>> extra;
+    for (uint32_t i = 0; i < n_extra; ++i) extra.emplace_back(extra_keys[i], extra_vals[i]);
+    uint64_t total = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (out_offsets) out_offsets[i] = total;
+        Result r = decode_any(fmt, c, sv((const char*)bytes + offsets[i], offsets[i + 1] - offsets[i]));
+        if (r.err) continue;
+        std::string j = gelf_encode(r.rec, extra);
+        if (out && total + j.size() <= cap) memcpy(out + total, j.data(), j.size());
+        total += j.size();
+    }
+    if (out_offsets) out_offsets[n] = total;
+    return (int64_t)total;
+}
+int fgo_dtoa(double v, char* out, int cap) {
+    std::string s = dtoa_text(v);
+    if ((int)s.size() + 1 > cap) return -1;
+    memcpy(out, s.c_str(), s.size() + 1);
+    return (int)s.size();
 }
 
 }  // extern "C"

@@ -70,6 +70,15 @@ double fgo_bench_decode(int fmt, const fgo_ltsv_cfg* cfg, const uint8_t* bytes,
                         const uint64_t* offsets, uint64_t n, int threads, uint64_t* checksum,
                         uint64_t* n_ok);
 
+/* GELF encoder (gelf_encoder.rs:59-115 + serde_json 0.8 serialisation): canonical Ok record -> JSON. */
+int64_t fgo_gelf_encode(const uint8_t* canonical, uint64_t len, const char* const* extra_keys,
+                        const char* const* extra_vals, uint32_t n_extra, uint8_t* out, uint64_t cap);
+int64_t fgo_decode_encode_gelf_batch(int fmt, const fgo_ltsv_cfg* cfg, const uint8_t* bytes,
+                                     const uint64_t* offsets, uint64_t n, const char* const* extra_keys,
+                                     const char* const* extra_vals, uint32_t n_extra, uint8_t* out,
+                                     uint64_t cap, uint64_t* out_offsets);
+int fgo_dtoa(double v, char* out, int cap); /* the dtoa crate's text for an f64 */
+
 /* Exposed pieces, for unit tests of the restated std/third-party semantics. */
 int fgo_rfc3339_to_unix(const uint8_t* s, uint64_t len, double* out);  /* 1 = ok */
 int fgo_rust_parse_f64(const uint8_t* s, uint64_t len, double* out);  /* 1 = ok */

@@ -41,6 +41,11 @@ class Oracle:
         for f in (L.fgo_rfc3339_to_unix, L.fgo_rust_parse_f64, L.fgo_english_time_to_unix):
             f.argtypes = [vp, u64, C.POINTER(C.c_double)]
         L.fgo_json_number.argtypes = [vp, u64, C.POINTER(C.c_int), C.POINTER(u64)]
+        L.fgo_gelf_encode.restype = C.c_int64
+        L.fgo_gelf_encode.argtypes = [vp, u64, vp, vp, C.c_uint32, vp, u64]
+        L.fgo_decode_encode_gelf_batch.restype = C.c_int64
+        L.fgo_decode_encode_gelf_batch.argtypes = [C.c_int, vp, vp, vp, u64, vp, vp, C.c_uint32, vp, u64, vp]
+        L.fgo_dtoa.argtypes = [C.c_double, vp, C.c_int]
 
     @staticmethod
     def make_cfg(config):
@@ -84,6 +89,42 @@ class Oracle:
         self.lib.fgo_decode_batch(fmt, cfgp, data.ctypes.data, offsets.ctypes.data, n, blob.ctypes.data, total,
                                   offs.ctypes.data, threads)
         return blob[:total], offs
+
+    @staticmethod
+    def _extra(extra):
+        extra = list((extra or {}).items())
+        ks = (C.c_char_p * max(len(extra), 1))(*[k.encode() for k, _ in extra])
+        vs = (C.c_char_p * max(len(extra), 1))(*[v.encode() for _, v in extra])
+        return ks, vs, len(extra)
+
+    def gelf_encode(self, canonical: bytes, extra=None) -> bytes:
+        """GelfEncoder::encode on a canonical Ok record; extra = the output.gelf_extra table (dict)."""
+        ks, vs, n = self._extra(extra)
+        need = self.lib.fgo_gelf_encode(canonical, len(canonical), ks, vs, n, None, 0)
+        assert need >= 0, "not an Ok record"
+        buf = C.create_string_buffer(int(need) + 1)
+        self.lib.fgo_gelf_encode(canonical, len(canonical), ks, vs, n, buf, need)
+        return buf.raw[:need]
+
+    def decode_encode_gelf_batch(self, fmt: int, data: np.ndarray, offsets: np.ndarray, config=None, extra=None):
+        data = np.ascontiguousarray(data, np.uint8)
+        offsets = np.ascontiguousarray(offsets, np.uint64)
+        n = len(offsets) - 1
+        cfg, keep = self.make_cfg(config)
+        cfgp = C.byref(cfg) if cfg is not None else None
+        ks, vs, ne = self._extra(extra)
+        offs = np.zeros(n + 1, np.uint64)
+        total = self.lib.fgo_decode_encode_gelf_batch(fmt, cfgp, data.ctypes.data, offsets.ctypes.data, n, ks, vs, ne, None, 0,
+                                                      offs.ctypes.data)
+        blob = np.zeros(max(int(total), 1), np.uint8)
+        self.lib.fgo_decode_encode_gelf_batch(fmt, cfgp, data.ctypes.data, offsets.ctypes.data, n, ks, vs, ne, blob.ctypes.data,
+                                              total, offs.ctypes.data)
+        return blob[:int(total)], offs
+
+    def dtoa(self, v: float) -> str:
+        buf = C.create_string_buffer(64)
+        n = self.lib.fgo_dtoa(v, buf, 64)
+        return buf.raw[:n].decode()
 
     def bench(self, fmt: int, data: np.ndarray, offsets: np.ndarray, threads: int, config=None):
         cfg, keep = self.make_cfg(config)
