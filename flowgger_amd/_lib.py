@@ -45,6 +45,10 @@ TABLE_FIELDS = ["meta", "ts", "hostname", "appname", "procid", "msgid", "msg", "
                 "ent_count", "ent_name", "ent_val", "ent_type", "ent_flags", "ent_used"]
 
 
+class fg_gelf_extra(C.Structure):
+    _fields_ = [("n", C.c_uint32), ("keys", C.POINTER(C.c_char_p)), ("values", C.POINTER(C.c_char_p))]
+
+
 class fg_cfg(C.Structure):
     _fields_ = [
         ("n_schema", C.c_uint32),
@@ -91,6 +95,8 @@ def lib() -> C.CDLL:
     L.fg_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.fg_frame_decode_batch.argtypes = [vp, C.c_int, C.c_int, vp, u64, C.c_int, C.POINTER(fg_tables), C.POINTER(vp),
                                         C.POINTER(u64), C.POINTER(u64)]
+    L.fg_encode_gelf_device.argtypes = [vp, C.c_int, vp, u64, vp, u64, C.POINTER(fg_tables), C.POINTER(fg_gelf_extra), vp, u64, vp,
+                                        C.POINTER(u64), vp]
     L.fg_alloc_pinned.argtypes = [u64, C.POINTER(vp)]
     L.fg_free_pinned.argtypes = [vp]
     L.fg_free_pinned.restype = None

@@ -9,6 +9,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <new>
 #include <string>
 #include <vector>
@@ -33,6 +34,23 @@ extern "C" int fg_launch_rfc5424(const uint8_t* d_bytes, const uint64_t* d_offse
                                  uint64_t avg_len, hipStream_t stream, uint64_t* stash, uint32_t stash_blocks, uint32_t strip,
                                  const uint8_t* line_bad);
 extern "C" uint64_t fg_stash_bytes(uint32_t blocks);
+namespace fg {
+// must match fg_encode.hip
+struct StaticKey {
+    uint32_t key_off, key_len, kind, val_off, val_len;
+};
+struct EncCfg {
+    const uint8_t* blob;
+    const StaticKey* keys;
+    uint32_t n_keys;
+    uint32_t suf_off[4], suf_len[4];
+    uint32_t src_fmt;
+};
+}  // namespace fg
+extern "C" int fg_launch_gelf_encode_sizes(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
+                                           const fg::EncCfg* cfg, uint32_t* d_sizes, uint64_t* d_out_offsets, hipStream_t stream);
+extern "C" int fg_launch_gelf_encode_write(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
+                                           const fg::EncCfg* cfg, const uint64_t* d_out_offsets, uint8_t* d_out, hipStream_t stream);
 extern "C" uint64_t fg_frame_scratch_bytes(uint64_t nbytes);
 extern "C" int fg_launch_frame(const uint8_t* d_bytes, uint64_t nbytes, uint32_t delim, uint8_t* scratch, uint64_t* d_offsets,
                                uint8_t* d_bad, uint64_t cap, uint64_t** d_total_out, hipStream_t stream);
@@ -68,6 +86,8 @@ struct fg_ctx {
     uint64_t d_bad_cap = 0;
     uint64_t* h_off = nullptr;   // fg_frame_decode_batch: pinned host copy of the frame offsets
     uint64_t h_off_cap = 0;
+    uint8_t* d_enc = nullptr;    // fg_encode_gelf_device: static key list + blob, then the per-line sizes
+    uint64_t d_enc_cap = 0;
     fg::LtsvDevCfg ltsv{};
     // staging for fg_decode_batch
     uint8_t* d_bytes = nullptr;
@@ -356,6 +376,7 @@ void fg_destroy(fg_ctx* ctx) {
     if (ctx->d_stash) (void)hipFree(ctx->d_stash);
     if (ctx->d_frame) (void)hipFree(ctx->d_frame);
     if (ctx->d_bad) (void)hipFree(ctx->d_bad);
+    if (ctx->d_enc) (void)hipFree(ctx->d_enc);
     if (ctx->h_off) (void)hipHostFree(ctx->h_off);
     if (ctx->h_tab) (void)hipHostFree(ctx->h_tab);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
@@ -696,6 +717,90 @@ int fg_frame_decode_batch(fg_ctx* ctx, fg_format fmt, fg_framing framing, const 
         *out = ht;
         return FG_OK;
     }
+}
+
+int fg_encode_gelf_device(fg_ctx* ctx, fg_format src_fmt, const uint8_t* d_bytes, uint64_t nbytes, const uint64_t* d_offsets,
+                          uint64_t n, const fg_tables* tables, const fg_gelf_extra* extra, uint8_t* d_out, uint64_t out_cap,
+                          uint64_t* d_out_offsets, uint64_t* total, void* stream) {
+    (void)nbytes;
+    if (!ctx || !tables || !d_out_offsets || !total || (n && (!d_offsets || !tables->meta))) return FG_ERR_ARG;
+    if (src_fmt != FG_RFC5424 && src_fmt != FG_LTSV) return FG_ERR_UNSUPPORTED;  // GELF-sourced spans hold JSON escapes (v1)
+    if (tables->n < n) return FG_ERR_ARG;
+    DeviceGuard g(ctx->device);
+    hipStream_t s = stream == FG_STREAM_OWN ? ctx->stream : (hipStream_t)stream;
+    *total = 0;
+    // ---- the static part of every object: nine fixed keys, replaced / extended by output.gelf_extra (inserted last,
+    //      gelf_encoder.rs:107-109), in BTreeMap (byte) order ------------------------------------------------------------
+    struct Ent {
+        uint32_t kind;
+        std::string val;
+    };
+    std::map<std::string, Ent> m;
+    const char* fixed[9] = {"application_name", "full_message", "host", "level", "process_id", "sd_id", "short_message", "timestamp", "version"};
+    for (uint32_t k = 0; k < 9; ++k) m[fixed[k]] = Ent{k, ""};
+    if (extra)
+        for (uint32_t i = 0; i < extra->n; ++i) {
+            if (!extra->keys || !extra->values || !extra->keys[i] || !extra->values[i]) return FG_ERR_ARG;
+            m[extra->keys[i]] = Ent{9u, extra->values[i]};
+        }
+    std::vector<uint8_t> blob;
+    std::vector<fg::StaticKey> keys;
+    for (const auto& kv : m) {
+        fg::StaticKey k{};
+        k.key_off = (uint32_t)blob.size();
+        k.key_len = (uint32_t)kv.first.size();
+        blob.insert(blob.end(), kv.first.begin(), kv.first.end());
+        k.kind = kv.second.kind;
+        k.val_off = (uint32_t)blob.size();
+        k.val_len = (uint32_t)kv.second.val.size();
+        blob.insert(blob.end(), kv.second.val.begin(), kv.second.val.end());
+        keys.push_back(k);
+    }
+    fg::EncCfg cfg{};
+    for (int k = 0; k < 4; ++k) {
+        cfg.suf_off[k] = (uint32_t)blob.size();
+        cfg.suf_len[k] = ctx->has_suffix[k] ? (uint32_t)ctx->suffix[k].size() : 0xFFFFFFFFu;
+        blob.insert(blob.end(), ctx->suffix[k].begin(), ctx->suffix[k].end());
+    }
+    cfg.src_fmt = (uint32_t)src_fmt;
+    cfg.n_keys = (uint32_t)keys.size();
+    const uint64_t keys_bytes = up(keys.size() * sizeof(fg::StaticKey), 256), blob_bytes = up(blob.size() + 16, 256);
+    int rc;
+    if ((rc = grow_dev(ctx, (void**)&ctx->d_enc, &ctx->d_enc_cap, keys_bytes + blob_bytes + up(n * 4 + 4, 256))) != FG_OK) return rc;
+    std::vector<uint8_t> host(keys_bytes + blob_bytes, 0);
+    memcpy(host.data(), keys.data(), keys.size() * sizeof(fg::StaticKey));
+    memcpy(host.data() + keys_bytes, blob.data(), blob.size());
+    // (synchronous copy of a few hundred bytes: `host` goes out of scope at return)
+    FG_HIP(ctx, hipMemcpyAsync(ctx->d_enc, host.data(), host.size(), hipMemcpyHostToDevice, s));
+    FG_HIP(ctx, hipStreamSynchronize(s));
+    cfg.keys = reinterpret_cast<const fg::StaticKey*>(ctx->d_enc);
+    cfg.blob = ctx->d_enc + keys_bytes;
+    uint32_t* d_sizes = reinterpret_cast<uint32_t*>(ctx->d_enc + keys_bytes + blob_bytes);
+    fg::DevTables dt = to_dev(*tables);
+    if (n == 0) {
+        FG_HIP(ctx, hipMemsetAsync(d_out_offsets, 0, 8, s));
+        return FG_OK;
+    }
+    int lrc = fg_launch_gelf_encode_sizes(d_bytes, d_offsets, n, &dt, &cfg, d_sizes, d_out_offsets, s);
+    if (lrc != 0) {
+        ctx->last_hip = lrc;
+        return FG_ERR_HIP;
+    }
+    FG_HIP(ctx, hipMemcpyAsync(total, d_out_offsets + n, 8, hipMemcpyDeviceToHost, s));
+    FG_HIP(ctx, hipStreamSynchronize(s));
+    if (!d_out) return FG_OK;  // sizing call
+    if (*total > out_cap) return FG_ERR_ENT_OVERFLOW;
+    if (ctx->timing) FG_HIP(ctx, hipEventRecord(ctx->ev0, s));
+    lrc = fg_launch_gelf_encode_write(d_bytes, d_offsets, n, &dt, &cfg, d_out_offsets, d_out, s);
+    if (lrc != 0) {
+        ctx->last_hip = lrc;
+        return FG_ERR_HIP;
+    }
+    if (ctx->timing) {
+        FG_HIP(ctx, hipEventRecord(ctx->ev1, s));
+        ctx->ev_valid = true;
+    }
+    return FG_OK;
 }
 
 const char* fg_error_string(fg_format fmt, uint8_t status) {

@@ -1,0 +1,375 @@
+// fg_dtoa.hpp -- f64 -> text exactly as the `dtoa` crate (0.2 / 0.4, what serde_json 0.8 uses for
+// Value::F64) prints it: Florian Loitsch's Grisu2 as implemented in rapidjson (DiyFp, the 87-entry
+// cached-power table, DigitGen with GrisuRound) + rapidjson's Prettify (decimal notation for
+// 1e-6 <= v < 1e21, "d.ddde[-]x" otherwise, ".0" after integral values).  Host + device; checked
+// on the CPU against the oracle's independent restatement and Python's float parser
+// (tests/test_encoder_cpu.py).
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define FGD_HD __host__ __device__ __forceinline__
+#else
+#define FGD_HD inline
+#endif
+
+namespace fg {
+namespace dtoa {
+
+struct DiyFp {
+    uint64_t f;
+    int e;
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FGD_TABLE static __device__ const
+#else
+#define FGD_TABLE static const
+#endif
+FGD_TABLE uint64_t kCachedF[87] = {
+    0xfa8fd5a0081c0288ull,
+    0xbaaee17fa23ebf76ull,
+    0x8b16fb203055ac76ull,
+    0xcf42894a5dce35eaull,
+    0x9a6bb0aa55653b2dull,
+    0xe61acf033d1a45dfull,
+    0xab70fe17c79ac6caull,
+    0xff77b1fcbebcdc4full,
+    0xbe5691ef416bd60cull,
+    0x8dd01fad907ffc3cull,
+    0xd3515c2831559a83ull,
+    0x9d71ac8fada6c9b5ull,
+    0xea9c227723ee8bcbull,
+    0xaecc49914078536dull,
+    0x823c12795db6ce57ull,
+    0xc21094364dfb5637ull,
+    0x9096ea6f3848984full,
+    0xd77485cb25823ac7ull,
+    0xa086cfcd97bf97f4ull,
+    0xef340a98172aace5ull,
+    0xb23867fb2a35b28eull,
+    0x84c8d4dfd2c63f3bull,
+    0xc5dd44271ad3cdbaull,
+    0x936b9fcebb25c996ull,
+    0xdbac6c247d62a584ull,
+    0xa3ab66580d5fdaf6ull,
+    0xf3e2f893dec3f126ull,
+    0xb5b5ada8aaff80b8ull,
+    0x87625f056c7c4a8bull,
+    0xc9bcff6034c13053ull,
+    0x964e858c91ba2655ull,
+    0xdff9772470297ebdull,
+    0xa6dfbd9fb8e5b88full,
+    0xf8a95fcf88747d94ull,
+    0xb94470938fa89bcfull,
+    0x8a08f0f8bf0f156bull,
+    0xcdb02555653131b6ull,
+    0x993fe2c6d07b7facull,
+    0xe45c10c42a2b3b06ull,
+    0xaa242499697392d3ull,
+    0xfd87b5f28300ca0eull,
+    0xbce5086492111aebull,
+    0x8cbccc096f5088ccull,
+    0xd1b71758e219652cull,
+    0x9c40000000000000ull,
+    0xe8d4a51000000000ull,
+    0xad78ebc5ac620000ull,
+    0x813f3978f8940984ull,
+    0xc097ce7bc90715b3ull,
+    0x8f7e32ce7bea5c70ull,
+    0xd5d238a4abe98068ull,
+    0x9f4f2726179a2245ull,
+    0xed63a231d4c4fb27ull,
+    0xb0de65388cc8ada8ull,
+    0x83c7088e1aab65dbull,
+    0xc45d1df942711d9aull,
+    0x924d692ca61be758ull,
+    0xda01ee641a708deaull,
+    0xa26da3999aef774aull,
+    0xf209787bb47d6b85ull,
+    0xb454e4a179dd1877ull,
+    0x865b86925b9bc5c2ull,
+    0xc83553c5c8965d3dull,
+    0x952ab45cfa97a0b3ull,
+    0xde469fbd99a05fe3ull,
+    0xa59bc234db398c25ull,
+    0xf6c69a72a3989f5cull,
+    0xb7dcbf5354e9beceull,
+    0x88fcf317f22241e2ull,
+    0xcc20ce9bd35c78a5ull,
+    0x98165af37b2153dfull,
+    0xe2a0b5dc971f303aull,
+    0xa8d9d1535ce3b396ull,
+    0xfb9b7cd9a4a7443cull,
+    0xbb764c4ca7a44410ull,
+    0x8bab8eefb6409c1aull,
+    0xd01fef10a657842cull,
+    0x9b10a4e5e9913129ull,
+    0xe7109bfba19c0c9dull,
+    0xac2820d9623bf429ull,
+    0x80444b5e7aa7cf85ull,
+    0xbf21e44003acdd2dull,
+    0x8e679c2f5e44ff8full,
+    0xd433179d9c8cb841ull,
+    0x9e19db92b4e31ba9ull,
+    0xeb96bf6ebadf77d9ull,
+    0xaf87023b9bf0ee6bull
+};
+FGD_TABLE int16_t kCachedE[87] = {
+    -1220,
+    -1193,
+    -1166,
+    -1140,
+    -1113,
+    -1087,
+    -1060,
+    -1034,
+    -1007,
+    -980,
+    -954,
+    -927,
+    -901,
+    -874,
+    -847,
+    -821,
+    -794,
+    -768,
+    -741,
+    -715,
+    -688,
+    -661,
+    -635,
+    -608,
+    -582,
+    -555,
+    -529,
+    -502,
+    -475,
+    -449,
+    -422,
+    -396,
+    -369,
+    -343,
+    -316,
+    -289,
+    -263,
+    -236,
+    -210,
+    -183,
+    -157,
+    -130,
+    -103,
+    -77,
+    -50,
+    -24,
+    3,
+    30,
+    56,
+    83,
+    109,
+    136,
+    162,
+    189,
+    216,
+    242,
+    269,
+    295,
+    322,
+    348,
+    375,
+    402,
+    428,
+    455,
+    481,
+    508,
+    534,
+    561,
+    588,
+    614,
+    641,
+    667,
+    694,
+    720,
+    747,
+    774,
+    800,
+    827,
+    853,
+    880,
+    907,
+    933,
+    960,
+    986,
+    1013,
+    1039,
+    1066
+};
+FGD_TABLE uint32_t kPow10[10] = {1, 10, 100, 1000, 10000, 100000, 1000000, 10000000, 100000000, 1000000000};
+#undef FGD_TABLE
+
+FGD_HD uint64_t mulhi_round(uint64_t a, uint64_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint64_t h = __umul64hi(a, b), l = a * b;
+#else
+    const unsigned __int128 p = (unsigned __int128)a * b;
+    const uint64_t h = (uint64_t)(p >> 64), l = (uint64_t)p;
+#endif
+    return h + (l >> 63);
+}
+FGD_HD DiyFp mul(DiyFp a, DiyFp b) { return DiyFp{mulhi_round(a.f, b.f), a.e + b.e + 64}; }
+
+FGD_HD void grisu_round(char* buf, int len, uint64_t delta, uint64_t rest, uint64_t ten_kappa, uint64_t wp_w) {
+    while (rest < wp_w && delta - rest >= ten_kappa && (rest + ten_kappa < wp_w || wp_w - rest > rest + ten_kappa - wp_w)) {
+        --buf[len - 1];
+        rest += ten_kappa;
+    }
+}
+FGD_HD int count_digits32(uint32_t n) {
+    int c = 1;
+    c += n >= 10u;
+    c += n >= 100u;
+    c += n >= 1000u;
+    c += n >= 10000u;
+    c += n >= 100000u;
+    c += n >= 1000000u;
+    c += n >= 10000000u;
+    c += n >= 100000000u;
+    c += n >= 1000000000u;
+    return c;
+}
+FGD_HD void digit_gen(DiyFp W, DiyFp Mp, uint64_t delta, char* buf, int* len, int* K) {
+    const int sh = -Mp.e;
+    const uint64_t one_f = 1ull << sh;
+    const uint64_t wp_w = Mp.f - W.f;
+    uint32_t p1 = (uint32_t)(Mp.f >> sh);
+    uint64_t p2 = Mp.f & (one_f - 1);
+    int kappa = count_digits32(p1);
+    *len = 0;
+    while (kappa > 0) {
+        const uint32_t div = kPow10[kappa - 1];
+        const uint32_t d = p1 / div;
+        p1 -= d * div;
+        if (d || *len) buf[(*len)++] = (char)('0' + d);
+        --kappa;
+        const uint64_t tmp = ((uint64_t)p1 << sh) + p2;
+        if (tmp <= delta) {
+            *K += kappa;
+            grisu_round(buf, *len, delta, tmp, (uint64_t)kPow10[kappa] << sh, wp_w);
+            return;
+        }
+    }
+    for (;;) {
+        p2 *= 10;
+        delta *= 10;
+        const char d = (char)(p2 >> sh);
+        if (d || *len) buf[(*len)++] = (char)('0' + d);
+        p2 &= one_f - 1;
+        --kappa;
+        if (p2 < delta) {
+            *K += kappa;
+            const int index = -kappa;
+            grisu_round(buf, *len, delta, p2, one_f, wp_w * (index < 9 ? kPow10[index] : 0u));
+            return;
+        }
+    }
+}
+FGD_HD void grisu2(double value, char* buf, int* len, int* K) {
+    uint64_t u;
+    memcpy(&u, &value, 8);
+    const int biased = (int)((u >> 52) & 0x7FFu);
+    const uint64_t frac = u & ((1ull << 52) - 1);
+    const DiyFp v = biased ? DiyFp{frac + (1ull << 52), biased - 1075} : DiyFp{frac, -1074};
+    DiyFp pl{(v.f << 1) + 1, v.e - 1};
+    while (!(pl.f & (1ull << 53))) {
+        pl.f <<= 1;
+        --pl.e;
+    }
+    pl.f <<= 10;
+    pl.e -= 10;
+    DiyFp mi = (v.f == (1ull << 52)) ? DiyFp{(v.f << 2) - 1, v.e - 2} : DiyFp{(v.f << 1) - 1, v.e - 1};
+    mi.f <<= mi.e - pl.e;
+    mi.e = pl.e;
+    // cached power for pl.e
+    const double dk = (-61 - pl.e) * 0.30102999566398114 + 347;
+    int k = (int)dk;
+    if (dk - k > 0.0) ++k;
+    const unsigned index = (unsigned)((k >> 3) + 1);
+    *K = -(-348 + (int)(index << 3));
+    const DiyFp c_mk{kCachedF[index], (int)kCachedE[index]};
+    const int s = __builtin_clzll(v.f);
+    const DiyFp W = mul(DiyFp{v.f << s, v.e - s}, c_mk);
+    DiyFp Wp = mul(pl, c_mk);
+    DiyFp Wm = mul(mi, c_mk);
+    ++Wm.f;
+    --Wp.f;
+    digit_gen(W, Wp, Wp.f - Wm.f, buf, len, K);
+}
+FGD_HD int write_exp(int K, char* p) {
+    int n = 0;
+    if (K < 0) {
+        p[n++] = '-';
+        K = -K;
+    }
+    if (K >= 100) {
+        p[n++] = (char)('0' + K / 100);
+        K %= 100;
+        p[n++] = (char)('0' + K / 10);
+        p[n++] = (char)('0' + K % 10);
+    } else if (K >= 10) {
+        p[n++] = (char)('0' + K / 10);
+        p[n++] = (char)('0' + K % 10);
+    } else {
+        p[n++] = (char)('0' + K);
+    }
+    return n;
+}
+// value must be finite.  Writes at most 26 characters into out, returns the count.
+FGD_HD int write(double value, char* out) {
+    int n = 0;
+    uint64_t u;
+    memcpy(&u, &value, 8);
+    if (u >> 63) {
+        out[n++] = '-';
+        value = -value;
+    }
+    if ((u << 1) == 0) {  // +-0.0
+        out[n++] = '0';
+        out[n++] = '.';
+        out[n++] = '0';
+        return n;
+    }
+    char d[20];
+    int len = 0, k = 0;
+    grisu2(value, d, &len, &k);
+    const int kk = len + k;  // 10^(kk-1) <= v < 10^kk
+    if (0 <= k && kk <= 21) {  // 1234e7 -> 12340000000.0
+        for (int i = 0; i < len; ++i) out[n++] = d[i];
+        for (int i = 0; i < k; ++i) out[n++] = '0';
+        out[n++] = '.';
+        out[n++] = '0';
+    } else if (0 < kk && kk <= 21) {  // 1234e-2 -> 12.34
+        for (int i = 0; i < kk; ++i) out[n++] = d[i];
+        out[n++] = '.';
+        for (int i = kk; i < len; ++i) out[n++] = d[i];
+    } else if (-6 < kk && kk <= 0) {  // 1234e-6 -> 0.001234
+        out[n++] = '0';
+        out[n++] = '.';
+        for (int i = 0; i < -kk; ++i) out[n++] = '0';
+        for (int i = 0; i < len; ++i) out[n++] = d[i];
+    } else if (len == 1) {  // 1e30
+        out[n++] = d[0];
+        out[n++] = 'e';
+        n += write_exp(kk - 1, out + n);
+    } else {  // 1234e30 -> 1.234e33
+        out[n++] = d[0];
+        out[n++] = '.';
+        for (int i = 1; i < len; ++i) out[n++] = d[i];
+        out[n++] = 'e';
+        n += write_exp(kk - 1, out + n);
+    }
+    return n;
+}
+
+}  // namespace dtoa
+}  // namespace fg

@@ -167,6 +167,30 @@ class Decoder:
         offsets = np.ctypeslib.as_array(C.cast(off, C.POINTER(C.c_uint64)), (nf + 1,)).copy()
         return HostTables.from_struct(st), offsets, int(used.value)
 
+    # -- GELF encoder from the tables ------------------------------------------------
+    def encode_gelf_device(self, d_bytes, d_offsets, n: int, tables: DeviceTables, extra: Optional[dict] = None, stream=None):
+        """GelfEncoder::encode (encoder/gelf_encoder.rs:59-115) for every decoded line of `tables`, on the
+        GPU, without materialising Records.  `extra` = the output.gelf_extra table.  Returns
+        (d_out uint8, d_out_offsets int64[n+1]): JSON of line i = d_out[off[i]:off[i+1]] (empty for a
+        line whose decode failed)."""
+        import torch
+
+        if stream is None:
+            stream = torch.cuda.current_stream(d_bytes.device)
+        items = list((extra or {}).items())
+        ks = (C.c_char_p * max(len(items), 1))(*[k.encode() for k, _ in items])
+        vs = (C.c_char_p * max(len(items), 1))(*[v.encode() for _, v in items])
+        ex = L.fg_gelf_extra(len(items), C.cast(ks, C.POINTER(C.c_char_p)), C.cast(vs, C.POINTER(C.c_char_p)))
+        d_off = torch.empty(n + 1, dtype=torch.int64, device=d_bytes.device)
+        total = C.c_uint64()
+        args = (self._ctx, self.fmt, d_bytes.data_ptr(), d_bytes.numel(), d_offsets.data_ptr(), n, C.byref(tables.struct), C.byref(ex))
+        L.check(L.lib().fg_encode_gelf_device(*args, None, 0, d_off.data_ptr(), C.byref(total), C.c_void_p(stream.cuda_stream)),
+                "fg_encode_gelf_device (size)")
+        d_out = torch.empty(max(int(total.value), 1), dtype=torch.uint8, device=d_bytes.device)
+        L.check(L.lib().fg_encode_gelf_device(*args, d_out.data_ptr(), d_out.numel(), d_off.data_ptr(), C.byref(total),
+                                              C.c_void_p(stream.cuda_stream)), "fg_encode_gelf_device")
+        return d_out[:int(total.value)], d_off
+
     def set_timing(self, enabled: bool = True) -> None:
         L.check(L.lib().fg_set_timing(self._ctx, int(enabled)), "fg_set_timing")
 

@@ -212,6 +212,27 @@ int fg_frame_decode_batch(fg_ctx* ctx, fg_format fmt, fg_framing framing, const 
                           uint64_t nbytes, int final, fg_tables* out, const uint64_t** out_offsets,
                           uint64_t* n_frames, uint64_t* consumed);
 
+/* GELF ENCODER FROM THE TABLES: replaces GelfEncoder::encode (src/flowgger/encoder/
+ * gelf_encoder.rs:59-115, serde_json 0.8 serialisation of the BTreeMap it builds) for a whole
+ * decoded batch, without materialising Records: the JSON text of line i is written to
+ * d_out[out_offsets[i] .. out_offsets[i+1]); a line whose decode failed (status != 0) produces
+ * nothing.  `extra` = the output.gelf_extra table (may be NULL); the LTSV suffixes come from ctx.
+ *   d_out_offsets  out, n + 1 entries (device)
+ *   total          out (host): bytes needed; the call synchronises the stream to read it
+ *   d_out == NULL  sizing call (only d_out_offsets / *total are produced);
+ *   *total > out_cap -> FG_ERR_ENT_OVERFLOW, nothing written.
+ * src_fmt says which decoder produced `tables`; FG_RFC5424 and FG_LTSV in this version
+ * (FG_GELF -> FG_ERR_UNSUPPORTED). */
+typedef struct fg_gelf_extra {
+    uint32_t n;
+    const char* const* keys;
+    const char* const* values;
+} fg_gelf_extra;
+int fg_encode_gelf_device(fg_ctx* ctx, fg_format src_fmt, const uint8_t* d_bytes, uint64_t nbytes,
+                          const uint64_t* d_offsets, uint64_t n, const fg_tables* tables,
+                          const fg_gelf_extra* extra, uint8_t* d_out, uint64_t out_cap,
+                          uint64_t* d_out_offsets, uint64_t* total, void* stream);
+
 /* Page-locked host memory for the framer's batch buffers (bytes, offsets). */
 int fg_alloc_pinned(uint64_t bytes, void** out);
 void fg_free_pinned(void* p);

@@ -104,3 +104,34 @@ def test_dtoa_text(oracle):
         shortest += (float(t) == float(r)) and (len(t.replace(".0", "").replace("e", "").replace("-", "").replace(".", "").lstrip("0"))
                                                  <= len(r.replace(".0", "").replace("e", "").replace("-", "").replace("+", "").replace(".", "").lstrip("0")) + 2)
     assert shortest > 0.99 * n
+
+
+def test_kernel_dtoa_header_equals_oracle_dtoa(oracle):
+    """fg_dtoa.hpp (host build of what the encoder kernel runs) == the oracle's restatement, on plausible
+    timestamps, typed values, powers of ten and random bit patterns."""
+    import ctypes as C
+    import subprocess
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    src, lib = root / "tests/native/dtoa_host.cpp", root / "tests/native/libdtoa_host.so"
+    hdr = root / "flowgger_amd/csrc/fg_dtoa.hpp"
+    if not lib.exists() or lib.stat().st_mtime < max(src.stat().st_mtime, hdr.stat().st_mtime):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fno-fast-math", "-o", str(lib), str(src)], check=True)
+    L = C.CDLL(str(lib))
+    rng = np.random.default_rng(9)
+    vals = np.concatenate([
+        rng.integers(0, 4102444800, 60000) + rng.integers(0, 10 ** 9, 60000) / 1e9,
+        rng.integers(-10 ** 6, 10 ** 6, 20000) / 10.0 ** rng.integers(0, 8, 20000),
+        10.0 ** rng.integers(-320, 308, 20000) * rng.random(20000),
+        np.frombuffer(rng.bytes(8 * 60000), np.float64),
+        np.array([0.0, -0.0, 1.0, 1e21, 1e-7, 5e-324, 1.7976931348623157e308, 123.456, 1385053862.3072, 2.0 ** 63, 2.0 ** 64])])
+    vals = np.ascontiguousarray(vals[np.isfinite(vals)], np.float64)
+    buf = C.create_string_buffer(32 * len(vals))
+    L.fgd_write_batch(vals.ctypes.data_as(C.POINTER(C.c_double)), C.c_uint64(len(vals)), buf)
+    raw = buf.raw
+    for i in range(0, len(vals), 1):
+        got = raw[32 * i:32 * i + 32].split(b"\0")[0].decode()
+        if i % 7 == 0 or i >= len(vals) - 11:
+            assert got == oracle.dtoa(float(vals[i])), (float(vals[i]), got, oracle.dtoa(float(vals[i])))
+        assert float(got) == float(vals[i])

@@ -646,3 +646,45 @@ def test_frame_decode_batch_chunked_stream(rfc, oracle):
             continue
         assert blob == oblob[int(ooffs[j]):int(ooffs[j + 1])].tobytes(), r[2][:60]
         j += 1
+
+
+# ---------------------------------------------------------------------------------------------
+# GELF encoder from the tables: GelfEncoder::encode, gelf_encoder.rs:59-115
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("src,extra", [
+    ("rfc5424", None), ("rfc5424_sd", {"secret-token": "secret"}),
+    ("rfc5424_sd", {"_k1_b": "replaced by gelf_extra", "host": "forced", "Zeta": "capital sorts first", "_a": "x\"y\\z\n\x01"}),
+    ("ltsv", {"zz": "last", "_counter_u64": "shadow"}), ("long_tail", None)])
+def test_gelf_encoder_matches_the_reference_pipeline(rfc, oracle, src, extra):
+    """decode on the GPU -> encode on the GPU == the oracle's decode -> GelfEncoder::encode, byte for byte,
+    for every line (sorted keys, later inserts win, gelf_extra last, escapes, Grisu2 timestamps)."""
+    import torch
+
+    if src == "ltsv":
+        dec, fmt, cfg, lines = LTSVDecoder(synth.LTSV_CONFIG), LTSV, synth.LTSV_CONFIG, synth.ltsv_lines(20_000)
+    elif src == "rfc5424":
+        dec, fmt, cfg, lines = rfc, RFC5424, None, synth.rfc5424_lines(30_000, cfg=2)
+    elif src == "long_tail":
+        dec, fmt, cfg, lines = rfc, RFC5424, None, synth.rfc5424_lines(6_000, cfg=5, sd=True, long_tail=True)
+    else:
+        dec, fmt, cfg = rfc, RFC5424, None
+        lines = synth.rfc5424_lines(20_000, cfg=4, sd=True)
+        hdr = b"<13>1 2015-08-05T15:53:45.637824Z host app 1234 ID7 "
+        lines += [hdr + b'[a x="1" x="2" y="3"][b x="4" request_id="r1" request_ip="r2" request_i="r3"] dup keys and 7-byte prefix ties',
+                  hdr + b'[big ' + b" ".join(b'k%02d="v%d"' % (99 - i, i) for i in range(40)) + b"] more than 32 pairs",
+                  hdr + b'[e esc="a\\"b\\\\c\\]d\\qe" ctl="tab\there"] escapes',
+                  b"<13>1 2015-08-05T15:53:45Z - - - - - ", b"<191>1 1999-12-31T23:59:59.999999999+14:00  a  p m - no host"]
+    data, offsets = synth.pack(lines)
+    tables, d_bytes, d_offsets = device_path(dec, data, offsets)
+    d_out, d_off = dec.encode_gelf_device(d_bytes, d_offsets, len(lines), tables, extra)
+    torch.cuda.synchronize()
+    out, off = d_out.cpu().numpy(), d_off.cpu().numpy()
+    oblob, ooffs = oracle.decode_encode_gelf_batch(fmt, data, offsets, cfg, extra)
+    assert int(off[-1]) == int(ooffs[-1]), (int(off[-1]), int(ooffs[-1]))
+    bad = np.flatnonzero(off.astype(np.uint64) != ooffs)
+    assert len(bad) == 0, (int(bad[0]), lines[int(bad[0]) - 1][:120])
+    if not np.array_equal(out, oblob):
+        i = int(np.searchsorted(ooffs, np.flatnonzero(out != oblob)[0], side="right") - 1)
+        a, b = out[int(off[i]):int(off[i + 1])].tobytes(), oblob[int(ooffs[i]):int(ooffs[i + 1])].tobytes()
+        raise AssertionError(f"line {i}: {lines[i][:100]!r}\n  gpu    {a!r}\n  oracle {b!r}")
+    assert (np.diff(ooffs.astype(np.int64)) > 0).sum() > 0.9 * len(lines)
