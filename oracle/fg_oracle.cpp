@@ -33,10 +33,12 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
+#include <charconv>
 #include <optional>
 #include <string>
 #include <string_view>
@@ -1469,6 +1471,237 @@ std::string gelf_encode(const Record& r, const std::vector<std::pair<std::string
     out.push_back('}');
     return out;
 }
+// ---------------------------------------------------------------------------------------
+// The other encoders and the mergers.
+// ---------------------------------------------------------------------------------------
+// Rust `impl Display for f64` ({} / to_string()): shortest round-trip digits (libstdc++'s
+// std::to_chars = Ryu gives the same digit string as core's Grisu3 + Dragon4: shortest, then
+// closest), laid out by core::fmt::float::float_to_decimal_display -> digits_to_dec_str with
+// frac_digits = 0: never an exponent, no ".0" for integral values, "NaN", "inf", "-0".
+std::string rust_display_f64(double v) {
+    if (std::isnan(v)) return "NaN";
+    std::string out;
+    if (std::signbit(v)) out.push_back('-');
+    v = std::fabs(v);
+    if (std::isinf(v)) return out + "inf";
+    if (v == 0.0) return out + "0";
+    char b[64];
+    auto r = std::to_chars(b, b + 64, v, std::chars_format::scientific);
+    std::string t(b, r.ptr);  // d[.ddd]e[+-]xx
+    size_t e = t.find('e');
+    std::string digits;
+    for (size_t i = 0; i < e; ++i)
+        if (t[i] != '.') digits.push_back(t[i]);
+    int exp10 = atoi(t.c_str() + e + 1) + 1;  // value = 0.digits * 10^exp10
+    int nd = (int)digits.size();
+    if (exp10 <= 0) return out + "0." + std::string((size_t)-exp10, '0') + digits;
+    if (exp10 < nd) return out + digits.substr(0, (size_t)exp10) + "." + digits.substr((size_t)exp10);
+    return out + digits + std::string((size_t)(exp10 - nd), '0');
+}
+std::string sdvalue_display(const SDValue& v) {
+    switch (v.type) {
+        case FGO_T_STRING: return v.s;
+        case FGO_T_BOOL: return v.bits ? "true" : "false";
+        case FGO_T_F64: {
+            double d;
+            memcpy(&d, &v.bits, 8);
+            return rust_display_f64(d);
+        }
+        case FGO_T_I64: return std::to_string((int64_t)v.bits);
+        case FGO_T_U64: return std::to_string(v.bits);
+        default: return "";
+    }
+}
+// impl fmt::Display for StructuredData (record.rs:42-67)
+std::string sd_display(const StructuredData& sd) {
+    std::string out = "[";
+    if (sd.sd_id) out += *sd.sd_id;
+    for (const auto& kv : sd.pairs) {
+        sv name = kv.first;
+        if (!name.empty() && name[0] == '_') name.remove_prefix(1);
+        out.push_back(' ');
+        out += name;
+        if (kv.second.type != FGO_T_NULL) {
+            out += "=\"";
+            out += sdvalue_display(kv.second);
+            out.push_back('"');
+        }
+    }
+    out.push_back(']');
+    return out;
+}
+const char* const kMonthShort[12] = {"Jan", "Feb", "Mar", "Apr", "May", "Jun", "Jul", "Aug", "Sep", "Oct", "Nov", "Dec"};
+// OffsetDateTime::from_unix_timestamp[_nanos] range (time 0.3 without `large-dates`): years -9999..=9999
+constexpr int64_t kMinUnix = -377705116800ll, kMaxUnix = 253402300799ll;
+inline __int128 f64_as_i128(double x) {  // Rust `as i128`: truncating, saturating, NaN -> 0
+    if (std::isnan(x)) return 0;
+    const __int128 mx = (__int128)(((unsigned __int128)1 << 127) - 1);
+    if (x >= 170141183460469231731687303715884105728.0) return mx;
+    if (x <= -170141183460469231731687303715884105728.0) return -mx - 1;
+    return (__int128)x;
+}
+inline int64_t f64_as_i64(double x) {  // Rust `as i64`
+    if (std::isnan(x)) return 0;
+    if (x >= 9223372036854775808.0) return INT64_MAX;
+    if (x <= -9223372036854775808.0) return INT64_MIN;
+    return (int64_t)x;
+}
+void pad(std::string* o, int v, int w) {
+    char b[16];
+    snprintf(b, sizeof b, "%0*d", w, v);
+    *o += b;
+}
+struct EncOpts {
+    std::vector<std::pair<std::string, std::string>> extra;  // output.gelf_extra / output.ltsv_extra, in the table's order
+    std::string prepend;  // build_prepend_ts(output.syslog_prepend_timestamp) evaluated by the caller (wall clock)
+    bool has_prepend = false;
+    double now_ts = 0.0;  // Record.ts of a GELF record without "timestamp" (gelf_decoder.rs:109, wall clock)
+};
+// encoder/rfc5424_encoder.rs:28-93
+const char* rfc5424_encode(const Record& r, const EncOpts&, std::string* res) {
+    if (r.facility && r.severity) {
+        uint8_t npri = (uint8_t)((uint8_t)((uint8_t)(*r.facility << 3) & 0xF8) + (*r.severity & 0x7));
+        *res += "<" + std::to_string(npri) + ">";
+    } else {
+        *res += "<13>";
+    }
+    *res += "1 ";
+    // ((ts * 1000.0) as i128) * 1_000_000 -- release-mode (wrapping) multiplication
+    const __int128 ts_ns = (__int128)((unsigned __int128)f64_as_i128(r.ts * 1000.0) * 1000000u);
+    __int128 secs = ts_ns / 1000000000;
+    __int128 nanos = ts_ns % 1000000000;
+    if (nanos < 0) { nanos += 1000000000; secs -= 1; }
+    if (secs < kMinUnix || secs > kMaxUnix) return "Failed to parse date";
+    int64_t s64 = (int64_t)secs;
+    int64_t days = s64 >= 0 ? s64 / 86400 : -((-s64 + 86399) / 86400);
+    int64_t sod = s64 - days * 86400;
+    int y, m, d;
+    civil_from_days(days, &y, &m, &d);
+    if (y < 0 || y > 9999) return "Failed to parse date as Rfc3339 format";
+    pad(res, y, 4); res->push_back('-'); pad(res, m, 2); res->push_back('-'); pad(res, d, 2); res->push_back('T');
+    pad(res, (int)(sod / 3600), 2); res->push_back(':'); pad(res, (int)(sod / 60 % 60), 2); res->push_back(':'); pad(res, (int)(sod % 60), 2);
+    if (nanos != 0) {  // time 0.3 Rfc3339: '.' + the nanoseconds without trailing zeros
+        char b[16];
+        snprintf(b, sizeof b, "%09d", (int)nanos);
+        std::string f = b;
+        while (!f.empty() && f.back() == '0') f.pop_back();
+        *res += "." + f;
+    }
+    *res += "Z ";
+    *res += r.hostname;
+    res->push_back(' ');
+    if (r.appname) { *res += *r.appname; res->push_back(' '); }
+    *res += r.procid ? *r.procid : std::string("-");
+    res->push_back(' ');
+    *res += r.msgid ? *r.msgid : std::string("-");
+    res->push_back(' ');
+    if (r.sd) {
+        for (const auto& sd : *r.sd) *res += sd_display(sd);
+        res->push_back(' ');
+    } else {
+        *res += "- ";
+    }
+    if (r.msg) *res += *r.msg;
+    return nullptr;
+}
+// encoder/rfc3164_encoder.rs:28-101
+const char* rfc3164_encode(const Record& r, const EncOpts& o, std::string* res) {
+    if (o.has_prepend) *res += o.prepend;
+    if (r.facility && r.severity) {
+        uint8_t npri = (uint8_t)((uint8_t)((uint8_t)(*r.facility << 3) & 0xF8) + (*r.severity & 0x7));
+        *res += "<" + std::to_string(npri) + ">";
+    }
+    const int64_t s64 = f64_as_i64(r.ts);
+    if (s64 < kMinUnix || s64 > kMaxUnix) return "Failed to parse unix timestamp in RFC3164 encoder";
+    int64_t days = s64 >= 0 ? s64 / 86400 : -((-s64 + 86399) / 86400);
+    int64_t sod = s64 - days * 86400;
+    int y, m, d;
+    civil_from_days(days, &y, &m, &d);
+    // "[month repr:short]  [day padding:none] [hour]:[minute]:[second] "
+    *res += kMonthShort[m - 1];
+    *res += "  ";
+    *res += std::to_string(d);
+    res->push_back(' ');
+    pad(res, (int)(sod / 3600), 2); res->push_back(':'); pad(res, (int)(sod / 60 % 60), 2); res->push_back(':'); pad(res, (int)(sod % 60), 2);
+    res->push_back(' ');
+    *res += r.hostname;
+    res->push_back(' ');
+    if (r.appname) *res += *r.appname;
+    if (r.procid) *res += "[" + *r.procid + "]: ";
+    if (r.msgid) { *res += *r.msgid; res->push_back(' '); }
+    if (r.sd) {
+        for (const auto& sd : *r.sd) *res += sd_display(sd);
+        res->push_back(' ');
+    }
+    if (r.msg) *res += *r.msg;
+    return nullptr;
+}
+// encoder/passthrough_encoder.rs:24-50
+const char* passthrough_encode(const Record& r, const EncOpts& o, std::string* res) {
+    if (!r.full_msg) return "Cannot output empty raw message";
+    if (o.has_prepend) *res += o.prepend;
+    *res += *r.full_msg;
+    return nullptr;
+}
+// encoder/ltsv_encoder.rs:33-125
+void ltsv_insert(std::string* out, sv key, sv value) {
+    if (!out->empty()) out->push_back('\t');
+    for (char c : key) out->push_back(c == '\n' || c == '\t' ? ' ' : c == ':' ? '_' : c);
+    out->push_back(':');
+    for (char c : value) out->push_back(c == '\n' || c == '\t' ? ' ' : c);
+}
+const char* ltsv_encode(const Record& r, const EncOpts& o, std::string* res) {
+    auto strip = [](sv name) { if (!name.empty() && name[0] == '_') name.remove_prefix(1); return name; };
+    if (r.sd)
+        for (const auto& sd : *r.sd)
+            for (const auto& kv : sd.pairs) ltsv_insert(res, strip(kv.first), sdvalue_display(kv.second));
+    for (const auto& kv : o.extra) ltsv_insert(res, strip(kv.first), kv.second);
+    ltsv_insert(res, "host", r.hostname);
+    ltsv_insert(res, "time", rust_display_f64(r.ts));
+    if (r.msg) ltsv_insert(res, "message", *r.msg);
+    if (r.full_msg) ltsv_insert(res, "full_message", *r.full_msg);
+    if (r.severity) ltsv_insert(res, "level", std::to_string(*r.severity));
+    if (r.facility) ltsv_insert(res, "facility", std::to_string(*r.facility));
+    if (r.appname) ltsv_insert(res, "appname", *r.appname);
+    if (r.procid) ltsv_insert(res, "procid", *r.procid);
+    if (r.msgid) ltsv_insert(res, "msgid", *r.msgid);
+    return nullptr;
+}
+// merger/{line,nul,syslen}_merger.rs
+void merge_frame(int merger, std::string* b) {
+    switch (merger) {
+        case FGO_MERGE_LINE: b->push_back('\n'); break;
+        case FGO_MERGE_NUL: b->push_back('\0'); break;
+        case FGO_MERGE_SYSLEN: *b = std::to_string(b->size() + 1) + " " + *b + "\n"; break;
+        default: break;
+    }
+}
+// encoder + merger for one record; nullptr = Ok
+const char* encode_any(int enc, int merger, Record r, const EncOpts& o, std::string* out) {
+    out->clear();
+    if (r.ts_now) { r.ts = o.now_ts; r.ts_now = false; }
+    const char* err = nullptr;
+    switch (enc) {
+        case FGO_ENC_GELF: *out = gelf_encode(r, o.extra); break;
+        case FGO_ENC_LTSV: err = ltsv_encode(r, o, out); break;
+        case FGO_ENC_RFC5424: err = rfc5424_encode(r, o, out); break;
+        case FGO_ENC_RFC3164: err = rfc3164_encode(r, o, out); break;
+        case FGO_ENC_PASSTHROUGH: err = passthrough_encode(r, o, out); break;
+        default: err = "unknown encoder";
+    }
+    if (err) { out->clear(); return err; }
+    merge_frame(merger, out);
+    return nullptr;
+}
+EncOpts make_opts(const fgo_enc_opts* o) {
+    EncOpts e;
+    if (!o) return e;
+    for (uint32_t i = 0; i < o->n_extra; ++i) e.extra.emplace_back(o->extra_keys[i], o->extra_vals[i]);
+    if (o->prepend) { e.prepend = o->prepend; e.has_prepend = true; }
+    e.now_ts = o->now_ts;
+    return e;
+}
+
 // canonical serialisation -> Record (Ok results only)
 bool parse_canonical(const uint8_t* p, uint64_t n, Record* r) {
     uint64_t i = 0;
@@ -1636,6 +1869,55 @@ int64_t fgo_decode_encode_gelf_batch(int fmt, const fgo_ltsv_cfg* cfg, const uin
     }
     if (out_offsets) out_offsets[n] = total;
     return (int64_t)total;
+}
+// Any encoder + merger on a canonical Ok record.  Returns the output length (even when > cap), -1 = not an
+// Ok record, -2 = the encoder returned Err (*err receives the reference's &'static str).
+int64_t fgo_encode(int enc, int merger, const uint8_t* canonical, uint64_t len, const fgo_enc_opts* opts, uint8_t* out,
+                   uint64_t cap, const char** err) {
+    Record r;
+    if (err) *err = nullptr;
+    if (!parse_canonical(canonical, len, &r)) return -1;
+    std::string j;
+    const char* e = encode_any(enc, merger, std::move(r), make_opts(opts), &j);
+    if (e) {
+        if (err) *err = e;
+        return -2;
+    }
+    if (out && j.size() <= cap) memcpy(out, j.data(), j.size());
+    return (int64_t)j.size();
+}
+// decode -> encode -> frame for n packed lines: what handle_line + the output's merger do per line
+// (line_splitter.rs:44-54).  A line whose decode or encode fails produces nothing; status[i] (may be NULL)
+// = 0 Ok, 1 decode failed, 2 encode failed.
+int64_t fgo_decode_encode_batch(int fmt, const fgo_ltsv_cfg* cfg, int enc, int merger, const uint8_t* bytes,
+                                const uint64_t* offsets, uint64_t n, const fgo_enc_opts* opts, uint8_t* out, uint64_t cap,
+                                uint64_t* out_offsets, uint8_t* status) {
+    if (fmt < 0 || fmt > 2) return -1;
+    LtsvCfg c = make_cfg(cfg);
+    EncOpts o = make_opts(opts);
+    uint64_t total = 0;
+    std::string j;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (out_offsets) out_offsets[i] = total;
+        Result r = decode_any(fmt, c, sv((const char*)bytes + offsets[i], offsets[i + 1] - offsets[i]));
+        if (r.err) {
+            if (status) status[i] = 1;
+            continue;
+        }
+        const char* e = encode_any(enc, merger, std::move(r.rec), o, &j);
+        if (status) status[i] = e ? 2 : 0;
+        if (e) continue;
+        if (out && total + j.size() <= cap) memcpy(out + total, j.data(), j.size());
+        total += j.size();
+    }
+    if (out_offsets) out_offsets[n] = total;
+    return (int64_t)total;
+}
+int fgo_rust_display_f64(double v, char* out, int cap) {
+    std::string s = rust_display_f64(v);
+    if ((int)s.size() + 1 > cap) return -1;
+    memcpy(out, s.c_str(), s.size() + 1);
+    return (int)s.size();
 }
 int fgo_dtoa(double v, char* out, int cap) {
     std::string s = dtoa_text(v);

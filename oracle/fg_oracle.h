@@ -79,6 +79,27 @@ int64_t fgo_decode_encode_gelf_batch(int fmt, const fgo_ltsv_cfg* cfg, const uin
                                      uint64_t cap, uint64_t* out_offsets);
 int fgo_dtoa(double v, char* out, int cap); /* the dtoa crate's text for an f64 */
 
+/* The other encoders (encoder/{ltsv,rfc5424,rfc3164,passthrough}_encoder.rs) and the mergers
+ * (merger/{line,nul,syslen}_merger.rs).  prepend = the already formatted output.syslog_prepend_timestamp
+ * header (wall clock in the reference; NULL = not configured); now_ts = Record.ts of GELF records
+ * decoded without a "timestamp" member (wall clock in the reference). extra_* = output.gelf_extra /
+ * output.ltsv_extra in the configuration table's iteration order (BTreeMap: sorted by key). */
+enum { FGO_ENC_GELF = 0, FGO_ENC_LTSV = 1, FGO_ENC_RFC5424 = 2, FGO_ENC_RFC3164 = 3, FGO_ENC_PASSTHROUGH = 4 };
+enum { FGO_MERGE_NONE = 0, FGO_MERGE_LINE = 1, FGO_MERGE_NUL = 2, FGO_MERGE_SYSLEN = 3 };
+typedef struct fgo_enc_opts {
+    const char* const* extra_keys;
+    const char* const* extra_vals;
+    uint32_t n_extra;
+    const char* prepend;
+    double now_ts;
+} fgo_enc_opts;
+int64_t fgo_encode(int enc, int merger, const uint8_t* canonical, uint64_t len, const fgo_enc_opts* opts,
+                   uint8_t* out, uint64_t cap, const char** err);
+int64_t fgo_decode_encode_batch(int fmt, const fgo_ltsv_cfg* cfg, int enc, int merger, const uint8_t* bytes,
+                                const uint64_t* offsets, uint64_t n, const fgo_enc_opts* opts, uint8_t* out,
+                                uint64_t cap, uint64_t* out_offsets, uint8_t* status);
+int fgo_rust_display_f64(double v, char* out, int cap); /* Rust `{}` of an f64 */
+
 /* Exposed pieces, for unit tests of the restated std/third-party semantics. */
 int fgo_rfc3339_to_unix(const uint8_t* s, uint64_t len, double* out);  /* 1 = ok */
 int fgo_rust_parse_f64(const uint8_t* s, uint64_t len, double* out);  /* 1 = ok */

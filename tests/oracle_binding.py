@@ -14,6 +14,15 @@ RFC5424, LTSV, GELF = 0, 1, 2
 _TYPE_IDS = {"string": 0, "bool": 1, "f64": 2, "i64": 3, "u64": 4}
 
 
+ENC_GELF, ENC_LTSV, ENC_RFC5424, ENC_RFC3164, ENC_PASSTHROUGH = 0, 1, 2, 3, 4
+MERGE_NONE, MERGE_LINE, MERGE_NUL, MERGE_SYSLEN = 0, 1, 2, 3
+
+
+class fgo_enc_opts(C.Structure):
+    _fields_ = [("extra_keys", C.POINTER(C.c_char_p)), ("extra_vals", C.POINTER(C.c_char_p)), ("n_extra", C.c_uint32),
+                ("prepend", C.c_char_p), ("now_ts", C.c_double)]
+
+
 class fgo_ltsv_cfg(C.Structure):
     _fields_ = [("schema_names", C.POINTER(C.c_char_p)), ("schema_types", C.POINTER(C.c_uint8)),
                 ("n_schema", C.c_uint32), ("suffix_bool", C.c_char_p), ("suffix_f64", C.c_char_p),
@@ -46,6 +55,11 @@ class Oracle:
         L.fgo_decode_encode_gelf_batch.restype = C.c_int64
         L.fgo_decode_encode_gelf_batch.argtypes = [C.c_int, vp, vp, vp, u64, vp, vp, C.c_uint32, vp, u64, vp]
         L.fgo_dtoa.argtypes = [C.c_double, vp, C.c_int]
+        L.fgo_rust_display_f64.argtypes = [C.c_double, vp, C.c_int]
+        L.fgo_encode.restype = C.c_int64
+        L.fgo_encode.argtypes = [C.c_int, C.c_int, vp, u64, vp, vp, u64, C.POINTER(C.c_char_p)]
+        L.fgo_decode_encode_batch.restype = C.c_int64
+        L.fgo_decode_encode_batch.argtypes = [C.c_int, vp, C.c_int, C.c_int, vp, vp, u64, vp, vp, u64, vp, vp]
 
     @staticmethod
     def make_cfg(config):
@@ -120,6 +134,54 @@ class Oracle:
         self.lib.fgo_decode_encode_gelf_batch(fmt, cfgp, data.ctypes.data, offsets.ctypes.data, n, ks, vs, ne, blob.ctypes.data,
                                               total, offs.ctypes.data)
         return blob[:int(total)], offs
+
+    def _opts(self, extra=None, prepend=None, now_ts=0.0):
+        """extra: dict, passed in sorted key order (the configuration table is a BTreeMap)."""
+        items = sorted((extra or {}).items())
+        ks = (C.c_char_p * max(len(items), 1))(*[k.encode() for k, _ in items])
+        vs = (C.c_char_p * max(len(items), 1))(*[v.encode() for _, v in items])
+        o = fgo_enc_opts()
+        o.extra_keys = C.cast(ks, C.POINTER(C.c_char_p))
+        o.extra_vals = C.cast(vs, C.POINTER(C.c_char_p))
+        o.n_extra = len(items)
+        o.prepend = None if prepend is None else (prepend.encode() if isinstance(prepend, str) else prepend)
+        o.now_ts = now_ts
+        return o, (ks, vs)
+
+    def encode(self, enc: int, canonical: bytes, merger: int = 0, extra=None, prepend=None, now_ts=0.0):
+        """Encoder::encode (+ Merger::frame) on a canonical Ok record -> bytes, or the Err string (str)."""
+        o, keep = self._opts(extra, prepend, now_ts)
+        err = C.c_char_p()
+        need = self.lib.fgo_encode(enc, merger, canonical, len(canonical), C.byref(o), None, 0, C.byref(err))
+        if need == -2:
+            return err.value.decode()
+        assert need >= 0, "not an Ok record"
+        buf = C.create_string_buffer(int(need) + 1)
+        self.lib.fgo_encode(enc, merger, canonical, len(canonical), C.byref(o), buf, need, C.byref(err))
+        return buf.raw[:need]
+
+    def decode_encode_batch(self, fmt: int, enc: int, merger: int, data: np.ndarray, offsets: np.ndarray, config=None,
+                            extra=None, prepend=None, now_ts=0.0):
+        """-> (blob, out_offsets, status) ; status 0 Ok / 1 decode failed / 2 encode failed"""
+        data = np.ascontiguousarray(data, np.uint8)
+        offsets = np.ascontiguousarray(offsets, np.uint64)
+        n = len(offsets) - 1
+        cfg, keep = self.make_cfg(config)
+        cfgp = C.byref(cfg) if cfg is not None else None
+        o, keep2 = self._opts(extra, prepend, now_ts)
+        offs = np.zeros(n + 1, np.uint64)
+        st = np.zeros(max(n, 1), np.uint8)
+        total = self.lib.fgo_decode_encode_batch(fmt, cfgp, enc, merger, data.ctypes.data, offsets.ctypes.data, n, C.byref(o),
+                                                 None, 0, offs.ctypes.data, st.ctypes.data)
+        blob = np.zeros(max(int(total), 1), np.uint8)
+        self.lib.fgo_decode_encode_batch(fmt, cfgp, enc, merger, data.ctypes.data, offsets.ctypes.data, n, C.byref(o),
+                                         blob.ctypes.data, total, offs.ctypes.data, st.ctypes.data)
+        return blob[:int(total)], offs, st[:n]
+
+    def rust_display(self, v: float) -> str:
+        buf = C.create_string_buffer(512)
+        n = self.lib.fgo_rust_display_f64(v, buf, 512)
+        return buf.raw[:n].decode()
 
     def dtoa(self, v: float) -> str:
         buf = C.create_string_buffer(64)

@@ -1,0 +1,193 @@
+"""CPU: the oracle's LTSV / RFC5424 / RFC3164 / passthrough encoders and the three mergers against the
+reference's own encoder tests (encoder/{ltsv,rfc5424,rfc3164,passthrough}_encoder.rs), Rust's `{}` of an f64,
+and the kernel's shortest-digits header (fg_shortest.hpp) against libstdc++'s std::to_chars."""
+import calendar
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import oracle_binding as OB
+from test_encoder_cpu import canonical
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def ts_of(y, mo, d, h, mi, s, ms=0):
+    """utils/test_utils.rs ts_from_date_time: unix_timestamp_nanos() as f64 / 1e9"""
+    return float(calendar.timegm((y, mo, d, h, mi, s)) * 10 ** 9 + ms * 10 ** 6) / 1e9
+
+
+S = lambda v: (0, v)
+U = lambda v: (4, v)
+TS_PARTIAL = ts_of(2015, 8, 6, 11, 15, 24)  # ts_from_partial_date_time uses the current year; any year gives the same text
+PT_MSG = 'Aug  6 11:15:24 testhostname appname 69 42 [origin@123 software="te\\st sc\\"ript" swVersion="0.0.1"] test message'
+
+RFC5424_VECTORS = [
+    ("rfc5424_encoder.rs:103-125 test_rfc5424_encode",
+     dict(ts=ts_of(2015, 8, 6, 11, 15, 24, 638), hostname="testhostname", msg="some test message", full_msg="x"),
+     '<13>1 2015-08-06T11:15:24.638Z testhostname - - - some test message'),
+    ("rfc5424_encoder.rs:127-162 test_rfc5424_full_encode",
+     dict(ts=ts_of(2015, 8, 5, 15, 53, 45, 382), hostname="testhostname", facility=3, severity=1, appname="appname", procid="69",
+          msgid="42", msg="test message", full_msg="x",
+          sd=[("origin@123", [("software", S('test sc\\"ript')), ("swVersion", S("0.0.1"))])]),
+     '<25>1 2015-08-05T15:53:45.382Z testhostname appname 69 42 [origin@123 software="test sc\\"ript" swVersion="0.0.1"] test message'),
+    ("rfc5424_encoder.rs:164-206 test_rfc5424_full_encode_multiple_sd",
+     dict(ts=ts_of(2015, 8, 5, 15, 53, 45, 382), hostname="testhostname", facility=3, severity=1, appname="appname", procid="69",
+          msgid="42", msg="test message", full_msg="x",
+          sd=[("origin@123", [("software", S('test sc\\"ript')), ("swVersion", S("0.0.1"))]),
+              ("master@456", [("key1", S("value1")), ("key2", S("value2"))])]),
+     '<25>1 2015-08-05T15:53:45.382Z testhostname appname 69 42 [origin@123 software="test sc\\"ript" swVersion="0.0.1"]'
+     '[master@456 key1="value1" key2="value2"] test message'),
+]
+FULL3164 = '<23>Aug  6 11:15:24 testhostname appname[69]: 42 - some test message'
+LTSV_VECTORS = [
+    ("ltsv_encoder.rs:135-159 test_ltsv_full_encode_no_sd",
+     dict(ts=TS_PARTIAL, hostname="testhostname", facility=2, severity=7, appname="appname", procid="69", msgid="42",
+          msg="some test message", full_msg=FULL3164),
+     "host:testhostname\ttime:{ts}\tmessage:some test message\tfull_message:" + FULL3164 +
+     "\tlevel:7\tfacility:2\tappname:appname\tprocid:69\tmsgid:42"),
+    ("ltsv_encoder.rs:161-197 test_ltsv_full_encode_multiple_sd",
+     dict(ts=TS_PARTIAL, hostname="testhostname", facility=2, severity=7, appname="appname", procid="69", msgid="42",
+          msg="some test message", full_msg="F",
+          sd=[("someid", [("a", S("b")), ("c", U(123456))]), ("someid2", [("a2", S("b2")), ("c2", U(123456))])]),
+     "a:b\tc:123456\ta2:b2\tc2:123456\thost:testhostname\ttime:{ts}\tmessage:some test message\tfull_message:F"
+     "\tlevel:7\tfacility:2\tappname:appname\tprocid:69\tmsgid:42"),
+]
+MSG3164 = 'appname 69 42 [origin@123 software="te\\st sc\\"ript" swVersion="0.0.1"] test message'
+RFC3164_VECTORS = [
+    ("rfc3164_encoder.rs:110-131 test_rfc3164_encode", dict(ts=TS_PARTIAL, hostname="testhostname", msg=MSG3164, full_msg="x"), None,
+     "Aug  6 11:15:24 testhostname " + MSG3164),
+    ("rfc3164_encoder.rs:133-153 test_rfc3164_withpri_encode",
+     dict(ts=TS_PARTIAL, hostname="testhostname", facility=2, severity=7, msg=MSG3164, full_msg="x"), None,
+     "<23>Aug  6 11:15:24 testhostname " + MSG3164),
+    ("rfc3164_encoder.rs:155-189 test_rfc3164_encode_with_prepend (header string supplied by the caller)",
+     dict(ts=TS_PARTIAL, hostname="testhostname", msg=MSG3164, full_msg="x"), "2026-09-23T10:11Z",
+     "2026-09-23T10:11ZAug  6 11:15:24 testhostname " + MSG3164),
+    ("rfc3164_encoder.rs:199-224 test_rfc3164_full_encode",
+     dict(ts=TS_PARTIAL, hostname="testhostname", facility=2, severity=7, appname="appname", procid="69", msgid="42",
+          msg="some test message", full_msg="x", sd=[("someid", [("a", S("b")), ("c", U(123456))])]), None,
+     '<23>Aug  6 11:15:24 testhostname appname[69]: 42 [someid a="b" c="123456"] some test message'),
+    ("rfc3164_encoder.rs:226-265 test_rfc3164_full_encode_multiple_sd",
+     dict(ts=TS_PARTIAL, hostname="testhostname", facility=2, severity=7, appname="appname", procid="69", msgid="42",
+          msg="some test message", full_msg="x",
+          sd=[("someid", [("a", S("b")), ("c", U(123456))]), ("someid2", [("a2", S("b2")), ("c2", U(123456))])]), None,
+     '<23>Aug  6 11:15:24 testhostname appname[69]: 42 [someid a="b" c="123456"][someid2 a2="b2" c2="123456"] some test message'),
+]
+
+
+@pytest.mark.parametrize("v", RFC5424_VECTORS, ids=[v[0].split()[-1] for v in RFC5424_VECTORS])
+def test_reference_rfc5424_encoder_vectors(oracle, v):
+    assert oracle.encode(OB.ENC_RFC5424, canonical(**v[1])).decode() == v[2]
+
+
+@pytest.mark.parametrize("v", LTSV_VECTORS, ids=[v[0].split()[-1] for v in LTSV_VECTORS])
+def test_reference_ltsv_encoder_vectors(oracle, v):
+    want = v[2].format(ts=oracle.rust_display(v[1]["ts"]))
+    assert "time:1438859724\t" in want
+    assert oracle.encode(OB.ENC_LTSV, canonical(**v[1])).decode() == want
+
+
+@pytest.mark.parametrize("v", RFC3164_VECTORS, ids=[v[0].split()[1] for v in RFC3164_VECTORS])
+def test_reference_rfc3164_encoder_vectors(oracle, v):
+    assert oracle.encode(OB.ENC_RFC3164, canonical(**v[1]), prepend=v[2]).decode() == v[3]
+
+
+def test_reference_passthrough_encoder_vectors(oracle):
+    rec = dict(ts=1.2, hostname="abcd", msg="test message", full_msg=PT_MSG)
+    assert oracle.encode(OB.ENC_PASSTHROUGH, canonical(**rec)).decode() == PT_MSG  # passthrough_encoder.rs:53-76
+    hdr = "[2026-09-23T10:11Z"  # :78-113 (the header is the wall clock: supplied by the caller)
+    assert oracle.encode(OB.ENC_PASSTHROUGH, canonical(**rec), prepend=hdr).decode() == hdr + PT_MSG
+    rec["full_msg"] = None  # :124-143
+    assert oracle.encode(OB.ENC_PASSTHROUGH, canonical(**rec)) == "Cannot output empty raw message"
+
+
+def test_structured_data_display(oracle):
+    """record.rs:93-114 test_structured_data_display, through the RFC5424 encoder's SD section"""
+    rec = dict(ts=0.0, hostname="h", msg="m",
+               sd=[("someid", [("a", S("a string")), ("b", U(123456)), ("c", (1, True)), ("d", (2, 123.456)), ("e", (3, -123456)),
+                               ("_f", (5, None))])])
+    got = oracle.encode(OB.ENC_RFC5424, canonical(**rec)).decode()
+    assert got == '<13>1 1970-01-01T00:00:00Z h - - [someid a="a string" b="123456" c="true" d="123.456" e="-123456" f] m'
+
+
+def test_mergers(oracle):
+    """merger/{line,nul,syslen}_merger.rs"""
+    rec = canonical(ts=1.2, hostname="abcd", full_msg="hello")
+    assert oracle.encode(OB.ENC_PASSTHROUGH, rec, OB.MERGE_NONE) == b"hello"
+    assert oracle.encode(OB.ENC_PASSTHROUGH, rec, OB.MERGE_LINE) == b"hello\n"
+    assert oracle.encode(OB.ENC_PASSTHROUGH, rec, OB.MERGE_NUL) == b"hello\0"
+    assert oracle.encode(OB.ENC_PASSTHROUGH, rec, OB.MERGE_SYSLEN) == b"6 hello\n"
+    long = canonical(ts=1.2, hostname="abcd", full_msg="x" * 1234)
+    assert oracle.encode(OB.ENC_PASSTHROUGH, long, OB.MERGE_SYSLEN) == b"1235 " + b"x" * 1234 + b"\n"
+
+
+def test_encoder_edges(oracle):
+    # LTSV escaping (ltsv_encoder.rs:41-58), '_' stripping, Null -> "", extras in table order with '_' stripped
+    rec = canonical(ts=-0.5, hostname="h\tx", msg="a\nb:c", sd=[(None, [("_k:1\t2\n3", S("v\t1\n2:3")), ("__u", (5, None)), ("n", (2, 1e21)),
+                                                                     ("_b", (1, False)), ("_i", (3, -7))])])
+    got = oracle.encode(OB.ENC_LTSV, rec, extra={"_x": "1", "a:b": "t\tt"}).decode()
+    assert got == "k_1 2 3:v 1 2:3\t_u:\tn:1000000000000000000000\tb:false\ti:-7\tx:1\ta_b:t t\thost:h x\ttime:-0.5\tmessage:a b:c"
+    # RFC5424: ms truncation toward zero, sub-millisecond digits dropped, trailing zeros of the fraction trimmed
+    for ts, want in [(1438859724.6389, "2015-08-06T11:15:24.638Z"), (1438859724.5, "2015-08-06T11:15:24.5Z"),
+                     (1438859724.25, "2015-08-06T11:15:24.25Z"), (-0.5, "1969-12-31T23:59:59.5Z"), (-0.0004, "1970-01-01T00:00:00Z"),
+                     (253402300799.999, "9999-12-31T23:59:59.999Z"), (-62167219200.0, "0000-01-01T00:00:00Z"),
+                     (float("nan"), "1970-01-01T00:00:00Z"), (float("inf"), "1969-12-31T23:59:59.999Z")]:
+        got = oracle.encode(OB.ENC_RFC5424, canonical(ts=ts, hostname="h", msg="m")).decode()
+        assert got == f"<13>1 {want} h - - - m", (ts, got)
+    assert oracle.encode(OB.ENC_RFC5424, canonical(ts=253402300800.0, hostname="h")) == "Failed to parse date"
+    assert oracle.encode(OB.ENC_RFC5424, canonical(ts=-62167219201.0, hostname="h")) == "Failed to parse date as Rfc3339 format"
+    assert oracle.encode(OB.ENC_RFC5424, canonical(ts=-377705116801.0, hostname="h")) == "Failed to parse date"
+    assert oracle.encode(OB.ENC_RFC5424, canonical(ts=1e25, hostname="h")) == "Failed to parse date"
+    # saturated i128 * 1_000_000 wraps in a release build (no overflow checks): i128::MAX -> -1_000_000 ns
+    assert oracle.encode(OB.ENC_RFC5424, canonical(ts=1e300, hostname="h", msg="m")).decode() == "<13>1 1969-12-31T23:59:59.999Z h - - - m"
+    # priority arithmetic ((f << 3) & 0xF8) + (s & 7) in u8; facility without severity -> default
+    assert oracle.encode(OB.ENC_RFC5424, canonical(ts=0.0, hostname="h", facility=31, severity=7)).decode().startswith("<255>1 ")
+    assert oracle.encode(OB.ENC_RFC5424, canonical(ts=0.0, hostname="h", facility=3)).decode().startswith("<13>1 ")
+    # RFC3164: seconds truncated, two spaces before an unpadded day, appname without a separator
+    got = oracle.encode(OB.ENC_RFC3164, canonical(ts=ts_of(2024, 2, 29, 23, 59, 59, 999), hostname="h", appname="app", msg="m")).decode()
+    assert got == "Feb  29 23:59:59 h appm"
+    assert oracle.encode(OB.ENC_RFC3164, canonical(ts=1e300, hostname="h")) == "Failed to parse unix timestamp in RFC3164 encoder"
+
+
+def test_rust_display_f64(oracle):
+    for v, want in [(1438790025.637824, "1438790025.637824"), (1.0, "1"), (0.0, "0"), (-0.0, "-0"), (123.456, "123.456"), (1e21, "1" + "0" * 21),
+                    (1e-7, "0.0000001"), (float("nan"), "NaN"), (float("inf"), "inf"), (float("-inf"), "-inf"), (0.1, "0.1"), (1.5, "1.5"),
+                    (2.0 ** 63, "9223372036854776000"), (5e-324, "0." + "0" * 323 + "5"), (1e23, "1" + "0" * 23)]:
+        assert oracle.rust_display(v) == want, (v, oracle.rust_display(v))
+    rng = np.random.default_rng(3)
+    for v in np.concatenate([np.frombuffer(rng.bytes(8 * 5000), np.float64), rng.integers(0, 2 ** 40, 2000) / 1e6]):
+        v = float(v)
+        if v == v and abs(v) != float("inf"):
+            t = oracle.rust_display(v)
+            assert float(t) == v and "e" not in t
+            assert len(t.replace("-", "").replace(".", "").strip("0")) <= len(repr(v).split("e")[0].replace("-", "").replace(".", "").strip("0"))
+
+
+def _shortest_lib():
+    src, lib = ROOT / "tests/native/shortest_host.cpp", ROOT / "tests/native/libshortest_host.so"
+    hdrs = [ROOT / "flowgger_amd/csrc/fg_shortest.hpp", ROOT / "flowgger_amd/csrc/fg_shortest_table.inc"]
+    if not lib.exists() or lib.stat().st_mtime < max(p.stat().st_mtime for p in [src] + hdrs):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fno-fast-math", "-o", str(lib), str(src)], check=True)
+    L = C.CDLL(str(lib))
+    L.fgs_selftest.restype = C.c_uint64
+    L.fgs_selftest.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_double)]
+    L.fgs_display.argtypes = [C.c_double, C.c_char_p, C.c_int]
+    return L
+
+
+def test_kernel_shortest_header_vs_to_chars(oracle):
+    """fg_shortest.hpp (Schubfach; the host build of what the encoder kernels run) == std::to_chars digits in Rust's layout:
+    random bit patterns, timestamps, short decimals, powers of two / subnormals (4 x 3 M values), and == the oracle."""
+    L = _shortest_lib()
+    for mode in range(4):
+        bad = C.c_double()
+        fails = L.fgs_selftest(mode, 3_000_000, 0x5eed + mode, C.byref(bad))
+        assert fails == 0, (mode, fails, bad.value)
+    buf = C.create_string_buffer(512)
+    for v in [1438790025.637824, 0.0, -0.0, 1.0, 1e21, 1e22, 1e23, 5e-324, 1.7976931348623157e308, 2.2250738585072014e-308, 0.3, 2.0 ** 53,
+              9007199254740993.0, float("nan"), float("-inf"), 123.456, 1e-7]:
+        n = L.fgs_display(v, buf, 512)
+        assert buf.raw[:n].decode() == oracle.rust_display(v)
