@@ -36,7 +36,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--tile-lines", type=int, default=1_000_000)
     ap.add_argument("--reps", type=int, default=100, help="tile replicas resident per GPU")
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5", "ltsv", "ltsv5", "frame"],
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5", "ltsv", "ltsv5", "frame", "cfg1"],
                     help="cfg2 = the BASELINE metric's configuration (default); the others time the remaining "
                          "kernels on their parity-test corpora (not bench lines, see DESIGN.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -55,6 +55,7 @@ WORKLOADS = {
     "ltsv": (1, "LTSV, typed schema (the LTSV half of BASELINE configs[4])"),
     "ltsv5": (1, "BASELINE configs[4] shape, LTSV half: log-uniform 64 B..8 KiB lines"),
     "frame": (0, "GPU framing + UTF-8 validation of the newline-terminated cfg2 stream (SURVEY 8f-1), then decode of the frames"),
+    "cfg1": (0, "BASELINE configs[0] pipeline on the GPU: RFC5424 decode -> GELF encoder -> line merger (SURVEY 8f-2/8f-4), cfg2 corpus"),
 }
 
 
@@ -145,8 +146,26 @@ def main():
         torch.cuda.synchronize(dev)
         frame_ms = evf[0].elapsed_time(evf[1]) / 3
 
+    encode_ms = []
+    if wl == "cfg1":
+        from flowgger_amd import GelfEncoder
+
+        enc = GelfEncoder(merger="line")
+        dec.decode_device(d_bytes, d_offsets, tables, stream)
+        e_out, e_off = enc.encode_device(dec, d_bytes, d_offsets, n, tables, stream=stream)  # sizes the output buffer
+        enc_bytes = int(e_out.numel())
+        e_buf = torch.empty(enc_bytes + 4096, dtype=torch.uint8, device=dev)
+        del e_out, e_off
+
     def step():
-        if wl == "frame":
+        if wl == "cfg1":
+            dec.decode_device(d_bytes, d_offsets, tables, stream)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            enc.encode_device(dec, d_bytes, d_offsets, n, tables, stream=stream, out=e_buf)
+            b.record(stream)
+            encode_ms.append((a, b))
+        elif wl == "frame":
             dec.decode_frames_device(raw_stream, f_off, n, tables, FL.FG_FRAME_LINE, f_bad, stream)
         else:
             dec.decode_device(d_bytes, d_offsets, tables, stream)
@@ -209,6 +228,15 @@ def main():
                 "read_only_frac": alg_read / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             },
         }
+        if wl == "cfg1":
+            ems = float(np.mean([a.elapsed_time(b) for a, b in encode_ms[-args.steps:]]))
+            out["encode"] = {"ms": ems, "out_bytes": enc_bytes, "lines_per_s": n / (ems * 1e-3),
+                             "GBps_in_plus_out": (tile_bytes * reps + 68 * n + enc_bytes) / (ems * 1e-3) / 1e9,
+                             "note": "fg_encode_device (count + scan + write kernels incl. the host sync for the total); "
+                                     "value / ms_per_step cover decode + encode; roofline.* is the decode kernel alone"}
+            out["roofline"]["kernel_ms"] = kernel_ms - ems
+            out["roofline"]["achieved"] = (alg_read + alg_written) / ((kernel_ms - ems) * 1e-3) / 1e9
+            out["roofline"]["frac"] = out["roofline"]["achieved"] / HBM_PEAK_GBPS
         if frame_ms is not None:
             out["framing"] = {"ms": frame_ms, "GBps": tile_bytes * reps / (frame_ms * 1e-3) / 1e9,
                               "note": "fg_frame_device: scan + prefix + emit kernels incl. the host sync that returns the frame count"}

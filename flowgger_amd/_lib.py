@@ -49,6 +49,15 @@ class fg_gelf_extra(C.Structure):
     _fields_ = [("n", C.c_uint32), ("keys", C.POINTER(C.c_char_p)), ("values", C.POINTER(C.c_char_p))]
 
 
+FG_ENC_GELF, FG_ENC_LTSV, FG_ENC_RFC5424, FG_ENC_RFC3164, FG_ENC_PASSTHROUGH = range(5)
+FG_MERGE_NONE, FG_MERGE_LINE, FG_MERGE_NUL, FG_MERGE_SYSLEN = range(4)
+
+
+class fg_encode_cfg(C.Structure):
+    _fields_ = [("encoder", C.c_int), ("merger", C.c_int), ("n_extra", C.c_uint32), ("extra_keys", C.POINTER(C.c_char_p)),
+                ("extra_values", C.POINTER(C.c_char_p)), ("prepend", C.c_char_p), ("now_ts", C.c_double)]
+
+
 class fg_cfg(C.Structure):
     _fields_ = [
         ("n_schema", C.c_uint32),
@@ -97,6 +106,10 @@ def lib() -> C.CDLL:
                                         C.POINTER(u64), C.POINTER(u64)]
     L.fg_encode_gelf_device.argtypes = [vp, C.c_int, vp, u64, vp, u64, C.POINTER(fg_tables), C.POINTER(fg_gelf_extra), vp, u64, vp,
                                         C.POINTER(u64), vp]
+    L.fg_encode_device.argtypes = [vp, C.c_int, C.POINTER(fg_encode_cfg), vp, u64, vp, u64, C.POINTER(fg_tables), vp, u64, vp, vp,
+                                   C.POINTER(u64), vp]
+    L.fg_encode_error_string.argtypes = [C.c_uint8]
+    L.fg_encode_error_string.restype = C.c_char_p
     L.fg_alloc_pinned.argtypes = [u64, C.POINTER(vp)]
     L.fg_free_pinned.argtypes = [vp]
     L.fg_free_pinned.restype = None

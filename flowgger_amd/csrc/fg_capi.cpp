@@ -16,6 +16,7 @@
 
 #include "../../include/fg_hip.h"
 #include "fg_device.hpp"
+#include "fg_enc_cfg.hpp"
 
 namespace fg {
 // device view of input.ltsv_schema / input.ltsv_suffixes (must match fg_ltsv.hip)
@@ -34,23 +35,11 @@ extern "C" int fg_launch_rfc5424(const uint8_t* d_bytes, const uint64_t* d_offse
                                  uint64_t avg_len, hipStream_t stream, uint64_t* stash, uint32_t stash_blocks, uint32_t strip,
                                  const uint8_t* line_bad);
 extern "C" uint64_t fg_stash_bytes(uint32_t blocks);
-namespace fg {
-// must match fg_encode.hip
-struct StaticKey {
-    uint32_t key_off, key_len, kind, val_off, val_len;
-};
-struct EncCfg {
-    const uint8_t* blob;
-    const StaticKey* keys;
-    uint32_t n_keys;
-    uint32_t suf_off[4], suf_len[4];
-    uint32_t src_fmt;
-};
-}  // namespace fg
-extern "C" int fg_launch_gelf_encode_sizes(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
-                                           const fg::EncCfg* cfg, uint32_t* d_sizes, uint64_t* d_out_offsets, hipStream_t stream);
-extern "C" int fg_launch_gelf_encode_write(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
-                                           const fg::EncCfg* cfg, const uint64_t* d_out_offsets, uint8_t* d_out, hipStream_t stream);
+extern "C" int fg_launch_encode_sizes(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
+                                      const fg::EncCfg* cfg, uint32_t* d_sizes, uint64_t* d_block_sums, uint8_t* d_status,
+                                      uint64_t* d_out_offsets, hipStream_t stream);
+extern "C" int fg_launch_encode_write(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
+                                      const fg::EncCfg* cfg, const uint64_t* d_out_offsets, uint8_t* d_out, hipStream_t stream);
 extern "C" uint64_t fg_frame_scratch_bytes(uint64_t nbytes);
 extern "C" int fg_launch_frame(const uint8_t* d_bytes, uint64_t nbytes, uint32_t delim, uint8_t* scratch, uint64_t* d_offsets,
                                uint8_t* d_bad, uint64_t cap, uint64_t** d_total_out, hipStream_t stream);
@@ -719,69 +708,39 @@ int fg_frame_decode_batch(fg_ctx* ctx, fg_format fmt, fg_framing framing, const 
     }
 }
 
-int fg_encode_gelf_device(fg_ctx* ctx, fg_format src_fmt, const uint8_t* d_bytes, uint64_t nbytes, const uint64_t* d_offsets,
-                          uint64_t n, const fg_tables* tables, const fg_gelf_extra* extra, uint8_t* d_out, uint64_t out_cap,
-                          uint64_t* d_out_offsets, uint64_t* total, void* stream) {
+int fg_encode_device(fg_ctx* ctx, fg_format src_fmt, const fg_encode_cfg* ecfg, const uint8_t* d_bytes, uint64_t nbytes,
+                     const uint64_t* d_offsets, uint64_t n, const fg_tables* tables, uint8_t* d_out, uint64_t out_cap,
+                     uint64_t* d_out_offsets, uint8_t* d_enc_status, uint64_t* total, void* stream) {
     (void)nbytes;
-    if (!ctx || !tables || !d_out_offsets || !total || (n && (!d_offsets || !tables->meta))) return FG_ERR_ARG;
-    if (src_fmt != FG_RFC5424 && src_fmt != FG_LTSV) return FG_ERR_UNSUPPORTED;  // GELF-sourced spans hold JSON escapes (v1)
+    if (!ctx || !ecfg || !tables || !d_out_offsets || !total || (n && (!d_offsets || !tables->meta))) return FG_ERR_ARG;
+    if ((int)src_fmt < 0 || (int)src_fmt > (int)FG_GELF) return FG_ERR_ARG;
     if (tables->n < n) return FG_ERR_ARG;
     DeviceGuard g(ctx->device);
     hipStream_t s = stream == FG_STREAM_OWN ? ctx->stream : (hipStream_t)stream;
     *total = 0;
-    // ---- the static part of every object: nine fixed keys, replaced / extended by output.gelf_extra (inserted last,
-    //      gelf_encoder.rs:107-109), in BTreeMap (byte) order ------------------------------------------------------------
-    struct Ent {
-        uint32_t kind;
-        std::string val;
-    };
-    std::map<std::string, Ent> m;
-    const char* fixed[9] = {"application_name", "full_message", "host", "level", "process_id", "sd_id", "short_message", "timestamp", "version"};
-    for (uint32_t k = 0; k < 9; ++k) m[fixed[k]] = Ent{k, ""};
-    if (extra)
-        for (uint32_t i = 0; i < extra->n; ++i) {
-            if (!extra->keys || !extra->values || !extra->keys[i] || !extra->values[i]) return FG_ERR_ARG;
-            m[extra->keys[i]] = Ent{9u, extra->values[i]};
-        }
-    std::vector<uint8_t> blob;
-    std::vector<fg::StaticKey> keys;
-    for (const auto& kv : m) {
-        fg::StaticKey k{};
-        k.key_off = (uint32_t)blob.size();
-        k.key_len = (uint32_t)kv.first.size();
-        blob.insert(blob.end(), kv.first.begin(), kv.first.end());
-        k.kind = kv.second.kind;
-        k.val_off = (uint32_t)blob.size();
-        k.val_len = (uint32_t)kv.second.val.size();
-        blob.insert(blob.end(), kv.second.val.begin(), kv.second.val.end());
-        keys.push_back(k);
-    }
-    fg::EncCfg cfg{};
-    for (int k = 0; k < 4; ++k) {
-        cfg.suf_off[k] = (uint32_t)blob.size();
-        cfg.suf_len[k] = ctx->has_suffix[k] ? (uint32_t)ctx->suffix[k].size() : 0xFFFFFFFFu;
-        blob.insert(blob.end(), ctx->suffix[k].begin(), ctx->suffix[k].end());
-    }
-    cfg.src_fmt = (uint32_t)src_fmt;
-    cfg.n_keys = (uint32_t)keys.size();
-    const uint64_t keys_bytes = up(keys.size() * sizeof(fg::StaticKey), 256), blob_bytes = up(blob.size() + 16, 256);
+    fg::EncCfgHost h;
+    if (!fg::build_enc_cfg(src_fmt, ecfg, ctx->suffix, ctx->has_suffix, &h)) return FG_ERR_ARG;
+    const uint64_t keys_bytes = up(h.keys.size() * sizeof(fg::StaticKey) + 16, 256), blob_bytes = up(h.blob.size() + 16, 256);
     int rc;
-    if ((rc = grow_dev(ctx, (void**)&ctx->d_enc, &ctx->d_enc_cap, keys_bytes + blob_bytes + up(n * 4 + 4, 256))) != FG_OK) return rc;
+    if ((rc = grow_dev(ctx, (void**)&ctx->d_enc, &ctx->d_enc_cap, keys_bytes + blob_bytes + up(n * 4 + 4, 256) + up((n / 64 + 2) * 8, 256))) != FG_OK) return rc;
     std::vector<uint8_t> host(keys_bytes + blob_bytes, 0);
-    memcpy(host.data(), keys.data(), keys.size() * sizeof(fg::StaticKey));
-    memcpy(host.data() + keys_bytes, blob.data(), blob.size());
+    if (!h.keys.empty()) memcpy(host.data(), h.keys.data(), h.keys.size() * sizeof(fg::StaticKey));
+    if (!h.blob.empty()) memcpy(host.data() + keys_bytes, h.blob.data(), h.blob.size());
     // (synchronous copy of a few hundred bytes: `host` goes out of scope at return)
     FG_HIP(ctx, hipMemcpyAsync(ctx->d_enc, host.data(), host.size(), hipMemcpyHostToDevice, s));
     FG_HIP(ctx, hipStreamSynchronize(s));
+    fg::EncCfg cfg = h.cfg;
     cfg.keys = reinterpret_cast<const fg::StaticKey*>(ctx->d_enc);
     cfg.blob = ctx->d_enc + keys_bytes;
     uint32_t* d_sizes = reinterpret_cast<uint32_t*>(ctx->d_enc + keys_bytes + blob_bytes);
+    uint64_t* d_block_sums = reinterpret_cast<uint64_t*>(ctx->d_enc + keys_bytes + blob_bytes + up(n * 4 + 4, 256));
     fg::DevTables dt = to_dev(*tables);
     if (n == 0) {
         FG_HIP(ctx, hipMemsetAsync(d_out_offsets, 0, 8, s));
         return FG_OK;
     }
-    int lrc = fg_launch_gelf_encode_sizes(d_bytes, d_offsets, n, &dt, &cfg, d_sizes, d_out_offsets, s);
+    if (ctx->timing) FG_HIP(ctx, hipEventRecord(ctx->ev0, s));
+    int lrc = fg_launch_encode_sizes(d_bytes, d_offsets, n, &dt, &cfg, d_sizes, d_block_sums, d_enc_status, d_out_offsets, s);
     if (lrc != 0) {
         ctx->last_hip = lrc;
         return FG_ERR_HIP;
@@ -790,17 +749,42 @@ int fg_encode_gelf_device(fg_ctx* ctx, fg_format src_fmt, const uint8_t* d_bytes
     FG_HIP(ctx, hipStreamSynchronize(s));
     if (!d_out) return FG_OK;  // sizing call
     if (*total > out_cap) return FG_ERR_ENT_OVERFLOW;
-    if (ctx->timing) FG_HIP(ctx, hipEventRecord(ctx->ev0, s));
-    lrc = fg_launch_gelf_encode_write(d_bytes, d_offsets, n, &dt, &cfg, d_out_offsets, d_out, s);
+    lrc = fg_launch_encode_write(d_bytes, d_offsets, n, &dt, &cfg, d_out_offsets, d_out, s);
     if (lrc != 0) {
         ctx->last_hip = lrc;
         return FG_ERR_HIP;
     }
-    if (ctx->timing) {
+    if (ctx->timing) {  // count + scan + write (fg_last_kernel_ms)
         FG_HIP(ctx, hipEventRecord(ctx->ev1, s));
         ctx->ev_valid = true;
     }
     return FG_OK;
+}
+
+int fg_encode_gelf_device(fg_ctx* ctx, fg_format src_fmt, const uint8_t* d_bytes, uint64_t nbytes, const uint64_t* d_offsets,
+                          uint64_t n, const fg_tables* tables, const fg_gelf_extra* extra, uint8_t* d_out, uint64_t out_cap,
+                          uint64_t* d_out_offsets, uint64_t* total, void* stream) {
+    fg_encode_cfg ec{};
+    ec.encoder = FG_ENC_GELF;
+    ec.merger = FG_MERGE_NONE;
+    if (extra) {
+        ec.n_extra = extra->n;
+        ec.extra_keys = extra->keys;
+        ec.extra_values = extra->values;
+    }
+    return fg_encode_device(ctx, src_fmt, &ec, d_bytes, nbytes, d_offsets, n, tables, d_out, out_cap, d_out_offsets, nullptr, total, stream);
+}
+
+const char* fg_encode_error_string(uint8_t st) {
+    switch (st) {
+        case fg::ES_OK:
+        case fg::ES_DECODE_FAILED: return "";
+        case fg::ES_5424_DATE: return "Failed to parse date";                                         // rfc5424_encoder.rs:46
+        case fg::ES_5424_FORMAT: return "Failed to parse date as Rfc3339 format";                     // rfc5424_encoder.rs:52
+        case fg::ES_3164_TS: return "Failed to parse unix timestamp in RFC3164 encoder";              // rfc3164_encoder.rs:53
+        case fg::ES_PASSTHROUGH_EMPTY: return "Cannot output empty raw message";                      // passthrough_encoder.rs:47
+    }
+    return nullptr;
 }
 
 const char* fg_error_string(fg_format fmt, uint8_t status) {

@@ -1,0 +1,989 @@
+// fg_emit.hpp -- the five Encoder::encode implementations + the three Merger::frame implementations, as
+// per-record emitters that read a decode-table row (spans into the packed line bytes + the entry slice)
+// and push the output bytes into a sink -- the Record is never materialised.
+//
+//   GelfEmitter         encoder/gelf_encoder.rs:59-115 (+ serde_json 0.8 serialisation of the BTreeMap)
+//   LtsvEmitter         encoder/ltsv_encoder.rs:33-125
+//   Rfc5424Emitter      encoder/rfc5424_encoder.rs:28-93  (+ impl Display for StructuredData, record.rs:42-67)
+//   Rfc3164Emitter      encoder/rfc3164_encoder.rs:28-101
+//   PassthroughEmitter  encoder/passthrough_encoder.rs:24-50
+//   frame               merger/{line,nul,syslen}_merger.rs
+//
+// A Record field is a DECODED view of a span: raw bytes (RFC5424 / LTSV sources), unescape_sd_value
+// (rfc5424_decoder.rs:105-125) for flagged RFC5424 SD values, JSON string unescaping (serde_json 0.8) for flagged
+// spans of GELF-decoded records.  `for_each_decoded` streams that view byte by byte; every emitter is written
+// against it, so the three decoders x five encoders all share one code path.
+//
+// Host + device (no HIP dependency): the kernels in fg_encode.hip instantiate the emitters with a GlobalReader and
+// a count / write sink; tests/native/emit_host.cpp instantiates the same code on the CPU against the oracle.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#include "fg_dtoa.hpp"
+#include "fg_shortest.hpp"
+#include "fg_tables_view.hpp"
+#include "fg_timeconv.hpp"
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define FGE_HD __host__ __device__ __forceinline__
+#define FGE_HD_NOINLINE __host__ __device__
+#else
+#define FGE_HD inline
+#define FGE_HD_NOINLINE inline
+#endif
+
+namespace fg {
+
+// static key list entry of the GELF encoder (host-built, sorted by key): what the value is
+enum : uint32_t { SK_APP = 0, SK_FULL = 1, SK_HOST = 2, SK_LEVEL = 3, SK_PROC = 4, SK_SDID = 5, SK_SHORT = 6, SK_TS = 7, SK_VERSION = 8, SK_EXTRA = 9 };
+struct StaticKey {
+    uint32_t key_off, key_len;  // into the blob
+    uint32_t kind;              // SK_*
+    uint32_t val_off, val_len;  // SK_EXTRA: the configured value
+};
+struct EncCfg {
+    const uint8_t* blob;       // GELF keys + extra values, LTSV suffixes, the LTSV extras text, the prepend header
+    const StaticKey* keys;     // GELF: sorted by key bytes
+    uint32_t n_keys;
+    uint32_t suf_off[4], suf_len[4];  // bool, f64, i64, u64 (len 0xFFFFFFFF = not configured)
+    uint32_t src_fmt;          // which decoder produced the tables (fg_format)
+    uint32_t enc;              // fg_encoder
+    uint32_t merger;           // fg_merger
+    uint32_t ltsv_extra_off, ltsv_extra_len;  // "k1:v1\tk2:v2" (already escaped, '_' stripped); len 0 = none
+    uint32_t prepend_off, prepend_len;        // syslog_prepend_timestamp header; len 0xFFFFFFFF = not configured
+    double now_ts;             // Record.ts of rows flagged FG_F_TS_NOW
+};
+
+// encode status per line (fg_encode_error_string)
+enum : uint32_t {
+    ES_OK = 0,
+    ES_DECODE_FAILED = 1,       // the row's decode status is an error: nothing to encode
+    ES_5424_DATE = 2,           // "Failed to parse date"                       rfc5424_encoder.rs:46
+    ES_5424_FORMAT = 3,         // "Failed to parse date as Rfc3339 format"     rfc5424_encoder.rs:52
+    ES_3164_TS = 4,             // "Failed to parse unix timestamp in RFC3164 encoder"  rfc3164_encoder.rs:53
+    ES_PASSTHROUGH_EMPTY = 5    // "Cannot output empty raw message"            passthrough_encoder.rs:47
+};
+
+namespace emit {
+
+enum : uint32_t { M_RAW = 0, M_SD = 1, M_JSON = 2, M_JSON_RETRY = 3 };
+
+FGE_HD uint32_t hexv(uint32_t c) {
+    if (c - '0' <= 9u) return c - '0';
+    c |= 0x20u;
+    if (c - 'a' <= 5u) return c - 'a' + 10u;
+    return 0;
+}
+
+// Streams the decoded bytes of rd[off .. off+len) into f(byte).
+template <class R, class F>
+FGE_HD void for_each_decoded(R& rd, uint32_t off, uint32_t len, uint32_t mode, F&& f) {
+    if (mode == M_RAW) {
+        for (uint32_t i = 0; i < len; ++i) f(rd.byte(off + i));
+    } else if (mode == M_SD) {  // unescape_sd_value: \" \\ \] lose the backslash, any other \x keeps both
+        bool esc = false;
+        for (uint32_t i = 0; i < len; ++i) {
+            const uint32_t c = rd.byte(off + i);
+            if (!esc) {
+                if (c == '\\') esc = true;
+                else f(c);
+            } else {
+                if (c != '"' && c != '\\' && c != ']') f((uint32_t)'\\');
+                f(c);
+                esc = false;
+            }
+        }
+    } else {  // JSON escapes of an already validated string body
+        const bool retry = mode == M_JSON_RETRY;
+        for (uint32_t i = 0; i < len;) {
+            const uint32_t c = rd.byte(off + i);
+            if (c != '\\' || i + 1 >= len) {
+                f(c);
+                ++i;
+                continue;
+            }
+            const uint32_t e = rd.byte(off + i + 1);
+            i += 2;
+            if (retry && e == '\n') {  // the reference replaced LF by "\\n": an escaped backslash, then 'n'
+                f((uint32_t)'\\');
+                f((uint32_t)'n');
+                continue;
+            }
+            if (e == 'b') f(8u);
+            else if (e == 'f') f(12u);
+            else if (e == 'n') f(10u);
+            else if (e == 'r') f(13u);
+            else if (e == 't') f(9u);
+            else if (e == 'u') {
+                if (i + 4 > len) continue;
+                uint32_t n1 = hexv(rd.byte(off + i)) << 12 | hexv(rd.byte(off + i + 1)) << 8 | hexv(rd.byte(off + i + 2)) << 4 | hexv(rd.byte(off + i + 3));
+                i += 4;
+                if (n1 >= 0xD800u && n1 <= 0xDBFFu && i + 6 <= len) {
+                    const uint32_t n2 = hexv(rd.byte(off + i + 2)) << 12 | hexv(rd.byte(off + i + 3)) << 8 | hexv(rd.byte(off + i + 4)) << 4 | hexv(rd.byte(off + i + 5));
+                    i += 6;
+                    n1 = (((n1 - 0xD800u) << 10) | (n2 - 0xDC00u)) + 0x10000u;
+                }
+                if (n1 < 0x80u) {
+                    f(n1);
+                } else if (n1 < 0x800u) {
+                    f(0xC0u | (n1 >> 6));
+                    f(0x80u | (n1 & 0x3Fu));
+                } else if (n1 < 0x10000u) {
+                    f(0xE0u | (n1 >> 12));
+                    f(0x80u | ((n1 >> 6) & 0x3Fu));
+                    f(0x80u | (n1 & 0x3Fu));
+                } else {
+                    f(0xF0u | (n1 >> 18));
+                    f(0x80u | ((n1 >> 12) & 0x3Fu));
+                    f(0x80u | ((n1 >> 6) & 0x3Fu));
+                    f(0x80u | (n1 & 0x3Fu));
+                }
+            } else {
+                f(e);  // " \ /
+            }
+        }
+    }
+}
+
+struct CountSink {
+    uint32_t n = 0;
+    FGE_HD void put(uint32_t) { ++n; }
+    FGE_HD void finish() {}
+};
+
+// Everything the emitters share: the row, the field views, the number formats.
+template <class S, class R>
+struct Base {
+    S& out;
+    const EncCfg& cfg;
+    R rd;  // the line's bytes
+    const DevTables& t;
+    uint64_t li;
+    uint32_t meta;
+
+    FGE_HD uint32_t flags() const { return FG_META_FLAGS(meta); }
+    FGE_HD uint32_t json_mode() const { return (flags() & FG_F_GELF_RETRY) ? (uint32_t)M_JSON_RETRY : (uint32_t)M_JSON; }
+    // decode mode of a top-level string field
+    FGE_HD uint32_t field_mode(int col) const {
+        if (cfg.src_fmt != FG_GELF) return M_RAW;
+        const uint32_t bit = col == S_HOST ? FG_F_HOST_ESC : col == S_MSG ? FG_F_MSG_ESC : col == S_FULL ? FG_F_FULLMSG_ESC : 0u;
+        return (flags() & bit) ? json_mode() : (uint32_t)M_RAW;
+    }
+    FGE_HD uint32_t value_mode(uint32_t e) const {
+        if (!(t.ent_flags[e] & FG_EF_VAL_ESC)) return M_RAW;
+        return cfg.src_fmt == FG_RFC5424 ? (uint32_t)M_SD : cfg.src_fmt == FG_GELF ? json_mode() : (uint32_t)M_RAW;
+    }
+    FGE_HD double record_ts() const { return (flags() & FG_F_TS_NOW) ? cfg.now_ts : t.ts[li]; }
+
+    FGE_HD void lit(const char* s, uint32_t n) {
+        for (uint32_t i = 0; i < n; ++i) out.put((uint32_t)(uint8_t)s[i]);
+    }
+    FGE_HD void blob(uint32_t off, uint32_t len) {
+        for (uint32_t i = 0; i < len; ++i) out.put(cfg.blob[off + i]);
+    }
+    FGE_HD void raw_field(int col) {  // a top-level field, decoded, unmodified
+        const fg_span s = t.span[col][li];
+        for_each_decoded(rd, s.off, s.len, field_mode(col), [&](uint32_t c) { out.put(c); });
+    }
+    FGE_HD void u64_text(uint64_t v) {
+        char buf[20];
+        int n = 0;
+        do {
+            buf[n++] = (char)('0' + (uint32_t)(v % 10u));
+            v /= 10u;
+        } while (v);
+        while (n) out.put((uint32_t)(uint8_t)buf[--n]);
+    }
+    FGE_HD void i64_text(int64_t x) {
+        if (x < 0) {
+            out.put('-');
+            u64_text(0ull - (uint64_t)x);
+        } else {
+            u64_text((uint64_t)x);
+        }
+    }
+    FGE_HD void pad2(uint32_t v) {
+        out.put('0' + v / 10u);
+        out.put('0' + v % 10u);
+    }
+    // <pri>: ((facility << 3) & 0xF8) + (severity & 7) in u8 arithmetic
+    FGE_HD void pri() {
+        const uint32_t npri = (((FG_META_FACILITY(meta) << 3) & 0xF8u) + (FG_META_SEVERITY(meta) & 7u)) & 0xFFu;
+        out.put('<');
+        u64_text(npri);
+        out.put('>');
+    }
+    FGE_HD bool has_pri() const { return FG_META_FACILITY(meta) != 0xFFu && FG_META_SEVERITY(meta) != 0xFFu; }
+
+    // ---- entry names: the Record key is '_' + name [+ LTSV suffix]; for GELF-decoded records the '_' is only added
+    //      when the (decoded) key does not start with one (gelf_decoder.rs:99-103) ------------------------------------
+    struct Dyn {
+        uint32_t off, len;  // raw name span
+        uint32_t mode;      // M_RAW / M_JSON*
+        uint32_t skip;      // decoded bytes to skip: 1 when a GELF key already starts with '_'
+        uint32_t dlen;      // decoded length after the skip
+        uint32_t so, sl;    // suffix in the blob (sl = 0: none)
+    };
+    FGE_HD Dyn dyn_of(uint32_t e) {
+        const fg_span nm = t.ent_name[e];
+        Dyn d{nm.off, nm.len, M_RAW, 0u, nm.len, 0u, 0u};
+        const uint32_t ty = t.ent_type[e];
+        const uint32_t ef = t.ent_flags[e];
+        if (cfg.src_fmt == FG_GELF) {
+            if (ef & FG_EF_NAME_ESC) {
+                d.mode = json_mode();
+                uint32_t n = 0, first = 0x100u;
+                for_each_decoded(rd, nm.off, nm.len, d.mode, [&](uint32_t c) {
+                    if (n == 0) first = c;
+                    ++n;
+                });
+                d.skip = first == '_' ? 1u : 0u;
+                d.dlen = n - d.skip;
+            } else if (nm.len && rd.byte(nm.off) == '_') {
+                d.skip = 1;
+                d.dlen = nm.len - 1u;
+            }
+        }
+        if ((ef & FG_EF_SUFFIX) && ty >= FG_T_BOOL && ty <= FG_T_U64 && cfg.suf_len[ty - FG_T_BOOL] != 0xFFFFFFFFu) {
+            d.so = cfg.suf_off[ty - FG_T_BOOL];
+            d.sl = cfg.suf_len[ty - FG_T_BOOL];
+        }
+        return d;
+    }
+    // streams the key WITHOUT its leading '_' (name after the skip, then the suffix)
+    template <class F>
+    FGE_HD void dyn_stream(const Dyn& d, F&& f) {
+        uint32_t k = 0;
+        for_each_decoded(rd, d.off, d.len, d.mode, [&](uint32_t c) {
+            if (k++ >= d.skip) f(c);
+        });
+        for (uint32_t i = 0; i < d.sl; ++i) f((uint32_t)cfg.blob[d.so + i]);
+    }
+    // byte k of the key WITHOUT its leading '_' (k < dlen + sl); escaped names (rare) decode from the start
+    FGE_HD uint32_t dyn_byte(const Dyn& d, uint32_t k) {
+        if (k >= d.dlen) return cfg.blob[d.so + (k - d.dlen)];
+        if (d.mode == M_RAW) return rd.byte(d.off + d.skip + k);
+        uint32_t i = 0, r = 0;
+        const uint32_t want = k + d.skip;
+        for_each_decoded(rd, d.off, d.len, d.mode, [&](uint32_t c) {
+            if (i++ == want) r = c;
+        });
+        return r;
+    }
+    // a pair's value as `{}` prints it (impl Display for SDValue's payload; Null prints nothing)
+    template <class F>
+    FGE_HD void value_display(uint32_t e, F&& f) {
+        const uint32_t ty = t.ent_type[e];
+        const uint64_t v = t.ent_val[e];
+        struct FnSink {
+            F& f;
+            FGE_HD void put(uint32_t c) { f(c); }
+        } fs{f};
+        if (ty == FG_T_STRING) {
+            for_each_decoded(rd, (uint32_t)v, (uint32_t)(v >> 32), value_mode(e), f);
+        } else if (ty == FG_T_BOOL) {
+            const char* s = v ? "true" : "false";
+            for (uint32_t i = 0; s[i]; ++i) f((uint32_t)(uint8_t)s[i]);
+        } else if (ty == FG_T_F64) {
+            double d;
+            memcpy(&d, &v, 8);
+            shortest::display_f64(d, fs);
+        } else if (ty == FG_T_I64 || ty == FG_T_U64) {
+            char buf[21];
+            int n = 0;
+            uint64_t m = v;
+            if (ty == FG_T_I64 && (int64_t)v < 0) {
+                f((uint32_t)'-');
+                m = 0ull - v;
+            }
+            do {
+                buf[n++] = (char)('0' + (uint32_t)(m % 10u));
+                m /= 10u;
+            } while (m);
+            while (n) f((uint32_t)(uint8_t)buf[--n]);
+        }
+    }
+    // every StructuredData of the record through `impl Display` (record.rs:42-67), concatenated
+    FGE_HD void sd_display() {
+        const uint32_t first = t.ent_first[li], cnt = t.ent_count[li];
+        bool open = false;
+        for (uint32_t e = first; e < first + cnt; ++e) {
+            if (t.ent_type[e] == FG_T_SDID) {
+                if (open) out.put(']');
+                out.put('[');
+                open = true;
+                const fg_span id = t.ent_name[e];
+                for (uint32_t i = 0; i < id.len; ++i) out.put(rd.byte(id.off + i));
+                continue;
+            }
+            if (!open) {  // LTSV / GELF records: one element, sd_id None
+                out.put('[');
+                open = true;
+            }
+            out.put(' ');
+            const Dyn d = dyn_of(e);
+            dyn_stream(d, [&](uint32_t c) { out.put(c); });
+            if (t.ent_type[e] != FG_T_NULL) {
+                out.put('=');
+                out.put('"');
+                value_display(e, [&](uint32_t c) { out.put(c); });
+                out.put('"');
+            }
+        }
+        if (open) out.put(']');
+    }
+    FGE_HD bool has_sd() const { return t.ent_count[li] != 0; }
+    FGE_HD bool some(int col) const { return t.span[col][li].len != FG_NONE; }
+};
+
+// =================================================================================================
+// GELF
+// =================================================================================================
+constexpr uint32_t kSortSlots = 32;
+
+template <class S, class R>
+struct GelfEmitter : Base<S, R> {
+    using B = Base<S, R>;
+    using typename B::Dyn;
+    using B::cfg;
+    using B::li;
+    using B::meta;
+    using B::out;
+    using B::rd;
+    using B::t;
+    bool first_member = true;
+
+    FGE_HD GelfEmitter(S& o, const EncCfg& c, R r, const DevTables& tb, uint64_t l, uint32_t m) : B{o, c, r, tb, l, m} {}
+
+    FGE_HD void esc_byte(uint32_t c) {  // serde_json 0.8 escape_str
+        if (c == '"' || c == '\\') {
+            out.put('\\');
+            out.put(c);
+        } else if (c >= 0x20u) {
+            out.put(c);
+        } else {
+            out.put('\\');
+            if (c == 8u) out.put('b');
+            else if (c == 9u) out.put('t');
+            else if (c == 10u) out.put('n');
+            else if (c == 12u) out.put('f');
+            else if (c == 13u) out.put('r');
+            else {
+                out.put('u');
+                out.put('0');
+                out.put('0');
+                out.put(c >> 4 ? '1' : '0');
+                const uint32_t lo = c & 15u;
+                out.put(lo < 10u ? '0' + lo : 'a' + lo - 10u);
+            }
+        }
+    }
+    FGE_HD void member_start() {
+        if (!first_member) out.put(',');
+        first_member = false;
+    }
+    FGE_HD void key_static(const StaticKey& k) {
+        member_start();
+        out.put('"');
+        for (uint32_t i = 0; i < k.key_len; ++i) esc_byte(cfg.blob[k.key_off + i]);
+        out.put('"');
+        out.put(':');
+    }
+    FGE_HD void str_field(int col) {
+        const fg_span s = t.span[col][li];
+        out.put('"');
+        for_each_decoded(rd, s.off, s.len, this->field_mode(col), [&](uint32_t c) { esc_byte(c); });
+        out.put('"');
+    }
+    FGE_HD void f64_text(double d) {
+        uint64_t b;
+        memcpy(&b, &d, 8);
+        if (((b >> 52) & 0x7FFu) == 0x7FFu) {  // NaN / inf
+            this->lit("null", 4);
+            return;
+        }
+        char buf[32];
+        const int n = dtoa::write(d, buf);
+        for (int i = 0; i < n; ++i) out.put((uint32_t)(uint8_t)buf[i]);
+    }
+    FGE_HD int cmp_dyn(const Dyn& a, const Dyn& b) {
+        const uint32_t la = a.dlen + a.sl, lb = b.dlen + b.sl, n = la < lb ? la : lb;
+        for (uint32_t k = 0; k < n; ++k) {
+            const uint32_t x = this->dyn_byte(a, k), y = this->dyn_byte(b, k);
+            if (x != y) return x < y ? -1 : 1;
+        }
+        return la == lb ? 0 : (la < lb ? -1 : 1);
+    }
+    // full key ('_' + ...) against a static key
+    FGE_HD int cmp_dyn_static(const Dyn& a, const StaticKey& s) {
+        if (s.key_len == 0) return 1;
+        const uint32_t s0 = cfg.blob[s.key_off];
+        if (s0 != '_') return '_' < s0 ? -1 : 1;
+        const uint32_t la = a.dlen + a.sl, lb = s.key_len - 1u, n = la < lb ? la : lb;
+        for (uint32_t k = 0; k < n; ++k) {
+            const uint32_t x = this->dyn_byte(a, k), y = cfg.blob[s.key_off + 1u + k];
+            if (x != y) return x < y ? -1 : 1;
+        }
+        return la == lb ? 0 : (la < lb ? -1 : 1);
+    }
+    FGE_HD void emit_dyn(uint32_t e) {
+        const Dyn d = this->dyn_of(e);
+        member_start();
+        out.put('"');
+        out.put('_');
+        this->dyn_stream(d, [&](uint32_t c) { esc_byte(c); });
+        out.put('"');
+        out.put(':');
+        const uint32_t ty = t.ent_type[e];
+        const uint64_t v = t.ent_val[e];
+        if (ty == FG_T_STRING) {
+            out.put('"');
+            for_each_decoded(rd, (uint32_t)v, (uint32_t)(v >> 32), this->value_mode(e), [&](uint32_t c) { esc_byte(c); });
+            out.put('"');
+        } else if (ty == FG_T_BOOL) {
+            if (v) this->lit("true", 4);
+            else this->lit("false", 5);
+        } else if (ty == FG_T_NULL) {
+            this->lit("null", 4);
+        } else if (ty == FG_T_U64) {
+            this->u64_text(v);
+        } else if (ty == FG_T_I64) {
+            this->i64_text((int64_t)v);
+        } else {
+            double d2;
+            memcpy(&d2, &v, 8);
+            f64_text(d2);
+        }
+    }
+    FGE_HD void emit_static(const StaticKey& k, uint32_t sdid_entry) {
+        switch (k.kind) {
+            case SK_APP: if (!this->some(S_APP)) return; break;
+            case SK_FULL: if (!this->some(S_FULL)) return; break;
+            case SK_PROC: if (!this->some(S_PROC)) return; break;
+            case SK_LEVEL: if (FG_META_SEVERITY(meta) == 0xFFu) return; break;
+            case SK_SDID: if (sdid_entry == 0xFFFFFFFFu) return; break;
+            default: break;
+        }
+        key_static(k);
+        switch (k.kind) {
+            case SK_APP: str_field(S_APP); break;
+            case SK_FULL: str_field(S_FULL); break;
+            case SK_PROC: str_field(S_PROC); break;
+            case SK_HOST: {
+                const fg_span s = t.span[S_HOST][li];
+                if (s.len == 0u || s.len == FG_NONE) {
+                    out.put('"');
+                    this->lit("unknown", 7);
+                    out.put('"');
+                } else {
+                    str_field(S_HOST);
+                }
+                break;
+            }
+            case SK_LEVEL: out.put('0' + FG_META_SEVERITY(meta)); break;
+            case SK_SDID: {
+                const fg_span id = t.ent_name[sdid_entry];
+                out.put('"');
+                for (uint32_t i = 0; i < id.len; ++i) esc_byte(rd.byte(id.off + i));
+                out.put('"');
+                break;
+            }
+            case SK_SHORT: {
+                if (!this->some(S_MSG)) {
+                    out.put('"');
+                    out.put('-');
+                    out.put('"');
+                } else {
+                    str_field(S_MSG);
+                }
+                break;
+            }
+            case SK_TS: f64_text(this->record_ts()); break;
+            case SK_VERSION:
+                out.put('"');
+                this->lit("1.1", 3);
+                out.put('"');
+                break;
+            default: {  // SK_EXTRA
+                out.put('"');
+                for (uint32_t i = 0; i < k.val_len; ++i) esc_byte(cfg.blob[k.val_off + i]);
+                out.put('"');
+            }
+        }
+    }
+
+    // keys64 / slot_ent / order: this lane's scratch (kSortSlots each)
+    FGE_HD uint32_t run(uint64_t* keys64, uint8_t* slot_ent, uint8_t* order) {
+        const uint32_t first = t.ent_first[li], cnt = t.ent_count[li];
+        // pairs -> slots (and the LAST sd_id: every element's insert replaces the previous one)
+        uint32_t sdid_entry = 0xFFFFFFFFu, np = 0;
+        bool ranked = cnt <= 255u;
+        for (uint32_t e = first; e < first + cnt; ++e) {
+            if (t.ent_type[e] == FG_T_SDID) {
+                sdid_entry = e;
+                continue;
+            }
+            if (np < kSortSlots && ranked) {
+                const Dyn d = this->dyn_of(e);
+                uint64_t pre = 0;
+                for (uint32_t k = 0; k < 7u; ++k) pre = (pre << 8) | (k < d.dlen + d.sl ? this->dyn_byte(d, k) : 0u);
+                keys64[np] = (pre << 8) | np;  // 7 key bytes big-endian, then the slot: equal keys keep insertion order
+                slot_ent[np] = (uint8_t)(e - first);
+            } else {
+                ranked = false;
+            }
+            ++np;
+        }
+        if (ranked) {
+            uint64_t k[kSortSlots];
+#pragma unroll
+            for (uint32_t j = 0; j < kSortSlots; ++j) k[j] = j < np ? keys64[j] : ~0ull;
+            for (uint32_t i = 0; i < np; ++i) {  // (k[] stays in registers: only the inner loop is unrolled)
+                const uint64_t ki = keys64[i];
+                uint32_t rank = 0;
+#pragma unroll
+                for (uint32_t j = 0; j < kSortSlots; ++j) rank += k[j] < ki ? 1u : 0u;
+                order[rank] = (uint8_t)i;
+            }
+            // adjacent equal 7-byte prefixes: duplicates (keep the later insert) or an unresolved order
+            for (uint32_t r = 0; r + 1u < np && ranked; ++r) {
+                const uint32_t sa = order[r], sb = order[r + 1u];
+                if ((keys64[sa] >> 8) != (keys64[sb] >> 8)) continue;
+                const int c = cmp_dyn(this->dyn_of(first + slot_ent[sa]), this->dyn_of(first + slot_ent[sb]));
+                if (c == 0) order[r] = 0xFFu;
+                else ranked = false;  // two different names share 7 bytes: exact selection below
+            }
+        }
+        out.put('{');
+        uint32_t sk = 0;  // next static key
+        if (ranked) {
+            for (uint32_t r = 0; r < np; ++r) {
+                if (order[r] == 0xFFu) continue;
+                const uint32_t e = first + slot_ent[order[r]];
+                const Dyn d = this->dyn_of(e);
+                bool shadowed = false;
+                while (sk < cfg.n_keys) {
+                    const int c = cmp_dyn_static(d, cfg.keys[sk]);
+                    if (c < 0) break;
+                    if (c == 0) shadowed = true;  // gelf_extra is inserted last: it replaces the pair
+                    emit_static(cfg.keys[sk], sdid_entry);
+                    ++sk;
+                }
+                if (!shadowed) emit_dyn(e);
+            }
+        } else {
+            // exact selection: repeatedly the smallest key greater than the previous one; among
+            // equal keys the LAST entry (the later insert)
+            uint32_t prev = 0xFFFFFFFFu;
+            for (;;) {
+                uint32_t best = 0xFFFFFFFFu;
+                for (uint32_t e = first; e < first + cnt; ++e) {
+                    if (t.ent_type[e] == FG_T_SDID) continue;
+                    const Dyn d = this->dyn_of(e);
+                    if (prev != 0xFFFFFFFFu && cmp_dyn(d, this->dyn_of(prev)) <= 0) continue;
+                    if (best == 0xFFFFFFFFu || cmp_dyn(d, this->dyn_of(best)) <= 0) best = e;
+                }
+                if (best == 0xFFFFFFFFu) break;
+                const Dyn d = this->dyn_of(best);
+                bool shadowed = false;
+                while (sk < cfg.n_keys) {
+                    const int c = cmp_dyn_static(d, cfg.keys[sk]);
+                    if (c < 0) break;
+                    if (c == 0) shadowed = true;
+                    emit_static(cfg.keys[sk], sdid_entry);
+                    ++sk;
+                }
+                if (!shadowed) emit_dyn(best);
+                prev = best;
+            }
+        }
+        for (; sk < cfg.n_keys; ++sk) emit_static(cfg.keys[sk], sdid_entry);
+        out.put('}');
+        return ES_OK;
+    }
+};
+
+// =================================================================================================
+// LTSV
+// =================================================================================================
+template <class S, class R>
+struct LtsvEmitter : Base<S, R> {
+    using B = Base<S, R>;
+    using B::cfg;
+    using B::li;
+    using B::meta;
+    using B::out;
+    using B::rd;
+    using B::t;
+    bool first = true;
+    FGE_HD LtsvEmitter(S& o, const EncCfg& c, R r, const DevTables& tb, uint64_t l, uint32_t m) : B{o, c, r, tb, l, m} {}
+
+    FGE_HD void key_byte(uint32_t c) { out.put(c == '\n' || c == '\t' ? (uint32_t)' ' : c == ':' ? (uint32_t)'_' : c); }
+    FGE_HD void val_byte(uint32_t c) { out.put(c == '\n' || c == '\t' ? (uint32_t)' ' : c); }
+    FGE_HD void start(const char* key, uint32_t n) {  // LTSVString::insert up to and including ':'
+        if (!first) out.put('\t');
+        first = false;
+        this->lit(key, n);
+        out.put(':');
+    }
+    FGE_HD void field(const char* key, uint32_t n, int col) {
+        start(key, n);
+        const fg_span s = t.span[col][li];
+        for_each_decoded(rd, s.off, s.len, this->field_mode(col), [&](uint32_t c) { val_byte(c); });
+    }
+    FGE_HD uint32_t run() {
+        const uint32_t ef = t.ent_first[li], cnt = t.ent_count[li];
+        for (uint32_t e = ef; e < ef + cnt; ++e) {
+            if (t.ent_type[e] == FG_T_SDID) continue;
+            if (!first) out.put('\t');
+            first = false;
+            const typename B::Dyn d = this->dyn_of(e);
+            this->dyn_stream(d, [&](uint32_t c) { key_byte(c); });
+            out.put(':');
+            this->value_display(e, [&](uint32_t c) { val_byte(c); });
+        }
+        if (cfg.ltsv_extra_len) {
+            if (!first) out.put('\t');
+            first = false;
+            this->blob(cfg.ltsv_extra_off, cfg.ltsv_extra_len);
+        }
+        start("host", 4);
+        if (this->some(S_HOST)) {
+            const fg_span s = t.span[S_HOST][li];
+            for_each_decoded(rd, s.off, s.len, this->field_mode(S_HOST), [&](uint32_t c) { val_byte(c); });
+        }
+        start("time", 4);
+        shortest::display_f64(this->record_ts(), out);
+        if (this->some(S_MSG)) field("message", 7, S_MSG);
+        if (this->some(S_FULL)) field("full_message", 12, S_FULL);
+        if (FG_META_SEVERITY(meta) != 0xFFu) {
+            start("level", 5);
+            this->u64_text(FG_META_SEVERITY(meta));
+        }
+        if (FG_META_FACILITY(meta) != 0xFFu) {
+            start("facility", 8);
+            this->u64_text(FG_META_FACILITY(meta));
+        }
+        if (this->some(S_APP)) field("appname", 7, S_APP);
+        if (this->some(S_PROC)) field("procid", 6, S_PROC);
+        if (this->some(S_MSGID)) field("msgid", 5, S_MSGID);
+        return ES_OK;
+    }
+};
+
+// =================================================================================================
+// RFC5424 / RFC3164 / passthrough
+// =================================================================================================
+constexpr int64_t kMinUnix = -377705116800ll, kMaxUnix = 253402300799ll;  // time 0.3: years -9999 ..= 9999
+
+// ((ts * 1000.0) as i128) * 1_000_000 (release build: saturating cast, wrapping multiplication), then
+// OffsetDateTime::from_unix_timestamp_nanos: false = out of range ("Failed to parse date").
+FGE_HD bool rfc5424_ts_split(double ts, int64_t* secs, uint32_t* nanos) {
+    const double x = ts * 1000.0;
+    // i128 two's complement as (hi, lo)
+    uint64_t hi, lo;
+    if (x != x) {
+        hi = lo = 0;
+    } else if (x >= 170141183460469231731687303715884105728.0) {
+        hi = 0x7FFFFFFFFFFFFFFFull;
+        lo = ~0ull;
+    } else if (x <= -170141183460469231731687303715884105728.0) {
+        hi = 0x8000000000000000ull;
+        lo = 0;
+    } else {
+        const double a = x < 0 ? -x : x;
+        uint64_t mh, ml;
+        if (a < 18446744073709551616.0) {
+            mh = 0;
+            ml = (uint64_t)a;  // truncates
+        } else {  // an integer m * 2^e with e >= 12
+            uint64_t b;
+            memcpy(&b, &a, 8);
+            const uint64_t m = (b & 0x000FFFFFFFFFFFFFull) | 0x0010000000000000ull;
+            const int sh = (int)((b >> 52) & 0x7FFu) - 1075;  // 12 .. 74
+            if (sh >= 64) {
+                mh = m << (sh - 64);
+                ml = 0;
+            } else {
+                mh = m >> (64 - sh);
+                ml = m << sh;
+            }
+        }
+        if (x < 0) {  // negate
+            ml = ~ml + 1u;
+            mh = ~mh + (ml == 0 ? 1u : 0u);
+        }
+        hi = mh;
+        lo = ml;
+    }
+    // * 1_000_000 mod 2^128
+    uint64_t ph, pl;
+    shortest::mul64(lo, 1000000u, &ph, &pl);
+    const uint64_t rh = ph + hi * 1000000u, rl = pl;
+    // the valid range needs |ns| < 2^79: hi must be a sign extension with small magnitude
+    const bool neg = (rh >> 63) != 0;
+    uint64_t ah = rh, al = rl;
+    if (neg) {
+        al = ~al + 1u;
+        ah = ~ah + (al == 0 ? 1u : 0u);
+    }
+    if (ah >= (1ull << 20)) return false;  // |ns| >= 2^84: far outside
+    // |ns| = ah * 2^64 + al with ah < 2^20  ->  seconds and nanoseconds: long division by 10^9 in two 32-bit steps
+    const uint64_t d = 1000000000ull;
+    const uint64_t c1 = (ah << 32) | (al >> 32);  // < 2^52
+    const uint64_t qh = c1 / d;                   // < 2^23
+    const uint64_t c0 = ((c1 % d) << 32) | (al & 0xFFFFFFFFull);  // < 10^9 * 2^32
+    const uint64_t q = (qh << 32) + c0 / d;       // c0 / d < 2^32
+    const uint64_t rem = c0 % d;
+    int64_t s = (int64_t)q;
+    uint32_t ns = (uint32_t)rem;
+    if (neg) {
+        s = -s;
+        if (ns) {
+            s -= 1;
+            ns = 1000000000u - ns;
+        }
+    }
+    if (s < kMinUnix || s > kMaxUnix) return false;
+    *secs = s;
+    *nanos = ns;
+    return true;
+}
+FGE_HD int64_t f64_as_i64(double x) {  // Rust `as i64`: truncating, saturating, NaN -> 0
+    if (x != x) return 0;
+    if (x >= 9223372036854775808.0) return INT64_MAX;
+    if (x <= -9223372036854775808.0) return INT64_MIN;
+    return (int64_t)x;
+}
+struct Civil {
+    int y, m, d;
+    uint32_t hh, mm, ss;
+};
+FGE_HD Civil civil_of(int64_t secs) {
+    const int64_t days = secs >= 0 ? secs / 86400 : -((-secs + 86399) / 86400);
+    const uint32_t sod = (uint32_t)(secs - days * 86400);
+    Civil c;
+    civil_from_days(days, &c.y, &c.m, &c.d);
+    c.hh = sod / 3600u;
+    c.mm = sod / 60u % 60u;
+    c.ss = sod % 60u;
+    return c;
+}
+
+template <class S, class R>
+struct Rfc5424Emitter : Base<S, R> {
+    using B = Base<S, R>;
+    using B::li;
+    using B::meta;
+    using B::out;
+    using B::t;
+    FGE_HD Rfc5424Emitter(S& o, const EncCfg& c, R r, const DevTables& tb, uint64_t l, uint32_t m) : B{o, c, r, tb, l, m} {}
+    FGE_HD uint32_t run() {
+        int64_t secs;
+        uint32_t nanos;
+        if (!rfc5424_ts_split(this->record_ts(), &secs, &nanos)) return ES_5424_DATE;
+        const Civil c = civil_of(secs);
+        if (c.y < 0 || c.y > 9999) return ES_5424_FORMAT;
+        if (this->has_pri()) this->pri();
+        else this->lit("<13>", 4);
+        out.put('1');
+        out.put(' ');
+        this->pad2((uint32_t)c.y / 100u);
+        this->pad2((uint32_t)c.y % 100u);
+        out.put('-');
+        this->pad2((uint32_t)c.m);
+        out.put('-');
+        this->pad2((uint32_t)c.d);
+        out.put('T');
+        this->pad2(c.hh);
+        out.put(':');
+        this->pad2(c.mm);
+        out.put(':');
+        this->pad2(c.ss);
+        if (nanos) {  // time 0.3 Rfc3339: '.' + the nanoseconds without trailing zeros
+            out.put('.');
+            uint32_t digs = 9, v = nanos;
+            while (v % 10u == 0) {
+                v /= 10u;
+                --digs;
+            }
+            uint32_t p = 1;
+            for (uint32_t i = 1; i < digs; ++i) p *= 10u;
+            for (; p; p /= 10u) out.put('0' + v / p % 10u);
+        }
+        out.put('Z');
+        out.put(' ');
+        if (this->some(S_HOST)) this->raw_field(S_HOST);
+        out.put(' ');
+        if (this->some(S_APP)) {
+            this->raw_field(S_APP);
+            out.put(' ');
+        }
+        if (this->some(S_PROC)) this->raw_field(S_PROC);
+        else out.put('-');
+        out.put(' ');
+        if (this->some(S_MSGID)) this->raw_field(S_MSGID);
+        else out.put('-');
+        out.put(' ');
+        if (this->has_sd()) {
+            this->sd_display();
+            out.put(' ');
+        } else {
+            out.put('-');
+            out.put(' ');
+        }
+        if (this->some(S_MSG)) this->raw_field(S_MSG);
+        return ES_OK;
+    }
+};
+
+template <class S, class R>
+struct Rfc3164Emitter : Base<S, R> {
+    using B = Base<S, R>;
+    using B::cfg;
+    using B::out;
+    FGE_HD Rfc3164Emitter(S& o, const EncCfg& c, R r, const DevTables& tb, uint64_t l, uint32_t m) : B{o, c, r, tb, l, m} {}
+    FGE_HD uint32_t run() {
+        const int64_t secs = f64_as_i64(this->record_ts());
+        if (secs < kMinUnix || secs > kMaxUnix) return ES_3164_TS;
+        if (cfg.prepend_len != 0xFFFFFFFFu) this->blob(cfg.prepend_off, cfg.prepend_len);
+        if (this->has_pri()) this->pri();
+        const Civil c = civil_of(secs);
+        // "[month repr:short]  [day padding:none] [hour]:[minute]:[second] "
+        const char* mon = "JanFebMarAprMayJunJulAugSepOctNovDec";
+        this->lit(mon + 3 * (c.m - 1), 3);
+        out.put(' ');
+        out.put(' ');
+        this->u64_text((uint64_t)c.d);
+        out.put(' ');
+        this->pad2(c.hh);
+        out.put(':');
+        this->pad2(c.mm);
+        out.put(':');
+        this->pad2(c.ss);
+        out.put(' ');
+        if (this->some(S_HOST)) this->raw_field(S_HOST);
+        out.put(' ');
+        if (this->some(S_APP)) this->raw_field(S_APP);
+        if (this->some(S_PROC)) {
+            out.put('[');
+            this->raw_field(S_PROC);
+            out.put(']');
+            out.put(':');
+            out.put(' ');
+        }
+        if (this->some(S_MSGID)) {
+            this->raw_field(S_MSGID);
+            out.put(' ');
+        }
+        if (this->has_sd()) {
+            this->sd_display();
+            out.put(' ');
+        }
+        if (this->some(S_MSG)) this->raw_field(S_MSG);
+        return ES_OK;
+    }
+};
+
+template <class S, class R>
+struct PassthroughEmitter : Base<S, R> {
+    using B = Base<S, R>;
+    using B::cfg;
+    FGE_HD PassthroughEmitter(S& o, const EncCfg& c, R r, const DevTables& tb, uint64_t l, uint32_t m) : B{o, c, r, tb, l, m} {}
+    FGE_HD uint32_t run() {
+        if (!this->some(S_FULL)) return ES_PASSTHROUGH_EMPTY;
+        if (cfg.prepend_len != 0xFFFFFFFFu) this->blob(cfg.prepend_off, cfg.prepend_len);
+        this->raw_field(S_FULL);
+        return ES_OK;
+    }
+};
+
+// ---- mergers ------------------------------------------------------------------------------------
+FGE_HD uint32_t dec_digits(uint64_t v) {
+    uint32_t n = 1;
+    while (v >= 10u) {
+        v /= 10u;
+        ++n;
+    }
+    return n;
+}
+// framed size of an encoded message of `n` bytes
+FGE_HD uint64_t framed_size(uint32_t merger, uint64_t n) {
+    switch (merger) {
+        case FG_MERGE_LINE:
+        case FG_MERGE_NUL: return n + 1u;
+        case FG_MERGE_SYSLEN: return n + 2u + dec_digits(n + 1u);  // "{n+1} " + bytes + "\n"
+        default: return n;
+    }
+}
+// the encoded size of a syslen frame of `total` bytes (framed_size is strictly increasing: unique)
+FGE_HD uint64_t syslen_payload(uint64_t total) {
+    for (uint32_t d = 1; d <= 20u; ++d) {
+        if (total < 2u + d) break;
+        const uint64_t n = total - 2u - d;
+        if (dec_digits(n + 1u) == d) return n;
+    }
+    return 0;
+}
+
+
+// ---- one row through encoder ENC (+ merger): the per-line body of the count and the write kernels, shared with the
+//      host tests.  keys64 / slot_ent / order: kSortSlots scratch entries each (used by the GELF emitter only). ------
+template <uint32_t ENC, class S, class R>
+FGE_HD uint32_t encode_row(S& sink, const EncCfg& cfg, R rd, const DevTables& t, uint64_t li, uint32_t meta, uint64_t* keys64,
+                           uint8_t* slot_ent, uint8_t* order) {
+    if (ENC == FG_ENC_GELF) {
+        GelfEmitter<S, R> em(sink, cfg, rd, t, li, meta);
+        return em.run(keys64, slot_ent, order);
+    } else if (ENC == FG_ENC_LTSV) {
+        LtsvEmitter<S, R> em(sink, cfg, rd, t, li, meta);
+        return em.run();
+    } else if (ENC == FG_ENC_RFC5424) {
+        Rfc5424Emitter<S, R> em(sink, cfg, rd, t, li, meta);
+        return em.run();
+    } else if (ENC == FG_ENC_RFC3164) {
+        Rfc3164Emitter<S, R> em(sink, cfg, rd, t, li, meta);
+        return em.run();
+    } else {
+        PassthroughEmitter<S, R> em(sink, cfg, rd, t, li, meta);
+        return em.run();
+    }
+}
+// count pass: the framed size of row li (0 when nothing is produced) and its encode status
+template <uint32_t ENC, class R>
+FGE_HD uint32_t row_size(const EncCfg& cfg, R rd, const DevTables& t, uint64_t li, uint32_t meta, uint64_t* keys64, uint8_t* slot_ent,
+                         uint8_t* order, uint32_t* status) {
+    if (FG_META_STATUS(meta) != 0u) {
+        *status = ES_DECODE_FAILED;
+        return 0;
+    }
+    CountSink cs;
+    const uint32_t st = encode_row<ENC>(cs, cfg, rd, t, li, meta, keys64, slot_ent, order);
+    *status = st;
+    return st == ES_OK ? (uint32_t)framed_size(cfg.merger, cs.n) : 0u;
+}
+// write pass: `total` = the framed size the count pass returned for this row (the sink starts at the row's offset)
+template <uint32_t ENC, class W, class R>
+FGE_HD void row_write(W& sink, uint64_t total, const EncCfg& cfg, R rd, const DevTables& t, uint64_t li, uint32_t meta, uint64_t* keys64,
+                      uint8_t* slot_ent, uint8_t* order) {
+    if (total == 0 || FG_META_STATUS(meta) != 0u) return;
+    if (cfg.merger == FG_MERGE_SYSLEN) {  // "{len + 1} " in front (syslen_merger.rs:18-20)
+        uint64_t v = syslen_payload(total) + 1u;
+        char buf[20];
+        int n = 0;
+        do {
+            buf[n++] = (char)('0' + (uint32_t)(v % 10u));
+            v /= 10u;
+        } while (v);
+        while (n) sink.put((uint32_t)(uint8_t)buf[--n]);
+        sink.put(' ');
+    }
+    (void)encode_row<ENC>(sink, cfg, rd, t, li, meta, keys64, slot_ent, order);
+    if (cfg.merger == FG_MERGE_LINE || cfg.merger == FG_MERGE_SYSLEN) sink.put('\n');
+    else if (cfg.merger == FG_MERGE_NUL) sink.put(0u);
+    sink.finish();
+}
+
+}  // namespace emit
+}  // namespace fg

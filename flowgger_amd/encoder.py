@@ -1,0 +1,96 @@
+"""Host-side mirror of flowgger's Encoder / Merger interface for the GPU encode path.
+
+Reference: ``trait Encoder { fn encode(&self, record: Record) -> Result<Vec<u8>, &'static str> }``
+(src/flowgger/encoder/mod.rs:54-56) with GelfEncoder / LTSVEncoder / RFC5424Encoder / RFC3164Encoder /
+PassthroughEncoder, and ``trait Merger { fn frame(&self, bytes: &mut Vec<u8>) }`` (merger/mod.rs:30-32) with
+LineMerger / NulMerger / SyslenMerger.  Here one call encodes AND frames a whole decoded batch on the GPU straight
+from the decode tables (fg_encode_device): the result is one contiguous byte stream in input order, which is what
+the outputs write.  Configuration keys are the reference's (output.gelf_extra, output.ltsv_extra,
+output.syslog_prepend_timestamp -- the latter as the already formatted header, since it is the wall clock).
+There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+from . import _lib as L
+from .tables import DeviceTables
+
+MERGERS = {None: L.FG_MERGE_NONE, "none": L.FG_MERGE_NONE, "line": L.FG_MERGE_LINE, "nul": L.FG_MERGE_NUL, "syslen": L.FG_MERGE_SYSLEN}
+
+
+class Encoder:
+    """Base class; subclasses fix ``enc`` (fg_encoder)."""
+    enc = -1
+    extra_key = None  # the output.* table with extra pairs, if the encoder has one
+
+    def __init__(self, config: Optional[dict] = None, merger: Optional[str] = None, prepend: Optional[str] = None):
+        out = (config or {}).get("output", {})
+        extra = out.get(self.extra_key) if self.extra_key else None
+        # the reference iterates a toml Table = BTreeMap: sorted by key
+        self.extra = sorted((extra or {}).items())
+        for k, v in self.extra:
+            if not isinstance(v, str):  # gelf_encoder.rs:27-29 / ltsv_encoder.rs:21-23
+                raise TypeError(f"output.{self.extra_key} values must be strings")
+        self.merger = MERGERS[merger if merger is not None else out.get("framing")]
+        self.prepend = prepend
+
+    def encode_device(self, decoder, d_bytes, d_offsets, n: int, tables: DeviceTables, now_ts: float = 0.0, stream=None,
+                      want_status: bool = False, out=None):
+        """Encode + frame the n decoded lines of `tables` (produced by `decoder` from d_bytes / d_offsets).
+        Returns (d_out uint8, d_out_offsets int64[n+1][, d_status uint8[n]]): message i = d_out[off[i]:off[i+1]],
+        empty when the line's decode or encode failed (status 1 / fg_encode_error_string).
+        `out` = an optional preallocated uint8 device tensor: one call (count, scan, write) when it is large
+        enough; otherwise a sizing call comes first."""
+        import torch
+
+        if stream is None:
+            stream = torch.cuda.current_stream(d_bytes.device)
+        ks = (C.c_char_p * max(len(self.extra), 1))(*[k.encode() for k, _ in self.extra])
+        vs = (C.c_char_p * max(len(self.extra), 1))(*[v.encode() for _, v in self.extra])
+        cfg = L.fg_encode_cfg(self.enc, self.merger, len(self.extra), C.cast(ks, C.POINTER(C.c_char_p)),
+                              C.cast(vs, C.POINTER(C.c_char_p)), None if self.prepend is None else self.prepend.encode(), now_ts)
+        d_off = torch.empty(n + 1, dtype=torch.int64, device=d_bytes.device)
+        d_st = torch.empty(max(n, 1), dtype=torch.uint8, device=d_bytes.device) if want_status else None
+        total = C.c_uint64()
+        args = (decoder._ctx, decoder.fmt, C.byref(cfg), d_bytes.data_ptr(), d_bytes.numel(), d_offsets.data_ptr(), n,
+                C.byref(tables.struct))
+        tail = (d_off.data_ptr(), d_st.data_ptr() if want_status else None, C.byref(total), C.c_void_p(stream.cuda_stream))
+        rc = L.FG_ERR_ENT_OVERFLOW
+        if out is not None:
+            rc = L.lib().fg_encode_device(*args, out.data_ptr(), out.numel(), *tail)
+            if rc not in (L.FG_OK, L.FG_ERR_ENT_OVERFLOW):
+                L.check(rc, "fg_encode_device")
+        if rc == L.FG_ERR_ENT_OVERFLOW:
+            if out is None:
+                L.check(L.lib().fg_encode_device(*args, None, 0, *tail), "fg_encode_device (size)")
+            out = torch.empty(max(int(total.value), 1), dtype=torch.uint8, device=d_bytes.device)
+            L.check(L.lib().fg_encode_device(*args, out.data_ptr(), out.numel(), *tail), "fg_encode_device")
+        res = (out[:int(total.value)], d_off)
+        return res + (d_st[:n],) if want_status else res
+
+    @staticmethod
+    def error_string(status: int) -> Optional[str]:
+        s = L.lib().fg_encode_error_string(status)
+        return None if s is None else s.decode()
+
+
+class GelfEncoder(Encoder):  # encoder/gelf_encoder.rs
+    enc, extra_key = L.FG_ENC_GELF, "gelf_extra"
+
+
+class LTSVEncoder(Encoder):  # encoder/ltsv_encoder.rs
+    enc, extra_key = L.FG_ENC_LTSV, "ltsv_extra"
+
+
+class RFC5424Encoder(Encoder):  # encoder/rfc5424_encoder.rs
+    enc = L.FG_ENC_RFC5424
+
+
+class RFC3164Encoder(Encoder):  # encoder/rfc3164_encoder.rs
+    enc = L.FG_ENC_RFC3164
+
+
+class PassthroughEncoder(Encoder):  # encoder/passthrough_encoder.rs
+    enc = L.FG_ENC_PASSTHROUGH

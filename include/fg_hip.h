@@ -221,8 +221,7 @@ int fg_frame_decode_batch(fg_ctx* ctx, fg_format fmt, fg_framing framing, const 
  *   total          out (host): bytes needed; the call synchronises the stream to read it
  *   d_out == NULL  sizing call (only d_out_offsets / *total are produced);
  *   *total > out_cap -> FG_ERR_ENT_OVERFLOW, nothing written.
- * src_fmt says which decoder produced `tables`; FG_RFC5424 and FG_LTSV in this version
- * (FG_GELF -> FG_ERR_UNSUPPORTED). */
+ * src_fmt says which decoder produced `tables`.  Same as fg_encode_device with FG_ENC_GELF / FG_MERGE_NONE. */
 typedef struct fg_gelf_extra {
     uint32_t n;
     const char* const* keys;
@@ -232,6 +231,43 @@ int fg_encode_gelf_device(fg_ctx* ctx, fg_format src_fmt, const uint8_t* d_bytes
                           const uint64_t* d_offsets, uint64_t n, const fg_tables* tables,
                           const fg_gelf_extra* extra, uint8_t* d_out, uint64_t out_cap,
                           uint64_t* d_out_offsets, uint64_t* total, void* stream);
+
+/* ANY ENCODER + MERGER FROM THE TABLES: replaces, for a whole decoded batch,
+ *   Encoder::encode   encoder/{gelf,ltsv,rfc5424,rfc3164,passthrough}_encoder.rs   (trait: encoder/mod.rs:54-56)
+ *   Merger::frame     merger/{line,nul,syslen}_merger.rs                             (trait: merger/mod.rs:30-32)
+ * i.e. the `encoder.encode(decoded)?` of handle_line (splitter/line_splitter.rs:44-54) and the framing the outputs
+ * apply to every message.  The encoded + framed bytes of line i are written to d_out[out_offsets[i] ..
+ * out_offsets[i+1]); a line whose decode failed or whose encode returns Err produces nothing (the reference prints
+ * the error and drops the line).  Records from all three decoders are accepted (GELF-sourced spans are JSON-unescaped
+ * on the fly).  The capnp encoder is not provided.
+ *   cfg->extra_*    output.gelf_extra (GELF) / output.ltsv_extra (LTSV) in the configuration table's iteration order
+ *                   (a BTreeMap: sorted by key)
+ *   cfg->prepend    RFC3164 / passthrough: the already formatted output.syslog_prepend_timestamp header (the
+ *                   reference formats the wall clock per message, encoder/mod.rs:81-93); NULL = not configured
+ *   cfg->now_ts     Record.ts of GELF records decoded without "timestamp" (rows flagged FG_F_TS_NOW; the reference
+ *                   reads the wall clock at decode time, gelf_decoder.rs:109)
+ *   d_out_offsets   out, n + 1 entries (device)
+ *   d_enc_status    out, n bytes (device), may be NULL: 0 = encoded, 1 = the row's decode had failed,
+ *                   else an encoder error (fg_encode_error_string)
+ *   total           out (host): bytes needed; the call synchronises the stream to read it
+ *   d_out == NULL   sizing call (only d_out_offsets / d_enc_status / *total are produced);
+ *   *total > out_cap -> FG_ERR_ENT_OVERFLOW, nothing written. */
+typedef enum fg_encoder { FG_ENC_GELF = 0, FG_ENC_LTSV = 1, FG_ENC_RFC5424 = 2, FG_ENC_RFC3164 = 3, FG_ENC_PASSTHROUGH = 4 } fg_encoder;
+typedef enum fg_merger { FG_MERGE_NONE = 0, FG_MERGE_LINE = 1, FG_MERGE_NUL = 2, FG_MERGE_SYSLEN = 3 } fg_merger;
+typedef struct fg_encode_cfg {
+    fg_encoder encoder;
+    fg_merger merger;
+    uint32_t n_extra;
+    const char* const* extra_keys;
+    const char* const* extra_values;
+    const char* prepend;
+    double now_ts;
+} fg_encode_cfg;
+int fg_encode_device(fg_ctx* ctx, fg_format src_fmt, const fg_encode_cfg* cfg, const uint8_t* d_bytes, uint64_t nbytes,
+                     const uint64_t* d_offsets, uint64_t n, const fg_tables* tables, uint8_t* d_out, uint64_t out_cap,
+                     uint64_t* d_out_offsets, uint8_t* d_enc_status, uint64_t* total, void* stream);
+/* The reference's exact &'static str of an encode status (0 / 1 -> "", unknown -> NULL). */
+const char* fg_encode_error_string(uint8_t enc_status);
 
 /* Page-locked host memory for the framer's batch buffers (bytes, offsets). */
 int fg_alloc_pinned(uint64_t bytes, void** out);

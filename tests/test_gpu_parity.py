@@ -688,3 +688,80 @@ def test_gelf_encoder_matches_the_reference_pipeline(rfc, oracle, src, extra):
         a, b = out[int(off[i]):int(off[i + 1])].tobytes(), oblob[int(ooffs[i]):int(ooffs[i + 1])].tobytes()
         raise AssertionError(f"line {i}: {lines[i][:100]!r}\n  gpu    {a!r}\n  oracle {b!r}")
     assert (np.diff(ooffs.astype(np.int64)) > 0).sum() > 0.9 * len(lines)
+
+
+# ---------------------------------------------------------------------------------------------
+# Every encoder x merger from the tables, records from all three decoders
+# ---------------------------------------------------------------------------------------------
+def _encode_corpus(src, rfc):
+    hdr = b"<13>1 2015-08-05T15:53:45.637824Z host app 1234 ID7 "
+    if src == "ltsv":
+        return LTSVDecoder(synth.LTSV_CONFIG), LTSV, synth.LTSV_CONFIG, synth.ltsv_lines(6_000)
+    if src == "gelf":
+        lines = synth.gelf_lines(6_000)
+        lines += [b'{"host":"h","short_message":"no timestamp: wall clock"}',
+                  b'{"host":"h\\u00e9\\ud834\\udd1e","short_message":"a\\"b\\\\c\\/d\\n\\t\\u0001","full_message":"x\\u20acy","timestamp":1.5,"level":3,'
+                  b'"_k\\u005f1":"v\\u0041","\\u005fesc":true,"plain":null,"_n":-5,"u":18446744073709551615,"f":1e21,"g":1.0e-7}',
+                  b'{"host":"retry","short_message":"raw\nnewline and \\\nbackslash-newline","_k":"v\n"}',
+                  b'{"host":"h","timestamp":253402300800,"short_message":"year 10000"}',
+                  b'{"host":"h","timestamp":-62167219201,"short_message":"year -1"}',
+                  b'{"host":"h","timestamp":1e300,"short_message":"saturating"}',
+                  b'{"host":"h","_dup":"1","dup":"2","_dup":"3","sd_id":"x","_sd_id":"y","__u":"z"}']
+        return GelfDecoder(), GELF, None, lines
+    if src == "long_tail":
+        return rfc, RFC5424, None, synth.rfc5424_lines(3_000, cfg=5, sd=True, long_tail=True)
+    lines = synth.rfc5424_lines(6_000, cfg=2) + synth.rfc5424_lines(6_000, cfg=4, sd=True)
+    lines += [hdr + b'[a x="1" x="2" y="3"][b x="4" request_id="r1" request_ip="r2" request_i="r3"] dup keys and 7-byte prefix ties',
+              hdr + b'[big ' + b" ".join(b'k%02d="v%d"' % (99 - i, i) for i in range(40)) + b"] more than 32 pairs",
+              hdr + b'[e esc="a\\"b\\\\c\\]d\\qe" ctl="tab\there" k:c="v:w"] escapes',
+              hdr + b"[empty ] element without pairs", hdr + b"[] []  - ",
+              b"<13>1 2015-08-05T15:53:45Z - - - - - ", b"<191>1 1999-12-31T23:59:59.999999999+14:00  a  p m - no host",
+              b"<13>1 9999-12-31T23:59:59.9996Z h a p m - last millisecond", b"<13>1 0000-01-01T00:00:00+01:00 h a p m - year -1 in UTC",
+              b"<13>1 9999-12-31T23:59:59+00:00 h a p m - x", b"<13>1 9999-12-31T23:59:59-23:00 h a p m - year 10000 in UTC",
+              b"<255>1 1970-01-01T00:00:00.5Z h a p m - half", b"<13>1 1969-12-31T23:59:59.25Z h a p m - negative ts"]
+    return rfc, RFC5424, None, lines
+
+
+@pytest.mark.parametrize("src", ["rfc5424", "ltsv", "gelf", "long_tail"])
+@pytest.mark.parametrize("enc", ["gelf", "ltsv", "rfc5424", "rfc3164", "passthrough"])
+def test_encoders_and_mergers_match_the_reference_pipeline(rfc, oracle, src, enc):
+    """decode on the GPU -> encode + frame on the GPU == the oracle's decode -> Encoder::encode -> Merger::frame, byte for
+    byte, for every line and every merger; lines whose decode or encode fails produce nothing and the right status."""
+    import torch
+
+    import oracle_binding as OB
+    from flowgger_amd import GelfEncoder, LTSVEncoder, PassthroughEncoder, RFC3164Encoder, RFC5424Encoder
+
+    dec, fmt, cfg, lines = _encode_corpus(src, rfc)
+    data, offsets = synth.pack(lines)
+    tables, d_bytes, d_offsets = device_path(dec, data, offsets)
+    cls, oenc, extra_key = {"gelf": (GelfEncoder, OB.ENC_GELF, "gelf_extra"), "ltsv": (LTSVEncoder, OB.ENC_LTSV, "ltsv_extra"),
+                            "rfc5424": (RFC5424Encoder, OB.ENC_RFC5424, None), "rfc3164": (RFC3164Encoder, OB.ENC_RFC3164, None),
+                            "passthrough": (PassthroughEncoder, OB.ENC_PASSTHROUGH, None)}[enc]
+    extra = {"_k1_b": "replaced", "host": "forced", "Zeta": "capital first", "_a": "x\"y\\z\n\t:1", "_counter_u64": "shadow"} if extra_key else None
+    prepend = "2026-09-23T10:11Z " if enc in ("rfc3164", "passthrough") else None
+    now_ts = 1438859724.638
+    seen_err = set()
+    for merger, om in (("none", OB.MERGE_NONE), ("line", OB.MERGE_LINE), ("nul", OB.MERGE_NUL), ("syslen", OB.MERGE_SYSLEN)):
+        if merger in ("nul", "line") and enc not in ("gelf", "rfc5424"):
+            continue  # the merger code is shared: all four with two encoders, none + syslen with every encoder
+        e = cls({"output": {extra_key: extra}} if extra_key else None, merger=merger, prepend=prepend)
+        d_out, d_off, d_st = e.encode_device(dec, d_bytes, d_offsets, len(lines), tables, now_ts=now_ts, want_status=True)
+        torch.cuda.synchronize()
+        out, off, st = d_out.cpu().numpy(), d_off.cpu().numpy().astype(np.uint64), d_st.cpu().numpy()
+        oblob, ooffs, ost = oracle.decode_encode_batch(fmt, oenc, om, data, offsets, cfg, extra=extra, prepend=prepend, now_ts=now_ts)
+        bad = np.flatnonzero(off != ooffs)
+        if len(bad) or not np.array_equal(out, oblob):
+            i = max(int(bad[0]) - 1, 0) if len(bad) else int(np.searchsorted(ooffs, np.flatnonzero(out != oblob)[0], side="right") - 1)
+            a, b = out[int(off[i]):int(off[i + 1])].tobytes(), oblob[int(ooffs[i]):int(ooffs[i + 1])].tobytes()
+            raise AssertionError(f"{merger}: line {i}: {lines[i][:160]!r}\n  gpu    {a!r}\n  oracle {b!r}")
+        assert np.array_equal(np.minimum(st, 2), ost), "encode status differs"
+        seen_err |= {e.error_string(int(s)) for s in np.unique(st) if s >= 2}
+        if (src, enc) != ("gelf", "passthrough"):  # GELF records rarely carry full_message: "Cannot output empty raw message"
+            assert (np.diff(ooffs.astype(np.int64)) > 0).sum() > 0.9 * len(lines)
+    if enc == "rfc5424" and src in ("rfc5424", "gelf"):
+        assert "Failed to parse date" in seen_err and "Failed to parse date as Rfc3339 format" in seen_err
+    if enc == "rfc3164" and src in ("rfc5424", "gelf"):
+        assert "Failed to parse unix timestamp in RFC3164 encoder" in seen_err
+    if enc == "passthrough" and src == "gelf":
+        assert "Cannot output empty raw message" in seen_err
