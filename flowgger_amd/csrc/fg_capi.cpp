@@ -36,10 +36,11 @@ extern "C" int fg_launch_rfc5424(const uint8_t* d_bytes, const uint64_t* d_offse
                                  const uint8_t* line_bad);
 extern "C" uint64_t fg_stash_bytes(uint32_t blocks);
 extern "C" int fg_launch_encode_sizes(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
-                                      const fg::EncCfg* cfg, uint32_t* d_sizes, uint64_t* d_block_sums, uint8_t* d_status,
-                                      uint64_t* d_out_offsets, hipStream_t stream);
+                                      const fg::EncCfg* cfg, uint32_t tile_cap, uint32_t cfg_lds, uint32_t* d_sizes,
+                                      uint64_t* d_block_sums, uint8_t* d_status, uint64_t* d_out_offsets, hipStream_t stream);
 extern "C" int fg_launch_encode_write(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
-                                      const fg::EncCfg* cfg, const uint64_t* d_out_offsets, uint8_t* d_out, hipStream_t stream);
+                                      const fg::EncCfg* cfg, uint32_t tile_cap, uint32_t cfg_lds, const uint64_t* d_out_offsets,
+                                      uint8_t* d_out, hipStream_t stream);
 extern "C" uint64_t fg_frame_scratch_bytes(uint64_t nbytes);
 extern "C" int fg_launch_frame(const uint8_t* d_bytes, uint64_t nbytes, uint32_t delim, uint8_t* scratch, uint64_t* d_offsets,
                                uint8_t* d_bad, uint64_t cap, uint64_t** d_total_out, hipStream_t stream);
@@ -711,7 +712,6 @@ int fg_frame_decode_batch(fg_ctx* ctx, fg_format fmt, fg_framing framing, const 
 int fg_encode_device(fg_ctx* ctx, fg_format src_fmt, const fg_encode_cfg* ecfg, const uint8_t* d_bytes, uint64_t nbytes,
                      const uint64_t* d_offsets, uint64_t n, const fg_tables* tables, uint8_t* d_out, uint64_t out_cap,
                      uint64_t* d_out_offsets, uint8_t* d_enc_status, uint64_t* total, void* stream) {
-    (void)nbytes;
     if (!ctx || !ecfg || !tables || !d_out_offsets || !total || (n && (!d_offsets || !tables->meta))) return FG_ERR_ARG;
     if ((int)src_fmt < 0 || (int)src_fmt > (int)FG_GELF) return FG_ERR_ARG;
     if (tables->n < n) return FG_ERR_ARG;
@@ -720,27 +720,37 @@ int fg_encode_device(fg_ctx* ctx, fg_format src_fmt, const fg_encode_cfg* ecfg, 
     *total = 0;
     fg::EncCfgHost h;
     if (!fg::build_enc_cfg(src_fmt, ecfg, ctx->suffix, ctx->has_suffix, &h)) return FG_ERR_ARG;
-    const uint64_t keys_bytes = up(h.keys.size() * sizeof(fg::StaticKey) + 16, 256), blob_bytes = up(h.blob.size() + 16, 256);
+    const uint64_t keys_bytes = up(h.keys.size() * sizeof(fg::StaticKey), 16), blob_bytes = up(h.blob.size() + 16, 256);
+    const uint64_t cfg_bytes = up(keys_bytes + blob_bytes, 256);
     int rc;
-    if ((rc = grow_dev(ctx, (void**)&ctx->d_enc, &ctx->d_enc_cap, keys_bytes + blob_bytes + up(n * 4 + 4, 256) + up((n / 64 + 2) * 8, 256))) != FG_OK) return rc;
-    std::vector<uint8_t> host(keys_bytes + blob_bytes, 0);
+    if ((rc = grow_dev(ctx, (void**)&ctx->d_enc, &ctx->d_enc_cap, cfg_bytes + up(n * 4 + 4, 256) + up((n / 64 + 2) * 8, 256))) != FG_OK) return rc;
+    std::vector<uint8_t> host(cfg_bytes, 0);
     if (!h.keys.empty()) memcpy(host.data(), h.keys.data(), h.keys.size() * sizeof(fg::StaticKey));
     if (!h.blob.empty()) memcpy(host.data() + keys_bytes, h.blob.data(), h.blob.size());
-    // (synchronous copy of a few hundred bytes: `host` goes out of scope at return)
+    // (synchronous copy of a few hundred bytes: `host` goes out of scope at return); the same sync brings back the
+    // number of entries the decode produced, which sizes the GELF ranking scratch
+    uint64_t ent_used = ~0ull;
     FG_HIP(ctx, hipMemcpyAsync(ctx->d_enc, host.data(), host.size(), hipMemcpyHostToDevice, s));
+    if (ecfg->encoder == FG_ENC_GELF && tables->ent_used)
+        FG_HIP(ctx, hipMemcpyAsync(&ent_used, tables->ent_used, 8, hipMemcpyDeviceToHost, s));
     FG_HIP(ctx, hipStreamSynchronize(s));
     fg::EncCfg cfg = h.cfg;
     cfg.keys = reinterpret_cast<const fg::StaticKey*>(ctx->d_enc);
     cfg.blob = ctx->d_enc + keys_bytes;
-    uint32_t* d_sizes = reinterpret_cast<uint32_t*>(ctx->d_enc + keys_bytes + blob_bytes);
-    uint64_t* d_block_sums = reinterpret_cast<uint64_t*>(ctx->d_enc + keys_bytes + blob_bytes + up(n * 4 + 4, 256));
+    if (ent_used <= 2 * n) cfg.sort_slots = 8;  // on average <= 2 pairs per line
+    // mirror [static keys | blob] in LDS when it is small (it nearly always is)
+    const uint32_t cfg_lds = keys_bytes + h.blob.size() <= 4096 ? (uint32_t)up(keys_bytes + h.blob.size(), 16) : 0u;
+    uint32_t* d_sizes = reinterpret_cast<uint32_t*>(ctx->d_enc + cfg_bytes);
+    uint64_t* d_block_sums = reinterpret_cast<uint64_t*>(ctx->d_enc + cfg_bytes + up(n * 4 + 4, 256));
     fg::DevTables dt = to_dev(*tables);
     if (n == 0) {
         FG_HIP(ctx, hipMemsetAsync(d_out_offsets, 0, 8, s));
         return FG_OK;
     }
+    // LDS tile of a 64-line group: average group + 6.25 % + 512 B, 4..40 KiB (longer groups read from global memory)
+    const uint32_t tile_cap = pick_tile_cap(nbytes, n, 40 * 1024);
     if (ctx->timing) FG_HIP(ctx, hipEventRecord(ctx->ev0, s));
-    int lrc = fg_launch_encode_sizes(d_bytes, d_offsets, n, &dt, &cfg, d_sizes, d_block_sums, d_enc_status, d_out_offsets, s);
+    int lrc = fg_launch_encode_sizes(d_bytes, d_offsets, n, &dt, &cfg, tile_cap, cfg_lds, d_sizes, d_block_sums, d_enc_status, d_out_offsets, s);
     if (lrc != 0) {
         ctx->last_hip = lrc;
         return FG_ERR_HIP;
@@ -749,7 +759,7 @@ int fg_encode_device(fg_ctx* ctx, fg_format src_fmt, const fg_encode_cfg* ecfg, 
     FG_HIP(ctx, hipStreamSynchronize(s));
     if (!d_out) return FG_OK;  // sizing call
     if (*total > out_cap) return FG_ERR_ENT_OVERFLOW;
-    lrc = fg_launch_encode_write(d_bytes, d_offsets, n, &dt, &cfg, d_out_offsets, d_out, s);
+    lrc = fg_launch_encode_write(d_bytes, d_offsets, n, &dt, &cfg, tile_cap, cfg_lds, d_out_offsets, d_out, s);
     if (lrc != 0) {
         ctx->last_hip = lrc;
         return FG_ERR_HIP;

@@ -37,6 +37,21 @@ struct LdsReader {
         }
         return __builtin_amdgcn_ubfe(cur, (a & 3u) * 8u, 8u);
     }
+    // 4 bytes starting at byte i (little-endian); only the low nb are meaningful.  The tile is padded: the dword
+    // behind the last byte is always readable.
+    __device__ __forceinline__ uint32_t load4(uint32_t i, uint32_t) {
+        const uint32_t a = base + i;
+        const uint32_t w = a >> 2;
+        if (w != cur_idx) {
+            cur = words[w];
+            cur_idx = w;
+        }
+        const uint32_t lo = cur;
+        if ((a & 3u) == 0) return lo;
+        cur = words[w + 1u];
+        cur_idx = w + 1u;
+        return __builtin_amdgcn_alignbyte(cur, lo, a & 3u);
+    }
 };
 struct GlobalReader {
     const uint32_t* words;  // packed buffer viewed as dwords (base is 16-byte aligned)
@@ -52,6 +67,21 @@ struct GlobalReader {
             cur_idx = w;
         }
         return __builtin_amdgcn_ubfe(cur, ((uint32_t)a & 3u) * 8u, 8u);
+    }
+    // 4 bytes starting at byte i; the dword behind is only touched when the nb wanted bytes reach into it (the
+    // packed buffer is readable up to nbytes rounded up to 16, not beyond)
+    __device__ __forceinline__ uint32_t load4(uint32_t i, uint32_t nb) {
+        const uint64_t a = base + i;
+        const uint64_t w = a >> 2;
+        if (w != cur_idx) {
+            cur = words[w];
+            cur_idx = w;
+        }
+        const uint32_t lo = cur, sh = (uint32_t)a & 3u;
+        if (sh + nb <= 4u) return lo >> (8u * sh);
+        cur = words[w + 1u];
+        cur_idx = w + 1u;
+        return __builtin_amdgcn_alignbyte(cur, lo, sh);
     }
 };
 

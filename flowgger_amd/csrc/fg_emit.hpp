@@ -38,9 +38,10 @@ namespace fg {
 // static key list entry of the GELF encoder (host-built, sorted by key): what the value is
 enum : uint32_t { SK_APP = 0, SK_FULL = 1, SK_HOST = 2, SK_LEVEL = 3, SK_PROC = 4, SK_SDID = 5, SK_SHORT = 6, SK_TS = 7, SK_VERSION = 8, SK_EXTRA = 9 };
 struct StaticKey {
-    uint32_t key_off, key_len;  // into the blob
-    uint32_t kind;              // SK_*
-    uint32_t val_off, val_len;  // SK_EXTRA: the configured value
+    uint32_t key_off, key_len;    // the raw key bytes (for the merge with the record's own keys), into the blob
+    uint32_t kind;                // SK_*
+    uint32_t text_off, text_len;  // the member text up to the value: `"key":` with the key JSON-escaped; SK_EXTRA:
+                                  // the whole member `"key":"value"` (4-byte aligned in the blob)
 };
 struct EncCfg {
     const uint8_t* blob;       // GELF keys + extra values, LTSV suffixes, the LTSV extras text, the prepend header
@@ -53,6 +54,7 @@ struct EncCfg {
     uint32_t ltsv_extra_off, ltsv_extra_len;  // "k1:v1\tk2:v2" (already escaped, '_' stripped); len 0 = none
     uint32_t prepend_off, prepend_len;        // syslog_prepend_timestamp header; len 0xFFFFFFFF = not configured
     double now_ts;             // Record.ts of rows flagged FG_F_TS_NOW
+    uint32_t sort_slots;       // GELF: entries of the per-lane ranking scratch (<= kSortSlots)
 };
 
 // encode status per line (fg_encode_error_string)
@@ -146,11 +148,69 @@ FGE_HD void for_each_decoded(R& rd, uint32_t off, uint32_t len, uint32_t mode, F
     }
 }
 
+// ---- sinks.  Protocol: put(c) one byte; put_word(w, nb) nb = 1..4 bytes, little-endian in w, the bytes above nb zero;
+//      finish().  kCount sinks only count (add(n) = n bytes whose values do not matter). -----------------------------
 struct CountSink {
+    static constexpr bool kCount = true;
     uint32_t n = 0;
     FGE_HD void put(uint32_t) { ++n; }
+    FGE_HD void put_word(uint32_t, uint32_t nb) { n += nb; }
+    FGE_HD void add(uint32_t k) { n += k; }
     FGE_HD void finish() {}
 };
+// Packs the byte stream into ALIGNED dword stores.  Messages of neighbouring lines are adjacent in the output and are
+// written by other lanes at the same time, so nothing outside [q, q + length) may be touched: the bytes of the first
+// dword before q and of the last dword after the end are never stored (byte stores there).
+struct PackSink {
+    static constexpr bool kCount = false;
+    uint8_t* p;     // aligned address of the dword being assembled
+    uint64_t acc;   // pending bytes: the low k bytes are valid (the first `head` of them are placeholders)
+    uint32_t k;
+    uint32_t head;  // bytes of the first dword that belong to the previous message
+    FGE_HD explicit PackSink(uint8_t* q) {
+        head = (uint32_t)((uintptr_t)q & 3u);
+        p = q - head;
+        acc = 0;
+        k = head;
+    }
+    FGE_HD void flush() {
+        if (head) {
+            for (uint32_t i = head; i < 4u; ++i) p[i] = (uint8_t)(acc >> (8u * i));
+            head = 0;
+        } else {
+            *reinterpret_cast<uint32_t*>(p) = (uint32_t)acc;
+        }
+        p += 4;
+        acc >>= 32;
+        k -= 4u;
+    }
+    FGE_HD void put_word(uint32_t w, uint32_t nb) {
+        acc |= (uint64_t)w << (8u * k);
+        k += nb;
+        if (k >= 4u) flush();
+    }
+    FGE_HD void put(uint32_t c) { put_word(c & 0xFFu, 1u); }
+    FGE_HD void add(uint32_t) {}
+    FGE_HD void finish() {
+        for (uint32_t i = head; i < k; ++i) p[i] = (uint8_t)(acc >> (8u * i));
+        p += k;
+        head = 0;
+        k = 0;
+        acc = 0;
+    }
+};
+
+// SWAR byte tests on a dword (exact as booleans: nonzero iff some byte matches)
+FGE_HD uint32_t swar_zero(uint32_t v) { return (v - 0x01010101u) & ~v & 0x80808080u; }
+FGE_HD uint32_t swar_lt20(uint32_t w) { return (w - 0x20202020u) & ~w & 0x80808080u; }
+FGE_HD uint32_t swar_has(uint32_t w, uint32_t c) { return swar_zero(w ^ (c * 0x01010101u)); }
+enum : uint32_t { ESC_NONE = 0, ESC_JSON = 1, ESC_LTSV_VAL = 2 };
+template <uint32_t ESC>
+FGE_HD bool word_needs_bytes(uint32_t w) {
+    if (ESC == ESC_JSON) return (swar_lt20(w) | swar_has(w, '"') | swar_has(w, '\\')) != 0;
+    if (ESC == ESC_LTSV_VAL) return (swar_has(w, '\t') | swar_has(w, '\n')) != 0;
+    return false;
+}
 
 // Everything the emitters share: the row, the field views, the number formats.
 template <class S, class R>
@@ -177,14 +237,52 @@ struct Base {
     FGE_HD double record_ts() const { return (flags() & FG_F_TS_NOW) ? cfg.now_ts : t.ts[li]; }
 
     FGE_HD void lit(const char* s, uint32_t n) {
-        for (uint32_t i = 0; i < n; ++i) out.put((uint32_t)(uint8_t)s[i]);
+        uint32_t i = 0;
+        for (; i + 4u <= n; i += 4u) {
+            uint32_t w;
+            memcpy(&w, s + i, 4);
+            out.put_word(w, 4u);
+        }
+        for (; i < n; ++i) out.put((uint32_t)(uint8_t)s[i]);
     }
+    // a piece of the configuration blob; every piece starts 4-byte aligned and is followed by readable padding
     FGE_HD void blob(uint32_t off, uint32_t len) {
-        for (uint32_t i = 0; i < len; ++i) out.put(cfg.blob[off + i]);
+        if (S::kCount) {
+            out.add(len);
+            return;
+        }
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(cfg.blob + off);
+        uint32_t i = 0;
+        for (; i + 4u <= len; i += 4u) out.put_word(w[i >> 2], 4u);
+        if (i < len) out.put_word(w[i >> 2] & (0xFFFFFFFFu >> (8u * (4u - (len - i)))), len - i);
+    }
+    // rd[off .. off+len) copied through the per-byte functor `fb` only where a dword holds a byte that needs it
+    // (ESC): everything else moves four bytes at a time
+    template <uint32_t ESC, class FB>
+    FGE_HD void copy_raw(uint32_t off, uint32_t len, FB&& fb) {
+        if (ESC == ESC_NONE && S::kCount) {
+            out.add(len);
+            return;
+        }
+        uint32_t i = 0;
+        for (; i + 4u <= len; i += 4u) {
+            const uint32_t w = rd.load4(off + i, 4u);
+            if (word_needs_bytes<ESC>(w)) {
+                fb(w & 0xFFu);
+                fb((w >> 8) & 0xFFu);
+                fb((w >> 16) & 0xFFu);
+                fb(w >> 24);
+            } else {
+                out.put_word(w, 4u);
+            }
+        }
+        for (; i < len; ++i) fb(rd.byte(off + i));
     }
     FGE_HD void raw_field(int col) {  // a top-level field, decoded, unmodified
         const fg_span s = t.span[col][li];
-        for_each_decoded(rd, s.off, s.len, field_mode(col), [&](uint32_t c) { out.put(c); });
+        const uint32_t mode = field_mode(col);
+        if (mode == M_RAW) copy_raw<ESC_NONE>(s.off, s.len, [&](uint32_t c) { out.put(c); });
+        else for_each_decoded(rd, s.off, s.len, mode, [&](uint32_t c) { out.put(c); });
     }
     FGE_HD void u64_text(uint64_t v) {
         char buf[20];
@@ -327,7 +425,12 @@ struct Base {
             if (t.ent_type[e] != FG_T_NULL) {
                 out.put('=');
                 out.put('"');
-                value_display(e, [&](uint32_t c) { out.put(c); });
+                if (t.ent_type[e] == FG_T_STRING && value_mode(e) == M_RAW) {
+                    const uint64_t v = t.ent_val[e];
+                    copy_raw<ESC_NONE>((uint32_t)v, (uint32_t)(v >> 32), [&](uint32_t c) { out.put(c); });
+                } else {
+                    value_display(e, [&](uint32_t c) { out.put(c); });
+                }
                 out.put('"');
             }
         }
@@ -383,18 +486,19 @@ struct GelfEmitter : Base<S, R> {
         if (!first_member) out.put(',');
         first_member = false;
     }
-    FGE_HD void key_static(const StaticKey& k) {
+    FGE_HD void key_static(const StaticKey& k) {  // `"key":` (escaped by the host), SK_EXTRA: `"key":"value"`
         member_start();
+        this->blob(k.text_off, k.text_len);
+    }
+    FGE_HD void str_span(uint32_t off, uint32_t len, uint32_t mode) {
         out.put('"');
-        for (uint32_t i = 0; i < k.key_len; ++i) esc_byte(cfg.blob[k.key_off + i]);
+        if (mode == M_RAW) this->template copy_raw<ESC_JSON>(off, len, [&](uint32_t c) { esc_byte(c); });
+        else for_each_decoded(rd, off, len, mode, [&](uint32_t c) { esc_byte(c); });
         out.put('"');
-        out.put(':');
     }
     FGE_HD void str_field(int col) {
         const fg_span s = t.span[col][li];
-        out.put('"');
-        for_each_decoded(rd, s.off, s.len, this->field_mode(col), [&](uint32_t c) { esc_byte(c); });
-        out.put('"');
+        str_span(s.off, s.len, this->field_mode(col));
     }
     FGE_HD void f64_text(double d) {
         uint64_t b;
@@ -438,9 +542,7 @@ struct GelfEmitter : Base<S, R> {
         const uint32_t ty = t.ent_type[e];
         const uint64_t v = t.ent_val[e];
         if (ty == FG_T_STRING) {
-            out.put('"');
-            for_each_decoded(rd, (uint32_t)v, (uint32_t)(v >> 32), this->value_mode(e), [&](uint32_t c) { esc_byte(c); });
-            out.put('"');
+            str_span((uint32_t)v, (uint32_t)(v >> 32), this->value_mode(e));
         } else if (ty == FG_T_BOOL) {
             if (v) this->lit("true", 4);
             else this->lit("false", 5);
@@ -505,11 +607,7 @@ struct GelfEmitter : Base<S, R> {
                 this->lit("1.1", 3);
                 out.put('"');
                 break;
-            default: {  // SK_EXTRA
-                out.put('"');
-                for (uint32_t i = 0; i < k.val_len; ++i) esc_byte(cfg.blob[k.val_off + i]);
-                out.put('"');
-            }
+            default: break;  // SK_EXTRA: the value is part of the precomputed member text
         }
     }
 
@@ -524,7 +622,7 @@ struct GelfEmitter : Base<S, R> {
                 sdid_entry = e;
                 continue;
             }
-            if (np < kSortSlots && ranked) {
+            if (np < cfg.sort_slots && ranked) {
                 const Dyn d = this->dyn_of(e);
                 uint64_t pre = 0;
                 for (uint32_t k = 0; k < 7u; ++k) pre = (pre << 8) | (k < d.dlen + d.sl ? this->dyn_byte(d, k) : 0u);
@@ -627,10 +725,14 @@ struct LtsvEmitter : Base<S, R> {
         this->lit(key, n);
         out.put(':');
     }
+    FGE_HD void val_span(uint32_t off, uint32_t len, uint32_t mode) {
+        if (mode == M_RAW) this->template copy_raw<ESC_LTSV_VAL>(off, len, [&](uint32_t c) { val_byte(c); });
+        else for_each_decoded(rd, off, len, mode, [&](uint32_t c) { val_byte(c); });
+    }
     FGE_HD void field(const char* key, uint32_t n, int col) {
         start(key, n);
         const fg_span s = t.span[col][li];
-        for_each_decoded(rd, s.off, s.len, this->field_mode(col), [&](uint32_t c) { val_byte(c); });
+        val_span(s.off, s.len, this->field_mode(col));
     }
     FGE_HD uint32_t run() {
         const uint32_t ef = t.ent_first[li], cnt = t.ent_count[li];
@@ -641,7 +743,12 @@ struct LtsvEmitter : Base<S, R> {
             const typename B::Dyn d = this->dyn_of(e);
             this->dyn_stream(d, [&](uint32_t c) { key_byte(c); });
             out.put(':');
-            this->value_display(e, [&](uint32_t c) { val_byte(c); });
+            if (t.ent_type[e] == FG_T_STRING) {
+                const uint64_t v = t.ent_val[e];
+                val_span((uint32_t)v, (uint32_t)(v >> 32), this->value_mode(e));
+            } else {
+                this->value_display(e, [&](uint32_t c) { val_byte(c); });
+            }
         }
         if (cfg.ltsv_extra_len) {
             if (!first) out.put('\t');
@@ -651,7 +758,7 @@ struct LtsvEmitter : Base<S, R> {
         start("host", 4);
         if (this->some(S_HOST)) {
             const fg_span s = t.span[S_HOST][li];
-            for_each_decoded(rd, s.off, s.len, this->field_mode(S_HOST), [&](uint32_t c) { val_byte(c); });
+            val_span(s.off, s.len, this->field_mode(S_HOST));
         }
         start("time", 4);
         shortest::display_f64(this->record_ts(), out);

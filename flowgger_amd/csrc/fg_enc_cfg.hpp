@@ -10,6 +10,9 @@
 
 namespace fg {
 
+inline void align4(std::vector<uint8_t>* b) {
+    while (b->size() & 3u) b->push_back(0);
+}
 struct EncCfgHost {
     std::vector<uint8_t> blob;
     std::vector<StaticKey> keys;
@@ -40,15 +43,44 @@ inline bool build_enc_cfg(fg_format src_fmt, const fg_encode_cfg* ec, const std:
         const char* fixed[9] = {"application_name", "full_message", "host", "level", "process_id", "sd_id", "short_message", "timestamp", "version"};
         for (uint32_t k = 0; k < 9; ++k) m[fixed[k]] = Ent{k, ""};
         for (uint32_t i = 0; i < ec->n_extra; ++i) m[ec->extra_keys[i]] = Ent{(uint32_t)SK_EXTRA, ec->extra_values[i]};
+        auto json_text = [](const std::string& x, std::string* o) {  // serde_json 0.8 escape_str
+            static const char hex[] = "0123456789abcdef";
+            o->push_back('"');
+            for (unsigned char c : x) {
+                switch (c) {
+                    case '"': *o += "\\\""; break;
+                    case '\\': *o += "\\\\"; break;
+                    case 8: *o += "\\b"; break;
+                    case 9: *o += "\\t"; break;
+                    case 10: *o += "\\n"; break;
+                    case 12: *o += "\\f"; break;
+                    case 13: *o += "\\r"; break;
+                    default:
+                        if (c < 0x20) {
+                            *o += "\\u00";
+                            o->push_back(hex[c >> 4]);
+                            o->push_back(hex[c & 15]);
+                        } else {
+                            o->push_back((char)c);
+                        }
+                }
+            }
+            o->push_back('"');
+        };
         for (const auto& kv : m) {
             StaticKey k{};
             k.key_off = (uint32_t)blob.size();
             k.key_len = (uint32_t)kv.first.size();
             blob.insert(blob.end(), kv.first.begin(), kv.first.end());
             k.kind = kv.second.kind;
-            k.val_off = (uint32_t)blob.size();
-            k.val_len = (uint32_t)kv.second.val.size();
-            blob.insert(blob.end(), kv.second.val.begin(), kv.second.val.end());
+            std::string text;
+            json_text(kv.first, &text);
+            text.push_back(':');
+            if (kv.second.kind == SK_EXTRA) json_text(kv.second.val, &text);
+            align4(&blob);
+            k.text_off = (uint32_t)blob.size();
+            k.text_len = (uint32_t)text.size();
+            blob.insert(blob.end(), text.begin(), text.end());
             out->keys.push_back(k);
         }
     }
@@ -57,6 +89,7 @@ inline bool build_enc_cfg(fg_format src_fmt, const fg_encode_cfg* ec, const std:
         cfg.suf_len[k] = has_suffix[k] ? (uint32_t)suffix[k].size() : 0xFFFFFFFFu;
         if (has_suffix[k]) blob.insert(blob.end(), suffix[k].begin(), suffix[k].end());
     }
+    align4(&blob);
     cfg.ltsv_extra_off = (uint32_t)blob.size();
     if (ec->encoder == FG_ENC_LTSV) {
         // output.ltsv_extra through LTSVString::insert (ltsv_encoder.rs:37-58,96-103): one leading '_' stripped from
@@ -71,6 +104,7 @@ inline bool build_enc_cfg(fg_format src_fmt, const fg_encode_cfg* ec, const std:
         }
     }
     cfg.ltsv_extra_len = (uint32_t)blob.size() - cfg.ltsv_extra_off;
+    align4(&blob);
     cfg.prepend_off = (uint32_t)blob.size();
     cfg.prepend_len = 0xFFFFFFFFu;
     if (ec->prepend && (ec->encoder == FG_ENC_RFC3164 || ec->encoder == FG_ENC_PASSTHROUGH)) {
@@ -78,11 +112,13 @@ inline bool build_enc_cfg(fg_format src_fmt, const fg_encode_cfg* ec, const std:
         blob.insert(blob.end(), p.begin(), p.end());
         cfg.prepend_len = (uint32_t)p.size();
     }
+    blob.resize(blob.size() + 8, 0);  // readable padding behind the last piece
     cfg.src_fmt = (uint32_t)src_fmt;
     cfg.enc = (uint32_t)ec->encoder;
     cfg.merger = (uint32_t)ec->merger;
     cfg.n_keys = (uint32_t)out->keys.size();
     cfg.now_ts = ec->now_ts;
+    cfg.sort_slots = emit::kSortSlots;
     return true;
 }
 

@@ -9,78 +9,82 @@
 //   k_block_scan + k_line_offsets   per-workgroup sums -> exclusive scan -> out_offsets[0..n]
 //   k_encode<ENC, true>   write at out + out_offsets[i]
 // so that the output is ONE contiguous, already framed byte stream in input order (what the outputs write).
-// The write sink packs bytes into dwords (byte stores only for the unaligned head and the tail of a message).
-// Byte-granular per-lane reads: this version is about exactness; the cooperative (LDS-staged) form is future work.
+// Input: the 64 lines of a workgroup are one contiguous byte range, staged into LDS with coalesced 16-byte loads.
+// Spans without bytes that need escaping move four bytes at a time (SWAR test per dword, fg_emit.hpp); the write sink
+// packs the byte stream into aligned dword stores (emit::PackSink).  Output stores are still per lane (each lane
+// streams into its own message): staging the output tile through LDS for coalesced stores is the next step.
 #include "fg_device.hpp"
 #include "fg_emit.hpp"
 
 namespace fg {
 
-struct WriteSink {
-    uint8_t* p;          // next byte to be stored
-    uint32_t acc = 0;    // pending bytes of the current (aligned) dword
-    uint32_t k = 0;      // number of pending bytes
-    uint32_t head;       // bytes still to be stored one by one before p is dword aligned
-    __device__ __forceinline__ explicit WriteSink(uint8_t* q) : p(q), head((uint32_t)(-(intptr_t)q) & 3u) {}
-    __device__ __forceinline__ void put(uint32_t c) {
-        if (head) {
-            *p++ = (uint8_t)c;
-            --head;
-            return;
-        }
-        acc |= (c & 0xFFu) << (8u * k);
-        if (++k == 4u) {
-            *reinterpret_cast<uint32_t*>(p) = acc;
-            p += 4;
-            acc = 0;
-            k = 0;
-        }
-    }
-    __device__ __forceinline__ void finish() {
-        for (uint32_t i = 0; i < k; ++i) p[i] = (uint8_t)(acc >> (8u * i));
-        p += k;
-        k = 0;
-        acc = 0;
-    }
-};
 
-// LDS scratch of the GELF emitter's key ranking (kSortSlots per lane); the other encoders need none.
-template <uint32_t ENC>
-struct Scratch {
-    static constexpr uint32_t kSlots = ENC == FG_ENC_GELF ? emit::kSortSlots : 1u;
-};
+// One 64-lane workgroup = 64 consecutive lines = ONE contiguous byte range of the packed buffer: it is staged into LDS
+// with coalesced 16-byte loads (stage_tile) and every lane then reads ITS line out of LDS; a group whose bytes exceed
+// the tile (long lines) reads from global memory instead (same emitter, GlobalReader).
+template <uint32_t ENC, bool WRITE, class R>
+__device__ __forceinline__ void encode_lane(R rd, uint64_t li, const DevTables& t, const EncCfg& cfg, uint64_t* keys64, uint8_t* slot_ent,
+                                            uint8_t* order, uint32_t* __restrict__ sizes, uint8_t* __restrict__ enc_status,
+                                            const uint64_t* __restrict__ out_offsets, uint8_t* __restrict__ out, uint32_t* size_out) {
+    const uint32_t meta = t.meta[li];
+    if (WRITE) {
+        const uint64_t o0 = out_offsets[li], total = out_offsets[li + 1] - o0;
+        emit::PackSink sink(out + o0);
+        emit::row_write<ENC>(sink, total, cfg, rd, t, li, meta, keys64, slot_ent, order);
+    } else {
+        uint32_t st;
+        const uint32_t size = emit::row_size<ENC>(cfg, rd, t, li, meta, keys64, slot_ent, order, &st);
+        sizes[li] = size;
+        if (enc_status) enc_status[li] = (uint8_t)st;
+        *size_out = size;
+    }
+}
 
-template <uint32_t ENC, bool WRITE>
+// SLOTS = per-lane entries of the GELF key-ranking scratch (0 for the other encoders); cfg_lds = bytes of the
+// configuration block [static keys | blob] to mirror in LDS (0: read it from global memory).
+template <uint32_t ENC, bool WRITE, uint32_t SLOTS>
 __global__ __launch_bounds__(kWave) void k_encode(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets, uint64_t n,
-                                                 DevTables t, EncCfg cfg, uint32_t* __restrict__ sizes, uint8_t* __restrict__ enc_status,
-                                                 uint64_t* __restrict__ block_sums, const uint64_t* __restrict__ out_offsets,
-                                                 uint8_t* __restrict__ out) {
-    constexpr uint32_t kSlots = Scratch<ENC>::kSlots;
+                                                 DevTables t, EncCfg cfg, uint32_t tile_cap, uint32_t cfg_lds, uint32_t* __restrict__ sizes,
+                                                 uint8_t* __restrict__ enc_status, uint64_t* __restrict__ block_sums,
+                                                 const uint64_t* __restrict__ out_offsets, uint8_t* __restrict__ out) {
+    constexpr uint32_t kSlots = SLOTS ? SLOTS : 1u;
     __shared__ uint64_t s_keys[kWave * kSlots];
     __shared__ uint8_t s_slot[kWave * kSlots];
     __shared__ uint8_t s_order[kWave * kSlots];
-    const uint64_t li = (uint64_t)blockIdx.x * kWave + threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_tile[];  // tile_cap + 16 bytes, then the configuration mirror
+    cfg.sort_slots = SLOTS;
+    if (cfg_lds) {  // every lane reads the same few hundred configuration bytes over and over: keep them in LDS
+        uint8_t* s_cfg = s_tile + tile_cap + 16u;
+        const uint8_t* g_cfg = reinterpret_cast<const uint8_t*>(cfg.keys);
+        for (uint32_t i = threadIdx.x * 4u; i < cfg_lds; i += kWave * 4u)
+            *reinterpret_cast<uint32_t*>(s_cfg + i) = *reinterpret_cast<const uint32_t*>(g_cfg + i);
+        cfg.blob = s_cfg + (cfg.blob - g_cfg);
+        cfg.keys = reinterpret_cast<const StaticKey*>(s_cfg);
+    }
+    const uint64_t g0 = (uint64_t)blockIdx.x * kWave;
+    const uint64_t g1 = g0 + kWave < n ? g0 + kWave : n;
+    const uint64_t li = g0 + threadIdx.x;
     uint64_t* keys64 = s_keys + threadIdx.x * kSlots;
     uint8_t* slot_ent = s_slot + threadIdx.x * kSlots;
     uint8_t* order = s_order + threadIdx.x * kSlots;
-    if (WRITE) {
-        if (li >= n) return;
-        const uint32_t meta = t.meta[li];
-        GlobalReader rd(reinterpret_cast<const uint32_t*>(bytes), offsets[li]);
-        const uint64_t o0 = out_offsets[li], total = out_offsets[li + 1] - o0;
-        WriteSink sink(out + o0);
-        emit::row_write<ENC>(sink, total, cfg, rd, t, li, meta, keys64, slot_ent, order);
-    } else {
-        uint32_t size = 0;
+    // the group's byte range (wave-uniform)
+    const uint64_t a_begin = offsets[g0], a_end = offsets[g1];
+    const uint64_t a0 = a_begin & ~15ull;
+    const uint64_t span = (a_end - a0 + 15ull) & ~15ull;
+    const bool staged = span <= (uint64_t)tile_cap;
+    uint32_t size = 0;
+    if (staged) {
+        stage_tile(bytes, a0, (uint32_t)span, s_tile);
+        __syncthreads();  // single-wave workgroup: orders the LDS writes before the lanes' reads
         if (li < n) {
-            const uint32_t meta = t.meta[li];
-            GlobalReader rd(reinterpret_cast<const uint32_t*>(bytes), offsets[li]);
-            uint32_t st;
-            size = emit::row_size<ENC>(cfg, rd, t, li, meta, keys64, slot_ent, order, &st);
-            sizes[li] = size;
-            if (enc_status) enc_status[li] = (uint8_t)st;
+            LdsReader rd(reinterpret_cast<const uint32_t*>(s_tile), (uint32_t)(offsets[li] - a0));
+            encode_lane<ENC, WRITE>(rd, li, t, cfg, keys64, slot_ent, order, sizes, enc_status, out_offsets, out, &size);
         }
-        // the 64 lines of this workgroup: one partial sum for the offset scan
+    } else if (li < n) {
+        GlobalReader rd(reinterpret_cast<const uint32_t*>(bytes), offsets[li]);
+        encode_lane<ENC, WRITE>(rd, li, t, cfg, keys64, slot_ent, order, sizes, enc_status, out_offsets, out, &size);
+    }
+    if (!WRITE) {  // the 64 lines of this workgroup: one partial sum for the offset scan
         uint64_t sum = size;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, kWave);
@@ -127,24 +131,29 @@ __global__ __launch_bounds__(kWave) void k_line_offsets(const uint32_t* __restri
 
 template <bool WRITE>
 static int launch_encode(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const DevTables& t, const EncCfg& cfg,
-                         uint32_t* d_sizes, uint8_t* d_status, uint64_t* d_block_sums, const uint64_t* d_out_offsets, uint8_t* d_out,
-                         hipStream_t stream) {
+                         uint32_t tile_cap, uint32_t cfg_lds, uint32_t* d_sizes, uint8_t* d_status, uint64_t* d_block_sums,
+                         const uint64_t* d_out_offsets, uint8_t* d_out, hipStream_t stream) {
     const uint64_t blocks = (n + kWave - 1) / kWave;
     if (blocks > 0x7FFFFFFFull) return -1;
     const dim3 g((uint32_t)blocks), b(kWave);
+    const uint32_t dyn_lds = tile_cap + 16u + cfg_lds;
+#define FG_LAUNCH(E, SL) \
+    hipLaunchKernelGGL((k_encode<E, WRITE, SL>), g, b, dyn_lds, stream, d_bytes, d_offsets, n, t, cfg, tile_cap, cfg_lds, d_sizes, d_status, \
+                       d_block_sums, d_out_offsets, d_out)
     switch (cfg.enc) {
-#define FG_CASE(E)                                                                                                              \
-    case E:                                                                                                                      \
-        hipLaunchKernelGGL((k_encode<E, WRITE>), g, b, 0, stream, d_bytes, d_offsets, n, t, cfg, d_sizes, d_status, d_block_sums, d_out_offsets, d_out); \
-        break;
-        FG_CASE(FG_ENC_GELF)
-        FG_CASE(FG_ENC_LTSV)
-        FG_CASE(FG_ENC_RFC5424)
-        FG_CASE(FG_ENC_RFC3164)
-        FG_CASE(FG_ENC_PASSTHROUGH)
-#undef FG_CASE
+        case FG_ENC_GELF:
+            // few pairs per line on average: a small ranking scratch (more LDS left for occupancy); a line with more
+            // pairs than slots takes the exact selection path
+            if (cfg.sort_slots <= 8u) FG_LAUNCH(FG_ENC_GELF, 8u);
+            else FG_LAUNCH(FG_ENC_GELF, emit::kSortSlots);
+            break;
+        case FG_ENC_LTSV: FG_LAUNCH(FG_ENC_LTSV, 0u); break;
+        case FG_ENC_RFC5424: FG_LAUNCH(FG_ENC_RFC5424, 0u); break;
+        case FG_ENC_RFC3164: FG_LAUNCH(FG_ENC_RFC3164, 0u); break;
+        case FG_ENC_PASSTHROUGH: FG_LAUNCH(FG_ENC_PASSTHROUGH, 0u); break;
         default: return -1;
     }
+#undef FG_LAUNCH
     return 0;
 }
 
@@ -152,18 +161,19 @@ static int launch_encode(const uint8_t* d_bytes, const uint64_t* d_offsets, uint
 
 // d_sizes: n u32; d_block_sums: ceil(n / 64) u64 (scratch)
 extern "C" int fg_launch_encode_sizes(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
-                                      const fg::EncCfg* cfg, uint32_t* d_sizes, uint64_t* d_block_sums, uint8_t* d_status,
-                                      uint64_t* d_out_offsets, hipStream_t stream) {
+                                      const fg::EncCfg* cfg, uint32_t tile_cap, uint32_t cfg_lds, uint32_t* d_sizes,
+                                      uint64_t* d_block_sums, uint8_t* d_status, uint64_t* d_out_offsets, hipStream_t stream) {
     if (n == 0) return 0;
-    if (fg::launch_encode<false>(d_bytes, d_offsets, n, *t, *cfg, d_sizes, d_status, d_block_sums, nullptr, nullptr, stream) != 0) return -1;
+    if (fg::launch_encode<false>(d_bytes, d_offsets, n, *t, *cfg, tile_cap, cfg_lds, d_sizes, d_status, d_block_sums, nullptr, nullptr, stream) != 0) return -1;
     const uint64_t nb = (n + fg::kWave - 1) / fg::kWave;
     hipLaunchKernelGGL(fg::k_block_scan, dim3(1), dim3(1024), 0, stream, d_block_sums, nb, d_out_offsets + n);
     hipLaunchKernelGGL(fg::k_line_offsets, dim3((uint32_t)nb), dim3(fg::kWave), 0, stream, d_sizes, d_block_sums, n, d_out_offsets);
     return (int)hipGetLastError();
 }
 extern "C" int fg_launch_encode_write(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
-                                      const fg::EncCfg* cfg, const uint64_t* d_out_offsets, uint8_t* d_out, hipStream_t stream) {
+                                      const fg::EncCfg* cfg, uint32_t tile_cap, uint32_t cfg_lds, const uint64_t* d_out_offsets,
+                                      uint8_t* d_out, hipStream_t stream) {
     if (n == 0) return 0;
-    if (fg::launch_encode<true>(d_bytes, d_offsets, n, *t, *cfg, nullptr, nullptr, nullptr, d_out_offsets, d_out, stream) != 0) return -1;
+    if (fg::launch_encode<true>(d_bytes, d_offsets, n, *t, *cfg, tile_cap, cfg_lds, nullptr, nullptr, nullptr, d_out_offsets, d_out, stream) != 0) return -1;
     return (int)hipGetLastError();
 }

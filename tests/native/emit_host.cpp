@@ -14,11 +14,11 @@ namespace {
 struct HostReader {
     const uint8_t* p;
     uint32_t byte(uint32_t i) { return p[i]; }
-};
-struct VecSink {
-    std::vector<uint8_t>* v;
-    void put(uint32_t c) { v->push_back((uint8_t)c); }
-    void finish() {}
+    uint32_t load4(uint32_t i, uint32_t nb) {
+        uint32_t w = 0;
+        memcpy(&w, p + i, nb);  // never reads past the wanted bytes: the line buffer has no padding
+        return w;
+    }
 };
 struct Cur {
     const uint8_t* p;
@@ -30,6 +30,7 @@ struct Cur {
     std::string str() { uint32_t l = u32(); if (i + l > n) { ok = false; return ""; } std::string s((const char*)p + i, l); i += l; return s; }
 };
 uint64_t rng_state;
+uint32_t g_sort_slots = fg::emit::kSortSlots;
 uint32_t rnd() {
     rng_state = rng_state * 6364136223846793005ull + 1442695040888963407ull;
     return (uint32_t)(rng_state >> 33);
@@ -95,6 +96,9 @@ std::string json_escape_src(const std::string& s, bool* esc) {
     return o;
 }
 }  // namespace
+
+// the GELF ranking scratch size the kernels pick per batch (8 or 32)
+extern "C" void fge_set_sort_slots(uint32_t n) { g_sort_slots = n; }
 
 // enc / merger: fg_encoder / fg_merger.  src_fmt: which decoder the synthetic row pretends to come from (escape style).
 // gelf_key_variant (src_fmt == FG_GELF): 0 = key spans include the leading '_', 1 = they do not (the decoder adds it).
@@ -223,8 +227,8 @@ extern "C" int64_t fge_encode_canonical(int enc, int merger, int src_fmt, int ge
     const bool has_suffix[4] = {false, false, false, false};
     fg::EncCfgHost h;
     if (!fg::build_enc_cfg((fg_format)src_fmt, &ec, suffix, has_suffix, &h)) return -1;
-    h.blob.resize(h.blob.size() + 16);
     h.cfg.blob = h.blob.data();
+    h.cfg.sort_slots = g_sort_slots;
     h.cfg.keys = h.keys.data();
 
     uint64_t keys64[fg::emit::kSortSlots];
@@ -232,23 +236,37 @@ extern "C" int64_t fge_encode_canonical(int enc, int merger, int src_fmt, int ge
     HostReader rd{(const uint8_t*)line.data()};
     uint32_t st = 0, size = 0;
     std::vector<uint8_t> res;
-    VecSink sink{&res};
+    // the write pass runs through the kernels' PackSink at all four start alignments, inside a guarded buffer: nothing
+    // outside [start, start + size) may change
+    for (uint32_t al = 0; al < 4; ++al) {
+        std::vector<uint8_t> buf;
 #define RUN(E)                                                                                                  \
-    case E:                                                                                                     \
+    case E: {                                                                                                   \
         size = fg::emit::row_size<E>(h.cfg, rd, t, li, meta[li], keys64, slot_ent, order, &st);               \
+        buf.assign((size_t)size + 64, 0xA5);                                                                    \
+        uint8_t* start = buf.data() + 16;                                                                       \
+        start += (al - ((uintptr_t)start & 3u)) & 3u;                                                           \
+        fg::emit::PackSink sink(start);                                                                         \
         fg::emit::row_write<E>(sink, size, h.cfg, rd, t, li, meta[li], keys64, slot_ent, order);              \
-        break;
-    switch (enc) {
-        RUN(FG_ENC_GELF)
-        RUN(FG_ENC_LTSV)
-        RUN(FG_ENC_RFC5424)
-        RUN(FG_ENC_RFC3164)
-        RUN(FG_ENC_PASSTHROUGH)
-        default: return -1;
+        for (uint8_t* q = buf.data(); q < buf.data() + buf.size(); ++q)                                         \
+            if ((q < start || q >= start + size) && *q != 0xA5) return -4;                                      \
+        if (size && sink.p != start + size) return -3; /* count and write passes disagree */                   \
+        std::vector<uint8_t> got(start, start + size);                                                          \
+        if (al && got != res) return -5;                                                                        \
+        res = got;                                                                                              \
+        break;                                                                                                  \
     }
+        switch (enc) {
+            RUN(FG_ENC_GELF)
+            RUN(FG_ENC_LTSV)
+            RUN(FG_ENC_RFC5424)
+            RUN(FG_ENC_RFC3164)
+            RUN(FG_ENC_PASSTHROUGH)
+            default: return -1;
+        }
 #undef RUN
+    }
     if (status) *status = st;
-    if (res.size() != size) return -3;  // count and write passes disagree
     if (out && res.size() <= cap) memcpy(out, res.data(), res.size());
     return (int64_t)res.size();
 }

@@ -44,6 +44,7 @@ def emit():
         assert n >= 0, n
         assert n <= len(buf)
         return (buf.raw[:n] if st.value == 0 else ES[st.value])
+    run.set_sort_slots = L.fge_set_sort_slots
     return run
 
 
@@ -138,6 +139,22 @@ def test_emitters_equal_oracle_on_random_records(emit, oracle, src, enc):
         assert got == want, (i, rec, merger, extra, prepend)
         n_ok += isinstance(want, bytes)
     assert n_ok > 100
+
+
+def test_gelf_emitter_with_the_small_ranking_scratch(emit, oracle):
+    """the kernels pick an 8-entry ranking scratch for batches with few pairs per line: lines with more pairs take the
+    exact selection path and must give the same bytes"""
+    emit.set_sort_slots(8)
+    try:
+        r = random.Random(77)
+        for i in range(600):
+            src = r.choice([RFC5424, LTSV, GELF])
+            rec = rrecord(r, src)
+            cb = canonical(**rec)
+            extra = r.choice([None, {"_k": "shadow", "host": "h2"}])
+            assert emit(OB.ENC_GELF, 1, src, cb, extra=extra, variant=i & 1, seed=i) == oracle.encode(OB.ENC_GELF, cb, 1, extra=extra), (i, rec)
+    finally:
+        emit.set_sort_slots(32)
 
 
 def test_ts_now_uses_the_callers_clock(emit, oracle):
