@@ -36,7 +36,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--tile-lines", type=int, default=1_000_000)
     ap.add_argument("--reps", type=int, default=100, help="tile replicas resident per GPU")
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5", "ltsv", "ltsv5", "frame", "cfg1"],
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5", "ltsv", "ltsv5", "frame", "cfg1", "rfc3164"],
                     help="cfg2 = the BASELINE metric's configuration (default); the others time the remaining "
                          "kernels on their parity-test corpora (not bench lines, see DESIGN.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -55,6 +55,7 @@ WORKLOADS = {
     "ltsv": (1, "LTSV, typed schema (the LTSV half of BASELINE configs[4])"),
     "ltsv5": (1, "BASELINE configs[4] shape, LTSV half: log-uniform 64 B..8 KiB lines"),
     "frame": (0, "GPU framing + UTF-8 validation of the newline-terminated cfg2 stream (SURVEY 8f-1), then decode of the frames"),
+    "rfc3164": (3, "RFC3164 (BSD syslog) decoder, both forms, 15 % with IANA zone names (SURVEY 8f-3)"),
     "cfg1": (0, "BASELINE configs[0] pipeline on the GPU: RFC5424 decode -> GELF encoder -> line merger (SURVEY 8f-2/8f-4), cfg2 corpus"),
 }
 
@@ -65,6 +66,10 @@ def cpu_baseline(fmt, data, offsets, n_lines, cfg=None):
     import oracle_binding
 
     o = oracle_binding.Oracle()
+    if fmt == 3:
+        from flowgger_amd import tzdb
+
+        o.set_rfc3164(2026, tzdb.default_table())
     cores = os.cpu_count() or 1
     passes, secs, n_ok = 0, 0.0, 0
     t_end = time.time() + 4.0  # a few seconds of wall time on every host core = tens of CPU-seconds
@@ -107,6 +112,8 @@ def main():
         lines = synth.gelf_lines(args.tile_lines, invalid_frac=args.invalid_frac)
     elif wl in ("ltsv", "ltsv5"):
         lines = synth.ltsv_lines(args.tile_lines, invalid_frac=args.invalid_frac, long_tail=wl == "ltsv5")
+    elif wl == "rfc3164":
+        lines = synth.rfc3164_lines(args.tile_lines, invalid_frac=args.invalid_frac)
     elif wl == "frame":
         lines = [ln + b"\n" for ln in synth.rfc5424_lines(args.tile_lines, cfg=2, invalid_frac=args.invalid_frac)]
     elif wl == "cfg5":
@@ -127,8 +134,13 @@ def main():
     del base, o, raw
     ent_cap = (tile_bytes * reps // 8 if wl != "cfg2" else 0) + 4096
     tables = DeviceTables(n, ent_cap, dev)
-    dec = (GelfDecoder(device=local) if fmt == 2 else LTSVDecoder(synth.LTSV_CONFIG, device=local) if fmt == 1
-           else RFC5424Decoder(device=local))
+    if fmt == 3:
+        from flowgger_amd import RFC3164Decoder
+
+        dec = RFC3164Decoder({"rfc3164": {"current_year": 2026}}, device=local)
+    else:
+        dec = (GelfDecoder(device=local) if fmt == 2 else LTSVDecoder(synth.LTSV_CONFIG, device=local) if fmt == 1
+               else RFC5424Decoder(device=local))
     stream = torch.cuda.current_stream(dev)
 
     frame_ms = None
@@ -223,7 +235,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                "kernel": ("fg::k_rfc5424", "fg::k_ltsv", "fg::k_gelf")[fmt], "kernel_ms": kernel_ms,
+                "kernel": ("fg::k_rfc5424", "fg::k_ltsv", "fg::k_gelf", "fg::k_rfc3164")[fmt], "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_launch": alg_read + alg_written,
                 "read_only_frac": alg_read / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             },

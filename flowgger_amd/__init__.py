@@ -4,10 +4,10 @@ Scope: the per-line ``Decoder::decode()`` hot path (RFC5424, LTSV, GELF) of awsl
 rebuilt as hand-written HIP kernels behind a C ABI (include/fg_hip.h).  See DESIGN.md.
 """
 from .record import DecodeError, Record, SDValue, StructuredData  # noqa: F401
-from .decoder import Decoder, GelfDecoder, LTSVDecoder, RFC5424Decoder, pack_lines  # noqa: F401
+from .decoder import Decoder, GelfDecoder, LTSVDecoder, RFC3164Decoder, RFC5424Decoder, pack_lines  # noqa: F401
 from .encoder import (Encoder, GelfEncoder, LTSVEncoder, PassthroughEncoder, RFC3164Encoder,  # noqa: F401
                       RFC5424Encoder)
 
-__all__ = ["Decoder", "RFC5424Decoder", "LTSVDecoder", "GelfDecoder", "Record", "StructuredData",
+__all__ = ["Decoder", "RFC5424Decoder", "RFC3164Decoder", "LTSVDecoder", "GelfDecoder", "Record", "StructuredData",
            "SDValue", "DecodeError", "pack_lines", "Encoder", "GelfEncoder", "LTSVEncoder", "RFC5424Encoder",
            "RFC3164Encoder", "PassthroughEncoder"]

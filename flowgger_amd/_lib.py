@@ -8,7 +8,7 @@ from pathlib import Path
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libfg_hip.so"
 
-FG_RFC5424, FG_LTSV, FG_GELF = 0, 1, 2
+FG_RFC5424, FG_LTSV, FG_GELF, FG_RFC3164 = 0, 1, 2, 3
 FG_FRAME_NONE, FG_FRAME_LINE, FG_FRAME_NUL = 0, 1, 2
 FG_ST_OVERFLOW, FG_ST_BAD_UTF8 = 0xFE, 0xFD
 FG_OK, FG_ERR_ARG, FG_ERR_HIP, FG_ERR_NO_DEVICE, FG_ERR_ENT_OVERFLOW, FG_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
@@ -56,6 +56,15 @@ FG_MERGE_NONE, FG_MERGE_LINE, FG_MERGE_NUL, FG_MERGE_SYSLEN = range(4)
 class fg_encode_cfg(C.Structure):
     _fields_ = [("encoder", C.c_int), ("merger", C.c_int), ("n_extra", C.c_uint32), ("extra_keys", C.POINTER(C.c_char_p)),
                 ("extra_values", C.POINTER(C.c_char_p)), ("prepend", C.c_char_p), ("now_ts", C.c_double)]
+
+
+class fg_tz_table(C.Structure):
+    _fields_ = [("n_zones", C.c_uint32), ("names", C.POINTER(C.c_char_p)), ("zone_first", C.c_void_p), ("utc_start", C.c_void_p),
+                ("utc_offset", C.c_void_p)]
+
+
+class fg_rfc3164_cfg(C.Structure):
+    _fields_ = [("current_year", C.c_int32), ("tz", C.POINTER(fg_tz_table))]
 
 
 class fg_cfg(C.Structure):
@@ -110,6 +119,7 @@ def lib() -> C.CDLL:
                                    C.POINTER(u64), vp]
     L.fg_encode_error_string.argtypes = [C.c_uint8]
     L.fg_encode_error_string.restype = C.c_char_p
+    L.fg_set_rfc3164.argtypes = [vp, C.POINTER(fg_rfc3164_cfg)]
     L.fg_alloc_pinned.argtypes = [u64, C.POINTER(vp)]
     L.fg_free_pinned.argtypes = [vp]
     L.fg_free_pinned.restype = None

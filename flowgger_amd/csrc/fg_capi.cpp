@@ -17,6 +17,7 @@
 #include "../../include/fg_hip.h"
 #include "fg_device.hpp"
 #include "fg_enc_cfg.hpp"
+#include "fg_rfc3164_parse.hpp"
 
 namespace fg {
 // device view of input.ltsv_schema / input.ltsv_suffixes (must match fg_ltsv.hip)
@@ -35,6 +36,9 @@ extern "C" int fg_launch_rfc5424(const uint8_t* d_bytes, const uint64_t* d_offse
                                  uint64_t avg_len, hipStream_t stream, uint64_t* stash, uint32_t stash_blocks, uint32_t strip,
                                  const uint8_t* line_bad);
 extern "C" uint64_t fg_stash_bytes(uint32_t blocks);
+extern "C" int fg_launch_rfc3164(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
+                                 const fg::r3164::Cfg* cfg, uint32_t tile_cap, hipStream_t stream, uint32_t strip,
+                                 const uint8_t* line_bad);
 extern "C" int fg_launch_encode_sizes(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
                                       const fg::EncCfg* cfg, uint32_t tile_cap, uint32_t cfg_lds, uint32_t* d_sizes,
                                       uint64_t* d_block_sums, uint8_t* d_status, uint64_t* d_out_offsets, hipStream_t stream);
@@ -76,6 +80,15 @@ struct fg_ctx {
     uint64_t d_bad_cap = 0;
     uint64_t* h_off = nullptr;   // fg_frame_decode_batch: pinned host copy of the frame offsets
     uint64_t h_off_cap = 0;
+    // RFC3164 configuration: host copies (for fg_clone) + one device block [names | name_off | zone_first | utc_start | utc_off]
+    bool r3164_set = false;
+    int32_t r3164_year = 1970;
+    std::vector<std::string> tz_names;
+    std::vector<uint32_t> tz_first;
+    std::vector<int64_t> tz_start;
+    std::vector<int32_t> tz_off;
+    uint8_t* d_tz = nullptr;
+    fg::r3164::Cfg r3164{};
     uint8_t* d_enc = nullptr;    // fg_encode_gelf_device: static key list + blob, then the per-line sizes
     uint64_t d_enc_cap = 0;
     fg::LtsvDevCfg ltsv{};
@@ -329,6 +342,8 @@ int fg_create(int device, const fg_cfg* cfg, fg_ctx** out) {
     return FG_OK;
 }
 
+static int upload_tz(fg_ctx* ctx);
+
 int fg_clone(const fg_ctx* src, fg_ctx** out) {
     if (!src || !out) return FG_ERR_ARG;
     fg_ctx* ctx = new (std::nothrow) fg_ctx();
@@ -349,6 +364,18 @@ int fg_clone(const fg_ctx* src, fg_ctx** out) {
         fg_destroy(ctx);
         return FG_ERR_HIP;
     }
+    if (src->r3164_set) {
+        ctx->r3164_set = true;
+        ctx->r3164_year = src->r3164_year;
+        ctx->tz_names = src->tz_names;
+        ctx->tz_first = src->tz_first;
+        ctx->tz_start = src->tz_start;
+        ctx->tz_off = src->tz_off;
+        if (upload_tz(ctx) != FG_OK) {
+            fg_destroy(ctx);
+            return FG_ERR_HIP;
+        }
+    }
     *out = ctx;
     return FG_OK;
 }
@@ -367,6 +394,7 @@ void fg_destroy(fg_ctx* ctx) {
     if (ctx->d_frame) (void)hipFree(ctx->d_frame);
     if (ctx->d_bad) (void)hipFree(ctx->d_bad);
     if (ctx->d_enc) (void)hipFree(ctx->d_enc);
+    if (ctx->d_tz) (void)hipFree(ctx->d_tz);
     if (ctx->h_off) (void)hipHostFree(ctx->h_off);
     if (ctx->h_tab) (void)hipHostFree(ctx->h_tab);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
@@ -485,6 +513,11 @@ static int decode_frames_impl(fg_ctx* ctx, fg_format fmt, fg_framing framing, co
         case FG_GELF:
             rc = fg_launch_gelf(d_bytes, d_offsets, n, &dt, (nbytes + n - 1) / n, s, ctx->d_stash, ctx->stash_blocks,
                                 (uint32_t)framing, d_bad_utf8);
+            break;
+        case FG_RFC3164:
+            if (!ctx->r3164_set) return FG_ERR_ARG;  // fg_set_rfc3164 first
+            rc = fg_launch_rfc3164(d_bytes, d_offsets, n, &dt, &ctx->r3164, pick_tile_cap(nbytes, n, 56 * 1024), s, (uint32_t)framing,
+                                   d_bad_utf8);
             break;
         default:
             return FG_ERR_UNSUPPORTED;
@@ -713,7 +746,7 @@ int fg_encode_device(fg_ctx* ctx, fg_format src_fmt, const fg_encode_cfg* ecfg, 
                      const uint64_t* d_offsets, uint64_t n, const fg_tables* tables, uint8_t* d_out, uint64_t out_cap,
                      uint64_t* d_out_offsets, uint8_t* d_enc_status, uint64_t* total, void* stream) {
     if (!ctx || !ecfg || !tables || !d_out_offsets || !total || (n && (!d_offsets || !tables->meta))) return FG_ERR_ARG;
-    if ((int)src_fmt < 0 || (int)src_fmt > (int)FG_GELF) return FG_ERR_ARG;
+    if ((int)src_fmt < 0 || (int)src_fmt > (int)FG_RFC3164) return FG_ERR_ARG;
     if (tables->n < n) return FG_ERR_ARG;
     DeviceGuard g(ctx->device);
     hipStream_t s = stream == FG_STREAM_OWN ? ctx->stream : (hipStream_t)stream;
@@ -797,6 +830,79 @@ const char* fg_encode_error_string(uint8_t st) {
     return nullptr;
 }
 
+const char* const kErr3164[] = {
+    "",
+    "Malformed RFC3164 event: Invalid priority",               // rfc3164_decoder.rs:128-130
+    "Invalid priority",                                        // :136
+    "Malformed RFC3164 event: Invalid timestamp or hostname",  // :121
+    "Invalid time format",                                     // :158
+    "Unable to parse RFC3164 date with year",                  // :176
+    "Unable to parse the date in RFC3164 decoder",             // :211
+    "<the reference panics here: index out of bounds (rfc3164_decoder.rs:67)>",
+};
+
+static int upload_tz(fg_ctx* ctx) {
+    DeviceGuard g(ctx->device);
+    if (ctx->d_tz) {
+        (void)hipFree(ctx->d_tz);
+        ctx->d_tz = nullptr;
+    }
+    ctx->r3164 = fg::r3164::Cfg{};
+    ctx->r3164.current_year = ctx->r3164_year;
+    const uint32_t nz = (uint32_t)ctx->tz_names.size();
+    if (nz == 0) return FG_OK;
+    std::vector<uint8_t> names;
+    std::vector<uint32_t> name_off(nz + 1, 0);
+    for (uint32_t z = 0; z < nz; ++z) {
+        name_off[z] = (uint32_t)names.size();
+        names.insert(names.end(), ctx->tz_names[z].begin(), ctx->tz_names[z].end());
+    }
+    name_off[nz] = (uint32_t)names.size();
+    const uint64_t ne = ctx->tz_start.size();
+    const uint64_t o_off = up(names.size(), 16), o_first = o_off + up((nz + 1) * 4, 16), o_start = o_first + up((nz + 1) * 4, 16),
+                   o_utc = o_start + up(ne * 8, 16), total = o_utc + up(ne * 4, 16);
+    std::vector<uint8_t> host(total, 0);
+    memcpy(host.data(), names.data(), names.size());
+    memcpy(host.data() + o_off, name_off.data(), (nz + 1) * 4);
+    memcpy(host.data() + o_first, ctx->tz_first.data(), (nz + 1) * 4);
+    memcpy(host.data() + o_start, ctx->tz_start.data(), ne * 8);
+    memcpy(host.data() + o_utc, ctx->tz_off.data(), ne * 4);
+    FG_HIP(ctx, hipMalloc((void**)&ctx->d_tz, total));
+    FG_HIP(ctx, hipMemcpy(ctx->d_tz, host.data(), total, hipMemcpyHostToDevice));
+    fg::r3164::TzView& v = ctx->r3164.tz;
+    v.names = ctx->d_tz;
+    v.name_off = reinterpret_cast<const uint32_t*>(ctx->d_tz + o_off);
+    v.nz = nz;
+    v.zone_first = reinterpret_cast<const uint32_t*>(ctx->d_tz + o_first);
+    v.utc_start = reinterpret_cast<const int64_t*>(ctx->d_tz + o_start);
+    v.utc_off = reinterpret_cast<const int32_t*>(ctx->d_tz + o_utc);
+    return FG_OK;
+}
+
+int fg_set_rfc3164(fg_ctx* ctx, const fg_rfc3164_cfg* cfg) {
+    if (!ctx || !cfg) return FG_ERR_ARG;
+    ctx->r3164_year = cfg->current_year;
+    ctx->tz_names.clear();
+    ctx->tz_first.clear();
+    ctx->tz_start.clear();
+    ctx->tz_off.clear();
+    if (cfg->tz && cfg->tz->n_zones) {
+        const fg_tz_table* t = cfg->tz;
+        if (!t->names || !t->zone_first || !t->utc_start || !t->utc_offset) return FG_ERR_ARG;
+        for (uint32_t z = 0; z < t->n_zones; ++z) {
+            if (!t->names[z] || t->zone_first[z + 1] <= t->zone_first[z]) return FG_ERR_ARG;
+            if (z && strcmp(t->names[z - 1], t->names[z]) >= 0) return FG_ERR_ARG;  // sorted bytewise, unique
+            ctx->tz_names.emplace_back(t->names[z]);
+        }
+        ctx->tz_first.assign(t->zone_first, t->zone_first + t->n_zones + 1);
+        const uint32_t ne = t->zone_first[t->n_zones];
+        ctx->tz_start.assign(t->utc_start, t->utc_start + ne);
+        ctx->tz_off.assign(t->utc_offset, t->utc_offset + ne);
+    }
+    ctx->r3164_set = true;
+    return upload_tz(ctx);
+}
+
 const char* fg_error_string(fg_format fmt, uint8_t status) {
     if (status == FG_ST_BAD_UTF8) return "Invalid UTF-8 input";  // line_splitter.rs:23, nul_splitter.rs:36
     switch (fmt) {
@@ -806,6 +912,8 @@ const char* fg_error_string(fg_format fmt, uint8_t status) {
             return status < sizeof(kErrLtsv) / sizeof(*kErrLtsv) ? kErrLtsv[status] : nullptr;
         case FG_GELF:
             return status < sizeof(kErrGelf) / sizeof(*kErrGelf) ? kErrGelf[status] : nullptr;
+        case FG_RFC3164:
+            return status < sizeof(kErr3164) / sizeof(*kErr3164) ? kErr3164[status] : nullptr;
     }
     return nullptr;
 }

@@ -21,6 +21,7 @@
 #include <string.h>
 
 #include "fg_dtoa.hpp"
+#include "fg_rfc3164_parse.hpp"
 #include "fg_shortest.hpp"
 #include "fg_tables_view.hpp"
 #include "fg_timeconv.hpp"
@@ -69,7 +70,7 @@ enum : uint32_t {
 
 namespace emit {
 
-enum : uint32_t { M_RAW = 0, M_SD = 1, M_JSON = 2, M_JSON_RETRY = 3 };
+enum : uint32_t { M_RAW = 0, M_SD = 1, M_JSON = 2, M_JSON_RETRY = 3, M_WSJOIN = 4 };
 
 FGE_HD uint32_t hexv(uint32_t c) {
     if (c - '0' <= 9u) return c - '0';
@@ -95,6 +96,22 @@ FGE_HD void for_each_decoded(R& rd, uint32_t off, uint32_t len, uint32_t mode, F
                 f(c);
                 esc = false;
             }
+        }
+    } else if (mode == M_WSJOIN) {  // str::split_whitespace(..).join(" ") (RFC3164 msg, rfc3164_decoder.rs:70)
+        bool in_tok = false, any = false;
+        for (uint32_t i = 0; i < len;) {
+            const uint32_t w = r3164::ws_at(rd, off + i, off + len);
+            if (w) {
+                in_tok = false;
+                i += w;
+                continue;
+            }
+            if (!in_tok) {
+                if (any) f((uint32_t)' ');
+                in_tok = any = true;
+            }
+            f(rd.byte(off + i));
+            ++i;
         }
     } else {  // JSON escapes of an already validated string body
         const bool retry = mode == M_JSON_RETRY;
@@ -226,6 +243,7 @@ struct Base {
     FGE_HD uint32_t json_mode() const { return (flags() & FG_F_GELF_RETRY) ? (uint32_t)M_JSON_RETRY : (uint32_t)M_JSON; }
     // decode mode of a top-level string field
     FGE_HD uint32_t field_mode(int col) const {
+        if (cfg.src_fmt == FG_RFC3164) return (col == S_MSG && (flags() & FG_F_MSG_JOIN)) ? (uint32_t)M_WSJOIN : (uint32_t)M_RAW;
         if (cfg.src_fmt != FG_GELF) return M_RAW;
         const uint32_t bit = col == S_HOST ? FG_F_HOST_ESC : col == S_MSG ? FG_F_MSG_ESC : col == S_FULL ? FG_F_FULLMSG_ESC : 0u;
         return (flags() & bit) ? json_mode() : (uint32_t)M_RAW;

@@ -96,6 +96,40 @@ void json_unescape(const uint8_t* p, uint32_t len, std::string* out, bool retry 
         }
     }
 }
+// byte length of the Unicode White_Space character at p[i] (0: none)
+uint32_t ws_len(const uint8_t* p, uint32_t i, uint32_t n) {
+    const uint8_t c = p[i];
+    if (c < 0x80) return (c == 32 || (c >= 9 && c <= 13)) ? 1 : 0;
+    if (c == 0xC2 && i + 1 < n) return (p[i + 1] == 0x85 || p[i + 1] == 0xA0) ? 2 : 0;
+    if (i + 2 >= n) return 0;
+    const uint8_t b1 = p[i + 1], b2 = p[i + 2];
+    if (c == 0xE2) {
+        if (b1 == 0x80) return ((b2 >= 0x80 && b2 <= 0x8A) || b2 == 0xA8 || b2 == 0xA9 || b2 == 0xAF) ? 3 : 0;
+        return (b1 == 0x81 && b2 == 0x9F) ? 3 : 0;
+    }
+    if (c == 0xE1) return (b1 == 0x9A && b2 == 0x80) ? 3 : 0;
+    if (c == 0xE3) return (b1 == 0x80 && b2 == 0x80) ? 3 : 0;
+    return 0;
+}
+// str::split_whitespace(..).join(" ")
+void ws_join(const uint8_t* p, uint32_t len, std::string* out) {
+    out->clear();
+    bool in_tok = false, any = false;
+    for (uint32_t i = 0; i < len;) {
+        const uint32_t w = ws_len(p, i, len);
+        if (w) {
+            in_tok = false;
+            i += w;
+            continue;
+        }
+        if (!in_tok) {
+            if (any) out->push_back(' ');
+            in_tok = any = true;
+        }
+        out->push_back((char)p[i]);
+        ++i;
+    }
+}
 // rfc5424_decoder.rs:105-125
 void sd_unescape(const uint8_t* p, uint32_t len, std::string* out) {
     out->clear();
@@ -119,7 +153,7 @@ extern "C" int64_t fg_tables_serialize(fg_format fmt, const fg_cfg* cfg, const u
                                        const fg_tables* t, uint64_t i0, uint64_t i1, uint8_t* out, uint64_t cap,
                                        uint64_t* out_offsets) {
     if (!t || !offsets || i1 < i0 || i1 > t->n) return FG_ERR_ARG;
-    if ((int)fmt < 0 || (int)fmt > 2) return FG_ERR_ARG;
+    if ((int)fmt < 0 || (int)fmt > (int)FG_RFC3164) return FG_ERR_ARG;
     Sink k{out, cap};
     std::string tmp;
     const char* suffix[6] = {nullptr, cfg ? cfg->suffix_bool : nullptr, cfg ? cfg->suffix_f64 : nullptr,
@@ -156,6 +190,10 @@ extern "C" int64_t fg_tables_serialize(fg_format fmt, const fg_cfg* cfg, const u
             k.u8(1);
             if (fmt == FG_GELF && (flags & esc_flag[c])) {
                 json_unescape(line + s.off, s.len, &tmp, (flags & FG_F_GELF_RETRY) != 0);
+                k.u32((uint32_t)tmp.size());
+                k.put(tmp.data(), tmp.size());
+            } else if (fmt == FG_RFC3164 && c == 4 && (flags & FG_F_MSG_JOIN)) {
+                ws_join(line + s.off, s.len, &tmp);  // `_log_tokens[1..].join(" ")`, rfc3164_decoder.rs:70
                 k.u32((uint32_t)tmp.size());
                 k.put(tmp.data(), tmp.size());
             } else {

@@ -1,0 +1,369 @@
+// fg_rfc3164_parse.hpp -- RFC3164Decoder::decode for ONE line, host + device.
+// reference: src/flowgger/decoder/rfc3164_decoder.rs:31-213
+//
+//   decode            :31-50   parse_strip_pri, then the "standard" form, then the "custom" form; the custom form's
+//                              error is the one that surfaces
+//   decode_rfc_standard :57-88 [<pri>]<date> [tz] <hostname> <message...>, split on Unicode whitespace;
+//                              msg = remaining tokens re-joined with ONE space (so: a span + FG_F_MSG_JOIN)
+//   decode_rfc_custom :90-123  [<pri>]<hostname>: <date> [tz]: <message>  split on ": "
+//   parse_strip_pri   :125-153
+//   parse_date_token / parse_date :155-213   "[year] [month repr:short] [day padding:none] [hour]:[minute]:[second]",
+//                              first with the CURRENT year prepended (configuration: the reference reads the clock),
+//                              then with the year taken from the line; the token after the time may be an IANA zone
+//                              name (time_tz::timezones::get_by_name -> the fg_tz_table of the configuration)
+//
+// One input can PANIC the reference (index out of bounds, :67: the date [+ zone] consumes every token of a line with
+// more than three tokens): status ST_REF_PANIC.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#include "fg_timeconv.hpp"
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define FG3_HD __host__ __device__ __forceinline__
+#else
+#define FG3_HD inline
+#endif
+
+namespace fg {
+namespace r3164 {
+
+enum : uint32_t {
+    ST_OK = 0,
+    ST_PRI_MALFORMED = 1,  // "Malformed RFC3164 event: Invalid priority"              :128-130
+    ST_PRI_INVALID = 2,    // "Invalid priority"                                       :136
+    ST_MALFORMED = 3,      // "Malformed RFC3164 event: Invalid timestamp or hostname"  :121
+    ST_TIME_FORMAT = 4,    // "Invalid time format"                                    :158
+    ST_DATE_YEAR = 5,      // "Unable to parse RFC3164 date with year"                 :176
+    ST_DATE = 6,           // "Unable to parse the date in RFC3164 decoder"            :211
+    ST_REF_PANIC = 7       // the reference panics (index out of bounds, :67)
+};
+
+struct TzView {
+    const uint8_t* names;        // concatenated zone names, sorted bytewise
+    const uint32_t* name_off;    // [nz + 1]
+    uint32_t nz;
+    const uint32_t* zone_first;  // [nz + 1] into utc_start / utc_off
+    const int64_t* utc_start;    // the offset utc_off[i] is in effect from utc_start[i] (first entry: INT64_MIN)
+    const int32_t* utc_off;
+};
+struct Cfg {
+    int32_t current_year;
+    TzView tz;
+};
+struct Row {
+    uint32_t status = ST_OK;
+    uint32_t fac = 0xFFu, sev = 0xFFu;  // 0xFF = None
+    bool msg_join = false;                // msg = split_whitespace(span).join(" ")
+    double ts = 0.0;
+    uint32_t host_off = 0, host_len = 0, msg_off = 0, msg_len = 0, full_len = 0;
+};
+
+// byte length of the Unicode White_Space character starting at rd[i] (0: not whitespace); char::is_whitespace
+template <class R>
+FG3_HD uint32_t ws_at(R& rd, uint32_t i, uint32_t end) {
+    const uint32_t c = rd.byte(i);
+    if (c < 0x80u) return (c == 32u || (c - 9u) <= 4u) ? 1u : 0u;
+    if (c == 0xC2u) {
+        if (i + 1 >= end) return 0;
+        const uint32_t d = rd.byte(i + 1);
+        return (d == 0x85u || d == 0xA0u) ? 2u : 0u;
+    }
+    if (c == 0xE1u || c == 0xE2u || c == 0xE3u) {
+        if (i + 2 >= end) return 0;
+        const uint32_t b1 = rd.byte(i + 1), b2 = rd.byte(i + 2);
+        if (c == 0xE2u) {
+            if (b1 == 0x80u) return ((b2 - 0x80u) <= 0x0Au || b2 == 0xA8u || b2 == 0xA9u || b2 == 0xAFu) ? 3u : 0u;
+            return (b1 == 0x81u && b2 == 0x9Fu) ? 3u : 0u;
+        }
+        if (c == 0xE1u) return (b1 == 0x9Au && b2 == 0x80u) ? 3u : 0u;
+        return (b1 == 0x80u && b2 == 0x80u) ? 3u : 0u;
+    }
+    return 0;
+}
+// str::split_whitespace: the next token of rd[pos .. end); false when there is none
+template <class R>
+FG3_HD bool next_token(R& rd, uint32_t& pos, uint32_t end, uint32_t* ts, uint32_t* te) {
+    while (pos < end) {
+        const uint32_t w = ws_at(rd, pos, end);
+        if (!w) break;
+        pos += w;
+    }
+    if (pos >= end) return false;
+    *ts = pos;
+    while (pos < end && !ws_at(rd, pos, end)) ++pos;  // (continuation bytes are never whitespace lead bytes)
+    *te = pos;
+    return true;
+}
+// str::trim_end of rd[s .. e): the new end
+template <class R>
+FG3_HD uint32_t trim_end_ws(R& rd, uint32_t s, uint32_t e) {
+    while (e > s) {
+        const uint32_t c = rd.byte(e - 1);
+        if (c < 0x80u) {
+            if (!(c == 32u || (c - 9u) <= 4u)) break;
+            e -= 1;
+        } else if (e - s >= 2 && ws_at(rd, e - 2, e) == 2u) {
+            e -= 2;
+        } else if (e - s >= 3 && ws_at(rd, e - 3, e) == 3u) {
+            e -= 3;
+        } else {
+            break;
+        }
+    }
+    return e;
+}
+
+struct Tok {
+    uint32_t s, e;
+};
+constexpr uint32_t kMaxTok = 7;  // year month day time zone hostname first-message-token
+
+template <class R>
+FG3_HD bool two_digits(R& rd, uint32_t at, uint32_t* v) {
+    const uint32_t a = rd.byte(at) - '0', b = rd.byte(at + 1) - '0';
+    if (a > 9u || b > 9u) return false;
+    *v = a * 10u + b;
+    return true;
+}
+// [month repr:short] [day padding:none] [hour]:[minute]:[second] from three whole tokens + a year -> seconds of the
+// PrimitiveDateTime taken as UTC
+template <class R>
+FG3_HD bool parse_mdt(R& rd, const Tok& mon, const Tok& day, const Tok& tim, int year, int64_t* local_secs) {
+    if (mon.e - mon.s != 3u) return false;
+    const uint32_t m3 = rd.byte(mon.s) << 16 | rd.byte(mon.s + 1) << 8 | rd.byte(mon.s + 2);
+    int month = 0;
+    switch (m3) {  // case-sensitive
+        case 0x4A616Eu: month = 1; break;   // Jan
+        case 0x466562u: month = 2; break;   // Feb
+        case 0x4D6172u: month = 3; break;   // Mar
+        case 0x417072u: month = 4; break;   // Apr
+        case 0x4D6179u: month = 5; break;   // May
+        case 0x4A756Eu: month = 6; break;   // Jun
+        case 0x4A756Cu: month = 7; break;   // Jul
+        case 0x417567u: month = 8; break;   // Aug
+        case 0x536570u: month = 9; break;   // Sep
+        case 0x4F6374u: month = 10; break;  // Oct
+        case 0x4E6F76u: month = 11; break;  // Nov
+        case 0x446563u: month = 12; break;  // Dec
+        default: return false;
+    }
+    const uint32_t dl = day.e - day.s;
+    if (dl < 1u || dl > 2u) return false;
+    uint32_t d = rd.byte(day.s) - '0';
+    if (d > 9u) return false;
+    if (dl == 2u) {
+        const uint32_t d2 = rd.byte(day.s + 1) - '0';
+        if (d2 > 9u) return false;
+        d = d * 10u + d2;
+    }
+    if (tim.e - tim.s != 8u) return false;
+    uint32_t hh, mm, ss;
+    if (!two_digits(rd, tim.s, &hh) || rd.byte(tim.s + 2) != ':' || !two_digits(rd, tim.s + 3, &mm) || rd.byte(tim.s + 5) != ':' ||
+        !two_digits(rd, tim.s + 6, &ss))
+        return false;
+    if (hh > 23u || mm > 59u || ss > 59u) return false;
+    if (d < 1u || (int)d > days_in_month(year, month)) return false;
+    *local_secs = days_from_civil(year, month, (int)d) * 86400ll + (int64_t)(hh * 3600u + mm * 60u + ss);
+    return true;
+}
+// [year]: optional sign, exactly four digits (time 0.3, no large-dates)
+template <class R>
+FG3_HD bool parse_year_tok(R& rd, const Tok& t, int* year) {
+    uint32_t s = t.s;
+    bool neg = false;
+    if (s < t.e) {
+        const uint32_t c = rd.byte(s);
+        if (c == '-' || c == '+') {
+            neg = c == '-';
+            ++s;
+        }
+    }
+    if (t.e - s != 4u) return false;
+    int v = 0;
+    for (uint32_t k = 0; k < 4u; ++k) {
+        const uint32_t d = rd.byte(s + k) - '0';
+        if (d > 9u) return false;
+        v = v * 10 + (int)d;
+    }
+    *year = neg ? -v : v;
+    return true;
+}
+// time_tz::timezones::get_by_name: exact match in the sorted name table; -1 = not a zone name
+template <class R>
+FG3_HD int32_t tz_lookup(R& rd, const Tok& t, const TzView& tz) {
+    const uint32_t len = t.e - t.s;
+    uint32_t lo = 0, hi = tz.nz;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const uint32_t no = tz.name_off[mid], nl = tz.name_off[mid + 1] - no;
+        const uint32_t n = len < nl ? len : nl;
+        int c = 0;
+        for (uint32_t k = 0; k < n; ++k) {
+            const uint32_t a = rd.byte(t.s + k), b = tz.names[no + k];
+            if (a != b) {
+                c = a < b ? -1 : 1;
+                break;
+            }
+        }
+        if (c == 0) c = len == nl ? 0 : (len < nl ? -1 : 1);
+        if (c == 0) return (int32_t)mid;
+        if (c < 0) hi = mid;
+        else lo = mid + 1;
+    }
+    return -1;
+}
+// PrimitiveDateTime::assume_timezone: the UTC offset for a LOCAL time: the first span (chronologically) whose local
+// end lies after it -- the earlier offset for an ambiguous time, the later one inside a gap (UNPINNED)
+FG3_HD int32_t tz_offset_local(const TzView& tz, uint32_t zone, int64_t local) {
+    uint32_t lo = tz.zone_first[zone], hi = tz.zone_first[zone + 1] - 1u;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (local < tz.utc_start[mid + 1] + (int64_t)tz.utc_off[mid]) hi = mid;
+        else lo = mid + 1;
+    }
+    return tz.utc_off[lo];
+}
+
+// parse_date_token (:155-162) over the first tokens of a region; *next = index of the first token after the date [+ zone]
+template <class R>
+FG3_HD uint32_t parse_date_token(R& rd, const Tok* tok, uint32_t ntok, const Cfg& cfg, double* ts, uint32_t* next) {
+    if (ntok < 3u) return ST_TIME_FORMAT;
+    int64_t local = 0;
+    uint32_t idx = 3;
+    bool ok = parse_mdt(rd, tok[0], tok[1], tok[2], cfg.current_year, &local);
+    if (!ok) {
+        if (ntok < 4u) return ST_DATE_YEAR;
+        int year;
+        if (!parse_year_tok(rd, tok[0], &year) || !parse_mdt(rd, tok[1], tok[2], tok[3], year, &local)) return ST_DATE;
+        idx = 4;
+    }
+    int64_t off = 0;
+    if (ntok > idx && cfg.tz.nz) {
+        const int32_t z = tz_lookup(rd, tok[idx], cfg.tz);
+        if (z >= 0) {
+            off = tz_offset_local(cfg.tz, (uint32_t)z, local);
+            ++idx;
+        }
+    }
+    *ts = unix_nanos_to_f64(local - off, 0u);
+    *next = idx;
+    return ST_OK;
+}
+
+// the whole decoder for rd[0 .. len)
+template <class R>
+FG3_HD void parse_line(R& rd, uint32_t len, const Cfg& cfg, Row& r) {
+    r = Row{};
+    // parse_strip_pri
+    uint32_t q0 = 0;
+    if (len && rd.byte(0) == '<') {
+        uint32_t gt = 0;
+        bool found = false;
+        for (uint32_t i = 1; i < len; ++i)
+            if (rd.byte(i) == '>') {
+                gt = i;
+                found = true;
+                break;
+            }
+        if (!found) {
+            r.status = ST_PRI_MALFORMED;
+            return;
+        }
+        // "<...>".trim_start_matches('<').trim_end_matches('>') parsed as u8: [+]digits, <= 255
+        uint32_t a = 0, b = gt + 1;
+        while (a < b && rd.byte(a) == '<') ++a;
+        while (b > a && rd.byte(b - 1) == '>') --b;
+        if (a < b && rd.byte(a) == '+') ++a;
+        if (a >= b) {
+            r.status = ST_PRI_INVALID;
+            return;
+        }
+        uint32_t v = 0;
+        for (uint32_t i = a; i < b; ++i) {
+            const uint32_t d = rd.byte(i) - '0';
+            if (d > 9u || (v = v * 10u + d) > 255u) {
+                r.status = ST_PRI_INVALID;
+                return;
+            }
+        }
+        r.fac = v >> 3;
+        r.sev = v & 7u;
+        q0 = gt + 1;
+    }
+    r.full_len = trim_end_ws(rd, 0, len);  // line.trim_end()
+
+    // ---- decode_rfc_standard ---------------------------------------------------------------------------------------
+    Tok tok[kMaxTok];
+    uint32_t ntok = 0, pos = q0;
+    while (ntok < kMaxTok) {
+        uint32_t s, e;
+        if (!next_token(rd, pos, len, &s, &e)) break;
+        tok[ntok].s = s;
+        tok[ntok].e = e;
+        ++ntok;
+    }
+    if (ntok > 3u) {
+        double ts;
+        uint32_t next;
+        if (parse_date_token(rd, tok, ntok, cfg, &ts, &next) == ST_OK) {
+            if (next >= ntok) {  // kMaxTok >= next + 2 always, so this is the true "no token left"
+                r.status = ST_REF_PANIC;
+                return;
+            }
+            r.ts = ts;
+            r.host_off = tok[next].s;
+            r.host_len = tok[next].e - tok[next].s;
+            if (next + 1u < ntok) {
+                r.msg_off = tok[next + 1u].s;
+                r.msg_len = trim_end_ws(rd, r.msg_off, len) - r.msg_off;
+                r.msg_join = true;
+            } else {
+                r.msg_off = tok[next].e;
+                r.msg_len = 0;
+            }
+            return;
+        }
+    }
+    // ---- decode_rfc_custom -----------------------------------------------------------------------------------------
+    uint32_t p1 = 0, p2 = 0, found = 0;
+    for (uint32_t i = q0; i + 1u < len;) {  // msg.split(": "): non-overlapping, left to right
+        if (rd.byte(i) == ':' && rd.byte(i + 1) == ' ') {
+            if (found == 0) p1 = i;
+            else p2 = i;
+            if (++found == 2u) break;
+            i += 2;
+        } else {
+            ++i;
+        }
+    }
+    if (found < 2u) {
+        r.status = ST_MALFORMED;
+        return;
+    }
+    ntok = 0;
+    pos = p1 + 2u;
+    while (ntok < kMaxTok) {
+        uint32_t s, e;
+        if (!next_token(rd, pos, p2, &s, &e)) break;
+        tok[ntok].s = s;
+        tok[ntok].e = e;
+        ++ntok;
+    }
+    double ts;
+    uint32_t next;
+    const uint32_t st = parse_date_token(rd, tok, ntok, cfg, &ts, &next);
+    if (st != ST_OK) {
+        r.status = st;
+        return;
+    }
+    r.ts = ts;
+    r.host_off = q0;
+    r.host_len = p1 - q0;
+    r.msg_off = p2 + 2u;
+    r.msg_len = len - r.msg_off;
+}
+
+}  // namespace r3164
+}  // namespace fg

@@ -214,6 +214,44 @@ class GelfDecoder(Decoder):
     fmt = L.FG_GELF
 
 
+class RFC3164Decoder(Decoder):
+    """src/flowgger/decoder/rfc3164_decoder.rs:10-213.  The reference's config is ignored (:13-15); two things it takes
+    from its environment are explicit here: ``current_year`` (it reads the clock, :179; default: this machine's UTC
+    year at construction) and the IANA zone table behind ``time_tz::timezones::get_by_name`` (:195; default: every zone
+    of the system tz database, flowgger_amd/tzdb.py).  {"rfc3164": {"current_year": 2020, "zones": [...] | None}}."""
+    fmt = L.FG_RFC3164
+
+    def __init__(self, config: Optional[dict] = None, device: int = 0):
+        super().__init__(config, device)
+        import time as _time
+
+        from . import tzdb
+
+        opt = (config or {}).get("rfc3164", {})
+        self.current_year = int(opt.get("current_year", _time.gmtime().tm_year))
+        zones = opt.get("zones", "all")
+        self.tz_table = tzdb.default_table() if zones == "all" else (tzdb.build_table(zones) if zones else None)
+        self._apply()
+
+    def _apply(self):
+        cfg = L.fg_rfc3164_cfg(self.current_year, None)
+        t = self.tz_table
+        if t is not None and len(t.names):
+            names = (C.c_char_p * len(t.names))(*[n.encode() for n in t.names])
+            zf = np.ascontiguousarray(t.zone_first, np.uint32)
+            us = np.ascontiguousarray(t.utc_start, np.int64)
+            uo = np.ascontiguousarray(t.utc_offset, np.int32)
+            tab = L.fg_tz_table(len(t.names), C.cast(names, C.POINTER(C.c_char_p)), zf.ctypes.data, us.ctypes.data, uo.ctypes.data)
+            cfg.tz = C.pointer(tab)
+            self._keep3164 = (names, zf, us, uo, tab)
+        L.check(L.lib().fg_set_rfc3164(self._ctx, C.byref(cfg)), "fg_set_rfc3164")
+
+    def clone_boxed(self) -> "Decoder":
+        other = super().clone_boxed()
+        other.current_year, other.tz_table = self.current_year, self.tz_table
+        return other
+
+
 class LTSVDecoder(Decoder):
     """src/flowgger/decoder/ltsv_decoder.rs:17-221.  `config` mirrors the TOML tables
     ``input.ltsv_schema`` (name -> "string|bool|f64|i64|u64", case-insensitive, :33-45) and

@@ -214,3 +214,56 @@ def pack(lines: List[bytes]):
 
 def dumps_gelf(d: dict) -> bytes:  # helper for hand-written test cases
     return json.dumps(d, separators=(",", ":")).encode()
+
+
+def rfc3164_invalid_lines() -> List[str]:
+    """One line per RFC3164 status (fg_error_string(FG_RFC3164, 1..7))."""
+    return [
+        "<13 no closing bracket",                              # 1 Malformed RFC3164 event: Invalid priority
+        "<1x3>Aug  6 11:15:24 host app: message",              # 2 Invalid priority
+        "neither form matches this line",                      # 3 Malformed RFC3164 event: Invalid timestamp or hostname
+        "host: Aug 6: message after a two-token date",         # 4 Invalid time format
+        "host: Aug 36 11:15:24: day out of range, 3 tokens",   # 5 Unable to parse RFC3164 date with year
+        "host: 2020 Feb 30 11:15:24: no such day",             # 6 Unable to parse the date in RFC3164 decoder
+        "<13>Aug  6 11:15:24 UTC",                             # 7 the reference panics (index out of bounds)
+    ]
+
+
+def rfc3164_lines(n: int, cfg: int = 6, invalid_frac: float = 0.01, lo: int = 128, hi: int = 320) -> List[bytes]:
+    """BSD-syslog lines in the shapes the reference's tests use (rfc3164_decoder.rs:215-441): 70 % standard form
+    `[<pri>]Mon  D HH:MM:SS [zone] host app[pid]: text` (day padded with a space like syslogd does), 10 % with a
+    leading year, 20 % custom form `[<pri>]host: YYYY Mon D HH:MM:SS [zone]: text`; 15 % carry an IANA zone name."""
+    rng = np.random.default_rng(SEED_BASE + cfg)
+    pool = _text_pool(rng)
+    hosts = [f"h{i:04d}.dc{i % 7}.example.com" for i in range(1024)]
+    apps = [f"app-{_WORDS[i % len(_WORDS)]}{i}" for i in range(64)]
+    zones = ["UTC", "America/Sao_Paulo", "Europe/Paris", "Asia/Kolkata", "America/New_York", "Asia/Tokyo", "Australia/Sydney"]
+    f = _ts_fields(rng, n)
+    pri = rng.integers(0, 192, n)
+    kind = rng.random(n)
+    zk = rng.random(n)
+    hi_ = rng.integers(0, 1024, n)
+    ai = rng.integers(0, 64, n)
+    pid = rng.integers(1, 65536, n)
+    tgt = rng.integers(lo, hi + 1, n)
+    po = rng.integers(0, len(pool) - 9000, n)
+    invalid = rfc3164_invalid_lines()
+    inv_every = int(1 / invalid_frac) if invalid_frac > 0 else 0
+    out: List[bytes] = []
+    for i in range(n):
+        if inv_every and i % inv_every == inv_every - 1:
+            out.append(invalid[(i // inv_every) % len(invalid)].encode())
+            continue
+        p = f"<{pri[i]}>" if pri[i] % 5 else ""
+        day = f"{f['d'][i]:2d}" if kind[i] < 0.8 else str(f["d"][i])
+        date = f"{_MONTHS[f['mo'][i] - 1]} {day} {f['h'][i]:02d}:{f['mi'][i]:02d}:{f['s'][i]:02d}"
+        zone = " " + zones[int(zk[i] * 1000) % len(zones)] if zk[i] < 0.15 else ""
+        if kind[i] < 0.7:
+            head = f"{p}{date}{zone} {hosts[hi_[i]]} {apps[ai[i]]}[{pid[i]}]: "
+        elif kind[i] < 0.8:
+            head = f"{p}{f['y'][i]} {date}{zone} {hosts[hi_[i]]} {apps[ai[i]]}[{pid[i]}]: "
+        else:
+            head = f"{p}{hosts[hi_[i]]}: {f['y'][i]} {date}{zone}: {apps[ai[i]]}: "
+        need = max(int(tgt[i]) - len(head), 1)
+        out.append((head + pool[po[i]:po[i] + need]).encode())
+    return out

@@ -8,6 +8,7 @@
  *   RFC5424Decoder::decode                          src/flowgger/decoder/rfc5424_decoder.rs:17-50
  *   LTSVDecoder::new / decode                       src/flowgger/decoder/ltsv_decoder.rs:23-221
  *   GelfDecoder::decode                             src/flowgger/decoder/gelf_decoder.rs:34-125
+ *   RFC3164Decoder::decode                          src/flowgger/decoder/rfc3164_decoder.rs:31-213
  *   Record / StructuredData / SDValue               src/flowgger/record.rs:3-82
  *   the per-line call site the batching framer replaces
  *                                                   src/flowgger/splitter/line_splitter.rs:44-54
@@ -32,7 +33,7 @@ extern "C" {
 
 #define FG_ABI_VERSION 1
 
-typedef enum fg_format { FG_RFC5424 = 0, FG_LTSV = 1, FG_GELF = 2 } fg_format;
+typedef enum fg_format { FG_RFC5424 = 0, FG_LTSV = 1, FG_GELF = 2, FG_RFC3164 = 3 } fg_format;
 
 /* return codes */
 enum {
@@ -69,8 +70,10 @@ enum {
     FG_F_MSG_ESC = 4,       /* GELF: short_message span holds JSON escapes */
     FG_F_FULLMSG_ESC = 8,   /* GELF: full_message span holds JSON escapes */
     FG_F_BOM = 16,          /* RFC5424: line started with U+FEFF (spans already skip it) */
-    FG_F_GELF_RETRY = 32    /* GELF: accepted via the '\n' -> "\\n" retry (gelf_decoder.rs:44-46); when decoding
+    FG_F_GELF_RETRY = 32,   /* GELF: accepted via the '\n' -> "\\n" retry (gelf_decoder.rs:44-46); when decoding
                                escapes a backslash followed by a raw LF means backslash + 'n' */
+    FG_F_MSG_JOIN = 64      /* RFC3164 standard form: Record.msg = the msg span's whitespace-separated tokens joined
+                               with single spaces (`_log_tokens[1..].join(" ")`, rfc3164_decoder.rs:70) */
 };
 #define FG_ST_OVERFLOW 0xFE /* status: the line's entries did not fit in ent_cap (re-run with more) */
 #define FG_ST_BAD_UTF8 0xFD /* status: the frame is not valid UTF-8; the reference never decodes it, it prints
@@ -133,6 +136,25 @@ typedef struct fg_cfg {
     const char* suffix_u64;
 } fg_cfg;
 
+/* RFC3164Decoder configuration.  The reference takes two things from its environment that are configuration here:
+ *   current_year  OffsetDateTime::now_utc().year() prepended to dates without a year (rfc3164_decoder.rs:179)
+ *   tz            the IANA zone table behind time_tz::timezones::get_by_name (rfc3164_decoder.rs:195; the time-tz
+ *                 crate embeds the tz database at build time): n_zones names SORTED BYTEWISE (exact match), zone i
+ *                 owns entries [zone_first[i], zone_first[i+1]) of (utc_start, utc_offset): utc_offset[k] seconds east
+ *                 of UTC are in effect from utc_start[k] on, the zone's first entry starts at INT64_MIN.  NULL = no
+ *                 zone name is recognised.  flowgger_amd/tzdb.py builds it from the system's TZif files. */
+typedef struct fg_tz_table {
+    uint32_t n_zones;
+    const char* const* names;
+    const uint32_t* zone_first;
+    const int64_t* utc_start;
+    const int32_t* utc_offset;
+} fg_tz_table;
+typedef struct fg_rfc3164_cfg {
+    int32_t current_year;
+    const fg_tz_table* tz;
+} fg_rfc3164_cfg;
+
 typedef struct fg_ctx fg_ctx;
 #define FG_STREAM_OWN ((void*)(intptr_t)-1)
 
@@ -147,6 +169,9 @@ int fg_create(int device, const fg_cfg* cfg, fg_ctx** out);
 int fg_clone(const fg_ctx* ctx, fg_ctx** out);
 void fg_destroy(fg_ctx* ctx);
 int fg_last_hip_error(const fg_ctx* ctx);
+/* Configure the RFC3164 decoder of this ctx (copied; clones made afterwards inherit it).  Required before the first
+ * FG_RFC3164 decode (FG_ERR_ARG otherwise). */
+int fg_set_rfc3164(fg_ctx* ctx, const fg_rfc3164_cfg* cfg);
 
 /* Bytes of device scratch fg_decode_batch_device needs in `tables` are all caller-provided;
  * this helper returns the byte size of every array of an fg_tables for (n, ent_cap) so that a

@@ -1130,10 +1130,182 @@ void serialise(const Result& r, Sink* k) {
         }
     }
 }
+// ---------------------------------------------------------------------------------------
+// RFC3164 decoder (rfc3164_decoder.rs:31-213).  Two inputs the reference takes from its environment are
+// configuration here: the current year (OffsetDateTime::now_utc().year(), :179) and the IANA zone table
+// (time_tz::timezones::get_by_name, :195 -- the crate embeds the tz database).
+// ---------------------------------------------------------------------------------------
+struct TzZone {
+    std::vector<int64_t> utc_start;  // offset[i] in effect from utc_start[i]; [0] = INT64_MIN
+    std::vector<int32_t> offset;
+};
+struct R3164Cfg {
+    int current_year = 1970;
+    std::map<std::string, TzZone, std::less<>> zones;
+};
+R3164Cfg g_r3164;
+
+std::vector<sv> split_whitespace(sv s) {  // str::split_whitespace (Unicode White_Space)
+    std::vector<sv> out;
+    size_t i = 0, start = std::string::npos;
+    while (i < s.size()) {
+        uint32_t cp;
+        int n = utf8_next(s, i, &cp);
+        if (is_ws_cp(cp)) {
+            if (start != std::string::npos) out.push_back(s.substr(start, i - start));
+            start = std::string::npos;
+        } else if (start == std::string::npos) {
+            start = i;
+        }
+        i += n;
+    }
+    if (start != std::string::npos) out.push_back(s.substr(start));
+    return out;
+}
+std::string join(const std::vector<sv>& v, size_t from, size_t to, sv sep) {
+    std::string o;
+    for (size_t i = from; i < to && i < v.size(); ++i) {
+        if (i > from) o += sep;
+        o += v[i];
+    }
+    return o;
+}
+// PrimitiveDateTime::parse(s, "[year] [month repr:short] [day padding:none] [hour]:[minute]:[second]") -> seconds of the
+// date-time read as UTC.  [year]: optional sign + exactly 4 digits; month names case-sensitive; day 1-2 digits;
+// the whole input must be consumed.
+bool parse_3164_datetime(sv s, int64_t* out) {
+    size_t i = 0;
+    bool neg = false;
+    if (i < s.size() && (s[i] == '+' || s[i] == '-')) { neg = s[i] == '-'; ++i; }
+    int year = 0;
+    if (!take_digits(s, &i, 4, &year)) return false;
+    if (neg) year = -year;
+    if (i >= s.size() || s[i] != ' ') return false;
+    ++i;
+    static const char* mon[12] = {"Jan", "Feb", "Mar", "Apr", "May", "Jun", "Jul", "Aug", "Sep", "Oct", "Nov", "Dec"};
+    int month = 0;
+    for (int m = 0; m < 12; ++m)
+        if (s.substr(i, 3) == mon[m]) month = m + 1;
+    if (!month) return false;
+    i += 3;
+    if (i >= s.size() || s[i] != ' ') return false;
+    ++i;
+    int day = 0, nd = 0;
+    while (nd < 2 && i < s.size() && s[i] >= '0' && s[i] <= '9') { day = day * 10 + (s[i] - '0'); ++i; ++nd; }
+    if (nd == 0) return false;
+    if (i >= s.size() || s[i] != ' ') return false;
+    ++i;
+    int hh, mm, ss;
+    if (!take_digits(s, &i, 2, &hh) || i >= s.size() || s[i] != ':') return false;
+    ++i;
+    if (!take_digits(s, &i, 2, &mm) || i >= s.size() || s[i] != ':') return false;
+    ++i;
+    if (!take_digits(s, &i, 2, &ss)) return false;
+    if (i != s.size()) return false;
+    if (day < 1 || day > days_in_month(year, month) || hh > 23 || mm > 59 || ss > 59) return false;
+    *out = days_from_civil(year, month, day) * 86400 + hh * 3600 + mm * 60 + ss;
+    return true;
+}
+// assume_timezone: offset of the zone for a LOCAL time -- the chronologically first span whose local end lies after
+// it (UNPINNED: ambiguous times take the earlier offset, times inside a gap the later one)
+int32_t tz_local_offset(const TzZone& z, int64_t local) {
+    for (size_t i = 0; i + 1 < z.utc_start.size(); ++i)
+        if (local < z.utc_start[i + 1] + z.offset[i]) return z.offset[i];
+    return z.offset.back();
+}
+struct DateTok {
+    const char* err = nullptr;
+    double ts = 0;
+    size_t next = 0;  // first token after the date [+ zone]
+};
+DateTok parse_date_3164(const std::vector<sv>& t, bool has_year) {  // :164-213
+    DateTok r;
+    size_t idx;
+    std::string ts_str;
+    if (has_year) {
+        idx = 4;
+        if (t.size() < 4) { r.err = "Unable to parse RFC3164 date with year"; return r; }
+        ts_str = join(t, 0, 4, " ");
+    } else {
+        idx = 3;
+        if (t.size() < 3) { r.err = "Unable to parse RFC3164 date without year"; return r; }
+        ts_str = std::to_string(g_r3164.current_year) + " " + join(t, 0, 3, " ");
+    }
+    int64_t local;
+    if (!parse_3164_datetime(ts_str, &local)) { r.err = "Unable to parse the date in RFC3164 decoder"; return r; }
+    int64_t secs = local;
+    if (t.size() > idx) {
+        auto it = g_r3164.zones.find(t[idx]);
+        if (it != g_r3164.zones.end()) {
+            secs = local - tz_local_offset(it->second, local);
+            ++idx;
+        }
+    }
+    r.ts = (double)((__int128)secs * 1000000000) / 1e9;
+    r.next = idx;
+    return r;
+}
+DateTok parse_date_token_3164(const std::vector<sv>& t) {  // :155-162
+    if (t.size() < 3) { DateTok r; r.err = "Invalid time format"; return r; }
+    DateTok a = parse_date_3164(t, false);
+    if (!a.err) return a;
+    return parse_date_3164(t, true);
+}
+Result decode_rfc3164(sv line) {  // :31-50
+    Result res;
+    Record& rec = res.rec;
+    sv msg = line;
+    if (!line.empty() && line[0] == '<') {  // parse_strip_pri :125-153
+        size_t gt = line.find('>');
+        if (gt == sv::npos) { res.err = "Malformed RFC3164 event: Invalid priority"; return res; }
+        sv pri = line.substr(0, gt + 1);
+        while (!pri.empty() && pri.front() == '<') pri.remove_prefix(1);
+        while (!pri.empty() && pri.back() == '>') pri.remove_suffix(1);
+        uint64_t v;
+        if (!rust_parse_unsigned(pri, 255, &v)) { res.err = "Invalid priority"; return res; }
+        rec.facility = (uint8_t)(v >> 3);
+        rec.severity = (uint8_t)(v & 7);
+        msg = line.substr(gt + 1);
+    }
+    {  // decode_rfc_standard :57-88
+        std::vector<sv> tok = split_whitespace(msg);
+        if (tok.size() > 3) {
+            DateTok d = parse_date_token_3164(tok);
+            if (!d.err) {
+                if (d.next >= tok.size()) { res.err = "<the reference panics here: index out of bounds (rfc3164_decoder.rs:67)>"; return res; }
+                rec.ts = d.ts;
+                rec.hostname = std::string(tok[d.next]);
+                rec.msg = join(tok, d.next + 1, tok.size(), " ");
+                rec.full_msg = std::string(trim_end(line));
+                return res;
+            }
+        }
+    }
+    {  // decode_rfc_custom :90-123
+        std::vector<sv> tok;
+        size_t from = 0;
+        for (;;) {
+            size_t p = msg.find(": ", from);
+            if (p == sv::npos) { tok.push_back(msg.substr(from)); break; }
+            tok.push_back(msg.substr(from, p - from));
+            from = p + 2;
+        }
+        if (tok.size() <= 2) { res.err = "Malformed RFC3164 event: Invalid timestamp or hostname"; return res; }
+        DateTok d = parse_date_token_3164(split_whitespace(tok[1]));
+        if (d.err) { res.err = d.err; return res; }
+        rec.ts = d.ts;
+        rec.hostname = std::string(tok[0]);
+        rec.msg = join(tok, 2, tok.size(), ": ");
+        rec.full_msg = std::string(trim_end(line));
+        return res;
+    }
+}
+
 Result decode_any(int fmt, const LtsvCfg& cfg, sv line) {
     switch (fmt) {
         case FGO_RFC5424: return decode_rfc5424(line);
         case FGO_LTSV: return decode_ltsv(line, cfg);
+        case FGO_RFC3164: return decode_rfc3164(line);
         default: return decode_gelf(line);
     }
 }
@@ -1751,7 +1923,7 @@ bool parse_canonical(const uint8_t* p, uint64_t n, Record* r) {
 extern "C" {
 
 int64_t fgo_decode(int fmt, const fgo_ltsv_cfg* cfg, const uint8_t* line, uint64_t len, uint8_t* out, uint64_t cap) {
-    if (fmt < 0 || fmt > 2) return -1;
+    if (fmt < 0 || fmt > 3) return -1;
     LtsvCfg c = make_cfg(cfg);
     Result r = decode_any(fmt, c, sv((const char*)line, len));
     Sink k{out, cap};
@@ -1761,7 +1933,7 @@ int64_t fgo_decode(int fmt, const fgo_ltsv_cfg* cfg, const uint8_t* line, uint64
 
 int64_t fgo_decode_batch(int fmt, const fgo_ltsv_cfg* cfg, const uint8_t* bytes, const uint64_t* offsets, uint64_t n,
                          uint8_t* out, uint64_t cap, uint64_t* out_offsets, int threads) {
-    if (fmt < 0 || fmt > 2) return -1;
+    if (fmt < 0 || fmt > 3) return -1;
     LtsvCfg c = make_cfg(cfg);
     if (threads <= 0) threads = 1;
     // pass 1: sizes (parallel), pass 2: write at the prefix-summed offsets (parallel)
@@ -1796,7 +1968,7 @@ int64_t fgo_decode_batch(int fmt, const fgo_ltsv_cfg* cfg, const uint8_t* bytes,
 
 double fgo_bench_decode(int fmt, const fgo_ltsv_cfg* cfg, const uint8_t* bytes, const uint64_t* offsets, uint64_t n,
                         int threads, uint64_t* checksum, uint64_t* n_ok) {
-    if (fmt < 0 || fmt > 2) return -1.0;
+    if (fmt < 0 || fmt > 3) return -1.0;
     LtsvCfg c = make_cfg(cfg);
     if (threads <= 0) threads = 1;
     std::vector<uint64_t> sums(threads, 0), oks(threads, 0);
@@ -1823,6 +1995,21 @@ double fgo_bench_decode(int fmt, const fgo_ltsv_cfg* cfg, const uint8_t* bytes, 
     return secs;
 }
 
+// RFC3164 decoder configuration (process-wide; test infrastructure): the current year and the zone table
+// (names[i] owns entries [zone_first[i], zone_first[i+1]) of utc_start / utc_offset).
+void fgo_set_rfc3164(int current_year, uint32_t n_zones, const char* const* names, const uint32_t* zone_first,
+                     const int64_t* utc_start, const int32_t* utc_offset) {
+    g_r3164.current_year = current_year;
+    g_r3164.zones.clear();
+    for (uint32_t z = 0; z < n_zones; ++z) {
+        TzZone zone;
+        for (uint32_t k = zone_first[z]; k < zone_first[z + 1]; ++k) {
+            zone.utc_start.push_back(utc_start[k]);
+            zone.offset.push_back(utc_offset[k]);
+        }
+        g_r3164.zones[names[z]] = std::move(zone);
+    }
+}
 int fgo_rfc3339_to_unix(const uint8_t* s, uint64_t len, double* out) { return rfc3339_to_unix(sv((const char*)s, len), out); }
 int fgo_rust_parse_f64(const uint8_t* s, uint64_t len, double* out) { return rust_parse_f64(sv((const char*)s, len), out); }
 int fgo_english_time_to_unix(const uint8_t* s, uint64_t len, double* out) { return english_time_to_unix(sv((const char*)s, len), out); }
@@ -1854,7 +2041,7 @@ int64_t fgo_gelf_encode(const uint8_t* canonical, uint64_t len, const char* cons
 int64_t fgo_decode_encode_gelf_batch(int fmt, const fgo_ltsv_cfg* cfg, const uint8_t* bytes, const uint64_t* offsets, uint64_t n,
                                      const char* const* extra_keys, const char* const* extra_vals, uint32_t n_extra,
                                      uint8_t* out, uint64_t cap, uint64_t* out_offsets) {
-    if (fmt < 0 || fmt > 2) return -1;
+    if (fmt < 0 || fmt > 3) return -1;
     LtsvCfg c = make_cfg(cfg);
     std::vector<std::pair<std::string, std::string>> extra;
     for (uint32_t i = 0; i < n_extra; ++i) extra.emplace_back(extra_keys[i], extra_vals[i]);
@@ -1892,7 +2079,7 @@ int64_t fgo_encode(int enc, int merger, const uint8_t* canonical, uint64_t len, 
 int64_t fgo_decode_encode_batch(int fmt, const fgo_ltsv_cfg* cfg, int enc, int merger, const uint8_t* bytes,
                                 const uint64_t* offsets, uint64_t n, const fgo_enc_opts* opts, uint8_t* out, uint64_t cap,
                                 uint64_t* out_offsets, uint8_t* status) {
-    if (fmt < 0 || fmt > 2) return -1;
+    if (fmt < 0 || fmt > 3) return -1;
     LtsvCfg c = make_cfg(cfg);
     EncOpts o = make_opts(opts);
     uint64_t total = 0;

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-enum { FGO_RFC5424 = 0, FGO_LTSV = 1, FGO_GELF = 2 };
+enum { FGO_RFC5424 = 0, FGO_LTSV = 1, FGO_GELF = 2, FGO_RFC3164 = 3 };
 enum { FGO_T_STRING = 0, FGO_T_BOOL = 1, FGO_T_F64 = 2, FGO_T_I64 = 3, FGO_T_U64 = 4, FGO_T_NULL = 5 };
 
 /* LTSV decoder configuration (input.ltsv_schema / input.ltsv_suffixes, ltsv_decoder.rs:24-84).
@@ -99,6 +99,11 @@ int64_t fgo_decode_encode_batch(int fmt, const fgo_ltsv_cfg* cfg, int enc, int m
                                 const uint64_t* offsets, uint64_t n, const fgo_enc_opts* opts, uint8_t* out,
                                 uint64_t cap, uint64_t* out_offsets, uint8_t* status);
 int fgo_rust_display_f64(double v, char* out, int cap); /* Rust `{}` of an f64 */
+
+/* RFC3164 decoder (rfc3164_decoder.rs:31-213) configuration, process-wide: the current year (the reference reads the
+ * clock, :179) and the IANA zone table (the reference's time-tz crate embeds the database, :195). */
+void fgo_set_rfc3164(int current_year, uint32_t n_zones, const char* const* names, const uint32_t* zone_first,
+                     const int64_t* utc_start, const int32_t* utc_offset);
 
 /* Exposed pieces, for unit tests of the restated std/third-party semantics. */
 int fgo_rfc3339_to_unix(const uint8_t* s, uint64_t len, double* out);  /* 1 = ok */

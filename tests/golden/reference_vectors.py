@@ -5,7 +5,7 @@ Used twice: tests/test_oracle_golden.py pins the CPU oracle with them (CPU), and
 tests/test_gpu_parity.py runs the same lines through the HIP path (GPU).
 """
 
-RFC5424, LTSV, GELF = 0, 1, 2
+RFC5424, LTSV, GELF, RFC3164 = 0, 1, 2, 3
 
 S = lambda v: ("String", v)  # noqa: E731
 
@@ -125,4 +125,56 @@ DERIVED_RFC5424 = [
     (RFC5424_HDR + '[a b="c" =] m', "Format error in the structured data"),
     (RFC5424_HDR + '[a b="c', "Missing ] after structured data"),
     (RFC5424_HDR + '[a é="c"] m', "Format error in the structured data"),
+]
+
+
+# ---- RFC3164 decoder (rfc3164_decoder.rs:215-425).  The reference's expected timestamps use the CURRENT year
+# (ts_from_partial_date_time); the decoder under test is configured with RFC3164_YEAR instead of reading the clock.
+import calendar as _cal  # noqa: E402
+
+RFC3164_YEAR = 2026
+RFC3164_CONFIG = {"rfc3164": {"current_year": RFC3164_YEAR}}
+_ts = lambda y, mo, d, h, mi, s: float(_cal.timegm((y, mo, d, h, mi, s)))  # noqa: E731
+_M3164 = r'appname 69 42 [origin@123 software="te\st sc\"ript" swVersion="0.0.1"] test message'
+RFC3164_VECTORS = [
+    dict(src="rfc3164_decoder.rs:222-242 test_rfc3164_decode_nopri", fmt=RFC3164, config=RFC3164_CONFIG,
+         line="Aug  6 11:15:24 testhostname " + _M3164,
+         ok=dict(facility=None, severity=None, ts=_ts(RFC3164_YEAR, 8, 6, 11, 15, 24), hostname="testhostname", appname=None, procid=None,
+                 msgid=None, msg=_M3164, full_msg="Aug  6 11:15:24 testhostname " + _M3164, sd_none=True)),
+    dict(src="rfc3164_decoder.rs:244-264 test_rfc3164_decode_with_pri", fmt=RFC3164, config=RFC3164_CONFIG,
+         line="<13>Aug  6 11:15:24 testhostname " + _M3164,
+         ok=dict(facility=1, severity=5, ts=_ts(RFC3164_YEAR, 8, 6, 11, 15, 24), hostname="testhostname", msg=_M3164,
+                 full_msg="<13>Aug  6 11:15:24 testhostname " + _M3164, sd_none=True)),
+    dict(src="rfc3164_decoder.rs:266-286 test_rfc3164_decode_with_pri_year", fmt=RFC3164, config=RFC3164_CONFIG,
+         line="<13>2020 Aug  6 11:15:24 testhostname " + _M3164,
+         ok=dict(facility=1, severity=5, ts=_ts(2020, 8, 6, 11, 15, 24), hostname="testhostname", msg=_M3164,
+                 full_msg="<13>2020 Aug  6 11:15:24 testhostname " + _M3164, sd_none=True)),
+    dict(src="rfc3164_decoder.rs:288-308 test_rfc3164_decode_with_pri_year_tz", fmt=RFC3164, config=RFC3164_CONFIG,
+         line="<13>2020 Aug 6 05:15:24 America/Sao_Paulo testhostname " + _M3164,
+         ok=dict(facility=1, severity=5, ts=_ts(2020, 8, 6, 8, 15, 24), hostname="testhostname", msg=_M3164,
+                 full_msg="<13>2020 Aug 6 05:15:24 America/Sao_Paulo testhostname " + _M3164, sd_none=True)),
+    dict(src="rfc3164_decoder.rs:310-330 test_rfc3164_decode_tz_no_year", fmt=RFC3164, config=RFC3164_CONFIG,
+         line="Aug  6 11:15:24 UTC testhostname " + _M3164,
+         ok=dict(facility=None, severity=None, ts=_ts(RFC3164_YEAR, 8, 6, 11, 15, 24), hostname="testhostname", msg=_M3164,
+                 full_msg="Aug  6 11:15:24 UTC testhostname " + _M3164, sd_none=True)),
+    dict(src="rfc3164_decoder.rs:332-340 test_rfc3164_decode_invalid_event", fmt=RFC3164, config=RFC3164_CONFIG,
+         line="test message", err="Malformed RFC3164 event: Invalid timestamp or hostname"),  # the test only asserts is_err()
+    dict(src="rfc3164_decoder.rs:342-350 test_rfc3164_decode_invalid_date", fmt=RFC3164, config=RFC3164_CONFIG,
+         line="Aug  36 11:15:24 testhostname " + _M3164, err="Malformed RFC3164 event: Invalid timestamp or hostname"),
+    dict(src="rfc3164_decoder.rs:352-375 test_rfc3164_decode_custom_with_year", fmt=RFC3164, config=RFC3164_CONFIG,
+         line="testhostname: 2020 Aug  6 11:15:24 UTC: appname 69 42 some test message",
+         ok=dict(facility=None, severity=None, ts=_ts(2020, 8, 6, 11, 15, 24), hostname="testhostname", msg="appname 69 42 some test message",
+                 full_msg="testhostname: 2020 Aug  6 11:15:24 UTC: appname 69 42 some test message", sd_none=True)),
+    dict(src="rfc3164_decoder.rs:377-397 test_rfc3164_decode_custom_with_year_notz", fmt=RFC3164, config=RFC3164_CONFIG,
+         line="testhostname: 2019 Mar 27 12:09:39: appname: a test message",
+         ok=dict(ts=_ts(2019, 3, 27, 12, 9, 39), hostname="testhostname", msg="appname: a test message",
+                 full_msg="testhostname: 2019 Mar 27 12:09:39: appname: a test message", sd_none=True)),
+    dict(src="rfc3164_decoder.rs:399-419 test_rfc3164_decode_custom_with_pri", fmt=RFC3164, config=RFC3164_CONFIG,
+         line="<13>testhostname: 2019 Mar 27 12:09:39 UTC: appname: test message",
+         ok=dict(facility=1, severity=5, ts=_ts(2019, 3, 27, 12, 9, 39), hostname="testhostname", msg="appname: test message",
+                 full_msg="<13>testhostname: 2019 Mar 27 12:09:39 UTC: appname: test message", sd_none=True)),
+    dict(src="rfc3164_decoder.rs:421-441 test_rfc3164_decode_custom_trimed", fmt=RFC3164, config=RFC3164_CONFIG,
+         line="<13>testhostname: 2019 Mar 27 12:09:39 UTC: appname: test message \n",
+         ok=dict(facility=1, severity=5, ts=_ts(2019, 3, 27, 12, 9, 39), hostname="testhostname",
+                 full_msg="<13>testhostname: 2019 Mar 27 12:09:39 UTC: appname: test message", sd_none=True)),
 ]

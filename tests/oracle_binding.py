@@ -10,7 +10,7 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent.parent
 ORACLE_DIR = ROOT / "oracle"
 LIB = ORACLE_DIR / "libfg_oracle.so"
-RFC5424, LTSV, GELF = 0, 1, 2
+RFC5424, LTSV, GELF, RFC3164 = 0, 1, 2, 3
 _TYPE_IDS = {"string": 0, "bool": 1, "f64": 2, "i64": 3, "u64": 4}
 
 
@@ -55,11 +55,24 @@ class Oracle:
         L.fgo_decode_encode_gelf_batch.restype = C.c_int64
         L.fgo_decode_encode_gelf_batch.argtypes = [C.c_int, vp, vp, vp, u64, vp, vp, C.c_uint32, vp, u64, vp]
         L.fgo_dtoa.argtypes = [C.c_double, vp, C.c_int]
+        L.fgo_set_rfc3164.restype = None
+        L.fgo_set_rfc3164.argtypes = [C.c_int, C.c_uint32, vp, vp, vp, vp]
         L.fgo_rust_display_f64.argtypes = [C.c_double, vp, C.c_int]
         L.fgo_encode.restype = C.c_int64
         L.fgo_encode.argtypes = [C.c_int, C.c_int, vp, u64, vp, vp, u64, C.POINTER(C.c_char_p)]
         L.fgo_decode_encode_batch.restype = C.c_int64
         L.fgo_decode_encode_batch.argtypes = [C.c_int, vp, C.c_int, C.c_int, vp, vp, u64, vp, vp, u64, vp, vp]
+
+    def set_rfc3164(self, current_year: int, table=None):
+        """table: flowgger_amd.tzdb.TzTable (None = no zone names)"""
+        if table is None:
+            self.lib.fgo_set_rfc3164(current_year, 0, None, None, None, None)
+            return
+        names = (C.c_char_p * len(table.names))(*[n.encode() for n in table.names])
+        zf = np.ascontiguousarray(table.zone_first, np.uint32)
+        us = np.ascontiguousarray(table.utc_start, np.int64)
+        uo = np.ascontiguousarray(table.utc_offset, np.int32)
+        self.lib.fgo_set_rfc3164(current_year, len(table.names), names, zf.ctypes.data, us.ctypes.data, uo.ctypes.data)
 
     @staticmethod
     def make_cfg(config):

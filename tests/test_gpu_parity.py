@@ -5,15 +5,16 @@ timestamps as raw IEEE bits) must be byte-identical to the oracle's."""
 import numpy as np
 import pytest
 
-from flowgger_amd import GelfDecoder, LTSVDecoder, RFC5424Decoder, pack_lines, synth
+from flowgger_amd import GelfDecoder, LTSVDecoder, RFC3164Decoder, RFC5424Decoder, pack_lines, synth
 from flowgger_amd.record import DecodeError
-from golden.reference_vectors import DERIVED_RFC5424, GELF, LTSV, RFC5424, VECTORS
+from golden.reference_vectors import (DERIVED_RFC5424, GELF, LTSV, RFC3164, RFC3164_CONFIG, RFC3164_VECTORS, RFC3164_YEAR, RFC5424,
+                                      VECTORS)
 from gpu_util import assert_same, device_path, host_path_blob
 from test_oracle_golden import check_vector
 
 pytestmark = pytest.mark.gpu
 
-DECODERS = {RFC5424: RFC5424Decoder, LTSV: LTSVDecoder, GELF: GelfDecoder}
+DECODERS = {RFC5424: RFC5424Decoder, LTSV: LTSVDecoder, GELF: GelfDecoder, RFC3164: RFC3164Decoder}
 IDEO = "\u3000"   # IDEOGRAPHIC SPACE (White_Space, 3 bytes)
 NBSP = "\u00a0"   # NO-BREAK SPACE (White_Space, 2 bytes)
 ZWSP = "\u200b"   # ZERO WIDTH SPACE (NOT White_Space)
@@ -35,7 +36,7 @@ def both_paths(dec, oracle, lines, config=None):
     assert_same(blob2, offs2, oblob, ooffs, lines)
 
 
-@pytest.mark.parametrize("v", VECTORS, ids=[v["src"].split()[-1] for v in VECTORS])
+@pytest.mark.parametrize("v", VECTORS + RFC3164_VECTORS, ids=[v["src"].split()[-1] for v in VECTORS + RFC3164_VECTORS])
 def test_reference_vectors(v):
     """The reference's own decoder tests, run through Decoder.decode() on the GPU."""
     dec = DECODERS[v["fmt"]](v["config"])
@@ -765,3 +766,98 @@ def test_encoders_and_mergers_match_the_reference_pipeline(rfc, oracle, src, enc
         assert "Failed to parse unix timestamp in RFC3164 encoder" in seen_err
     if enc == "passthrough" and src == "gelf":
         assert "Cannot output empty raw message" in seen_err
+
+
+# ---------------------------------------------------------------------------------------------
+# RFC3164 decoder: rfc3164_decoder.rs:31-213
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def r3164(oracle):
+    from flowgger_amd import tzdb
+
+    oracle.set_rfc3164(RFC3164_YEAR, tzdb.default_table())
+    return RFC3164Decoder(RFC3164_CONFIG)
+
+
+def test_rfc3164_corpus_and_fuzz_bit_exact(r3164, oracle):
+    """both forms, zones, the year fallback, every error string and the input on which the reference panics: host-buffer
+    and device paths == the oracle; then the same lines as newline-framed stream through GPU framing + decode"""
+    from test_rfc3164_cpu import fuzz_lines
+
+    lines = [v["line"].encode() for v in RFC3164_VECTORS] + synth.rfc3164_lines(30_000) + fuzz_lines(30_000, 23)
+    lines += [b"", b"<", b"<>", b"Aug", b"a: b: ", b": : ", b"Aug 6 11:15:24 " + b"h" * 9000 + b" long hostname token", "Aug 6 11:15:24 h é　x".encode()]
+    both_paths(r3164, oracle, lines)
+    clone = r3164.clone_boxed()            # decoder/mod.rs:29-36: the clone carries year + zone table
+    both_paths(clone, oracle, lines[:500])
+
+
+def test_rfc3164_long_lines_take_the_global_path(r3164, oracle):
+    rng = np.random.default_rng(5)
+    lines = []
+    for i in range(600):
+        body = " ".join(synth._WORDS[int(k)] for k in rng.integers(0, len(synth._WORDS), int(rng.integers(1, 3000))))
+        lines.append((("<%d>" % (i % 192)) + "Aug %2d 11:15:24 Europe/Paris host%d " % (1 + i % 28, i) + body).encode())
+    both_paths(r3164, oracle, lines)
+
+
+def test_rfc3164_frames(r3164, oracle):
+    import torch
+
+    from flowgger_amd import _lib as L
+
+    lines = synth.rfc3164_lines(20_000)
+    lines[7] = lines[7] + b"\r"
+    lines[9] = b"Aug  6 11:15:24 h \xff\xfe not utf-8"
+    stream = b"".join(ln + b"\n" for ln in lines)
+    raw = torch.frombuffer(bytearray(stream + b"\0" * 32), dtype=torch.uint8).cuda()[:len(stream)]
+    d_off, d_bad, nf = r3164.frame_device(raw, L.FG_FRAME_LINE)
+    assert nf == len(lines)
+    from flowgger_amd.tables import DeviceTables
+
+    tables = DeviceTables(nf, 16, raw.device)
+    r3164.decode_frames_device(raw, d_off, nf, tables, L.FG_FRAME_LINE, d_bad)
+    torch.cuda.synchronize()
+    off = d_off[:nf + 1].cpu().numpy().astype(np.uint64)
+    data = np.frombuffer(stream, np.uint8)
+    blob, offs = tables.to_host().serialize(r3164.fmt, data, off)
+    good = [ln[:-1] if ln.endswith(b"\r") else ln for ln in lines]
+    gdata, goffs = synth.pack(good)
+    oblob, ooffs = oracle.decode_batch(RFC3164, gdata, goffs)
+    from flowgger_amd.record import parse_canonical
+
+    for i in (0, 7, 8, 9, 10, len(lines) - 1):
+        got = parse_canonical(blob[int(offs[i]):int(offs[i + 1])].tobytes())
+        if i == 9:
+            assert str(got) == "Invalid UTF-8 input"
+        else:
+            assert blob[int(offs[i]):int(offs[i + 1])].tobytes() == oblob[int(ooffs[i]):int(ooffs[i + 1])].tobytes(), (i, got)
+    st = tables.to_host().status()
+    ost = np.array([oblob[int(ooffs[i])] for i in range(len(lines))])
+    assert int((st != 0).sum()) == int((ost != 0).sum())  # line 9 fails either way
+
+
+@pytest.mark.parametrize("enc", ["gelf", "ltsv", "rfc5424", "rfc3164", "passthrough"])
+def test_encoders_on_rfc3164_records(r3164, oracle, enc):
+    """records decoded from BSD-syslog lines (msg = re-joined tokens) through every encoder + the syslen merger"""
+    import torch
+
+    import oracle_binding as OB
+    from flowgger_amd import GelfEncoder, LTSVEncoder, PassthroughEncoder, RFC3164Encoder, RFC5424Encoder
+    from test_rfc3164_cpu import fuzz_lines
+
+    lines = synth.rfc3164_lines(8_000) + fuzz_lines(4_000, 31) + ["Aug 6 11:15:24 h  a\t\tb 　 c\"d\\e ".encode()]
+    data, offsets = synth.pack(lines)
+    tables, d_bytes, d_offsets = device_path(r3164, data, offsets)
+    cls, oenc = {"gelf": (GelfEncoder, OB.ENC_GELF), "ltsv": (LTSVEncoder, OB.ENC_LTSV), "rfc5424": (RFC5424Encoder, OB.ENC_RFC5424),
+                 "rfc3164": (RFC3164Encoder, OB.ENC_RFC3164), "passthrough": (PassthroughEncoder, OB.ENC_PASSTHROUGH)}[enc]
+    e = cls(None, merger="syslen")
+    d_out, d_off = e.encode_device(r3164, d_bytes, d_offsets, len(lines), tables)
+    torch.cuda.synchronize()
+    out, off = d_out.cpu().numpy(), d_off.cpu().numpy().astype(np.uint64)
+    oblob, ooffs, _ = oracle.decode_encode_batch(RFC3164, oenc, OB.MERGE_SYSLEN, data, offsets)
+    bad = np.flatnonzero(off != ooffs)
+    if len(bad) or not np.array_equal(out, oblob):
+        i = max(int(bad[0]) - 1, 0) if len(bad) else int(np.searchsorted(ooffs, np.flatnonzero(out != oblob)[0], side="right") - 1)
+        a, b = out[int(off[i]):int(off[i + 1])].tobytes(), oblob[int(ooffs[i]):int(ooffs[i + 1])].tobytes()
+        raise AssertionError(f"line {i}: {lines[i][:160]!r}\n  gpu    {a!r}\n  oracle {b!r}")
+    assert (np.diff(ooffs.astype(np.int64)) > 0).sum() > 0.5 * len(lines)

@@ -21,6 +21,8 @@ def check_vector(res, v):
             assert getattr(res, f) == exp[f], (v["src"], f)
     if "ts" in exp:  # the reference asserts `res.ts == literal` on f64: exact bits
         assert struct.pack("<d", res.ts) == struct.pack("<d", exp["ts"]), (v["src"], res.ts)
+    if exp.get("sd_none"):
+        assert res.sd is None, v["src"]
     if "n_sd" in exp:
         assert res.sd is not None and len(res.sd) == exp["n_sd"], v["src"]
     if "sd_ids" in exp:
