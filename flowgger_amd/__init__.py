@@ -5,9 +5,9 @@ rebuilt as hand-written HIP kernels behind a C ABI (include/fg_hip.h).  See DESI
 """
 from .record import DecodeError, Record, SDValue, StructuredData  # noqa: F401
 from .decoder import Decoder, GelfDecoder, LTSVDecoder, RFC3164Decoder, RFC5424Decoder, pack_lines  # noqa: F401
-from .encoder import (Encoder, GelfEncoder, LTSVEncoder, PassthroughEncoder, RFC3164Encoder,  # noqa: F401
-                      RFC5424Encoder)
+from .encoder import (Encoder, GelfEncoder, LTSVEncoder, PassthroughEncoder, Pipeline, RFC3164Encoder,  # noqa: F401
+                      RFC5424Encoder, Transcoded)
 
 __all__ = ["Decoder", "RFC5424Decoder", "RFC3164Decoder", "LTSVDecoder", "GelfDecoder", "Record", "StructuredData",
            "SDValue", "DecodeError", "pack_lines", "Encoder", "GelfEncoder", "LTSVEncoder", "RFC5424Encoder",
-           "RFC3164Encoder", "PassthroughEncoder"]
+           "RFC3164Encoder", "PassthroughEncoder", "Pipeline", "Transcoded"]

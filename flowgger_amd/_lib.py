@@ -58,6 +58,11 @@ class fg_encode_cfg(C.Structure):
                 ("extra_values", C.POINTER(C.c_char_p)), ("prepend", C.c_char_p), ("now_ts", C.c_double)]
 
 
+class fg_transcoded(C.Structure):
+    _fields_ = [("out", C.c_void_p), ("out_bytes", C.c_uint64), ("out_offsets", C.c_void_p), ("meta", C.c_void_p),
+                ("enc_status", C.c_void_p), ("frame_offsets", C.c_void_p), ("n", C.c_uint64), ("consumed", C.c_uint64)]
+
+
 class fg_tz_table(C.Structure):
     _fields_ = [("n_zones", C.c_uint32), ("names", C.POINTER(C.c_char_p)), ("zone_first", C.c_void_p), ("utc_start", C.c_void_p),
                 ("utc_offset", C.c_void_p)]
@@ -117,6 +122,7 @@ def lib() -> C.CDLL:
                                         C.POINTER(u64), vp]
     L.fg_encode_device.argtypes = [vp, C.c_int, C.POINTER(fg_encode_cfg), vp, u64, vp, u64, C.POINTER(fg_tables), vp, u64, vp, vp,
                                    C.POINTER(u64), vp]
+    L.fg_transcode_batch.argtypes = [vp, C.c_int, C.c_int, C.POINTER(fg_encode_cfg), vp, u64, vp, u64, C.c_int, C.POINTER(fg_transcoded)]
     L.fg_encode_error_string.argtypes = [C.c_uint8]
     L.fg_encode_error_string.restype = C.c_char_p
     L.fg_set_rfc3164.argtypes = [vp, C.POINTER(fg_rfc3164_cfg)]

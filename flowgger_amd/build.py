@@ -61,6 +61,17 @@ def _stale(target: Path, deps: list[Path]) -> bool:
     return any(d.exists() and d.stat().st_mtime > t for d in deps)
 
 
+def _depfile_deps(depfile: Path) -> list[Path] | None:
+    """Prerequisites recorded by the compiler (-MD -MF) at the last compile of an object; None = unknown."""
+    try:
+        text = depfile.read_text()
+    except OSError:
+        return None
+    text = text.replace("\\\n", " ")
+    _, _, rhs = text.partition(":")
+    return [Path(tok) for tok in rhs.split() if tok.startswith(str(ROOT.parent))]
+
+
 def build(force: bool = False, verbose: bool = False) -> Path:
     hipcc = _hipcc()
     objdir = ROOT / "build"
@@ -68,22 +79,48 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     headers = list(CSRC.glob("*.hpp")) + [ROOT.parent / "include" / "fg_hip.h", Path(__file__)]
     common = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-fast-math",
               "-ffp-contract=off", f"-I{ROOT.parent / 'include'}"]
-    objs: list[Path] = []
+    # (source, object, extra defines); fg_encode.hip is compiled once per (encoder, pass) -- its emitters are large
+    # force-inlined templates (one object took 18 minutes) -- plus once for the dispatcher
+    units: list[tuple[str, Path, list[str]]] = []
     for name in HIP_SOURCES + HIP_HOST_SOURCES + CXX_SOURCES:
+        if not (CSRC / name).exists():
+            continue
+        units.append((name, objdir / (name + ".o"), []))
+        if name == "fg_encode.hip":
+            for enc in range(5):  # fg_encoder values; GELF (0) has two ranking-scratch sizes
+                for wr in (0, 1):
+                    for slots in ((8, 32) if enc == 0 else (0,)):
+                        units.append((name, objdir / f"fg_encode.e{enc}w{wr}s{slots}.o",
+                                      [f"-DFG_ENC_TU={enc}", f"-DFG_ENC_TU_WRITE={wr}", f"-DFG_ENC_TU_SLOTS={slots}"]))
+    objs = [u[1] for u in units]
+
+    def compile_unit(unit: tuple[str, Path, list[str]]) -> None:
+        name, obj, defs = unit
         src = CSRC / name
-        if not src.exists():
-            continue
-        obj = objdir / (name + ".o")
-        objs.append(obj)
-        if not force and not _stale(obj, [src] + headers):
-            continue
+        depfile = obj.with_suffix(".d")
+        # the headers the object really includes (compiler-written depfile); every header when that is unknown
+        deps = _depfile_deps(depfile)
+        if not force and not _stale(obj, [src, Path(__file__)] + (deps if deps is not None else headers)):
+            return
+        md = ["-MD", "-MF", str(depfile)]
         if name in CXX_SOURCES:
-            cmd = ["g++", *common, "-c", str(src), "-o", str(obj)]
+            cmd = ["g++", *common, *defs, *md, "-c", str(src), "-o", str(obj)]
         else:
-            cmd = [hipcc, f"--offload-arch={ARCH}", "-x", "hip", *common, "-c", str(src), "-o", str(obj)]
+            cmd = [hipcc, f"--offload-arch={ARCH}", "-x", "hip", *common, *defs, *md, "-c", str(src), "-o", str(obj)]
         if verbose:
-            print(" ".join(cmd))
+            print(" ".join(cmd), flush=True)
         _run(cmd)
+
+    from concurrent.futures import ThreadPoolExecutor
+
+    jobs = int(os.environ.get("FG_BUILD_JOBS", "0")) or max(1, os.cpu_count() or 1)
+    with ThreadPoolExecutor(max_workers=jobs) as pool:
+        # heaviest first so the long poles start immediately
+        order = sorted(units, key=lambda u: 0 if "fg_encode.e0w1" in u[1].name else 1 if "fg_encode.e" in u[1].name else 2)
+        for _ in pool.map(compile_unit, order):
+            pass
+    if os.environ.get("FG_BUILD_NO_LINK"):  # compile only (e.g. while a gpurun snapshot of the tree is in flight)
+        return LIB
     if force or _stale(LIB, objs):
         rt = _hip_runtime_dir()
         cmd = ["g++", "-shared", "-o", str(LIB), *map(str, objs), f"-L{rt}", "-lamdhip64",

@@ -18,6 +18,7 @@
 #include "fg_device.hpp"
 #include "fg_enc_cfg.hpp"
 #include "fg_rfc3164_parse.hpp"
+#include "fg_tz_index.hpp"
 
 namespace fg {
 // device view of input.ltsv_schema / input.ltsv_suffixes (must match fg_ltsv.hip)
@@ -101,6 +102,13 @@ struct fg_ctx {
     uint64_t d_tab_cap = 0;
     uint8_t* h_tab = nullptr;  // pinned host mirror
     uint64_t h_tab_cap = 0;
+    // fg_transcode_batch: device output (messages | out_offsets | enc_status) and its pinned host mirror
+    uint8_t* d_tout = nullptr;
+    uint64_t d_tout_cap = 0;
+    uint8_t* d_tmeta = nullptr;  // out_offsets[n + 1] then enc_status[n]
+    uint64_t d_tmeta_cap = 0;
+    uint8_t* h_tout = nullptr;   // pinned: messages | out_offsets | meta | enc_status
+    uint64_t h_tout_cap = 0;
 };
 
 namespace {
@@ -284,6 +292,17 @@ int grow_dev(fg_ctx* ctx, void** p, uint64_t* cap, uint64_t need) {
     return FG_OK;
 }
 
+int grow_pinned(fg_ctx* ctx, void** p, uint64_t* cap, uint64_t need) {
+    if (need <= *cap) return FG_OK;
+    if (*p) FG_HIP(ctx, hipHostFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    uint64_t want = up(need + need / 4, 1 << 20);
+    FG_HIP(ctx, hipHostMalloc(p, want, hipHostMallocDefault));
+    *cap = want;
+    return FG_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -397,6 +416,9 @@ void fg_destroy(fg_ctx* ctx) {
     if (ctx->d_tz) (void)hipFree(ctx->d_tz);
     if (ctx->h_off) (void)hipHostFree(ctx->h_off);
     if (ctx->h_tab) (void)hipHostFree(ctx->h_tab);
+    if (ctx->d_tout) (void)hipFree(ctx->d_tout);
+    if (ctx->d_tmeta) (void)hipFree(ctx->d_tmeta);
+    if (ctx->h_tout) (void)hipHostFree(ctx->h_tout);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->ev_ready) (void)hipEventDestroy(ctx->ev_ready);
@@ -644,6 +666,8 @@ int fg_decode_batch(fg_ctx* ctx, fg_format fmt, const uint8_t* bytes, uint64_t n
     }
 }
 
+static int frame_stage(fg_ctx* ctx, fg_framing framing, uint64_t nbytes, int final, uint64_t* n_frames, uint64_t* consumed);
+
 int fg_frame_decode_batch(fg_ctx* ctx, fg_format fmt, fg_framing framing, const uint8_t* bytes, uint64_t nbytes, int final,
                           fg_tables* out, const uint64_t** out_offsets, uint64_t* n_frames, uint64_t* consumed) {
     if (!ctx || !out || !out_offsets || !n_frames || !consumed || (nbytes && !bytes)) return FG_ERR_ARG;
@@ -658,30 +682,9 @@ int fg_frame_decode_batch(fg_ctx* ctx, fg_format fmt, fg_framing framing, const 
     if ((rc = grow_dev(ctx, (void**)&ctx->d_bytes, &ctx->d_bytes_cap, up(nbytes, 16) + 16)) != FG_OK) return rc;
     FG_HIP(ctx, hipMemcpyAsync(ctx->d_bytes, bytes, nbytes, hipMemcpyHostToDevice, s));
     FG_HIP(ctx, hipMemsetAsync(ctx->d_bytes + nbytes, 0, up(nbytes, 16) + 16 - nbytes, s));
-    // 1. frame: offsets + UTF-8 verdicts (capacity: one frame per 32 bytes to start with, exact on retry)
-    uint64_t cap = nbytes / 32 + 1024, total = 0, last_end = 0;
-    for (;;) {
-        if ((rc = grow_dev(ctx, (void**)&ctx->d_offsets, &ctx->d_offsets_cap, (cap + 2) * 8)) != FG_OK) return rc;
-        if ((rc = grow_dev(ctx, (void**)&ctx->d_bad, &ctx->d_bad_cap, cap + 1)) != FG_OK) return rc;
-        if ((rc = grow_dev(ctx, (void**)&ctx->d_frame, &ctx->d_frame_cap, fg_frame_scratch_bytes(nbytes))) != FG_OK) return rc;
-        uint64_t* d_total = nullptr;
-        int lrc = fg_launch_frame(ctx->d_bytes, nbytes, framing == FG_FRAME_LINE ? 0x0Au : 0x00u, ctx->d_frame, ctx->d_offsets,
-                                  ctx->d_bad, cap, &d_total, s);
-        if (lrc != 0) {
-            ctx->last_hip = lrc;
-            return FG_ERR_HIP;
-        }
-        FG_HIP(ctx, hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, s));
-        FG_HIP(ctx, hipStreamSynchronize(s));
-        if (total + 1 <= cap) break;
-        cap = total + 16;
-    }
-    FG_HIP(ctx, hipMemcpyAsync(&last_end, ctx->d_offsets + total, 8, hipMemcpyDeviceToHost, s));
-    FG_HIP(ctx, hipStreamSynchronize(s));
-    // terminated frames = total; a trailing unterminated piece is a frame only at the end of the stream
-    const bool tail = last_end != nbytes;
-    const uint64_t n = total + ((tail && final) ? 1 : 0);
-    *consumed = (tail && !final) ? last_end : nbytes;
+    // 1. frame: offsets + UTF-8 verdicts
+    uint64_t n = 0;
+    if ((rc = frame_stage(ctx, framing, nbytes, final, &n, consumed)) != FG_OK) return rc;
     *n_frames = n;
     if ((n + 1) * 8 > ctx->h_off_cap) {
         if (ctx->h_off) FG_HIP(ctx, hipHostFree(ctx->h_off));
@@ -740,6 +743,138 @@ int fg_frame_decode_batch(fg_ctx* ctx, fg_format fmt, fg_framing framing, const 
         *out = ht;
         return FG_OK;
     }
+}
+
+// Framing stage shared by fg_frame_decode_batch and fg_transcode_batch: the raw chunk is already in ctx->d_bytes
+// (zero padded); fills ctx->d_offsets / ctx->d_bad and says how many frames the chunk holds and how many of its bytes
+// they cover (an unterminated tail is a frame only when `final`).
+static int frame_stage(fg_ctx* ctx, fg_framing framing, uint64_t nbytes, int final, uint64_t* n_frames, uint64_t* consumed) {
+    hipStream_t s = ctx->stream;
+    int rc;
+    uint64_t cap = nbytes / 32 + 1024, total = 0, last_end = 0;
+    for (;;) {  // capacity: one frame per 32 bytes to start with, exact on retry
+        if ((rc = grow_dev(ctx, (void**)&ctx->d_offsets, &ctx->d_offsets_cap, (cap + 2) * 8)) != FG_OK) return rc;
+        if ((rc = grow_dev(ctx, (void**)&ctx->d_bad, &ctx->d_bad_cap, cap + 1)) != FG_OK) return rc;
+        if ((rc = grow_dev(ctx, (void**)&ctx->d_frame, &ctx->d_frame_cap, fg_frame_scratch_bytes(nbytes))) != FG_OK) return rc;
+        uint64_t* d_total = nullptr;
+        int lrc = fg_launch_frame(ctx->d_bytes, nbytes, framing == FG_FRAME_LINE ? 0x0Au : 0x00u, ctx->d_frame, ctx->d_offsets,
+                                  ctx->d_bad, cap, &d_total, s);
+        if (lrc != 0) {
+            ctx->last_hip = lrc;
+            return FG_ERR_HIP;
+        }
+        FG_HIP(ctx, hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, s));
+        FG_HIP(ctx, hipStreamSynchronize(s));
+        if (total + 1 <= cap) break;
+        cap = total + 16;
+    }
+    FG_HIP(ctx, hipMemcpyAsync(&last_end, ctx->d_offsets + total, 8, hipMemcpyDeviceToHost, s));
+    FG_HIP(ctx, hipStreamSynchronize(s));
+    const bool tail = last_end != nbytes;  // terminated frames = total
+    *n_frames = total + ((tail && final) ? 1 : 0);
+    *consumed = (tail && !final) ? last_end : nbytes;
+    return FG_OK;
+}
+
+// Decode ctx->d_bytes / ctx->d_offsets into tables carved from ctx->d_tab, growing the entry table until it fits.
+static int decode_stage(fg_ctx* ctx, fg_format fmt, fg_framing framing, uint64_t nbytes, uint64_t n, const uint8_t* d_bad,
+                        fg_tables* dt, uint64_t* ent_used) {
+    hipStream_t s = ctx->stream;
+    int rc;
+    uint64_t ent_cap = fmt == FG_RFC5424 ? nbytes / 16 + 1024 : nbytes / 8 + 1024;
+    if (fmt == FG_RFC3164) ent_cap = 16;  // RFC3164 produces no entries
+    for (;;) {
+        if (ent_cap > 0xFFFFFFF0ull) ent_cap = 0xFFFFFFF0ull;
+        uint64_t bytes_total = 0;
+        carve(nullptr, n, ent_cap, nullptr, &bytes_total);
+        if ((rc = grow_dev(ctx, (void**)&ctx->d_tab, &ctx->d_tab_cap, bytes_total)) != FG_OK) return rc;
+        carve(ctx->d_tab, n, ent_cap, dt, nullptr);
+        rc = fg_decode_frames_device(ctx, fmt, framing, ctx->d_bytes, nbytes, ctx->d_offsets, n, d_bad, dt, FG_STREAM_OWN);
+        if (rc != FG_OK) return rc;
+        uint64_t used = 0;
+        FG_HIP(ctx, hipMemcpyAsync(&used, dt->ent_used, 8, hipMemcpyDeviceToHost, s));
+        FG_HIP(ctx, hipStreamSynchronize(s));
+        if (used > ent_cap) {
+            if (ent_cap >= 0xFFFFFFF0ull) return FG_ERR_ENT_OVERFLOW;
+            ent_cap = used + used / 8 + 1024;
+            continue;
+        }
+        *ent_used = used;
+        return FG_OK;
+    }
+}
+
+int fg_transcode_batch(fg_ctx* ctx, fg_format fmt, fg_framing framing, const fg_encode_cfg* ecfg, const uint8_t* bytes,
+                       uint64_t nbytes, const uint64_t* offsets, uint64_t n, int final, fg_transcoded* out) {
+    if (!ctx || !ecfg || !out || (nbytes && !bytes)) return FG_ERR_ARG;
+    if ((int)framing < 0 || (int)framing > 2) return FG_ERR_ARG;
+    if (framing == FG_FRAME_NONE) {
+        if (n && !offsets) return FG_ERR_ARG;
+        if (n && (offsets[n] > nbytes || offsets[0] > offsets[n])) return FG_ERR_ARG;
+    } else if (offsets) {
+        return FG_ERR_ARG;  // a raw stream chunk is framed here; it does not come with offsets
+    }
+    *out = fg_transcoded{};
+    if (framing != FG_FRAME_NONE && nbytes == 0) return FG_OK;
+    DeviceGuard g(ctx->device);
+    hipStream_t s = ctx->stream;
+    int rc;
+    // 1. the chunk (and, for framed input, its offsets) to HBM
+    if ((rc = grow_dev(ctx, (void**)&ctx->d_bytes, &ctx->d_bytes_cap, up(nbytes, 16) + 16)) != FG_OK) return rc;
+    if (nbytes) FG_HIP(ctx, hipMemcpyAsync(ctx->d_bytes, bytes, nbytes, hipMemcpyHostToDevice, s));
+    FG_HIP(ctx, hipMemsetAsync(ctx->d_bytes + nbytes, 0, up(nbytes, 16) + 16 - nbytes, s));
+    uint64_t consumed = nbytes;
+    const uint8_t* d_bad = nullptr;
+    if (framing == FG_FRAME_NONE) {
+        if ((rc = grow_dev(ctx, (void**)&ctx->d_offsets, &ctx->d_offsets_cap, (n + 1) * 8)) != FG_OK) return rc;
+        if (n) FG_HIP(ctx, hipMemcpyAsync(ctx->d_offsets, offsets, (n + 1) * 8, hipMemcpyHostToDevice, s));
+    } else {
+        if ((rc = frame_stage(ctx, framing, nbytes, final, &n, &consumed)) != FG_OK) return rc;
+        d_bad = ctx->d_bad;
+    }
+    out->n = n;
+    out->consumed = consumed;
+    if (n == 0) {
+        FG_HIP(ctx, hipStreamSynchronize(s));
+        return FG_OK;
+    }
+    // 2. decode (tables stay in HBM)
+    fg_tables dt{};
+    uint64_t ent_used = 0;
+    if ((rc = decode_stage(ctx, fmt, framing, consumed, n, d_bad, &dt, &ent_used)) != FG_OK) return rc;
+    // 3. encode + frame from the tables; the output buffer grows to the batch (steady state: one count + one write)
+    const uint64_t offs_bytes = up((n + 1) * 8, 256);
+    if ((rc = grow_dev(ctx, (void**)&ctx->d_tmeta, &ctx->d_tmeta_cap, offs_bytes + up(n, 256))) != FG_OK) return rc;
+    uint64_t* d_out_offsets = reinterpret_cast<uint64_t*>(ctx->d_tmeta);
+    uint8_t* d_enc_status = ctx->d_tmeta + offs_bytes;
+    if (!ctx->d_tout && (rc = grow_dev(ctx, (void**)&ctx->d_tout, &ctx->d_tout_cap, consumed + consumed / 2 + 4096)) != FG_OK) return rc;
+    uint64_t total = 0;
+    rc = fg_encode_device(ctx, fmt, ecfg, ctx->d_bytes, consumed, ctx->d_offsets, n, &dt, ctx->d_tout, ctx->d_tout_cap, d_out_offsets,
+                          d_enc_status, &total, FG_STREAM_OWN);
+    if (rc == FG_ERR_ENT_OVERFLOW) {
+        if ((rc = grow_dev(ctx, (void**)&ctx->d_tout, &ctx->d_tout_cap, total + 4096)) != FG_OK) return rc;
+        rc = fg_encode_device(ctx, fmt, ecfg, ctx->d_bytes, consumed, ctx->d_offsets, n, &dt, ctx->d_tout, ctx->d_tout_cap, d_out_offsets,
+                              d_enc_status, &total, FG_STREAM_OWN);
+    }
+    if (rc != FG_OK) return rc;
+    // 4. only the encoded stream and the per-line verdicts cross PCIe back
+    const uint64_t o_msgs = 0, o_offs = up(total, 256), o_meta = o_offs + offs_bytes, o_st = o_meta + up(n * 4, 256),
+                   o_frames = o_st + up(n, 256), h_total = o_frames + (framing != FG_FRAME_NONE ? offs_bytes : 0);
+    if ((rc = grow_pinned(ctx, (void**)&ctx->h_tout, &ctx->h_tout_cap, h_total)) != FG_OK) return rc;
+    uint8_t* h = ctx->h_tout;
+    if (total) FG_HIP(ctx, hipMemcpyAsync(h + o_msgs, ctx->d_tout, total, hipMemcpyDeviceToHost, s));
+    FG_HIP(ctx, hipMemcpyAsync(h + o_offs, d_out_offsets, (n + 1) * 8, hipMemcpyDeviceToHost, s));
+    FG_HIP(ctx, hipMemcpyAsync(h + o_meta, dt.meta, n * 4, hipMemcpyDeviceToHost, s));
+    FG_HIP(ctx, hipMemcpyAsync(h + o_st, d_enc_status, n, hipMemcpyDeviceToHost, s));
+    if (framing != FG_FRAME_NONE) FG_HIP(ctx, hipMemcpyAsync(h + o_frames, ctx->d_offsets, (n + 1) * 8, hipMemcpyDeviceToHost, s));
+    FG_HIP(ctx, hipStreamSynchronize(s));
+    out->out = h + o_msgs;
+    out->out_bytes = total;
+    out->out_offsets = reinterpret_cast<const uint64_t*>(h + o_offs);
+    out->meta = reinterpret_cast<const uint32_t*>(h + o_meta);
+    out->enc_status = h + o_st;
+    out->frame_offsets = framing != FG_FRAME_NONE ? reinterpret_cast<const uint64_t*>(h + o_frames) : nullptr;
+    return FG_OK;
 }
 
 int fg_encode_device(fg_ctx* ctx, fg_format src_fmt, const fg_encode_cfg* ecfg, const uint8_t* d_bytes, uint64_t nbytes,
@@ -849,33 +984,12 @@ static int upload_tz(fg_ctx* ctx) {
     }
     ctx->r3164 = fg::r3164::Cfg{};
     ctx->r3164.current_year = ctx->r3164_year;
-    const uint32_t nz = (uint32_t)ctx->tz_names.size();
-    if (nz == 0) return FG_OK;
-    std::vector<uint8_t> names;
-    std::vector<uint32_t> name_off(nz + 1, 0);
-    for (uint32_t z = 0; z < nz; ++z) {
-        name_off[z] = (uint32_t)names.size();
-        names.insert(names.end(), ctx->tz_names[z].begin(), ctx->tz_names[z].end());
-    }
-    name_off[nz] = (uint32_t)names.size();
-    const uint64_t ne = ctx->tz_start.size();
-    const uint64_t o_off = up(names.size(), 16), o_first = o_off + up((nz + 1) * 4, 16), o_start = o_first + up((nz + 1) * 4, 16),
-                   o_utc = o_start + up(ne * 8, 16), total = o_utc + up(ne * 4, 16);
-    std::vector<uint8_t> host(total, 0);
-    memcpy(host.data(), names.data(), names.size());
-    memcpy(host.data() + o_off, name_off.data(), (nz + 1) * 4);
-    memcpy(host.data() + o_first, ctx->tz_first.data(), (nz + 1) * 4);
-    memcpy(host.data() + o_start, ctx->tz_start.data(), ne * 8);
-    memcpy(host.data() + o_utc, ctx->tz_off.data(), ne * 4);
-    FG_HIP(ctx, hipMalloc((void**)&ctx->d_tz, total));
-    FG_HIP(ctx, hipMemcpy(ctx->d_tz, host.data(), total, hipMemcpyHostToDevice));
-    fg::r3164::TzView& v = ctx->r3164.tz;
-    v.names = ctx->d_tz;
-    v.name_off = reinterpret_cast<const uint32_t*>(ctx->d_tz + o_off);
-    v.nz = nz;
-    v.zone_first = reinterpret_cast<const uint32_t*>(ctx->d_tz + o_first);
-    v.utc_start = reinterpret_cast<const int64_t*>(ctx->d_tz + o_start);
-    v.utc_off = reinterpret_cast<const int32_t*>(ctx->d_tz + o_utc);
+    if (ctx->tz_names.empty()) return FG_OK;
+    fg::r3164::TzIndex idx;  // hash index, reject masks, year hints (fg_tz_index.hpp)
+    if (!idx.build(ctx->tz_names, ctx->tz_first, ctx->tz_start, ctx->tz_off, ctx->r3164_year)) return FG_ERR_ARG;
+    FG_HIP(ctx, hipMalloc((void**)&ctx->d_tz, idx.blob.size()));
+    FG_HIP(ctx, hipMemcpy(ctx->d_tz, idx.blob.data(), idx.blob.size(), hipMemcpyHostToDevice));
+    ctx->r3164.tz = idx.view(ctx->d_tz);
     return FG_OK;
 }
 

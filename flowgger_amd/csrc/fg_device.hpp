@@ -219,22 +219,28 @@ __device__ __forceinline__ bool parse_rfc3339(R& rd, uint32_t q, uint32_t end, d
 
 // Stream [a0, a0+span) of the packed buffer into the wave's LDS tile: 16 B per lane, 1 KiB per
 // wave-instruction, 8 loads in flight per lane (a0 and span are multiples of 16).
+// Loads AND stores are unconditional (lanes past the end move the last chunk once more, same bytes to the same
+// address): with `if (idx < nchunk)` around either, the compiler kept v[] in scratch memory or sank each load into
+// its store's branch, and waited for every load before issuing the next one -- eight serialised HBM round trips per
+// 8 KiB instead of eight loads in flight (round-1 finding).
 __device__ __forceinline__ void stage_tile(const uint8_t* __restrict__ bytes, uint64_t a0, uint32_t span, uint8_t* smem) {
     const uint4* __restrict__ src = reinterpret_cast<const uint4*>(bytes + a0);
     uint4* dst = reinterpret_cast<uint4*>(smem);
     const uint32_t nchunk = span >> 4;
+    if (nchunk == 0) return;
     const uint32_t lane = threadIdx.x;
+    const uint32_t last = nchunk - 1u;
     for (uint32_t c0 = 0; c0 < nchunk; c0 += kWave * 8) {
         uint4 v[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            uint32_t idx = c0 + k * kWave + lane;
-            if (idx < nchunk) v[k] = src[idx];
+            const uint32_t idx = c0 + k * kWave + lane;
+            v[k] = src[idx < last ? idx : last];
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            uint32_t idx = c0 + k * kWave + lane;
-            if (idx < nchunk) dst[idx] = v[k];
+            const uint32_t idx = c0 + k * kWave + lane;
+            dst[idx < last ? idx : last] = v[k];
         }
     }
 }

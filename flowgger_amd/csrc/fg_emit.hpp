@@ -21,7 +21,7 @@
 #include <string.h>
 
 #include "fg_dtoa.hpp"
-#include "fg_rfc3164_parse.hpp"
+#include "fg_unicode_ws.hpp"
 #include "fg_shortest.hpp"
 #include "fg_tables_view.hpp"
 #include "fg_timeconv.hpp"
@@ -80,88 +80,93 @@ FGE_HD uint32_t hexv(uint32_t c) {
 }
 
 // Streams the decoded bytes of rd[off .. off+len) into f(byte).
+// Code size matters here: the emitters instantiate this once per call site with the sink's escaping inlined into f,
+// so every mode produces "up to four decoded bytes of this step" (w, little-endian; nb) and ALL modes share ONE
+// call site of f (M_RAW: its own).
 template <class R, class F>
 FGE_HD void for_each_decoded(R& rd, uint32_t off, uint32_t len, uint32_t mode, F&& f) {
     if (mode == M_RAW) {
         for (uint32_t i = 0; i < len; ++i) f(rd.byte(off + i));
-    } else if (mode == M_SD) {  // unescape_sd_value: \" \\ \] lose the backslash, any other \x keeps both
-        bool esc = false;
-        for (uint32_t i = 0; i < len; ++i) {
-            const uint32_t c = rd.byte(off + i);
+        return;
+    }
+    const bool retry = mode == M_JSON_RETRY;
+    bool esc = false;                  // M_SD: the previous byte was an unconsumed backslash
+    bool in_tok = false, any = false;  // M_WSJOIN
+    for (uint32_t i = 0; i < len;) {
+        const uint32_t c = rd.byte(off + i);
+        uint32_t w = c, nb = 1u;
+        if (mode == M_SD) {  // unescape_sd_value: \" \\ \] lose the backslash, any other \x keeps both
+            ++i;
             if (!esc) {
-                if (c == '\\') esc = true;
-                else f(c);
+                if (c == '\\') {
+                    esc = true;
+                    nb = 0u;
+                }
             } else {
-                if (c != '"' && c != '\\' && c != ']') f((uint32_t)'\\');
-                f(c);
+                if (c != '"' && c != '\\' && c != ']') {
+                    w = (uint32_t)'\\' | c << 8;
+                    nb = 2u;
+                }
                 esc = false;
             }
-        }
-    } else if (mode == M_WSJOIN) {  // str::split_whitespace(..).join(" ") (RFC3164 msg, rfc3164_decoder.rs:70)
-        bool in_tok = false, any = false;
-        for (uint32_t i = 0; i < len;) {
-            const uint32_t w = r3164::ws_at(rd, off + i, off + len);
-            if (w) {
+        } else if (mode == M_WSJOIN) {  // str::split_whitespace(..).join(" ") (RFC3164 msg, rfc3164_decoder.rs:70)
+            const uint32_t ws = r3164::ws_at(rd, off + i, off + len);
+            if (ws) {
                 in_tok = false;
-                i += w;
-                continue;
-            }
-            if (!in_tok) {
-                if (any) f((uint32_t)' ');
-                in_tok = any = true;
-            }
-            f(rd.byte(off + i));
-            ++i;
-        }
-    } else {  // JSON escapes of an already validated string body
-        const bool retry = mode == M_JSON_RETRY;
-        for (uint32_t i = 0; i < len;) {
-            const uint32_t c = rd.byte(off + i);
-            if (c != '\\' || i + 1 >= len) {
-                f(c);
+                i += ws;
+                nb = 0u;
+            } else {
                 ++i;
-                continue;
+                if (!in_tok) {
+                    if (any) {
+                        w = (uint32_t)' ' | c << 8;
+                        nb = 2u;
+                    }
+                    in_tok = any = true;
+                }
             }
+        } else if (c != '\\' || i + 1 >= len) {  // JSON escapes of an already validated string body: a plain byte
+            ++i;
+        } else {
             const uint32_t e = rd.byte(off + i + 1);
             i += 2;
             if (retry && e == '\n') {  // the reference replaced LF by "\\n": an escaped backslash, then 'n'
-                f((uint32_t)'\\');
-                f((uint32_t)'n');
-                continue;
-            }
-            if (e == 'b') f(8u);
-            else if (e == 'f') f(12u);
-            else if (e == 'n') f(10u);
-            else if (e == 'r') f(13u);
-            else if (e == 't') f(9u);
+                w = (uint32_t)'\\' | (uint32_t)'n' << 8;
+                nb = 2u;
+            } else if (e == 'b') w = 8u;
+            else if (e == 'f') w = 12u;
+            else if (e == 'n') w = 10u;
+            else if (e == 'r') w = 13u;
+            else if (e == 't') w = 9u;
             else if (e == 'u') {
-                if (i + 4 > len) continue;
-                uint32_t n1 = hexv(rd.byte(off + i)) << 12 | hexv(rd.byte(off + i + 1)) << 8 | hexv(rd.byte(off + i + 2)) << 4 | hexv(rd.byte(off + i + 3));
-                i += 4;
-                if (n1 >= 0xD800u && n1 <= 0xDBFFu && i + 6 <= len) {
-                    const uint32_t n2 = hexv(rd.byte(off + i + 2)) << 12 | hexv(rd.byte(off + i + 3)) << 8 | hexv(rd.byte(off + i + 4)) << 4 | hexv(rd.byte(off + i + 5));
-                    i += 6;
-                    n1 = (((n1 - 0xD800u) << 10) | (n2 - 0xDC00u)) + 0x10000u;
-                }
-                if (n1 < 0x80u) {
-                    f(n1);
-                } else if (n1 < 0x800u) {
-                    f(0xC0u | (n1 >> 6));
-                    f(0x80u | (n1 & 0x3Fu));
-                } else if (n1 < 0x10000u) {
-                    f(0xE0u | (n1 >> 12));
-                    f(0x80u | ((n1 >> 6) & 0x3Fu));
-                    f(0x80u | (n1 & 0x3Fu));
+                if (i + 4 > len) {
+                    nb = 0u;
                 } else {
-                    f(0xF0u | (n1 >> 18));
-                    f(0x80u | ((n1 >> 12) & 0x3Fu));
-                    f(0x80u | ((n1 >> 6) & 0x3Fu));
-                    f(0x80u | (n1 & 0x3Fu));
+                    uint32_t n1 = hexv(rd.byte(off + i)) << 12 | hexv(rd.byte(off + i + 1)) << 8 | hexv(rd.byte(off + i + 2)) << 4 | hexv(rd.byte(off + i + 3));
+                    i += 4;
+                    if (n1 >= 0xD800u && n1 <= 0xDBFFu && i + 6 <= len) {
+                        const uint32_t n2 = hexv(rd.byte(off + i + 2)) << 12 | hexv(rd.byte(off + i + 3)) << 8 | hexv(rd.byte(off + i + 4)) << 4 | hexv(rd.byte(off + i + 5));
+                        i += 6;
+                        n1 = (((n1 - 0xD800u) << 10) | (n2 - 0xDC00u)) + 0x10000u;
+                    }
+                    if (n1 < 0x80u) {
+                        w = n1;
+                    } else if (n1 < 0x800u) {
+                        w = (0xC0u | (n1 >> 6)) | (0x80u | (n1 & 0x3Fu)) << 8;
+                        nb = 2u;
+                    } else if (n1 < 0x10000u) {
+                        w = (0xE0u | (n1 >> 12)) | (0x80u | ((n1 >> 6) & 0x3Fu)) << 8 | (0x80u | (n1 & 0x3Fu)) << 16;
+                        nb = 3u;
+                    } else {
+                        w = (0xF0u | (n1 >> 18)) | (0x80u | ((n1 >> 12) & 0x3Fu)) << 8 | (0x80u | ((n1 >> 6) & 0x3Fu)) << 16 | (0x80u | (n1 & 0x3Fu)) << 24;
+                        nb = 4u;
+                    }
                 }
             } else {
-                f(e);  // " \ /
+                w = e;  // " \ /
             }
         }
+        for (uint32_t j = 0; j < nb; ++j) f((w >> (8u * j)) & 0xFFu);
     }
 }
 
@@ -282,19 +287,20 @@ struct Base {
             out.add(len);
             return;
         }
-        uint32_t i = 0;
-        for (; i + 4u <= len; i += 4u) {
-            const uint32_t w = rd.load4(off + i, 4u);
-            if (word_needs_bytes<ESC>(w)) {
-                fb(w & 0xFFu);
-                fb((w >> 8) & 0xFFu);
-                fb((w >> 16) & 0xFFu);
-                fb(w >> 24);
-            } else {
-                out.put_word(w, 4u);
+        for (uint32_t i = 0; i < len;) {
+            uint32_t nb = len - i;  // the tail, or a dword with a byte that needs fb: byte-wise through ONE fb call site
+            if (nb >= 4u) {
+                const uint32_t w = rd.load4(off + i, 4u);
+                if (!word_needs_bytes<ESC>(w)) {
+                    out.put_word(w, 4u);
+                    i += 4u;
+                    continue;
+                }
+                nb = 4u;
             }
+            for (uint32_t j = 0; j < nb; ++j) fb(rd.byte(off + i + j));
+            i += nb;
         }
-        for (; i < len; ++i) fb(rd.byte(off + i));
     }
     FGE_HD void raw_field(int col) {  // a top-level field, decoded, unmodified
         const fg_span s = t.span[col][li];
@@ -477,28 +483,23 @@ struct GelfEmitter : Base<S, R> {
 
     FGE_HD GelfEmitter(S& o, const EncCfg& c, R r, const DevTables& tb, uint64_t l, uint32_t m) : B{o, c, r, tb, l, m} {}
 
-    FGE_HD void esc_byte(uint32_t c) {  // serde_json 0.8 escape_str
+    FGE_HD void esc_byte(uint32_t c) {  // serde_json 0.8 escape_str; one or two put_word sites (code size)
+        uint32_t w = c, nb = 1u;
         if (c == '"' || c == '\\') {
-            out.put('\\');
-            out.put(c);
-        } else if (c >= 0x20u) {
-            out.put(c);
-        } else {
-            out.put('\\');
-            if (c == 8u) out.put('b');
-            else if (c == 9u) out.put('t');
-            else if (c == 10u) out.put('n');
-            else if (c == 12u) out.put('f');
-            else if (c == 13u) out.put('r');
-            else {
-                out.put('u');
-                out.put('0');
-                out.put('0');
-                out.put(c >> 4 ? '1' : '0');
+            w = (uint32_t)'\\' | c << 8;
+            nb = 2u;
+        } else if (c < 0x20u) {
+            const uint32_t x = c == 8u ? 'b' : c == 9u ? 't' : c == 10u ? 'n' : c == 12u ? 'f' : c == 13u ? 'r' : 0u;
+            if (x) {
+                w = (uint32_t)'\\' | x << 8;
+            } else {  // \u00XX
+                out.put_word((uint32_t)'\\' | (uint32_t)'u' << 8 | (uint32_t)'0' << 16 | (uint32_t)'0' << 24, 4u);
                 const uint32_t lo = c & 15u;
-                out.put(lo < 10u ? '0' + lo : 'a' + lo - 10u);
+                w = (c >> 4 ? (uint32_t)'1' : (uint32_t)'0') | (lo < 10u ? '0' + lo : 'a' + lo - 10u) << 8;
             }
+            nb = 2u;
         }
+        out.put_word(w, nb);
     }
     FGE_HD void member_start() {
         if (!first_member) out.put(',');
@@ -586,10 +587,11 @@ struct GelfEmitter : Base<S, R> {
             default: break;
         }
         key_static(k);
+        int col = -1;  // a string field: ONE str_field call site below
         switch (k.kind) {
-            case SK_APP: str_field(S_APP); break;
-            case SK_FULL: str_field(S_FULL); break;
-            case SK_PROC: str_field(S_PROC); break;
+            case SK_APP: col = S_APP; break;
+            case SK_FULL: col = S_FULL; break;
+            case SK_PROC: col = S_PROC; break;
             case SK_HOST: {
                 const fg_span s = t.span[S_HOST][li];
                 if (s.len == 0u || s.len == FG_NONE) {
@@ -597,7 +599,7 @@ struct GelfEmitter : Base<S, R> {
                     this->lit("unknown", 7);
                     out.put('"');
                 } else {
-                    str_field(S_HOST);
+                    col = S_HOST;
                 }
                 break;
             }
@@ -615,7 +617,7 @@ struct GelfEmitter : Base<S, R> {
                     out.put('-');
                     out.put('"');
                 } else {
-                    str_field(S_MSG);
+                    col = S_MSG;
                 }
                 break;
             }
@@ -627,6 +629,7 @@ struct GelfEmitter : Base<S, R> {
                 break;
             default: break;  // SK_EXTRA: the value is part of the precomputed member text
         }
+        if (col >= 0) str_field(col);
     }
 
     // keys64 / slot_ent / order: this lane's scratch (kSortSlots each)
@@ -672,49 +675,43 @@ struct GelfEmitter : Base<S, R> {
             }
         }
         out.put('{');
+        // ONE member loop for both orders (one emit_static / emit_dyn call site each: code size): the next entry in
+        // key order comes from the ranking or, when that is not available, from an exact selection -- repeatedly the
+        // smallest key greater than the previous one, among equal keys the LAST entry (the later insert)
+        const uint32_t kNone = 0xFFFFFFFFu;
         uint32_t sk = 0;  // next static key
-        if (ranked) {
-            for (uint32_t r = 0; r < np; ++r) {
-                if (order[r] == 0xFFu) continue;
-                const uint32_t e = first + slot_ent[order[r]];
-                const Dyn d = this->dyn_of(e);
-                bool shadowed = false;
-                while (sk < cfg.n_keys) {
-                    const int c = cmp_dyn_static(d, cfg.keys[sk]);
-                    if (c < 0) break;
-                    if (c == 0) shadowed = true;  // gelf_extra is inserted last: it replaces the pair
-                    emit_static(cfg.keys[sk], sdid_entry);
-                    ++sk;
+        uint32_t r = 0, prev = kNone;
+        for (;;) {
+            uint32_t e = kNone;
+            if (ranked) {
+                while (r < np && order[r] == 0xFFu) ++r;
+                if (r < np) e = first + slot_ent[order[r++]];
+            } else {
+                for (uint32_t c = first; c < first + cnt; ++c) {
+                    if (t.ent_type[c] == FG_T_SDID) continue;
+                    const Dyn dc = this->dyn_of(c);
+                    if (prev != kNone && cmp_dyn(dc, this->dyn_of(prev)) <= 0) continue;
+                    if (e == kNone || cmp_dyn(dc, this->dyn_of(e)) <= 0) e = c;
                 }
-                if (!shadowed) emit_dyn(e);
+                prev = e;
             }
-        } else {
-            // exact selection: repeatedly the smallest key greater than the previous one; among
-            // equal keys the LAST entry (the later insert)
-            uint32_t prev = 0xFFFFFFFFu;
-            for (;;) {
-                uint32_t best = 0xFFFFFFFFu;
-                for (uint32_t e = first; e < first + cnt; ++e) {
-                    if (t.ent_type[e] == FG_T_SDID) continue;
-                    const Dyn d = this->dyn_of(e);
-                    if (prev != 0xFFFFFFFFu && cmp_dyn(d, this->dyn_of(prev)) <= 0) continue;
-                    if (best == 0xFFFFFFFFu || cmp_dyn(d, this->dyn_of(best)) <= 0) best = e;
-                }
-                if (best == 0xFFFFFFFFu) break;
-                const Dyn d = this->dyn_of(best);
-                bool shadowed = false;
-                while (sk < cfg.n_keys) {
+            // the static keys that sort before the entry (an equal one replaces it: gelf_extra is inserted last);
+            // all the remaining ones once the entries are exhausted
+            Dyn d{};
+            if (e != kNone) d = this->dyn_of(e);
+            bool shadowed = false;
+            while (sk < cfg.n_keys) {
+                if (e != kNone) {
                     const int c = cmp_dyn_static(d, cfg.keys[sk]);
                     if (c < 0) break;
                     if (c == 0) shadowed = true;
-                    emit_static(cfg.keys[sk], sdid_entry);
-                    ++sk;
                 }
-                if (!shadowed) emit_dyn(best);
-                prev = best;
+                emit_static(cfg.keys[sk], sdid_entry);
+                ++sk;
             }
+            if (e == kNone) break;
+            if (!shadowed) emit_dyn(e);
         }
-        for (; sk < cfg.n_keys; ++sk) emit_static(cfg.keys[sk], sdid_entry);
         out.put('}');
         return ES_OK;
     }

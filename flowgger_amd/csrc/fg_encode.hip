@@ -16,9 +16,19 @@
 #include "fg_device.hpp"
 #include "fg_emit.hpp"
 
+// Build: the emitters are large force-inlined templates, so this file is compiled once per kernel with
+// -DFG_ENC_TU=<FG_ENC_*> -DFG_ENC_TU_WRITE=<0|1> -DFG_ENC_TU_SLOTS=<n> (twelve objects, in parallel:
+// flowgger_amd/build.py) and once without FG_ENC_TU for the scan kernels, the dispatcher and the C entry points.
 namespace fg {
 
+#define FG_ENC_ARGS                                                                                                             \
+    const uint8_t *d_bytes, const uint64_t *d_offsets, uint64_t n, const DevTables &t, const EncCfg &cfg, uint32_t tile_cap,    \
+        uint32_t cfg_lds, uint32_t *d_sizes, uint8_t *d_status, uint64_t *d_block_sums, const uint64_t *d_out_offsets,          \
+        uint8_t *d_out, hipStream_t stream
+// one definition per (encoder, pass, ranking slots) object
+template <uint32_t ENC, bool WRITE, uint32_t SLOTS> int launch_encode_tu(FG_ENC_ARGS);
 
+#ifdef FG_ENC_TU
 // One 64-lane workgroup = 64 consecutive lines = ONE contiguous byte range of the packed buffer: it is staged into LDS
 // with coalesced 16-byte loads (stage_tile) and every lane then reads ITS line out of LDS; a group whose bytes exceed
 // the tile (long lines) reads from global memory instead (same emitter, GlobalReader).
@@ -92,6 +102,17 @@ __global__ __launch_bounds__(kWave) void k_encode(const uint8_t* __restrict__ by
     }
 }
 
+template <>
+int launch_encode_tu<FG_ENC_TU, (FG_ENC_TU_WRITE != 0), FG_ENC_TU_SLOTS>(FG_ENC_ARGS) {
+    const uint64_t blocks = (n + kWave - 1) / kWave;
+    if (blocks > 0x7FFFFFFFull) return -1;
+    hipLaunchKernelGGL((k_encode<FG_ENC_TU, (FG_ENC_TU_WRITE != 0), FG_ENC_TU_SLOTS>), dim3((uint32_t)blocks), dim3(kWave),
+                       tile_cap + 16u + cfg_lds, stream, d_bytes, d_offsets, n, t, cfg, tile_cap, cfg_lds, d_sizes, d_status, d_block_sums,
+                       d_out_offsets, d_out);
+    return 0;
+}
+#else  // !FG_ENC_TU: scan kernels, dispatcher, C entry points
+
 // exclusive scan of the per-workgroup sums (nb = ceil(n / 64) of them) in place; off_n[0] = the grand total.  One workgroup.
 __global__ __launch_bounds__(1024) void k_block_scan(uint64_t* __restrict__ block_sums, uint64_t nb, uint64_t* __restrict__ off_n) {
     __shared__ uint64_t wave_tot[16];
@@ -130,35 +151,29 @@ __global__ __launch_bounds__(kWave) void k_line_offsets(const uint32_t* __restri
 }
 
 template <bool WRITE>
-static int launch_encode(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const DevTables& t, const EncCfg& cfg,
-                         uint32_t tile_cap, uint32_t cfg_lds, uint32_t* d_sizes, uint8_t* d_status, uint64_t* d_block_sums,
-                         const uint64_t* d_out_offsets, uint8_t* d_out, hipStream_t stream) {
-    const uint64_t blocks = (n + kWave - 1) / kWave;
-    if (blocks > 0x7FFFFFFFull) return -1;
-    const dim3 g((uint32_t)blocks), b(kWave);
-    const uint32_t dyn_lds = tile_cap + 16u + cfg_lds;
-#define FG_LAUNCH(E, SL) \
-    hipLaunchKernelGGL((k_encode<E, WRITE, SL>), g, b, dyn_lds, stream, d_bytes, d_offsets, n, t, cfg, tile_cap, cfg_lds, d_sizes, d_status, \
-                       d_block_sums, d_out_offsets, d_out)
+static int launch_encode(FG_ENC_ARGS) {
+#define FG_CALL(E, SL) \
+    return launch_encode_tu<E, WRITE, SL>(d_bytes, d_offsets, n, t, cfg, tile_cap, cfg_lds, d_sizes, d_status, d_block_sums, d_out_offsets, d_out, stream)
     switch (cfg.enc) {
         case FG_ENC_GELF:
             // few pairs per line on average: a small ranking scratch (more LDS left for occupancy); a line with more
             // pairs than slots takes the exact selection path
-            if (cfg.sort_slots <= 8u) FG_LAUNCH(FG_ENC_GELF, 8u);
-            else FG_LAUNCH(FG_ENC_GELF, emit::kSortSlots);
-            break;
-        case FG_ENC_LTSV: FG_LAUNCH(FG_ENC_LTSV, 0u); break;
-        case FG_ENC_RFC5424: FG_LAUNCH(FG_ENC_RFC5424, 0u); break;
-        case FG_ENC_RFC3164: FG_LAUNCH(FG_ENC_RFC3164, 0u); break;
-        case FG_ENC_PASSTHROUGH: FG_LAUNCH(FG_ENC_PASSTHROUGH, 0u); break;
+            static_assert(emit::kSortSlots == 32u, "flowgger_amd/build.py compiles the GELF kernels for 8 and 32 slots");
+            if (cfg.sort_slots <= 8u) FG_CALL(FG_ENC_GELF, 8u);
+            FG_CALL(FG_ENC_GELF, 32u);
+        case FG_ENC_LTSV: FG_CALL(FG_ENC_LTSV, 0u);
+        case FG_ENC_RFC5424: FG_CALL(FG_ENC_RFC5424, 0u);
+        case FG_ENC_RFC3164: FG_CALL(FG_ENC_RFC3164, 0u);
+        case FG_ENC_PASSTHROUGH: FG_CALL(FG_ENC_PASSTHROUGH, 0u);
         default: return -1;
     }
-#undef FG_LAUNCH
-    return 0;
+#undef FG_CALL
 }
+#endif  // FG_ENC_TU
 
 }  // namespace fg
 
+#ifndef FG_ENC_TU
 // d_sizes: n u32; d_block_sums: ceil(n / 64) u64 (scratch)
 extern "C" int fg_launch_encode_sizes(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
                                       const fg::EncCfg* cfg, uint32_t tile_cap, uint32_t cfg_lds, uint32_t* d_sizes,
@@ -177,3 +192,4 @@ extern "C" int fg_launch_encode_write(const uint8_t* d_bytes, const uint64_t* d_
     if (fg::launch_encode<true>(d_bytes, d_offsets, n, *t, *cfg, tile_cap, cfg_lds, nullptr, nullptr, nullptr, d_out_offsets, d_out, stream) != 0) return -1;
     return (int)hipGetLastError();
 }
+#endif  // !FG_ENC_TU

@@ -19,12 +19,8 @@
 #include <string.h>
 
 #include "fg_timeconv.hpp"
+#include "fg_unicode_ws.hpp"
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
-#define FG3_HD __host__ __device__ __forceinline__
-#else
-#define FG3_HD inline
-#endif
 
 namespace fg {
 namespace r3164 {
@@ -40,13 +36,25 @@ enum : uint32_t {
     ST_REF_PANIC = 7       // the reference panics (index out of bounds, :67)
 };
 
+// The zone table as the kernel sees it (built by fg_tz_index.hpp on the host).  A lookup is: two register-resident
+// masks that reject most tokens without touching memory (first byte, length), one probe of an open-addressing hash
+// table, one word-wise name comparison; the offset search starts from the span range that covers the configured year.
+struct TzZone {
+    uint32_t name_off, name_len;  // into name_words (byte offset, a multiple of 4)
+    uint32_t first, last;         // the zone's spans [first, last] of utc_start / utc_off
+    uint32_t y_lo, y_hi;          // the spans a local time inside [hint_lo, hint_hi) can fall into
+};
 struct TzView {
-    const uint8_t* names;        // concatenated zone names, sorted bytewise
-    const uint32_t* name_off;    // [nz + 1]
+    const TzZone* zones;         // [nz], sorted by name (bytewise)
     uint32_t nz;
-    const uint32_t* zone_first;  // [nz + 1] into utc_start / utc_off
+    const uint32_t* name_words;  // every name starts on a dword and is zero padded to the next one
+    const uint32_t* slots;       // [slot_mask + 1]: (hash >> 16) << 16 | (zone + 1), 0 = empty; linear probing
+    uint32_t slot_mask;
     const int64_t* utc_start;    // the offset utc_off[i] is in effect from utc_start[i] (first entry: INT64_MIN)
     const int32_t* utc_off;
+    int64_t hint_lo, hint_hi;    // local seconds of the configured year [Jan 1, Jan 1 next year)
+    uint64_t first_lo, first_hi; // bit b: some zone name starts with byte b (0..63 / 64..127); bytes >= 128 always pass
+    uint64_t len_mask;           // bit min(len, 63): some zone name has this length
 };
 struct Cfg {
     int32_t current_year;
@@ -60,28 +68,6 @@ struct Row {
     uint32_t host_off = 0, host_len = 0, msg_off = 0, msg_len = 0, full_len = 0;
 };
 
-// byte length of the Unicode White_Space character starting at rd[i] (0: not whitespace); char::is_whitespace
-template <class R>
-FG3_HD uint32_t ws_at(R& rd, uint32_t i, uint32_t end) {
-    const uint32_t c = rd.byte(i);
-    if (c < 0x80u) return (c == 32u || (c - 9u) <= 4u) ? 1u : 0u;
-    if (c == 0xC2u) {
-        if (i + 1 >= end) return 0;
-        const uint32_t d = rd.byte(i + 1);
-        return (d == 0x85u || d == 0xA0u) ? 2u : 0u;
-    }
-    if (c == 0xE1u || c == 0xE2u || c == 0xE3u) {
-        if (i + 2 >= end) return 0;
-        const uint32_t b1 = rd.byte(i + 1), b2 = rd.byte(i + 2);
-        if (c == 0xE2u) {
-            if (b1 == 0x80u) return ((b2 - 0x80u) <= 0x0Au || b2 == 0xA8u || b2 == 0xA9u || b2 == 0xAFu) ? 3u : 0u;
-            return (b1 == 0x81u && b2 == 0x9Fu) ? 3u : 0u;
-        }
-        if (c == 0xE1u) return (b1 == 0x9Au && b2 == 0x80u) ? 3u : 0u;
-        return (b1 == 0x80u && b2 == 0x80u) ? 3u : 0u;
-    }
-    return 0;
-}
 // str::split_whitespace: the next token of rd[pos .. end); false when there is none
 template <class R>
 FG3_HD bool next_token(R& rd, uint32_t& pos, uint32_t end, uint32_t* ts, uint32_t* te) {
@@ -118,7 +104,6 @@ FG3_HD uint32_t trim_end_ws(R& rd, uint32_t s, uint32_t e) {
 struct Tok {
     uint32_t s, e;
 };
-constexpr uint32_t kMaxTok = 7;  // year month day time zone hostname first-message-token
 
 template <class R>
 FG3_HD bool two_digits(R& rd, uint32_t at, uint32_t* v) {
@@ -190,34 +175,43 @@ FG3_HD bool parse_year_tok(R& rd, const Tok& t, int* year) {
     *year = neg ? -v : v;
     return true;
 }
-// time_tz::timezones::get_by_name: exact match in the sorted name table; -1 = not a zone name
+// hash of a zone name / a token (FNV-1a, 32 bit)
+FG3_HD uint32_t tz_hash_step(uint32_t h, uint32_t byte) { return (h ^ byte) * 16777619u; }
+constexpr uint32_t kTzHashInit = 2166136261u;
+
+// time_tz::timezones::get_by_name: exact, case-sensitive match of the whole token; -1 = not a zone name
 template <class R>
 FG3_HD int32_t tz_lookup(R& rd, const Tok& t, const TzView& tz) {
     const uint32_t len = t.e - t.s;
-    uint32_t lo = 0, hi = tz.nz;
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        const uint32_t no = tz.name_off[mid], nl = tz.name_off[mid + 1] - no;
-        const uint32_t n = len < nl ? len : nl;
-        int c = 0;
-        for (uint32_t k = 0; k < n; ++k) {
-            const uint32_t a = rd.byte(t.s + k), b = tz.names[no + k];
-            if (a != b) {
-                c = a < b ? -1 : 1;
-                break;
-            }
+    const uint32_t c0 = rd.byte(t.s);
+    const uint64_t fm = c0 < 64u ? tz.first_lo : tz.first_hi;
+    if (c0 < 128u && !((fm >> (c0 & 63u)) & 1ull)) return -1;
+    if (!((tz.len_mask >> (len < 63u ? len : 63u)) & 1ull)) return -1;
+    uint32_t h = kTzHashInit;
+    for (uint32_t k = 0; k < len; ++k) h = tz_hash_step(h, rd.byte(t.s + k));
+    for (uint32_t slot = h & tz.slot_mask;; slot = (slot + 1u) & tz.slot_mask) {
+        const uint32_t v = tz.slots[slot];
+        if (v == 0u) return -1;
+        if ((v >> 16) != (h >> 16)) continue;
+        const uint32_t z = (v & 0xFFFFu) - 1u;
+        const TzZone zr = tz.zones[z];
+        if (zr.name_len != len) continue;
+        const uint32_t* nw = tz.name_words + (zr.name_off >> 2);
+        uint32_t diff = 0;
+        for (uint32_t k = 0; k < len; k += 4u) {
+            const uint32_t w = nw[k >> 2];
+            const uint32_t nb = len - k < 4u ? len - k : 4u;
+            for (uint32_t j = 0; j < nb; ++j) diff |= rd.byte(t.s + k + j) ^ ((w >> (8u * j)) & 0xFFu);
         }
-        if (c == 0) c = len == nl ? 0 : (len < nl ? -1 : 1);
-        if (c == 0) return (int32_t)mid;
-        if (c < 0) hi = mid;
-        else lo = mid + 1;
+        if (diff == 0u) return (int32_t)z;
     }
-    return -1;
 }
 // PrimitiveDateTime::assume_timezone: the UTC offset for a LOCAL time: the first span (chronologically) whose local
 // end lies after it -- the earlier offset for an ambiguous time, the later one inside a gap (UNPINNED)
 FG3_HD int32_t tz_offset_local(const TzView& tz, uint32_t zone, int64_t local) {
-    uint32_t lo = tz.zone_first[zone], hi = tz.zone_first[zone + 1] - 1u;
+    const TzZone zr = tz.zones[zone];
+    const bool hinted = local >= tz.hint_lo && local < tz.hint_hi;
+    uint32_t lo = hinted ? zr.y_lo : zr.first, hi = hinted ? zr.y_hi : zr.last;
     while (lo < hi) {
         const uint32_t mid = (lo + hi) >> 1;
         if (local < tz.utc_start[mid + 1] + (int64_t)tz.utc_off[mid]) hi = mid;
@@ -226,29 +220,36 @@ FG3_HD int32_t tz_offset_local(const TzView& tz, uint32_t zone, int64_t local) {
     return tz.utc_off[lo];
 }
 
-// parse_date_token (:155-162) over the first tokens of a region; *next = index of the first token after the date [+ zone]
+// parse_date_token (:155-162) over the tokens of rd[pos .. end), read one at a time (no token array: a dynamically
+// indexed array would live in scratch memory on the GPU).  On ST_OK: *nx = the first token after the date [+ zone]
+// (*have_nx = false: there is none) and pos stands behind it.
 template <class R>
-FG3_HD uint32_t parse_date_token(R& rd, const Tok* tok, uint32_t ntok, const Cfg& cfg, double* ts, uint32_t* next) {
-    if (ntok < 3u) return ST_TIME_FORMAT;
+FG3_HD uint32_t parse_date_token(R& rd, uint32_t& pos, uint32_t end, const Cfg& cfg, bool need4, double* ts, Tok* nx, bool* have_nx) {
+    Tok t0, t1, t2, t3;
+    if (!next_token(rd, pos, end, &t0.s, &t0.e) || !next_token(rd, pos, end, &t1.s, &t1.e) || !next_token(rd, pos, end, &t2.s, &t2.e))
+        return ST_TIME_FORMAT;  // fewer than three tokens
+    const bool have3 = next_token(rd, pos, end, &t3.s, &t3.e);
+    if (need4 && !have3) return ST_TIME_FORMAT;  // the standard form is only tried on more than three tokens (:61-63)
     int64_t local = 0;
-    uint32_t idx = 3;
-    bool ok = parse_mdt(rd, tok[0], tok[1], tok[2], cfg.current_year, &local);
-    if (!ok) {
-        if (ntok < 4u) return ST_DATE_YEAR;
+    Tok cand = t3;
+    bool have = have3;
+    if (!parse_mdt(rd, t0, t1, t2, cfg.current_year, &local)) {
+        if (!have3) return ST_DATE_YEAR;
         int year;
-        if (!parse_year_tok(rd, tok[0], &year) || !parse_mdt(rd, tok[1], tok[2], tok[3], year, &local)) return ST_DATE;
-        idx = 4;
+        if (!parse_year_tok(rd, t0, &year) || !parse_mdt(rd, t1, t2, t3, year, &local)) return ST_DATE;
+        have = next_token(rd, pos, end, &cand.s, &cand.e);
     }
     int64_t off = 0;
-    if (ntok > idx && cfg.tz.nz) {
-        const int32_t z = tz_lookup(rd, tok[idx], cfg.tz);
+    if (have && cfg.tz.nz) {
+        const int32_t z = tz_lookup(rd, cand, cfg.tz);
         if (z >= 0) {
             off = tz_offset_local(cfg.tz, (uint32_t)z, local);
-            ++idx;
+            have = next_token(rd, pos, end, &cand.s, &cand.e);
         }
     }
     *ts = unix_nanos_to_f64(local - off, 0u);
-    *next = idx;
+    *nx = cand;
+    *have_nx = have;
     return ST_OK;
 }
 
@@ -295,35 +296,31 @@ FG3_HD void parse_line(R& rd, uint32_t len, const Cfg& cfg, Row& r) {
     r.full_len = trim_end_ws(rd, 0, len);  // line.trim_end()
 
     // ---- decode_rfc_standard ---------------------------------------------------------------------------------------
-    Tok tok[kMaxTok];
-    uint32_t ntok = 0, pos = q0;
-    while (ntok < kMaxTok) {
-        uint32_t s, e;
-        if (!next_token(rd, pos, len, &s, &e)) break;
-        tok[ntok].s = s;
-        tok[ntok].e = e;
-        ++ntok;
-    }
-    if (ntok > 3u) {
-        double ts;
-        uint32_t next;
-        if (parse_date_token(rd, tok, ntok, cfg, &ts, &next) == ST_OK) {
-            if (next >= ntok) {  // kMaxTok >= next + 2 always, so this is the true "no token left"
-                r.status = ST_REF_PANIC;
+    {   // needs more than three tokens (:61-63); then the date [+ zone], the hostname, the message tokens
+        uint32_t pos = q0;
+        {
+            double ts;
+            Tok host;
+            bool have_host;
+            if (parse_date_token(rd, pos, len, cfg, true, &ts, &host, &have_host) == ST_OK) {
+                if (!have_host) {  // the date [+ zone] consumed every token: index out of bounds in the reference (:67)
+                    r.status = ST_REF_PANIC;
+                    return;
+                }
+                r.ts = ts;
+                r.host_off = host.s;
+                r.host_len = host.e - host.s;
+                Tok m;
+                if (next_token(rd, pos, len, &m.s, &m.e)) {
+                    r.msg_off = m.s;
+                    r.msg_len = trim_end_ws(rd, r.msg_off, len) - r.msg_off;
+                    r.msg_join = true;
+                } else {
+                    r.msg_off = host.e;
+                    r.msg_len = 0;
+                }
                 return;
             }
-            r.ts = ts;
-            r.host_off = tok[next].s;
-            r.host_len = tok[next].e - tok[next].s;
-            if (next + 1u < ntok) {
-                r.msg_off = tok[next + 1u].s;
-                r.msg_len = trim_end_ws(rd, r.msg_off, len) - r.msg_off;
-                r.msg_join = true;
-            } else {
-                r.msg_off = tok[next].e;
-                r.msg_len = 0;
-            }
-            return;
         }
     }
     // ---- decode_rfc_custom -----------------------------------------------------------------------------------------
@@ -342,18 +339,11 @@ FG3_HD void parse_line(R& rd, uint32_t len, const Cfg& cfg, Row& r) {
         r.status = ST_MALFORMED;
         return;
     }
-    ntok = 0;
-    pos = p1 + 2u;
-    while (ntok < kMaxTok) {
-        uint32_t s, e;
-        if (!next_token(rd, pos, p2, &s, &e)) break;
-        tok[ntok].s = s;
-        tok[ntok].e = e;
-        ++ntok;
-    }
+    uint32_t pos = p1 + 2u;
     double ts;
-    uint32_t next;
-    const uint32_t st = parse_date_token(rd, tok, ntok, cfg, &ts, &next);
+    Tok nx;
+    bool have_nx;
+    const uint32_t st = parse_date_token(rd, pos, p2, cfg, false, &ts, &nx, &have_nx);
     if (st != ST_OK) {
         r.status = st;
         return;

@@ -36,6 +36,14 @@ class Encoder:
         self.merger = MERGERS[merger if merger is not None else out.get("framing")]
         self.prepend = prepend
 
+    def _cfg_struct(self, now_ts: float = 0.0):
+        """fg_encode_cfg for this encoder (+ the ctypes arrays that must stay alive while it is used)."""
+        ks = (C.c_char_p * max(len(self.extra), 1))(*[k.encode() for k, _ in self.extra])
+        vs = (C.c_char_p * max(len(self.extra), 1))(*[v.encode() for _, v in self.extra])
+        cfg = L.fg_encode_cfg(self.enc, self.merger, len(self.extra), C.cast(ks, C.POINTER(C.c_char_p)),
+                              C.cast(vs, C.POINTER(C.c_char_p)), None if self.prepend is None else self.prepend.encode(), now_ts)
+        return cfg, (ks, vs)
+
     def encode_device(self, decoder, d_bytes, d_offsets, n: int, tables: DeviceTables, now_ts: float = 0.0, stream=None,
                       want_status: bool = False, out=None):
         """Encode + frame the n decoded lines of `tables` (produced by `decoder` from d_bytes / d_offsets).
@@ -47,10 +55,7 @@ class Encoder:
 
         if stream is None:
             stream = torch.cuda.current_stream(d_bytes.device)
-        ks = (C.c_char_p * max(len(self.extra), 1))(*[k.encode() for k, _ in self.extra])
-        vs = (C.c_char_p * max(len(self.extra), 1))(*[v.encode() for _, v in self.extra])
-        cfg = L.fg_encode_cfg(self.enc, self.merger, len(self.extra), C.cast(ks, C.POINTER(C.c_char_p)),
-                              C.cast(vs, C.POINTER(C.c_char_p)), None if self.prepend is None else self.prepend.encode(), now_ts)
+        cfg, _keep = self._cfg_struct(now_ts)
         d_off = torch.empty(n + 1, dtype=torch.int64, device=d_bytes.device)
         d_st = torch.empty(max(n, 1), dtype=torch.uint8, device=d_bytes.device) if want_status else None
         total = C.c_uint64()
@@ -94,3 +99,70 @@ class RFC3164Encoder(Encoder):  # encoder/rfc3164_encoder.rs
 
 class PassthroughEncoder(Encoder):  # encoder/passthrough_encoder.rs
     enc = L.FG_ENC_PASSTHROUGH
+
+
+class Transcoded:
+    """Result of Pipeline.run: the encoded + framed stream and one verdict per line (copies of ctx-owned pinned memory)."""
+
+    def __init__(self, out, out_offsets, meta, enc_status, frame_offsets, consumed):
+        self.out, self.out_offsets, self.meta, self.enc_status = out, out_offsets, meta, enc_status
+        self.frame_offsets, self.consumed = frame_offsets, consumed
+
+    @property
+    def n(self) -> int:
+        return len(self.enc_status)
+
+    @property
+    def dec_status(self):
+        return (self.meta & 0xFF).astype("uint8")
+
+    def message(self, i: int) -> bytes:
+        return self.out[int(self.out_offsets[i]):int(self.out_offsets[i + 1])].tobytes()
+
+
+class Pipeline:
+    """decoder -> encoder -> merger for whole batches with HOST buffers (fg_transcode_batch): what
+    ``handle_line`` (splitter/line_splitter.rs:44-54) does per line.  Only the encoded bytes and the per-line
+    verdicts come back over PCIe; the decode tables stay in HBM."""
+
+    def __init__(self, decoder, encoder: Encoder):
+        self.decoder, self.encoder = decoder, encoder
+
+    def _call(self, framing: int, data, nbytes: int, offsets, n: int, final: bool, now_ts: float) -> Transcoded:
+        import numpy as np
+
+        cfg, _keep = self.encoder._cfg_struct(now_ts)
+        res = L.fg_transcoded()
+        rc = L.lib().fg_transcode_batch(self.decoder._ctx, self.decoder.fmt, framing, C.byref(cfg), data.ctypes.data, nbytes,
+                                        None if offsets is None else offsets.ctypes.data, n, int(final), C.byref(res))
+        L.check(rc, "fg_transcode_batch")
+        m = int(res.n)
+
+        def view(ptr, count, dt):
+            if not count or not ptr:
+                return np.zeros(0, dt)
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), (count * np.dtype(dt).itemsize,)).view(dt).copy()
+
+        return Transcoded(view(res.out, int(res.out_bytes), np.uint8),
+                          view(res.out_offsets, m + 1 if m else 0, np.uint64) if m else np.zeros(1, np.uint64),
+                          view(res.meta, m, np.uint32), view(res.enc_status, m, np.uint8),
+                          view(res.frame_offsets, m + 1, np.uint64) if (m and res.frame_offsets) else None, int(res.consumed))
+
+    def run_packed(self, data, offsets, now_ts: float = 0.0) -> Transcoded:
+        """framed lines (packed bytes + offsets[n + 1], as produced by pack_lines)"""
+        import numpy as np
+
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        return self._call(L.FG_FRAME_NONE, data, int(offsets[-1]) if n else 0, offsets, n, True, now_ts)
+
+    def run_stream(self, raw, framing: int, final: bool = True, now_ts: float = 0.0) -> Transcoded:
+        """a raw stream chunk, framed on the GPU ("\\n" / NUL); bytes past `.consumed` belong to the next chunk"""
+        import numpy as np
+
+        data = np.frombuffer(raw, dtype=np.uint8) if isinstance(raw, (bytes, bytearray)) else np.ascontiguousarray(raw, dtype=np.uint8)
+        if len(data) == 0:
+            data = np.zeros(1, np.uint8)
+            return self._call(framing, data, 0, None, 0, final, now_ts)
+        return self._call(framing, data, len(data), None, 0, final, now_ts)

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <functional>
 #include <istream>
+#include <map>
 #include <memory>
 #include <optional>
 #include <ostream>
@@ -230,6 +231,19 @@ class LTSVDecoder : public Decoder {  // decoder/ltsv_decoder.rs:17-221
     LTSVDecoder(const LTSVDecoder& o, int) : Decoder(o, 0) {}
 };
 
+class RFC3164Decoder : public Decoder {  // decoder/rfc3164_decoder.rs:14-213
+  public:
+    // current_year / tz: what the reference reads from the wall clock (:179) and from time_tz's zone database (:195)
+    // become configuration; tz may be null (no zone name is recognised).  fg_clone carries both over.
+    RFC3164Decoder(int32_t current_year, const fg_tz_table* tz, int device = 0) : Decoder(FG_RFC3164, device, nullptr) {
+        fg_rfc3164_cfg c{current_year, tz};
+        if (fg_set_rfc3164(ctx_, &c) != FG_OK) throw std::runtime_error("fg_set_rfc3164 failed");
+    }
+    std::unique_ptr<Decoder> clone_boxed() const override { return std::unique_ptr<Decoder>(new RFC3164Decoder(*this, 0)); }
+  private:
+    RFC3164Decoder(const RFC3164Decoder& o, int) : Decoder(o, 0) {}
+};
+
 // ---------------------------------------------------------------------------------------------
 // Batching framers: same framing and error reporting as the reference splitters, one
 // decode_batch per `max_lines` / `max_bytes` instead of one decode per line.
@@ -423,6 +437,86 @@ class GpuFramingSplitter {
         }
     }
     Framing f_;
+    size_t chunk_;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Encoder / Merger configuration (encoder/mod.rs:54-56, merger/mod.rs:30-32) and the splitter that runs the WHOLE
+// handle_line on the GPU (fg_transcode_batch): framing, UTF-8 check, decode, encode, merger.  What comes back is the
+// byte stream the output writes, plus one verdict per line for the reference's stderr messages.
+// ---------------------------------------------------------------------------------------------
+struct EncoderConfig {
+    fg_encoder encoder = FG_ENC_GELF;
+    fg_merger merger = FG_MERGE_LINE;
+    std::map<std::string, std::string> extra;  // output.gelf_extra / output.ltsv_extra (a sorted table, like toml's)
+    std::optional<std::string> prepend;        // the formatted output.syslog_prepend_timestamp header
+    double now_ts = 0.0;                       // ts of GELF records decoded without "timestamp" (gelf_decoder.rs:109)
+};
+
+class TranscodingSplitter {
+  public:
+    enum Framing { Line, Nul };
+    TranscodingSplitter(Framing f, EncoderConfig enc, size_t chunk_bytes = 8u << 20) : f_(f), enc_(std::move(enc)), chunk_(chunk_bytes) {}
+
+    // LineSplitter::run / NulSplitter::run (line_splitter.rs:10-41, nul_splitter.rs:10-50) + the output thread's write:
+    // `out` receives the encoded, framed messages in input order; `err` what the reference prints for dropped lines.
+    void run(std::istream& in, const Decoder& d, std::ostream& out, std::ostream& err) {
+        std::vector<const char*> ks, vs;
+        for (auto& kv : enc_.extra) { ks.push_back(kv.first.c_str()); vs.push_back(kv.second.c_str()); }
+        fg_encode_cfg ec{};
+        ec.encoder = enc_.encoder;
+        ec.merger = enc_.merger;
+        ec.n_extra = (uint32_t)ks.size();
+        ec.extra_keys = ks.data();
+        ec.extra_values = vs.data();
+        ec.prepend = enc_.prepend ? enc_.prepend->c_str() : nullptr;
+        ec.now_ts = enc_.now_ts;
+        std::vector<uint8_t> buf;
+        bool eof = false;
+        while (!eof || !buf.empty()) {
+            const size_t have = buf.size();
+            if (!eof) {
+                buf.resize(have + chunk_);
+                in.read((char*)buf.data() + have, (std::streamsize)chunk_);
+                const size_t got = (size_t)in.gcount();
+                buf.resize(have + got);
+                eof = got < chunk_;
+            }
+            if (buf.empty()) break;
+            fg_transcoded r{};
+            int rc = fg_transcode_batch(d.ctx(), d.format(), f_ == Line ? FG_FRAME_LINE : FG_FRAME_NUL, &ec, buf.data(), buf.size(), nullptr,
+                                        0, eof ? 1 : 0, &r);
+            if (rc != FG_OK) throw std::runtime_error("fg_transcode_batch failed: " + std::to_string(rc));
+            if (r.out_bytes) out.write((const char*)r.out, (std::streamsize)r.out_bytes);
+            for (uint64_t i = 0; i < r.n; ++i) {
+                const uint8_t st = FG_META_STATUS(r.meta[i]), es = r.enc_status[i];
+                if (st == 0 && es == 0) continue;
+                if (st == FG_ST_BAD_UTF8) {
+                    err << "Invalid UTF-8 input\n";  // line_splitter.rs:22-25, nul_splitter.rs:35-38
+                    continue;
+                }
+                uint64_t b = r.frame_offsets[i], e = r.frame_offsets[i + 1];  // the line without its terminator
+                if (f_ == Line) {
+                    if (e > b && buf[e - 1] == '\n') { --e; if (e > b && buf[e - 1] == '\r') --e; }
+                } else if (e > b && buf[e - 1] == 0) {
+                    --e;
+                }
+                std::string_view tl = detail::trim(std::string_view((const char*)buf.data() + b, e - b));
+                if (f_ == Nul && tl.empty()) continue;  // nul_splitter.rs:41-46
+                const char* msg = st ? fg_error_string(d.format(), st) : fg_encode_error_string(es);
+                err << (msg ? msg : "?") << ": [" << tl << "]\n";  // line_splitter.rs:37-39
+            }
+            if (r.consumed == 0 && !eof && r.n == 0) {  // one frame longer than the chunk: read more
+                chunk_ *= 2;
+                continue;
+            }
+            buf.erase(buf.begin(), buf.begin() + (std::ptrdiff_t)r.consumed);
+        }
+    }
+
+  private:
+    Framing f_;
+    EncoderConfig enc_;
     size_t chunk_;
 };
 

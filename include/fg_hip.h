@@ -294,6 +294,37 @@ int fg_encode_device(fg_ctx* ctx, fg_format src_fmt, const fg_encode_cfg* cfg, c
 /* The reference's exact &'static str of an encode status (0 / 1 -> "", unknown -> NULL). */
 const char* fg_encode_error_string(uint8_t enc_status);
 
+/* THE WHOLE handle_line OF A BATCH -- HOST BUFFERS IN, ENCODED STREAM OUT (BASELINE configs[0]: input -> decoder ->
+ * encoder -> output).  Replaces, for every line of a batch, the body of handle_line (splitter/line_splitter.rs:44-54:
+ * `decoder.decode(line)` -> `encoder.encode(decoded)` -> `tx.send(..)`) plus the Merger::frame the output applies
+ * (merger/mod.rs:30-32), and -- when `framing` is FG_FRAME_LINE / FG_FRAME_NUL -- the splitter's own framing + UTF-8
+ * check (line_splitter.rs:17-25, nul_splitter.rs:18-40).  Everything between the two PCIe copies stays in HBM: the
+ * decode tables are never copied back; what returns is the encoded + framed byte stream in input order and one
+ * verdict per line, i.e. what the output thread writes and what the splitter prints to stderr.
+ *   framing == FG_FRAME_NONE: `bytes` / `offsets[n + 1]` are framed lines (as for fg_decode_batch); `final` is ignored.
+ *   framing == FG_FRAME_LINE / _NUL: `bytes` is a raw stream chunk, `offsets` must be NULL and `n` is ignored; an
+ *     unterminated tail is a frame only when `final` != 0, otherwise out->consumed < nbytes and the caller carries
+ *     the rest over to the next call (as for fg_frame_decode_batch).
+ * Results (pinned host memory owned by ctx, valid until the next host-buffer call on it):
+ *   out / out_bytes / out_offsets[n + 1]   message i = out[out_offsets[i] .. out_offsets[i + 1]) -- empty when the
+ *                                          line was dropped
+ *   meta[n]         the table's meta column: meta & 0xFF = decoder status (fg_error_string; FG_ST_BAD_UTF8)
+ *   enc_status[n]   0 = encoded, 1 = the decode had failed, else an encoder error (fg_encode_error_string)
+ *   frame_offsets   the frames found in the chunk (n + 1 entries; NULL for FG_FRAME_NONE), for the stderr message
+ *   n, consumed     lines handled, input bytes they cover */
+typedef struct fg_transcoded {
+    const uint8_t* out;
+    uint64_t out_bytes;
+    const uint64_t* out_offsets;
+    const uint32_t* meta;
+    const uint8_t* enc_status;
+    const uint64_t* frame_offsets;
+    uint64_t n;
+    uint64_t consumed;
+} fg_transcoded;
+int fg_transcode_batch(fg_ctx* ctx, fg_format fmt, fg_framing framing, const fg_encode_cfg* cfg, const uint8_t* bytes,
+                       uint64_t nbytes, const uint64_t* offsets, uint64_t n, int final, fg_transcoded* out);
+
 /* Page-locked host memory for the framer's batch buffers (bytes, offsets). */
 int fg_alloc_pinned(uint64_t bytes, void** out);
 void fg_free_pinned(void* p);

@@ -8,6 +8,7 @@
 
 #include "../../include/fg_hip.h"
 #include "../../flowgger_amd/csrc/fg_rfc3164_parse.hpp"
+#include "../../flowgger_amd/csrc/fg_tz_index.hpp"
 
 namespace {
 struct HostReader {
@@ -19,16 +20,16 @@ struct HostReader {
 extern "C" int fg3_decode_batch(const uint8_t* bytes, const uint64_t* offsets, uint64_t n, int32_t current_year, uint32_t n_zones,
                                 const char* const* names, const uint32_t* zone_first, const int64_t* utc_start,
                                 const int32_t* utc_offset, fg_tables* t) {
-    std::vector<uint8_t> blob;
-    std::vector<uint32_t> name_off(n_zones + 1, 0);
-    for (uint32_t z = 0; z < n_zones; ++z) {
-        name_off[z] = (uint32_t)blob.size();
-        blob.insert(blob.end(), names[z], names[z] + strlen(names[z]));
-    }
-    name_off[n_zones] = (uint32_t)blob.size();
+    // the same index the product uploads to the GPU (fg_tz_index.hpp), bound to host memory
+    std::vector<std::string> nm(names, names + n_zones);
+    const uint32_t ne = n_zones ? zone_first[n_zones] : 0u;
+    fg::r3164::TzIndex idx;
+    if (!idx.build(nm, std::vector<uint32_t>(zone_first, zone_first + (n_zones ? n_zones + 1 : 0)),
+                   std::vector<int64_t>(utc_start, utc_start + ne), std::vector<int32_t>(utc_offset, utc_offset + ne), current_year))
+        return -1;
     fg::r3164::Cfg cfg{};
     cfg.current_year = current_year;
-    cfg.tz = fg::r3164::TzView{blob.data(), name_off.data(), n_zones, zone_first, utc_start, utc_offset};
+    cfg.tz = idx.view(idx.blob.data());
     const fg_span none{0u, FG_NONE};
     for (uint64_t i = 0; i < n; ++i) {
         // an exact-size private copy of the line: reads outside [0, len) would be caught by ASan-style tooling and

@@ -831,7 +831,7 @@ def test_rfc3164_frames(r3164, oracle):
             assert str(got) == "Invalid UTF-8 input"
         else:
             assert blob[int(offs[i]):int(offs[i + 1])].tobytes() == oblob[int(ooffs[i]):int(ooffs[i + 1])].tobytes(), (i, got)
-    st = tables.to_host().status()
+    st = tables.to_host().status
     ost = np.array([oblob[int(ooffs[i])] for i in range(len(lines))])
     assert int((st != 0).sum()) == int((ost != 0).sum())  # line 9 fails either way
 
@@ -861,3 +861,119 @@ def test_encoders_on_rfc3164_records(r3164, oracle, enc):
         a, b = out[int(off[i]):int(off[i + 1])].tobytes(), oblob[int(ooffs[i]):int(ooffs[i + 1])].tobytes()
         raise AssertionError(f"line {i}: {lines[i][:160]!r}\n  gpu    {a!r}\n  oracle {b!r}")
     assert (np.diff(ooffs.astype(np.int64)) > 0).sum() > 0.5 * len(lines)
+
+
+# ---------------------------------------------------------------------------------------------
+# fg_transcode_batch: the whole handle_line of a batch with host buffers (BASELINE configs[0] through the C ABI)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("src,enc,merger", [("rfc5424", "gelf", "line"), ("rfc5424", "rfc5424", "syslen"), ("ltsv", "ltsv", "line"),
+                                            ("gelf", "gelf", "nul"), ("rfc3164", "rfc3164", "line"), ("rfc5424", "passthrough", "none")])
+def test_transcode_batch_equals_the_reference_pipeline(rfc, r3164, oracle, src, enc, merger):
+    """host buffers in -> (H2D, decode, encode, frame, D2H of the bytes only) -> exactly the oracle's
+    decode -> Encoder::encode -> Merger::frame stream, with the decoder / encoder verdict per line"""
+    import oracle_binding as OB
+    from flowgger_amd import GelfEncoder, LTSVEncoder, PassthroughEncoder, Pipeline, RFC3164Encoder, RFC5424Encoder
+
+    if src == "rfc3164":
+        dec, fmt, cfg, lines = r3164, RFC3164, None, synth.rfc3164_lines(6_000)
+    else:
+        dec, fmt, cfg, lines = _encode_corpus(src, rfc)
+    data, offsets = synth.pack(lines)
+    cls, oenc = {"gelf": (GelfEncoder, OB.ENC_GELF), "ltsv": (LTSVEncoder, OB.ENC_LTSV), "rfc5424": (RFC5424Encoder, OB.ENC_RFC5424),
+                 "rfc3164": (RFC3164Encoder, OB.ENC_RFC3164), "passthrough": (PassthroughEncoder, OB.ENC_PASSTHROUGH)}[enc]
+    om = {"none": OB.MERGE_NONE, "line": OB.MERGE_LINE, "nul": OB.MERGE_NUL, "syslen": OB.MERGE_SYSLEN}[merger]
+    now_ts = 1438859724.638
+    pipe = Pipeline(dec, cls(None, merger=merger))
+    oblob, ooffs, ost = oracle.decode_encode_batch(fmt, oenc, om, data, offsets, cfg, extra=None, prepend=None, now_ts=now_ts)
+    oracle_dec, odec_offs = oracle.decode_batch(fmt, data, offsets, cfg)
+    for rep in range(2):  # the second call reuses the grown buffers
+        r = pipe.run_packed(data, offsets, now_ts=now_ts)
+        assert r.n == len(lines) and r.consumed == int(offsets[-1])
+        assert np.array_equal(r.out_offsets, ooffs) and np.array_equal(r.out, oblob)
+        assert np.array_equal(np.minimum(r.enc_status, 2), ost)
+        # decoder verdict per line: Ok exactly where the oracle's Record is Ok
+        assert np.array_equal(r.dec_status != 0, oracle_dec[odec_offs[:-1].astype(np.int64)] != 0)
+    # an empty batch and a one-line batch
+    e = pipe.run_packed(np.zeros(16, np.uint8), np.zeros(1, np.uint64))
+    assert e.n == 0 and len(e.out) == 0
+    d1, o1 = synth.pack(lines[:1])
+    one = pipe.run_packed(d1, o1, now_ts=now_ts)
+    assert one.out.tobytes() == oblob[:int(ooffs[1])].tobytes()
+
+
+def test_transcode_stream_chunks_concatenate(rfc, oracle):
+    """raw "\\n" stream cut into arbitrary chunks -> GPU framing + UTF-8 check + decode + GELF encode + line merger:
+    the concatenated output equals the oracle's pipeline over the valid frames (stdin -> rfc5424 -> gelf, configs[0])"""
+    import oracle_binding as OB
+    from flowgger_amd import GelfEncoder, Pipeline
+    from flowgger_amd import _lib as L
+
+    lines = synth.rfc5424_lines(20_000, cfg=2) + synth.rfc5424_lines(1_000, cfg=4, sd=True)
+    tort = _utf8_torture()
+    raw = b"".join((ln + (b" " + tort[i % len(tort)] if i % 11 == 4 else b"")) + (b"\r\n" if i % 4 == 0 else b"\n")
+                   for i, ln in enumerate(lines)) + b"<13>1 2015-08-05T15:53:45Z h a p m - unterminated last line"
+    ref = _frames_reference(raw, "line")
+    good = [r[2] for r in ref if r[3]]
+    gdata, goffs = synth.pack(good)
+    oblob, ooffs, ost = oracle.decode_encode_batch(RFC5424, OB.ENC_GELF, OB.MERGE_LINE, gdata, goffs, None, extra=None, prepend=None, now_ts=0.0)
+    pipe = Pipeline(rfc, GelfEncoder(None, merger="line"))
+    rng = np.random.default_rng(5)
+    out, n_frames, n_bad, pos, carry = [], 0, 0, 0, b""
+    while True:
+        step = int(rng.integers(1, 900_000))
+        chunk = carry + raw[pos:pos + step]
+        pos += step
+        final = pos >= len(raw)
+        r = pipe.run_stream(chunk, L.FG_FRAME_LINE, final=final)
+        out.append(r.out.tobytes())
+        n_frames += r.n
+        n_bad += int((r.dec_status == L.FG_ST_BAD_UTF8).sum())
+        if r.n:
+            assert int(r.frame_offsets[-1]) == r.consumed or final
+        carry = chunk[r.consumed:]
+        if final:
+            assert carry == b""
+            break
+    assert n_frames == len(ref) and n_bad == sum(1 for r in ref if not r[3])
+    assert b"".join(out) == oblob.tobytes()
+
+
+@pytest.mark.parametrize("fmt,framing", [("rfc5424", "pipe-line"), ("gelf", "pipe-nul")])
+def test_cpp_transcoding_splitter_is_the_reference_pipeline(tmp_path, oracle, fmt, framing):
+    """fg::TranscodingSplitter (C++): raw stream -> the GELF stream the output writes + the reference's stderr lines,
+    i.e. BASELINE configs[0] (input -> decoder -> gelf encoder -> output) with every stage on the GPU"""
+    import subprocess
+    from pathlib import Path
+
+    import oracle_binding as OB
+
+    root = Path(__file__).resolve().parent.parent
+    exe = tmp_path / "host_mirror_test"
+    subprocess.run(["g++", "-std=c++17", "-O1", str(root / "tests/native/host_mirror_test.cpp"), "-o", str(exe),
+                    f"-L{root / 'flowgger_amd'}", "-lfg_hip", f"-Wl,-rpath,{root / 'flowgger_amd'}",
+                    "-L/opt/rocm/lib", "-lamdhip64"], check=True)
+    code = {"rfc5424": RFC5424, "gelf": GELF}[fmt]
+    lines = synth.rfc5424_lines(3000, cfg=4, sd=True) + synth.rfc5424_lines(3000, cfg=2) if fmt == "rfc5424" else synth.gelf_lines(3000)
+    term = b"\n" if framing == "pipe-line" else b"\0"
+    lines = [ln for ln in lines if b"\n" not in ln and b"\0" not in ln]
+    bad_utf8 = b"<13>1 2015-08-05T15:53:45Z h a p m - \xff\xfe"
+    raw = b"".join(ln + term for ln in lines[:100]) + bad_utf8 + term + b"".join(ln + term for ln in lines[100:-1]) + lines[-1]
+    f = tmp_path / "in.bin"
+    f.write_bytes(raw)
+    p = subprocess.run([str(exe), fmt, framing, str(f), "30011"], capture_output=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    data, offsets = synth.pack(lines)
+    extra = {"_site": "dc1", "a_first": "x\"y"}
+    oblob, ooffs, ost = oracle.decode_encode_batch(code, OB.ENC_GELF, OB.MERGE_LINE if term == b"\n" else OB.MERGE_NUL, data, offsets, None,
+                                                   extra=extra, prepend=None, now_ts=1438859724.638)
+    assert p.stdout == oblob.tobytes()
+    want_err = []
+    for i, ln in enumerate(lines):
+        if i == 100:
+            want_err.append("Invalid UTF-8 input")
+        c = oracle.decode(code, ln, None)
+        if c[0] != 0:
+            t = ln.decode("utf-8", "replace").strip()
+            if not (term == b"\0" and t == ""):
+                want_err.append(f"{c[5:].decode()}: [{t}]")
+    assert p.stderr.decode("utf-8", "replace").splitlines() == want_err

@@ -112,7 +112,7 @@ def fuzz_lines(n, seed):
 @pytest.fixture(scope="module")
 def host3164():
     src, lib = ROOT / "tests/native/rfc3164_host.cpp", ROOT / "tests/native/librfc3164_host.so"
-    deps = [src, ROOT / "flowgger_amd/csrc/fg_rfc3164_parse.hpp", ROOT / "flowgger_amd/csrc/fg_timeconv.hpp", ROOT / "include/fg_hip.h"]
+    deps = [src, ROOT / "flowgger_amd/csrc/fg_rfc3164_parse.hpp", ROOT / "flowgger_amd/csrc/fg_tz_index.hpp", ROOT / "flowgger_amd/csrc/fg_timeconv.hpp", ROOT / "include/fg_hip.h"]
     if not lib.exists() or lib.stat().st_mtime < max(p.stat().st_mtime for p in deps):
         subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-fno-fast-math", "-o", str(lib), str(src)], check=True)
     lib = C.CDLL(str(lib))
@@ -143,3 +143,41 @@ def test_kernel_parser_equals_oracle(host3164, oracle3164):
     errs = {str(r) for r in res if isinstance(r, DecodeError)}
     assert len(errs) == 7, errs                      # every status is exercised
     assert sum(not isinstance(r, DecodeError) for r in res) > 0.2 * len(lines)
+
+
+def test_zone_index_near_misses_and_unhinted_years(host3164, oracle3164):
+    """the hash index / reject masks / year hints of fg_tz_index.hpp: tokens that pass the masks but are no zone,
+    every zone name of the table, and dates (with a year) far outside the hinted year -- all == the oracle's
+    linear get_by_name + assume_timezone"""
+    T = tzdb.default_table()
+    names = list(T.names)
+    lines = []
+    for k, z in enumerate(names):  # every zone, in the configured year (hinted) -- both halves of the year (DST)
+        mon = ("Jan", "Jul", "Mar", "Oct", "Nov")[k % 5]
+        lines.append(f"<13>{mon} {1 + k % 28} 0{k % 10}:30:1{k % 10} {z} host{k} message {k}".encode())
+    for k, z in enumerate(names[::7]):  # with a year: far past, far future, around the first / last transitions
+        for year in (1850, 1901, 1916, 1942, 1970, 1986, 2007, 2037, 2038, 2100, 9999):
+            lines.append(f"{year} Mar {25 + k % 6} 02:30:00 {z} h m".encode())
+            lines.append(f"{year} Oct {25 + k % 6} 02:30:00 {z} h m".encode())
+    near = []
+    for z in names[::11]:  # near misses: same first byte and a plausible length, not a zone
+        near += [z[:-1], z + "s", z.lower(), z.upper(), z[0] + z[1:].swapcase(), z.replace("/", "_"), z + "/", "/" + z]
+    near += ["UTCx", "UT", "U", "Z", "Zulu0", "EST5ED", "GMT+", "GMT-15", "Etc/GMT+13", "É", "Ünicode", "Europe", "Europe/"]
+    known = set(names)
+    for k, tok in enumerate(near):
+        if tok and tok not in known and " " not in tok:
+            lines.append(f"Aug  6 11:15:24 {tok} rest of the message {k}".encode())  # tok is the hostname
+            lines.append(f"Aug  6 11:15:24 {tok}".encode())                          # ... and nothing follows
+    (blob, offs), data, offsets = host3164(lines)
+    oblob, ooffs = oracle3164.decode_batch(RFC3164, data, offsets)
+    for i in range(len(lines)):
+        a, b = blob[int(offs[i]):int(offs[i + 1])].tobytes(), oblob[int(ooffs[i]):int(ooffs[i + 1])].tobytes()
+        assert a == b, (i, lines[i], parse_canonical(a), parse_canonical(b))
+    # a different configured year moves the hint window: same equality
+    (blob, offs), data, offsets = host3164(lines[:len(names)], year=1999)
+    oracle3164.set_rfc3164(1999, T)
+    try:
+        oblob, ooffs = oracle3164.decode_batch(RFC3164, data, offsets)
+    finally:
+        oracle3164.set_rfc3164(RFC3164_YEAR, T)
+    assert np.array_equal(offs, ooffs) and np.array_equal(blob, oblob)
