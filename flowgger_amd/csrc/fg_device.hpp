@@ -52,6 +52,16 @@ struct LdsReader {
         cur_idx = w + 1u;
         return __builtin_amdgcn_alignbyte(cur, lo, a & 3u);
     }
+    // 16 bytes starting at byte i, all wanted: five independent dword reads in flight (ONE LDS round trip instead of
+    // four dependent ones); the fifth is only looked at when the start is not dword aligned
+    __device__ __forceinline__ void load16(uint32_t i, uint32_t* q) {
+        const uint32_t a = base + i, w = a >> 2, sh = a & 3u;
+        const uint32_t d0 = words[w], d1 = words[w + 1u], d2 = words[w + 2u], d3 = words[w + 3u], d4 = words[w + (sh ? 4u : 3u)];
+        q[0] = __builtin_amdgcn_alignbyte(d1, d0, sh);
+        q[1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+        q[2] = __builtin_amdgcn_alignbyte(d3, d2, sh);
+        q[3] = __builtin_amdgcn_alignbyte(d4, d3, sh);
+    }
 };
 struct GlobalReader {
     const uint32_t* words;  // packed buffer viewed as dwords (base is 16-byte aligned)
@@ -82,6 +92,16 @@ struct GlobalReader {
         cur = words[w + 1u];
         cur_idx = w + 1u;
         return __builtin_amdgcn_alignbyte(cur, lo, sh);
+    }
+    // 16 wanted bytes starting at byte i (see LdsReader::load16); never reads a dword without wanted bytes
+    __device__ __forceinline__ void load16(uint32_t i, uint32_t* q) {
+        const uint64_t a = base + i, w = a >> 2;
+        const uint32_t sh = (uint32_t)a & 3u;
+        const uint32_t d0 = words[w], d1 = words[w + 1u], d2 = words[w + 2u], d3 = words[w + 3u], d4 = words[w + (sh ? 4u : 3u)];
+        q[0] = __builtin_amdgcn_alignbyte(d1, d0, sh);
+        q[1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+        q[2] = __builtin_amdgcn_alignbyte(d3, d2, sh);
+        q[3] = __builtin_amdgcn_alignbyte(d4, d3, sh);
     }
 };
 

@@ -219,9 +219,21 @@ FGD_HD uint64_t mulhi_round(uint64_t a, uint64_t b) {
 }
 FGD_HD DiyFp mul(DiyFp a, DiyFp b) { return DiyFp{mulhi_round(a.f, b.f), a.e + b.e + 64}; }
 
-FGD_HD void grisu_round(char* buf, int len, uint64_t delta, uint64_t rest, uint64_t ten_kappa, uint64_t wp_w) {
+// The digits live in a register as a decimal integer (at most 17 digits fit a u64), never in a char buffer: a
+// dynamically indexed local array is scratch memory on the GPU, i.e. one dependent memory round trip per digit.
+struct Digits {
+    uint64_t v = 0;  // the digits read as one integer
+    int len = 0;     // how many (leading zeros are never generated)
+    FGD_HD void push(uint32_t d) {
+        if (d || len) {
+            v = v * 10u + d;
+            ++len;
+        }
+    }
+};
+FGD_HD void grisu_round(Digits& dg, uint64_t delta, uint64_t rest, uint64_t ten_kappa, uint64_t wp_w) {
     while (rest < wp_w && delta - rest >= ten_kappa && (rest + ten_kappa < wp_w || wp_w - rest > rest + ten_kappa - wp_w)) {
-        --buf[len - 1];
+        --dg.v;  // --buffer[len - 1]: the last digit (Grisu never takes it below '0')
         rest += ten_kappa;
     }
 }
@@ -238,43 +250,42 @@ FGD_HD int count_digits32(uint32_t n) {
     c += n >= 1000000000u;
     return c;
 }
-FGD_HD void digit_gen(DiyFp W, DiyFp Mp, uint64_t delta, char* buf, int* len, int* K) {
+FGD_HD void digit_gen(DiyFp W, DiyFp Mp, uint64_t delta, Digits& dg, int* K) {
     const int sh = -Mp.e;
     const uint64_t one_f = 1ull << sh;
     const uint64_t wp_w = Mp.f - W.f;
     uint32_t p1 = (uint32_t)(Mp.f >> sh);
     uint64_t p2 = Mp.f & (one_f - 1);
     int kappa = count_digits32(p1);
-    *len = 0;
     while (kappa > 0) {
         const uint32_t div = kPow10[kappa - 1];
         const uint32_t d = p1 / div;
         p1 -= d * div;
-        if (d || *len) buf[(*len)++] = (char)('0' + d);
+        dg.push(d);
         --kappa;
         const uint64_t tmp = ((uint64_t)p1 << sh) + p2;
         if (tmp <= delta) {
             *K += kappa;
-            grisu_round(buf, *len, delta, tmp, (uint64_t)kPow10[kappa] << sh, wp_w);
+            grisu_round(dg, delta, tmp, (uint64_t)kPow10[kappa] << sh, wp_w);
             return;
         }
     }
     for (;;) {
         p2 *= 10;
         delta *= 10;
-        const char d = (char)(p2 >> sh);
-        if (d || *len) buf[(*len)++] = (char)('0' + d);
+        const uint32_t d = (uint32_t)(p2 >> sh) & 0xFFu;
+        dg.push(d);
         p2 &= one_f - 1;
         --kappa;
         if (p2 < delta) {
             *K += kappa;
             const int index = -kappa;
-            grisu_round(buf, *len, delta, p2, one_f, wp_w * (index < 9 ? kPow10[index] : 0u));
+            grisu_round(dg, delta, p2, one_f, wp_w * (index < 9 ? kPow10[index] : 0u));
             return;
         }
     }
 }
-FGD_HD void grisu2(double value, char* buf, int* len, int* K) {
+FGD_HD void grisu2(double value, Digits& dg, int* K) {
     uint64_t u;
     memcpy(&u, &value, 8);
     const int biased = (int)((u >> 52) & 0x7FFu);
@@ -303,72 +314,110 @@ FGD_HD void grisu2(double value, char* buf, int* len, int* K) {
     DiyFp Wm = mul(mi, c_mk);
     ++Wm.f;
     --Wp.f;
-    digit_gen(W, Wp, Wp.f - Wm.f, buf, len, K);
+    digit_gen(W, Wp, Wp.f - Wm.f, dg, K);
 }
-FGD_HD int write_exp(int K, char* p) {
-    int n = 0;
-    if (K < 0) {
-        p[n++] = '-';
-        K = -K;
+
+// The generated digits as 17 BCD nibbles (digit 0 first; digits past len are zero) for reading digit i with shifts.
+struct Bcd17 {
+    uint32_t top;   // digit 0
+    uint32_t a, b;  // digits 1..8 and 9..16, eight nibbles each, the first digit in the highest nibble
+    FGD_HD static uint32_t bcd8(uint32_t x) {  // x < 10^8
+        uint32_t r = 0;
+        r |= (x / 10000000u) << 28;
+        r |= (x / 1000000u % 10u) << 24;
+        r |= (x / 100000u % 10u) << 20;
+        r |= (x / 10000u % 10u) << 16;
+        r |= (x / 1000u % 10u) << 12;
+        r |= (x / 100u % 10u) << 8;
+        r |= (x / 10u % 10u) << 4;
+        r |= x % 10u;
+        return r;
     }
-    if (K >= 100) {
-        p[n++] = (char)('0' + K / 100);
-        K %= 100;
-        p[n++] = (char)('0' + K / 10);
-        p[n++] = (char)('0' + K % 10);
-    } else if (K >= 10) {
-        p[n++] = (char)('0' + K / 10);
-        p[n++] = (char)('0' + K % 10);
-    } else {
-        p[n++] = (char)('0' + K);
+    FGD_HD explicit Bcd17(const Digits& dg) {
+        uint64_t n = dg.v;
+        for (int j = dg.len; j < 17; ++j) n *= 10u;  // left-align to 17 digits
+        top = (uint32_t)(n / 10000000000000000ull);
+        const uint64_t rest = n % 10000000000000000ull;
+        a = bcd8((uint32_t)(rest / 100000000ull));
+        b = bcd8((uint32_t)(rest % 100000000ull));
     }
-    return n;
-}
-// value must be finite.  Writes at most 26 characters into out, returns the count.
-FGD_HD int write(double value, char* out) {
-    int n = 0;
+    FGD_HD uint32_t digit(int i) const {  // 0 <= i < 17
+        if (i == 0) return top;
+        const uint32_t w = i <= 8 ? a : b;
+        const int j = i <= 8 ? i - 1 : i - 9;
+        return (w >> (4 * (7 - j))) & 15u;
+    }
+};
+
+// value must be finite.  Streams at most 26 characters into sink.put(char code).
+template <class Sink>
+FGD_HD void write_to(double value, Sink& sink) {
     uint64_t u;
     memcpy(&u, &value, 8);
     if (u >> 63) {
-        out[n++] = '-';
+        sink.put((uint32_t)'-');
         value = -value;
     }
     if ((u << 1) == 0) {  // +-0.0
-        out[n++] = '0';
-        out[n++] = '.';
-        out[n++] = '0';
-        return n;
+        sink.put((uint32_t)'0');
+        sink.put((uint32_t)'.');
+        sink.put((uint32_t)'0');
+        return;
     }
-    char d[20];
-    int len = 0, k = 0;
-    grisu2(value, d, &len, &k);
+    Digits dg;
+    int k = 0;
+    grisu2(value, dg, &k);
+    const int len = dg.len;
+    const Bcd17 bcd(dg);
     const int kk = len + k;  // 10^(kk-1) <= v < 10^kk
-    if (0 <= k && kk <= 21) {  // 1234e7 -> 12340000000.0
-        for (int i = 0; i < len; ++i) out[n++] = d[i];
-        for (int i = 0; i < k; ++i) out[n++] = '0';
-        out[n++] = '.';
-        out[n++] = '0';
-    } else if (0 < kk && kk <= 21) {  // 1234e-2 -> 12.34
-        for (int i = 0; i < kk; ++i) out[n++] = d[i];
-        out[n++] = '.';
-        for (int i = kk; i < len; ++i) out[n++] = d[i];
-    } else if (-6 < kk && kk <= 0) {  // 1234e-6 -> 0.001234
-        out[n++] = '0';
-        out[n++] = '.';
-        for (int i = 0; i < -kk; ++i) out[n++] = '0';
-        for (int i = 0; i < len; ++i) out[n++] = d[i];
-    } else if (len == 1) {  // 1e30
-        out[n++] = d[0];
-        out[n++] = 'e';
-        n += write_exp(kk - 1, out + n);
-    } else {  // 1234e30 -> 1.234e33
-        out[n++] = d[0];
-        out[n++] = '.';
-        for (int i = 1; i < len; ++i) out[n++] = d[i];
-        out[n++] = 'e';
-        n += write_exp(kk - 1, out + n);
+    // rapidjson's Prettify as ONE stream: `lead` zeros ("0." + zeros for 1234e-6 -> 0.001234), the digits with a '.'
+    // after digit `dot` (0: none), `trail` zeros and ".0" (1234e7 -> 12340000000.0), or an exponent
+    int dot = 0, trail = 0, lead = 0;
+    bool exp = false, point_zero = false;
+    if (0 <= k && kk <= 21) {
+        trail = k;
+        point_zero = true;
+    } else if (0 < kk && kk <= 21) {
+        dot = kk;
+    } else if (-6 < kk && kk <= 0) {
+        lead = -kk;
+        sink.put((uint32_t)'0');
+        sink.put((uint32_t)'.');
+    } else {
+        exp = true;
+        dot = len > 1 ? 1 : 0;  // 1e30 / 1.234e33
     }
-    return n;
+    for (int i = 0; i < lead; ++i) sink.put((uint32_t)'0');
+    for (int i = 0; i < len; ++i) {
+        if (dot && i == dot) sink.put((uint32_t)'.');
+        sink.put((uint32_t)'0' + bcd.digit(i));
+    }
+    for (int i = 0; i < trail; ++i) sink.put((uint32_t)'0');
+    if (point_zero) {
+        sink.put((uint32_t)'.');
+        sink.put((uint32_t)'0');
+    }
+    if (exp) {
+        sink.put((uint32_t)'e');
+        int K = kk - 1;
+        if (K < 0) {
+            sink.put((uint32_t)'-');
+            K = -K;
+        }
+        if (K >= 100) sink.put((uint32_t)'0' + (uint32_t)(K / 100));
+        if (K >= 10) sink.put((uint32_t)'0' + (uint32_t)(K / 10 % 10));
+        sink.put((uint32_t)'0' + (uint32_t)(K % 10));
+    }
+}
+// Buffer form (host tests): writes at most 26 characters into out, returns the count.
+FGD_HD int write(double value, char* out) {
+    struct BufSink {
+        char* p;
+        int n;
+        FGD_HD void put(uint32_t c) { p[n++] = (char)c; }
+    } bs{out, 0};
+    write_to(value, bs);
+    return bs.n;
 }
 
 }  // namespace dtoa

@@ -234,6 +234,26 @@ FGE_HD bool word_needs_bytes(uint32_t w) {
     return false;
 }
 
+// decimal text of v through f(char code), without a digit buffer (a dynamically indexed local array is scratch
+// memory on the GPU): 2 + 9 + 9 digits, leading zeros suppressed
+template <class F>
+FGE_HD void u64_digits(uint64_t v, F&& f) {
+    const uint32_t c0 = (uint32_t)(v % 1000000000ull);
+    const uint64_t r = v / 1000000000ull;
+    const uint32_t c1 = (uint32_t)(r % 1000000000ull), c2 = (uint32_t)(r / 1000000000ull);  // c2 <= 18
+    bool started = false;
+    for (uint32_t chunk = 0; chunk < 3u; ++chunk) {
+        const uint32_t c = chunk == 0 ? c2 : chunk == 1 ? c1 : c0;
+        for (uint32_t p = chunk == 0 ? 10u : 100000000u; p; p /= 10u) {
+            const uint32_t d = c / p % 10u;
+            if (d || started || (chunk == 2u && p == 1u)) {
+                f((uint32_t)'0' + d);
+                started = true;
+            }
+        }
+    }
+}
+
 // Everything the emitters share: the row, the field views, the number formats.
 template <class S, class R>
 struct Base {
@@ -243,6 +263,28 @@ struct Base {
     const DevTables& t;
     uint64_t li;
     uint32_t meta;
+    // the line's table row, fetched ONCE with every load in flight (load_row(), first thing the emitters do): fetched
+    // where they are used, each of the ~10 fields costs the wave a dependent HBM round trip
+    fg_span s0{}, s1{}, s2{}, s3{}, s4{}, s5{};
+    double row_ts = 0.0;
+    uint32_t row_ef = 0, row_ec = 0;
+    FGE_HD void load_row() {
+        s0 = t.span[0][li];
+        s1 = t.span[1][li];
+        s2 = t.span[2][li];
+        s3 = t.span[3][li];
+        s4 = t.span[4][li];
+        s5 = t.span[5][li];
+        row_ts = t.ts[li];
+        row_ef = t.ent_first[li];
+        row_ec = t.ent_count[li];
+    }
+    FGE_HD fg_span span(int col) const {  // scalar selects (a ternary chain over the structs kept the emitter in memory)
+        fg_span r;
+        r.off = col == 0 ? s0.off : col == 1 ? s1.off : col == 2 ? s2.off : col == 3 ? s3.off : col == 4 ? s4.off : s5.off;
+        r.len = col == 0 ? s0.len : col == 1 ? s1.len : col == 2 ? s2.len : col == 3 ? s3.len : col == 4 ? s4.len : s5.len;
+        return r;
+    }
 
     FGE_HD uint32_t flags() const { return FG_META_FLAGS(meta); }
     FGE_HD uint32_t json_mode() const { return (flags() & FG_F_GELF_RETRY) ? (uint32_t)M_JSON_RETRY : (uint32_t)M_JSON; }
@@ -257,7 +299,7 @@ struct Base {
         if (!(t.ent_flags[e] & FG_EF_VAL_ESC)) return M_RAW;
         return cfg.src_fmt == FG_RFC5424 ? (uint32_t)M_SD : cfg.src_fmt == FG_GELF ? json_mode() : (uint32_t)M_RAW;
     }
-    FGE_HD double record_ts() const { return (flags() & FG_F_TS_NOW) ? cfg.now_ts : t.ts[li]; }
+    FGE_HD double record_ts() const { return (flags() & FG_F_TS_NOW) ? cfg.now_ts : row_ts; }
 
     FGE_HD void lit(const char* s, uint32_t n) {
         uint32_t i = 0;
@@ -288,7 +330,20 @@ struct Base {
             return;
         }
         for (uint32_t i = 0; i < len;) {
-            uint32_t nb = len - i;  // the tail, or a dword with a byte that needs fb: byte-wise through ONE fb call site
+            uint32_t nb = len - i;
+            if (nb >= 16u) {  // 16 bytes per LDS round trip (the copy is latency-bound: one wave or two per SIMD)
+                uint32_t q[4];
+                rd.load16(off + i, q);
+                if (!(word_needs_bytes<ESC>(q[0]) || word_needs_bytes<ESC>(q[1]) || word_needs_bytes<ESC>(q[2]) || word_needs_bytes<ESC>(q[3]))) {
+                    out.put_word(q[0], 4u);
+                    out.put_word(q[1], 4u);
+                    out.put_word(q[2], 4u);
+                    out.put_word(q[3], 4u);
+                    i += 16u;
+                    continue;
+                }
+            }
+            // the tail, or a dword with a byte that needs fb: byte-wise through ONE fb call site
             if (nb >= 4u) {
                 const uint32_t w = rd.load4(off + i, 4u);
                 if (!word_needs_bytes<ESC>(w)) {
@@ -303,19 +358,20 @@ struct Base {
         }
     }
     FGE_HD void raw_field(int col) {  // a top-level field, decoded, unmodified
-        const fg_span s = t.span[col][li];
+        const fg_span s = this->span(col);
         const uint32_t mode = field_mode(col);
         if (mode == M_RAW) copy_raw<ESC_NONE>(s.off, s.len, [&](uint32_t c) { out.put(c); });
         else for_each_decoded(rd, s.off, s.len, mode, [&](uint32_t c) { out.put(c); });
     }
     FGE_HD void u64_text(uint64_t v) {
-        char buf[20];
-        int n = 0;
-        do {
-            buf[n++] = (char)('0' + (uint32_t)(v % 10u));
-            v /= 10u;
-        } while (v);
-        while (n) out.put((uint32_t)(uint8_t)buf[--n]);
+        if (v < 1000u) {  // <pri>, level, facility: the common case
+            const uint32_t x = (uint32_t)v;
+            if (x >= 100u) out.put('0' + x / 100u);
+            if (x >= 10u) out.put('0' + x / 10u % 10u);
+            out.put('0' + x % 10u);
+            return;
+        }
+        u64_digits(v, [&](uint32_t c) { out.put(c); });
     }
     FGE_HD void i64_text(int64_t x) {
         if (x < 0) {
@@ -412,23 +468,17 @@ struct Base {
             memcpy(&d, &v, 8);
             shortest::display_f64(d, fs);
         } else if (ty == FG_T_I64 || ty == FG_T_U64) {
-            char buf[21];
-            int n = 0;
             uint64_t m = v;
             if (ty == FG_T_I64 && (int64_t)v < 0) {
                 f((uint32_t)'-');
                 m = 0ull - v;
             }
-            do {
-                buf[n++] = (char)('0' + (uint32_t)(m % 10u));
-                m /= 10u;
-            } while (m);
-            while (n) f((uint32_t)(uint8_t)buf[--n]);
+            u64_digits(m, f);
         }
     }
     // every StructuredData of the record through `impl Display` (record.rs:42-67), concatenated
     FGE_HD void sd_display() {
-        const uint32_t first = t.ent_first[li], cnt = t.ent_count[li];
+        const uint32_t first = this->row_ef, cnt = this->row_ec;
         bool open = false;
         for (uint32_t e = first; e < first + cnt; ++e) {
             if (t.ent_type[e] == FG_T_SDID) {
@@ -460,8 +510,8 @@ struct Base {
         }
         if (open) out.put(']');
     }
-    FGE_HD bool has_sd() const { return t.ent_count[li] != 0; }
-    FGE_HD bool some(int col) const { return t.span[col][li].len != FG_NONE; }
+    FGE_HD bool has_sd() const { return this->row_ec != 0; }
+    FGE_HD bool some(int col) const { return this->span(col).len != FG_NONE; }
 };
 
 // =================================================================================================
@@ -481,7 +531,7 @@ struct GelfEmitter : Base<S, R> {
     using B::t;
     bool first_member = true;
 
-    FGE_HD GelfEmitter(S& o, const EncCfg& c, R r, const DevTables& tb, uint64_t l, uint32_t m) : B{o, c, r, tb, l, m} {}
+    FGE_HD GelfEmitter(S& o, const EncCfg& c, R r, const DevTables& tb, uint64_t l, uint32_t m) : B{o, c, r, tb, l, m} { this->load_row(); }
 
     FGE_HD void esc_byte(uint32_t c) {  // serde_json 0.8 escape_str; one or two put_word sites (code size)
         uint32_t w = c, nb = 1u;
@@ -516,7 +566,7 @@ struct GelfEmitter : Base<S, R> {
         out.put('"');
     }
     FGE_HD void str_field(int col) {
-        const fg_span s = t.span[col][li];
+        const fg_span s = this->span(col);
         str_span(s.off, s.len, this->field_mode(col));
     }
     FGE_HD void f64_text(double d) {
@@ -526,9 +576,7 @@ struct GelfEmitter : Base<S, R> {
             this->lit("null", 4);
             return;
         }
-        char buf[32];
-        const int n = dtoa::write(d, buf);
-        for (int i = 0; i < n; ++i) out.put((uint32_t)(uint8_t)buf[i]);
+        dtoa::write_to(d, out);  // digits in registers, streamed (no char buffer: that would be scratch memory)
     }
     FGE_HD int cmp_dyn(const Dyn& a, const Dyn& b) {
         const uint32_t la = a.dlen + a.sl, lb = b.dlen + b.sl, n = la < lb ? la : lb;
@@ -593,7 +641,7 @@ struct GelfEmitter : Base<S, R> {
             case SK_FULL: col = S_FULL; break;
             case SK_PROC: col = S_PROC; break;
             case SK_HOST: {
-                const fg_span s = t.span[S_HOST][li];
+                const fg_span s = this->span(S_HOST);
                 if (s.len == 0u || s.len == FG_NONE) {
                     out.put('"');
                     this->lit("unknown", 7);
@@ -634,7 +682,7 @@ struct GelfEmitter : Base<S, R> {
 
     // keys64 / slot_ent / order: this lane's scratch (kSortSlots each)
     FGE_HD uint32_t run(uint64_t* keys64, uint8_t* slot_ent, uint8_t* order) {
-        const uint32_t first = t.ent_first[li], cnt = t.ent_count[li];
+        const uint32_t first = this->row_ef, cnt = this->row_ec;
         // pairs -> slots (and the LAST sd_id: every element's insert replaces the previous one)
         uint32_t sdid_entry = 0xFFFFFFFFu, np = 0;
         bool ranked = cnt <= 255u;
@@ -730,7 +778,7 @@ struct LtsvEmitter : Base<S, R> {
     using B::rd;
     using B::t;
     bool first = true;
-    FGE_HD LtsvEmitter(S& o, const EncCfg& c, R r, const DevTables& tb, uint64_t l, uint32_t m) : B{o, c, r, tb, l, m} {}
+    FGE_HD LtsvEmitter(S& o, const EncCfg& c, R r, const DevTables& tb, uint64_t l, uint32_t m) : B{o, c, r, tb, l, m} { this->load_row(); }
 
     FGE_HD void key_byte(uint32_t c) { out.put(c == '\n' || c == '\t' ? (uint32_t)' ' : c == ':' ? (uint32_t)'_' : c); }
     FGE_HD void val_byte(uint32_t c) { out.put(c == '\n' || c == '\t' ? (uint32_t)' ' : c); }
@@ -746,11 +794,11 @@ struct LtsvEmitter : Base<S, R> {
     }
     FGE_HD void field(const char* key, uint32_t n, int col) {
         start(key, n);
-        const fg_span s = t.span[col][li];
+        const fg_span s = this->span(col);
         val_span(s.off, s.len, this->field_mode(col));
     }
     FGE_HD uint32_t run() {
-        const uint32_t ef = t.ent_first[li], cnt = t.ent_count[li];
+        const uint32_t ef = this->row_ef, cnt = this->row_ec;
         for (uint32_t e = ef; e < ef + cnt; ++e) {
             if (t.ent_type[e] == FG_T_SDID) continue;
             if (!first) out.put('\t');
@@ -772,7 +820,7 @@ struct LtsvEmitter : Base<S, R> {
         }
         start("host", 4);
         if (this->some(S_HOST)) {
-            const fg_span s = t.span[S_HOST][li];
+            const fg_span s = this->span(S_HOST);
             val_span(s.off, s.len, this->field_mode(S_HOST));
         }
         start("time", 4);
@@ -900,7 +948,7 @@ struct Rfc5424Emitter : Base<S, R> {
     using B::meta;
     using B::out;
     using B::t;
-    FGE_HD Rfc5424Emitter(S& o, const EncCfg& c, R r, const DevTables& tb, uint64_t l, uint32_t m) : B{o, c, r, tb, l, m} {}
+    FGE_HD Rfc5424Emitter(S& o, const EncCfg& c, R r, const DevTables& tb, uint64_t l, uint32_t m) : B{o, c, r, tb, l, m} { this->load_row(); }
     FGE_HD uint32_t run() {
         int64_t secs;
         uint32_t nanos;
@@ -965,7 +1013,7 @@ struct Rfc3164Emitter : Base<S, R> {
     using B = Base<S, R>;
     using B::cfg;
     using B::out;
-    FGE_HD Rfc3164Emitter(S& o, const EncCfg& c, R r, const DevTables& tb, uint64_t l, uint32_t m) : B{o, c, r, tb, l, m} {}
+    FGE_HD Rfc3164Emitter(S& o, const EncCfg& c, R r, const DevTables& tb, uint64_t l, uint32_t m) : B{o, c, r, tb, l, m} { this->load_row(); }
     FGE_HD uint32_t run() {
         const int64_t secs = f64_as_i64(this->record_ts());
         if (secs < kMinUnix || secs > kMaxUnix) return ES_3164_TS;
@@ -1012,7 +1060,7 @@ template <class S, class R>
 struct PassthroughEmitter : Base<S, R> {
     using B = Base<S, R>;
     using B::cfg;
-    FGE_HD PassthroughEmitter(S& o, const EncCfg& c, R r, const DevTables& tb, uint64_t l, uint32_t m) : B{o, c, r, tb, l, m} {}
+    FGE_HD PassthroughEmitter(S& o, const EncCfg& c, R r, const DevTables& tb, uint64_t l, uint32_t m) : B{o, c, r, tb, l, m} { this->load_row(); }
     FGE_HD uint32_t run() {
         if (!this->some(S_FULL)) return ES_PASSTHROUGH_EMPTY;
         if (cfg.prepend_len != 0xFFFFFFFFu) this->blob(cfg.prepend_off, cfg.prepend_len);
@@ -1091,14 +1139,7 @@ FGE_HD void row_write(W& sink, uint64_t total, const EncCfg& cfg, R rd, const De
                       uint8_t* slot_ent, uint8_t* order) {
     if (total == 0 || FG_META_STATUS(meta) != 0u) return;
     if (cfg.merger == FG_MERGE_SYSLEN) {  // "{len + 1} " in front (syslen_merger.rs:18-20)
-        uint64_t v = syslen_payload(total) + 1u;
-        char buf[20];
-        int n = 0;
-        do {
-            buf[n++] = (char)('0' + (uint32_t)(v % 10u));
-            v /= 10u;
-        } while (v);
-        while (n) sink.put((uint32_t)(uint8_t)buf[--n]);
+        u64_digits(syslen_payload(total) + 1u, [&](uint32_t c) { sink.put(c); });
         sink.put(' ');
     }
     (void)encode_row<ENC>(sink, cfg, rd, t, li, meta, keys64, slot_ent, order);

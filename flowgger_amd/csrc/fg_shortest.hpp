@@ -13,6 +13,7 @@
 // (both are "shortest, then closest").  Host + device; checked on the CPU against libstdc++'s
 // std::to_chars (Ryu) over 10^8-scale random and structured inputs (tests/test_shortest_cpu.py).
 #pragma once
+#include "fg_dtoa.hpp"
 #include <stdint.h>
 #include <string.h>
 
@@ -151,29 +152,25 @@ FGS_HD void display_f64(double v, S& out) {
         return;
     }
     const Dec d = to_decimal(mag);
-    char digs[20];
-    int nd = 0;
-    uint64_t s = d.sig;
-    while (s) {
-        digs[nd++] = (char)('0' + (uint32_t)(s % 10u));
-        s /= 10u;
-    }
-    // digits digs[nd-1] .. digs[0]; value = 0.d1d2... * 10^e10
+    // the digits stay in registers (17 BCD nibbles): a char buffer would be scratch memory on the GPU
+    int nd = 1;
+    for (uint64_t p = 10u; d.sig >= p && nd < 19; p *= 10u) ++nd;
+    dtoa::Digits dg;
+    dg.v = d.sig;
+    dg.len = nd;
+    const dtoa::Bcd17 bcd(dg);
+    // value = 0.d1d2... * 10^e10
     const int e10 = d.exp + nd;
     if (e10 <= 0) {
         out.put('0');
         out.put('.');
         for (int i = 0; i < -e10; ++i) out.put('0');
-        for (int i = nd - 1; i >= 0; --i) out.put((uint32_t)(uint8_t)digs[i]);
-    } else if (e10 < nd) {
-        for (int i = nd - 1; i >= 0; --i) {
-            if (nd - 1 - i == e10) out.put('.');
-            out.put((uint32_t)(uint8_t)digs[i]);
-        }
-    } else {
-        for (int i = nd - 1; i >= 0; --i) out.put((uint32_t)(uint8_t)digs[i]);
-        for (int i = 0; i < e10 - nd; ++i) out.put('0');
     }
+    for (int i = 0; i < nd; ++i) {
+        if (e10 > 0 && i == e10) out.put('.');
+        out.put((uint32_t)'0' + bcd.digit(i));
+    }
+    for (int i = nd; i < e10; ++i) out.put('0');
 }
 
 }  // namespace shortest

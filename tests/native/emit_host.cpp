@@ -19,6 +19,7 @@ struct HostReader {
         memcpy(&w, p + i, nb);  // never reads past the wanted bytes: the line buffer has no padding
         return w;
     }
+    void load16(uint32_t i, uint32_t* q) { memcpy(q, p + i, 16); }  // all 16 bytes are wanted by contract
 };
 struct Cur {
     const uint8_t* p;

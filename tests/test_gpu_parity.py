@@ -833,7 +833,10 @@ def test_rfc3164_frames(r3164, oracle):
             assert blob[int(offs[i]):int(offs[i + 1])].tobytes() == oblob[int(ooffs[i]):int(ooffs[i + 1])].tobytes(), (i, got)
     st = tables.to_host().status
     ost = np.array([oblob[int(ooffs[i])] for i in range(len(lines))])
-    assert int((st != 0).sum()) == int((ost != 0).sum())  # line 9 fails either way
+    # every other line: same verdict (the oracle is handed line 9's bytes although they are not a &str: it has no UTF-8 check,
+    # the splitter rejects the line before decode)
+    keep = np.arange(len(lines)) != 9
+    assert np.array_equal((st != 0)[keep], (ost != 0)[keep]) and st[9] == L.FG_ST_BAD_UTF8
 
 
 @pytest.mark.parametrize("enc", ["gelf", "ltsv", "rfc5424", "rfc3164", "passthrough"])
