@@ -89,7 +89,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         if name == "fg_encode.hip":
             for enc in range(5):  # fg_encoder values; GELF (0) has two ranking-scratch sizes
                 for wr in (0, 1):
-                    for slots in ((8, 32) if enc == 0 else (0,)):
+                    for slots in ((1, 8, 32) if enc == 0 else (0,)):
                         units.append((name, objdir / f"fg_encode.e{enc}w{wr}s{slots}.o",
                                       [f"-DFG_ENC_TU={enc}", f"-DFG_ENC_TU_WRITE={wr}", f"-DFG_ENC_TU_SLOTS={slots}"]))
     objs = [u[1] for u in units]

@@ -190,13 +190,13 @@ fg::DevTables to_dev(const fg_tables& t) {
 
 // LDS tile per 64-line wave: room for 64 average lines + 12.5 % + 512 B, 4..56 KiB (the kernel
 // adds the space bitmap, 1/8 of the tile, on top).  FG_TILE_CAP overrides (bytes), for tuning.
-uint32_t pick_tile_cap(uint64_t nbytes, uint64_t n, uint64_t max_cap) {
+uint32_t pick_tile_cap(uint64_t nbytes, uint64_t n, uint64_t max_cap, uint32_t margin_16ths = 2) {
     if (const char* e = getenv("FG_TILE_CAP")) {
         uint64_t v = strtoull(e, nullptr, 10);
         if (v >= 1024 && v <= max_cap) return (uint32_t)up(v, 1024);
     }
     uint64_t avg = n ? (nbytes + n - 1) / n : 0;
-    uint64_t want = up(64 * avg * 9 / 8 + 512, 1024);
+    uint64_t want = up(64 * avg * (16 + margin_16ths) / 16 + 512, 1024);
     if (want < 4096) want = 4096;
     if (want > max_cap) want = max_cap;
     return (uint32_t)want;
@@ -905,7 +905,8 @@ int fg_encode_device(fg_ctx* ctx, fg_format src_fmt, const fg_encode_cfg* ecfg, 
     fg::EncCfg cfg = h.cfg;
     cfg.keys = reinterpret_cast<const fg::StaticKey*>(ctx->d_enc);
     cfg.blob = ctx->d_enc + keys_bytes;
-    if (ent_used <= 2 * n) cfg.sort_slots = 8;  // on average <= 2 pairs per line
+    if (ent_used == 0) cfg.sort_slots = 1;           // no pairs at all (e.g. RFC5424 without structured data)
+    else if (ent_used <= 2 * n) cfg.sort_slots = 8;  // on average <= 2 pairs per line
     // mirror [static keys | blob] in LDS when it is small (it nearly always is)
     const uint32_t cfg_lds = keys_bytes + h.blob.size() <= 4096 ? (uint32_t)up(keys_bytes + h.blob.size(), 16) : 0u;
     uint32_t* d_sizes = reinterpret_cast<uint32_t*>(ctx->d_enc + cfg_bytes);
@@ -915,8 +916,9 @@ int fg_encode_device(fg_ctx* ctx, fg_format src_fmt, const fg_encode_cfg* ecfg, 
         FG_HIP(ctx, hipMemsetAsync(d_out_offsets, 0, 8, s));
         return FG_OK;
     }
-    // LDS tile of a 64-line group: average group + 6.25 % + 512 B, 4..40 KiB (longer groups read from global memory)
-    const uint32_t tile_cap = pick_tile_cap(nbytes, n, 40 * 1024);
+    // LDS tile of a 64-line group: average group + 6.25 % + 512 B, 4..40 KiB (longer groups read from global memory);
+    // the tile is what limits the waves per CU (the emitters are latency-bound: occupancy is throughput)
+    const uint32_t tile_cap = pick_tile_cap(nbytes, n, 40 * 1024, 1);
     if (ctx->timing) FG_HIP(ctx, hipEventRecord(ctx->ev0, s));
     int lrc = fg_launch_encode_sizes(d_bytes, d_offsets, n, &dt, &cfg, tile_cap, cfg_lds, d_sizes, d_block_sums, d_enc_status, d_out_offsets, s);
     if (lrc != 0) {

@@ -158,7 +158,8 @@ static int launch_encode(FG_ENC_ARGS) {
         case FG_ENC_GELF:
             // few pairs per line on average: a small ranking scratch (more LDS left for occupancy); a line with more
             // pairs than slots takes the exact selection path
-            static_assert(emit::kSortSlots == 32u, "flowgger_amd/build.py compiles the GELF kernels for 8 and 32 slots");
+            static_assert(emit::kSortSlots == 32u, "flowgger_amd/build.py compiles the GELF kernels for 1, 8 and 32 slots");
+            if (cfg.sort_slots <= 1u) FG_CALL(FG_ENC_GELF, 1u);  // no pairs in the batch: 4.5 KiB of LDS back for occupancy
             if (cfg.sort_slots <= 8u) FG_CALL(FG_ENC_GELF, 8u);
             FG_CALL(FG_ENC_GELF, 32u);
         case FG_ENC_LTSV: FG_CALL(FG_ENC_LTSV, 0u);

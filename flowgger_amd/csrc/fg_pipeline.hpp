@@ -305,20 +305,22 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
         }
         if (nrow > (uint32_t)NB) {  // rare: bytes beyond the register window
             const uint4* __restrict__ src = reinterpret_cast<const uint4*>(bytes + a0);
+            // Loads and stores are UNCONDITIONAL (lanes past the end move the last chunk once more: same bytes, same
+            // address): with `if (idx < nchunk)` the compiler kept w[] in scratch memory and waited for each load
+            // before issuing the next -- serialised HBM round trips instead of four loads in flight.
+            const uint32_t last = nchunk - 1u;
             for (uint32_t c0 = NB * kWave; c0 < nchunk; c0 += kWave * 4) {
                 uint4 w[4];  // (the window registers are dead here)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    uint32_t idx = c0 + k * kWave + lane;
-                    if (idx < nchunk) w[k] = src[idx];
+                    const uint32_t idx = c0 + k * kWave + lane;
+                    w[k] = src[idx < last ? idx : last];
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    uint32_t idx = c0 + k * kWave + lane;
-                    if (idx < nchunk) {
-                        dst[idx] = w[k];
-                        if (F::kStageABitmap) bm16[idx] = (uint16_t)F::mask16(w[k]);
-                    }
+                    const uint32_t idx = c0 + k * kWave + lane, ci = idx < last ? idx : last;
+                    dst[ci] = w[k];
+                    if (F::kStageABitmap) bm16[ci] = (uint16_t)F::mask16(w[k]);
                 }
             }
         }
@@ -401,20 +403,19 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
                     {
                         const uint4* __restrict__ src = reinterpret_cast<const uint4*>(bytes + ta0);
                         const uint32_t nch = tspan >> 4;
+                        const uint32_t lastc = nch ? nch - 1u : 0u;  // (unconditional, clamped: see the tail loop of stage A)
                         for (uint32_t c0 = 0; c0 < nch; c0 += kWave * 2) {  // (few registers: the prefetch window is live)
                             uint4 w[2];
 #pragma unroll
                             for (int k = 0; k < 2; ++k) {
-                                uint32_t idx = c0 + k * kWave + lane;
-                                if (idx < nch) w[k] = src[idx];
+                                const uint32_t idx = c0 + k * kWave + lane;
+                                w[k] = src[idx < lastc ? idx : lastc];
                             }
 #pragma unroll
                             for (int k = 0; k < 2; ++k) {
-                                uint32_t idx = c0 + k * kWave + lane;
-                                if (idx < nch) {
-                                    dst[idx] = w[k];
-                                    if (F::kStageABitmap) bm16[idx] = (uint16_t)F::mask16(w[k]);
-                                }
+                                const uint32_t idx = c0 + k * kWave + lane, ci = idx < lastc ? idx : lastc;
+                                dst[ci] = w[k];
+                                if (F::kStageABitmap) bm16[ci] = (uint16_t)F::mask16(w[k]);
                             }
                         }
                     }
