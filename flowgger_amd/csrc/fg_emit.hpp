@@ -186,7 +186,7 @@ struct CountSink {
 struct PackSink {
     static constexpr bool kCount = false;
     uint8_t* p;     // aligned address of the dword being assembled
-    uint64_t acc;   // pending bytes: the low k bytes are valid (the first `head` of them are placeholders)
+    uint32_t acc;   // pending bytes: the low k (< 4) bytes are valid (the first `head` of them are placeholders)
     uint32_t k;
     uint32_t head;  // bytes of the first dword that belong to the previous message
     FGE_HD explicit PackSink(uint8_t* q) {
@@ -195,21 +195,25 @@ struct PackSink {
         acc = 0;
         k = head;
     }
-    FGE_HD void flush() {
-        if (head) {
-            for (uint32_t i = head; i < 4u; ++i) p[i] = (uint8_t)(acc >> (8u * i));
-            head = 0;
-        } else {
-            *reinterpret_cast<uint32_t*>(p) = (uint32_t)acc;
-        }
-        p += 4;
-        acc >>= 32;
-        k -= 4u;
-    }
+    // 32-bit arithmetic only (64-bit shifts are slow on the vector ALU): w's low bytes complete the dword, its high
+    // bytes start the next one
     FGE_HD void put_word(uint32_t w, uint32_t nb) {
-        acc |= (uint64_t)w << (8u * k);
+        const uint32_t sh = 8u * k;
+        const uint32_t lo = acc | (w << sh);
         k += nb;
-        if (k >= 4u) flush();
+        if (k >= 4u) {
+            if (head) {
+                for (uint32_t i = head; i < 4u; ++i) p[i] = (uint8_t)(lo >> (8u * i));
+                head = 0;
+            } else {
+                *reinterpret_cast<uint32_t*>(p) = lo;
+            }
+            p += 4;
+            acc = sh ? w >> (32u - sh) : 0u;
+            k -= 4u;
+        } else {
+            acc = lo;
+        }
     }
     FGE_HD void put(uint32_t c) { put_word(c & 0xFFu, 1u); }
     FGE_HD void add(uint32_t) {}

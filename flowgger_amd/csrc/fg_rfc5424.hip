@@ -737,6 +737,8 @@ __device__ __forceinline__ void parse_tail_sd_tile(const Tile& T, uint32_t base,
     }
 }
 
+constexpr uint32_t kShortSdTail = 64;  // bytes after the header up to which a lone SD tail is walked byte-wise
+
 // The format policy of the streaming pipeline (fg_pipeline.hpp): stage A builds the SPACE bitmap;
 // decode() = stage B + SD entries + the table row for ONE line group whose tile is in LDS.
 struct Rfc5424Format {
@@ -785,8 +787,12 @@ struct Rfc5424Format {
     }
     // ---- 2. structured data in this group?  Then the space bitmap (no longer needed) becomes the
     //         quote/backslash bitmap, built by the whole wave -------------------------------------
-    const bool sd_lane = valid && !(route & R_GENERIC) && (route & R_TAIL) && r.status == E_OK && f.c7 == '[';
-    const bool group_has_sd = __any(sd_lane);  // wave-uniform
+    // (a group with only a few SHORT bracketed tails -- typically malformed lines of a corpus without structured
+    //  data -- is not worth two barriers and a pass over the whole tile: those lanes take the byte-wise parse_tail)
+    const bool sd_any = valid && !(route & R_GENERIC) && (route & R_TAIL) && r.status == E_OK && f.c7 == '[';
+    const uint64_t sd_ballot = __ballot(sd_any);
+    const bool group_has_sd = __any(sd_any && len - f.d0 > kShortSdTail) || __popcll(sd_ballot) > 4;  // wave-uniform
+    const bool sd_lane = sd_any && group_has_sd;
     if (group_has_sd) {
         __syncthreads();
         rebuild_bitmap<QuoteClass>(smem, bm16, span >> 4);

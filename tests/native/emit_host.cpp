@@ -237,16 +237,16 @@ extern "C" int64_t fge_encode_canonical(int enc, int merger, int src_fmt, int ge
     HostReader rd{(const uint8_t*)line.data()};
     uint32_t st = 0, size = 0;
     std::vector<uint8_t> res;
-    // the write pass runs through the kernels' PackSink at all four start alignments, inside a guarded buffer: nothing
+    // the write pass runs through the kernels' PackSink (dword and 16-byte stores) at all sixteen start alignments, inside a guarded buffer: nothing
     // outside [start, start + size) may change
-    for (uint32_t al = 0; al < 4; ++al) {
+    for (uint32_t al = 0; al < 16; ++al) {
         std::vector<uint8_t> buf;
 #define RUN(E)                                                                                                  \
     case E: {                                                                                                   \
         size = fg::emit::row_size<E>(h.cfg, rd, t, li, meta[li], keys64, slot_ent, order, &st);               \
-        buf.assign((size_t)size + 64, 0xA5);                                                                    \
-        uint8_t* start = buf.data() + 16;                                                                       \
-        start += (al - ((uintptr_t)start & 3u)) & 3u;                                                           \
+        buf.assign((size_t)size + 96, 0xA5);                                                                    \
+        uint8_t* start = buf.data() + 32;                                                                       \
+        start += (al - ((uintptr_t)start & 15u)) & 15u;                                                          \
         fg::emit::PackSink sink(start);                                                                         \
         fg::emit::row_write<E>(sink, size, h.cfg, rd, t, li, meta[li], keys64, slot_ent, order);              \
         for (uint8_t* q = buf.data(); q < buf.data() + buf.size(); ++q)                                         \
