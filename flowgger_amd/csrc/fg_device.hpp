@@ -243,6 +243,8 @@ __device__ __forceinline__ bool parse_rfc3339(R& rd, uint32_t q, uint32_t end, d
 // address): with `if (idx < nchunk)` around either, the compiler kept v[] in scratch memory or sank each load into
 // its store's branch, and waited for every load before issuing the next one -- eight serialised HBM round trips per
 // 8 KiB instead of eight loads in flight (round-1 finding).
+// K = 16-byte loads in flight per lane (K KiB per round trip; 4 K VGPRs that are dead again afterwards).
+template <int K = 8>
 __device__ __forceinline__ void stage_tile(const uint8_t* __restrict__ bytes, uint64_t a0, uint32_t span, uint8_t* smem) {
     const uint4* __restrict__ src = reinterpret_cast<const uint4*>(bytes + a0);
     uint4* dst = reinterpret_cast<uint4*>(smem);
@@ -250,17 +252,65 @@ __device__ __forceinline__ void stage_tile(const uint8_t* __restrict__ bytes, ui
     if (nchunk == 0) return;
     const uint32_t lane = threadIdx.x;
     const uint32_t last = nchunk - 1u;
-    for (uint32_t c0 = 0; c0 < nchunk; c0 += kWave * 8) {
-        uint4 v[8];
+    for (uint32_t c0 = 0; c0 < nchunk; c0 += kWave * K) {
+        uint4 v[K];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < K; ++k) {
             const uint32_t idx = c0 + k * kWave + lane;
             v[k] = src[idx < last ? idx : last];
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < K; ++k) {
             const uint32_t idx = c0 + k * kWave + lane;
             dst[idx < last ? idx : last] = v[k];
+        }
+    }
+}
+
+// stage_tile plus a small second block (at most 4 KiB = four 16-byte loads per lane, e.g. a configuration mirror)
+// whose loads ride in the same round trip: tile loads, rider loads, tile stores, rider stores -- straight-line code for
+// the first K KiB so that the compiler has no branch to sink the rider's loads behind.
+template <int K>
+__device__ __forceinline__ void stage_tile_rider(const uint8_t* __restrict__ bytes, uint64_t a0, uint32_t span, uint8_t* smem,
+                                                 const uint4* __restrict__ rider_src, uint32_t rider_chunks, uint4* rider_dst) {
+    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(bytes + a0);
+    uint4* dst = reinterpret_cast<uint4*>(smem);
+    const uint32_t nchunk = span >> 4;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t last = nchunk ? nchunk - 1u : 0u;   // (span == 0: the tile's 16 spare bytes take chunk 0 of the buffer's padding)
+    const uint32_t rlast = rider_chunks ? rider_chunks - 1u : 0u;
+    uint4 v[K], r[4];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const uint32_t idx = k * kWave + lane;
+        v[k] = src[idx < last ? idx : last];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t idx = k * kWave + lane;
+        r[k] = rider_src[idx < rlast ? idx : rlast];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const uint32_t idx = k * kWave + lane;
+        dst[idx < last ? idx : last] = v[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t idx = k * kWave + lane;
+        rider_dst[idx < rlast ? idx : rlast] = r[k];
+    }
+    for (uint32_t c0 = kWave * K; c0 < nchunk; c0 += kWave * K) {  // rare: a tile beyond K KiB
+        uint4 w[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const uint32_t idx = c0 + k * kWave + lane;
+            w[k] = src[idx < last ? idx : last];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const uint32_t idx = c0 + k * kWave + lane;
+            dst[idx < last ? idx : last] = w[k];
         }
     }
 }

@@ -258,6 +258,25 @@ FGE_HD void u64_digits(uint64_t v, F&& f) {
     }
 }
 
+// A line's table row in registers.  The kernel fetches it BEFORE it stages the tile (every load in flight, hidden
+// behind the staging) and hands it to the emitter; without it the emitter fetches the row itself (load_row()).
+struct RowRegs {
+    fg_span s0, s1, s2, s3, s4, s5;
+    double ts;
+    uint32_t ef, ec;
+    FGE_HD void load(const DevTables& t, uint64_t li) {
+        s0 = t.span[0][li];
+        s1 = t.span[1][li];
+        s2 = t.span[2][li];
+        s3 = t.span[3][li];
+        s4 = t.span[4][li];
+        s5 = t.span[5][li];
+        ts = t.ts[li];
+        ef = t.ent_first[li];
+        ec = t.ent_count[li];
+    }
+};
+
 // Everything the emitters share: the row, the field views, the number formats.
 template <class S, class R>
 struct Base {
@@ -272,7 +291,19 @@ struct Base {
     fg_span s0{}, s1{}, s2{}, s3{}, s4{}, s5{};
     double row_ts = 0.0;
     uint32_t row_ef = 0, row_ec = 0;
-    FGE_HD void load_row() {
+    FGE_HD void load_row(const RowRegs* pre) {
+        if (pre) {
+            s0 = pre->s0;
+            s1 = pre->s1;
+            s2 = pre->s2;
+            s3 = pre->s3;
+            s4 = pre->s4;
+            s5 = pre->s5;
+            row_ts = pre->ts;
+            row_ef = pre->ef;
+            row_ec = pre->ec;
+            return;
+        }
         s0 = t.span[0][li];
         s1 = t.span[1][li];
         s2 = t.span[2][li];
@@ -535,7 +566,7 @@ struct GelfEmitter : Base<S, R> {
     using B::t;
     bool first_member = true;
 
-    FGE_HD GelfEmitter(S& o, const EncCfg& c, R r, const DevTables& tb, uint64_t l, uint32_t m) : B{o, c, r, tb, l, m} { this->load_row(); }
+    FGE_HD GelfEmitter(S& o, const EncCfg& c, R r, const DevTables& tb, uint64_t l, uint32_t m, const RowRegs* pre) : B{o, c, r, tb, l, m} { this->load_row(pre); }
 
     FGE_HD void esc_byte(uint32_t c) {  // serde_json 0.8 escape_str; one or two put_word sites (code size)
         uint32_t w = c, nb = 1u;
@@ -782,7 +813,7 @@ struct LtsvEmitter : Base<S, R> {
     using B::rd;
     using B::t;
     bool first = true;
-    FGE_HD LtsvEmitter(S& o, const EncCfg& c, R r, const DevTables& tb, uint64_t l, uint32_t m) : B{o, c, r, tb, l, m} { this->load_row(); }
+    FGE_HD LtsvEmitter(S& o, const EncCfg& c, R r, const DevTables& tb, uint64_t l, uint32_t m, const RowRegs* pre) : B{o, c, r, tb, l, m} { this->load_row(pre); }
 
     FGE_HD void key_byte(uint32_t c) { out.put(c == '\n' || c == '\t' ? (uint32_t)' ' : c == ':' ? (uint32_t)'_' : c); }
     FGE_HD void val_byte(uint32_t c) { out.put(c == '\n' || c == '\t' ? (uint32_t)' ' : c); }
@@ -952,7 +983,7 @@ struct Rfc5424Emitter : Base<S, R> {
     using B::meta;
     using B::out;
     using B::t;
-    FGE_HD Rfc5424Emitter(S& o, const EncCfg& c, R r, const DevTables& tb, uint64_t l, uint32_t m) : B{o, c, r, tb, l, m} { this->load_row(); }
+    FGE_HD Rfc5424Emitter(S& o, const EncCfg& c, R r, const DevTables& tb, uint64_t l, uint32_t m, const RowRegs* pre) : B{o, c, r, tb, l, m} { this->load_row(pre); }
     FGE_HD uint32_t run() {
         int64_t secs;
         uint32_t nanos;
@@ -1017,7 +1048,7 @@ struct Rfc3164Emitter : Base<S, R> {
     using B = Base<S, R>;
     using B::cfg;
     using B::out;
-    FGE_HD Rfc3164Emitter(S& o, const EncCfg& c, R r, const DevTables& tb, uint64_t l, uint32_t m) : B{o, c, r, tb, l, m} { this->load_row(); }
+    FGE_HD Rfc3164Emitter(S& o, const EncCfg& c, R r, const DevTables& tb, uint64_t l, uint32_t m, const RowRegs* pre) : B{o, c, r, tb, l, m} { this->load_row(pre); }
     FGE_HD uint32_t run() {
         const int64_t secs = f64_as_i64(this->record_ts());
         if (secs < kMinUnix || secs > kMaxUnix) return ES_3164_TS;
@@ -1064,7 +1095,7 @@ template <class S, class R>
 struct PassthroughEmitter : Base<S, R> {
     using B = Base<S, R>;
     using B::cfg;
-    FGE_HD PassthroughEmitter(S& o, const EncCfg& c, R r, const DevTables& tb, uint64_t l, uint32_t m) : B{o, c, r, tb, l, m} { this->load_row(); }
+    FGE_HD PassthroughEmitter(S& o, const EncCfg& c, R r, const DevTables& tb, uint64_t l, uint32_t m, const RowRegs* pre) : B{o, c, r, tb, l, m} { this->load_row(pre); }
     FGE_HD uint32_t run() {
         if (!this->some(S_FULL)) return ES_PASSTHROUGH_EMPTY;
         if (cfg.prepend_len != 0xFFFFFFFFu) this->blob(cfg.prepend_off, cfg.prepend_len);
@@ -1106,47 +1137,47 @@ FGE_HD uint64_t syslen_payload(uint64_t total) {
 //      host tests.  keys64 / slot_ent / order: kSortSlots scratch entries each (used by the GELF emitter only). ------
 template <uint32_t ENC, class S, class R>
 FGE_HD uint32_t encode_row(S& sink, const EncCfg& cfg, R rd, const DevTables& t, uint64_t li, uint32_t meta, uint64_t* keys64,
-                           uint8_t* slot_ent, uint8_t* order) {
+                           uint8_t* slot_ent, uint8_t* order, const RowRegs* pre = nullptr) {
     if (ENC == FG_ENC_GELF) {
-        GelfEmitter<S, R> em(sink, cfg, rd, t, li, meta);
+        GelfEmitter<S, R> em(sink, cfg, rd, t, li, meta, pre);
         return em.run(keys64, slot_ent, order);
     } else if (ENC == FG_ENC_LTSV) {
-        LtsvEmitter<S, R> em(sink, cfg, rd, t, li, meta);
+        LtsvEmitter<S, R> em(sink, cfg, rd, t, li, meta, pre);
         return em.run();
     } else if (ENC == FG_ENC_RFC5424) {
-        Rfc5424Emitter<S, R> em(sink, cfg, rd, t, li, meta);
+        Rfc5424Emitter<S, R> em(sink, cfg, rd, t, li, meta, pre);
         return em.run();
     } else if (ENC == FG_ENC_RFC3164) {
-        Rfc3164Emitter<S, R> em(sink, cfg, rd, t, li, meta);
+        Rfc3164Emitter<S, R> em(sink, cfg, rd, t, li, meta, pre);
         return em.run();
     } else {
-        PassthroughEmitter<S, R> em(sink, cfg, rd, t, li, meta);
+        PassthroughEmitter<S, R> em(sink, cfg, rd, t, li, meta, pre);
         return em.run();
     }
 }
 // count pass: the framed size of row li (0 when nothing is produced) and its encode status
 template <uint32_t ENC, class R>
 FGE_HD uint32_t row_size(const EncCfg& cfg, R rd, const DevTables& t, uint64_t li, uint32_t meta, uint64_t* keys64, uint8_t* slot_ent,
-                         uint8_t* order, uint32_t* status) {
+                         uint8_t* order, uint32_t* status, const RowRegs* pre = nullptr) {
     if (FG_META_STATUS(meta) != 0u) {
         *status = ES_DECODE_FAILED;
         return 0;
     }
     CountSink cs;
-    const uint32_t st = encode_row<ENC>(cs, cfg, rd, t, li, meta, keys64, slot_ent, order);
+    const uint32_t st = encode_row<ENC>(cs, cfg, rd, t, li, meta, keys64, slot_ent, order, pre);
     *status = st;
     return st == ES_OK ? (uint32_t)framed_size(cfg.merger, cs.n) : 0u;
 }
 // write pass: `total` = the framed size the count pass returned for this row (the sink starts at the row's offset)
 template <uint32_t ENC, class W, class R>
 FGE_HD void row_write(W& sink, uint64_t total, const EncCfg& cfg, R rd, const DevTables& t, uint64_t li, uint32_t meta, uint64_t* keys64,
-                      uint8_t* slot_ent, uint8_t* order) {
+                      uint8_t* slot_ent, uint8_t* order, const RowRegs* pre = nullptr) {
     if (total == 0 || FG_META_STATUS(meta) != 0u) return;
     if (cfg.merger == FG_MERGE_SYSLEN) {  // "{len + 1} " in front (syslen_merger.rs:18-20)
         u64_digits(syslen_payload(total) + 1u, [&](uint32_t c) { sink.put(c); });
         sink.put(' ');
     }
-    (void)encode_row<ENC>(sink, cfg, rd, t, li, meta, keys64, slot_ent, order);
+    (void)encode_row<ENC>(sink, cfg, rd, t, li, meta, keys64, slot_ent, order, pre);
     if (cfg.merger == FG_MERGE_LINE || cfg.merger == FG_MERGE_SYSLEN) sink.put('\n');
     else if (cfg.merger == FG_MERGE_NUL) sink.put(0u);
     sink.finish();

@@ -32,18 +32,23 @@ template <uint32_t ENC, bool WRITE, uint32_t SLOTS> int launch_encode_tu(FG_ENC_
 // One 64-lane workgroup = 64 consecutive lines = ONE contiguous byte range of the packed buffer: it is staged into LDS
 // with coalesced 16-byte loads (stage_tile) and every lane then reads ITS line out of LDS; a group whose bytes exceed
 // the tile (long lines) reads from global memory instead (same emitter, GlobalReader).
+// what a lane needs from HBM besides the tile: fetched before the tile is staged, every load in flight
+struct LanePre {
+    uint64_t o0;         // offsets[li]
+    uint32_t meta;
+    emit::RowRegs row;
+    uint64_t oo0, oo1;   // WRITE: out_offsets[li], out_offsets[li + 1]
+};
 template <uint32_t ENC, bool WRITE, class R>
 __device__ __forceinline__ void encode_lane(R rd, uint64_t li, const DevTables& t, const EncCfg& cfg, uint64_t* keys64, uint8_t* slot_ent,
                                             uint8_t* order, uint32_t* __restrict__ sizes, uint8_t* __restrict__ enc_status,
-                                            const uint64_t* __restrict__ out_offsets, uint8_t* __restrict__ out, uint32_t* size_out) {
-    const uint32_t meta = t.meta[li];
+                                            const LanePre& pre, uint8_t* __restrict__ out, uint32_t* size_out) {
     if (WRITE) {
-        const uint64_t o0 = out_offsets[li], total = out_offsets[li + 1] - o0;
-        emit::PackSink sink(out + o0);
-        emit::row_write<ENC>(sink, total, cfg, rd, t, li, meta, keys64, slot_ent, order);
+        emit::PackSink sink(out + pre.oo0);
+        emit::row_write<ENC>(sink, pre.oo1 - pre.oo0, cfg, rd, t, li, pre.meta, keys64, slot_ent, order, &pre.row);
     } else {
         uint32_t st;
-        const uint32_t size = emit::row_size<ENC>(cfg, rd, t, li, meta, keys64, slot_ent, order, &st);
+        const uint32_t size = emit::row_size<ENC>(cfg, rd, t, li, pre.meta, keys64, slot_ent, order, &st, &pre.row);
         sizes[li] = size;
         if (enc_status) enc_status[li] = (uint8_t)st;
         *size_out = size;
@@ -56,43 +61,59 @@ template <uint32_t ENC, bool WRITE, uint32_t SLOTS>
 __global__ __launch_bounds__(kWave) void k_encode(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets, uint64_t n,
                                                  DevTables t, EncCfg cfg, uint32_t tile_cap, uint32_t cfg_lds, uint32_t* __restrict__ sizes,
                                                  uint8_t* __restrict__ enc_status, uint64_t* __restrict__ block_sums,
-                                                 const uint64_t* __restrict__ out_offsets, uint8_t* __restrict__ out) {
+                                                 const uint64_t* __restrict__ out_offsets, uint8_t* __restrict__ out,
+                                                 const uint4* __restrict__ cfg_block /* = cfg.keys, as a plain pointer */) {
     constexpr uint32_t kSlots = SLOTS ? SLOTS : 1u;
     __shared__ uint64_t s_keys[kWave * kSlots];
     __shared__ uint8_t s_slot[kWave * kSlots];
     __shared__ uint8_t s_order[kWave * kSlots];
     extern __shared__ __attribute__((aligned(16))) uint8_t s_tile[];  // tile_cap + 16 bytes, then the configuration mirror
     cfg.sort_slots = SLOTS;
-    if (cfg_lds) {  // every lane reads the same few hundred configuration bytes over and over: keep them in LDS
-        uint8_t* s_cfg = s_tile + tile_cap + 16u;
-        const uint8_t* g_cfg = reinterpret_cast<const uint8_t*>(cfg.keys);
-        for (uint32_t i = threadIdx.x * 4u; i < cfg_lds; i += kWave * 4u)
-            *reinterpret_cast<uint32_t*>(s_cfg + i) = *reinterpret_cast<const uint32_t*>(g_cfg + i);
-        cfg.blob = s_cfg + (cfg.blob - g_cfg);
-        cfg.keys = reinterpret_cast<const StaticKey*>(s_cfg);
-    }
+    // every lane reads the same few hundred configuration bytes over and over: keep them in LDS (at most 4 KiB; its
+    // loads ride along with the tile's, stage_tile_rider)
+    uint8_t* s_cfg = s_tile + tile_cap + 16u;
     const uint64_t g0 = (uint64_t)blockIdx.x * kWave;
     const uint64_t g1 = g0 + kWave < n ? g0 + kWave : n;
     const uint64_t li = g0 + threadIdx.x;
     uint64_t* keys64 = s_keys + threadIdx.x * kSlots;
     uint8_t* slot_ent = s_slot + threadIdx.x * kSlots;
     uint8_t* order = s_order + threadIdx.x * kSlots;
+    // Everything the lane needs from HBM first (offsets, table row, output slot), all loads in flight: the staging
+    // below hides them.  (Fetched where they are used, each is a dependent round trip of the whole wave.)
+    const bool live = li < n;
+    const uint64_t lic = live ? li : n - 1u;
+    LanePre pre;
+    pre.o0 = offsets[lic];
+    pre.meta = t.meta[lic];
+    pre.row.load(t, lic);
+    pre.oo0 = pre.oo1 = 0;
+    if (WRITE) {
+        pre.oo0 = out_offsets[lic];
+        pre.oo1 = out_offsets[lic + 1u];
+    }
     // the group's byte range (wave-uniform)
     const uint64_t a_begin = offsets[g0], a_end = offsets[g1];
     const uint64_t a0 = a_begin & ~15ull;
     const uint64_t span = (a_end - a0 + 15ull) & ~15ull;
     const bool staged = span <= (uint64_t)tile_cap;
     uint32_t size = 0;
+    // (20 KiB per round trip: the usual tile in one.  A group that exceeds the tile reads from global memory: only the
+    //  mirror is staged -- without a mirror, cfg_lds == 0, one chunk lands in the 16 spare bytes the launch reserves.)
+    stage_tile_rider<20>(bytes, a0, staged ? (uint32_t)span : 0u, s_tile, cfg_block, cfg_lds >> 4, reinterpret_cast<uint4*>(s_cfg));
+    {
+        const uint8_t* g_cfg = reinterpret_cast<const uint8_t*>(cfg.keys);
+        cfg.blob = cfg_lds ? s_cfg + (cfg.blob - g_cfg) : cfg.blob;
+        cfg.keys = cfg_lds ? reinterpret_cast<const StaticKey*>(s_cfg) : cfg.keys;
+    }
+    __syncthreads();  // single-wave workgroup: orders the LDS writes before the lanes' reads
     if (staged) {
-        stage_tile(bytes, a0, (uint32_t)span, s_tile);
-        __syncthreads();  // single-wave workgroup: orders the LDS writes before the lanes' reads
-        if (li < n) {
-            LdsReader rd(reinterpret_cast<const uint32_t*>(s_tile), (uint32_t)(offsets[li] - a0));
-            encode_lane<ENC, WRITE>(rd, li, t, cfg, keys64, slot_ent, order, sizes, enc_status, out_offsets, out, &size);
+        if (live) {
+            LdsReader rd(reinterpret_cast<const uint32_t*>(s_tile), (uint32_t)(pre.o0 - a0));
+            encode_lane<ENC, WRITE>(rd, li, t, cfg, keys64, slot_ent, order, sizes, enc_status, pre, out, &size);
         }
-    } else if (li < n) {
-        GlobalReader rd(reinterpret_cast<const uint32_t*>(bytes), offsets[li]);
-        encode_lane<ENC, WRITE>(rd, li, t, cfg, keys64, slot_ent, order, sizes, enc_status, out_offsets, out, &size);
+    } else if (live) {
+        GlobalReader rd(reinterpret_cast<const uint32_t*>(bytes), pre.o0);
+        encode_lane<ENC, WRITE>(rd, li, t, cfg, keys64, slot_ent, order, sizes, enc_status, pre, out, &size);
     }
     if (!WRITE) {  // the 64 lines of this workgroup: one partial sum for the offset scan
         uint64_t sum = size;
@@ -107,8 +128,8 @@ int launch_encode_tu<FG_ENC_TU, (FG_ENC_TU_WRITE != 0), FG_ENC_TU_SLOTS>(FG_ENC_
     const uint64_t blocks = (n + kWave - 1) / kWave;
     if (blocks > 0x7FFFFFFFull) return -1;
     hipLaunchKernelGGL((k_encode<FG_ENC_TU, (FG_ENC_TU_WRITE != 0), FG_ENC_TU_SLOTS>), dim3((uint32_t)blocks), dim3(kWave),
-                       tile_cap + 16u + cfg_lds, stream, d_bytes, d_offsets, n, t, cfg, tile_cap, cfg_lds, d_sizes, d_status, d_block_sums,
-                       d_out_offsets, d_out);
+                       tile_cap + 16u + (cfg_lds ? cfg_lds : 16u), stream, d_bytes, d_offsets, n, t, cfg, tile_cap, cfg_lds, d_sizes, d_status, d_block_sums,
+                       d_out_offsets, d_out, reinterpret_cast<const uint4*>(cfg.keys));
     return 0;
 }
 #else  // !FG_ENC_TU: scan kernels, dispatcher, C entry points

@@ -58,19 +58,21 @@ __global__ __launch_bounds__(kWave) void k_rfc3164(const uint8_t* __restrict__ b
     const uint64_t g0 = (uint64_t)blockIdx.x * kWave;
     const uint64_t g1 = g0 + kWave < n ? g0 + kWave : n;
     const uint64_t li = g0 + threadIdx.x;
+    // the lane's own offsets first (in flight while the tile is staged; fetched after it they are a dependent round trip)
+    const bool live = li < n;
+    const uint64_t lic = live ? li : n - 1u;
+    const uint64_t o0 = offsets[lic], o1 = offsets[lic + 1u];
     const uint64_t a_begin = offsets[g0], a_end = offsets[g1];
     const uint64_t a0 = a_begin & ~15ull;
     const uint64_t span = (a_end - a0 + 15ull) & ~15ull;
     if (span <= (uint64_t)tile_cap) {
-        stage_tile(bytes, a0, (uint32_t)span, s_tile);
+        stage_tile<20>(bytes, a0, (uint32_t)span, s_tile);  // (20 KiB per round trip: the usual tile in one)
         __syncthreads();  // single-wave workgroup: orders the LDS writes before the lanes' reads
-        if (li < n) {
-            const uint64_t o0 = offsets[li], o1 = offsets[li + 1];
+        if (live) {
             LdsReader rd(reinterpret_cast<const uint32_t*>(s_tile), (uint32_t)(o0 - a0));
             r3164_lane(rd, (uint32_t)(o1 - o0), li, t, a);
         }
-    } else if (li < n) {
-        const uint64_t o0 = offsets[li], o1 = offsets[li + 1];
+    } else if (live) {
         GlobalReader rd(reinterpret_cast<const uint32_t*>(bytes), o0);
         r3164_lane(rd, (uint32_t)(o1 - o0), li, t, a);
     }

@@ -45,3 +45,20 @@ for _ in range(3):
     best = min(best, time.perf_counter() - t0)
 print(f"fg_decode_batch (pinned source, tables left in the ctx's pinned buffer): {best * 1e3:.1f} ms = {n / best / 1e6:.1f} M lines/s, "
       f"{data.size / best / 1e9:.2f} GB/s of input")
+
+# fg_transcode_batch: chunk in -> decode -> GELF encode -> line merger -> bytes out (BASELINE configs[0] on the GPU)
+from flowgger_amd import GelfEncoder  # noqa: E402
+
+enc = GelfEncoder(None, merger="line")
+cfg, _keep = enc._cfg_struct(0.0)
+for label, framing, src, offs_ptr, nn in (
+        ("framed lines (pinned)", L.FG_FRAME_NONE, pdata, poffs.ctypes.data, n),
+        ("raw '\\n' stream framed on the GPU (pinned)", L.FG_FRAME_LINE, pinned_copy(np.frombuffer(b"\n".join(lines) + b"\n", np.uint8)), None, 0)):
+    best, res = 1e9, L.fg_transcoded()
+    for _ in range(4):
+        t0 = time.perf_counter()
+        L.check(L.lib().fg_transcode_batch(dec._ctx, dec.fmt, framing, C.byref(cfg), src.ctypes.data, src.size, offs_ptr, nn, 1, C.byref(res)),
+                "fg_transcode_batch")
+        best = min(best, time.perf_counter() - t0)
+    print(f"fg_transcode_batch, {label}: {int(res.n)} lines, {src.size / 1e6:.0f} MB in, {int(res.out_bytes) / 1e6:.0f} MB out, "
+          f"{best * 1e3:.1f} ms = {int(res.n) / best / 1e6:.1f} M lines/s ({(src.size + int(res.out_bytes)) / best / 1e9:.1f} GB/s over PCIe, both directions)")
