@@ -455,11 +455,14 @@ struct EncoderConfig {
 
 class TranscodingSplitter {
   public:
-    enum Framing { Line, Nul };
+    enum Framing { Line, Nul, Syslen };
     TranscodingSplitter(Framing f, EncoderConfig enc, size_t chunk_bytes = 8u << 20) : f_(f), enc_(std::move(enc)), chunk_(chunk_bytes) {}
 
-    // LineSplitter::run / NulSplitter::run (line_splitter.rs:10-41, nul_splitter.rs:10-50) + the output thread's write:
-    // `out` receives the encoded, framed messages in input order; `err` what the reference prints for dropped lines.
+    // LineSplitter / NulSplitter / SyslenSplitter::run (splitter/*_splitter.rs) + the output thread's write: `out`
+    // receives the encoded, framed messages in input order; `err` what the reference prints for dropped lines.
+    // Line / Nul: the GPU frames the raw chunks.  Syslen ("<len> " + len bytes, syslen_splitter.rs:42-57): the length
+    // prefixes are a sequential chain -- the host hops from prefix to prefix (it never touches the message bytes
+    // otherwise) and hands the GPU the packed messages with their offsets.
     void run(std::istream& in, const Decoder& d, std::ostream& out, std::ostream& err) {
         std::vector<const char*> ks, vs;
         for (auto& kv : enc_.extra) { ks.push_back(kv.first.c_str()); vs.push_back(kv.second.c_str()); }
@@ -471,6 +474,10 @@ class TranscodingSplitter {
         ec.extra_values = vs.data();
         ec.prepend = enc_.prepend ? enc_.prepend->c_str() : nullptr;
         ec.now_ts = enc_.now_ts;
+        if (f_ == Syslen) {
+            run_syslen(in, d, ec, out, err);
+            return;
+        }
         std::vector<uint8_t> buf;
         bool eof = false;
         while (!eof || !buf.empty()) {
@@ -488,24 +495,7 @@ class TranscodingSplitter {
                                         0, eof ? 1 : 0, &r);
             if (rc != FG_OK) throw std::runtime_error("fg_transcode_batch failed: " + std::to_string(rc));
             if (r.out_bytes) out.write((const char*)r.out, (std::streamsize)r.out_bytes);
-            for (uint64_t i = 0; i < r.n; ++i) {
-                const uint8_t st = FG_META_STATUS(r.meta[i]), es = r.enc_status[i];
-                if (st == 0 && es == 0) continue;
-                if (st == FG_ST_BAD_UTF8) {
-                    err << "Invalid UTF-8 input\n";  // line_splitter.rs:22-25, nul_splitter.rs:35-38
-                    continue;
-                }
-                uint64_t b = r.frame_offsets[i], e = r.frame_offsets[i + 1];  // the line without its terminator
-                if (f_ == Line) {
-                    if (e > b && buf[e - 1] == '\n') { --e; if (e > b && buf[e - 1] == '\r') --e; }
-                } else if (e > b && buf[e - 1] == 0) {
-                    --e;
-                }
-                std::string_view tl = detail::trim(std::string_view((const char*)buf.data() + b, e - b));
-                if (f_ == Nul && tl.empty()) continue;  // nul_splitter.rs:41-46
-                const char* msg = st ? fg_error_string(d.format(), st) : fg_encode_error_string(es);
-                err << (msg ? msg : "?") << ": [" << tl << "]\n";  // line_splitter.rs:37-39
-            }
+            report(d, r, buf.data(), r.frame_offsets, err);
             if (r.consumed == 0 && !eof && r.n == 0) {  // one frame longer than the chunk: read more
                 chunk_ *= 2;
                 continue;
@@ -515,6 +505,81 @@ class TranscodingSplitter {
     }
 
   private:
+    // stderr for the lines the pipeline dropped, as the reference prints them
+    void report(const Decoder& d, const fg_transcoded& r, const uint8_t* bytes, const uint64_t* offs, std::ostream& err) const {
+        for (uint64_t i = 0; i < r.n; ++i) {
+            const uint8_t st = FG_META_STATUS(r.meta[i]), es = r.enc_status[i];
+            if (st == 0 && es == 0) continue;
+            if (st == FG_ST_BAD_UTF8) {
+                err << "Invalid UTF-8 input\n";  // line_splitter.rs:22-25, nul_splitter.rs:35-38
+                continue;
+            }
+            uint64_t b = offs[i], e = offs[i + 1];  // the line without its terminator
+            if (f_ == Line) {
+                if (e > b && bytes[e - 1] == '\n') { --e; if (e > b && bytes[e - 1] == '\r') --e; }
+            } else if (f_ == Nul && e > b && bytes[e - 1] == 0) {
+                --e;
+            }
+            std::string_view tl = detail::trim(std::string_view((const char*)bytes + b, e - b));
+            if (f_ == Nul && tl.empty()) continue;  // nul_splitter.rs:41-46
+            const char* msg = st ? fg_error_string(d.format(), st) : fg_encode_error_string(es);
+            err << (msg ? msg : "?") << ": [" << tl << "]\n";  // line_splitter.rs:37-39, syslen_splitter.rs:35-37
+        }
+    }
+    void flush_syslen(const Decoder& d, const fg_encode_cfg& ec, std::vector<uint8_t>& bytes, std::vector<uint64_t>& offs,
+                      std::ostream& out, std::ostream& err) const {
+        const uint64_t n = offs.size() - 1;
+        if (n == 0) return;
+        const uint64_t nbytes = bytes.size();
+        bytes.resize(nbytes + 16);  // readable slack
+        fg_transcoded r{};
+        int rc = fg_transcode_batch(d.ctx(), d.format(), FG_FRAME_NONE, &ec, bytes.data(), nbytes, offs.data(), n, 1, &r);
+        if (rc != FG_OK) throw std::runtime_error("fg_transcode_batch failed: " + std::to_string(rc));
+        if (r.out_bytes) out.write((const char*)r.out, (std::streamsize)r.out_bytes);
+        report(d, r, bytes.data(), offs.data(), err);
+        bytes.clear();
+        offs.assign(1, 0);
+    }
+    void run_syslen(std::istream& in, const Decoder& d, const fg_encode_cfg& ec, std::ostream& out, std::ostream& err) {
+        std::vector<uint8_t> bytes;
+        std::vector<uint64_t> offs(1, 0);
+        std::string num;
+        for (;;) {
+            num.clear();
+            int c;
+            while ((c = in.get()) != EOF && c != ' ') num.push_back((char)c);
+            // read_msglen (:42-57): EOF / nothing before the space / not a usize -> "Can't read message's length" (:20-25)
+            bool ok = c != EOF && !num.empty();
+            size_t len = 0, k = (ok && num[0] == '+') ? 1 : 0;
+            if (ok && k >= num.size()) ok = false;
+            for (; ok && k < num.size(); ++k) {
+                if (num[k] < '0' || num[k] > '9') ok = false;
+                else len = len * 10 + (size_t)(num[k] - '0');
+            }
+            if (!ok) {
+                flush_syslen(d, ec, bytes, offs, out, err);
+                err << "Can't read message's length\n";
+                return;
+            }
+            const size_t at = bytes.size();
+            bytes.resize(at + len);
+            in.read((char*)bytes.data() + at, (std::streamsize)len);
+            if ((size_t)in.gcount() != len) {  // read_exact fails (:27-30): the partial frame is dropped
+                bytes.resize(at);
+                flush_syslen(d, ec, bytes, offs, out, err);
+                err << "failed to fill whole buffer\n";
+                return;
+            }
+            if (!detail::valid_utf8(bytes.data() + at, len)) {  // String::from_utf8(..).unwrap() panics (:33): the thread ends
+                bytes.resize(at);
+                flush_syslen(d, ec, bytes, offs, out, err);
+                err << "Invalid UTF-8 input\n";
+                return;
+            }
+            offs.push_back(bytes.size());
+            if (bytes.size() >= chunk_) flush_syslen(d, ec, bytes, offs, out, err);
+        }
+    }
     Framing f_;
     EncoderConfig enc_;
     size_t chunk_;

@@ -1,6 +1,6 @@
 // Exercises the C++ host mirror (flowgger_amd/host/fg_decoder.hpp): frames a file like the
 // reference splitters, decodes in batches on the GPU, prints one hex canonical Record per Ok line
-// on stdout and the reference's error lines on stderr.  usage: host_mirror_test <rfc5424|ltsv|gelf> <line|nul|syslen|gpu-line|gpu-nul|pipe-line|pipe-nul> <file> [batch]
+// on stdout and the reference's error lines on stderr.  usage: host_mirror_test <rfc5424|ltsv|gelf> <line|nul|syslen|gpu-line|gpu-nul|pipe-line|pipe-nul|pipe-syslen> <file> [batch]
 #include <cstdio>
 #include <fstream>
 #include <iostream>
@@ -28,13 +28,13 @@ int main(int argc, char** argv) {
         for (unsigned char ch : c) printf("%02x", ch);
         printf("\n");
     };
-    if (fr == "pipe-line" || fr == "pipe-nul") {  // the whole handle_line on the GPU: encoded GELF stream on stdout
+    if (fr == "pipe-line" || fr == "pipe-nul" || fr == "pipe-syslen") {  // the whole handle_line on the GPU: encoded GELF stream on stdout
         fg::EncoderConfig ec;
         ec.encoder = FG_ENC_GELF;
-        ec.merger = fr == "pipe-line" ? FG_MERGE_LINE : FG_MERGE_NUL;
+        ec.merger = fr == "pipe-line" ? FG_MERGE_LINE : fr == "pipe-nul" ? FG_MERGE_NUL : FG_MERGE_SYSLEN;
         ec.extra = {{"_site", "dc1"}, {"a_first", "x\"y"}};
         ec.now_ts = 1438859724.638;
-        fg::TranscodingSplitter tsp(fr == "pipe-line" ? fg::TranscodingSplitter::Line : fg::TranscodingSplitter::Nul, ec,
+        fg::TranscodingSplitter tsp(fr == "pipe-line" ? fg::TranscodingSplitter::Line : fr == "pipe-nul" ? fg::TranscodingSplitter::Nul : fg::TranscodingSplitter::Syslen, ec,
                                     argc > 4 ? (size_t)atoi(argv[4]) : (8u << 20));
         std::ifstream pin(argv[3], std::ios::binary);
         tsp.run(pin, *clone, std::cout, std::cerr);

@@ -941,10 +941,11 @@ def test_transcode_stream_chunks_concatenate(rfc, oracle):
     assert b"".join(out) == oblob.tobytes()
 
 
-@pytest.mark.parametrize("fmt,framing", [("rfc5424", "pipe-line"), ("gelf", "pipe-nul")])
+@pytest.mark.parametrize("fmt,framing", [("rfc5424", "pipe-line"), ("gelf", "pipe-nul"), ("rfc5424", "pipe-syslen")])
 def test_cpp_transcoding_splitter_is_the_reference_pipeline(tmp_path, oracle, fmt, framing):
     """fg::TranscodingSplitter (C++): raw stream -> the GELF stream the output writes + the reference's stderr lines,
-    i.e. BASELINE configs[0] (input -> decoder -> gelf encoder -> output) with every stage on the GPU"""
+    i.e. BASELINE configs[0] (input -> decoder -> gelf encoder -> output) with every stage on the GPU; syslen framing
+    ("<len> " prefixes, syslen_splitter.rs) is hopped through on the host, the messages go to the GPU packed"""
     import subprocess
     from pathlib import Path
 
@@ -957,26 +958,32 @@ def test_cpp_transcoding_splitter_is_the_reference_pipeline(tmp_path, oracle, fm
                     "-L/opt/rocm/lib", "-lamdhip64"], check=True)
     code = {"rfc5424": RFC5424, "gelf": GELF}[fmt]
     lines = synth.rfc5424_lines(3000, cfg=4, sd=True) + synth.rfc5424_lines(3000, cfg=2) if fmt == "rfc5424" else synth.gelf_lines(3000)
+    syslen = framing == "pipe-syslen"
     term = b"\n" if framing == "pipe-line" else b"\0"
     lines = [ln for ln in lines if b"\n" not in ln and b"\0" not in ln]
     bad_utf8 = b"<13>1 2015-08-05T15:53:45Z h a p m - \xff\xfe"
-    raw = b"".join(ln + term for ln in lines[:100]) + bad_utf8 + term + b"".join(ln + term for ln in lines[100:-1]) + lines[-1]
+    if syslen:  # the reference unwrap()-panics on invalid UTF-8 here: not in the stream; it ends with an unreadable length
+        raw = b"".join(str(len(ln)).encode() + b" " + ln for ln in lines) + b"12x "
+    else:
+        raw = b"".join(ln + term for ln in lines[:100]) + bad_utf8 + term + b"".join(ln + term for ln in lines[100:-1]) + lines[-1]
     f = tmp_path / "in.bin"
     f.write_bytes(raw)
     p = subprocess.run([str(exe), fmt, framing, str(f), "30011"], capture_output=True)
     assert p.returncode == 0, p.stderr[-2000:]
     data, offsets = synth.pack(lines)
     extra = {"_site": "dc1", "a_first": "x\"y"}
-    oblob, ooffs, ost = oracle.decode_encode_batch(code, OB.ENC_GELF, OB.MERGE_LINE if term == b"\n" else OB.MERGE_NUL, data, offsets, None,
-                                                   extra=extra, prepend=None, now_ts=1438859724.638)
+    om = OB.MERGE_SYSLEN if syslen else OB.MERGE_LINE if term == b"\n" else OB.MERGE_NUL
+    oblob, ooffs, ost = oracle.decode_encode_batch(code, OB.ENC_GELF, om, data, offsets, None, extra=extra, prepend=None, now_ts=1438859724.638)
     assert p.stdout == oblob.tobytes()
     want_err = []
     for i, ln in enumerate(lines):
-        if i == 100:
+        if i == 100 and not syslen:
             want_err.append("Invalid UTF-8 input")
         c = oracle.decode(code, ln, None)
         if c[0] != 0:
             t = ln.decode("utf-8", "replace").strip()
-            if not (term == b"\0" and t == ""):
+            if not (framing == "pipe-nul" and t == ""):
                 want_err.append(f"{c[5:].decode()}: [{t}]")
+    if syslen:
+        want_err.append("Can't read message's length")
     assert p.stderr.decode("utf-8", "replace").splitlines() == want_err
