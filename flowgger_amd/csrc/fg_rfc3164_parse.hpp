@@ -68,6 +68,12 @@ struct Row {
     uint32_t host_off = 0, host_len = 0, msg_off = 0, msg_len = 0, full_len = 0;
 };
 
+// SWAR: nonzero iff some byte of w could be (part of) a White_Space character -- 0x20, anything below 0x0E (covers
+// 0x09..0x0D), or a non-ASCII byte.  Conservative: a hit only means "look at the bytes".
+FG3_HD uint32_t maybe_ws4(uint32_t w) {
+    const uint32_t sp = w ^ 0x20202020u;
+    return (w & 0x80808080u) | ((w - 0x0E0E0E0Eu) & ~w & 0x80808080u) | ((sp - 0x01010101u) & ~sp & 0x80808080u);
+}
 // str::split_whitespace: the next token of rd[pos .. end); false when there is none
 template <class R>
 FG3_HD bool next_token(R& rd, uint32_t& pos, uint32_t end, uint32_t* ts, uint32_t* te) {
@@ -78,7 +84,11 @@ FG3_HD bool next_token(R& rd, uint32_t& pos, uint32_t end, uint32_t* ts, uint32_
     }
     if (pos >= end) return false;
     *ts = pos;
-    while (pos < end && !ws_at(rd, pos, end)) ++pos;  // (continuation bytes are never whitespace lead bytes)
+    for (;;) {  // the token body: four bytes at a time while none of them can be whitespace
+        while (pos + 4u <= end && !maybe_ws4(rd.load4(pos, 4u))) pos += 4u;
+        if (pos >= end || ws_at(rd, pos, end)) break;  // (continuation bytes are never whitespace lead bytes)
+        ++pos;
+    }
     *te = pos;
     return true;
 }
@@ -326,6 +336,13 @@ FG3_HD void parse_line(R& rd, uint32_t len, const Cfg& cfg, Row& r) {
     // ---- decode_rfc_custom -----------------------------------------------------------------------------------------
     uint32_t p1 = 0, p2 = 0, found = 0;
     for (uint32_t i = q0; i + 1u < len;) {  // msg.split(": "): non-overlapping, left to right
+        if (i + 4u <= len) {  // four bytes without a ':' cannot start a separator
+            const uint32_t c4 = rd.load4(i, 4u) ^ 0x3A3A3A3Au;
+            if (!((c4 - 0x01010101u) & ~c4 & 0x80808080u)) {
+                i += 4u;
+                continue;
+            }
+        }
         if (rd.byte(i) == ':' && rd.byte(i + 1) == ' ') {
             if (found == 0) p1 = i;
             else p2 = i;

@@ -14,6 +14,11 @@ namespace {
 struct HostReader {
     const uint8_t* p;
     uint32_t byte(uint32_t i) { return p[i]; }
+    uint32_t load4(uint32_t i, uint32_t nb) {  // only the nb wanted bytes are read (the private copy has no padding)
+        uint32_t w = 0;
+        memcpy(&w, p + i, nb);
+        return w;
+    }
 };
 }  // namespace
 
