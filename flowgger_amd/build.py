@@ -22,7 +22,7 @@ ARCH = "gfx950"
 
 HIP_SOURCES = ["fg_rfc5424.hip", "fg_ltsv.hip", "fg_gelf.hip", "fg_frame.hip", "fg_encode.hip", "fg_rfc3164.hip"]
 HIP_HOST_SOURCES = ["fg_capi.cpp"]  # host code that needs the HIP headers / launch syntax
-CXX_SOURCES = ["fg_materialize.cpp", "fg_host.cpp"]
+CXX_SOURCES = ["fg_materialize.cpp"]
 
 
 def _hipcc() -> str:
