@@ -9,10 +9,13 @@
 //   k_block_scan + k_line_offsets   per-workgroup sums -> exclusive scan -> out_offsets[0..n]
 //   k_encode<ENC, true>   write at out + out_offsets[i]
 // so that the output is ONE contiguous, already framed byte stream in input order (what the outputs write).
-// Input: the 64 lines of a workgroup are one contiguous byte range, staged into LDS with coalesced 16-byte loads.
-// Spans without bytes that need escaping move four bytes at a time (SWAR test per dword, fg_emit.hpp); the write sink
-// packs the byte stream into aligned dword stores (emit::PackSink).  Output stores are still per lane (each lane
-// streams into its own message): staging the output tile through LDS for coalesced stores is the next step.
+// Input: the 64 lines of a workgroup are one contiguous byte range, staged into LDS with coalesced 16-byte loads; every
+// HBM input of a lane (its offsets, its table row, its output slot) and the configuration mirror are requested BEFORE
+// the tile so that one round trip covers them all (stage_tile_rider).  Spans without bytes that need escaping move
+// sixteen bytes per LDS round trip (SWAR test per dword, fg_emit.hpp); the write sink packs the byte stream into
+// aligned dword stores (emit::PackSink).  Output stores are per lane (each lane streams into its own message).
+// Measured: the kernels are latency-bound at two waves per SIMD (the LDS tile is the occupancy
+// limit); 16-byte output stores were slower than dword stores, a cheaper sink accumulator changed nothing.
 #include "fg_device.hpp"
 #include "fg_emit.hpp"
 
