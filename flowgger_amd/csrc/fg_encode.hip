@@ -137,17 +137,28 @@ int launch_encode_tu<FG_ENC_TU, (FG_ENC_TU_WRITE != 0), FG_ENC_TU_SLOTS>(FG_ENC_
 }
 #else  // !FG_ENC_TU: scan kernels, dispatcher, C entry points
 
-// exclusive scan of the per-workgroup sums (nb = ceil(n / 64) of them) in place; off_n[0] = the grand total.  One workgroup.
+// exclusive scan of the per-workgroup sums (nb = ceil(n / 64) of them) in place; off_n[0] = the grand total.  One
+// workgroup; every thread owns kScanPerThread consecutive sums per round (8192 sums per round: 100 M lines = 191 rounds).
+constexpr uint32_t kScanPerThread = 8;
 __global__ __launch_bounds__(1024) void k_block_scan(uint64_t* __restrict__ block_sums, uint64_t nb, uint64_t* __restrict__ off_n) {
     __shared__ uint64_t wave_tot[16];
     __shared__ uint64_t carry_s;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     if (tid == 0) carry_s = 0;
     __syncthreads();
-    for (uint64_t b0 = 0; b0 < nb; b0 += 1024) {
-        const uint64_t i = b0 + tid;
-        const uint64_t x = i < nb ? block_sums[i] : 0;
-        uint64_t inc = x;
+    const uint64_t last = nb ? nb - 1u : 0u;
+    for (uint64_t b0 = 0; b0 < nb; b0 += 1024ull * kScanPerThread) {
+        const uint64_t i0 = b0 + (uint64_t)tid * kScanPerThread;
+        uint64_t x[kScanPerThread];
+        uint64_t t = 0;
+#pragma unroll
+        for (uint32_t v = 0; v < kScanPerThread; ++v) {  // (unconditional, index-clamped loads: all in flight)
+            const uint64_t i = i0 + v;
+            const uint64_t val = block_sums[i < last ? i : last];
+            x[v] = i < nb ? val : 0ull;
+            t += x[v];
+        }
+        uint64_t inc = t;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             uint64_t y = __shfl_up(inc, d, 64);
@@ -157,7 +168,13 @@ __global__ __launch_bounds__(1024) void k_block_scan(uint64_t* __restrict__ bloc
         __syncthreads();
         uint64_t o = carry_s;
         for (uint32_t w = 0; w < wv; ++w) o += wave_tot[w];
-        if (i < nb) block_sums[i] = o + inc - x;
+        uint64_t run = o + inc - t;  // exclusive prefix of this thread's first sum
+#pragma unroll
+        for (uint32_t v = 0; v < kScanPerThread; ++v) {
+            const uint64_t i = i0 + v;
+            if (i < nb) block_sums[i] = run;
+            run += x[v];
+        }
         __syncthreads();
         if (tid == 1023) carry_s = o + inc;
         __syncthreads();

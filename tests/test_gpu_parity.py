@@ -987,3 +987,28 @@ def test_cpp_transcoding_splitter_is_the_reference_pipeline(tmp_path, oracle, fm
     if syslen:
         want_err.append("Can't read message's length")
     assert p.stderr.decode("utf-8", "replace").splitlines() == want_err
+
+
+def test_encode_offsets_at_scale(rfc):
+    """600 K lines = more 64-line blocks than one round of the offset scan holds: the output must be one gap-free stream in
+    which every message ends with the merger's "\\n" and no other byte is a raw newline (GELF escapes them) -- a
+    size-independent check of count -> block scan -> line offsets -> write"""
+    import torch
+
+    from flowgger_amd import GelfEncoder
+
+    lines = synth.rfc5424_lines(600_000, cfg=2)
+    data, offsets = synth.pack(lines)
+    tables, d_bytes, d_offsets = device_path(rfc, data, offsets)
+    d_out, d_off, d_st = GelfEncoder(None, merger="line").encode_device(rfc, d_bytes, d_offsets, len(lines), tables, want_status=True)
+    torch.cuda.synchronize()
+    sizes = d_off[1:] - d_off[:-1]
+    assert int(d_off[0]) == 0 and int(d_off[-1]) == d_out.numel() and bool((sizes >= 0).all())
+    produced = sizes > 0
+    assert bool((produced == (d_st == 0)).all())
+    ends = (d_off[1:][produced] - 1).long()
+    assert bool((d_out[ends] == 10).all())
+    assert int((d_out == 10).sum()) == int(produced.sum())
+    # and the first / last messages are the oracle-checked ones of the small tests: valid JSON objects
+    first = bytes(d_out[:int(d_off[1])].cpu().numpy())
+    assert first.startswith(b"{") and first.endswith(b"}\n")
