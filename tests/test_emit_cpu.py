@@ -166,3 +166,20 @@ def test_ts_now_uses_the_callers_clock(emit, oracle):
         got = emit(enc, 1, GELF, cb, now_ts=1438859724.638)
         assert got == oracle.encode(enc, cb, 1, now_ts=1438859724.638)
         assert b"1438859724.638" in got or b"11:15:24" in got
+
+
+def test_integer_text_at_the_chunk_boundaries(emit, oracle):
+    """u64_digits prints 2 + 9 + 9 digit chunks with the leading zeros suppressed: every power-of-ten boundary, the
+    chunk borders (10^9, 10^18) and the type limits, as U64 / I64 pair values through the LTSV and GELF encoders and as
+    the syslen prefix (message lengths around 10, 100, 1000)"""
+    vals = sorted({0, 2 ** 64 - 1, 2 ** 63, 2 ** 63 - 1} | {10 ** k + d for k in range(0, 20) for d in (-1, 0, 1) if 0 <= 10 ** k + d < 2 ** 64})
+    for src in (LTSV, GELF):
+        for i in range(0, len(vals), 8):
+            pairs = [(f"_u{j}", (4, v)) for j, v in enumerate(vals[i:i + 8])]
+            pairs += [(f"_i{j}", (3, -v if v <= 2 ** 63 else -(2 ** 63))) for j, v in enumerate(vals[i:i + 8])]
+            cb = canonical(ts=1.5, hostname="h", severity=5, facility=23, msg="m", sd=[(None, pairs)])
+            for enc in (OB.ENC_LTSV, OB.ENC_GELF, OB.ENC_RFC5424):
+                assert emit(enc, 0, src, cb) == oracle.encode(enc, cb, 0), (src, enc, vals[i:i + 8])
+    for n in (1, 5, 6, 7, 95, 96, 97, 98, 995, 996, 997, 998, 9996, 9997, 9998):  # framed length crosses 10 / 100 / 1000 / 10000
+        cb = canonical(ts=1.5, hostname="h", msg="m", full_msg="x" * n)
+        assert emit(OB.ENC_PASSTHROUGH, 3, RFC5424, cb) == oracle.encode(OB.ENC_PASSTHROUGH, cb, 3), n
