@@ -24,7 +24,7 @@ ES = {0: None, 2: "Failed to parse date", 3: "Failed to parse date as Rfc3339 fo
 def emit():
     src, lib = ROOT / "tests/native/emit_host.cpp", ROOT / "tests/native/libemit_host.so"
     deps = [src] + [ROOT / "flowgger_amd/csrc" / n for n in ("fg_emit.hpp", "fg_enc_cfg.hpp", "fg_shortest.hpp", "fg_dtoa.hpp",
-                                                             "fg_tables_view.hpp", "fg_timeconv.hpp")] + [ROOT / "include/fg_hip.h"]
+                                                             "fg_tables_view.hpp", "fg_timeconv.hpp", "fg_unicode_ws.hpp")] + [ROOT / "include/fg_hip.h"]
     if not lib.exists() or lib.stat().st_mtime < max(p.stat().st_mtime for p in deps):
         subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-fno-fast-math", "-Wno-unknown-pragmas", "-o", str(lib), str(src)],
                        check=True)

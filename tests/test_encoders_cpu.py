@@ -168,7 +168,7 @@ def test_rust_display_f64(oracle):
 
 def _shortest_lib():
     src, lib = ROOT / "tests/native/shortest_host.cpp", ROOT / "tests/native/libshortest_host.so"
-    hdrs = [ROOT / "flowgger_amd/csrc/fg_shortest.hpp", ROOT / "flowgger_amd/csrc/fg_shortest_table.inc"]
+    hdrs = [ROOT / "flowgger_amd/csrc/fg_shortest.hpp", ROOT / "flowgger_amd/csrc/fg_shortest_table.inc", ROOT / "flowgger_amd/csrc/fg_dtoa.hpp"]
     if not lib.exists() or lib.stat().st_mtime < max(p.stat().st_mtime for p in [src] + hdrs):
         subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fno-fast-math", "-o", str(lib), str(src)], check=True)
     L = C.CDLL(str(lib))
