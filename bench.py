@@ -7,16 +7,22 @@ HBM with rebased offsets, 1 % invalid lines).  A "step" = ONE pass of the hot pa
 (fg_decode_batch_device through the C ABI) over the whole resident batch: every line tokenised,
 every table row written.  Inputs are resident in HBM when the timed region starts.
 
-One JSON line on stdout (rank 0).  `roofline.achieved` = algorithmic bytes per launch (DESIGN.md:
-line bytes + 8 B offset read, 68 B table row written, + 18 B per SD entry) / mean kernel time
+One JSON line on stdout (rank 0).  `roofline.achieved` = algorithmic bytes per launch (SURVEY 8d:
+line bytes + 4 B offset read, 64 B table row written, + 20 B per SD entry) / mean kernel time
 measured with HIP events on the launch stream.  `cpu_baseline` = the C++ oracle (a restatement of
-the reference's CPU decoders, "port") timed on this box's host cores on a bounded sample.
+the reference's CPU decoders, "port") timed on this box's host cores on a bounded sample, one
+thread and all cores.  `e2e` = the PCIe-inclusive host-buffer entry points (never `value`).
+
+`python bench.py --gpus N` launches its own N ranks (torch.distributed.run, one per GPU, RCCL for the
+barrier / max-over-ranks) when no launcher has set WORLD_SIZE; under torchrun it uses the env as given.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -40,6 +46,10 @@ def parse_args():
                     help="cfg2 = the BASELINE metric's configuration (default); the others time the remaining "
                          "kernels on their parity-test corpora (not bench lines, see DESIGN.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive host-buffer legs (fg_decode_batch / fg_transcode_batch)")
+    ap.add_argument("--spawn", action="store_true",
+                    help="launch the ranks through torch.distributed.run even for --gpus 1 (the path --gpus N>1 takes by itself "
+                         "when WORLD_SIZE is not set)")
     ap.add_argument("--line-len", type=int, nargs=2, default=None, metavar=("LO", "HI"),
                     help="cfg2 only: uniform line-length range instead of 192..320 (tuning experiments)")
     ap.add_argument("--invalid-frac", type=float, default=0.01, help="share of invalid lines in the tile (SURVEY 8d: 1 %%)")
@@ -60,7 +70,79 @@ WORKLOADS = {
 }
 
 
-def cpu_baseline(fmt, data, offsets, n_lines, cfg=None):
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` with no torchrun around it: re-exec under torch.distributed.run, one rank per GPU
+    (the driver's own launch line for N>1 does the same and never gets here: it sets WORLD_SIZE)."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    argv = [a for a in sys.argv[1:] if a != "--spawn"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *argv]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), FG_BENCH_SPAWNED="1")
+    return subprocess.call(cmd, env=env)
+
+
+def source_hash() -> str:
+    """Identity of the kernel sources a PMC traffic figure belongs to (profiles/traffic.json, tools/update_traffic.py)."""
+    from flowgger_amd.build import source_hash as h
+
+    return h()
+
+
+def e2e_legs(dec, fmt, data, offsets, n_tile, tile_bytes, want_transcode):
+    """PCIe-inclusive rates of the host-buffer entry points on a bounded sample (4 tiles from pinned memory):
+    fg_decode_batch = H2D + kernels + D2H of the tables; fg_transcode_batch = H2D + decode + GELF encode + line merger +
+    D2H of the encoded stream.  Reported beside `value`, never as `value`."""
+    import ctypes as C
+
+    from flowgger_amd import GelfEncoder
+    from flowgger_amd import _lib as L
+
+    reps = 4
+    n = n_tile * reps
+
+    def pinned(nbytes, dt):
+        p = C.c_void_p()
+        L.check(L.lib().fg_alloc_pinned(nbytes, C.byref(p)), "fg_alloc_pinned")
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (nbytes,)).view(dt), p
+
+    pdata, hd = pinned(tile_bytes * reps + 32, np.uint8)
+    poffs, ho = pinned((n + 1) * 8, np.uint64)
+    for r in range(reps):
+        pdata[r * tile_bytes:(r + 1) * tile_bytes] = data[:tile_bytes]
+        poffs[r * n_tile:(r + 1) * n_tile] = offsets[:-1] + np.uint64(r * tile_bytes)
+    poffs[n] = tile_bytes * reps
+    out = {"sample": f"{n} lines ({reps} tiles) from pinned host memory, best of 3"}
+    try:
+        best = 1e9
+        for _ in range(4):
+            st = L.fg_tables()
+            t0 = time.perf_counter()
+            L.check(L.lib().fg_decode_batch(dec._ctx, fmt, pdata.ctypes.data, tile_bytes * reps, poffs.ctypes.data, n, C.byref(st)),
+                    "fg_decode_batch")
+            best = min(best, time.perf_counter() - t0)
+        out["decode_batch"] = {"lines_per_s": n / best, "GBps_in": tile_bytes * reps / best / 1e9, "ms": best * 1e3,
+                               "what": "fg_decode_batch: H2D + kernels + D2H of the tables"}
+        if want_transcode:
+            enc = GelfEncoder(None, merger="line")
+            cfg, _keep = enc._cfg_struct(0.0)
+            best, res = 1e9, L.fg_transcoded()
+            for _ in range(4):
+                t0 = time.perf_counter()
+                L.check(L.lib().fg_transcode_batch(dec._ctx, fmt, L.FG_FRAME_NONE, C.byref(cfg), pdata.ctypes.data, tile_bytes * reps,
+                                                   poffs.ctypes.data, n, 1, C.byref(res)), "fg_transcode_batch")
+                best = min(best, time.perf_counter() - t0)
+            out["transcode_batch"] = {"lines_per_s": n / best, "GBps_in_plus_out": (tile_bytes * reps + int(res.out_bytes)) / best / 1e9,
+                                      "out_bytes": int(res.out_bytes), "ms": best * 1e3,
+                                      "what": "fg_transcode_batch: H2D + decode + GELF encode + line merger + D2H of the stream"}
+    finally:
+        L.lib().fg_free_pinned(hd)
+        L.lib().fg_free_pinned(ho)
+    return out
+
+
+def cpu_baseline(fmt, data, offsets, n_lines, cfg=None, pipeline=False):
     """Oracle timing leg (the ONLY place bench.py touches oracle/)."""
     sys.path.insert(0, str(ROOT / "tests"))
     import oracle_binding
@@ -71,21 +153,35 @@ def cpu_baseline(fmt, data, offsets, n_lines, cfg=None):
 
         o.set_rfc3164(2026, tzdb.default_table())
     cores = os.cpu_count() or 1
-    passes, secs, n_ok = 0, 0.0, 0
-    t_end = time.time() + 4.0  # a few seconds of wall time on every host core = tens of CPU-seconds
-    while passes < 2 or (time.time() < t_end and passes < 256):
-        s, n_ok = o.bench(fmt, data, offsets, cores, cfg)
-        secs += s
-        passes += 1
+    ENC_GELF, MERGE_LINE = oracle_binding.ENC_GELF, oracle_binding.MERGE_LINE
+
+    def run(threads, budget_s):
+        passes, secs, n_ok = 0, 0.0, 0
+        t_end = time.time() + budget_s
+        while passes < 1 or (time.time() < t_end and passes < 256):
+            if pipeline:
+                s, n_ok, _ = o.bench_pipeline(fmt, ENC_GELF, MERGE_LINE, data, offsets, threads, cfg)
+            else:
+                s, n_ok = o.bench(fmt, data, offsets, threads, cfg)
+            secs += s
+            passes += 1
+        return n_lines * passes / secs, passes, n_ok
+
+    one, p1, n_ok = run(1, 3.0)        # a few seconds of one core
+    allc, pn, n_ok = run(cores, 4.0)   # a few seconds of wall time on every host core = tens of CPU-seconds
+    what = "decode + GELF encode + line merger + null sink (SURVEY 8d configuration 1)" if pipeline else "decode, owned Record per line"
     return {
-        "value": n_lines * passes / secs, "unit": "lines/s", "cores": cores, "kind": "port",
-        "sample": f"{passes} passes over the {n_lines}-line tile of the same workload, {cores} threads, "
-                  "owned Record per line (C++ restatement of the Rust decoders; the Rust build is unavailable)",
+        "value": allc, "unit": "lines/s", "cores": cores, "kind": "port",
+        "single_thread": {"value": one, "cores": 1, "passes": p1},
+        "sample": f"{pn} passes over the {n_lines}-line tile of the same workload on {cores} threads (and {p1} on one thread): {what}; "
+                  "C++ restatement of the Rust decoders/encoders, not the Rust build (unavailable here)",
     }, n_ok
 
 
 def main():
     args = parse_args()
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
+        raise SystemExit(self_launch(args))
     import torch
     import torch.distributed as dist
 
@@ -203,24 +299,38 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    rank_ms = [kernel_ms]
+    if world > 1:  # every rank's own kernel time (HIP events on its stream), gathered over RCCL
+        g = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(g, torch.tensor([kernel_ms], device=dev, dtype=torch.float64))
+        rank_ms = [float(x.item()) for x in g]
 
-    # ---- validity: every row was produced (status histogram of replica 0 == every replica) ----
+    # ---- validity: every replica of the tile produced the SAME rows -- all fixed columns, not only the status
+    #      (ent_first is the one column that legitimately differs: entry slices are placed by wave-level allocation) ----
     meta = tables.column("meta").view(torch.int32).view(reps, n_tile)
     status = meta & 0xFF
     n_ok_tile = int((status[0] == 0).sum().item())
-    assert os.environ.get("FG_ABLATE") or bool((status == status[0:1]).all()), "replicas disagree: work was skipped or corrupted"
+    if not os.environ.get("FG_ABLATE"):
+        for col, width in (("meta", 4), ("ts", 8), ("hostname", 8), ("appname", 8), ("procid", 8), ("msgid", 8), ("msg", 8),
+                           ("full_msg", 8), ("ent_count", 4)):
+            c = tables.column(col)[: n * width].view(torch.int64 if width == 8 else torch.int32).view(reps, n_tile)
+            assert bool((c == c[0:1]).all()), f"replicas disagree in column {col}: work was skipped or corrupted"
     used = int(tables.column("ent_used").view(torch.int64)[0].item())
     assert used <= ent_cap, "entry table overflow"
 
     if rank == 0:
-        alg_read = tile_bytes * reps + 8 * (n + 1)
-        alg_written = 68 * n + 18 * used
+        # SURVEY 8d's algorithmic bytes: line + one u32 offset read; a 64-byte row (+ 8 + 20 per structured-data pair)
+        # written.  What this layout really moves is a little more (u64 offsets, 68-byte row, 18-byte entries): reported
+        # beside it as `moved_bytes_per_launch`; `achieved` / `frac` use the SURVEY figure.
+        alg_read = tile_bytes * reps + 4 * n
+        alg_written = 64 * n + 20 * used
+        moved = tile_bytes * reps + 8 * (n + 1) + 68 * n + 18 * used
         achieved = (alg_read + alg_written) / (kernel_ms * 1e-3) / 1e9
         out = {
             "metric": "log lines/sec (RFC5424, 256B avg) at 1/2/4/8 MI355X; achieved HBM GB/s",
             "value": n * world * args.steps / elapsed,
             "unit": "lines/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": dist.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
@@ -237,8 +347,12 @@ def main():
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                 "kernel": ("fg::k_rfc5424", "fg::k_ltsv", "fg::k_gelf", "fg::k_rfc3164")[fmt], "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_launch": alg_read + alg_written,
+                "moved_bytes_per_launch": moved, "moved_frac": moved / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                 "read_only_frac": alg_read / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             },
+            "ranks": {"n": len(rank_ms), "kernel_ms": rank_ms, "kernel_ms_min": min(rank_ms), "kernel_ms_max": max(rank_ms),
+                      "launcher": "self (torch.distributed.run)" if os.environ.get("FG_BENCH_SPAWNED") else
+                                  "external (WORLD_SIZE set)" if "WORLD_SIZE" in os.environ else "single process"},
         }
         if wl == "cfg1":
             ems = float(np.mean([a.elapsed_time(b) for a, b in encode_ms[-args.steps:]]))
@@ -252,16 +366,26 @@ def main():
         if frame_ms is not None:
             out["framing"] = {"ms": frame_ms, "GBps": tile_bytes * reps / (frame_ms * 1e-3) / 1e9,
                               "note": "fg_frame_device: scan + prefix + emit kernels incl. the host sync that returns the frame count"}
+        # HBM traffic from the PMC passes (tools/prof.sh -> profiles/traffic.json): only when it was measured on THESE
+        # kernel sources -- a figure from older code is not reported
         tr = ROOT / "profiles" / "traffic.json"
         if tr.exists():
             try:
                 t = json.loads(tr.read_text()).get(args.workload)
-                if t:
+                if t and t.get("src_hash") == source_hash():
                     out["roofline"]["traffic"] = t["hbm_bytes_per_line"] * n
+                    out["roofline"]["traffic_profile"] = t.get("profile")
+                elif t:
+                    out["roofline"]["traffic_note"] = "profiles/traffic.json holds a figure for older kernel sources: not reported"
             except Exception:
                 pass
+        if world == 1 and not args.no_e2e and wl in ("cfg2", "cfg1", "cfg3", "cfg4", "ltsv"):
+            try:
+                out["e2e"] = e2e_legs(dec, fmt, data, offsets, n_tile, tile_bytes, want_transcode=wl in ("cfg2", "cfg1"))
+            except Exception as e:  # the PCIe legs never take the bench line down
+                out["e2e"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
-            cb, n_ok_cpu = cpu_baseline(fmt, data, offsets, n_tile, synth.LTSV_CONFIG if fmt == 1 else None)
+            cb, n_ok_cpu = cpu_baseline(fmt, data, offsets, n_tile, synth.LTSV_CONFIG if fmt == 1 else None, pipeline=wl == "cfg1")
             assert n_ok_cpu == n_ok_tile, f"GPU Ok count {n_ok_tile} != oracle Ok count {n_ok_cpu}"
             out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)

@@ -11,12 +11,13 @@ LIB_PATH = _HERE / "libfg_hip.so"
 FG_RFC5424, FG_LTSV, FG_GELF, FG_RFC3164 = 0, 1, 2, 3
 FG_FRAME_NONE, FG_FRAME_LINE, FG_FRAME_NUL = 0, 1, 2
 FG_ST_OVERFLOW, FG_ST_BAD_UTF8 = 0xFE, 0xFD
-FG_OK, FG_ERR_ARG, FG_ERR_HIP, FG_ERR_NO_DEVICE, FG_ERR_ENT_OVERFLOW, FG_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
+FG_OK, FG_ERR_ARG, FG_ERR_HIP, FG_ERR_NO_DEVICE, FG_ERR_ENT_OVERFLOW, FG_ERR_UNSUPPORTED, FG_ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6
+FG_YEAR_NOW = 0
 FG_NONE = 0xFFFFFFFF
 FG_T_STRING, FG_T_BOOL, FG_T_F64, FG_T_I64, FG_T_U64, FG_T_NULL, FG_T_SDID = range(7)
 FG_TABLE_ARRAYS = 15
 _ERRNAMES = {-1: "FG_ERR_ARG", -2: "FG_ERR_HIP", -3: "FG_ERR_NO_DEVICE (no gfx950 GPU; there is no CPU fallback)",
-             -4: "FG_ERR_ENT_OVERFLOW", -5: "FG_ERR_UNSUPPORTED"}
+             -4: "FG_ERR_ENT_OVERFLOW", -5: "FG_ERR_UNSUPPORTED", -6: "FG_ERR_NOMEM"}
 
 
 class FgError(RuntimeError):
@@ -114,6 +115,11 @@ def lib() -> C.CDLL:
     L.fg_tables_serialize.argtypes = [C.c_int, C.POINTER(fg_cfg), vp, vp, C.POINTER(fg_tables), u64, u64, vp, u64, vp]
     L.fg_tables_serialize.restype = C.c_int64
     L.fg_shard_plan.argtypes = [vp, u64, u32, vp]
+    L.fg_gather_size.argtypes = [C.POINTER(fg_tables), u32, C.POINTER(u64), C.POINTER(u64)]
+    L.fg_gather_tables.argtypes = [C.POINTER(fg_tables), u32, C.POINTER(fg_tables)]
+    L.fg_merge_tables.argtypes = [C.POINTER(fg_tables), u32, C.POINTER(vp), C.POINTER(fg_tables), vp]
+    L.fg_ordered_merge.argtypes = [u32, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp, u64, vp]
+    L.fg_ordered_merge.restype = C.c_int64
     L.fg_set_timing.argtypes = [vp, C.c_int]
     L.fg_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.fg_frame_decode_batch.argtypes = [vp, C.c_int, C.c_int, vp, u64, C.c_int, C.POINTER(fg_tables), C.POINTER(vp),

@@ -22,7 +22,7 @@ ARCH = "gfx950"
 
 HIP_SOURCES = ["fg_rfc5424.hip", "fg_ltsv.hip", "fg_gelf.hip", "fg_frame.hip", "fg_encode.hip", "fg_rfc3164.hip"]
 HIP_HOST_SOURCES = ["fg_capi.cpp"]  # host code that needs the HIP headers / launch syntax
-CXX_SOURCES = ["fg_materialize.cpp"]
+CXX_SOURCES = ["fg_materialize.cpp", "fg_gather.cpp"]
 
 
 def _hipcc() -> str:
@@ -70,6 +70,18 @@ def _depfile_deps(depfile: Path) -> list[Path] | None:
     text = text.replace("\\\n", " ")
     _, _, rhs = text.partition(":")
     return [Path(tok) for tok in rhs.split() if tok.startswith(str(ROOT.parent))]
+
+
+def source_hash() -> str:
+    """sha256 (16 hex digits) over the kernel / C-ABI sources: what a measured figure (profiles/traffic.json) belongs to."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted(CSRC.glob("*")) + [ROOT.parent / "include" / "fg_hip.h"]:
+        if f.suffix in (".hip", ".hpp", ".cpp", ".inc", ".h"):
+            h.update(f.name.encode())
+            h.update(f.read_bytes())
+    return h.hexdigest()[:16]
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:

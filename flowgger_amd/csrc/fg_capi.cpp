@@ -17,6 +17,8 @@
 #include "../../include/fg_hip.h"
 #include "fg_device.hpp"
 #include "fg_enc_cfg.hpp"
+#include <time.h>
+
 #include "fg_rfc3164_parse.hpp"
 #include "fg_tz_index.hpp"
 
@@ -83,7 +85,9 @@ struct fg_ctx {
     uint64_t h_off_cap = 0;
     // RFC3164 configuration: host copies (for fg_clone) + one device block [names | name_off | zone_first | utc_start | utc_off]
     bool r3164_set = false;
+    bool r3164_auto_year = false;  // current_year == FG_YEAR_NOW: follow the wall clock like the reference (:179)
     int32_t r3164_year = 1970;
+    std::vector<uint8_t*> retired_tz;  // zone blocks replaced at a year change (kernels may still read them; freed at destroy)
     std::vector<std::string> tz_names;
     std::vector<uint32_t> tz_first;
     std::vector<int64_t> tz_start;
@@ -333,8 +337,13 @@ int fg_create(int device, const fg_cfg* cfg, fg_ctx** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return FG_ERR_NO_DEVICE;
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return FG_ERR_NO_DEVICE;  // kernels are gfx950-only
+    if (cfg && cfg->n_schema) {
+        if (!cfg->schema_names || !cfg->schema_types) return FG_ERR_ARG;
+        for (uint32_t i = 0; i < cfg->n_schema; ++i)
+            if (!cfg->schema_names[i] || cfg->schema_types[i] > FG_T_U64) return FG_ERR_ARG;
+    }
     fg_ctx* ctx = new (std::nothrow) fg_ctx();
-    if (!ctx) return FG_ERR_ARG;
+    if (!ctx) return FG_ERR_NOMEM;
     ctx->device = device;
     if (cfg) {
         for (uint32_t i = 0; i < cfg->n_schema; ++i) {
@@ -362,11 +371,30 @@ int fg_create(int device, const fg_cfg* cfg, fg_ctx** out) {
 }
 
 static int upload_tz(fg_ctx* ctx);
+static int utc_year_now() {
+    const time_t t = time(nullptr);
+    struct tm g;
+    gmtime_r(&t, &g);
+    return g.tm_year + 1900;
+}
+// OffsetDateTime::now_utc().year() is evaluated per parse by the reference (rfc3164_decoder.rs:179); here once per decode
+// call when the ctx was configured with FG_YEAR_NOW: a long-lived decoder crosses New Year without a restart.
+static int refresh_year(fg_ctx* ctx) {
+    if (!ctx->r3164_auto_year) return FG_OK;
+    const int y = utc_year_now();
+    if (y == ctx->r3164_year) return FG_OK;
+    ctx->r3164_year = y;
+    if (ctx->d_tz) {  // launches already queued on the caller's streams may still read the old block
+        ctx->retired_tz.push_back(ctx->d_tz);
+        ctx->d_tz = nullptr;
+    }
+    return upload_tz(ctx);
+}
 
 int fg_clone(const fg_ctx* src, fg_ctx** out) {
     if (!src || !out) return FG_ERR_ARG;
     fg_ctx* ctx = new (std::nothrow) fg_ctx();
-    if (!ctx) return FG_ERR_ARG;
+    if (!ctx) return FG_ERR_NOMEM;
     ctx->device = src->device;
     ctx->schema_names = src->schema_names;
     ctx->schema_types = src->schema_types;
@@ -385,6 +413,7 @@ int fg_clone(const fg_ctx* src, fg_ctx** out) {
     }
     if (src->r3164_set) {
         ctx->r3164_set = true;
+        ctx->r3164_auto_year = src->r3164_auto_year;
         ctx->r3164_year = src->r3164_year;
         ctx->tz_names = src->tz_names;
         ctx->tz_first = src->tz_first;
@@ -414,6 +443,7 @@ void fg_destroy(fg_ctx* ctx) {
     if (ctx->d_bad) (void)hipFree(ctx->d_bad);
     if (ctx->d_enc) (void)hipFree(ctx->d_enc);
     if (ctx->d_tz) (void)hipFree(ctx->d_tz);
+    for (uint8_t* p : ctx->retired_tz) (void)hipFree(p);
     if (ctx->h_off) (void)hipHostFree(ctx->h_off);
     if (ctx->h_tab) (void)hipHostFree(ctx->h_tab);
     if (ctx->d_tout) (void)hipFree(ctx->d_tout);
@@ -490,19 +520,21 @@ int fg_frame_device(fg_ctx* ctx, fg_framing framing, const uint8_t* d_bytes, uin
 
 static int decode_frames_impl(fg_ctx* ctx, fg_format fmt, fg_framing framing, const uint8_t* d_bytes, uint64_t nbytes,
                               const uint64_t* d_offsets, uint64_t n, const uint8_t* d_bad_utf8, const fg_tables* tables,
-                              void* stream, bool reset_counter);
+                              void* stream, bool reset_counter, uint64_t span_bytes);
 
 int fg_decode_frames_device(fg_ctx* ctx, fg_format fmt, fg_framing framing, const uint8_t* d_bytes, uint64_t nbytes,
                             const uint64_t* d_offsets, uint64_t n, const uint8_t* d_bad_utf8, const fg_tables* tables,
                             void* stream) {
-    return decode_frames_impl(ctx, fmt, framing, d_bytes, nbytes, d_offsets, n, d_bad_utf8, tables, stream, true);
+    return decode_frames_impl(ctx, fmt, framing, d_bytes, nbytes, d_offsets, n, d_bad_utf8, tables, stream, true, nbytes);
 }
 
 // reset_counter = false: a further slice of a batch whose entry counter is already live (the
-// pipelined host path decodes one batch as several slices on two streams)
+// pipelined host path decodes one batch as several slices on two streams).  span_bytes = the bytes
+// the n lines cover (the launch geometry is planned from the average line length; nbytes is only
+// the readable range of d_bytes and, for a slice, covers the whole batch).
 static int decode_frames_impl(fg_ctx* ctx, fg_format fmt, fg_framing framing, const uint8_t* d_bytes, uint64_t nbytes,
                               const uint64_t* d_offsets, uint64_t n, const uint8_t* d_bad_utf8, const fg_tables* tables,
-                              void* stream, bool reset_counter) {
+                              void* stream, bool reset_counter, uint64_t span_bytes) {
     if ((int)framing < 0 || (int)framing > 2) return FG_ERR_ARG;
     if (!ctx || !tables || (n && (!d_offsets || !tables->meta))) return FG_ERR_ARG;
     if (nbytes && !d_bytes) return FG_ERR_ARG;
@@ -523,22 +555,24 @@ static int decode_frames_impl(fg_ctx* ctx, fg_format fmt, fg_framing framing, co
     }
     if (ctx->timing) FG_HIP(ctx, hipEventRecord(ctx->ev0, s));
     int rc;
+    const uint64_t avg_len = (span_bytes + n - 1) / n;
     switch (fmt) {
         case FG_RFC5424:
-            rc = fg_launch_rfc5424(d_bytes, d_offsets, n, &dt, (nbytes + n - 1) / n, s, ctx->d_stash, ctx->stash_blocks, (uint32_t)framing,
+            rc = fg_launch_rfc5424(d_bytes, d_offsets, n, &dt, avg_len, s, ctx->d_stash, ctx->stash_blocks, (uint32_t)framing,
                                    d_bad_utf8);
             break;
         case FG_LTSV:
-            rc = fg_launch_ltsv(d_bytes, d_offsets, n, &dt, &ctx->ltsv, (nbytes + n - 1) / n, s, ctx->d_stash, ctx->stash_blocks,
+            rc = fg_launch_ltsv(d_bytes, d_offsets, n, &dt, &ctx->ltsv, avg_len, s, ctx->d_stash, ctx->stash_blocks,
                                 (uint32_t)framing, d_bad_utf8);
             break;
         case FG_GELF:
-            rc = fg_launch_gelf(d_bytes, d_offsets, n, &dt, (nbytes + n - 1) / n, s, ctx->d_stash, ctx->stash_blocks,
+            rc = fg_launch_gelf(d_bytes, d_offsets, n, &dt, avg_len, s, ctx->d_stash, ctx->stash_blocks,
                                 (uint32_t)framing, d_bad_utf8);
             break;
         case FG_RFC3164:
             if (!ctx->r3164_set) return FG_ERR_ARG;  // fg_set_rfc3164 first
-            rc = fg_launch_rfc3164(d_bytes, d_offsets, n, &dt, &ctx->r3164, pick_tile_cap(nbytes, n, 56 * 1024), s, (uint32_t)framing,
+            if ((rc = refresh_year(ctx)) != FG_OK) return rc;
+            rc = fg_launch_rfc3164(d_bytes, d_offsets, n, &dt, &ctx->r3164, pick_tile_cap(span_bytes, n, 56 * 1024), s, (uint32_t)framing,
                                    d_bad_utf8);
             break;
         default:
@@ -630,8 +664,12 @@ int fg_decode_batch(fg_ctx* ctx, fg_format fmt, const uint8_t* bytes, uint64_t n
             sl.ent_first += l0;
             sl.ent_count += l0;
             rc = decode_frames_impl(ctx, fmt, FG_FRAME_NONE, ctx->d_bytes, nbytes, ctx->d_offsets + l0, l1 - l0, nullptr, &sl,
-                                    (void*)s, false);
-            if (rc != FG_OK) return rc;
+                                    (void*)s, false, offsets[l1] - offsets[l0]);
+            if (rc != FG_OK) {  // copies of earlier slices may still be in flight into h_tab / d_tab: drain both lanes
+                (void)hipStreamSynchronize(lanes[0]);
+                (void)hipStreamSynchronize(lanes[1]);
+                return rc;
+            }
             const uint64_t rows = l1 - l0;
             FG_HIP(ctx, hipMemcpyAsync(ht.meta + l0, dt.meta + l0, rows * 4, hipMemcpyDeviceToHost, s));
             FG_HIP(ctx, hipMemcpyAsync(ht.ts + l0, dt.ts + l0, rows * 8, hipMemcpyDeviceToHost, s));
@@ -997,7 +1035,8 @@ static int upload_tz(fg_ctx* ctx) {
 
 int fg_set_rfc3164(fg_ctx* ctx, const fg_rfc3164_cfg* cfg) {
     if (!ctx || !cfg) return FG_ERR_ARG;
-    ctx->r3164_year = cfg->current_year;
+    ctx->r3164_auto_year = cfg->current_year == FG_YEAR_NOW;
+    ctx->r3164_year = ctx->r3164_auto_year ? utc_year_now() : cfg->current_year;
     ctx->tz_names.clear();
     ctx->tz_first.clear();
     ctx->tz_start.clear();

@@ -216,19 +216,18 @@ class GelfDecoder(Decoder):
 
 class RFC3164Decoder(Decoder):
     """src/flowgger/decoder/rfc3164_decoder.rs:10-213.  The reference's config is ignored (:13-15); two things it takes
-    from its environment are explicit here: ``current_year`` (it reads the clock, :179; default: this machine's UTC
-    year at construction) and the IANA zone table behind ``time_tz::timezones::get_by_name`` (:195; default: every zone
+    from its environment are explicit here: ``current_year`` (it reads the clock per parse, :179; default
+    FG_YEAR_NOW: the library re-reads the UTC year at every decode call, so a long-lived decoder and its clones cross
+    New Year like the reference; a fixed year is for tests / replays) and the IANA zone table behind ``time_tz::timezones::get_by_name`` (:195; default: every zone
     of the system tz database, flowgger_amd/tzdb.py).  {"rfc3164": {"current_year": 2020, "zones": [...] | None}}."""
     fmt = L.FG_RFC3164
 
     def __init__(self, config: Optional[dict] = None, device: int = 0):
         super().__init__(config, device)
-        import time as _time
-
         from . import tzdb
 
         opt = (config or {}).get("rfc3164", {})
-        self.current_year = int(opt.get("current_year", _time.gmtime().tm_year))
+        self.current_year = int(opt.get("current_year", L.FG_YEAR_NOW))
         zones = opt.get("zones", "all")
         self.tz_table = tzdb.default_table() if zones == "all" else (tzdb.build_table(zones) if zones else None)
         self._apply()

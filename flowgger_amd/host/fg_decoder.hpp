@@ -308,25 +308,53 @@ class BatchingSplitter {
         std::string line;
         if (f_ == Syslen) {
             for (;;) {  // syslen_splitter.rs:42-57: "<len> " then exactly len bytes
+                // read_msglen: read_until(b' ') -- at EOF without a space the reference still drops the LAST byte it
+                // read (it assumes the delimiter), parses the rest and then fails in read_exact (:27-30)
                 std::string num;
                 int c;
                 while ((c = in.get()) != EOF && c != ' ') num.push_back((char)c);
-                if (c == EOF || num.empty()) { flush(decoder, sink, err); err << "Can't read message's length\n"; break; }  // :20-25
+                const bool at_eof = c == EOF;
+                const size_t got = num.size() + (at_eof ? 0 : 1);  // bytes read_until returned
+                if (got <= 1) { flush(decoder, sink, err); err << "Can't read message's length\n"; break; }  // :45-46, :20-25
+                if (at_eof) num.pop_back();
                 size_t len = 0;
-                bool ok = true;
-                size_t k = num[0] == '+' ? 1 : 0;
+                bool ok = !num.empty();
+                size_t k = (!num.empty() && num[0] == '+') ? 1 : 0;  // usize::from_str accepts a leading '+'
                 if (k >= num.size()) ok = false;
-                for (; k < num.size() && ok; ++k) { if (num[k] < '0' || num[k] > '9') ok = false; else len = len * 10 + (num[k] - '0'); }
+                for (; k < num.size() && ok; ++k) {
+                    if (num[k] < '0' || num[k] > '9' || len > (SIZE_MAX - 9) / 10) ok = false;
+                    else len = len * 10 + (size_t)(num[k] - '0');
+                }
                 if (!ok) { flush(decoder, sink, err); err << "Can't read message's length\n"; break; }
-                line.resize(len);
-                in.read(&line[0], (std::streamsize)len);
-                if ((size_t)in.gcount() != len) break;
+                line.resize(at_eof ? 0 : len);
+                if (!at_eof) in.read(&line[0], (std::streamsize)len);
+                if (at_eof ? len != 0 : (size_t)in.gcount() != len) {  // read_exact's UnexpectedEof, printed with `{}` (:27-30)
+                    flush(decoder, sink, err);
+                    err << "failed to fill whole buffer\n";
+                    break;
+                }
+                if (at_eof) {  // "0?" + EOF: an empty message is handled, then the next read_msglen sees Ok(0)
+                    push(line, decoder, sink, err);
+                    flush(decoder, sink, err);
+                    err << "Can't read message's length\n";
+                    break;
+                }
+                if (!detail::valid_utf8((const uint8_t*)line.data(), line.size())) {
+                    // String::from_utf8(buffer).unwrap() (:32): the reference PANICS here, i.e. this connection's thread
+                    // ends; mirrored as: everything before it is delivered, the panic text goes to `err`, run() returns
+                    flush(decoder, sink, err);
+                    err << "thread panicked: called `Result::unwrap()` on an `Err` value: FromUtf8Error (syslen_splitter.rs:32)\n";
+                    return;
+                }
                 push(line, decoder, sink, err);
             }
         } else {
             const char delim = f_ == Line ? '\n' : '\0';
             while (std::getline(in, line, delim)) {
-                if (f_ == Line && !line.empty() && line.back() == '\r') line.pop_back();  // BufRead::lines()
+                // BufRead::lines() drops a '\r' only together with the '\n' it precedes: an unterminated last line
+                // keeps its trailing '\r' (getline sets eofbit when it ran into EOF instead of the delimiter)
+                const bool terminated = !in.eof();
+                if (f_ == Line && terminated && !line.empty() && line.back() == '\r') line.pop_back();
                 push(line, decoder, sink, err);
             }
         }

@@ -14,8 +14,10 @@ from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
 
+import ctypes as C
+
 from . import _lib as L
-from .tables import HostTables, _DT
+from .tables import HostTables, _DT, layout
 
 
 def shard_plan(offsets: np.ndarray, g: int) -> np.ndarray:
@@ -33,32 +35,47 @@ def shard_slice(data: np.ndarray, offsets: np.ndarray, starts: np.ndarray, k: in
     return data[lo:hi], (offsets[a:b + 1] - np.uint64(lo)).astype(np.uint64)
 
 
-def concat_tables(parts: Sequence[HostTables]) -> HostTables:
-    """Concatenate per-shard tables in shard order; entry indices are rebased, spans are
-    line-relative and need no change."""
-    n = sum(p.n for p in parts)
+def _alloc_tables(n: int, ent: int) -> HostTables:
+    """Host tables with room for n rows / ent entries (numpy; every array at least one element)."""
+    offs, _ = layout(n, ent)
     arrays = {}
-    for name in L.TABLE_FIELDS:
-        if name in ("ent_first", "ent_used"):
-            continue
-        if name.startswith("ent_") and name != "ent_count":
-            chunks = [p.a[name][: p.ent_used * (2 if name == "ent_name" else 1)] for p in parts]
-        elif name in ("meta", "ts", "ent_count"):
-            chunks = [p.a[name][: p.n] for p in parts]
-        else:  # span columns: 2 uint32 per row
-            chunks = [p.a[name][: 2 * p.n] for p in parts]
-        arrays[name] = np.concatenate(chunks) if chunks else np.zeros(0, _DT[name])
-        if arrays[name].size == 0:
-            arrays[name] = np.zeros(1, _DT[name])
-    base, firsts = 0, []
-    for p in parts:
-        firsts.append(p.a["ent_first"][: p.n].astype(np.uint64) + np.uint64(base))
-        base += p.ent_used
-    arrays["ent_first"] = (np.concatenate(firsts) if firsts else np.zeros(1, np.uint64)).astype(np.uint32)
-    if arrays["ent_first"].size == 0:
-        arrays["ent_first"] = np.zeros(1, np.uint32)
-    arrays["ent_used"] = np.array([base], np.uint64)
-    return HostTables(n, base, arrays)
+    for name, (_, size) in zip(L.TABLE_FIELDS, offs):
+        dt = np.dtype(_DT[name])
+        arrays[name] = np.zeros(max(size // dt.itemsize, 1), dt)
+    return HostTables(n, ent, arrays)
+
+
+def _part_array(parts: Sequence[HostTables]):
+    arr = (L.fg_tables * max(len(parts), 1))()
+    for k, p in enumerate(parts):
+        C.memmove(C.byref(arr[k]), C.byref(p.struct), C.sizeof(L.fg_tables))
+        arr[k].ent_cap = max(int(p.ent_cap), p.ent_used)
+    return arr
+
+
+def concat_tables(parts: Sequence[HostTables]) -> HostTables:
+    """The ordered host gather: fg_gather_tables (C ABI) concatenates per-shard tables in shard order; entry indices
+    are rebased, spans are line-relative and need no change."""
+    arr = _part_array(parts)
+    n, e = C.c_uint64(), C.c_uint64()
+    L.check(L.lib().fg_gather_size(arr, len(parts), C.byref(n), C.byref(e)), "fg_gather_size")
+    out = _alloc_tables(int(n.value), int(e.value))
+    L.check(L.lib().fg_gather_tables(arr, len(parts), C.byref(out.struct)), "fg_gather_tables")
+    return out
+
+
+def merge_tables(parts: Sequence[HostTables], index: Sequence[np.ndarray]) -> Tuple[HostTables, np.ndarray]:
+    """Config 5 on tables: sub-batches split off by format go back to their original line positions (fg_merge_tables).
+    index[k][j] = original position of row j of parts[k].  Returns (tables, src_part uint8[n])."""
+    arr = _part_array(parts)
+    n, e = C.c_uint64(), C.c_uint64()
+    L.check(L.lib().fg_gather_size(arr, len(parts), C.byref(n), C.byref(e)), "fg_gather_size")
+    out = _alloc_tables(int(n.value), int(e.value))
+    ix = [np.ascontiguousarray(i, np.uint64) for i in index]
+    ptrs = (C.c_void_p * max(len(ix), 1))(*[a.ctypes.data for a in ix])
+    src = np.zeros(max(int(n.value), 1), np.uint8)
+    L.check(L.lib().fg_merge_tables(arr, len(parts), ptrs, C.byref(out.struct), src.ctypes.data), "fg_merge_tables")
+    return out, src[: int(n.value)]
 
 
 def decode_sharded(decode: Callable[[np.ndarray, np.ndarray, int], HostTables], data: np.ndarray,
@@ -69,36 +86,82 @@ def decode_sharded(decode: Callable[[np.ndarray, np.ndarray, int], HostTables], 
     return concat_tables([decode(*shard_slice(data, offsets, starts, k), k) for k in range(g)])
 
 
+def _pack(t: HostTables) -> np.ndarray:
+    """One contiguous byte buffer per shard for the wire: the table arrays in TABLE_FIELDS order, entry columns cut at
+    ent_used."""
+    used = t.ent_used
+    offs, total = layout(t.n, used)
+    buf = np.zeros(total, np.uint8)
+    for name, (off, size) in zip(L.TABLE_FIELDS, offs):
+        if size:
+            buf[off:off + size] = t.a[name].view(np.uint8)[:size]
+    return buf
+
+
+def _unpack(buf: np.ndarray, n: int, used: int) -> HostTables:
+    offs, _ = layout(n, used)
+    arrays = {}
+    for name, (off, size) in zip(L.TABLE_FIELDS, offs):
+        dt = np.dtype(_DT[name])
+        arrays[name] = buf[off:off + size].view(dt) if size else np.zeros(1, dt)
+    return HostTables(n, used, arrays)
+
+
 def decode_distributed(decode: Callable[[np.ndarray, np.ndarray], HostTables], data: np.ndarray, offsets: np.ndarray,
                        dst: int = 0, group=None) -> Optional[HostTables]:
     """One process per GPU (torch.distributed): every rank decodes its byte-balanced slice of the
-    SAME packed batch; tables are gathered to `dst` in rank order.  Returns the full table on dst,
-    None elsewhere.  Backend-agnostic (gloo on CPU tests, nccl = RCCL on GPUs)."""
+    SAME packed batch; the tables travel to `dst` as ONE byte tensor per rank (sizes first, then
+    point-to-point sends -- no pickling, no collective on the data path) and are put in rank order
+    by fg_gather_tables.  Returns the full table on dst, None elsewhere.  Backend-agnostic
+    (gloo on CPU tests; with nccl = RCCL the byte tensors are staged through the rank's GPU)."""
+    import torch
     import torch.distributed as dist
 
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     starts = shard_plan(offsets, world)
     mine = decode(*shard_slice(data, offsets, starts, rank))
-    payload = {"n": mine.n, "used": mine.ent_used, "a": mine.a}
-    gathered: Optional[List] = [None] * world if rank == dst else None
-    dist.gather_object(payload, gathered, dst=dst, group=group)
+    on_gpu = dist.get_backend(group) == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+    wire = torch.from_numpy(_pack(mine))
+    dims = torch.tensor([mine.n, mine.ent_used, wire.numel()], dtype=torch.int64, device=dev)
+    all_dims = [torch.zeros(3, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(all_dims, dims, group=group)
     if rank != dst:
+        dist.send(wire.to(dev), dst=dst, group=group)
         return None
-    return concat_tables([HostTables(p["n"], p["used"], p["a"]) for p in gathered])
+    parts = []
+    for r in range(world):
+        n_r, used_r, bytes_r = (int(x) for x in all_dims[r].tolist())
+        if r == rank:
+            parts.append(mine)
+            continue
+        buf = torch.empty(bytes_r, dtype=torch.uint8, device=dev)
+        dist.recv(buf, src=r, group=group)
+        parts.append(_unpack(buf.cpu().numpy(), n_r, used_r))
+    return concat_tables(parts)
 
 
 def ordered_merge(parts: Sequence[Tuple[np.ndarray, np.ndarray, np.ndarray]]) -> Tuple[np.ndarray, np.ndarray]:
-    """Config 5's ordered gather: parts = [(orig_index[int64 m], blob uint8, offs uint64[m+1])] per
-    format sub-batch (canonical Record blobs); returns (blob, offs) in original line order."""
-    n = sum(len(ix) for ix, _, _ in parts)
-    sizes = np.zeros(n, np.int64)
-    for ix, _, offs in parts:
-        sizes[ix] = np.diff(offs.astype(np.int64))
+    """Config 5's ordered gather for byte records: parts = [(orig_index[int64 m], blob uint8, offs uint64[m+1])] per
+    format sub-batch (canonical Record blobs or encoded messages); returns (blob, offs) in original line order
+    (fg_ordered_merge: runs of neighbouring lines move as one copy)."""
+    g = len(parts)
+    ix = [np.ascontiguousarray(p[0], np.uint64) for p in parts]
+    blobs = [np.ascontiguousarray(p[1], np.uint8) for p in parts]
+    offs = [np.ascontiguousarray(p[2], np.uint64) for p in parts]
+    m = np.array([len(i) for i in ix], np.uint64)
+    n = int(m.sum())
+    vp = C.c_void_p
+    pix = (vp * max(g, 1))(*[a.ctypes.data for a in ix])
+    pbl = (vp * max(g, 1))(*[a.ctypes.data for a in blobs])
+    pof = (vp * max(g, 1))(*[a.ctypes.data for a in offs])
     out_offs = np.zeros(n + 1, np.uint64)
-    out_offs[1:] = np.cumsum(sizes)
-    out = np.zeros(int(out_offs[-1]), np.uint8)
-    for ix, blob, offs in parts:
-        o = offs.astype(np.int64)
-        for j, i in enumerate(ix):  # per-line copy; sub-batches are already in relative order
-            out[int(out_offs[i]):int(out_offs[i + 1])] = blob[o[j]:o[j + 1]]
-    return out, out_offs
+    lib = L.lib()
+    total = lib.fg_ordered_merge(g, m.ctypes.data, pix, pbl, pof, None, 0, out_offs.ctypes.data)
+    if total < 0:
+        raise L.FgError(int(total), "fg_ordered_merge")
+    out = np.zeros(max(int(total), 1), np.uint8)
+    total = lib.fg_ordered_merge(g, m.ctypes.data, pix, pbl, pof, out.ctypes.data, int(total), out_offs.ctypes.data)
+    if total < 0:
+        raise L.FgError(int(total), "fg_ordered_merge")
+    return out[: int(total)], out_offs

@@ -42,7 +42,8 @@ enum {
     FG_ERR_HIP = -2,       /* a HIP runtime call failed (fg_last_hip_error has the code) */
     FG_ERR_NO_DEVICE = -3, /* no gfx950 device / kernels not loadable: there is NO CPU fallback */
     FG_ERR_ENT_OVERFLOW = -4, /* entry table too small; tables are valid except status==FG_ST_OVERFLOW rows */
-    FG_ERR_UNSUPPORTED = -5
+    FG_ERR_UNSUPPORTED = -5,
+    FG_ERR_NOMEM = -6      /* host allocation failed */
 };
 
 /* SDValue discriminants (record.rs:3-11) + the SD-element marker used in the entry table */
@@ -137,7 +138,9 @@ typedef struct fg_cfg {
 } fg_cfg;
 
 /* RFC3164Decoder configuration.  The reference takes two things from its environment that are configuration here:
- *   current_year  OffsetDateTime::now_utc().year() prepended to dates without a year (rfc3164_decoder.rs:179)
+ *   current_year  OffsetDateTime::now_utc().year() prepended to dates without a year (rfc3164_decoder.rs:179): a fixed
+ *                 year (tests, replays), or FG_YEAR_NOW = what the reference does -- the library re-reads the UTC year
+ *                 at every FG_RFC3164 decode call, so a long-lived decoder (and its clones) crosses New Year correctly
  *   tz            the IANA zone table behind time_tz::timezones::get_by_name (rfc3164_decoder.rs:195; the time-tz
  *                 crate embeds the tz database at build time): n_zones names SORTED BYTEWISE (exact match), zone i
  *                 owns entries [zone_first[i], zone_first[i+1]) of (utc_start, utc_offset): utc_offset[k] seconds east
@@ -150,6 +153,7 @@ typedef struct fg_tz_table {
     const int64_t* utc_start;
     const int32_t* utc_offset;
 } fg_tz_table;
+#define FG_YEAR_NOW 0 /* current_year: follow the wall clock (UTC year re-read at every FG_RFC3164 decode call) */
 typedef struct fg_rfc3164_cfg {
     int32_t current_year;
     const fg_tz_table* tz;
@@ -343,6 +347,28 @@ int64_t fg_tables_serialize(fg_format fmt, const fg_cfg* cfg, const uint8_t* byt
 /* Multi-GPU sharding plan (host): split n lines into g contiguous ranges balanced by BYTES;
  * line_starts receives g+1 line indices (line_starts[0] = 0, line_starts[g] = n). */
 int fg_shard_plan(const uint64_t* offsets, uint64_t n, uint32_t g, uint64_t* line_starts);
+
+/* ORDERED HOST GATHER of the multi-GPU path (order contract: handle_line runs in input order per
+ * connection, src/flowgger/splitter/line_splitter.rs:17-54).  Every pointer is HOST memory (pinned or pageable);
+ * plain memory moves threaded over row ranges, no GPU involved.
+ *   fg_gather_size    sum of rows / used entries over the g parts (the capacity `out` needs)
+ *   fg_gather_tables  parts = the tables of the g shards of ONE batch, in shard order (fg_shard_plan): `out` receives
+ *                     their concatenation; ent_first is rebased onto the concatenated entry table, spans are
+ *                     line-relative and are copied as they are.  out->n >= rows, out->ent_cap >= entries.
+ *   fg_merge_tables   parts = sub-batches split off by FORMAT (BASELINE configuration 5: the reference has one decoder
+ *                     per input, flowgger/mod.rs:413-422, so a mixed stream is decoded as tagged sub-batches);
+ *                     index[k][j] = original position of row j of part k (strictly increasing inside a part, every
+ *                     position 0..rows-1 exactly once): rows go back to their original positions;
+ *                     src_part[i] (may be NULL) receives the part a row came from (= which decoder's error strings /
+ *                     materialisation rules apply to it)
+ *   fg_ordered_merge  the same for variable-size byte records (canonical Records, encoded messages): part k holds
+ *                     m[k] records, record j = blobs[k][offs[k][j] .. offs[k][j+1]); out_offs receives rows+1 offsets;
+ *                     returns the total bytes (call with out == NULL to size), negative FG_ERR_* on bad arguments */
+int fg_gather_size(const fg_tables* parts, uint32_t g, uint64_t* n_rows, uint64_t* n_entries);
+int fg_gather_tables(const fg_tables* parts, uint32_t g, fg_tables* out);
+int fg_merge_tables(const fg_tables* parts, uint32_t g, const uint64_t* const* index, fg_tables* out, uint8_t* src_part);
+int64_t fg_ordered_merge(uint32_t g, const uint64_t* m, const uint64_t* const* index, const uint8_t* const* blobs,
+                         const uint64_t* const* offs, uint8_t* out, uint64_t cap, uint64_t* out_offs);
 
 /* Duration in milliseconds of the most recent decode kernel launch(es) of this ctx measured
  * with HIP events on the launch stream (0 when timing is disabled). fg_set_timing(ctx, 1)

@@ -2100,6 +2100,42 @@ int64_t fgo_decode_encode_batch(int fmt, const fgo_ltsv_cfg* cfg, int enc, int m
     if (out_offsets) out_offsets[n] = total;
     return (int64_t)total;
 }
+// SURVEY 8d, configuration 1: decode + encode + merger + a null sink (the bytes are summed, not kept), threaded like
+// fgo_bench_decode.  Returns seconds; *out_bytes = encoded bytes produced, *n_ok = lines that reached the sink.
+double fgo_bench_pipeline(int fmt, const fgo_ltsv_cfg* cfg, int enc, int merger, const fgo_enc_opts* opts, const uint8_t* bytes,
+                          const uint64_t* offsets, uint64_t n, int threads, uint64_t* out_bytes, uint64_t* n_ok) {
+    if (fmt < 0 || fmt > 3) return -1.0;
+    LtsvCfg c = make_cfg(cfg);
+    EncOpts o = make_opts(opts);
+    if (threads <= 0) threads = 1;
+    std::vector<uint64_t> sums(threads, 0), oks(threads, 0), sink(threads, 0);
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; ++t) {
+        th.emplace_back([&, t]() {
+            uint64_t lo = n * t / threads, hi = n * (t + 1) / threads, total = 0, ok = 0, acc = 0;
+            std::string j;
+            for (uint64_t i = lo; i < hi; ++i) {
+                Result r = decode_any(fmt, c, sv((const char*)bytes + offsets[i], offsets[i + 1] - offsets[i]));
+                if (r.err) continue;
+                if (encode_any(enc, merger, std::move(r.rec), o, &j)) continue;
+                total += j.size();
+                acc += j.empty() ? 0u : (uint8_t)j[0] + (uint8_t)j[j.size() - 1];  // the null sink looks at the message
+                ++ok;
+            }
+            sums[t] = total;
+            oks[t] = ok;
+            sink[t] = acc;
+        });
+    }
+    for (auto& x : th) x.join();
+    double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    uint64_t s = 0, ok = 0;
+    for (int t = 0; t < threads; ++t) { s += sums[t]; ok += oks[t]; }
+    if (out_bytes) *out_bytes = s;
+    if (n_ok) *n_ok = ok;
+    return secs;
+}
 int fgo_rust_display_f64(double v, char* out, int cap) {
     std::string s = rust_display_f64(v);
     if ((int)s.size() + 1 > cap) return -1;

@@ -98,6 +98,10 @@ int64_t fgo_encode(int enc, int merger, const uint8_t* canonical, uint64_t len, 
 int64_t fgo_decode_encode_batch(int fmt, const fgo_ltsv_cfg* cfg, int enc, int merger, const uint8_t* bytes,
                                 const uint64_t* offsets, uint64_t n, const fgo_enc_opts* opts, uint8_t* out,
                                 uint64_t cap, uint64_t* out_offsets, uint8_t* status);
+/* decode + encode + merger + null sink, threaded (SURVEY 8d configuration 1); returns seconds */
+double fgo_bench_pipeline(int fmt, const fgo_ltsv_cfg* cfg, int enc, int merger, const fgo_enc_opts* opts,
+                          const uint8_t* bytes, const uint64_t* offsets, uint64_t n, int threads,
+                          uint64_t* out_bytes, uint64_t* n_ok);
 int fgo_rust_display_f64(double v, char* out, int cap); /* Rust `{}` of an f64 */
 
 /* RFC3164 decoder (rfc3164_decoder.rs:31-213) configuration, process-wide: the current year (the reference reads the

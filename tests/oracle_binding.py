@@ -209,6 +209,18 @@ class Oracle:
                                          C.byref(chk), C.byref(nok))
         return secs, nok.value
 
+    def bench_pipeline(self, fmt: int, enc: int, merger: int, data: np.ndarray, offsets: np.ndarray, threads: int, config=None):
+        """decode -> encode -> merger -> null sink, threaded; -> (seconds, lines that reached the sink, encoded bytes)"""
+        cfg, keep = self.make_cfg(config)
+        cfgp = C.byref(cfg) if cfg is not None else None
+        o, keep2 = self._opts(None, None, 0.0)
+        nb, nok = C.c_uint64(), C.c_uint64()
+        self.lib.fgo_bench_pipeline.restype = C.c_double
+        secs = self.lib.fgo_bench_pipeline(C.c_int(fmt), cfgp, C.c_int(enc), C.c_int(merger), C.byref(o), C.c_void_p(data.ctypes.data),
+                                           C.c_void_p(offsets.ctypes.data), C.c_uint64(len(offsets) - 1), C.c_int(threads),
+                                           C.byref(nb), C.byref(nok))
+        return secs, nok.value, nb.value
+
     def rfc3339(self, s: str):
         out = C.c_double()
         b = s.encode()

@@ -36,4 +36,11 @@ if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
     # r01b, so it is taken as is.
     out["hbm_bytes_per_dispatch"] = {"read": 2 * pm["FETCH_SIZE"] * 1024, "written": pm["WRITE_SIZE"] * 1024,
                                      "total": 2 * pm["FETCH_SIZE"] * 1024 + pm["WRITE_SIZE"] * 1024}
+try:  # which kernel sources these numbers belong to (bench.py reports a traffic figure only for matching sources)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from flowgger_amd.build import source_hash
+
+    out["src_hash"] = source_hash()
+except Exception as e:  # pragma: no cover
+    out["src_hash"] = None
 print(json.dumps(out, indent=1))
