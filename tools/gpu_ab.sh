@@ -5,7 +5,7 @@ OUT=${1:-gpurun_out/ab.log}; shift
 while read -r envs; do
   [ -z "$envs" ] && continue
   echo "## $envs" >> $OUT
-  env $envs python bench.py --steps 10 --warmup 2 --reps 40 --no-cpu-baseline $BENCH_ARGS 2> gpurun_out/ab_stderr.tmp | tail -1 | python -c "
+  env $envs python bench.py --steps 10 --warmup 2 --reps 40 --no-cpu-baseline --no-e2e $BENCH_ARGS 2> gpurun_out/ab_stderr.tmp | tail -1 | python -c "
 import sys,json
 for l in sys.stdin:
     try:

@@ -6,7 +6,7 @@ ROOT=$(pwd)
 OUT=/tmp/traffic_$TAG
 rm -rf $OUT; mkdir -p $OUT $ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline $@"
+BENCH="python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e $@"
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/pmc3 -o pmc3 -- $BENCH > $OUT/pmc3.log 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/pmc4 -o pmc4 -- $BENCH > $OUT/pmc4.log 2>&1
 cd $ROOT
