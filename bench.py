@@ -315,8 +315,10 @@ def main():
                            ("full_msg", 8), ("ent_count", 4)):
             c = tables.column(col)[: n * width].view(torch.int64 if width == 8 else torch.int32).view(reps, n_tile)
             assert bool((c == c[0:1]).all()), f"replicas disagree in column {col}: work was skipped or corrupted"
-    used = int(tables.column("ent_used").view(torch.int64)[0].item())
-    assert used <= ent_cap, "entry table overflow"
+    reserved = int(tables.column("ent_used").view(torch.int64)[0].item())
+    assert reserved <= ent_cap, "entry table overflow"
+    # entries written (slots are reserved in per-wave chunks; `reserved` is a little more than what the lines own)
+    used = int(tables.column("ent_count")[: n * 4].view(torch.int32).to(torch.int64).sum().item())
 
     if rank == 0:
         # SURVEY 8d's algorithmic bytes: line + one u32 offset read; a 64-byte row (+ 8 + 20 per structured-data pair)

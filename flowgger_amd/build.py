@@ -91,6 +91,9 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     headers = list(CSRC.glob("*.hpp")) + [ROOT.parent / "include" / "fg_hip.h", Path(__file__)]
     common = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-fast-math",
               "-ffp-contract=off", f"-I{ROOT.parent / 'include'}"]
+    # (fg_wave.hpp's host branch includes the fiber emulation from tests/native; the device branch never does, but the
+    #  host pass of hipcc still has to find the header)
+    common.append(f"-I{ROOT.parent / 'tests' / 'native'}")
     # (source, object, extra defines); fg_encode.hip is compiled once per (encoder, pass) -- its emitters are large
     # force-inlined templates (one object took 18 minutes) -- plus once for the dispatcher
     units: list[tuple[str, Path, list[str]]] = []

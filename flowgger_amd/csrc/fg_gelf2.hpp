@@ -1,0 +1,818 @@
+// fg_gelf2.hpp -- wave-cooperative tokeniser for GelfDecoder::decode
+// (reference: src/flowgger/decoder/gelf_decoder.rs:34-125; JSON semantics = serde_json 0.8).
+//
+// The round-1 kernel gave every lane a LINE: a group cost max-over-lanes of the member count, the lanes diverged on the
+// value kinds, and every member was a chain of dependent LDS round trips in ONE lane.  Here the work item is smaller than
+// a line and the structural scan is byte-parallel, as the north_star describes (ballot / prefix-sum delimiter scans):
+//
+//   stage A   (pipeline, byte-parallel) five class bitmaps of the tile, one bit per byte:  '"' | '\' | {}[], | != ' ' | < 0x20
+//   word pass (lane = 64 tile bytes)    escaped characters from the backslash runs, REAL quotes, the in-string mask as a
+//                                       prefix-XOR of the real quotes carried across the wave (popcount parity + ballot), reset
+//                                       at every line start; structural characters OUTSIDE strings -> the ITEM bitmap; a wave
+//                                       prefix sum numbers the items
+//   blocks    (lane = one item)         whole lines are packed into blocks of at most 64 items; an item is a '{' or ',' (it owns the
+//                                       member that follows) or the closing '}'.  The lane delimits  ws "key" ws : ws value ws  with
+//                                       bit scans of 64-bit bitmap windows held in registers, checks every byte outside the tokens,
+//                                       parses numbers (serde_json 0.8 algorithm) and literals -- 13 members of 64 lines are 13 full
+//                                       iterations of 64 lanes, whatever the members per line.  BTreeMap order: rank = members of the
+//                                       same line with a smaller key (7-byte prefix + index, 512 bytes of LDS per block); duplicates:
+//                                       the last one wins; gelf_decoder.rs:51-106 is dispatched per member, the FIRST error in sorted
+//                                       order wins through an LDS min.  Member records never leave the registers.
+//   output                              rows from the lane that owns the line; extras are parked in an LDS stash at
+//                                       offset(line) + rank among extras and leave for the entry table in ONE coalesced copy per
+//                                       tile behind ONE atomic
+//
+// Exactness: this is a FAST FORM.  It accepts flat objects whose keys hold no escapes, with ' ' as the only whitespace
+// between tokens, at most kMaxLineItems structural characters -- every GELF producer's output -- and proves every byte of
+// the line to be part of that shape.  Anything else (nesting, escaped keys, TAB / CR / LF between tokens, raw control
+// characters = the '\n' retry, syntax errors, two keys sharing 7 bytes, ...) is handed back untouched (`handled = false`) and
+// takes the exact general form of fg_gelf.hip, which owns every error message of malformed input.
+//
+// Portable: compiled by hipcc for gfx950 and by g++ over the fiber emulation of a wave (fg_wave.hpp) for the CPU suite.
+#pragma once
+#include "fg_numparse.hpp"
+#include "fg_tables_view.hpp"
+#include "fg_wave.hpp"
+
+namespace fg {
+namespace gelf2 {
+
+// status codes == index into the reference's error strings (fg_error_string)
+enum : uint32_t {
+    G_OK = 0,
+    G_JSON = 1,     // "Invalid GELF input, unable to parse as a JSON object"   :49
+    G_EMPTY = 2,    // "Empty GELF input"                                       :50
+    G_TS = 3,       // "Invalid GELF timestamp"                                 :53
+    G_HOST = 4,     // "GELF host name must be a string"                        :58
+    G_SHORT = 5,    // "GELF short message must be a string"                    :66
+    G_FULL = 6,     // "GELF full message must be a string"                     :74
+    G_VERSTR = 7,   // "GELF version must be a string"                          :78
+    G_VER = 8,      // "Unsupported GELF version"                               :80
+    G_LEVEL = 9,    // "Invalid severity level"                                 :83
+    G_LEVEL7 = 10,  // "Invalid severity level (too high)"                      :85
+    G_SDTYPE = 11,  // "Invalid value type in structured data"                  :97
+    G_NOHOST = 12   // "Missing hostname"                                       :110
+};
+enum : uint32_t { V_STRING = 0, V_BOOL = 1, V_F64 = 2, V_I64 = 3, V_U64 = 4, V_NULL = 5 };  // == FG_T_*
+enum : uint32_t { K_TS = 0, K_HOST = 1, K_SHORT = 2, K_FULL = 3, K_VERSION = 4, K_LEVEL = 5, K_OTHER = 6 };
+
+// stage-A classes (one 16-bit mask per 16-byte chunk each)
+enum : uint32_t { C_Q = 0, C_B = 1, C_ST = 2, C_NS = 3, C_CT = 4, kClasses = 5 };
+constexpr uint32_t kMaxLineItems = 64;   // structural characters of a line on the fast form ('{' + commas + '}')
+constexpr uint32_t kLines = 64;
+
+FG_WV void classify(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t m[kClasses]) {
+    const uint32_t x[4] = {x0, x1, x2, x3};
+    uint32_t q[4], b[4], st[4], ns[4], ct[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        q[k] = wv::eq_flags(x[k], 0x22222222u);
+        b[k] = wv::eq_flags(x[k], 0x5C5C5C5Cu);
+        st[k] = wv::eq_flags(x[k], 0x2C2C2C2Cu) | wv::eq_flags(x[k], 0x7B7B7B7Bu) | wv::eq_flags(x[k], 0x7D7D7D7Du) |
+                wv::eq_flags(x[k], 0x5B5B5B5Bu) | wv::eq_flags(x[k], 0x5D5D5D5Du);
+        ns[k] = ~wv::eq_flags(x[k], 0x20202020u) & 0x80808080u;
+        ct[k] = wv::ctrl_flags(x[k]);
+    }
+    m[C_Q] = wv::gather16(q[0], q[1], q[2], q[3]);
+    m[C_B] = wv::gather16(b[0], b[1], b[2], b[3]);
+    m[C_ST] = wv::gather16(st[0], st[1], st[2], st[3]);
+    m[C_NS] = wv::gather16(ns[0], ns[1], ns[2], ns[3]);
+    m[C_CT] = wv::gather16(ct[0], ct[1], ct[2], ct[3]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The wave's LDS beyond the tile and the class bitmaps ("extra" block of the pipeline)
+// ---------------------------------------------------------------------------------------------
+struct Lds {
+    wv::Bytes T;             // tile bytes
+    uint32_t* bm[kClasses];  // class bitmaps, one bit per tile byte (C_Q becomes the REAL quotes, C_ST the item bitmap)
+    uint8_t* wpar;           // [words + 1] string parity carried INTO each 64-byte word
+    uint16_t* wcnt;          // [words + 1] items before each word
+    uint16_t* items;         // [item_cap] tile position of every item of the tile
+    uint64_t* kblk;          // [64] the block's sort keys: 7 key bytes big endian | extra << 7 | index in line;  ~0 = not a member
+    uint32_t* kinfo;         // [64] the block's key spans: key_b | key_len << 16
+    uint64_t* s_name;        // [ent_cap] entry stash: name span (line relative) off | len << 32
+    uint64_t* s_val;         // [ent_cap] ent_val
+    uint16_t* s_tf;          // [ent_cap] type | flags << 8
+    uint32_t *l_se, *l_fife, *l_flags, *l_err, *l_cnt, *l_eoff, *l_sev;  // [lines] per line
+    uint32_t* l_row;         // [lines][8]: ts lo, ts hi, host off, host len, msg off, msg len, full off, full len
+    uint32_t* tile_ents;     // [1] entries parked in the stash
+    double* p10;             // [23] 10^0 .. 10^22 (exact): the number parser's divisors without a trip to global memory
+    uint32_t* ent_state;     // the wave's entry-slot reservation (persists across tiles; set by the caller, wv::wave_alloc)
+    uint32_t alloc_chunk;    // its reservation size
+    uint32_t item_cap, ent_cap;
+};
+FG_WVH uint32_t up8(uint32_t v) { return (v + 7u) & ~7u; }
+// items / stash entries the arrays hold for a tile: one structural character per 12 bytes (GELF producers: one per ~20), one
+// extra per 32 bytes (~40); a tile with more items, a line whose extras no longer fit, takes the general form
+FG_WVH uint32_t item_cap_for(uint32_t tile_cap) { return up8(tile_cap / 12u); }  // (+ 8 spare slots in the array)
+FG_WVH uint32_t ent_cap_for(uint32_t tile_cap, uint32_t lines) { return up8(tile_cap / 32u + 2u * lines); }
+// bytes of the extra block
+FG_WVH uint32_t extra_bytes(uint32_t tile_cap, uint32_t lines) {
+    const uint32_t words = tile_cap / 64u + 2u;
+    return up8(words) + up8(words * 2u) + up8(item_cap_for(tile_cap) * 2u + 16u) + 64u * 8u + 64u * 4u + ent_cap_for(tile_cap, lines) * 18u + 16u +
+           lines * (7u * 4u + 32u) + 23u * 8u + 64u;
+}
+FG_WV Lds carve(const uint8_t* tile, uint16_t* bm16, uint32_t tile_cap, uint8_t* extra, uint32_t lines) {
+    Lds L;
+    L.T.w = reinterpret_cast<const uint32_t*>(tile);
+    const uint32_t stride16 = tile_cap / 16u + 16u;
+    for (uint32_t c = 0; c < kClasses; ++c) L.bm[c] = reinterpret_cast<uint32_t*>(bm16 + c * stride16);
+    const uint32_t words = tile_cap / 64u + 2u;
+    L.item_cap = item_cap_for(tile_cap);
+    L.ent_cap = ent_cap_for(tile_cap, lines);
+    uint8_t* p = extra;  // (8-byte members first)
+    L.p10 = reinterpret_cast<double*>(p); p += 23u * 8u;
+    L.kblk = reinterpret_cast<uint64_t*>(p); p += 64u * 8u;
+    L.s_name = reinterpret_cast<uint64_t*>(p); p += L.ent_cap * 8u;
+    L.s_val = reinterpret_cast<uint64_t*>(p); p += L.ent_cap * 8u;
+    L.l_row = reinterpret_cast<uint32_t*>(p); p += lines * 32u;
+    L.kinfo = reinterpret_cast<uint32_t*>(p); p += 64u * 4u;
+    L.l_se = reinterpret_cast<uint32_t*>(p); p += lines * 4u;
+    L.l_fife = reinterpret_cast<uint32_t*>(p); p += lines * 4u;
+    L.l_flags = reinterpret_cast<uint32_t*>(p); p += lines * 4u;
+    L.l_err = reinterpret_cast<uint32_t*>(p); p += lines * 4u;
+    L.l_cnt = reinterpret_cast<uint32_t*>(p); p += lines * 4u;
+    L.l_eoff = reinterpret_cast<uint32_t*>(p); p += lines * 4u;
+    L.l_sev = reinterpret_cast<uint32_t*>(p); p += lines * 4u;
+    L.tile_ents = reinterpret_cast<uint32_t*>(p); p += 8u;
+    L.s_tf = reinterpret_cast<uint16_t*>(p); p += up8(L.ent_cap * 2u);
+    L.wcnt = reinterpret_cast<uint16_t*>(p); p += up8(words * 2u);
+    L.items = reinterpret_cast<uint16_t*>(p); p += up8(L.item_cap * 2u + 16u);
+    L.wpar = p;
+    L.ent_state = nullptr;
+    L.alloc_chunk = 64u;
+    return L;
+}
+// once per wave, before the first tile: the powers of ten (exact doubles up to 10^22)
+FG_WV void init_lds(const Lds& L) {
+    if (wv::lane() == 0) {
+        double v = 1.0;
+        for (uint32_t k = 0; k < 23u; ++k) {
+            L.p10[k] = v;
+            v *= 10.0;
+        }
+    }
+    wv::sync();
+}
+
+enum : uint32_t { LF_BAIL = 1, LF_CLOSED = 2, LF_HAVE_TS = 4, LF_HAVE_HOST = 8, LF_DUP = 16, LF_DONE = 32 };  // l_flags; FG_F_* in bits 8..15
+
+// what the lane that owns a line gets back
+struct LineOut {
+    bool handled;  // false: the caller runs the exact general form for this line
+    uint32_t status, severity, flags;
+    uint32_t have_ts;
+    double ts;
+    uint32_t host_off, host_len, msg_off, msg_len, full_off, full_len;
+    uint32_t first, n_ent;
+};
+
+// ---------------------------------------------------------------------------------------------
+// small pieces
+// ---------------------------------------------------------------------------------------------
+FG_WV uint64_t prefix_xor64(uint64_t x) {
+    x ^= x << 1;
+    x ^= x << 2;
+    x ^= x << 4;
+    x ^= x << 8;
+    x ^= x << 16;
+    x ^= x << 32;
+    return x;
+}
+// characters escaped by a backslash (simdjson's odd-backslash-run arithmetic); cin = bit 0 is escaped from the word before
+FG_WV uint64_t find_escaped(uint64_t bs, uint64_t cin) {
+    bs &= ~cin;
+    const uint64_t follows = (bs << 1) | cin;
+    const uint64_t even = 0x5555555555555555ull;
+    const uint64_t odd_starts = bs & ~even & ~follows;
+    const uint64_t seq_even = odd_starts + bs;
+    const uint64_t invert = seq_even << 1;
+    return (even ^ invert) & follows;
+}
+FG_WV uint64_t below(uint32_t bit) { return bit >= 64u ? ~0ull : (1ull << bit) - 1ull; }
+
+FG_WV uint32_t known_key(uint32_t n, const uint32_t w[4]) {
+    if (n == 9u && w[0] == 0x656D6974u && w[1] == 0x6D617473u && (w[2] & 0xFFu) == 'p') return K_TS;                            // timestamp
+    if (n == 4u && w[0] == 0x74736F68u) return K_HOST;                                                                          // host
+    if (n == 13u && w[0] == 0x726F6873u && w[1] == 0x656D5F74u && w[2] == 0x67617373u && (w[3] & 0xFFu) == 'e') return K_SHORT;  // short_message
+    if (n == 12u && w[0] == 0x6C6C7566u && w[1] == 0x73656D5Fu && w[2] == 0x65676173u) return K_FULL;                           // full_message
+    if (n == 7u && w[0] == 0x73726576u && (w[1] & 0xFFFFFFu) == 0x6E6F69u) return K_VERSION;                                    // version
+    if (n == 5u && w[0] == 0x6576656Cu && (w[1] & 0xFFu) == 'l') return K_LEVEL;                                                // level
+    return K_OTHER;
+}
+FG_WV bool hex4_ok(uint32_t v) {  // four ASCII hex digits in a dword
+    const uint32_t d = v ^ 0x30303030u;
+    const uint32_t dig_bad = (d | ((d & 0x7F7F7F7Fu) + 0x76767676u)) & 0x80808080u;
+    const uint32_t l = (v | 0x20202020u) ^ 0x60606060u;
+    const uint32_t let_hi = (l | ((l & 0x7F7F7F7Fu) + 0x79797979u)) & 0x80808080u;
+    const uint32_t let_zero = ~(((l & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | l) & 0x80808080u;
+    return (dig_bad & (let_hi | let_zero)) == 0u;
+}
+// JSON escapes of the string body [p, e) (serde_json 0.8 parse_escape): true = all valid.  Only called for bodies that hold
+// a backslash; bmB = the backslash bitmap.
+FG_WV bool escapes_ok(const wv::Bytes& T, const uint32_t* bmB, uint32_t p, uint32_t e) {
+    for (;;) {
+        const uint32_t h = wv::find_bit(bmB, p, e);
+        if (h >= e) return true;
+        if (h + 1u >= e) return false;
+        const uint64_t v = T.load8(h);
+        const uint32_t c = (uint32_t)(v >> 8) & 0xFFu;
+        if (c == '"' || c == '\\' || c == '/' || c == 'b' || c == 'f' || c == 'n' || c == 'r' || c == 't') {
+            p = h + 2u;
+            continue;
+        }
+        if (c != 'u' || h + 6u > e) return false;
+        const uint32_t hx = (uint32_t)(v >> 16);
+        if (!hex4_ok(hx)) return false;
+        const uint32_t d0 = hx & 0xFFu, d1 = (hx >> 8) & 0xFFu, d1l = d1 | 0x20u;
+        const bool is_d = (d0 | 0x20u) == 'd';
+        const bool high = is_d && (d1 == '8' || d1 == '9' || d1l == 'a' || d1l == 'b');
+        const bool low = is_d && (d1l >= 'c' && d1l <= 'f');
+        if (low) return false;  // lone low surrogate
+        if (high) {             // must be followed by \uDC00..\uDFFF
+            if (h + 12u > e) return false;
+            const uint64_t v2 = T.load8(h + 6u);
+            if (((uint32_t)v2 & 0xFFFFu) != (('u' << 8) | '\\')) return false;
+            const uint32_t hx2 = (uint32_t)(v2 >> 16);
+            if (!hex4_ok(hx2)) return false;
+            const uint32_t e0 = hx2 & 0xFFu, e1 = ((hx2 >> 8) & 0xFFu) | 0x20u;
+            if (!((e0 | 0x20u) == 'd' && e1 >= 'c' && e1 <= 'f')) return false;
+            p = h + 12u;
+        } else {
+            p = h + 6u;
+        }
+    }
+}
+// reader over a token of the tile for fg_numparse (the rare shapes: exponents, 20+ digits): byte-wise out of LDS
+struct TokReader {
+    const wv::Bytes& T;
+    FG_WV explicit TokReader(const wv::Bytes& t) : T(t) {}
+    FG_WV uint32_t byte(uint32_t i) const { return T.byte(i); }
+};
+FG_WV uint32_t p10_small(uint32_t c) {  // 10^c, c <= 6
+    uint32_t r = (c & 1u) ? 10u : 1u;
+    r = (c & 2u) ? wv::mad24(r, 100u, 0u) : r;
+    r = (c & 4u) ? wv::mad24(r, 10000u, 0u) : r;
+    return r;
+}
+// serde_json 0.8 number (fg_numparse.hpp json_number) for the everyday shape  -?D+(.D+)?  with at most 19 digits, on a token
+// of n <= 24 bytes held in registers: class masks by SWAR, then Horner in 24-bit multiply-adds over STATIC byte positions (four
+// chunks of six).  false = not that shape: the caller runs json_number, which owns every error.
+FG_WV bool parse_num24(const uint32_t w[6], uint32_t n, const double* p10, uint32_t* kind, uint64_t* bits) {
+    const bool neg = (w[0] & 0xFFu) == '-';
+    uint32_t ndm = 0, dtm = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 6; ++k) {
+        const uint32_t x = w[k] ^ 0x30303030u;
+        const uint32_t nd = (x | ((x & 0x7F7F7F7Fu) + 0x76767676u)) & 0x80808080u;  // bit 7: the byte is not a digit
+        ndm |= wv::udot4(nd >> 7, 0x08040201u, 0u) << (4u * k);
+        dtm |= wv::udot4(wv::eq_flags(w[k], 0x2E2E2E2Eu) >> 7, 0x08040201u, 0u) << (4u * k);
+    }
+    const uint32_t tok = (1u << n) - 1u;  // n <= 24
+    const uint32_t body = tok & ~(neg ? 1u : 0u);
+    const uint32_t nondig = ndm & body, digits = body & ~ndm;
+    const uint32_t nd_total = wv::popc32(digits);
+    const bool has_dot = nondig != 0u;
+    const uint32_t o = neg ? 1u : 0u;
+    const uint32_t dp = has_dot ? wv::ctz32(nondig) : n;
+    const uint32_t ni = dp - o, nf = has_dot ? n - dp - 1u : 0u;
+    const uint32_t c0 = neg ? ((w[0] >> 8) & 0xFFu) : (w[0] & 0xFFu);
+    const bool ok = (nondig & (nondig - 1u)) == 0u && (nondig & ~dtm) == 0u && nd_total >= 1u && nd_total <= 19u && dp >= o + 1u &&
+                    (!has_dot || nf >= 1u) && !(c0 == '0' && ni > 1u);
+    if (!ok) return false;
+    uint64_t sig = 0;
+#pragma unroll
+    for (uint32_t c = 0; c < 4; ++c) {
+        uint32_t acc = 0, cnt = 0;
+#pragma unroll
+        for (uint32_t i = 6u * c; i < 6u * c + 6u; ++i) {
+            const uint32_t bit = (digits >> i) & 1u;
+            const uint32_t d = (wv::bfe(w[i >> 2], 8u * (i & 3u), 8u) - 48u) & (0u - bit);
+            acc = wv::mad24(acc, wv::mad24(bit, 9u, 1u), d);
+            cnt += bit;
+        }
+        sig = sig * (uint64_t)p10_small(cnt) + acc;
+    }
+    if (has_dot) {
+        // visit_f64_from_parts: f = sig as f64; f /= POW10[nf]   (nf <= 18 here: the divisor comes from LDS)
+        *kind = V_F64;
+        const double f = (double)sig / p10[nf];
+        *bits = num::f64_to_bits(neg ? -f : f);
+        return true;
+    }
+    if (!neg) {
+        *kind = V_U64;
+        *bits = sig;
+        return true;
+    }
+    const int64_t neg64 = (int64_t)(0ull - sig);
+    if (neg64 > 0) {  // magnitude above i64: becomes a float
+        *kind = V_F64;
+        *bits = num::f64_to_bits(-(double)sig);
+    } else if (neg64 < 0) {
+        *kind = V_I64;
+        *bits = (uint64_t)neg64;
+    } else {
+        *kind = V_U64;  // "-0" -> visit_i64(0) -> U64(0)
+        *bits = 0;
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The tile decoder.  Called by all 64 lanes in wave-uniform control flow.
+//   span          staged tile bytes (wave-uniform)
+//   valid         this lane owns a line that lies inside the tile: bytes [base, base + len)   (lane < lines of carve())
+//   t             tables (entries of handled lines are written here)
+// ---------------------------------------------------------------------------------------------
+template <bool PROF = false>
+FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base, uint32_t len, const DevTables& t,
+                          unsigned long long* phase = nullptr) {
+    const uint32_t lane = wv::lane();
+    // measurement build: cycles of  0 word pass  1 line pass  2 item parse  3 rank  4 dispatch  5 verdict + stash  6 copy-out + rows
+    uint64_t pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tk = PROF ? wv::clock() : 0;
+    auto tick = [&](int k) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(FG_ASM_MARKS)
+        asm volatile("; FGMARK tick %0" ::"n"(0));
+        (void)k;
+#endif
+        if (PROF) {
+            const uint64_t now = wv::clock();
+            pc[k] += now - tk;
+            tk = now;
+        }
+    };
+    const wv::Bytes& T = L.T;
+    uint64_t* Q = reinterpret_cast<uint64_t*>(L.bm[C_Q]);
+    const uint64_t* B = reinterpret_cast<const uint64_t*>(L.bm[C_B]);
+    uint64_t* ST = reinterpret_cast<uint64_t*>(L.bm[C_ST]);
+    const uint64_t* CT = reinterpret_cast<const uint64_t*>(L.bm[C_CT]);
+    const uint32_t* bmQ = L.bm[C_Q];
+    const uint32_t* bmB = L.bm[C_B];
+    const uint32_t* bmN = L.bm[C_NS];
+    LineOut out{};
+    out.handled = false;
+
+    // ================= word pass: real quotes, string parity, items =================
+    const uint32_t nwords = (span + 63u) >> 6;
+    const uint32_t wn = (nwords + wv::kLanes - 1u) / wv::kLanes;  // words per lane (wave-uniform)
+    const uint32_t w0 = lane * wn < nwords ? lane * wn : nwords;
+    const uint32_t w1 = w0 + wn < nwords ? w0 + wn : nwords;
+    bool chain = false;  // a word of 64 backslashes: the escape carry would chain through it -- not worth a scan
+    uint32_t par = 0;
+    {
+        uint32_t last_odd = 0;
+        if (w1 > w0) {
+            const uint64_t b = B[w1 - 1u];
+            last_odd = b == ~0ull ? 0u : (wv::clz64(~b) & 1u);
+        }
+        uint32_t cin = wv::shfl_up(last_odd, 1u);
+        if (lane == 0) cin = 0;
+        for (uint32_t w = w0; w < w1; ++w) {
+            const uint64_t q = Q[w], b = B[w];
+            chain = chain || b == ~0ull;
+            const uint64_t qr = q & ~find_escaped(b, (uint64_t)cin);
+            Q[w] = qr;
+            L.wpar[w] = (uint8_t)par;
+            par ^= wv::popc64(qr) & 1u;
+            cin = b == ~0ull ? 0u : (wv::clz64(~b) & 1u);
+        }
+        const uint32_t pin = wv::mbcnt(wv::ballot(par != 0u)) & 1u;
+        if (pin)
+            for (uint32_t w = w0; w < w1; ++w) L.wpar[w] ^= 1u;
+    }
+    const bool tile_bail = wv::any(chain);
+    wv::sync();
+    // ---- the in-string state starts afresh at every line: toggle where the raw parity at a line's start differs from the line before
+    bool use_t = false;
+    uint32_t* Tg = reinterpret_cast<uint32_t*>(L.s_name);  // the toggle bitmap borrows the (still unused) entry stash
+    {
+        uint32_t rk = 0;
+        if (valid) {
+            const uint64_t qr = Q[base >> 6];
+            rk = (uint32_t)L.wpar[base >> 6] ^ (wv::popc64(qr & below(base & 63u)) & 1u);
+        }
+        uint32_t rprev = wv::shfl_up(valid ? rk : 0u, 1u);
+        if (lane == 0) rprev = 0;
+        const bool flip = valid && (rk ^ rprev) != 0u;
+        use_t = wv::any(flip);
+        if (use_t) {  // rare for GELF: a line with an odd number of quotes came before
+            const uint32_t nw32 = nwords * 2u;
+            for (uint32_t i = lane; i < nw32; i += wv::kLanes) Tg[i] = 0u;
+            wv::sync();
+            if (flip) wv::lds_xor(&Tg[base >> 5], 1u << (base & 31u));
+            wv::sync();
+            const uint64_t* Tg64 = reinterpret_cast<const uint64_t*>(Tg);
+            par = 0;
+            for (uint32_t w = w0; w < w1; ++w) {
+                L.wpar[w] = (uint8_t)par;
+                par ^= wv::popc64(Q[w] ^ Tg64[w]) & 1u;
+            }
+            const uint32_t pin = wv::mbcnt(wv::ballot(par != 0u)) & 1u;
+            if (pin)
+                for (uint32_t w = w0; w < w1; ++w) L.wpar[w] ^= 1u;
+            wv::sync();
+        }
+    }
+    // ---- items = structural characters outside strings (control characters count everywhere: they end the fast form)
+    uint32_t n_items_tile = 0;
+    {
+        const uint64_t* Tg64 = reinterpret_cast<const uint64_t*>(Tg);
+        uint32_t cnt = 0;
+        for (uint32_t w = w0; w < w1; ++w) {
+            const uint64_t x = use_t ? (Q[w] ^ Tg64[w]) : Q[w];
+            const uint64_t S = prefix_xor64(x) ^ (L.wpar[w] ? ~0ull : 0ull);
+            const uint32_t left = span - 64u * w;
+            const uint64_t E = ((ST[w] & ~S) | CT[w]) & below(left);
+            ST[w] = E;
+            L.wcnt[w] = (uint16_t)cnt;
+            cnt += wv::popc64(E);
+        }
+        const uint32_t before = wv::excl_sum(cnt, &n_items_tile);
+        // ---- item positions, tile wide (lane = the word's owner) ----
+        const bool fits = n_items_tile <= L.item_cap;  // wave-uniform
+        uint32_t idx = before;
+        for (uint32_t w = w0; w < w1; ++w) {
+            L.wcnt[w] = (uint16_t)idx;
+            uint64_t E = ST[w];
+            while (E) {
+                const uint32_t bit = wv::ctz64(E);
+                E &= E - 1ull;
+                if (fits) L.items[idx] = (uint16_t)(w * 64u + bit);
+                ++idx;
+            }
+        }
+        if (lane == 0) {
+            L.wcnt[nwords] = (uint16_t)n_items_tile;
+            ST[nwords] = 0ull;
+            *L.tile_ents = 0u;
+        }
+    }
+    wv::sync();  // (the toggle bitmap is dead from here on: the entry stash is free)
+    tick(0);
+
+    // ================= line pass =================
+    const uint32_t s = base, e = base + len;
+    uint32_t fi = 0, fe = 0;
+    if (valid) {
+        fi = (uint32_t)L.wcnt[s >> 6] + wv::popc64(ST[s >> 6] & below(s & 63u));
+        fe = (uint32_t)L.wcnt[e >> 6] + wv::popc64(ST[e >> 6] & below(e & 63u));
+    }
+    const bool fast = valid && !tile_bail && n_items_tile <= L.item_cap && len >= 2u && (fe - fi) >= 2u && (fe - fi) <= kMaxLineItems;
+    if (valid) {
+        L.l_se[lane] = s | (e << 16);
+        L.l_fife[lane] = fi | (fe << 16);
+        L.l_flags[lane] = fast ? 0u : LF_BAIL;
+        L.l_err[lane] = 0xFFFFFFFFu;
+        L.l_cnt[lane] = 0u;
+        L.l_eoff[lane] = 0u;
+        L.l_sev[lane] = 0xFFu;
+        uint32_t* row = L.l_row + lane * 8u;
+        row[0] = row[1] = 0u;
+        row[2] = 0u; row[3] = 0u;            // hostname: off, len
+        row[4] = 0u; row[5] = FG_NONE;       // msg
+        row[6] = 0u; row[7] = FG_NONE;       // full_msg
+    }
+    wv::sync();
+
+    tick(1);
+    // ================= blocks: whole lines, at most 64 items, one item per lane =================
+    const uint64_t valid_m = wv::ballot(valid);
+    uint32_t lb = valid_m ? wv::ctz64(valid_m) : wv::kLanes;
+    const uint32_t lend = valid_m ? 64u - wv::clz64(valid_m) : 0u;  // one past the last valid lane
+    while (lb < lend) {
+        const uint32_t fi_lb = wv::shfl(fi, lb);
+        const bool over = lane >= lb && lane < lend && (!valid || (fe - fi_lb) > wv::kLanes);
+        const uint64_t over_m = wv::ballot(over);
+        const uint32_t le = over_m ? wv::ctz64(over_m) : lend;
+        if (le == lb) {  // a single line with more than 64 items (not a fast-form line: flagged above), or a hole
+            lb = lb + 1u;
+            continue;
+        }
+        const uint32_t n_items = wv::shfl(fe, le - 1u) - fi_lb;
+
+        // ---- the item of this lane ----
+        const uint32_t jj = lane;
+        bool act = jj < n_items;
+        uint32_t k = lb;  // the item's line: the last line of the block that starts at or before it
+        for (uint32_t q = lb + 1u; q < le; ++q)
+            if ((L.l_fife[q] & 0xFFFFu) - fi_lb <= jj) k = q;
+        const uint32_t se = L.l_se[k], ff = L.l_fife[k];
+        const uint32_t ls = se & 0xFFFFu, le_ = se >> 16;
+        const uint32_t kfi = (ff & 0xFFFFu) - fi_lb, kfe = (ff >> 16) - fi_lb;  // the line's items: lanes [kfi, kfe)
+        act = act && !(L.l_flags[k] & LF_BAIL);
+        bool member = false;
+        uint64_t key = ~0ull, bits = 0;
+        uint32_t key_b = 0, kl = 0, which = K_OTHER, kind = V_NULL, v_b = 0, v_len = 0, v_esc = 0;
+        if (act) {
+            const uint32_t pos = L.items[fi_lb + jj];
+            const bool first_item = jj == kfi, last_item = jj + 1u == kfe;
+            const uint32_t nxt = last_item ? pos + 1u : (uint32_t)L.items[fi_lb + jj + 1u];
+            const uint32_t c = T.byte(pos), rb = T.byte(nxt);
+            bool ok;
+            if (c == '}') {
+                // the closing brace: last item, only spaces behind it, and something opened before it
+                ok = last_item && !first_item && wv::find_bit(bmN, pos + 1u, le_) >= le_;
+                if (ok) wv::lds_or(&L.l_flags[k], LF_CLOSED);
+            } else {
+                // '{' or ',' owns the member up to the next item, which must be ',' or '}'  ('[' / ']' = nesting, control characters:
+                // not fast-form material).  Straight-line from here: every read below is at a clamped, always readable position and the
+                // verdict is ONE conjunction -- a short-circuit per test would cost a dozen scalar instructions of exec-mask work each.
+                ok = (c == '{' || c == ',') & ((c == '{') == first_item) & !last_item & (rb == ',' || rb == '}');
+                if (first_item && pos != ls) ok = ok & (wv::find_bit(bmN, ls, pos) >= pos);  // only spaces before the '{'
+                // ---- the member's bytes (pos, nxt): 64-bit windows of the bitmaps from a = pos + 1 ----
+                const uint32_t a = pos + 1u, m = nxt - a;
+                const uint64_t in = below(m), top = 1ull << 63;
+                const uint64_t NSr = wv::window64(bmN, a), NSw = NSr & in, Qw = wv::window64(bmQ, a) & in, Bw = wv::window64(bmB, a) & in;
+                const bool empty = NSw == 0ull;
+                // ws "key" ws : ws value ws   -- key, colon and the value's first byte inside the window
+                const uint32_t p = wv::ctz64(NSw | top);
+                const uint64_t above_p = ~1ull << p;
+                const uint64_t q2 = Qw & above_p;
+                const uint32_t ke = wv::ctz64(q2 | top);  // the key's closing quote
+                const uint64_t above_ke = ~1ull << ke;
+                const uint64_t n3 = NSw & above_ke;
+                const uint32_t col = wv::ctz64(n3 | top);
+                const uint64_t n4 = NSw & (~1ull << col);
+                const uint32_t v = wv::ctz64(n4 | top);
+                key_b = a + p + 1u;
+                kl = ke - p - 1u;
+                const bool okm = ((Qw >> p) & 1ull) & (q2 != 0ull) & ((Bw & above_p & below(ke)) == 0ull) & (n3 != 0ull) &
+                                 (T.byte(a + col) == ':') & (n4 != 0ull) & (kl <= 255u);
+                uint32_t vend = v;  // window-relative index just past the value
+                bool okv = false;
+                if (ok & okm & !empty) {
+                    if ((Qw >> v) & 1ull) {
+                        // ---- string: the closing quote is the next real quote (beyond the window: bit scan of the bitmap) ----
+                        kind = V_STRING;
+                        const uint64_t above_v = ~1ull << v;
+                        const uint64_t q3 = Qw & above_v;
+                        uint32_t ve;
+                        bool esc;
+                        if (q3 != 0ull) {
+                            ve = wv::ctz64(q3);
+                            esc = (Bw & above_v & below(ve)) != 0ull;
+                            okv = (NSw & (~1ull << ve)) == 0ull && (m <= 64u || wv::find_bit(bmN, a + 64u, nxt) >= nxt);
+                        } else {
+                            ve = m > 64u ? wv::find_bit(bmQ, a + 64u, nxt) - a : m;
+                            esc = ve < m && wv::any_bit(bmB, a + v + 1u, a + ve);
+                            okv = ve < m && wv::find_bit(bmN, a + ve + 1u, nxt) >= nxt;
+                        }
+                        v_b = a + v + 1u;
+                        v_len = ve - v - 1u;
+                        vend = ve + 1u;
+                        if (okv && esc) {
+                            v_esc = 1;
+                            okv = escapes_ok(T, bmB, v_b, a + ve);
+                        }
+                    } else {
+                        // ---- number / literal: the token ends at the first space (or at the delimiter) ----
+                        const uint64_t sp = ~NSr & (~0ull << v);
+                        const uint32_t te = wv::ctz64(sp | top);
+                        vend = te < m ? te : m;
+                        const uint32_t n = vend - v;
+                        okv = m <= 64u && (NSw & ~below(vend)) == 0ull;  // (a token with 40 spaces behind it is not fast-form material)
+                        uint32_t wv6[6], lo[4], hi[4];
+                        T.load16(a + v, lo);
+                        T.load16(a + v + 16u, hi);
+                        wv6[0] = lo[0]; wv6[1] = lo[1]; wv6[2] = lo[2]; wv6[3] = lo[3]; wv6[4] = hi[0]; wv6[5] = hi[1];
+                        const uint32_t cv = wv6[0] & 0xFFu;
+                        if (cv == '-' || (cv - '0') <= 9u) {
+                            uint32_t k2 = 0;
+                            bool good = n <= 24u && parse_num24(wv6, n, L.p10, &k2, &bits);
+                            if (!good) {  // exponents, 20+ digits, malformed: the byte-wise parser decides
+                                TokReader rd(T);
+                                uint32_t endp = 0;
+                                good = num::json_number(rd, a + v, a + vend, &endp, &k2, &bits) && endp == a + vend;
+                            }
+                            okv = okv && good;
+                            kind = k2;
+                        } else {
+                            const bool tt = n == 4u && wv6[0] == 0x65757274u;                            // true
+                            const bool ff2 = n == 5u && wv6[0] == 0x736C6166u && (wv6[1] & 0xFFu) == 'e';  // false
+                            const bool nn = n == 4u && wv6[0] == 0x6C6C756Eu;                            // null
+                            okv = okv && (tt || ff2 || nn);
+                            kind = nn ? V_NULL : V_BOOL;
+                            bits = tt ? 1u : 0u;
+                        }
+                    }
+                    if (okv) {
+                        uint32_t kw[4];
+                        T.load16(key_b, kw);
+                        which = known_key(kl, kw);
+                        uint64_t pre = (uint64_t)kw[0] | ((uint64_t)kw[1] << 32);
+                        if (kl < 8u) pre &= kl == 0u ? 0ull : (~0ull >> (64u - 8u * kl));
+                        const uint64_t be = __builtin_bswap64(pre);
+                        key = (be & ~0xFFull) | (which == K_OTHER ? 0x80ull : 0ull) | (jj - kfi);  // index in line < 64
+                        member = true;
+                    }
+                }
+                // "{}": no member at all; "{,", ",,", ",}" are syntax errors
+                ok = ok & (empty ? (m <= 64u && c == '{' && rb == '}') : (okm & okv));
+            }
+            if (!ok) wv::lds_or(&L.l_flags[k], LF_BAIL);
+        }
+        L.kblk[lane] = key;
+        L.kinfo[lane] = key_b | (kl << 16);
+        wv::sync();
+        tick(2);
+
+        // ---- BTreeMap order inside the line: rank among the members (orders the errors) and among the extras (the slot) ----
+        uint32_t rank_all = 0, rank_x = 0;
+        bool dropped = false;
+        member = member && !(L.l_flags[k] & LF_BAIL);
+        if (member) {
+            bool bail = false, dup = false;
+            // (four keys per round trip: the loads of a batch are issued before the first compare)
+            for (uint32_t t0 = kfi; t0 < kfe; t0 += 4u) {
+                uint64_t ko[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) ko[u] = L.kblk[(t0 + u) & 63u];  // (past the line: masked out below)
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) {
+                    const uint32_t tt = t0 + u;
+                    const bool in = tt < kfe;
+                    rank_all += (in && ko[u] < key) ? 1u : 0u;
+                    rank_x += (in && ko[u] < key && (ko[u] & 0x80ull)) ? 1u : 0u;
+                    if (in && tt != jj && (ko[u] >> 8) == (key >> 8)) {
+                        // same 7-byte prefix: the same key twice (the later one wins, BTreeMap::insert), or two keys the prefix
+                        // cannot order (the general form sorts them)
+                        const uint32_t oi = L.kinfo[tt];
+                        const uint32_t ob = oi & 0xFFFFu, ol = oi >> 16;
+                        bool same = ol == kl;
+                        for (uint32_t q = 7; q < kl && same; ++q) same = T.byte(key_b + q) == T.byte(ob + q);
+                        if (!same) bail = true;
+                        else if (tt > jj) dropped = true;
+                        dup = true;
+                    }
+                }
+            }
+            if (bail) wv::lds_or(&L.l_flags[k], LF_BAIL);
+            else if (dup) wv::lds_or(&L.l_flags[k], LF_DUP);
+        }
+        if (wv::any(dropped)) {  // rare: erase the dropped duplicates and recount their lines
+            wv::sync();
+            if (dropped) L.kblk[lane] = ~0ull;
+            wv::sync();
+            if (member && !dropped && (L.l_flags[k] & LF_DUP)) {
+                rank_all = rank_x = 0;
+                for (uint32_t tt = kfi; tt < kfe; ++tt) {
+                    const uint64_t ko = L.kblk[tt];
+                    rank_all += ko < key ? 1u : 0u;
+                    rank_x += (ko < key && (ko & 0x80ull)) ? 1u : 0u;
+                }
+            }
+        }
+        member = member && !dropped;
+        tick(3);
+        // ---- gelf_decoder.rs:51-106 for this member ----
+        if (member && !(L.l_flags[k] & LF_BAIL)) {
+            uint32_t* row = L.l_row + k * 8u;
+            uint32_t st = G_OK;
+            switch (which) {
+                case K_TS: {
+                    double tsv = 0.0;
+                    if (kind == V_F64) tsv = num::bits_to_f64(bits);
+                    else if (kind == V_U64) tsv = (double)bits;
+                    else if (kind == V_I64) tsv = (double)(int64_t)bits;
+                    else st = G_TS;
+                    const uint64_t tb = num::f64_to_bits(tsv);
+                    row[0] = (uint32_t)tb;
+                    row[1] = (uint32_t)(tb >> 32);
+                    wv::lds_or(&L.l_flags[k], LF_HAVE_TS);
+                    break;
+                }
+                case K_HOST:
+                    if (kind != V_STRING) st = G_HOST;
+                    row[2] = v_b - ls;
+                    row[3] = v_len;
+                    wv::lds_or(&L.l_flags[k], LF_HAVE_HOST | (v_esc ? (uint32_t)FG_F_HOST_ESC << 8 : 0u));
+                    break;
+                case K_SHORT:
+                    if (kind != V_STRING) st = G_SHORT;
+                    row[4] = v_b - ls;
+                    row[5] = v_len;
+                    if (v_esc) wv::lds_or(&L.l_flags[k], (uint32_t)FG_F_MSG_ESC << 8);
+                    break;
+                case K_FULL:
+                    if (kind != V_STRING) st = G_FULL;
+                    row[6] = v_b - ls;
+                    row[7] = v_len;
+                    if (v_esc) wv::lds_or(&L.l_flags[k], (uint32_t)FG_F_FULLMSG_ESC << 8);
+                    break;
+                case K_VERSION:
+                    if (kind != V_STRING) {
+                        st = G_VERSTR;
+                    } else if (v_esc) {
+                        wv::lds_or(&L.l_flags[k], LF_BAIL);  // "1.0" / "1.1" by DECODED value: an escaped spelling is for the general form
+                    } else {
+                        const uint32_t three = (uint32_t)T.load8(v_b) & 0xFFFFFFu;
+                        if (!(v_len == 3u && (three == 0x302E31u || three == 0x312E31u))) st = G_VER;
+                    }
+                    break;
+                case K_LEVEL:
+                    if (kind != V_U64) st = G_LEVEL;  // Value::as_u64 (NumCast): floats and negatives -> None
+                    else if (bits > 7u) st = G_LEVEL7;
+                    else L.l_sev[k] = (uint32_t)bits;
+                    break;
+                default:
+                    wv::lds_add(&L.l_cnt[k], 1u);  // an extra (nested values never reach the fast form)
+            }
+            if (st != G_OK) wv::lds_min(&L.l_err[k], (rank_all << 8) | st);
+        }
+        wv::sync();
+        tick(4);
+        // ---- the line's verdict and its room in the entry stash: by the lane of the line's first item ----
+        if (jj < n_items && jj == kfi) {
+            const uint32_t lf = L.l_flags[k];
+            if (!(lf & LF_BAIL) && (lf & LF_CLOSED)) {
+                const uint32_t err = L.l_err[k];
+                uint32_t status = err == 0xFFFFFFFFu ? G_OK : (err & 0xFFu);
+                if (status == G_OK && !(lf & LF_HAVE_HOST)) status = G_NOHOST;  // :110
+                const uint32_t n_ent = status == G_OK ? L.l_cnt[k] : 0u;
+                const uint32_t off = n_ent ? wv::lds_add(L.tile_ents, n_ent) : 0u;
+                if (off + n_ent > L.ent_cap) {
+                    wv::lds_or(&L.l_flags[k], LF_BAIL);  // no room in the stash (its slots stay unused): the general form takes the line
+                } else {
+                    L.l_err[k] = status;  // (reused: the final status)
+                    L.l_cnt[k] = n_ent;
+                    L.l_eoff[k] = off;
+                    wv::lds_or(&L.l_flags[k], LF_DONE);
+                }
+            } else {
+                wv::lds_or(&L.l_flags[k], LF_BAIL);
+            }
+        }
+        wv::sync();
+        // ---- extras -> the stash, at offset(line) + rank among the line's extras (BTreeMap order) ----
+        if (member && which == K_OTHER) {
+            const uint32_t lf = L.l_flags[k];
+            if ((lf & (LF_BAIL | LF_DONE)) == LF_DONE && L.l_cnt[k] != 0u) {
+                const uint32_t slot = L.l_eoff[k] + rank_x;
+                L.s_name[slot] = (uint64_t)(key_b - ls) | ((uint64_t)kl << 32);
+                L.s_val[slot] = kind == V_STRING ? ((uint64_t)(v_b - ls) | ((uint64_t)v_len << 32)) : kind == V_NULL ? 0ull : bits;
+                L.s_tf[slot] = (uint16_t)(kind | (((kind == V_STRING && v_esc) ? (uint32_t)FG_EF_VAL_ESC : 0u) << 8));
+            }
+        }
+        lb = le;
+        tick(5);
+    }
+    wv::sync();
+
+    // ================= the tile's entries: ONE atomic, ONE coalesced copy =================
+    const uint32_t n_stash = *L.tile_ents > L.ent_cap ? L.ent_cap : *L.tile_ents;  // (slots of lines that did not fit were never filled)
+    // (what is left of the wave's chunk takes the lines whose slices fit, whole; the rest opens the next chunk)
+    uint32_t my_off = 0, my_cnt = 0;
+    if (valid && fast && (L.l_flags[lane] & (LF_BAIL | LF_DONE)) == LF_DONE) {
+        my_off = L.l_eoff[lane];
+        my_cnt = L.l_cnt[lane];
+    }
+    const uint32_t left = wv::wave_left(L.ent_state);
+    const uint64_t straddle = wv::ballot(my_cnt != 0u && my_off < left && my_off + my_cnt > left);
+    const uint32_t cut_at = straddle ? wv::shfl(my_off, wv::ctz64(straddle)) : left;
+    const wv::Slots es = wv::wave_alloc(t.ent_used, t.ent_cap, L.ent_state, n_stash, cut_at < n_stash ? cut_at : n_stash, L.alloc_chunk);
+    const bool overflow = es.overflow;
+    if (n_stash != 0u) {
+        for (uint32_t i = lane; i < n_stash; i += wv::kLanes) {
+            if (overflow && i >= es.cut) continue;  // (lines beyond the cut report FG_ST_OVERFLOW below)
+            const uint64_t nm = L.s_name[i];
+            const uint32_t tf = L.s_tf[i];
+            const uint32_t slot = es.at(i);
+            t.ent_name[slot] = fg_span{(uint32_t)nm, (uint32_t)(nm >> 32)};
+            t.ent_val[slot] = L.s_val[i];
+            t.ent_type[slot] = (uint8_t)(tf & 0xFFu);
+            t.ent_flags[slot] = (uint8_t)(tf >> 8);
+        }
+    }
+    // ================= rows =================
+    if (valid && fast) {
+        const uint32_t lf = L.l_flags[lane];
+        if ((lf & (LF_BAIL | LF_DONE)) == LF_DONE) {
+            out.handled = true;
+            out.status = L.l_err[lane];
+            out.n_ent = L.l_cnt[lane];
+            out.first = out.n_ent ? es.at(L.l_eoff[lane]) : 0u;
+            if (overflow && out.n_ent && L.l_eoff[lane] >= es.cut) {
+                out.status = FG_ST_OVERFLOW;
+                out.n_ent = 0;
+                out.first = 0;
+            }
+            out.have_ts = (lf & LF_HAVE_TS) ? 1u : 0u;
+            out.flags = ((lf >> 8) & 0xFFu) | ((lf & LF_HAVE_TS) ? 0u : (uint32_t)FG_F_TS_NOW);  // :109
+            out.severity = L.l_sev[lane];
+            const uint32_t* row = L.l_row + lane * 8u;
+            out.ts = num::bits_to_f64((uint64_t)row[0] | ((uint64_t)row[1] << 32));
+            out.host_off = row[2]; out.host_len = row[3];
+            out.msg_off = row[4]; out.msg_len = row[5];
+            out.full_off = row[6]; out.full_len = row[7];
+        }
+    }
+    tick(6);
+    if (PROF && phase && lane == 0)
+        for (int k = 0; k < 7; ++k) wv::glb_add(phase + k, (unsigned long long)pc[k]);
+    return out;
+}
+
+}  // namespace gelf2
+}  // namespace fg

@@ -297,7 +297,10 @@ struct SuffixEnt {                      // 16 bytes: the four configured suffixe
 constexpr uint32_t kLtsvExtraLds = 768u + kSchemaLds * sizeof(SchemaEnt) + 4u * sizeof(SuffixEnt);
 
 struct LtsvFormat {
-    static constexpr bool kStageABitmap = true;
+    static constexpr uint32_t kClasses = 1;
+    static __device__ __forceinline__ void classify_store(const uint4& q, uint16_t* bm16, uint32_t chunk, uint32_t) {
+        bm16[chunk] = (uint16_t)mask16(q);
+    }
     LtsvDevCfg cfg;
     uint8_t* lds_digits;        // 768-byte digit buffer for dec2flt's slow path
     const SchemaEnt* schema;    // LDS mirror of the first kSchemaLds schema entries
@@ -492,7 +495,7 @@ struct LtsvFormat {
             if (r.status != L_OK) r.n_ent = 0;
         }
         bool overflow;
-        const uint32_t first = alloc_entries(t, r.n_ent, &overflow);
+        const uint32_t first = alloc_entries(t, r.n_ent, &overflow, c.ent_state);
         if (overflow) {
             r.status = FG_ST_OVERFLOW;
             r.n_ent = 0;

@@ -14,6 +14,7 @@
 // HBM sees only coalesced 1 KiB-per-wave-instruction reads, each byte once.
 #pragma once
 #include "fg_device.hpp"
+#include "fg_wave.hpp"
 
 namespace fg {
 
@@ -177,27 +178,31 @@ __device__ __forceinline__ void store_row(const DevTables& t, uint64_t li, const
 constexpr uint32_t kStashEntries = 48;
 constexpr uint32_t kStashWords = 2;  // u64 words per stashed entry (scratch is sized for this)
 
-// Wave-aggregated allocation of entry slots: returns this lane's first slot, or sets *overflow.
-__device__ __forceinline__ uint32_t alloc_entries(const DevTables& t, uint32_t n_ent, bool* overflow) {
+// Wave-aggregated allocation of entry slots out of the wave's reserved chunk (fg_wave.hpp wave_alloc): returns this lane's
+// first slot, or sets *overflow.  ent_state = the wave's two persistent LDS words.
+__device__ __forceinline__ uint32_t alloc_entries(const DevTables& t, uint32_t n_ent, bool* overflow, uint32_t* ent_state) {
     *overflow = false;
     if (!__any(n_ent != 0u)) return 0;  // wave-uniform; the common case of the no-SD corpus skips the scan
     uint32_t total;
-    uint32_t ex = wave_exclusive_sum(n_ent, &total);
-    unsigned long long slot0 = 0;
-    if (threadIdx.x == 0) slot0 = atomicAdd(t.ent_used, (unsigned long long)total);
-    slot0 = __shfl(slot0, 0, kWave);
-    unsigned long long mine = slot0 + ex;
-    if (n_ent != 0 && mine + n_ent > t.ent_cap) {
-        *overflow = true;
-        return 0;
+    const uint32_t ex = wave_exclusive_sum(n_ent, &total);
+    // lines whose slice still fits what is left of the wave's chunk stay there, the others open the next chunk
+    const uint32_t left = wv::wave_left(ent_state);
+    const unsigned long long nofit = __ballot(n_ent != 0u && ex + n_ent > left);
+    const uint32_t cut = nofit ? (uint32_t)__shfl((int)ex, (int)__builtin_ctzll(nofit), kWave) : total;
+    const wv::Slots s = wv::wave_alloc(t.ent_used, t.ent_cap, ent_state, total, cut, wv::alloc_chunk_for(t.ent_cap, gridDim.x));
+    if (s.overflow) {
+        *overflow = n_ent != 0u && ex >= s.cut;
+        if (*overflow) return 0;
     }
-    return (uint32_t)mine;
+    return s.at(ex);
 }
 
 // ---------------------------------------------------------------------------------------------
 // The persistent streaming loop.  F supplies
-//     static uint32_t F::mask16(const uint4&)                  stage-A byte class
-//     RowOut F::decode(const GroupCtx&)  (member, may use its own state)
+//     static constexpr uint32_t F::kClasses                                    stage-A class bitmaps kept in LDS (0..5)
+//     static void F::classify_store(const uint4& q, uint16_t* bm16, uint32_t chunk, uint32_t stride)
+//                                                                              16-bit class masks of a 16-byte chunk -> bm16[c * stride + chunk]
+//     RowOut F::decode(const GroupCtx&)  (member, may use its own state; called by all 64 lanes, converged)
 // ---------------------------------------------------------------------------------------------
 struct GroupCtx {
     const uint8_t* bytes;   // packed buffer (global)
@@ -209,6 +214,8 @@ struct GroupCtx {
     bool valid;             // this lane owns a line
     uint64_t* stash;        // the wave's entry stash (or null)
     uint32_t ablate;        // measurement build only
+    uint32_t* ent_state;    // the wave's entry-slot reservation (two LDS words that persist across groups, wv::wave_alloc)
+    unsigned long long* phase;  // measurement build only: ten format-specific phase clocks (lane 0 adds), else null
 };
 
 // Framing of the frames handed to the decoders (fg_decode_frames_device): what to strip from the
@@ -224,6 +231,7 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
                                                 unsigned long long* prof, uint64_t* stash_base, F& fmt, FrameArgs fr) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint16_t* bm16 = reinterpret_cast<uint16_t*>(smem + tile_cap + 64u);
+    const uint32_t bm_stride = tile_cap / 16u + 16u;  // u16 entries per class bitmap (F::kClasses of them, back to back)
     uint4* dst = reinterpret_cast<uint4*>(smem);
     const uint32_t lane = threadIdx.x;
     const uint64_t G = gridDim.x;
@@ -264,6 +272,9 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
         for (int k = 0; k < NB; ++k) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(lane * 16u + k * 1024u), 0, 0);
     };
 
+    // (the last 8 bytes of the 64-byte pad behind the tile: no tile read reaches them)
+    uint32_t* ent_state = reinterpret_cast<uint32_t*>(smem + tile_cap + 56u);
+    if (lane < 2u) ent_state[lane] = 0u;
     uint64_t g = blockIdx.x;
     if (g >= groups) return;
     uint64_t o0, o1, a0;
@@ -300,7 +311,7 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
                 uint32_t idx = k * kWave + lane;
                 uint4 q = make_uint4(v[k][0], v[k][1], v[k][2], v[k][3]);
                 dst[idx] = q;
-                if (F::kStageABitmap) bm16[idx] = (uint16_t)F::mask16(q);
+                F::classify_store(q, bm16, idx, bm_stride);
             }
         }
         if (nrow > (uint32_t)NB) {  // rare: bytes beyond the register window
@@ -320,7 +331,7 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
                 for (int k = 0; k < 4; ++k) {
                     const uint32_t idx = c0 + k * kWave + lane, ci = idx < last ? idx : last;
                     dst[ci] = w[k];
-                    if (F::kStageABitmap) bm16[ci] = (uint16_t)F::mask16(w[k]);
+                    F::classify_store(w[k], bm16, ci, bm_stride);
                 }
             }
         }
@@ -371,7 +382,7 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
             // case -- everything fits -- is kept apart so that it pays nothing for the loop.
             const bool fits0 = valid && (o1 - a0) <= (uint64_t)span;
             if (__ballot(valid && !fits0) == 0ull) {  // wave-uniform
-                GroupCtx c{bytes, smem, bm16, o0, e1, a0, span, valid, (ablate & 8u) ? nullptr : stash, ablate};
+                GroupCtx c{bytes, smem, bm16, o0, e1, a0, span, valid, (ablate & 8u) ? nullptr : stash, ablate, ent_state, PROF ? prof + 6 : nullptr};
                 pend = fmt.decode(c, t);
             } else {
                 uint64_t ta0 = a0;
@@ -383,7 +394,7 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
                     if (todo_m == 0ull) break;  // wave-uniform
                     bool now = fits;
                     if (fit_m == 0ull) now = todo && lane == (uint32_t)__builtin_ctzll(todo_m);  // longer than the tile: alone, from global
-                    GroupCtx c{bytes, smem, bm16, o0, e1, ta0, tspan, now, (ablate & 8u) ? nullptr : stash, ablate};
+                    GroupCtx c{bytes, smem, bm16, o0, e1, ta0, tspan, now, (ablate & 8u) ? nullptr : stash, ablate, ent_state, PROF ? prof + 6 : nullptr};
                     const RowOut r = fmt.decode(c, t);
                     if (now) pend = r;
                     todo = todo && !now;
@@ -415,7 +426,7 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
                             for (int k = 0; k < 2; ++k) {
                                 const uint32_t idx = c0 + k * kWave + lane, ci = idx < lastc ? idx : lastc;
                                 dst[ci] = w[k];
-                                if (F::kStageABitmap) bm16[ci] = (uint16_t)F::mask16(w[k]);
+                                F::classify_store(w[k], bm16, ci, bm_stride);
                             }
                         }
                     }
@@ -490,7 +501,8 @@ struct LaunchPlan {
 // memory.  FG_TILE_CAP / FG_LINES_PER_GROUP / FG_WAVES_PER_CU override (tuning, parity sweeps).
 template <class K>
 inline int plan_launch(K kernel, uint64_t n, uint64_t avg_len, uint32_t extra_lds, uint32_t max_tile, uint32_t stash_blocks,
-                       LaunchPlan* p, uint32_t max_lines = 64) {
+                       LaunchPlan* p, uint32_t max_lines = 64, uint32_t n_classes = 1,
+                       uint32_t (*extra_for)(uint32_t tile, uint32_t lines) = nullptr) {
     const uint64_t window = (uint64_t)kWindowKiB * 1024u;
     // (+6.25 % + 256 B over the average group: a few sigma for the corpora at hand; a longer group just takes
     //  another pass over a restaged tile, while every KiB of LDS saved is occupancy)
@@ -514,7 +526,8 @@ inline int plan_launch(K kernel, uint64_t n, uint64_t avg_len, uint32_t extra_ld
     }
     p->L = L;
     p->tile = tile;
-    p->lds = tile + 64u + (tile / 16u + 16u) * 2u + extra_lds;
+    // (extra_for: LDS a format needs as a function of the tile and the lines per group, e.g. per-item arrays)
+    p->lds = tile + 64u + (tile / 16u + 16u) * 2u * (n_classes ? n_classes : 1u) + extra_lds + (extra_for ? extra_for(tile, L) : 0u);
     p->groups = (n + L - 1) / L;
     int dev = 0, cus = 0;  // (per call: a process may drive several devices)
     if (hipGetDevice(&dev) != hipSuccess ||
@@ -536,7 +549,7 @@ inline int plan_launch(K kernel, uint64_t n, uint64_t avg_len, uint32_t extra_ld
 // FG_PROF=1: run the measurement build of a kernel synchronously and print the per-phase split.
 struct ProfRun {
     unsigned long long* d = nullptr;
-    unsigned long long h[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long h[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // [6..15]: format-specific phase clocks (GroupCtx::phase)
     bool begin(hipStream_t stream) {
         if (const char* e = getenv("FG_ABLATE")) h[5] = (unsigned long long)atoi(e);
         if (hipMalloc((void**)&d, sizeof(h)) != hipSuccess) return false;
@@ -552,6 +565,13 @@ struct ProfRun {
                 "[fg prof] %s: grid %u x64, L %u, tile %u, iters/wave %.1f | cycles per iteration: wait %.0f, stageA %.0f, "
                 "stores+prefetch-issue %.0f, stageB %.0f\n",
                 name, p.blocks, p.L, p.tile, it / (double)(p.blocks ? p.blocks : 1), h[0] / it, h[1] / it, h[2] / it, h[3] / it);
+        bool any_phase = false;
+        for (int k = 6; k < 16; ++k) any_phase = any_phase || h[k] != 0;
+        if (any_phase) {
+            fprintf(stderr, "[fg prof] %s stage-B phases (cycles per iteration):", name);
+            for (int k = 6; k < 16; ++k) fprintf(stderr, " %.0f", h[k] / it);
+            fprintf(stderr, "\n");
+        }
     }
 };
 }  // namespace fg

@@ -744,8 +744,8 @@ constexpr uint32_t kShortSdTail = 64;  // bytes after the header up to which a l
 struct Rfc5424Format {
     // no stage-A bitmap: the fast path classifies the header bytes itself, the SD walker's
     // quote bitmap is built on demand (rebuild_bitmap) for groups that hold SD lines
-    static constexpr bool kStageABitmap = false;
-    static __device__ __forceinline__ uint32_t mask16(const uint4&) { return 0u; }
+    static constexpr uint32_t kClasses = 0;
+    static __device__ __forceinline__ void classify_store(const uint4&, uint16_t*, uint32_t, uint32_t) {}
 
     __device__ __forceinline__ RowOut decode(const GroupCtx& c, const DevTables& t) const {
     const uint8_t* __restrict__ bytes = c.bytes;
@@ -842,7 +842,7 @@ struct Rfc5424Format {
     uint32_t first = 0;
     {
         bool overflow;
-        const uint32_t mine = alloc_entries(t, r.n_ent, &overflow);
+        const uint32_t mine = alloc_entries(t, r.n_ent, &overflow, c.ent_state);
         if (overflow) {
             r.status = FG_ST_OVERFLOW;
             r.n_ent = 0;

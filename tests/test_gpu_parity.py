@@ -231,7 +231,9 @@ def test_entry_workloads_at_scale_replicas_and_checksums(rfc, oracle, shape):
     used = int(tables.column("ent_used").view(torch.int64)[0].item())
     cnt = tables.column("ent_count").view(torch.int32).view(reps, n)
     per_rep = int(cnt[0].sum().item())
-    assert used == per_rep * reps and per_rep > 0
+    # (slots are reserved in per-wave chunks of at most 1024: `used` counts the reserved slots -- the entries plus what every wave
+    #  left of its last chunk)
+    assert per_rep > 0 and per_rep * reps <= used <= per_rep * reps * 1.02 + 2_500_000
     first = tables.column("ent_first").view(torch.int32).view(reps, n).to(torch.int64)
     name = tables.column("ent_name").view(torch.int64)[:used]
     val = tables.column("ent_val").view(torch.int64)[:used]
@@ -255,7 +257,8 @@ def test_host_path_slices_and_entries(rfc, oracle):
     oblob, ooffs = oracle.decode_batch(RFC5424, data, offsets)
     (blob, offs), tab = host_path_blob(rfc, data, offsets)
     assert_same(blob, offs, oblob, ooffs, lines)
-    assert tab.ent_used == int(tab.a["ent_count"].sum())
+    total = int(tab.a["ent_count"].sum())
+    assert total <= tab.ent_used <= total * 1.02 + 2_500_000  # (reserved in per-wave chunks)
 
 
 # ------------------------------------------------------------------------------------- LTSV

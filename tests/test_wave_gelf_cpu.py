@@ -1,0 +1,145 @@
+"""CPU: the wave-cooperative GELF tokeniser (flowgger_amd/csrc/fg_gelf2.hpp) -- the SAME source the gfx950 kernel is built
+from -- run lane for lane over the fiber emulation of a wavefront (tests/native/fg_wave_emu.hpp) against the oracle.
+
+The fast form either handles a line (then its row and its entries must be byte-identical to the oracle's Record) or hands it
+back for the exact general form (allowed for anything that is not a flat object in GELF producers' spelling -- but NOT for
+the well-formed corpus, and never with a wrong result)."""
+import numpy as np
+import pytest
+
+from flowgger_amd import synth
+
+GELF = 2
+
+
+@pytest.fixture(scope="module")
+def wave():
+    import wave_binding
+
+    return wave_binding.WaveHost()
+
+
+def check(wave, oracle, lines, must_handle=None, **geom):
+    lines = [ln.encode("utf-8", "surrogateescape") if isinstance(ln, str) else ln for ln in lines]
+    data, offsets = synth.pack(lines) if lines else (np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+    pad = np.concatenate([data, np.zeros(64, np.uint8)])
+    tab, handled = wave.gelf(pad, offsets, **geom)
+    oblob, ooffs = oracle.decode_batch(GELF, data, offsets)
+    blob, offs = tab.serialize(GELF, pad, offsets)
+    for i in np.nonzero(handled)[0]:
+        got = blob[int(offs[i]):int(offs[i + 1])].tobytes()
+        want = oblob[int(ooffs[i]):int(ooffs[i + 1])].tobytes()
+        assert got == want, f"line {i}: {lines[i][:300]!r}\n  wave   {got[:300]!r}\n  oracle {want[:300]!r}"
+    # entry slices of handled lines never overlap and stay inside the allocated range
+    used = tab.ent_used
+    seen = np.zeros(used + 1, np.int32)
+    for i in np.nonzero(handled)[0]:
+        f, c = int(tab.a["ent_first"][i]), int(tab.a["ent_count"][i])
+        assert f + c <= used
+        seen[f:f + c] += 1
+    assert seen.max(initial=0) <= 1
+    if must_handle is not None:
+        for i in must_handle:
+            assert handled[i], f"the fast form handed back a line it must handle: {lines[i][:200]!r}"
+    return handled
+
+
+@pytest.mark.parametrize("geom", [dict(lines_per_group=32, tile_cap=12288), dict(lines_per_group=64, tile_cap=22528),
+                                  dict(lines_per_group=16, tile_cap=6144), dict(lines_per_group=7, tile_cap=4096),
+                                  dict(lines_per_group=48, tile_cap=16384)])
+def test_corpus(wave, oracle, geom):
+    lines = synth.gelf_lines(6000)
+    handled = check(wave, oracle, lines, **geom)
+    # BASELINE configs[2] corpus: everything but the deliberately malformed lines (1 %) is fast-form material
+    assert handled.mean() > 0.985, handled.mean()
+
+
+def test_semantics(wave, oracle):
+    many = "{" + ",".join(f'"k{(i * 7919) % 100:03d}":{i}' for i in range(100)) + ',"host":"h"}'
+    sixty = "{" + ",".join(f'"k{(i * 31) % 60:02d}":{i}' for i in range(60)) + ',"host":"h"}'
+    lines = [
+        '{"host":"h","b":1,"a":2,"_c":null,"B":true,"a":-3}', "[1,2]", '{"host":"h"} x', '{"a":1}', '{"host":1}',
+        '{"host":"h","level":-1}', '{"host":"h","level":1.0}', '{"host":"h","version":1}', '{"host":"h","short_message":1}',
+        '{"host":"h","full_message":null}', '{"host":"h","x":{"y":1}}', '{"host":"h\\u00e9\\n\\ud83d\\ude00","timestamp":1}',
+        '{"host":"a\nb","timestamp":1}', '{"host":"a\tb"}', '{"host":1,"_x":[]}', "", " ", "null", "true", '"str"', "12", "-",
+        "{}", "{ }", '{"host":"h",}', '{,"host":"h"}', '{"host" "h"}', '{"host":"h"', '{"host":"h"}}', "[", "[1,]", "[,1]",
+        '{"host":"h","a":[1,{"b":[true,false,null,"x",-1.5e3]}],"c":1}', '{"host":"h","a":[1 2]}', '{"host":"h","a":{"b":1,}}',
+        '{"host":"h","a":tru}', '{"host":"h","a":nul}', '{"host":"h","a":falsE}', '{"host":"h","a":01}', '{"host":"h","a":1.}',
+        '{"host":"h","a":-}', '{"host":"h","a":1e}', '{"host":"h","a":1e999}', '{"host":"h","a":-1e999}', '{"host":"h","a":1e-999}',
+        '{"host":"h","a":18446744073709551615,"b":18446744073709551616,"c":-9223372036854775808,"d":-9223372036854775809}',
+        '{"host":"h","a":0.1,"b":1385053862.3072,"c":123456789012345678901234567890.5e-5,"d":-0,"e":-0.0,"f":1E+2}',
+        '{"host":"h","timestamp":-5}', '{"host":"h","timestamp":18446744073709551615}', '{"host":"h","timestamp":true}',
+        '{"h\\u006fst":"escaped key","_a\\"b":"q","_a\\u0022b":"dup wins","a\\\\b":1,"a\\/b":2,"a\\tb":3}',
+        '{"host":"h","s":"\\ud83d"}', '{"host":"h","s":"\\ud83d\\u0041"}', '{"host":"h","s":"\\udc00"}', '{"host":"h","s":"\\u12g4"}',
+        '{"host":"h","s":"\\x"}', '{"host":"h","s":"abc', '{"host":"h","s":"\\', '{"host":"h","s":"\\u00"}', '{"host":"h","s":"\\u0000"}',
+        '{"host":"h","version":"1.0"}', '{"host":"h","version":"1.\\u0031"}', '{"host":"h","version":"1.2"}', '{"host":"h","level":7}',
+        '{"host":"h","level":8}', '{"host":"h","level":"1"}', '{"_":1,"__":2,"":3,"host":"h"}',
+        '{"host":"line1\nline2\nline3","short_message":"with\nnewline","_k\ney":"v"}', '{"host":"a\nb",\n"x":1}', '{"host":"a\\\nb"}',
+        '{"host":"a\nb\\\nc","k\\\n":"v\\\n"}', '{"host":"a\nb","s":"\\ud83d\n\\ude00"}', '{"host":"a\rb"}', '{"host":"a\x00b"}',
+        '\n{"host":"h"}\n', '{"host":"h","a":"x\x7fy"}', '{"host":"h","a":"caf\u00e9 \u4e2d\u6587 \U0001F600"}',
+        many, sixty, '{"host":"h","big":' + "9" * 400 + "}", '{"host":"h","big":0.' + "9" * 400 + "}",
+        '{"host":"h","e":1e2147483648}', '{"host":"h","e":0e2147483648}', '{"host":"h","e":1e-2147483649}',
+        '{"zz":[],"host":5}', '{"timestamp":"x","level":99,"host":"h"}', '{"version":"9","timestamp":"x","host":"h"}',
+        # spacing, ordering and duplicates the fast form must get right itself
+        ' {  "host" : "h" ,  "b" :  1 , "a":"x"  }  ', '{"host":"h","dup":1,"dup":2,"dup":"three"}', '{"host":"a","host":"b","host":"c"}',
+        '{"abcdefg1":1,"abcdefg2":2,"host":"h"}', '{"abcdefgh":1,"abcdefgh":2,"host":"h"}', '{"abcdefg":1,"abcdefgh":2,"host":"h"}',
+        '{"level":3,"level":"bad","host":"h"}', '{"level":"bad","level":3,"host":"h"}', '{"host":"h","version":"1.1","version":7}',
+        '{"timestamp":1.5,"timestamp":2,"host":"h"}', '{"host":"h","q":"say \\"hi\\"","p":"back\\\\slash","r":"a\\\\"}',
+        '{"host":"h","k":"v\\\\","l":"\\\\\\"x"}', '{"host":"h","a":"}","b":",","c":"{","d":"]:["}', '{"host":"h","a":"x"x}',
+        '{"host":"h" "a":1}', '{"host":"h","a":1 2}', '{"host":"h","a": }', '{"host":"h","":""}', '{"host":"h","a":"\\u00e9\\ud83d\\ude00"}',
+        '{"host":"h","a":truex}', '{"host":"h","a":1,"b"}', '{"host":"h","a":1,"b":}', '{"host":"h","a":1,:2}', '{"host":"h"},',
+        '{"host":"h","a":1.5e3,"b":-0.0001,"c":1e-7,"d":12345678901234567890,"e":0}', '{"host":"h","level":0}', '{"host":"h","level":007}',
+        '{"host":"h","x":"' + "y" * 3000 + '"}', '{"' + "k" * 255 + '":1,"host":"h"}', '{"' + "k" * 256 + '":1,"host":"h"}',
+    ]
+    handled = check(wave, oracle, lines)
+    by_line = dict(zip(lines, handled))  # (keyed by the str spelling above)
+    # producers' spelling is fast-form material
+    for ln in ('{"host":"h","b":1,"a":2,"_c":null,"B":true,"a":-3}', "{}", ' {  "host" : "h" ,  "b" :  1 , "a":"x"  }  ',
+               '{"host":"h","dup":1,"dup":2,"dup":"three"}', '{"level":"bad","level":3,"host":"h"}', sixty,
+               '{"host":"h","q":"say \\"hi\\"","p":"back\\\\slash","r":"a\\\\"}', '{"host":"h","a":"}","b":",","c":"{","d":"]:["}',
+               '{"timestamp":"x","level":99,"host":"h"}', '{"host":"h","level":8}'):
+        assert by_line[ln], ln
+    # ... and these are not: they must be handed back, never guessed
+    for ln in ('{"host":"h","x":{"y":1}}', '{"abcdefg1":1,"abcdefg2":2,"host":"h"}', '{"host":"a\nb","timestamp":1}', many,
+               '{"host":"h","version":"1.\\u0031"}', '{"host":"h","a":01}'):
+        assert not by_line[ln], ln
+
+
+def test_odd_quotes_do_not_leak_into_the_next_line(wave, oracle):
+    """A line with an unbalanced quote flips the raw string parity of everything behind it in the tile: the in-string state
+    must start afresh at every line (the toggle pass)."""
+    good = ['{"host":"h%d","a":"x,y","n":%d}' % (i, i) for i in range(40)]
+    bad = ['{"host":"h","s":"abc', '"', '{"a":"\\"}', 'x"y"z"', '{"host":"h"}"']
+    lines = []
+    for i, g in enumerate(good):
+        lines.append(g)
+        if i % 3 == 0:
+            lines.append(bad[(i // 3) % len(bad)])
+    handled = check(wave, oracle, lines, must_handle=[i for i, ln in enumerate(lines) if ln in good])
+    assert handled.sum() >= len(good)
+
+
+def test_fuzz_mutations(wave, oracle):
+    rng = np.random.default_rng(808)
+    base = synth.gelf_lines(4000, invalid_frac=0)
+    alphabet = [b'"', b"\\", b",", b":", b"{", b"}", b"[", b"]", b" ", b"\n", b"\t", b"0", b"-", b".", b"e", b"u", b"n",
+                b"true", b"null", b"", b"\\u00e9", b"\\n", "é".encode(), b"\x01", b"_"]
+    lines = []
+    for ln in base:
+        b = bytearray(ln)
+        for _ in range(int(rng.integers(1, 4))):
+            pos = int(rng.integers(0, len(b)))
+            if b[pos] >= 0x80:
+                continue
+            b[pos:pos + 1] = alphabet[int(rng.integers(0, len(alphabet)))]
+        lines.append(bytes(b))
+    check(wave, oracle, lines)
+    check(wave, oracle, lines, lines_per_group=64, tile_cap=24576)
+
+
+def test_ragged_groups_and_lines_outside_the_tile(wave, oracle):
+    ok = '{"host":"h","a":%d,"s":"%s"}'
+    lines = [ok % (i, "z" * ((i * 37) % 900)) for i in range(150)] + [""] * 5 + [ok % (1, "q" * 20000)] + [ok % (2, "")] * 3
+    check(wave, oracle, lines, lines_per_group=32, tile_cap=8192)
+    check(wave, oracle, lines[:1])
+    check(wave, oracle, [])
