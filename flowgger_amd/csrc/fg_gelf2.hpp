@@ -98,6 +98,7 @@ struct Lds {
     uint32_t* l_row;         // [lines][8]: ts lo, ts hi, host off, host len, msg off, msg len, full off, full len
     uint32_t* tile_ents;     // [1] entries parked in the stash
     double* p10;             // [23] 10^0 .. 10^22 (exact): the number parser's divisors without a trip to global memory
+    uint32_t* dw;            // [16 + 8] digit weights of a dword by its 4-bit digit mask (parse_num24), then 10^0 .. 10^4
     uint32_t* ent_state;     // the wave's entry-slot reservation (persists across tiles; set by the caller, wv::wave_alloc)
     uint32_t alloc_chunk;    // its reservation size
     uint32_t item_cap, ent_cap;
@@ -111,7 +112,7 @@ FG_WVH uint32_t ent_cap_for(uint32_t tile_cap, uint32_t lines) { return up8(tile
 FG_WVH uint32_t extra_bytes(uint32_t tile_cap, uint32_t lines) {
     const uint32_t words = tile_cap / 64u + 2u;
     return up8(words) + up8(words * 2u) + up8(item_cap_for(tile_cap) * 2u + 16u) + 64u * 8u + 64u * 4u + ent_cap_for(tile_cap, lines) * 18u + 16u +
-           lines * (7u * 4u + 32u) + 23u * 8u + 64u;
+           lines * (7u * 4u + 32u) + 23u * 8u + 24u * 4u + 64u;
 }
 FG_WV Lds carve(const uint8_t* tile, uint16_t* bm16, uint32_t tile_cap, uint8_t* extra, uint32_t lines) {
     Lds L;
@@ -136,6 +137,7 @@ FG_WV Lds carve(const uint8_t* tile, uint16_t* bm16, uint32_t tile_cap, uint8_t*
     L.l_eoff = reinterpret_cast<uint32_t*>(p); p += lines * 4u;
     L.l_sev = reinterpret_cast<uint32_t*>(p); p += lines * 4u;
     L.tile_ents = reinterpret_cast<uint32_t*>(p); p += 8u;
+    L.dw = reinterpret_cast<uint32_t*>(p); p += 24u * 4u;
     L.s_tf = reinterpret_cast<uint16_t*>(p); p += up8(L.ent_cap * 2u);
     L.wcnt = reinterpret_cast<uint16_t*>(p); p += up8(words * 2u);
     L.items = reinterpret_cast<uint16_t*>(p); p += up8(L.item_cap * 2u + 16u);
@@ -144,14 +146,33 @@ FG_WV Lds carve(const uint8_t* tile, uint16_t* bm16, uint32_t tile_cap, uint8_t*
     L.alloc_chunk = 64u;
     return L;
 }
-// once per wave, before the first tile: the powers of ten (exact doubles up to 10^22)
+// once per wave, before the first tile: the powers of ten (exact doubles up to 10^22) and the digit-weight table
 FG_WV void init_lds(const Lds& L) {
-    if (wv::lane() == 0) {
+    const uint32_t lane = wv::lane();
+    if (lane == 0) {
         double v = 1.0;
         for (uint32_t k = 0; k < 23u; ++k) {
             L.p10[k] = v;
             v *= 10.0;
         }
+    }
+    if (lane < 16u) {
+        // byte i of entry m: 10^(digit bytes above i) when bit i of m is set, else 0 -- except 1000 (m = 15, byte 0), which does
+        // not fit a byte and is added separately
+        uint32_t wgt = 0, above = 0;
+        for (int i = 3; i >= 0; --i) {
+            if ((lane >> i) & 1u) {
+                const uint32_t p = above == 0 ? 1u : above == 1 ? 10u : above == 2 ? 100u : 0u;
+                wgt |= p << (8 * i);
+                ++above;
+            }
+        }
+        L.dw[lane] = wgt;
+    }
+    if (lane >= 16u && lane < 21u) {
+        uint32_t p = 1;
+        for (uint32_t k = 16u; k < lane; ++k) p *= 10u;
+        L.dw[lane] = p;
     }
     wv::sync();
 }
@@ -250,24 +271,19 @@ struct TokReader {
     FG_WV explicit TokReader(const wv::Bytes& t) : T(t) {}
     FG_WV uint32_t byte(uint32_t i) const { return T.byte(i); }
 };
-FG_WV uint32_t p10_small(uint32_t c) {  // 10^c, c <= 6
-    uint32_t r = (c & 1u) ? 10u : 1u;
-    r = (c & 2u) ? wv::mad24(r, 100u, 0u) : r;
-    r = (c & 4u) ? wv::mad24(r, 10000u, 0u) : r;
-    return r;
-}
 // serde_json 0.8 number (fg_numparse.hpp json_number) for the everyday shape  -?D+(.D+)?  with at most 19 digits, on a token
-// of n <= 24 bytes held in registers: class masks by SWAR, then Horner in 24-bit multiply-adds over STATIC byte positions (four
-// chunks of six).  false = not that shape: the caller runs json_number, which owns every error.
-FG_WV bool parse_num24(const uint32_t w[6], uint32_t n, const double* p10, uint32_t* kind, uint64_t* bits) {
+// of n <= 24 bytes held in registers.  Class masks by SWAR; then every dword's digits are folded with ONE v_dot4 against a
+// weight vector looked up by the dword's 4-bit digit mask (a '.' or the sign inside the dword gets weight 0), and the six
+// partial values are chained with 10^(digits of the dword).  false = not that shape: the caller runs json_number, which owns
+// every error.  dwt = Lds::dw.
+FG_WV bool parse_num24(const uint32_t w[6], uint32_t n, const double* p10, const uint32_t* dwt, uint32_t* kind, uint64_t* bits) {
     const bool neg = (w[0] & 0xFFu) == '-';
-    uint32_t ndm = 0, dtm = 0;
+    uint32_t x[6], ndm = 0;
 #pragma unroll
     for (uint32_t k = 0; k < 6; ++k) {
-        const uint32_t x = w[k] ^ 0x30303030u;
-        const uint32_t nd = (x | ((x & 0x7F7F7F7Fu) + 0x76767676u)) & 0x80808080u;  // bit 7: the byte is not a digit
+        x[k] = w[k] ^ 0x30303030u;
+        const uint32_t nd = (x[k] | ((x[k] & 0x7F7F7F7Fu) + 0x76767676u)) & 0x80808080u;  // bit 7: the byte is not a digit
         ndm |= wv::udot4(nd >> 7, 0x08040201u, 0u) << (4u * k);
-        dtm |= wv::udot4(wv::eq_flags(w[k], 0x2E2E2E2Eu) >> 7, 0x08040201u, 0u) << (4u * k);
     }
     const uint32_t tok = (1u << n) - 1u;  // n <= 24
     const uint32_t body = tok & ~(neg ? 1u : 0u);
@@ -278,21 +294,20 @@ FG_WV bool parse_num24(const uint32_t w[6], uint32_t n, const double* p10, uint3
     const uint32_t dp = has_dot ? wv::ctz32(nondig) : n;
     const uint32_t ni = dp - o, nf = has_dot ? n - dp - 1u : 0u;
     const uint32_t c0 = neg ? ((w[0] >> 8) & 0xFFu) : (w[0] & 0xFFu);
-    const bool ok = (nondig & (nondig - 1u)) == 0u && (nondig & ~dtm) == 0u && nd_total >= 1u && nd_total <= 19u && dp >= o + 1u &&
-                    (!has_dot || nf >= 1u) && !(c0 == '0' && ni > 1u);
+    // the one non-digit must be a '.': its byte, picked out of the six dwords
+    uint32_t dsel = w[0];
+#pragma unroll
+    for (uint32_t k = 1; k < 6; ++k) dsel = (dp >> 2) == k ? w[k] : dsel;
+    const bool dot_ok = !has_dot || ((dsel >> (8u * (dp & 3u))) & 0xFFu) == '.';
+    const bool ok = (nondig & (nondig - 1u)) == 0u && dot_ok && nd_total >= 1u && nd_total <= 19u && dp >= o + 1u && (!has_dot || nf >= 1u) &&
+                    !(c0 == '0' && ni > 1u);
     if (!ok) return false;
     uint64_t sig = 0;
 #pragma unroll
-    for (uint32_t c = 0; c < 4; ++c) {
-        uint32_t acc = 0, cnt = 0;
-#pragma unroll
-        for (uint32_t i = 6u * c; i < 6u * c + 6u; ++i) {
-            const uint32_t bit = (digits >> i) & 1u;
-            const uint32_t d = (wv::bfe(w[i >> 2], 8u * (i & 3u), 8u) - 48u) & (0u - bit);
-            acc = wv::mad24(acc, wv::mad24(bit, 9u, 1u), d);
-            cnt += bit;
-        }
-        sig = sig * (uint64_t)p10_small(cnt) + acc;
+    for (uint32_t k = 0; k < 6; ++k) {
+        const uint32_t m = (digits >> (4u * k)) & 15u;
+        const uint32_t v = wv::udot4(x[k], dwt[m], m == 15u ? (x[k] & 0xFFu) * 1000u : 0u);
+        sig = sig * (uint64_t)dwt[16u + wv::popc32(m)] + v;
     }
     if (has_dot) {
         // visit_f64_from_parts: f = sig as f64; f /= POW10[nf]   (nf <= 18 here: the divisor comes from LDS)
@@ -580,7 +595,7 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
                         const uint32_t cv = wv6[0] & 0xFFu;
                         if (cv == '-' || (cv - '0') <= 9u) {
                             uint32_t k2 = 0;
-                            bool good = n <= 24u && parse_num24(wv6, n, L.p10, &k2, &bits);
+                            bool good = n <= 24u && parse_num24(wv6, n, L.p10, L.dw, &k2, &bits);
                             if (!good) {  // exponents, 20+ digits, malformed: the byte-wise parser decides
                                 TokReader rd(T);
                                 uint32_t endp = 0;

@@ -102,3 +102,28 @@ extern "C" int fgw_gelf_decode(const uint8_t* bytes, uint64_t nbytes, const uint
         return -1;
     }
 }
+
+// the register-resident number parser of the GELF fast form on ONE token (unit test hook): returns 1 = parsed (kind / bits as
+// serde_json 0.8 would give), 0 = "not the everyday shape" (the kernel then runs the byte-wise json_number)
+extern "C" int fgw_parse_num24(const uint8_t* tok, uint32_t n, uint32_t* kind, uint64_t* bits) {
+    using namespace fg;
+    if (n == 0 || n > 24) return 0;
+    uint32_t w[6] = {0, 0, 0, 0, 0, 0};
+    uint8_t buf[24];
+    memset(buf, 0xA5, sizeof(buf));  // garbage behind the token, as in the tile
+    memcpy(buf, tok, n);
+    memcpy(w, buf, 24);
+    static double p10[23];
+    static uint32_t dw[24];
+    static bool init = false;
+    if (!init) {
+        std::vector<uint64_t> lds(4096);
+        gelf2::Lds L = gelf2::carve(reinterpret_cast<uint8_t*>(lds.data()), reinterpret_cast<uint16_t*>(lds.data() + 1024), 4096,
+                                    reinterpret_cast<uint8_t*>(lds.data() + 2048), 4);
+        emu::run_wave([&]() { gelf2::init_lds(L); });
+        memcpy(p10, L.p10, sizeof(p10));
+        memcpy(dw, L.dw, sizeof(dw));
+        init = true;
+    }
+    return gelf2::parse_num24(w, n, p10, dw, kind, bits) ? 1 : 0;
+}

@@ -143,3 +143,36 @@ def test_ragged_groups_and_lines_outside_the_tile(wave, oracle):
     check(wave, oracle, lines, lines_per_group=32, tile_cap=8192)
     check(wave, oracle, lines[:1])
     check(wave, oracle, [])
+
+
+def test_register_number_parser_matches_serde_json(wave, oracle):
+    """parse_num24 (the v_dot4 digit fold on a token held in registers) against the oracle's serde_json 0.8 number scanner:
+    identical kind and bits whenever it accepts, and it must accept the everyday shapes (else the kernel silently falls back to
+    the byte-wise parser and the fast form is not fast)."""
+    import ctypes as C
+
+    rng = np.random.default_rng(24)
+    toks = ["0", "-0", "7", "42", "-1", "8080", "65535", "4294967295", "4294967296", "9999999999999999999", "1234567890123456789",
+            "-9223372036854775808", "-9223372036854775809", "-9223372036854775807", "18446744073709551615", "0.5", "-0.5", "0.0",
+            "1385053862.3072", "1438790025.637824", "123456789.123456789", "0.000001", "99999.99999", "1.0", "-12345.678",
+            "3.141592653589793", "0.1234567890123456789", "1234567890.123456789", "12.5", "100000000000000000.5"]
+    for _ in range(3000):
+        ni, nf = int(rng.integers(1, 20)), int(rng.integers(0, 19))
+        s = ("-" if rng.random() < 0.3 else "") + str(int(rng.integers(1, 10))) + "".join(str(int(d)) for d in rng.integers(0, 10, ni - 1))
+        if rng.random() < 0.5 and nf:
+            s += "." + "".join(str(int(d)) for d in rng.integers(0, 10, nf))
+        toks.append(s[:24])
+    odd = ["01", "1.", ".5", "-", "1e5", "1E-3", "1.5e3", "--1", "1-", "1..2", "1.2.3", "+1", "0x10", "12a", "1 ", "00", "-01", "0.5.", "-.5"]
+    accepted = 0
+    for t in toks + odd:
+        b = t.encode()
+        kind, bits = C.c_uint32(), C.c_uint64()
+        ok = wave.lib.fgw_parse_num24(b, len(b), C.byref(kind), C.byref(bits))
+        want = oracle.json_number(t)
+        if ok:
+            accepted += 1
+            assert want is not None and (kind.value, bits.value) == want, (t, kind.value, hex(bits.value), want)
+        elif t in toks:
+            digits = sum(ch.isdigit() for ch in t)
+            assert digits > 19, f"everyday shape rejected: {t}"
+    assert accepted >= sum(1 for t in toks if sum(ch.isdigit() for ch in t) <= 19)
