@@ -77,6 +77,8 @@ struct fg_ctx {
     // parse and the copy into the entry table (allocated on the first decode; 8 waves on every CU)
     uint64_t* d_stash = nullptr;
     uint32_t stash_blocks = 0;
+    uint32_t* d_pending = nullptr;  // ring of kPendingRing hand-over words (DevTables::pending), zeroed once
+    uint32_t epoch = 0;             // launch counter of this ctx
     uint8_t* d_frame = nullptr;  // fg_frame_device scratch (delimiter / UTF-8 masks, block counts)
     uint64_t d_frame_cap = 0;
     uint8_t* d_bad = nullptr;    // fg_frame_decode_batch: per-frame UTF-8 verdicts
@@ -189,6 +191,8 @@ fg::DevTables to_dev(const fg_tables& t) {
     d.ent_type = t.ent_type;
     d.ent_flags = t.ent_flags;
     d.ent_used = (unsigned long long*)t.ent_used;
+    d.pending = nullptr;
+    d.epoch = 0;
     return d;
 }
 
@@ -439,6 +443,7 @@ void fg_destroy(fg_ctx* ctx) {
     if (ctx->d_tab) (void)hipFree(ctx->d_tab);
     if (ctx->d_cfg) (void)hipFree(ctx->d_cfg);
     if (ctx->d_stash) (void)hipFree(ctx->d_stash);
+    if (ctx->d_pending) (void)hipFree(ctx->d_pending);
     if (ctx->d_frame) (void)hipFree(ctx->d_frame);
     if (ctx->d_bad) (void)hipFree(ctx->d_bad);
     if (ctx->d_enc) (void)hipFree(ctx->d_enc);
@@ -553,6 +558,15 @@ static int decode_frames_impl(fg_ctx* ctx, fg_format fmt, fg_framing framing, co
         FG_HIP(ctx, hipMalloc((void**)&ctx->d_stash, fg_stash_bytes(blocks)));
         ctx->stash_blocks = blocks;
     }
+    constexpr uint32_t kPendingRing = 1024;
+    if (!ctx->d_pending) {
+        FG_HIP(ctx, hipMalloc((void**)&ctx->d_pending, kPendingRing * sizeof(uint32_t)));
+        FG_HIP(ctx, hipMemset(ctx->d_pending, 0, kPendingRing * sizeof(uint32_t)));
+    }
+    ctx->epoch += 1u;
+    if (ctx->epoch == 0u) ctx->epoch = 1u;  // (0 = the ring's initial content: never a valid epoch)
+    dt.epoch = ctx->epoch;
+    dt.pending = ctx->d_pending + (ctx->epoch % kPendingRing);
     if (ctx->timing) FG_HIP(ctx, hipEventRecord(ctx->ev0, s));
     int rc;
     const uint64_t avg_len = (span_bytes + n - 1) / n;

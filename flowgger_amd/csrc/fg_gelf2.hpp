@@ -345,8 +345,9 @@ template <bool PROF = false>
 FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base, uint32_t len, const DevTables& t,
                           unsigned long long* phase = nullptr) {
     const uint32_t lane = wv::lane();
-    // measurement build: cycles of  0 word pass  1 line pass  2 item parse  3 rank  4 dispatch  5 verdict + stash  6 copy-out + rows
-    uint64_t pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tk = PROF ? wv::clock() : 0;
+    // measurement build: cycles of  0 word pass  1 line pass  2 item parse (rest)  3 rank  4 dispatch  5 verdict + stash  6 copy-out + rows
+    //                               7 item: fetch + line lookup  8 item: windows + delimiting  9 item: value
+    uint64_t pc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tk = PROF ? wv::clock() : 0;
     auto tick = [&](int k) {
 #if defined(__HIP_DEVICE_COMPILE__) && defined(FG_ASM_MARKS)
         asm volatile("; FGMARK tick %0" ::"n"(0));
@@ -382,8 +383,7 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
             const uint64_t b = B[w1 - 1u];
             last_odd = b == ~0ull ? 0u : (wv::clz64(~b) & 1u);
         }
-        uint32_t cin = wv::shfl_up(last_odd, 1u);
-        if (lane == 0) cin = 0;
+        uint32_t cin = wv::shfl_up1(last_odd, 0u);
         for (uint32_t w = w0; w < w1; ++w) {
             const uint64_t q = Q[w], b = B[w];
             chain = chain || b == ~0ull;
@@ -408,8 +408,7 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
             const uint64_t qr = Q[base >> 6];
             rk = (uint32_t)L.wpar[base >> 6] ^ (wv::popc64(qr & below(base & 63u)) & 1u);
         }
-        uint32_t rprev = wv::shfl_up(valid ? rk : 0u, 1u);
-        if (lane == 0) rprev = 0;
+        const uint32_t rprev = wv::shfl_up1(valid ? rk : 0u, 0u);
         const bool flip = valid && (rk ^ rprev) != 0u;
         use_t = wv::any(flip);
         if (use_t) {  // rare for GELF: a line with an odd number of quotes came before
@@ -497,7 +496,7 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
     uint32_t lb = valid_m ? wv::ctz64(valid_m) : wv::kLanes;
     const uint32_t lend = valid_m ? 64u - wv::clz64(valid_m) : 0u;  // one past the last valid lane
     while (lb < lend) {
-        const uint32_t fi_lb = wv::shfl(fi, lb);
+        const uint32_t fi_lb = wv::bcast(fi, lb);
         const bool over = lane >= lb && lane < lend && (!valid || (fe - fi_lb) > wv::kLanes);
         const uint64_t over_m = wv::ballot(over);
         const uint32_t le = over_m ? wv::ctz64(over_m) : lend;
@@ -505,7 +504,7 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
             lb = lb + 1u;
             continue;
         }
-        const uint32_t n_items = wv::shfl(fe, le - 1u) - fi_lb;
+        const uint32_t n_items = wv::bcast(fe, le - 1u) - fi_lb;
 
         // ---- the item of this lane ----
         const uint32_t jj = lane;
@@ -517,6 +516,7 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
         const uint32_t ls = se & 0xFFFFu, le_ = se >> 16;
         const uint32_t kfi = (ff & 0xFFFFu) - fi_lb, kfe = (ff >> 16) - fi_lb;  // the line's items: lanes [kfi, kfe)
         act = act && !(L.l_flags[k] & LF_BAIL);
+        tick(7);
         bool member = false;
         uint64_t key = ~0ull, bits = 0;
         uint32_t key_b = 0, kl = 0, which = K_OTHER, kind = V_NULL, v_b = 0, v_len = 0, v_esc = 0;
@@ -557,6 +557,7 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
                                  (T.byte(a + col) == ':') & (n4 != 0ull) & (kl <= 255u);
                 uint32_t vend = v;  // window-relative index just past the value
                 bool okv = false;
+                tick(8);
                 if (ok & okm & !empty) {
                     if ((Qw >> v) & 1ull) {
                         // ---- string: the closing quote is the next real quote (beyond the window: bit scan of the bitmap) ----
@@ -612,6 +613,7 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
                             bits = tt ? 1u : 0u;
                         }
                     }
+                    tick(9);
                     if (okv) {
                         uint32_t kw[4];
                         T.load16(key_b, kw);
@@ -785,7 +787,7 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
     }
     const uint32_t left = wv::wave_left(L.ent_state);
     const uint64_t straddle = wv::ballot(my_cnt != 0u && my_off < left && my_off + my_cnt > left);
-    const uint32_t cut_at = straddle ? wv::shfl(my_off, wv::ctz64(straddle)) : left;
+    const uint32_t cut_at = straddle ? wv::bcast(my_off, wv::ctz64(straddle)) : left;
     const wv::Slots es = wv::wave_alloc(t.ent_used, t.ent_cap, L.ent_state, n_stash, cut_at < n_stash ? cut_at : n_stash, L.alloc_chunk);
     const bool overflow = es.overflow;
     if (n_stash != 0u) {
@@ -825,7 +827,7 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
     }
     tick(6);
     if (PROF && phase && lane == 0)
-        for (int k = 0; k < 7; ++k) wv::glb_add(phase + k, (unsigned long long)pc[k]);
+        for (int k = 0; k < 10; ++k) wv::glb_add(phase + k, (unsigned long long)pc[k]);
     return out;
 }
 

@@ -163,8 +163,10 @@ struct RowOut {
     double ts;
     fg_span span[6];
     uint32_t first, count;
+    bool skip = false;  // the format has written what it wants of this row itself (kernels that complete rows of an earlier kernel)
 };
 __device__ __forceinline__ void store_row(const DevTables& t, uint64_t li, const RowOut& o) {
+    if (o.skip) return;
     t.meta[li] = o.meta;
     t.ts[li] = o.ts;
 #pragma unroll
@@ -184,7 +186,7 @@ __device__ __forceinline__ uint32_t alloc_entries(const DevTables& t, uint32_t n
     *overflow = false;
     if (!__any(n_ent != 0u)) return 0;  // wave-uniform; the common case of the no-SD corpus skips the scan
     uint32_t total;
-    const uint32_t ex = wave_exclusive_sum(n_ent, &total);
+    const uint32_t ex = wv::excl_sum(n_ent, &total);
     // lines whose slice still fits what is left of the wave's chunk stay there, the others open the next chunk
     const uint32_t left = wv::wave_left(ent_state);
     const unsigned long long nofit = __ballot(n_ent != 0u && ex + n_ent > left);
@@ -212,6 +214,7 @@ struct GroupCtx {
     uint64_t a0;            // packed-buffer address of tile byte 0
     uint32_t span;          // tile bytes staged
     bool valid;             // this lane owns a line
+    uint64_t li;            // its index in the batch
     uint64_t* stash;        // the wave's entry stash (or null)
     uint32_t ablate;        // measurement build only
     uint32_t* ent_state;    // the wave's entry-slot reservation (two LDS words that persist across groups, wv::wave_alloc)
@@ -382,7 +385,7 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
             // case -- everything fits -- is kept apart so that it pays nothing for the loop.
             const bool fits0 = valid && (o1 - a0) <= (uint64_t)span;
             if (__ballot(valid && !fits0) == 0ull) {  // wave-uniform
-                GroupCtx c{bytes, smem, bm16, o0, e1, a0, span, valid, (ablate & 8u) ? nullptr : stash, ablate, ent_state, PROF ? prof + 6 : nullptr};
+                GroupCtx c{bytes, smem, bm16, o0, e1, a0, span, valid, li, (ablate & 8u) ? nullptr : stash, ablate, ent_state, PROF ? prof + 6 : nullptr};
                 pend = fmt.decode(c, t);
             } else {
                 uint64_t ta0 = a0;
@@ -394,7 +397,7 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
                     if (todo_m == 0ull) break;  // wave-uniform
                     bool now = fits;
                     if (fit_m == 0ull) now = todo && lane == (uint32_t)__builtin_ctzll(todo_m);  // longer than the tile: alone, from global
-                    GroupCtx c{bytes, smem, bm16, o0, e1, ta0, tspan, now, (ablate & 8u) ? nullptr : stash, ablate, ent_state, PROF ? prof + 6 : nullptr};
+                    GroupCtx c{bytes, smem, bm16, o0, e1, ta0, tspan, now, li, (ablate & 8u) ? nullptr : stash, ablate, ent_state, PROF ? prof + 6 : nullptr};
                     const RowOut r = fmt.decode(c, t);
                     if (now) pend = r;
                     todo = todo && !now;

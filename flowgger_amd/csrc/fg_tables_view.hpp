@@ -22,6 +22,11 @@ struct DevTables {
     uint8_t* ent_type;
     uint8_t* ent_flags;
     unsigned long long* ent_used;
+    // hand-over between the two kernels of a decode (fast form -> exact general form, fg_gelf.hip / fg_rfc5424.hip): the first
+    // kernel stores `epoch` here when it leaves lines for the second one, which returns at once when the word holds anything
+    // else.  One word of a ctx-owned ring per launch (epoch = the ctx's launch counter), so launches in flight never share one.
+    uint32_t* pending;
+    uint32_t epoch;
 };
 enum { S_HOST = 0, S_APP = 1, S_PROC = 2, S_MSGID = 3, S_MSG = 4, S_FULL = 5 };
 

@@ -35,6 +35,14 @@ FG_WV void sync() { __syncthreads(); }  // single-wave workgroup: orders LDS tra
 FG_WV uint64_t ballot(bool p) { return __ballot(p); }
 FG_WV uint32_t shfl(uint32_t v, uint32_t src) { return (uint32_t)__shfl((int)v, (int)src, 64); }
 FG_WV uint32_t shfl_up(uint32_t v, uint32_t d) { return (uint32_t)__shfl_up((int)v, d, 64); }
+// v of lane `src`, src WAVE-UNIFORM: one v_readlane instead of a trip through the LDS crossbar (ds_bpermute)
+FG_WV uint32_t bcast(uint32_t v, uint32_t src) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane((int)src));
+}
+// v of the lane below (lane 0 keeps `first`): DPP wave_shr:1
+FG_WV uint32_t shfl_up1(uint32_t v, uint32_t first) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x138, 0xf, 0xf, false);
+}
 // number of set bits of m at positions below this lane
 FG_WV uint32_t mbcnt(uint64_t m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -68,6 +76,11 @@ FG_WV void sync() { emu::collective(0, emu::OP_SYNC, 0); }
 FG_WV uint64_t ballot(bool p) { return emu::collective(p ? 1u : 0u, emu::OP_BALLOT, 0); }
 FG_WV uint32_t shfl(uint32_t v, uint32_t src) { return (uint32_t)emu::collective(v, emu::OP_SHFL, src & 63u); }
 FG_WV uint32_t shfl_up(uint32_t v, uint32_t d) { return (uint32_t)emu::collective(v, emu::OP_SHFL_UP, d); }
+FG_WV uint32_t bcast(uint32_t v, uint32_t src) { return (uint32_t)emu::collective(v, emu::OP_SHFL, src & 63u); }
+FG_WV uint32_t shfl_up1(uint32_t v, uint32_t first) {
+    const uint32_t r = (uint32_t)emu::collective(v, emu::OP_SHFL_UP, 1u);
+    return emu::lane() == 0 ? first : r;
+}
 FG_WV uint32_t mbcnt(uint64_t m) { return (uint32_t)__builtin_popcountll(m & ((1ull << emu::lane()) - 1ull)); }
 FG_WV uint32_t lds_or(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
 FG_WV uint32_t lds_xor(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o ^ v; return o; }
@@ -96,10 +109,29 @@ FG_WV uint64_t clock() { return 0; }
 FG_WV bool any(bool p) { return ballot(p) != 0ull; }
 
 // wave-wide exclusive prefix sum; *total = the wave sum
+#if defined(__HIPCC__)
+// DPP scan (no LDS crossbar): three row shifts of the input, then shifts by 4 and 8 inside the rows of 16, then the two row
+// broadcasts -- the classic GCN sequence.
+template <int CTRL, int ROW_MASK, int BANK_MASK, bool BOUND>
+FG_WV uint32_t dpp_(uint32_t src) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)src, CTRL, ROW_MASK, BANK_MASK, BOUND);
+}
+FG_WV uint32_t excl_sum(uint32_t v, uint32_t* total) {
+    uint32_t x = v;
+    x += dpp_<0x111, 0xf, 0xf, true>(v);   // row_shr:1
+    x += dpp_<0x112, 0xf, 0xf, true>(v);   // row_shr:2
+    x += dpp_<0x113, 0xf, 0xf, true>(v);   // row_shr:3
+    x += dpp_<0x114, 0xf, 0xe, false>(x);  // row_shr:4, banks 1..3
+    x += dpp_<0x118, 0xf, 0xc, false>(x);  // row_shr:8, banks 2..3
+    x += dpp_<0x142, 0xa, 0xf, false>(x);  // row_bcast:15 into rows 1 and 3
+    x += dpp_<0x143, 0xc, 0xf, false>(x);  // row_bcast:31 into rows 2 and 3
+    *total = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+    return x - v;
+}
+#else
 FG_WV uint32_t excl_sum(uint32_t v, uint32_t* total) {
     const uint32_t l = lane();
     uint32_t inc = v;
-#pragma unroll
     for (uint32_t d = 1; d < kLanes; d <<= 1) {
         const uint32_t t = shfl_up(inc, d);
         if (l >= d) inc += t;
@@ -107,6 +139,7 @@ FG_WV uint32_t excl_sum(uint32_t v, uint32_t* total) {
     *total = shfl(inc, kLanes - 1u);
     return inc - v;
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // Entry-table slots, wave-cooperative.  Every allocation used to be one atomic on the SAME global word (ent_used): 250 K atomics
@@ -143,7 +176,7 @@ FG_WV Slots wave_alloc(unsigned long long* ent_used, uint64_t ent_cap, uint32_t*
         const uint32_t grab = rest > chunk ? rest : chunk;
         unsigned long long b = 0;
         if (lane() == 0) b = glb_add(ent_used, (unsigned long long)grab);
-        const uint32_t lo = shfl((uint32_t)b, 0), hi = shfl((uint32_t)(b >> 32), 0);
+        const uint32_t lo = bcast((uint32_t)b, 0u), hi = bcast((uint32_t)(b >> 32), 0u);
         b = ((unsigned long long)hi << 32) | lo;
         const unsigned long long room = b < ent_cap ? ent_cap - b : 0ull;
         const uint32_t usable = room < grab ? (uint32_t)room : grab;

@@ -127,3 +127,4 @@ extern "C" int fgw_parse_num24(const uint8_t* tok, uint32_t n, uint32_t* kind, u
     }
     return gelf2::parse_num24(w, n, p10, dw, kind, bits) ? 1 : 0;
 }
+

@@ -54,3 +54,4 @@ class WaveHost:
         if rc != 0:
             raise RuntimeError(self.lib.fgw_last_error().decode())
         return t, handled[:n]
+
