@@ -45,6 +45,11 @@ extern "C" int fg_launch_rfc3164(const uint8_t* d_bytes, const uint64_t* d_offse
 extern "C" int fg_launch_encode_sizes(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
                                       const fg::EncCfg* cfg, uint32_t tile_cap, uint32_t cfg_lds, uint32_t* d_sizes,
                                       uint64_t* d_block_sums, uint8_t* d_status, uint64_t* d_out_offsets, hipStream_t stream);
+extern "C" int fg_launch_encode_count(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
+                                      const fg::EncCfg* cfg, uint32_t tile_cap, uint32_t cfg_lds, uint32_t* d_sizes,
+                                      uint64_t* d_block_sums, uint8_t* d_status, hipStream_t stream);
+extern "C" int fg_launch_encode_scan(const uint32_t* d_sizes, uint64_t* d_block_sums, uint64_t n, uint64_t* d_out_offsets, uint64_t base,
+                                     hipStream_t stream);
 extern "C" int fg_launch_encode_write(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
                                       const fg::EncCfg* cfg, uint32_t tile_cap, uint32_t cfg_lds, const uint64_t* d_out_offsets,
                                       uint8_t* d_out, hipStream_t stream);
@@ -856,6 +861,165 @@ static int decode_stage(fg_ctx* ctx, fg_format fmt, fg_framing framing, uint64_t
     }
 }
 
+// fg_transcode_batch for a LARGE batch of framed lines: the batch goes through H2D -> decode -> encode -> D2H as slices of ~32 MiB
+// on the ctx's two streams, so that the upload of slice k+1 and the (2-3x larger) download of slice k's messages share the
+// full-duplex link, and the kernels hide behind both.  The host only waits for one small number per slice (its encoded size:
+// the next slice's messages start there).  Returns FG_ERR_UNSUPPORTED when the batch must take the one-piece path (an output
+// estimate that turned out too small): nothing has been returned to the caller by then.
+static int transcode_sliced(fg_ctx* ctx, fg_format fmt, const fg_encode_cfg* ecfg, const uint8_t* bytes, uint64_t nbytes,
+                            const uint64_t* offsets, uint64_t n, fg_transcoded* out) {
+    int rc;
+    if (!ctx->stream2) {
+        FG_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+        FG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming));
+    }
+    hipStream_t lanes[2] = {ctx->stream, ctx->stream2};
+    uint32_t slices = (uint32_t)(nbytes / (32ull << 20));
+    if (slices < 2) slices = 2;
+    if (slices > 64) slices = 64;
+    if (n < slices) return FG_ERR_UNSUPPORTED;
+    std::vector<uint64_t> cut(slices + 1);
+    if (fg_shard_plan(offsets, n, slices, cut.data()) != FG_OK) return FG_ERR_ARG;
+    // ---- device buffers: input, tables (whole batch), out_offsets / enc_status, encoder scratch ----
+    if ((rc = grow_dev(ctx, (void**)&ctx->d_bytes, &ctx->d_bytes_cap, up(nbytes, 16) + 16)) != FG_OK) return rc;
+    if ((rc = grow_dev(ctx, (void**)&ctx->d_offsets, &ctx->d_offsets_cap, (n + 1) * 8)) != FG_OK) return rc;
+    uint64_t ent_cap = fmt == FG_RFC5424 ? nbytes / 16 + 1024 : nbytes / 8 + 1024;
+    if (fmt == FG_RFC3164) ent_cap = 16;
+    if (ent_cap > 0xFFFFFFF0ull) ent_cap = 0xFFFFFFF0ull;
+    uint64_t tab_bytes = 0;
+    carve(nullptr, n, ent_cap, nullptr, &tab_bytes);
+    if ((rc = grow_dev(ctx, (void**)&ctx->d_tab, &ctx->d_tab_cap, tab_bytes)) != FG_OK) return rc;
+    fg_tables dt{};
+    carve(ctx->d_tab, n, ent_cap, &dt, nullptr);
+    const uint64_t offs_bytes = up((n + 1) * 8, 256);
+    if ((rc = grow_dev(ctx, (void**)&ctx->d_tmeta, &ctx->d_tmeta_cap, offs_bytes + up(n, 256))) != FG_OK) return rc;
+    uint64_t* d_out_offsets = reinterpret_cast<uint64_t*>(ctx->d_tmeta);
+    uint8_t* d_enc_status = ctx->d_tmeta + offs_bytes;
+    fg::EncCfgHost h;
+    if (!fg::build_enc_cfg(fmt, ecfg, ctx->suffix, ctx->has_suffix, &h)) return FG_ERR_ARG;
+    const uint64_t keys_bytes = up(h.keys.size() * sizeof(fg::StaticKey), 16), blob_bytes = up(h.blob.size() + 16, 256);
+    const uint64_t cfg_bytes = up(keys_bytes + blob_bytes, 256);
+    const uint64_t sizes_bytes = up(n * 4 + 4, 256), sums_bytes = up((n / 64 + slices + 2) * 8, 256);
+    if ((rc = grow_dev(ctx, (void**)&ctx->d_enc, &ctx->d_enc_cap, cfg_bytes + sizes_bytes + sums_bytes)) != FG_OK) return rc;
+    std::vector<uint8_t> host(cfg_bytes, 0);
+    if (!h.keys.empty()) memcpy(host.data(), h.keys.data(), h.keys.size() * sizeof(fg::StaticKey));
+    if (!h.blob.empty()) memcpy(host.data() + keys_bytes, h.blob.data(), h.blob.size());
+    FG_HIP(ctx, hipMemcpyAsync(ctx->d_enc, host.data(), host.size(), hipMemcpyHostToDevice, lanes[0]));
+    FG_HIP(ctx, hipMemcpyAsync(ctx->d_offsets, offsets, (n + 1) * 8, hipMemcpyHostToDevice, lanes[0]));
+    FG_HIP(ctx, hipMemsetAsync(dt.ent_used, 0, 8, lanes[0]));
+    FG_HIP(ctx, hipStreamSynchronize(lanes[0]));  // (`host` is a local; lane 1 may start)
+    fg::EncCfg cfg = h.cfg;
+    cfg.keys = reinterpret_cast<const fg::StaticKey*>(ctx->d_enc);
+    cfg.blob = ctx->d_enc + keys_bytes;
+    const uint32_t cfg_lds = keys_bytes + h.blob.size() <= 4096 ? (uint32_t)up(keys_bytes + h.blob.size(), 16) : 0u;
+    uint32_t* d_sizes = reinterpret_cast<uint32_t*>(ctx->d_enc + cfg_bytes);
+    uint64_t* d_block_sums = reinterpret_cast<uint64_t*>(ctx->d_enc + cfg_bytes + sizes_bytes);
+    const uint32_t tile_cap = pick_tile_cap(nbytes, n, 40 * 1024, 1);
+    fg::DevTables ddt = to_dev(dt);
+    // ---- host buffer: fixed-size arrays first, the messages behind them (they grow slice by slice) ----
+    const uint64_t o_offs = 0, o_meta = o_offs + offs_bytes, o_st = o_meta + up(n * 4, 256), o_msgs = o_st + up(n, 256);
+    uint64_t base = 0;  // encoded bytes of the slices finished so far
+    auto sl_tables = [&](uint64_t l0, uint64_t l1) {
+        fg_tables sl = dt;
+        sl.n = l1 - l0;
+        sl.meta += l0; sl.ts += l0; sl.hostname += l0; sl.appname += l0; sl.procid += l0; sl.msgid += l0; sl.msg += l0; sl.full_msg += l0;
+        sl.ent_first += l0; sl.ent_count += l0;
+        return sl;
+    };
+    auto blocks_before = [&](uint32_t k) { return cut[k] / 64 + k; };  // first scratch sum of slice k (disjoint per slice)
+    auto drain = [&]() {
+        (void)hipStreamSynchronize(lanes[0]);
+        (void)hipStreamSynchronize(lanes[1]);
+    };
+    // queue a slice's upload, decode and count kernel
+    auto enqueue = [&](uint32_t k) -> int {
+        hipStream_t s = lanes[k & 1u];
+        const uint64_t l0 = cut[k], l1 = cut[k + 1];
+        if (l1 == l0) return FG_OK;
+        const uint64_t b0 = offsets[l0] & ~15ull, b1 = offsets[l1];
+        if (b1 > b0) FG_HIP(ctx, hipMemcpyAsync(ctx->d_bytes + b0, bytes + b0, b1 - b0, hipMemcpyHostToDevice, s));
+        const fg_tables sl = sl_tables(l0, l1);
+        int r = decode_frames_impl(ctx, fmt, FG_FRAME_NONE, ctx->d_bytes, nbytes, ctx->d_offsets + l0, l1 - l0, nullptr, &sl, (void*)s, false,
+                                   offsets[l1] - offsets[l0]);
+        if (r != FG_OK) return r;
+        if (k == 0 && ecfg->encoder == FG_ENC_GELF) {  // the GELF ranking scratch is sized by the pairs per line: look at the first slice
+            uint64_t used = ~0ull;
+            FG_HIP(ctx, hipMemcpyAsync(&used, dt.ent_used, 8, hipMemcpyDeviceToHost, s));
+            FG_HIP(ctx, hipStreamSynchronize(s));
+            if (used == 0) cfg.sort_slots = 1;
+            else if (used <= 2 * (l1 - l0)) cfg.sort_slots = 8;
+        }
+        fg::DevTables sdt = to_dev(sl);
+        sdt.ent_cap = ddt.ent_cap;
+        if (fg_launch_encode_count(ctx->d_bytes, ctx->d_offsets + l0, l1 - l0, &sdt, &cfg, tile_cap, cfg_lds, d_sizes + l0,
+                                   d_block_sums + blocks_before(k), d_enc_status + l0, s) != 0)
+            return FG_ERR_HIP;
+        return FG_OK;
+    };
+    for (uint32_t k = 0; k < slices; ++k) {
+        if (k == 0 && (rc = enqueue(0)) != FG_OK) {
+            drain();
+            return rc;
+        }
+        if (k + 1 < slices && (rc = enqueue(k + 1)) != FG_OK) {
+            drain();
+            return rc;
+        }
+        // ---- finish slice k: offsets from `base`, its size, the write kernel, the download ----
+        hipStream_t s = lanes[k & 1u];
+        const uint64_t l0 = cut[k], l1 = cut[k + 1], rows = l1 - l0;
+        if (rows == 0) continue;
+        if (fg_launch_encode_scan(d_sizes + l0, d_block_sums + blocks_before(k), rows, d_out_offsets + l0, base, s) != 0) {
+            drain();
+            return FG_ERR_HIP;
+        }
+        uint64_t end = 0;
+        FG_HIP(ctx, hipMemcpyAsync(&end, d_out_offsets + l1, 8, hipMemcpyDeviceToHost, s));
+        FG_HIP(ctx, hipStreamSynchronize(s));
+        if (k == 0) {
+            // size the output buffers from the first slice (+ 12 %); a batch that outgrows the estimate takes the one-piece path
+            const uint64_t in0 = offsets[l1] - offsets[l0];
+            const uint64_t est = (uint64_t)((double)end * ((double)nbytes / (double)(in0 ? in0 : 1)) * 1.12) + (4ull << 20);
+            if ((rc = grow_dev(ctx, (void**)&ctx->d_tout, &ctx->d_tout_cap, est)) != FG_OK || (rc = grow_pinned(ctx, (void**)&ctx->h_tout, &ctx->h_tout_cap, o_msgs + est)) != FG_OK) {
+                drain();
+                return rc;
+            }
+        }
+        if (end > ctx->d_tout_cap || o_msgs + end > ctx->h_tout_cap) {
+            drain();
+            return FG_ERR_UNSUPPORTED;
+        }
+        const fg_tables sl = sl_tables(l0, l1);
+        fg::DevTables sdt = to_dev(sl);
+        sdt.ent_cap = ddt.ent_cap;
+        if (fg_launch_encode_write(ctx->d_bytes, ctx->d_offsets + l0, rows, &sdt, &cfg, tile_cap, cfg_lds, d_out_offsets + l0, ctx->d_tout, s) != 0) {
+            drain();
+            return FG_ERR_HIP;
+        }
+        uint8_t* hh = ctx->h_tout;
+        if (end > base) FG_HIP(ctx, hipMemcpyAsync(hh + o_msgs + base, ctx->d_tout + base, end - base, hipMemcpyDeviceToHost, s));
+        FG_HIP(ctx, hipMemcpyAsync(hh + o_offs + l0 * 8, d_out_offsets + l0, (rows + 1) * 8, hipMemcpyDeviceToHost, s));
+        FG_HIP(ctx, hipMemcpyAsync(hh + o_meta + l0 * 4, dt.meta + l0, rows * 4, hipMemcpyDeviceToHost, s));
+        FG_HIP(ctx, hipMemcpyAsync(hh + o_st + l0, d_enc_status + l0, rows, hipMemcpyDeviceToHost, s));
+        base = end;
+    }
+    drain();
+    // an entry table that was too small shows up as FG_ST_OVERFLOW rows: the one-piece path sizes it exactly
+    uint64_t used = 0;
+    FG_HIP(ctx, hipMemcpy(&used, dt.ent_used, 8, hipMemcpyDeviceToHost));
+    if (used > ent_cap) return FG_ERR_UNSUPPORTED;
+    uint8_t* hh = ctx->h_tout;
+    out->n = n;
+    out->consumed = nbytes;
+    out->out = hh + o_msgs;
+    out->out_bytes = base;
+    out->out_offsets = reinterpret_cast<const uint64_t*>(hh + o_offs);
+    out->meta = reinterpret_cast<const uint32_t*>(hh + o_meta);
+    out->enc_status = hh + o_st;
+    out->frame_offsets = nullptr;
+    return FG_OK;
+}
+
 int fg_transcode_batch(fg_ctx* ctx, fg_format fmt, fg_framing framing, const fg_encode_cfg* ecfg, const uint8_t* bytes,
                        uint64_t nbytes, const uint64_t* offsets, uint64_t n, int final, fg_transcoded* out) {
     if (!ctx || !ecfg || !out || (nbytes && !bytes)) return FG_ERR_ARG;
@@ -871,6 +1035,11 @@ int fg_transcode_batch(fg_ctx* ctx, fg_format fmt, fg_framing framing, const fg_
     DeviceGuard g(ctx->device);
     hipStream_t s = ctx->stream;
     int rc;
+    if (framing == FG_FRAME_NONE && nbytes >= (64ull << 20) && n >= 4096 && !getenv("FG_TRANSCODE_ONE_PIECE")) {
+        rc = transcode_sliced(ctx, fmt, ecfg, bytes, nbytes, offsets, n, out);
+        if (rc != FG_ERR_UNSUPPORTED) return rc;
+        *out = fg_transcoded{};
+    }
     // 1. the chunk (and, for framed input, its offsets) to HBM
     if ((rc = grow_dev(ctx, (void**)&ctx->d_bytes, &ctx->d_bytes_cap, up(nbytes, 16) + 16)) != FG_OK) return rc;
     if (nbytes) FG_HIP(ctx, hipMemcpyAsync(ctx->d_bytes, bytes, nbytes, hipMemcpyHostToDevice, s));

@@ -140,11 +140,13 @@ int launch_encode_tu<FG_ENC_TU, (FG_ENC_TU_WRITE != 0), FG_ENC_TU_SLOTS>(FG_ENC_
 // exclusive scan of the per-workgroup sums (nb = ceil(n / 64) of them) in place; off_n[0] = the grand total.  One
 // workgroup; every thread owns kScanPerThread consecutive sums per round (8192 sums per round: 100 M lines = 191 rounds).
 constexpr uint32_t kScanPerThread = 8;
-__global__ __launch_bounds__(1024) void k_block_scan(uint64_t* __restrict__ block_sums, uint64_t nb, uint64_t* __restrict__ off_n) {
+// `base` = where this batch's (this slice's) first message goes: offsets come out absolute.
+__global__ __launch_bounds__(1024) void k_block_scan(uint64_t* __restrict__ block_sums, uint64_t nb, uint64_t* __restrict__ off_n,
+                                                     uint64_t base) {
     __shared__ uint64_t wave_tot[16];
     __shared__ uint64_t carry_s;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    if (tid == 0) carry_s = 0;
+    if (tid == 0) carry_s = base;
     __syncthreads();
     const uint64_t last = nb ? nb - 1u : 0u;
     for (uint64_t b0 = 0; b0 < nb; b0 += 1024ull * kScanPerThread) {
@@ -216,16 +218,31 @@ static int launch_encode(FG_ENC_ARGS) {
 }  // namespace fg
 
 #ifndef FG_ENC_TU
-// d_sizes: n u32; d_block_sums: ceil(n / 64) u64 (scratch)
+// d_sizes: n u32; d_block_sums: ceil(n / 64) u64 (scratch).  Two steps so that a caller that encodes a batch slice by slice can
+// queue the (long) count kernel of a slice before it knows where the slice's output starts:
+//   fg_launch_encode_count   sizes per line + per-64-line sums
+//   fg_launch_encode_scan    sums -> out_offsets[0 .. n], absolute from `base`; out_offsets[n] = base + the slice's bytes
+extern "C" int fg_launch_encode_count(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
+                                      const fg::EncCfg* cfg, uint32_t tile_cap, uint32_t cfg_lds, uint32_t* d_sizes,
+                                      uint64_t* d_block_sums, uint8_t* d_status, hipStream_t stream) {
+    if (n == 0) return 0;
+    if (fg::launch_encode<false>(d_bytes, d_offsets, n, *t, *cfg, tile_cap, cfg_lds, d_sizes, d_status, d_block_sums, nullptr, nullptr, stream) != 0) return -1;
+    return (int)hipGetLastError();
+}
+extern "C" int fg_launch_encode_scan(const uint32_t* d_sizes, uint64_t* d_block_sums, uint64_t n, uint64_t* d_out_offsets, uint64_t base,
+                                     hipStream_t stream) {
+    if (n == 0) return 0;
+    const uint64_t nb = (n + fg::kWave - 1) / fg::kWave;
+    hipLaunchKernelGGL(fg::k_block_scan, dim3(1), dim3(1024), 0, stream, d_block_sums, nb, d_out_offsets + n, base);
+    hipLaunchKernelGGL(fg::k_line_offsets, dim3((uint32_t)nb), dim3(fg::kWave), 0, stream, d_sizes, d_block_sums, n, d_out_offsets);
+    return (int)hipGetLastError();
+}
 extern "C" int fg_launch_encode_sizes(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
                                       const fg::EncCfg* cfg, uint32_t tile_cap, uint32_t cfg_lds, uint32_t* d_sizes,
                                       uint64_t* d_block_sums, uint8_t* d_status, uint64_t* d_out_offsets, hipStream_t stream) {
     if (n == 0) return 0;
-    if (fg::launch_encode<false>(d_bytes, d_offsets, n, *t, *cfg, tile_cap, cfg_lds, d_sizes, d_status, d_block_sums, nullptr, nullptr, stream) != 0) return -1;
-    const uint64_t nb = (n + fg::kWave - 1) / fg::kWave;
-    hipLaunchKernelGGL(fg::k_block_scan, dim3(1), dim3(1024), 0, stream, d_block_sums, nb, d_out_offsets + n);
-    hipLaunchKernelGGL(fg::k_line_offsets, dim3((uint32_t)nb), dim3(fg::kWave), 0, stream, d_sizes, d_block_sums, n, d_out_offsets);
-    return (int)hipGetLastError();
+    if (fg_launch_encode_count(d_bytes, d_offsets, n, t, cfg, tile_cap, cfg_lds, d_sizes, d_block_sums, d_status, stream) != 0) return -1;
+    return fg_launch_encode_scan(d_sizes, d_block_sums, n, d_out_offsets, 0ull, stream);
 }
 extern "C" int fg_launch_encode_write(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
                                       const fg::EncCfg* cfg, uint32_t tile_cap, uint32_t cfg_lds, const uint64_t* d_out_offsets,

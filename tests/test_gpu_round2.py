@@ -87,3 +87,39 @@ def test_bench_launches_its_own_ranks():
     assert out["n_gpus"] == 1 and out["steps"] == 2 and out["value"] > 0
     assert out["ranks"]["launcher"].startswith("self") and out["ranks"]["n"] == 1
     assert out["config"]["lines_per_gpu"] == 200000
+
+
+@pytest.mark.parametrize("src,enc,merger", [("rfc5424", "gelf", "line"), ("sd", "rfc5424", "syslen"), ("gelf", "gelf", "nul")])
+def test_transcode_large_batch_is_sliced_over_two_streams(oracle, monkeypatch, src, enc, merger):
+    """fg_transcode_batch above 64 MiB: the batch goes through upload -> decode -> encode -> download as ~32 MiB slices on two
+    streams.  Same bytes as the one-piece path (FG_TRANSCODE_ONE_PIECE) and as the oracle's decode -> encode -> merger."""
+    import oracle_binding as OB
+    from flowgger_amd import GelfEncoder, Pipeline, RFC5424Encoder
+
+    if src == "rfc5424":
+        dec, fmt, lines = RFC5424Decoder(), RFC5424, synth.rfc5424_lines(330_000, cfg=2)
+    elif src == "sd":
+        dec, fmt, lines = RFC5424Decoder(), RFC5424, synth.rfc5424_lines(160_000, cfg=4, sd=True)
+    else:
+        dec, fmt, lines = GelfDecoder(), GELF, synth.gelf_lines(260_000)
+    data, offsets = synth.pack(lines)
+    assert data.size > (72 << 20)
+    data = np.concatenate([data, np.zeros(64, np.uint8)])
+    cls, oenc = {"gelf": (GelfEncoder, OB.ENC_GELF), "rfc5424": (RFC5424Encoder, OB.ENC_RFC5424)}[enc]
+    om = {"line": OB.MERGE_LINE, "nul": OB.MERGE_NUL, "syslen": OB.MERGE_SYSLEN}[merger]
+    now_ts = 1438859724.638
+    pipe = Pipeline(dec, cls(None, merger=merger))
+    sliced = pipe.run_packed(data, offsets, now_ts=now_ts)
+    again = pipe.run_packed(data, offsets, now_ts=now_ts)  # buffers already at size
+    monkeypatch.setenv("FG_TRANSCODE_ONE_PIECE", "1")
+    whole = pipe.run_packed(data, offsets, now_ts=now_ts)
+    monkeypatch.delenv("FG_TRANSCODE_ONE_PIECE")
+    for r in (sliced, again):
+        assert r.n == len(lines) and r.consumed == int(offsets[-1])
+        assert np.array_equal(r.out_offsets, whole.out_offsets) and np.array_equal(r.out, whole.out)
+        assert np.array_equal(r.enc_status, whole.enc_status) and np.array_equal(r.dec_status, whole.dec_status)
+    # the oracle on a prefix (it encodes ~250 K lines per second)
+    m = 60_000
+    oblob, ooffs, ost = oracle.decode_encode_batch(fmt, oenc, om, data, offsets[: m + 1], None, extra=None, prepend=None, now_ts=now_ts)
+    assert np.array_equal(sliced.out_offsets[: m + 1], ooffs) and np.array_equal(sliced.out[: int(ooffs[-1])], oblob)
+    assert np.array_equal(np.minimum(sliced.enc_status[:m], 2), ost)
