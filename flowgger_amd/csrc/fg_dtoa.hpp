@@ -8,7 +8,7 @@
 #include <stdint.h>
 #include <string.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define FGD_HD __host__ __device__ __forceinline__
 #else
 #define FGD_HD inline

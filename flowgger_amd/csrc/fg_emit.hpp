@@ -26,7 +26,7 @@
 #include "fg_tables_view.hpp"
 #include "fg_timeconv.hpp"
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define FGE_HD __host__ __device__ __forceinline__
 #define FGE_HD_NOINLINE __host__ __device__
 #else

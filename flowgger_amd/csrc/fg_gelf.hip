@@ -555,13 +555,13 @@ inline uint32_t gelf_extra_lds(uint32_t tile, uint32_t lines) { return gelf2::ex
 struct GelfFormat {
     static constexpr uint32_t kClasses = gelf2::kClasses;
     static __device__ __forceinline__ void classify_store(const uint4& q, uint16_t* bm16, uint32_t chunk, uint32_t stride) {
-        uint32_t m[gelf2::kClasses];
+        uint32_t m[gelf2::kClasses + 1];
         gelf2::classify(q.x, q.y, q.z, q.w, m);
-#pragma unroll
-        for (uint32_t c = 0; c < gelf2::kClasses; ++c) bm16[c * stride + chunk] = (uint16_t)m[c];
+        gelf2::store_classes(m, bm16, chunk, stride);
     }
     uint8_t* extra;  // LDS behind the class bitmaps
     uint32_t tile_cap, lines;
+    unsigned long long* pacc;  // measurement build: the wave's phase clocks (LDS; a hot global atomic per phase would BE the profile)
 
     __device__ __forceinline__ RowOut decode(const GroupCtx& c, const DevTables& t) const {
         const uint32_t lane = threadIdx.x;
@@ -572,7 +572,7 @@ struct GelfFormat {
         L.ent_state = c.ent_state;
         L.alloc_chunk = wv::alloc_chunk_for(t.ent_cap, gridDim.x);
         const bool tile_lane = c.valid && in_tile && lane < lines && !(c.ablate & 4u);
-        const gelf2::LineOut f = c.phase ? gelf2::decode_tile<true>(L, c.span, tile_lane, base, len, t, c.phase)
+        const gelf2::LineOut f = c.phase ? gelf2::decode_tile<true>(L, c.span, tile_lane, base, len, t, pacc)
                                          : gelf2::decode_tile<false>(L, c.span, tile_lane, base, len, t);
         RowOut o;
         const fg_span none{0, FG_NONE};
@@ -596,9 +596,19 @@ __global__ __launch_bounds__(kWave, MINW) void k_gelf(const uint8_t* __restrict_
                                                   uint64_t n, DevTables t, uint32_t tile_cap, uint32_t L, uint64_t groups,
                                                   unsigned long long* prof, uint64_t* stash_base, FrameArgs fr) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    GelfFormat fmt{smem + tile_cap + 64u + (tile_cap / 16u + 16u) * 2u * GelfFormat::kClasses, tile_cap, L};
-    gelf2::init_lds(gelf2::carve(smem, reinterpret_cast<uint16_t*>(smem + tile_cap + 64u), tile_cap, fmt.extra, L));
+    __shared__ unsigned long long pacc[PROF ? 10 : 1];
+    GelfFormat fmt{smem + tile_cap + 64u + (tile_cap / 16u + 16u) * 2u * GelfFormat::kClasses, tile_cap, L, pacc};
+    if (PROF && threadIdx.x < 10) pacc[threadIdx.x] = 0ull;
+    {
+        const gelf2::Lds lds = gelf2::carve(smem, reinterpret_cast<uint16_t*>(smem + tile_cap + 64u), tile_cap, fmt.extra, L);
+        gelf2::init_lds(lds);
+        gelf2::clear_dirty(lds, tile_cap);
+    }
     persistent_loop<NB, PROF>(bytes, offsets, n, t, tile_cap, L, groups, prof, stash_base, fmt, fr);
+    if (PROF) {
+        __syncthreads();
+        if (threadIdx.x < 10) atomicAdd(&prof[6 + threadIdx.x], pacc[threadIdx.x]);
+    }
 }
 
 // ---- kernel 2: pending lines -> the general form, straight from global memory --------------------------------------
@@ -681,18 +691,21 @@ extern "C" int fg_launch_gelf(const uint8_t* d_bytes, const uint64_t* d_offsets,
     (void)stash_blocks;
     if (n == 0) return 0;
     fg::LaunchPlan p;
-    // The fast form is latency bound: it lives on waves per SIMD, and its LDS (tile + five bitmaps + the per-item / per-entry
-    // arrays) grows with the lines per group.  Take the largest power of two whose LDS still lets nine waves share a CU
-    // (measured on the 307-byte corpus: 16 lines per group 755 M lines/s, 32: 500 M, 64: 250 M, 8: 560 M).  The fast form keeps
-    // its records in registers and its entries in LDS: no global stash, no cap on the grid.
+    // The fast form keeps its records in registers and writes entries straight to the table: what it needs in LDS is the tile,
+    // four class bitmaps and the per-item / per-line arrays, which grow with the lines per group.  Take the largest power of two
+    // whose LDS still lets sixteen waves share a CU (measured on the 307-byte corpus, M lines/s: 8 lines per group 1050,
+    // 16: 677, 32: 803, 64: 398, 4: 436).  No global stash, no cap on the grid.
     uint32_t max_lines = fg::kGelfLines;
-    if (!getenv("FG_LINES_PER_GROUP")) {
+    uint32_t lds_budget = 10u * 1024u;  // sixteen waves per CU
+    if (const char* e = getenv("FG_GELF_LDS_BUDGET")) lds_budget = (uint32_t)atoi(e);  // tuning
+    if (const char* e = getenv("FG_LINES_PER_GROUP")) max_lines = (uint32_t)atoi(e);
+    else {
         while (max_lines > 4u) {
             if (fg::plan_launch(fg::k_gelf<fg::kComputeBoundWindow, false>, n, avg_len, 0u, 40960u, 0u, &p, max_lines, fg::GelfFormat::kClasses,
                                 fg::gelf_extra_lds))
                 return -1;
             if (p.L < max_lines) max_lines = p.L;  // (the geometry already settled on fewer lines)
-            if (p.lds <= 18u * 1024u) break;
+            if (p.lds <= lds_budget) break;
             max_lines >>= 1;
         }
     }
@@ -700,18 +713,20 @@ extern "C" int fg_launch_gelf(const uint8_t* d_bytes, const uint64_t* d_offsets,
                         fg::gelf_extra_lds))
         return -1;
     dim3 grid(p.blocks), block(fg::kWave);
+    if (getenv("FG_PLAN")) fprintf(stderr, "gelf plan: L %u tile %u lds %u blocks %u\n", p.L, p.tile, p.lds, p.blocks);
     if (getenv("FG_PROF")) {
         fg::ProfRun pr;
         if (!pr.begin(stream)) return -1;
         hipLaunchKernelGGL((fg::k_gelf<fg::kComputeBoundWindow, true>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L,
                            p.groups, pr.d, (uint64_t*)nullptr, fg::FrameArgs{strip, line_bad});
         pr.end(stream, "gelf", p);
-    } else if (getenv("FG_GELF_W3")) {  // tuning: three waves per SIMD, 168 registers (fewer scalar spills)
+    } else if (getenv("FG_GELF_W5")) {  // tuning: five waves per SIMD, 96 registers
         fg::LaunchPlan p3;
-        if (fg::plan_launch(fg::k_gelf<fg::kComputeBoundWindow, false, 3>, n, avg_len, 0u, 40960u, 0u, &p3, fg::kGelfLines,
+        if (fg::plan_launch(fg::k_gelf<fg::kComputeBoundWindow, false, 5>, n, avg_len, 0u, 40960u, 0u, &p3, max_lines,
                             fg::GelfFormat::kClasses, fg::gelf_extra_lds))
             return -1;
-        hipLaunchKernelGGL((fg::k_gelf<fg::kComputeBoundWindow, false, 3>), dim3(p3.blocks), block, p3.lds, stream, d_bytes, d_offsets, n, *t,
+        if (getenv("FG_PLAN")) fprintf(stderr, "gelf plan w5: L %u tile %u lds %u blocks %u\n", p3.L, p3.tile, p3.lds, p3.blocks);
+        hipLaunchKernelGGL((fg::k_gelf<fg::kComputeBoundWindow, false, 5>), dim3(p3.blocks), block, p3.lds, stream, d_bytes, d_offsets, n, *t,
                            p3.tile, p3.L, p3.groups, (unsigned long long*)nullptr, (uint64_t*)nullptr, fg::FrameArgs{strip, line_bad});
     } else {
         hipLaunchKernelGGL((fg::k_gelf<fg::kComputeBoundWindow, false>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L,

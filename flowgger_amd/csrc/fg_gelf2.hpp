@@ -18,9 +18,9 @@
 //                                       same line with a smaller key (7-byte prefix + index, 512 bytes of LDS per block); duplicates:
 //                                       the last one wins; gelf_decoder.rs:51-106 is dispatched per member, the FIRST error in sorted
 //                                       order wins through an LDS min.  Member records never leave the registers.
-//   output                              rows from the lane that owns the line; extras are parked in an LDS stash at
-//                                       offset(line) + rank among extras and leave for the entry table in ONE coalesced copy per
-//                                       tile behind ONE atomic
+//   output                              rows from the lane that owns the line; extras go to first(line) + rank among the line's extras:
+//                                       the lanes of a block store into ONE contiguous stretch of the entry table, reserved out
+//                                       of the wave's chunk (fg_wave.hpp wave_alloc) without a trip to the global counter
 //
 // Exactness: this is a FAST FORM.  It accepts flat objects whose keys hold no escapes, with ' ' as the only whitespace
 // between tokens, at most kMaxLineItems structural characters -- every GELF producer's output -- and proves every byte of
@@ -57,11 +57,13 @@ enum : uint32_t { V_STRING = 0, V_BOOL = 1, V_F64 = 2, V_I64 = 3, V_U64 = 4, V_N
 enum : uint32_t { K_TS = 0, K_HOST = 1, K_SHORT = 2, K_FULL = 3, K_VERSION = 4, K_LEVEL = 5, K_OTHER = 6 };
 
 // stage-A classes (one 16-bit mask per 16-byte chunk each)
-enum : uint32_t { C_Q = 0, C_B = 1, C_ST = 2, C_NS = 3, C_CT = 4, kClasses = 5 };
+enum : uint32_t { C_Q = 0, C_B = 1, C_ST = 2, C_NS = 3, kClasses = 4 };
+// (control characters end the fast form wherever they stand: they are not a bitmap but one DIRTY bit per 64-byte word of the tile,
+//  kept at the start of the extra block -- classify() returns the chunk's control mask as m[kClasses])
 constexpr uint32_t kMaxLineItems = 64;   // structural characters of a line on the fast form ('{' + commas + '}')
 constexpr uint32_t kLines = 64;
 
-FG_WV void classify(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t m[kClasses]) {
+FG_WV void classify(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t m[kClasses + 1]) {
     const uint32_t x[4] = {x0, x1, x2, x3};
     uint32_t q[4], b[4], st[4], ns[4], ct[4];
 #pragma unroll
@@ -77,10 +79,19 @@ FG_WV void classify(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t
     m[C_B] = wv::gather16(b[0], b[1], b[2], b[3]);
     m[C_ST] = wv::gather16(st[0], st[1], st[2], st[3]);
     m[C_NS] = wv::gather16(ns[0], ns[1], ns[2], ns[3]);
-    m[C_CT] = wv::gather16(ct[0], ct[1], ct[2], ct[3]);
+    m[kClasses] = ct[0] | ct[1] | ct[2] | ct[3];  // nonzero: the chunk holds a byte < 0x20
 }
 
 // ---------------------------------------------------------------------------------------------
+// stage A's store of one 16-byte chunk: four 16-bit class masks, and the dirty bit of the chunk's word
+FG_WV void store_classes(const uint32_t m[kClasses + 1], uint16_t* bm16, uint32_t chunk, uint32_t stride) {
+#pragma unroll
+    for (uint32_t c = 0; c < kClasses; ++c) bm16[c * stride + chunk] = (uint16_t)m[c];
+    if (m[kClasses]) {  // rare
+        uint32_t* dirty = reinterpret_cast<uint32_t*>(bm16 + kClasses * stride);  // = the first bytes of the extra block
+        wv::lds_or(&dirty[chunk >> 7], 1u << ((chunk >> 2) & 31u));
+    }
+}
 // The wave's LDS beyond the tile and the class bitmaps ("extra" block of the pipeline)
 // ---------------------------------------------------------------------------------------------
 struct Lds {
@@ -91,27 +102,24 @@ struct Lds {
     uint16_t* items;         // [item_cap] tile position of every item of the tile
     uint64_t* kblk;          // [64] the block's sort keys: 7 key bytes big endian | extra << 7 | index in line;  ~0 = not a member
     uint32_t* kinfo;         // [64] the block's key spans: key_b | key_len << 16
-    uint64_t* s_name;        // [ent_cap] entry stash: name span (line relative) off | len << 32
-    uint64_t* s_val;         // [ent_cap] ent_val
-    uint16_t* s_tf;          // [ent_cap] type | flags << 8
-    uint32_t *l_se, *l_fife, *l_flags, *l_err, *l_cnt, *l_eoff, *l_sev;  // [lines] per line
+    uint32_t* dirty;         // [words / 32 + 1] bit w: word w of the tile holds a control character (set by stage A, cleared here)
+    uint32_t *l_se, *l_fife, *l_flags, *l_err, *l_cnt, *l_eoff, *l_sev;  // [lines] per line (l_eoff: the line's first entry slot)
     uint32_t* l_row;         // [lines][8]: ts lo, ts hi, host off, host len, msg off, msg len, full off, full len
-    uint32_t* tile_ents;     // [1] entries parked in the stash
     double* p10;             // [23] 10^0 .. 10^22 (exact): the number parser's divisors without a trip to global memory
     uint32_t* dw;            // [16 + 8] digit weights of a dword by its 4-bit digit mask (parse_num24), then 10^0 .. 10^4
     uint32_t* ent_state;     // the wave's entry-slot reservation (persists across tiles; set by the caller, wv::wave_alloc)
     uint32_t alloc_chunk;    // its reservation size
-    uint32_t item_cap, ent_cap;
+    uint32_t item_cap;
 };
 FG_WVH uint32_t up8(uint32_t v) { return (v + 7u) & ~7u; }
-// items / stash entries the arrays hold for a tile: one structural character per 12 bytes (GELF producers: one per ~20), one
-// extra per 32 bytes (~40); a tile with more items, a line whose extras no longer fit, takes the general form
+// items the array holds for a tile: one structural character per 12 bytes (GELF producers: one per ~20); a tile with more takes
+// the general form
 FG_WVH uint32_t item_cap_for(uint32_t tile_cap) { return up8(tile_cap / 12u); }  // (+ 8 spare slots in the array)
-FG_WVH uint32_t ent_cap_for(uint32_t tile_cap, uint32_t lines) { return up8(tile_cap / 32u + 2u * lines); }
+FG_WVH uint32_t dirty_bytes(uint32_t tile_cap) { return up8((tile_cap / 64u / 32u + 2u) * 4u); }
 // bytes of the extra block
 FG_WVH uint32_t extra_bytes(uint32_t tile_cap, uint32_t lines) {
     const uint32_t words = tile_cap / 64u + 2u;
-    return up8(words) + up8(words * 2u) + up8(item_cap_for(tile_cap) * 2u + 16u) + 64u * 8u + 64u * 4u + ent_cap_for(tile_cap, lines) * 18u + 16u +
+    return dirty_bytes(tile_cap) + up8(words) + up8(words * 2u) + up8(item_cap_for(tile_cap) * 2u + 16u) + 64u * 8u + 64u * 4u +
            lines * (7u * 4u + 32u) + 23u * 8u + 24u * 4u + 64u;
 }
 FG_WV Lds carve(const uint8_t* tile, uint16_t* bm16, uint32_t tile_cap, uint8_t* extra, uint32_t lines) {
@@ -121,12 +129,10 @@ FG_WV Lds carve(const uint8_t* tile, uint16_t* bm16, uint32_t tile_cap, uint8_t*
     for (uint32_t c = 0; c < kClasses; ++c) L.bm[c] = reinterpret_cast<uint32_t*>(bm16 + c * stride16);
     const uint32_t words = tile_cap / 64u + 2u;
     L.item_cap = item_cap_for(tile_cap);
-    L.ent_cap = ent_cap_for(tile_cap, lines);
-    uint8_t* p = extra;  // (8-byte members first)
+    uint8_t* p = extra;
+    L.dirty = reinterpret_cast<uint32_t*>(p); p += dirty_bytes(tile_cap);  // (first: stage A finds it right behind the bitmaps)
     L.p10 = reinterpret_cast<double*>(p); p += 23u * 8u;
     L.kblk = reinterpret_cast<uint64_t*>(p); p += 64u * 8u;
-    L.s_name = reinterpret_cast<uint64_t*>(p); p += L.ent_cap * 8u;
-    L.s_val = reinterpret_cast<uint64_t*>(p); p += L.ent_cap * 8u;
     L.l_row = reinterpret_cast<uint32_t*>(p); p += lines * 32u;
     L.kinfo = reinterpret_cast<uint32_t*>(p); p += 64u * 4u;
     L.l_se = reinterpret_cast<uint32_t*>(p); p += lines * 4u;
@@ -136,9 +142,7 @@ FG_WV Lds carve(const uint8_t* tile, uint16_t* bm16, uint32_t tile_cap, uint8_t*
     L.l_cnt = reinterpret_cast<uint32_t*>(p); p += lines * 4u;
     L.l_eoff = reinterpret_cast<uint32_t*>(p); p += lines * 4u;
     L.l_sev = reinterpret_cast<uint32_t*>(p); p += lines * 4u;
-    L.tile_ents = reinterpret_cast<uint32_t*>(p); p += 8u;
     L.dw = reinterpret_cast<uint32_t*>(p); p += 24u * 4u;
-    L.s_tf = reinterpret_cast<uint16_t*>(p); p += up8(L.ent_cap * 2u);
     L.wcnt = reinterpret_cast<uint16_t*>(p); p += up8(words * 2u);
     L.items = reinterpret_cast<uint16_t*>(p); p += up8(L.item_cap * 2u + 16u);
     L.wpar = p;
@@ -174,6 +178,11 @@ FG_WV void init_lds(const Lds& L) {
         for (uint32_t k = 16u; k < lane; ++k) p *= 10u;
         L.dw[lane] = p;
     }
+    wv::sync();
+}
+// the dirty bits of a tile with room for tile_cap bytes (before the first tile; decode_tile clears what it has looked at)
+FG_WV void clear_dirty(const Lds& L, uint32_t tile_cap) {
+    for (uint32_t i = wv::lane(); i < dirty_bytes(tile_cap) / 4u; i += wv::kLanes) L.dirty[i] = 0u;
     wv::sync();
 }
 
@@ -363,7 +372,6 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
     uint64_t* Q = reinterpret_cast<uint64_t*>(L.bm[C_Q]);
     const uint64_t* B = reinterpret_cast<const uint64_t*>(L.bm[C_B]);
     uint64_t* ST = reinterpret_cast<uint64_t*>(L.bm[C_ST]);
-    const uint64_t* CT = reinterpret_cast<const uint64_t*>(L.bm[C_CT]);
     const uint32_t* bmQ = L.bm[C_Q];
     const uint32_t* bmB = L.bm[C_B];
     const uint32_t* bmN = L.bm[C_NS];
@@ -401,7 +409,7 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
     wv::sync();
     // ---- the in-string state starts afresh at every line: toggle where the raw parity at a line's start differs from the line before
     bool use_t = false;
-    uint32_t* Tg = reinterpret_cast<uint32_t*>(L.s_name);  // the toggle bitmap borrows the (still unused) entry stash
+    uint32_t* Tg = reinterpret_cast<uint32_t*>(L.items);  // the toggle bitmap borrows the (not yet filled) item array
     {
         uint32_t rk = 0;
         if (valid) {
@@ -429,7 +437,7 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
             wv::sync();
         }
     }
-    // ---- items = structural characters outside strings (control characters count everywhere: they end the fast form)
+    // ---- items = structural characters outside strings
     uint32_t n_items_tile = 0;
     {
         const uint64_t* Tg64 = reinterpret_cast<const uint64_t*>(Tg);
@@ -438,12 +446,13 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
             const uint64_t x = use_t ? (Q[w] ^ Tg64[w]) : Q[w];
             const uint64_t S = prefix_xor64(x) ^ (L.wpar[w] ? ~0ull : 0ull);
             const uint32_t left = span - 64u * w;
-            const uint64_t E = ((ST[w] & ~S) | CT[w]) & below(left);
+            const uint64_t E = ST[w] & ~S & below(left);
             ST[w] = E;
             L.wcnt[w] = (uint16_t)cnt;
             cnt += wv::popc64(E);
         }
         const uint32_t before = wv::excl_sum(cnt, &n_items_tile);
+        if (use_t) wv::sync();  // (the item array is about to overwrite the toggle bitmap the loop above read)
         // ---- item positions, tile wide (lane = the word's owner) ----
         const bool fits = n_items_tile <= L.item_cap;  // wave-uniform
         uint32_t idx = before;
@@ -460,10 +469,9 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
         if (lane == 0) {
             L.wcnt[nwords] = (uint16_t)n_items_tile;
             ST[nwords] = 0ull;
-            *L.tile_ents = 0u;
         }
     }
-    wv::sync();  // (the toggle bitmap is dead from here on: the entry stash is free)
+    wv::sync();
     tick(0);
 
     // ================= line pass =================
@@ -473,7 +481,13 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
         fi = (uint32_t)L.wcnt[s >> 6] + wv::popc64(ST[s >> 6] & below(s & 63u));
         fe = (uint32_t)L.wcnt[e >> 6] + wv::popc64(ST[e >> 6] & below(e & 63u));
     }
-    const bool fast = valid && !tile_bail && n_items_tile <= L.item_cap && len >= 2u && (fe - fi) >= 2u && (fe - fi) <= kMaxLineItems;
+    // a control character in the line: not fast-form material.  The dirty bits say which 64-byte words hold one; a line that
+    // touches a dirty word looks at its own bytes (rare: producers escape them)
+    bool clean = true;
+    if (valid && len != 0u && wv::any_bit(L.dirty, s >> 6, ((e - 1u) >> 6) + 1u)) {
+        for (uint32_t i = s; i < e && clean; ++i) clean = L.T.byte(i) >= 0x20u;
+    }
+    const bool fast = valid && clean && !tile_bail && n_items_tile <= L.item_cap && len >= 2u && (fe - fi) >= 2u && (fe - fi) <= kMaxLineItems;
     if (valid) {
         L.l_se[lane] = s | (e << 16);
         L.l_fife[lane] = fi | (fe << 16);
@@ -740,68 +754,57 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
         }
         wv::sync();
         tick(4);
-        // ---- the line's verdict and its room in the entry stash: by the lane of the line's first item ----
+        // ---- the line's verdict, by the lane of its first item; entry slots for the block out of the wave's chunk ----
+        uint32_t my_ent = 0;
+        bool done = false;
         if (jj < n_items && jj == kfi) {
             const uint32_t lf = L.l_flags[k];
             if (!(lf & LF_BAIL) && (lf & LF_CLOSED)) {
                 const uint32_t err = L.l_err[k];
                 uint32_t status = err == 0xFFFFFFFFu ? G_OK : (err & 0xFFu);
                 if (status == G_OK && !(lf & LF_HAVE_HOST)) status = G_NOHOST;  // :110
-                const uint32_t n_ent = status == G_OK ? L.l_cnt[k] : 0u;
-                const uint32_t off = n_ent ? wv::lds_add(L.tile_ents, n_ent) : 0u;
-                if (off + n_ent > L.ent_cap) {
-                    wv::lds_or(&L.l_flags[k], LF_BAIL);  // no room in the stash (its slots stay unused): the general form takes the line
-                } else {
-                    L.l_err[k] = status;  // (reused: the final status)
-                    L.l_cnt[k] = n_ent;
-                    L.l_eoff[k] = off;
-                    wv::lds_or(&L.l_flags[k], LF_DONE);
-                }
+                my_ent = status == G_OK ? L.l_cnt[k] : 0u;
+                L.l_err[k] = status;  // (reused: the final status)
+                done = true;
             } else {
                 wv::lds_or(&L.l_flags[k], LF_BAIL);
             }
         }
+        uint32_t bl_total;
+        const uint32_t bl_off = wv::excl_sum(my_ent, &bl_total);  // (lanes that do not own a line contribute 0)
+        // (what is left of the wave's chunk takes the lines whose slices fit, whole; the rest opens the next chunk)
+        const uint32_t left = wv::wave_left(L.ent_state);
+        const uint64_t nofit = wv::ballot(my_ent != 0u && bl_off + my_ent > left);
+        const uint32_t cut_at = nofit ? wv::bcast(bl_off, wv::ctz64(nofit)) : bl_total;
+        const wv::Slots es = wv::wave_alloc(t.ent_used, t.ent_cap, L.ent_state, bl_total, cut_at, L.alloc_chunk);
+        if (done) {
+            const bool ov = es.overflow && my_ent != 0u && bl_off >= es.cut;
+            if (ov) L.l_err[k] = FG_ST_OVERFLOW;
+            L.l_cnt[k] = ov ? 0u : my_ent;
+            L.l_eoff[k] = my_ent ? es.at(bl_off) : 0u;
+            wv::lds_or(&L.l_flags[k], LF_DONE);
+        }
         wv::sync();
-        // ---- extras -> the stash, at offset(line) + rank among the line's extras (BTreeMap order) ----
+        // ---- extras -> the entry table, at first(line) + rank among the line's extras (BTreeMap order): the lanes of a block
+        //      write ONE contiguous stretch of slots ----
         if (member && which == K_OTHER) {
             const uint32_t lf = L.l_flags[k];
             if ((lf & (LF_BAIL | LF_DONE)) == LF_DONE && L.l_cnt[k] != 0u) {
                 const uint32_t slot = L.l_eoff[k] + rank_x;
-                L.s_name[slot] = (uint64_t)(key_b - ls) | ((uint64_t)kl << 32);
-                L.s_val[slot] = kind == V_STRING ? ((uint64_t)(v_b - ls) | ((uint64_t)v_len << 32)) : kind == V_NULL ? 0ull : bits;
-                L.s_tf[slot] = (uint16_t)(kind | (((kind == V_STRING && v_esc) ? (uint32_t)FG_EF_VAL_ESC : 0u) << 8));
+                t.ent_name[slot] = fg_span{key_b - ls, kl};
+                t.ent_val[slot] = kind == V_STRING ? ((uint64_t)(v_b - ls) | ((uint64_t)v_len << 32)) : kind == V_NULL ? 0ull : bits;
+                t.ent_type[slot] = (uint8_t)kind;
+                t.ent_flags[slot] = (uint8_t)((kind == V_STRING && v_esc) ? FG_EF_VAL_ESC : 0);
             }
         }
         lb = le;
         tick(5);
     }
+    // the dirty bits of this tile have been looked at: clean for the next one
+    if (wv::any(valid)) {
+        for (uint32_t i = lane; i < (nwords + 31u) / 32u + 1u; i += wv::kLanes) L.dirty[i] = 0u;
+    }
     wv::sync();
-
-    // ================= the tile's entries: ONE atomic, ONE coalesced copy =================
-    const uint32_t n_stash = *L.tile_ents > L.ent_cap ? L.ent_cap : *L.tile_ents;  // (slots of lines that did not fit were never filled)
-    // (what is left of the wave's chunk takes the lines whose slices fit, whole; the rest opens the next chunk)
-    uint32_t my_off = 0, my_cnt = 0;
-    if (valid && fast && (L.l_flags[lane] & (LF_BAIL | LF_DONE)) == LF_DONE) {
-        my_off = L.l_eoff[lane];
-        my_cnt = L.l_cnt[lane];
-    }
-    const uint32_t left = wv::wave_left(L.ent_state);
-    const uint64_t straddle = wv::ballot(my_cnt != 0u && my_off < left && my_off + my_cnt > left);
-    const uint32_t cut_at = straddle ? wv::bcast(my_off, wv::ctz64(straddle)) : left;
-    const wv::Slots es = wv::wave_alloc(t.ent_used, t.ent_cap, L.ent_state, n_stash, cut_at < n_stash ? cut_at : n_stash, L.alloc_chunk);
-    const bool overflow = es.overflow;
-    if (n_stash != 0u) {
-        for (uint32_t i = lane; i < n_stash; i += wv::kLanes) {
-            if (overflow && i >= es.cut) continue;  // (lines beyond the cut report FG_ST_OVERFLOW below)
-            const uint64_t nm = L.s_name[i];
-            const uint32_t tf = L.s_tf[i];
-            const uint32_t slot = es.at(i);
-            t.ent_name[slot] = fg_span{(uint32_t)nm, (uint32_t)(nm >> 32)};
-            t.ent_val[slot] = L.s_val[i];
-            t.ent_type[slot] = (uint8_t)(tf & 0xFFu);
-            t.ent_flags[slot] = (uint8_t)(tf >> 8);
-        }
-    }
     // ================= rows =================
     if (valid && fast) {
         const uint32_t lf = L.l_flags[lane];
@@ -809,12 +812,7 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
             out.handled = true;
             out.status = L.l_err[lane];
             out.n_ent = L.l_cnt[lane];
-            out.first = out.n_ent ? es.at(L.l_eoff[lane]) : 0u;
-            if (overflow && out.n_ent && L.l_eoff[lane] >= es.cut) {
-                out.status = FG_ST_OVERFLOW;
-                out.n_ent = 0;
-                out.first = 0;
-            }
+            out.first = out.n_ent ? L.l_eoff[lane] : 0u;
             out.have_ts = (lf & LF_HAVE_TS) ? 1u : 0u;
             out.flags = ((lf >> 8) & 0xFFu) | ((lf & LF_HAVE_TS) ? 0u : (uint32_t)FG_F_TS_NOW);  // :109
             out.severity = L.l_sev[lane];
@@ -827,7 +825,7 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
     }
     tick(6);
     if (PROF && phase && lane == 0)
-        for (int k = 0; k < 10; ++k) wv::glb_add(phase + k, (unsigned long long)pc[k]);
+        for (int k = 0; k < 10; ++k) phase[k] += (unsigned long long)pc[k];  // (the wave's own accumulators)
     return out;
 }
 

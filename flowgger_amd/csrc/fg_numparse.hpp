@@ -15,7 +15,7 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define FG_HD __host__ __device__ __forceinline__
 #define FG_HDN __host__ __device__ inline
 #else

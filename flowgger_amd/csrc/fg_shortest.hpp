@@ -17,7 +17,7 @@
 #include <stdint.h>
 #include <string.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define FGS_HD __host__ __device__ __forceinline__
 #else
 #define FGS_HD inline

@@ -10,7 +10,7 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define FGT_HD __host__ __device__ __forceinline__
 #else
 #define FGT_HD inline

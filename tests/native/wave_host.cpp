@@ -56,16 +56,22 @@ extern "C" int fgw_gelf_decode(const uint8_t* bytes, uint64_t nbytes, const uint
             const uint64_t want = offsets[g0 + nl] - a0;
             const uint32_t span = want > tile_cap ? tile_cap : (uint32_t)((want + 15ull) & ~15ull);
             // stage the tile: garbage beyond the span on purpose (the kernels must not depend on it)
+            gelf2::Lds lds = gelf2::carve(smem, bm16, tile_cap, extra, lines_per_group);
+            // (everything but the dirty bits is wiped: they persist from tile to tile -- decode_tile clears what it used)
+            std::vector<uint8_t> keep(gelf2::dirty_bytes(tile_cap));
+            if (g0 == 0) memset(keep.data(), 0, keep.size());
+            else memcpy(keep.data(), lds.dirty, keep.size());
             memset(smem, 0xA5, lds_bytes);
+            memcpy(lds.dirty, keep.data(), keep.size());
             for (uint32_t i = 0; i < span; ++i) smem[i] = a0 + i < nbytes ? bytes[a0 + i] : 0;
             for (uint32_t c = 0; c < span / 16u; ++c) {
-                uint32_t x[4], m[gelf2::kClasses];
+                uint32_t x[4], m[gelf2::kClasses + 1];
                 memcpy(x, smem + 16u * c, 16);
                 gelf2::classify(x[0], x[1], x[2], x[3], m);
                 for (uint32_t k = 0; k < gelf2::kClasses; ++k) bm16[k * stride16 + c] = (uint16_t)m[k];
+                if (m[gelf2::kClasses]) lds.dirty[c >> 7] |= 1u << ((c >> 2) & 31u);
             }
             gelf2::LineOut outs[64];
-            gelf2::Lds lds = gelf2::carve(smem, bm16, tile_cap, extra, lines_per_group);
             lds.ent_state = ent_state;  // persists across tiles, like the pipeline's two LDS words
             lds.alloc_chunk = alloc_chunk;
             emu::run_wave([&]() {
