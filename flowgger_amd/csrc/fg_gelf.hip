@@ -554,9 +554,9 @@ inline uint32_t gelf_extra_lds(uint32_t tile, uint32_t lines) { return gelf2::ex
 
 struct GelfFormat {
     static constexpr uint32_t kClasses = gelf2::kClasses;
-    static __device__ __forceinline__ void classify_store(const uint4& q, uint16_t* bm16, uint32_t chunk, uint32_t stride) {
+    static __device__ __forceinline__ void classify_store(const uint4& q, uint16_t* bm16, uint32_t chunk, uint32_t stride, uint32_t term4) {
         uint32_t m[gelf2::kClasses + 1];
-        gelf2::classify(q.x, q.y, q.z, q.w, m);
+        gelf2::classify(q.x, q.y, q.z, q.w, m, term4);
         gelf2::store_classes(m, bm16, chunk, stride);
     }
     uint8_t* extra;  // LDS behind the class bitmaps
@@ -591,10 +591,13 @@ struct GelfFormat {
     }
 };
 
-template <int NB, bool PROF, int MINW = 4>
+// TILE / LINES != 0: the geometry as compile-time constants (every LDS address becomes lane * k + immediate: without them the
+// addresses of the class bitmaps alone were 12 hoisted registers, spilled to scratch and reloaded in front of every store)
+template <int NB, bool PROF, int MINW = 4, uint32_t TILE = 0, uint32_t LINES = 0>
 __global__ __launch_bounds__(kWave, MINW) void k_gelf(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets,
-                                                  uint64_t n, DevTables t, uint32_t tile_cap, uint32_t L, uint64_t groups,
+                                                  uint64_t n, DevTables t, uint32_t tile_cap_, uint32_t L_, uint64_t groups,
                                                   unsigned long long* prof, uint64_t* stash_base, FrameArgs fr) {
+    const uint32_t tile_cap = TILE ? TILE : tile_cap_, L = LINES ? LINES : L_;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ unsigned long long pacc[PROF ? 10 : 1];
     GelfFormat fmt{smem + tile_cap + 64u + (tile_cap / 16u + 16u) * 2u * GelfFormat::kClasses, tile_cap, L, pacc};
@@ -684,6 +687,36 @@ __global__ __launch_bounds__(kWave, 2) void k_gelf_general(const uint8_t* __rest
 
 }  // namespace fg
 
+namespace {
+// the fast-form kernel with a register window of NB KiB (the bytes of the NEXT group, prefetched while this one is decoded)
+template <int NB>
+int launch_gelf_fast(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t, uint64_t avg_len,
+                     hipStream_t stream, uint32_t max_lines, fg::FrameArgs fr) {
+    fg::LaunchPlan p;
+    if (fg::plan_launch(fg::k_gelf<NB, false>, n, avg_len, 0u, 40960u, 0u, &p, max_lines, fg::GelfFormat::kClasses, fg::gelf_extra_lds))
+        return -1;
+    dim3 grid(p.blocks), block(fg::kWave);
+    if (getenv("FG_PLAN")) fprintf(stderr, "gelf plan: L %u tile %u lds %u blocks %u window %d KiB\n", p.L, p.tile, p.lds, p.blocks, NB);
+    if (NB == 3 && p.tile == 4096u && p.L == 8u && !getenv("FG_PROF") && !getenv("FG_GELF_GENERIC")) {
+        // the geometry of ~300-byte GELF (the BASELINE corpus): constants
+        hipLaunchKernelGGL((fg::k_gelf<NB, false, 4, 4096u, 8u>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L, p.groups,
+                           (unsigned long long*)nullptr, (uint64_t*)nullptr, fr);
+        return 0;
+    }
+    if (getenv("FG_PROF")) {
+        fg::ProfRun pr;
+        if (!pr.begin(stream)) return -1;
+        hipLaunchKernelGGL((fg::k_gelf<NB, true>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L, p.groups, pr.d,
+                           (uint64_t*)nullptr, fr);
+        pr.end(stream, "gelf", p);
+    } else {
+        hipLaunchKernelGGL((fg::k_gelf<NB, false>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L, p.groups,
+                           (unsigned long long*)nullptr, (uint64_t*)nullptr, fr);
+    }
+    return 0;
+}
+}  // namespace
+
 extern "C" int fg_launch_gelf(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
                               uint64_t avg_len, hipStream_t stream, uint64_t* stash, uint32_t stash_blocks, uint32_t strip,
                               const uint8_t* line_bad) {
@@ -701,37 +734,26 @@ extern "C" int fg_launch_gelf(const uint8_t* d_bytes, const uint64_t* d_offsets,
     if (const char* e = getenv("FG_LINES_PER_GROUP")) max_lines = (uint32_t)atoi(e);
     else {
         while (max_lines > 4u) {
-            if (fg::plan_launch(fg::k_gelf<fg::kComputeBoundWindow, false>, n, avg_len, 0u, 40960u, 0u, &p, max_lines, fg::GelfFormat::kClasses,
-                                fg::gelf_extra_lds))
+            if (fg::plan_launch(fg::k_gelf<2, false>, n, avg_len, 0u, 40960u, 0u, &p, max_lines, fg::GelfFormat::kClasses, fg::gelf_extra_lds))
                 return -1;
             if (p.L < max_lines) max_lines = p.L;  // (the geometry already settled on fewer lines)
             if (p.lds <= lds_budget) break;
             max_lines >>= 1;
         }
     }
-    if (fg::plan_launch(fg::k_gelf<fg::kComputeBoundWindow, false>, n, avg_len, 0u, 40960u, 0u, &p, max_lines, fg::GelfFormat::kClasses,
-                        fg::gelf_extra_lds))
+    if (fg::plan_launch(fg::k_gelf<2, false>, n, avg_len, 0u, 40960u, 0u, &p, max_lines, fg::GelfFormat::kClasses, fg::gelf_extra_lds))
         return -1;
-    dim3 grid(p.blocks), block(fg::kWave);
-    if (getenv("FG_PLAN")) fprintf(stderr, "gelf plan: L %u tile %u lds %u blocks %u\n", p.L, p.tile, p.lds, p.blocks);
-    if (getenv("FG_PROF")) {
-        fg::ProfRun pr;
-        if (!pr.begin(stream)) return -1;
-        hipLaunchKernelGGL((fg::k_gelf<fg::kComputeBoundWindow, true>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L,
-                           p.groups, pr.d, (uint64_t*)nullptr, fg::FrameArgs{strip, line_bad});
-        pr.end(stream, "gelf", p);
-    } else if (getenv("FG_GELF_W5")) {  // tuning: five waves per SIMD, 96 registers
-        fg::LaunchPlan p3;
-        if (fg::plan_launch(fg::k_gelf<fg::kComputeBoundWindow, false, 5>, n, avg_len, 0u, 40960u, 0u, &p3, max_lines,
-                            fg::GelfFormat::kClasses, fg::gelf_extra_lds))
-            return -1;
-        if (getenv("FG_PLAN")) fprintf(stderr, "gelf plan w5: L %u tile %u lds %u blocks %u\n", p3.L, p3.tile, p3.lds, p3.blocks);
-        hipLaunchKernelGGL((fg::k_gelf<fg::kComputeBoundWindow, false, 5>), dim3(p3.blocks), block, p3.lds, stream, d_bytes, d_offsets, n, *t,
-                           p3.tile, p3.L, p3.groups, (unsigned long long*)nullptr, (uint64_t*)nullptr, fg::FrameArgs{strip, line_bad});
-    } else {
-        hipLaunchKernelGGL((fg::k_gelf<fg::kComputeBoundWindow, false>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L,
-                           p.groups, (unsigned long long*)nullptr, (uint64_t*)nullptr, fg::FrameArgs{strip, line_bad});
-    }
+    // The register window should hold the whole average group: what lies beyond it is staged by plain loads whose latency
+    // nothing hides (and four chunks at a time).  1 KiB of window = 4 registers.
+    uint64_t want = ((uint64_t)p.L * avg_len * 17u / 16u + 128u + 1023u) / 1024u;
+    if (const char* e = getenv("FG_GELF_WINDOW")) want = (uint64_t)atoi(e);  // tuning
+    const fg::FrameArgs fr{strip, line_bad};
+    const dim3 block(fg::kWave);
+    int rc;
+    if (want <= 2) rc = launch_gelf_fast<2>(d_bytes, d_offsets, n, t, avg_len, stream, p.L, fr);
+    else if (want == 3) rc = launch_gelf_fast<3>(d_bytes, d_offsets, n, t, avg_len, stream, p.L, fr);
+    else rc = launch_gelf_fast<4>(d_bytes, d_offsets, n, t, avg_len, stream, p.L, fr);
+    if (rc) return rc;
     if (hipGetLastError() != hipSuccess) return -1;
     // pending lines (a frame flagged as invalid UTF-8 never is: the pipeline has overwritten its status)
     int dev = 0, cus = 0;

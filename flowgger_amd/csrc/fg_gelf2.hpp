@@ -63,23 +63,36 @@ enum : uint32_t { C_Q = 0, C_B = 1, C_ST = 2, C_NS = 3, kClasses = 4 };
 constexpr uint32_t kMaxLineItems = 64;   // structural characters of a line on the fast form ('{' + commas + '}')
 constexpr uint32_t kLines = 64;
 
-FG_WV void classify(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t m[kClasses + 1]) {
+// term4: the frame terminator ('\n' or NUL in all four bytes) that separates the lines of the tile, wv::kNoTerm without framing: a
+// terminator is not part of any line, so it does not make its word dirty (nor does the zero padding, wv::kPastSpan).
+//   C_ST is '{' '}' ',' only: a '[' or ']' outside a string always lands where a key, a value or trailing space must be, and the
+//   member fails there.  C_NS is "byte > 0x20": what it says about control characters is never used (dirty lines are not fast).
+FG_WV void classify(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t m[kClasses + 1], uint32_t term4 = wv::kNoTerm) {
     const uint32_t x[4] = {x0, x1, x2, x3};
     uint32_t q[4], b[4], st[4], ns[4], ct[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         q[k] = wv::eq_flags(x[k], 0x22222222u);
         b[k] = wv::eq_flags(x[k], 0x5C5C5C5Cu);
-        st[k] = wv::eq_flags(x[k], 0x2C2C2C2Cu) | wv::eq_flags(x[k], 0x7B7B7B7Bu) | wv::eq_flags(x[k], 0x7D7D7D7Du) |
-                wv::eq_flags(x[k], 0x5B5B5B5Bu) | wv::eq_flags(x[k], 0x5D5D5D5Du);
-        ns[k] = ~wv::eq_flags(x[k], 0x20202020u) & 0x80808080u;
+        st[k] = wv::eq_flags(x[k], 0x2C2C2C2Cu) | wv::eq_flags(x[k], 0x7B7B7B7Bu) | wv::eq_flags(x[k], 0x7D7D7D7Du);
+        ns[k] = wv::gt_flags(x[k], 0x20u);
         ct[k] = wv::ctrl_flags(x[k]);
+    }
+    uint32_t dirty = ct[0] | ct[1] | ct[2] | ct[3];
+    if (term4 != wv::kNoTerm && dirty) {  // (rare beyond the terminators themselves)
+        if (term4 == wv::kPastSpan) {
+            dirty = 0;  // the zeros behind the staged bytes are nobody's control characters
+        } else {
+            dirty = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dirty |= ct[k] & ~wv::eq_flags(x[k], term4);
+        }
     }
     m[C_Q] = wv::gather16(q[0], q[1], q[2], q[3]);
     m[C_B] = wv::gather16(b[0], b[1], b[2], b[3]);
     m[C_ST] = wv::gather16(st[0], st[1], st[2], st[3]);
     m[C_NS] = wv::gather16(ns[0], ns[1], ns[2], ns[3]);
-    m[kClasses] = ct[0] | ct[1] | ct[2] | ct[3];  // nonzero: the chunk holds a byte < 0x20
+    m[kClasses] = dirty;  // nonzero: the chunk holds a byte < 0x20
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -358,10 +371,6 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
     //                               7 item: fetch + line lookup  8 item: windows + delimiting  9 item: value
     uint64_t pc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tk = PROF ? wv::clock() : 0;
     auto tick = [&](int k) {
-#if defined(__HIP_DEVICE_COMPILE__) && defined(FG_ASM_MARKS)
-        asm volatile("; FGMARK tick %0" ::"n"(0));
-        (void)k;
-#endif
         if (PROF) {
             const uint64_t now = wv::clock();
             pc[k] += now - tk;
@@ -472,6 +481,7 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
         }
     }
     wv::sync();
+    FG_MARK(0);
     tick(0);
 
     // ================= line pass =================
@@ -504,6 +514,8 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
     }
     wv::sync();
 
+    FG_MARK(1);
+
     tick(1);
     // ================= blocks: whole lines, at most 64 items, one item per lane =================
     const uint64_t valid_m = wv::ballot(valid);
@@ -530,6 +542,7 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
         const uint32_t ls = se & 0xFFFFu, le_ = se >> 16;
         const uint32_t kfi = (ff & 0xFFFFu) - fi_lb, kfe = (ff >> 16) - fi_lb;  // the line's items: lanes [kfi, kfe)
         act = act && !(L.l_flags[k] & LF_BAIL);
+        FG_MARK(7);
         tick(7);
         bool member = false;
         uint64_t key = ~0ull, bits = 0;
@@ -571,6 +584,7 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
                                  (T.byte(a + col) == ':') & (n4 != 0ull) & (kl <= 255u);
                 uint32_t vend = v;  // window-relative index just past the value
                 bool okv = false;
+                FG_MARK(8);
                 tick(8);
                 if (ok & okm & !empty) {
                     if ((Qw >> v) & 1ull) {
@@ -627,6 +641,7 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
                             bits = tt ? 1u : 0u;
                         }
                     }
+                    FG_MARK(9);
                     tick(9);
                     if (okv) {
                         uint32_t kw[4];
@@ -647,6 +662,7 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
         L.kblk[lane] = key;
         L.kinfo[lane] = key_b | (kl << 16);
         wv::sync();
+        FG_MARK(2);
         tick(2);
 
         // ---- BTreeMap order inside the line: rank among the members (orders the errors) and among the extras (the slot) ----
@@ -696,6 +712,7 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
             }
         }
         member = member && !dropped;
+        FG_MARK(3);
         tick(3);
         // ---- gelf_decoder.rs:51-106 for this member ----
         if (member && !(L.l_flags[k] & LF_BAIL)) {
@@ -753,6 +770,7 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
             if (st != G_OK) wv::lds_min(&L.l_err[k], (rank_all << 8) | st);
         }
         wv::sync();
+        FG_MARK(4);
         tick(4);
         // ---- the line's verdict, by the lane of its first item; entry slots for the block out of the wave's chunk ----
         uint32_t my_ent = 0;
@@ -798,6 +816,7 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
             }
         }
         lb = le;
+        FG_MARK(5);
         tick(5);
     }
     // the dirty bits of this tile have been looked at: clean for the next one
@@ -823,6 +842,7 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
             out.full_off = row[6]; out.full_len = row[7];
         }
     }
+    FG_MARK(6);
     tick(6);
     if (PROF && phase && lane == 0)
         for (int k = 0; k < 10; ++k) phase[k] += (unsigned long long)pc[k];  // (the wave's own accumulators)

@@ -298,7 +298,7 @@ constexpr uint32_t kLtsvExtraLds = 768u + kSchemaLds * sizeof(SchemaEnt) + 4u * 
 
 struct LtsvFormat {
     static constexpr uint32_t kClasses = 1;
-    static __device__ __forceinline__ void classify_store(const uint4& q, uint16_t* bm16, uint32_t chunk, uint32_t) {
+    static __device__ __forceinline__ void classify_store(const uint4& q, uint16_t* bm16, uint32_t chunk, uint32_t, uint32_t) {
         bm16[chunk] = (uint16_t)mask16(q);
     }
     LtsvDevCfg cfg;

@@ -202,7 +202,9 @@ __device__ __forceinline__ uint32_t alloc_entries(const DevTables& t, uint32_t n
 // ---------------------------------------------------------------------------------------------
 // The persistent streaming loop.  F supplies
 //     static constexpr uint32_t F::kClasses                                    stage-A class bitmaps kept in LDS (0..5)
-//     static void F::classify_store(const uint4& q, uint16_t* bm16, uint32_t chunk, uint32_t stride)
+//     static void F::classify_store(const uint4& q, uint16_t* bm16, uint32_t chunk, uint32_t stride, uint32_t term4)
+//         (term4: the framing's terminator byte in all four bytes of a dword, wv::kNoTerm without framing,
+//          wv::kPastSpan for a chunk of zeros behind the last staged byte)
 //                                                                              16-bit class masks of a 16-byte chunk -> bm16[c * stride + chunk]
 //     RowOut F::decode(const GroupCtx&)  (member, may use its own state; called by all 64 lanes, converged)
 // ---------------------------------------------------------------------------------------------
@@ -298,6 +300,8 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
     // measurement build only: prof[5] = ablation flags (1 = no table stores, 2 = no stage B,
     // 4 / 8 = format-specific, see the decoders)
     const uint32_t ablate = PROF ? (uint32_t)prof[5] : 0u;
+    // the frame terminator the tile's bytes carry BETWEEN lines (never inside one), for formats whose classes care
+    const uint32_t term4 = fr.strip == FG_FRAME_LINE ? 0x0A0A0A0Au : fr.strip == FG_FRAME_NUL ? 0u : wv::kNoTerm;
 
     for (;;) {
         if (PROF) {
@@ -306,6 +310,7 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
             tm1 = __builtin_amdgcn_s_memtime();
         }
         // ---- stage A for group g: registers -> LDS, classify on the way ----------------------
+        FG_MARK(A);
         const uint32_t nchunk = span >> 4;
         const uint32_t nrow = (nchunk + kWave - 1u) / kWave;  // wave-uniform
 #pragma unroll
@@ -314,7 +319,7 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
                 uint32_t idx = k * kWave + lane;
                 uint4 q = make_uint4(v[k][0], v[k][1], v[k][2], v[k][3]);
                 dst[idx] = q;
-                F::classify_store(q, bm16, idx, bm_stride);
+                F::classify_store(q, bm16, idx, bm_stride, idx < nchunk ? term4 : wv::kPastSpan);
             }
         }
         if (nrow > (uint32_t)NB) {  // rare: bytes beyond the register window
@@ -334,11 +339,12 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
                 for (int k = 0; k < 4; ++k) {
                     const uint32_t idx = c0 + k * kWave + lane, ci = idx < last ? idx : last;
                     dst[ci] = w[k];
-                    F::classify_store(w[k], bm16, ci, bm_stride);
+                    F::classify_store(w[k], bm16, ci, bm_stride, term4);
                 }
             }
         }
         __builtin_amdgcn_sched_barrier(0);  // keep the old window dead before the new one is loaded
+        FG_MARK(S);
         if (PROF) {
             __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): LDS writes retired
             tm2 = __builtin_amdgcn_s_memtime();
@@ -356,6 +362,7 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
             load_window(pa0, pspan, v);
         }
         __builtin_amdgcn_sched_barrier(0);
+        FG_MARK(B);
         if (PROF) tm3 = __builtin_amdgcn_s_memtime();
         __syncthreads();  // single-wave workgroup: orders the LDS writes before stage B's reads
         // ---- stage B for group g ------------------------------------------------------------
@@ -429,7 +436,7 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
                             for (int k = 0; k < 2; ++k) {
                                 const uint32_t idx = c0 + k * kWave + lane, ci = idx < lastc ? idx : lastc;
                                 dst[ci] = w[k];
-                                F::classify_store(w[k], bm16, ci, bm_stride);
+                                F::classify_store(w[k], bm16, ci, bm_stride, term4);
                             }
                         }
                     }
@@ -456,6 +463,7 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
             acc3 += tm4 - tm3;
             iters += 1;
         }
+        FG_MARK(Z);
         if (!more) break;
         __syncthreads();  // stage B's LDS reads are done before the next tile overwrites them
         g = gn;

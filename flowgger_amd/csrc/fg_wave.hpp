@@ -21,6 +21,14 @@
 #include "fg_wave_emu.hpp"  // tests/native: the fiber scheduler behind the host versions below
 #endif
 
+// FG_MARK(k): with -DFG_ASM_MARKS a comment line "; FGMARK k" in the device assembly (tools/valu_count.py counts the instructions
+// between marks: these kernels are VALU-issue bound, so the static count of a straight-line phase IS its cost); else nothing
+#if defined(__HIP_DEVICE_COMPILE__) && defined(FG_ASM_MARKS)
+#define FG_MARK(k) asm volatile("; FGMARK " #k)
+#else
+#define FG_MARK(k) ((void)0)
+#endif
+
 namespace fg {
 namespace wv {
 
@@ -210,6 +218,11 @@ FG_WV uint32_t eq_flags(uint32_t x, uint32_t pat) {  // pat bytes < 0x80; exact
     const uint32_t s = ((x & 0x7F7F7F7Fu) ^ pat) + 0x7F7F7F7Fu;
     return ~(s | x) & 0x80808080u;
 }
+FG_WV uint32_t gt_flags(uint32_t x, uint32_t c) {  // byte > c (c < 0x7F); bytes >= 0x80 count as greater
+    return (((x & 0x7F7F7F7Fu) + (0x7F7F7F7Fu - c * 0x01010101u)) | x) & 0x80808080u;
+}
+constexpr uint32_t kNoTerm = 0xFFFFFFFFu;    // "no frame terminator" for the classifiers
+constexpr uint32_t kPastSpan = 0xFFFFFFFEu;  // "this chunk is the padding behind the staged bytes"
 FG_WV uint32_t ctrl_flags(uint32_t x) {  // byte < 0x20
     const uint32_t ge32 = (x & 0x7F7F7F7Fu) + 0x60606060u;
     return ~(ge32 | x) & 0x80808080u;
