@@ -119,7 +119,7 @@ struct Lds {
     uint32_t *l_se, *l_fife, *l_flags, *l_err, *l_cnt, *l_eoff, *l_sev;  // [lines] per line (l_eoff: the line's first entry slot)
     uint32_t* l_row;         // [lines][8]: ts lo, ts hi, host off, host len, msg off, msg len, full off, full len
     double* p10;             // [23] 10^0 .. 10^22 (exact): the number parser's divisors without a trip to global memory
-    uint32_t* dw;            // [16 + 8] digit weights of a dword by its 4-bit digit mask (parse_num24), then 10^0 .. 10^4
+    uint32_t* dw;            // [16 + 12] digit weights of a dword by its 4-bit digit mask (parse_num24), then 10^0 .. 10^8
     uint32_t* ent_state;     // the wave's entry-slot reservation (persists across tiles; set by the caller, wv::wave_alloc)
     uint32_t alloc_chunk;    // its reservation size
     uint32_t item_cap;
@@ -133,7 +133,7 @@ FG_WVH uint32_t dirty_bytes(uint32_t tile_cap) { return up8((tile_cap / 64u / 32
 FG_WVH uint32_t extra_bytes(uint32_t tile_cap, uint32_t lines) {
     const uint32_t words = tile_cap / 64u + 2u;
     return dirty_bytes(tile_cap) + up8(words) + up8(words * 2u) + up8(item_cap_for(tile_cap) * 2u + 16u) + 64u * 8u + 64u * 4u +
-           lines * (7u * 4u + 32u) + 23u * 8u + 24u * 4u + 64u;
+           lines * (7u * 4u + 32u) + 23u * 8u + 28u * 4u + 64u;
 }
 FG_WV Lds carve(const uint8_t* tile, uint16_t* bm16, uint32_t tile_cap, uint8_t* extra, uint32_t lines) {
     Lds L;
@@ -155,7 +155,7 @@ FG_WV Lds carve(const uint8_t* tile, uint16_t* bm16, uint32_t tile_cap, uint8_t*
     L.l_cnt = reinterpret_cast<uint32_t*>(p); p += lines * 4u;
     L.l_eoff = reinterpret_cast<uint32_t*>(p); p += lines * 4u;
     L.l_sev = reinterpret_cast<uint32_t*>(p); p += lines * 4u;
-    L.dw = reinterpret_cast<uint32_t*>(p); p += 24u * 4u;
+    L.dw = reinterpret_cast<uint32_t*>(p); p += 28u * 4u;
     L.wcnt = reinterpret_cast<uint16_t*>(p); p += up8(words * 2u);
     L.items = reinterpret_cast<uint16_t*>(p); p += up8(L.item_cap * 2u + 16u);
     L.wpar = p;
@@ -186,7 +186,7 @@ FG_WV void init_lds(const Lds& L) {
         }
         L.dw[lane] = wgt;
     }
-    if (lane >= 16u && lane < 21u) {
+    if (lane >= 16u && lane < 25u) {
         uint32_t p = 1;
         for (uint32_t k = 16u; k < lane; ++k) p *= 10u;
         L.dw[lane] = p;
@@ -324,13 +324,20 @@ FG_WV bool parse_num24(const uint32_t w[6], uint32_t n, const double* p10, const
     const bool ok = (nondig & (nondig - 1u)) == 0u && dot_ok && nd_total >= 1u && nd_total <= 19u && dp >= o + 1u && (!has_dot || nf >= 1u) &&
                     !(c0 == '0' && ni > 1u);
     if (!ok) return false;
-    uint64_t sig = 0;
+    // the dwords' values (<= 9999 each) pair up with 24-bit multiplies (full rate); two wide multiplies chain the three pairs
+    uint32_t val[6], cnt[6];
 #pragma unroll
     for (uint32_t k = 0; k < 6; ++k) {
         const uint32_t m = (digits >> (4u * k)) & 15u;
-        const uint32_t v = wv::udot4(x[k], dwt[m], m == 15u ? (x[k] & 0xFFu) * 1000u : 0u);
-        sig = sig * (uint64_t)dwt[16u + wv::popc32(m)] + v;
+        val[k] = wv::udot4(x[k], dwt[m], m == 15u ? (x[k] & 0xFFu) * 1000u : 0u);
+        cnt[k] = wv::popc32(m);
     }
+    const uint32_t* p10u = dwt + 16;
+    const uint32_t p0 = wv::mad24(val[0], p10u[cnt[1]], val[1]);  // < 10^8
+    const uint32_t p1 = wv::mad24(val[2], p10u[cnt[3]], val[3]);
+    const uint32_t p2 = wv::mad24(val[4], p10u[cnt[5]], val[5]);
+    uint64_t sig = (uint64_t)p0 * p10u[cnt[2] + cnt[3]] + p1;  // < 10^16
+    sig = sig * p10u[cnt[4] + cnt[5]] + p2;                   // <= 19 digits: < 2^64
     if (has_dot) {
         // visit_f64_from_parts: f = sig as f64; f /= POW10[nf]   (nf <= 18 here: the divisor comes from LDS)
         *kind = V_F64;
@@ -594,10 +601,23 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
                         const uint64_t q3 = Qw & above_v;
                         uint32_t ve;
                         bool esc;
+                        uint64_t bsw = 0ull;  // the body's backslashes, when the whole body lies inside the first window
+                        bool whole = false;
                         if (q3 != 0ull) {
                             ve = wv::ctz64(q3);
-                            esc = (Bw & above_v & below(ve)) != 0ull;
+                            bsw = Bw & above_v & below(ve);
+                            whole = true;
+                            esc = bsw != 0ull;
                             okv = (NSw & (~1ull << ve)) == 0ull && (m <= 64u || wv::find_bit(bmN, a + 64u, nxt) >= nxt);
+                        } else if (m > 64u && m <= 128u) {
+                            // the closing quote in the second 64 bytes of the member (a short_message of 60+ bytes): one more window
+                            const uint64_t in2 = below(m - 64u);
+                            const uint64_t Q2 = wv::window64(bmQ, a + 64u) & in2, N2 = wv::window64(bmN, a + 64u) & in2;
+                            const uint64_t B2 = wv::window64(bmB, a + 64u) & in2;
+                            const uint32_t ve2 = wv::ctz64(Q2 | top);
+                            ve = Q2 != 0ull ? 64u + ve2 : m;
+                            esc = ((Bw & above_v) | (B2 & below(ve2))) != 0ull;
+                            okv = Q2 != 0ull && (N2 & (~1ull << ve2)) == 0ull;
                         } else {
                             ve = m > 64u ? wv::find_bit(bmQ, a + 64u, nxt) - a : m;
                             esc = ve < m && wv::any_bit(bmB, a + v + 1u, a + ve);
@@ -608,7 +628,15 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
                         vend = ve + 1u;
                         if (okv && esc) {
                             v_esc = 1;
-                            okv = escapes_ok(T, bmB, v_b, a + ve);
+                            // the everyday case: ONE escape, of the two-byte kind
+                            bool simple = false;
+                            if (whole) {
+                                const uint32_t hb = wv::ctz64(bsw | top);
+                                const uint32_t c2 = T.byte(a + hb + 1u);
+                                const bool two = c2 == '"' || c2 == '\\' || c2 == '/' || c2 == 'b' || c2 == 'f' || c2 == 'n' || c2 == 'r' || c2 == 't';
+                                simple = two && hb + 1u < ve && (bsw & ~(3ull << hb)) == 0ull;
+                            }
+                            if (!simple) okv = escapes_ok(T, bmB, v_b, a + ve);
                         }
                     } else {
                         // ---- number / literal: the token ends at the first space (or at the delimiter) ----
@@ -617,10 +645,8 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
                         vend = te < m ? te : m;
                         const uint32_t n = vend - v;
                         okv = m <= 64u && (NSw & ~below(vend)) == 0ull;  // (a token with 40 spaces behind it is not fast-form material)
-                        uint32_t wv6[6], lo[4], hi[4];
-                        T.load16(a + v, lo);
-                        T.load16(a + v + 16u, hi);
-                        wv6[0] = lo[0]; wv6[1] = lo[1]; wv6[2] = lo[2]; wv6[3] = lo[3]; wv6[4] = hi[0]; wv6[5] = hi[1];
+                        uint32_t wv6[6];
+                        T.load24(a + v, wv6);
                         const uint32_t cv = wv6[0] & 0xFFu;
                         if (cv == '-' || (cv - '0') <= 9u) {
                             uint32_t k2 = 0;
@@ -666,7 +692,7 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
         tick(2);
 
         // ---- BTreeMap order inside the line: rank among the members (orders the errors) and among the extras (the slot) ----
-        uint32_t rank_all = 0, rank_x = 0;
+        uint32_t rank_x = 0;  // (the rank among ALL members only orders errors: counted where one is found)
         bool dropped = false;
         member = member && !(L.l_flags[k] & LF_BAIL);
         if (member) {
@@ -680,7 +706,6 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
                 for (uint32_t u = 0; u < 4u; ++u) {
                     const uint32_t tt = t0 + u;
                     const bool in = tt < kfe;
-                    rank_all += (in && ko[u] < key) ? 1u : 0u;
                     rank_x += (in && ko[u] < key && (ko[u] & 0x80ull)) ? 1u : 0u;
                     if (in && tt != jj && (ko[u] >> 8) == (key >> 8)) {
                         // same 7-byte prefix: the same key twice (the later one wins, BTreeMap::insert), or two keys the prefix
@@ -703,10 +728,9 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
             if (dropped) L.kblk[lane] = ~0ull;
             wv::sync();
             if (member && !dropped && (L.l_flags[k] & LF_DUP)) {
-                rank_all = rank_x = 0;
+                rank_x = 0;
                 for (uint32_t tt = kfi; tt < kfe; ++tt) {
                     const uint64_t ko = L.kblk[tt];
-                    rank_all += ko < key ? 1u : 0u;
                     rank_x += (ko < key && (ko & 0x80ull)) ? 1u : 0u;
                 }
             }
@@ -767,7 +791,11 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
                 default:
                     wv::lds_add(&L.l_cnt[k], 1u);  // an extra (nested values never reach the fast form)
             }
-            if (st != G_OK) wv::lds_min(&L.l_err[k], (rank_all << 8) | st);
+            if (st != G_OK) {  // the FIRST error in BTreeMap order is the line's: rank among all members
+                uint32_t rank_all = 0;
+                for (uint32_t tt = kfi; tt < kfe; ++tt) rank_all += L.kblk[tt] < key ? 1u : 0u;
+                wv::lds_min(&L.l_err[k], (rank_all << 8) | st);
+            }
         }
         wv::sync();
         FG_MARK(4);

@@ -254,6 +254,14 @@ struct Bytes {
         q[2] = alignbyte(r3, r2, s);
         q[3] = alignbyte(r4, r3, s);
     }
+    FG_WV void load24(uint32_t a, uint32_t q[6]) const {  // (reads up to 27 bytes past a: inside the tile's padding)
+        const uint32_t d = a >> 2, s = a & 3u;
+        uint32_t r[7];
+#pragma unroll
+        for (uint32_t k = 0; k < 7u; ++k) r[k] = w[d + k];
+#pragma unroll
+        for (uint32_t k = 0; k < 6u; ++k) q[k] = alignbyte(r[k + 1], r[k], s);
+    }
 };
 
 // first set bit of bitmap bm at tile position >= p and < lim, else lim.  INV = true searches the complement.

@@ -120,7 +120,7 @@ extern "C" int fgw_parse_num24(const uint8_t* tok, uint32_t n, uint32_t* kind, u
     memcpy(buf, tok, n);
     memcpy(w, buf, 24);
     static double p10[23];
-    static uint32_t dw[24];
+    static uint32_t dw[28];
     static bool init = false;
     if (!init) {
         std::vector<uint64_t> lds(4096);

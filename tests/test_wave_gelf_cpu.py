@@ -89,7 +89,14 @@ def test_semantics(wave, oracle):
         '{"host":"h" "a":1}', '{"host":"h","a":1 2}', '{"host":"h","a": }', '{"host":"h","":""}', '{"host":"h","a":"\\u00e9\\ud83d\\ude00"}',
         '{"host":"h","a":truex}', '{"host":"h","a":1,"b"}', '{"host":"h","a":1,"b":}', '{"host":"h","a":1,:2}', '{"host":"h"},',
         '{"host":"h","a":1.5e3,"b":-0.0001,"c":1e-7,"d":12345678901234567890,"e":0}', '{"host":"h","level":0}', '{"host":"h","level":007}',
-        '{"host":"h","x":"' + "y" * 3000 + '"}', '{"' + "k" * 255 + '":1,"host":"h"}', '{"' + "k" * 256 + '":1,"host":"h"}',
+        '{"host":"h","x":"' + "y" * 3000 + '"}',
+        # strings whose closing quote lies in the member's second 64 bytes; one / two / odd escapes
+        '{"host":"h","short_message":"' + "m" * 70 + '"}', '{"host":"h","short_message":"' + "m" * 70 + '\\n tail"}',
+        '{"host":"h","short_message":"' + "m" * 70 + '"  }', '{"host":"h","short_message":"' + "m" * 70 + '" x}',
+        '{"host":"h","short_message":"' + "m" * 70 + '\\q"}', '{"host":"h","short_message":"\\t' + "m" * 70 + '"}',
+        '{"host":"h","short_message":"' + "m" * 110 + '"}', '{"host":"h","short_message":"' + "m" * 130 + '"}',
+        '{"host":"h","a":"x\\\\"}', '{"host":"h","a":"\\\\\\n"}', '{"host":"h","a":"\\n\\t"}', '{"host":"h","a":"\\q"}',
+        '{"host":"h","a":"\\/"}', '{"host":"h","a":"tab\\there"}', '{"host":"h","a":"\\u00e9"}', '{"host":"h","a":"\\"}', '{"' + "k" * 255 + '":1,"host":"h"}', '{"' + "k" * 256 + '":1,"host":"h"}',
     ]
     handled = check(wave, oracle, lines)
     by_line = dict(zip(lines, handled))  # (keyed by the str spelling above)
