@@ -752,7 +752,9 @@ extern "C" int fg_launch_gelf(const uint8_t* d_bytes, const uint64_t* d_offsets,
     int rc;
     if (want <= 2) rc = launch_gelf_fast<2>(d_bytes, d_offsets, n, t, avg_len, stream, p.L, fr);
     else if (want == 3) rc = launch_gelf_fast<3>(d_bytes, d_offsets, n, t, avg_len, stream, p.L, fr);
-    else rc = launch_gelf_fast<4>(d_bytes, d_offsets, n, t, avg_len, stream, p.L, fr);
+    else if (want == 4) rc = launch_gelf_fast<4>(d_bytes, d_offsets, n, t, avg_len, stream, p.L, fr);
+    else if (want == 5) rc = launch_gelf_fast<5>(d_bytes, d_offsets, n, t, avg_len, stream, p.L, fr);
+    else rc = launch_gelf_fast<6>(d_bytes, d_offsets, n, t, avg_len, stream, p.L, fr);
     if (rc) return rc;
     if (hipGetLastError() != hipSuccess) return -1;
     // pending lines (a frame flagged as invalid UTF-8 never is: the pipeline has overwritten its status)

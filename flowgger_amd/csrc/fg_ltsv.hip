@@ -298,6 +298,7 @@ constexpr uint32_t kLtsvExtraLds = 768u + kSchemaLds * sizeof(SchemaEnt) + 4u * 
 
 struct LtsvFormat {
     static constexpr uint32_t kClasses = 1;
+    static constexpr int kTailBatch = 16;  // the whole tile beyond the 2 KiB window in one round trip
     static __device__ __forceinline__ void classify_store(const uint4& q, uint16_t* bm16, uint32_t chunk, uint32_t, uint32_t) {
         bm16[chunk] = (uint16_t)mask16(q);
     }
@@ -312,16 +313,24 @@ struct LtsvFormat {
     // whose first 16 bytes are in w[] (zero padded)
     __device__ __forceinline__ uint32_t lookup(LdsReader& rd, uint32_t nb, uint32_t nl, const uint32_t w[4]) const {
         const uint32_t ns = cfg.n_schema < kSchemaLds ? cfg.n_schema : kSchemaLds;
-        for (uint32_t k = 0; k < ns; ++k) {
-            const SchemaEnt& e = schema[k];
-            if (e.len != nl) continue;
-            if (e.name[0] != w[0] || e.name[1] != w[1] || e.name[2] != w[2] || e.name[3] != w[3]) continue;
-            bool eq = true;
-            if (nl > 16u) {
-                const uint32_t o = cfg.name_off[k];
-                for (uint32_t i = 16; i < nl && eq; ++i) eq = rd.byte(nb + i) == cfg.blob[o + i];
+        // four entries per LDS round trip (every lane reads the same entry: a broadcast); the loads of a batch are issued
+        // before the first compare
+        for (uint32_t k0 = 0; k0 < ns; k0 += 4u) {
+            SchemaEnt e[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; ++j) e[j] = schema[k0 + j < ns ? k0 + j : ns - 1u];
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; ++j) {
+                if (k0 + j >= ns) break;  // scalar
+                if (e[j].len == nl && e[j].name[0] == w[0] && e[j].name[1] == w[1] && e[j].name[2] == w[2] && e[j].name[3] == w[3]) {
+                    bool eq = true;
+                    if (nl > 16u) {
+                        const uint32_t o = cfg.name_off[k0 + j];
+                        for (uint32_t i = 16; i < nl && eq; ++i) eq = rd.byte(nb + i) == cfg.blob[o + i];
+                    }
+                    if (eq) return e[j].type;
+                }
             }
-            if (eq) return e.type;
         }
         for (uint32_t k = kSchemaLds; k < cfg.n_schema; ++k) {
             uint32_t o = cfg.name_off[k], l = cfg.name_off[k + 1] - o;
@@ -335,7 +344,18 @@ struct LtsvFormat {
 
     // One forward pass over a line in the tile; pairs go to the stash (or, STASH = false, are
     // only counted -- a line with more than kStashEntries pairs is re-walked by ltsv_walk<true>).
-    __device__ __forceinline__ void walk_tile(const Tile& T, uint32_t base, uint32_t len, LRow& r, uint64_t* stash) const {
+    // (measurement build: cycles of  0 part end + name window + ':'  1 time  2 host / message / level  3 schema lookup
+    //  4 typed value  5 suffix + stash  6 slots + copy-out; lane 0 adds them up per tile)
+    template <bool PROF>
+    __device__ __forceinline__ void walk_tile(const Tile& T, uint32_t base, uint32_t len, LRow& r, uint64_t* stash, uint64_t* pc) const {
+        uint64_t tk = PROF ? wv::clock() : 0;
+        auto tick = [&](int k) {
+            if (PROF) {
+                const uint64_t now = wv::clock();
+                pc[k] += now - tk;
+                tk = now;
+            }
+        };
         LdsReader rd(T.w, base);
         WinReader wr(T, base);  // numbers / timestamps: 16 bytes per LDS round trip
         uint32_t cnt = 0;
@@ -357,6 +377,7 @@ struct LtsvFormat {
                 while (q < pe && rd.byte(q) != ':') ++q;
                 if (q < pe) colon = q;
             }
+            tick(0);
             if (colon != 0xFFFFFFFFu) {  // else: println!("Missing value for name ...") :99, no effect on the Record
                 const uint32_t nb = ps, ne = colon, nl = colon - ps, vb = colon + 1, ve = pe;
                 // the name's first 16 bytes, zero padded (for the key matches)
@@ -380,6 +401,7 @@ struct LtsvFormat {
                     }
                     r.ts = ts;
                     r.have_ts = 1;
+                    tick(1);
                 } else if (nl == 4u && short4 && k[0] == 0x74736F68u) {    // "host"
                     r.host_off = vb;
                     r.host_len = ve - vb;
@@ -398,8 +420,11 @@ struct LtsvFormat {
                         return;
                     }
                     r.severity = (uint32_t)lv;
+                    tick(2);
                 } else {
+                    tick(2);
                     const uint32_t ty = lookup(rd, nb, nl, k);
+                    tick(3);
                     uint64_t val = (uint64_t)vb | ((uint64_t)(ve - vb) << 32);
                     uint32_t flags = 0;
                     if (ty != FG_T_STRING) {
@@ -432,6 +457,7 @@ struct LtsvFormat {
                             }
                             val = x;
                         }
+                        tick(4);
                         // suffix: appended unless the name already ends with it (:131-136)
                         const SuffixEnt sf = suffix[ty - FG_T_BOOL];
                         if (sf.len != 0xFFFFFFFFu) {
@@ -457,6 +483,7 @@ struct LtsvFormat {
                         stash[(cnt * 2u + 1u) * kWave + threadIdx.x] = val;
                     }
                     ++cnt;
+                    tick(5);
                 }
             }
             if (pe >= len) break;
@@ -482,9 +509,13 @@ struct LtsvFormat {
         LRow r;
         const bool name_fits = len < 65536u;  // stash records keep 16-bit name offsets
         const bool tile_lane = c.valid && in_tile && name_fits;
+        uint64_t pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        uint64_t t6 = c.phase ? wv::clock() : 0;
         if (c.valid) {
             if (tile_lane) {
-                walk_tile(T, base, len, r, c.stash);
+                if (c.phase) walk_tile<true>(T, base, len, r, c.stash, pc);
+                else walk_tile<false>(T, base, len, r, c.stash, pc);
+                if (c.phase) t6 = wv::clock();
             } else if (in_tile) {
                 LdsReader rd(T.w, base);
                 ltsv_walk<false>(rd, len, cfg, lds_digits, r, t, 0);
@@ -502,13 +533,26 @@ struct LtsvFormat {
         }
         if (r.n_ent != 0) {
             if (tile_lane && c.stash && r.n_ent <= kStashEntries) {
-                for (uint32_t k = 0; k < r.n_ent; ++k) {  // k-major in the stash: coalesced reads
-                    const uint64_t rec = c.stash[(k * 2u) * kWave + lane];
-                    const uint64_t val = c.stash[(k * 2u + 1u) * kWave + lane];
-                    t.ent_name[first + k] = fg_span{(uint32_t)rec & 0xFFFFu, (uint32_t)(rec >> 16) & 0xFFFFu};
-                    t.ent_val[first + k] = val;
-                    t.ent_type[first + k] = (uint8_t)((rec >> 32) & 0xFFu);
-                    t.ent_flags[first + k] = (uint8_t)((rec >> 40) & 0xFFu);
+                // k-major in the stash: coalesced reads.  Four records are in flight before the first store (the compiler cannot
+                // hoist a stash load above a table store: for all it knows they alias)
+                for (uint32_t k0 = 0; k0 < r.n_ent; k0 += 4u) {
+                    uint64_t rec[4], val[4];
+#pragma unroll
+                    for (uint32_t j = 0; j < 4u; ++j) {
+                        const uint32_t k = k0 + j < r.n_ent ? k0 + j : r.n_ent - 1u;
+                        rec[j] = c.stash[(k * 2u) * kWave + lane];
+                        val[j] = c.stash[(k * 2u + 1u) * kWave + lane];
+                    }
+#pragma unroll
+                    for (uint32_t j = 0; j < 4u; ++j) {
+                        const uint32_t k = k0 + j;
+                        if (k < r.n_ent) {
+                            t.ent_name[first + k] = fg_span{(uint32_t)rec[j] & 0xFFFFu, (uint32_t)(rec[j] >> 16) & 0xFFFFu};
+                            t.ent_val[first + k] = val[j];
+                            t.ent_type[first + k] = (uint8_t)((rec[j] >> 32) & 0xFFu);
+                            t.ent_flags[first + k] = (uint8_t)((rec[j] >> 40) & 0xFFu);
+                        }
+                    }
                 }
             } else {
                 LRow scratch = r;
@@ -520,6 +564,11 @@ struct LtsvFormat {
                     ltsv_walk<true>(rd, len, cfg, lds_digits, scratch, t, first);
                 }
             }
+        }
+        if (c.phase) {
+            pc[6] += wv::clock() - t6;
+            if (lane == 0)
+                for (int k = 0; k < 7; ++k) atomicAdd(c.phase + k, (unsigned long long)pc[k]);
         }
         RowOut o;
         const bool ok = r.status == L_OK;

@@ -230,6 +230,12 @@ struct FrameArgs {
     const uint8_t* line_bad;  // [n] 1 = not valid UTF-8 (or null)
 };
 
+// rows of 1 KiB the tail of stage A loads before it stores the first (a format overrides it with  static constexpr int kTailBatch)
+template <class F, class = void>
+struct tail_batch { static constexpr int value = 4; };
+template <class F>
+struct tail_batch<F, decltype((void)F::kTailBatch)> { static constexpr int value = F::kTailBatch; };
+
 template <int NB, bool PROF, class F>
 __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets,
                                                 uint64_t n, const DevTables& t, uint32_t tile_cap, uint32_t L, uint64_t groups,
@@ -328,18 +334,23 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
             // address): with `if (idx < nchunk)` the compiler kept w[] in scratch memory and waited for each load
             // before issuing the next -- serialised HBM round trips instead of four loads in flight.
             const uint32_t last = nchunk - 1u;
-            for (uint32_t c0 = NB * kWave; c0 < nchunk; c0 += kWave * 4) {
-                uint4 w[4];  // (the window registers are dead here)
+            // (TB loads in flight per lane: a format whose tile is mostly staged HERE -- a 2 KiB window under an 18 KiB tile -- pays
+            //  the load latency once per TB KiB, and stage B's registers are dead at this point)
+            constexpr int TB = tail_batch<F>::value;
+            for (uint32_t c0 = NB * kWave; c0 < nchunk; c0 += kWave * TB) {
+                uint4 w[TB];  // (the window registers are dead here)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < TB; ++k) {
                     const uint32_t idx = c0 + k * kWave + lane;
                     w[k] = src[idx < last ? idx : last];
                 }
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint32_t idx = c0 + k * kWave + lane, ci = idx < last ? idx : last;
-                    dst[ci] = w[k];
-                    F::classify_store(w[k], bm16, ci, bm_stride, term4);
+                for (int k = 0; k < TB; ++k) {
+                    if (k == 0 || c0 + k * kWave < nchunk) {  // (scalar: whole rows past the end are skipped)
+                        const uint32_t idx = c0 + k * kWave + lane, ci = idx < last ? idx : last;
+                        dst[ci] = w[k];
+                        F::classify_store(w[k], bm16, ci, bm_stride, term4);
+                    }
                 }
             }
         }
