@@ -123,3 +123,111 @@ def test_transcode_large_batch_is_sliced_over_two_streams(oracle, monkeypatch, s
     oblob, ooffs, ost = oracle.decode_encode_batch(fmt, oenc, om, data, offsets[: m + 1], None, extra=None, prepend=None, now_ts=now_ts)
     assert np.array_equal(sliced.out_offsets[: m + 1], ooffs) and np.array_equal(sliced.out[: int(ooffs[-1])], oblob)
     assert np.array_equal(np.minimum(sliced.enc_status[:m], 2), ost)
+
+
+def _frames(raw: bytes, framing: str):
+    """(start, end incl. terminator, body) per frame: BufRead::lines() / split(0) (line_splitter.rs:17-25, nul_splitter.rs:18-40)."""
+    delim = b"\n" if framing == "line" else b"\0"
+    out, pos = [], 0
+    while pos < len(raw):
+        k = raw.find(delim, pos)
+        end = len(raw) if k < 0 else k + 1
+        body = raw[pos:end]
+        if k >= 0:
+            body = body[:-1]
+            if framing == "line" and body.endswith(b"\r"):
+                body = body[:-1]
+        out.append((pos, end, body))
+        pos = end
+    return out
+
+
+@pytest.mark.parametrize("fmt_name", ["gelf", "ltsv"])
+@pytest.mark.parametrize("framing", ["line", "nul"])
+def test_framed_streams_decode_like_bare_lines(oracle, fmt_name, framing):
+    """GPU framing + decode of a raw stream for the decoders whose tiles carry class bitmaps: the frame terminators sit between the
+    lines of a tile (GELF: they must not count as control characters of a line; a control character INSIDE a line still does),
+    CRLF endings, empty frames, an unterminated tail.  Every row equals the oracle's decode of the bare line."""
+    import torch
+    from flowgger_amd import _lib as L
+    from flowgger_amd.tables import DeviceTables
+
+    if fmt_name == "gelf":
+        dec, fmt, cfg = GelfDecoder(), GELF, None
+        lines = synth.gelf_lines(6000, cfg=3)
+        extra = [b'{"host":"h","a":"tab\there"}', b'{"host":"h",\t"a":1}', b'{"host":"a\rb"}', b'{"host":"h","a":"x\x01y"}', b'{"host":"h"}\r',
+                 b' {"host":"h" , "b" : 1}', b'{"host":"h","s":"' + b"m" * 90 + b'"}', b'{"host":"h","s":"q\\"uote","t":"\\u00e9"}', b"{}", b"[1,2]"]
+        if framing == "nul":
+            extra += [b'{"host":"line1\nline2"}', b'{"host":"h",\n"a":1}', b'\n{"host":"h"}\n']
+    else:
+        dec, fmt, cfg = LTSVDecoder(synth.LTSV_CONFIG), LTSV, synth.LTSV_CONFIG
+        lines = synth.ltsv_lines(6000, cfg=5)
+        extra = [b"time:1\thost:h\tcounter:18446744073709551615\tscore:-9223372036854775808\tmean:1e308\tdone:true", b"time:1\thost:h\r",
+                 b"host:h\ttime:[2000-01-01T00:00:00Z]\tmessage:m", b"time:1\thost:h\tcounter:+5", b"time:1\thost:h\tmean:.5\tscore:+7"]
+    rng = np.random.default_rng(0x51a)
+    delim = b"\n" if framing == "line" else b"\0"
+    pieces = []
+    for i, ln in enumerate(lines):
+        if i % 13 == 4:
+            ln = extra[(i // 13) % len(extra)]
+        if framing == "line" and i % 5 == 1 and b"\n" not in ln:
+            ln = ln + b"\r"
+        if i % 211 == 0:
+            ln = b""
+        pieces.append(ln + delim)
+    for tail in (b"", b'{"host":"tail"}' if fmt_name == "gelf" else b"time:1\thost:tail"):
+        raw = b"".join(pieces) + tail
+        ref = _frames(raw, framing)
+        dev = torch.device("cuda", dec.device)
+        d_bytes = torch.cat([torch.frombuffer(bytearray(raw), dtype=torch.uint8), torch.zeros(32, dtype=torch.uint8)]).to(dev)
+        d_raw = d_bytes[:len(raw)]
+        fr = L.FG_FRAME_LINE if framing == "line" else L.FG_FRAME_NUL
+        d_offsets, d_bad, n = dec.frame_device(d_raw, fr)
+        assert n == len(ref)
+        offs = d_offsets[:n + 1].cpu().numpy().astype(np.uint64)
+        assert np.array_equal(offs[:-1], np.array([r[0] for r in ref], np.uint64))
+        tables = DeviceTables(n, len(raw) // 8 + 1024, dev)
+        dec.decode_frames_device(d_raw, d_offsets, n, tables, fr, d_bad)
+        torch.cuda.synchronize(dev)
+        host = tables.to_host()
+        bare = [r[2] for r in ref]
+        gdata, goffs = synth.pack(bare)
+        oblob, ooffs = oracle.decode_batch(fmt, gdata, goffs, cfg)
+        blob, boffs = host.serialize(fmt, np.frombuffer(raw, np.uint8), offs, cfg=dec._cfg)
+        for i in range(n):
+            a = blob[int(boffs[i]):int(boffs[i + 1])].tobytes()
+            b = oblob[int(ooffs[i]):int(ooffs[i + 1])].tobytes()
+            assert a == b, (i, bare[i][:100])
+
+
+def test_ltsv_schema_lookup_beyond_one_batch(oracle):
+    """The LDS schema mirror is matched four entries per round trip: schemas of 1, 4, 5, 9 and 40 names (beyond the 32 mirrored
+    entries), names longer than the 16 mirrored bytes, names that share their first 16 bytes, every type."""
+    from gpu_util import host_path_blob
+
+    types = ["u64", "i64", "f64", "bool", "string"]
+    vals = {"u64": "12345", "i64": "-77", "f64": "2.5", "bool": "true", "string": "text"}
+    for n_names in (1, 4, 5, 9, 40):
+        names = [f"k{j:02d}" for j in range(n_names)]
+        names[0] = "a_name_longer_than_sixteen_bytes_x"
+        if n_names > 4:
+            names[3] = "a_name_longer_than_sixteen_bytes_y"  # same first 16 bytes, same length
+            names[4] = "a_name_longer_than_sixteen_bytes_yz"
+        schema = {nm: types[j % 5] for j, nm in enumerate(names)}
+        config = {"input": {"ltsv_schema": schema, "ltsv_suffixes": {"u64": "_u64", "bool": "_b"}}}
+        dec = LTSVDecoder(config)
+        lines = []
+        for r in range(300):
+            parts = ["time:1385053862.3072", "host:h"]
+            for j in range(r % 7, n_names, max(1, n_names // 6)):
+                parts.append(f"{names[j]}:{vals[schema[names[j]]]}")
+            parts.append("zzz_not_in_schema:1")
+            parts.append("a_name_longer_than_sixteen_bytes_q:free text")
+            if r % 50 == 49:
+                parts.append(f"{names[0]}:not a number")
+            lines.append("\t".join(parts).encode())
+        data, offsets = synth.pack(lines)
+        oblob, ooffs = oracle.decode_batch(LTSV, data, offsets, config)
+        (blob, offs), _ = host_path_blob(dec, data, offsets)
+        assert np.array_equal(offs, ooffs)
+        assert blob[:int(offs[-1])].tobytes() == oblob[:int(ooffs[-1])].tobytes()
