@@ -299,6 +299,7 @@ constexpr uint32_t kLtsvExtraLds = 768u + kSchemaLds * sizeof(SchemaEnt) + 4u * 
 struct LtsvFormat {
     static constexpr uint32_t kClasses = 1;
     static constexpr int kTailBatch = 16;  // the whole tile beyond the 2 KiB window in one round trip
+    static constexpr bool kDeferRowStore = false;  // (stage A waits for the tail's loads anyway)
     static __device__ __forceinline__ void classify_store(const uint4& q, uint16_t* bm16, uint32_t chunk, uint32_t, uint32_t) {
         bm16[chunk] = (uint16_t)mask16(q);
     }
@@ -516,23 +517,39 @@ struct LtsvFormat {
                 if (c.phase) walk_tile<true>(T, base, len, r, c.stash, pc);
                 else walk_tile<false>(T, base, len, r, c.stash, pc);
                 if (c.phase) t6 = wv::clock();
-            } else if (in_tile) {
-                LdsReader rd(T.w, base);
-                ltsv_walk<false>(rd, len, cfg, lds_digits, r, t, 0);
             } else {
-                GlobalReader rd(reinterpret_cast<const uint32_t*>(c.bytes), c.o0);
-                ltsv_walk<false>(rd, len, cfg, lds_digits, r, t, 0);
+                // (rare; a real call: its LRow lives in memory, so it gets its own -- `r` must never have its address taken, or
+                //  the fast path's row would live in scratch memory too)
+                // The same goes for the tables and the configuration: passed by reference from HERE they would be kept in scratch
+                // memory for the whole kernel (every table store then reloads its column pointer from there): the call gets copies.
+                LRow slow;
+                const DevTables t_copy = t;
+                const LtsvDevCfg cfg_copy = cfg;
+                if (in_tile) {
+                    LdsReader rd(T.w, base);
+                    ltsv_walk<false>(rd, len, cfg_copy, lds_digits, slow, t_copy, 0);
+                } else {
+                    GlobalReader rd(reinterpret_cast<const uint32_t*>(c.bytes), c.o0);
+                    ltsv_walk<false>(rd, len, cfg_copy, lds_digits, slow, t_copy, 0);
+                }
+                r = slow;
             }
             if (r.status != L_OK) r.n_ent = 0;
         }
-        bool overflow;
-        const uint32_t first = alloc_entries(t, r.n_ent, &overflow, c.ent_state);
-        if (overflow) {
+        const EntAlloc ea = alloc_entries_ex(t, r.n_ent, c.ent_state);
+        if (ea.overflow) {
             r.status = FG_ST_OVERFLOW;
             r.n_ent = 0;
         }
-        if (r.n_ent != 0) {
-            if (tile_lane && c.stash && r.n_ent <= kStashEntries) {
+        const uint32_t first = (ea.overflow || ea.total == 0u) ? 0u : ea.s.at(ea.ex);
+        const bool parked = tile_lane && c.stash && r.n_ent <= kStashEntries;
+        const bool coop = stash_to_table<2>(c, t, ea, r.n_ent, parked, [](uint64_t rec, uint64_t val, uint64_t* name, uint64_t* v, uint32_t* tf) {
+            *name = (rec & 0xFFFFull) | (((rec >> 16) & 0xFFFFull) << 32);
+            *v = val;
+            *tf = (uint32_t)((rec >> 32) & 0xFFFFu);  // type | flags << 8
+        });
+        if (!coop && r.n_ent != 0) {
+            if (parked) {
                 // k-major in the stash: coalesced reads.  Four records are in flight before the first store (the compiler cannot
                 // hoist a stash load above a table store: for all it knows they alias)
                 for (uint32_t k0 = 0; k0 < r.n_ent; k0 += 4u) {
@@ -556,12 +573,14 @@ struct LtsvFormat {
                 }
             } else {
                 LRow scratch = r;
+                const DevTables t_copy = t;  // (see above)
+                const LtsvDevCfg cfg_copy = cfg;
                 if (in_tile) {
                     LdsReader rd(T.w, base);
-                    ltsv_walk<true>(rd, len, cfg, lds_digits, scratch, t, first);
+                    ltsv_walk<true>(rd, len, cfg_copy, lds_digits, scratch, t_copy, first);
                 } else {
                     GlobalReader rd(reinterpret_cast<const uint32_t*>(c.bytes), c.o0);
-                    ltsv_walk<true>(rd, len, cfg, lds_digits, scratch, t, first);
+                    ltsv_walk<true>(rd, len, cfg_copy, lds_digits, scratch, t_copy, first);
                 }
             }
         }

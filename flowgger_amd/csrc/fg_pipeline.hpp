@@ -182,21 +182,28 @@ constexpr uint32_t kStashWords = 2;  // u64 words per stashed entry (scratch is 
 
 // Wave-aggregated allocation of entry slots out of the wave's reserved chunk (fg_wave.hpp wave_alloc): returns this lane's
 // first slot, or sets *overflow.  ent_state = the wave's two persistent LDS words.
-__device__ __forceinline__ uint32_t alloc_entries(const DevTables& t, uint32_t n_ent, bool* overflow, uint32_t* ent_state) {
-    *overflow = false;
-    if (!__any(n_ent != 0u)) return 0;  // wave-uniform; the common case of the no-SD corpus skips the scan
-    uint32_t total;
-    const uint32_t ex = wv::excl_sum(n_ent, &total);
+struct EntAlloc {
+    uint32_t ex = 0;      // entries of the lanes before this one
+    uint32_t total = 0;   // entries of the wave
+    wv::Slots s{};        // where they go: [base0, base0 + cut) and [base1, ...) (wv::wave_alloc)
+    bool overflow = false;  // THIS lane's entries did not get slots (the table is full)
+};
+__device__ __forceinline__ EntAlloc alloc_entries_ex(const DevTables& t, uint32_t n_ent, uint32_t* ent_state) {
+    EntAlloc a;
+    if (!__any(n_ent != 0u)) return a;  // wave-uniform; the common case of the no-SD corpus skips the scan
+    a.ex = wv::excl_sum(n_ent, &a.total);
     // lines whose slice still fits what is left of the wave's chunk stay there, the others open the next chunk
     const uint32_t left = wv::wave_left(ent_state);
-    const unsigned long long nofit = __ballot(n_ent != 0u && ex + n_ent > left);
-    const uint32_t cut = nofit ? (uint32_t)__shfl((int)ex, (int)__builtin_ctzll(nofit), kWave) : total;
-    const wv::Slots s = wv::wave_alloc(t.ent_used, t.ent_cap, ent_state, total, cut, wv::alloc_chunk_for(t.ent_cap, gridDim.x));
-    if (s.overflow) {
-        *overflow = n_ent != 0u && ex >= s.cut;
-        if (*overflow) return 0;
-    }
-    return s.at(ex);
+    const unsigned long long nofit = __ballot(n_ent != 0u && a.ex + n_ent > left);
+    const uint32_t cut = nofit ? (uint32_t)__shfl((int)a.ex, (int)__builtin_ctzll(nofit), kWave) : a.total;
+    a.s = wv::wave_alloc(t.ent_used, t.ent_cap, ent_state, a.total, cut, wv::alloc_chunk_for(t.ent_cap, gridDim.x));
+    a.overflow = a.s.overflow && n_ent != 0u && a.ex >= a.s.cut;
+    return a;
+}
+__device__ __forceinline__ uint32_t alloc_entries(const DevTables& t, uint32_t n_ent, bool* overflow, uint32_t* ent_state) {
+    const EntAlloc a = alloc_entries_ex(t, n_ent, ent_state);
+    *overflow = a.overflow;
+    return (a.overflow || a.total == 0u) ? 0u : a.s.at(a.ex);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -223,6 +230,58 @@ struct GroupCtx {
     unsigned long long* phase;  // measurement build only: ten format-specific phase clocks (lane 0 adds), else null
 };
 
+// The entries a wave parked in its stash -> the entry table THROUGH THE TILE: once every lane has parsed its line the tile's
+// bytes are dead, so the records are laid out there in slot order and leave with one entry per lane and store instruction --
+// consecutive lanes, consecutive addresses (lane-per-line stores are `n_ent` entries apart: every store instruction touched
+// every cache line of the wave's range, and the 1-byte columns were read-modify-written at HBM: 2.2x the algorithmic bytes).
+// WORDS = u64 words per stashed record (k-major: stash[(k * WORDS + w) * 64 + lane]); un(w0, w1, &name, &val, &type_flags).
+// mine = this lane's entries are in the stash.  false = not done (the caller stores lane by lane): some lane's entries are
+// not in the stash, the table overflowed, or the wave has more entries than fit the tile.
+template <uint32_t WORDS, class Unpack>
+__device__ __forceinline__ bool stash_to_table(const GroupCtx& c, const DevTables& t, const EntAlloc& a, uint32_t n_ent, bool mine,
+                                               Unpack un) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t cap = (c.span / 18u) & ~3u;  // 8 + 8 + 2 bytes per entry
+    if (a.total == 0u || a.total > cap || a.s.overflow || c.stash == nullptr || __any(n_ent != 0u && !mine)) return false;  // wave-uniform
+    uint64_t* s_name = reinterpret_cast<uint64_t*>(const_cast<uint8_t*>(c.smem));
+    uint64_t* s_val = s_name + cap;
+    uint16_t* s_tf = reinterpret_cast<uint16_t*>(s_val + cap);
+    __syncthreads();  // every lane is done with the tile's bytes
+    for (uint32_t k0 = 0; k0 < n_ent; k0 += 4u) {  // (four records in flight per lane)
+        uint64_t w0[4], w1[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            const uint32_t k = k0 + j < n_ent ? k0 + j : n_ent - 1u;
+            w0[j] = c.stash[(k * WORDS) * kWave + lane];
+            w1[j] = WORDS > 1u ? c.stash[(k * WORDS + 1u) * kWave + lane] : 0ull;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            if (k0 + j < n_ent) {
+                uint64_t name, val;
+                uint32_t tf;
+                un(w0[j], w1[j], &name, &val, &tf);
+                const uint32_t idx = a.ex + k0 + j;
+                s_name[idx] = name;
+                s_val[idx] = val;
+                s_tf[idx] = (uint16_t)tf;
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t idx = lane; idx < a.total; idx += kWave) {
+        const uint32_t slot = a.s.at(idx);
+        const uint64_t name = s_name[idx];
+        const uint32_t tf = s_tf[idx];
+        t.ent_name[slot] = fg_span{(uint32_t)name, (uint32_t)(name >> 32)};
+        t.ent_val[slot] = s_val[idx];
+        t.ent_type[slot] = (uint8_t)(tf & 0xFFu);
+        t.ent_flags[slot] = (uint8_t)(tf >> 8);
+    }
+    return true;
+}
+
+
 // Framing of the frames handed to the decoders (fg_decode_frames_device): what to strip from the
 // end of [offsets[i], offsets[i+1]) before decoding, and which frames to reject as invalid UTF-8.
 struct FrameArgs {
@@ -230,11 +289,33 @@ struct FrameArgs {
     const uint8_t* line_bad;  // [n] 1 = not valid UTF-8 (or null)
 };
 
+// The input is read ONCE: its loads carry the non-temporal hint (aux bit 1 = nt on gfx950) so that the stream does not push the
+// wave's stash, scratch and table lines out of the XCD's L2 between two uses.
+#ifndef FG_STREAM_AUX
+#define FG_STREAM_AUX 2
+#endif
+__device__ __forceinline__ uint4 stream_load(const uint4* p) {
+#if FG_STREAM_AUX
+    typedef uint32_t nt4 __attribute__((ext_vector_type(4)));
+    const nt4 v = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+
 // rows of 1 KiB the tail of stage A loads before it stores the first (a format overrides it with  static constexpr int kTailBatch)
 template <class F, class = void>
 struct tail_batch { static constexpr int value = 4; };
 template <class F>
 struct tail_batch<F, decltype((void)F::kTailBatch)> { static constexpr int value = F::kTailBatch; };
+
+// The table row of a group is normally stored one iteration late (see below); a format says  static constexpr bool kDeferRowStore =
+// false  when that only keeps 17 registers alive across stage A (and, at the register limit, in scratch memory)
+template <class F, class = void>
+struct defer_row_store { static constexpr bool value = true; };
+template <class F>
+struct defer_row_store<F, decltype((void)F::kDeferRowStore)> { static constexpr bool value = F::kDeferRowStore; };
 
 template <int NB, bool PROF, class F>
 __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets,
@@ -280,7 +361,7 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
         __amdgpu_buffer_rsrc_t rsrc =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(bytes + a0), (short)0, (int)span, 0x00020000);
 #pragma unroll
-        for (int k = 0; k < NB; ++k) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(lane * 16u + k * 1024u), 0, 0);
+        for (int k = 0; k < NB; ++k) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(lane * 16u + k * 1024u), 0, FG_STREAM_AUX);
     };
 
     // (the last 8 bytes of the 64-byte pad behind the tile: no tile read reaches them)
@@ -342,7 +423,7 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
 #pragma unroll
                 for (int k = 0; k < TB; ++k) {
                     const uint32_t idx = c0 + k * kWave + lane;
-                    w[k] = src[idx < last ? idx : last];
+                    w[k] = stream_load(src + (idx < last ? idx : last));
                 }
 #pragma unroll
                 for (int k = 0; k < TB; ++k) {
@@ -463,6 +544,10 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
             }
             pend_li = li;
             pend_valid = valid;
+            if (!defer_row_store<F>::value) {  // (a format whose stage A waits for its own loads anyway: nothing to hide behind)
+                if (pend_valid && !(ablate & 1u)) store_row(t, pend_li, pend);
+                pend_valid = false;
+            }
         }
         if (PROF) {
             __builtin_amdgcn_sched_barrier(0);

@@ -841,15 +841,25 @@ struct Rfc5424Format {
     // ---- structured-data entries: wave prefix sum + one atomic per wave ---------------------
     uint32_t first = 0;
     {
-        bool overflow;
-        const uint32_t mine = alloc_entries(t, r.n_ent, &overflow, c.ent_state);
-        if (overflow) {
+        const EntAlloc ea = alloc_entries_ex(t, r.n_ent, c.ent_state);
+        const uint32_t mine = (ea.overflow || ea.total == 0u) ? 0u : ea.s.at(ea.ex);
+        if (ea.overflow) {
             r.status = FG_ST_OVERFLOW;
             r.n_ent = 0;
         }
-        if (r.n_ent != 0) {
+        // parked records leave through the (now dead) tile, one entry per lane and store (fg_pipeline.hpp stash_to_table)
+        const bool parked = sd_lane && stash && r.n_ent <= kStashEntries;
+        const bool coop = !(ablate & 4u) && stash_to_table<1>(c, t, ea, r.n_ent, parked, [](uint64_t rec, uint64_t, uint64_t* name, uint64_t* v, uint32_t* tf) {
+            const uint32_t name_s = (uint32_t)rec & 0xFFFFu, name_len = (uint32_t)(rec >> 16) & 0xFFFFu;
+            const uint32_t val_len = (uint32_t)(rec >> 32) & 0xFFFFu;
+            const bool sdid = (rec >> 49) & 1u;
+            *name = (uint64_t)name_s | ((uint64_t)name_len << 32);
+            *v = sdid ? 0ull : ((uint64_t)(name_s + name_len + 2u) | ((uint64_t)val_len << 32));
+            *tf = (sdid ? (uint32_t)FG_T_SDID : (uint32_t)FG_T_STRING) | ((((rec >> 48) & 1u) ? (uint32_t)FG_EF_VAL_ESC : 0u) << 8);
+        });
+        first = r.n_ent != 0 ? mine : 0u;
+        if (r.n_ent != 0 && !coop) {
             {
-                first = (uint32_t)mine;
                 uint32_t msg_at, cnt;
                 if (ablate & 4u) {
                 } else if (sd_lane && stash && r.n_ent <= kStashEntries) {
