@@ -48,7 +48,16 @@ struct EncCfg {
     const uint8_t* blob;       // GELF keys + extra values, LTSV suffixes, the LTSV extras text, the prepend header
     const StaticKey* keys;     // GELF: sorted by key bytes
     uint32_t n_keys;
-    uint32_t suf_off[4], suf_len[4];  // bool, f64, i64, u64 (len 0xFFFFFFFF = not configured)
+    // LTSV suffixes of bool, f64, i64, u64 (len 0xFFFFFFFF = not configured).  Named fields, not arrays: ONE dynamically indexed
+    // member keeps the whole struct -- a kernel argument -- in scratch memory, and every read of any field then waits behind the
+    // lane's output stores (the compiler also turns a chain of selects over array elements back into an indexed load)
+    uint32_t suf_off0, suf_off1, suf_off2, suf_off3, suf_len0, suf_len1, suf_len2, suf_len3;
+    FGE_HD void set_suffix(uint32_t k, uint32_t off, uint32_t len) {
+        if (k == 0u) { suf_off0 = off; suf_len0 = len; }
+        else if (k == 1u) { suf_off1 = off; suf_len1 = len; }
+        else if (k == 2u) { suf_off2 = off; suf_len2 = len; }
+        else { suf_off3 = off; suf_len3 = len; }
+    }
     uint32_t src_fmt;          // which decoder produced the tables (fg_format)
     uint32_t enc;              // fg_encoder
     uint32_t merger;           // fg_merger
@@ -458,9 +467,15 @@ struct Base {
                 d.dlen = nm.len - 1u;
             }
         }
-        if ((ef & FG_EF_SUFFIX) && ty >= FG_T_BOOL && ty <= FG_T_U64 && cfg.suf_len[ty - FG_T_BOOL] != 0xFFFFFFFFu) {
-            d.so = cfg.suf_off[ty - FG_T_BOOL];
-            d.sl = cfg.suf_len[ty - FG_T_BOOL];
+        const uint32_t si = ty - FG_T_BOOL;
+        // (mask-and-or, each term ONE field: `c ? field_a : field_b` is folded into a load through a selected pointer before
+        //  this function is inlined into the kernel -- which is the dynamically indexed access again)
+        const uint32_t m0 = 0u - (uint32_t)(si == 0u), m1 = 0u - (uint32_t)(si == 1u), m2 = 0u - (uint32_t)(si == 2u), m3 = 0u - (uint32_t)(si == 3u);
+        const uint32_t sl = (cfg.suf_len0 & m0) | (cfg.suf_len1 & m1) | (cfg.suf_len2 & m2) | (cfg.suf_len3 & m3);
+        const uint32_t so = (cfg.suf_off0 & m0) | (cfg.suf_off1 & m1) | (cfg.suf_off2 & m2) | (cfg.suf_off3 & m3);
+        if ((ef & FG_EF_SUFFIX) && ty >= FG_T_BOOL && ty <= FG_T_U64 && sl != 0xFFFFFFFFu) {
+            d.so = so;
+            d.sl = sl;
         }
         return d;
     }

@@ -85,8 +85,7 @@ inline bool build_enc_cfg(fg_format src_fmt, const fg_encode_cfg* ec, const std:
         }
     }
     for (int k = 0; k < 4; ++k) {
-        cfg.suf_off[k] = (uint32_t)blob.size();
-        cfg.suf_len[k] = has_suffix[k] ? (uint32_t)suffix[k].size() : 0xFFFFFFFFu;
+        cfg.set_suffix((uint32_t)k, (uint32_t)blob.size(), has_suffix[k] ? (uint32_t)suffix[k].size() : 0xFFFFFFFFu);
         if (has_suffix[k]) blob.insert(blob.end(), suffix[k].begin(), suffix[k].end());
     }
     align4(&blob);

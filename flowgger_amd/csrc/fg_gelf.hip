@@ -697,11 +697,13 @@ int launch_gelf_fast(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t
         return -1;
     dim3 grid(p.blocks), block(fg::kWave);
     if (getenv("FG_PLAN")) fprintf(stderr, "gelf plan: L %u tile %u lds %u blocks %u window %d KiB\n", p.L, p.tile, p.lds, p.blocks, NB);
-    if (NB == 3 && p.tile == 4096u && p.L == 8u && !getenv("FG_PROF") && !getenv("FG_GELF_GENERIC")) {
-        // the geometry of ~300-byte GELF (the BASELINE corpus): constants
-        hipLaunchKernelGGL((fg::k_gelf<NB, false, 4, 4096u, 8u>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L, p.groups,
-                           (unsigned long long*)nullptr, (uint64_t*)nullptr, fr);
-        return 0;
+    if constexpr (NB == 3) {
+        if (p.tile == 4096u && p.L == 8u && !getenv("FG_PROF") && !getenv("FG_GELF_GENERIC")) {
+            // the geometry of ~300-byte GELF (the BASELINE corpus): constants
+            hipLaunchKernelGGL((fg::k_gelf<NB, false, 4, 4096u, 8u>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L,
+                               p.groups, (unsigned long long*)nullptr, (uint64_t*)nullptr, fr);
+            return 0;
+        }
     }
     if (getenv("FG_PROF")) {
         fg::ProfRun pr;
