@@ -30,6 +30,7 @@
 //
 // Portable: compiled by hipcc for gfx950 and by g++ over the fiber emulation of a wave (fg_wave.hpp) for the CPU suite.
 #pragma once
+#include "fg_numfold.hpp"
 #include "fg_numparse.hpp"
 #include "fg_tables_view.hpp"
 #include "fg_wave.hpp"
@@ -165,32 +166,7 @@ FG_WV Lds carve(const uint8_t* tile, uint16_t* bm16, uint32_t tile_cap, uint8_t*
 }
 // once per wave, before the first tile: the powers of ten (exact doubles up to 10^22) and the digit-weight table
 FG_WV void init_lds(const Lds& L) {
-    const uint32_t lane = wv::lane();
-    if (lane == 0) {
-        double v = 1.0;
-        for (uint32_t k = 0; k < 23u; ++k) {
-            L.p10[k] = v;
-            v *= 10.0;
-        }
-    }
-    if (lane < 16u) {
-        // byte i of entry m: 10^(digit bytes above i) when bit i of m is set, else 0 -- except 1000 (m = 15, byte 0), which does
-        // not fit a byte and is added separately
-        uint32_t wgt = 0, above = 0;
-        for (int i = 3; i >= 0; --i) {
-            if ((lane >> i) & 1u) {
-                const uint32_t p = above == 0 ? 1u : above == 1 ? 10u : above == 2 ? 100u : 0u;
-                wgt |= p << (8 * i);
-                ++above;
-            }
-        }
-        L.dw[lane] = wgt;
-    }
-    if (lane >= 16u && lane < 25u) {
-        uint32_t p = 1;
-        for (uint32_t k = 16u; k < lane; ++k) p *= 10u;
-        L.dw[lane] = p;
-    }
+    numfold::init_tables(L.dw, L.p10);
     wv::sync();
 }
 // the dirty bits of a tile with room for tile_cap bytes (before the first tile; decode_tile clears what it has looked at)
@@ -294,50 +270,14 @@ struct TokReader {
     FG_WV uint32_t byte(uint32_t i) const { return T.byte(i); }
 };
 // serde_json 0.8 number (fg_numparse.hpp json_number) for the everyday shape  -?D+(.D+)?  with at most 19 digits, on a token
-// of n <= 24 bytes held in registers.  Class masks by SWAR; then every dword's digits are folded with ONE v_dot4 against a
-// weight vector looked up by the dword's 4-bit digit mask (a '.' or the sign inside the dword gets weight 0), and the six
-// partial values are chained with 10^(digits of the dword).  false = not that shape: the caller runs json_number, which owns
-// every error.  dwt = Lds::dw.
+// of n <= 24 bytes held in registers: the significand by fg_numfold.hpp, then serde's arithmetic.  false = not that shape: the
+// caller runs json_number, which owns every error.  dwt = Lds::dw.
 FG_WV bool parse_num24(const uint32_t w[6], uint32_t n, const double* p10, const uint32_t* dwt, uint32_t* kind, uint64_t* bits) {
-    const bool neg = (w[0] & 0xFFu) == '-';
-    uint32_t x[6], ndm = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < 6; ++k) {
-        x[k] = w[k] ^ 0x30303030u;
-        const uint32_t nd = (x[k] | ((x[k] & 0x7F7F7F7Fu) + 0x76767676u)) & 0x80808080u;  // bit 7: the byte is not a digit
-        ndm |= wv::udot4(nd >> 7, 0x08040201u, 0u) << (4u * k);
-    }
-    const uint32_t tok = (1u << n) - 1u;  // n <= 24
-    const uint32_t body = tok & ~(neg ? 1u : 0u);
-    const uint32_t nondig = ndm & body, digits = body & ~ndm;
-    const uint32_t nd_total = wv::popc32(digits);
-    const bool has_dot = nondig != 0u;
-    const uint32_t o = neg ? 1u : 0u;
-    const uint32_t dp = has_dot ? wv::ctz32(nondig) : n;
-    const uint32_t ni = dp - o, nf = has_dot ? n - dp - 1u : 0u;
-    const uint32_t c0 = neg ? ((w[0] >> 8) & 0xFFu) : (w[0] & 0xFFu);
-    // the one non-digit must be a '.': its byte, picked out of the six dwords
-    uint32_t dsel = w[0];
-#pragma unroll
-    for (uint32_t k = 1; k < 6; ++k) dsel = (dp >> 2) == k ? w[k] : dsel;
-    const bool dot_ok = !has_dot || ((dsel >> (8u * (dp & 3u))) & 0xFFu) == '.';
-    const bool ok = (nondig & (nondig - 1u)) == 0u && dot_ok && nd_total >= 1u && nd_total <= 19u && dp >= o + 1u && (!has_dot || nf >= 1u) &&
-                    !(c0 == '0' && ni > 1u);
-    if (!ok) return false;
-    // the dwords' values (<= 9999 each) pair up with 24-bit multiplies (full rate); two wide multiplies chain the three pairs
-    uint32_t val[6], cnt[6];
-#pragma unroll
-    for (uint32_t k = 0; k < 6; ++k) {
-        const uint32_t m = (digits >> (4u * k)) & 15u;
-        val[k] = wv::udot4(x[k], dwt[m], m == 15u ? (x[k] & 0xFFu) * 1000u : 0u);
-        cnt[k] = wv::popc32(m);
-    }
-    const uint32_t* p10u = dwt + 16;
-    const uint32_t p0 = wv::mad24(val[0], p10u[cnt[1]], val[1]);  // < 10^8
-    const uint32_t p1 = wv::mad24(val[2], p10u[cnt[3]], val[3]);
-    const uint32_t p2 = wv::mad24(val[4], p10u[cnt[5]], val[5]);
-    uint64_t sig = (uint64_t)p0 * p10u[cnt[2] + cnt[3]] + p1;  // < 10^16
-    sig = sig * p10u[cnt[4] + cnt[5]] + p2;                   // <= 19 digits: < 2^64
+    const numfold::Folded f = numfold::fold24(w, n, dwt);
+    if (!f.ok || (f.c0 == '0' && f.ni > 1u)) return false;  // (JSON: no leading zeros)
+    const bool neg = f.neg, has_dot = f.has_dot;
+    const uint32_t nf = f.nf;
+    const uint64_t sig = f.sig;
     if (has_dot) {
         // visit_f64_from_parts: f = sig as f64; f /= POW10[nf]   (nf <= 18 here: the divisor comes from LDS)
         *kind = V_F64;

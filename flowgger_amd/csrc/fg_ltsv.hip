@@ -12,7 +12,9 @@
 // once the wave has its slots (single parse); the byte-walking two-pass form below stays for
 // lines outside the tile and lines with more than kStashEntries pairs.
 #include "fg_pipeline.hpp"
+#include "fg_numfold.hpp"
 #include "fg_numparse.hpp"
+#include "fg_tsfast.hpp"
 
 namespace fg {
 
@@ -294,7 +296,8 @@ struct SuffixEnt {                      // 16 bytes: the four configured suffixe
     uint32_t pad;
     uint64_t bytes;                     // first 8 bytes, zero padded
 };
-constexpr uint32_t kLtsvExtraLds = 768u + kSchemaLds * sizeof(SchemaEnt) + 4u * sizeof(SuffixEnt);
+constexpr uint32_t kLtsvTablesAt = 768u + kSchemaLds * sizeof(SchemaEnt) + 4u * sizeof(SuffixEnt);  // fg_numfold.hpp tables (8-byte aligned)
+constexpr uint32_t kLtsvExtraLds = kLtsvTablesAt + ((numfold::kTableBytes + 15u) & ~15u);
 
 struct LtsvFormat {
     static constexpr uint32_t kClasses = 1;
@@ -307,6 +310,37 @@ struct LtsvFormat {
     uint8_t* lds_digits;        // 768-byte digit buffer for dec2flt's slow path
     const SchemaEnt* schema;    // LDS mirror of the first kSchemaLds schema entries
     const SuffixEnt* suffix;    // LDS mirror of the four suffixes
+    const double* p10;          // fg_numfold.hpp tables (LDS)
+    const uint32_t* dw;
+
+    // ---- the everyday spellings straight out of registers; false = NOT DECIDED: the byte-wise parser of the grammar runs ----
+    // f64::from_str of  -?D+(.D+)?  with a significand below 2^53: Clinger's fast path, w / 10^k is the correctly rounded result
+    __device__ __forceinline__ bool fast_f64(const uint32_t w[6], uint32_t n, double* out) const {
+        const numfold::Folded f = numfold::fold24(w, n, dw);
+        const double d = (double)f.sig / p10[f.nf <= 22u ? f.nf : 0u];
+        *out = f.neg ? -d : d;
+        return n <= 24u && f.ok && f.sig < (1ull << 53);
+    }
+    // parse_ts (ltsv_decoder.rs:263-267) of [b, e): the float, RFC3339 and the two English forms; accepted only where the chain
+    // f64 -> RFC3339 -> English -> English with subsecond accepts with the same value (an RFC3339 / English text never parses as f64)
+    __device__ __forceinline__ bool fast_ts(const Tile& T, uint32_t a, uint32_t n, double* out) const {
+        uint32_t r[9];
+        {
+            const uint32_t d = a >> 2, sh = a & 3u;
+            uint32_t x[10];
+#pragma unroll
+            for (int k = 0; k < 10; ++k) x[k] = T.w[d + k];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) r[k] = __builtin_amdgcn_alignbyte(x[k + 1], x[k], sh);
+        }
+        double v0, v1 = 0.0, v2;
+        const bool is_f = fast_f64(r, n, &v0);
+        const uint32_t c3339 = fast_rfc3339_core(r, n, [&](uint32_t pos, uint32_t* z0, uint32_t* z1) { load8(T, a + pos, z0, z1); }, &v1);
+        const bool is_e = fast_english(r, n, &v2);
+        *out = is_f ? v0 : c3339 == 1u ? v1 : v2;
+        // (c3339 == 2: the byte-wise RFC3339 parser decides, BEFORE the English forms get their turn)
+        return is_f || c3339 == 1u || (c3339 == 0u && is_e);
+    }
 
     static __device__ __forceinline__ uint32_t mask16(const uint4& v) { return mask16_eq(v, 0x09090909u); }
 
@@ -396,7 +430,7 @@ struct LtsvFormat {
                         --e;
                     }
                     double ts;
-                    if (!ltsv_parse_ts(wr, b, e, lds_digits, &ts)) {
+                    if (!fast_ts(T, base + b, e - b, &ts) && !ltsv_parse_ts(wr, b, e, lds_digits, &ts)) {
                         r.status = L_ENGLISH;
                         return;
                     }
@@ -412,9 +446,15 @@ struct LtsvFormat {
                     r.msg_len = ve - vb;
                 } else if (nl == 5u && k[0] == 0x6576656Cu && k[1] == 0x0000006Cu && k[2] == 0u && k[3] == 0u) {  // "level"
                     uint64_t lv;
-                    if (!num::parse_unsigned(wr, vb, ve, 255, &lv)) {
-                        r.status = L_LEVEL;
-                        return;
+                    {
+                        uint32_t w6[6];
+                        wv::Bytes{T.w}.load24(base + vb, w6);
+                        const numfold::Folded f = numfold::fold24(w6, ve - vb, dw);
+                        lv = f.sig;
+                        if (!(ve - vb <= 24u && f.ok && !f.neg && !f.has_dot && f.sig <= 255u) && !num::parse_unsigned(wr, vb, ve, 255, &lv)) {
+                            r.status = L_LEVEL;
+                            return;
+                        }
                     }
                     if (lv > 7) {
                         r.status = L_LEVEL7;
@@ -429,30 +469,40 @@ struct LtsvFormat {
                     uint64_t val = (uint64_t)vb | ((uint64_t)(ve - vb) << 32);
                     uint32_t flags = 0;
                     if (ty != FG_T_STRING) {
+                        // the value's first 24 bytes, once; the everyday spellings are decided from them
+                        uint32_t w6[6];
+                        wv::Bytes{T.w}.load24(base + vb, w6);
+                        const uint32_t vn = ve - vb;
+                        const numfold::Folded f = numfold::fold24(w6, vn, dw);
+                        const bool shaped = vn <= 24u && f.ok;
                         if (ty == FG_T_BOOL) {
-                            if (key_is(rd, vb, ve, "true", 4)) val = 1;
-                            else if (key_is(rd, vb, ve, "false", 5)) val = 0;
+                            const bool tt = vn == 4u && w6[0] == 0x65757274u;                            // true
+                            const bool ff = vn == 5u && w6[0] == 0x736C6166u && (w6[1] & 0xFFu) == 'e';  // false
+                            if (tt) val = 1;
+                            else if (ff) val = 0;
                             else {
                                 r.status = L_BOOL;
                                 return;
                             }
                         } else if (ty == FG_T_F64) {
-                            double d;
-                            if (!parse_f64_wave(wr, vb, ve, lds_digits, &d)) {
+                            double d = (double)f.sig / p10[f.nf <= 22u ? f.nf : 0u];
+                            d = f.neg ? -d : d;
+                            if (!(shaped && f.sig < (1ull << 53)) && !parse_f64_wave(wr, vb, ve, lds_digits, &d)) {
                                 r.status = L_F64;
                                 return;
                             }
                             val = num::f64_to_bits(d);
                         } else if (ty == FG_T_I64) {
-                            int64_t x;
-                            if (!num::parse_i64(wr, vb, ve, &x)) {
+                            int64_t x = (int64_t)(f.neg ? 0ull - f.sig : f.sig);
+                            const bool fits = f.neg ? f.sig <= (1ull << 63) : f.sig < (1ull << 63);
+                            if (!(shaped && !f.has_dot && fits) && !num::parse_i64(wr, vb, ve, &x)) {
                                 r.status = L_I64;
                                 return;
                             }
                             val = (uint64_t)x;
                         } else {
-                            uint64_t x;
-                            if (!num::parse_unsigned(wr, vb, ve, 0xFFFFFFFFFFFFFFFFull, &x)) {
+                            uint64_t x = f.sig;
+                            if (!(shaped && !f.has_dot && !f.neg) && !num::parse_unsigned(wr, vb, ve, 0xFFFFFFFFFFFFFFFFull, &x)) {
                                 r.status = L_U64;
                                 return;
                             }
@@ -642,8 +692,11 @@ __global__ __launch_bounds__(kWave, 2) void k_ltsv(const uint8_t* __restrict__ b
             for (uint32_t i = 0; i < cfg.suf_len[k] && i < 8u; ++i) e.bytes |= (uint64_t)cfg.blob[cfg.suf_off[k] + i] << (8u * i);
         suffix[k] = e;
     }
+    double* p10 = reinterpret_cast<double*>(extra + kLtsvTablesAt);
+    uint32_t* dw = reinterpret_cast<uint32_t*>(extra + kLtsvTablesAt + numfold::kP10Words * 8u);
+    numfold::init_tables(dw, p10);
     __syncthreads();
-    LtsvFormat fmt{cfg, extra, schema, suffix};
+    LtsvFormat fmt{cfg, extra, schema, suffix, p10, dw};
     persistent_loop<NB, PROF>(bytes, offsets, n, t, tile_cap, L, groups, prof, stash_base, fmt, fr);
 }
 

@@ -25,6 +25,7 @@
 #include <cstdlib>
 
 #include "fg_pipeline.hpp"
+#include "fg_tsfast.hpp"
 
 namespace fg {
 
@@ -287,17 +288,6 @@ __device__ __forceinline__ void parse_line_generic(R& rd, uint32_t len, Row& r, 
 // Stage B: register-resident fast path
 // =============================================================================================
 
-// every byte of x (already XORed with the expected pattern) must be <= its limit, where
-// add = 0x7F - limit per byte: returns nonzero iff some byte exceeds its limit.
-__device__ __forceinline__ uint32_t swar_exceeds(uint32_t x, uint32_t add) {
-    return (x | ((x & 0x7F7F7F7Fu) + add)) & 0x80808080u;
-}
-// four ASCII-digit values (0..9 per byte, first digit in the low byte) -> 0..9999
-__device__ __forceinline__ uint32_t digits4(uint32_t x) {
-    uint32_t t = (x * 10u + (x >> 8)) & 0x00FF00FFu;  // byte0 = 10*d0+d1, byte2 = 10*d2+d3
-    return (t & 0xFFu) * 100u + (t >> 16);
-}
-
 // What the straight-line fast path could not finish; each bit sends the lane through one rare,
 // branchy piece of the generic parser afterwards.
 enum : uint32_t {
@@ -329,60 +319,7 @@ __device__ __forceinline__ uint32_t fast_rfc3339(const Tile& T, uint32_t base, c
     uint32_t r[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) r[k] = __builtin_amdgcn_alignbyte(hdr[k + 2], hdr[k + 1], s);
-    // bytes 0..18 = "YYYY-MM-DDtHH:MM:SS" ; XOR with the pattern: digits -> 0..9, literals -> 0
-    const uint32_t x0 = r[0] ^ 0x30303030u;                         // Y Y Y Y
-    const uint32_t x1 = r[1] ^ 0x2D30302Du;                         // - M M -
-    const uint32_t x2 = (r[2] | 0x00200000u) ^ 0x30743030u;         // D D t H   ('T'|0x20 == 't')
-    const uint32_t x3 = r[3] ^ 0x30303A30u;                         // H : M M
-    const uint32_t x4 = (r[4] & 0x00FFFFFFu) ^ 0x0030303Au;         // : S S (byte 19 cleared)
-    uint32_t bad = swar_exceeds(x0, 0x76767676u) | swar_exceeds(x1, 0x7F76767Fu) | swar_exceeds(x2, 0x767F7676u) |
-                   swar_exceeds(x3, 0x76767F76u) | swar_exceeds(x4, 0x7F76767Fu);
-    bad |= L < 20u ? 1u : 0u;
-    DateTimeParts p;
-    p.year = (int)digits4(x0);
-    p.month = (int)(((x1 >> 8) & 0xFFu) * 10u + ((x1 >> 16) & 0xFFu));
-    p.day = (int)((x2 & 0xFFu) * 10u + ((x2 >> 8) & 0xFFu));
-    p.hour = (int)((x2 >> 24) * 10u + (x3 & 0xFFu));
-    p.minute = (int)(((x3 >> 16) & 0xFFu) * 10u + (x3 >> 24));
-    p.second = (int)(((x4 >> 8) & 0xFFu) * 10u + ((x4 >> 16) & 0xFFu));
-    // optional fraction: digits live in bytes 20..35 = r[5..8]; count the leading digits
-    const bool has_frac = (r[4] >> 24) == '.';
-    const uint32_t f0 = r[5] ^ 0x30303030u, f1 = r[6] ^ 0x30303030u, f2 = r[7] ^ 0x30303030u, f3 = r[8] ^ 0x30303030u;
-    const uint32_t n0 = swar_exceeds(f0, 0x76767676u), n1 = swar_exceeds(f1, 0x76767676u);
-    const uint32_t n2 = swar_exceeds(f2, 0x76767676u), n3 = swar_exceeds(f3, 0x76767676u);
-    uint32_t nd = n0 ? (uint32_t)__builtin_ctz(n0) >> 3
-                     : n1 ? 4u + ((uint32_t)__builtin_ctz(n1) >> 3)
-                          : n2 ? 8u + ((uint32_t)__builtin_ctz(n2) >> 3)
-                               : n3 ? 12u + ((uint32_t)__builtin_ctz(n3) >> 3) : 16u;
-    const uint32_t room = L - 20u;  // (garbage when L < 20: `bad` is already set)
-    nd = nd > room ? room : nd;
-    bad |= (has_frac && nd == 0u) ? 1u : 0u;
-    const bool undecided = has_frac && nd >= 16u;  // very long fraction: the byte-wise parser decides
-    // keep the first min(nd,9) digits, zero the rest => nine digits with trailing zeros
-    const uint32_t keep = nd < 9u ? nd : 9u;
-    const uint32_t k0 = keep >= 4u ? 0xFFFFFFFFu : (1u << (8u * keep)) - 1u;
-    const uint32_t k1 = keep >= 8u ? 0xFFFFFFFFu : keep <= 4u ? 0u : (1u << (8u * (keep - 4u))) - 1u;
-    const uint32_t d8 = keep >= 9u ? (f2 & 0xFFu) : 0u;
-    const uint32_t nano = (digits4(f0 & k0) * 10000u + digits4(f1 & k1)) * 10u + d8;
-    p.nano = has_frac ? nano : 0u;
-    const uint32_t pos = has_frac ? 20u + nd : 19u;  // index of the time-zone designator
-    uint32_t bad_tz = pos >= L ? 1u : 0u;            // (judged only when the fraction was decided here)
-    // time-zone designator: re-read 8 bytes at its (data-dependent) position
-    uint32_t z0, z1;
-    load8(T, a + pos, &z0, &z1);
-    const uint32_t c = z0 & 0xFFu;
-    const bool is_z = (c | 0x20u) == 'z';
-    const bool is_off = c == '+' || c == '-';
-    // bytes 1..5 = H H : M M
-    const uint32_t y0 = (z0 >> 8) ^ 0x003A3030u;   // H H :   (3 bytes)
-    const uint32_t y1 = (z1 & 0xFFFFu) ^ 0x3030u;  // M M
-    const uint32_t off_bad = swar_exceeds(y0, 0x7F7F7676u) | swar_exceeds(y1, 0x7F7F7676u);
-    bad_tz |= is_z ? (pos + 1u != L ? 1u : 0u) : is_off ? ((pos + 6u != L ? 1u : 0u) | off_bad) : 1u;
-    p.off_sign = c == '-' ? -1 : 1;
-    p.off_h = is_off ? (int)((y0 & 0xFFu) * 10u + ((y0 >> 8) & 0xFFu)) : 0;
-    p.off_m = is_off ? (int)((y1 & 0xFFu) * 10u + ((y1 >> 8) & 0xFFu)) : 0;
-    const uint32_t conv = (uint32_t)datetime_to_unix_fast(p, out);
-    return bad ? 0u : undecided ? 2u : bad_tz ? 0u : conv;
+    return fast_rfc3339_core(r, L, [&](uint32_t pos, uint32_t* z0, uint32_t* z1) { load8(T, a + pos, z0, z1); }, out);
 }
 
 // Lowest set bit of the 128-bit window (lo, hi) -> its index, cleared from the window; `none`

@@ -231,3 +231,63 @@ def test_ltsv_schema_lookup_beyond_one_batch(oracle):
         (blob, offs), _ = host_path_blob(dec, data, offsets)
         assert np.array_equal(offs, ooffs)
         assert blob[:int(offs[-1])].tobytes() == oblob[:int(ooffs[-1])].tobytes()
+
+
+def test_ltsv_register_parsers_match_the_byte_wise_chain(oracle):
+    """The LTSV kernel decides the everyday spellings of `time` (float, RFC3339, both "English" forms) and of typed values from
+    registers and leaves everything else to the byte-wise parsers: sweep the boundaries of what the register forms accept --
+    every value and every error must equal the oracle's (ltsv_decoder.rs:116-199, 224-267)."""
+    from gpu_util import host_path_blob
+
+    rng = np.random.default_rng(0x7157)
+    mon = ["Jan", "Feb", "Mar", "Apr", "May", "Jun", "Jul", "Aug", "Sep", "Oct", "Nov", "Dec"]
+    ts = ["0", "-0", "1", "1.5", "-1.5", "1385053862.3072", "1438790025.637824", "9007199254740991", "9007199254740992", "9007199254740993",
+          "90071992547409.93", "0.1234567890123456789", "123456789012345678.9", "1234567890123456789012", "00012.50", "1.", ".5", "+1.5",
+          "1e5", "1E-3", "inf", "-inf", "nan", "NaN", "infinity", "1_0", "1..2", "1.2.3", "--1", "", " 1", "1 ", "0x10",
+          "2000-01-01T00:00:00Z", "2000-01-01t00:00:00z", "2000-01-01T00:00:00+00:00", "2000-01-01T00:00:00-07:00", "2000-01-01T00:00:00+25:59",
+          "2000-01-01T00:00:00+26:00", "2000-01-01T00:00:00.5Z", "2000-01-01T00:00:00.123456789Z", "2000-01-01T00:00:00.1234567891234Z",
+          "2000-01-01T00:00:00.1234567890123456Z", "2000-01-01T00:00:00.12345678901234567Z", "2000-01-01T00:00:00.Z", "2000-01-01T00:00:00",
+          "2000-01-01T00:00:60Z", "2016-12-31T23:59:60Z", "2000-02-30T00:00:00Z", "2000-13-01T00:00:00Z", "1969-12-31T23:59:59Z", "0000-01-01T00:00:00Z",
+          "9999-12-31T23:59:59Z", "2000-01-01 00:00:00Z", "2000-01-01T24:00:00Z", "2000-1-01T00:00:00Z", "2000-01-01T00:00:00+0700", "2000-01-01T00:00:00ZZ",
+          "5/Oct/2000:13:55:36 -0700", "05/Oct/2000:13:55:36 -0700", "15/Oct/2000:13:55:36 +0000", "15/Oct/2000:13:55:36.5 +0130",
+          "15/Oct/2000:13:55:36.123456 +0130", "15/Oct/2000:13:55:36.123456789 -2559", "15/Oct/2000:13:55:36.1234567891 -0000",
+          "15/Oct/2000:13:55:36. +0000", "15/Oct/2000:13:55:36 +2600", "15/Oct/2000:13:55:36 +0060", "15/oct/2000:13:55:36 +0000",
+          "15/OCT/2000:13:55:36 +0000", "15/Okt/2000:13:55:36 +0000", "0/Oct/2000:13:55:36 +0000", "32/Oct/2000:13:55:36 +0000", "29/Feb/2001:00:00:00 +0000",
+          "29/Feb/2000:00:00:00 +0000", "15/Oct/+2000:13:55:36 +0000", "15/Oct/-2000:13:55:36 +0000", "15/Oct/200:13:55:36 +0000", "15/Oct/20000:13:55:36 +0000",
+          "15/Oct/2000:13:55:60 +0000", "15/Oct/2000:24:00:00 +0000", "15/Oct/2000:13:55:36 0000", "15/Oct/2000:13:55:36  +0000", "15/Oct/2000:13:55:36 +000",
+          "15/Oct/2000:13:55:36 +00000", "15/Oct/2000:13:55:36 +0000 ", "15/Oct/1969:23:59:59 +0000", "31/Dec/1969:23:59:59 -0001", "1/Jan/1970:00:00:00 +0000",
+          "1/Jan/2514:00:00:00 +0000", "1/Jan/2515:00:00:00 +0000", "115/Oct/2000:13:55:36 +0000", "1x/Oct/2000:13:55:36 +0000", "15-Oct-2000:13:55:36 +0000"]
+    for _ in range(1500):
+        y, mo, d = int(rng.integers(1970, 2400)), int(rng.integers(1, 13)), int(rng.integers(1, 29))
+        h, mi, s2 = int(rng.integers(0, 24)), int(rng.integers(0, 60)), int(rng.integers(0, 60))
+        nd = int(rng.integers(0, 12))
+        frac = ("." + "".join(str(int(x)) for x in rng.integers(0, 10, nd))) if nd else ""
+        sg, oh, om = "+-"[int(rng.integers(0, 2))], int(rng.integers(0, 24)), int(rng.integers(0, 60))
+        k = int(rng.integers(0, 4))
+        if k == 0:
+            ts.append(f"{y:04d}-{mo:02d}-{d:02d}T{h:02d}:{mi:02d}:{s2:02d}{frac}" + ("Z" if om % 2 else f"{sg}{oh:02d}:{om:02d}"))
+        elif k == 1:
+            ts.append(f"{d}/{mon[mo - 1]}/{y:04d}:{h:02d}:{mi:02d}:{s2:02d}{frac} {sg}{oh:02d}{om:02d}")
+        elif k == 2:
+            ni = int(rng.integers(1, 20))
+            ts.append(("-" if nd % 3 == 0 else "") + "".join(str(int(x)) for x in rng.integers(0, 10, ni)) + frac)
+        else:
+            ts.append(f"{int(rng.integers(0, 2**40))}.{int(rng.integers(0, 10**6)):06d}")
+    nums = ["0", "-0", "+0", "5", "-5", "+5", "007", "255", "256", "18446744073709551615", "18446744073709551616", "9223372036854775807",
+            "9223372036854775808", "-9223372036854775808", "-9223372036854775809", "1.5", "-1.5", "1e3", "", " ", "12a", "1234567890123456789",
+            "12345678901234567890", "123456789012345678901234", "1234567890123456789012345", "true", "false", "True", "tru", "falsE", "0.1", ".1", "1."]
+    lines = []
+    for i, t in enumerate(ts):
+        br = "[" + t + "]" if i % 2 else t
+        lines.append(f"time:{br}\thost:h\tlevel:{i % 8}".encode())
+    for v in nums:
+        for key in ("counter", "score", "mean", "done", "level"):
+            lines.append(f"time:1\thost:h\t{key}:{v}".encode())
+    data, offsets = synth.pack(lines)
+    dec = LTSVDecoder(synth.LTSV_CONFIG)
+    oblob, ooffs = oracle.decode_batch(LTSV, data, offsets, synth.LTSV_CONFIG)
+    (blob, offs), _ = host_path_blob(dec, data, offsets)
+    for i in range(len(lines)):
+        a = blob[int(offs[i]):int(offs[i + 1])].tobytes()
+        b = oblob[int(ooffs[i]):int(ooffs[i + 1])].tobytes()
+        assert a == b, (i, lines[i])
