@@ -394,11 +394,38 @@ struct LtsvFormat {
         LdsReader rd(T.w, base);
         WinReader wr(T, base);  // numbers / timestamps: 16 bytes per LDS round trip
         uint32_t cnt = 0;
+        // The TABs of the line out of a 64-bit register window of the bitmap (one LDS round trip covers three or four parts), and the
+        // NEXT part's end and name window requested before this part is looked at: the part loop is a chain of dependent LDS
+        // round trips, and these two were half of it.
+        uint64_t tabw = 0;
+        uint32_t tw0 = 0x80000000u;  // line index of the window's first bit (initially: nothing is within 64 of it)
+        auto next_tab = [&](uint32_t from) -> uint32_t {  // first TAB at line index >= from, else len
+            while (from < len) {
+                const uint32_t off = from - tw0;
+                if (off < 64u) {
+                    const uint64_t m = tabw >> off;
+                    if (m) {
+                        const uint32_t r = from + (uint32_t)__builtin_ctzll(m);
+                        return r < len ? r : len;
+                    }
+                    from = tw0 + 64u;
+                } else {
+                    tabw = wv::window64(T.bm, base + from);
+                    tw0 = from;
+                }
+            }
+            return len;
+        };
         uint32_t ps = 0;
+        uint32_t pe = next_tab(0u);
+        uint32_t w[4];
+        load16(T, base + ps, w);
         for (;;) {  // line.split('\t')
-            const uint32_t pe = find_bit_long(T.bm, base, ps, len);
-            uint32_t w[4];
-            load16(T, base + ps, w);
+            const bool more = pe < len;
+            const uint32_t nps = pe + 1u;
+            const uint32_t npe = more ? next_tab(nps) : len;
+            uint32_t nw[4];
+            load16(T, base + (more ? nps : ps), nw);  // (unconditional: a clamped address instead of a branch around the loads)
             // first ':' of the part: in the 16-byte window, else (long name) byte-wise
             const uint32_t plen = pe - ps;
             const uint32_t in_part = plen >= 16u ? 0xFFFFu : (1u << plen) - 1u;
@@ -537,8 +564,11 @@ struct LtsvFormat {
                     tick(5);
                 }
             }
-            if (pe >= len) break;
-            ps = pe + 1;
+            if (!more) break;
+            ps = nps;
+            pe = npe;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = nw[j];
         }
         if (!r.have_ts) {
             r.status = L_NOTS;
