@@ -128,6 +128,8 @@ def lib() -> C.CDLL:
                                         C.POINTER(u64), vp]
     L.fg_encode_device.argtypes = [vp, C.c_int, C.POINTER(fg_encode_cfg), vp, u64, vp, u64, C.POINTER(fg_tables), vp, u64, vp, vp,
                                    C.POINTER(u64), vp]
+    L.fg_encode_device_async.argtypes = [vp, C.c_int, C.POINTER(fg_encode_cfg), vp, u64, vp, u64, C.POINTER(fg_tables), vp, u64, vp, vp,
+                                         u64, vp]
     L.fg_transcode_batch.argtypes = [vp, C.c_int, C.c_int, C.POINTER(fg_encode_cfg), vp, u64, vp, u64, C.c_int, C.POINTER(fg_transcoded)]
     L.fg_encode_error_string.argtypes = [C.c_uint8]
     L.fg_encode_error_string.restype = C.c_char_p

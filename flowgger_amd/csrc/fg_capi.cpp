@@ -103,6 +103,11 @@ struct fg_ctx {
     fg::r3164::Cfg r3164{};
     uint8_t* d_enc = nullptr;    // fg_encode_gelf_device: static key list + blob, then the per-line sizes
     uint64_t d_enc_cap = 0;
+    // fg_encode_device_async: pinned ring the encoder configuration is uploaded from without a host sync
+    static constexpr uint32_t kEncRing = 4, kEncSlot = 16 * 1024;
+    uint8_t* h_enc_ring = nullptr;
+    hipEvent_t ev_enc[kEncRing] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t enc_ring_next = 0;
     fg::LtsvDevCfg ltsv{};
     // staging for fg_decode_batch
     uint8_t* d_bytes = nullptr;
@@ -452,6 +457,9 @@ void fg_destroy(fg_ctx* ctx) {
     if (ctx->d_frame) (void)hipFree(ctx->d_frame);
     if (ctx->d_bad) (void)hipFree(ctx->d_bad);
     if (ctx->d_enc) (void)hipFree(ctx->d_enc);
+    if (ctx->h_enc_ring) (void)hipHostFree(ctx->h_enc_ring);
+    for (hipEvent_t e : ctx->ev_enc)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->d_tz) (void)hipFree(ctx->d_tz);
     for (uint8_t* p : ctx->retired_tz) (void)hipFree(p);
     if (ctx->h_off) (void)hipHostFree(ctx->h_off);
@@ -1098,31 +1106,55 @@ int fg_transcode_batch(fg_ctx* ctx, fg_format fmt, fg_framing framing, const fg_
     return FG_OK;
 }
 
-int fg_encode_device(fg_ctx* ctx, fg_format src_fmt, const fg_encode_cfg* ecfg, const uint8_t* d_bytes, uint64_t nbytes,
-                     const uint64_t* d_offsets, uint64_t n, const fg_tables* tables, uint8_t* d_out, uint64_t out_cap,
-                     uint64_t* d_out_offsets, uint8_t* d_enc_status, uint64_t* total, void* stream) {
-    if (!ctx || !ecfg || !tables || !d_out_offsets || !total || (n && (!d_offsets || !tables->meta))) return FG_ERR_ARG;
+namespace {
+// fg_encode_device (total != nullptr: synchronises for the configuration's entry count and for the total) and
+// fg_encode_device_async (total == nullptr: nothing on the host waits; ent_hint replaces the entry count read back)
+int encode_device_impl(fg_ctx* ctx, fg_format src_fmt, const fg_encode_cfg* ecfg, const uint8_t* d_bytes, uint64_t nbytes,
+                       const uint64_t* d_offsets, uint64_t n, const fg_tables* tables, uint8_t* d_out, uint64_t out_cap,
+                       uint64_t* d_out_offsets, uint8_t* d_enc_status, uint64_t* total, uint64_t ent_hint, void* stream) {
+    const bool async = total == nullptr;
+    if (!ctx || !ecfg || !tables || !d_out_offsets || (n && (!d_offsets || !tables->meta))) return FG_ERR_ARG;
+    if (async && !d_out) return FG_ERR_ARG;
     if ((int)src_fmt < 0 || (int)src_fmt > (int)FG_RFC3164) return FG_ERR_ARG;
     if (tables->n < n) return FG_ERR_ARG;
     DeviceGuard g(ctx->device);
     hipStream_t s = stream == FG_STREAM_OWN ? ctx->stream : (hipStream_t)stream;
-    *total = 0;
+    if (total) *total = 0;
     fg::EncCfgHost h;
     if (!fg::build_enc_cfg(src_fmt, ecfg, ctx->suffix, ctx->has_suffix, &h)) return FG_ERR_ARG;
     const uint64_t keys_bytes = up(h.keys.size() * sizeof(fg::StaticKey), 16), blob_bytes = up(h.blob.size() + 16, 256);
     const uint64_t cfg_bytes = up(keys_bytes + blob_bytes, 256);
     int rc;
     if ((rc = grow_dev(ctx, (void**)&ctx->d_enc, &ctx->d_enc_cap, cfg_bytes + up(n * 4 + 4, 256) + up((n / 64 + 2) * 8, 256))) != FG_OK) return rc;
-    std::vector<uint8_t> host(cfg_bytes, 0);
-    if (!h.keys.empty()) memcpy(host.data(), h.keys.data(), h.keys.size() * sizeof(fg::StaticKey));
-    if (!h.blob.empty()) memcpy(host.data() + keys_bytes, h.blob.data(), h.blob.size());
-    // (synchronous copy of a few hundred bytes: `host` goes out of scope at return); the same sync brings back the
-    // number of entries the decode produced, which sizes the GELF ranking scratch
     uint64_t ent_used = ~0ull;
-    FG_HIP(ctx, hipMemcpyAsync(ctx->d_enc, host.data(), host.size(), hipMemcpyHostToDevice, s));
-    if (ecfg->encoder == FG_ENC_GELF && tables->ent_used)
-        FG_HIP(ctx, hipMemcpyAsync(&ent_used, tables->ent_used, 8, hipMemcpyDeviceToHost, s));
-    FG_HIP(ctx, hipStreamSynchronize(s));
+    if (async && cfg_bytes <= fg_ctx::kEncSlot) {
+        // the configuration through a pinned ring: the copy is queued, nothing waits (a slot is reused four calls later; its
+        // event has long fired by then)
+        if (!ctx->h_enc_ring) {
+            FG_HIP(ctx, hipHostMalloc((void**)&ctx->h_enc_ring, (size_t)fg_ctx::kEncRing * fg_ctx::kEncSlot, hipHostMallocDefault));
+            for (uint32_t k = 0; k < fg_ctx::kEncRing; ++k) FG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_enc[k], hipEventDisableTiming));
+        }
+        const uint32_t slot = ctx->enc_ring_next++ % fg_ctx::kEncRing;
+        FG_HIP(ctx, hipEventSynchronize(ctx->ev_enc[slot]));
+        uint8_t* hp = ctx->h_enc_ring + (size_t)slot * fg_ctx::kEncSlot;
+        memset(hp, 0, cfg_bytes);
+        if (!h.keys.empty()) memcpy(hp, h.keys.data(), h.keys.size() * sizeof(fg::StaticKey));
+        if (!h.blob.empty()) memcpy(hp + keys_bytes, h.blob.data(), h.blob.size());
+        FG_HIP(ctx, hipMemcpyAsync(ctx->d_enc, hp, cfg_bytes, hipMemcpyHostToDevice, s));
+        FG_HIP(ctx, hipEventRecord(ctx->ev_enc[slot], s));
+        ent_used = ent_hint;
+    } else {
+        std::vector<uint8_t> host(cfg_bytes, 0);
+        if (!h.keys.empty()) memcpy(host.data(), h.keys.data(), h.keys.size() * sizeof(fg::StaticKey));
+        if (!h.blob.empty()) memcpy(host.data() + keys_bytes, h.blob.data(), h.blob.size());
+        // (synchronous copy of a few hundred bytes: `host` goes out of scope at return); the same sync brings back the
+        // number of entries the decode produced, which sizes the GELF ranking scratch
+        FG_HIP(ctx, hipMemcpyAsync(ctx->d_enc, host.data(), host.size(), hipMemcpyHostToDevice, s));
+        if (!async && ecfg->encoder == FG_ENC_GELF && tables->ent_used)
+            FG_HIP(ctx, hipMemcpyAsync(&ent_used, tables->ent_used, 8, hipMemcpyDeviceToHost, s));
+        FG_HIP(ctx, hipStreamSynchronize(s));
+        if (async) ent_used = ent_hint;
+    }
     fg::EncCfg cfg = h.cfg;
     cfg.keys = reinterpret_cast<const fg::StaticKey*>(ctx->d_enc);
     cfg.blob = ctx->d_enc + keys_bytes;
@@ -1146,10 +1178,14 @@ int fg_encode_device(fg_ctx* ctx, fg_format src_fmt, const fg_encode_cfg* ecfg, 
         ctx->last_hip = lrc;
         return FG_ERR_HIP;
     }
-    FG_HIP(ctx, hipMemcpyAsync(total, d_out_offsets + n, 8, hipMemcpyDeviceToHost, s));
-    FG_HIP(ctx, hipStreamSynchronize(s));
-    if (!d_out) return FG_OK;  // sizing call
-    if (*total > out_cap) return FG_ERR_ENT_OVERFLOW;
+    if (!async) {
+        FG_HIP(ctx, hipMemcpyAsync(total, d_out_offsets + n, 8, hipMemcpyDeviceToHost, s));
+        FG_HIP(ctx, hipStreamSynchronize(s));
+        if (!d_out) return FG_OK;  // sizing call
+        if (*total > out_cap) return FG_ERR_ENT_OVERFLOW;
+    } else {
+        cfg.out_cap = out_cap ? out_cap : 1;  // the write kernel reads out_offsets[n] itself and leaves d_out alone when it exceeds this
+    }
     lrc = fg_launch_encode_write(d_bytes, d_offsets, n, &dt, &cfg, tile_cap, cfg_lds, d_out_offsets, d_out, s);
     if (lrc != 0) {
         ctx->last_hip = lrc;
@@ -1160,6 +1196,21 @@ int fg_encode_device(fg_ctx* ctx, fg_format src_fmt, const fg_encode_cfg* ecfg, 
         ctx->ev_valid = true;
     }
     return FG_OK;
+}
+}  // namespace
+
+int fg_encode_device(fg_ctx* ctx, fg_format src_fmt, const fg_encode_cfg* ecfg, const uint8_t* d_bytes, uint64_t nbytes,
+                     const uint64_t* d_offsets, uint64_t n, const fg_tables* tables, uint8_t* d_out, uint64_t out_cap,
+                     uint64_t* d_out_offsets, uint8_t* d_enc_status, uint64_t* total, void* stream) {
+    if (!total) return FG_ERR_ARG;
+    return encode_device_impl(ctx, src_fmt, ecfg, d_bytes, nbytes, d_offsets, n, tables, d_out, out_cap, d_out_offsets, d_enc_status, total, 0, stream);
+}
+
+int fg_encode_device_async(fg_ctx* ctx, fg_format src_fmt, const fg_encode_cfg* ecfg, const uint8_t* d_bytes, uint64_t nbytes,
+                           const uint64_t* d_offsets, uint64_t n, const fg_tables* tables, uint8_t* d_out, uint64_t out_cap,
+                           uint64_t* d_out_offsets, uint8_t* d_enc_status, uint64_t ent_hint, void* stream) {
+    return encode_device_impl(ctx, src_fmt, ecfg, d_bytes, nbytes, d_offsets, n, tables, d_out, out_cap, d_out_offsets, d_enc_status, nullptr,
+                              ent_hint, stream);
 }
 
 int fg_encode_gelf_device(fg_ctx* ctx, fg_format src_fmt, const uint8_t* d_bytes, uint64_t nbytes, const uint64_t* d_offsets,

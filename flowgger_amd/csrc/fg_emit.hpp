@@ -65,6 +65,7 @@ struct EncCfg {
     uint32_t prepend_off, prepend_len;        // syslog_prepend_timestamp header; len 0xFFFFFFFF = not configured
     double now_ts;             // Record.ts of rows flagged FG_F_TS_NOW
     uint32_t sort_slots;       // GELF: entries of the per-lane ranking scratch (<= kSortSlots)
+    uint64_t out_cap;          // write pass: nonzero = leave the output alone when out_offsets[n] exceeds it (fg_encode_device_async)
 };
 
 // encode status per line (fg_encode_error_string)

@@ -66,6 +66,8 @@ __global__ __launch_bounds__(kWave) void k_encode(const uint8_t* __restrict__ by
                                                  uint8_t* __restrict__ enc_status, uint64_t* __restrict__ block_sums,
                                                  const uint64_t* __restrict__ out_offsets, uint8_t* __restrict__ out,
                                                  const uint4* __restrict__ cfg_block /* = cfg.keys, as a plain pointer */) {
+    // (asynchronous form: the host never saw the total -- the capacity is checked here, by every workgroup, wave-uniform)
+    if (WRITE && cfg.out_cap != 0ull && out_offsets[n] > cfg.out_cap) return;
     constexpr uint32_t kSlots = SLOTS ? SLOTS : 1u;
     __shared__ uint64_t s_keys[kWave * kSlots];
     __shared__ uint8_t s_slot[kWave * kSlots];

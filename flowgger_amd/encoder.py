@@ -75,6 +75,23 @@ class Encoder:
         res = (out[:int(total.value)], d_off)
         return res + (d_st[:n],) if want_status else res
 
+    def encode_device_async(self, decoder, d_bytes, d_offsets, n: int, tables: DeviceTables, out, now_ts: float = 0.0, stream=None,
+                            ent_hint: int = 0xFFFFFFFFFFFFFFFF):
+        """fg_encode_device_async: count, scan and write queued on `stream`, no host synchronisation.  Returns (d_out_offsets
+        int64[n+1], d_status uint8[n]); d_out_offsets[n] (device) = the bytes the batch needs -- when that exceeds out.numel()
+        nothing was written to `out`.  ent_hint: an upper bound of the entries in `tables` (0 = none)."""
+        import torch
+
+        if stream is None:
+            stream = torch.cuda.current_stream(d_bytes.device)
+        cfg, _keep = self._cfg_struct(now_ts)
+        d_off = torch.empty(n + 1, dtype=torch.int64, device=d_bytes.device)
+        d_st = torch.empty(max(n, 1), dtype=torch.uint8, device=d_bytes.device)
+        L.check(L.lib().fg_encode_device_async(decoder._ctx, decoder.fmt, C.byref(cfg), d_bytes.data_ptr(), d_bytes.numel(), d_offsets.data_ptr(),
+                                               n, C.byref(tables.struct), out.data_ptr(), out.numel(), d_off.data_ptr(), d_st.data_ptr(),
+                                               ent_hint, C.c_void_p(stream.cuda_stream)), "fg_encode_device_async")
+        return d_off, d_st[:n]
+
     @staticmethod
     def error_string(status: int) -> Optional[str]:
         s = L.lib().fg_encode_error_string(status)

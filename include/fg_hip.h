@@ -295,6 +295,18 @@ typedef struct fg_encode_cfg {
 int fg_encode_device(fg_ctx* ctx, fg_format src_fmt, const fg_encode_cfg* cfg, const uint8_t* d_bytes, uint64_t nbytes,
                      const uint64_t* d_offsets, uint64_t n, const fg_tables* tables, uint8_t* d_out, uint64_t out_cap,
                      uint64_t* d_out_offsets, uint8_t* d_enc_status, uint64_t* total, void* stream);
+
+/* The same WITHOUT a host synchronisation (a device-resident pipeline must not wait on the host for a byte count):
+ * count, scan and write are queued on `stream` and the call returns.  Nothing comes back to the host:
+ *   d_out_offsets[n]  (device) = the bytes the batch needs; when it exceeds out_cap the write kernel leaves d_out untouched --
+ *                     the caller checks that word whenever it next synchronises (d_out_offsets / d_enc_status are always produced)
+ *   ent_hint          an upper bound of the entries in `tables` (sizes the GELF encoder's key-ranking scratch instead of the
+ *                     ent_used read-back): 0 = none (RFC5424 without structured data), ~0 = unknown
+ * The first calls on a ctx may still synchronise while its scratch grows to the batch size (hipFree / hipMalloc).
+ * replaces: the same `encoder.encode` + `merger.frame` as fg_encode_device (splitter/line_splitter.rs:44-54). */
+int fg_encode_device_async(fg_ctx* ctx, fg_format src_fmt, const fg_encode_cfg* cfg, const uint8_t* d_bytes, uint64_t nbytes,
+                           const uint64_t* d_offsets, uint64_t n, const fg_tables* tables, uint8_t* d_out, uint64_t out_cap,
+                           uint64_t* d_out_offsets, uint8_t* d_enc_status, uint64_t ent_hint, void* stream);
 /* The reference's exact &'static str of an encode status (0 / 1 -> "", unknown -> NULL). */
 const char* fg_encode_error_string(uint8_t enc_status);
 

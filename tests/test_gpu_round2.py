@@ -291,3 +291,40 @@ def test_ltsv_register_parsers_match_the_byte_wise_chain(oracle):
         a = blob[int(offs[i]):int(offs[i + 1])].tobytes()
         b = oblob[int(ooffs[i]):int(ooffs[i + 1])].tobytes()
         assert a == b, (i, lines[i])
+
+
+@pytest.mark.parametrize("src,enc_name", [("rfc5424", "gelf"), ("ltsv", "gelf"), ("gelf", "ltsv"), ("rfc5424sd", "rfc5424")])
+def test_encode_device_async_needs_no_host_sync(oracle, src, enc_name):
+    """fg_encode_device_async queues count + scan + write and returns: same bytes, offsets and statuses as fg_encode_device; with a
+    buffer that is too small the output is left untouched and the need stands in d_out_offsets[n]."""
+    import torch
+    from flowgger_amd import GelfEncoder, LTSVEncoder, RFC5424Encoder
+    from gpu_util import device_path
+
+    if src == "rfc5424":
+        dec, lines = RFC5424Decoder(), synth.rfc5424_lines(30_000, cfg=2)
+    elif src == "rfc5424sd":
+        dec, lines = RFC5424Decoder(), synth.rfc5424_lines(20_000, cfg=4, sd=True)
+    elif src == "ltsv":
+        dec, lines = LTSVDecoder(synth.LTSV_CONFIG), synth.ltsv_lines(30_000, cfg=5)
+    else:
+        dec, lines = GelfDecoder(), synth.gelf_lines(30_000, cfg=3)
+    enc = {"gelf": GelfEncoder, "ltsv": LTSVEncoder, "rfc5424": RFC5424Encoder}[enc_name]({"output": {"framing": "line"}})
+    data, offsets = synth.pack(lines)
+    tables, d_bytes, d_offsets = device_path(dec, data, offsets)
+    n = len(lines)
+    ref_out, ref_off, ref_st = enc.encode_device(dec, d_bytes, d_offsets, n, tables, now_ts=1.5, want_status=True)
+    torch.cuda.synchronize()
+    total = int(ref_off[n].item())
+    assert total == ref_out.numel() and total > 0
+    for hint in (0xFFFFFFFFFFFFFFFF, 0 if src == "rfc5424" else 64 * n):
+        out = torch.full((total + 64,), 0xAA, dtype=torch.uint8, device=d_bytes.device)
+        d_off, d_st = enc.encode_device_async(dec, d_bytes, d_offsets, n, tables, out, now_ts=1.5, ent_hint=hint)
+        torch.cuda.synchronize()
+        assert torch.equal(d_off, ref_off) and torch.equal(d_st, ref_st)
+        assert torch.equal(out[:total], ref_out) and bool((out[total:] == 0xAA).all())
+    small = torch.full((total - 1,), 0x55, dtype=torch.uint8, device=d_bytes.device)
+    d_off, d_st = enc.encode_device_async(dec, d_bytes, d_offsets, n, tables, small, now_ts=1.5)
+    torch.cuda.synchronize()
+    assert int(d_off[n].item()) == total and torch.equal(d_off, ref_off)
+    assert bool((small == 0x55).all())
