@@ -578,6 +578,8 @@ struct GelfFormat {
         const fg_span none{0, FG_NONE};
         const bool ok = f.handled && f.status == G_OK;
         o.meta = f.handled ? (f.status | (0xFFu << 8) | ((ok ? f.severity : 0xFFu) << 16) | ((ok ? f.flags : 0u) << 24)) : kPending;
+        // (tell the general kernel that this launch left it something: any lane, the same value, idempotent)
+        if (t.pending && c.valid && !f.handled) *t.pending = t.epoch;
         o.ts = (ok && f.have_ts) ? f.ts : 0.0;
         o.span[S_HOST] = ok ? fg_span{f.host_off, f.host_len} : none;
         o.span[S_APP] = none;
@@ -615,6 +617,7 @@ __global__ __launch_bounds__(kWave, MINW) void k_gelf(const uint8_t* __restrict_
 }
 
 // ---- kernel 2: pending lines -> the general form, straight from global memory --------------------------------------
+constexpr uint32_t kGeneralSpan = 4096;  // lines a wave of the general kernel collects pending lines from at a time
 constexpr uint32_t kLaneBlock = kMaxStored * 4u + kMaxDepth / 8u;  // per lane: keypos[32] + the nesting stack (kMaxDepth bits)
 
 __global__ __launch_bounds__(kWave, 2) void k_gelf_general(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets,
@@ -626,11 +629,34 @@ __global__ __launch_bounds__(kWave, 2) void k_gelf_general(const uint8_t* __rest
     __syncthreads();
     uint32_t* keypos = reinterpret_cast<uint32_t*>(scratch + lane * kLaneBlock);
     uint32_t* stack = reinterpret_cast<uint32_t*>(scratch + lane * kLaneBlock + kMaxStored * 4u);
-    const uint64_t chunks = (n + kWave - 1) / kWave;
-    for (uint64_t ch = blockIdx.x; ch < chunks; ch += gridDim.x) {
-        const uint64_t li = ch * kWave + lane;
-        const bool mine = li < n && (t.meta[li] & 0xFFu) == kPending;
-        if (!__any(mine)) continue;  // wave-uniform: nearly every chunk
+    // (the fast form says whether it left anything at all: one word of the ctx's ring per launch)
+    if (t.pending && *t.pending != t.epoch) return;
+    // Pending lines are rare (~1 per 100): a wave first COLLECTS the pending lines of a 4096-line span into an LDS list, then
+    // takes them 64 at a time -- lane per pending line instead of one busy lane per 64-line chunk.
+    __shared__ uint16_t s_list[kGeneralSpan];
+    const uint64_t spans = (n + kGeneralSpan - 1) / kGeneralSpan;
+    for (uint64_t sp = blockIdx.x; sp < spans; sp += gridDim.x) {
+      const uint64_t l0 = sp * kGeneralSpan;
+      uint32_t cnt = 0;  // wave-uniform
+      for (uint32_t k0 = 0; k0 < kGeneralSpan / kWave; k0 += 8u) {
+          uint32_t m8[8];
+#pragma unroll
+          for (uint32_t j = 0; j < 8u; ++j) {  // (eight loads in flight)
+              const uint64_t q = l0 + (uint64_t)(k0 + j) * kWave + lane;
+              m8[j] = q < n ? t.meta[q] : 0u;
+          }
+#pragma unroll
+          for (uint32_t j = 0; j < 8u; ++j) {
+              const bool p = (m8[j] & 0xFFu) == kPending;
+              const unsigned long long b = __ballot(p);
+              if (p) s_list[cnt + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] = (uint16_t)((k0 + j) * kWave + lane);
+              cnt += (uint32_t)__popcll(b);
+          }
+      }
+      __syncthreads();
+      for (uint32_t at = 0; at < cnt; at += kWave) {
+        const bool mine = at + lane < cnt;
+        const uint64_t li = l0 + (mine ? (uint32_t)s_list[at + lane] : 0u);
         GRow r;
         uint64_t o0 = 0;
         uint32_t len = 0;
@@ -682,6 +708,8 @@ __global__ __launch_bounds__(kWave, 2) void k_gelf_general(const uint8_t* __rest
             o.count = r.n_ent;
             store_row(t, li, o);
         }
+      }
+      __syncthreads();  // the list is rebuilt for the next span
     }
 }
 
@@ -763,7 +791,7 @@ extern "C" int fg_launch_gelf(const uint8_t* d_bytes, const uint64_t* d_offsets,
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
         return -1;
-    uint64_t chunks = (n + fg::kWave - 1) / fg::kWave;
+    uint64_t chunks = (n + fg::kGeneralSpan - 1) / fg::kGeneralSpan;
     uint64_t gblocks = (uint64_t)cus * 8u;
     if (gblocks > chunks) gblocks = chunks;
     hipLaunchKernelGGL(fg::k_gelf_general, dim3((uint32_t)gblocks), block, 0, stream, d_bytes, d_offsets, n, *t, fg::FrameArgs{strip, line_bad});
