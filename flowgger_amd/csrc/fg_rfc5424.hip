@@ -682,7 +682,6 @@ struct Rfc5424Format {
     // no stage-A bitmap: the fast path classifies the header bytes itself, the SD walker's
     // quote bitmap is built on demand (rebuild_bitmap) for groups that hold SD lines
     static constexpr uint32_t kClasses = 0;
-    static constexpr int kTailBatch = 16;  // (a group beyond the 20 KiB window: the rest in one round trip)
     static __device__ __forceinline__ void classify_store(const uint4&, uint16_t*, uint32_t, uint32_t, uint32_t) {}
 
     __device__ __forceinline__ RowOut decode(const GroupCtx& c, const DevTables& t) const {
