@@ -19,6 +19,7 @@ struct HostReader {
         memcpy(&w, p + i, nb);
         return w;
     }
+    void load16(uint32_t i, uint32_t* q) { memcpy(q, p + i, 16); }  // (only called with sixteen wanted bytes)
 };
 }  // namespace
 

@@ -181,3 +181,32 @@ def test_zone_index_near_misses_and_unhinted_years(host3164, oracle3164):
     finally:
         oracle3164.set_rfc3164(RFC3164_YEAR, T)
     assert np.array_equal(offs, ooffs) and np.array_equal(blob, oblob)
+
+
+def test_sixteen_byte_scans_at_every_offset(host3164, oracle3164):
+    """The token scan and the custom form's ": " search move sixteen bytes per step: whitespace (ASCII and multi-byte), ':' and
+    ": " at every offset of the windows, tokens of 1..48 bytes, non-ASCII bytes that are NOT whitespace inside tokens."""
+    r = random.Random(316416)
+    ws = [" ", "\t", "\n", "\u00a0", "\u2003", "\u3000", "\u0085", "  "]
+    filler = "abcdefghijklmnopqrstuvwxyz0123456789-_.:/[]\u00e9\u4e2d\u200b"   # (U+200B is NOT White_Space)
+    lines = []
+    for k in range(6000):
+        def tok(n):
+            return "".join(r.choice(filler) for _ in range(n))
+        date = "Aug %2d 11:15:24" % r.randint(1, 28)
+        host = tok(r.randint(1, 48)).replace(": ", ":_")
+        sep = r.choice(ws) if r.random() < 0.3 else " "
+        pri = r.choice(["", "<13>", "<191>"])
+        if k % 3 == 0:   # standard form, long host / first message token
+            lines.append(f"{pri}{date}{sep}{host}{sep}{tok(r.randint(1, 40))} {tok(r.randint(0, 30))}")
+        elif k % 3 == 1:  # custom form: the two separators anywhere
+            lines.append(f"{pri}{host}: 2020 {date}: {tok(r.randint(0, 60))}")
+        else:             # separators / colons at the edges of the windows
+            pad = tok(r.randint(0, 40)).replace(": ", "::")
+            lines.append(f"{pri}{pad}:{r.choice(['', ' ', '  '])}{date}{r.choice([':', ': ', ' :', ''])}{tok(r.randint(0, 20))}{r.choice(['', ':', ': '])}")
+    enc = [ln.encode("utf-8") for ln in lines]
+    (blob, offs), data, offsets = host3164(enc)
+    oblob, ooffs = oracle3164.decode_batch(RFC3164, data, offsets)
+    for i in range(len(enc)):
+        a, b = blob[int(offs[i]):int(offs[i + 1])].tobytes(), oblob[int(ooffs[i]):int(ooffs[i + 1])].tobytes()
+        assert a == b, (i, enc[i], parse_canonical(a), parse_canonical(b))
