@@ -34,10 +34,13 @@ extern "C" const char* fgw_last_error() { return g_err.c_str(); }
 
 // GELF: decode n framed lines; rows of lines the fast form handled are written to `t` (host arrays), handled[i] = 1;
 // other rows are left untouched (handled[i] = 0: on the GPU they take the general form).  Returns 0, or -1 (fgw_last_error).
-extern "C" int fgw_gelf_decode(const uint8_t* bytes, uint64_t nbytes, const uint64_t* offsets, uint64_t n, const fg_tables* tables,
-                               uint32_t lines_per_group, uint32_t tile_cap, uint8_t* handled) {
+// strip = FG_FRAME_NONE: offsets delimit bare lines.  FG_FRAME_LINE / FG_FRAME_NUL: frames of a raw stream INCLUDING their
+// terminators (what fg_frame_device produces): stripped per lane as the pipeline does, and stage A is told the terminator byte.
+extern "C" int fgw_gelf_decode_framed(const uint8_t* bytes, uint64_t nbytes, const uint64_t* offsets, uint64_t n, const fg_tables* tables,
+                                      uint32_t lines_per_group, uint32_t tile_cap, uint8_t* handled, uint32_t strip) {
     using namespace fg;
     try {
+        const uint32_t term4 = strip == FG_FRAME_LINE ? 0x0A0A0A0Au : strip == FG_FRAME_NUL ? 0u : wv::kNoTerm;
         if (lines_per_group < 1 || lines_per_group > 64 || tile_cap % 1024 != 0 || tile_cap > 57344) throw std::runtime_error("bad geometry");
         const DevTables t = to_dev(*tables);
         *t.ent_used = 0;
@@ -67,7 +70,7 @@ extern "C" int fgw_gelf_decode(const uint8_t* bytes, uint64_t nbytes, const uint
             for (uint32_t c = 0; c < span / 16u; ++c) {
                 uint32_t x[4], m[gelf2::kClasses + 1];
                 memcpy(x, smem + 16u * c, 16);
-                gelf2::classify(x[0], x[1], x[2], x[3], m);
+                gelf2::classify(x[0], x[1], x[2], x[3], m, term4);
                 for (uint32_t k = 0; k < gelf2::kClasses; ++k) bm16[k * stride16 + c] = (uint16_t)m[k];
                 if (m[gelf2::kClasses]) lds.dirty[c >> 7] |= 1u << ((c >> 2) & 31u);
             }
@@ -78,8 +81,20 @@ extern "C" int fgw_gelf_decode(const uint8_t* bytes, uint64_t nbytes, const uint
                 gelf2::init_lds(lds);  // (the staging above wiped the LDS; the kernel does this once per wave)
                 const uint32_t lane = wv::lane();
                 const bool has = lane < nl;
-                const uint64_t o0 = has ? offsets[g0 + lane] : 0, o1 = has ? offsets[g0 + lane + 1] : 0;
+                const uint64_t o0 = has ? offsets[g0 + lane] : 0;
+                uint64_t o1 = has ? offsets[g0 + lane + 1] : 0;
                 const bool in_tile = has && (o1 - a0) <= (uint64_t)span;
+                if (has && strip != FG_FRAME_NONE && o1 > o0) {  // terminator stripping (fg_pipeline.hpp stage B)
+                    const uint32_t b1 = bytes[o1 - 1];
+                    if (strip == FG_FRAME_LINE) {
+                        if (b1 == '\n') {
+                            --o1;
+                            if (o1 > o0 && bytes[o1 - 1] == '\r') --o1;
+                        }
+                    } else if (b1 == 0u) {
+                        --o1;
+                    }
+                }
                 const gelf2::LineOut o = gelf2::decode_tile(lds, span, in_tile, (uint32_t)(o0 - a0), (uint32_t)(o1 - o0), t);
                 outs[lane] = o;
             });
@@ -107,6 +122,11 @@ extern "C" int fgw_gelf_decode(const uint8_t* bytes, uint64_t nbytes, const uint
         g_err = e.what();
         return -1;
     }
+}
+
+extern "C" int fgw_gelf_decode(const uint8_t* bytes, uint64_t nbytes, const uint64_t* offsets, uint64_t n, const fg_tables* tables,
+                               uint32_t lines_per_group, uint32_t tile_cap, uint8_t* handled) {
+    return fgw_gelf_decode_framed(bytes, nbytes, offsets, n, tables, lines_per_group, tile_cap, handled, FG_FRAME_NONE);
 }
 
 // the register-resident number parser of the GELF fast form on ONE token (unit test hook): returns 1 = parsed (kind / bits as

@@ -183,3 +183,51 @@ def test_register_number_parser_matches_serde_json(wave, oracle):
             digits = sum(ch.isdigit() for ch in t)
             assert digits > 19, f"everyday shape rejected: {t}"
     assert accepted >= sum(1 for t in toks if sum(ch.isdigit() for ch in t) <= 19)
+
+
+@pytest.mark.parametrize("framing", ["line", "nul"])
+@pytest.mark.parametrize("geom", [dict(lines_per_group=8, tile_cap=4096), dict(lines_per_group=32, tile_cap=12288)])
+def test_framed_streams(wave, oracle, framing, geom):
+    """Frames of a raw stream (terminators still in the tile, between the lines): a terminator is not a control character of either
+    neighbour, a control character INSIDE a line still takes it out of the fast form; CRLF, empty frames, an unterminated tail.
+    Every handled row equals the oracle's decode of the bare line, and the well-formed corpus stays fast-form material."""
+    delim = b"\n" if framing == "line" else b"\0"
+    lines = synth.gelf_lines(3000)
+    extra = [b'{"host":"h","a":"tab\there"}', b'{"host":"h",\t"a":1}', b'{"host":"a\rb"}', b'{"host":"h","a":"x\x01y"}', b'{"host":"h"}\r',
+             b' {"host":"h" , "b" : 1}', b'{"host":"h","s":"' + b"m" * 90 + b'"}', b"{}", b"[1,2]", b""]
+    if framing == "nul":
+        extra += [b'{"host":"line1\nline2"}', b'{"host":"h",\n"a":1}', b'\n{"host":"h"}\n']
+    bare, frames = [], []
+    for i, ln in enumerate(lines):
+        if i % 11 == 4:
+            ln = extra[(i // 11) % len(extra)]
+        term = delim
+        body = ln
+        if framing == "line" and i % 5 == 1 and b"\n" not in ln:
+            term = b"\r\n"           # lines(): "\n", then ONE "\r", are not part of the line
+        frames.append(body + term)
+        whole = body + term
+        cut = whole[:-1]                  # BufRead::lines() / split(0): the terminator, then (lines only) ONE "\r"
+        if framing == "line" and cut.endswith(b"\r"):
+            cut = cut[:-1]
+        bare.append(cut)
+    frames.append(b'{"host":"tail"}')  # unterminated last frame
+    bare.append(b'{"host":"tail"}')
+    raw = b"".join(frames)
+    offsets = np.zeros(len(frames) + 1, np.uint64)
+    offsets[1:] = np.cumsum([len(f) for f in frames])
+    pad = np.concatenate([np.frombuffer(raw, np.uint8), np.zeros(64, np.uint8)])
+    tab, handled = wave.gelf(pad, offsets, strip=1 if framing == "line" else 2, **geom)
+    bdata, boffs = synth.pack(bare)
+    oblob, ooffs = oracle.decode_batch(GELF, bdata, boffs)
+    blob, offs = tab.serialize(GELF, pad, offsets)
+    for i in np.nonzero(handled)[0]:
+        got = blob[int(offs[i]):int(offs[i + 1])].tobytes()
+        want = oblob[int(ooffs[i]):int(ooffs[i + 1])].tobytes()
+        assert got == want, f"frame {i}: {bare[i][:200]!r}\n  wave   {got[:300]!r}\n  oracle {want[:300]!r}"
+    corpus = np.array([i % 11 != 4 for i in range(len(lines))] + [True])
+    assert handled[corpus].mean() > 0.985, handled[corpus].mean()
+    # a control character inside a line is never fast-form material
+    for i, b in enumerate(bare):
+        if any(c < 0x20 for c in b):
+            assert not handled[i], b
