@@ -83,11 +83,12 @@ def self_launch(args) -> int:
     return subprocess.call(cmd, env=env)
 
 
-def source_hash() -> str:
-    """Identity of the kernel sources a PMC traffic figure belongs to (profiles/traffic.json, tools/update_traffic.py)."""
+def source_hash(workload=None) -> str:
+    """Identity of the kernel sources a PMC traffic figure belongs to (profiles/traffic.json, tools/update_traffic.py): the files
+    the workload's kernel object was compiled from."""
     from flowgger_amd.build import source_hash as h
 
-    return h()
+    return h(workload)
 
 
 def e2e_legs(dec, fmt, data, offsets, n_tile, tile_bytes, want_transcode):
@@ -379,7 +380,9 @@ def main():
         if tr.exists():
             try:
                 t = json.loads(tr.read_text()).get(args.workload)
-                if t and t.get("src_hash") == source_hash():
+                # (per workload: the files its kernel object was compiled from; where the dependency files are missing that
+                #  falls back to the hash over every kernel source, which the entry carries as src_hash_all)
+                if t and (t.get("src_hash") == source_hash(wl) or (t.get("src_hash_all") and t.get("src_hash_all") == source_hash())):
                     out["roofline"]["traffic"] = t["hbm_bytes_per_line"] * n
                     out["roofline"]["traffic_profile"] = t.get("profile")
                 elif t:

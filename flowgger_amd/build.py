@@ -72,16 +72,63 @@ def _depfile_deps(depfile: Path) -> list[Path] | None:
     return [Path(tok) for tok in rhs.split() if tok.startswith(str(ROOT.parent))]
 
 
-def source_hash() -> str:
-    """sha256 (16 hex digits) over the kernel / C-ABI sources: what a measured figure (profiles/traffic.json) belongs to."""
+# the object whose kernel a bench workload times (plus the host side of the C ABI, which picks the launch geometry)
+WORKLOAD_UNITS = {
+    "cfg2": ["fg_rfc5424.hip", "fg_capi.cpp"], "cfg4": ["fg_rfc5424.hip", "fg_capi.cpp"], "cfg5": ["fg_rfc5424.hip", "fg_capi.cpp"],
+    "cfg1": ["fg_rfc5424.hip", "fg_capi.cpp"], "frame": ["fg_rfc5424.hip", "fg_frame.hip", "fg_capi.cpp"],
+    "cfg3": ["fg_gelf.hip", "fg_capi.cpp"], "ltsv": ["fg_ltsv.hip", "fg_capi.cpp"], "ltsv5": ["fg_ltsv.hip", "fg_capi.cpp"],
+    "rfc3164": ["fg_rfc3164.hip", "fg_capi.cpp"],
+}
+
+
+def _repo_deps(unit: str) -> list[Path] | None:
+    """The repository files the object of `unit` was compiled from (its compiler-written dependency file), as local paths; None =
+    unknown (never built here)."""
+    try:
+        text = (ROOT / "build" / (unit + ".d")).read_text()
+    except OSError:
+        return None
+    _, _, rhs = text.replace("\\\n", " ").partition(":")
+    out = set()
+    for tok in rhs.split():
+        # (by position in the tree, not by absolute prefix: the snapshot on a GPU box lives under another root)
+        for marker, base in (("/flowgger_amd/csrc/", CSRC), ("/include/", ROOT.parent / "include"), ("/tests/native/", ROOT.parent / "tests" / "native")):
+            if marker in tok and "/rocm" not in tok and "/usr/" not in tok:
+                f = (base / tok.rsplit(marker, 1)[1]).resolve()
+                if f.exists():
+                    out.add(f)
+                break
+    return sorted(out) or None
+
+
+def source_hash(workload: str | None = None) -> str:
+    """sha256 (16 hex digits) over the sources a measured figure (profiles/traffic.json) belongs to: with a workload, the files its
+    kernel's object was compiled from (so that an edit of the RFC3164 parser does not disown the RFC5424 kernel's PMC figure);
+    without one -- or when the dependency files are not there -- every kernel / C-ABI source."""
     import hashlib
 
+    files = None
+    if workload in WORKLOAD_UNITS:
+        files = []
+        for unit in WORKLOAD_UNITS[workload]:
+            d = _repo_deps(unit)
+            if d is None:
+                files = None
+                break
+            files += d
+        if files is not None:
+            files = sorted(set(files))
+    if files is None:
+        files = [f for f in sorted(CSRC.glob("*")) + [ROOT.parent / "include" / "fg_hip.h"] if f.suffix in (".hip", ".hpp", ".cpp", ".inc", ".h")]
     h = hashlib.sha256()
-    for f in sorted(CSRC.glob("*")) + [ROOT.parent / "include" / "fg_hip.h"]:
-        if f.suffix in (".hip", ".hpp", ".cpp", ".inc", ".h"):
-            h.update(f.name.encode())
-            h.update(f.read_bytes())
+    for f in files:
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
     return h.hexdigest()[:16]
+
+
+def source_hashes() -> dict:
+    return {w: source_hash(w) for w in WORKLOAD_UNITS} | {"*": source_hash()}
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:

@@ -38,9 +38,11 @@ if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
                                      "total": 2 * pm["FETCH_SIZE"] * 1024 + pm["WRITE_SIZE"] * 1024}
 try:  # which kernel sources these numbers belong to (bench.py reports a traffic figure only for matching sources)
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-    from flowgger_amd.build import source_hash
+    from flowgger_amd.build import source_hash, source_hashes
 
     out["src_hash"] = source_hash()
+    out["src_hashes"] = source_hashes()  # per workload: the files its kernel object was compiled from
 except Exception as e:  # pragma: no cover
     out["src_hash"] = None
+    out["src_hashes"] = {}
 print(json.dumps(out, indent=1))
