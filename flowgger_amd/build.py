@@ -81,13 +81,37 @@ WORKLOAD_UNITS = {
 }
 
 
-def _repo_deps(unit: str) -> list[Path] | None:
-    """The repository files the object of `unit` was compiled from (its compiler-written dependency file), as local paths; None =
-    unknown (never built here)."""
+DEPS_MANIFEST = ROOT / "kernel_deps.json"  # beside the library: travels with it where the build directory does not (GPU box)
+
+
+def _write_deps_manifest() -> None:
+    import json
+
+    units = sorted({u for us in WORKLOAD_UNITS.values() for u in us})
+    man = {}
+    for u in units:
+        d = _repo_deps(u, manifest=False)
+        if d is None:
+            return
+        man[u] = [str(f.relative_to(ROOT.parent)) for f in d]
+    DEPS_MANIFEST.write_text(json.dumps(man, indent=1) + "\n")
+
+
+def _repo_deps(unit: str, manifest: bool = True) -> list[Path] | None:
+    """The repository files the object of `unit` was compiled from (its compiler-written dependency file -- or, where the build
+    directory is absent, the manifest build() leaves beside the library), as local paths; None = unknown."""
     try:
         text = (ROOT / "build" / (unit + ".d")).read_text()
     except OSError:
-        return None
+        if not manifest:
+            return None
+        try:
+            import json
+
+            fs = [ROOT.parent / f for f in json.loads(DEPS_MANIFEST.read_text())[unit]]
+            return fs if all(f.exists() for f in fs) else None
+        except (OSError, KeyError, ValueError):
+            return None
     _, _, rhs = text.replace("\\\n", " ").partition(":")
     out = set()
     for tok in rhs.split():
@@ -111,6 +135,11 @@ def source_hash(workload: str | None = None) -> str:
     if workload in WORKLOAD_UNITS:
         files = []
         for unit in WORKLOAD_UNITS[workload]:
+            if unit == "fg_capi.cpp":
+                # the host side picks streams, staging and scratch sizes; what it INCLUDES (the encoders' configuration, the
+                # RFC3164 zone index ...) does not reach another format's kernel
+                files += [CSRC / "fg_capi.cpp", ROOT.parent / "include" / "fg_hip.h"]
+                continue
             d = _repo_deps(unit)
             if d is None:
                 files = None
@@ -190,6 +219,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         if verbose:
             print(" ".join(cmd))
         _run(cmd)
+    _write_deps_manifest()
     return LIB
 
 
