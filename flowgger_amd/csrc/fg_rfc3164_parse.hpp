@@ -141,38 +141,39 @@ FG3_HD bool two_digits(R& rd, uint32_t at, uint32_t* v) {
 // PrimitiveDateTime taken as UTC
 template <class R>
 FG3_HD bool parse_mdt(R& rd, const Tok& mon, const Tok& day, const Tok& tim, int year, int64_t* local_secs) {
-    if (mon.e - mon.s != 3u) return false;
-    const uint32_t m3 = rd.byte(mon.s) << 16 | rd.byte(mon.s + 1) << 8 | rd.byte(mon.s + 2);
+    const uint32_t dl = day.e - day.s;
+    if (mon.e - mon.s != 3u || dl < 1u || dl > 2u || tim.e - tim.s != 8u) return false;
+    // the three tokens' bytes with every load in flight (byte by byte, with a verdict after each, they were a chain of dependent
+    // memory round trips), then everything out of registers
+    const uint32_t mw = rd.load4(mon.s, 3u) & 0xFFFFFFu, dw = rd.load4(day.s, dl), t0 = rd.load4(tim.s, 4u), t1 = rd.load4(tim.s + 4u, 4u);
     int month = 0;
-    switch (m3) {  // case-sensitive
-        case 0x4A616Eu: month = 1; break;   // Jan
-        case 0x466562u: month = 2; break;   // Feb
-        case 0x4D6172u: month = 3; break;   // Mar
-        case 0x417072u: month = 4; break;   // Apr
-        case 0x4D6179u: month = 5; break;   // May
-        case 0x4A756Eu: month = 6; break;   // Jun
-        case 0x4A756Cu: month = 7; break;   // Jul
-        case 0x417567u: month = 8; break;   // Aug
-        case 0x536570u: month = 9; break;   // Sep
-        case 0x4F6374u: month = 10; break;  // Oct
-        case 0x4E6F76u: month = 11; break;  // Nov
-        case 0x446563u: month = 12; break;  // Dec
+    switch (mw) {  // case-sensitive; little endian: first letter in the low byte
+        case 0x6E614Au: month = 1; break;   // Jan
+        case 0x626546u: month = 2; break;   // Feb
+        case 0x72614Du: month = 3; break;   // Mar
+        case 0x727041u: month = 4; break;   // Apr
+        case 0x79614Du: month = 5; break;   // May
+        case 0x6E754Au: month = 6; break;   // Jun
+        case 0x6C754Au: month = 7; break;   // Jul
+        case 0x677541u: month = 8; break;   // Aug
+        case 0x706553u: month = 9; break;   // Sep
+        case 0x74634Fu: month = 10; break;  // Oct
+        case 0x766F4Eu: month = 11; break;  // Nov
+        case 0x636544u: month = 12; break;  // Dec
         default: return false;
     }
-    const uint32_t dl = day.e - day.s;
-    if (dl < 1u || dl > 2u) return false;
-    uint32_t d = rd.byte(day.s) - '0';
+    uint32_t d = (dw & 0xFFu) - '0';
     if (d > 9u) return false;
     if (dl == 2u) {
-        const uint32_t d2 = rd.byte(day.s + 1) - '0';
+        const uint32_t d2 = ((dw >> 8) & 0xFFu) - '0';
         if (d2 > 9u) return false;
         d = d * 10u + d2;
     }
-    if (tim.e - tim.s != 8u) return false;
-    uint32_t hh, mm, ss;
-    if (!two_digits(rd, tim.s, &hh) || rd.byte(tim.s + 2) != ':' || !two_digits(rd, tim.s + 3, &mm) || rd.byte(tim.s + 5) != ':' ||
-        !two_digits(rd, tim.s + 6, &ss))
-        return false;
+    // "HH:M" "M:SS"
+    const uint32_t h1 = (t0 & 0xFFu) - '0', h2 = ((t0 >> 8) & 0xFFu) - '0', m1 = (t0 >> 24) - '0';
+    const uint32_t m2 = (t1 & 0xFFu) - '0', s1 = ((t1 >> 16) & 0xFFu) - '0', s2 = (t1 >> 24) - '0';
+    if (h1 > 9u || h2 > 9u || m1 > 9u || m2 > 9u || s1 > 9u || s2 > 9u || ((t0 >> 16) & 0xFFu) != ':' || ((t1 >> 8) & 0xFFu) != ':') return false;
+    const uint32_t hh = h1 * 10u + h2, mm = m1 * 10u + m2, ss = s1 * 10u + s2;
     if (hh > 23u || mm > 59u || ss > 59u) return false;
     if (d < 1u || (int)d > days_in_month(year, month)) return false;
     *local_secs = days_from_civil(year, month, (int)d) * 86400ll + (int64_t)(hh * 3600u + mm * 60u + ss);
