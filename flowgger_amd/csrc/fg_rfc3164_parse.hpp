@@ -107,6 +107,71 @@ FG3_HD bool next_token(R& rd, uint32_t& pos, uint32_t end, uint32_t* ts, uint32_
     *te = pos;
     return true;
 }
+// ---- tokens out of a 64-byte REGISTER window ------------------------------------------------------------------------
+// The date, the zone and the hostname are four to six short tokens at the start of the line: read one by one, each costs a
+// dependent memory round trip (the next token starts where the last one ended).  The window holds, for 64 bytes from `w0`, one
+// bit per byte for "is an ASCII space" (exact) and one for "could be some OTHER White_Space character" (conservative: a tab, a
+// line feed, any non-ASCII byte ...): as long as no `other` bit lies inside what a token request looks at, the split is decided
+// from the two masks; anything else -- and everything beyond the window -- is next_token's business.
+struct TokWin {
+    uint32_t w0 = 0;
+    uint64_t sp = 0, other = 0;
+    bool valid = false;
+};
+FG3_HD uint32_t gather4(uint32_t flags) {  // flags in bit 7 of each byte -> four bits
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_udot4(flags >> 7, 0x08040201u, 0u, false);
+#else
+    return (((flags >> 7) * 0x00204081u) >> 21) & 0xFu;
+#endif
+}
+template <class R>
+FG3_HD void tokwin_load(R& rd, TokWin& w, uint32_t pos, uint32_t end) {
+    w.valid = pos + 64u <= end;  // (sixty-four WANTED bytes: the readers do not read beyond them)
+    if (!w.valid) return;
+    w.w0 = pos;
+    uint32_t q[16];
+    rd.load16(pos, q);
+    rd.load16(pos + 16u, q + 4);
+    rd.load16(pos + 32u, q + 8);
+    rd.load16(pos + 48u, q + 12);
+    uint64_t sp = 0, maybe = 0;
+    for (int k = 0; k < 16; ++k) {
+        const uint32_t x = q[k] ^ 0x20202020u;
+        const uint32_t is_sp = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;  // exact
+        sp |= (uint64_t)gather4(is_sp) << (4 * k);
+        maybe |= (uint64_t)gather4(maybe_ws4(q[k])) << (4 * k);
+    }
+    w.sp = sp;
+    w.other = maybe & ~sp;
+}
+// next_token through the window (loaded at the first request, kept while requests stay inside it)
+template <class R>
+FG3_HD bool next_token_w(R& rd, TokWin& w, uint32_t& pos, uint32_t end, uint32_t* ts, uint32_t* te) {
+    if (!w.valid || pos - w.w0 >= 64u) {
+        if (w.valid || pos == w.w0) tokwin_load(rd, w, pos, end);  // (a window that could not be loaded once is not retried further in)
+    }
+    if (w.valid && pos - w.w0 < 64u) {
+        const uint32_t off = pos - w.w0;
+        const uint64_t nonsp = ~w.sp >> off;
+        if (nonsp != 0ull) {
+            const uint32_t a = off + (uint32_t)__builtin_ctzll(nonsp);
+            const uint64_t sp2 = w.sp >> a;
+            if (sp2 != 0ull) {
+                const uint32_t b = a + (uint32_t)__builtin_ctzll(sp2);  // the space that ends the token: a < b <= 63
+                const uint64_t span = (b - off >= 63u ? ~0ull : ((1ull << (b - off + 1u)) - 1ull)) << off;
+                if ((w.other & span) == 0ull) {
+                    *ts = w.w0 + a;
+                    *te = w.w0 + b;
+                    pos = w.w0 + b;
+                    return true;
+                }
+            }
+        }
+    }
+    return next_token(rd, pos, end, ts, te);
+}
+
 // str::trim_end of rd[s .. e): the new end
 template <class R>
 FG3_HD uint32_t trim_end_ws(R& rd, uint32_t s, uint32_t e) {
@@ -252,9 +317,12 @@ FG3_HD int32_t tz_offset_local(const TzView& tz, uint32_t zone, int64_t local) {
 template <class R>
 FG3_HD uint32_t parse_date_token(R& rd, uint32_t& pos, uint32_t end, const Cfg& cfg, bool need4, double* ts, Tok* nx, bool* have_nx) {
     Tok t0, t1, t2, t3;
-    if (!next_token(rd, pos, end, &t0.s, &t0.e) || !next_token(rd, pos, end, &t1.s, &t1.e) || !next_token(rd, pos, end, &t2.s, &t2.e))
+    TokWin win;
+    win.w0 = pos;
+    if (!next_token_w(rd, win, pos, end, &t0.s, &t0.e) || !next_token_w(rd, win, pos, end, &t1.s, &t1.e) ||
+        !next_token_w(rd, win, pos, end, &t2.s, &t2.e))
         return ST_TIME_FORMAT;  // fewer than three tokens
-    const bool have3 = next_token(rd, pos, end, &t3.s, &t3.e);
+    const bool have3 = next_token_w(rd, win, pos, end, &t3.s, &t3.e);
     if (need4 && !have3) return ST_TIME_FORMAT;  // the standard form is only tried on more than three tokens (:61-63)
     int64_t local = 0;
     Tok cand = t3;
@@ -263,14 +331,14 @@ FG3_HD uint32_t parse_date_token(R& rd, uint32_t& pos, uint32_t end, const Cfg& 
         if (!have3) return ST_DATE_YEAR;
         int year;
         if (!parse_year_tok(rd, t0, &year) || !parse_mdt(rd, t1, t2, t3, year, &local)) return ST_DATE;
-        have = next_token(rd, pos, end, &cand.s, &cand.e);
+        have = next_token_w(rd, win, pos, end, &cand.s, &cand.e);
     }
     int64_t off = 0;
     if (have && cfg.tz.nz) {
         const int32_t z = tz_lookup(rd, cand, cfg.tz);
         if (z >= 0) {
             off = tz_offset_local(cfg.tz, (uint32_t)z, local);
-            have = next_token(rd, pos, end, &cand.s, &cand.e);
+            have = next_token_w(rd, win, pos, end, &cand.s, &cand.e);
         }
     }
     *ts = unix_nanos_to_f64(local - off, 0u);
