@@ -126,7 +126,7 @@ FG3_HD uint32_t gather4(uint32_t flags) {  // flags in bit 7 of each byte -> fou
 #endif
 }
 template <class R>
-FG3_HD void tokwin_load(R& rd, TokWin& w, uint32_t pos, uint32_t end) {
+FG3_HD void tokwin_load(R& rd, TokWin& w, uint32_t pos, uint32_t end, uint32_t* head0 = nullptr, uint32_t* head1 = nullptr) {
     w.valid = pos + 64u <= end;  // (sixty-four WANTED bytes: the readers do not read beyond them)
     if (!w.valid) return;
     w.w0 = pos;
@@ -144,6 +144,10 @@ FG3_HD void tokwin_load(R& rd, TokWin& w, uint32_t pos, uint32_t end) {
     }
     w.sp = sp;
     w.other = maybe & ~sp;
+    if (head0) {  // the window's first eight bytes (the line's "<PRI>")
+        *head0 = q[0];
+        *head1 = q[1];
+    }
 }
 // next_token through the window (loaded at the first request, kept while requests stay inside it)
 template <class R>
@@ -315,10 +319,9 @@ FG3_HD int32_t tz_offset_local(const TzView& tz, uint32_t zone, int64_t local) {
 // indexed array would live in scratch memory on the GPU).  On ST_OK: *nx = the first token after the date [+ zone]
 // (*have_nx = false: there is none) and pos stands behind it.
 template <class R>
-FG3_HD uint32_t parse_date_token(R& rd, uint32_t& pos, uint32_t end, const Cfg& cfg, bool need4, double* ts, Tok* nx, bool* have_nx) {
+FG3_HD uint32_t parse_date_token(R& rd, uint32_t& pos, uint32_t end, const Cfg& cfg, bool need4, double* ts, Tok* nx, bool* have_nx,
+                                 TokWin& win) {
     Tok t0, t1, t2, t3;
-    TokWin win;
-    win.w0 = pos;
     if (!next_token_w(rd, win, pos, end, &t0.s, &t0.e) || !next_token_w(rd, win, pos, end, &t1.s, &t1.e) ||
         !next_token_w(rd, win, pos, end, &t2.s, &t2.e))
         return ST_TIME_FORMAT;  // fewer than three tokens
@@ -351,9 +354,47 @@ FG3_HD uint32_t parse_date_token(R& rd, uint32_t& pos, uint32_t end, const Cfg& 
 template <class R>
 FG3_HD void parse_line(R& rd, uint32_t len, const Cfg& cfg, Row& r) {
     r = Row{};
-    // parse_strip_pri
+    // parse_strip_pri.  The line's first 64 bytes go into the register window the date tokens are read from (ONE memory round
+    // trip); "<PRI>" is decided from its first eight bytes when its '>' lies there -- else, and for short lines, byte by byte.
     uint32_t q0 = 0;
-    if (len && rd.byte(0) == '<') {
+    TokWin lwin;
+    uint32_t h0 = 0, h1 = 0;
+    tokwin_load(rd, lwin, 0u, len, &h0, &h1);
+    bool pri_done = false;
+    if (lwin.valid) {
+        if ((h0 & 0xFFu) != '<') {
+            pri_done = true;  // no priority
+        } else {
+            const uint64_t hv = (uint64_t)h0 | ((uint64_t)h1 << 32);
+            uint32_t gt = 0;
+            for (uint32_t i = 7; i >= 1u; --i)
+                if (((hv >> (8u * i)) & 0xFFu) == '>') gt = i;  // the first '>' of bytes 1..7
+            if (gt != 0u) {
+                auto hb = [&](uint32_t i) -> uint32_t { return (uint32_t)(hv >> (8u * i)) & 0xFFu; };  // i <= gt <= 7
+                uint32_t a = 0, b = gt + 1;
+                while (a < b && hb(a) == '<') ++a;
+                while (b > a && hb(b - 1) == '>') --b;
+                if (a < b && hb(a) == '+') ++a;
+                if (a >= b) {
+                    r.status = ST_PRI_INVALID;
+                    return;
+                }
+                uint32_t v = 0;
+                for (uint32_t i = a; i < b; ++i) {
+                    const uint32_t d = hb(i) - '0';
+                    if (d > 9u || (v = v * 10u + d) > 255u) {
+                        r.status = ST_PRI_INVALID;
+                        return;
+                    }
+                }
+                r.fac = v >> 3;
+                r.sev = v & 7u;
+                q0 = gt + 1;
+                pri_done = true;
+            }
+        }
+    }
+    if (!pri_done && len && rd.byte(0) == '<') {
         uint32_t gt = 0;
         bool found = false;
         for (uint32_t i = 1; i < len; ++i)
@@ -396,7 +437,7 @@ FG3_HD void parse_line(R& rd, uint32_t len, const Cfg& cfg, Row& r) {
             double ts;
             Tok host;
             bool have_host;
-            if (parse_date_token(rd, pos, len, cfg, true, &ts, &host, &have_host) == ST_OK) {
+            if (parse_date_token(rd, pos, len, cfg, true, &ts, &host, &have_host, lwin) == ST_OK) {
                 if (!have_host) {  // the date [+ zone] consumed every token: index out of bounds in the reference (:67)
                     r.status = ST_REF_PANIC;
                     return;
@@ -459,7 +500,9 @@ FG3_HD void parse_line(R& rd, uint32_t len, const Cfg& cfg, Row& r) {
     double ts;
     Tok nx;
     bool have_nx;
-    const uint32_t st = parse_date_token(rd, pos, p2, cfg, false, &ts, &nx, &have_nx);
+    TokWin cwin;
+    cwin.w0 = pos;
+    const uint32_t st = parse_date_token(rd, pos, p2, cfg, false, &ts, &nx, &have_nx, cwin);
     if (st != ST_OK) {
         r.status = st;
         return;
