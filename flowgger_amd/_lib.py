@@ -5,14 +5,18 @@ from __future__ import annotations
 import ctypes as C
 from pathlib import Path
 
+import os
+
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "libfg_hip.so"
+# FLOWGGER_AMD_PROF_LIB=1 (tools/ only): the measurement build, `FG_BUILD_PROF=1 python -m flowgger_amd.build` (s_memtime phase clocks,
+# ablation flags -- csrc/fg_pipeline.hpp).  The product library has neither.
+LIB_PATH = _HERE / ("libfg_hip_prof.so" if os.environ.get("FLOWGGER_AMD_PROF_LIB") else "libfg_hip.so")
 
 FG_RFC5424, FG_LTSV, FG_GELF, FG_RFC3164 = 0, 1, 2, 3
 FG_FRAME_NONE, FG_FRAME_LINE, FG_FRAME_NUL = 0, 1, 2
 FG_ST_OVERFLOW, FG_ST_BAD_UTF8 = 0xFE, 0xFD
 FG_OK, FG_ERR_ARG, FG_ERR_HIP, FG_ERR_NO_DEVICE, FG_ERR_ENT_OVERFLOW, FG_ERR_UNSUPPORTED, FG_ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6
-FG_YEAR_NOW = 0
+FG_YEAR_NOW = -2147483648  # INT32_MIN (include/fg_hip.h)
 FG_NONE = 0xFFFFFFFF
 FG_T_STRING, FG_T_BOOL, FG_T_F64, FG_T_I64, FG_T_U64, FG_T_NULL, FG_T_SDID = range(7)
 FG_TABLE_ARRAYS = 15
@@ -57,6 +61,14 @@ FG_MERGE_NONE, FG_MERGE_LINE, FG_MERGE_NUL, FG_MERGE_SYSLEN = range(4)
 class fg_encode_cfg(C.Structure):
     _fields_ = [("encoder", C.c_int), ("merger", C.c_int), ("n_extra", C.c_uint32), ("extra_keys", C.POINTER(C.c_char_p)),
                 ("extra_values", C.POINTER(C.c_char_p)), ("prepend", C.c_char_p), ("now_ts", C.c_double)]
+
+
+class fg_launch_opts(C.Structure):
+    _fields_ = [("lines_per_group", C.c_uint32), ("tile_cap", C.c_uint32), ("waves_per_cu", C.c_uint32),
+                ("gelf_lds_budget", C.c_uint32), ("gelf_window_kib", C.c_uint32), ("flags", C.c_uint32)]
+
+
+FG_LO_GELF_GENERIC, FG_LO_TRANSCODE_ONE_PIECE = 1, 2
 
 
 class fg_transcoded(C.Structure):
@@ -107,6 +119,7 @@ def lib() -> C.CDLL:
     L.fg_destroy.argtypes = [vp]
     L.fg_destroy.restype = None
     L.fg_last_hip_error.argtypes = [vp]
+    L.fg_set_launch_opts.argtypes = [vp, C.POINTER(fg_launch_opts)]
     L.fg_tables_layout.argtypes = [u64, u64, C.POINTER(u64)]
     L.fg_decode_batch_device.argtypes = [vp, C.c_int, vp, u64, vp, u64, C.POINTER(fg_tables), vp]
     L.fg_decode_batch.argtypes = [vp, C.c_int, vp, u64, vp, u64, C.POINTER(fg_tables)]

@@ -17,7 +17,11 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
 CSRC = ROOT / "csrc"
-LIB = ROOT / "libfg_hip.so"
+# FG_BUILD_PROF=1: the MEASUREMENT build (-DFG_PROF_BUILD: s_memtime phase clocks, FG_PROF / FG_ABLATE / FG_PLAN in the
+# environment -- csrc/fg_pipeline.hpp) as libfg_hip_prof.so from its own object directory.  tools/ load it with
+# FLOWGGER_AMD_PROF_LIB=1; the product library has none of it.
+PROF = bool(os.environ.get("FG_BUILD_PROF"))
+LIB = ROOT / ("libfg_hip_prof.so" if PROF else "libfg_hip.so")
 ARCH = "gfx950"
 
 HIP_SOURCES = ["fg_rfc5424.hip", "fg_ltsv.hip", "fg_gelf.hip", "fg_frame.hip", "fg_encode.hip", "fg_rfc3164.hip"]
@@ -162,7 +166,7 @@ def source_hashes() -> dict:
 
 def build(force: bool = False, verbose: bool = False) -> Path:
     hipcc = _hipcc()
-    objdir = ROOT / "build"
+    objdir = ROOT / ("build_prof" if PROF else "build")
     objdir.mkdir(exist_ok=True)
     headers = list(CSRC.glob("*.hpp")) + [ROOT.parent / "include" / "fg_hip.h", Path(__file__)]
     common = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-fast-math",
@@ -170,6 +174,8 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     # (fg_wave.hpp's host branch includes the fiber emulation from tests/native; the device branch never does, but the
     #  host pass of hipcc still has to find the header)
     common.append(f"-I{ROOT.parent / 'tests' / 'native'}")
+    if PROF:
+        common.append("-DFG_PROF_BUILD")
     # (source, object, extra defines); fg_encode.hip is compiled once per (encoder, pass) -- its emitters are large
     # force-inlined templates (one object took 18 minutes) -- plus once for the dispatcher
     units: list[tuple[str, Path, list[str]]] = []
@@ -219,7 +225,8 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         if verbose:
             print(" ".join(cmd))
         _run(cmd)
-    _write_deps_manifest()
+    if not PROF:
+        _write_deps_manifest()
     return LIB
 
 

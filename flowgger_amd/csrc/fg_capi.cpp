@@ -37,7 +37,7 @@ struct LtsvDevCfg {
 
 extern "C" int fg_launch_rfc5424(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
                                  uint64_t avg_len, hipStream_t stream, uint64_t* stash, uint32_t stash_blocks, uint32_t strip,
-                                 const uint8_t* line_bad);
+                                 const uint8_t* line_bad, const fg_launch_opts* lo);
 extern "C" uint64_t fg_stash_bytes(uint32_t blocks);
 extern "C" int fg_launch_rfc3164(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
                                  const fg::r3164::Cfg* cfg, uint32_t tile_cap, hipStream_t stream, uint32_t strip,
@@ -58,10 +58,10 @@ extern "C" int fg_launch_frame(const uint8_t* d_bytes, uint64_t nbytes, uint32_t
                                uint8_t* d_bad, uint64_t cap, uint64_t** d_total_out, hipStream_t stream);
 extern "C" int fg_launch_ltsv(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
                               const fg::LtsvDevCfg* cfg, uint64_t avg_len, hipStream_t stream, uint64_t* stash,
-                              uint32_t stash_blocks, uint32_t strip, const uint8_t* line_bad);
+                              uint32_t stash_blocks, uint32_t strip, const uint8_t* line_bad, const fg_launch_opts* lo);
 extern "C" int fg_launch_gelf(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
                               uint64_t avg_len, hipStream_t stream, uint64_t* stash, uint32_t stash_blocks, uint32_t strip,
-                              const uint8_t* line_bad);
+                              const uint8_t* line_bad, const fg_launch_opts* lo);
 
 struct fg_ctx {
     int device = 0;
@@ -69,6 +69,7 @@ struct fg_ctx {
     hipStream_t stream2 = nullptr;  // second lane of the pipelined host path (created on first use)
     hipEvent_t ev_ready = nullptr;
     int last_hip = 0;
+    fg_launch_opts lo{};  // launch-geometry overrides (fg_set_launch_opts); all zero = the library's own choices
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
@@ -207,12 +208,9 @@ fg::DevTables to_dev(const fg_tables& t) {
 }
 
 // LDS tile per 64-line wave: room for 64 average lines + 12.5 % + 512 B, 4..56 KiB (the kernel
-// adds the space bitmap, 1/8 of the tile, on top).  FG_TILE_CAP overrides (bytes), for tuning.
-uint32_t pick_tile_cap(uint64_t nbytes, uint64_t n, uint64_t max_cap, uint32_t margin_16ths = 2) {
-    if (const char* e = getenv("FG_TILE_CAP")) {
-        uint64_t v = strtoull(e, nullptr, 10);
-        if (v >= 1024 && v <= max_cap) return (uint32_t)up(v, 1024);
-    }
+// adds the space bitmap, 1/8 of the tile, on top).  fg_launch_opts::tile_cap overrides (bytes), for tuning.
+uint32_t pick_tile_cap(const fg_ctx* ctx, uint64_t nbytes, uint64_t n, uint64_t max_cap, uint32_t margin_16ths = 2) {
+    if (ctx->lo.tile_cap >= 1024 && ctx->lo.tile_cap <= max_cap) return (uint32_t)up(ctx->lo.tile_cap, 1024);
     uint64_t avg = n ? (nbytes + n - 1) / n : 0;
     uint64_t want = up(64 * avg * (16 + margin_16ths) / 16 + 512, 1024);
     if (want < 4096) want = 4096;
@@ -397,12 +395,24 @@ static int refresh_year(fg_ctx* ctx) {
     if (!ctx->r3164_auto_year) return FG_OK;
     const int y = utc_year_now();
     if (y == ctx->r3164_year) return FG_OK;
+    // launches already queued on the caller's streams may still read the old block: it is retired, not freed.  The year is
+    // taken over only when the new block is in place -- a failed upload leaves year, block and view as they were, so the next
+    // call tries again instead of decoding zone-tagged lines without a zone table.
+    const int32_t old_year = ctx->r3164_year;
+    uint8_t* const old_tz = ctx->d_tz;
+    const fg::r3164::Cfg old_cfg = ctx->r3164;
     ctx->r3164_year = y;
-    if (ctx->d_tz) {  // launches already queued on the caller's streams may still read the old block
-        ctx->retired_tz.push_back(ctx->d_tz);
-        ctx->d_tz = nullptr;
+    ctx->d_tz = nullptr;
+    const int rc = upload_tz(ctx);
+    if (rc != FG_OK) {
+        if (ctx->d_tz) (void)hipFree(ctx->d_tz);
+        ctx->d_tz = old_tz;
+        ctx->r3164 = old_cfg;
+        ctx->r3164_year = old_year;
+        return rc;
     }
-    return upload_tz(ctx);
+    if (old_tz) ctx->retired_tz.push_back(old_tz);
+    return FG_OK;
 }
 
 int fg_clone(const fg_ctx* src, fg_ctx** out) {
@@ -410,6 +420,7 @@ int fg_clone(const fg_ctx* src, fg_ctx** out) {
     fg_ctx* ctx = new (std::nothrow) fg_ctx();
     if (!ctx) return FG_ERR_NOMEM;
     ctx->device = src->device;
+    ctx->lo = src->lo;
     ctx->schema_names = src->schema_names;
     ctx->schema_types = src->schema_types;
     for (int k = 0; k < 4; ++k) {
@@ -475,6 +486,13 @@ void fg_destroy(fg_ctx* ctx) {
 }
 
 int fg_last_hip_error(const fg_ctx* ctx) { return ctx ? ctx->last_hip : 0; }
+
+int fg_set_launch_opts(fg_ctx* ctx, const fg_launch_opts* opts) {
+    if (!ctx) return FG_ERR_ARG;
+    if (opts && (opts->lines_per_group > 64 || (opts->gelf_window_kib && (opts->gelf_window_kib < 2 || opts->gelf_window_kib > 6)))) return FG_ERR_ARG;
+    ctx->lo = opts ? *opts : fg_launch_opts{};
+    return FG_OK;
+}
 
 int fg_set_timing(fg_ctx* ctx, int enabled) {
     if (!ctx) return FG_ERR_ARG;
@@ -586,20 +604,20 @@ static int decode_frames_impl(fg_ctx* ctx, fg_format fmt, fg_framing framing, co
     switch (fmt) {
         case FG_RFC5424:
             rc = fg_launch_rfc5424(d_bytes, d_offsets, n, &dt, avg_len, s, ctx->d_stash, ctx->stash_blocks, (uint32_t)framing,
-                                   d_bad_utf8);
+                                   d_bad_utf8, &ctx->lo);
             break;
         case FG_LTSV:
             rc = fg_launch_ltsv(d_bytes, d_offsets, n, &dt, &ctx->ltsv, avg_len, s, ctx->d_stash, ctx->stash_blocks,
-                                (uint32_t)framing, d_bad_utf8);
+                                (uint32_t)framing, d_bad_utf8, &ctx->lo);
             break;
         case FG_GELF:
             rc = fg_launch_gelf(d_bytes, d_offsets, n, &dt, avg_len, s, ctx->d_stash, ctx->stash_blocks,
-                                (uint32_t)framing, d_bad_utf8);
+                                (uint32_t)framing, d_bad_utf8, &ctx->lo);
             break;
         case FG_RFC3164:
             if (!ctx->r3164_set) return FG_ERR_ARG;  // fg_set_rfc3164 first
             if ((rc = refresh_year(ctx)) != FG_OK) return rc;
-            rc = fg_launch_rfc3164(d_bytes, d_offsets, n, &dt, &ctx->r3164, pick_tile_cap(span_bytes, n, 56 * 1024), s, (uint32_t)framing,
+            rc = fg_launch_rfc3164(d_bytes, d_offsets, n, &dt, &ctx->r3164, pick_tile_cap(ctx, span_bytes, n, 56 * 1024), s, (uint32_t)framing,
                                    d_bad_utf8);
             break;
         default:
@@ -922,7 +940,7 @@ static int transcode_sliced(fg_ctx* ctx, fg_format fmt, const fg_encode_cfg* ecf
     const uint32_t cfg_lds = keys_bytes + h.blob.size() <= 4096 ? (uint32_t)up(keys_bytes + h.blob.size(), 16) : 0u;
     uint32_t* d_sizes = reinterpret_cast<uint32_t*>(ctx->d_enc + cfg_bytes);
     uint64_t* d_block_sums = reinterpret_cast<uint64_t*>(ctx->d_enc + cfg_bytes + sizes_bytes);
-    const uint32_t tile_cap = pick_tile_cap(nbytes, n, 40 * 1024, 1);
+    const uint32_t tile_cap = pick_tile_cap(ctx, nbytes, n, 40 * 1024, 1);
     fg::DevTables ddt = to_dev(dt);
     // ---- host buffer: fixed-size arrays first, the messages behind them (they grow slice by slice) ----
     const uint64_t o_offs = 0, o_meta = o_offs + offs_bytes, o_st = o_meta + up(n * 4, 256), o_msgs = o_st + up(n, 256);
@@ -1043,7 +1061,7 @@ int fg_transcode_batch(fg_ctx* ctx, fg_format fmt, fg_framing framing, const fg_
     DeviceGuard g(ctx->device);
     hipStream_t s = ctx->stream;
     int rc;
-    if (framing == FG_FRAME_NONE && nbytes >= (64ull << 20) && n >= 4096 && !getenv("FG_TRANSCODE_ONE_PIECE")) {
+    if (framing == FG_FRAME_NONE && nbytes >= (64ull << 20) && n >= 4096 && !(ctx->lo.flags & FG_LO_TRANSCODE_ONE_PIECE)) {
         rc = transcode_sliced(ctx, fmt, ecfg, bytes, nbytes, offsets, n, out);
         if (rc != FG_ERR_UNSUPPORTED) return rc;
         *out = fg_transcoded{};
@@ -1171,7 +1189,7 @@ int encode_device_impl(fg_ctx* ctx, fg_format src_fmt, const fg_encode_cfg* ecfg
     }
     // LDS tile of a 64-line group: average group + 6.25 % + 512 B, 4..40 KiB (longer groups read from global memory);
     // the tile is what limits the waves per CU (the emitters are latency-bound: occupancy is throughput)
-    const uint32_t tile_cap = pick_tile_cap(nbytes, n, 40 * 1024, 1);
+    const uint32_t tile_cap = pick_tile_cap(ctx, nbytes, n, 40 * 1024, 1);
     if (ctx->timing) FG_HIP(ctx, hipEventRecord(ctx->ev0, s));
     int lrc = fg_launch_encode_sizes(d_bytes, d_offsets, n, &dt, &cfg, tile_cap, cfg_lds, d_sizes, d_block_sums, d_enc_status, d_out_offsets, s);
     if (lrc != 0) {

@@ -55,6 +55,16 @@ bool part_ok(const fg_tables& p) {
     return true;
 }
 
+// the output table of a gather / merge: every column the n rows and e entries are written to must be there
+bool out_ok(const fg_tables* out, uint64_t n, uint64_t e) {
+    if (!out || out->n < n || out->ent_cap < e || !out->ent_used) return false;
+    if (n && (!out->meta || !out->ts || !out->hostname || !out->appname || !out->procid || !out->msgid || !out->msg || !out->full_msg ||
+              !out->ent_first || !out->ent_count))
+        return false;
+    if (e && (!out->ent_name || !out->ent_val || !out->ent_type || !out->ent_flags)) return false;
+    return true;
+}
+
 // entry columns of part k -> out[base ..]
 void copy_entries(const fg_tables& p, uint64_t base, fg_tables* out) {
     const uint64_t u = used_of(p);
@@ -86,9 +96,8 @@ int fg_gather_tables(const fg_tables* parts, uint32_t g, fg_tables* out) {
     uint64_t n = 0, e = 0;
     int rc = fg_gather_size(parts, g, &n, &e);
     if (rc != FG_OK) return rc;
-    if (!out || out->n < n || out->ent_cap < e || !out->ent_used) return FG_ERR_ARG;
+    if (!out_ok(out, n, e)) return FG_ERR_ARG;
     if (e > 0xFFFFFFFFull) return FG_ERR_ENT_OVERFLOW;  // ent_first is 32 bits wide
-    if (n && (!out->meta || !out->ts || !out->ent_first || !out->ent_count)) return FG_ERR_ARG;
     uint64_t row0 = 0, ent0 = 0;
     uint64_t bytes = n * FG_ROW_BYTES + e * FG_ENT_BYTES;
     const unsigned threads = pool_size(bytes);
@@ -117,7 +126,7 @@ int fg_merge_tables(const fg_tables* parts, uint32_t g, const uint64_t* const* i
     uint64_t n = 0, e = 0;
     int rc = fg_gather_size(parts, g, &n, &e);
     if (rc != FG_OK) return rc;
-    if (!out || out->n < n || out->ent_cap < e || !out->ent_used || (g && !index)) return FG_ERR_ARG;
+    if (!out_ok(out, n, e) || (g && !index)) return FG_ERR_ARG;
     if (e > 0xFFFFFFFFull) return FG_ERR_ENT_OVERFLOW;
     if (g > 255) return FG_ERR_ARG;
     // every original position exactly once, increasing inside a part (sub-batches keep their relative order)
@@ -166,7 +175,7 @@ int64_t fg_ordered_merge(uint32_t g, const uint64_t* m, const uint64_t* const* i
     // pass 1: sizes at the original positions -> exclusive scan
     for (uint64_t i = 0; i <= n; ++i) out_offs[i] = ~0ull;
     for (uint32_t k = 0; k < g; ++k) {
-        if (m[k] && (!index[k] || !offs[k])) return FG_ERR_ARG;
+        if (m[k] && (!index[k] || !offs[k] || !blobs[k])) return FG_ERR_ARG;
         for (uint64_t j = 0; j < m[k]; ++j) {
             const uint64_t i = index[k][j];
             if (i >= n || out_offs[i + 1] != ~0ull || offs[k][j + 1] < offs[k][j] || (j && index[k][j - 1] >= i)) return FG_ERR_ARG;

@@ -719,37 +719,42 @@ namespace {
 // the fast-form kernel with a register window of NB KiB (the bytes of the NEXT group, prefetched while this one is decoded)
 template <int NB>
 int launch_gelf_fast(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t, uint64_t avg_len,
-                     hipStream_t stream, uint32_t max_lines, fg::FrameArgs fr) {
+                     hipStream_t stream, uint32_t max_lines, fg::FrameArgs fr, const fg_launch_opts& lo) {
     fg::LaunchPlan p;
-    if (fg::plan_launch(fg::k_gelf<NB, false>, n, avg_len, 0u, 40960u, 0u, &p, max_lines, fg::GelfFormat::kClasses, fg::gelf_extra_lds))
+    if (fg::plan_launch(fg::k_gelf<NB, false>, n, avg_len, 0u, 40960u, 0u, &p, lo, max_lines, fg::GelfFormat::kClasses, fg::gelf_extra_lds))
         return -1;
     dim3 grid(p.blocks), block(fg::kWave);
+#if defined(FG_PROF_BUILD)
     if (getenv("FG_PLAN")) fprintf(stderr, "gelf plan: L %u tile %u lds %u blocks %u window %d KiB\n", p.L, p.tile, p.lds, p.blocks, NB);
+#endif
     if constexpr (NB == 3) {
-        if (p.tile == 4096u && p.L == 8u && !getenv("FG_PROF") && !getenv("FG_GELF_GENERIC")) {
+        if (p.tile == 4096u && p.L == 8u && !fg::prof_requested() && !(lo.flags & FG_LO_GELF_GENERIC)) {
             // the geometry of ~300-byte GELF (the BASELINE corpus): constants
             hipLaunchKernelGGL((fg::k_gelf<NB, false, 4, 4096u, 8u>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L,
                                p.groups, (unsigned long long*)nullptr, (uint64_t*)nullptr, fr);
             return 0;
         }
     }
-    if (getenv("FG_PROF")) {
+#if defined(FG_PROF_BUILD)
+    if (fg::prof_requested()) {
         fg::ProfRun pr;
         if (!pr.begin(stream)) return -1;
         hipLaunchKernelGGL((fg::k_gelf<NB, true>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L, p.groups, pr.d,
                            (uint64_t*)nullptr, fr);
         pr.end(stream, "gelf", p);
-    } else {
-        hipLaunchKernelGGL((fg::k_gelf<NB, false>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L, p.groups,
-                           (unsigned long long*)nullptr, (uint64_t*)nullptr, fr);
+        return 0;
     }
+#endif
+    hipLaunchKernelGGL((fg::k_gelf<NB, false>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L, p.groups,
+                       (unsigned long long*)nullptr, (uint64_t*)nullptr, fr);
     return 0;
 }
 }  // namespace
 
 extern "C" int fg_launch_gelf(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
                               uint64_t avg_len, hipStream_t stream, uint64_t* stash, uint32_t stash_blocks, uint32_t strip,
-                              const uint8_t* line_bad) {
+                              const uint8_t* line_bad, const fg_launch_opts* lop) {
+    const fg_launch_opts& lo = *lop;
     (void)stash;
     (void)stash_blocks;
     if (n == 0) return 0;
@@ -760,31 +765,31 @@ extern "C" int fg_launch_gelf(const uint8_t* d_bytes, const uint64_t* d_offsets,
     // 16: 677, 32: 803, 64: 398, 4: 436).  No global stash, no cap on the grid.
     uint32_t max_lines = fg::kGelfLines;
     uint32_t lds_budget = 10u * 1024u;  // sixteen waves per CU
-    if (const char* e = getenv("FG_GELF_LDS_BUDGET")) lds_budget = (uint32_t)atoi(e);  // tuning
-    if (const char* e = getenv("FG_LINES_PER_GROUP")) max_lines = (uint32_t)atoi(e);
+    if (lo.gelf_lds_budget) lds_budget = lo.gelf_lds_budget;  // tuning
+    if (lo.lines_per_group) max_lines = lo.lines_per_group;
     else {
         while (max_lines > 4u) {
-            if (fg::plan_launch(fg::k_gelf<2, false>, n, avg_len, 0u, 40960u, 0u, &p, max_lines, fg::GelfFormat::kClasses, fg::gelf_extra_lds))
+            if (fg::plan_launch(fg::k_gelf<2, false>, n, avg_len, 0u, 40960u, 0u, &p, lo, max_lines, fg::GelfFormat::kClasses, fg::gelf_extra_lds))
                 return -1;
             if (p.L < max_lines) max_lines = p.L;  // (the geometry already settled on fewer lines)
             if (p.lds <= lds_budget) break;
             max_lines >>= 1;
         }
     }
-    if (fg::plan_launch(fg::k_gelf<2, false>, n, avg_len, 0u, 40960u, 0u, &p, max_lines, fg::GelfFormat::kClasses, fg::gelf_extra_lds))
+    if (fg::plan_launch(fg::k_gelf<2, false>, n, avg_len, 0u, 40960u, 0u, &p, lo, max_lines, fg::GelfFormat::kClasses, fg::gelf_extra_lds))
         return -1;
     // The register window should hold the whole average group: what lies beyond it is staged by plain loads whose latency
     // nothing hides (and four chunks at a time).  1 KiB of window = 4 registers.
     uint64_t want = ((uint64_t)p.L * avg_len * 17u / 16u + 128u + 1023u) / 1024u;
-    if (const char* e = getenv("FG_GELF_WINDOW")) want = (uint64_t)atoi(e);  // tuning
+    if (lo.gelf_window_kib) want = lo.gelf_window_kib;  // tuning
     const fg::FrameArgs fr{strip, line_bad};
     const dim3 block(fg::kWave);
     int rc;
-    if (want <= 2) rc = launch_gelf_fast<2>(d_bytes, d_offsets, n, t, avg_len, stream, p.L, fr);
-    else if (want == 3) rc = launch_gelf_fast<3>(d_bytes, d_offsets, n, t, avg_len, stream, p.L, fr);
-    else if (want == 4) rc = launch_gelf_fast<4>(d_bytes, d_offsets, n, t, avg_len, stream, p.L, fr);
-    else if (want == 5) rc = launch_gelf_fast<5>(d_bytes, d_offsets, n, t, avg_len, stream, p.L, fr);
-    else rc = launch_gelf_fast<6>(d_bytes, d_offsets, n, t, avg_len, stream, p.L, fr);
+    if (want <= 2) rc = launch_gelf_fast<2>(d_bytes, d_offsets, n, t, avg_len, stream, p.L, fr, lo);
+    else if (want == 3) rc = launch_gelf_fast<3>(d_bytes, d_offsets, n, t, avg_len, stream, p.L, fr, lo);
+    else if (want == 4) rc = launch_gelf_fast<4>(d_bytes, d_offsets, n, t, avg_len, stream, p.L, fr, lo);
+    else if (want == 5) rc = launch_gelf_fast<5>(d_bytes, d_offsets, n, t, avg_len, stream, p.L, fr, lo);
+    else rc = launch_gelf_fast<6>(d_bytes, d_offsets, n, t, avg_len, stream, p.L, fr, lo);
     if (rc) return rc;
     if (hipGetLastError() != hipSuccess) return -1;
     // pending lines (a frame flagged as invalid UTF-8 never is: the pipeline has overwritten its status)

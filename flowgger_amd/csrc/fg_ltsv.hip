@@ -734,14 +734,15 @@ __global__ __launch_bounds__(kWave, 2) void k_ltsv(const uint8_t* __restrict__ b
 
 extern "C" int fg_launch_ltsv(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
                               const fg::LtsvDevCfg* cfg, uint64_t avg_len, hipStream_t stream, uint64_t* stash,
-                              uint32_t stash_blocks, uint32_t strip, const uint8_t* line_bad) {
+                              uint32_t stash_blocks, uint32_t strip, const uint8_t* line_bad, const fg_launch_opts* lo) {
     if (n == 0) return 0;
     fg::LaunchPlan p;
-    if (fg::plan_launch(fg::k_ltsv<fg::kComputeBoundWindow, false>, n, avg_len, fg::kLtsvExtraLds, 57344u, stash ? stash_blocks : 0u, &p))
+    if (fg::plan_launch(fg::k_ltsv<fg::kComputeBoundWindow, false>, n, avg_len, fg::kLtsvExtraLds, 57344u, stash ? stash_blocks : 0u, &p, *lo))
         return -1;
     if (stash_blocks == 0) stash = nullptr;
     dim3 grid(p.blocks), block(fg::kWave);
-    if (getenv("FG_PROF")) {
+#if defined(FG_PROF_BUILD)
+    if (fg::prof_requested()) {
         fg::ProfRun pr;
         if (!pr.begin(stream)) return -1;
         hipLaunchKernelGGL((fg::k_ltsv<fg::kComputeBoundWindow, true>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, *cfg, p.tile,
@@ -749,6 +750,7 @@ extern "C" int fg_launch_ltsv(const uint8_t* d_bytes, const uint64_t* d_offsets,
         pr.end(stream, "ltsv", p);
         return (int)hipGetLastError();
     }
+#endif
     hipLaunchKernelGGL((fg::k_ltsv<fg::kComputeBoundWindow, false>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, *cfg, p.tile,
                        p.L, p.groups, (unsigned long long*)nullptr, stash, fg::FrameArgs{strip, line_bad});
     return (int)hipGetLastError();

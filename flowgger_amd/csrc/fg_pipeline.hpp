@@ -605,10 +605,11 @@ struct LaunchPlan {
 // (+6.25 % + 256 B) fits the register prefetch window, so that a whole group is prefetched.
 // Lines longer than the window get L = 1 and a tile of up to `max_tile` (the part beyond the
 // window is staged by the tail loop); anything that still does not fit is parsed from global
-// memory.  FG_TILE_CAP / FG_LINES_PER_GROUP / FG_WAVES_PER_CU override (tuning, parity sweeps).
+// memory.  fg_launch_opts (fg_set_launch_opts: tuning, parity sweeps) overrides tile / lines per group / waves per CU; the
+// library itself reads no environment variable.
 template <class K>
 inline int plan_launch(K kernel, uint64_t n, uint64_t avg_len, uint32_t extra_lds, uint32_t max_tile, uint32_t stash_blocks,
-                       LaunchPlan* p, uint32_t max_lines = 64, uint32_t n_classes = 1,
+                       LaunchPlan* p, const fg_launch_opts& lo, uint32_t max_lines = 64, uint32_t n_classes = 1,
                        uint32_t (*extra_for)(uint32_t tile, uint32_t lines) = nullptr) {
     const uint64_t window = (uint64_t)kWindowKiB * 1024u;
     // (+6.25 % + 256 B over the average group: a few sigma for the corpora at hand; a longer group just takes
@@ -620,17 +621,11 @@ inline int plan_launch(K kernel, uint64_t n, uint64_t avg_len, uint32_t extra_ld
     //  the 554-byte structured-data corpus L = 32 at 6 waves/CU beats L = 16 at 8 by 30 %)
     while (L > 1 && tile_for(L) > window + 2048u) L >>= 1;
     uint32_t tile = clamp(tile_for(L));
-    if (const char* e = getenv("FG_LINES_PER_GROUP")) {
-        uint32_t forced = (uint32_t)atoi(e);
-        if (forced >= 1 && forced <= max_lines) {
-            L = forced;
-            tile = clamp(tile_for(L));
-        }
+    if (lo.lines_per_group >= 1 && lo.lines_per_group <= max_lines) {
+        L = lo.lines_per_group;
+        tile = clamp(tile_for(L));
     }
-    if (const char* e = getenv("FG_TILE_CAP")) {
-        uint64_t v = strtoull(e, nullptr, 10);
-        if (v >= 1024 && v <= max_tile) tile = (uint32_t)((v + 1023u) / 1024u * 1024u);
-    }
+    if (lo.tile_cap >= 1024 && lo.tile_cap <= max_tile) tile = (lo.tile_cap + 1023u) / 1024u * 1024u;
     p->L = L;
     p->tile = tile;
     // (extra_for: LDS a format needs as a function of the tile and the lines per group, e.g. per-item arrays)
@@ -642,10 +637,7 @@ inline int plan_launch(K kernel, uint64_t n, uint64_t avg_len, uint32_t extra_ld
         return -1;
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kWave, p->lds) != hipSuccess || per_cu < 1) per_cu = 1;
-    if (const char* e = getenv("FG_WAVES_PER_CU")) {
-        int cap = atoi(e);
-        if (cap > 0 && per_cu > cap) per_cu = cap;
-    }
+    if (lo.waves_per_cu > 0 && per_cu > (int)lo.waves_per_cu) per_cu = (int)lo.waves_per_cu;
     uint64_t blocks = (uint64_t)per_cu * (uint64_t)cus;
     if (blocks > p->groups) blocks = p->groups;
     if (stash_blocks && blocks > stash_blocks) blocks = stash_blocks;
@@ -653,12 +645,21 @@ inline int plan_launch(K kernel, uint64_t n, uint64_t avg_len, uint32_t extra_ld
     return 0;
 }
 
-// FG_PROF=1: run the measurement build of a kernel synchronously and print the per-phase split.
+// The measurement build (-DFG_PROF_BUILD, `FG_BUILD_PROF=1 python -m flowgger_amd.build` -> libfg_hip_prof.so) also compiles the
+// PROF = true instantiation of each kernel; FG_PROF=1 in the environment then runs it synchronously and prints the per-phase split
+// (FG_ABLATE: ablation flags).  The product library has neither the instantiations nor any read of the environment.
+#if defined(FG_PROF_BUILD)
+inline bool prof_requested() { return getenv("FG_PROF") != nullptr; }
+#else
+constexpr bool prof_requested() { return false; }
+#endif
 struct ProfRun {
     unsigned long long* d = nullptr;
     unsigned long long h[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // [6..15]: format-specific phase clocks (GroupCtx::phase)
     bool begin(hipStream_t stream) {
+#if defined(FG_PROF_BUILD)
         if (const char* e = getenv("FG_ABLATE")) h[5] = (unsigned long long)atoi(e);
+#endif
         if (hipMalloc((void**)&d, sizeof(h)) != hipSuccess) return false;
         (void)hipMemcpyAsync(d, h, sizeof(h), hipMemcpyHostToDevice, stream);
         return true;

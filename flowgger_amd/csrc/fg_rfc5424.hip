@@ -858,13 +858,14 @@ extern "C" uint64_t fg_stash_bytes(uint32_t blocks) {
 // bytes (or NULL: SD lines are then parsed twice); the persistent grid is capped at stash_blocks.
 extern "C" int fg_launch_rfc5424(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
                                  uint64_t avg_len, hipStream_t stream, uint64_t* stash, uint32_t stash_blocks, uint32_t strip,
-                              const uint8_t* line_bad) {
+                                 const uint8_t* line_bad, const fg_launch_opts* lo) {
     if (n == 0) return 0;
     fg::LaunchPlan p;
-    if (fg::plan_launch(fg::k_rfc5424<fg::kWindowKiB, false>, n, avg_len, 0u, 57344u, stash ? stash_blocks : 0u, &p)) return -1;
+    if (fg::plan_launch(fg::k_rfc5424<fg::kWindowKiB, false>, n, avg_len, 0u, 57344u, stash ? stash_blocks : 0u, &p, *lo)) return -1;
     if (stash_blocks == 0) stash = nullptr;
     dim3 grid(p.blocks), block(fg::kWave);
-    if (getenv("FG_PROF")) {
+#if defined(FG_PROF_BUILD)
+    if (fg::prof_requested()) {
         fg::ProfRun pr;
         if (!pr.begin(stream)) return -1;
         hipLaunchKernelGGL((fg::k_rfc5424<fg::kWindowKiB, true>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile,
@@ -872,6 +873,7 @@ extern "C" int fg_launch_rfc5424(const uint8_t* d_bytes, const uint64_t* d_offse
         pr.end(stream, "rfc5424", p);
         return (int)hipGetLastError();
     }
+#endif
     hipLaunchKernelGGL((fg::k_rfc5424<fg::kWindowKiB, false>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L,
                        p.groups, (unsigned long long*)nullptr, stash, fg::FrameArgs{strip, line_bad});
     return (int)hipGetLastError();

@@ -189,7 +189,16 @@ FG_WV Slots wave_alloc(unsigned long long* ent_used, uint64_t ent_cap, uint32_t*
         const unsigned long long room = b < ent_cap ? ent_cap - b : 0ull;
         const uint32_t usable = room < grab ? (uint32_t)room : grab;
         if (usable < rest) {
-            r.overflow = true;  // (the state is left as it was: the lines of this request report FG_ST_OVERFLOW)
+            // The table is full: the lines at and behind `cut` report FG_ST_OVERFLOW.  The lines before it KEEP their slots
+            // [base0, base0 + cut), so that part of the chunk must be committed -- otherwise the next request that fits what is
+            // left gets the same base0 and overwrites entries of rows that are not flagged (fg_hip.h: "tables are valid except
+            // status == FG_ST_OVERFLOW rows").
+            r.overflow = true;
+            if (lane() == 0) {
+                st[0] = next;
+                st[1] = left;
+            }
+            sync();
             return r;
         }
         r.base1 = (uint32_t)b;
@@ -204,10 +213,13 @@ FG_WV Slots wave_alloc(unsigned long long* ent_used, uint64_t ent_cap, uint32_t*
     return r;
 }
 FG_WVH uint32_t alloc_chunk_for(uint64_t ent_cap, uint32_t waves) {
-    // a wave strands what is left of its LAST chunk: keep the worst case (every wave, a whole chunk) below 1/64 of the table
+    // a wave strands what is left of its LAST chunk: keep the worst case (every wave, a whole chunk) below 1/64 of the table.
+    // A table too small for chunks of 256 slots gets EXACT reservations (chunk 0: every request takes what it needs from the
+    // global word and nothing is stranded) -- a caller that sized the table tightly must not see FG_ST_OVERFLOW because of
+    // slots parked in 64-slot chunks, and a table that small is not where the counter is contended.
     uint64_t c = ent_cap / (64ull * (waves ? waves : 1u));
     if (c > 1024u) c = 1024u;
-    if (c < 64u) c = 64u;
+    if (c < 256u) c = 0u;
     return (uint32_t)c;
 }
 

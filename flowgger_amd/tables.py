@@ -108,12 +108,16 @@ class DeviceTables:
         off, size = self.offs[L.TABLE_FIELDS.index(name)]
         return self.buf[off:off + size]
 
-    def to_host(self) -> HostTables:
+    def to_host(self, allow_overflow: bool = False) -> HostTables:
+        """Copy to the host.  allow_overflow: a table whose entries did not all fit (rows with status FG_ST_OVERFLOW) is
+        returned as it is -- every other row is valid (include/fg_hip.h) -- instead of raising."""
         import torch
 
         used = int(self.column("ent_used").view(torch.int64)[0].item())
         if used > self.ent_cap:
-            raise L.FgError(L.FG_ERR_ENT_OVERFLOW, f"entry table overflow ({used} > {self.ent_cap})")
+            if not allow_overflow:
+                raise L.FgError(L.FG_ERR_ENT_OVERFLOW, f"entry table overflow ({used} > {self.ent_cap})")
+            used = self.ent_cap
         arrays = {}
         for name, (off, size) in zip(L.TABLE_FIELDS, self.offs):
             dt = np.dtype(_DT[name])

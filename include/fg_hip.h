@@ -76,7 +76,8 @@ enum {
     FG_F_MSG_JOIN = 64      /* RFC3164 standard form: Record.msg = the msg span's whitespace-separated tokens joined
                                with single spaces (`_log_tokens[1..].join(" ")`, rfc3164_decoder.rs:70) */
 };
-#define FG_ST_OVERFLOW 0xFE /* status: the line's entries did not fit in ent_cap (re-run with more) */
+#define FG_ST_OVERFLOW 0xFE /* status: the line's entries did not get slots: the table (ent_cap) is used up, counting the slots
+                               parked in other waves' reservations (see ent_used).  Re-run with more; all other rows are valid */
 #define FG_ST_BAD_UTF8 0xFD /* status: the frame is not valid UTF-8; the reference never decodes it, it prints
                                "Invalid UTF-8 input" and drops it (line_splitter.rs:22-25, nul_splitter.rs:34-40) */
 
@@ -118,7 +119,15 @@ typedef struct fg_tables {
     uint64_t* ent_val;   /* [ent_cap] */
     uint8_t*  ent_type;  /* [ent_cap] */
     uint8_t*  ent_flags; /* [ent_cap] */
-    uint64_t* ent_used;  /* [1] entries allocated by the call (may exceed ent_cap on overflow) */
+    uint64_t* ent_used;  /* [1] entry slots RESERVED by the call (may exceed ent_cap on overflow).  Waves reserve slots in
+                            chunks (one atomic per chunk instead of one per line group), so this is >= the sum of ent_count and
+                            the range [0, ent_used) contains slots no row refers to (uninitialised holes): always walk the
+                            entries through ent_first / ent_count.  Sizing ent_cap: a table with fewer than 256 slots per
+                            resident wave x 64 (ent_cap < ~34 M on an MI355X) gets exact reservations -- no slack needed
+                            beyond the entries themselves; above that, up to ent_cap / 64 slots plus one line's entries per
+                            1024-slot chunk can be stranded: size from the input bytes (the host-buffer entry points use
+                            nbytes / 16 for RFC5424, nbytes / 8 otherwise) and retry with ent_used + ent_used / 8 on
+                            FG_ERR_ENT_OVERFLOW, as they do. */
 } fg_tables;
 
 /* Fixed table bytes written per line (meta 4 + ts 8 + 6 spans 48 + ent_first/count 8). */
@@ -153,7 +162,9 @@ typedef struct fg_tz_table {
     const int64_t* utc_start;
     const int32_t* utc_offset;
 } fg_tz_table;
-#define FG_YEAR_NOW 0 /* current_year: follow the wall clock (UTC year re-read at every FG_RFC3164 decode call) */
+/* current_year: follow the wall clock (UTC year re-read at every FG_RFC3164 decode call).  Outside every representable year
+ * (INT32_MIN), so that year 0 -- which `time` accepts -- can be configured explicitly. */
+#define FG_YEAR_NOW (-2147483647 - 1)
 typedef struct fg_rfc3164_cfg {
     int32_t current_year;
     const fg_tz_table* tz;
@@ -164,6 +175,23 @@ typedef struct fg_ctx fg_ctx;
 
 int fg_abi_version(void);
 
+/* Launch-geometry overrides of a ctx: the parity sweeps over the kernel variants (tests/) and tuning (tools/) set them through
+ * this call.  The library reads NO environment variables (a stray FG_* in a daemon's environment must not change how it runs);
+ * a zero field = the library's own choice; results are identical for every setting.  Clones made afterwards inherit them.
+ * opts == NULL restores the defaults. */
+typedef struct fg_launch_opts {
+    uint32_t lines_per_group; /* lines a wave takes per group, 1..64 */
+    uint32_t tile_cap;        /* LDS tile bytes (rounded up to 1 KiB) */
+    uint32_t waves_per_cu;    /* upper bound of resident waves per CU */
+    uint32_t gelf_lds_budget; /* GELF: LDS bytes per wave the lines per group are fitted to */
+    uint32_t gelf_window_kib; /* GELF: register prefetch window in KiB (2..6) */
+    uint32_t flags;           /* FG_LO_* */
+} fg_launch_opts;
+enum {
+    FG_LO_GELF_GENERIC = 1,        /* GELF: the run-time-geometry kernel even where the constant-geometry instantiation applies */
+    FG_LO_TRANSCODE_ONE_PIECE = 2  /* fg_transcode_batch: never slice a large batch over two streams */
+};
+
 /* Create a decoder context on HIP device `device` (replaces XDecoder::new(&Config),
  * flowgger/mod.rs:413-422).  cfg may be NULL (RFC5424 / GELF take no configuration).
  * Fails with FG_ERR_NO_DEVICE when no gfx950 GPU is usable -- there is no CPU fallback.
@@ -173,6 +201,7 @@ int fg_create(int device, const fg_cfg* cfg, fg_ctx** out);
 int fg_clone(const fg_ctx* ctx, fg_ctx** out);
 void fg_destroy(fg_ctx* ctx);
 int fg_last_hip_error(const fg_ctx* ctx);
+int fg_set_launch_opts(fg_ctx* ctx, const fg_launch_opts* opts);
 /* Configure the RFC3164 decoder of this ctx (copied; clones made afterwards inherit it).  Required before the first
  * FG_RFC3164 decode (FG_ERR_ARG otherwise). */
 int fg_set_rfc3164(fg_ctx* ctx, const fg_rfc3164_cfg* cfg);

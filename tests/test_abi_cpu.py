@@ -37,6 +37,26 @@ def test_product_never_touches_the_oracle():
             assert "fg_oracle" not in txt and "libfg_oracle" not in txt and "oracle_binding" not in txt, p
 
 
+def test_product_library_reads_no_environment_variables():
+    """tuning knobs out of the product launch path.  libfg_hip.so neither imports getenv nor carries the names of the
+    old FG_* knobs; launch geometry is set per ctx (fg_set_launch_opts), the phase-clock kernels exist only in the measurement
+    build (-DFG_PROF_BUILD -> libfg_hip_prof.so)."""
+    import subprocess
+
+    L.lib()
+    blob = L.LIB_PATH.read_bytes()
+    for knob in (b"FG_PROF", b"FG_PLAN", b"FG_ABLATE", b"FG_TILE_CAP", b"FG_LINES_PER_GROUP", b"FG_WAVES_PER_CU", b"FG_GELF_",
+                 b"FG_TRANSCODE_ONE_PIECE"):
+        assert knob not in blob, knob
+    syms = subprocess.run(["nm", "-D", "--undefined-only", str(L.LIB_PATH)], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in syms
+    for src in (ROOT / "flowgger_amd" / "csrc").glob("*"):
+        if src.suffix in (".hip", ".hpp", ".cpp"):
+            txt = src.read_text(errors="replace")
+            outside = re.sub(r"#if defined\(FG_PROF_BUILD\).*?#endif", "", txt, flags=re.S)
+            assert "getenv" not in outside, f"{src.name}: getenv outside an FG_PROF_BUILD block"
+
+
 def test_no_gpu_means_loud_failure():
     import torch
 

@@ -137,17 +137,17 @@ def test_long_tail_lengths_match_oracle(rfc, oracle):
 
 
 @pytest.mark.parametrize("knobs", [
-    {"FG_LINES_PER_GROUP": "64"}, {"FG_LINES_PER_GROUP": "32"}, {"FG_LINES_PER_GROUP": "8"},
-    {"FG_LINES_PER_GROUP": "1"}, {"FG_LINES_PER_GROUP": "48"}, {"FG_WAVES_PER_CU": "1"}, {"FG_TILE_CAP": "4096"},
-    {"FG_TILE_CAP": "40960", "FG_LINES_PER_GROUP": "64"},
-], ids=lambda k: ",".join(f"{a[3:]}={b}" for a, b in k.items()))
-def test_kernel_variants_are_bit_identical(rfc, oracle, knobs, monkeypatch):
+    {"lines_per_group": 64}, {"lines_per_group": 32}, {"lines_per_group": 8},
+    {"lines_per_group": 1}, {"lines_per_group": 48}, {"waves_per_cu": 1}, {"tile_cap": 4096},
+    {"tile_cap": 40960, "lines_per_group": 64},
+], ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
+def test_kernel_variants_are_bit_identical(oracle, knobs):
     """Every launch shape of the RFC5424 kernel (64..1 lines
     per group, one wave per CU, tiles smaller than a group so that lines fall back to the global
     reader, tiles larger than the register window so that the tail loop runs) gives the oracle's
-    bytes on all three corpora shapes."""
-    for k, v in knobs.items():
-        monkeypatch.setenv(k, v)
+    bytes on all three corpora shapes.  The shapes are set through fg_set_launch_opts: the library reads no environment."""
+    rfc = RFC5424Decoder()
+    rfc.set_launch_opts(**knobs)
     lines = (synth.rfc5424_lines(20_000, cfg=2) + synth.rfc5424_lines(6_000, cfg=4, sd=True) +
              synth.rfc5424_lines(3_000, cfg=5, sd=True, long_tail=True))
     data, offsets = synth.pack(lines)
@@ -167,6 +167,42 @@ def test_entry_table_overflow_is_reported(rfc):
     assert used > 100
     meta = tables.column("meta").view(torch.int32).cpu().numpy()
     assert ((meta & 0xFF) == 0xFE).sum() > 0
+
+
+@pytest.mark.parametrize("fmt", [RFC5424, LTSV, GELF])
+@pytest.mark.parametrize("share", [0.15, 0.5, 0.9])
+def test_rows_that_are_not_flagged_stay_valid_when_the_entry_table_overflows(oracle, fmt, share):
+    """include/fg_hip.h: "tables are valid except status == FG_ST_OVERFLOW rows".  A wave whose request straddles the end of the
+    table keeps the slots of the lines before the cut; they must stay theirs (the partial allocation was not
+    committed, a later group of the same wave was handed the same slots)."""
+    if fmt == RFC5424:
+        dec, lines, cfg = RFC5424Decoder(), synth.rfc5424_lines(6000, cfg=4, sd=True), None
+    elif fmt == LTSV:
+        dec, lines, cfg = LTSVDecoder(synth.LTSV_CONFIG), synth.ltsv_lines(6000), synth.LTSV_CONFIG
+    else:
+        dec, lines, cfg = GelfDecoder(), synth.gelf_lines(6000), None
+    data, offsets = synth.pack(lines)
+    oblob, ooffs = oracle.decode_batch(fmt, data, offsets, cfg)
+    full, _, _ = device_path(dec, data, offsets)
+    need = int(full.to_host().a["ent_count"].sum())
+    cap = max(64, int(need * share))
+    tables, _, _ = device_path(dec, data, offsets, ent_cap=cap)
+    host = tables.to_host(allow_overflow=True)
+    st = host.status
+    over = st == 0xFE
+    assert over.any() and not over.all()
+    ok_rows = np.flatnonzero(~over)
+    first, count = host.a["ent_first"][ok_rows].astype(np.int64), host.a["ent_count"][ok_rows].astype(np.int64)
+    assert bool(((first + count <= cap) | (count == 0)).all()), "a row that is not flagged owns slots beyond ent_cap"
+    # slices of unflagged rows are disjoint
+    owner = np.zeros(cap + 1, np.int32)
+    np.add.at(owner, first[count > 0], 1)
+    np.add.at(owner, (first + count)[count > 0], -1)
+    assert int(np.cumsum(owner).max()) <= 1, "two rows own the same entry slots"
+    blob, offs = host.serialize(fmt, data, offsets, cfg=dec._cfg)
+    bad = [int(i) for i in ok_rows
+           if blob[int(offs[i]):int(offs[i + 1])].tobytes() != oblob[int(ooffs[i]):int(ooffs[i + 1])].tobytes()]
+    assert not bad, f"{len(bad)} unflagged rows differ from the oracle, first: line {bad[0]} {lines[bad[0]]!r}"
 
 
 def test_fuzz_mutations_match_oracle(rfc, oracle):

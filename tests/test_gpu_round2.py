@@ -90,9 +90,9 @@ def test_bench_launches_its_own_ranks():
 
 
 @pytest.mark.parametrize("src,enc,merger", [("rfc5424", "gelf", "line"), ("sd", "rfc5424", "syslen"), ("gelf", "gelf", "nul")])
-def test_transcode_large_batch_is_sliced_over_two_streams(oracle, monkeypatch, src, enc, merger):
+def test_transcode_large_batch_is_sliced_over_two_streams(oracle, src, enc, merger):
     """fg_transcode_batch above 64 MiB: the batch goes through upload -> decode -> encode -> download as ~32 MiB slices on two
-    streams.  Same bytes as the one-piece path (FG_TRANSCODE_ONE_PIECE) and as the oracle's decode -> encode -> merger."""
+    streams.  Same bytes as the one-piece path (fg_launch_opts: FG_LO_TRANSCODE_ONE_PIECE) and as the oracle's decode -> encode -> merger."""
     import oracle_binding as OB
     from flowgger_amd import GelfEncoder, Pipeline, RFC5424Encoder
 
@@ -111,9 +111,9 @@ def test_transcode_large_batch_is_sliced_over_two_streams(oracle, monkeypatch, s
     pipe = Pipeline(dec, cls(None, merger=merger))
     sliced = pipe.run_packed(data, offsets, now_ts=now_ts)
     again = pipe.run_packed(data, offsets, now_ts=now_ts)  # buffers already at size
-    monkeypatch.setenv("FG_TRANSCODE_ONE_PIECE", "1")
+    dec.set_launch_opts(transcode_one_piece=True)
     whole = pipe.run_packed(data, offsets, now_ts=now_ts)
-    monkeypatch.delenv("FG_TRANSCODE_ONE_PIECE")
+    dec.set_launch_opts()
     for r in (sliced, again):
         assert r.n == len(lines) and r.consumed == int(offsets[-1])
         assert np.array_equal(r.out_offsets, whole.out_offsets) and np.array_equal(r.out, whole.out)

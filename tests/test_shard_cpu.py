@@ -194,3 +194,30 @@ def test_gather_and_merge_at_scale_take_milliseconds():
             assert np.array_equal(blob[int(out_offs[i]):int(out_offs[i + 1])], b[int(o[j]):int(o[j + 1])])
     print(f"gather 1M rows: {dt_gather * 1e3:.1f} ms; ordered merge 1M records ({len(blob) / 1e6:.0f} MB): {dt_merge * 1e3:.1f} ms")
     assert dt_gather < 2.0 and dt_merge < 5.0
+
+
+def test_gather_and_merge_refuse_partially_filled_tables(corpus):
+    """a C / Rust caller that leaves a column of `out` (or a blob pointer) NULL gets FG_ERR_ARG, not a null dereference."""
+    import ctypes as C
+
+    data, offsets = corpus
+    part = fake_decode(data, offsets)
+    assert part.ent_used > 0
+    arr = shard._part_array([part])
+    lib = L.lib()
+    ix = np.arange(part.n, dtype=np.uint64)
+    ptrs = (C.c_void_p * 1)(ix.ctypes.data)
+    for hole in ("hostname", "full_msg", "ent_name", "ent_val", "ent_type", "ent_flags", "ent_count", "ent_used"):
+        out = shard._alloc_tables(part.n, part.ent_used)
+        setattr(out.struct, hole, None)
+        assert lib.fg_gather_tables(arr, 1, C.byref(out.struct)) == L.FG_ERR_ARG, hole
+        assert lib.fg_merge_tables(arr, 1, ptrs, C.byref(out.struct), None) == L.FG_ERR_ARG, hole
+    # fg_ordered_merge: records without a blob
+    m = np.array([2], np.uint64)
+    offs = np.array([0, 3, 5], np.uint64)
+    idx = np.array([0, 1], np.uint64)
+    out_offs = np.zeros(3, np.uint64)
+    vp = C.c_void_p
+    rc = lib.fg_ordered_merge(1, m.ctypes.data, (vp * 1)(idx.ctypes.data), (vp * 1)(None), (vp * 1)(offs.ctypes.data), None, 0,
+                              out_offs.ctypes.data)
+    assert rc == L.FG_ERR_ARG

@@ -54,6 +54,36 @@ def test_corpus(wave, oracle, geom):
     assert handled.mean() > 0.985, handled.mean()
 
 
+@pytest.mark.parametrize("ent_cap", [96, 700, 2500])
+def test_rows_that_are_not_flagged_stay_valid_when_the_entry_table_overflows(wave, oracle, ent_cap):
+    """wv::wave_alloc's overflow branch (ADVICE r2): the lines before the cut keep their slots, so that part of the chunk must be
+    committed -- a later tile of the same wave must not be handed the same slots.  (The emulation reserves chunks of 96.)"""
+    base = synth.gelf_lines(800, invalid_frac=0)
+    rng = np.random.default_rng(ent_cap)
+    lines = []
+    for i, ln in enumerate(base):  # (the corpus has eight extras on every line: chunks would be used up exactly)
+        k = int(rng.integers(0, 6))
+        extras = ",".join(f'"_x{j}":{i * 7 + j}' for j in range(k))
+        lines.append(ln if k == 0 else (b'{"host":"h%d",%s}' % (i, extras.encode())))
+    data, offsets = synth.pack(lines)
+    pad = np.concatenate([data, np.zeros(64, np.uint8)])
+    tab, handled = wave.gelf(pad, offsets, lines_per_group=8, tile_cap=4096, ent_cap=ent_cap)
+    oblob, ooffs = oracle.decode_batch(GELF, data, offsets)
+    st = tab.status
+    over = st == 0xFE
+    assert over.any() and not over.all()
+    blob, offs = tab.serialize(GELF, pad, offsets)
+    seen = np.zeros(ent_cap + 1, np.int32)
+    for i in np.nonzero(handled & ~over)[0]:
+        f, c = int(tab.a["ent_first"][i]), int(tab.a["ent_count"][i])
+        assert c == 0 or f + c <= ent_cap, f"line {i} owns slots beyond ent_cap"
+        seen[f:f + c] += 1
+        got = blob[int(offs[i]):int(offs[i + 1])].tobytes()
+        want = oblob[int(ooffs[i]):int(ooffs[i + 1])].tobytes()
+        assert got == want, f"line {i} is not flagged FG_ST_OVERFLOW but differs from the oracle"
+    assert seen.max(initial=0) <= 1, "two unflagged lines own the same entry slots"
+
+
 def test_semantics(wave, oracle):
     many = "{" + ",".join(f'"k{(i * 7919) % 100:03d}":{i}' for i in range(100)) + ',"host":"h"}'
     sixty = "{" + ",".join(f'"k{(i * 31) % 60:02d}":{i}' for i in range(60)) + ',"host":"h"}'

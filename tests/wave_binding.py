@@ -42,13 +42,13 @@ class WaveHost:
         self.lib = C.CDLL(str(build()))
         self.lib.fgw_last_error.restype = C.c_char_p
 
-    def gelf(self, data: np.ndarray, offsets: np.ndarray, lines_per_group=32, tile_cap=12288, strip=0):
+    def gelf(self, data: np.ndarray, offsets: np.ndarray, lines_per_group=32, tile_cap=12288, strip=0, ent_cap=None):
         """-> (HostTables, handled uint8[n]).  strip = FG_FRAME_LINE (1) / FG_FRAME_NUL (2): `offsets` delimit frames of a raw stream
         including their terminators."""
         data = np.ascontiguousarray(data, np.uint8)
         offsets = np.ascontiguousarray(offsets, np.uint64)
         n = len(offsets) - 1
-        t = empty_tables(n, int(data.size) // 8 + 1024)
+        t = empty_tables(n, int(data.size) // 8 + 1024 if ent_cap is None else ent_cap)
         handled = np.zeros(max(n, 1), np.uint8)
         rc = self.lib.fgw_gelf_decode_framed(C.c_void_p(data.ctypes.data), C.c_uint64(data.size), C.c_void_p(offsets.ctypes.data),
                                              C.c_uint64(n), C.byref(t.struct), C.c_uint32(lines_per_group), C.c_uint32(tile_cap),
