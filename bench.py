@@ -11,7 +11,14 @@ One JSON line on stdout (rank 0).  `roofline.achieved` = algorithmic bytes per l
 line bytes + 4 B offset read, 64 B table row written, + 20 B per SD entry) / mean kernel time
 measured with HIP events on the launch stream.  `cpu_baseline` = the C++ oracle (a restatement of
 the reference's CPU decoders, "port") timed on this box's host cores on a bounded sample, one
-thread and all cores.  `e2e` = the PCIe-inclusive host-buffer entry points (never `value`).
+thread and all cores (persistent threads: start-up is outside the timed region).
+`e2e` = the PCIe-inclusive host-buffer entry points (never `value`), run on EVERY rank at the same
+time from pinned buffers allocated on the GPU's NUMA node, with the measured link peak
+(fg_measure_link) beside them: `e2e.aggregate` is the whole job's rate -- the regime the
+north_star's "1 B lines/s on 8 GPUs" lives in.
+`--workload cfg5mix` = BASELINE configs[4]: a 50/50 tagged RFC5424 + LTSV long-tail stream decoded
+as two sub-batches and put back in arrival order by the host gather (fg_merge_tables; at N > 1 also
+fg_gather_tables over the ranks' tables): `gather_ms`.
 
 `python bench.py --gpus N` launches its own N ranks (torch.distributed.run, one per GPU, RCCL for the
 barrier / max-over-ranks) when no launcher has set WORLD_SIZE; under torchrun it uses the env as given.
@@ -40,9 +47,10 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--tile-lines", type=int, default=1_000_000)
-    ap.add_argument("--reps", type=int, default=100, help="tile replicas resident per GPU")
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5", "ltsv", "ltsv5", "frame", "cfg1", "rfc3164"],
+    ap.add_argument("--tile-lines", type=int, default=None, help="lines of the generated tile (default 1 M; cfg5mix 400 K)")
+    ap.add_argument("--reps", type=int, default=None, help="tile replicas resident per GPU (default 100; cfg5mix 10)")
+    ap.add_argument("--workload", default="cfg2",
+                    choices=["cfg2", "cfg3", "cfg4", "cfg5", "cfg5mix", "ltsv", "ltsv5", "frame", "cfg1", "rfc3164"],
                     help="cfg2 = the BASELINE metric's configuration (default); the others time the remaining "
                          "kernels on their parity-test corpora (not bench lines, see DESIGN.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -53,7 +61,13 @@ def parse_args():
     ap.add_argument("--line-len", type=int, nargs=2, default=None, metavar=("LO", "HI"),
                     help="cfg2 only: uniform line-length range instead of 192..320 (tuning experiments)")
     ap.add_argument("--invalid-frac", type=float, default=0.01, help="share of invalid lines in the tile (SURVEY 8d: 1 %%)")
-    return ap.parse_args()
+    ap.add_argument("--launch-opts", default="", help="fg_set_launch_opts overrides, e.g. lines_per_group=32,waves_per_cu=6 (tuning)")
+    a = ap.parse_args()
+    if a.tile_lines is None:
+        a.tile_lines = 400_000 if a.workload == "cfg5mix" else 1_000_000
+    if a.reps is None:
+        a.reps = 10 if a.workload == "cfg5mix" else 100
+    return a
 
 
 WORKLOADS = {
@@ -61,6 +75,8 @@ WORKLOADS = {
     "cfg2": (0, "BASELINE configs[1]: RFC5424 no structured data"),
     "cfg4": (0, "BASELINE configs[3] shape: RFC5424 with structured data (~12 pairs)"),
     "cfg5": (0, "BASELINE configs[4] shape: RFC5424, log-uniform 64 B..8 KiB lines with structured data"),
+    "cfg5mix": (0, "BASELINE configs[4]: 50/50 tagged RFC5424 + LTSV stream, log-uniform 64 B..8 KiB lines, two sub-batches, host-side "
+                   "ordered gather by arrival index"),
     "cfg3": (2, "BASELINE configs[2]: GELF/JSON, 8 flat extra fields"),
     "ltsv": (1, "LTSV, typed schema (the LTSV half of BASELINE configs[4])"),
     "ltsv5": (1, "BASELINE configs[4] shape, LTSV half: log-uniform 64 B..8 KiB lines"),
@@ -68,6 +84,7 @@ WORKLOADS = {
     "rfc3164": (3, "RFC3164 (BSD syslog) decoder, both forms, 15 % with IANA zone names (SURVEY 8f-3)"),
     "cfg1": (0, "BASELINE configs[0] pipeline on the GPU: RFC5424 decode -> GELF encoder -> line merger (SURVEY 8f-2/8f-4), cfg2 corpus"),
 }
+KERNELS = ("fg::k_rfc5424", "fg::k_ltsv", "fg::k_gelf", "fg::k_rfc3164")
 
 
 def self_launch(args) -> int:
@@ -91,92 +108,281 @@ def source_hash(workload=None) -> str:
     return h(workload)
 
 
-def e2e_legs(dec, fmt, data, offsets, n_tile, tile_bytes, want_transcode):
-    """PCIe-inclusive rates of the host-buffer entry points on a bounded sample (4 tiles from pinned memory):
-    fg_decode_batch = H2D + kernels + D2H of the tables; fg_transcode_batch = H2D + decode + GELF encode + line merger +
-    D2H of the encoded stream.  Reported beside `value`, never as `value`."""
+def bind_to_gpu_numa_node(local: int):
+    """One process per GPU: run this rank (and first-touch its pinned staging buffers) on the CPUs of the NUMA node the GPU hangs
+    off, so that H2D / D2H do not cross the socket interconnect.  Best effort; returns what was done for the JSON line."""
+    try:
+        import torch
+
+        p = torch.cuda.get_device_properties(local)
+        bdf = f"{getattr(p, 'pci_domain_id', 0):04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        node = int(Path(f"/sys/bus/pci/devices/{bdf}/numa_node").read_text())
+        if node < 0:
+            return {"pci": bdf, "numa_node": None}
+        cpus = set()
+        for part in Path(f"/sys/devices/system/node/node{node}/cpulist").read_text().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+        return {"pci": bdf, "numa_node": node, "cpus": len(cpus)}
+    except Exception as e:  # noqa: BLE001
+        return {"numa_node": None, "note": repr(e)[:80]}
+
+
+class Dist:
+    """torch.distributed over RCCL when a launcher set WORLD_SIZE (also for one rank: the same code runs at N = 1 and N = 8)."""
+
+    def __init__(self, dev):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist, self.dev = torch, dist, dev
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.on = "WORLD_SIZE" in os.environ
+        if self.on:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            dist.init_process_group("nccl", device_id=dev)
+
+    def barrier(self):
+        if self.on:
+            self.dist.barrier()
+        self.torch.cuda.synchronize(self.dev)
+
+    def max(self, v: float) -> float:
+        if not self.on:
+            return v
+        t = self.torch.tensor([v], device=self.dev, dtype=self.torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def all(self, vals):
+        """every rank's list of floats -> list (by rank) of lists"""
+        if not self.on:
+            return [list(vals)]
+        mine = self.torch.tensor(list(vals), device=self.dev, dtype=self.torch.float64)
+        g = [self.torch.zeros_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(g, mine)
+        return [[float(x) for x in t.tolist()] for t in g]
+
+    def close(self):
+        if self.on:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def pinned(nbytes, dt):
+    import ctypes as C
+
+    from flowgger_amd import _lib as L
+
+    p = C.c_void_p()
+    L.check(L.lib().fg_alloc_pinned(nbytes, C.byref(p)), "fg_alloc_pinned")
+    return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (nbytes,)).view(dt), p
+
+
+def e2e_legs(D: Dist, dec, fmt, data, offsets, n_tile, tile_bytes, want_transcode, want_stream):
+    """PCIe-inclusive rates of the host-buffer entry points on a bounded sample (4 tiles from pinned memory), on EVERY rank at
+    the same time (barrier, then ITERS calls per rank, wall clock around them; aggregate = all ranks' lines / the slowest rank):
+      fg_decode_batch        H2D of bytes + offsets, kernels, D2H of the tables
+      fg_frame_decode_batch  H2D of the raw "\\n" stream ONLY, framing + UTF-8 + decode on the GPU, D2H of tables + frame offsets
+      fg_transcode_batch     H2D, decode, GELF encode, line merger, D2H of the encoded stream
+    with the link's measured peak (fg_measure_link) beside them.  Reported beside `value`, never as `value`."""
     import ctypes as C
 
     from flowgger_amd import GelfEncoder
     from flowgger_amd import _lib as L
 
-    reps = 4
+    reps, iters = 4, 3
     n = n_tile * reps
-
-    def pinned(nbytes, dt):
-        p = C.c_void_p()
-        L.check(L.lib().fg_alloc_pinned(nbytes, C.byref(p)), "fg_alloc_pinned")
-        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (nbytes,)).view(dt), p
-
+    lib = L.lib()
     pdata, hd = pinned(tile_bytes * reps + 32, np.uint8)
     poffs, ho = pinned((n + 1) * 8, np.uint64)
     for r in range(reps):
         pdata[r * tile_bytes:(r + 1) * tile_bytes] = data[:tile_bytes]
         poffs[r * n_tile:(r + 1) * n_tile] = offsets[:-1] + np.uint64(r * tile_bytes)
     poffs[n] = tile_bytes * reps
-    out = {"sample": f"{n} lines ({reps} tiles) from pinned host memory, best of 3"}
+    out = {"sample": f"{n} lines ({reps} tiles) per rank from pinned host memory, {iters} calls per rank, all {D.world} rank(s) at once"}
+    frees = [hd, ho]
+
+    def leg(name, call, in_bytes, what, extra=None):
+        call()  # warm-up: staging buffers at size
+        D.barrier()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            call()
+        dt = time.perf_counter() - t0
+        per_rank = [x[0] for x in D.all([dt])]
+        slowest = max(per_rank)
+        ent = {"lines_per_s": n * iters / dt, "GBps_in": in_bytes * iters / dt / 1e9, "ms": dt / iters * 1e3, "what": what,
+               "aggregate": {"lines_per_s": n * iters * D.world / slowest, "GBps_in": in_bytes * iters * D.world / slowest / 1e9,
+                             "ranks": D.world, "per_rank_lines_per_s": [n * iters / t for t in per_rank]}}
+        if extra:
+            ent.update(extra())
+        out[name] = ent
+
     try:
-        best = 1e9
-        for _ in range(4):
-            st = L.fg_tables()
-            t0 = time.perf_counter()
-            L.check(L.lib().fg_decode_batch(dec._ctx, fmt, pdata.ctypes.data, tile_bytes * reps, poffs.ctypes.data, n, C.byref(st)),
-                    "fg_decode_batch")
-            best = min(best, time.perf_counter() - t0)
-        out["decode_batch"] = {"lines_per_s": n / best, "GBps_in": tile_bytes * reps / best / 1e9, "ms": best * 1e3,
-                               "what": "fg_decode_batch: H2D + kernels + D2H of the tables"}
+        gb = (C.c_double * 3)()
+        L.check(lib.fg_measure_link(dec._ctx, 1 << 30, gb), "fg_measure_link")
+        link = [float(gb[0]), float(gb[1]), float(gb[2])]
+        allr = D.all(link)
+        out["link_peak"] = {"h2d_GBps": link[0], "d2h_GBps": link[1], "bidir_GBps": link[2],
+                            "what": "fg_measure_link: hipMemcpyAsync of a pinned 1 GiB buffer, best of 3 (one rank at a time is NOT "
+                                    "enforced: every rank measures at once, as the legs below run)",
+                            "per_rank_h2d_GBps": [r[0] for r in allr], "per_rank_d2h_GBps": [r[1] for r in allr]}
+        st = L.fg_tables()
+        leg("decode_batch",
+            lambda: L.check(lib.fg_decode_batch(dec._ctx, fmt, pdata.ctypes.data, tile_bytes * reps, poffs.ctypes.data, n, C.byref(st)),
+                            "fg_decode_batch"),
+            tile_bytes * reps + 8 * (n + 1), "fg_decode_batch: H2D of bytes + offsets, kernels, D2H of the tables")
+        out["decode_batch"]["frac_of_link_h2d"] = out["decode_batch"]["GBps_in"] / link[0] if link[0] else None
+        if want_stream and not bool((data[:tile_bytes] == 0x0A).any()):
+            # the same lines as ONE raw newline-terminated stream: what LineSplitter reads off the socket
+            ln = np.diff(offsets.astype(np.int64))
+            stream_bytes = tile_bytes + n_tile
+            ps, hs = pinned(stream_bytes * reps + 32, np.uint8)
+            frees.append(hs)
+            one = np.empty(stream_bytes, np.uint8)
+            dst = (offsets[:-1].astype(np.int64) + np.arange(n_tile))
+            one[:] = 0x0A
+            # (scatter the tile's lines into their slots: each line is followed by one "\n")
+            idx = np.repeat(dst - offsets[:-1].astype(np.int64), ln) + np.arange(tile_bytes)
+            one[idx] = data[:tile_bytes]
+            for r in range(reps):
+                ps[r * stream_bytes:(r + 1) * stream_bytes] = one
+            st2, po, nf, cons = L.fg_tables(), C.c_void_p(), C.c_uint64(), C.c_uint64()
+
+            def call_stream():
+                L.check(lib.fg_frame_decode_batch(dec._ctx, fmt, L.FG_FRAME_LINE, ps.ctypes.data, stream_bytes * reps, 1, C.byref(st2),
+                                                  C.byref(po), C.byref(nf), C.byref(cons)), "fg_frame_decode_batch")
+                assert nf.value == n, (nf.value, n)
+
+            leg("frame_decode_batch", call_stream, stream_bytes * reps,
+                "fg_frame_decode_batch: H2D of the raw stream only, framing + UTF-8 + decode on the GPU, D2H of tables + frame offsets")
+            out["frame_decode_batch"]["frac_of_link_h2d"] = out["frame_decode_batch"]["GBps_in"] / link[0] if link[0] else None
         if want_transcode:
             enc = GelfEncoder(None, merger="line")
             cfg, _keep = enc._cfg_struct(0.0)
-            best, res = 1e9, L.fg_transcoded()
-            for _ in range(4):
-                t0 = time.perf_counter()
-                L.check(L.lib().fg_transcode_batch(dec._ctx, fmt, L.FG_FRAME_NONE, C.byref(cfg), pdata.ctypes.data, tile_bytes * reps,
-                                                   poffs.ctypes.data, n, 1, C.byref(res)), "fg_transcode_batch")
-                best = min(best, time.perf_counter() - t0)
-            out["transcode_batch"] = {"lines_per_s": n / best, "GBps_in_plus_out": (tile_bytes * reps + int(res.out_bytes)) / best / 1e9,
-                                      "out_bytes": int(res.out_bytes), "ms": best * 1e3,
-                                      "what": "fg_transcode_batch: H2D + decode + GELF encode + line merger + D2H of the stream"}
+            res = L.fg_transcoded()
+            leg("transcode_batch",
+                lambda: L.check(lib.fg_transcode_batch(dec._ctx, fmt, L.FG_FRAME_NONE, C.byref(cfg), pdata.ctypes.data, tile_bytes * reps,
+                                                       poffs.ctypes.data, n, 1, C.byref(res)), "fg_transcode_batch"),
+                tile_bytes * reps + 8 * (n + 1),
+                "fg_transcode_batch: H2D, decode, GELF encode, line merger, D2H of the stream (D2H-bound: the GELF text is 2.4x the input)",
+                extra=lambda: {"out_bytes": int(res.out_bytes)})
+            t = out["transcode_batch"]
+            t["GBps_out"] = t["out_bytes"] / (t["ms"] * 1e-3) / 1e9
+            t["frac_of_link_d2h"] = t["GBps_out"] / link[1] if link[1] else None
     finally:
-        L.lib().fg_free_pinned(hd)
-        L.lib().fg_free_pinned(ho)
+        for h in frees:
+            lib.fg_free_pinned(h)
+    out["aggregate"] = {k: out[k]["aggregate"]["lines_per_s"] for k in ("decode_batch", "frame_decode_batch", "transcode_batch") if k in out}
     return out
 
 
-def cpu_baseline(fmt, data, offsets, n_lines, cfg=None, pipeline=False):
-    """Oracle timing leg (the ONLY place bench.py touches oracle/)."""
+def cpu_baseline(legs, pipeline=False):
+    """Oracle timing leg (the ONLY place bench.py touches oracle/).  legs = [(fmt, data, offsets, n_lines, cfg)] (one per
+    sub-batch; their times add).  Persistent threads (oracle/fg_oracle.cpp fgo_bench_timed): created and parked before the
+    clock starts, each walks the whole tile for the budget -- thread start-up and allocator warm-up are outside the figure."""
     sys.path.insert(0, str(ROOT / "tests"))
     import oracle_binding
 
     o = oracle_binding.Oracle()
-    if fmt == 3:
+    if any(fmt == 3 for fmt, *_ in legs):
         from flowgger_amd import tzdb
 
         o.set_rfc3164(2026, tzdb.default_table())
-    cores = os.cpu_count() or 1
-    ENC_GELF, MERGE_LINE = oracle_binding.ENC_GELF, oracle_binding.MERGE_LINE
-
-    def run(threads, budget_s):
-        passes, secs, n_ok = 0, 0.0, 0
-        t_end = time.time() + budget_s
-        while passes < 1 or (time.time() < t_end and passes < 256):
-            if pipeline:
-                s, n_ok, _ = o.bench_pipeline(fmt, ENC_GELF, MERGE_LINE, data, offsets, threads, cfg)
-            else:
-                s, n_ok = o.bench(fmt, data, offsets, threads, cfg)
-            secs += s
-            passes += 1
-        return n_lines * passes / secs, passes, n_ok
-
-    one, p1, n_ok = run(1, 3.0)        # a few seconds of one core
-    allc, pn, n_ok = run(cores, 4.0)   # a few seconds of wall time on every host core = tens of CPU-seconds
+    cores = len(os.sched_getaffinity(0)) or os.cpu_count() or 1
+    enc, mrg = (oracle_binding.ENC_GELF, oracle_binding.MERGE_LINE) if pipeline else (-1, 0)
+    n_ok, total = 0, 0
+    sec_one, sec_all = 0.0, 0.0  # seconds per line, summed over the sub-batches weighted by their share
+    for fmt, data, offsets, n_lines, cfg in legs:
+        _, ok = o.bench(fmt, data, offsets, 1, cfg)  # one plain pass: the Ok count the GPU must reproduce
+        n_ok += ok
+        s1, l1 = o.bench_timed(fmt, data, offsets, 1, 3.0 / len(legs), cfg, enc, mrg)
+        sa, la = o.bench_timed(fmt, data, offsets, cores, 4.0 / len(legs), cfg, enc, mrg)
+        sec_one += n_lines * s1 / l1
+        sec_all += n_lines * sa / la
+        total += n_lines
+    one, allc = total / sec_one, total / sec_all
     what = "decode + GELF encode + line merger + null sink (SURVEY 8d configuration 1)" if pipeline else "decode, owned Record per line"
     return {
         "value": allc, "unit": "lines/s", "cores": cores, "kind": "port",
-        "single_thread": {"value": one, "cores": 1, "passes": p1},
-        "sample": f"{pn} passes over the {n_lines}-line tile of the same workload on {cores} threads (and {p1} on one thread): {what}; "
-                  "C++ restatement of the Rust decoders/encoders, not the Rust build (unavailable here)",
+        "single_thread": {"value": one, "cores": 1},
+        "parallel_efficiency": allc / (one * cores),
+        "allocator": "glibc malloc, one arena per thread",
+        "sample": f"~4 s of wall time on {cores} persistent threads (each walks the whole {total}-line tile of the same workload; thread start "
+                  f"outside the timed region) and ~3 s on one thread: {what}; C++ restatement of the Rust decoders/encoders (-O3), not the "
+                  "Rust build (unavailable here)",
     }, n_ok
+
+
+def make_decoder(fmt, local, opts):
+    from flowgger_amd import GelfDecoder, LTSVDecoder, RFC3164Decoder, RFC5424Decoder, synth
+
+    if fmt == 3:
+        dec = RFC3164Decoder({"rfc3164": {"current_year": 2026}}, device=local)
+    else:
+        dec = (GelfDecoder(device=local) if fmt == 2 else LTSVDecoder(synth.LTSV_CONFIG, device=local) if fmt == 1
+               else RFC5424Decoder(device=local))
+    if opts:
+        dec.set_launch_opts(**opts)
+    return dec
+
+
+class Resident:
+    """One sub-batch resident in HBM: a tile replicated `reps` times with rebased offsets, its tables, its decoder."""
+
+    def __init__(self, fmt, lines, reps, dev, local, opts, entries=True):
+        import torch
+
+        from flowgger_amd import synth
+        from flowgger_amd.tables import DeviceTables
+
+        self.fmt, self.reps = fmt, reps
+        self.data, self.offsets = synth.pack(lines)
+        self.n_tile, self.tile_bytes = len(lines), int(self.offsets[-1])
+        self.n = self.n_tile * reps
+        tb = self.tile_bytes
+        raw = torch.from_numpy(self.data[:tb]).to(dev)
+        # (filled in place: `cat(raw.repeat(reps), pad)` holds the batch twice for a moment -- 110 GB for configs[3]'s share)
+        self.d_bytes = torch.empty(tb * reps + 32, dtype=torch.uint8, device=dev)
+        self.d_bytes[tb * reps:] = 0
+        self.d_bytes[:tb * reps].view(reps, tb).copy_(raw.unsqueeze(0).expand(reps, tb))
+        o = torch.from_numpy(self.offsets[:-1].astype(np.int64)).to(dev)
+        base = torch.arange(reps, device=dev, dtype=torch.int64).repeat_interleave(self.n_tile) * tb
+        self.d_offsets = torch.cat([o.repeat(reps) + base, torch.tensor([tb * reps], device=dev, dtype=torch.int64)])
+        del base, o, raw
+        # entry slots: one per 24 input bytes (the corpora hold one pair per 38-42 bytes; a batch that needs more reports
+        # FG_ST_OVERFLOW rows and fails the Ok-count check below) -- 0.75 x the input in HBM instead of 2.25 x
+        self.ent_cap = (tb * reps // 24 if entries else 0) + 4096 + 64 * 1024 * 256
+        self.tables = DeviceTables(self.n, self.ent_cap, dev)
+        self.dec = make_decoder(fmt, local, opts)
+
+    def decode(self, stream):
+        self.dec.decode_device(self.d_bytes, self.d_offsets, self.tables, stream)
+
+    def check_replicas(self):
+        """every replica of the tile produced the SAME rows -- all fixed columns, not only the status (ent_first is the one
+        column that legitimately differs: entry slices are placed by wave-level allocation); -> (Ok rows of one tile, entries)"""
+        import torch
+
+        t, reps, n_tile, n = self.tables, self.reps, self.n_tile, self.n
+        meta = t.column("meta").view(torch.int32).view(reps, n_tile)
+        n_ok_tile = int(((meta[0] & 0xFF) == 0).sum().item())
+        if not os.environ.get("FG_ABLATE"):
+            for col, width in (("meta", 4), ("ts", 8), ("hostname", 8), ("appname", 8), ("procid", 8), ("msgid", 8), ("msg", 8),
+                               ("full_msg", 8), ("ent_count", 4)):
+                c = t.column(col)[: n * width].view(torch.int64 if width == 8 else torch.int32).view(reps, n_tile)
+                assert bool((c == c[0:1]).all()), f"replicas disagree in column {col}: work was skipped or corrupted"
+        reserved = int(t.column("ent_used").view(torch.int64)[0].item())
+        assert reserved <= self.ent_cap, "entry table overflow"
+        # entries written (slots are reserved in per-wave chunks; `reserved` is a little more than what the lines own)
+        used = int(t.column("ent_count")[: n * 4].view(torch.int32).to(torch.int64).sum().item())
+        return n_ok_tile, used
 
 
 def main():
@@ -184,65 +390,52 @@ def main():
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
         raise SystemExit(self_launch(args))
     import torch
-    import torch.distributed as dist
 
-    from flowgger_amd import GelfDecoder, LTSVDecoder, RFC5424Decoder, synth
-    from flowgger_amd.tables import DeviceTables
+    from flowgger_amd import synth
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the decode path has no CPU fallback")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+    all_cpus = os.sched_getaffinity(0)
+    numa = bind_to_gpu_numa_node(local)
+    D = Dist(dev)
+    world, rank = D.world, D.rank
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    opts = {k: int(v) for k, v in (kv.split("=") for kv in args.launch_opts.split(",") if kv)}
 
     # ---- synthetic batch, resident in HBM -------------------------------------------------
     wl = args.workload
     fmt, wl_desc = WORKLOADS[wl]
     sd = wl in ("cfg4", "cfg5")
-    if wl == "cfg3":
-        lines = synth.gelf_lines(args.tile_lines, invalid_frac=args.invalid_frac)
-    elif wl in ("ltsv", "ltsv5"):
-        lines = synth.ltsv_lines(args.tile_lines, invalid_frac=args.invalid_frac, long_tail=wl == "ltsv5")
-    elif wl == "rfc3164":
-        lines = synth.rfc3164_lines(args.tile_lines, invalid_frac=args.invalid_frac)
-    elif wl == "frame":
-        lines = [ln + b"\n" for ln in synth.rfc5424_lines(args.tile_lines, cfg=2, invalid_frac=args.invalid_frac)]
-    elif wl == "cfg5":
-        lines = synth.rfc5424_lines(args.tile_lines, cfg=5, sd=True, invalid_frac=args.invalid_frac, long_tail=True)
+    index = None
+    if wl == "cfg5mix":
+        tag, (la, ia), (lb, ib) = synth.mixed_cfg5(args.tile_lines, invalid_frac=args.invalid_frac)
+        subs = [Resident(0, la, args.reps, dev, local, opts), Resident(1, lb, args.reps, dev, local, opts)]
+        # arrival position of row j of replica r of a sub-batch: r * tile + position inside the tile
+        index = [np.concatenate([ix + np.uint64(r * args.tile_lines) for r in range(args.reps)]) for ix in (ia, ib)]
+        del la, lb
     else:
-        kw = {"lo": args.line_len[0], "hi": args.line_len[1]} if (args.line_len and not sd) else {}
-        lines = synth.rfc5424_lines(args.tile_lines, cfg=4 if sd else 2, sd=sd, invalid_frac=args.invalid_frac, **kw)
-    data, offsets = synth.pack(lines)
-    n_tile, tile_bytes = len(lines), int(offsets[-1])
-    del lines
-    reps = args.reps
+        if wl == "cfg3":
+            lines = synth.gelf_lines(args.tile_lines, invalid_frac=args.invalid_frac)
+        elif wl in ("ltsv", "ltsv5"):
+            lines = synth.ltsv_lines(args.tile_lines, invalid_frac=args.invalid_frac, long_tail=wl == "ltsv5")
+        elif wl == "rfc3164":
+            lines = synth.rfc3164_lines(args.tile_lines, invalid_frac=args.invalid_frac)
+        elif wl == "frame":
+            lines = [ln + b"\n" for ln in synth.rfc5424_lines(args.tile_lines, cfg=2, invalid_frac=args.invalid_frac)]
+        elif wl == "cfg5":
+            lines = synth.rfc5424_lines(args.tile_lines, cfg=5, sd=True, invalid_frac=args.invalid_frac, long_tail=True)
+        else:
+            kw = {"lo": args.line_len[0], "hi": args.line_len[1]} if (args.line_len and not sd) else {}
+            lines = synth.rfc5424_lines(args.tile_lines, cfg=4 if sd else 2, sd=sd, invalid_frac=args.invalid_frac, **kw)
+        subs = [Resident(fmt, lines, args.reps, dev, local, opts, entries=wl != "cfg2")]
+        del lines
+    R = subs[0]
+    dec, tables, d_bytes, d_offsets = R.dec, R.tables, R.d_bytes, R.d_offsets
+    n_tile, tile_bytes, reps = sum(s.n_tile for s in subs), sum(s.tile_bytes for s in subs), args.reps
     n = n_tile * reps
-    raw = torch.from_numpy(data[:tile_bytes]).to(dev)
-    # (filled in place: `cat(raw.repeat(reps), pad)` holds the batch twice for a moment -- 110 GB for configs[3]'s share)
-    d_bytes = torch.empty(tile_bytes * reps + 32, dtype=torch.uint8, device=dev)
-    d_bytes[tile_bytes * reps:] = 0
-    d_bytes[:tile_bytes * reps].view(reps, tile_bytes).copy_(raw.unsqueeze(0).expand(reps, tile_bytes))
-    o = torch.from_numpy(offsets[:-1].astype(np.int64)).to(dev)
-    base = torch.arange(reps, device=dev, dtype=torch.int64).repeat_interleave(n_tile) * tile_bytes
-    d_offsets = torch.cat([o.repeat(reps) + base, torch.tensor([tile_bytes * reps], device=dev, dtype=torch.int64)])
-    del base, o, raw
-    # entry slots: one per 24 input bytes (the corpora hold one pair per 38-42 bytes; a batch that needs more reports
-    # FG_ST_OVERFLOW rows and fails the Ok-count check below) -- 0.75 x the input in HBM instead of 2.25 x
-    ent_cap = (tile_bytes * reps // 24 if wl != "cfg2" else 0) + 4096 + 64 * 1024 * 256
-    tables = DeviceTables(n, ent_cap, dev)
-    if fmt == 3:
-        from flowgger_amd import RFC3164Decoder
-
-        dec = RFC3164Decoder({"rfc3164": {"current_year": 2026}}, device=local)
-    else:
-        dec = (GelfDecoder(device=local) if fmt == 2 else LTSVDecoder(synth.LTSV_CONFIG, device=local) if fmt == 1
-               else RFC5424Decoder(device=local))
     stream = torch.cuda.current_stream(dev)
 
     frame_ms = None
@@ -271,6 +464,8 @@ def main():
         e_buf = torch.empty(enc_bytes + 4096, dtype=torch.uint8, device=dev)
         del e_out, e_off
 
+    sub_ev = []  # cfg5mix: (start, between, end) per step -> the two kernels' times
+
     def step():
         if wl == "cfg1":
             dec.decode_device(d_bytes, d_offsets, tables, stream)
@@ -281,50 +476,83 @@ def main():
             encode_ms.append((a, b))
         elif wl == "frame":
             dec.decode_frames_device(raw_stream, f_off, n, tables, FL.FG_FRAME_LINE, f_bad, stream)
+        elif wl == "cfg5mix":
+            mid = torch.cuda.Event(enable_timing=True)
+            subs[0].decode(stream)
+            mid.record(stream)
+            subs[1].decode(stream)
+            sub_ev.append(mid)
         else:
-            dec.decode_device(d_bytes, d_offsets, tables, stream)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+            R.decode(stream)
 
     for _ in range(args.warmup):
         step()
-    barrier()
+    D.barrier()
+    sub_ev.clear()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for a, b in ev:
         a.record(stream)
         step()
         b.record(stream)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    D.barrier()
+    elapsed = D.max(time.perf_counter() - t0)
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    rank_ms = [kernel_ms]
-    if world > 1:  # every rank's own kernel time (HIP events on its stream), gathered over RCCL
-        g = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
-        dist.all_gather(g, torch.tensor([kernel_ms], device=dev, dtype=torch.float64))
-        rank_ms = [float(x.item()) for x in g]
+    rank_ms = [r[0] for r in D.all([kernel_ms])]  # every rank's own kernel time (HIP events on its stream), gathered over RCCL
 
-    # ---- validity: every replica of the tile produced the SAME rows -- all fixed columns, not only the status
-    #      (ent_first is the one column that legitimately differs: entry slices are placed by wave-level allocation) ----
-    meta = tables.column("meta").view(torch.int32).view(reps, n_tile)
-    status = meta & 0xFF
-    n_ok_tile = int((status[0] == 0).sum().item())
-    if not os.environ.get("FG_ABLATE"):
-        for col, width in (("meta", 4), ("ts", 8), ("hostname", 8), ("appname", 8), ("procid", 8), ("msgid", 8), ("msg", 8),
-                           ("full_msg", 8), ("ent_count", 4)):
-            c = tables.column(col)[: n * width].view(torch.int64 if width == 8 else torch.int32).view(reps, n_tile)
-            assert bool((c == c[0:1]).all()), f"replicas disagree in column {col}: work was skipped or corrupted"
-    reserved = int(tables.column("ent_used").view(torch.int64)[0].item())
-    assert reserved <= ent_cap, "entry table overflow"
-    # entries written (slots are reserved in per-wave chunks; `reserved` is a little more than what the lines own)
-    used = int(tables.column("ent_count")[: n * 4].view(torch.int32).to(torch.int64).sum().item())
+    # ---- validity --------------------------------------------------------------------------
+    checks = [s.check_replicas() for s in subs]
+    n_ok_tile, used = sum(c[0] for c in checks), sum(c[1] for c in checks)
+
+    # ---- configs[4]: the host-side ordered gather (SURVEY 8d "same + gather time") -----------
+    gather = None
+    if wl == "cfg5mix":
+        from flowgger_amd import shard
+
+        side = torch.cuda.Stream(dev)
+        parts = [s.tables.to_host_pinned(side) for s in subs]  # (allocates + pins the staging buffers: a framer keeps them)
+        D.barrier()
+        t0 = time.perf_counter()
+        parts = [s.tables.to_host_pinned(side, host=p._pinned) for s, p in zip(subs, parts)]  # D2H of both sub-batches' tables
+        d2h_ms = (time.perf_counter() - t0) * 1e3
+        merged, src = shard.merge_tables(parts, index)       # first call allocates + faults the output in
+        t0 = time.perf_counter()
+        merged, src = shard.merge_tables(parts, index, out=merged, src=src)
+        merge_ms = (time.perf_counter() - t0) * 1e3
+        assert merged.n == n and np.array_equal(src[: args.tile_lines], tag), "merge did not restore the arrival order"
+        # spot check: rows went back where they came from
+        for k, s_ in enumerate(subs):
+            j = np.array([0, s_.n_tile // 2, s_.n - 1])
+            assert np.array_equal(merged.a["meta"][index[k][j].astype(np.int64)], parts[k].a["meta"][j])
+        table_bytes = sum(int(p.n) * 68 + int(p.ent_used) * 18 for p in parts)
+        gather = {"gather_ms": d2h_ms + merge_ms, "d2h_ms": d2h_ms, "merge_ms": merge_ms, "rows": int(merged.n),
+                  "entries": int(merged.ent_used), "table_bytes": table_bytes, "d2h_GBps": table_bytes / (d2h_ms * 1e-3) / 1e9,
+                  "lines_per_s": n / ((d2h_ms + merge_ms) * 1e-3),
+                  "what": "D2H of both sub-batches' tables into pinned memory + fg_merge_tables by arrival index (whole resident batch)"}
+        if D.on:  # N ranks: the ranks' merged tables -> one table on rank 0, in rank (= shard) order
+            D.barrier()
+            t0 = time.perf_counter()
+            full = shard.gather_distributed(merged, dst=0)
+            D.barrier()
+            gather["ranks_gather_ms"] = D.max((time.perf_counter() - t0) * 1e3)
+            gather["ranks_what"] = "shard.gather_distributed: every rank's table to rank 0 (RCCL send / recv) + fg_gather_tables"
+            if rank == 0:
+                assert full.n == n * world
+                gather["ranks_rows"] = int(full.n)
+            gather["gather_ms"] += gather["ranks_gather_ms"]
+        gather["all_ranks_gather_ms"] = [r[0] for r in D.all([gather["gather_ms"]])]
+        del parts, merged
+
+    # ---- PCIe-inclusive legs: every rank, at the same time -----------------------------------
+    e2e = None
+    if not args.no_e2e and wl in ("cfg2", "cfg1", "cfg3", "cfg4", "ltsv"):
+        try:
+            e2e = e2e_legs(D, dec, fmt, R.data, R.offsets, R.n_tile, R.tile_bytes, want_transcode=wl in ("cfg2", "cfg1"),
+                           want_stream=wl in ("cfg2", "cfg1", "cfg3", "cfg4", "ltsv"))
+        except AssertionError:
+            raise
+        except Exception as e:  # the PCIe legs never take the bench line down
+            e2e = {"error": repr(e)}
 
     if rank == 0:
         # SURVEY 8d's algorithmic bytes: line + one u32 offset read; a 64-byte row (+ 8 + 20 per structured-data pair)
@@ -338,7 +566,7 @@ def main():
             "metric": "log lines/sec (RFC5424, 256B avg) at 1/2/4/8 MI355X; achieved HBM GB/s",
             "value": n * world * args.steps / elapsed,
             "unit": "lines/s",
-            "n_gpus": dist.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
@@ -353,15 +581,27 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                "kernel": ("fg::k_rfc5424", "fg::k_ltsv", "fg::k_gelf", "fg::k_rfc3164")[fmt], "kernel_ms": kernel_ms,
+                "kernel": KERNELS[fmt] if wl != "cfg5mix" else "fg::k_rfc5424 + fg::k_ltsv", "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_launch": alg_read + alg_written,
                 "moved_bytes_per_launch": moved, "moved_frac": moved / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                 "read_only_frac": alg_read / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             },
             "ranks": {"n": len(rank_ms), "kernel_ms": rank_ms, "kernel_ms_min": min(rank_ms), "kernel_ms_max": max(rank_ms),
+                      "numa": numa,
                       "launcher": "self (torch.distributed.run)" if os.environ.get("FG_BENCH_SPAWNED") else
                                   "external (WORLD_SIZE set)" if "WORLD_SIZE" in os.environ else "single process"},
         }
+        if opts:
+            out["config"]["launch_opts"] = opts
+        if wl == "cfg5mix":
+            a_ms = float(np.mean([ev[i][0].elapsed_time(sub_ev[i]) for i in range(args.steps)]))
+            out["sub_batches"] = [
+                {"format": "rfc5424", "lines": subs[0].n, "bytes": subs[0].tile_bytes * reps, "kernel_ms": a_ms,
+                 "lines_per_s": subs[0].n / (a_ms * 1e-3)},
+                {"format": "ltsv", "lines": subs[1].n, "bytes": subs[1].tile_bytes * reps, "kernel_ms": kernel_ms - a_ms,
+                 "lines_per_s": subs[1].n / ((kernel_ms - a_ms) * 1e-3)}]
+            out["gather_ms"] = gather["gather_ms"]
+            out["gather"] = gather
         if wl == "cfg1":
             ems = float(np.mean([a.elapsed_time(b) for a, b in encode_ms[-args.steps:]]))
             out["encode"] = {"ms": ems, "out_bytes": enc_bytes, "lines_per_s": n / (ems * 1e-3),
@@ -389,19 +629,16 @@ def main():
                     out["roofline"]["traffic_note"] = "profiles/traffic.json holds a figure for older kernel sources: not reported"
             except Exception:
                 pass
-        if world == 1 and not args.no_e2e and wl in ("cfg2", "cfg1", "cfg3", "cfg4", "ltsv"):
-            try:
-                out["e2e"] = e2e_legs(dec, fmt, data, offsets, n_tile, tile_bytes, want_transcode=wl in ("cfg2", "cfg1"))
-            except Exception as e:  # the PCIe legs never take the bench line down
-                out["e2e"] = {"error": repr(e)}
-        if world == 1 and not args.no_cpu_baseline:
-            cb, n_ok_cpu = cpu_baseline(fmt, data, offsets, n_tile, synth.LTSV_CONFIG if fmt == 1 else None, pipeline=wl == "cfg1")
+        if e2e is not None:
+            out["e2e"] = e2e
+        if world == 1 and not args.no_cpu_baseline:  # (the contract: the CPU leg runs on rank 0 at N = 1 only)
+            os.sched_setaffinity(0, all_cpus)  # (the CPU leg uses every host core, not only the GPU's NUMA node)
+            legs = [(s.fmt, s.data, s.offsets, s.n_tile, synth.LTSV_CONFIG if s.fmt == 1 else None) for s in subs]
+            cb, n_ok_cpu = cpu_baseline(legs, pipeline=wl == "cfg1")
             assert n_ok_cpu == n_ok_tile, f"GPU Ok count {n_ok_tile} != oracle Ok count {n_ok_cpu}"
             out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    D.close()
 
 
 if __name__ == "__main__":

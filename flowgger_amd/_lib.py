@@ -147,6 +147,7 @@ def lib() -> C.CDLL:
     L.fg_encode_error_string.argtypes = [C.c_uint8]
     L.fg_encode_error_string.restype = C.c_char_p
     L.fg_set_rfc3164.argtypes = [vp, C.POINTER(fg_rfc3164_cfg)]
+    L.fg_measure_link.argtypes = [vp, u64, C.POINTER(C.c_double)]
     L.fg_alloc_pinned.argtypes = [u64, C.POINTER(vp)]
     L.fg_free_pinned.argtypes = [vp]
     L.fg_free_pinned.restype = None

@@ -7,6 +7,7 @@
 // configuration and cloned per connection thread.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -641,6 +642,67 @@ int fg_alloc_pinned(uint64_t bytes, void** out) {
 }
 void fg_free_pinned(void* p) {
     if (p) (void)hipHostFree(p);
+}
+
+int fg_measure_link(fg_ctx* ctx, uint64_t nbytes, double gbps[3]) {
+    if (!ctx || !gbps || nbytes < 4096) return FG_ERR_ARG;
+    DeviceGuard g(ctx->device);
+    if (!ctx->stream2) {
+        FG_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+        FG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming));
+    }
+    uint8_t *h0 = nullptr, *h1 = nullptr, *d0 = nullptr, *d1 = nullptr;
+    hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
+    int rc = FG_OK;
+    auto fail = [&](hipError_t err) {
+        if (err != hipSuccess && rc == FG_OK) {
+            ctx->last_hip = (int)err;
+            rc = FG_ERR_HIP;
+        }
+        return err != hipSuccess;
+    };
+    do {
+        if (fail(hipHostMalloc((void**)&h0, nbytes, hipHostMallocDefault)) || fail(hipHostMalloc((void**)&h1, nbytes, hipHostMallocDefault))) break;
+        if (fail(hipMalloc((void**)&d0, nbytes)) || fail(hipMalloc((void**)&d1, nbytes))) break;
+        memset(h0, 0x5A, nbytes);  // (touch the pages: first use must not be part of the figure)
+        memset(h1, 0, nbytes);
+        bool bad = false;
+        for (auto& ev : e) bad = bad || fail(hipEventCreate(&ev));
+        if (bad) break;
+        double best[3] = {0, 0, 0};
+        for (int rep = 0; rep < 4 && rc == FG_OK; ++rep) {  // (rep 0 warms the path up)
+            float ms = 0.f;
+            // host -> device
+            if (fail(hipEventRecord(e[0], ctx->stream)) || fail(hipMemcpyAsync(d0, h0, nbytes, hipMemcpyHostToDevice, ctx->stream)) ||
+                fail(hipEventRecord(e[1], ctx->stream)) || fail(hipEventSynchronize(e[1])) || fail(hipEventElapsedTime(&ms, e[0], e[1])))
+                break;
+            if (rep && ms > 0.f) best[0] = std::max(best[0], (double)nbytes / (ms * 1e-3) / 1e9);
+            // device -> host
+            if (fail(hipEventRecord(e[0], ctx->stream)) || fail(hipMemcpyAsync(h1, d1, nbytes, hipMemcpyDeviceToHost, ctx->stream)) ||
+                fail(hipEventRecord(e[1], ctx->stream)) || fail(hipEventSynchronize(e[1])) || fail(hipEventElapsedTime(&ms, e[0], e[1])))
+                break;
+            if (rep && ms > 0.f) best[1] = std::max(best[1], (double)nbytes / (ms * 1e-3) / 1e9);
+            // both at once: the slower stream bounds the pair (wall clock around both)
+            if (fail(hipStreamSynchronize(ctx->stream)) || fail(hipStreamSynchronize(ctx->stream2))) break;
+            timespec a, b;
+            clock_gettime(CLOCK_MONOTONIC, &a);
+            if (fail(hipMemcpyAsync(d0, h0, nbytes, hipMemcpyHostToDevice, ctx->stream)) ||
+                fail(hipMemcpyAsync(h1, d1, nbytes, hipMemcpyDeviceToHost, ctx->stream2)) || fail(hipStreamSynchronize(ctx->stream)) ||
+                fail(hipStreamSynchronize(ctx->stream2)))
+                break;
+            clock_gettime(CLOCK_MONOTONIC, &b);
+            const double s = (double)(b.tv_sec - a.tv_sec) + (double)(b.tv_nsec - a.tv_nsec) * 1e-9;
+            if (rep && s > 0) best[2] = std::max(best[2], 2.0 * (double)nbytes / s / 1e9);
+        }
+        for (int k = 0; k < 3; ++k) gbps[k] = best[k];
+    } while (false);
+    for (auto& ev : e)
+        if (ev) (void)hipEventDestroy(ev);
+    if (d0) (void)hipFree(d0);
+    if (d1) (void)hipFree(d1);
+    if (h0) (void)hipHostFree(h0);
+    if (h1) (void)hipHostFree(h1);
+    return rc;
 }
 
 int fg_decode_batch(fg_ctx* ctx, fg_format fmt, const uint8_t* bytes, uint64_t nbytes, const uint64_t* offsets,

@@ -64,16 +64,20 @@ def concat_tables(parts: Sequence[HostTables]) -> HostTables:
     return out
 
 
-def merge_tables(parts: Sequence[HostTables], index: Sequence[np.ndarray]) -> Tuple[HostTables, np.ndarray]:
+def merge_tables(parts: Sequence[HostTables], index: Sequence[np.ndarray], out: Optional[HostTables] = None,
+                 src: Optional[np.ndarray] = None) -> Tuple[HostTables, np.ndarray]:
     """Config 5 on tables: sub-batches split off by format go back to their original line positions (fg_merge_tables).
-    index[k][j] = original position of row j of parts[k].  Returns (tables, src_part uint8[n])."""
+    index[k][j] = original position of row j of parts[k].  Returns (tables, src_part uint8[n]).  `out` / `src`: buffers of an
+    earlier call to reuse (a framer merges batch after batch into the same memory)."""
     arr = _part_array(parts)
     n, e = C.c_uint64(), C.c_uint64()
     L.check(L.lib().fg_gather_size(arr, len(parts), C.byref(n), C.byref(e)), "fg_gather_size")
-    out = _alloc_tables(int(n.value), int(e.value))
+    if out is None or out.n < int(n.value) or out.ent_cap < int(e.value):
+        out = _alloc_tables(int(n.value), int(e.value))
     ix = [np.ascontiguousarray(i, np.uint64) for i in index]
     ptrs = (C.c_void_p * max(len(ix), 1))(*[a.ctypes.data for a in ix])
-    src = np.zeros(max(int(n.value), 1), np.uint8)
+    if src is None or len(src) < int(n.value):
+        src = np.zeros(max(int(n.value), 1), np.uint8)
     L.check(L.lib().fg_merge_tables(arr, len(parts), ptrs, C.byref(out.struct), src.ctypes.data), "fg_merge_tables")
     return out, src[: int(n.value)]
 
@@ -114,12 +118,22 @@ def decode_distributed(decode: Callable[[np.ndarray, np.ndarray], HostTables], d
     point-to-point sends -- no pickling, no collective on the data path) and are put in rank order
     by fg_gather_tables.  Returns the full table on dst, None elsewhere.  Backend-agnostic
     (gloo on CPU tests; with nccl = RCCL the byte tensors are staged through the rank's GPU)."""
-    import torch
     import torch.distributed as dist
 
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     starts = shard_plan(offsets, world)
     mine = decode(*shard_slice(data, offsets, starts, rank))
+    return gather_distributed(mine, dst, group)
+
+
+def gather_distributed(mine: HostTables, dst: int = 0, group=None) -> Optional[HostTables]:
+    """The ordered host gather across ranks: every rank hands in the table of ITS shard (rank order = shard order), `dst` gets
+    their concatenation (fg_gather_tables), the others None.  One byte tensor per rank, sizes first, point-to-point sends -- no
+    pickling, no collective on the data path."""
+    import torch
+    import torch.distributed as dist
+
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
     on_gpu = dist.get_backend(group) == "nccl"
     dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
     wire = torch.from_numpy(_pack(mine))

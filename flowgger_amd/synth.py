@@ -206,6 +206,19 @@ def ltsv_lines(n: int, cfg: int = 5, invalid_frac: float = 0.01, long_tail: bool
     return out
 
 
+def mixed_cfg5(n: int, invalid_frac: float = 0.01):
+    """BASELINE configs[4]: a 50/50 stream of RFC5424 and LTSV lines, log-uniform 64 B .. 8 KiB, as two TAGGED sub-batches --
+    the reference has one decoder per input (flowgger/mod.rs:413-422), so a mixed stream is two inputs whose lines carry
+    their arrival position.  Returns (tag uint8[n], (rfc5424 lines, their positions), (ltsv lines, their positions)); the
+    host-side ordered gather (fg_merge_tables) puts the decoded rows back at those positions."""
+    rng = np.random.default_rng(SEED_BASE + 5 + 200)
+    tag = rng.integers(0, 2, n).astype(np.uint8)
+    ia, ib = np.flatnonzero(tag == 0), np.flatnonzero(tag == 1)
+    la = rfc5424_lines(len(ia), cfg=5, sd=True, invalid_frac=invalid_frac, long_tail=True)
+    lb = ltsv_lines(len(ib), invalid_frac=invalid_frac, long_tail=True)
+    return tag, (la, ia.astype(np.uint64)), (lb, ib.astype(np.uint64))
+
+
 def pack(lines: List[bytes]):
     offsets = np.zeros(len(lines) + 1, np.uint64)
     offsets[1:] = np.cumsum(np.fromiter((len(b) for b in lines), np.int64, len(lines)))

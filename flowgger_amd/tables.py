@@ -128,3 +128,34 @@ class DeviceTables:
             else:
                 arrays[name] = self.buf[off:off + size].cpu().numpy().view(dt).copy()
         return HostTables(self.n, used, arrays)
+
+    def to_host_pinned(self, stream=None, host=None) -> HostTables:
+        """The D2H leg of the host gather as a framer would run it: every column (entry columns up to ent_used) into ONE pinned
+        host buffer with asynchronous copies on `stream`, one synchronisation at the end.  The HostTables views that buffer."""
+        import torch
+
+        used = int(self.column("ent_used").view(torch.int64)[0].item())
+        if used > self.ent_cap:
+            raise L.FgError(L.FG_ERR_ENT_OVERFLOW, f"entry table overflow ({used} > {self.ent_cap})")
+        offs, total = layout(self.n, used)
+        if host is None or host.numel() < total:  # (`host`: the pinned buffer of an earlier call, HostTables._pinned)
+            host = torch.empty(total, dtype=torch.uint8, pin_memory=True)
+        ctx = torch.cuda.stream(stream) if stream is not None else None
+        if ctx is not None:
+            ctx.__enter__()
+        try:
+            for name, (doff, _), (hoff, size) in zip(L.TABLE_FIELDS, self.offs, offs):
+                if size:
+                    host[hoff:hoff + size].copy_(self.buf[doff:doff + size], non_blocking=True)
+        finally:
+            if ctx is not None:
+                ctx.__exit__(None, None, None)
+        (stream if stream is not None else torch.cuda.current_stream(self.buf.device)).synchronize()
+        flat = host.numpy()
+        arrays = {}
+        for name, (hoff, size) in zip(L.TABLE_FIELDS, offs):
+            dt = np.dtype(_DT[name])
+            arrays[name] = flat[hoff:hoff + size].view(dt) if size else np.zeros(1, dt)
+        t = HostTables(self.n, used, arrays)
+        t._pinned = host  # keeps the buffer alive
+        return t

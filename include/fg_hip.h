@@ -374,6 +374,12 @@ int fg_transcode_batch(fg_ctx* ctx, fg_format fmt, fg_framing framing, const fg_
 int fg_alloc_pinned(uint64_t bytes, void** out);
 void fg_free_pinned(void* p);
 
+/* The host <-> device link of ctx's GPU, MEASURED: hipMemcpyAsync of a pinned buffer of `nbytes` (>= 64 MiB for a steady figure;
+ * bench.py uses 1 GiB), best of three, in GB/s: gbps[0] host -> device, gbps[1] device -> host, gbps[2] both directions at once
+ * on two streams (sum of both).  This is the roof the host-buffer entry points (fg_decode_batch, fg_transcode_batch ...) are
+ * priced against -- SURVEY 8d: end-to-end is PCIe-bound -- instead of a nominal Gen5 figure. */
+int fg_measure_link(fg_ctx* ctx, uint64_t nbytes, double gbps[3]);
+
 /* The reference's exact &'static str for a status code of a format (0 -> "", unknown -> NULL). */
 const char* fg_error_string(fg_format fmt, uint8_t status);
 

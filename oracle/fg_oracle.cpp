@@ -2136,6 +2136,65 @@ double fgo_bench_pipeline(int fmt, const fgo_ltsv_cfg* cfg, int enc, int merger,
     if (n_ok) *n_ok = ok;
     return secs;
 }
+// The CPU-baseline leg proper (fgo_bench_decode / fgo_bench_pipeline start and join a fresh std::thread per core
+// per pass over n / threads lines -- with 256 threads and a 1 M-line tile that is half a millisecond of work per thread, and
+// the "all-core" figure was thread creation).  Here the threads are PERSISTENT for the measurement: every thread is created
+// and parked on a start gate BEFORE the clock starts, then walks the WHOLE tile (from its own starting line, wrapping around)
+// for `seconds` of wall time, looking at the clock every 64 lines; the clock stops when the last thread has finished its
+// current stretch.  Each thread works out of its own glibc malloc arena (glibc gives every thread one, up to 8 x cores), as
+// the reference's per-connection threads do.  enc < 0: decode only (owned Record per line); else decode + encode + merger +
+// null sink (SURVEY 8d configuration 1).  Returns the wall seconds; *lines = lines decoded by all threads together.
+double fgo_bench_timed(int fmt, const fgo_ltsv_cfg* cfg, int enc, int merger, const fgo_enc_opts* opts, const uint8_t* bytes,
+                       const uint64_t* offsets, uint64_t n, int threads, double seconds, uint64_t* lines, uint64_t* checksum) {
+    if (fmt < 0 || fmt > 3 || n == 0) return -1.0;
+    LtsvCfg c = make_cfg(cfg);
+    EncOpts o = make_opts(opts);
+    if (threads <= 0) threads = 1;
+    std::vector<uint64_t> done(threads, 0), sums(threads, 0);
+    std::atomic<int> ready{0};
+    std::atomic<bool> go{false};
+    std::chrono::steady_clock::time_point t0;
+    std::vector<std::thread> th;
+    th.reserve(threads);
+    for (int t = 0; t < threads; ++t) {
+        th.emplace_back([&, t]() {
+            {  // warm this thread's allocator arena and the decoder's code before the clock starts
+                Result w = decode_any(fmt, c, sv((const char*)bytes + offsets[0], offsets[1] - offsets[0]));
+                (void)w;
+            }
+            ready.fetch_add(1, std::memory_order_release);
+            while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+            const auto deadline = t0 + std::chrono::duration_cast<std::chrono::steady_clock::duration>(std::chrono::duration<double>(seconds));
+            uint64_t i = n * (uint64_t)t / (uint64_t)threads, cnt = 0, s = 0;
+            std::string j;
+            for (;;) {
+                for (int k = 0; k < 64; ++k) {
+                    Result r = decode_any(fmt, c, sv((const char*)bytes + offsets[i], offsets[i + 1] - offsets[i]));
+                    if (enc < 0) {
+                        s += record_checksum(r);
+                    } else if (!r.err && !encode_any(enc, merger, std::move(r.rec), o, &j)) {
+                        s += j.size() + (j.empty() ? 0u : (uint8_t)j[0] + (uint8_t)j[j.size() - 1]);  // the null sink looks at the message
+                    }
+                    if (++i == n) i = 0;
+                }
+                cnt += 64;
+                if (std::chrono::steady_clock::now() >= deadline) break;
+            }
+            done[t] = cnt;
+            sums[t] = s;
+        });
+    }
+    while (ready.load(std::memory_order_acquire) < threads) std::this_thread::yield();
+    t0 = std::chrono::steady_clock::now();
+    go.store(true, std::memory_order_release);
+    for (auto& x : th) x.join();
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    uint64_t total = 0, s = 0;
+    for (int t = 0; t < threads; ++t) { total += done[t]; s += sums[t]; }
+    if (lines) *lines = total;
+    if (checksum) *checksum = s;
+    return secs;
+}
 int fgo_rust_display_f64(double v, char* out, int cap) {
     std::string s = rust_display_f64(v);
     if ((int)s.size() + 1 > cap) return -1;

@@ -102,6 +102,11 @@ int64_t fgo_decode_encode_batch(int fmt, const fgo_ltsv_cfg* cfg, int enc, int m
 double fgo_bench_pipeline(int fmt, const fgo_ltsv_cfg* cfg, int enc, int merger, const fgo_enc_opts* opts,
                           const uint8_t* bytes, const uint64_t* offsets, uint64_t n, int threads,
                           uint64_t* out_bytes, uint64_t* n_ok);
+/* The CPU-baseline leg of bench.py: `threads` PERSISTENT threads (created and parked before the clock starts) each walk the
+ * whole tile for `seconds` of wall time; enc < 0 = decode only (owned Record per line), else decode + encode + merger + null
+ * sink.  Returns wall seconds, *lines = lines handled by all threads together. */
+double fgo_bench_timed(int fmt, const fgo_ltsv_cfg* cfg, int enc, int merger, const fgo_enc_opts* opts, const uint8_t* bytes,
+                       const uint64_t* offsets, uint64_t n, int threads, double seconds, uint64_t* lines, uint64_t* checksum);
 int fgo_rust_display_f64(double v, char* out, int cap); /* Rust `{}` of an f64 */
 
 /* RFC3164 decoder (rfc3164_decoder.rs:31-213) configuration, process-wide: the current year (the reference reads the

@@ -221,6 +221,21 @@ class Oracle:
                                            C.byref(nb), C.byref(nok))
         return secs, nok.value, nb.value
 
+    def bench_timed(self, fmt: int, data: np.ndarray, offsets: np.ndarray, threads: int, seconds: float, config=None, enc: int = -1,
+                    merger: int = 0):
+        """fgo_bench_timed: persistent threads, each walking the whole tile for `seconds`; -> (wall seconds, lines handled)."""
+        cfg, keep = self.make_cfg(config)
+        cfgp = C.byref(cfg) if cfg is not None else None
+        o, keep2 = self._opts(None, None, 0.0)
+        lines, chk = C.c_uint64(), C.c_uint64()
+        self.lib.fgo_bench_timed.restype = C.c_double
+        secs = self.lib.fgo_bench_timed(C.c_int(fmt), cfgp, C.c_int(enc), C.c_int(merger), C.byref(o), C.c_void_p(data.ctypes.data),
+                                        C.c_void_p(offsets.ctypes.data), C.c_uint64(len(offsets) - 1), C.c_int(threads),
+                                        C.c_double(seconds), C.byref(lines), C.byref(chk))
+        if secs <= 0:
+            raise RuntimeError("fgo_bench_timed failed")
+        return secs, lines.value
+
     def rfc3339(self, s: str):
         out = C.c_double()
         b = s.encode()

@@ -468,6 +468,59 @@ def test_cfg5_mixed_formats_ordered_merge(rfc, oracle):
         assert blob[int(offs[i]):int(offs[i + 1])].tobytes() == want, i
 
 
+def test_cfg5mix_one_million_tagged_lines_match_the_oracle(oracle):
+    """BASELINE configs[4] as specified: a 50/50 tagged RFC5424 + LTSV stream, log-uniform 64 B..8 KiB, decoded as
+    two sub-batches on the GPU; each sub-batch's Records == the oracle's; fg_merge_tables puts the rows (and their entries)
+    back at their arrival positions; fg_ordered_merge of the Records gives the arrival-order stream the reference's two
+    inputs would have produced.  1 M lines, ~1.7 GB."""
+    import os
+
+    from flowgger_amd import shard
+
+    n = 1_000_000
+    tag, (la, ia), (lb, ib) = synth.mixed_cfg5(n)
+    assert len(la) + len(lb) == n and abs(len(la) - len(lb)) < n // 50
+    threads = min(len(os.sched_getaffinity(0)), 64)
+    parts, recs, index = [], [], [ia, ib]
+    for fmt, lines, ix, dec, cfg in ((RFC5424, la, ia, RFC5424Decoder(), None),
+                                     (LTSV, lb, ib, LTSVDecoder(synth.LTSV_CONFIG), synth.LTSV_CONFIG)):
+        data, offsets = synth.pack(lines)
+        tables, _, _ = device_path(dec, data, offsets, ent_cap=int(offsets[-1]) // 16 + (1 << 22))
+        host = tables.to_host_pinned()
+        blob, offs = host.serialize(fmt, data, offsets, cfg=dec._cfg)
+        oblob, ooffs = oracle.decode_batch(fmt, data, offsets, cfg, threads=threads)
+        assert_same(blob, offs, oblob, ooffs, lines)
+        parts.append(host)
+        recs.append((ix, oblob, ooffs))
+        del data, tables
+    merged, src = shard.merge_tables(parts, index)
+    assert merged.n == n and np.array_equal(src, tag)
+    ent0 = 0
+    for k, (p, ix) in enumerate(zip(parts, index)):
+        ix = ix.astype(np.int64)
+        for col in ("meta", "ts", "ent_count"):
+            assert np.array_equal(merged.a[col][ix], p.a[col][: p.n]), col
+        for col in ("hostname", "appname", "procid", "msgid", "msg", "full_msg"):
+            assert np.array_equal(merged.a[col].reshape(-1, 2)[ix], p.a[col].reshape(-1, 2)[: p.n]), col
+        has = p.a["ent_count"][: p.n] != 0
+        assert np.array_equal(merged.a["ent_first"][ix][has], p.a["ent_first"][: p.n][has] + np.uint32(ent0))
+        u = p.ent_used
+        for col, w in (("ent_name", 2), ("ent_val", 1), ("ent_type", 1), ("ent_flags", 1)):
+            assert np.array_equal(merged.a[col][ent0 * w:(ent0 + u) * w], p.a[col][: u * w]), col
+        ent0 += u
+    # the arrival-order Record stream: record i is the oracle's record of the line that arrived i-th
+    blob, offs = shard.ordered_merge(recs)
+    sizes = np.diff(offs.astype(np.int64))
+    for ix, ob, oo in recs:
+        assert np.array_equal(sizes[ix.astype(np.int64)], np.diff(oo.astype(np.int64)))
+    rng = np.random.default_rng(4)
+    for i in rng.integers(0, n, 2000):
+        k = int(tag[i])
+        j = int(np.searchsorted(index[k], i))
+        ix, ob, oo = recs[k]
+        assert blob[int(offs[i]):int(offs[i + 1])].tobytes() == ob[int(oo[j]):int(oo[j + 1])].tobytes()
+
+
 # ---------------------------------------------------------------------- C++ host mirror + framers
 @pytest.mark.parametrize("fmt,framing", [("rfc5424", "line"), ("gelf", "nul"), ("ltsv", "syslen"), ("rfc5424", "gpu-line"),
                                          ("ltsv", "gpu-line"), ("gelf", "gpu-nul")])

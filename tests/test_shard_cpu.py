@@ -221,3 +221,32 @@ def test_gather_and_merge_refuse_partially_filled_tables(corpus):
     rc = lib.fg_ordered_merge(1, m.ctypes.data, (vp * 1)(idx.ctypes.data), (vp * 1)(None), (vp * 1)(offs.ctypes.data), None, 0,
                               out_offs.ctypes.data)
     assert rc == L.FG_ERR_ARG
+
+
+def test_mixed_cfg5_stream_and_merge_into_reused_buffers():
+    """synth.mixed_cfg5 (BASELINE configs[4]): every arrival position belongs to exactly one sub-batch; fg_merge_tables into the
+    buffers of an earlier call gives the same table."""
+    tag, (la, ia), (lb, ib) = synth.mixed_cfg5(4000)
+    assert len(la) == len(ia) and len(lb) == len(ib) and len(la) + len(lb) == 4000
+    assert np.array_equal(np.sort(np.concatenate([ia, ib])), np.arange(4000, dtype=np.uint64))
+    assert np.array_equal(tag[ia.astype(np.int64)], np.zeros(len(ia), np.uint8)) and bool((tag[ib.astype(np.int64)] == 1).all())
+    assert la[0].startswith(b"<") and b"\t" in lb[0]
+    parts = [fake_decode(*synth.pack(la)), fake_decode(*synth.pack(lb))]
+    first, src = shard.merge_tables(parts, [ia, ib])
+    want = rows(first)
+    again, src2 = shard.merge_tables(parts, [ia, ib], out=first, src=src)
+    assert again is first and rows(again) == want and np.array_equal(src2, tag)
+
+
+def test_cpu_baseline_threads_are_persistent(oracle):
+    """The CPU-baseline leg (oracle/fg_oracle.cpp fgo_bench_timed; VERDICT r2: the all-core figure was thread creation): with the
+    threads parked before the clock starts, N threads do close to N times the work of one.  (Lenient: the box may be busy.)"""
+    cores = min(len(os.sched_getaffinity(0)), 8)
+    if cores < 2:
+        pytest.skip("one core")
+    data, offsets = synth.pack(synth.rfc5424_lines(20_000, cfg=2))
+    s1, l1 = oracle.bench_timed(0, data, offsets, 1, 0.5)
+    sn, ln = oracle.bench_timed(0, data, offsets, cores, 0.5)
+    assert 0.45 < s1 < 1.5 and 0.45 < sn < 1.5
+    eff = (ln / sn) / (l1 / s1) / cores
+    assert eff > 0.35, eff
