@@ -295,7 +295,18 @@ def cpu_baseline(legs, pipeline=False):
         from flowgger_amd import tzdb
 
         o.set_rfc3164(2026, tzdb.default_table())
-    cores = len(os.sched_getaffinity(0)) or os.cpu_count() or 1
+    # the cores this process may really use: its affinity mask, cut down to the container's CPU quota (cgroup v2 cpu.max) --
+    # 256 hardware threads are visible on the GPU boxes of this pool but the cgroup grants 16 CPUs: more threads than that only
+    # add throttling (measured: linear to 16 threads, 130 M lines/s, then DOWN to 68 M at 256)
+    visible = len(os.sched_getaffinity(0)) or os.cpu_count() or 1
+    cores, quota = visible, None
+    try:
+        q, per = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if q != "max":
+            quota = float(q) / float(per)
+            cores = max(1, min(visible, int(quota)))
+    except Exception:  # noqa: BLE001
+        pass
     enc, mrg = (oracle_binding.ENC_GELF, oracle_binding.MERGE_LINE) if pipeline else (-1, 0)
     n_ok, total = 0, 0
     sec_one, sec_all = 0.0, 0.0  # seconds per line, summed over the sub-batches weighted by their share
@@ -313,6 +324,7 @@ def cpu_baseline(legs, pipeline=False):
         "value": allc, "unit": "lines/s", "cores": cores, "kind": "port",
         "single_thread": {"value": one, "cores": 1},
         "parallel_efficiency": allc / (one * cores),
+        "host_threads_visible": visible, "cgroup_cpu_quota": quota,
         "allocator": "glibc malloc, one arena per thread",
         "sample": f"~4 s of wall time on {cores} persistent threads (each walks the whole {total}-line tile of the same workload; thread start "
                   f"outside the timed region) and ~3 s on one thread: {what}; C++ restatement of the Rust decoders/encoders (-O3), not the "

@@ -127,6 +127,8 @@ def lib() -> C.CDLL:
     L.fg_error_string.restype = C.c_char_p
     L.fg_tables_serialize.argtypes = [C.c_int, C.POINTER(fg_cfg), vp, vp, C.POINTER(fg_tables), u64, u64, vp, u64, vp]
     L.fg_tables_serialize.restype = C.c_int64
+    L.fg_tables_stdout.argtypes = [C.c_int, C.c_int, vp, vp, C.POINTER(fg_tables), u64, u64, vp, u64]
+    L.fg_tables_stdout.restype = C.c_int64
     L.fg_shard_plan.argtypes = [vp, u64, u32, vp]
     L.fg_gather_size.argtypes = [C.POINTER(fg_tables), u32, C.POINTER(u64), C.POINTER(u64)]
     L.fg_gather_tables.argtypes = [C.POINTER(fg_tables), u32, C.POINTER(fg_tables)]

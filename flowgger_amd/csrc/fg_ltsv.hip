@@ -49,6 +49,7 @@ struct LRow {
     uint32_t have_ts = 0, have_host = 0;
     uint32_t host_off = 0, host_len = 0, msg_off = 0, msg_len = FG_NONE;
     uint32_t n_ent = 0;
+    uint32_t novalue = 0;  // parts without ':' met so far: the reference println!s "Missing value for name '{}'" for each (:99)
 };
 
 // f64::from_str on [b,e); the Decimal slow path is serialised over the wave's LDS digit buffer.
@@ -265,6 +266,8 @@ __device__ void ltsv_walk(R& rd, uint32_t len, const LtsvDevCfg& cfg, uint8_t* l
                 }
                 ++cnt;
             }
+        } else if (!EMIT) {
+            ++r.novalue;
         }
         if (pe >= len) break;
         ps = pe + 1;
@@ -563,6 +566,8 @@ struct LtsvFormat {
                     ++cnt;
                     tick(5);
                 }
+            } else {
+                ++r.novalue;
             }
             if (!more) break;
             ps = nps;
@@ -672,9 +677,14 @@ struct LtsvFormat {
         RowOut o;
         const bool ok = r.status == L_OK;
         const fg_span none{0, FG_NONE};
-        o.meta = r.status | (0xFFu << 8) | ((ok ? r.severity : 0xFFu) << 16);
+        // FG_F_LTSV_NOVALUE: the reference wrote to stdout while it decoded this line; a row whose decode FAILED says in
+        // hostname.off how many parts it had printed for by then (the walk stops at the first error, :116-190)
+        // (and, saturated at 254, in the meta word's facility byte -- always None for LTSV otherwise -- for callers that only get the
+        //  meta column back: fg_transcode_batch)
+        const uint32_t fac = (!ok && r.novalue) ? (r.novalue < 254u ? r.novalue : 254u) : 0xFFu;
+        o.meta = r.status | (fac << 8) | ((ok ? r.severity : 0xFFu) << 16) | ((r.novalue ? (uint32_t)FG_F_LTSV_NOVALUE : 0u) << 24);
         o.ts = ok ? r.ts : 0.0;
-        o.span[S_HOST] = ok ? fg_span{r.host_off, r.host_len} : none;
+        o.span[S_HOST] = ok ? fg_span{r.host_off, r.host_len} : fg_span{r.novalue, FG_NONE};
         o.span[S_APP] = none;
         o.span[S_PROC] = none;
         o.span[S_MSGID] = none;

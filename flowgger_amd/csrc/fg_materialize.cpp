@@ -273,3 +273,45 @@ extern "C" int64_t fg_tables_serialize(fg_format fmt, const fg_cfg* cfg, const u
     if (out_offsets) out_offsets[i1 - i0] = k.n;
     return (int64_t)k.n;
 }
+
+// The reference's stdout side effects for rows [i0, i1) (include/fg_hip.h).  LTSV: `println!("Missing value for name '{}'", name)`
+// for every tab-separated part without ':' (ltsv_decoder.rs:93-101: `name` is the whole part), in order, up to the part where the
+// decode stopped -- all of them for a row that decoded, the first hostname.off of them for a row that failed.
+extern "C" int64_t fg_tables_stdout(fg_format fmt, fg_framing framing, const uint8_t* bytes, const uint64_t* offsets, const fg_tables* t,
+                                    uint64_t i0, uint64_t i1, uint8_t* out, uint64_t cap) {
+    if (!t || i1 < i0 || i1 > t->n || (i1 > i0 && (!offsets || !bytes || !t->meta))) return FG_ERR_ARG;
+    if ((int)framing < 0 || (int)framing > 2) return FG_ERR_ARG;
+    Sink k{out, cap};
+    if (fmt != FG_LTSV) return 0;
+    static const char kHead[] = "Missing value for name '";
+    for (uint64_t i = i0; i < i1; ++i) {
+        const uint32_t m = t->meta[i];
+        if (!(FG_META_FLAGS(m) & FG_F_LTSV_NOVALUE)) continue;
+        const uint8_t st = FG_META_STATUS(m);
+        if (st == FG_ST_BAD_UTF8) continue;  // never decoded
+        uint64_t b = offsets[i], e = offsets[i + 1];
+        if (framing == FG_FRAME_LINE) {
+            if (e > b && bytes[e - 1] == '\n') {
+                --e;
+                if (e > b && bytes[e - 1] == '\r') --e;
+            }
+        } else if (framing == FG_FRAME_NUL && e > b && bytes[e - 1] == 0) {
+            --e;
+        }
+        uint64_t budget = (st == 0 || st == FG_ST_OVERFLOW) ? ~0ull : t->hostname ? (uint64_t)t->hostname[i].off : (uint64_t)FG_META_FACILITY(m);
+        uint64_t ps = b;
+        while (budget) {
+            const uint8_t* tab = (const uint8_t*)memchr(bytes + ps, '\t', e - ps);
+            const uint64_t pe = tab ? (uint64_t)(tab - bytes) : e;
+            if (!memchr(bytes + ps, ':', pe - ps)) {
+                k.put(kHead, sizeof(kHead) - 1);
+                k.put(bytes + ps, pe - ps);
+                k.put("'\n", 2);
+                --budget;
+            }
+            if (!tab) break;
+            ps = pe + 1;
+        }
+    }
+    return (int64_t)k.n;
+}

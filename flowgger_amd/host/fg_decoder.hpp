@@ -9,7 +9,9 @@
 // New: decode_batch() -- N framed lines, ONE call into the gfx950 kernels.  There is no CPU decode
 // path in here: construction throws std::runtime_error when no gfx950 device is usable.
 #pragma once
+#include <algorithm>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <functional>
 #include <istream>
@@ -159,6 +161,7 @@ class Decoder {
         fg_tables t{};
         int rc = fg_decode_batch(ctx_, fmt_, bytes, nbytes, offsets, n, &t);
         if (rc != FG_OK) throw std::runtime_error("fg_decode_batch failed: " + std::to_string(rc));
+        side_effects(fmt_, FG_FRAME_NONE, bytes, offsets, t);
         std::vector<uint64_t> offs(n + 1);
         int64_t total = fg_tables_serialize(fmt_, cfgp(), bytes, offsets, &t, 0, n, nullptr, 0, offs.data());
         if (total < 0) throw std::runtime_error("fg_tables_serialize failed");
@@ -168,6 +171,16 @@ class Decoder {
         out.reserve(n);
         for (uint64_t i = 0; i < n; ++i) out.push_back(detail::from_canonical(blob.data() + offs[i], fmt_, FG_META_STATUS(t.meta[i])));
         return out;
+    }
+    // what the reference decoder writes to the process's stdout while it decodes (SURVEY 8b "Side effects": LTSV's
+    // println!("Missing value for name '{}'"), ltsv_decoder.rs:99): reproduced after each batch from the rows' flags
+    static void side_effects(fg_format fmt, fg_framing framing, const uint8_t* bytes, const uint64_t* offsets, const fg_tables& t) {
+        if (fmt != FG_LTSV || t.n == 0) return;
+        const int64_t need = fg_tables_stdout(fmt, framing, bytes, offsets, &t, 0, t.n, nullptr, 0);
+        if (need <= 0) return;
+        std::string text((size_t)need, '\0');
+        fg_tables_stdout(fmt, framing, bytes, offsets, &t, 0, t.n, (uint8_t*)&text[0], (uint64_t)need);
+        fwrite(text.data(), 1, text.size(), stdout);
     }
     virtual std::unique_ptr<Decoder> clone_boxed() const = 0;  // decoder/mod.rs:29-36
     fg_ctx* ctx() const { return ctx_; }
@@ -293,6 +306,199 @@ inline std::string_view trim(std::string_view s) {  // str::trim on valid UTF-8
 }
 }  // namespace detail
 
+
+// ---------------------------------------------------------------------------------------------
+// What the splitters read from, and WHEN a batch is handed to the GPU.
+//
+// The reference handles every line as soon as `buf_reader.lines()` yields it and treats a read timeout (ErrorKind::WouldBlock:
+// tcp_input.rs:41 sets `input.timeout` on the socket) as "Client hasn't sent any data for a while - Closing idle connection"
+// (line_splitter.rs:26-33, nul_splitter.rs:22-29).  A batching framer that waited for a full chunk would sit on a trickling
+// connection's lines for hours, so a batch is flushed when ANY of these holds:
+//   * size      max_bytes / max_lines reached;
+//   * drained   the source has nothing more to read right now (a read would block) -- after a LINGER of at most max_latency_ms
+//               since the batch's first byte, and only while the batch is still small (< linger_below bytes): a burst that is
+//               still arriving becomes one GPU call instead of one per packet;
+//   * end       EOF, or the idle timeout: what is complete is decoded, then the reference's message is printed and run() returns.
+// ---------------------------------------------------------------------------------------------
+struct ByteSource {
+    enum : long { kEof = 0, kWouldBlock = -1, kError = -2 };
+    virtual ~ByteSource() = default;
+    // up to cap bytes into dst; waits at most wait_ms for the first of them (< 0: for as long as it takes, 0: only what is
+    // readable now).  > 0 bytes read, kEof, kWouldBlock (nothing within wait_ms), kError.
+    virtual long read(uint8_t* dst, size_t cap, int wait_ms) = 0;
+};
+// a file, a string stream: never blocks, a short read means EOF is next
+struct IstreamSource : ByteSource {
+    std::istream& in;
+    explicit IstreamSource(std::istream& s) : in(s) {}
+    long read(uint8_t* dst, size_t cap, int) override {
+        in.read((char*)dst, (std::streamsize)cap);
+        const long got = (long)in.gcount();
+        return got > 0 ? got : (long)kEof;
+    }
+};
+// a socket / pipe / tty file descriptor (BufReader<TcpStream>, stdin): poll() + read()
+struct FdSource : ByteSource {
+    int fd;
+    explicit FdSource(int f) : fd(f) {}
+    long read(uint8_t* dst, size_t cap, int wait_ms) override;
+};
+struct FlushPolicy {
+    size_t max_bytes = 8u << 20;     // a batch never grows beyond this (the GPU path is at link speed long before)
+    size_t max_lines = 1u << 16;     // host-framing splitters only
+    int idle_timeout_ms = -1;        // `input.timeout` (tcp_input.rs:26,41); < 0: none (stdin, files)
+    int max_latency_ms = 5;          // linger: how long the first line of a batch may wait for company
+    size_t linger_below = 64u << 10; // ... and only while the batch is smaller than this
+};
+
+}  // namespace fg
+#include <poll.h>
+#include <unistd.h>
+
+#include <cerrno>
+#include <chrono>
+namespace fg {
+inline long FdSource::read(uint8_t* dst, size_t cap, int wait_ms) {
+    for (;;) {
+        pollfd p{fd, POLLIN, 0};
+        const int r = ::poll(&p, 1, wait_ms);
+        if (r == 0) return kWouldBlock;
+        if (r < 0) {
+            if (errno == EINTR) continue;  // ErrorKind::Interrupted => continue (line_splitter.rs:21)
+            return kError;
+        }
+        const ssize_t n = ::read(fd, dst, cap);
+        if (n > 0) return (long)n;
+        if (n == 0) return kEof;
+        if (errno == EINTR) continue;
+        if (errno == EAGAIN || errno == EWOULDBLOCK) return kWouldBlock;
+        return kError;
+    }
+}
+
+// Buffered reader over a ByteSource with the flush policy built in: the splitter registers `pending` (bytes of framed lines it
+// holds back for the next GPU call) and `flush`; before the reader BLOCKS for more input it lingers (policy) and then flushes.
+class BufferedSource {
+  public:
+    enum End { None, Eof, Idle, Error };
+    BufferedSource(ByteSource& s, const FlushPolicy& p) : src_(s), pol_(p) {}
+    void on_block(std::function<size_t()> pending, std::function<void()> flush) {
+        pending_ = std::move(pending);
+        flush_ = std::move(flush);
+    }
+    End end() const { return end_; }
+    // next byte, or -1 at the end of the input (end() says which end)
+    int get() {
+        if (pos_ == buf_.size() && !more()) return -1;
+        return buf_[pos_++];
+    }
+    // up to n bytes appended to out; fewer only at the end of the input
+    size_t read_exact(std::string& out, size_t n) {
+        size_t got = 0;
+        while (got < n) {
+            if (pos_ == buf_.size() && !more()) break;
+            const size_t k = std::min(n - got, buf_.size() - pos_);
+            out.append((const char*)buf_.data() + pos_, k);
+            pos_ += k;
+            got += k;
+        }
+        return got;
+    }
+    // bytes up to (not including) the next `delim` appended to out; true = the delimiter was found (and consumed)
+    bool read_until(uint8_t delim, std::string& out) {
+        for (;;) {
+            if (pos_ == buf_.size() && !more()) return false;
+            const uint8_t* b = buf_.data() + pos_;
+            const uint8_t* hit = (const uint8_t*)memchr(b, delim, buf_.size() - pos_);
+            const size_t k = hit ? (size_t)(hit - b) : buf_.size() - pos_;
+            out.append((const char*)b, k);
+            pos_ += k + (hit ? 1 : 0);
+            if (hit) return true;
+        }
+    }
+    // a raw chunk for the GPU framers: appends what is there to `out` (at most room bytes) under the same policy, where the
+    // batch in the making is `out` itself.  false = nothing was added and the input has ended.
+    bool read_chunk(std::vector<uint8_t>& out, size_t room) {
+        using clock = std::chrono::steady_clock;
+        const size_t had = out.size();
+        bool started = false;
+        clock::time_point t0{};
+        while (out.size() - had < room) {
+            const size_t want = std::min(room - (out.size() - had), (size_t)1 << 20);
+            const size_t at = out.size();
+            out.resize(at + want);
+            int wait = 0;
+            if (out.size() - want == had && !started) wait = pol_.idle_timeout_ms;  // the first bytes: block (idle timeout)
+            long n = src_.read(out.data() + at, want, wait);
+            if (n == ByteSource::kWouldBlock && started && at < had + pol_.linger_below) {  // drained: linger while the batch is small
+                const auto left = std::chrono::milliseconds(pol_.max_latency_ms) - std::chrono::duration_cast<std::chrono::milliseconds>(clock::now() - t0);
+                if (left.count() > 0) n = src_.read(out.data() + at, want, (int)left.count());
+            }
+            out.resize(at + (n > 0 ? (size_t)n : 0));
+            if (n > 0) {
+                if (!started) {
+                    started = true;
+                    t0 = clock::now();
+                }
+                continue;
+            }
+            if (n == ByteSource::kWouldBlock && started) break;  // drained: the batch goes out
+            end_ = n == ByteSource::kEof ? Eof : n == ByteSource::kWouldBlock ? Idle : Error;
+            break;
+        }
+        return out.size() > had;
+    }
+
+  private:
+    bool more() {
+        using clock = std::chrono::steady_clock;
+        if (end_ != None) return false;
+        buf_.resize(1 << 16);
+        pos_ = 0;
+        long n = src_.read(buf_.data(), buf_.size(), 0);  // whatever is readable now
+        if (n == ByteSource::kWouldBlock) {
+            // a read would block.  Lines held back for the next GPU call: linger while the batch is young and small, then flush
+            const size_t pend = pending_ ? pending_() : 0;
+            if (pend) {
+                if (!batch_open_) {
+                    batch_open_ = true;
+                    batch_t0_ = clock::now();
+                }
+                if (pend < pol_.linger_below) {
+                    const auto left = std::chrono::milliseconds(pol_.max_latency_ms) - std::chrono::duration_cast<std::chrono::milliseconds>(clock::now() - batch_t0_);
+                    if (left.count() > 0) n = src_.read(buf_.data(), buf_.size(), (int)left.count());
+                }
+                if (n == ByteSource::kWouldBlock) {
+                    flush_();
+                    batch_open_ = false;
+                }
+            }
+            if (n == ByteSource::kWouldBlock) n = src_.read(buf_.data(), buf_.size(), pol_.idle_timeout_ms);
+        }
+        if (n > 0) {
+            if (!batch_open_) {
+                batch_open_ = true;
+                batch_t0_ = clock::now();
+            }
+            buf_.resize((size_t)n);
+            return true;
+        }
+        buf_.clear();
+        end_ = n == ByteSource::kEof ? Eof : n == ByteSource::kWouldBlock ? Idle : Error;
+        return false;
+    }
+    ByteSource& src_;
+    FlushPolicy pol_;
+    std::vector<uint8_t> buf_;
+    size_t pos_ = 0;
+    End end_ = None;
+    std::function<size_t()> pending_;
+    std::function<void()> flush_;
+    bool batch_open_ = false;
+    std::chrono::steady_clock::time_point batch_t0_{};
+};
+inline const char* kIdleMessage = "Client hasn't sent any data for a while - Closing idle connection";  // line_splitter.rs:26-33
+
 using RecordSink = std::function<void(Record&&)>;  // stands in for encoder.encode(record) -> tx.send(bytes)
 
 class BatchingSplitter {
@@ -303,8 +509,21 @@ class BatchingSplitter {
     // Mirrors LineSplitter/NulSplitter/SyslenSplitter::run: frames `in`, decodes in batches, hands Ok records to
     // `sink` in input order, reports errors on `err` exactly like the reference.
     void run(std::istream& in, const Decoder& decoder, const RecordSink& sink, std::ostream& err) {
+        IstreamSource src(in);
+        FlushPolicy pol;
+        pol.max_lines = max_lines_;
+        pol.max_bytes = max_bytes_;
+        run(src, pol, decoder, sink, err);
+    }
+    // The same over a socket / pipe (FdSource) with the flush policy above: a batch goes to the GPU when it is full, when the
+    // source has nothing more to give right now (after the linger), at EOF and at the idle timeout.
+    void run(ByteSource& src, const FlushPolicy& pol, const Decoder& decoder, const RecordSink& sink, std::ostream& err) {
+        max_lines_ = pol.max_lines;
+        max_bytes_ = pol.max_bytes;
         bytes_.clear();
         offsets_.assign(1, 0);
+        BufferedSource in(src, pol);
+        in.on_block([&] { return bytes_.size() + (offsets_.size() - 1); }, [&] { flush(decoder, sink, err); });
         std::string line;
         if (f_ == Syslen) {
             for (;;) {  // syslen_splitter.rs:42-57: "<len> " then exactly len bytes
@@ -312,8 +531,13 @@ class BatchingSplitter {
                 // read (it assumes the delimiter), parses the rest and then fails in read_exact (:27-30)
                 std::string num;
                 int c;
-                while ((c = in.get()) != EOF && c != ' ') num.push_back((char)c);
-                const bool at_eof = c == EOF;
+                while ((c = in.get()) >= 0 && c != ' ') num.push_back((char)c);
+                if (c < 0 && in.end() != BufferedSource::Eof) {  // read_until returned Err (WouldBlock: idle timeout): :45 `Err(_)`
+                    flush(decoder, sink, err);
+                    err << "Can't read message's length\n";
+                    break;
+                }
+                const bool at_eof = c < 0;
                 const size_t got = num.size() + (at_eof ? 0 : 1);  // bytes read_until returned
                 if (got <= 1) { flush(decoder, sink, err); err << "Can't read message's length\n"; break; }  // :45-46, :20-25
                 if (at_eof) num.pop_back();
@@ -326,11 +550,12 @@ class BatchingSplitter {
                     else len = len * 10 + (size_t)(num[k] - '0');
                 }
                 if (!ok) { flush(decoder, sink, err); err << "Can't read message's length\n"; break; }
-                line.resize(at_eof ? 0 : len);
-                if (!at_eof) in.read(&line[0], (std::streamsize)len);
-                if (at_eof ? len != 0 : (size_t)in.gcount() != len) {  // read_exact's UnexpectedEof, printed with `{}` (:27-30)
+                line.clear();
+                const size_t have = at_eof ? 0 : in.read_exact(line, len);
+                if (at_eof ? len != 0 : have != len) {  // read_exact's error, printed with `{}` (:27-30)
                     flush(decoder, sink, err);
-                    err << "failed to fill whole buffer\n";
+                    err << (in.end() == BufferedSource::Idle ? "Resource temporarily unavailable (os error 11)\n"  // io::Error Display of EAGAIN
+                                                              : "failed to fill whole buffer\n");                  // UnexpectedEof
                     break;
                 }
                 if (at_eof) {  // "0?" + EOF: an empty message is handled, then the next read_msglen sees Ok(0)
@@ -349,14 +574,23 @@ class BatchingSplitter {
                 push(line, decoder, sink, err);
             }
         } else {
-            const char delim = f_ == Line ? '\n' : '\0';
-            while (std::getline(in, line, delim)) {
-                // BufRead::lines() drops a '\r' only together with the '\n' it precedes: an unterminated last line
-                // keeps its trailing '\r' (getline sets eofbit when it ran into EOF instead of the delimiter)
-                const bool terminated = !in.eof();
-                if (f_ == Line && terminated && !line.empty() && line.back() == '\r') line.pop_back();
+            const uint8_t delim = f_ == Line ? '\n' : '\0';
+            for (;;) {
+                line.clear();
+                const bool terminated = in.read_until(delim, line);
+                if (!terminated) {
+                    // BufRead::lines() / split(): at EOF an unterminated last piece is a line when it is not empty (and keeps its
+                    // trailing '\r': that is dropped only together with the '\n' it precedes); on any other end (idle timeout, I/O
+                    // error) the iterator yields Err and the partial line is gone with it
+                    if (in.end() == BufferedSource::Eof && !line.empty()) push(line, decoder, sink, err);
+                    break;
+                }
+                if (f_ == Line && !line.empty() && line.back() == '\r') line.pop_back();
                 push(line, decoder, sink, err);
             }
+            flush(decoder, sink, err);
+            if (in.end() == BufferedSource::Idle) err << kIdleMessage << "\n";  // line_splitter.rs:26-33, nul_splitter.rs:22-29
+            return;
         }
         flush(decoder, sink, err);
     }
@@ -394,6 +628,86 @@ class BatchingSplitter {
 };
 
 
+// ---------------------------------------------------------------------------------------------
+// The per-record callers: UDP, Redis and the file tailer call `decoder.decode(record)` once per record with no splitter
+// in between (input/udp_input.rs:139, input/redis_input.rs:159, input/file/worker.rs:116).  Through the drop-in trait method
+// that is one GPU launch + stream synchronisation + table copy per record -- tens of microseconds against ~0.15 us for the CPU
+// decoder -- so for these inputs the GPU path only pays when records are decoded in batches (tools/host_path_bench.py
+// --workload latency: the crossover with one CPU thread is at a few hundred lines per call).  MicroBatcher is that adapter:
+// records are parked for at most max_latency_ms (or until max_lines / max_bytes are there) and decoded in ONE call; results
+// come back in arrival order.  The receive loop of udp_input.rs:78-88 becomes
+//     for (;;) { n = recv(sock, buf, timeout = mb.wait_ms()); if (n > 0) mb.push({buf, n}); mb.poll(); }
+// ---------------------------------------------------------------------------------------------
+class MicroBatcher {
+  public:
+    using ErrorSink = std::function<void(const char* err, std::string_view record)>;  // udp_input.rs:84-86: writeln!(stderr(), "{}", e)
+    MicroBatcher(const Decoder& d, RecordSink sink, ErrorSink on_error, size_t max_lines = 4096, int max_latency_ms = 5,
+                 size_t max_bytes = 4u << 20)
+        : d_(d), sink_(std::move(sink)), on_error_(std::move(on_error)), max_lines_(max_lines), max_bytes_(max_bytes), latency_(max_latency_ms) {
+        offsets_.assign(1, 0);
+    }
+    ~MicroBatcher() { flush(); }
+    // one record (handle_record, udp_input.rs:125-143): the UTF-8 check happens here, in arrival order with the decode errors
+    void push(std::string_view record) {
+        if (offsets_.size() == 1) t0_ = std::chrono::steady_clock::now();
+        bytes_.insert(bytes_.end(), record.begin(), record.end());
+        offsets_.push_back(bytes_.size());
+        if (offsets_.size() - 1 >= max_lines_ || bytes_.size() >= max_bytes_) flush();
+    }
+    // how long the caller may block in its receive call before poll() is due: -1 = nothing is parked
+    int wait_ms() const {
+        if (offsets_.size() == 1) return -1;
+        const auto waited = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0_).count();
+        return waited >= latency_ ? 0 : (int)(latency_ - waited);
+    }
+    void poll() {
+        if (offsets_.size() > 1 && wait_ms() == 0) flush();
+    }
+    void flush() {
+        const uint64_t n = offsets_.size() - 1;
+        if (n == 0) return;
+        // invalid UTF-8 never reaches decode() ("Invalid UTF-8 input", udp_input.rs:135-138): such records are cut out of the
+        // batch but reported at their place
+        std::vector<uint8_t> ok_bytes;
+        std::vector<uint64_t> ok_offs(1, 0);
+        std::vector<uint8_t> valid(n);
+        for (uint64_t i = 0; i < n; ++i) {
+            valid[i] = detail::valid_utf8(bytes_.data() + offsets_[i], offsets_[i + 1] - offsets_[i]);
+            if (valid[i]) {
+                ok_bytes.insert(ok_bytes.end(), bytes_.begin() + (std::ptrdiff_t)offsets_[i], bytes_.begin() + (std::ptrdiff_t)offsets_[i + 1]);
+                ok_offs.push_back(ok_bytes.size());
+            }
+        }
+        ok_bytes.resize(ok_bytes.size() + 16);  // readable slack
+        auto res = d_.decode_batch(ok_bytes.data(), ok_offs.back(), ok_offs.data(), ok_offs.size() - 1);
+        uint64_t j = 0;
+        for (uint64_t i = 0; i < n; ++i) {
+            std::string_view rec((const char*)bytes_.data() + offsets_[i], offsets_[i + 1] - offsets_[i]);
+            if (!valid[i]) {
+                on_error_("Invalid UTF-8 input", rec);
+                continue;
+            }
+            if (res[j].ok()) sink_(std::move(res[j].record));
+            else on_error_(res[j].err, rec);
+            ++j;
+        }
+        bytes_.clear();
+        offsets_.assign(1, 0);
+    }
+    size_t pending() const { return offsets_.size() - 1; }
+
+  private:
+    const Decoder& d_;
+    RecordSink sink_;
+    ErrorSink on_error_;
+    size_t max_lines_, max_bytes_;
+    long latency_;
+    std::vector<uint8_t> bytes_;
+    std::vector<uint64_t> offsets_;
+    std::chrono::steady_clock::time_point t0_{};
+};
+
+
 // LineSplitter / NulSplitter with the framing itself on the GPU: raw chunks of the stream go to
 // fg_frame_decode_batch (framing + UTF-8 validation + decode in one call); the host only carries an
 // unterminated tail over to the next chunk and reports like the reference.
@@ -403,18 +717,25 @@ class GpuFramingSplitter {
     explicit GpuFramingSplitter(Framing f, size_t chunk_bytes = 8u << 20) : f_(f), chunk_(chunk_bytes) {}
 
     void run(std::istream& in, const Decoder& d, const RecordSink& sink, std::ostream& err) {
-        std::vector<uint8_t> buf;
-        bool eof = false;
-        while (!eof || !buf.empty()) {
-            const size_t have = buf.size();
-            if (!eof) {
-                buf.resize(have + chunk_);
-                in.read((char*)buf.data() + have, (std::streamsize)chunk_);
-                const size_t got = (size_t)in.gcount();
-                buf.resize(have + got);
-                eof = got < chunk_;
-            }
+        IstreamSource src(in);
+        FlushPolicy pol;
+        pol.max_bytes = chunk_;
+        run(src, pol, d, sink, err);
+    }
+    // over a socket / pipe with the flush policy (see FlushPolicy): whatever has arrived goes to the GPU when the source runs dry
+    void run(ByteSource& src, const FlushPolicy& pol, const Decoder& d, const RecordSink& sink, std::ostream& err) {
+        chunk_ = pol.max_bytes;
+        BufferedSource in(src, pol);
+        std::vector<uint8_t> buf;  // the unterminated tail of the last chunk + what arrived since
+        for (;;) {
+            const bool got = in.read_chunk(buf, chunk_ > buf.size() ? chunk_ - buf.size() : chunk_);
+            const bool eof = in.end() == BufferedSource::Eof;
+            if (!got && in.end() != BufferedSource::None && !(eof && !buf.empty())) break;  // (at EOF the tail is a frame)
             if (buf.empty()) break;
+            if (!eof && in.end() == BufferedSource::None && !memchr(buf.data(), f_ == Line ? '\n' : 0, buf.size())) {
+                if (buf.size() >= chunk_) chunk_ *= 2;  // one frame longer than the chunk: read more
+                continue;                                // no frame is complete yet
+            }
             fg_tables t{};
             const uint64_t* off = nullptr;
             uint64_t n = 0, consumed = 0;
@@ -423,14 +744,16 @@ class GpuFramingSplitter {
             int rc = fg_frame_decode_batch(d.ctx(), d.format(), f_ == Line ? FG_FRAME_LINE : FG_FRAME_NUL, buf.data(), nbytes,
                                            eof ? 1 : 0, &t, &off, &n, &consumed);
             if (rc != FG_OK) throw std::runtime_error("fg_frame_decode_batch failed: " + std::to_string(rc));
-            if (n) emit(d, buf.data(), off, n, t, sink, err);
-            buf.resize(nbytes);
-            if (consumed == 0 && !eof && n == 0) {  // one frame longer than the chunk: read more
-                chunk_ *= 2;
-                continue;
+            if (n) {
+                Decoder::side_effects(d.format(), f_ == Line ? FG_FRAME_LINE : FG_FRAME_NUL, buf.data(), off, t);
+                emit(d, buf.data(), off, n, t, sink, err);
             }
+            buf.resize(nbytes);
+            if (consumed == 0 && !eof && n == 0 && buf.size() >= chunk_) chunk_ *= 2;  // one frame longer than the chunk: read more
             buf.erase(buf.begin(), buf.begin() + (std::ptrdiff_t)consumed);
+            if (eof || in.end() != BufferedSource::None) break;
         }
+        if (in.end() == BufferedSource::Idle) err << kIdleMessage << "\n";  // (the unterminated tail is dropped, as lines() drops it)
     }
 
   private:
@@ -492,6 +815,14 @@ class TranscodingSplitter {
     // prefixes are a sequential chain -- the host hops from prefix to prefix (it never touches the message bytes
     // otherwise) and hands the GPU the packed messages with their offsets.
     void run(std::istream& in, const Decoder& d, std::ostream& out, std::ostream& err) {
+        IstreamSource src(in);
+        FlushPolicy pol;
+        pol.max_bytes = chunk_;
+        run(src, pol, d, out, err);
+    }
+    // over a socket / pipe with the flush policy (see FlushPolicy)
+    void run(ByteSource& src, const FlushPolicy& pol, const Decoder& d, std::ostream& out, std::ostream& err) {
+        chunk_ = pol.max_bytes;
         std::vector<const char*> ks, vs;
         for (auto& kv : enc_.extra) { ks.push_back(kv.first.c_str()); vs.push_back(kv.second.c_str()); }
         fg_encode_cfg ec{};
@@ -502,39 +833,46 @@ class TranscodingSplitter {
         ec.extra_values = vs.data();
         ec.prepend = enc_.prepend ? enc_.prepend->c_str() : nullptr;
         ec.now_ts = enc_.now_ts;
+        BufferedSource bin(src, pol);
         if (f_ == Syslen) {
-            run_syslen(in, d, ec, out, err);
+            run_syslen(bin, d, ec, out, err);
             return;
         }
-        std::vector<uint8_t> buf;
-        bool eof = false;
-        while (!eof || !buf.empty()) {
-            const size_t have = buf.size();
-            if (!eof) {
-                buf.resize(have + chunk_);
-                in.read((char*)buf.data() + have, (std::streamsize)chunk_);
-                const size_t got = (size_t)in.gcount();
-                buf.resize(have + got);
-                eof = got < chunk_;
-            }
+        std::vector<uint8_t> buf;  // the unterminated tail of the last chunk + what arrived since
+        for (;;) {
+            const bool got = bin.read_chunk(buf, chunk_ > buf.size() ? chunk_ - buf.size() : chunk_);
+            const bool eof = bin.end() == BufferedSource::Eof;
+            if (!got && bin.end() != BufferedSource::None && !(eof && !buf.empty())) break;  // (at EOF the tail is a frame)
             if (buf.empty()) break;
+            if (!eof && bin.end() == BufferedSource::None && !memchr(buf.data(), f_ == Line ? '\n' : 0, buf.size())) {
+                if (buf.size() >= chunk_) chunk_ *= 2;  // one frame longer than the chunk: read more
+                continue;                                // no frame is complete yet
+            }
             fg_transcoded r{};
             int rc = fg_transcode_batch(d.ctx(), d.format(), f_ == Line ? FG_FRAME_LINE : FG_FRAME_NUL, &ec, buf.data(), buf.size(), nullptr,
                                         0, eof ? 1 : 0, &r);
             if (rc != FG_OK) throw std::runtime_error("fg_transcode_batch failed: " + std::to_string(rc));
-            if (r.out_bytes) out.write((const char*)r.out, (std::streamsize)r.out_bytes);
-            report(d, r, buf.data(), r.frame_offsets, err);
-            if (r.consumed == 0 && !eof && r.n == 0) {  // one frame longer than the chunk: read more
-                chunk_ *= 2;
-                continue;
+            if (r.out_bytes) {
+                out.write((const char*)r.out, (std::streamsize)r.out_bytes);
+                out.flush();  // (the batch is what has arrived: it goes out now, not when the stream's buffer fills)
             }
+            report(d, r, buf.data(), r.frame_offsets, err);
+            if (r.consumed == 0 && !eof && r.n == 0 && buf.size() >= chunk_) chunk_ *= 2;
             buf.erase(buf.begin(), buf.begin() + (std::ptrdiff_t)r.consumed);
+            if (eof || bin.end() != BufferedSource::None) break;
         }
+        if (bin.end() == BufferedSource::Idle) err << kIdleMessage << "\n";  // line_splitter.rs:26-33
     }
 
   private:
     // stderr for the lines the pipeline dropped, as the reference prints them
     void report(const Decoder& d, const fg_transcoded& r, const uint8_t* bytes, const uint64_t* offs, std::ostream& err) const {
+        if (r.n) {  // the decoder's stdout side effects, from the meta column alone
+            fg_tables only_meta{};
+            only_meta.n = r.n;
+            only_meta.meta = const_cast<uint32_t*>(r.meta);
+            Decoder::side_effects(d.format(), f_ == Line ? FG_FRAME_LINE : f_ == Nul ? FG_FRAME_NUL : FG_FRAME_NONE, bytes, offs, only_meta);
+        }
         for (uint64_t i = 0; i < r.n; ++i) {
             const uint8_t st = FG_META_STATUS(r.meta[i]), es = r.enc_status[i];
             if (st == 0 && es == 0) continue;
@@ -563,21 +901,25 @@ class TranscodingSplitter {
         fg_transcoded r{};
         int rc = fg_transcode_batch(d.ctx(), d.format(), FG_FRAME_NONE, &ec, bytes.data(), nbytes, offs.data(), n, 1, &r);
         if (rc != FG_OK) throw std::runtime_error("fg_transcode_batch failed: " + std::to_string(rc));
-        if (r.out_bytes) out.write((const char*)r.out, (std::streamsize)r.out_bytes);
+        if (r.out_bytes) {
+            out.write((const char*)r.out, (std::streamsize)r.out_bytes);
+            out.flush();
+        }
         report(d, r, bytes.data(), offs.data(), err);
         bytes.clear();
         offs.assign(1, 0);
     }
-    void run_syslen(std::istream& in, const Decoder& d, const fg_encode_cfg& ec, std::ostream& out, std::ostream& err) {
+    void run_syslen(BufferedSource& in, const Decoder& d, const fg_encode_cfg& ec, std::ostream& out, std::ostream& err) {
         std::vector<uint8_t> bytes;
         std::vector<uint64_t> offs(1, 0);
-        std::string num;
+        in.on_block([&] { return bytes.size() + (offs.size() - 1); }, [&] { flush_syslen(d, ec, bytes, offs, out, err); });
+        std::string num, msg;
         for (;;) {
             num.clear();
             int c;
-            while ((c = in.get()) != EOF && c != ' ') num.push_back((char)c);
-            // read_msglen (:42-57): EOF / nothing before the space / not a usize -> "Can't read message's length" (:20-25)
-            bool ok = c != EOF && !num.empty();
+            while ((c = in.get()) >= 0 && c != ' ') num.push_back((char)c);
+            // read_msglen (:42-57): EOF / idle timeout / nothing before the space / not a usize -> "Can't read message's length" (:20-25)
+            bool ok = c >= 0 && !num.empty();
             size_t len = 0, k = (ok && num[0] == '+') ? 1 : 0;
             if (ok && k >= num.size()) ok = false;
             for (; ok && k < num.size(); ++k) {
@@ -589,21 +931,18 @@ class TranscodingSplitter {
                 err << "Can't read message's length\n";
                 return;
             }
-            const size_t at = bytes.size();
-            bytes.resize(at + len);
-            in.read((char*)bytes.data() + at, (std::streamsize)len);
-            if ((size_t)in.gcount() != len) {  // read_exact fails (:27-30): the partial frame is dropped
-                bytes.resize(at);
+            msg.clear();
+            if (in.read_exact(msg, len) != len) {  // read_exact fails (:27-30): the partial frame is dropped
                 flush_syslen(d, ec, bytes, offs, out, err);
-                err << "failed to fill whole buffer\n";
+                err << (in.end() == BufferedSource::Idle ? "Resource temporarily unavailable (os error 11)\n" : "failed to fill whole buffer\n");
                 return;
             }
-            if (!detail::valid_utf8(bytes.data() + at, len)) {  // String::from_utf8(..).unwrap() panics (:33): the thread ends
-                bytes.resize(at);
+            if (!detail::valid_utf8((const uint8_t*)msg.data(), len)) {  // String::from_utf8(..).unwrap() panics (:33): the thread ends
                 flush_syslen(d, ec, bytes, offs, out, err);
                 err << "Invalid UTF-8 input\n";
                 return;
             }
+            bytes.insert(bytes.end(), msg.begin(), msg.end());
             offs.push_back(bytes.size());
             if (bytes.size() >= chunk_) flush_syslen(d, ec, bytes, offs, out, err);
         }

@@ -87,6 +87,18 @@ class HostTables:
         return blob[:int(total)], offs
 
 
+def tables_stdout(t: HostTables, fmt: int, bytes_np: np.ndarray, offsets_np: np.ndarray, framing: int = 0) -> bytes:
+    """fg_tables_stdout: what the reference decoders print to stdout while decoding these rows (ltsv_decoder.rs:99)."""
+    lib = L.lib()
+    args = (fmt, framing, bytes_np.ctypes.data, offsets_np.ctypes.data, C.byref(t.struct), 0, t.n)
+    n = lib.fg_tables_stdout(*args, None, 0)
+    if n < 0:
+        raise L.FgError(int(n), "fg_tables_stdout")
+    buf = np.zeros(max(int(n), 1), np.uint8)
+    lib.fg_tables_stdout(*args, buf.ctypes.data, int(n))
+    return buf[: int(n)].tobytes()
+
+
 class DeviceTables:
     """Tables in HBM: one torch uint8 allocation carved into the 15 arrays."""
 

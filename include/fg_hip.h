@@ -73,8 +73,13 @@ enum {
     FG_F_BOM = 16,          /* RFC5424: line started with U+FEFF (spans already skip it) */
     FG_F_GELF_RETRY = 32,   /* GELF: accepted via the '\n' -> "\\n" retry (gelf_decoder.rs:44-46); when decoding
                                escapes a backslash followed by a raw LF means backslash + 'n' */
-    FG_F_MSG_JOIN = 64      /* RFC3164 standard form: Record.msg = the msg span's whitespace-separated tokens joined
+    FG_F_MSG_JOIN = 64,     /* RFC3164 standard form: Record.msg = the msg span's whitespace-separated tokens joined
                                with single spaces (`_log_tokens[1..].join(" ")`, rfc3164_decoder.rs:70) */
+    FG_F_LTSV_NOVALUE = 128 /* LTSV: the line has tab-separated parts without ':'; the reference println!s
+                               "Missing value for name '{}'" for each while it decodes (ltsv_decoder.rs:99) -- set on Ok AND on
+                               failed rows (a failed row's hostname.off = how many parts had been reported when the decode
+                               stopped; the same number, saturated at 254, is in its facility byte for callers that only
+                               see the meta column).  fg_tables_stdout reproduces the text. */
 };
 #define FG_ST_OVERFLOW 0xFE /* status: the line's entries did not get slots: the table (ent_cap) is used up, counting the slots
                                parked in other waves' reservations (see ent_used).  Re-run with more; all other rows are valid */
@@ -390,6 +395,16 @@ const char* fg_error_string(fg_format fmt, uint8_t status);
 int64_t fg_tables_serialize(fg_format fmt, const fg_cfg* cfg, const uint8_t* bytes,
                             const uint64_t* offsets, const fg_tables* tables, uint64_t i0,
                             uint64_t i1, uint8_t* out, uint64_t cap, uint64_t* out_offsets);
+
+/* SIDE EFFECTS of decode(): the bytes the reference decoders write to the process's stdout while decoding rows [i0, i1), in row
+ * order (SURVEY 8b "Side effects"; today one statement: LTSV's `println!("Missing value for name '{}'", name)`,
+ * ltsv_decoder.rs:99 -- rows flagged FG_F_LTSV_NOVALUE).  A drop-in shim writes them to stdout after each batch.
+ * `framing` says whether [offsets[i], offsets[i+1]) still carries its terminator (frames of fg_frame_decode_batch: FG_FRAME_LINE /
+ * FG_FRAME_NUL) or is a bare line (FG_FRAME_NONE).  out may be NULL to size.  Returns the total bytes (even when > cap), or
+ * negative FG_ERR_*.  Only `meta` and `hostname` of `tables` are read; hostname may be NULL (fg_transcode_batch returns the meta
+ * column only): the count of a failed row then comes from its facility byte. */
+int64_t fg_tables_stdout(fg_format fmt, fg_framing framing, const uint8_t* bytes, const uint64_t* offsets, const fg_tables* tables,
+                         uint64_t i0, uint64_t i1, uint8_t* out, uint64_t cap);
 
 /* Multi-GPU sharding plan (host): split n lines into g contiguous ranges balanced by BYTES;
  * line_starts receives g+1 line indices (line_starts[0] = 0, line_starts[g] = n). */

@@ -22,6 +22,7 @@ use std::str;
 
 use fg_hip_sys::*;
 
+use super::rfc5424_decoder::unescape_sd_value; // the reference's own function (rfc5424_decoder.rs:105-125), made `pub(crate)` by the patch
 use super::Decoder;
 use crate::flowgger::config::Config;
 use crate::flowgger::record::{Record, SDValue, StructuredData};
@@ -37,7 +38,7 @@ pub enum GpuFormat {
 }
 
 impl GpuFormat {
-    fn raw(self) -> fg_format {
+    pub(crate) fn raw(self) -> fg_format {
         match self {
             GpuFormat::Rfc5424 => FG_RFC5424,
             GpuFormat::Ltsv => FG_LTSV,
@@ -113,6 +114,9 @@ impl GpuDecoder {
     pub(crate) fn raw_ctx(&self) -> *mut fg_ctx {
         self.ctx
     }
+    pub(crate) fn ltsv(&self) -> &LtsvSchema {
+        &self.ltsv
+    }
 }
 
 /// The IANA zone table of `fg_tz_table`: names sorted bytewise; zone i owns entries
@@ -167,12 +171,90 @@ pub trait BatchDecoder: Decoder {
 }
 
 impl Decoder for GpuDecoder {
-    /// The reference's trait method: a batch of one.
+    /// The reference's trait method: a batch of one -- one launch, one stream synchronisation and one table copy per record
+    /// (tens of microseconds; tools/host_path_bench.py --workload latency).  The per-record callers (`udp_input.rs:139`,
+    /// `redis_input.rs:159`, `file/worker.rs:116`) should go through `MicroBatcher` below instead.
     fn decode(&self, line: &str) -> Result<Record, &'static str> {
         let mut buf = Vec::with_capacity(line.len() + 16);
         buf.extend_from_slice(line.as_bytes());
         let offsets = [0u64, line.len() as u64];
         self.decode_batch(&buf, &offsets).pop().unwrap()
+    }
+    /// `Decoder::as_gpu` is a PROVIDED method the patch adds to the trait (`decoder/mod.rs:44-46`: `fn as_gpu(&self) ->
+    /// Option<&GpuDecoder> { None }`); only this impl overrides it.  It is how `GpuSplitter::run`, which receives a
+    /// `Box<dyn Decoder>` like every splitter (`splitter/mod.rs:18-26`), gets at the ctx.
+    fn as_gpu(&self) -> Option<&GpuDecoder> {
+        Some(self)
+    }
+}
+
+/// The per-record callers' adapter (`input/udp_input.rs:78-88`, `input/redis_input.rs:150-165`, `input/file/worker.rs:110-120`
+/// call `decoder.decode(record)` once per record): records are parked for at most `max_latency` (or until `max_lines` are there)
+/// and decoded in ONE GPU call; results come back in arrival order through `deliver`.  The UDP loop becomes
+/// ```ignore
+/// socket.set_read_timeout(mb.wait())?;                 // None = block: nothing is parked
+/// match socket.recv_from(&mut buf) { Ok((n, _)) => mb.push(&buf[..n]), Err(_) => {} }
+/// mb.poll(|res, rec| match res.and_then(|r| encoder.encode(r)) { Ok(b) => tx.send(b).unwrap(), Err(e) => { let _ = writeln!(stderr(), "{}", e); } });
+/// ```
+pub struct MicroBatcher<'a> {
+    decoder: &'a GpuDecoder,
+    bytes: Vec<u8>,
+    offsets: Vec<u64>,
+    first: Option<std::time::Instant>,
+    max_lines: usize,
+    max_latency: std::time::Duration,
+}
+
+impl<'a> MicroBatcher<'a> {
+    pub fn new(decoder: &'a GpuDecoder, max_lines: usize, max_latency: std::time::Duration) -> MicroBatcher<'a> {
+        MicroBatcher { decoder, bytes: Vec::new(), offsets: vec![0], first: None, max_lines, max_latency }
+    }
+    /// One record (`handle_record`, `udp_input.rs:125-143`); invalid UTF-8 is reported at its place by `poll` / `flush`.
+    pub fn push(&mut self, record: &[u8]) {
+        if self.first.is_none() {
+            self.first = Some(std::time::Instant::now());
+        }
+        self.bytes.extend_from_slice(record);
+        self.offsets.push(self.bytes.len() as u64);
+    }
+    /// How long the caller may block in its receive call before `poll` is due; `None` = nothing is parked.
+    pub fn wait(&self) -> Option<std::time::Duration> {
+        self.first.map(|t| self.max_latency.checked_sub(t.elapsed()).unwrap_or(std::time::Duration::from_millis(1)))
+    }
+    /// Decodes what is parked when it is due (full, or the oldest record has waited `max_latency`).
+    pub fn poll<F: FnMut(Result<Record, &'static str>, &[u8])>(&mut self, deliver: F) {
+        let due = self.offsets.len() - 1 >= self.max_lines || self.first.map_or(false, |t| t.elapsed() >= self.max_latency);
+        if due {
+            self.flush(deliver);
+        }
+    }
+    pub fn flush<F: FnMut(Result<Record, &'static str>, &[u8])>(&mut self, mut deliver: F) {
+        let n = self.offsets.len() - 1;
+        if n == 0 {
+            return;
+        }
+        // "Invalid UTF-8 input" (udp_input.rs:135-138) never reaches decode(): such records are cut out of the batch
+        let valid: Vec<bool> = (0..n).map(|i| str::from_utf8(&self.bytes[self.offsets[i] as usize..self.offsets[i + 1] as usize]).is_ok()).collect();
+        let mut ok_bytes = Vec::with_capacity(self.bytes.len() + 16);
+        let mut ok_offs = vec![0u64];
+        for i in 0..n {
+            if valid[i] {
+                ok_bytes.extend_from_slice(&self.bytes[self.offsets[i] as usize..self.offsets[i + 1] as usize]);
+                ok_offs.push(ok_bytes.len() as u64);
+            }
+        }
+        let mut res = self.decoder.decode_batch(&ok_bytes, &ok_offs).into_iter();
+        for i in 0..n {
+            let rec = &self.bytes[self.offsets[i] as usize..self.offsets[i + 1] as usize];
+            if valid[i] {
+                deliver(res.next().unwrap(), rec);
+            } else {
+                deliver(Err("Invalid UTF-8 input"), rec);
+            }
+        }
+        self.bytes.clear();
+        self.offsets.truncate(1);
+        self.first = None;
     }
 }
 
@@ -295,28 +377,6 @@ pub unsafe fn materialise(fmt: GpuFormat, ltsv: &LtsvSchema, t: &fg_tables, byte
         full_msg,
         sd: if sd_vec.is_empty() { None } else { Some(sd_vec) },
     })
-}
-
-/// rfc5424_decoder.rs:105-125, byte for byte.
-fn unescape_sd_value(value: &str) -> String {
-    let mut res = "".to_owned();
-    let mut esc = false;
-    for c in value.chars() {
-        match (c, esc) {
-            ('\\', false) => esc = true,
-            (_, false) => res.push(c),
-            ('"', true) | ('\\', true) | (']', true) => {
-                res.push(c);
-                esc = false;
-            }
-            (_, true) => {
-                res.push('\\');
-                res.push(c);
-                esc = false;
-            }
-        }
-    }
-    res
 }
 
 /// serde_json 0.8's `parse_escape` over an ALREADY VALIDATED string body (the kernel rejected malformed escapes).

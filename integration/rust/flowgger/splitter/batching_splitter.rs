@@ -1,142 +1,204 @@
-//! batching_splitter.rs -- `LineSplitter` / `NulSplitter` with ONE GPU call per chunk of the stream instead of one
-//! `decoder.decode()` per line.  Drop into `src/flowgger/splitter/` (replaces the `run` bodies of
-//! `line_splitter.rs:10-41` and `nul_splitter.rs:10-60`; `handle_line`, `line_splitter.rs:44-54`, becomes the loop over a
-//! batch's results).  Two variants:
+//! batching_splitter.rs -- `LineSplitter` / `NulSplitter` with ONE GPU call per batch of the stream instead of one
+//! `decoder.decode()` per line.  Drop into `src/flowgger/splitter/` beside `line_splitter.rs`; `GpuSplitter` implements the
+//! reference's `Splitter<T>` (`splitter/mod.rs:18-26`), so an input selects it exactly like the others
+//! (`stdin_input.rs:57-64`, `tcp_input.rs:77-84`: one more arm in the `match &config.framing`).  Two bodies:
 //!   * `run_decode`    raw chunk -> `fg_frame_decode_batch` (GPU framing + UTF-8 validation + decode); `Record`s are
-//!                     materialised on the host and go through the unchanged `Encoder` trait objects;
+//!                     materialised on the host and go through the unchanged `Encoder` trait object (what `run` uses);
 //!   * `run_transcode` raw chunk -> `fg_transcode_batch` (framing + decode + encode + merger on the GPU): only the
 //!                     encoded, already framed bytes come back -- for the encoders libfg_hip provides (all but capnp).
-//! Per-connection order and the reference's stderr messages are preserved.
-use std::io::{stderr, BufReader, Read, Write};
+//! WHEN a batch goes to the GPU (the reference handles every line the moment `lines()` yields it, `line_splitter.rs:17`): when
+//! `max_bytes` have accumulated, or -- the usual case on a live connection -- when a read returns LESS than it could hold: the
+//! peer has nothing more in flight right now, so what has arrived is decoded now instead of waiting for a full chunk.  A read
+//! timeout (`ErrorKind::WouldBlock`, `input.timeout` via `tcp_input.rs:41`) decodes the complete lines that are buffered, prints
+//! the reference's message and ends the connection (`line_splitter.rs:26-33`, `nul_splitter.rs:22-29`); the unterminated tail is
+//! dropped exactly as `lines()` drops it.  Per-connection order and the reference's stderr / stdout texts are preserved.
+use std::io::{stderr, stdout, BufRead, BufReader, ErrorKind, Read, Write};
 use std::ptr;
 use std::sync::mpsc::SyncSender;
 
 use fg_hip_sys::*;
 
-use crate::flowgger::decoder::gpu_decoder::{error_str, host_slice, materialise, GpuDecoder, LtsvSchema};
+use super::Splitter;
+use crate::flowgger::decoder::gpu_decoder::{error_str, host_slice, materialise, GpuDecoder};
+use crate::flowgger::decoder::Decoder;
 use crate::flowgger::encoder::Encoder;
 
-const CHUNK: usize = 8 << 20;
+/// A batch never grows beyond this (the GPU path runs at link speed long before).
+const MAX_BYTES: usize = 8 << 20;
 
 pub struct GpuSplitter {
     pub framing: fg_framing, // FG_FRAME_LINE (lines()) or FG_FRAME_NUL (split(0))
 }
 
+/// How a `fill` ended.
+#[derive(PartialEq, Eq, Clone, Copy)]
+enum Fill {
+    Data,  // bytes were added and the source has nothing more right now (or the batch is full)
+    Eof,   // end of the stream (bytes may have been added before it)
+    Idle,  // ErrorKind::WouldBlock: the read timeout expired
+    Error, // any other error: the reference's `_ => return`
+}
+
+impl<T: Read> Splitter<T> for GpuSplitter {
+    /// The reference's signature (`splitter/mod.rs:18-26`).  The boxed decoder is a `GpuDecoder` when the configuration
+    /// selected one (`Decoder::as_gpu`, a provided trait method that only `GpuDecoder` overrides -- INTEGRATION.md section 3);
+    /// with any other decoder this splitter has nothing to batch for.
+    fn run(&self, buf_reader: BufReader<T>, tx: SyncSender<Vec<u8>>, decoder: Box<dyn Decoder>, encoder: Box<dyn Encoder>) {
+        let gpu = decoder.as_gpu().expect("framing = \"gpu-line\" / \"gpu-nul\" needs a GPU decoder (input.format + input.gpu = true)");
+        self.run_decode(buf_reader, tx, gpu, encoder)
+    }
+}
+
 impl GpuSplitter {
-    pub fn run_decode<T: Read>(&self, mut reader: BufReader<T>, tx: SyncSender<Vec<u8>>, decoder: GpuDecoder, encoder: Box<dyn Encoder>, ltsv: &LtsvSchema) {
-        let mut buf: Vec<u8> = Vec::with_capacity(2 * CHUNK);
-        let mut eof = false;
-        while !eof || !buf.is_empty() {
-            eof = eof || fill(&mut reader, &mut buf, CHUNK) == 0;
-            if buf.is_empty() {
-                break;
-            }
-            let nbytes = buf.len();
-            buf.resize(nbytes + 16, 0); // readable slack
-            let mut t: fg_tables = unsafe { std::mem::zeroed() };
-            let (mut off, mut n, mut used) = (ptr::null(), 0u64, 0u64);
-            let rc = unsafe {
-                fg_frame_decode_batch(decoder.raw_ctx(), fmt_of(&decoder), self.framing, buf.as_ptr(), nbytes as u64, eof as i32, &mut t, &mut off, &mut n, &mut used)
-            };
-            assert_eq!(rc, FG_OK, "fg_frame_decode_batch failed: {}", rc);
-            let offs = unsafe { host_slice(off, n + 1) };
-            for i in 0..n as usize {
-                let frame = &buf[offs[i] as usize..offs[i + 1] as usize];
-                let status = FG_META_STATUS(unsafe { *t.meta.add(i) });
-                if status == FG_ST_BAD_UTF8 {
-                    let _ = writeln!(stderr(), "Invalid UTF-8 input"); // line_splitter.rs:22-25, nul_splitter.rs:35-38
-                    continue;
-                }
-                let res = unsafe { materialise(decoder.format(), ltsv, &t, &buf, offs[i] as usize, i) }.and_then(|r| encoder.encode(r));
-                match res {
-                    Ok(bytes) => tx.send(bytes).unwrap(), // line_splitter.rs:52
-                    Err(e) => {
-                        let text = String::from_utf8_lossy(frame);
-                        let text = text.trim();
-                        if self.framing == FG_FRAME_NUL && text.is_empty() {
-                            continue; // nul_splitter.rs:41-46
+    pub fn run_decode<T: Read>(&self, mut reader: BufReader<T>, tx: SyncSender<Vec<u8>>, decoder: &GpuDecoder, encoder: Box<dyn Encoder>) {
+        let mut buf: Vec<u8> = Vec::with_capacity(2 * MAX_BYTES);
+        loop {
+            let how = fill(&mut reader, &mut buf, MAX_BYTES);
+            let last = how != Fill::Data;
+            let eof = how == Fill::Eof;
+            if !buf.is_empty() && (eof || has_frame(&buf, self.framing)) {
+                let nbytes = buf.len();
+                buf.resize(nbytes + 16, 0); // readable slack
+                let mut t: fg_tables = unsafe { std::mem::zeroed() };
+                let (mut off, mut n, mut used) = (ptr::null(), 0u64, 0u64);
+                let rc = unsafe {
+                    fg_frame_decode_batch(decoder.raw_ctx(), decoder.format().raw(), self.framing, buf.as_ptr(), nbytes as u64, eof as i32, &mut t, &mut off, &mut n, &mut used)
+                };
+                assert_eq!(rc, FG_OK, "fg_frame_decode_batch failed: {}", rc);
+                let offs = unsafe { host_slice(off, n + 1) };
+                print_side_effects(decoder, self.framing, &buf, offs, &t, n);
+                for i in 0..n as usize {
+                    let frame = &buf[offs[i] as usize..offs[i + 1] as usize];
+                    let status = FG_META_STATUS(unsafe { *t.meta.add(i) });
+                    if status == FG_ST_BAD_UTF8 {
+                        let _ = writeln!(stderr(), "Invalid UTF-8 input"); // line_splitter.rs:22-25, nul_splitter.rs:35-38
+                        continue;
+                    }
+                    let res = unsafe { materialise(decoder.format(), decoder.ltsv(), &t, &buf, offs[i] as usize, i) }.and_then(|r| encoder.encode(r));
+                    match res {
+                        Ok(bytes) => tx.send(bytes).unwrap(), // line_splitter.rs:52
+                        Err(e) => {
+                            let text = String::from_utf8_lossy(frame);
+                            let text = text.trim();
+                            if self.framing == FG_FRAME_NUL && text.is_empty() {
+                                continue; // nul_splitter.rs:41-46
+                            }
+                            let _ = writeln!(stderr(), "{}: [{}]", e, text); // line_splitter.rs:37-39
                         }
-                        let _ = writeln!(stderr(), "{}: [{}]", e, text); // line_splitter.rs:37-39
                     }
                 }
+                buf.truncate(nbytes);
+                buf.drain(..used as usize); // an unterminated tail waits for more bytes
             }
-            buf.truncate(nbytes);
-            if used == 0 && n == 0 && !eof {
-                continue; // one frame longer than the chunk: read more
+            if last {
+                if how == Fill::Idle {
+                    // line_splitter.rs:26-33 / nul_splitter.rs:22-29; the partial line goes with the iterator, as in the reference
+                    let _ = writeln!(stderr(), "Client hasn't sent any data for a while - Closing idle connection");
+                }
+                return;
             }
-            buf.drain(..used as usize); // an unterminated tail waits for more bytes
         }
     }
 
-    pub fn run_transcode<T: Read>(&self, mut reader: BufReader<T>, tx: SyncSender<Vec<u8>>, decoder: GpuDecoder, enc: &fg_encode_cfg) {
-        let mut buf: Vec<u8> = Vec::with_capacity(2 * CHUNK);
-        let mut eof = false;
-        while !eof || !buf.is_empty() {
-            eof = eof || fill(&mut reader, &mut buf, CHUNK) == 0;
-            if buf.is_empty() {
-                break;
-            }
-            let nbytes = buf.len();
-            buf.resize(nbytes + 16, 0);
-            let mut r: fg_transcoded = unsafe { std::mem::zeroed() };
-            let rc = unsafe {
-                fg_transcode_batch(decoder.raw_ctx(), fmt_of(&decoder), self.framing, enc, buf.as_ptr(), nbytes as u64, ptr::null(), 0, eof as i32, &mut r)
-            };
-            assert_eq!(rc, FG_OK, "fg_transcode_batch failed: {}", rc);
-            let (out, offs, meta, es, frames) = unsafe {
-                (host_slice(r.out, r.out_bytes), host_slice(r.out_offsets, r.n + 1), host_slice(r.meta, r.n), host_slice(r.enc_status, r.n), host_slice(r.frame_offsets, r.n + 1))
-            };
-            for i in 0..r.n as usize {
-                let status = FG_META_STATUS(meta[i]);
-                let text = || String::from_utf8_lossy(&buf[frames[i] as usize..frames[i + 1] as usize]).trim().to_owned();
-                if status == FG_ST_BAD_UTF8 {
-                    let _ = writeln!(stderr(), "Invalid UTF-8 input");
-                } else if status != 0 {
-                    let t = text();
-                    if !(self.framing == FG_FRAME_NUL && t.is_empty()) {
-                        let _ = writeln!(stderr(), "{}: [{}]", error_str(decoder.format(), status), t);
+    pub fn run_transcode<T: Read>(&self, mut reader: BufReader<T>, tx: SyncSender<Vec<u8>>, decoder: &GpuDecoder, enc: &fg_encode_cfg) {
+        let mut buf: Vec<u8> = Vec::with_capacity(2 * MAX_BYTES);
+        loop {
+            let how = fill(&mut reader, &mut buf, MAX_BYTES);
+            let last = how != Fill::Data;
+            let eof = how == Fill::Eof;
+            if !buf.is_empty() && (eof || has_frame(&buf, self.framing)) {
+                let nbytes = buf.len();
+                buf.resize(nbytes + 16, 0);
+                let mut r: fg_transcoded = unsafe { std::mem::zeroed() };
+                let rc = unsafe {
+                    fg_transcode_batch(decoder.raw_ctx(), decoder.format().raw(), self.framing, enc, buf.as_ptr(), nbytes as u64, ptr::null(), 0, eof as i32, &mut r)
+                };
+                assert_eq!(rc, FG_OK, "fg_transcode_batch failed: {}", rc);
+                let (out, offs, meta, es, frames) = unsafe {
+                    (host_slice(r.out, r.out_bytes), host_slice(r.out_offsets, r.n + 1), host_slice(r.meta, r.n), host_slice(r.enc_status, r.n), host_slice(r.frame_offsets, r.n + 1))
+                };
+                // only the meta column came back: fg_tables_stdout takes a failed row's count from its facility byte
+                let mut only_meta: fg_tables = unsafe { std::mem::zeroed() };
+                only_meta.n = r.n;
+                only_meta.meta = r.meta as *mut u32;
+                print_side_effects(decoder, self.framing, &buf, frames, &only_meta, r.n);
+                for i in 0..r.n as usize {
+                    let status = FG_META_STATUS(meta[i]);
+                    let text = || String::from_utf8_lossy(&buf[frames[i] as usize..frames[i + 1] as usize]).trim().to_owned();
+                    if status == FG_ST_BAD_UTF8 {
+                        let _ = writeln!(stderr(), "Invalid UTF-8 input");
+                    } else if status != 0 {
+                        let t = text();
+                        if !(self.framing == FG_FRAME_NUL && t.is_empty()) {
+                            let _ = writeln!(stderr(), "{}: [{}]", error_str(decoder.format(), status), t);
+                        }
+                    } else if es[i] > 1 {
+                        let e = unsafe { std::ffi::CStr::from_ptr(fg_encode_error_string(es[i])) }.to_string_lossy();
+                        let _ = writeln!(stderr(), "{}: [{}]", e, text());
+                    } else {
+                        // one message per send keeps the outputs' queue semantics (line_splitter.rs:52); the messages are
+                        // already framed by the merger, so an output that writes the queue back to back may also take
+                        // `out` whole
+                        tx.send(out[offs[i] as usize..offs[i + 1] as usize].to_vec()).unwrap();
                     }
-                } else if es[i] > 1 {
-                    let e = unsafe { std::ffi::CStr::from_ptr(fg_encode_error_string(es[i])) }.to_string_lossy();
-                    let _ = writeln!(stderr(), "{}: [{}]", e, text());
-                } else {
-                    // one message per send keeps the outputs' queue semantics (line_splitter.rs:52); the messages are
-                    // already framed by the merger, so an output that writes the queue back to back may also take
-                    // `out` whole
-                    tx.send(out[offs[i] as usize..offs[i + 1] as usize].to_vec()).unwrap();
                 }
+                buf.truncate(nbytes);
+                buf.drain(..r.consumed as usize);
             }
-            buf.truncate(nbytes);
-            if r.consumed == 0 && r.n == 0 && !eof {
-                continue;
+            if last {
+                if how == Fill::Idle {
+                    let _ = writeln!(stderr(), "Client hasn't sent any data for a while - Closing idle connection");
+                }
+                return;
             }
-            buf.drain(..r.consumed as usize);
         }
     }
 }
 
-fn fmt_of(d: &GpuDecoder) -> fg_format {
-    use crate::flowgger::decoder::gpu_decoder::GpuFormat::*;
-    match d.format() {
-        Rfc5424 => FG_RFC5424,
-        Ltsv => FG_LTSV,
-        Gelf => FG_GELF,
-        Rfc3164 => FG_RFC3164,
+/// The decoder's stdout side effects for the rows of a batch (`ltsv_decoder.rs:99`: `println!("Missing value for name '{}'")`):
+/// rows flagged FG_F_LTSV_NOVALUE, text rebuilt by the library from the frames.
+fn print_side_effects(decoder: &GpuDecoder, framing: fg_framing, buf: &[u8], offs: &[u64], t: &fg_tables, n: u64) {
+    if n == 0 || decoder.format().raw() != FG_LTSV {
+        return;
     }
+    let need = unsafe { fg_tables_stdout(decoder.format().raw(), framing, buf.as_ptr(), offs.as_ptr(), t, 0, n, ptr::null_mut(), 0) };
+    if need <= 0 {
+        return;
+    }
+    let mut text = vec![0u8; need as usize];
+    unsafe { fg_tables_stdout(decoder.format().raw(), framing, buf.as_ptr(), offs.as_ptr(), t, 0, n, text.as_mut_ptr(), need as u64) };
+    let _ = stdout().write_all(&text);
 }
 
-fn fill<T: Read>(reader: &mut BufReader<T>, buf: &mut Vec<u8>, want: usize) -> usize {
-    let have = buf.len();
-    buf.resize(have + want, 0);
-    let mut got = 0;
-    while got < want {
-        match reader.read(&mut buf[have + got..]) {
-            Ok(0) => break,
-            Ok(k) => got += k,
-            Err(ref e) if e.kind() == std::io::ErrorKind::Interrupted => continue,
-            Err(_) => break,
+/// Is there at least one complete frame in `buf`?  (A batch without one would be a GPU call for nothing.)
+fn has_frame(buf: &[u8], framing: fg_framing) -> bool {
+    let delim = if framing == FG_FRAME_NUL { 0u8 } else { b'\n' };
+    buf.contains(&delim)
+}
+
+/// Append what the source has to `buf`: blocks for the first bytes (the read timeout of the socket applies), then keeps taking
+/// what `BufReader` gets per read while each read fills its whole buffer -- a SHORT read means the peer has nothing more in
+/// flight, and the batch goes out.  (`BufReader::with_capacity(1 << 20, ..)` in the input keeps the syscall count down; the
+/// reference's 8 KiB default works, 32 lines per read.)
+fn fill<T: Read>(reader: &mut BufReader<T>, buf: &mut Vec<u8>, max_bytes: usize) -> Fill {
+    let cap = reader.capacity();
+    let mut added = 0usize;
+    loop {
+        let chunk = match reader.fill_buf() {
+            Ok(c) => c,
+            Err(ref e) if e.kind() == ErrorKind::Interrupted => continue, // line_splitter.rs:21
+            Err(ref e) if e.kind() == ErrorKind::WouldBlock => return Fill::Idle,
+            Err(_) => return Fill::Error,
+        };
+        let k = chunk.len();
+        if k == 0 {
+            return Fill::Eof;
+        }
+        buf.extend_from_slice(chunk);
+        reader.consume(k);
+        added += k;
+        if k < cap || added >= max_bytes {
+            return Fill::Data; // a short read: nothing more is pending -- or the batch is full
         }
     }
-    buf.truncate(have + got);
-    got
 }

@@ -596,6 +596,9 @@ bool ltsv_parse_ts(sv s, double* out, const char** err) {  // :263-267
     *err = ELTSV_ENGLISH;
     return false;
 }
+// what the decoders write to the process's stdout while decoding (ltsv_decoder.rs:99 is the only such statement): collected
+// here when a caller asks for it (fgo_decode_stdout), dropped otherwise
+static thread_local std::string* g_stdout_capture = nullptr;
 Result decode_ltsv(sv line, const LtsvCfg& cfg) {  // :87-221
     Result r;
     StructuredData sd;
@@ -607,7 +610,12 @@ Result decode_ltsv(sv line, const LtsvCfg& cfg) {  // :87-221
         sv part = line.substr(pos, tab == sv::npos ? sv::npos : tab - pos);
         size_t colon = part.find(':');
         if (colon == sv::npos) {
-            // :99 println!("Missing value for name '{}'") -- stdout side effect only
+            // :99 println!("Missing value for name '{}'", name) -- stdout side effect only; the name is the whole part
+            if (g_stdout_capture) {
+                g_stdout_capture->append("Missing value for name '");
+                g_stdout_capture->append(part.data(), part.size());
+                g_stdout_capture->append("'\n");
+            }
         } else {
             sv name = part.substr(0, colon), value = part.substr(colon + 1);
             if (name == "time") {
@@ -1929,6 +1937,20 @@ int64_t fgo_decode(int fmt, const fgo_ltsv_cfg* cfg, const uint8_t* line, uint64
     Sink k{out, cap};
     serialise(r, &k);
     return (int64_t)k.n;
+}
+
+// The bytes Decoder::decode(line) writes to the process's stdout (SURVEY 8b "Side effects": LTSV's println!, ltsv_decoder.rs:99).
+// Returns the length (even when > cap).
+int64_t fgo_decode_stdout(int fmt, const fgo_ltsv_cfg* cfg, const uint8_t* line, uint64_t len, uint8_t* out, uint64_t cap) {
+    if (fmt < 0 || fmt > 3) return -1;
+    LtsvCfg c = make_cfg(cfg);
+    std::string text;
+    g_stdout_capture = &text;
+    Result r = decode_any(fmt, c, sv((const char*)line, len));
+    (void)r;
+    g_stdout_capture = nullptr;
+    if (out && text.size() <= cap) memcpy(out, text.data(), text.size());
+    return (int64_t)text.size();
 }
 
 int64_t fgo_decode_batch(int fmt, const fgo_ltsv_cfg* cfg, const uint8_t* bytes, const uint64_t* offsets, uint64_t n,

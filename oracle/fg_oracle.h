@@ -62,6 +62,10 @@ int64_t fgo_decode_batch(int fmt, const fgo_ltsv_cfg* cfg, const uint8_t* bytes,
                          const uint64_t* offsets, uint64_t n, uint8_t* out, uint64_t cap,
                          uint64_t* out_offsets, int threads);
 
+/* The bytes Decoder::decode(line) writes to the process's stdout (LTSV: println!("Missing value for name '{}'"), ltsv_decoder.rs:99);
+ * returns the length (even when > cap). */
+int64_t fgo_decode_stdout(int fmt, const fgo_ltsv_cfg* cfg, const uint8_t* line, uint64_t len, uint8_t* out, uint64_t cap);
+
 /* CPU-baseline timing leg: decode n lines into owned Record objects (one heap string per
  * field, like the reference) with `threads` std::threads; returns wall seconds for ONE pass.
  * *checksum receives a value that depends on every record (defeats dead-code elimination);

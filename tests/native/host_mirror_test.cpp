@@ -1,6 +1,9 @@
 // Exercises the C++ host mirror (flowgger_amd/host/fg_decoder.hpp): frames a file like the
 // reference splitters, decodes in batches on the GPU, prints one hex canonical Record per Ok line
 // on stdout and the reference's error lines on stderr.  usage: host_mirror_test <rfc5424|ltsv|gelf> <line|nul|syslen|gpu-line|gpu-nul|pipe-line|pipe-nul|pipe-syslen> <file> [batch]
+//        host_mirror_test <fmt> <fd-line|fd-gpu-line|fd-pipe-line|fd-syslen> - <idle_timeout_ms> [max_latency_ms]   frames STDIN (a pipe / socket)
+//            with the flush policy of fg::FlushPolicy: what has arrived is decoded when the source runs dry, the idle timeout closes
+//        host_mirror_test <fmt> micro <file> <max_lines> [max_latency_ms]   the per-record callers' adapter: one push() per line of the file
 #include <cstdio>
 #include <fstream>
 #include <iostream>
@@ -28,6 +31,47 @@ int main(int argc, char** argv) {
         for (unsigned char ch : c) printf("%02x", ch);
         printf("\n");
     };
+    if (fr.rfind("fd-", 0) == 0) {  // a live source: stdin
+        fg::FdSource src(0);
+        fg::FlushPolicy pol;
+        pol.idle_timeout_ms = argc > 4 ? atoi(argv[4]) : -1;
+        if (argc > 5) pol.max_latency_ms = atoi(argv[5]);
+        auto flush_sink = [&](fg::Record&& r) {
+            hex_sink(std::move(r));
+            fflush(stdout);
+        };
+        if (fr == "fd-line" || fr == "fd-syslen") {
+            fg::BatchingSplitter sp(fr == "fd-line" ? fg::BatchingSplitter::Line : fg::BatchingSplitter::Syslen);
+            sp.run(src, pol, *clone, flush_sink, std::cerr);
+        } else if (fr == "fd-gpu-line") {
+            fg::GpuFramingSplitter sp(fg::GpuFramingSplitter::Line);
+            sp.run(src, pol, *clone, flush_sink, std::cerr);
+        } else {
+            fg::EncoderConfig ec;
+            ec.encoder = FG_ENC_GELF;
+            ec.merger = FG_MERGE_LINE;
+            fg::TranscodingSplitter sp(fg::TranscodingSplitter::Line, ec);
+            sp.run(src, pol, *clone, std::cout, std::cerr);
+        }
+        fflush(stdout);
+        return 0;
+    }
+    if (fr == "micro") {  // udp_input.rs:78-88 with the micro-batching adapter: one record per push()
+        fg::MicroBatcher mb(*clone, hex_sink, [](const char* e, std::string_view) { std::cerr << e << "\n"; },
+                            argc > 4 ? (size_t)atoi(argv[4]) : 4096, argc > 5 ? atoi(argv[5]) : 5);
+        std::ifstream min(argv[3], std::ios::binary);
+        std::string rec;
+        size_t pushed = 0, max_pending = 0;
+        while (std::getline(min, rec, '\n')) {
+            mb.push(rec);
+            mb.poll();
+            ++pushed;
+            if (mb.pending() > max_pending) max_pending = mb.pending();
+        }
+        mb.flush();
+        fprintf(stderr, "micro: %zu records, at most %zu parked\n", pushed, max_pending);
+        return 0;
+    }
     if (fr == "pipe-line" || fr == "pipe-nul" || fr == "pipe-syslen") {  // the whole handle_line on the GPU: encoded GELF stream on stdout
         fg::EncoderConfig ec;
         ec.encoder = FG_ENC_GELF;

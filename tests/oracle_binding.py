@@ -201,6 +201,17 @@ class Oracle:
         n = self.lib.fgo_dtoa(v, buf, 64)
         return buf.raw[:n].decode()
 
+    def decode_stdout(self, fmt: int, line: bytes, config=None) -> bytes:
+        """what Decoder::decode(line) prints to stdout (ltsv_decoder.rs:99)"""
+        cfg, keep = self.make_cfg(config)
+        cfgp = C.byref(cfg) if cfg is not None else None
+        self.lib.fgo_decode_stdout.restype = C.c_int64
+        self.lib.fgo_decode_stdout.argtypes = [C.c_int, C.c_void_p, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64]
+        n = self.lib.fgo_decode_stdout(fmt, cfgp, line, len(line), None, 0)
+        buf = C.create_string_buffer(int(n) + 1)
+        self.lib.fgo_decode_stdout(fmt, cfgp, line, len(line), buf, n)
+        return buf.raw[:n]
+
     def bench(self, fmt: int, data: np.ndarray, offsets: np.ndarray, threads: int, config=None):
         cfg, keep = self.make_cfg(config)
         cfgp = C.byref(cfg) if cfg is not None else None

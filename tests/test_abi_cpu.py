@@ -142,3 +142,40 @@ def test_serialize_hand_built_rows(oracle):
     a["meta"][0] = 13
     blob, _ = t.serialize(0, data, offsets)
     assert str(parse_canonical(blob.tobytes())) == "Missing log message"
+
+
+LTSV_NOVALUE_LINES = [
+    b"time:1\thost:h\tnovalue\tmessage:m", b"novalue1\tnovalue2\ttime:1\thost:h", b"time:1\thost:h\t", b"\t\ttime:1\thost:h",
+    b"a\tlevel:9\tb\ttime:1\thost:h", b"a\tb\tcounter:x\tc", b"time:1\thost:h\tlevel:3\tx y z\tscore:-4", b"nothing at all",
+    b"", b"time:bad\tq", b"q\ttime:bad\tr", b"time:1\tq", b"k:v\tq\thost:h",
+    "time:1\thost:h\tcaf\u00e9 \u4e2d\tmessage:ok".encode(),
+]
+
+
+def test_tables_stdout_reproduces_the_ltsv_println(oracle):
+    """fg_tables_stdout (SURVEY 8b "Side effects", ltsv_decoder.rs:99): from rows flagged FG_F_LTSV_NOVALUE -- built here from the
+    oracle's verdicts, by the kernels on the GPU (tests/test_gpu_round3.py) -- the exact text the reference prints, in order, and
+    only for the parts it reached before a failing one."""
+    from flowgger_amd import synth
+    from flowgger_amd.tables import tables_stdout
+
+    lines = LTSV_NOVALUE_LINES
+    data, offsets = synth.pack(lines)
+    data = np.concatenate([data, np.zeros(16, np.uint8)])
+    t = _host_tables(len(lines), 1)
+    want = b""
+    for i, ln in enumerate(lines):
+        text = oracle.decode_stdout(1, ln, synth.LTSV_CONFIG)
+        res = parse_canonical(oracle.decode(1, ln, synth.LTSV_CONFIG))
+        failed = isinstance(res, DecodeError)
+        k = text.count(b"\n")
+        t.a["meta"][i] = (7 if failed else 0) | (0xFF << 8) | (0xFF << 16) | ((128 if k else 0) << 24)
+        t.a["hostname"].reshape(-1, 2)[i] = (k, 0xFFFFFFFF) if failed else (0, 1)
+        want += text
+    assert want.count(b"Missing value for name '") >= 12
+    assert tables_stdout(t, 1, data, offsets) == want
+    # frames that still carry their terminators
+    for framing, term in ((1, b"\r\n"), (2, b"\0")):
+        fdata, foffs = synth.pack([ln + term for ln in lines])
+        fdata = np.concatenate([fdata, np.zeros(16, np.uint8)])
+        assert tables_stdout(t, 1, fdata, foffs, framing=framing) == want

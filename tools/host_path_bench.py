@@ -8,7 +8,51 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from flowgger_amd import RFC5424Decoder, synth  # noqa: E402
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+if "--workload" in sys.argv and sys.argv[sys.argv.index("--workload") + 1] == "latency":
+    # the per-record callers (udp_input.rs:139, redis_input.rs:159, file/worker.rs:116) call decode() once per
+    # record = a batch of one.  Sweep of the batch size through fg_decode_batch (host buffers, pinned): microseconds per call and
+    # lines/s -- where the GPU path overtakes one CPU thread (BENCH cpu_baseline.single_thread, ~8 M lines/s = 0.12 us per line).
+    import ctypes as C
+    import json
+
+    import numpy as np
+
+    from flowgger_amd import _lib as L
+
+    lines = synth.rfc5424_lines(4_000_000 if "--full" in sys.argv else 1_000_000, cfg=2)
+    data, offsets = synth.pack(lines)
+    dec = RFC5424Decoder()
+
+    def pinned_copy(a):
+        p = C.c_void_p()
+        L.check(L.lib().fg_alloc_pinned(a.nbytes + 32, C.byref(p)), "fg_alloc_pinned")
+        buf = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (a.nbytes,)).view(a.dtype)
+        buf[:] = a
+        return buf
+
+    pdata, poffs = pinned_copy(data), pinned_copy(offsets)
+    rows = []
+    for b in (1, 8, 64, 512, 1024, 4096, 16384, 65536, 262144, len(lines)):
+        if b > len(lines):
+            continue
+        st = L.fg_tables()
+        nb = int(offsets[b])
+        reps = max(3, min(2000, int(2_000_000 / b)))
+
+        def call():
+            L.check(L.lib().fg_decode_batch(dec._ctx, dec.fmt, pdata.ctypes.data, nb, poffs.ctypes.data, b, C.byref(st)), "fg_decode_batch")
+
+        for _ in range(3):
+            call()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            call()
+        dt = (time.perf_counter() - t0) / reps
+        rows.append({"batch_lines": b, "us_per_call": dt * 1e6, "us_per_line": dt * 1e6 / b, "lines_per_s": b / dt})
+        print(f"batch {b:>8} lines: {dt * 1e6:10.1f} us per call, {dt * 1e6 / b:9.3f} us per line, {b / dt / 1e6:9.2f} M lines/s", flush=True)
+    print(json.dumps({"latency_sweep": rows, "entry": "fg_decode_batch (pinned host buffers in, tables in the ctx's pinned buffer out)"}))
+    raise SystemExit(0)
+n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 1_000_000
 lines = synth.rfc5424_lines(n, cfg=2)
 data, offsets = synth.pack(lines)
 import ctypes as C
