@@ -57,6 +57,10 @@ extern "C" int fg_launch_encode_write(const uint8_t* d_bytes, const uint64_t* d_
 extern "C" uint64_t fg_frame_scratch_bytes(uint64_t nbytes);
 extern "C" int fg_launch_frame(const uint8_t* d_bytes, uint64_t nbytes, uint32_t delim, uint8_t* scratch, uint64_t* d_offsets,
                                uint8_t* d_bad, uint64_t cap, uint64_t** d_total_out, hipStream_t stream);
+extern "C" uint64_t fg_frame_block_bytes(void);
+extern "C" int fg_launch_frame_slice(const uint8_t* d_bytes, uint64_t nbytes, uint32_t delim, uint8_t* scratch, uint64_t* d_offsets,
+                                     uint8_t* d_bad, uint64_t cap, uint64_t blk0, uint64_t blk1, uint64_t** d_total_out,
+                                     hipStream_t stream);
 extern "C" int fg_launch_ltsv(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
                               const fg::LtsvDevCfg* cfg, uint64_t avg_len, hipStream_t stream, uint64_t* stash,
                               uint32_t stash_blocks, uint32_t strip, const uint8_t* line_bad, const fg_launch_opts* lo);
@@ -67,7 +71,10 @@ extern "C" int fg_launch_gelf(const uint8_t* d_bytes, const uint64_t* d_offsets,
 struct fg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;  // second lane of the pipelined host path (created on first use)
+    hipStream_t stream2 = nullptr;  // the pipelined host paths (created on first use): uploads / second lane
+    hipStream_t stream3 = nullptr;  // ... downloads
+    std::vector<hipEvent_t> ev_slice;  // ... two events per slice: uploaded, decoded
+    hipStream_t s_up = nullptr, s_down = nullptr, s_run = nullptr;  // ... which of the three does what
     hipEvent_t ev_ready = nullptr;
     int last_hip = 0;
     fg_launch_opts lo{};  // launch-geometry overrides (fg_set_launch_opts); all zero = the library's own choices
@@ -83,6 +90,7 @@ struct fg_ctx {
     // per-wave scratch where entries (SD pairs / LTSV pairs / GELF extras) are parked between the
     // parse and the copy into the entry table (allocated on the first decode; 8 waves on every CU)
     uint64_t* d_stash = nullptr;
+    uint64_t* d_stash2 = nullptr;  // the second lane's (fg_transcode_batch)
     uint32_t stash_blocks = 0;
     uint32_t* d_pending = nullptr;  // ring of kPendingRing hand-over words (DevTables::pending), zeroed once
     uint32_t epoch = 0;             // launch counter of this ctx
@@ -92,6 +100,8 @@ struct fg_ctx {
     uint64_t d_bad_cap = 0;
     uint64_t* h_off = nullptr;   // fg_frame_decode_batch: pinned host copy of the frame offsets
     uint64_t h_off_cap = 0;
+    uint64_t* h_cnt = nullptr;   // ... pinned words the pipelined form reads the slices' frame counts through
+    double frames_per_byte = 1.0 / 200.0;  // ... what the last raw chunk held (sizes the next one's tables before its frames are counted)
     // RFC3164 configuration: host copies (for fg_clone) + one device block [names | name_off | zone_first | utc_start | utc_off]
     bool r3164_set = false;
     bool r3164_auto_year = false;  // current_year == FG_YEAR_NOW: follow the wall clock like the reference (:179)
@@ -465,6 +475,7 @@ void fg_destroy(fg_ctx* ctx) {
     if (ctx->d_tab) (void)hipFree(ctx->d_tab);
     if (ctx->d_cfg) (void)hipFree(ctx->d_cfg);
     if (ctx->d_stash) (void)hipFree(ctx->d_stash);
+    if (ctx->d_stash2) (void)hipFree(ctx->d_stash2);
     if (ctx->d_pending) (void)hipFree(ctx->d_pending);
     if (ctx->d_frame) (void)hipFree(ctx->d_frame);
     if (ctx->d_bad) (void)hipFree(ctx->d_bad);
@@ -475,11 +486,15 @@ void fg_destroy(fg_ctx* ctx) {
     if (ctx->d_tz) (void)hipFree(ctx->d_tz);
     for (uint8_t* p : ctx->retired_tz) (void)hipFree(p);
     if (ctx->h_off) (void)hipHostFree(ctx->h_off);
+    if (ctx->h_cnt) (void)hipHostFree(ctx->h_cnt);
     if (ctx->h_tab) (void)hipHostFree(ctx->h_tab);
     if (ctx->d_tout) (void)hipFree(ctx->d_tout);
     if (ctx->d_tmeta) (void)hipFree(ctx->d_tmeta);
     if (ctx->h_tout) (void)hipHostFree(ctx->h_tout);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+    if (ctx->stream3) (void)hipStreamSynchronize(ctx->stream3);
+    for (hipEvent_t e : ctx->ev_slice) (void)hipEventDestroy(e);
+    if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->ev_ready) (void)hipEventDestroy(ctx->ev_ready);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -557,7 +572,7 @@ int fg_frame_device(fg_ctx* ctx, fg_framing framing, const uint8_t* d_bytes, uin
 
 static int decode_frames_impl(fg_ctx* ctx, fg_format fmt, fg_framing framing, const uint8_t* d_bytes, uint64_t nbytes,
                               const uint64_t* d_offsets, uint64_t n, const uint8_t* d_bad_utf8, const fg_tables* tables,
-                              void* stream, bool reset_counter, uint64_t span_bytes);
+                              void* stream, bool reset_counter, uint64_t span_bytes, uint32_t lane = 0);
 
 int fg_decode_frames_device(fg_ctx* ctx, fg_format fmt, fg_framing framing, const uint8_t* d_bytes, uint64_t nbytes,
                             const uint64_t* d_offsets, uint64_t n, const uint8_t* d_bad_utf8, const fg_tables* tables,
@@ -571,7 +586,7 @@ int fg_decode_frames_device(fg_ctx* ctx, fg_format fmt, fg_framing framing, cons
 // the readable range of d_bytes and, for a slice, covers the whole batch).
 static int decode_frames_impl(fg_ctx* ctx, fg_format fmt, fg_framing framing, const uint8_t* d_bytes, uint64_t nbytes,
                               const uint64_t* d_offsets, uint64_t n, const uint8_t* d_bad_utf8, const fg_tables* tables,
-                              void* stream, bool reset_counter, uint64_t span_bytes) {
+                              void* stream, bool reset_counter, uint64_t span_bytes, uint32_t lane) {
     if ((int)framing < 0 || (int)framing > 2) return FG_ERR_ARG;
     if (!ctx || !tables || (n && (!d_offsets || !tables->meta))) return FG_ERR_ARG;
     if (nbytes && !d_bytes) return FG_ERR_ARG;
@@ -590,6 +605,11 @@ static int decode_frames_impl(fg_ctx* ctx, fg_format fmt, fg_framing framing, co
         FG_HIP(ctx, hipMalloc((void**)&ctx->d_stash, fg_stash_bytes(blocks)));
         ctx->stash_blocks = blocks;
     }
+    uint64_t* stash = ctx->d_stash;
+    if (lane) {  // a second launch that may be in flight at the same time (fg_transcode_batch's second lane)
+        if (!ctx->d_stash2) FG_HIP(ctx, hipMalloc((void**)&ctx->d_stash2, fg_stash_bytes(ctx->stash_blocks)));
+        stash = ctx->d_stash2;
+    }
     constexpr uint32_t kPendingRing = 1024;
     if (!ctx->d_pending) {
         FG_HIP(ctx, hipMalloc((void**)&ctx->d_pending, kPendingRing * sizeof(uint32_t)));
@@ -604,15 +624,15 @@ static int decode_frames_impl(fg_ctx* ctx, fg_format fmt, fg_framing framing, co
     const uint64_t avg_len = (span_bytes + n - 1) / n;
     switch (fmt) {
         case FG_RFC5424:
-            rc = fg_launch_rfc5424(d_bytes, d_offsets, n, &dt, avg_len, s, ctx->d_stash, ctx->stash_blocks, (uint32_t)framing,
+            rc = fg_launch_rfc5424(d_bytes, d_offsets, n, &dt, avg_len, s, stash, ctx->stash_blocks, (uint32_t)framing,
                                    d_bad_utf8, &ctx->lo);
             break;
         case FG_LTSV:
-            rc = fg_launch_ltsv(d_bytes, d_offsets, n, &dt, &ctx->ltsv, avg_len, s, ctx->d_stash, ctx->stash_blocks,
+            rc = fg_launch_ltsv(d_bytes, d_offsets, n, &dt, &ctx->ltsv, avg_len, s, stash, ctx->stash_blocks,
                                 (uint32_t)framing, d_bad_utf8, &ctx->lo);
             break;
         case FG_GELF:
-            rc = fg_launch_gelf(d_bytes, d_offsets, n, &dt, avg_len, s, ctx->d_stash, ctx->stash_blocks,
+            rc = fg_launch_gelf(d_bytes, d_offsets, n, &dt, avg_len, s, stash, ctx->stash_blocks,
                                 (uint32_t)framing, d_bad_utf8, &ctx->lo);
             break;
         case FG_RFC3164:
@@ -644,13 +664,65 @@ void fg_free_pinned(void* p) {
     if (p) (void)hipHostFree(p);
 }
 
-int fg_measure_link(fg_ctx* ctx, uint64_t nbytes, double gbps[3]) {
-    if (!ctx || !gbps || nbytes < 4096) return FG_ERR_ARG;
-    DeviceGuard g(ctx->device);
+// Streams and events of the pipelined host paths (created on first use): uploads (stream2), kernels (stream3) and downloads (the
+// ctx's FIRST stream) each get their own stream, chained by events per slice.  Which stream carries which direction matters on
+// this platform (tools/probe/stream_pairs.cpp, MI355X / ROCm 7.2): an H2D and a D2H copy run at the same time -- 97 GB/s for
+// the two together -- only when one of the two streams is the first one created; any other pair shares a copy path and the two
+// directions take turns (57 GB/s for both together).  fg_measure_link measures on exactly these streams.
+// Chained by events per slice -- H2D copies run back to back on one stream (nothing else is ever queued between two of
+// them), D2H copies on another, and the link carries both directions at once.  (Round 2 alternated whole slices -- H2D, kernel,
+// D2H -- between two streams: measured, that gave the rate of NO overlap at all, 42 of 57 GB/s.)
+static int ensure_pipeline(fg_ctx* ctx, uint32_t slices) {
     if (!ctx->stream2) {
         FG_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
         FG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming));
     }
+    if (!ctx->stream3) FG_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
+    while (ctx->ev_slice.size() < 2ull * slices) {
+        hipEvent_t e = nullptr;
+        FG_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->ev_slice.push_back(e);
+    }
+    if (!ctx->s_up) {
+        // The runtime binds its copy paths to streams as they FIRST copy, and which stream went first decides whether the uploads
+        // and downloads below overlap (measured, tools/probe/stream_pairs.cpp and four orderings of this code: with the ctx's own
+        // stream first, fg_decode_batch runs at 198 M lines/s; with stream2 / stream3 first, at 160 M).  So the ctx's own stream
+        // copies a few bytes each way before the other two are ever used.
+        uint64_t probe = 0;
+        uint64_t* d_probe = nullptr;
+        FG_HIP(ctx, hipMalloc((void**)&d_probe, 8));
+        (void)hipMemcpyAsync(d_probe, &probe, 8, hipMemcpyHostToDevice, ctx->stream);
+        (void)hipMemcpyAsync(&probe, d_probe, 8, hipMemcpyDeviceToHost, ctx->stream);
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(d_probe);
+    }
+    ctx->s_up = ctx->stream2;
+    ctx->s_run = ctx->stream;
+    ctx->s_down = ctx->stream3;
+    return FG_OK;
+}
+// slices of a host batch: small enough that filling and draining the pipeline costs little (1/8 of the batch at most), large
+// enough that a slice's fourteen API calls stay far below its transfer time
+static uint32_t slice_count(uint64_t nbytes, uint64_t n) {
+    if (nbytes < (32ull << 20)) return 1;  // small batches: one stream, no events (a batch of one line costs what it did)
+    uint64_t slice = nbytes / 8;
+    if (slice < (8ull << 20)) slice = 8ull << 20;
+    if (slice > (32ull << 20)) slice = 32ull << 20;
+    uint64_t k = (nbytes + slice - 1) / slice;
+    if (k < 1) k = 1;
+    if (k > 256) k = 256;
+    if (n < k) k = n ? n : 1;
+    return (uint32_t)k;
+}
+
+int fg_measure_link(fg_ctx* ctx, uint64_t nbytes, double gbps[3]) {
+    if (!ctx || !gbps || nbytes < 4096) return FG_ERR_ARG;
+    DeviceGuard g(ctx->device);
+    {   // on the very streams the pipelined host paths copy on: uploads on stream2, downloads on the ctx's first stream
+        const int prc = ensure_pipeline(ctx, 1);
+        if (prc != FG_OK) return prc;
+    }
+    const hipStream_t s_up = ctx->s_up, s_down = ctx->s_down;
     uint8_t *h0 = nullptr, *h1 = nullptr, *d0 = nullptr, *d1 = nullptr;
     hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
     int rc = FG_OK;
@@ -673,22 +745,22 @@ int fg_measure_link(fg_ctx* ctx, uint64_t nbytes, double gbps[3]) {
         for (int rep = 0; rep < 4 && rc == FG_OK; ++rep) {  // (rep 0 warms the path up)
             float ms = 0.f;
             // host -> device
-            if (fail(hipEventRecord(e[0], ctx->stream)) || fail(hipMemcpyAsync(d0, h0, nbytes, hipMemcpyHostToDevice, ctx->stream)) ||
-                fail(hipEventRecord(e[1], ctx->stream)) || fail(hipEventSynchronize(e[1])) || fail(hipEventElapsedTime(&ms, e[0], e[1])))
+            if (fail(hipEventRecord(e[0], s_up)) || fail(hipMemcpyAsync(d0, h0, nbytes, hipMemcpyHostToDevice, s_up)) ||
+                fail(hipEventRecord(e[1], s_up)) || fail(hipEventSynchronize(e[1])) || fail(hipEventElapsedTime(&ms, e[0], e[1])))
                 break;
             if (rep && ms > 0.f) best[0] = std::max(best[0], (double)nbytes / (ms * 1e-3) / 1e9);
             // device -> host
-            if (fail(hipEventRecord(e[0], ctx->stream)) || fail(hipMemcpyAsync(h1, d1, nbytes, hipMemcpyDeviceToHost, ctx->stream)) ||
-                fail(hipEventRecord(e[1], ctx->stream)) || fail(hipEventSynchronize(e[1])) || fail(hipEventElapsedTime(&ms, e[0], e[1])))
+            if (fail(hipEventRecord(e[0], s_down)) || fail(hipMemcpyAsync(h1, d1, nbytes, hipMemcpyDeviceToHost, s_down)) ||
+                fail(hipEventRecord(e[1], s_down)) || fail(hipEventSynchronize(e[1])) || fail(hipEventElapsedTime(&ms, e[0], e[1])))
                 break;
             if (rep && ms > 0.f) best[1] = std::max(best[1], (double)nbytes / (ms * 1e-3) / 1e9);
             // both at once: the slower stream bounds the pair (wall clock around both)
-            if (fail(hipStreamSynchronize(ctx->stream)) || fail(hipStreamSynchronize(ctx->stream2))) break;
+            if (fail(hipStreamSynchronize(s_up)) || fail(hipStreamSynchronize(s_down))) break;
             timespec a, b;
             clock_gettime(CLOCK_MONOTONIC, &a);
-            if (fail(hipMemcpyAsync(d0, h0, nbytes, hipMemcpyHostToDevice, ctx->stream)) ||
-                fail(hipMemcpyAsync(h1, d1, nbytes, hipMemcpyDeviceToHost, ctx->stream2)) || fail(hipStreamSynchronize(ctx->stream)) ||
-                fail(hipStreamSynchronize(ctx->stream2)))
+            if (fail(hipMemcpyAsync(d0, h0, nbytes, hipMemcpyHostToDevice, s_up)) ||
+                fail(hipMemcpyAsync(h1, d1, nbytes, hipMemcpyDeviceToHost, s_down)) || fail(hipStreamSynchronize(s_up)) ||
+                fail(hipStreamSynchronize(s_down)))
                 break;
             clock_gettime(CLOCK_MONOTONIC, &b);
             const double s = (double)(b.tv_sec - a.tv_sec) + (double)(b.tv_nsec - a.tv_nsec) * 1e-9;
@@ -711,55 +783,50 @@ int fg_decode_batch(fg_ctx* ctx, fg_format fmt, const uint8_t* bytes, uint64_t n
     if (n && (offsets[n] > nbytes || offsets[0] > offsets[n])) return FG_ERR_ARG;
     DeviceGuard g(ctx->device);
     int rc;
-    if (!ctx->stream2) {
-        FG_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-        FG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming));
-    }
+    const uint32_t slices = slice_count(nbytes, n);
+    if (slices > 1 && (rc = ensure_pipeline(ctx, slices)) != FG_OK) return rc;  // (a small batch stays on the ctx's own stream)
     if ((rc = grow_dev(ctx, (void**)&ctx->d_bytes, &ctx->d_bytes_cap, up(nbytes, 16) + 16)) != FG_OK) return rc;
     if ((rc = grow_dev(ctx, (void**)&ctx->d_offsets, &ctx->d_offsets_cap, (n + 1) * 8)) != FG_OK) return rc;
-    // Slices of ~32 MiB of line bytes, alternating between two streams: the H2D copy of slice k+1
-    // overlaps the kernel and the D2H copy of slice k's rows (PCIe is full duplex; the kernels are
-    // two orders of magnitude faster than the link).  Rows land at their final position, entries
-    // share one counter, so the result is the same as one monolithic launch.
-    uint32_t slices = (uint32_t)(nbytes / (32ull << 20));
-    if (slices < 1) slices = 1;
-    if (slices > 16) slices = 16;
-    if (n < slices) slices = n ? (uint32_t)n : 1;
     std::vector<uint64_t> cut(slices + 1);
     if (fg_shard_plan(offsets, n, slices, cut.data()) != FG_OK) return FG_ERR_ARG;
-    hipStream_t lanes[2] = {ctx->stream, ctx->stream2};
+    const bool piped = slices > 1;
+    const hipStream_t s_down = piped ? ctx->s_down : ctx->stream, s_up = piped ? ctx->s_up : s_down, s_run = piped ? ctx->s_run : s_down;
+    auto drain = [&]() {
+        (void)hipStreamSynchronize(s_up);
+        (void)hipStreamSynchronize(s_run);
+        (void)hipStreamSynchronize(s_down);
+    };
     // entry capacity: start from one entry per 16 (RFC5424) / 8 input bytes, grow on overflow
     uint64_t ent_cap = fmt == FG_RFC5424 ? nbytes / 16 + 1024 : nbytes / 8 + 1024;
+    if (fmt == FG_RFC3164) ent_cap = 16;  // RFC3164 produces no entries
     for (;;) {
         if (ent_cap > 0xFFFFFFF0ull) ent_cap = 0xFFFFFFF0ull;
         uint64_t total = 0;
         carve(nullptr, n, ent_cap, nullptr, &total);
         if ((rc = grow_dev(ctx, (void**)&ctx->d_tab, &ctx->d_tab_cap, total)) != FG_OK) return rc;
-        if (total > ctx->h_tab_cap) {
-            if (ctx->h_tab) FG_HIP(ctx, hipHostFree(ctx->h_tab));
-            ctx->h_tab = nullptr;
-            ctx->h_tab_cap = 0;
-            uint64_t want = up(total + total / 4, 1 << 20);
-            FG_HIP(ctx, hipHostMalloc((void**)&ctx->h_tab, want, hipHostMallocDefault));
-            ctx->h_tab_cap = want;
-        }
+        if ((rc = grow_pinned(ctx, (void**)&ctx->h_tab, &ctx->h_tab_cap, total)) != FG_OK) return rc;
         fg_tables dt, ht;
         carve(ctx->d_tab, n, ent_cap, &dt, nullptr);
         carve(ctx->h_tab, n, ent_cap, &ht, nullptr);
-        // offsets + the entry counter first (lane 0); lane 1 waits for them
-        if (n) FG_HIP(ctx, hipMemcpyAsync(ctx->d_offsets, offsets, (n + 1) * 8, hipMemcpyHostToDevice, lanes[0]));
-        FG_HIP(ctx, hipMemsetAsync(dt.ent_used, 0, 8, lanes[0]));
-        FG_HIP(ctx, hipEventRecord(ctx->ev_ready, lanes[0]));
-        FG_HIP(ctx, hipStreamWaitEvent(lanes[1], ctx->ev_ready, 0));
+        FG_HIP(ctx, hipMemsetAsync(dt.ent_used, 0, 8, s_run));
+        // Rows land at their final position, entries share one counter: the result is the same as one monolithic launch.
         for (uint32_t k = 0; k < slices && n; ++k) {
-            hipStream_t s = lanes[k & 1u];
-            const uint64_t l0 = cut[k], l1 = cut[k + 1];
-            if (l1 == l0) continue;
-            // bytes of the slice, copied on 16-byte boundaries (the neighbouring bytes are the same data)
+            const uint64_t l0 = cut[k], l1 = cut[k + 1], rows = l1 - l0;
+            if (rows == 0) continue;
+            hipEvent_t e_up = piped ? ctx->ev_slice[2 * k] : nullptr, e_run = piped ? ctx->ev_slice[2 * k + 1] : nullptr;
+            // ---- upload: the slice's offsets (the first slice also takes offsets[0]) and its bytes, copied on 16-byte boundaries
+            //      (the neighbouring bytes are the same data)
+            const uint64_t o0 = k == 0 ? l0 : l0 + 1;
+            FG_HIP(ctx, hipMemcpyAsync(ctx->d_offsets + o0, offsets + o0, (l1 + 1 - o0) * 8, hipMemcpyHostToDevice, s_up));
             const uint64_t b0 = offsets[l0] & ~15ull, b1 = offsets[l1];
-            if (b1 > b0) FG_HIP(ctx, hipMemcpyAsync(ctx->d_bytes + b0, bytes + b0, b1 - b0, hipMemcpyHostToDevice, s));
+            if (b1 > b0) FG_HIP(ctx, hipMemcpyAsync(ctx->d_bytes + b0, bytes + b0, b1 - b0, hipMemcpyHostToDevice, s_up));
+            if (piped) {
+                FG_HIP(ctx, hipEventRecord(e_up, s_up));
+                FG_HIP(ctx, hipStreamWaitEvent(s_run, e_up, 0));
+            }
+            // ---- decode
             fg_tables sl = dt;  // the slice's rows: same arrays, shifted by l0
-            sl.n = l1 - l0;
+            sl.n = rows;
             sl.meta += l0;
             sl.ts += l0;
             sl.hostname += l0;
@@ -770,42 +837,44 @@ int fg_decode_batch(fg_ctx* ctx, fg_format fmt, const uint8_t* bytes, uint64_t n
             sl.full_msg += l0;
             sl.ent_first += l0;
             sl.ent_count += l0;
-            rc = decode_frames_impl(ctx, fmt, FG_FRAME_NONE, ctx->d_bytes, nbytes, ctx->d_offsets + l0, l1 - l0, nullptr, &sl,
-                                    (void*)s, false, offsets[l1] - offsets[l0]);
-            if (rc != FG_OK) {  // copies of earlier slices may still be in flight into h_tab / d_tab: drain both lanes
-                (void)hipStreamSynchronize(lanes[0]);
-                (void)hipStreamSynchronize(lanes[1]);
+            rc = decode_frames_impl(ctx, fmt, FG_FRAME_NONE, ctx->d_bytes, nbytes, ctx->d_offsets + l0, rows, nullptr, &sl, (void*)s_run, false,
+                                    offsets[l1] - offsets[l0]);
+            if (rc != FG_OK) {  // copies of earlier slices may still be in flight into h_tab / d_tab
+                drain();
                 return rc;
             }
-            const uint64_t rows = l1 - l0;
-            FG_HIP(ctx, hipMemcpyAsync(ht.meta + l0, dt.meta + l0, rows * 4, hipMemcpyDeviceToHost, s));
-            FG_HIP(ctx, hipMemcpyAsync(ht.ts + l0, dt.ts + l0, rows * 8, hipMemcpyDeviceToHost, s));
+            // ---- download the slice's rows
+            if (piped) {
+                FG_HIP(ctx, hipEventRecord(e_run, s_run));
+                FG_HIP(ctx, hipStreamWaitEvent(s_down, e_run, 0));
+            }
+            FG_HIP(ctx, hipMemcpyAsync(ht.meta + l0, dt.meta + l0, rows * 4, hipMemcpyDeviceToHost, s_down));
+            FG_HIP(ctx, hipMemcpyAsync(ht.ts + l0, dt.ts + l0, rows * 8, hipMemcpyDeviceToHost, s_down));
             fg_span* hs[6] = {ht.hostname, ht.appname, ht.procid, ht.msgid, ht.msg, ht.full_msg};
             fg_span* ds[6] = {dt.hostname, dt.appname, dt.procid, dt.msgid, dt.msg, dt.full_msg};
-            for (int j = 0; j < 6; ++j) FG_HIP(ctx, hipMemcpyAsync(hs[j] + l0, ds[j] + l0, rows * 8, hipMemcpyDeviceToHost, s));
-            FG_HIP(ctx, hipMemcpyAsync(ht.ent_first + l0, dt.ent_first + l0, rows * 4, hipMemcpyDeviceToHost, s));
-            FG_HIP(ctx, hipMemcpyAsync(ht.ent_count + l0, dt.ent_count + l0, rows * 4, hipMemcpyDeviceToHost, s));
+            for (int j = 0; j < 6; ++j) FG_HIP(ctx, hipMemcpyAsync(hs[j] + l0, ds[j] + l0, rows * 8, hipMemcpyDeviceToHost, s_down));
+            FG_HIP(ctx, hipMemcpyAsync(ht.ent_first + l0, dt.ent_first + l0, rows * 4, hipMemcpyDeviceToHost, s_down));
+            FG_HIP(ctx, hipMemcpyAsync(ht.ent_count + l0, dt.ent_count + l0, rows * 4, hipMemcpyDeviceToHost, s_down));
         }
-        FG_HIP(ctx, hipStreamSynchronize(lanes[1]));
         uint64_t used = 0;
-        FG_HIP(ctx, hipMemcpyAsync(&used, dt.ent_used, 8, hipMemcpyDeviceToHost, lanes[0]));
-        FG_HIP(ctx, hipStreamSynchronize(lanes[0]));
+        FG_HIP(ctx, hipMemcpyAsync(&used, dt.ent_used, 8, hipMemcpyDeviceToHost, s_run));
+        FG_HIP(ctx, hipStreamSynchronize(s_run));
         if (used > ent_cap) {
+            drain();
             if (ent_cap >= 0xFFFFFFF0ull) return FG_ERR_ENT_OVERFLOW;
             ent_cap = used + used / 8 + 1024;
             continue;
         }
-        // the entry columns, up to `used`
-        hipStream_t s = lanes[0];
+        // the entry columns, up to `used` (the kernels are done: s_run is idle, two streams share the copies)
         if (used) {
-            FG_HIP(ctx, hipMemcpyAsync(ht.ent_name, dt.ent_name, used * 8, hipMemcpyDeviceToHost, s));
-            FG_HIP(ctx, hipMemcpyAsync(ht.ent_val, dt.ent_val, used * 8, hipMemcpyDeviceToHost, lanes[1]));
-            FG_HIP(ctx, hipMemcpyAsync(ht.ent_type, dt.ent_type, used, hipMemcpyDeviceToHost, s));
-            FG_HIP(ctx, hipMemcpyAsync(ht.ent_flags, dt.ent_flags, used, hipMemcpyDeviceToHost, lanes[1]));
+            FG_HIP(ctx, hipMemcpyAsync(ht.ent_name, dt.ent_name, used * 8, hipMemcpyDeviceToHost, s_run));
+            FG_HIP(ctx, hipMemcpyAsync(ht.ent_val, dt.ent_val, used * 8, hipMemcpyDeviceToHost, s_down));
+            FG_HIP(ctx, hipMemcpyAsync(ht.ent_type, dt.ent_type, used, hipMemcpyDeviceToHost, s_run));
+            FG_HIP(ctx, hipMemcpyAsync(ht.ent_flags, dt.ent_flags, used, hipMemcpyDeviceToHost, s_down));
         }
         *ht.ent_used = used;
-        FG_HIP(ctx, hipStreamSynchronize(lanes[1]));
-        FG_HIP(ctx, hipStreamSynchronize(s));
+        FG_HIP(ctx, hipStreamSynchronize(s_down));
+        FG_HIP(ctx, hipStreamSynchronize(s_run));
         *out = ht;
         return FG_OK;
     }
@@ -813,8 +882,8 @@ int fg_decode_batch(fg_ctx* ctx, fg_format fmt, const uint8_t* bytes, uint64_t n
 
 static int frame_stage(fg_ctx* ctx, fg_framing framing, uint64_t nbytes, int final, uint64_t* n_frames, uint64_t* consumed);
 
-int fg_frame_decode_batch(fg_ctx* ctx, fg_format fmt, fg_framing framing, const uint8_t* bytes, uint64_t nbytes, int final,
-                          fg_tables* out, const uint64_t** out_offsets, uint64_t* n_frames, uint64_t* consumed) {
+static int frame_decode_one_piece(fg_ctx* ctx, fg_format fmt, fg_framing framing, const uint8_t* bytes, uint64_t nbytes, int final,
+                                  fg_tables* out, const uint64_t** out_offsets, uint64_t* n_frames, uint64_t* consumed) {
     if (!ctx || !out || !out_offsets || !n_frames || !consumed || (nbytes && !bytes)) return FG_ERR_ARG;
     if (framing != FG_FRAME_LINE && framing != FG_FRAME_NUL) return FG_ERR_UNSUPPORTED;
     *n_frames = 0;
@@ -831,6 +900,7 @@ int fg_frame_decode_batch(fg_ctx* ctx, fg_format fmt, fg_framing framing, const 
     uint64_t n = 0;
     if ((rc = frame_stage(ctx, framing, nbytes, final, &n, consumed)) != FG_OK) return rc;
     *n_frames = n;
+    if (n && nbytes >= (1u << 20)) ctx->frames_per_byte = (double)n / (double)nbytes;
     if ((n + 1) * 8 > ctx->h_off_cap) {
         if (ctx->h_off) FG_HIP(ctx, hipHostFree(ctx->h_off));
         ctx->h_off = nullptr;
@@ -888,6 +958,180 @@ int fg_frame_decode_batch(fg_ctx* ctx, fg_format fmt, fg_framing framing, const 
         *out = ht;
         return FG_OK;
     }
+}
+
+// fg_frame_decode_batch for a LARGE raw chunk: the chunk crosses the link in slices (multiples of the framing kernels' 16 KiB
+// block) on the upload stream; as soon as a slice is there it is framed (delimiter ranks continue where the slice before stopped),
+// its frame count comes back to the host through a pinned word, the frames that END in it are decoded, and their rows + offsets go
+// back on the download stream -- all while the next slices are still on the link.  The host never frames, never uploads offsets.
+// Tables are sized from what the ctx's last chunk held; a chunk that outgrows the estimate (or the entry table) returns
+// FG_ERR_UNSUPPORTED and takes the one-piece path, which counts first.
+static int frame_decode_sliced(fg_ctx* ctx, fg_format fmt, fg_framing framing, const uint8_t* bytes, uint64_t nbytes, int final,
+                               fg_tables* out, const uint64_t** out_offsets, uint64_t* n_frames, uint64_t* consumed) {
+    int rc;
+    const uint64_t blk = fg_frame_block_bytes();
+    uint64_t slice = nbytes / 8;
+    if (slice < (8ull << 20)) slice = 8ull << 20;
+    if (slice > (32ull << 20)) slice = 32ull << 20;
+    slice = slice / blk * blk;
+    const uint32_t slices = (uint32_t)((nbytes + slice - 1) / slice);
+    const uint64_t nblk_total = nbytes / blk + 1;
+    if ((rc = ensure_pipeline(ctx, slices)) != FG_OK) return rc;
+    const hipStream_t s_up = ctx->s_up, s_run = ctx->s_run, s_down = ctx->s_down;
+    auto drain = [&]() {
+        (void)hipStreamSynchronize(s_up);
+        (void)hipStreamSynchronize(s_run);
+        (void)hipStreamSynchronize(s_down);
+    };
+    // capacities from the ctx's experience: frames, rows, entries
+    const uint64_t cap = (uint64_t)((double)nbytes * ctx->frames_per_byte * 1.25) + 4096;
+    const uint64_t ent_cap0 = fmt == FG_RFC3164 ? 16 : fmt == FG_RFC5424 ? nbytes / 16 + 1024 : nbytes / 8 + 1024;
+    const uint64_t ent_cap = ent_cap0 > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : ent_cap0;
+    if ((rc = grow_dev(ctx, (void**)&ctx->d_bytes, &ctx->d_bytes_cap, up(nbytes, 16) + 16)) != FG_OK) return rc;
+    if ((rc = grow_dev(ctx, (void**)&ctx->d_offsets, &ctx->d_offsets_cap, (cap + 2) * 8)) != FG_OK) return rc;
+    if ((rc = grow_dev(ctx, (void**)&ctx->d_bad, &ctx->d_bad_cap, cap + 1)) != FG_OK) return rc;
+    if ((rc = grow_dev(ctx, (void**)&ctx->d_frame, &ctx->d_frame_cap, fg_frame_scratch_bytes(nbytes))) != FG_OK) return rc;
+    if ((rc = grow_pinned(ctx, (void**)&ctx->h_off, &ctx->h_off_cap, (cap + 2) * 8)) != FG_OK) return rc;
+    if (!ctx->h_cnt) FG_HIP(ctx, hipHostMalloc((void**)&ctx->h_cnt, 65536, hipHostMallocDefault));
+    if (slices + 2 > 65536 / 8) return FG_ERR_UNSUPPORTED;
+    uint64_t tab_bytes = 0;
+    carve(nullptr, cap, ent_cap, nullptr, &tab_bytes);
+    if ((rc = grow_dev(ctx, (void**)&ctx->d_tab, &ctx->d_tab_cap, tab_bytes)) != FG_OK) return rc;
+    if ((rc = grow_pinned(ctx, (void**)&ctx->h_tab, &ctx->h_tab_cap, tab_bytes)) != FG_OK) return rc;
+    fg_tables dt, ht;
+    carve(ctx->d_tab, cap, ent_cap, &dt, nullptr);
+    carve(ctx->h_tab, cap, ent_cap, &ht, nullptr);
+    FG_HIP(ctx, hipMemsetAsync(dt.ent_used, 0, 8, s_run));
+    FG_HIP(ctx, hipMemsetAsync(ctx->d_bad, 0, cap + 1, s_run));
+    const uint32_t delim = framing == FG_FRAME_LINE ? 0x0Au : 0x00u;
+    std::vector<hipEvent_t>& ev = ctx->ev_slice;
+    // every upload is queued NOW (they depend on nothing): the link never waits for the host
+    for (uint32_t k = 0; k < slices; ++k) {
+        const uint64_t b0 = (uint64_t)k * slice, b1 = k + 1 == slices ? nbytes : b0 + slice;
+        FG_HIP(ctx, hipMemcpyAsync(ctx->d_bytes + b0, bytes + b0, b1 - b0, hipMemcpyHostToDevice, s_up));
+        if (k + 1 == slices) FG_HIP(ctx, hipMemsetAsync(ctx->d_bytes + nbytes, 0, up(nbytes, 16) + 16 - nbytes, s_up));
+        FG_HIP(ctx, hipEventRecord(ev[2 * k], s_up));
+    }
+    // frame slice k once it is there, bring its cumulative frame count back (all asynchronous)
+    auto enqueue = [&](uint32_t k) -> int {
+        const uint64_t b0 = (uint64_t)k * slice, b1 = k + 1 == slices ? nbytes : b0 + slice;
+        FG_HIP(ctx, hipStreamWaitEvent(s_run, ev[2 * k], 0));
+        uint64_t* d_total = nullptr;
+        const uint64_t blk0 = b0 / blk, blk1 = k + 1 == slices ? nblk_total : b1 / blk;
+        const int lrc = fg_launch_frame_slice(ctx->d_bytes, nbytes, delim, ctx->d_frame, ctx->d_offsets, ctx->d_bad, cap, blk0, blk1, &d_total, s_run);
+        if (lrc != 0) {
+            ctx->last_hip = lrc;
+            return FG_ERR_HIP;
+        }
+        FG_HIP(ctx, hipMemcpyAsync(ctx->h_cnt + k, d_total, 8, hipMemcpyDeviceToHost, s_run));
+        FG_HIP(ctx, hipEventRecord(ev[2 * k + 1], s_run));
+        return FG_OK;
+    };
+    uint64_t done = 0;  // frames decoded so far
+    auto decode_rows = [&](uint64_t f0, uint64_t f1, uint64_t span_bytes) -> int {  // frames [f0, f1): decode + download
+        if (f1 == f0) return FG_OK;
+        const uint64_t rows = f1 - f0;
+        fg_tables sl = dt;
+        sl.n = rows;
+        sl.meta += f0; sl.ts += f0; sl.hostname += f0; sl.appname += f0; sl.procid += f0; sl.msgid += f0; sl.msg += f0; sl.full_msg += f0;
+        sl.ent_first += f0; sl.ent_count += f0;
+        int r = decode_frames_impl(ctx, fmt, framing, ctx->d_bytes, nbytes, ctx->d_offsets + f0, rows, ctx->d_bad + f0, &sl, (void*)s_run, false, span_bytes);
+        if (r != FG_OK) return r;
+        FG_HIP(ctx, hipEventRecord(ctx->ev_ready, s_run));
+        FG_HIP(ctx, hipStreamWaitEvent(s_down, ctx->ev_ready, 0));
+        FG_HIP(ctx, hipMemcpyAsync(ctx->h_off + f0 + (f0 ? 1 : 0), ctx->d_offsets + f0 + (f0 ? 1 : 0), (rows + (f0 ? 0 : 1)) * 8, hipMemcpyDeviceToHost, s_down));
+        FG_HIP(ctx, hipMemcpyAsync(ht.meta + f0, dt.meta + f0, rows * 4, hipMemcpyDeviceToHost, s_down));
+        FG_HIP(ctx, hipMemcpyAsync(ht.ts + f0, dt.ts + f0, rows * 8, hipMemcpyDeviceToHost, s_down));
+        fg_span* hs[6] = {ht.hostname, ht.appname, ht.procid, ht.msgid, ht.msg, ht.full_msg};
+        fg_span* ds[6] = {dt.hostname, dt.appname, dt.procid, dt.msgid, dt.msg, dt.full_msg};
+        for (int j = 0; j < 6; ++j) FG_HIP(ctx, hipMemcpyAsync(hs[j] + f0, ds[j] + f0, rows * 8, hipMemcpyDeviceToHost, s_down));
+        FG_HIP(ctx, hipMemcpyAsync(ht.ent_first + f0, dt.ent_first + f0, rows * 4, hipMemcpyDeviceToHost, s_down));
+        FG_HIP(ctx, hipMemcpyAsync(ht.ent_count + f0, dt.ent_count + f0, rows * 4, hipMemcpyDeviceToHost, s_down));
+        return FG_OK;
+    };
+    if ((rc = enqueue(0)) != FG_OK) {
+        drain();
+        return rc;
+    }
+    for (uint32_t k = 0; k < slices; ++k) {
+        if (k + 1 < slices && (rc = enqueue(k + 1)) != FG_OK) {
+            drain();
+            return rc;
+        }
+        FG_HIP(ctx, hipEventSynchronize(ev[2 * k + 1]));
+        const uint64_t total = ctx->h_cnt[k];  // delimiters up to the end of slice k = frames that are complete
+        if (total + 1 > cap) {
+            drain();
+            ctx->frames_per_byte = (double)(total + 1) / (double)(((uint64_t)k + 1) * slice);
+            return FG_ERR_UNSUPPORTED;
+        }
+        const uint64_t b1 = k + 1 == slices ? nbytes : ((uint64_t)k + 1) * slice;
+        if (k + 1 < slices) {
+            if ((rc = decode_rows(done, total, b1 - (uint64_t)k * slice)) != FG_OK) {
+                drain();
+                return rc;
+            }
+            done = total;
+            continue;
+        }
+        // the last slice: an unterminated tail is one more frame when the stream ends here, else it stays with the caller
+        uint64_t last_end = 0;
+        FG_HIP(ctx, hipMemcpyAsync(&last_end, ctx->d_offsets + total, 8, hipMemcpyDeviceToHost, s_run));
+        FG_HIP(ctx, hipStreamSynchronize(s_run));
+        const bool tail = last_end != nbytes;
+        uint64_t n = total;
+        if (tail && final) {
+            ctx->h_cnt[slices] = nbytes;
+            FG_HIP(ctx, hipMemcpyAsync(ctx->d_offsets + total + 1, ctx->h_cnt + slices, 8, hipMemcpyHostToDevice, s_run));
+            n = total + 1;
+        }
+        *consumed = (tail && !final) ? last_end : nbytes;
+        if ((rc = decode_rows(done, n, *consumed > (uint64_t)k * slice ? *consumed - (uint64_t)k * slice : 1)) != FG_OK) {
+            drain();
+            return rc;
+        }
+        done = n;
+    }
+    uint64_t used = 0;
+    FG_HIP(ctx, hipMemcpyAsync(&used, dt.ent_used, 8, hipMemcpyDeviceToHost, s_run));
+    FG_HIP(ctx, hipStreamSynchronize(s_run));
+    if (done) ctx->frames_per_byte = (double)done / (double)nbytes;
+    if (used > ent_cap) {
+        drain();
+        return FG_ERR_UNSUPPORTED;
+    }
+    if (used) {
+        FG_HIP(ctx, hipMemcpyAsync(ht.ent_name, dt.ent_name, used * 8, hipMemcpyDeviceToHost, s_run));
+        FG_HIP(ctx, hipMemcpyAsync(ht.ent_val, dt.ent_val, used * 8, hipMemcpyDeviceToHost, s_down));
+        FG_HIP(ctx, hipMemcpyAsync(ht.ent_type, dt.ent_type, used, hipMemcpyDeviceToHost, s_run));
+        FG_HIP(ctx, hipMemcpyAsync(ht.ent_flags, dt.ent_flags, used, hipMemcpyDeviceToHost, s_down));
+    }
+    *ht.ent_used = used;
+    drain();
+    ht.n = done;
+    *out = ht;
+    *out_offsets = ctx->h_off;
+    *n_frames = done;
+    if (done == 0) {
+        fg_tables empty{};
+        *out = empty;
+    }
+    return FG_OK;
+}
+
+int fg_frame_decode_batch(fg_ctx* ctx, fg_format fmt, fg_framing framing, const uint8_t* bytes, uint64_t nbytes, int final,
+                          fg_tables* out, const uint64_t** out_offsets, uint64_t* n_frames, uint64_t* consumed) {
+    if (!ctx || !out || !out_offsets || !n_frames || !consumed || (nbytes && !bytes)) return FG_ERR_ARG;
+    if (framing != FG_FRAME_LINE && framing != FG_FRAME_NUL) return FG_ERR_UNSUPPORTED;
+    if (nbytes >= (48ull << 20) && !(ctx->lo.flags & FG_LO_TRANSCODE_ONE_PIECE)) {
+        DeviceGuard g(ctx->device);
+        *n_frames = 0;
+        *consumed = 0;
+        *out_offsets = nullptr;
+        const int rc = frame_decode_sliced(ctx, fmt, framing, bytes, nbytes, final, out, out_offsets, n_frames, consumed);
+        if (rc != FG_ERR_UNSUPPORTED) return rc;
+    }
+    return frame_decode_one_piece(ctx, fmt, framing, bytes, nbytes, final, out, out_offsets, n_frames, consumed);
 }
 
 // Framing stage shared by fg_frame_decode_batch and fg_transcode_batch: the raw chunk is already in ctx->d_bytes
@@ -1027,8 +1271,9 @@ static int transcode_sliced(fg_ctx* ctx, fg_format fmt, const fg_encode_cfg* ecf
         const uint64_t b0 = offsets[l0] & ~15ull, b1 = offsets[l1];
         if (b1 > b0) FG_HIP(ctx, hipMemcpyAsync(ctx->d_bytes + b0, bytes + b0, b1 - b0, hipMemcpyHostToDevice, s));
         const fg_tables sl = sl_tables(l0, l1);
+        // (the two lanes' kernels may be in flight at the same time: each lane parks its entries in its own stash)
         int r = decode_frames_impl(ctx, fmt, FG_FRAME_NONE, ctx->d_bytes, nbytes, ctx->d_offsets + l0, l1 - l0, nullptr, &sl, (void*)s, false,
-                                   offsets[l1] - offsets[l0]);
+                                   offsets[l1] - offsets[l0], k & 1u);
         if (r != FG_OK) return r;
         if (k == 0 && ecfg->encoder == FG_ENC_GELF) {  // the GELF ranking scratch is sized by the pairs per line: look at the first slice
             uint64_t used = ~0ull;

@@ -65,10 +65,12 @@ __device__ __forceinline__ uint32_t utf8_err_flags(uint32_t b, uint32_t p) {
 }
 
 // pass 1.  masks[chunk] = delimiter mask | error mask << 16 (chunk = 16 bytes); counts[block].
+// (blk0: first block of the range this launch covers -- a SLICE of the stream whose bytes have arrived; the pipelined host path frames
+//  slice by slice while the next one is still on the link)
 __global__ __launch_bounds__(kWave) void k_frame_scan(const uint8_t* __restrict__ bytes, uint64_t nbytes, uint32_t delim_pat,
-                                                     uint32_t* __restrict__ masks, uint32_t* __restrict__ counts) {
+                                                     uint32_t* __restrict__ masks, uint32_t* __restrict__ counts, uint64_t blk0) {
     const uint32_t lane = threadIdx.x;
-    const uint64_t blk = blockIdx.x;
+    const uint64_t blk = blk0 + blockIdx.x;
     const uint64_t base = blk * kFrameBlock;
     const uint64_t left = nbytes - base;  // the last block may be empty: it only carries the "cut off by the end" check
     const uint32_t span = left >= kFrameBlock ? kFrameBlock : (uint32_t)((left + 15u) & ~15ull);
@@ -109,12 +111,14 @@ __global__ __launch_bounds__(kWave) void k_frame_scan(const uint8_t* __restrict_
     if (lane == 0) counts[blk] = total;
 }
 
-// exclusive scan of counts[0..nblk) -> pref[0..nblk], pref[nblk] = total; one workgroup.
-__global__ __launch_bounds__(1024) void k_frame_prefix(const uint32_t* __restrict__ counts, uint64_t nblk, uint64_t* __restrict__ pref) {
+// exclusive scan of counts[0..nblk) -> pref[0..nblk], pref[nblk] = total; one workgroup.  carry_in: the scan continues the one
+// of the blocks before (pref[0] already holds their total: the previous slice's pref[nblk]).
+__global__ __launch_bounds__(1024) void k_frame_prefix(const uint32_t* __restrict__ counts, uint64_t nblk, uint64_t* __restrict__ pref,
+                                                       uint32_t carry_in) {
     __shared__ uint64_t wave_tot[16];
     __shared__ uint64_t carry_s;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    if (tid == 0) carry_s = 0;
+    if (tid == 0) carry_s = carry_in ? pref[0] : 0;
     __syncthreads();
     for (uint64_t b0 = 0; b0 < nblk; b0 += 1024) {
         const uint64_t i = b0 + tid;
@@ -138,11 +142,13 @@ __global__ __launch_bounds__(1024) void k_frame_prefix(const uint32_t* __restric
 }
 
 // pass 2.  A lane owns 16 consecutive chunks (256 bytes) of its block.
+// (blk0 / whole: see k_frame_scan; a slice launch leaves the end of a final unterminated frame to the host, which knows the total
+//  only after the last slice)
 __global__ __launch_bounds__(kWave) void k_frame_emit(const uint32_t* __restrict__ masks, const uint64_t* __restrict__ pref,
                                                      uint64_t nbytes, uint64_t nblk, uint64_t* __restrict__ offsets,
-                                                     uint8_t* __restrict__ bad, uint64_t cap) {
+                                                     uint8_t* __restrict__ bad, uint64_t cap, uint64_t blk0, uint32_t whole) {
     const uint32_t lane = threadIdx.x;
-    const uint64_t blk = blockIdx.x;
+    const uint64_t blk = blk0 + blockIdx.x;
     const uint4* src = reinterpret_cast<const uint4*>(masks + blk * (kFrameBlock / 16u) + lane * 16u);
     uint4 m[4];
 #pragma unroll
@@ -158,10 +164,12 @@ __global__ __launch_bounds__(kWave) void k_frame_emit(const uint32_t* __restrict
     uint32_t total;
     const uint32_t ex = wave_exclusive_sum(mine, &total);
     uint64_t rank = pref[blk] + ex;  // delimiters before this lane's first byte
-    const uint64_t total_delims = pref[nblk];
     if (blk == 0 && lane == 0) {
         offsets[0] = 0;
-        if (total_delims + 1 <= cap) offsets[total_delims + 1] = nbytes;  // end of a final unterminated frame
+        if (whole) {
+            const uint64_t total_delims = pref[nblk];
+            if (total_delims + 1 <= cap) offsets[total_delims + 1] = nbytes;  // end of a final unterminated frame
+        }
     }
     if (mine == 0 && any_err == 0) return;
     const uint64_t lane_base = blk * (uint64_t)kFrameBlock + (uint64_t)lane * 256u;
@@ -205,10 +213,32 @@ extern "C" int fg_launch_frame(const uint8_t* d_bytes, uint64_t nbytes, uint32_t
     uint64_t* pref = reinterpret_cast<uint64_t*>(scratch + nblk * 4096u + ((nblk * 4u + 255u) & ~255ull));
     const uint32_t pat = delim * 0x01010101u;
     (void)hipMemsetAsync(d_bad, 0, cap, stream);
-    hipLaunchKernelGGL(fg::k_frame_scan, dim3((uint32_t)nblk), dim3(fg::kWave), 0, stream, d_bytes, nbytes, pat, masks, counts);
-    hipLaunchKernelGGL(fg::k_frame_prefix, dim3(1), dim3(1024), 0, stream, counts, nblk, pref);
+    hipLaunchKernelGGL(fg::k_frame_scan, dim3((uint32_t)nblk), dim3(fg::kWave), 0, stream, d_bytes, nbytes, pat, masks, counts, (uint64_t)0);
+    hipLaunchKernelGGL(fg::k_frame_prefix, dim3(1), dim3(1024), 0, stream, counts, nblk, pref, 0u);
     hipLaunchKernelGGL(fg::k_frame_emit, dim3((uint32_t)nblk), dim3(fg::kWave), 0, stream, masks, pref, nbytes, nblk, d_offsets,
-                       d_bad, cap);
+                       d_bad, cap, (uint64_t)0, 1u);
     *d_total_out = pref + nblk;
+    return (int)hipGetLastError();
+}
+
+// One SLICE of the stream: the blocks [blk0, blk1) (slice boundaries are multiples of the 16 KiB block; the last slice ends at
+// frame_blocks(nbytes)), whose bytes -- and everything before them -- are in d_bytes.  Continues the delimiter ranks where the
+// slice before stopped; *d_total_out = the device word that holds the delimiters up to the end of this slice.  d_bad must have
+// been cleared for the whole batch beforehand; offsets[total + 1] of a final unterminated frame is the caller's business.
+extern "C" uint64_t fg_frame_block_bytes(void) { return fg::kFrameBlock; }
+extern "C" int fg_launch_frame_slice(const uint8_t* d_bytes, uint64_t nbytes, uint32_t delim, uint8_t* scratch, uint64_t* d_offsets,
+                                     uint8_t* d_bad, uint64_t cap, uint64_t blk0, uint64_t blk1, uint64_t** d_total_out,
+                                     hipStream_t stream) {
+    const uint64_t nblk = frame_blocks(nbytes);
+    if (nblk > 0x7FFFFFFFull || blk1 > nblk || blk0 >= blk1) return -1;
+    uint32_t* masks = reinterpret_cast<uint32_t*>(scratch);
+    uint32_t* counts = reinterpret_cast<uint32_t*>(scratch + nblk * 4096u);
+    uint64_t* pref = reinterpret_cast<uint64_t*>(scratch + nblk * 4096u + ((nblk * 4u + 255u) & ~255ull));
+    const uint32_t pat = delim * 0x01010101u;
+    const uint32_t nb = (uint32_t)(blk1 - blk0);
+    hipLaunchKernelGGL(fg::k_frame_scan, dim3(nb), dim3(fg::kWave), 0, stream, d_bytes, nbytes, pat, masks, counts, blk0);
+    hipLaunchKernelGGL(fg::k_frame_prefix, dim3(1), dim3(1024), 0, stream, counts + blk0, (uint64_t)nb, pref + blk0, blk0 ? 1u : 0u);
+    hipLaunchKernelGGL(fg::k_frame_emit, dim3(nb), dim3(fg::kWave), 0, stream, masks, pref, nbytes, nblk, d_offsets, d_bad, cap, blk0, 0u);
+    *d_total_out = pref + blk1;
     return (int)hipGetLastError();
 }

@@ -146,3 +146,59 @@ def test_ltsv_stdout_side_effect_matches_the_reference_text(oracle):
     buf = np.zeros(int(n) + 1, np.uint8)
     L.lib().fg_tables_stdout(LTSV, 0, pad.ctypes.data, offsets.ctypes.data, C.byref(only_meta), 0, tab.n, buf.ctypes.data, int(n))
     assert buf[: int(n)].tobytes() == want
+
+
+@pytest.mark.parametrize("fmt_name,final", [("rfc5424", True), ("rfc5424", False), ("ltsv", True), ("gelf", True)])
+def test_raw_stream_pipelined_over_three_streams_equals_one_piece_and_oracle(oracle, fmt_name, final):
+    """fg_frame_decode_batch above 48 MiB: the chunk crosses the link in slices, each slice is framed as soon as it is there (the
+    delimiter ranks continue where the slice before stopped), the frames that end in it are decoded and their rows go back while the
+    next slices are still on the link.  Same tables, frame offsets and `consumed` as the one-piece path -- with "\\r\\n", invalid
+    UTF-8 (also across a slice boundary), an unterminated tail -- and the oracle's Records on a prefix."""
+    from flowgger_amd import GelfDecoder, RFC5424Decoder
+    from flowgger_amd import _lib as L
+
+    if fmt_name == "rfc5424":
+        dec, fmt, cfg = RFC5424Decoder(), 0, None
+        lines = synth.rfc5424_lines(150_000, cfg=2) + synth.rfc5424_lines(60_000, cfg=4, sd=True)
+    elif fmt_name == "ltsv":
+        dec, fmt, cfg, lines = LTSVDecoder(synth.LTSV_CONFIG), 1, synth.LTSV_CONFIG, synth.ltsv_lines(260_000)
+    else:
+        dec, fmt, cfg = GelfDecoder(), 2, None
+        lines = [ln for ln in synth.gelf_lines(230_000) if b"\n" not in ln]
+    rng = np.random.default_rng(7)
+    parts = []
+    for i, ln in enumerate(lines):
+        if i % 997 == 5:
+            ln = ln + b" \xe4\xb8"          # a sequence cut off by the terminator
+        if i % 1499 == 7:
+            ln = b"\xff" + ln
+        parts.append(ln + (b"\r\n" if i % 7 == 0 else b"\n"))
+    raw = b"".join(parts) + b"<13>1 2015-08-05T15:53:45Z tail without a terminator"
+    assert len(raw) > (56 << 20)
+    # a multi-byte sequence right across the first slice boundary (8 MiB): overwrite message text, keep the framing
+    buf = bytearray(raw)
+    cut = 8 << 20
+    for p in (cut - 1, cut, cut + 1):
+        assert buf[p] not in (0x0A, 0x0D)
+    buf[cut - 1:cut + 2] = "中".encode()
+    raw = bytes(buf)
+    piped = dec.frame_decode_batch(raw, L.FG_FRAME_LINE, final=final)
+    dec.set_launch_opts(transcode_one_piece=True)
+    whole = dec.frame_decode_batch(raw, L.FG_FRAME_LINE, final=final)
+    dec.set_launch_opts()
+    (pt, poff, pcons), (wt, woff, wcons) = piped, whole
+    assert pcons == wcons and np.array_equal(poff, woff) and pt.n == wt.n == len(lines) + (1 if final else 0)
+    assert pcons == (len(raw) if final else len(raw) - len(b"<13>1 2015-08-05T15:53:45Z tail without a terminator"))
+    data = np.frombuffer(raw + b"\0" * 16, np.uint8)
+    pb, po = pt.serialize(fmt, data, poff, cfg=dec._cfg)
+    wb, wo = wt.serialize(fmt, data, woff, cfg=dec._cfg)
+    assert np.array_equal(po, wo) and np.array_equal(pb, wb)
+    assert int((pt.status == 0xFD).sum()) == len([i for i in range(len(lines)) if i % 997 == 5 or i % 1499 == 7])
+    # the oracle on a prefix of the frames (terminators stripped as BufRead::lines() does)
+    m = 40_000
+    stripped = [p[:-2] if p.endswith(b"\r\n") else p[:-1] for p in parts[:m]]
+    for i in rng.integers(0, m, 3000):
+        got = pb[int(po[i]):int(po[i + 1])].tobytes()
+        if pt.status[i] == 0xFD:
+            continue
+        assert got == oracle.decode(fmt, stripped[i], cfg), i
