@@ -321,6 +321,7 @@ template <int NB, bool PROF, class F>
 __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets,
                                                 uint64_t n, const DevTables& t, uint32_t tile_cap, uint32_t L, uint64_t groups,
                                                 unsigned long long* prof, uint64_t* stash_base, F& fmt, FrameArgs fr) {
+    (void)groups;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint16_t* bm16 = reinterpret_cast<uint16_t*>(smem + tile_cap + 64u);
     const uint32_t bm_stride = tile_cap / 16u + 16u;  // u16 entries per class bitmap (F::kClasses of them, back to back)
@@ -329,29 +330,41 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
     const uint64_t G = gridDim.x;
     uint64_t* stash = stash_base ? stash_base + (uint64_t)blockIdx.x * (kStashEntries * kStashWords * kWave) : nullptr;
 
-    // group geometry from the lanes' offsets, as SCALARS: tile start (16-byte aligned) + staged span
-    auto geometry = [&](uint64_t g, uint64_t o0, uint64_t o1, uint64_t* a0, uint32_t* span) {
-        const uint64_t l0 = g * L;
-        const uint32_t nl = (uint32_t)((l0 + L <= n) ? L : n - l0);
+    // A wave owns a CONTIGUOUS range of lines [p, hi) and cuts it into groups BY BYTES: a group = as many consecutive lines as
+    // fit the tile, at most L of them (one per lane).  (Round 2 cut groups by line count, L lines of AVERAGE length per tile: on
+    // the long-tail corpora -- 64 B .. 8 KiB -- a third of the groups overflowed the tile and were finished in further passes over
+    // a synchronously restaged tile, which is where those workloads spent their time.)  Short lines give groups of L lines as
+    // before; only a single line longer than the whole tile is still parsed from global memory.
+    const uint64_t hi_line = n * (uint64_t)(blockIdx.x + 1u) / G;  // (n < 2^50, a grid of a few thousand waves: no overflow)
+    uint64_t p = n * (uint64_t)blockIdx.x / G;
+
+    // the L offsets from line q on (clamped to the wave's range), as o0 = start / o1 = end of lane's line
+    auto load_offsets = [&](uint64_t q, uint64_t* o0, uint64_t* o1) {
+        const uint64_t li = q + lane;
+        const bool in = lane < L && li < hi_line;
+        *o0 = offsets[in ? li : hi_line];
+        *o1 = offsets[in ? li + 1 : hi_line];
+    };
+    // group geometry from the lanes' offsets, as SCALARS: lines in the group, tile start (16-byte aligned), staged span
+    auto geometry = [&](uint64_t q, uint64_t o0, uint64_t o1, uint32_t* nl, uint64_t* a0, uint32_t* span) {
+        const uint64_t left = hi_line - q;
+        const uint32_t avail = left < (uint64_t)L ? (uint32_t)left : L;  // >= 1
         // (the builtins return int: widen through uint32_t or bit 31 sign-extends into the high word)
-        const uint32_t last = (uint32_t)__builtin_amdgcn_readfirstlane((int)(nl - 1u));
         const uint32_t lo_l = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)o0);
         const uint32_t lo_h = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(o0 >> 32));
+        const uint64_t lo = (uint64_t)lo_l | ((uint64_t)lo_h << 32);
+        *a0 = lo & ~15ull;
+        // leading lanes whose line ends inside the tile; the first line always goes (alone, from global memory, when too long)
+        const unsigned long long fit = __ballot(lane < avail && (o1 - *a0) <= (uint64_t)tile_cap);
+        uint32_t cnt = fit == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~fit);  // leading ones
+        if (cnt == 0u) cnt = 1u;
+        *nl = cnt;
+        const uint32_t last = cnt - 1u;
         const uint32_t hi_l = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)o1, (int)last);
         const uint32_t hi_h = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(o1 >> 32), (int)last);
-        const uint64_t lo = (uint64_t)lo_l | ((uint64_t)lo_h << 32);
         const uint64_t hi = (uint64_t)hi_l | ((uint64_t)hi_h << 32);
-        *a0 = lo & ~15ull;
         const uint64_t want = hi - *a0;
         *span = want > tile_cap ? tile_cap : (uint32_t)((want + 15ull) & ~15ull);
-    };
-    auto load_offsets = [&](uint64_t g, uint64_t* o0, uint64_t* o1) {
-        const uint64_t l0 = g * L;
-        uint64_t li = l0 + lane;
-        const uint64_t last = (l0 + L < n) ? l0 + L : n;
-        const bool valid = lane < L && li < n;
-        *o0 = offsets[valid ? li : last];
-        *o1 = offsets[valid ? li + 1 : last];
     };
     // the register window: NB buffer loads of 16 B per lane; the buffer descriptor bounds the
     // tile, so rows past `span` fetch nothing and return zeros -- no per-row predication.  The
@@ -367,17 +380,14 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
     // (the last 8 bytes of the 64-byte pad behind the tile: no tile read reaches them)
     uint32_t* ent_state = reinterpret_cast<uint32_t*>(smem + tile_cap + 56u);
     if (lane < 2u) ent_state[lane] = 0u;
-    uint64_t g = blockIdx.x;
-    if (g >= groups) return;
+    if (p >= hi_line) return;
     uint64_t o0, o1, a0;
-    uint32_t span;
-    load_offsets(g, &o0, &o1);
-    geometry(g, o0, o1, &a0, &span);
+    uint32_t span, nl;
+    load_offsets(p, &o0, &o1);
+    geometry(p, o0, o1, &nl, &a0, &span);
     u32x4 v[NB];
     load_window(a0, span, v);
-    uint64_t no0 = 0, no1 = 0;
-    if (g + G < groups) load_offsets(g + G, &no0, &no1);
-    // The table row of a group is stored one iteration LATE (after the next group's stage A,
+    // The table row of a group is normally stored one iteration LATE (after the next group's stage A,
     // before the prefetch after that is issued): vmcnt retires in order, so stores issued
     // behind the window loads would have to be waited for at the top of every iteration.
     RowOut pend{};
@@ -391,12 +401,18 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
     const uint32_t term4 = fr.strip == FG_FRAME_LINE ? 0x0A0A0A0Au : fr.strip == FG_FRAME_NUL ? 0u : wv::kNoTerm;
 
     for (;;) {
+        // the next group starts where this one ends: its offsets are requested NOW (they ride behind the window loads and are
+        // needed only after stage A, when the next window is issued)
+        const uint64_t pn = p + nl;
+        const bool more = pn < hi_line;  // wave-uniform
+        uint64_t no0 = 0, no1 = 0;
+        if (more) load_offsets(pn, &no0, &no1);
         if (PROF) {
             tm0 = __builtin_amdgcn_s_memtime();
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the window has landed
             tm1 = __builtin_amdgcn_s_memtime();
         }
-        // ---- stage A for group g: registers -> LDS, classify on the way ----------------------
+        // ---- stage A for this group: registers -> LDS, classify on the way ----------------------
         FG_MARK(A);
         const uint32_t nchunk = span >> 4;
         const uint32_t nrow = (nchunk + kWave - 1u) / kWave;  // wave-uniform
@@ -409,7 +425,7 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
                 F::classify_store(q, bm16, idx, bm_stride, idx < nchunk ? term4 : wv::kPastSpan);
             }
         }
-        if (nrow > (uint32_t)NB) {  // rare: bytes beyond the register window
+        if (nrow > (uint32_t)NB) {  // bytes beyond the register window
             const uint4* __restrict__ src = reinterpret_cast<const uint4*>(bytes + a0);
             // Loads and stores are UNCONDITIONAL (lanes past the end move the last chunk once more: same bytes, same
             // address): with `if (idx < nchunk)` the compiler kept w[] in scratch memory and waited for each load
@@ -442,30 +458,26 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
             tm2 = __builtin_amdgcn_s_memtime();
         }
         if (pend_valid && !(ablate & 1u)) store_row(t, pend_li, pend);
-        // ---- prefetch: offsets of g+2G first (they must not queue behind the data), then the
-        //      bytes of g+G into the register window ------------------------------------------
-        const uint64_t gn = g + G;
-        const bool more = gn < groups;  // wave-uniform
-        uint64_t po0 = no0, po1 = no1, pa0 = 0;
-        uint32_t pspan = 0;
+        // ---- prefetch: the next group's geometry from its offsets, then its bytes into the register window ----
+        uint64_t pa0 = 0;
+        uint32_t pspan = 0, pnl = 0;
         if (more) {
-            if (gn + G < groups) load_offsets(gn + G, &no0, &no1);
-            geometry(gn, po0, po1, &pa0, &pspan);
+            geometry(pn, no0, no1, &pnl, &pa0, &pspan);
             load_window(pa0, pspan, v);
         }
         __builtin_amdgcn_sched_barrier(0);
         FG_MARK(B);
         if (PROF) tm3 = __builtin_amdgcn_s_memtime();
         __syncthreads();  // single-wave workgroup: orders the LDS writes before stage B's reads
-        // ---- stage B for group g ------------------------------------------------------------
+        // ---- stage B for this group ---------------------------------------------------------
         if (!(ablate & 2u)) {
-            const uint64_t li = g * L + lane;
-            const bool valid = lane < L && li < n;
+            const uint64_t li = p + lane;
+            const bool valid = lane < nl;
             // terminator stripping (BufRead::lines / split(0) semantics, see fg_frame.hip)
             uint64_t e1 = o1;
             if (fr.strip != FG_FRAME_NONE && valid && e1 > o0) {
-                auto byte_at = [&](uint64_t p) -> uint32_t {
-                    return (p - a0) < (uint64_t)span ? (uint32_t)smem[p - a0] : (uint32_t)bytes[p];
+                auto byte_at = [&](uint64_t q) -> uint32_t {
+                    return (q - a0) < (uint64_t)span ? (uint32_t)smem[q - a0] : (uint32_t)bytes[q];
                 };
                 const uint32_t b1 = byte_at(e1 - 1);
                 if (fr.strip == FG_FRAME_LINE) {
@@ -477,64 +489,10 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
                     --e1;
                 }
             }
-            // Lines are tokenised out of the tile.  The tile was sized for the AVERAGE group; when
-            // this group is longer, the lines that did not fit are done in further passes over a tile
-            // restaged from the first of them (plain loads: rare, so not prefetched).  Only a single
-            // line longer than the whole tile is parsed straight from global memory.  The common
-            // case -- everything fits -- is kept apart so that it pays nothing for the loop.
-            const bool fits0 = valid && (o1 - a0) <= (uint64_t)span;
-            if (__ballot(valid && !fits0) == 0ull) {  // wave-uniform
-                GroupCtx c{bytes, smem, bm16, o0, e1, a0, span, valid, li, (ablate & 8u) ? nullptr : stash, ablate, ent_state, PROF ? prof + 6 : nullptr};
-                pend = fmt.decode(c, t);
-            } else {
-                uint64_t ta0 = a0;
-                uint32_t tspan = span;
-                bool todo = valid;
-                for (;;) {
-                    const bool fits = todo && (o1 - ta0) <= (uint64_t)tspan;
-                    const unsigned long long fit_m = __ballot(fits), todo_m = __ballot(todo);
-                    if (todo_m == 0ull) break;  // wave-uniform
-                    bool now = fits;
-                    if (fit_m == 0ull) now = todo && lane == (uint32_t)__builtin_ctzll(todo_m);  // longer than the tile: alone, from global
-                    GroupCtx c{bytes, smem, bm16, o0, e1, ta0, tspan, now, li, (ablate & 8u) ? nullptr : stash, ablate, ent_state, PROF ? prof + 6 : nullptr};
-                    const RowOut r = fmt.decode(c, t);
-                    if (now) pend = r;
-                    todo = todo && !now;
-                    const unsigned long long left_m = __ballot(todo);
-                    if (left_m == 0ull) break;
-                    // restage: tile starts at the first unfinished line
-                    const uint32_t j = (uint32_t)__builtin_ctzll(left_m);
-                    const uint32_t nl = (uint32_t)((g * L + L <= n) ? L : n - g * L);
-                    const uint64_t lo = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)o0, (int)j) |
-                                        ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(o0 >> 32), (int)j) << 32);
-                    const uint64_t hi = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)o1, (int)(nl - 1u)) |
-                                        ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(o1 >> 32), (int)(nl - 1u)) << 32);
-                    ta0 = lo & ~15ull;
-                    const uint64_t want = hi - ta0;
-                    tspan = want > tile_cap ? tile_cap : (uint32_t)((want + 15ull) & ~15ull);
-                    __syncthreads();  // every lane is done reading the old tile
-                    {
-                        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(bytes + ta0);
-                        const uint32_t nch = tspan >> 4;
-                        const uint32_t lastc = nch ? nch - 1u : 0u;  // (unconditional, clamped: see the tail loop of stage A)
-                        for (uint32_t c0 = 0; c0 < nch; c0 += kWave * 2) {  // (few registers: the prefetch window is live)
-                            uint4 w[2];
-#pragma unroll
-                            for (int k = 0; k < 2; ++k) {
-                                const uint32_t idx = c0 + k * kWave + lane;
-                                w[k] = src[idx < lastc ? idx : lastc];
-                            }
-#pragma unroll
-                            for (int k = 0; k < 2; ++k) {
-                                const uint32_t idx = c0 + k * kWave + lane, ci = idx < lastc ? idx : lastc;
-                                dst[ci] = w[k];
-                                F::classify_store(w[k], bm16, ci, bm_stride, term4);
-                            }
-                        }
-                    }
-                    __syncthreads();
-                }
-            }
+            // Every line of the group lies inside the tile by construction -- except a single line longer than the whole tile,
+            // which is a group of its own and is parsed straight from global memory (the decoders look at o1 - a0 <= span).
+            GroupCtx c{bytes, smem, bm16, o0, e1, a0, span, valid, li, (ablate & 8u) ? nullptr : stash, ablate, ent_state, PROF ? prof + 6 : nullptr};
+            pend = fmt.decode(c, t);
             if (fr.line_bad && valid && fr.line_bad[li]) {  // "Invalid UTF-8 input": the frame never reaches decode()
                 pend.meta = FG_ST_BAD_UTF8 | (0xFFu << 8) | (0xFFu << 16);
                 pend.ts = 0.0;
@@ -562,9 +520,10 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
         FG_MARK(Z);
         if (!more) break;
         __syncthreads();  // stage B's LDS reads are done before the next tile overwrites them
-        g = gn;
-        o0 = po0;
-        o1 = po1;
+        p = pn;
+        nl = pnl;
+        o0 = no0;
+        o1 = no1;
         a0 = pa0;
         span = pspan;
     }
@@ -626,11 +585,21 @@ inline int plan_launch(K kernel, uint64_t n, uint64_t avg_len, uint32_t extra_ld
         tile = clamp(tile_for(L));
     }
     if (lo.tile_cap >= 1024 && lo.tile_cap <= max_tile) tile = (lo.tile_cap + 1023u) / 1024u * 1024u;
+    // Groups are cut BY BYTES (persistent_loop): L is only the cap on the lines of a group.  A format without per-line LDS arrays
+    // takes the full wave width -- however long the lines, a group then holds as many as fit the tile; the tile of long lines
+    // (fewer than 16 average lines in the window) is raised to what eight waves per CU leave each other anyway.
+    if (!extra_for && !(lo.lines_per_group >= 1 && lo.lines_per_group <= max_lines)) {
+        if (L <= 16u && !(lo.tile_cap >= 1024 && lo.tile_cap <= max_tile) && tile < 18432u && max_tile >= 18432u) tile = 18432u;
+        L = max_lines;
+    }
     p->L = L;
     p->tile = tile;
     // (extra_for: LDS a format needs as a function of the tile and the lines per group, e.g. per-item arrays)
     p->lds = tile + 64u + (tile / 16u + 16u) * 2u * (n_classes ? n_classes : 1u) + extra_lds + (extra_for ? extra_for(tile, L) : 0u);
-    p->groups = (n + L - 1) / L;
+    {   // an estimate (the waves cut their ranges themselves): by lines and by bytes
+        const uint64_t by_lines = (n + L - 1) / L, by_bytes = (n * avg_len + tile - 1) / tile;
+        p->groups = by_lines > by_bytes ? by_lines : by_bytes;
+    }
     int dev = 0, cus = 0;  // (per call: a process may drive several devices)
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
