@@ -731,7 +731,7 @@ int launch_gelf_fast(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t
         if (p.tile == 4096u && p.L == 8u && !fg::prof_requested() && !(lo.flags & FG_LO_GELF_GENERIC)) {
             // the geometry of ~300-byte GELF (the BASELINE corpus): constants
             hipLaunchKernelGGL((fg::k_gelf<NB, false, 4, 4096u, 8u>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L,
-                               p.groups, (unsigned long long*)nullptr, (uint64_t*)nullptr, fr);
+                               p.chunk, (unsigned long long*)nullptr, (uint64_t*)nullptr, fr);
             return 0;
         }
     }
@@ -739,13 +739,13 @@ int launch_gelf_fast(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t
     if (fg::prof_requested()) {
         fg::ProfRun pr;
         if (!pr.begin(stream)) return -1;
-        hipLaunchKernelGGL((fg::k_gelf<NB, true>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L, p.groups, pr.d,
+        hipLaunchKernelGGL((fg::k_gelf<NB, true>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L, p.chunk, pr.d,
                            (uint64_t*)nullptr, fr);
         pr.end(stream, "gelf", p);
         return 0;
     }
 #endif
-    hipLaunchKernelGGL((fg::k_gelf<NB, false>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L, p.groups,
+    hipLaunchKernelGGL((fg::k_gelf<NB, false>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L, p.chunk,
                        (unsigned long long*)nullptr, (uint64_t*)nullptr, fr);
     return 0;
 }

@@ -384,8 +384,17 @@ struct LtsvFormat {
     // only counted -- a line with more than kStashEntries pairs is re-walked by ltsv_walk<true>).
     // (measurement build: cycles of  0 part end + name window + ':'  1 time  2 host / message / level  3 schema lookup
     //  4 typed value  5 suffix + stash  6 slots + copy-out; lane 0 adds them up per tile)
+    // Where the pairs go while the line is parsed: INTO THE LINE ITSELF.  A lane walks its line left to right; everything before the
+    // next part's first byte is dead (names and values are recorded as OFFSETS), so the 16-byte record of a pair is written over the
+    // line's own consumed bytes in the tile -- no LDS beyond the tile, no round trip through a stash in global memory (round 2: 96 B
+    // per line of HBM traffic and 28 % of stage B).  Records start at the line's first 4-byte boundary; a pair whose record would reach
+    // into bytes that are still to be read (a line of many tiny parts: `a:1\tb:2\t...`) clears *in_tile_records, and the line's pairs
+    // are written by a second walk over the line in GLOBAL memory (its bytes in the tile are no longer intact).
     template <bool PROF>
-    __device__ __forceinline__ void walk_tile(const Tile& T, uint32_t base, uint32_t len, LRow& r, uint64_t* stash, uint64_t* pc) const {
+    __device__ __forceinline__ void walk_tile(const Tile& T, uint32_t base, uint32_t len, LRow& r, uint32_t* tile_w, bool* in_tile_records,
+                                              uint64_t* pc) const {
+        uint32_t wpos = (base + 3u) & ~3u;  // tile byte where the next record goes
+        bool rec_ok = true;
         uint64_t tk = PROF ? wv::clock() : 0;
         auto tick = [&](int k) {
             if (PROF) {
@@ -558,10 +567,17 @@ struct LtsvFormat {
                             if (!ends) flags |= FG_EF_SUFFIX;
                         }
                     }
-                    if (stash && cnt < kStashEntries) {
-                        stash[(cnt * 2u) * kWave + threadIdx.x] =
-                            (uint64_t)nb | ((uint64_t)nl << 16) | ((uint64_t)ty << 32) | ((uint64_t)flags << 40);
-                        stash[(cnt * 2u + 1u) * kWave + threadIdx.x] = val;
+                    if (rec_ok) {
+                        if (wpos + 16u <= base + (more ? nps : len)) {  // (everything before the next part's first byte is dead)
+                            uint32_t* d = tile_w + (wpos >> 2);
+                            d[0] = nb | (nl << 16);
+                            d[1] = ty | (flags << 8);
+                            d[2] = (uint32_t)val;
+                            d[3] = (uint32_t)(val >> 32);
+                            wpos += 16u;
+                        } else {
+                            rec_ok = false;
+                        }
                     }
                     ++cnt;
                     tick(5);
@@ -575,6 +591,7 @@ struct LtsvFormat {
 #pragma unroll
             for (int j = 0; j < 4; ++j) w[j] = nw[j];
         }
+        *in_tile_records = rec_ok;
         if (!r.have_ts) {
             r.status = L_NOTS;
             return;
@@ -593,14 +610,16 @@ struct LtsvFormat {
         const uint32_t base = (uint32_t)(c.o0 - c.a0);
         Tile T{reinterpret_cast<const uint32_t*>(c.smem), reinterpret_cast<const uint32_t*>(c.bm16)};
         LRow r;
-        const bool name_fits = len < 65536u;  // stash records keep 16-bit name offsets
+        const bool name_fits = len < 65536u;  // the in-tile records keep 16-bit name offsets
+        uint32_t* tile_w = reinterpret_cast<uint32_t*>(const_cast<uint8_t*>(c.smem));
+        bool in_tile_records = false;
         const bool tile_lane = c.valid && in_tile && name_fits;
         uint64_t pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         uint64_t t6 = c.phase ? wv::clock() : 0;
         if (c.valid) {
             if (tile_lane) {
-                if (c.phase) walk_tile<true>(T, base, len, r, c.stash, pc);
-                else walk_tile<false>(T, base, len, r, c.stash, pc);
+                if (c.phase) walk_tile<true>(T, base, len, r, tile_w, &in_tile_records, pc);
+                else walk_tile<false>(T, base, len, r, tile_w, &in_tile_records, pc);
                 if (c.phase) t6 = wv::clock();
             } else {
                 // (rare; a real call: its LRow lives in memory, so it gets its own -- `r` must never have its address taken, or
@@ -627,40 +646,37 @@ struct LtsvFormat {
             r.n_ent = 0;
         }
         const uint32_t first = (ea.overflow || ea.total == 0u) ? 0u : ea.s.at(ea.ex);
-        const bool parked = tile_lane && c.stash && r.n_ent <= kStashEntries;
-        const bool coop = stash_to_table<2>(c, t, ea, r.n_ent, parked, [](uint64_t rec, uint64_t val, uint64_t* name, uint64_t* v, uint32_t* tf) {
-            *name = (rec & 0xFFFFull) | (((rec >> 16) & 0xFFFFull) << 32);
-            *v = val;
-            *tf = (uint32_t)((rec >> 32) & 0xFFFFu);  // type | flags << 8
-        });
-        if (!coop && r.n_ent != 0) {
-            if (parked) {
-                // k-major in the stash: coalesced reads.  Four records are in flight before the first store (the compiler cannot
-                // hoist a stash load above a table store: for all it knows they alias)
+        if (r.n_ent != 0) {
+            if (tile_lane && in_tile_records) {
+                // the records sit in the line's own (consumed) bytes: four in flight before the first store (the compiler cannot hoist
+                // an LDS read above a table store: for all it knows they alias)
+                const uint32_t* rec = tile_w + (((base + 3u) & ~3u) >> 2);
                 for (uint32_t k0 = 0; k0 < r.n_ent; k0 += 4u) {
-                    uint64_t rec[4], val[4];
+                    uint32_t q[4][4];
 #pragma unroll
                     for (uint32_t j = 0; j < 4u; ++j) {
                         const uint32_t k = k0 + j < r.n_ent ? k0 + j : r.n_ent - 1u;
-                        rec[j] = c.stash[(k * 2u) * kWave + lane];
-                        val[j] = c.stash[(k * 2u + 1u) * kWave + lane];
+#pragma unroll
+                        for (uint32_t d = 0; d < 4u; ++d) q[j][d] = rec[k * 4u + d];
                     }
 #pragma unroll
                     for (uint32_t j = 0; j < 4u; ++j) {
                         const uint32_t k = k0 + j;
                         if (k < r.n_ent) {
-                            t.ent_name[first + k] = fg_span{(uint32_t)rec[j] & 0xFFFFu, (uint32_t)(rec[j] >> 16) & 0xFFFFu};
-                            t.ent_val[first + k] = val[j];
-                            t.ent_type[first + k] = (uint8_t)((rec[j] >> 32) & 0xFFu);
-                            t.ent_flags[first + k] = (uint8_t)((rec[j] >> 40) & 0xFFu);
+                            t.ent_name[first + k] = fg_span{q[j][0] & 0xFFFFu, q[j][0] >> 16};
+                            t.ent_val[first + k] = (uint64_t)q[j][2] | ((uint64_t)q[j][3] << 32);
+                            t.ent_type[first + k] = (uint8_t)(q[j][1] & 0xFFu);
+                            t.ent_flags[first + k] = (uint8_t)((q[j][1] >> 8) & 0xFFu);
                         }
                     }
                 }
             } else {
+                // (a line outside the tile -- or one whose records did not fit its consumed bytes, whose copy in the tile is therefore
+                //  no longer intact: from global memory then)
                 LRow scratch = r;
                 const DevTables t_copy = t;  // (see above)
                 const LtsvDevCfg cfg_copy = cfg;
-                if (in_tile) {
+                if (in_tile && !tile_lane) {
                     LdsReader rd(T.w, base);
                     ltsv_walk<true>(rd, len, cfg_copy, lds_digits, scratch, t_copy, first);
                 } else {
@@ -756,12 +772,12 @@ extern "C" int fg_launch_ltsv(const uint8_t* d_bytes, const uint64_t* d_offsets,
         fg::ProfRun pr;
         if (!pr.begin(stream)) return -1;
         hipLaunchKernelGGL((fg::k_ltsv<fg::kComputeBoundWindow, true>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, *cfg, p.tile,
-                           p.L, p.groups, pr.d, stash, fg::FrameArgs{strip, line_bad});
+                           p.L, p.chunk, pr.d, stash, fg::FrameArgs{strip, line_bad});
         pr.end(stream, "ltsv", p);
         return (int)hipGetLastError();
     }
 #endif
     hipLaunchKernelGGL((fg::k_ltsv<fg::kComputeBoundWindow, false>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, *cfg, p.tile,
-                       p.L, p.groups, (unsigned long long*)nullptr, stash, fg::FrameArgs{strip, line_bad});
+                       p.L, p.chunk, (unsigned long long*)nullptr, stash, fg::FrameArgs{strip, line_bad});
     return (int)hipGetLastError();
 }

@@ -319,9 +319,9 @@ struct defer_row_store<F, decltype((void)F::kDeferRowStore)> { static constexpr 
 
 template <int NB, bool PROF, class F>
 __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets,
-                                                uint64_t n, const DevTables& t, uint32_t tile_cap, uint32_t L, uint64_t groups,
+                                                uint64_t n, const DevTables& t, uint32_t tile_cap, uint32_t L, uint64_t chunk_lines,
                                                 unsigned long long* prof, uint64_t* stash_base, F& fmt, FrameArgs fr) {
-    (void)groups;
+    const uint64_t kChunkLines = chunk_lines;  // lines a wave takes at a time (LaunchPlan::chunk)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint16_t* bm16 = reinterpret_cast<uint16_t*>(smem + tile_cap + 64u);
     const uint32_t bm_stride = tile_cap / 16u + 16u;  // u16 entries per class bitmap (F::kClasses of them, back to back)
@@ -335,8 +335,14 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
     // the long-tail corpora -- 64 B .. 8 KiB -- a third of the groups overflowed the tile and were finished in further passes over
     // a synchronously restaged tile, which is where those workloads spent their time.)  Short lines give groups of L lines as
     // before; only a single line longer than the whole tile is still parsed from global memory.
-    const uint64_t hi_line = n * (uint64_t)(blockIdx.x + 1u) / G;  // (n < 2^50, a grid of a few thousand waves: no overflow)
-    uint64_t p = n * (uint64_t)blockIdx.x / G;
+    // The ranges are CHUNKS of kChunkLines lines dealt out round-robin (wave b takes chunks b, b + G, ...): the grid as a whole
+    // still sweeps the buffer front to back.  (One big range per wave -- 1792 streams spread over 25 GB -- cost the headline
+    // configuration 10 %: DRAM pages and TLB entries want neighbours in time to be neighbours in memory.)  The last group of a
+    // chunk may be short: 256 lines = 4 full groups of 64 short lines, a dozen or more groups of long ones (small batches get
+    // smaller chunks, so that every wave of the grid has one).
+    uint64_t chunk = blockIdx.x;
+    uint64_t hi_line = (chunk + 1u) * kChunkLines < n ? (chunk + 1u) * kChunkLines : n;
+    uint64_t p = chunk * kChunkLines;
 
     // the L offsets from line q on (clamped to the wave's range), as o0 = start / o1 = end of lane's line
     auto load_offsets = [&](uint64_t q, uint64_t* o0, uint64_t* o1) {
@@ -403,8 +409,13 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
     for (;;) {
         // the next group starts where this one ends: its offsets are requested NOW (they ride behind the window loads and are
         // needed only after stage A, when the next window is issued)
-        const uint64_t pn = p + nl;
-        const bool more = pn < hi_line;  // wave-uniform
+        uint64_t pn = p + nl;
+        if (pn >= hi_line) {  // this chunk is done: on to the wave's next one
+            chunk += G;
+            pn = chunk * kChunkLines;
+            hi_line = (chunk + 1u) * kChunkLines < n ? (chunk + 1u) * kChunkLines : n;
+        }
+        const bool more = pn < n;  // wave-uniform
         uint64_t no0 = 0, no1 = 0;
         if (more) load_offsets(pn, &no0, &no1);
         if (PROF) {
@@ -556,7 +567,8 @@ struct LaunchPlan {
     uint32_t L = 64;      // lines per group
     uint32_t tile = 0;    // LDS tile bytes (multiple of 1024)
     uint32_t lds = 0;     // dynamic LDS bytes per workgroup = tile + 64 + bitmap + extra
-    uint64_t groups = 0;
+    uint64_t groups = 0;  // an estimate (the waves cut their ranges into groups themselves)
+    uint64_t chunk = 256; // lines a wave takes at a time, dealt out round-robin
     uint32_t blocks = 0;  // persistent grid
 };
 
@@ -610,6 +622,19 @@ inline int plan_launch(K kernel, uint64_t n, uint64_t avg_len, uint32_t extra_ld
     uint64_t blocks = (uint64_t)per_cu * (uint64_t)cus;
     if (blocks > p->groups) blocks = p->groups;
     if (stash_blocks && blocks > stash_blocks) blocks = stash_blocks;
+    // 256 lines per chunk (four groups of 64 short lines: the HBM-bound configuration keeps its sweep tight) -- 1024 when a group
+    // holds fewer than L average lines, so that the short group at the end of every chunk stays a few per cent -- provided the batch
+    // gives every wave at least two chunks; else what spreads the batch over the grid
+    const uint64_t full = (avg_len ? (uint64_t)p->tile / avg_len : p->L) >= p->L ? 256u : 1024u;
+    uint64_t chunk = full;
+    if (n < blocks * 2u * chunk) {
+        chunk = (n + blocks - 1) / (blocks ? blocks : 1);
+        if (chunk < p->L) chunk = p->L;
+        if (chunk > full) chunk = full;
+    }
+    const uint64_t chunks = (n + chunk - 1) / chunk;
+    if (blocks > chunks) blocks = chunks;
+    p->chunk = chunk;
     p->blocks = (uint32_t)blocks;
     return 0;
 }

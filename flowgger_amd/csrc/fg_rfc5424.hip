@@ -869,13 +869,13 @@ extern "C" int fg_launch_rfc5424(const uint8_t* d_bytes, const uint64_t* d_offse
         fg::ProfRun pr;
         if (!pr.begin(stream)) return -1;
         hipLaunchKernelGGL((fg::k_rfc5424<fg::kWindowKiB, true>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile,
-                           p.L, p.groups, pr.d, stash, fg::FrameArgs{strip, line_bad});
+                           p.L, p.chunk, pr.d, stash, fg::FrameArgs{strip, line_bad});
         pr.end(stream, "rfc5424", p);
         return (int)hipGetLastError();
     }
 #endif
     hipLaunchKernelGGL((fg::k_rfc5424<fg::kWindowKiB, false>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L,
-                       p.groups, (unsigned long long*)nullptr, stash, fg::FrameArgs{strip, line_bad});
+                       p.chunk, (unsigned long long*)nullptr, stash, fg::FrameArgs{strip, line_bad});
     return (int)hipGetLastError();
 }
 
