@@ -55,6 +55,9 @@ def parse_args():
                          "kernels on their parity-test corpora (not bench lines, see DESIGN.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive host-buffer legs (fg_decode_batch / fg_transcode_batch)")
+    ap.add_argument("--no-mix", action="store_true",
+                    help="default workload, one GPU, no launcher: skip the bounded BASELINE configs[4] leg (a cfg5mix sample run as a child "
+                         "process; its rate and gather_ms ride along in the line as `configs4`)")
     ap.add_argument("--spawn", action="store_true",
                     help="launch the ranks through torch.distributed.run even for --gpus 1 (the path --gpus N>1 takes by itself "
                          "when WORLD_SIZE is not set)")
@@ -643,6 +646,19 @@ def main():
                 pass
         if e2e is not None:
             out["e2e"] = e2e
+        if wl == "cfg2" and world == 1 and "WORLD_SIZE" not in os.environ and not args.no_mix:
+            # BASELINE configs[4] (mixed RFC5424 + LTSV long-tail stream, host-side ordered gather) on a bounded sample, so that the
+            # driver's default run carries its rate and gather time too: this very script, --workload cfg5mix, as a child process
+            try:
+                r = subprocess.run([sys.executable, str(Path(__file__).resolve()), "--workload", "cfg5mix", "--tile-lines", "200000", "--reps", "5",
+                                    "--steps", "5", "--warmup", "2", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300)
+                m = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+                out["configs4"] = {"workload": m["config"]["workload"], "value": m["value"], "unit": m["unit"], "ms_per_step": m["ms_per_step"],
+                                   "gather_ms": m["gather_ms"], "gather": m["gather"], "sub_batches": m["sub_batches"],
+                                   "roofline_frac": m["roofline"]["frac"],
+                                   "what": "python bench.py --workload cfg5mix on a bounded sample (1 M lines resident); full size: that command alone"}
+            except Exception as e:  # noqa: BLE001 -- the extra leg never takes the bench line down
+                out["configs4"] = {"error": repr(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:  # (the contract: the CPU leg runs on rank 0 at N = 1 only)
             os.sched_setaffinity(0, all_cpus)  # (the CPU leg uses every host core, not only the GPU's NUMA node)
             legs = [(s.fmt, s.data, s.offsets, s.n_tile, synth.LTSV_CONFIG if s.fmt == 1 else None) for s in subs]

@@ -65,7 +65,7 @@ class fg_encode_cfg(C.Structure):
 
 class fg_launch_opts(C.Structure):
     _fields_ = [("lines_per_group", C.c_uint32), ("tile_cap", C.c_uint32), ("waves_per_cu", C.c_uint32),
-                ("gelf_lds_budget", C.c_uint32), ("gelf_window_kib", C.c_uint32), ("flags", C.c_uint32)]
+                ("gelf_lds_budget", C.c_uint32), ("gelf_window_kib", C.c_uint32), ("flags", C.c_uint32), ("chunk_lines", C.c_uint32)]
 
 
 FG_LO_GELF_GENERIC, FG_LO_TRANSCODE_ONE_PIECE = 1, 2

@@ -622,15 +622,17 @@ inline int plan_launch(K kernel, uint64_t n, uint64_t avg_len, uint32_t extra_ld
     uint64_t blocks = (uint64_t)per_cu * (uint64_t)cus;
     if (blocks > p->groups) blocks = p->groups;
     if (stash_blocks && blocks > stash_blocks) blocks = stash_blocks;
-    // 256 lines per chunk (four groups of 64 short lines: the HBM-bound configuration keeps its sweep tight) -- 1024 when a group
-    // holds fewer than L average lines, so that the short group at the end of every chunk stays a few per cent -- provided the batch
-    // gives every wave at least two chunks; else what spreads the batch over the grid
-    const uint64_t full = (avg_len ? (uint64_t)p->tile / avg_len : p->L) >= p->L ? 256u : 1024u;
-    uint64_t chunk = full;
+    // 256 lines per chunk (four groups of 64 short lines: the HBM-bound configuration keeps its sweep tight) -- 512 when a group
+    // holds fewer than L average lines, so that the short group at the end of every chunk stays a few per cent (same-box sweep,
+    // tools/sweep.py, 4 M lines: cfg4 1058 / 1150 / 974 M lines/s at 256 / 512 / 1024 -- the grid's 1792 waves need a few rounds
+    // of chunks each to finish together) -- provided the batch gives every wave at least two chunks; else what spreads the batch
+    // over the grid
+    const uint64_t full = (avg_len ? (uint64_t)p->tile / avg_len : p->L) >= p->L ? 256u : 512u;
+    uint64_t chunk = lo.chunk_lines >= p->L && lo.chunk_lines <= 65536u ? lo.chunk_lines : full;
     if (n < blocks * 2u * chunk) {
         chunk = (n + blocks - 1) / (blocks ? blocks : 1);
         if (chunk < p->L) chunk = p->L;
-        if (chunk > full) chunk = full;
+        if (chunk > full && !lo.chunk_lines) chunk = full;
     }
     const uint64_t chunks = (n + chunk - 1) / chunk;
     if (blocks > chunks) blocks = chunks;

@@ -191,6 +191,7 @@ typedef struct fg_launch_opts {
     uint32_t gelf_lds_budget; /* GELF: LDS bytes per wave the lines per group are fitted to */
     uint32_t gelf_window_kib; /* GELF: register prefetch window in KiB (2..6) */
     uint32_t flags;           /* FG_LO_* */
+    uint32_t chunk_lines;     /* lines a wave takes at a time (dealt out round-robin over the grid), 64..65536 */
 } fg_launch_opts;
 enum {
     FG_LO_GELF_GENERIC = 1,        /* GELF: the run-time-geometry kernel even where the constant-geometry instantiation applies */

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""One corpus, many launch geometries: tools/sweep.py <workload> [--lines N] [--reps R] opts;opts;...   (opts = k=v,k=v; empty = defaults)
+Generates the workload's tile ONCE, keeps it resident, and times fg_decode_batch_device under each fg_set_launch_opts setting (HIP
+events, 5 launches after 2 warm-ups) -- an A/B on the SAME box in seconds instead of one bench.py process per point."""
+import sys
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from flowgger_amd import synth  # noqa: E402
+
+
+def main():
+    wl = sys.argv[1]
+    args = sys.argv[2:]
+    lines_n, reps = 1_000_000, 4
+    while args and args[0].startswith("--"):
+        if args[0] == "--lines":
+            lines_n = int(args[1])
+        elif args[0] == "--reps":
+            reps = int(args[1])
+        args = args[2:]
+    settings = (args[0] if args else "").split(";")
+    fmt = bench.WORKLOADS[wl][0]
+    if wl == "cfg3":
+        lines = synth.gelf_lines(lines_n)
+    elif wl in ("ltsv", "ltsv5"):
+        lines = synth.ltsv_lines(lines_n, long_tail=wl == "ltsv5")
+    elif wl == "cfg5":
+        lines = synth.rfc5424_lines(lines_n, cfg=5, sd=True, long_tail=True)
+    else:
+        lines = synth.rfc5424_lines(lines_n, cfg=4 if wl == "cfg4" else 2, sd=wl == "cfg4")
+    dev = torch.device("cuda", 0)
+    R = bench.Resident(fmt, lines, reps, dev, 0, {}, entries=wl != "cfg2")
+    stream = torch.cuda.current_stream(dev)
+    for s in settings:
+        opts = {k: int(v) for k, v in (kv.split("=") for kv in s.split(",") if kv)}
+        R.dec.set_launch_opts(**opts)
+        for _ in range(2):
+            R.decode(stream)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+        for a, b in ev:
+            a.record(stream)
+            R.decode(stream)
+            b.record(stream)
+        torch.cuda.synchronize(dev)
+        ms = float(np.median([a.elapsed_time(b) for a, b in ev]))
+        n_ok, used = R.check_replicas()
+        print(f"{wl:6s} {s or 'defaults':40s} {R.n / ms / 1e3:9.1f} M lines/s  {ms:8.3f} ms  ok/tile {n_ok}", flush=True)
+
+
+main()
