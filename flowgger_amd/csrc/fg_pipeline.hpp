@@ -228,6 +228,10 @@ struct GroupCtx {
     uint32_t ablate;        // measurement build only
     uint32_t* ent_state;    // the wave's entry-slot reservation (two LDS words that persist across groups, wv::wave_alloc)
     unsigned long long* phase;  // measurement build only: ten format-specific phase clocks (lane 0 adds), else null
+    // HEAD staging (persistent_loop<..., HEAD = true>; else unused): the tile holds only the first bytes of every line
+    uint32_t tbase = 0;     // tile byte of this lane's line
+    uint32_t tlen = 0;      // bytes of the line that are in the tile, from its first byte (== its length when it is there whole)
+    uint32_t last2 = 0;     // the line's last byte | the byte before it << 8 (the trims look there; 0 where the line has none)
 };
 
 // The entries a wave parked in its stash -> the entry table THROUGH THE TILE: once every lane has parsed its line the tile's
@@ -317,10 +321,19 @@ struct defer_row_store { static constexpr bool value = true; };
 template <class F>
 struct defer_row_store<F, decltype((void)F::kDeferRowStore)> { static constexpr bool value = F::kDeferRowStore; };
 
-template <int NB, bool PROF, class F>
+// HEAD = true: LONG lines.  Per-line parse work does not grow with the message, and the lines a CU can have in flight are what its LDS
+// holds (these kernels run at lines-in-flight / per-line latency: tools/sweep.py, throughput linear in the waves per CU) -- so a
+// format that never looks inside the message (RFC5424: header, structured data, the trims) stages only the HEAD of every line,
+// its first kHeadCap bytes, one 1 KiB row per line (coalesced, bounds-checked by a buffer descriptor per row): three to four times
+// the lines per tile on the 64 B .. 8 KiB corpus.  The decoder gets the line's last two bytes beside it (the trims) and takes the
+// rare line whose structured data runs past its head from global memory.
+constexpr uint32_t kHeadCap = 1024;  // bytes of a line staged in HEAD mode, alignment slack included (a multiple of 16)
+
+template <int NB, bool PROF, class F, bool HEAD = false>
 __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets,
                                                 uint64_t n, const DevTables& t, uint32_t tile_cap, uint32_t L, uint64_t chunk_lines,
                                                 unsigned long long* prof, uint64_t* stash_base, F& fmt, FrameArgs fr) {
+    static_assert(!HEAD || F::kClasses == 0, "HEAD staging is for formats without stage-A byte classes");
     const uint64_t kChunkLines = chunk_lines;  // lines a wave takes at a time (LaunchPlan::chunk)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint16_t* bm16 = reinterpret_cast<uint16_t*>(smem + tile_cap + 64u);
@@ -382,17 +395,64 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
 #pragma unroll
         for (int k = 0; k < NB; ++k) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(lane * 16u + k * 1024u), 0, FG_STREAM_AUX);
     };
+    // ---- HEAD mode ----
+    // per lane: st = bytes of its line's row in the tile (alignment slack + head, a multiple of 16, <= kHeadCap), tb = the row's tile
+    // offset (exclusive prefix sum); a group = the leading lines whose rows fit the tile
+    auto geometry_head = [&](uint64_t q, uint64_t o0, uint64_t o1, uint32_t* nl, uint32_t* span, uint32_t* st_out, uint32_t* tb_out) {
+        const uint64_t left = hi_line - q;
+        const uint32_t avail = left < (uint64_t)L ? (uint32_t)left : L;  // >= 1
+        const uint64_t want = (o1 - o0) + (o0 & 15ull);
+        uint32_t st = want >= kHeadCap ? kHeadCap : (uint32_t)((want + 15ull) & ~15ull);
+        if (lane >= avail) st = 0u;
+        uint32_t total;
+        const uint32_t tb = wv::excl_sum(st, &total);
+        const unsigned long long fit = __ballot(lane < avail && tb + st <= tile_cap);
+        uint32_t cnt = fit == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~fit);
+        if (cnt == 0u) cnt = 1u;  // (cannot happen: a row is at most kHeadCap <= tile_cap)
+        *nl = cnt;
+        const uint32_t last = cnt - 1u;
+        *span = (uint32_t)__builtin_amdgcn_readlane((int)tb, (int)last) + (uint32_t)__builtin_amdgcn_readlane((int)st, (int)last);
+        *st_out = lane < cnt ? st : 0u;
+        *tb_out = tb;
+    };
+    // row k of the window = the head of line k (a buffer descriptor per row: base = the line's first 16-byte boundary, range = its
+    // row's bytes; lanes beyond fetch nothing)
+    auto load_window_head = [&](uint64_t o0, uint32_t st, u32x4* v) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)o0, k);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(o0 >> 32), k);
+            const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)st, k);
+            const uint64_t b = ((uint64_t)lo | ((uint64_t)hi << 32)) & ~15ull;
+            __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(bytes + b), (short)0, (int)sk, 0x00020000);
+            v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(lane * 16u), 0, FG_STREAM_AUX);
+        }
+    };
+    // the line's last two bytes (the trims and the terminator strip look there)
+    auto load_last2 = [&](uint64_t o0, uint64_t o1) -> uint32_t {
+        const uint64_t len = o1 - o0;
+        uint32_t r = 0;
+        if (len >= 1u) r = bytes[o1 - 1u];
+        if (len >= 2u) r |= (uint32_t)bytes[o1 - 2u] << 8;
+        return r;
+    };
 
     // (the last 8 bytes of the 64-byte pad behind the tile: no tile read reaches them)
     uint32_t* ent_state = reinterpret_cast<uint32_t*>(smem + tile_cap + 56u);
     if (lane < 2u) ent_state[lane] = 0u;
     if (p >= hi_line) return;
-    uint64_t o0, o1, a0;
-    uint32_t span, nl;
+    uint64_t o0, o1, a0 = 0;
+    uint32_t span, nl, st = 0, tb = 0, last2 = 0;
     load_offsets(p, &o0, &o1);
-    geometry(p, o0, o1, &nl, &a0, &span);
     u32x4 v[NB];
-    load_window(a0, span, v);
+    if constexpr (HEAD) {
+        geometry_head(p, o0, o1, &nl, &span, &st, &tb);
+        load_window_head(o0, st, v);
+        last2 = load_last2(o0, o1);
+    } else {
+        geometry(p, o0, o1, &nl, &a0, &span);
+        load_window(a0, span, v);
+    }
     // The table row of a group is normally stored one iteration LATE (after the next group's stage A,
     // before the prefetch after that is issued): vmcnt retires in order, so stores issued
     // behind the window loads would have to be waited for at the top of every iteration.
@@ -426,7 +486,37 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
         // ---- stage A for this group: registers -> LDS, classify on the way ----------------------
         FG_MARK(A);
         const uint32_t nchunk = span >> 4;
-        const uint32_t nrow = (nchunk + kWave - 1u) / kWave;  // wave-uniform
+        const uint32_t nrow = HEAD ? nl : (nchunk + kWave - 1u) / kWave;  // wave-uniform
+        if constexpr (HEAD) {
+            // row k = the head of line k: its chunks go to the row's place in the tile
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                if ((uint32_t)k < nl) {  // scalar branch
+                    const uint32_t tk = (uint32_t)__builtin_amdgcn_readlane((int)tb, k), sk = (uint32_t)__builtin_amdgcn_readlane((int)st, k);
+                    if (lane * 16u < sk) dst[(tk >> 4) + lane] = make_uint4(v[k][0], v[k][1], v[k][2], v[k][3]);
+                }
+            }
+            // lines beyond the window: four rows in flight
+            for (uint32_t r0 = NB; r0 < nl; r0 += 4u) {
+                uint4 w[4];
+                uint32_t tk[4], sk[4];
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; ++j) {
+                    const uint32_t r = r0 + j < nl ? r0 + j : nl - 1u;
+                    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)o0, (int)r);
+                    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(o0 >> 32), (int)r);
+                    tk[j] = (uint32_t)__builtin_amdgcn_readlane((int)tb, (int)r);
+                    sk[j] = (uint32_t)__builtin_amdgcn_readlane((int)st, (int)r);
+                    const uint64_t b = ((uint64_t)lo | ((uint64_t)hi << 32)) & ~15ull;
+                    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(bytes + b), (short)0, (int)sk[j], 0x00020000);
+                    const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(lane * 16u), 0, FG_STREAM_AUX);
+                    w[j] = make_uint4(x[0], x[1], x[2], x[3]);
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; ++j)
+                    if (lane * 16u < sk[j]) dst[(tk[j] >> 4) + lane] = w[j];  // (a clamped duplicate row writes the same bytes again)
+            }
+        } else {
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             if ((uint32_t)k < nrow) {  // scalar branch; lanes past the span store zeros inside the tile
@@ -436,7 +526,8 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
                 F::classify_store(q, bm16, idx, bm_stride, idx < nchunk ? term4 : wv::kPastSpan);
             }
         }
-        if (nrow > (uint32_t)NB) {  // bytes beyond the register window
+        }
+        if (!HEAD && nrow > (uint32_t)NB) {  // bytes beyond the register window
             const uint4* __restrict__ src = reinterpret_cast<const uint4*>(bytes + a0);
             // Loads and stores are UNCONDITIONAL (lanes past the end move the last chunk once more: same bytes, same
             // address): with `if (idx < nchunk)` the compiler kept w[] in scratch memory and waited for each load
@@ -471,10 +562,16 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
         if (pend_valid && !(ablate & 1u)) store_row(t, pend_li, pend);
         // ---- prefetch: the next group's geometry from its offsets, then its bytes into the register window ----
         uint64_t pa0 = 0;
-        uint32_t pspan = 0, pnl = 0;
+        uint32_t pspan = 0, pnl = 0, pst = 0, ptb = 0, plast2 = 0;
         if (more) {
-            geometry(pn, no0, no1, &pnl, &pa0, &pspan);
-            load_window(pa0, pspan, v);
+            if constexpr (HEAD) {
+                geometry_head(pn, no0, no1, &pnl, &pspan, &pst, &ptb);
+                load_window_head(no0, pst, v);
+                plast2 = load_last2(no0, no1);
+            } else {
+                geometry(pn, no0, no1, &pnl, &pa0, &pspan);
+                load_window(pa0, pspan, v);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         FG_MARK(B);
@@ -486,23 +583,36 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
             const bool valid = lane < nl;
             // terminator stripping (BufRead::lines / split(0) semantics, see fg_frame.hip)
             uint64_t e1 = o1;
+            uint32_t l2 = last2;  // (HEAD) the last two bytes of the line AS DECODED, i.e. behind its terminator
             if (fr.strip != FG_FRAME_NONE && valid && e1 > o0) {
                 auto byte_at = [&](uint64_t q) -> uint32_t {
+                    if constexpr (HEAD) return (uint32_t)bytes[q];
                     return (q - a0) < (uint64_t)span ? (uint32_t)smem[q - a0] : (uint32_t)bytes[q];
                 };
-                const uint32_t b1 = byte_at(e1 - 1);
+                const uint32_t b1 = HEAD ? (last2 & 0xFFu) : byte_at(e1 - 1);
                 if (fr.strip == FG_FRAME_LINE) {
                     if (b1 == '\n') {
                         --e1;
-                        if (e1 > o0 && byte_at(e1 - 1) == '\r') --e1;
+                        if (e1 > o0 && (HEAD ? ((last2 >> 8) & 0xFFu) : byte_at(e1 - 1)) == '\r') --e1;
                     }
                 } else if (b1 == 0u) {
                     --e1;
+                }
+                if (HEAD && e1 != o1) {  // (rare in HEAD mode -- long lines come framed by offsets -- so: two plain loads)
+                    l2 = 0u;
+                    if (e1 - o0 >= 1u) l2 = byte_at(e1 - 1);
+                    if (e1 - o0 >= 2u) l2 |= byte_at(e1 - 2) << 8;
                 }
             }
             // Every line of the group lies inside the tile by construction -- except a single line longer than the whole tile,
             // which is a group of its own and is parsed straight from global memory (the decoders look at o1 - a0 <= span).
             GroupCtx c{bytes, smem, bm16, o0, e1, a0, span, valid, li, (ablate & 8u) ? nullptr : stash, ablate, ent_state, PROF ? prof + 6 : nullptr};
+            if constexpr (HEAD) {
+                const uint32_t al = (uint32_t)(o0 & 15ull), len = (uint32_t)(e1 - o0);
+                c.tbase = tb + al;
+                c.tlen = st == 0u ? 0u : (st - al < len ? st - al : len);
+                c.last2 = l2;
+            }
             pend = fmt.decode(c, t);
             if (fr.line_bad && valid && fr.line_bad[li]) {  // "Invalid UTF-8 input": the frame never reaches decode()
                 pend.meta = FG_ST_BAD_UTF8 | (0xFFu << 8) | (0xFFu << 16);
@@ -537,6 +647,11 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
         o1 = no1;
         a0 = pa0;
         span = pspan;
+        if constexpr (HEAD) {
+            st = pst;
+            tb = ptb;
+            last2 = plast2;
+        }
     }
     if (pend_valid && !(ablate & 1u)) store_row(t, pend_li, pend);
     if (PROF && lane == 0) {

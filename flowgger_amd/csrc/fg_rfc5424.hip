@@ -338,14 +338,17 @@ __device__ __forceinline__ uint32_t take_space(uint64_t& lo, uint64_t& hi, uint3
 // common shape `<PRI>1 TS HOST APP PROC MSGID - MSG` (every independent LDS read issued up front,
 // everything else selects), so that lanes with valid, invalid-but-simple and oddly shaped lines
 // stay converged; what it cannot decide is reported in Fast::route.
-__device__ __forceinline__ Fast parse_line_fast(const Tile& T, uint32_t base, uint32_t len, Row& r) {
+// (last_byte: the line's last byte when the caller has it -- HEAD staging, where the end of a long line is not in the tile --
+//  else kNoLastByte: read from the tile)
+constexpr uint32_t kNoLastByte = 0xFFFFFFFFu;
+__device__ __forceinline__ Fast parse_line_fast(const Tile& T, uint32_t base, uint32_t len, Row& r, uint32_t last_byte = kNoLastByte) {
     Fast f;
     // ---- independent LDS reads: the line's first 132 bytes (line-aligned dwords) and its last byte.
     //      The space mask of the header is derived HERE, per line, from those registers: classifying
     //      only the ~128 header bytes of each line costs fewer wave-instructions than classifying
     //      every byte of the tile in stage A (most bytes of a log line are message text).
-    uint32_t l0, l1;
-    load8(T, base + (len ? len - 1u : 0u), &l0, &l1);
+    uint32_t l0 = last_byte, l1;
+    if (last_byte == kNoLastByte) load8(T, base + (len ? len - 1u : 0u), &l0, &l1);
     uint32_t hdr[33];
     {
         const uint32_t d = base >> 2, sft = base & 3u;
@@ -652,18 +655,45 @@ __device__ __forceinline__ uint32_t sd_walk_tile(const Tile& T, uint32_t base, u
 }
 // parse_tail for a line in the tile whose part 7 starts with '[' and whose group has the
 // quote bitmap built.
-__device__ __forceinline__ void parse_tail_sd_tile(const Tile& T, uint32_t base, uint32_t q, uint32_t len, Row& r,
-                                                   const DevTables& t, uint64_t* stash) {
+// walk_len < len (HEAD staging): only the line's first walk_len bytes are in the tile.  The walk runs over them as if the line
+// ended there; when it closes the structured data inside them, and the trims are the everyday ones (one ASCII non-blank byte at
+// each end: the line's last byte comes in last2), the result does not depend on the bytes that are not there.  Anything else
+// returns false: the caller parses the line from global memory.
+__device__ __forceinline__ bool parse_tail_sd_tile(const Tile& T, uint32_t base, uint32_t q, uint32_t len, uint32_t walk_len, uint32_t last2, Row& r,
+                                                   const DevTables& t, uint64_t* stash, const uint8_t* gbytes, uint64_t o0) {
     r.data0 = q;
     uint32_t msg_at = 0;
-    uint32_t st = stash ? sd_walk_tile<SD_STASH>(T, base, q, len, &msg_at, &r.n_ent, t, 0, stash)
-                        : sd_walk_tile<SD_COUNT>(T, base, q, len, &msg_at, &r.n_ent, t, 0);
+    uint32_t st = stash ? sd_walk_tile<SD_STASH>(T, base, q, walk_len, &msg_at, &r.n_ent, t, 0, stash)
+                        : sd_walk_tile<SD_COUNT>(T, base, q, walk_len, &msg_at, &r.n_ent, t, 0);
     if (st != E_OK) {
-        r.status = st;
         r.n_ent = 0;
-        return;
+        if (walk_len < len) return false;
+        r.status = st;
+        return true;
     }
     LdsReader rd(T.w, base);
+    if (walk_len < len) {
+        // the trims: the message starts in the head (a run of whitespace that reaches its end is not decided here); the line's end is
+        // its last byte when that is a plain one, else the few bytes behind it are looked at where they are, in global memory
+        const uint32_t s = trim_start(rd, msg_at, walk_len - 8u);
+        if (s + 8u >= walk_len) {
+            r.n_ent = 0;
+            return false;
+        }
+        const uint32_t last = last2 & 0xFFu;
+        uint32_t e = len;
+        if (!(last > 0x20u && last < 0x80u)) {
+            GlobalReader grd(reinterpret_cast<const uint32_t*>(gbytes), o0);
+            e = trim_end(grd, 0u, len);
+        }
+        r.off[S_FULL] = 0;
+        r.len[S_FULL] = e;
+        if (e > s) {
+            r.off[S_MSG] = s;
+            r.len[S_MSG] = e - s;
+        }
+        return true;
+    }
     uint32_t e = trim_end(rd, 0u, len);
     r.off[S_FULL] = 0;
     r.len[S_FULL] = e;
@@ -672,13 +702,15 @@ __device__ __forceinline__ void parse_tail_sd_tile(const Tile& T, uint32_t base,
         r.off[S_MSG] = s;
         r.len[S_MSG] = e - s;
     }
+    return true;
 }
 
 constexpr uint32_t kShortSdTail = 64;  // bytes after the header up to which a lone SD tail is walked byte-wise
 
 // The format policy of the streaming pipeline (fg_pipeline.hpp): stage A builds the SPACE bitmap;
 // decode() = stage B + SD entries + the table row for ONE line group whose tile is in LDS.
-struct Rfc5424Format {
+template <bool HEAD>
+struct Rfc5424FormatT {
     // no stage-A bitmap: the fast path classifies the header bytes itself, the SD walker's
     // quote bitmap is built on demand (rebuild_bitmap) for groups that hold SD lines
     static constexpr uint32_t kClasses = 0;
@@ -700,16 +732,20 @@ struct Rfc5424Format {
         r.len[k] = FG_NONE;
     }
     const uint32_t len = (uint32_t)(o1 - o0);
-    const bool in_tile = (o1 - a0) <= (uint64_t)span;
-    const uint32_t base = (uint32_t)(o0 - a0);
+    // HEAD staging: the tile holds the line's first c.tlen bytes at c.tbase -- the whole line (in_tile) or its head only
+    const bool in_tile = HEAD ? c.tlen == len : (o1 - a0) <= (uint64_t)span;
+    const bool head_only = HEAD && !in_tile && c.tlen >= 512u;
+    const uint32_t walk_len = HEAD ? c.tlen : len;
+    const uint32_t base = HEAD ? c.tbase : (uint32_t)(o0 - a0);
+    bool from_global = false;  // the line ended up parsed from global memory (its entries are written from there as well)
     Tile T{reinterpret_cast<const uint32_t*>(smem), reinterpret_cast<const uint32_t*>(bm16)};
     // ---- 1. straight-line fast path for every line of the tile --------------------------------
     uint32_t route = 0;
     Fast f{};
     if (valid) {
         route = R_GENERIC;
-        if (in_tile) {
-            f = parse_line_fast(T, base, len, r);
+        if (in_tile || head_only) {
+            f = parse_line_fast(T, base, len, r, HEAD ? (len ? (c.last2 & 0xFFu) : 0u) : kNoLastByte);
             route = f.route;
             if (!(route & R_GENERIC)) {
                 if (route & R_TS_SLOW) {  // rare
@@ -736,11 +772,14 @@ struct Rfc5424Format {
         __syncthreads();
     }
     // ---- 3. the rare / heavy routes ------------------------------------------------------------
+    bool redo = false;  // (HEAD) the head of the line was not enough: the whole line again, from global memory
     if (valid) {
         if (!(route & R_GENERIC)) {
             if (r.status == E_OK) {
                 if (sd_lane) {
-                    parse_tail_sd_tile(T, base, f.d0, len, r, t, stash);
+                    redo = !parse_tail_sd_tile(T, base, f.d0, len, walk_len, c.last2, r, t, stash, bytes, o0);
+                } else if (head_only && (route & R_TAIL)) {
+                    redo = true;  // (a short bracketed tail or garbage in a long line)
                 } else if (route & R_TAIL) {  // garbage instead of '-' / '['
                     LdsReader rd(T.w, base);
                     parse_tail(rd, f.d0, 0u, len, r, t);
@@ -748,8 +787,15 @@ struct Rfc5424Format {
                     uint32_t e = f.e, s0 = f.s;
                     if (route & R_TRIM) {  // rare
                         LdsReader rd(T.w, base);
-                        e = trim_end(rd, 0u, len);
-                        s0 = trim_start(rd, f.d0 + 1u, len);
+                        if (head_only) {  // the message starts in the head; its end is looked at in global memory
+                            s0 = trim_start(rd, f.d0 + 1u, walk_len - 8u);
+                            GlobalReader grd(reinterpret_cast<const uint32_t*>(bytes), o0);
+                            e = trim_end(grd, 0u, len);
+                            redo = s0 + 8u >= walk_len;
+                        } else {
+                            e = trim_end(rd, 0u, len);
+                            s0 = trim_start(rd, f.d0 + 1u, len);
+                        }
                     }
                     r.data0 = f.d0;
                     r.off[S_FULL] = 0;
@@ -759,19 +805,28 @@ struct Rfc5424Format {
                 }
             }
         } else {  // rare: anything the fast path does not recognise, or a line outside the tile
+            redo = !in_tile;
+            if (in_tile) {
+                r = Row();
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    r.off[k] = 0;
+                    r.len[k] = FG_NONE;
+                }
+                LdsReader rd(T.w, base);
+                parse_line_generic(rd, len, r, t);
+            }
+        }
+        if (redo) {
+            from_global = true;
             r = Row();
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
                 r.off[k] = 0;
                 r.len[k] = FG_NONE;
             }
-            if (in_tile) {
-                LdsReader rd(T.w, base);
-                parse_line_generic(rd, len, r, t);
-            } else {
-                GlobalReader rd(reinterpret_cast<const uint32_t*>(bytes), o0);
-                parse_line_generic(rd, len, r, t);
-            }
+            GlobalReader rd(reinterpret_cast<const uint32_t*>(bytes), o0);
+            parse_line_generic(rd, len, r, t);
         }
     }
 
@@ -785,7 +840,7 @@ struct Rfc5424Format {
             r.n_ent = 0;
         }
         // parked records leave through the (now dead) tile, one entry per lane and store (fg_pipeline.hpp stash_to_table)
-        const bool parked = sd_lane && stash && r.n_ent <= kStashEntries;
+        const bool parked = sd_lane && !from_global && stash && r.n_ent <= kStashEntries;
         const bool coop = !(ablate & 4u) && stash_to_table<1>(c, t, ea, r.n_ent, parked, [](uint64_t rec, uint64_t, uint64_t* name, uint64_t* v, uint32_t* tf) {
             const uint32_t name_s = (uint32_t)rec & 0xFFFFu, name_len = (uint32_t)(rec >> 16) & 0xFFFFu;
             const uint32_t val_len = (uint32_t)(rec >> 32) & 0xFFFFu;
@@ -799,6 +854,9 @@ struct Rfc5424Format {
             {
                 uint32_t msg_at, cnt;
                 if (ablate & 4u) {
+                } else if (from_global) {
+                    GlobalReader rd(reinterpret_cast<const uint32_t*>(bytes), o0);
+                    sd_walk<true>(rd, r.data0, len, &msg_at, &cnt, t, first);
                 } else if (sd_lane && stash && r.n_ent <= kStashEntries) {
                     // copy the parked records out (k-major in the stash: coalesced reads)
                     for (uint32_t k = 0; k < r.n_ent; ++k) {
@@ -812,7 +870,7 @@ struct Rfc5424Format {
                         t.ent_flags[first + k] = ((rec >> 48) & 1u) ? FG_EF_VAL_ESC : 0;
                     }
                 } else if (sd_lane) {
-                    sd_walk_tile<SD_EMIT>(T, base, r.data0, len, &msg_at, &cnt, t, first);
+                    sd_walk_tile<SD_EMIT>(T, base, r.data0, walk_len, &msg_at, &cnt, t, first);
                 } else if (in_tile) {
                     LdsReader rd(T.w, base);
                     sd_walk<true>(rd, r.data0, len, &msg_at, &cnt, t, first);
@@ -839,13 +897,16 @@ struct Rfc5424Format {
 
 // PROF = true is a measurement build of the same kernel (s_memtime stamps at the phase boundaries,
 // FG_PROF=1 / FG_ABLATE, see fg_pipeline.hpp); never the product path.
-template <int NB, bool PROF>
+using Rfc5424Format = Rfc5424FormatT<false>;
+
+// HEAD = true: the instantiation for LONG lines (only the head of every line is staged, fg_pipeline.hpp)
+template <int NB, bool PROF, bool HEAD = false>
 __global__ __launch_bounds__(kWave, 2) void k_rfc5424(const uint8_t* __restrict__ bytes,
                                                      const uint64_t* __restrict__ offsets, uint64_t n, DevTables t,
                                                      uint32_t tile_cap, uint32_t L, uint64_t groups,
                                                      unsigned long long* prof, uint64_t* stash_base, FrameArgs fr) {
-    Rfc5424Format fmt;
-    persistent_loop<NB, PROF>(bytes, offsets, n, t, tile_cap, L, groups, prof, stash_base, fmt, fr);
+    Rfc5424FormatT<HEAD> fmt;
+    persistent_loop<NB, PROF, Rfc5424FormatT<HEAD>, HEAD>(bytes, offsets, n, t, tile_cap, L, groups, prof, stash_base, fmt, fr);
 }
 
 }  // namespace fg
@@ -861,21 +922,33 @@ extern "C" int fg_launch_rfc5424(const uint8_t* d_bytes, const uint64_t* d_offse
                                  const uint8_t* line_bad, const fg_launch_opts* lo) {
     if (n == 0) return 0;
     fg::LaunchPlan p;
-    if (fg::plan_launch(fg::k_rfc5424<fg::kWindowKiB, false>, n, avg_len, 0u, 57344u, stash ? stash_blocks : 0u, &p, *lo)) return -1;
+    // long lines: only the head of every line is staged (persistent_loop<..., HEAD>): the message is never looked into
+    const bool head = (lo->flags & FG_LO_FORCE_HEAD) || (avg_len >= 768u && !(lo->flags & FG_LO_NO_HEAD));
+    if (head ? fg::plan_launch(fg::k_rfc5424<fg::kWindowKiB, false, true>, n, avg_len < fg::kHeadCap ? avg_len : fg::kHeadCap, 0u, 57344u,
+                               stash ? stash_blocks : 0u, &p, *lo)
+             : fg::plan_launch(fg::k_rfc5424<fg::kWindowKiB, false>, n, avg_len, 0u, 57344u, stash ? stash_blocks : 0u, &p, *lo))
+        return -1;
     if (stash_blocks == 0) stash = nullptr;
     dim3 grid(p.blocks), block(fg::kWave);
 #if defined(FG_PROF_BUILD)
     if (fg::prof_requested()) {
         fg::ProfRun pr;
         if (!pr.begin(stream)) return -1;
-        hipLaunchKernelGGL((fg::k_rfc5424<fg::kWindowKiB, true>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile,
-                           p.L, p.chunk, pr.d, stash, fg::FrameArgs{strip, line_bad});
-        pr.end(stream, "rfc5424", p);
+        if (head)
+            hipLaunchKernelGGL((fg::k_rfc5424<fg::kWindowKiB, true, true>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile,
+                               p.L, p.chunk, pr.d, stash, fg::FrameArgs{strip, line_bad});
+        else
+            hipLaunchKernelGGL((fg::k_rfc5424<fg::kWindowKiB, true>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile,
+                               p.L, p.chunk, pr.d, stash, fg::FrameArgs{strip, line_bad});
+        pr.end(stream, head ? "rfc5424 (head)" : "rfc5424", p);
         return (int)hipGetLastError();
     }
 #endif
-    hipLaunchKernelGGL((fg::k_rfc5424<fg::kWindowKiB, false>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L,
-                       p.chunk, (unsigned long long*)nullptr, stash, fg::FrameArgs{strip, line_bad});
+    if (head)
+        hipLaunchKernelGGL((fg::k_rfc5424<fg::kWindowKiB, false, true>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L,
+                           p.chunk, (unsigned long long*)nullptr, stash, fg::FrameArgs{strip, line_bad});
+    else
+        hipLaunchKernelGGL((fg::k_rfc5424<fg::kWindowKiB, false>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L,
+                           p.chunk, (unsigned long long*)nullptr, stash, fg::FrameArgs{strip, line_bad});
     return (int)hipGetLastError();
 }
-

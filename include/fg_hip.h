@@ -195,7 +195,9 @@ typedef struct fg_launch_opts {
 } fg_launch_opts;
 enum {
     FG_LO_GELF_GENERIC = 1,        /* GELF: the run-time-geometry kernel even where the constant-geometry instantiation applies */
-    FG_LO_TRANSCODE_ONE_PIECE = 2  /* fg_transcode_batch: never slice a large batch over two streams */
+    FG_LO_TRANSCODE_ONE_PIECE = 2, /* fg_transcode_batch / fg_frame_decode_batch: never slice a large batch over the streams */
+    FG_LO_NO_HEAD = 4,             /* RFC5424: stage whole lines even when they are long (the head-only kernel is the default from 768 B) */
+    FG_LO_FORCE_HEAD = 8           /* RFC5424: the head-only kernel for lines of any length (parity sweeps) */
 };
 
 /* Create a decoder context on HIP device `device` (replaces XDecoder::new(&Config),

@@ -140,6 +140,7 @@ def test_long_tail_lengths_match_oracle(rfc, oracle):
     {"lines_per_group": 64}, {"lines_per_group": 32}, {"lines_per_group": 8},
     {"lines_per_group": 1}, {"lines_per_group": 48}, {"waves_per_cu": 1}, {"tile_cap": 4096},
     {"tile_cap": 40960, "lines_per_group": 64}, {"chunk_lines": 64}, {"chunk_lines": 5000, "tile_cap": 8192},
+    {"force_head": 1}, {"force_head": 1, "tile_cap": 4096}, {"force_head": 1, "tile_cap": 40960, "lines_per_group": 7}, {"no_head": 1},
 ], ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
 def test_kernel_variants_are_bit_identical(oracle, knobs):
     """Every launch shape of the RFC5424 kernel (64..1 lines
