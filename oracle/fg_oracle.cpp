@@ -1939,6 +1939,65 @@ int64_t fgo_decode(int fmt, const fgo_ltsv_cfg* cfg, const uint8_t* line, uint64
     return (int64_t)k.n;
 }
 
+// ---------------------------------------------------------------------------------------
+// The splitters' framing + UTF-8 check, restated: what `for line in buf_reader.lines()` (line_splitter.rs:17-25) and
+// `for line in buf_reader.split(0)` + `str::from_utf8(&line)` (nul_splitter.rs:18-40) hand to decode().
+//   BufRead::lines(): read_line() reads up to and including '\n'; the item is the text without the '\n' and without ONE '\r' before
+//   it; at EOF a last piece without terminator is an item when it is not empty; bytes that are not valid UTF-8 make the item an
+//   Err(InvalidData) -- the splitter prints "Invalid UTF-8 input" and goes on with the next line.
+//   BufRead::split(0): the same with '\0' and nothing else stripped; validity is checked by from_utf8 in the splitter.
+//   str::from_utf8: well-formed UTF-8 per the Unicode standard (table 3-7): no overlongs (C0, C1, E0 80..9F, F0 80..8F), no
+//   surrogates (ED A0..BF), nothing above U+10FFFF (F4 90.., F5..FF), no stray or missing continuation bytes.
+// ---------------------------------------------------------------------------------------
+static bool rust_str_from_utf8(const uint8_t* s, size_t n) {
+    size_t i = 0;
+    while (i < n) {
+        const uint8_t c = s[i];
+        if (c < 0x80) { ++i; continue; }
+        size_t need;
+        uint8_t lo = 0x80, hi = 0xBF;  // allowed range of the SECOND byte
+        if (c >= 0xC2 && c <= 0xDF) need = 1;
+        else if (c == 0xE0) { need = 2; lo = 0xA0; }
+        else if (c >= 0xE1 && c <= 0xEC) need = 2;
+        else if (c == 0xED) { need = 2; hi = 0x9F; }
+        else if (c >= 0xEE && c <= 0xEF) need = 2;
+        else if (c == 0xF0) { need = 3; lo = 0x90; }
+        else if (c >= 0xF1 && c <= 0xF3) need = 3;
+        else if (c == 0xF4) { need = 3; hi = 0x8F; }
+        else return false;  // 80..BF (stray continuation), C0, C1, F5..FF
+        if (i + need >= n) return false;  // the sequence is cut off by the end of the item
+        if (s[i + 1] < lo || s[i + 1] > hi) return false;
+        for (size_t k = 2; k <= need; ++k)
+            if (s[i + k] < 0x80 || s[i + k] > 0xBF) return false;
+        i += need + 1;
+    }
+    return true;
+}
+// frames of `bytes` as the splitter iterates them: starts[i] .. ends[i] = the frame INCLUDING its terminator, body = what decode()
+// would see is [starts[i], body_end[i]); valid[i] = 0 when the item is not valid UTF-8.  Returns the number of frames (even when
+// > cap; nothing beyond cap is written).  framing: 1 = lines(), 2 = split(0).
+int64_t fgo_frame(int framing, const uint8_t* bytes, uint64_t n, uint64_t* starts, uint64_t* ends, uint64_t* body_end, uint8_t* valid,
+                  uint64_t cap) {
+    if (framing != 1 && framing != 2) return -1;
+    const uint8_t delim = framing == 1 ? '\n' : 0;
+    uint64_t pos = 0, k = 0;
+    while (pos < n) {
+        const uint8_t* hit = (const uint8_t*)memchr(bytes + pos, delim, n - pos);
+        const uint64_t end = hit ? (uint64_t)(hit - bytes) + 1 : n;
+        uint64_t be = hit ? end - 1 : end;
+        if (framing == 1 && hit && be > pos && bytes[be - 1] == '\r') --be;
+        if (k < cap) {
+            starts[k] = pos;
+            ends[k] = end;
+            body_end[k] = be;
+            valid[k] = rust_str_from_utf8(bytes + pos, be - pos) ? 1 : 0;
+        }
+        ++k;
+        pos = end;
+    }
+    return (int64_t)k;
+}
+
 // The bytes Decoder::decode(line) writes to the process's stdout (SURVEY 8b "Side effects": LTSV's println!, ltsv_decoder.rs:99).
 // Returns the length (even when > cap).
 int64_t fgo_decode_stdout(int fmt, const fgo_ltsv_cfg* cfg, const uint8_t* line, uint64_t len, uint8_t* out, uint64_t cap) {

@@ -62,6 +62,12 @@ int64_t fgo_decode_batch(int fmt, const fgo_ltsv_cfg* cfg, const uint8_t* bytes,
                          const uint64_t* offsets, uint64_t n, uint8_t* out, uint64_t cap,
                          uint64_t* out_offsets, int threads);
 
+/* The splitters' framing + UTF-8 check, restated (BufRead::lines() / split(0) + str::from_utf8: splitter/line_splitter.rs:17-25,
+ * nul_splitter.rs:18-40): frame i = bytes[starts[i] .. ends[i]) including its terminator, decode() sees [starts[i], body_end[i]);
+ * valid[i] = 0: "Invalid UTF-8 input".  framing 1 = lines(), 2 = split(0).  Returns the number of frames (even when > cap). */
+int64_t fgo_frame(int framing, const uint8_t* bytes, uint64_t n, uint64_t* starts, uint64_t* ends, uint64_t* body_end,
+                  uint8_t* valid, uint64_t cap);
+
 /* The bytes Decoder::decode(line) writes to the process's stdout (LTSV: println!("Missing value for name '{}'"), ltsv_decoder.rs:99);
  * returns the length (even when > cap). */
 int64_t fgo_decode_stdout(int fmt, const fgo_ltsv_cfg* cfg, const uint8_t* line, uint64_t len, uint8_t* out, uint64_t cap);

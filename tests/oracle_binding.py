@@ -201,6 +201,19 @@ class Oracle:
         n = self.lib.fgo_dtoa(v, buf, 64)
         return buf.raw[:n].decode()
 
+    def frame(self, raw: bytes, framing: str):
+        """fgo_frame: the splitters' framing + UTF-8 check -> list of (start, end_with_terminator, body bytes, is_valid_utf8)"""
+        data = np.frombuffer(raw, np.uint8) if raw else np.zeros(1, np.uint8)
+        self.lib.fgo_frame.restype = C.c_int64
+        fr = 1 if framing == "line" else 2
+        vp = C.c_void_p
+        n = self.lib.fgo_frame(C.c_int(fr), vp(data.ctypes.data), C.c_uint64(len(raw)), None, None, None, None, C.c_uint64(0))
+        starts, ends, be = (np.zeros(max(int(n), 1), np.uint64) for _ in range(3))
+        valid = np.zeros(max(int(n), 1), np.uint8)
+        self.lib.fgo_frame(C.c_int(fr), vp(data.ctypes.data), C.c_uint64(len(raw)), vp(starts.ctypes.data), vp(ends.ctypes.data),
+                           vp(be.ctypes.data), vp(valid.ctypes.data), C.c_uint64(int(n)))
+        return [(int(starts[i]), int(ends[i]), raw[int(starts[i]):int(be[i])], bool(valid[i])) for i in range(int(n))]
+
     def decode_stdout(self, fmt: int, line: bytes, config=None) -> bytes:
         """what Decoder::decode(line) prints to stdout (ltsv_decoder.rs:99)"""
         cfg, keep = self.make_cfg(config)

@@ -646,7 +646,8 @@ def test_gpu_framing_and_utf8_match_the_splitters(rfc, oracle, framing):
         pieces.append(ln + delim)
     for tail in (b"", b"unterminated tail \xe2\x82", b"plain tail", b"\r"):
         raw = b"".join(pieces) + tail
-        ref = _frames_reference(raw, framing)
+        ref = oracle.frame(raw, framing)
+        assert ref == _frames_reference(raw, framing)  # (the oracle's restatement and the standard library's verdicts agree)
         dev = torch.device("cuda", rfc.device)
         d_bytes = torch.cat([torch.frombuffer(bytearray(raw), dtype=torch.uint8), torch.zeros(32, dtype=torch.uint8)]).to(dev)[:len(raw) + 32]
         d_raw = d_bytes[:len(raw)]

@@ -172,3 +172,47 @@ def test_ltsv_semantics(oracle):
     assert str(d("level:9\ttime:x")) == "Severity level should be <= 7"  # first failing part wins
     assert d("time:[1]\thost:h").ts == 1.0 and math.isnan(d("time:nan\thost:h").ts)
     assert d("time:1\ttime:2\thost:a\thost:b").hostname == "b"
+
+
+def test_framing_restatement_known_answers(oracle):
+    """oracle fgo_frame = BufRead::lines() / split(0) + str::from_utf8 (line_splitter.rs:17-25, nul_splitter.rs:18-40): the documented
+    behaviours of the std items it restates (std::io::BufRead::lines: "each string returned will not have a newline byte (the 0xA
+    byte) or CRLF (0xD, 0xA bytes) at the end"; a final piece without terminator is an item; `"a\\r\\r\\n"` keeps one '\\r'), the
+    well-formedness table of str::from_utf8 -- and agreement with Python's own UTF-8 decoder on random byte soup."""
+    import numpy as np
+
+    f = lambda raw, fr="line": [(b, ok) for _, _, b, ok in oracle.frame(raw, fr)]
+    assert f(b"") == []
+    assert f(b"\n") == [(b"", True)]
+    assert f(b"a\nb\r\nc") == [(b"a", True), (b"b", True), (b"c", True)]
+    assert f(b"a\r\r\n\r\n\r") == [(b"a\r", True), (b"", True), (b"\r", True)]  # an unterminated "\r" stays
+    assert f(b"x\0y\0\0z", "nul") == [(b"x", True), (b"y", True), (b"", True), (b"z", True)]
+    assert f(b"x\r\0", "nul") == [(b"x\r", True)]                                 # split(0) strips nothing else
+    good = ["café", "€", "\U0001F600", "߿ࠀ￿\U00010000\U0010ffff"]
+    for g in good:
+        assert f(g.encode() + b"\n") == [(g.encode(), True)]
+    bad = [b"\xff", b"\xc0\xaf", b"\xc1\xbf", b"\xe0\x80\x80", b"\xe0\x9f\xbf", b"\xed\xa0\x80", b"\xed\xbf\xbf", b"\xf0\x80\x80\x80",
+           b"\xf0\x8f\xbf\xbf", b"\xf4\x90\x80\x80", b"\xf5\x80\x80\x80", b"\x80", b"a\x80b", b"\xc2", b"\xe2\x82", b"\xf0\x9f\x98",
+           b"\xc2\x41", b"\xe2\x28\xa1", b"\xf8\x88\x80\x80\x80"]
+    for b in bad:
+        assert f(b + b"\n" + b"ok\n") == [(b, False), (b"ok", True)], b
+    rng = np.random.default_rng(17)
+    alphabet = np.frombuffer(b"\n\r\0a\xc2\xa9\xe2\x82\xac\xf0\x9f\x98\x80\xed\xa0\x80\xff\xc0 ", np.uint8)
+    for _ in range(300):
+        raw = rng.choice(alphabet, int(rng.integers(0, 200))).tobytes()
+        for fr, delim in (("line", b"\n"), ("nul", b"\0")):
+            want = []
+            pieces = raw.split(delim)
+            for i, piece in enumerate(pieces):
+                if i == len(pieces) - 1:
+                    if piece == b"":
+                        break
+                elif fr == "line" and piece.endswith(b"\r"):
+                    piece = piece[:-1]
+                try:
+                    piece.decode("utf-8")
+                    ok = True
+                except UnicodeDecodeError:
+                    ok = False
+                want.append((piece, ok))
+            assert f(raw, fr) == want, (raw, fr)
