@@ -512,12 +512,31 @@ enum { SD_COUNT = 0, SD_EMIT = 1, SD_STASH = 2 };
 __device__ __forceinline__ uint64_t stash_pack(uint32_t name_s, uint32_t name_len, uint32_t val_len, uint32_t esc, uint32_t sdid) {
     return (uint64_t)name_s | ((uint64_t)name_len << 16) | ((uint64_t)val_len << 32) | ((uint64_t)esc << 48) | ((uint64_t)sdid << 49);
 }
+// SD_STASH: the records go INTO THE LINE ITSELF -- the tile bytes the walk has already consumed (header, earlier pairs) are dead, names
+// and values are recorded as offsets -- as 8-byte records from the line's first 4-byte boundary on (round 2 parked them in a stash
+// in global memory: 224 B per line of HBM traffic on the 13-pair corpus).  A record that would reach into bytes still to be read
+// (many tiny pairs: `a="" b="" ...`) clears *rec_ok: the caller then writes the line's entries by a second walk over the line in
+// GLOBAL memory (its copy in the tile is no longer intact).
 template <int MODE>
 __device__ __forceinline__ uint32_t sd_walk_tile(const Tile& T, uint32_t base, uint32_t pos, uint32_t len, uint32_t* msg_at,
-                                                 uint32_t* n_ent, const DevTables& t, uint32_t slot, uint64_t* stash = nullptr) {
+                                                 uint32_t* n_ent, const DevTables& t, uint32_t slot, uint32_t* tile_w = nullptr,
+                                                 bool* rec_ok_out = nullptr) {
     constexpr bool EMIT = MODE == SD_EMIT;
     LdsReader rd(T.w, base);
     uint32_t cnt = 0;
+    uint32_t wpos = (base + 3u) & ~3u;  // tile byte of the next record
+    bool rec_ok = true;
+    auto record = [&](uint64_t rec, uint32_t consumed) {  // consumed: line index up to which the walk is done with the bytes
+        if (rec_ok) {
+            if (wpos + 8u <= base + consumed) {
+                tile_w[wpos >> 2] = (uint32_t)rec;
+                tile_w[(wpos >> 2) + 1u] = (uint32_t)(rec >> 32);
+                wpos += 8u;
+            } else {
+                rec_ok = false;
+            }
+        }
+    };
     for (;;) {
         // sd_id = bytes after '[' up to the first ' ' (anything allowed)            :175-177
         const uint32_t s = pos + 1;
@@ -541,7 +560,7 @@ __device__ __forceinline__ uint32_t sd_walk_tile(const Tile& T, uint32_t base, u
             t.ent_type[slot + cnt] = FG_T_SDID;
             t.ent_flags[slot + cnt] = 0;
         }
-        if (MODE == SD_STASH && cnt < kStashEntries) stash[cnt * kWave + threadIdx.x] = stash_pack(s, sp - s, 0, 0, 1);
+        if (MODE == SD_STASH) record(stash_pack(s, sp - s, 0, 0, 1), sp + 1u);
         ++cnt;
         uint32_t status = E_OK;
         uint32_t i = sp + 1;       // OUT state: next unread byte
@@ -577,8 +596,7 @@ __device__ __forceinline__ uint32_t sd_walk_tile(const Tile& T, uint32_t base, u
                     t.ent_type[slot + cnt] = FG_T_STRING;
                     t.ent_flags[slot + cnt] = esc_seen ? FG_EF_VAL_ESC : 0;
                 }
-                if (MODE == SD_STASH && cnt < kStashEntries)
-                    stash[cnt * kWave + threadIdx.x] = stash_pack(name_s, name_e - name_s, w0 - val_s, esc_seen, 0);
+                if (MODE == SD_STASH) record(stash_pack(name_s, name_e - name_s, w0 - val_s, esc_seen, 0), w0 + 1u);
                 ++cnt;
                 in_value = false;
             }
@@ -650,6 +668,7 @@ __device__ __forceinline__ uint32_t sd_walk_tile(const Tile& T, uint32_t base, u
         if (c != ' ') return E_MALFORMED;  // :154
         *msg_at = after;
         *n_ent = cnt;
+        if (rec_ok_out) *rec_ok_out = rec_ok;
         return E_OK;
     }
 }
@@ -660,11 +679,11 @@ __device__ __forceinline__ uint32_t sd_walk_tile(const Tile& T, uint32_t base, u
 // each end: the line's last byte comes in last2), the result does not depend on the bytes that are not there.  Anything else
 // returns false: the caller parses the line from global memory.
 __device__ __forceinline__ bool parse_tail_sd_tile(const Tile& T, uint32_t base, uint32_t q, uint32_t len, uint32_t walk_len, uint32_t last2, Row& r,
-                                                   const DevTables& t, uint64_t* stash, const uint8_t* gbytes, uint64_t o0) {
+                                                   const DevTables& t, uint32_t* tile_w, bool* rec_ok, const uint8_t* gbytes, uint64_t o0) {
     r.data0 = q;
     uint32_t msg_at = 0;
-    uint32_t st = stash ? sd_walk_tile<SD_STASH>(T, base, q, walk_len, &msg_at, &r.n_ent, t, 0, stash)
-                        : sd_walk_tile<SD_COUNT>(T, base, q, walk_len, &msg_at, &r.n_ent, t, 0);
+    uint32_t st = tile_w ? sd_walk_tile<SD_STASH>(T, base, q, walk_len, &msg_at, &r.n_ent, t, 0, tile_w, rec_ok)
+                         : sd_walk_tile<SD_COUNT>(T, base, q, walk_len, &msg_at, &r.n_ent, t, 0);
     if (st != E_OK) {
         r.n_ent = 0;
         if (walk_len < len) return false;
@@ -738,6 +757,8 @@ struct Rfc5424FormatT {
     const uint32_t walk_len = HEAD ? c.tlen : len;
     const uint32_t base = HEAD ? c.tbase : (uint32_t)(o0 - a0);
     bool from_global = false;  // the line ended up parsed from global memory (its entries are written from there as well)
+    uint32_t* tile_w = reinterpret_cast<uint32_t*>(const_cast<uint8_t*>(smem));
+    bool rec_ok = false;       // the structured-data walk left the line's entries as records in the line's own tile bytes
     Tile T{reinterpret_cast<const uint32_t*>(smem), reinterpret_cast<const uint32_t*>(bm16)};
     // ---- 1. straight-line fast path for every line of the tile --------------------------------
     uint32_t route = 0;
@@ -777,7 +798,7 @@ struct Rfc5424FormatT {
         if (!(route & R_GENERIC)) {
             if (r.status == E_OK) {
                 if (sd_lane) {
-                    redo = !parse_tail_sd_tile(T, base, f.d0, len, walk_len, c.last2, r, t, stash, bytes, o0);
+                    redo = !parse_tail_sd_tile(T, base, f.d0, len, walk_len, c.last2, r, t, stash ? tile_w : nullptr, &rec_ok, bytes, o0);
                 } else if (head_only && (route & R_TAIL)) {
                     redo = true;  // (a short bracketed tail or garbage in a long line)
                 } else if (route & R_TAIL) {  // garbage instead of '-' / '['
@@ -839,45 +860,46 @@ struct Rfc5424FormatT {
             r.status = FG_ST_OVERFLOW;
             r.n_ent = 0;
         }
-        // parked records leave through the (now dead) tile, one entry per lane and store (fg_pipeline.hpp stash_to_table)
-        const bool parked = sd_lane && !from_global && stash && r.n_ent <= kStashEntries;
-        const bool coop = !(ablate & 4u) && stash_to_table<1>(c, t, ea, r.n_ent, parked, [](uint64_t rec, uint64_t, uint64_t* name, uint64_t* v, uint32_t* tf) {
-            const uint32_t name_s = (uint32_t)rec & 0xFFFFu, name_len = (uint32_t)(rec >> 16) & 0xFFFFu;
-            const uint32_t val_len = (uint32_t)(rec >> 32) & 0xFFFFu;
-            const bool sdid = (rec >> 49) & 1u;
-            *name = (uint64_t)name_s | ((uint64_t)name_len << 32);
-            *v = sdid ? 0ull : ((uint64_t)(name_s + name_len + 2u) | ((uint64_t)val_len << 32));
-            *tf = (sdid ? (uint32_t)FG_T_SDID : (uint32_t)FG_T_STRING) | ((((rec >> 48) & 1u) ? (uint32_t)FG_EF_VAL_ESC : 0u) << 8);
-        });
         first = r.n_ent != 0 ? mine : 0u;
-        if (r.n_ent != 0 && !coop) {
-            {
-                uint32_t msg_at, cnt;
-                if (ablate & 4u) {
-                } else if (from_global) {
-                    GlobalReader rd(reinterpret_cast<const uint32_t*>(bytes), o0);
-                    sd_walk<true>(rd, r.data0, len, &msg_at, &cnt, t, first);
-                } else if (sd_lane && stash && r.n_ent <= kStashEntries) {
-                    // copy the parked records out (k-major in the stash: coalesced reads)
-                    for (uint32_t k = 0; k < r.n_ent; ++k) {
-                        const uint64_t rec = stash[k * kWave + lane];
-                        const uint32_t name_s = (uint32_t)rec & 0xFFFFu, name_len = (uint32_t)(rec >> 16) & 0xFFFFu;
-                        const uint32_t val_len = (uint32_t)(rec >> 32) & 0xFFFFu;
-                        const bool sdid = (rec >> 49) & 1u;
-                        t.ent_name[first + k] = fg_span{name_s, name_len};
-                        t.ent_val[first + k] = sdid ? 0ull : ((uint64_t)(name_s + name_len + 2u) | ((uint64_t)val_len << 32));
-                        t.ent_type[first + k] = sdid ? FG_T_SDID : FG_T_STRING;
-                        t.ent_flags[first + k] = ((rec >> 48) & 1u) ? FG_EF_VAL_ESC : 0;
+        if (r.n_ent != 0 && !(ablate & 4u)) {
+            uint32_t msg_at, cnt;
+            if (sd_lane && !from_global && stash && rec_ok) {
+                // the records sit in the line's own (consumed) bytes: four in flight before the first store
+                const uint32_t* rec32 = tile_w + (((base + 3u) & ~3u) >> 2);
+                for (uint32_t k0 = 0; k0 < r.n_ent; k0 += 4u) {
+                    uint32_t lo[4], hi[4];
+#pragma unroll
+                    for (uint32_t j = 0; j < 4u; ++j) {
+                        const uint32_t k = k0 + j < r.n_ent ? k0 + j : r.n_ent - 1u;
+                        lo[j] = rec32[k * 2u];
+                        hi[j] = rec32[k * 2u + 1u];
                     }
-                } else if (sd_lane) {
-                    sd_walk_tile<SD_EMIT>(T, base, r.data0, walk_len, &msg_at, &cnt, t, first);
-                } else if (in_tile) {
-                    LdsReader rd(T.w, base);
-                    sd_walk<true>(rd, r.data0, len, &msg_at, &cnt, t, first);
-                } else {
-                    GlobalReader rd(reinterpret_cast<const uint32_t*>(bytes), o0);
-                    sd_walk<true>(rd, r.data0, len, &msg_at, &cnt, t, first);
+#pragma unroll
+                    for (uint32_t j = 0; j < 4u; ++j) {
+                        const uint32_t k = k0 + j;
+                        if (k < r.n_ent) {
+                            const uint32_t name_s = lo[j] & 0xFFFFu, name_len = lo[j] >> 16, val_len = hi[j] & 0xFFFFu;
+                            const bool sdid = (hi[j] >> 17) & 1u;
+                            t.ent_name[first + k] = fg_span{name_s, name_len};
+                            t.ent_val[first + k] = sdid ? 0ull : ((uint64_t)(name_s + name_len + 2u) | ((uint64_t)val_len << 32));
+                            t.ent_type[first + k] = sdid ? FG_T_SDID : FG_T_STRING;
+                            t.ent_flags[first + k] = ((hi[j] >> 16) & 1u) ? FG_EF_VAL_ESC : 0;
+                        }
+                    }
                 }
+            } else if (from_global || (sd_lane && stash)) {
+                // parsed from global memory -- or a line whose records did not fit its consumed bytes, whose copy in the tile is
+                // therefore no longer intact
+                GlobalReader rd(reinterpret_cast<const uint32_t*>(bytes), o0);
+                sd_walk<true>(rd, r.data0, len, &msg_at, &cnt, t, first);
+            } else if (sd_lane) {  // (measurement build without records: the tile is intact)
+                sd_walk_tile<SD_EMIT>(T, base, r.data0, walk_len, &msg_at, &cnt, t, first);
+            } else if (in_tile) {
+                LdsReader rd(T.w, base);
+                sd_walk<true>(rd, r.data0, len, &msg_at, &cnt, t, first);
+            } else {
+                GlobalReader rd(reinterpret_cast<const uint32_t*>(bytes), o0);
+                sd_walk<true>(rd, r.data0, len, &msg_at, &cnt, t, first);
             }
         }
     }
