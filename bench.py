@@ -212,13 +212,27 @@ def e2e_legs(D: Dist, dec, fmt, data, offsets, n_tile, tile_bytes, want_transcod
     frees = [hd, ho]
 
     def leg(name, call, in_bytes, what, extra=None):
-        call()  # warm-up: staging buffers at size
+        # (every rank reaches the barrier and the gather of every leg, whatever happens in its own calls: a rank that fails a leg
+        #  reports it -- the other ranks must not be left waiting in a collective)
+        err, dt = None, float("nan")
+        try:
+            call()  # warm-up: staging buffers at size
+        except Exception as e:  # noqa: BLE001
+            err = repr(e)[:200]
         D.barrier()
-        t0 = time.perf_counter()
-        for _ in range(iters):
-            call()
-        dt = time.perf_counter() - t0
-        per_rank = [x[0] for x in D.all([dt])]
+        if err is None:
+            try:
+                t0 = time.perf_counter()
+                for _ in range(iters):
+                    call()
+                dt = time.perf_counter() - t0
+            except Exception as e:  # noqa: BLE001
+                err = repr(e)[:200]
+        per_rank = [x[0] for x in D.all([dt if err is None else -1.0])]
+        good = [t for t in per_rank if t > 0]
+        if err is not None or len(good) != len(per_rank):
+            out[name] = {"error": err or "another rank failed this leg", "what": what}
+            return False
         slowest = max(per_rank)
         ent = {"lines_per_s": n * iters / dt, "GBps_in": in_bytes * iters / dt / 1e9, "ms": dt / iters * 1e3, "what": what,
                "aggregate": {"lines_per_s": n * iters * D.world / slowest, "GBps_in": in_bytes * iters * D.world / slowest / 1e9,
@@ -226,10 +240,12 @@ def e2e_legs(D: Dist, dec, fmt, data, offsets, n_tile, tile_bytes, want_transcod
         if extra:
             ent.update(extra())
         out[name] = ent
+        return True
 
     try:
         gb = (C.c_double * 3)()
-        L.check(lib.fg_measure_link(dec._ctx, 1 << 30, gb), "fg_measure_link")
+        if lib.fg_measure_link(dec._ctx, 1 << 30, gb) != 0:
+            gb[0] = gb[1] = gb[2] = 0.0
         link = [float(gb[0]), float(gb[1]), float(gb[2])]
         allr = D.all(link)
         out["link_peak"] = {"h2d_GBps": link[0], "d2h_GBps": link[1], "bidir_GBps": link[2],
@@ -237,11 +253,11 @@ def e2e_legs(D: Dist, dec, fmt, data, offsets, n_tile, tile_bytes, want_transcod
                                     "enforced: every rank measures at once, as the legs below run)",
                             "per_rank_h2d_GBps": [r[0] for r in allr], "per_rank_d2h_GBps": [r[1] for r in allr]}
         st = L.fg_tables()
-        leg("decode_batch",
-            lambda: L.check(lib.fg_decode_batch(dec._ctx, fmt, pdata.ctypes.data, tile_bytes * reps, poffs.ctypes.data, n, C.byref(st)),
-                            "fg_decode_batch"),
-            tile_bytes * reps + 8 * (n + 1), "fg_decode_batch: H2D of bytes + offsets, kernels, D2H of the tables")
-        out["decode_batch"]["frac_of_link_h2d"] = out["decode_batch"]["GBps_in"] / link[0] if link[0] else None
+        if leg("decode_batch",
+               lambda: L.check(lib.fg_decode_batch(dec._ctx, fmt, pdata.ctypes.data, tile_bytes * reps, poffs.ctypes.data, n, C.byref(st)),
+                               "fg_decode_batch"),
+               tile_bytes * reps + 8 * (n + 1), "fg_decode_batch: H2D of bytes + offsets, kernels, D2H of the tables"):
+            out["decode_batch"]["frac_of_link_h2d"] = out["decode_batch"]["GBps_in"] / link[0] if link[0] else None
         if want_stream and not bool((data[:tile_bytes] == 0x0A).any()):
             # the same lines as ONE raw newline-terminated stream: what LineSplitter reads off the socket
             ln = np.diff(offsets.astype(np.int64))
@@ -263,26 +279,27 @@ def e2e_legs(D: Dist, dec, fmt, data, offsets, n_tile, tile_bytes, want_transcod
                                                   C.byref(po), C.byref(nf), C.byref(cons)), "fg_frame_decode_batch")
                 assert nf.value == n, (nf.value, n)
 
-            leg("frame_decode_batch", call_stream, stream_bytes * reps,
-                "fg_frame_decode_batch: H2D of the raw stream only, framing + UTF-8 + decode on the GPU, D2H of tables + frame offsets")
-            out["frame_decode_batch"]["frac_of_link_h2d"] = out["frame_decode_batch"]["GBps_in"] / link[0] if link[0] else None
+            if leg("frame_decode_batch", call_stream, stream_bytes * reps,
+                   "fg_frame_decode_batch: H2D of the raw stream only, framing + UTF-8 + decode on the GPU, D2H of tables + frame offsets"):
+                out["frame_decode_batch"]["frac_of_link_h2d"] = out["frame_decode_batch"]["GBps_in"] / link[0] if link[0] else None
         if want_transcode:
             enc = GelfEncoder(None, merger="line")
             cfg, _keep = enc._cfg_struct(0.0)
             res = L.fg_transcoded()
-            leg("transcode_batch",
-                lambda: L.check(lib.fg_transcode_batch(dec._ctx, fmt, L.FG_FRAME_NONE, C.byref(cfg), pdata.ctypes.data, tile_bytes * reps,
-                                                       poffs.ctypes.data, n, 1, C.byref(res)), "fg_transcode_batch"),
-                tile_bytes * reps + 8 * (n + 1),
-                "fg_transcode_batch: H2D, decode, GELF encode, line merger, D2H of the stream (D2H-bound: the GELF text is 2.4x the input)",
-                extra=lambda: {"out_bytes": int(res.out_bytes)})
-            t = out["transcode_batch"]
-            t["GBps_out"] = t["out_bytes"] / (t["ms"] * 1e-3) / 1e9
-            t["frac_of_link_d2h"] = t["GBps_out"] / link[1] if link[1] else None
+            if leg("transcode_batch",
+                   lambda: L.check(lib.fg_transcode_batch(dec._ctx, fmt, L.FG_FRAME_NONE, C.byref(cfg), pdata.ctypes.data, tile_bytes * reps,
+                                                          poffs.ctypes.data, n, 1, C.byref(res)), "fg_transcode_batch"),
+                   tile_bytes * reps + 8 * (n + 1),
+                   "fg_transcode_batch: H2D, decode, GELF encode, line merger, D2H of the stream (D2H-bound: the GELF text is 2.4x the input)",
+                   extra=lambda: {"out_bytes": int(res.out_bytes)}):
+                t = out["transcode_batch"]
+                t["GBps_out"] = t["out_bytes"] / (t["ms"] * 1e-3) / 1e9
+                t["frac_of_link_d2h"] = t["GBps_out"] / link[1] if link[1] else None
     finally:
         for h in frees:
             lib.fg_free_pinned(h)
-    out["aggregate"] = {k: out[k]["aggregate"]["lines_per_s"] for k in ("decode_batch", "frame_decode_batch", "transcode_batch") if k in out}
+    out["aggregate"] = {k: out[k]["aggregate"]["lines_per_s"] for k in ("decode_batch", "frame_decode_batch", "transcode_batch")
+                        if k in out and "aggregate" in out[k]}
     return out
 
 
