@@ -202,3 +202,33 @@ def test_raw_stream_pipelined_over_three_streams_equals_one_piece_and_oracle(ora
         if pt.status[i] == 0xFD:
             continue
         assert got == oracle.decode(fmt, stripped[i], cfg), i
+
+
+def test_sliced_host_paths_bring_entries_back_per_slice_and_survive_an_entry_table_that_is_too_small(oracle):
+    """fg_decode_batch / fg_frame_decode_batch on batches cut into slices: the entry columns come back per slice (the range between
+    two values of the shared counter).  Lines made of tiny pairs need more than the first capacity (one entry per 16 input bytes):
+    the sliced path must notice in the middle of the batch, take the counter's final value and decode again -- same Records as the
+    oracle either way; the raw-stream path falls back to its one-piece form."""
+    from flowgger_amd import RFC5424Decoder
+    from flowgger_amd import _lib as L
+    from gpu_util import host_path_blob
+
+    rng = np.random.default_rng(11)
+    dense = [b"<13>1 2015-08-05T15:53:45Z h a p m [x@1 " + b" ".join(b'%c="%d"' % (97 + j % 26, (i + j) % 10) for j in range(int(rng.integers(30, 60))))
+             + b"] m%d" % i for i in range(90_000)]
+    sparse = synth.rfc5424_lines(100_000, cfg=2)
+    for lines in (sparse[:50_000] + dense * 2 + sparse[50_000:], dense * 2):
+        data, offsets = synth.pack(lines)
+        assert data.size > (36 << 20)
+        dec = RFC5424Decoder()
+        oblob, ooffs = oracle.decode_batch(RFC5424, data, offsets)
+        (blob, offs), tab = host_path_blob(dec, data, offsets)
+        assert np.array_equal(offs, ooffs) and np.array_equal(blob, oblob)
+        total = int(tab.a["ent_count"].sum())
+        assert total <= tab.ent_used and total > data.size // 16  # (the first capacity was too small)
+        raw = b"\n".join(lines) + b"\n"
+        assert len(raw) > (48 << 20)
+        ft, foff, cons = dec.frame_decode_batch(raw, L.FG_FRAME_LINE, final=True)
+        assert cons == len(raw) and ft.n == len(lines)
+        fb, fo = ft.serialize(RFC5424, np.frombuffer(raw + b"\0" * 16, np.uint8), foff, cfg=dec._cfg)
+        assert np.array_equal(fo, ooffs) and np.array_equal(fb, oblob)
