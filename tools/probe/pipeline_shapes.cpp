@@ -3,6 +3,9 @@
 // ~70 GB/s.)  Copies only, no kernels: 32 slices of 32 MiB up, and per slice `parts` downloads of `down` bytes in total.
 //   shape A  three roles: all uploads on stream U (queued first), downloads on stream D behind an event per slice
 //   shape B  two lanes: slice k on lane k & 1 -- upload, then its downloads, on the same stream
+//   shape K / S  shape A with a kernel per slice on a third stream between upload and downloads (stream index 3): K = a kernel without
+//            private (scratch) memory, S = the same kernel with ~512 B of scratch per lane (k_ltsv and k_gelf_general reserve 508 / 476 B,
+//            k_rfc5424 none -- and only the RFC5424 corpora overlap their two directions through fg_decode_batch)
 // usage: pipeline_shapes <A|B> <U> <D> <prime> <down_MiB_per_slice> <parts>     U, D, prime = stream indices 0..3 (creation order);
 //        prime = the stream that copies a few bytes each way before anything else (-1: none)
 // build: hipcc --offload-arch=gfx950 -O2 tools/probe/pipeline_shapes.cpp -o tools/probe/pipeline_shapes
@@ -13,6 +16,24 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+
+template <bool SCRATCH>
+__global__ void touch(const uint8_t* in, uint8_t* out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    uint32_t acc = 0;
+    if (SCRATCH) {
+        uint32_t a[128];  // indexed by data: lives in private memory
+        for (int j = 0; j < 128; ++j) a[j] = j * 2654435761u;
+        for (size_t p = i * 16; p < n; p += stride * 16) {
+            const uint32_t v = *(const uint32_t*)(in + p);
+            a[v & 127] += v;
+            acc += a[(v >> 8) & 127];
+        }
+    } else {
+        for (size_t p = i * 16; p < n; p += stride * 16) acc += *(const uint32_t*)(in + p) * 2654435761u;
+    }
+    if (acc == 0x12345678u) out[i & 4095] = (uint8_t)acc;
+}
 
 int main(int argc, char** argv) {
     if (argc < 7) return 2;
@@ -31,6 +52,8 @@ int main(int argc, char** argv) {
     for (auto& x : s) hipStreamCreateWithFlags(&x, hipStreamNonBlocking);
     std::vector<hipEvent_t> ev(slices);
     for (auto& e : ev) hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    std::vector<hipEvent_t> ev2(slices);
+    for (auto& e : ev2) hipEventCreateWithFlags(&e, hipEventDisableTiming);
     if (prime >= 0) {
         hipMemcpyAsync(d_in, h_in, 8, hipMemcpyHostToDevice, s[prime]);
         hipMemcpyAsync(h_out, d_out, 8, hipMemcpyDeviceToHost, s[prime]);
@@ -41,7 +64,22 @@ int main(int argc, char** argv) {
         hipDeviceSynchronize();
         auto t0 = std::chrono::steady_clock::now();
         const size_t part = down / parts;
-        if (shape == 'A') {
+        if (shape == 'K' || shape == 'S') {
+            for (int k = 0; k < slices; ++k) {
+                hipMemcpyAsync(d_in + k * up, h_in + k * up, up, hipMemcpyHostToDevice, s[U]);
+                hipEventRecord(ev[k], s[U]);
+            }
+            for (int k = 0; k < slices; ++k) {
+                hipStreamWaitEvent(s[3], ev[k], 0);
+                if (shape == 'S') touch<true><<<2048, 64, 0, s[3]>>>(d_in + k * up, d_out + k * down, up);
+                else touch<false><<<2048, 64, 0, s[3]>>>(d_in + k * up, d_out + k * down, up);
+                hipEventRecord(ev2[k], s[3]);
+                hipStreamWaitEvent(s[D], ev2[k], 0);
+                for (int j = 0; j < parts; ++j)
+                    hipMemcpyAsync(h_out + k * down + j * part, d_out + k * down + j * part, part, hipMemcpyDeviceToHost, s[D]);
+            }
+            hipStreamSynchronize(s[3]);
+        } else if (shape == 'A') {
             for (int k = 0; k < slices; ++k) {
                 hipMemcpyAsync(d_in + k * up, h_in + k * up, up, hipMemcpyHostToDevice, s[U]);
                 hipEventRecord(ev[k], s[U]);
