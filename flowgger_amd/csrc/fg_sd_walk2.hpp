@@ -3,8 +3,9 @@
 //
 // STATUS: staged for round 4.  fg_rfc5424.hip still runs its own sd_walk_tile; this header has the same
 // contract, is validated on the CPU against the oracle (tests/test_sd_walk2_cpu.py runs THIS source, compiled by g++, over the
-// structured-data corpora and adversarial mutations of them) and has been compiled for gfx950 to count its instructions, but it
-// has not run on a GPU yet and nothing in libfg_hip.so includes it.
+// structured-data corpora and adversarial mutations of them -- the per-line walk lane by lane, the group step walk_group /
+// copy_out on the fiber emulation of a wavefront) and has been compiled for gfx950 to count its instructions, but it has not
+// run on a GPU yet and nothing in libfg_hip.so includes it.
 //
 // Why another form.  The measured cost of the corpus with ~13 pairs per line (profiles/r03z_cfg4_rfc5424_sd.json) is 306 VALU
 // wave-instructions per line at 59 % VALU utilisation, and the pair loop is ~45 % of them: one iteration of sd_walk_tile is ~240
@@ -393,6 +394,112 @@ FG_WV uint32_t pick_split(const Tile& T, uint32_t base, uint32_t pos, uint32_t l
         res = wv::find_bit<false>(T.bm, base + res + 1u, base + len) - base;
     }
     return kNoSplit;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The walk of a whole group, wave-cooperative (all 64 lanes call it in wave-uniform control flow): what stage B of the RFC5424
+// kernel does between the header fast path and the entry slots.
+//   two    wave-uniform: the group holds at most 32 lines (lanes 32..63 have none) -- each line with structured data gets lane
+//          l + 32 as its second lane
+//   sd     this lane's line has structured data to walk at line index `pos` (line = tile bytes [base, base + len))
+// ---------------------------------------------------------------------------------------------
+struct PairOut {
+    // the line's lane:
+    uint32_t status;  // E_OK or the walk's error (meaningless when redo)
+    uint32_t n_ent;   // entries of the line (0 unless E_OK)
+    uint32_t msg_at;  // index of the ' ' that starts the message (E_OK)
+    bool rec_ok;      // every entry of the line sits in a record in the tile (else: EMIT walk over a clean copy of the line)
+    bool redo;        // the second lane's guess did not hold: parse the line again from a clean copy (its tile bytes are not intact)
+    // both lanes -- the copy-out: this lane holds n_own records from tile byte rec_at on; they are entries [skip, skip + n_own) of
+    // the line of lane l & 31 (n_own = 0 whenever the line is not E_OK / rec_ok / redo)
+    uint32_t n_own, rec_at, skip;
+};
+template <int MODE>
+FG_WV PairOut walk_group(const Tile& T, uint32_t* tile_w, bool two, bool sd, uint32_t base, uint32_t pos, uint32_t len, const DevTables& t) {
+    PairOut o{E_OK, 0u, 0u, false, false, 0u, 0u, 0u};
+    if (!two) {
+        if (sd) {
+            uint32_t m = 0, cnt = 0;
+            bool ok = false;
+            o.status = walk<MODE>(T, base, pos, len, &m, &cnt, t, 0u, tile_w, &ok);
+            if (o.status == E_OK) {
+                o.n_ent = cnt;
+                o.msg_at = m;
+                o.rec_ok = ok;
+                o.n_own = ok ? cnt : 0u;
+                o.rec_at = (base + 3u) & ~3u;
+            }
+        }
+        return o;
+    }
+    const uint32_t l = wv::lane();
+    const bool second = l >= 32u;
+    // the second lane adopts the line of lane l - 32
+    const bool sdl = wv::shfl(sd ? 1u : 0u, l & 31u) != 0u;
+    const uint32_t b = wv::shfl(base, l & 31u), p = wv::shfl(pos, l & 31u), n = wv::shfl(len, l & 31u);
+    const uint32_t split = sdl ? pick_split(T, b, p, n) : kNoSplit;  // (the same value in both lanes of a line)
+    uint32_t st = E_OK, cnt = 0, m = 0;
+    bool ok = false;
+    if (sdl && (!second || split != kNoSplit))
+        st = walk<MODE>(T, b, p, n, &m, &cnt, t, 0u, tile_w, &ok, second ? kNoSplit : split, second ? split + 1u : 0u);
+    // exchange across the halves
+    const uint32_t st_b = wv::shfl(st, l | 32u), cnt_b = wv::shfl(cnt, l | 32u), m_b = wv::shfl(m, l | 32u), ok_b = wv::shfl(ok ? 1u : 0u, l | 32u);
+    const uint32_t st_a = wv::shfl(st, l & 31u), cnt_a = wv::shfl(cnt, l & 31u), ok_a = wv::shfl(ok ? 1u : 0u, l & 31u);
+    if (!sdl) return o;
+    const bool handed = split != kNoSplit && st_a == E_HANDOFF;
+    const bool line_ok = handed ? st_b == E_OK : st_a == E_OK;
+    const bool recs = line_ok && ok_a != 0u && (!handed || ok_b != 0u);
+    if (!second) {
+        if (handed) {
+            o.status = st_b;
+            if (st_b == E_OK) {
+                o.n_ent = cnt + cnt_b;
+                o.msg_at = m_b;
+            }
+        } else if (st == E_REDO) {
+            o.redo = true;
+        } else {
+            o.status = st;  // the whole walk (no second lane was started), or an error before the split
+            if (st == E_OK) {
+                o.n_ent = cnt;
+                o.msg_at = m;
+            }
+        }
+        o.rec_ok = recs;
+        o.n_own = recs ? cnt : 0u;
+        o.rec_at = (b + 3u) & ~3u;
+    } else {
+        o.n_own = (handed && recs) ? cnt : 0u;
+        o.rec_at = (b + split + 1u + 3u) & ~3u;
+        o.skip = cnt_a;
+    }
+    return o;
+}
+
+// The records of one lane -> entry slots first .. first + n (four records in flight before the first store)
+FG_WV void copy_out(const uint32_t* tile_w, uint32_t rec_at, uint32_t n, uint32_t first, const DevTables& t) {
+    const uint32_t* rec32 = tile_w + (rec_at >> 2);
+    for (uint32_t k0 = 0; k0 < n; k0 += 4u) {
+        uint32_t lo[4], hi[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            const uint32_t k = k0 + j < n ? k0 + j : n - 1u;
+            lo[j] = rec32[k * 2u];
+            hi[j] = rec32[k * 2u + 1u];
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            const uint32_t k = k0 + j;
+            if (k < n) {
+                const uint32_t name_s = lo[j] & 0xFFFFu, name_len = lo[j] >> 16, val_len = hi[j] & 0xFFFFu;
+                const bool sdid = (hi[j] >> 17) & 1u;
+                t.ent_name[first + k] = fg_span{name_s, name_len};
+                t.ent_val[first + k] = sdid ? 0ull : ((uint64_t)(name_s + name_len + 2u) | ((uint64_t)val_len << 32));
+                t.ent_type[first + k] = sdid ? FG_T_SDID : FG_T_STRING;
+                t.ent_flags[first + k] = ((hi[j] >> 16) & 1u) ? FG_EF_VAL_ESC : 0;
+            }
+        }
+    }
 }
 
 }  // namespace sd2

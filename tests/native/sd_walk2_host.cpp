@@ -240,3 +240,98 @@ extern "C" long fgs_walk_two(const uint8_t* bytes, uint64_t nbytes, const uint64
     return (long)used;
 }
 
+
+// The whole group through sd2::walk_group + wave prefix sum + sd2::copy_out on the fiber emulation of a wavefront (what stage B of
+// the kernel will do): fills status / msg_at / n_ent / ent_first and the entry arrays (ent_name, ent_val, ent_type, ent_flags of
+// `tables`); lines the group walk hands back (redo, records that did not fit) are walked alone in EMIT mode over a fresh copy, as
+// the kernel does from global memory.  kinds[i]: 0 = records copied out by one lane, 1 = by two lanes, 2 = redo, 3 = records did
+// not fit, 4 = not OK.  Returns entries used or -1.
+extern "C" long fgs_walk_wave(const uint8_t* bytes, uint64_t nbytes, const uint64_t* offsets, uint64_t n, const uint32_t* sd_pos,
+                              uint32_t lines_per_group, const fg_tables* tables, uint32_t* status, uint32_t* msg_at, uint8_t* kinds) {
+    using namespace fg;
+    DevTables t{};
+    t.ent_cap = tables->ent_cap;
+    t.ent_name = tables->ent_name;
+    t.ent_val = tables->ent_val;
+    t.ent_type = tables->ent_type;
+    t.ent_flags = tables->ent_flags;
+    uint32_t used = 0;
+    const uint32_t L = lines_per_group;
+    for (uint64_t g0 = 0; g0 < n; g0 += L) {
+        const uint32_t nl = (uint32_t)(g0 + L <= n ? L : n - g0);
+        const uint64_t a0 = offsets[g0] & ~15ull;
+        const uint32_t span = (uint32_t)((offsets[g0 + nl] - a0 + 15ull) & ~15ull);
+        std::vector<uint32_t> tile_words(span / 4 + 16), bm_words(span / 32 + 4);
+        auto stage = [&]() {
+            uint8_t* tb = reinterpret_cast<uint8_t*>(tile_words.data());
+            memset(tb, 0xA5, tile_words.size() * 4);
+            for (uint32_t k = 0; k < span; ++k) tb[k] = a0 + k < nbytes ? bytes[a0 + k] : 0x22;
+            memset(bm_words.data(), 0xFF, bm_words.size() * 4);
+            uint16_t* bm16 = reinterpret_cast<uint16_t*>(bm_words.data());
+            for (uint32_t c = 0; c < span / 16; ++c) {
+                uint32_t m = 0;
+                for (uint32_t k = 0; k < 16; ++k) m |= (tb[16 * c + k] == '"' || tb[16 * c + k] == '\\') ? 1u << k : 0u;
+                bm16[c] = (uint16_t)m;
+            }
+        };
+        stage();
+        sd2::Tile T{wv::Bytes{tile_words.data()}, bm_words.data()};
+        uint32_t* tw = tile_words.data();
+        sd2::PairOut outs[64];
+        uint32_t firsts[64];
+        uint32_t group_total = 0;
+        const bool two = nl <= 32;
+        emu::run_wave([&]() {
+            const uint32_t l = wv::lane();
+            const bool has = l < nl;
+            const uint32_t base = has ? (uint32_t)(offsets[g0 + l] - a0) : 0u, len = has ? (uint32_t)(offsets[g0 + l + 1] - offsets[g0 + l]) : 0u;
+            const sd2::PairOut o = sd2::walk_group<sd2::SD_STASH>(T, tw, two, has, base, has ? sd_pos[g0 + l] : 0u, len, t);
+            // slots: the line's lane asks for the line's entries (only lines whose records can be copied out take part here)
+            const uint32_t want = (has && !o.redo && o.status == sd2::E_OK && o.rec_ok) ? o.n_ent : 0u;
+            uint32_t total = 0;
+            const uint32_t ex = wv::excl_sum(want, &total);
+            const uint32_t first = used + ex;
+            const uint32_t line_first = wv::shfl(first, l & 31u);
+            sd2::copy_out(tw, o.rec_at, o.n_own, (two ? line_first : first) + o.skip, t);
+            outs[l] = o;
+            firsts[l] = first;
+            if (l == 0) group_total = total;
+        });
+        used += group_total;
+        for (uint32_t j = 0; j < nl; ++j) {
+            const uint64_t i = g0 + j;
+            const sd2::PairOut& o = outs[j];
+            const uint32_t base = (uint32_t)(offsets[i] - a0), len = (uint32_t)(offsets[i + 1] - offsets[i]);
+            if (!o.redo && o.status == sd2::E_OK && o.rec_ok) {
+                status[i] = sd2::E_OK;
+                msg_at[i] = o.msg_at;
+                tables->ent_first[i] = firsts[j];
+                tables->ent_count[i] = o.n_ent;
+                kinds[i] = (two && outs[j + 32].n_own) ? 1 : 0;
+                continue;
+            }
+            if (!o.redo && o.status != sd2::E_OK) {
+                status[i] = o.status;
+                msg_at[i] = 0;
+                tables->ent_first[i] = 0;
+                tables->ent_count[i] = 0;
+                kinds[i] = 4;
+                continue;
+            }
+            // handed back: alone, over a fresh copy, entries straight into the table
+            kinds[i] = o.redo ? 2 : 3;
+            stage();
+            uint32_t m = 0, cnt = 0;
+            status[i] = sd2::walk<sd2::SD_COUNT, true>(T, base, sd_pos[i], len, &m, &cnt, t, 0);
+            msg_at[i] = status[i] == sd2::E_OK ? m : 0;
+            if (status[i] != sd2::E_OK) cnt = 0;
+            if (used + cnt > tables->ent_cap) return -1;
+            if (cnt) sd2::walk<sd2::SD_EMIT, true>(T, base, sd_pos[i], len, &m, &cnt, t, used);
+            tables->ent_first[i] = used;
+            tables->ent_count[i] = cnt;
+            used += cnt;
+        }
+    }
+    *tables->ent_used = used;
+    return (long)used;
+}
