@@ -149,7 +149,7 @@ FG_WV uint32_t walk(const Tile& T, uint32_t base, uint32_t pos, uint32_t len, ui
     const bool first_of_two = stop_at != kNoSplit;
     auto record = [&](uint64_t rec, uint32_t consumed) {  // consumed: line index up to which the walk is done with the bytes
         if (rec_ok) {
-            if (wpos + 8u <= base + consumed) {
+            if (tile_w != nullptr && wpos + 8u <= base + consumed) {
                 tile_w[wpos >> 2] = (uint32_t)rec;
                 tile_w[(wpos >> 2) + 1u] = (uint32_t)(rec >> 32);
                 wpos += 8u;
@@ -417,31 +417,29 @@ struct PairOut {
 template <int MODE>
 FG_WV PairOut walk_group(const Tile& T, uint32_t* tile_w, bool two, bool sd, uint32_t base, uint32_t pos, uint32_t len, const DevTables& t) {
     PairOut o{E_OK, 0u, 0u, false, false, 0u, 0u, 0u};
-    if (!two) {
-        if (sd) {
-            uint32_t m = 0, cnt = 0;
-            bool ok = false;
-            o.status = walk<MODE>(T, base, pos, len, &m, &cnt, t, 0u, tile_w, &ok);
-            if (o.status == E_OK) {
-                o.n_ent = cnt;
-                o.msg_at = m;
-                o.rec_ok = ok;
-                o.n_own = ok ? cnt : 0u;
-                o.rec_at = (base + 3u) & ~3u;
-            }
-        }
-        return o;
-    }
     const uint32_t l = wv::lane();
-    const bool second = l >= 32u;
-    // the second lane adopts the line of lane l - 32
-    const bool sdl = wv::shfl(sd ? 1u : 0u, l & 31u) != 0u;
-    const uint32_t b = wv::shfl(base, l & 31u), p = wv::shfl(pos, l & 31u), n = wv::shfl(len, l & 31u);
-    const uint32_t split = sdl ? pick_split(T, b, p, n) : kNoSplit;  // (the same value in both lanes of a line)
+    const bool second = two && l >= 32u;
+    // the second lane adopts the line of lane l - 32  (ONE inlined walk for every case: the walk is the kernel's largest piece of
+    // code, and a copy per mode was measurably worse than the instructions it saved)
+    const uint32_t src = two ? (l & 31u) : l;
+    const bool sdl = wv::shfl(sd ? 1u : 0u, src) != 0u;
+    const uint32_t b = wv::shfl(base, src), p = wv::shfl(pos, src), n = wv::shfl(len, src);
+    const uint32_t split = (two && sdl) ? pick_split(T, b, p, n) : kNoSplit;  // (the same value in both lanes of a line)
     uint32_t st = E_OK, cnt = 0, m = 0;
     bool ok = false;
     if (sdl && (!second || split != kNoSplit))
         st = walk<MODE>(T, b, p, n, &m, &cnt, t, 0u, tile_w, &ok, second ? kNoSplit : split, second ? split + 1u : 0u);
+    if (!two) {
+        if (sdl && st == E_OK) {
+            o.n_ent = cnt;
+            o.msg_at = m;
+            o.rec_ok = ok;
+            o.n_own = ok ? cnt : 0u;
+            o.rec_at = (b + 3u) & ~3u;
+        }
+        o.status = sdl ? st : E_OK;
+        return o;
+    }
     // exchange across the halves
     const uint32_t st_b = wv::shfl(st, l | 32u), cnt_b = wv::shfl(cnt, l | 32u), m_b = wv::shfl(m, l | 32u), ok_b = wv::shfl(ok ? 1u : 0u, l | 32u);
     const uint32_t st_a = wv::shfl(st, l & 31u), cnt_a = wv::shfl(cnt, l & 31u), ok_a = wv::shfl(ok ? 1u : 0u, l & 31u);
