@@ -1,0 +1,138 @@
+// The HOST side of the C ABI (flowgger_amd/csrc/fg_capi.cpp + fg_gather.cpp + fg_materialize.cpp, unchanged) compiled with g++ against
+// a synchronous stand-in for the HIP runtime (tests/native/fakehip) and the FAKE kernel launchers below, so that `pytest -m "not gpu"`
+// runs its bookkeeping: slices cut at line boundaries, rows at their final index, entry ranges per slice of one shared counter, the
+// retry when the entry table is too small, the raw-stream path's frame counts per slice and its fall-back, error paths.
+// The fake decode "kernel" is deterministic nonsense with the REAL kernels' contract: one row per line, one entry per '=' of the
+// line, slots taken from the shared counter (which keeps counting past the capacity), FG_ST_OVERFLOW rows without entries,
+// terminators stripped as the kernels strip them, FG_ST_BAD_UTF8 for flagged frames.  The fake framing "kernels" are a plain
+// delimiter scan with the real ones' contract (ranks continue from slice to slice; a frame is bad when it holds a byte >= 0xF8).
+// Test infrastructure: nothing here is shipped, and it says nothing about what the GPU computes.
+#include "../../flowgger_amd/csrc/fg_capi.cpp"
+#include "../../flowgger_amd/csrc/fg_gather.cpp"
+#include "../../flowgger_amd/csrc/fg_materialize.cpp"
+
+namespace {
+unsigned long long g_launches = 0;
+
+int fake_decode(const uint8_t* bytes, const uint64_t* offsets, uint64_t n, const fg::DevTables* t, uint32_t strip, const uint8_t* line_bad) {
+    ++g_launches;
+    const fg_span none{0u, FG_NONE};
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint8_t* ln = bytes + offsets[i];
+        uint32_t len = (uint32_t)(offsets[i + 1] - offsets[i]);
+        if (strip == FG_FRAME_LINE && len && ln[len - 1] == '\n') {
+            --len;
+            if (len && ln[len - 1] == '\r') --len;
+        } else if (strip == FG_FRAME_NUL && len && ln[len - 1] == 0) {
+            --len;
+        }
+        uint32_t status = len == 0 ? 1u : 0u;
+        if (line_bad && line_bad[i]) status = FG_ST_BAD_UTF8;
+        uint32_t k = 0;
+        if (status == 0)
+            for (uint32_t p = 0; p < len; ++p) k += ln[p] == '=';
+        uint32_t first = 0;
+        if (k) {
+            const unsigned long long at = *t->ent_used;
+            *t->ent_used = at + k;  // (keeps counting: the final value is what the batch needs)
+            if (at + k > t->ent_cap) {
+                status = FG_ST_OVERFLOW;
+                k = 0;
+            } else {
+                first = (uint32_t)at;
+                uint32_t j = 0;
+                for (uint32_t p = 0; p < len; ++p)
+                    if (ln[p] == '=') {
+                        t->ent_name[first + j] = fg_span{p ? p - 1u : 0u, 1u};
+                        const uint32_t vl = len - p - 1u < 3u ? len - p - 1u : 3u;
+                        t->ent_val[first + j] = (uint64_t)(p + 1u) | ((uint64_t)vl << 32);
+                        t->ent_type[first + j] = FG_T_STRING;
+                        t->ent_flags[first + j] = 0;
+                        ++j;
+                    }
+            }
+        }
+        const bool ok = status == 0;
+        t->meta[i] = status | ((ok ? (uint32_t)(ln[0] & 0x17u) : 0xFFu) << 8) | ((ok ? len & 7u : 0xFFu) << 16);
+        t->ts[i] = ok ? (double)len + 0.5 : 0.0;
+        t->span[0][i] = ok ? fg_span{0u, len < 4u ? len : 4u} : none;
+        t->span[1][i] = none;
+        t->span[2][i] = none;
+        t->span[3][i] = none;
+        t->span[4][i] = ok && len > 1u ? fg_span{len / 2u, len - len / 2u} : none;
+        t->span[5][i] = ok ? fg_span{0u, len} : none;
+        t->ent_first[i] = first;
+        t->ent_count[i] = k;
+    }
+    return 0;
+}
+}  // namespace
+
+extern "C" unsigned long long fgf_launches(int reset) {
+    const unsigned long long v = g_launches;
+    if (reset) g_launches = 0;
+    return v;
+}
+extern "C" void fgf_counters(unsigned long long out[3], int reset) {
+    out[0] = fakehip::copies();
+    out[1] = fakehip::bytes_h2d();
+    out[2] = fakehip::bytes_d2h();
+    if (reset) fakehip::copies() = fakehip::bytes_h2d() = fakehip::bytes_d2h() = 0;
+}
+extern "C" void fgf_fail_malloc_after(long long n) { fakehip::fail_malloc_after() = n; }
+
+extern "C" uint64_t fg_stash_bytes(uint32_t blocks) { return 64ull * blocks; }
+extern "C" int fg_launch_rfc5424(const uint8_t* b, const uint64_t* o, uint64_t n, const fg::DevTables* t, uint64_t, hipStream_t, uint64_t*, uint32_t,
+                                 uint32_t strip, const uint8_t* bad, const fg_launch_opts*) { return fake_decode(b, o, n, t, strip, bad); }
+extern "C" int fg_launch_ltsv(const uint8_t* b, const uint64_t* o, uint64_t n, const fg::DevTables* t, const fg::LtsvDevCfg*, uint64_t, hipStream_t,
+                              uint64_t*, uint32_t, uint32_t strip, const uint8_t* bad, const fg_launch_opts*) { return fake_decode(b, o, n, t, strip, bad); }
+extern "C" int fg_launch_gelf(const uint8_t* b, const uint64_t* o, uint64_t n, const fg::DevTables* t, uint64_t, hipStream_t, uint64_t*, uint32_t,
+                              uint32_t strip, const uint8_t* bad, const fg_launch_opts*) { return fake_decode(b, o, n, t, strip, bad); }
+extern "C" int fg_launch_rfc3164(const uint8_t* b, const uint64_t* o, uint64_t n, const fg::DevTables* t, const fg::r3164::Cfg*, uint32_t, hipStream_t,
+                                 uint32_t strip, const uint8_t* bad) { return fake_decode(b, o, n, t, strip, bad); }
+// the encoders are not part of this harness
+extern "C" int fg_launch_encode_sizes(const uint8_t*, const uint64_t*, uint64_t, const fg::DevTables*, const fg::EncCfg*, uint32_t, uint32_t, uint32_t*,
+                                      uint64_t*, uint8_t*, uint64_t*, hipStream_t) { return -1; }
+extern "C" int fg_launch_encode_count(const uint8_t*, const uint64_t*, uint64_t, const fg::DevTables*, const fg::EncCfg*, uint32_t, uint32_t, uint32_t*,
+                                      uint64_t*, uint8_t*, hipStream_t) { return -1; }
+extern "C" int fg_launch_encode_scan(const uint32_t*, uint64_t*, uint64_t, uint64_t*, uint64_t, hipStream_t) { return -1; }
+extern "C" int fg_launch_encode_write(const uint8_t*, const uint64_t*, uint64_t, const fg::DevTables*, const fg::EncCfg*, uint32_t, uint32_t,
+                                      const uint64_t*, uint8_t*, hipStream_t) { return -1; }
+
+// ---- framing: offsets[0] = 0, offsets[r + 1] = the byte behind the delimiter of rank r; the word behind block k of `scratch` holds
+//      the delimiters of the blocks before k (so the word at [blk1] is "up to the end of this slice")
+extern "C" uint64_t fg_frame_block_bytes(void) { return 16384; }
+extern "C" uint64_t fg_frame_scratch_bytes(uint64_t nbytes) { return (nbytes / 16384 + 3) * 8; }
+static int frame_blocks_fake(const uint8_t* d_bytes, uint64_t nbytes, uint32_t delim, uint8_t* scratch, uint64_t* d_offsets, uint8_t* d_bad, uint64_t cap,
+                             uint64_t blk0, uint64_t blk1, uint64_t** d_total_out) {
+    uint64_t* pref = reinterpret_cast<uint64_t*>(scratch);
+    if (blk0 == 0) {
+        pref[0] = 0;
+        d_offsets[0] = 0;
+    }
+    uint64_t rank = pref[blk0];
+    const uint64_t b0 = blk0 * 16384, b1 = blk1 * 16384 < nbytes ? blk1 * 16384 : nbytes;
+    for (uint64_t p = b0; p < b1; ++p) {
+        if (d_bytes[p] >= 0xF8u && rank < cap) d_bad[rank] = 1;  // (the frame this byte belongs to has rank = delimiters before it)
+        if (d_bytes[p] == (uint8_t)delim) {
+            if (rank + 1 <= cap + 1) d_offsets[rank + 1] = p + 1;
+            ++rank;
+        }
+    }
+    for (uint64_t k = blk0 + 1; k <= blk1; ++k) pref[k] = rank;  // (only [blk1] is read)
+    *d_total_out = pref + blk1;
+    return 0;
+}
+extern "C" int fg_launch_frame(const uint8_t* d_bytes, uint64_t nbytes, uint32_t delim, uint8_t* scratch, uint64_t* d_offsets, uint8_t* d_bad, uint64_t cap,
+                               uint64_t** d_total_out, hipStream_t) {
+    memset(d_bad, 0, cap);
+    const int rc = frame_blocks_fake(d_bytes, nbytes, delim, scratch, d_offsets, d_bad, cap, 0, nbytes / 16384 + 1, d_total_out);
+    const uint64_t total = **d_total_out;  // the whole-stream form also ends an unterminated last frame at nbytes
+    if (total + 1 <= cap && d_offsets[total] != nbytes) d_offsets[total + 1] = nbytes;
+    return rc;
+}
+extern "C" int fg_launch_frame_slice(const uint8_t* d_bytes, uint64_t nbytes, uint32_t delim, uint8_t* scratch, uint64_t* d_offsets, uint8_t* d_bad,
+                                     uint64_t cap, uint64_t blk0, uint64_t blk1, uint64_t** d_total_out, hipStream_t) {
+    if (blk1 > nbytes / 16384 + 1 || blk0 >= blk1) return -1;
+    return frame_blocks_fake(d_bytes, nbytes, delim, scratch, d_offsets, d_bad, cap, blk0, blk1, d_total_out);
+}

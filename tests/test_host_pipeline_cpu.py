@@ -1,0 +1,222 @@
+"""CPU: the HOST side of the C ABI -- flowgger_amd/csrc/fg_capi.cpp itself, compiled by g++ against a synchronous stand-in for the
+HIP runtime (tests/native/fakehip) and fake kernel launchers with the real kernels' contract (tests/native/host_pipeline_fake.cpp).
+What is tested is the bookkeeping of the host paths: slices cut at line boundaries, rows at their final index, the entry columns
+brought back per slice as ranges of one shared counter, the retry when the entry table is too small, the raw-stream path's
+per-slice frame counts and its fall-back to the one-piece form, unterminated tails, error paths.  The sliced paths must give what
+ONE call of the device entry point gives on the same batch.  (What the GPU computes is the -m gpu suite's business.)"""
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from flowgger_amd import _lib as L
+
+ROOT = Path(__file__).resolve().parent.parent
+HERE = ROOT / "tests" / "native"
+LIB = HERE / "libhost_pipeline_fake.so"
+SRC = [HERE / "host_pipeline_fake.cpp", HERE / "fakehip/hip/hip_runtime.h"] + [ROOT / "flowgger_amd/csrc" / f for f in
+                                                                                ("fg_capi.cpp", "fg_gather.cpp", "fg_materialize.cpp")] + [ROOT / "include/fg_hip.h"]
+u64, vp = C.c_uint64, C.c_void_p
+COLS = ["meta", "ts", "hostname", "appname", "procid", "msgid", "msg", "full_msg", "ent_count"]
+
+
+@pytest.fixture(scope="module")
+def fake():
+    if not LIB.exists() or any(s.stat().st_mtime > LIB.stat().st_mtime for s in SRC):
+        subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas",
+                        "-Wno-unused-variable", f"-I{HERE / 'fakehip'}", f"-I{ROOT / 'include'}", "-o", str(LIB), str(HERE / "host_pipeline_fake.cpp")],
+                       check=True)
+    lib = C.CDLL(str(LIB))
+    lib.fg_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
+    lib.fg_destroy.argtypes = [vp]
+    lib.fg_destroy.restype = None
+    lib.fg_set_launch_opts.argtypes = [vp, C.POINTER(L.fg_launch_opts)]
+    lib.fg_tables_layout.argtypes = [u64, u64, C.POINTER(u64)]
+    lib.fg_decode_batch_device.argtypes = [vp, C.c_int, vp, u64, vp, u64, C.POINTER(L.fg_tables), vp]
+    lib.fg_decode_batch.argtypes = [vp, C.c_int, vp, u64, vp, u64, C.POINTER(L.fg_tables)]
+    lib.fg_frame_decode_batch.argtypes = [vp, C.c_int, C.c_int, vp, u64, C.c_int, C.POINTER(L.fg_tables), C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
+    lib.fgf_launches.restype = C.c_ulonglong
+    lib.fgf_fail_malloc_after.argtypes = [C.c_longlong]
+    return lib
+
+
+class Ctx:
+    def __init__(self, lib):
+        self.lib, self.h = lib, vp()
+        assert lib.fg_create(0, None, C.byref(self.h)) == 0
+
+    def close(self):
+        self.lib.fg_destroy(self.h)
+
+
+def snapshot(st, n):
+    """per-line content of ctx-owned tables: fixed columns + the line's entries"""
+    used = int(np.ctypeslib.as_array(C.cast(st.ent_used, C.POINTER(C.c_uint64)), (1,))[0])
+    def arr(name, dt, cnt):
+        p = getattr(st, name)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (cnt * np.dtype(dt).itemsize,)).view(dt).copy() if cnt else np.zeros(0, dt)
+    out = {"meta": arr("meta", np.uint32, n), "ts": arr("ts", np.float64, n), "ent_first": arr("ent_first", np.uint32, n),
+           "ent_count": arr("ent_count", np.uint32, n)}
+    for c in ("hostname", "appname", "procid", "msgid", "msg", "full_msg"):
+        out[c] = arr(c, np.uint64, n)
+    out["ent_name"], out["ent_val"] = arr("ent_name", np.uint64, used), arr("ent_val", np.uint64, used)
+    out["ent_type"], out["ent_flags"] = arr("ent_type", np.uint8, used), arr("ent_flags", np.uint8, used)
+    out["used"] = used
+    return out
+
+
+def device_reference(lib, data, offsets, ent_cap):
+    """one call of the device entry point on the whole batch (host arrays play the device)"""
+    n = len(offsets) - 1
+    sizes = (u64 * L.FG_TABLE_ARRAYS)()
+    assert lib.fg_tables_layout(n, ent_cap, sizes) == 0
+    bufs = [np.zeros(max(int(s), 8), np.uint8) for s in sizes]
+    st = L.fg_tables()
+    st.n, st.ent_cap = n, ent_cap
+    for name, b in zip(L.TABLE_FIELDS, bufs):
+        setattr(st, name, b.ctypes.data)
+    c = Ctx(lib)
+    pad = np.concatenate([data, np.zeros(64, np.uint8)])
+    assert lib.fg_decode_batch_device(c.h, 0, pad.ctypes.data, data.size, offsets.ctypes.data, n, C.byref(st), None) == 0
+    snap = snapshot(st, n)
+    c.close()
+    snap["_keep"] = bufs
+    return snap
+
+
+def same_lines(a, b, n):
+    for c in COLS:
+        assert np.array_equal(a[c][:n], b[c][:n]), c
+    # the entries of every line, wherever its slice of the table lies
+    for i in np.nonzero(a["ent_count"][:n])[0]:
+        fa, fb, k = int(a["ent_first"][i]), int(b["ent_first"][i]), int(a["ent_count"][i])
+        for c in ("ent_name", "ent_val", "ent_type", "ent_flags"):
+            assert np.array_equal(a[c][fa:fa + k], b[c][fb:fb + k]), (c, int(i))
+
+
+def corpus(n, rng, eq_lo=0, eq_hi=6, length=240):
+    lines = []
+    for i in range(n):
+        k = int(rng.integers(eq_lo, eq_hi + 1))
+        body = (b"<%d>" % (i % 190)) + b" ".join(b'k%d="v%d"' % (j, (i + j) % 97) for j in range(k))
+        lines.append(body + b" " + b"m" * max(length - len(body), 1) if i % 1009 else b"")
+    return lines
+
+
+def pack(lines):
+    offsets = np.zeros(len(lines) + 1, np.uint64)
+    np.cumsum([len(x) for x in lines], out=offsets[1:])
+    return np.frombuffer(b"".join(lines), np.uint8).copy(), offsets
+
+
+def test_sliced_decode_batch_equals_one_launch(fake):
+    rng = np.random.default_rng(1)
+    lines = corpus(330_000, rng)
+    data, offsets = pack(lines)
+    assert data.size > 2 * (32 << 20)
+    n = len(lines)
+    c = Ctx(fake)
+    st = L.fg_tables()
+    cnt = (C.c_ulonglong * 3)()
+    fake.fgf_launches(1)
+    fake.fgf_counters(cnt, 1)
+    assert fake.fg_decode_batch(c.h, 0, data.ctypes.data, data.size, offsets.ctypes.data, n, C.byref(st)) == 0
+    launches = fake.fgf_launches(1)
+    fake.fgf_counters(cnt, 1)
+    got = snapshot(st, n)
+    want = device_reference(fake, data, offsets, data.size // 16 + 1024)
+    assert launches >= 3 and got["used"] == want["used"] == int(got["ent_count"].sum())
+    same_lines(got, want, n)
+    # every table byte crossed the link once: rows (76 B) + entries (18 B) + the counters, nothing twice
+    assert cnt[2] <= n * 76 + got["used"] * 18 + 64 * launches, (int(cnt[2]), n * 76 + got["used"] * 18)
+    assert cnt[1] <= data.size + 16 * launches + (n + 1) * 8 + 64
+    # a second, smaller batch on the same ctx (buffers are reused; one slice: the single-stream path)
+    small, soffs = pack(lines[:5000])
+    assert fake.fg_decode_batch(c.h, 0, small.ctypes.data, small.size, soffs.ctypes.data, 5000, C.byref(st)) == 0
+    same_lines(snapshot(st, 5000), device_reference(fake, small, soffs, small.size // 16 + 1024), 5000)
+    c.close()
+
+
+def test_entry_table_too_small_is_noticed_mid_batch_and_the_retry_is_exact(fake):
+    rng = np.random.default_rng(2)
+    lines = corpus(60_000, rng, 0, 2) + corpus(150_000, rng, 30, 40, 300) + corpus(60_000, rng, 0, 2)  # > one entry per 16 bytes in the middle
+    data, offsets = pack(lines)
+    n = len(lines)
+    assert data.size > (64 << 20)
+    total = sum(ln.count(b"=") for ln in lines)
+    assert total > data.size // 16 + 1024
+    c = Ctx(fake)
+    st = L.fg_tables()
+    fake.fgf_launches(1)
+    assert fake.fg_decode_batch(c.h, 0, data.ctypes.data, data.size, offsets.ctypes.data, n, C.byref(st)) == 0
+    launches = fake.fgf_launches(1)
+    got = snapshot(st, n)
+    assert got["used"] == total and not (got["meta"] & 0xFF == 0xFE).any()
+    sl = min(max(data.size // 8, 8 << 20), 32 << 20)  # (fg_capi.cpp's slice_count)
+    slices = (data.size + sl - 1) // sl
+    assert launches == 2 * slices  # every slice ran twice: once counting past the capacity, once with the capacity the counter asked for
+    same_lines(got, device_reference(fake, data, offsets, total + 16), n)
+    c.close()
+
+
+@pytest.mark.parametrize("final", [1, 0])
+@pytest.mark.parametrize("dense", [False, True])
+def test_raw_stream_sliced_equals_one_piece(fake, final, dense):
+    rng = np.random.default_rng(3)
+    lines = [ln for ln in corpus(250_000, rng, 30 if dense else 0, 40 if dense else 5, 300 if dense else 240)]
+    parts = [ln + (b"\r\n" if i % 7 == 0 else b"\n") for i, ln in enumerate(lines)]
+    parts[1234] = b"\xff" + parts[1234]
+    tail = b"<1>tail without a terminator a=1"
+    raw = np.frombuffer(b"".join(parts) + tail, np.uint8).copy()
+    assert raw.size > (48 << 20)
+    res = {}
+    for one_piece in (False, True):
+        c = Ctx(fake)
+        lo = L.fg_launch_opts()
+        lo.flags = L.FG_LO_TRANSCODE_ONE_PIECE if one_piece else 0
+        assert fake.fg_set_launch_opts(c.h, C.byref(lo)) == 0
+        st, po, nf, cons = L.fg_tables(), vp(), u64(), u64()
+        pad = np.concatenate([raw, np.zeros(64, np.uint8)])
+        rc = fake.fg_frame_decode_batch(c.h, 0, 1, pad.ctypes.data, raw.size, final, C.byref(st), C.byref(po), C.byref(nf), C.byref(cons))
+        assert rc == 0
+        n = int(nf.value)
+        offs = np.ctypeslib.as_array(C.cast(po, C.POINTER(C.c_uint64)), (n + 1,)).copy()
+        res[one_piece] = (snapshot(st, n), offs, int(cons.value), n)
+        c.close()
+    (a, ao, ac, an), (b, bo, bc, bn) = res[False], res[True]
+    assert an == bn == len(lines) + (1 if final else 0) and ac == bc == (raw.size if final else raw.size - len(tail))
+    assert np.array_equal(ao, bo)
+    same_lines(a, b, an)
+    assert (a["meta"][1234] & 0xFF) == 0xFD and int((a["meta"] & 0xFF == 0xFD).sum()) == 1
+    assert a["used"] == int(a["ent_count"].sum()) == b["used"]
+
+
+def test_a_failed_device_allocation_is_an_error_and_the_ctx_stays_usable(fake):
+    rng = np.random.default_rng(4)
+    data, offsets = pack(corpus(20_000, rng))
+    n = len(offsets) - 1
+    c = Ctx(fake)
+    st = L.fg_tables()
+    fake.fgf_fail_malloc_after(1)
+    rc = fake.fg_decode_batch(c.h, 0, data.ctypes.data, data.size, offsets.ctypes.data, n, C.byref(st))
+    fake.fgf_fail_malloc_after(-1)
+    assert rc == -2  # FG_ERR_HIP
+    assert fake.fg_decode_batch(c.h, 0, data.ctypes.data, data.size, offsets.ctypes.data, n, C.byref(st)) == 0
+    same_lines(snapshot(st, n), device_reference(fake, data, offsets, data.size // 16 + 1024), n)
+    c.close()
+
+
+def test_argument_errors(fake):
+    c = Ctx(fake)
+    st = L.fg_tables()
+    data, offsets = pack([b"<1>a=1", b"<2>b"])
+    assert fake.fg_decode_batch(c.h, 0, data.ctypes.data, data.size, None, 2, C.byref(st)) == -1
+    bad = offsets.copy()
+    bad[2] = data.size + 5
+    assert fake.fg_decode_batch(c.h, 0, data.ctypes.data, data.size, bad.ctypes.data, 2, C.byref(st)) == -1
+    assert fake.fg_decode_batch(c.h, 0, data.ctypes.data, data.size, offsets.ctypes.data, 0, C.byref(st)) == 0
+    assert fake.fg_decode_batch(c.h, 0, data.ctypes.data, data.size, offsets.ctypes.data, 2, C.byref(st)) == 0
+    assert int(snapshot(st, 2)["ent_count"].sum()) == 1
+    c.close()
