@@ -90,14 +90,49 @@ extern "C" int fg_launch_gelf(const uint8_t* b, const uint64_t* o, uint64_t n, c
                               uint32_t strip, const uint8_t* bad, const fg_launch_opts*) { return fake_decode(b, o, n, t, strip, bad); }
 extern "C" int fg_launch_rfc3164(const uint8_t* b, const uint64_t* o, uint64_t n, const fg::DevTables* t, const fg::r3164::Cfg*, uint32_t, hipStream_t,
                                  uint32_t strip, const uint8_t* bad) { return fake_decode(b, o, n, t, strip, bad); }
-// the encoders are not part of this harness
-extern "C" int fg_launch_encode_sizes(const uint8_t*, const uint64_t*, uint64_t, const fg::DevTables*, const fg::EncCfg*, uint32_t, uint32_t, uint32_t*,
-                                      uint64_t*, uint8_t*, uint64_t*, hipStream_t) { return -1; }
-extern "C" int fg_launch_encode_count(const uint8_t*, const uint64_t*, uint64_t, const fg::DevTables*, const fg::EncCfg*, uint32_t, uint32_t, uint32_t*,
-                                      uint64_t*, uint8_t*, hipStream_t) { return -1; }
-extern "C" int fg_launch_encode_scan(const uint32_t*, uint64_t*, uint64_t, uint64_t*, uint64_t, hipStream_t) { return -1; }
-extern "C" int fg_launch_encode_write(const uint8_t*, const uint64_t*, uint64_t, const fg::DevTables*, const fg::EncCfg*, uint32_t, uint32_t,
-                                      const uint64_t*, uint8_t*, hipStream_t) { return -1; }
+// ---- the fake encoder: an Ok row's message = its line + one '#' per entry + '\n' (so rows AND entry counts of the right slice matter);
+//      other rows encode to nothing with enc_status 1.  Contracts of the real launchers (fg_encode.hip): count -> sizes per line +
+//      sums per 64 lines; scan -> out_offsets[0 .. n] absolute from `base`; sizes = both with base 0; write -> the bytes.
+static uint32_t fake_size(const uint64_t* o, const fg::DevTables* t, uint64_t i) {
+    return (t->meta[i] & 0xFFu) == 0u ? (uint32_t)(o[i + 1] - o[i]) + t->ent_count[i] + 1u : 0u;
+}
+extern "C" int fg_launch_encode_count(const uint8_t*, const uint64_t* o, uint64_t n, const fg::DevTables* t, const fg::EncCfg*, uint32_t, uint32_t,
+                                      uint32_t* d_sizes, uint64_t* d_block_sums, uint8_t* d_status, hipStream_t) {
+    for (uint64_t i = 0; i < n; ++i) {
+        d_sizes[i] = fake_size(o, t, i);
+        d_status[i] = (t->meta[i] & 0xFFu) == 0u ? 0 : 1;
+        if (i % 64 == 0) d_block_sums[i / 64] = 0;
+        d_block_sums[i / 64] += d_sizes[i];
+    }
+    return 0;
+}
+extern "C" int fg_launch_encode_scan(const uint32_t* d_sizes, uint64_t* d_block_sums, uint64_t n, uint64_t* d_out_offsets, uint64_t base, hipStream_t) {
+    uint64_t at = base, check = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        d_out_offsets[i] = at;
+        at += d_sizes[i];
+    }
+    d_out_offsets[n] = at;
+    for (uint64_t j = 0; j < (n + 63) / 64; ++j) check += d_block_sums[j];  // (the sums the count step left must be this slice's)
+    return check == at - base ? 0 : -7;
+}
+extern "C" int fg_launch_encode_sizes(const uint8_t* b, const uint64_t* o, uint64_t n, const fg::DevTables* t, const fg::EncCfg* c, uint32_t tc, uint32_t cl,
+                                      uint32_t* d_sizes, uint64_t* d_block_sums, uint8_t* d_status, uint64_t* d_out_offsets, hipStream_t s) {
+    const int rc = fg_launch_encode_count(b, o, n, t, c, tc, cl, d_sizes, d_block_sums, d_status, s);
+    return rc ? rc : fg_launch_encode_scan(d_sizes, d_block_sums, n, d_out_offsets, 0, s);
+}
+extern "C" int fg_launch_encode_write(const uint8_t* b, const uint64_t* o, uint64_t n, const fg::DevTables* t, const fg::EncCfg*, uint32_t, uint32_t,
+                                      const uint64_t* d_out_offsets, uint8_t* d_out, hipStream_t) {
+    for (uint64_t i = 0; i < n; ++i) {
+        if ((t->meta[i] & 0xFFu) != 0u) continue;
+        uint8_t* w = d_out + d_out_offsets[i];
+        const uint32_t len = (uint32_t)(o[i + 1] - o[i]);
+        memcpy(w, b + o[i], len);
+        memset(w + len, '#', t->ent_count[i]);
+        w[len + t->ent_count[i]] = '\n';
+    }
+    return 0;
+}
 
 // ---- framing: offsets[0] = 0, offsets[r + 1] = the byte behind the delimiter of rank r; the word behind block k of `scratch` holds
 //      the delimiters of the blocks before k (so the word at [blk1] is "up to the end of this slice")

@@ -220,3 +220,45 @@ def test_argument_errors(fake):
     assert fake.fg_decode_batch(c.h, 0, data.ctypes.data, data.size, offsets.ctypes.data, 2, C.byref(st)) == 0
     assert int(snapshot(st, 2)["ent_count"].sum()) == 1
     c.close()
+
+
+@pytest.mark.parametrize("dense", [False, True])
+def test_transcode_sliced_equals_one_piece(fake, dense):
+    """fg_transcode_batch above 64 MiB: slices alternate between two lanes (upload, decode, count; then scan from the running base,
+    write, download), output buffers sized from the first slice; same stream, offsets, row meta and encoder status as the one-piece
+    form -- also when the entry table is too small for the sliced form (it then hands the batch to the one-piece form)."""
+    fake.fg_transcode_batch.argtypes = [vp, C.c_int, C.c_int, C.POINTER(L.fg_encode_cfg), vp, u64, vp, u64, C.c_int, C.POINTER(L.fg_transcoded)]
+    rng = np.random.default_rng(6)
+    lines = corpus(300_000, rng, 30 if dense else 0, 40 if dense else 5, 300 if dense else 240)
+    data, offsets = pack(lines)
+    n = len(lines)
+    assert data.size > (64 << 20)
+    ecfg = L.fg_encode_cfg()
+    ecfg.encoder, ecfg.merger = L.FG_ENC_GELF, L.FG_MERGE_LINE
+    res = {}
+    for one_piece in (False, True):
+        c = Ctx(fake)
+        lo = L.fg_launch_opts()
+        lo.flags = L.FG_LO_TRANSCODE_ONE_PIECE if one_piece else 0
+        assert fake.fg_set_launch_opts(c.h, C.byref(lo)) == 0
+        out = L.fg_transcoded()
+        fake.fgf_launches(1)
+        assert fake.fg_transcode_batch(c.h, 0, 0, C.byref(ecfg), data.ctypes.data, data.size, offsets.ctypes.data, n, 1, C.byref(out)) == 0
+        launches = fake.fgf_launches(1)
+        assert int(out.n) == n and int(out.consumed) == data.size
+        nb = int(out.out_bytes)
+        get = lambda p, dt, cnt: np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (cnt * np.dtype(dt).itemsize,)).view(dt).copy()  # noqa: E731
+        res[one_piece] = (get(out.out, np.uint8, nb), get(out.out_offsets, np.uint64, n + 1), get(out.meta, np.uint32, n), get(out.enc_status, np.uint8, n),
+                          launches)
+        c.close()
+    a, b = res[False], res[True]
+    for x, y in zip(a[:4], b[:4]):
+        assert np.array_equal(x, y)
+    # what the fake encoder writes for an Ok row: the line, one '#' per entry, '\\n'
+    ok = (a[2] & 0xFF) == 0
+    want = sum(len(ln) + ln.count(b"=") + 1 for ln, k in zip(lines, ok) if k)
+    assert int(a[1][-1]) == len(a[0]) == want
+    i = int(np.nonzero(ok)[0][12345])
+    assert a[0][int(a[1][i]):int(a[1][i + 1])].tobytes() == lines[i] + b"#" * lines[i].count(b"=") + b"\n"
+    if not dense:
+        assert a[4] > b[4] >= 1  # the sliced form launched one decode per slice
