@@ -10,7 +10,9 @@ import os
 _HERE = Path(__file__).resolve().parent
 # FLOWGGER_AMD_PROF_LIB=1 (tools/ only): the measurement build, `FG_BUILD_PROF=1 python -m flowgger_amd.build` (s_memtime phase clocks,
 # ablation flags -- csrc/fg_pipeline.hpp).  The product library has neither.
-LIB_PATH = _HERE / ("libfg_hip_prof.so" if os.environ.get("FLOWGGER_AMD_PROF_LIB") else "libfg_hip.so")
+# FLOWGGER_AMD_LIB=<file name beside this module> (tools/ only): another build of the same ABI, e.g. a branch's kernels for an A/B on
+# one box (tools/r04_ab.sh).  This is the PYTHON loader's choice of file; the library itself reads no environment variable.
+LIB_PATH = _HERE / (os.environ.get("FLOWGGER_AMD_LIB") or ("libfg_hip_prof.so" if os.environ.get("FLOWGGER_AMD_PROF_LIB") else "libfg_hip.so"))
 
 FG_RFC5424, FG_LTSV, FG_GELF, FG_RFC3164 = 0, 1, 2, 3
 FG_FRAME_NONE, FG_FRAME_LINE, FG_FRAME_NUL = 0, 1, 2
