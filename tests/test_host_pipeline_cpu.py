@@ -262,3 +262,19 @@ def test_transcode_sliced_equals_one_piece(fake, dense):
     assert a[0][int(a[1][i]):int(a[1][i + 1])].tobytes() == lines[i] + b"#" * lines[i].count(b"=") + b"\n"
     if not dense:
         assert a[4] > b[4] >= 1  # the sliced form launched one decode per slice
+
+
+def test_the_timeline_probe_runs_against_the_fake_runtime(fake, tmp_path):
+    """tools/probe/e2e_timeline.cpp (the per-slice timeline of the sliced host path, for the GPU box) compiled with g++ against the
+    fake runtime: both modes walk their slices, tables and entry ranges without a fault (the times it prints here mean nothing)."""
+    from flowgger_amd import synth
+
+    exe = tmp_path / "e2e_timeline_fake"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-w", f"-I{HERE / 'fakehip'}", f"-I{ROOT / 'include'}", str(ROOT / "tools/probe/e2e_timeline.cpp"), "-o", str(exe),
+                    f"-L{HERE}", "-lhost_pipeline_fake", f"-Wl,-rpath,{HERE}"], check=True)
+    corpus_file = tmp_path / "lines.txt"
+    corpus_file.write_bytes(b"\n".join(synth.rfc5424_lines(60_000, cfg=4, sd=True)))
+    for mode, mib in (("all", "8"), ("collect", "1")):
+        r = subprocess.run([str(exe), "rfc5424", str(corpus_file), mib, mode], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-500:]
+        assert "total" in r.stdout.splitlines()[-1] and f"mode {mode}" in r.stdout.splitlines()[0]
