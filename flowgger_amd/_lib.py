@@ -10,13 +10,20 @@ import os
 _HERE = Path(__file__).resolve().parent
 # FLOWGGER_AMD_PROF_LIB=1 (tools/ only): the measurement build, `FG_BUILD_PROF=1 python -m flowgger_amd.build` (s_memtime phase clocks,
 # ablation flags -- csrc/fg_pipeline.hpp).  The product library has neither.
-# FLOWGGER_AMD_LIB=<file name beside this module> (tools/ only): another build of the same ABI, e.g. a branch's kernels for an A/B on
-# one box (tools/r04_ab.sh).  This is the PYTHON loader's choice of file; the library itself reads no environment variable.
-LIB_PATH = _HERE / (os.environ.get("FLOWGGER_AMD_LIB") or ("libfg_hip_prof.so" if os.environ.get("FLOWGGER_AMD_PROF_LIB") else "libfg_hip.so"))
+# FLOWGGER_AMD_LIB=<bare file name beside this module> (tools/ only): another build of the same ABI, e.g. a branch's kernels for an A/B on
+# one box.  A BARE NAME only -- anything with a directory part is refused, so the variable cannot point the product package at an
+# arbitrary shared object -- and fg_abi_version() must match.  This is the PYTHON loader's choice of file; the library itself
+# reads no environment variable.
+_ALT = os.environ.get("FLOWGGER_AMD_LIB") or ""
+if _ALT and (Path(_ALT).name != _ALT or not _ALT.startswith("libfg_hip") or not _ALT.endswith(".so")):
+    raise RuntimeError(f"FLOWGGER_AMD_LIB={_ALT!r}: only a bare libfg_hip*.so file name beside flowgger_amd/_lib.py is accepted")
+LIB_PATH = _HERE / (_ALT or ("libfg_hip_prof.so" if os.environ.get("FLOWGGER_AMD_PROF_LIB") else "libfg_hip.so"))
 
+FG_ABI_VERSION = 2  # include/fg_hip.h
 FG_RFC5424, FG_LTSV, FG_GELF, FG_RFC3164 = 0, 1, 2, 3
 FG_FRAME_NONE, FG_FRAME_LINE, FG_FRAME_NUL = 0, 1, 2
 FG_ST_OVERFLOW, FG_ST_BAD_UTF8 = 0xFE, 0xFD
+FG_F_LTSV_NOVALUE = 128  # meta flags bit (include/fg_hip.h)
 FG_OK, FG_ERR_ARG, FG_ERR_HIP, FG_ERR_NO_DEVICE, FG_ERR_ENT_OVERFLOW, FG_ERR_UNSUPPORTED, FG_ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6
 FG_YEAR_NOW = -2147483648  # INT32_MIN (include/fg_hip.h)
 FG_NONE = 0xFFFFFFFF
@@ -152,12 +159,13 @@ def lib() -> C.CDLL:
     L.fg_encode_error_string.restype = C.c_char_p
     L.fg_set_rfc3164.argtypes = [vp, C.POINTER(fg_rfc3164_cfg)]
     L.fg_measure_link.argtypes = [vp, u64, C.POINTER(C.c_double)]
+    L.fg_calibrate_device.argtypes = [vp, C.c_int, vp, vp, u64, vp]
     L.fg_alloc_pinned.argtypes = [u64, C.POINTER(vp)]
     L.fg_free_pinned.argtypes = [vp]
     L.fg_free_pinned.restype = None
     L.fg_frame_device.argtypes = [vp, C.c_int, vp, u64, vp, vp, u64, C.POINTER(u64), vp]
     L.fg_decode_frames_device.argtypes = [vp, C.c_int, C.c_int, vp, u64, vp, u64, vp, C.POINTER(fg_tables), vp]
-    if L.fg_abi_version() != 1:
+    if L.fg_abi_version() != FG_ABI_VERSION:
         raise RuntimeError("libfg_hip.so ABI version mismatch")
     _lib = L
     return L

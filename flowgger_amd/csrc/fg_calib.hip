@@ -1,0 +1,65 @@
+// fg_calib.hip -- calibration sweeps over a resident buffer (fg_calibrate_device, include/fg_hip.h): what THIS box's memory system
+// gives a plain streaming kernel, measured in the same process and on the same buffer as the decode kernels, so that a decoder's
+// GB/s can be priced against the box it ran on (bench.py: roofline.copy_GBps / read_GBps, frac_of_copy) instead of against another
+// box's number.  No reference analogue; measurement support, not part of the decode path.
+//   mode 0  float4 copy   src -> dst           (2 x nbytes of traffic; the guide's "float4 copy" figure, ~6.3 TB/s)
+//   mode 1  read-only     src -> one word      (nbytes of traffic: the roof of a decoder that writes little)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fg {
+
+constexpr int kCalibThreads = 256;
+constexpr int kCalibUnroll = 4;  // 16-byte loads in flight per lane
+
+__global__ __launch_bounds__(kCalibThreads) void k_calib_copy(const uint4* __restrict__ src, uint4* __restrict__ dst, uint64_t n16) {
+    const uint64_t stride = (uint64_t)gridDim.x * kCalibThreads;
+    uint64_t i = (uint64_t)blockIdx.x * kCalibThreads + threadIdx.x;
+    for (; i + (kCalibUnroll - 1) * stride < n16; i += kCalibUnroll * stride) {
+        uint4 v[kCalibUnroll];
+#pragma unroll
+        for (int k = 0; k < kCalibUnroll; ++k) v[k] = src[i + k * stride];
+#pragma unroll
+        for (int k = 0; k < kCalibUnroll; ++k) dst[i + k * stride] = v[k];
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(kCalibThreads) void k_calib_read(const uint4* __restrict__ src, uint64_t n16, uint32_t* __restrict__ sink) {
+    const uint64_t stride = (uint64_t)gridDim.x * kCalibThreads;
+    uint64_t i = (uint64_t)blockIdx.x * kCalibThreads + threadIdx.x;
+    uint32_t acc = 0;
+    for (; i + (kCalibUnroll - 1) * stride < n16; i += kCalibUnroll * stride) {
+        uint4 v[kCalibUnroll];
+#pragma unroll
+        for (int k = 0; k < kCalibUnroll; ++k) v[k] = src[i + k * stride];
+#pragma unroll
+        for (int k = 0; k < kCalibUnroll; ++k) acc ^= v[k].x ^ v[k].y ^ v[k].z ^ v[k].w;
+    }
+    for (; i < n16; i += stride) {
+        const uint4 v = src[i];
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x9E3779B9u) *sink = acc;  // (keeps the loads alive; practically never taken)
+}
+
+}  // namespace fg
+
+// host-side launcher (called from fg_capi.cpp)
+extern "C" int fg_launch_calib(int mode, const uint8_t* d_src, uint8_t* d_dst, uint64_t nbytes, uint32_t* d_sink, hipStream_t stream) {
+    const uint64_t n16 = nbytes / 16;
+    if (n16 == 0) return 0;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+        return -1;
+    uint64_t blocks = (uint64_t)cus * 8u;  // 2048 threads per CU: every wave slot
+    const uint64_t need = (n16 + fg::kCalibThreads - 1) / fg::kCalibThreads;
+    if (blocks > need) blocks = need;
+    if (mode == 0)
+        hipLaunchKernelGGL(fg::k_calib_copy, dim3((uint32_t)blocks), dim3(fg::kCalibThreads), 0, stream, reinterpret_cast<const uint4*>(d_src),
+                           reinterpret_cast<uint4*>(d_dst), n16);
+    else
+        hipLaunchKernelGGL(fg::k_calib_read, dim3((uint32_t)blocks), dim3(fg::kCalibThreads), 0, stream, reinterpret_cast<const uint4*>(d_src), n16,
+                           d_sink);
+    return (int)hipGetLastError();
+}

@@ -5,229 +5,9 @@
 // It mirrors what XDecoder::new(&Config) + Box<dyn Decoder+Send>::clone do in the reference
 // (src/flowgger/mod.rs:413-422, src/flowgger/decoder/mod.rs:23-36): a ctx is built once from the
 // configuration and cloned per connection thread.
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <cstdlib>
-#include <cstring>
-#include <map>
-#include <new>
-#include <string>
-#include <vector>
-
-#include "../../include/fg_hip.h"
-#include "fg_device.hpp"
-#include "fg_enc_cfg.hpp"
-#include <time.h>
-
-#include "fg_rfc3164_parse.hpp"
-#include "fg_tz_index.hpp"
-
-namespace fg {
-// device view of input.ltsv_schema / input.ltsv_suffixes (must match fg_ltsv.hip)
-struct LtsvDevCfg {
-    uint32_t n_schema;
-    const uint8_t* blob;
-    const uint32_t* name_off;
-    const uint8_t* types;
-    uint32_t suf_off[4];
-    uint32_t suf_len[4];
-    uint32_t has_suf[4];
-};
-}  // namespace fg
-
-extern "C" int fg_launch_rfc5424(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
-                                 uint64_t avg_len, hipStream_t stream, uint64_t* stash, uint32_t stash_blocks, uint32_t strip,
-                                 const uint8_t* line_bad, const fg_launch_opts* lo);
-extern "C" uint64_t fg_stash_bytes(uint32_t blocks);
-extern "C" int fg_launch_rfc3164(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
-                                 const fg::r3164::Cfg* cfg, uint32_t tile_cap, hipStream_t stream, uint32_t strip,
-                                 const uint8_t* line_bad);
-extern "C" int fg_launch_encode_sizes(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
-                                      const fg::EncCfg* cfg, uint32_t tile_cap, uint32_t cfg_lds, uint32_t* d_sizes,
-                                      uint64_t* d_block_sums, uint8_t* d_status, uint64_t* d_out_offsets, hipStream_t stream);
-extern "C" int fg_launch_encode_count(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
-                                      const fg::EncCfg* cfg, uint32_t tile_cap, uint32_t cfg_lds, uint32_t* d_sizes,
-                                      uint64_t* d_block_sums, uint8_t* d_status, hipStream_t stream);
-extern "C" int fg_launch_encode_scan(const uint32_t* d_sizes, uint64_t* d_block_sums, uint64_t n, uint64_t* d_out_offsets, uint64_t base,
-                                     hipStream_t stream);
-extern "C" int fg_launch_encode_write(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
-                                      const fg::EncCfg* cfg, uint32_t tile_cap, uint32_t cfg_lds, const uint64_t* d_out_offsets,
-                                      uint8_t* d_out, hipStream_t stream);
-extern "C" uint64_t fg_frame_scratch_bytes(uint64_t nbytes);
-extern "C" int fg_launch_frame(const uint8_t* d_bytes, uint64_t nbytes, uint32_t delim, uint8_t* scratch, uint64_t* d_offsets,
-                               uint8_t* d_bad, uint64_t cap, uint64_t** d_total_out, hipStream_t stream);
-extern "C" uint64_t fg_frame_block_bytes(void);
-extern "C" int fg_launch_frame_slice(const uint8_t* d_bytes, uint64_t nbytes, uint32_t delim, uint8_t* scratch, uint64_t* d_offsets,
-                                     uint8_t* d_bad, uint64_t cap, uint64_t blk0, uint64_t blk1, uint64_t** d_total_out,
-                                     hipStream_t stream);
-extern "C" int fg_launch_ltsv(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
-                              const fg::LtsvDevCfg* cfg, uint64_t avg_len, hipStream_t stream, uint64_t* stash,
-                              uint32_t stash_blocks, uint32_t strip, const uint8_t* line_bad, const fg_launch_opts* lo);
-extern "C" int fg_launch_gelf(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
-                              uint64_t avg_len, hipStream_t stream, uint64_t* stash, uint32_t stash_blocks, uint32_t strip,
-                              const uint8_t* line_bad, const fg_launch_opts* lo);
-
-struct fg_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;  // the pipelined host paths (created on first use): uploads / second lane
-    hipStream_t stream3 = nullptr;  // ... downloads
-    std::vector<hipEvent_t> ev_slice;  // ... two events per slice: uploaded, decoded
-    hipStream_t s_up = nullptr, s_down = nullptr, s_run = nullptr;  // ... which of the three does what
-    hipEvent_t ev_ready = nullptr;
-    int last_hip = 0;
-    fg_launch_opts lo{};  // launch-geometry overrides (fg_set_launch_opts); all zero = the library's own choices
-    bool timing = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool ev_valid = false;
-    // LTSV configuration (owned copies)
-    std::vector<std::string> schema_names;
-    std::vector<uint8_t> schema_types;
-    std::string suffix[4];
-    bool has_suffix[4] = {false, false, false, false};
-    uint8_t* d_cfg = nullptr;  // device copy of the LTSV configuration (blob | name_off | types)
-    // per-wave scratch where entries (SD pairs / LTSV pairs / GELF extras) are parked between the
-    // parse and the copy into the entry table (allocated on the first decode; 8 waves on every CU)
-    uint64_t* d_stash = nullptr;
-    uint64_t* d_stash2 = nullptr;  // the second lane's (fg_transcode_batch)
-    uint32_t stash_blocks = 0;
-    uint32_t* d_pending = nullptr;  // ring of kPendingRing hand-over words (DevTables::pending), zeroed once
-    uint32_t epoch = 0;             // launch counter of this ctx
-    uint8_t* d_frame = nullptr;  // fg_frame_device scratch (delimiter / UTF-8 masks, block counts)
-    uint64_t d_frame_cap = 0;
-    uint8_t* d_bad = nullptr;    // fg_frame_decode_batch: per-frame UTF-8 verdicts
-    uint64_t d_bad_cap = 0;
-    uint64_t* h_off = nullptr;   // fg_frame_decode_batch: pinned host copy of the frame offsets
-    uint64_t h_off_cap = 0;
-    uint64_t* h_cnt = nullptr;   // ... pinned words the pipelined form reads the slices' frame counts through
-    double frames_per_byte = 1.0 / 200.0;  // ... what the last raw chunk held (sizes the next one's tables before its frames are counted)
-    // RFC3164 configuration: host copies (for fg_clone) + one device block [names | name_off | zone_first | utc_start | utc_off]
-    bool r3164_set = false;
-    bool r3164_auto_year = false;  // current_year == FG_YEAR_NOW: follow the wall clock like the reference (:179)
-    int32_t r3164_year = 1970;
-    std::vector<uint8_t*> retired_tz;  // zone blocks replaced at a year change (kernels may still read them; freed at destroy)
-    std::vector<std::string> tz_names;
-    std::vector<uint32_t> tz_first;
-    std::vector<int64_t> tz_start;
-    std::vector<int32_t> tz_off;
-    uint8_t* d_tz = nullptr;
-    fg::r3164::Cfg r3164{};
-    uint8_t* d_enc = nullptr;    // fg_encode_gelf_device: static key list + blob, then the per-line sizes
-    uint64_t d_enc_cap = 0;
-    // fg_encode_device_async: pinned ring the encoder configuration is uploaded from without a host sync
-    static constexpr uint32_t kEncRing = 4, kEncSlot = 16 * 1024;
-    uint8_t* h_enc_ring = nullptr;
-    hipEvent_t ev_enc[kEncRing] = {nullptr, nullptr, nullptr, nullptr};
-    uint32_t enc_ring_next = 0;
-    fg::LtsvDevCfg ltsv{};
-    // staging for fg_decode_batch
-    uint8_t* d_bytes = nullptr;
-    uint64_t d_bytes_cap = 0;
-    uint64_t* d_offsets = nullptr;
-    uint64_t d_offsets_cap = 0;
-    uint8_t* d_tab = nullptr;  // one device allocation carved into the table arrays
-    uint64_t d_tab_cap = 0;
-    uint8_t* h_tab = nullptr;  // pinned host mirror
-    uint64_t h_tab_cap = 0;
-    // fg_transcode_batch: device output (messages | out_offsets | enc_status) and its pinned host mirror
-    uint8_t* d_tout = nullptr;
-    uint64_t d_tout_cap = 0;
-    uint8_t* d_tmeta = nullptr;  // out_offsets[n + 1] then enc_status[n]
-    uint64_t d_tmeta_cap = 0;
-    uint8_t* h_tout = nullptr;   // pinned: messages | out_offsets | meta | enc_status
-    uint64_t h_tout_cap = 0;
-};
+#include "fg_ctx.hpp"
 
 namespace {
-
-struct DeviceGuard {
-    int prev = -1;
-    explicit DeviceGuard(int dev) {
-        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        if (prev != dev) (void)hipSetDevice(dev);
-    }
-    ~DeviceGuard() {
-        if (prev >= 0) (void)hipSetDevice(prev);
-    }
-};
-
-#define FG_HIP(ctx, call)                         \
-    do {                                          \
-        hipError_t e_ = (call);                   \
-        if (e_ != hipSuccess) {                   \
-            (ctx)->last_hip = (int)e_;            \
-            return FG_ERR_HIP;                    \
-        }                                         \
-    } while (0)
-
-inline uint64_t up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
-
-// carve `base` into the arrays of an fg_tables (256-byte aligned pieces)
-void carve(uint8_t* base, uint64_t n, uint64_t ent_cap, fg_tables* t, uint64_t* total) {
-    uint64_t sizes[FG_TABLE_ARRAYS];
-    fg_tables_layout(n, ent_cap, sizes);
-    uint64_t off = 0;
-    uint8_t* p[FG_TABLE_ARRAYS];
-    for (int k = 0; k < FG_TABLE_ARRAYS; ++k) {
-        p[k] = base ? base + off : nullptr;
-        off += up(sizes[k], 256);
-    }
-    if (total) *total = off;
-    if (!t) return;
-    t->n = n;
-    t->ent_cap = ent_cap;
-    t->meta = (uint32_t*)p[0];
-    t->ts = (double*)p[1];
-    t->hostname = (fg_span*)p[2];
-    t->appname = (fg_span*)p[3];
-    t->procid = (fg_span*)p[4];
-    t->msgid = (fg_span*)p[5];
-    t->msg = (fg_span*)p[6];
-    t->full_msg = (fg_span*)p[7];
-    t->ent_first = (uint32_t*)p[8];
-    t->ent_count = (uint32_t*)p[9];
-    t->ent_name = (fg_span*)p[10];
-    t->ent_val = (uint64_t*)p[11];
-    t->ent_type = (uint8_t*)p[12];
-    t->ent_flags = (uint8_t*)p[13];
-    t->ent_used = (uint64_t*)p[14];
-}
-
-fg::DevTables to_dev(const fg_tables& t) {
-    fg::DevTables d;
-    d.n = t.n;
-    d.ent_cap = t.ent_cap;
-    d.meta = t.meta;
-    d.ts = t.ts;
-    d.span[0] = t.hostname;
-    d.span[1] = t.appname;
-    d.span[2] = t.procid;
-    d.span[3] = t.msgid;
-    d.span[4] = t.msg;
-    d.span[5] = t.full_msg;
-    d.ent_first = t.ent_first;
-    d.ent_count = t.ent_count;
-    d.ent_name = t.ent_name;
-    d.ent_val = t.ent_val;
-    d.ent_type = t.ent_type;
-    d.ent_flags = t.ent_flags;
-    d.ent_used = (unsigned long long*)t.ent_used;
-    d.pending = nullptr;
-    d.epoch = 0;
-    return d;
-}
-
-// LDS tile per 64-line wave: room for 64 average lines + 12.5 % + 512 B, 4..56 KiB (the kernel
-// adds the space bitmap, 1/8 of the tile, on top).  fg_launch_opts::tile_cap overrides (bytes), for tuning.
-uint32_t pick_tile_cap(const fg_ctx* ctx, uint64_t nbytes, uint64_t n, uint64_t max_cap, uint32_t margin_16ths = 2) {
-    if (ctx->lo.tile_cap >= 1024 && ctx->lo.tile_cap <= max_cap) return (uint32_t)up(ctx->lo.tile_cap, 1024);
-    uint64_t avg = n ? (nbytes + n - 1) / n : 0;
-    uint64_t want = up(64 * avg * (16 + margin_16ths) / 16 + 512, 1024);
-    if (want < 4096) want = 4096;
-    if (want > max_cap) want = max_cap;
-    return (uint32_t)want;
-}
 
 const char* const kErr5424[] = {
     "",
@@ -305,28 +85,6 @@ int upload_ltsv_cfg(fg_ctx* ctx) {
     c.name_off = (const uint32_t*)(ctx->d_cfg + blob_sz);
     c.types = ctx->d_cfg + blob_sz + off_sz;
     ctx->ltsv = c;
-    return FG_OK;
-}
-
-int grow_dev(fg_ctx* ctx, void** p, uint64_t* cap, uint64_t need) {
-    if (need <= *cap) return FG_OK;
-    if (*p) FG_HIP(ctx, hipFree(*p));
-    *p = nullptr;
-    *cap = 0;
-    uint64_t want = up(need + need / 4, 1 << 20);
-    FG_HIP(ctx, hipMalloc(p, want));
-    *cap = want;
-    return FG_OK;
-}
-
-int grow_pinned(fg_ctx* ctx, void** p, uint64_t* cap, uint64_t need) {
-    if (need <= *cap) return FG_OK;
-    if (*p) FG_HIP(ctx, hipHostFree(*p));
-    *p = nullptr;
-    *cap = 0;
-    uint64_t want = up(need + need / 4, 1 << 20);
-    FG_HIP(ctx, hipHostMalloc(p, want, hipHostMallocDefault));
-    *cap = want;
     return FG_OK;
 }
 
@@ -477,6 +235,7 @@ void fg_destroy(fg_ctx* ctx) {
     if (ctx->d_stash) (void)hipFree(ctx->d_stash);
     if (ctx->d_stash2) (void)hipFree(ctx->d_stash2);
     if (ctx->d_pending) (void)hipFree(ctx->d_pending);
+    if (ctx->d_sink) (void)hipFree(ctx->d_sink);
     if (ctx->d_frame) (void)hipFree(ctx->d_frame);
     if (ctx->d_bad) (void)hipFree(ctx->d_bad);
     if (ctx->d_enc) (void)hipFree(ctx->d_enc);
@@ -532,6 +291,20 @@ int fg_last_kernel_ms(fg_ctx* ctx, float* ms) {
     return FG_OK;
 }
 
+int fg_calibrate_device(fg_ctx* ctx, int mode, const uint8_t* d_src, uint8_t* d_dst, uint64_t nbytes, void* stream) {
+    if (!ctx || !d_src || (mode != FG_CALIB_COPY && mode != FG_CALIB_READ) || (mode == FG_CALIB_COPY && !d_dst)) return FG_ERR_ARG;
+    if ((((uintptr_t)d_src) | ((uintptr_t)d_dst)) & 15u) return FG_ERR_ARG;
+    DeviceGuard g(ctx->device);
+    if (!ctx->d_sink) FG_HIP(ctx, hipMalloc((void**)&ctx->d_sink, 256));
+    hipStream_t s = stream == FG_STREAM_OWN ? ctx->stream : (hipStream_t)stream;
+    const int rc = fg_launch_calib(mode, d_src, d_dst, nbytes, ctx->d_sink, s);
+    if (rc != 0) {
+        ctx->last_hip = rc;
+        return FG_ERR_HIP;
+    }
+    return FG_OK;
+}
+
 int fg_decode_batch_device(fg_ctx* ctx, fg_format fmt, const uint8_t* d_bytes, uint64_t nbytes,
                            const uint64_t* d_offsets, uint64_t n, const fg_tables* tables, void* stream) {
     return fg_decode_frames_device(ctx, fmt, FG_FRAME_NONE, d_bytes, nbytes, d_offsets, n, nullptr, tables, stream);
@@ -570,21 +343,17 @@ int fg_frame_device(fg_ctx* ctx, fg_framing framing, const uint8_t* d_bytes, uin
     return FG_OK;
 }
 
-static int decode_frames_impl(fg_ctx* ctx, fg_format fmt, fg_framing framing, const uint8_t* d_bytes, uint64_t nbytes,
-                              const uint64_t* d_offsets, uint64_t n, const uint8_t* d_bad_utf8, const fg_tables* tables,
-                              void* stream, bool reset_counter, uint64_t span_bytes, uint32_t lane = 0);
-
 int fg_decode_frames_device(fg_ctx* ctx, fg_format fmt, fg_framing framing, const uint8_t* d_bytes, uint64_t nbytes,
                             const uint64_t* d_offsets, uint64_t n, const uint8_t* d_bad_utf8, const fg_tables* tables,
                             void* stream) {
-    return decode_frames_impl(ctx, fmt, framing, d_bytes, nbytes, d_offsets, n, d_bad_utf8, tables, stream, true, nbytes);
+    return fg_decode_frames_impl(ctx, fmt, framing, d_bytes, nbytes, d_offsets, n, d_bad_utf8, tables, stream, true, nbytes);
 }
 
 // reset_counter = false: a further slice of a batch whose entry counter is already live (the
 // pipelined host path decodes one batch as several slices on two streams).  span_bytes = the bytes
 // the n lines cover (the launch geometry is planned from the average line length; nbytes is only
 // the readable range of d_bytes and, for a slice, covers the whole batch).
-static int decode_frames_impl(fg_ctx* ctx, fg_format fmt, fg_framing framing, const uint8_t* d_bytes, uint64_t nbytes,
+int fg_decode_frames_impl(fg_ctx* ctx, fg_format fmt, fg_framing framing, const uint8_t* d_bytes, uint64_t nbytes,
                               const uint64_t* d_offsets, uint64_t n, const uint8_t* d_bad_utf8, const fg_tables* tables,
                               void* stream, bool reset_counter, uint64_t span_bytes, uint32_t lane) {
     if ((int)framing < 0 || (int)framing > 2) return FG_ERR_ARG;
@@ -655,865 +424,6 @@ static int decode_frames_impl(fg_ctx* ctx, fg_format fmt, fg_framing framing, co
     return FG_OK;
 }
 
-int fg_alloc_pinned(uint64_t bytes, void** out) {
-    if (!out) return FG_ERR_ARG;
-    *out = nullptr;
-    return hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? FG_OK : FG_ERR_HIP;
-}
-void fg_free_pinned(void* p) {
-    if (p) (void)hipHostFree(p);
-}
-
-// Streams and events of the pipelined host paths (created on first use): uploads (stream2), kernels (stream3) and downloads (the
-// ctx's FIRST stream) each get their own stream, chained by events per slice.  Which stream carries which direction matters on
-// this platform (tools/probe/stream_pairs.cpp, MI355X / ROCm 7.2): an H2D and a D2H copy run at the same time -- 97 GB/s for
-// the two together -- only when one of the two streams is the first one created; any other pair shares a copy path and the two
-// directions take turns (57 GB/s for both together).  fg_measure_link measures on exactly these streams.
-// Chained by events per slice -- H2D copies run back to back on one stream (nothing else is ever queued between two of
-// them), D2H copies on another, and the link carries both directions at once.  (Round 2 alternated whole slices -- H2D, kernel,
-// D2H -- between two streams: measured, that gave the rate of NO overlap at all, 42 of 57 GB/s.)
-static int ensure_pipeline(fg_ctx* ctx, uint32_t slices) {
-    if (!ctx->stream2) {
-        FG_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-        FG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming));
-    }
-    if (!ctx->stream3) FG_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
-    while (ctx->ev_slice.size() < 2ull * slices) {
-        hipEvent_t e = nullptr;
-        FG_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        ctx->ev_slice.push_back(e);
-    }
-    if (!ctx->s_up) {
-        // The runtime binds its copy paths to streams as they FIRST copy, and which stream went first decides whether the uploads
-        // and downloads below overlap (measured, tools/probe/stream_pairs.cpp and four orderings of this code: with the ctx's own
-        // stream first, fg_decode_batch runs at 198 M lines/s; with stream2 / stream3 first, at 160 M).  So the ctx's own stream
-        // copies a few bytes each way before the other two are ever used.
-        uint64_t probe = 0;
-        uint64_t* d_probe = nullptr;
-        FG_HIP(ctx, hipMalloc((void**)&d_probe, 8));
-        (void)hipMemcpyAsync(d_probe, &probe, 8, hipMemcpyHostToDevice, ctx->stream);
-        (void)hipMemcpyAsync(&probe, d_probe, 8, hipMemcpyDeviceToHost, ctx->stream);
-        (void)hipStreamSynchronize(ctx->stream);
-        (void)hipFree(d_probe);
-    }
-    ctx->s_up = ctx->stream2;
-    ctx->s_run = ctx->stream;
-    ctx->s_down = ctx->stream3;
-    return FG_OK;
-}
-// slices of a host batch: small enough that filling and draining the pipeline costs little (1/8 of the batch at most), large
-// enough that a slice's fourteen API calls stay far below its transfer time
-static uint32_t slice_count(uint64_t nbytes, uint64_t n) {
-    if (nbytes < (32ull << 20)) return 1;  // small batches: one stream, no events (a batch of one line costs what it did)
-    uint64_t slice = nbytes / 8;
-    if (slice < (8ull << 20)) slice = 8ull << 20;
-    if (slice > (32ull << 20)) slice = 32ull << 20;
-    uint64_t k = (nbytes + slice - 1) / slice;
-    if (k < 1) k = 1;
-    if (k > 256) k = 256;
-    if (n < k) k = n ? n : 1;
-    return (uint32_t)k;
-}
-
-int fg_measure_link(fg_ctx* ctx, uint64_t nbytes, double gbps[3]) {
-    if (!ctx || !gbps || nbytes < 4096) return FG_ERR_ARG;
-    DeviceGuard g(ctx->device);
-    {   // on the very streams the pipelined host paths copy on: uploads on stream2, downloads on the ctx's first stream
-        const int prc = ensure_pipeline(ctx, 1);
-        if (prc != FG_OK) return prc;
-    }
-    const hipStream_t s_up = ctx->s_up, s_down = ctx->s_down;
-    uint8_t *h0 = nullptr, *h1 = nullptr, *d0 = nullptr, *d1 = nullptr;
-    hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
-    int rc = FG_OK;
-    auto fail = [&](hipError_t err) {
-        if (err != hipSuccess && rc == FG_OK) {
-            ctx->last_hip = (int)err;
-            rc = FG_ERR_HIP;
-        }
-        return err != hipSuccess;
-    };
-    do {
-        if (fail(hipHostMalloc((void**)&h0, nbytes, hipHostMallocDefault)) || fail(hipHostMalloc((void**)&h1, nbytes, hipHostMallocDefault))) break;
-        if (fail(hipMalloc((void**)&d0, nbytes)) || fail(hipMalloc((void**)&d1, nbytes))) break;
-        memset(h0, 0x5A, nbytes);  // (touch the pages: first use must not be part of the figure)
-        memset(h1, 0, nbytes);
-        bool bad = false;
-        for (auto& ev : e) bad = bad || fail(hipEventCreate(&ev));
-        if (bad) break;
-        double best[3] = {0, 0, 0};
-        for (int rep = 0; rep < 4 && rc == FG_OK; ++rep) {  // (rep 0 warms the path up)
-            float ms = 0.f;
-            // host -> device
-            if (fail(hipEventRecord(e[0], s_up)) || fail(hipMemcpyAsync(d0, h0, nbytes, hipMemcpyHostToDevice, s_up)) ||
-                fail(hipEventRecord(e[1], s_up)) || fail(hipEventSynchronize(e[1])) || fail(hipEventElapsedTime(&ms, e[0], e[1])))
-                break;
-            if (rep && ms > 0.f) best[0] = std::max(best[0], (double)nbytes / (ms * 1e-3) / 1e9);
-            // device -> host
-            if (fail(hipEventRecord(e[0], s_down)) || fail(hipMemcpyAsync(h1, d1, nbytes, hipMemcpyDeviceToHost, s_down)) ||
-                fail(hipEventRecord(e[1], s_down)) || fail(hipEventSynchronize(e[1])) || fail(hipEventElapsedTime(&ms, e[0], e[1])))
-                break;
-            if (rep && ms > 0.f) best[1] = std::max(best[1], (double)nbytes / (ms * 1e-3) / 1e9);
-            // both at once: the slower stream bounds the pair (wall clock around both)
-            if (fail(hipStreamSynchronize(s_up)) || fail(hipStreamSynchronize(s_down))) break;
-            timespec a, b;
-            clock_gettime(CLOCK_MONOTONIC, &a);
-            if (fail(hipMemcpyAsync(d0, h0, nbytes, hipMemcpyHostToDevice, s_up)) ||
-                fail(hipMemcpyAsync(h1, d1, nbytes, hipMemcpyDeviceToHost, s_down)) || fail(hipStreamSynchronize(s_up)) ||
-                fail(hipStreamSynchronize(s_down)))
-                break;
-            clock_gettime(CLOCK_MONOTONIC, &b);
-            const double s = (double)(b.tv_sec - a.tv_sec) + (double)(b.tv_nsec - a.tv_nsec) * 1e-9;
-            if (rep && s > 0) best[2] = std::max(best[2], 2.0 * (double)nbytes / s / 1e9);
-        }
-        for (int k = 0; k < 3; ++k) gbps[k] = best[k];
-    } while (false);
-    for (auto& ev : e)
-        if (ev) (void)hipEventDestroy(ev);
-    if (d0) (void)hipFree(d0);
-    if (d1) (void)hipFree(d1);
-    if (h0) (void)hipHostFree(h0);
-    if (h1) (void)hipHostFree(h1);
-    return rc;
-}
-
-int fg_decode_batch(fg_ctx* ctx, fg_format fmt, const uint8_t* bytes, uint64_t nbytes, const uint64_t* offsets,
-                    uint64_t n, fg_tables* out) {
-    if (!ctx || !out || (n && !offsets) || (nbytes && !bytes)) return FG_ERR_ARG;
-    if (n && (offsets[n] > nbytes || offsets[0] > offsets[n])) return FG_ERR_ARG;
-    DeviceGuard g(ctx->device);
-    int rc;
-    const uint32_t slices = slice_count(nbytes, n);
-    if (slices > 1 && (rc = ensure_pipeline(ctx, slices)) != FG_OK) return rc;  // (a small batch stays on the ctx's own stream)
-    if (slices > 1 && !ctx->h_cnt) FG_HIP(ctx, hipHostMalloc((void**)&ctx->h_cnt, 65536, hipHostMallocDefault));
-    if ((rc = grow_dev(ctx, (void**)&ctx->d_bytes, &ctx->d_bytes_cap, up(nbytes, 16) + 16)) != FG_OK) return rc;
-    if ((rc = grow_dev(ctx, (void**)&ctx->d_offsets, &ctx->d_offsets_cap, (n + 1) * 8)) != FG_OK) return rc;
-    std::vector<uint64_t> cut(slices + 1);
-    if (fg_shard_plan(offsets, n, slices, cut.data()) != FG_OK) return FG_ERR_ARG;
-    const bool piped = slices > 1;
-    const hipStream_t s_down = piped ? ctx->s_down : ctx->stream, s_up = piped ? ctx->s_up : s_down, s_run = piped ? ctx->s_run : s_down;
-    auto drain = [&]() {
-        (void)hipStreamSynchronize(s_up);
-        (void)hipStreamSynchronize(s_run);
-        (void)hipStreamSynchronize(s_down);
-    };
-    // entry capacity: start from one entry per 16 (RFC5424) / 8 input bytes, grow on overflow
-    uint64_t ent_cap = fmt == FG_RFC5424 ? nbytes / 16 + 1024 : nbytes / 8 + 1024;
-    if (fmt == FG_RFC3164) ent_cap = 16;  // RFC3164 produces no entries
-    for (;;) {
-        if (ent_cap > 0xFFFFFFF0ull) ent_cap = 0xFFFFFFF0ull;
-        uint64_t total = 0;
-        carve(nullptr, n, ent_cap, nullptr, &total);
-        if ((rc = grow_dev(ctx, (void**)&ctx->d_tab, &ctx->d_tab_cap, total)) != FG_OK) return rc;
-        if ((rc = grow_pinned(ctx, (void**)&ctx->h_tab, &ctx->h_tab_cap, total)) != FG_OK) return rc;
-        fg_tables dt, ht;
-        carve(ctx->d_tab, n, ent_cap, &dt, nullptr);
-        carve(ctx->h_tab, n, ent_cap, &ht, nullptr);
-        FG_HIP(ctx, hipMemsetAsync(dt.ent_used, 0, 8, s_run));
-        // Rows land at their final position, entries share one counter: the result is the same as one monolithic launch.
-        // A slice is ISSUED (upload, kernels, the entry counter's value after it into a pinned word) and later COLLECTED (its rows and
-        // the entries its kernels appended -- the range between two counter values -- come back on the download stream).  The host
-        // issues sixteen slices ahead of the one it collects, so the link has uploads queued at all times and every table, the
-        // entry columns included, crosses it while later slices are still going up.
-        uint64_t* const ent_cnt = piped ? ctx->h_cnt + 1024 : nullptr;
-        fg_span* hs[6] = {ht.hostname, ht.appname, ht.procid, ht.msgid, ht.msg, ht.full_msg};
-        fg_span* ds[6] = {dt.hostname, dt.appname, dt.procid, dt.msgid, dt.msg, dt.full_msg};
-        auto issue = [&](uint32_t k) -> int {
-            const uint64_t l0 = cut[k], l1 = cut[k + 1], rows = l1 - l0;
-            if (rows == 0) return FG_OK;
-            // ---- upload: the slice's offsets (the first slice also takes offsets[0]) and its bytes, copied on 16-byte boundaries
-            //      (the neighbouring bytes are the same data)
-            const uint64_t o0 = k == 0 ? l0 : l0 + 1;
-            FG_HIP(ctx, hipMemcpyAsync(ctx->d_offsets + o0, offsets + o0, (l1 + 1 - o0) * 8, hipMemcpyHostToDevice, s_up));
-            const uint64_t b0 = offsets[l0] & ~15ull, b1 = offsets[l1];
-            if (b1 > b0) FG_HIP(ctx, hipMemcpyAsync(ctx->d_bytes + b0, bytes + b0, b1 - b0, hipMemcpyHostToDevice, s_up));
-            if (piped) {
-                FG_HIP(ctx, hipEventRecord(ctx->ev_slice[2 * k], s_up));
-                FG_HIP(ctx, hipStreamWaitEvent(s_run, ctx->ev_slice[2 * k], 0));
-            }
-            // ---- decode
-            fg_tables sl = dt;  // the slice's rows: same arrays, shifted by l0
-            sl.n = rows;
-            sl.meta += l0;
-            sl.ts += l0;
-            sl.hostname += l0;
-            sl.appname += l0;
-            sl.procid += l0;
-            sl.msgid += l0;
-            sl.msg += l0;
-            sl.full_msg += l0;
-            sl.ent_first += l0;
-            sl.ent_count += l0;
-            const int drc = decode_frames_impl(ctx, fmt, FG_FRAME_NONE, ctx->d_bytes, nbytes, ctx->d_offsets + l0, rows, nullptr, &sl, (void*)s_run, false,
-                                               offsets[l1] - offsets[l0]);
-            if (drc != FG_OK) return drc;
-            if (piped) {
-                FG_HIP(ctx, hipMemcpyAsync(ent_cnt + k, dt.ent_used, 8, hipMemcpyDeviceToHost, s_run));
-                FG_HIP(ctx, hipEventRecord(ctx->ev_slice[2 * k + 1], s_run));
-            }
-            return FG_OK;
-        };
-        auto download_rows = [&](uint64_t l0, uint64_t rows) -> int {
-            FG_HIP(ctx, hipMemcpyAsync(ht.meta + l0, dt.meta + l0, rows * 4, hipMemcpyDeviceToHost, s_down));
-            FG_HIP(ctx, hipMemcpyAsync(ht.ts + l0, dt.ts + l0, rows * 8, hipMemcpyDeviceToHost, s_down));
-            for (int j = 0; j < 6; ++j) FG_HIP(ctx, hipMemcpyAsync(hs[j] + l0, ds[j] + l0, rows * 8, hipMemcpyDeviceToHost, s_down));
-            FG_HIP(ctx, hipMemcpyAsync(ht.ent_first + l0, dt.ent_first + l0, rows * 4, hipMemcpyDeviceToHost, s_down));
-            FG_HIP(ctx, hipMemcpyAsync(ht.ent_count + l0, dt.ent_count + l0, rows * 4, hipMemcpyDeviceToHost, s_down));
-            return FG_OK;
-        };
-        auto download_entries = [&](uint64_t e0, uint64_t e1) -> int {
-            if (e1 <= e0) return FG_OK;
-            FG_HIP(ctx, hipMemcpyAsync(ht.ent_name + e0, dt.ent_name + e0, (e1 - e0) * 8, hipMemcpyDeviceToHost, s_down));
-            FG_HIP(ctx, hipMemcpyAsync(ht.ent_val + e0, dt.ent_val + e0, (e1 - e0) * 8, hipMemcpyDeviceToHost, s_down));
-            FG_HIP(ctx, hipMemcpyAsync(ht.ent_type + e0, dt.ent_type + e0, e1 - e0, hipMemcpyDeviceToHost, s_down));
-            FG_HIP(ctx, hipMemcpyAsync(ht.ent_flags + e0, dt.ent_flags + e0, e1 - e0, hipMemcpyDeviceToHost, s_down));
-            return FG_OK;
-        };
-        uint64_t used = 0;
-        bool overflow = false;
-        uint32_t issued = 0;
-        for (uint32_t k = 0; k < slices && n; ++k) {
-            while (issued < slices && issued < k + 16) {
-                if ((rc = issue(issued)) != FG_OK) {  // copies of earlier slices may still be in flight into h_tab / d_tab
-                    drain();
-                    return rc;
-                }
-                ++issued;
-            }
-            const uint64_t l0 = cut[k], rows = cut[k + 1] - l0;
-            if (rows == 0) continue;
-            if (piped) {
-                if (hipEventSynchronize(ctx->ev_slice[2 * k + 1]) != hipSuccess) {
-                    drain();
-                    return FG_ERR_HIP;
-                }
-                const uint64_t cnt = ent_cnt[k];  // the counter after this slice's kernels: its entries are [used, cnt)
-                if (cnt > ent_cap) {
-                    overflow = true;
-                    break;
-                }
-                if ((rc = download_rows(l0, rows)) != FG_OK || (rc = download_entries(used, cnt)) != FG_OK) {
-                    drain();
-                    return rc;
-                }
-                used = cnt;
-            } else if ((rc = download_rows(l0, rows)) != FG_OK) {
-                drain();
-                return rc;
-            }
-        }
-        if (!piped || overflow) {  // one stream (a small batch), or the entry table ran out: the counter's final value
-            while (overflow && issued < slices) {  // (kernels past the capacity still count: the counter then says what the batch needs)
-                if ((rc = issue(issued)) != FG_OK) {
-                    drain();
-                    return rc;
-                }
-                ++issued;
-            }
-            if (overflow) drain();
-            FG_HIP(ctx, hipMemcpyAsync(&used, dt.ent_used, 8, hipMemcpyDeviceToHost, s_run));
-            FG_HIP(ctx, hipStreamSynchronize(s_run));
-            overflow = used > ent_cap;
-        }
-        if (overflow) {
-            drain();
-            if (ent_cap >= 0xFFFFFFF0ull) return FG_ERR_ENT_OVERFLOW;
-            ent_cap = used + used / 8 + 1024;
-            continue;
-        }
-        if (!piped && (rc = download_entries(0, used)) != FG_OK) {
-            drain();
-            return rc;
-        }
-        *ht.ent_used = used;
-        FG_HIP(ctx, hipStreamSynchronize(s_down));
-        FG_HIP(ctx, hipStreamSynchronize(s_run));
-        *out = ht;
-        return FG_OK;
-    }
-}
-
-static int frame_stage(fg_ctx* ctx, fg_framing framing, uint64_t nbytes, int final, uint64_t* n_frames, uint64_t* consumed);
-
-static int frame_decode_one_piece(fg_ctx* ctx, fg_format fmt, fg_framing framing, const uint8_t* bytes, uint64_t nbytes, int final,
-                                  fg_tables* out, const uint64_t** out_offsets, uint64_t* n_frames, uint64_t* consumed) {
-    if (!ctx || !out || !out_offsets || !n_frames || !consumed || (nbytes && !bytes)) return FG_ERR_ARG;
-    if (framing != FG_FRAME_LINE && framing != FG_FRAME_NUL) return FG_ERR_UNSUPPORTED;
-    *n_frames = 0;
-    *consumed = 0;
-    *out_offsets = nullptr;
-    if (nbytes == 0) return FG_OK;
-    DeviceGuard g(ctx->device);
-    hipStream_t s = ctx->stream;
-    int rc;
-    if ((rc = grow_dev(ctx, (void**)&ctx->d_bytes, &ctx->d_bytes_cap, up(nbytes, 16) + 16)) != FG_OK) return rc;
-    FG_HIP(ctx, hipMemcpyAsync(ctx->d_bytes, bytes, nbytes, hipMemcpyHostToDevice, s));
-    FG_HIP(ctx, hipMemsetAsync(ctx->d_bytes + nbytes, 0, up(nbytes, 16) + 16 - nbytes, s));
-    // 1. frame: offsets + UTF-8 verdicts
-    uint64_t n = 0;
-    if ((rc = frame_stage(ctx, framing, nbytes, final, &n, consumed)) != FG_OK) return rc;
-    *n_frames = n;
-    if (n && nbytes >= (1u << 20)) ctx->frames_per_byte = (double)n / (double)nbytes;
-    if ((n + 1) * 8 > ctx->h_off_cap) {
-        if (ctx->h_off) FG_HIP(ctx, hipHostFree(ctx->h_off));
-        ctx->h_off = nullptr;
-        ctx->h_off_cap = 0;
-        uint64_t want = up((n + 1) * 8 + (n + 1) * 2, 1 << 16);
-        FG_HIP(ctx, hipHostMalloc((void**)&ctx->h_off, want, hipHostMallocDefault));
-        ctx->h_off_cap = want;
-    }
-    FG_HIP(ctx, hipMemcpyAsync(ctx->h_off, ctx->d_offsets, (n + 1) * 8, hipMemcpyDeviceToHost, s));
-    *out_offsets = ctx->h_off;
-    if (n == 0) {
-        FG_HIP(ctx, hipStreamSynchronize(s));
-        fg_tables empty{};
-        *out = empty;
-        return FG_OK;
-    }
-    // 2. decode the frames in place (terminators stripped in-kernel, invalid UTF-8 -> FG_ST_BAD_UTF8)
-    const uint64_t used_bytes = *consumed;
-    uint64_t ent_cap = fmt == FG_RFC5424 ? used_bytes / 16 + 1024 : used_bytes / 8 + 1024;
-    for (;;) {
-        if (ent_cap > 0xFFFFFFF0ull) ent_cap = 0xFFFFFFF0ull;
-        uint64_t bytes_total = 0;
-        carve(nullptr, n, ent_cap, nullptr, &bytes_total);
-        if ((rc = grow_dev(ctx, (void**)&ctx->d_tab, &ctx->d_tab_cap, bytes_total)) != FG_OK) return rc;
-        if (bytes_total > ctx->h_tab_cap) {
-            if (ctx->h_tab) FG_HIP(ctx, hipHostFree(ctx->h_tab));
-            ctx->h_tab = nullptr;
-            ctx->h_tab_cap = 0;
-            uint64_t want = up(bytes_total + bytes_total / 4, 1 << 20);
-            FG_HIP(ctx, hipHostMalloc((void**)&ctx->h_tab, want, hipHostMallocDefault));
-            ctx->h_tab_cap = want;
-        }
-        fg_tables dt, ht;
-        carve(ctx->d_tab, n, ent_cap, &dt, nullptr);
-        carve(ctx->h_tab, n, ent_cap, &ht, nullptr);
-        rc = fg_decode_frames_device(ctx, fmt, framing, ctx->d_bytes, used_bytes, ctx->d_offsets, n, ctx->d_bad, &dt, FG_STREAM_OWN);
-        if (rc != FG_OK) return rc;
-        uint64_t used = 0;
-        FG_HIP(ctx, hipMemcpyAsync(&used, dt.ent_used, 8, hipMemcpyDeviceToHost, s));
-        FG_HIP(ctx, hipStreamSynchronize(s));
-        if (used > ent_cap) {
-            if (ent_cap >= 0xFFFFFFF0ull) return FG_ERR_ENT_OVERFLOW;
-            ent_cap = used + used / 8 + 1024;
-            continue;
-        }
-        uint64_t sizes[FG_TABLE_ARRAYS];
-        fg_tables_layout(n, used, sizes);
-        void* dsts[FG_TABLE_ARRAYS] = {ht.meta, ht.ts, ht.hostname, ht.appname, ht.procid, ht.msgid, ht.msg, ht.full_msg,
-                                       ht.ent_first, ht.ent_count, ht.ent_name, ht.ent_val, ht.ent_type, ht.ent_flags, ht.ent_used};
-        void* srcs[FG_TABLE_ARRAYS] = {dt.meta, dt.ts, dt.hostname, dt.appname, dt.procid, dt.msgid, dt.msg, dt.full_msg,
-                                       dt.ent_first, dt.ent_count, dt.ent_name, dt.ent_val, dt.ent_type, dt.ent_flags, dt.ent_used};
-        for (int k = 0; k < FG_TABLE_ARRAYS; ++k)
-            if (sizes[k]) FG_HIP(ctx, hipMemcpyAsync(dsts[k], srcs[k], sizes[k], hipMemcpyDeviceToHost, s));
-        FG_HIP(ctx, hipStreamSynchronize(s));
-        *out = ht;
-        return FG_OK;
-    }
-}
-
-// fg_frame_decode_batch for a LARGE raw chunk: the chunk crosses the link in slices (multiples of the framing kernels' 16 KiB
-// block) on the upload stream; as soon as a slice is there it is framed (delimiter ranks continue where the slice before stopped),
-// its frame count comes back to the host through a pinned word, the frames that END in it are decoded, and their rows + offsets go
-// back on the download stream -- all while the next slices are still on the link.  The host never frames, never uploads offsets.
-// Tables are sized from what the ctx's last chunk held; a chunk that outgrows the estimate (or the entry table) returns
-// FG_ERR_UNSUPPORTED and takes the one-piece path, which counts first.
-static int frame_decode_sliced(fg_ctx* ctx, fg_format fmt, fg_framing framing, const uint8_t* bytes, uint64_t nbytes, int final,
-                               fg_tables* out, const uint64_t** out_offsets, uint64_t* n_frames, uint64_t* consumed) {
-    int rc;
-    const uint64_t blk = fg_frame_block_bytes();
-    uint64_t slice = nbytes / 8;
-    if (slice < (8ull << 20)) slice = 8ull << 20;
-    if (slice > (32ull << 20)) slice = 32ull << 20;
-    slice = slice / blk * blk;
-    const uint32_t slices = (uint32_t)((nbytes + slice - 1) / slice);
-    const uint64_t nblk_total = nbytes / blk + 1;
-    if ((rc = ensure_pipeline(ctx, slices)) != FG_OK) return rc;
-    const hipStream_t s_up = ctx->s_up, s_run = ctx->s_run, s_down = ctx->s_down;
-    auto drain = [&]() {
-        (void)hipStreamSynchronize(s_up);
-        (void)hipStreamSynchronize(s_run);
-        (void)hipStreamSynchronize(s_down);
-    };
-    // capacities from the ctx's experience: frames, rows, entries
-    const uint64_t cap = (uint64_t)((double)nbytes * ctx->frames_per_byte * 1.25) + 4096;
-    const uint64_t ent_cap0 = fmt == FG_RFC3164 ? 16 : fmt == FG_RFC5424 ? nbytes / 16 + 1024 : nbytes / 8 + 1024;
-    const uint64_t ent_cap = ent_cap0 > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : ent_cap0;
-    if ((rc = grow_dev(ctx, (void**)&ctx->d_bytes, &ctx->d_bytes_cap, up(nbytes, 16) + 16)) != FG_OK) return rc;
-    if ((rc = grow_dev(ctx, (void**)&ctx->d_offsets, &ctx->d_offsets_cap, (cap + 2) * 8)) != FG_OK) return rc;
-    if ((rc = grow_dev(ctx, (void**)&ctx->d_bad, &ctx->d_bad_cap, cap + 1)) != FG_OK) return rc;
-    if ((rc = grow_dev(ctx, (void**)&ctx->d_frame, &ctx->d_frame_cap, fg_frame_scratch_bytes(nbytes))) != FG_OK) return rc;
-    if ((rc = grow_pinned(ctx, (void**)&ctx->h_off, &ctx->h_off_cap, (cap + 2) * 8)) != FG_OK) return rc;
-    if (!ctx->h_cnt) FG_HIP(ctx, hipHostMalloc((void**)&ctx->h_cnt, 65536, hipHostMallocDefault));
-    if (slices + 2 > 4096) return FG_ERR_UNSUPPORTED;  // (h_cnt: frame counts in the first half, entry counters in the second)
-    uint64_t tab_bytes = 0;
-    carve(nullptr, cap, ent_cap, nullptr, &tab_bytes);
-    if ((rc = grow_dev(ctx, (void**)&ctx->d_tab, &ctx->d_tab_cap, tab_bytes)) != FG_OK) return rc;
-    if ((rc = grow_pinned(ctx, (void**)&ctx->h_tab, &ctx->h_tab_cap, tab_bytes)) != FG_OK) return rc;
-    fg_tables dt, ht;
-    carve(ctx->d_tab, cap, ent_cap, &dt, nullptr);
-    carve(ctx->h_tab, cap, ent_cap, &ht, nullptr);
-    FG_HIP(ctx, hipMemsetAsync(dt.ent_used, 0, 8, s_run));
-    FG_HIP(ctx, hipMemsetAsync(ctx->d_bad, 0, cap + 1, s_run));
-    const uint32_t delim = framing == FG_FRAME_LINE ? 0x0Au : 0x00u;
-    std::vector<hipEvent_t>& ev = ctx->ev_slice;
-    // every upload is queued NOW (they depend on nothing): the link never waits for the host
-    for (uint32_t k = 0; k < slices; ++k) {
-        const uint64_t b0 = (uint64_t)k * slice, b1 = k + 1 == slices ? nbytes : b0 + slice;
-        FG_HIP(ctx, hipMemcpyAsync(ctx->d_bytes + b0, bytes + b0, b1 - b0, hipMemcpyHostToDevice, s_up));
-        if (k + 1 == slices) FG_HIP(ctx, hipMemsetAsync(ctx->d_bytes + nbytes, 0, up(nbytes, 16) + 16 - nbytes, s_up));
-        FG_HIP(ctx, hipEventRecord(ev[2 * k], s_up));
-    }
-    // frame slice k once it is there, bring its cumulative frame count back (all asynchronous)
-    auto enqueue = [&](uint32_t k) -> int {
-        const uint64_t b0 = (uint64_t)k * slice, b1 = k + 1 == slices ? nbytes : b0 + slice;
-        FG_HIP(ctx, hipStreamWaitEvent(s_run, ev[2 * k], 0));
-        uint64_t* d_total = nullptr;
-        const uint64_t blk0 = b0 / blk, blk1 = k + 1 == slices ? nblk_total : b1 / blk;
-        const int lrc = fg_launch_frame_slice(ctx->d_bytes, nbytes, delim, ctx->d_frame, ctx->d_offsets, ctx->d_bad, cap, blk0, blk1, &d_total, s_run);
-        if (lrc != 0) {
-            ctx->last_hip = lrc;
-            return FG_ERR_HIP;
-        }
-        FG_HIP(ctx, hipMemcpyAsync(ctx->h_cnt + k, d_total, 8, hipMemcpyDeviceToHost, s_run));
-        FG_HIP(ctx, hipEventRecord(ev[2 * k + 1], s_run));
-        return FG_OK;
-    };
-    uint64_t done = 0;  // frames decoded so far
-    // The entry columns come back per slice as well: after a slice's decode the entry counter goes into a pinned word, and two
-    // iterations later -- the frame-count event the host waits for then was queued behind it -- the entries between two counter
-    // values are copied on the download stream, while later slices are still on the link.  RFC5424 only: measured (profiles/
-    // r03y_e2e_*.json, 4 M lines per call) the structured-data corpus goes from 63 to 90 M lines/s with it, while the GELF and LTSV
-    // corpora got SLOWER on this path (78 -> 46, 108 -> 87 M lines/s; not understood yet) -- their entries come back at the end.
-    const bool early = fmt == FG_RFC5424;
-    uint64_t* const ent_cnt = ctx->h_cnt + 4096;
-    uint64_t ent_done = 0;
-    auto count_entries = [&](uint32_t k) -> int {
-        if (early) FG_HIP(ctx, hipMemcpyAsync(ent_cnt + k, dt.ent_used, 8, hipMemcpyDeviceToHost, s_run));
-        return FG_OK;
-    };
-    auto download_entries = [&](uint64_t e1) -> int {  // entries [ent_done, e1)
-        if (e1 <= ent_done) return FG_OK;
-        const uint64_t e0 = ent_done, m = e1 - e0;
-        FG_HIP(ctx, hipMemcpyAsync(ht.ent_name + e0, dt.ent_name + e0, m * 8, hipMemcpyDeviceToHost, s_down));
-        FG_HIP(ctx, hipMemcpyAsync(ht.ent_val + e0, dt.ent_val + e0, m * 8, hipMemcpyDeviceToHost, s_down));
-        FG_HIP(ctx, hipMemcpyAsync(ht.ent_type + e0, dt.ent_type + e0, m, hipMemcpyDeviceToHost, s_down));
-        FG_HIP(ctx, hipMemcpyAsync(ht.ent_flags + e0, dt.ent_flags + e0, m, hipMemcpyDeviceToHost, s_down));
-        ent_done = e1;
-        return FG_OK;
-    };
-    auto decode_rows = [&](uint64_t f0, uint64_t f1, uint64_t span_bytes) -> int {  // frames [f0, f1): decode + download
-        if (f1 == f0) return FG_OK;
-        const uint64_t rows = f1 - f0;
-        fg_tables sl = dt;
-        sl.n = rows;
-        sl.meta += f0; sl.ts += f0; sl.hostname += f0; sl.appname += f0; sl.procid += f0; sl.msgid += f0; sl.msg += f0; sl.full_msg += f0;
-        sl.ent_first += f0; sl.ent_count += f0;
-        int r = decode_frames_impl(ctx, fmt, framing, ctx->d_bytes, nbytes, ctx->d_offsets + f0, rows, ctx->d_bad + f0, &sl, (void*)s_run, false, span_bytes);
-        if (r != FG_OK) return r;
-        FG_HIP(ctx, hipEventRecord(ctx->ev_ready, s_run));
-        FG_HIP(ctx, hipStreamWaitEvent(s_down, ctx->ev_ready, 0));
-        FG_HIP(ctx, hipMemcpyAsync(ctx->h_off + f0 + (f0 ? 1 : 0), ctx->d_offsets + f0 + (f0 ? 1 : 0), (rows + (f0 ? 0 : 1)) * 8, hipMemcpyDeviceToHost, s_down));
-        FG_HIP(ctx, hipMemcpyAsync(ht.meta + f0, dt.meta + f0, rows * 4, hipMemcpyDeviceToHost, s_down));
-        FG_HIP(ctx, hipMemcpyAsync(ht.ts + f0, dt.ts + f0, rows * 8, hipMemcpyDeviceToHost, s_down));
-        fg_span* hs[6] = {ht.hostname, ht.appname, ht.procid, ht.msgid, ht.msg, ht.full_msg};
-        fg_span* ds[6] = {dt.hostname, dt.appname, dt.procid, dt.msgid, dt.msg, dt.full_msg};
-        for (int j = 0; j < 6; ++j) FG_HIP(ctx, hipMemcpyAsync(hs[j] + f0, ds[j] + f0, rows * 8, hipMemcpyDeviceToHost, s_down));
-        FG_HIP(ctx, hipMemcpyAsync(ht.ent_first + f0, dt.ent_first + f0, rows * 4, hipMemcpyDeviceToHost, s_down));
-        FG_HIP(ctx, hipMemcpyAsync(ht.ent_count + f0, dt.ent_count + f0, rows * 4, hipMemcpyDeviceToHost, s_down));
-        return FG_OK;
-    };
-    if ((rc = enqueue(0)) != FG_OK) {
-        drain();
-        return rc;
-    }
-    for (uint32_t k = 0; k < slices; ++k) {
-        if (k + 1 < slices && (rc = enqueue(k + 1)) != FG_OK) {
-            drain();
-            return rc;
-        }
-        FG_HIP(ctx, hipEventSynchronize(ev[2 * k + 1]));
-        const uint64_t total = ctx->h_cnt[k];  // delimiters up to the end of slice k = frames that are complete
-        if (early && k >= 2) {  // the decode of slice k - 2 and its counter copy were queued before this slice's framing: both are done
-            const uint64_t cnt = ent_cnt[k - 2];
-            if (cnt > ent_cap) {
-                drain();
-                return FG_ERR_UNSUPPORTED;
-            }
-            if ((rc = download_entries(cnt)) != FG_OK) {
-                drain();
-                return rc;
-            }
-        }
-        if (total + 1 > cap) {
-            drain();
-            ctx->frames_per_byte = (double)(total + 1) / (double)(((uint64_t)k + 1) * slice);
-            return FG_ERR_UNSUPPORTED;
-        }
-        const uint64_t b1 = k + 1 == slices ? nbytes : ((uint64_t)k + 1) * slice;
-        if (k + 1 < slices) {
-            if ((rc = decode_rows(done, total, b1 - (uint64_t)k * slice)) != FG_OK || (rc = count_entries(k)) != FG_OK) {
-                drain();
-                return rc;
-            }
-            done = total;
-            continue;
-        }
-        // the last slice: an unterminated tail is one more frame when the stream ends here, else it stays with the caller
-        uint64_t last_end = 0;
-        FG_HIP(ctx, hipMemcpyAsync(&last_end, ctx->d_offsets + total, 8, hipMemcpyDeviceToHost, s_run));
-        FG_HIP(ctx, hipStreamSynchronize(s_run));
-        const bool tail = last_end != nbytes;
-        uint64_t n = total;
-        if (tail && final) {
-            ctx->h_cnt[slices] = nbytes;
-            FG_HIP(ctx, hipMemcpyAsync(ctx->d_offsets + total + 1, ctx->h_cnt + slices, 8, hipMemcpyHostToDevice, s_run));
-            n = total + 1;
-        }
-        *consumed = (tail && !final) ? last_end : nbytes;
-        if ((rc = decode_rows(done, n, *consumed > (uint64_t)k * slice ? *consumed - (uint64_t)k * slice : 1)) != FG_OK) {
-            drain();
-            return rc;
-        }
-        done = n;
-    }
-    uint64_t used = 0;
-    FG_HIP(ctx, hipMemcpyAsync(&used, dt.ent_used, 8, hipMemcpyDeviceToHost, s_run));
-    FG_HIP(ctx, hipStreamSynchronize(s_run));
-    if (done) ctx->frames_per_byte = (double)done / (double)nbytes;
-    if (used > ent_cap) {
-        drain();
-        return FG_ERR_UNSUPPORTED;
-    }
-    if ((rc = download_entries(used)) != FG_OK) {  // what the last two slices appended
-        drain();
-        return rc;
-    }
-    *ht.ent_used = used;
-    drain();
-    ht.n = done;
-    *out = ht;
-    *out_offsets = ctx->h_off;
-    *n_frames = done;
-    if (done == 0) {
-        fg_tables empty{};
-        *out = empty;
-    }
-    return FG_OK;
-}
-
-int fg_frame_decode_batch(fg_ctx* ctx, fg_format fmt, fg_framing framing, const uint8_t* bytes, uint64_t nbytes, int final,
-                          fg_tables* out, const uint64_t** out_offsets, uint64_t* n_frames, uint64_t* consumed) {
-    if (!ctx || !out || !out_offsets || !n_frames || !consumed || (nbytes && !bytes)) return FG_ERR_ARG;
-    if (framing != FG_FRAME_LINE && framing != FG_FRAME_NUL) return FG_ERR_UNSUPPORTED;
-    if (nbytes >= (48ull << 20) && !(ctx->lo.flags & FG_LO_TRANSCODE_ONE_PIECE)) {
-        DeviceGuard g(ctx->device);
-        *n_frames = 0;
-        *consumed = 0;
-        *out_offsets = nullptr;
-        const int rc = frame_decode_sliced(ctx, fmt, framing, bytes, nbytes, final, out, out_offsets, n_frames, consumed);
-        if (rc != FG_ERR_UNSUPPORTED) return rc;
-    }
-    return frame_decode_one_piece(ctx, fmt, framing, bytes, nbytes, final, out, out_offsets, n_frames, consumed);
-}
-
-// Framing stage shared by fg_frame_decode_batch and fg_transcode_batch: the raw chunk is already in ctx->d_bytes
-// (zero padded); fills ctx->d_offsets / ctx->d_bad and says how many frames the chunk holds and how many of its bytes
-// they cover (an unterminated tail is a frame only when `final`).
-static int frame_stage(fg_ctx* ctx, fg_framing framing, uint64_t nbytes, int final, uint64_t* n_frames, uint64_t* consumed) {
-    hipStream_t s = ctx->stream;
-    int rc;
-    uint64_t cap = nbytes / 32 + 1024, total = 0, last_end = 0;
-    for (;;) {  // capacity: one frame per 32 bytes to start with, exact on retry
-        if ((rc = grow_dev(ctx, (void**)&ctx->d_offsets, &ctx->d_offsets_cap, (cap + 2) * 8)) != FG_OK) return rc;
-        if ((rc = grow_dev(ctx, (void**)&ctx->d_bad, &ctx->d_bad_cap, cap + 1)) != FG_OK) return rc;
-        if ((rc = grow_dev(ctx, (void**)&ctx->d_frame, &ctx->d_frame_cap, fg_frame_scratch_bytes(nbytes))) != FG_OK) return rc;
-        uint64_t* d_total = nullptr;
-        int lrc = fg_launch_frame(ctx->d_bytes, nbytes, framing == FG_FRAME_LINE ? 0x0Au : 0x00u, ctx->d_frame, ctx->d_offsets,
-                                  ctx->d_bad, cap, &d_total, s);
-        if (lrc != 0) {
-            ctx->last_hip = lrc;
-            return FG_ERR_HIP;
-        }
-        FG_HIP(ctx, hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, s));
-        FG_HIP(ctx, hipStreamSynchronize(s));
-        if (total + 1 <= cap) break;
-        cap = total + 16;
-    }
-    FG_HIP(ctx, hipMemcpyAsync(&last_end, ctx->d_offsets + total, 8, hipMemcpyDeviceToHost, s));
-    FG_HIP(ctx, hipStreamSynchronize(s));
-    const bool tail = last_end != nbytes;  // terminated frames = total
-    *n_frames = total + ((tail && final) ? 1 : 0);
-    *consumed = (tail && !final) ? last_end : nbytes;
-    return FG_OK;
-}
-
-// Decode ctx->d_bytes / ctx->d_offsets into tables carved from ctx->d_tab, growing the entry table until it fits.
-static int decode_stage(fg_ctx* ctx, fg_format fmt, fg_framing framing, uint64_t nbytes, uint64_t n, const uint8_t* d_bad,
-                        fg_tables* dt, uint64_t* ent_used) {
-    hipStream_t s = ctx->stream;
-    int rc;
-    uint64_t ent_cap = fmt == FG_RFC5424 ? nbytes / 16 + 1024 : nbytes / 8 + 1024;
-    if (fmt == FG_RFC3164) ent_cap = 16;  // RFC3164 produces no entries
-    for (;;) {
-        if (ent_cap > 0xFFFFFFF0ull) ent_cap = 0xFFFFFFF0ull;
-        uint64_t bytes_total = 0;
-        carve(nullptr, n, ent_cap, nullptr, &bytes_total);
-        if ((rc = grow_dev(ctx, (void**)&ctx->d_tab, &ctx->d_tab_cap, bytes_total)) != FG_OK) return rc;
-        carve(ctx->d_tab, n, ent_cap, dt, nullptr);
-        rc = fg_decode_frames_device(ctx, fmt, framing, ctx->d_bytes, nbytes, ctx->d_offsets, n, d_bad, dt, FG_STREAM_OWN);
-        if (rc != FG_OK) return rc;
-        uint64_t used = 0;
-        FG_HIP(ctx, hipMemcpyAsync(&used, dt->ent_used, 8, hipMemcpyDeviceToHost, s));
-        FG_HIP(ctx, hipStreamSynchronize(s));
-        if (used > ent_cap) {
-            if (ent_cap >= 0xFFFFFFF0ull) return FG_ERR_ENT_OVERFLOW;
-            ent_cap = used + used / 8 + 1024;
-            continue;
-        }
-        *ent_used = used;
-        return FG_OK;
-    }
-}
-
-// fg_transcode_batch for a LARGE batch of framed lines: the batch goes through H2D -> decode -> encode -> D2H as slices of ~32 MiB
-// on the ctx's two streams, so that the upload of slice k+1 and the (2-3x larger) download of slice k's messages share the
-// full-duplex link, and the kernels hide behind both.  The host only waits for one small number per slice (its encoded size:
-// the next slice's messages start there).  Returns FG_ERR_UNSUPPORTED when the batch must take the one-piece path (an output
-// estimate that turned out too small): nothing has been returned to the caller by then.
-static int transcode_sliced(fg_ctx* ctx, fg_format fmt, const fg_encode_cfg* ecfg, const uint8_t* bytes, uint64_t nbytes,
-                            const uint64_t* offsets, uint64_t n, fg_transcoded* out) {
-    int rc;
-    if (!ctx->stream2) {
-        FG_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-        FG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming));
-    }
-    hipStream_t lanes[2] = {ctx->stream, ctx->stream2};
-    uint32_t slices = (uint32_t)(nbytes / (32ull << 20));
-    if (slices < 2) slices = 2;
-    if (slices > 64) slices = 64;
-    if (n < slices) return FG_ERR_UNSUPPORTED;
-    std::vector<uint64_t> cut(slices + 1);
-    if (fg_shard_plan(offsets, n, slices, cut.data()) != FG_OK) return FG_ERR_ARG;
-    // ---- device buffers: input, tables (whole batch), out_offsets / enc_status, encoder scratch ----
-    if ((rc = grow_dev(ctx, (void**)&ctx->d_bytes, &ctx->d_bytes_cap, up(nbytes, 16) + 16)) != FG_OK) return rc;
-    if ((rc = grow_dev(ctx, (void**)&ctx->d_offsets, &ctx->d_offsets_cap, (n + 1) * 8)) != FG_OK) return rc;
-    uint64_t ent_cap = fmt == FG_RFC5424 ? nbytes / 16 + 1024 : nbytes / 8 + 1024;
-    if (fmt == FG_RFC3164) ent_cap = 16;
-    if (ent_cap > 0xFFFFFFF0ull) ent_cap = 0xFFFFFFF0ull;
-    uint64_t tab_bytes = 0;
-    carve(nullptr, n, ent_cap, nullptr, &tab_bytes);
-    if ((rc = grow_dev(ctx, (void**)&ctx->d_tab, &ctx->d_tab_cap, tab_bytes)) != FG_OK) return rc;
-    fg_tables dt{};
-    carve(ctx->d_tab, n, ent_cap, &dt, nullptr);
-    const uint64_t offs_bytes = up((n + 1) * 8, 256);
-    if ((rc = grow_dev(ctx, (void**)&ctx->d_tmeta, &ctx->d_tmeta_cap, offs_bytes + up(n, 256))) != FG_OK) return rc;
-    uint64_t* d_out_offsets = reinterpret_cast<uint64_t*>(ctx->d_tmeta);
-    uint8_t* d_enc_status = ctx->d_tmeta + offs_bytes;
-    fg::EncCfgHost h;
-    if (!fg::build_enc_cfg(fmt, ecfg, ctx->suffix, ctx->has_suffix, &h)) return FG_ERR_ARG;
-    const uint64_t keys_bytes = up(h.keys.size() * sizeof(fg::StaticKey), 16), blob_bytes = up(h.blob.size() + 16, 256);
-    const uint64_t cfg_bytes = up(keys_bytes + blob_bytes, 256);
-    const uint64_t sizes_bytes = up(n * 4 + 4, 256), sums_bytes = up((n / 64 + slices + 2) * 8, 256);
-    if ((rc = grow_dev(ctx, (void**)&ctx->d_enc, &ctx->d_enc_cap, cfg_bytes + sizes_bytes + sums_bytes)) != FG_OK) return rc;
-    std::vector<uint8_t> host(cfg_bytes, 0);
-    if (!h.keys.empty()) memcpy(host.data(), h.keys.data(), h.keys.size() * sizeof(fg::StaticKey));
-    if (!h.blob.empty()) memcpy(host.data() + keys_bytes, h.blob.data(), h.blob.size());
-    FG_HIP(ctx, hipMemcpyAsync(ctx->d_enc, host.data(), host.size(), hipMemcpyHostToDevice, lanes[0]));
-    FG_HIP(ctx, hipMemcpyAsync(ctx->d_offsets, offsets, (n + 1) * 8, hipMemcpyHostToDevice, lanes[0]));
-    FG_HIP(ctx, hipMemsetAsync(dt.ent_used, 0, 8, lanes[0]));
-    FG_HIP(ctx, hipStreamSynchronize(lanes[0]));  // (`host` is a local; lane 1 may start)
-    fg::EncCfg cfg = h.cfg;
-    cfg.keys = reinterpret_cast<const fg::StaticKey*>(ctx->d_enc);
-    cfg.blob = ctx->d_enc + keys_bytes;
-    const uint32_t cfg_lds = keys_bytes + h.blob.size() <= 4096 ? (uint32_t)up(keys_bytes + h.blob.size(), 16) : 0u;
-    uint32_t* d_sizes = reinterpret_cast<uint32_t*>(ctx->d_enc + cfg_bytes);
-    uint64_t* d_block_sums = reinterpret_cast<uint64_t*>(ctx->d_enc + cfg_bytes + sizes_bytes);
-    const uint32_t tile_cap = pick_tile_cap(ctx, nbytes, n, 40 * 1024, 1);
-    fg::DevTables ddt = to_dev(dt);
-    // ---- host buffer: fixed-size arrays first, the messages behind them (they grow slice by slice) ----
-    const uint64_t o_offs = 0, o_meta = o_offs + offs_bytes, o_st = o_meta + up(n * 4, 256), o_msgs = o_st + up(n, 256);
-    uint64_t base = 0;  // encoded bytes of the slices finished so far
-    auto sl_tables = [&](uint64_t l0, uint64_t l1) {
-        fg_tables sl = dt;
-        sl.n = l1 - l0;
-        sl.meta += l0; sl.ts += l0; sl.hostname += l0; sl.appname += l0; sl.procid += l0; sl.msgid += l0; sl.msg += l0; sl.full_msg += l0;
-        sl.ent_first += l0; sl.ent_count += l0;
-        return sl;
-    };
-    auto blocks_before = [&](uint32_t k) { return cut[k] / 64 + k; };  // first scratch sum of slice k (disjoint per slice)
-    auto drain = [&]() {
-        (void)hipStreamSynchronize(lanes[0]);
-        (void)hipStreamSynchronize(lanes[1]);
-    };
-    // queue a slice's upload, decode and count kernel
-    auto enqueue = [&](uint32_t k) -> int {
-        hipStream_t s = lanes[k & 1u];
-        const uint64_t l0 = cut[k], l1 = cut[k + 1];
-        if (l1 == l0) return FG_OK;
-        const uint64_t b0 = offsets[l0] & ~15ull, b1 = offsets[l1];
-        if (b1 > b0) FG_HIP(ctx, hipMemcpyAsync(ctx->d_bytes + b0, bytes + b0, b1 - b0, hipMemcpyHostToDevice, s));
-        const fg_tables sl = sl_tables(l0, l1);
-        // (the two lanes' kernels may be in flight at the same time: each lane parks its entries in its own stash)
-        int r = decode_frames_impl(ctx, fmt, FG_FRAME_NONE, ctx->d_bytes, nbytes, ctx->d_offsets + l0, l1 - l0, nullptr, &sl, (void*)s, false,
-                                   offsets[l1] - offsets[l0], k & 1u);
-        if (r != FG_OK) return r;
-        if (k == 0 && ecfg->encoder == FG_ENC_GELF) {  // the GELF ranking scratch is sized by the pairs per line: look at the first slice
-            uint64_t used = ~0ull;
-            FG_HIP(ctx, hipMemcpyAsync(&used, dt.ent_used, 8, hipMemcpyDeviceToHost, s));
-            FG_HIP(ctx, hipStreamSynchronize(s));
-            if (used == 0) cfg.sort_slots = 1;
-            else if (used <= 2 * (l1 - l0)) cfg.sort_slots = 8;
-        }
-        fg::DevTables sdt = to_dev(sl);
-        sdt.ent_cap = ddt.ent_cap;
-        if (fg_launch_encode_count(ctx->d_bytes, ctx->d_offsets + l0, l1 - l0, &sdt, &cfg, tile_cap, cfg_lds, d_sizes + l0,
-                                   d_block_sums + blocks_before(k), d_enc_status + l0, s) != 0)
-            return FG_ERR_HIP;
-        return FG_OK;
-    };
-    for (uint32_t k = 0; k < slices; ++k) {
-        if (k == 0 && (rc = enqueue(0)) != FG_OK) {
-            drain();
-            return rc;
-        }
-        if (k + 1 < slices && (rc = enqueue(k + 1)) != FG_OK) {
-            drain();
-            return rc;
-        }
-        // ---- finish slice k: offsets from `base`, its size, the write kernel, the download ----
-        hipStream_t s = lanes[k & 1u];
-        const uint64_t l0 = cut[k], l1 = cut[k + 1], rows = l1 - l0;
-        if (rows == 0) continue;
-        if (fg_launch_encode_scan(d_sizes + l0, d_block_sums + blocks_before(k), rows, d_out_offsets + l0, base, s) != 0) {
-            drain();
-            return FG_ERR_HIP;
-        }
-        uint64_t end = 0;
-        FG_HIP(ctx, hipMemcpyAsync(&end, d_out_offsets + l1, 8, hipMemcpyDeviceToHost, s));
-        FG_HIP(ctx, hipStreamSynchronize(s));
-        if (k == 0) {
-            // size the output buffers from the first slice (+ 12 %); a batch that outgrows the estimate takes the one-piece path
-            const uint64_t in0 = offsets[l1] - offsets[l0];
-            const uint64_t est = (uint64_t)((double)end * ((double)nbytes / (double)(in0 ? in0 : 1)) * 1.12) + (4ull << 20);
-            if ((rc = grow_dev(ctx, (void**)&ctx->d_tout, &ctx->d_tout_cap, est)) != FG_OK || (rc = grow_pinned(ctx, (void**)&ctx->h_tout, &ctx->h_tout_cap, o_msgs + est)) != FG_OK) {
-                drain();
-                return rc;
-            }
-        }
-        if (end > ctx->d_tout_cap || o_msgs + end > ctx->h_tout_cap) {
-            drain();
-            return FG_ERR_UNSUPPORTED;
-        }
-        const fg_tables sl = sl_tables(l0, l1);
-        fg::DevTables sdt = to_dev(sl);
-        sdt.ent_cap = ddt.ent_cap;
-        if (fg_launch_encode_write(ctx->d_bytes, ctx->d_offsets + l0, rows, &sdt, &cfg, tile_cap, cfg_lds, d_out_offsets + l0, ctx->d_tout, s) != 0) {
-            drain();
-            return FG_ERR_HIP;
-        }
-        uint8_t* hh = ctx->h_tout;
-        if (end > base) FG_HIP(ctx, hipMemcpyAsync(hh + o_msgs + base, ctx->d_tout + base, end - base, hipMemcpyDeviceToHost, s));
-        FG_HIP(ctx, hipMemcpyAsync(hh + o_offs + l0 * 8, d_out_offsets + l0, (rows + 1) * 8, hipMemcpyDeviceToHost, s));
-        FG_HIP(ctx, hipMemcpyAsync(hh + o_meta + l0 * 4, dt.meta + l0, rows * 4, hipMemcpyDeviceToHost, s));
-        FG_HIP(ctx, hipMemcpyAsync(hh + o_st + l0, d_enc_status + l0, rows, hipMemcpyDeviceToHost, s));
-        base = end;
-    }
-    drain();
-    // an entry table that was too small shows up as FG_ST_OVERFLOW rows: the one-piece path sizes it exactly
-    uint64_t used = 0;
-    FG_HIP(ctx, hipMemcpy(&used, dt.ent_used, 8, hipMemcpyDeviceToHost));
-    if (used > ent_cap) return FG_ERR_UNSUPPORTED;
-    uint8_t* hh = ctx->h_tout;
-    out->n = n;
-    out->consumed = nbytes;
-    out->out = hh + o_msgs;
-    out->out_bytes = base;
-    out->out_offsets = reinterpret_cast<const uint64_t*>(hh + o_offs);
-    out->meta = reinterpret_cast<const uint32_t*>(hh + o_meta);
-    out->enc_status = hh + o_st;
-    out->frame_offsets = nullptr;
-    return FG_OK;
-}
-
-int fg_transcode_batch(fg_ctx* ctx, fg_format fmt, fg_framing framing, const fg_encode_cfg* ecfg, const uint8_t* bytes,
-                       uint64_t nbytes, const uint64_t* offsets, uint64_t n, int final, fg_transcoded* out) {
-    if (!ctx || !ecfg || !out || (nbytes && !bytes)) return FG_ERR_ARG;
-    if ((int)framing < 0 || (int)framing > 2) return FG_ERR_ARG;
-    if (framing == FG_FRAME_NONE) {
-        if (n && !offsets) return FG_ERR_ARG;
-        if (n && (offsets[n] > nbytes || offsets[0] > offsets[n])) return FG_ERR_ARG;
-    } else if (offsets) {
-        return FG_ERR_ARG;  // a raw stream chunk is framed here; it does not come with offsets
-    }
-    *out = fg_transcoded{};
-    if (framing != FG_FRAME_NONE && nbytes == 0) return FG_OK;
-    DeviceGuard g(ctx->device);
-    hipStream_t s = ctx->stream;
-    int rc;
-    if (framing == FG_FRAME_NONE && nbytes >= (64ull << 20) && n >= 4096 && !(ctx->lo.flags & FG_LO_TRANSCODE_ONE_PIECE)) {
-        rc = transcode_sliced(ctx, fmt, ecfg, bytes, nbytes, offsets, n, out);
-        if (rc != FG_ERR_UNSUPPORTED) return rc;
-        *out = fg_transcoded{};
-    }
-    // 1. the chunk (and, for framed input, its offsets) to HBM
-    if ((rc = grow_dev(ctx, (void**)&ctx->d_bytes, &ctx->d_bytes_cap, up(nbytes, 16) + 16)) != FG_OK) return rc;
-    if (nbytes) FG_HIP(ctx, hipMemcpyAsync(ctx->d_bytes, bytes, nbytes, hipMemcpyHostToDevice, s));
-    FG_HIP(ctx, hipMemsetAsync(ctx->d_bytes + nbytes, 0, up(nbytes, 16) + 16 - nbytes, s));
-    uint64_t consumed = nbytes;
-    const uint8_t* d_bad = nullptr;
-    if (framing == FG_FRAME_NONE) {
-        if ((rc = grow_dev(ctx, (void**)&ctx->d_offsets, &ctx->d_offsets_cap, (n + 1) * 8)) != FG_OK) return rc;
-        if (n) FG_HIP(ctx, hipMemcpyAsync(ctx->d_offsets, offsets, (n + 1) * 8, hipMemcpyHostToDevice, s));
-    } else {
-        if ((rc = frame_stage(ctx, framing, nbytes, final, &n, &consumed)) != FG_OK) return rc;
-        d_bad = ctx->d_bad;
-    }
-    out->n = n;
-    out->consumed = consumed;
-    if (n == 0) {
-        FG_HIP(ctx, hipStreamSynchronize(s));
-        return FG_OK;
-    }
-    // 2. decode (tables stay in HBM)
-    fg_tables dt{};
-    uint64_t ent_used = 0;
-    if ((rc = decode_stage(ctx, fmt, framing, consumed, n, d_bad, &dt, &ent_used)) != FG_OK) return rc;
-    // 3. encode + frame from the tables; the output buffer grows to the batch (steady state: one count + one write)
-    const uint64_t offs_bytes = up((n + 1) * 8, 256);
-    if ((rc = grow_dev(ctx, (void**)&ctx->d_tmeta, &ctx->d_tmeta_cap, offs_bytes + up(n, 256))) != FG_OK) return rc;
-    uint64_t* d_out_offsets = reinterpret_cast<uint64_t*>(ctx->d_tmeta);
-    uint8_t* d_enc_status = ctx->d_tmeta + offs_bytes;
-    if (!ctx->d_tout && (rc = grow_dev(ctx, (void**)&ctx->d_tout, &ctx->d_tout_cap, consumed + consumed / 2 + 4096)) != FG_OK) return rc;
-    uint64_t total = 0;
-    rc = fg_encode_device(ctx, fmt, ecfg, ctx->d_bytes, consumed, ctx->d_offsets, n, &dt, ctx->d_tout, ctx->d_tout_cap, d_out_offsets,
-                          d_enc_status, &total, FG_STREAM_OWN);
-    if (rc == FG_ERR_ENT_OVERFLOW) {
-        if ((rc = grow_dev(ctx, (void**)&ctx->d_tout, &ctx->d_tout_cap, total + 4096)) != FG_OK) return rc;
-        rc = fg_encode_device(ctx, fmt, ecfg, ctx->d_bytes, consumed, ctx->d_offsets, n, &dt, ctx->d_tout, ctx->d_tout_cap, d_out_offsets,
-                              d_enc_status, &total, FG_STREAM_OWN);
-    }
-    if (rc != FG_OK) return rc;
-    // 4. only the encoded stream and the per-line verdicts cross PCIe back
-    const uint64_t o_msgs = 0, o_offs = up(total, 256), o_meta = o_offs + offs_bytes, o_st = o_meta + up(n * 4, 256),
-                   o_frames = o_st + up(n, 256), h_total = o_frames + (framing != FG_FRAME_NONE ? offs_bytes : 0);
-    if ((rc = grow_pinned(ctx, (void**)&ctx->h_tout, &ctx->h_tout_cap, h_total)) != FG_OK) return rc;
-    uint8_t* h = ctx->h_tout;
-    if (total) FG_HIP(ctx, hipMemcpyAsync(h + o_msgs, ctx->d_tout, total, hipMemcpyDeviceToHost, s));
-    FG_HIP(ctx, hipMemcpyAsync(h + o_offs, d_out_offsets, (n + 1) * 8, hipMemcpyDeviceToHost, s));
-    FG_HIP(ctx, hipMemcpyAsync(h + o_meta, dt.meta, n * 4, hipMemcpyDeviceToHost, s));
-    FG_HIP(ctx, hipMemcpyAsync(h + o_st, d_enc_status, n, hipMemcpyDeviceToHost, s));
-    if (framing != FG_FRAME_NONE) FG_HIP(ctx, hipMemcpyAsync(h + o_frames, ctx->d_offsets, (n + 1) * 8, hipMemcpyDeviceToHost, s));
-    FG_HIP(ctx, hipStreamSynchronize(s));
-    out->out = h + o_msgs;
-    out->out_bytes = total;
-    out->out_offsets = reinterpret_cast<const uint64_t*>(h + o_offs);
-    out->meta = reinterpret_cast<const uint32_t*>(h + o_meta);
-    out->enc_status = h + o_st;
-    out->frame_offsets = framing != FG_FRAME_NONE ? reinterpret_cast<const uint64_t*>(h + o_frames) : nullptr;
-    return FG_OK;
-}
 
 namespace {
 // fg_encode_device (total != nullptr: synchronises for the configuration's entry count and for the total) and

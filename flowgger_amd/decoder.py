@@ -106,14 +106,17 @@ class Decoder:
     def decode_batch(self, lines: Sequence[Union[str, bytes]]) -> List[Union[Record, DecodeError]]:
         data, offsets = pack_lines(lines)
         tab = self.decode_packed(data, offsets)
+        n_rows = len(offsets) - 1
         if self.fmt == L.FG_LTSV:  # the decoder's stdout side effect (ltsv_decoder.rs:99), reproduced from the rows' flags
             import sys
 
             from .tables import tables_stdout
 
-            text = tables_stdout(tab, self.fmt, np.concatenate([data, np.zeros(16, np.uint8)]), offsets)
-            if text:
-                sys.stdout.write(text.decode("utf-8", "replace"))
+            # (only when a row carries the flag; fg_tables_stdout reads [offsets[i], offsets[i+1]) only: no copy, no slack -- ADVICE r3)
+            if n_rows and bool(((tab.a["meta"][:n_rows] >> 24) & L.FG_F_LTSV_NOVALUE).any()):
+                text = tables_stdout(tab, self.fmt, data, offsets)
+                if text:
+                    sys.stdout.write(text.decode("utf-8", "replace"))
         blob, offs = tab.serialize(self.fmt, data, offsets, cfg=self._cfg)
         raw = blob.tobytes()
         return [parse_canonical(raw[int(offs[i]):int(offs[i + 1])]) for i in range(len(lines))]

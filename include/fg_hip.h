@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FG_ABI_VERSION 1
+#define FG_ABI_VERSION 2 /* 2 (round 4): FG_YEAR_NOW = INT32_MIN, FG_F_LTSV_NOVALUE and the failed-LTSV-row count, ent_used = RESERVED slots, fg_calibrate_device */
 
 typedef enum fg_format { FG_RFC5424 = 0, FG_LTSV = 1, FG_GELF = 2, FG_RFC3164 = 3 } fg_format;
 
@@ -387,6 +387,15 @@ void fg_free_pinned(void* p);
  * on two streams (sum of both).  This is the roof the host-buffer entry points (fg_decode_batch, fg_transcode_batch ...) are
  * priced against -- SURVEY 8d: end-to-end is PCIe-bound -- instead of a nominal Gen5 figure. */
 int fg_measure_link(fg_ctx* ctx, uint64_t nbytes, double gbps[3]);
+
+/* CALIBRATION of the memory system the decode kernels run on, in the caller's process and on the caller's own resident buffer: a
+ * plain streaming kernel over [d_src, d_src + nbytes) on `stream` (asynchronous; time it with events like a decode launch).
+ *   FG_CALIB_COPY  float4 copy into d_dst (nbytes readable / writable, 16-byte aligned): 2 x nbytes of HBM traffic
+ *   FG_CALIB_READ  read-only sweep (d_dst ignored): nbytes of traffic -- the roof of a decoder that writes little
+ * bench.py reports both beside the decoder's achieved GB/s (roofline.copy_GBps / read_GBps) so that box-to-box variance is not
+ * mistaken for a code change.  No reference analogue (measurement support). */
+enum { FG_CALIB_COPY = 0, FG_CALIB_READ = 1 };
+int fg_calibrate_device(fg_ctx* ctx, int mode, const uint8_t* d_src, uint8_t* d_dst, uint64_t nbytes, void* stream);
 
 /* The reference's exact &'static str for a status code of a format (0 -> "", unknown -> NULL). */
 const char* fg_error_string(fg_format fmt, uint8_t status);

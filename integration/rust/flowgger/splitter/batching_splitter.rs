@@ -53,7 +53,7 @@ impl GpuSplitter {
     pub fn run_decode<T: Read>(&self, mut reader: BufReader<T>, tx: SyncSender<Vec<u8>>, decoder: &GpuDecoder, encoder: Box<dyn Encoder>) {
         let mut buf: Vec<u8> = Vec::with_capacity(2 * MAX_BYTES);
         loop {
-            let how = fill(&mut reader, &mut buf, MAX_BYTES);
+            let how = fill(&mut reader, &mut buf, MAX_BYTES, self.framing);
             let last = how != Fill::Data;
             let eof = how == Fill::Eof;
             if !buf.is_empty() && (eof || has_frame(&buf, self.framing)) {
@@ -103,7 +103,7 @@ impl GpuSplitter {
     pub fn run_transcode<T: Read>(&self, mut reader: BufReader<T>, tx: SyncSender<Vec<u8>>, decoder: &GpuDecoder, enc: &fg_encode_cfg) {
         let mut buf: Vec<u8> = Vec::with_capacity(2 * MAX_BYTES);
         loop {
-            let how = fill(&mut reader, &mut buf, MAX_BYTES);
+            let how = fill(&mut reader, &mut buf, MAX_BYTES, self.framing);
             let last = how != Fill::Data;
             let eof = how == Fill::Eof;
             if !buf.is_empty() && (eof || has_frame(&buf, self.framing)) {
@@ -178,9 +178,14 @@ fn has_frame(buf: &[u8], framing: fg_framing) -> bool {
 
 /// Append what the source has to `buf`: blocks for the first bytes (the read timeout of the socket applies), then keeps taking
 /// what `BufReader` gets per read while each read fills its whole buffer -- a SHORT read means the peer has nothing more in
-/// flight, and the batch goes out.  (`BufReader::with_capacity(1 << 20, ..)` in the input keeps the syscall count down; the
-/// reference's 8 KiB default works, 32 lines per read.)
-fn fill<T: Read>(reader: &mut BufReader<T>, buf: &mut Vec<u8>, max_bytes: usize) -> Fill {
+/// flight, and the batch goes out.  A FULL read says nothing either way (the peer may have sent exactly `cap` bytes and gone
+/// quiet), and the next `fill_buf()` would block on the socket for up to `input.timeout` with complete lines sitting undecoded:
+/// so a full read only reads on while `buf` holds NO complete frame yet -- never block while there is something to decode
+/// (the reference hands every line to the decoder as soon as `lines()` yields it, line_splitter.rs:17).  The batch
+/// size under sustained load is therefore the reader's capacity: construct the input's reader as
+/// `BufReader::with_capacity(1 << 20, ..)` (4000 lines of 256 bytes per GPU call); the reference's 8 KiB default works and
+/// gives 32-line batches.
+fn fill<T: Read>(reader: &mut BufReader<T>, buf: &mut Vec<u8>, max_bytes: usize, framing: fg_framing) -> Fill {
     let cap = reader.capacity();
     let mut added = 0usize;
     loop {
@@ -194,11 +199,60 @@ fn fill<T: Read>(reader: &mut BufReader<T>, buf: &mut Vec<u8>, max_bytes: usize)
         if k == 0 {
             return Fill::Eof;
         }
+        let fresh_has_frame = has_frame(chunk, framing);
         buf.extend_from_slice(chunk);
         reader.consume(k);
         added += k;
-        if k < cap || added >= max_bytes {
-            return Fill::Data; // a short read: nothing more is pending -- or the batch is full
+        // a short read: nothing more is pending -- or the batch is full -- or there is a complete frame to decode and the next
+        // read might block (the frame may also have been completed by these bytes: look at the whole buffer then)
+        if k < cap || added >= max_bytes || fresh_has_frame || has_frame(buf, framing) {
+            return Fill::Data;
         }
+    }
+}
+
+#[cfg(test)]
+mod tests {
+    use super::*;
+    use std::io::{self, Read};
+
+    /// yields its pieces one per `read`; a read after the last piece is the peer going quiet: the test fails instead of blocking
+    struct Pieces {
+        pieces: Vec<Vec<u8>>,
+        next: usize,
+    }
+    impl Read for Pieces {
+        fn read(&mut self, out: &mut [u8]) -> io::Result<usize> {
+            assert!(self.next < self.pieces.len(), "fill() read again while complete frames were buffered: it would have blocked");
+            let p = &self.pieces[self.next];
+            assert!(p.len() <= out.len());
+            out[..p.len()].copy_from_slice(p);
+            self.next += 1;
+            Ok(p.len())
+        }
+    }
+
+    #[test]
+    fn a_read_that_exactly_fills_the_reader_does_not_block_on_buffered_lines() {
+        let cap = 64usize;
+        let mut piece = vec![b'x'; cap];
+        piece[10] = b'\n';
+        piece[cap - 1] = b'\n';
+        let mut reader = BufReader::with_capacity(cap, Pieces { pieces: vec![piece], next: 0 });
+        let mut buf = Vec::new();
+        assert!(fill(&mut reader, &mut buf, 1 << 20, FG_FRAME_LINE) == Fill::Data);
+        assert_eq!(buf.len(), cap);
+    }
+
+    #[test]
+    fn a_full_read_without_a_frame_reads_on() {
+        let cap = 64usize;
+        let first = vec![b'x'; cap]; // no terminator yet: nothing to decode, reading on is the only way forward
+        let mut second = vec![b'y'; 20];
+        second[19] = b'\n';
+        let mut reader = BufReader::with_capacity(cap, Pieces { pieces: vec![first, second], next: 0 });
+        let mut buf = Vec::new();
+        assert!(fill(&mut reader, &mut buf, 1 << 20, FG_FRAME_LINE) == Fill::Data);
+        assert_eq!(buf.len(), cap + 20);
     }
 }

@@ -1,4 +1,4 @@
-// The HOST side of the C ABI (flowgger_amd/csrc/fg_capi.cpp + fg_gather.cpp + fg_materialize.cpp, unchanged) compiled with g++ against
+// The HOST side of the C ABI (flowgger_amd/csrc/fg_capi.cpp + fg_host_pipeline.cpp + fg_gather.cpp + fg_materialize.cpp, unchanged) compiled with g++ against
 // a synchronous stand-in for the HIP runtime (tests/native/fakehip) and the FAKE kernel launchers below, so that `pytest -m "not gpu"`
 // runs its bookkeeping: slices cut at line boundaries, rows at their final index, entry ranges per slice of one shared counter, the
 // retry when the entry table is too small, the raw-stream path's frame counts per slice and its fall-back, error paths.
@@ -8,6 +8,7 @@
 // delimiter scan with the real ones' contract (ranks continue from slice to slice; a frame is bad when it holds a byte >= 0xF8).
 // Test infrastructure: nothing here is shipped, and it says nothing about what the GPU computes.
 #include "../../flowgger_amd/csrc/fg_capi.cpp"
+#include "../../flowgger_amd/csrc/fg_host_pipeline.cpp"
 #include "../../flowgger_amd/csrc/fg_gather.cpp"
 #include "../../flowgger_amd/csrc/fg_materialize.cpp"
 
@@ -82,6 +83,10 @@ extern "C" void fgf_counters(unsigned long long out[3], int reset) {
 extern "C" void fgf_fail_malloc_after(long long n) { fakehip::fail_malloc_after() = n; }
 
 extern "C" uint64_t fg_stash_bytes(uint32_t blocks) { return 64ull * blocks; }
+extern "C" int fg_launch_calib(int mode, const uint8_t* src, uint8_t* dst, uint64_t nbytes, uint32_t*, hipStream_t) {
+    if (mode == 0) memcpy(dst, src, nbytes / 16 * 16);
+    return 0;
+}
 extern "C" int fg_launch_rfc5424(const uint8_t* b, const uint64_t* o, uint64_t n, const fg::DevTables* t, uint64_t, hipStream_t, uint64_t*, uint32_t,
                                  uint32_t strip, const uint8_t* bad, const fg_launch_opts*) { return fake_decode(b, o, n, t, strip, bad); }
 extern "C" int fg_launch_ltsv(const uint8_t* b, const uint64_t* o, uint64_t n, const fg::DevTables* t, const fg::LtsvDevCfg*, uint64_t, hipStream_t,

@@ -1,4 +1,4 @@
-"""CPU: the HOST side of the C ABI -- flowgger_amd/csrc/fg_capi.cpp itself, compiled by g++ against a synchronous stand-in for the
+"""CPU: the HOST side of the C ABI -- flowgger_amd/csrc/fg_capi.cpp + fg_host_pipeline.cpp themselves, compiled by g++ against a synchronous stand-in for the
 HIP runtime (tests/native/fakehip) and fake kernel launchers with the real kernels' contract (tests/native/host_pipeline_fake.cpp).
 What is tested is the bookkeeping of the host paths: slices cut at line boundaries, rows at their final index, the entry columns
 brought back per slice as ranges of one shared counter, the retry when the entry table is too small, the raw-stream path's
@@ -17,7 +17,7 @@ ROOT = Path(__file__).resolve().parent.parent
 HERE = ROOT / "tests" / "native"
 LIB = HERE / "libhost_pipeline_fake.so"
 SRC = [HERE / "host_pipeline_fake.cpp", HERE / "fakehip/hip/hip_runtime.h"] + [ROOT / "flowgger_amd/csrc" / f for f in
-                                                                                ("fg_capi.cpp", "fg_gather.cpp", "fg_materialize.cpp")] + [ROOT / "include/fg_hip.h"]
+                                                                                ("fg_capi.cpp", "fg_host_pipeline.cpp", "fg_ctx.hpp", "fg_tile_cap.hpp", "fg_gather.cpp", "fg_materialize.cpp")] + [ROOT / "include/fg_hip.h"]
 u64, vp = C.c_uint64, C.c_void_p
 COLS = ["meta", "ts", "hostname", "appname", "procid", "msgid", "msg", "full_msg", "ent_count"]
 
@@ -139,6 +139,29 @@ def test_sliced_decode_batch_equals_one_launch(fake):
     c.close()
 
 
+def test_a_few_short_lines_described_inside_a_large_buffer(fake):
+    """fg_shard_plan gives EMPTY leading slices when the lines cover fewer bytes than there are slices (a few short
+    lines -- or only empty ones -- whose offsets live in a >= 32 MiB buffer): the first slice WITH rows must upload its own start
+    offset, or line 0 is decoded from a stale device value."""
+    big = np.zeros(40 << 20, np.uint8)
+    lines = [b'<1>a="b" c="d" x', b"", b'<2>e="f" y']
+    blob = b"".join(lines)
+    start = 1 << 20  # (not at the front of the buffer: a stale zero would be wrong)
+    big[start:start + len(blob)] = np.frombuffer(blob, np.uint8)
+    offsets = np.array([start, start + len(lines[0]), start + len(lines[0]), start + len(blob)], np.uint64)
+    for offs in (offsets, np.full(6, start + 3, np.uint64)):  # (and: nothing but empty lines)
+        n = len(offs) - 1
+        c = Ctx(fake)
+        st = L.fg_tables()
+        # poison the ctx's device offsets with an earlier batch that started elsewhere
+        warm, woffs = pack([b'<9>q="r" zzzz'] * 8)
+        wbig = np.concatenate([np.zeros(64, np.uint8), warm, np.zeros(40 << 20, np.uint8)])
+        assert fake.fg_decode_batch(c.h, 0, wbig.ctypes.data, wbig.size, (woffs + np.uint64(64)).ctypes.data, 8, C.byref(st)) == 0
+        assert fake.fg_decode_batch(c.h, 0, big.ctypes.data, big.size, offs.ctypes.data, n, C.byref(st)) == 0
+        same_lines(snapshot(st, n), device_reference(fake, big, offs, big.size // 16 + 1024), n)
+        c.close()
+
+
 def test_entry_table_too_small_is_noticed_mid_batch_and_the_retry_is_exact(fake):
     rng = np.random.default_rng(2)
     lines = corpus(60_000, rng, 0, 2) + corpus(150_000, rng, 30, 40, 300) + corpus(60_000, rng, 0, 2)  # > one entry per 16 bytes in the middle
@@ -154,7 +177,7 @@ def test_entry_table_too_small_is_noticed_mid_batch_and_the_retry_is_exact(fake)
     launches = fake.fgf_launches(1)
     got = snapshot(st, n)
     assert got["used"] == total and not (got["meta"] & 0xFF == 0xFE).any()
-    sl = min(max(data.size // 8, 8 << 20), 32 << 20)  # (fg_capi.cpp's slice_count)
+    sl = min(max(data.size // 8, 8 << 20), 32 << 20)  # (fg_host_pipeline.cpp's slice_count)
     slices = (data.size + sl - 1) // sl
     assert launches == 2 * slices  # every slice ran twice: once counting past the capacity, once with the capacity the counter asked for
     same_lines(got, device_reference(fake, data, offsets, total + 16), n)

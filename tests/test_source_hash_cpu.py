@@ -30,6 +30,18 @@ def test_a_workload_hash_covers_its_kernel_and_nothing_else():
     assert B.source_hash("no such workload") == hashes["*"]
 
 
+def test_host_side_edits_do_not_disown_a_kernel_figure(tmp_path, monkeypatch):
+    """the host pipelines (copies, streams, events) were hashed into every kernel's identity, so host-side work reported
+    four of five PMC traffic figures as null.  The host side of the C ABI is no unit of any workload now."""
+    for w, units in B.WORKLOAD_UNITS.items():
+        assert not ({"fg_capi.cpp", "fg_host_pipeline.cpp", "fg_ctx.hpp"} & set(units)), w
+        for u in units:
+            if u.endswith(".hip"):
+                assert not ({"fg_capi.cpp", "fg_host_pipeline.cpp", "fg_ctx.hpp"} & _deps(u)), (w, u)
+    # ... while the one host-picked tile size (RFC3164, encoders) still is part of those kernels' identity
+    assert "fg_tile_cap.hpp" in B.WORKLOAD_UNITS["rfc3164"] and "fg_tile_cap.hpp" in B.WORKLOAD_UNITS["cfg1"]
+
+
 def test_traffic_entries_are_stamped():
     """profiles/traffic.json: the entries bench.py may report carry the 16-hex-digit hash of the sources they were measured on
     (bench.py compares it with source_hash(workload) and reports null for anything else); entries without one are history."""
