@@ -1,0 +1,161 @@
+"""-m gpu, round 4: parity hardening.
+
+* whole-line mutation fuzz for RFC5424 with structured data (round 3 mutated bytes 0..119 only; the structured data of a 554-byte
+  line spans bytes ~70..450) -- rfc5424_decoder.rs:127-242;
+* a structural mutation fuzz for LTSV (TAB, ':', '[', ']', digits, signs, multi-byte) -- ltsv_decoder.rs:87-221;
+* >= 1 M mutated lines per format, generated on the fly (seeded, vectorised), decoded through fg_decode_batch_device and compared
+  with the oracle as canonical Records in chunks -- including lines that straddle the LDS tile end and the 768-byte head-staging
+  threshold of the RFC5424 kernel.
+The oracle is the checker (tests/oracle_binding.py); the product path is the C ABI.
+"""
+import numpy as np
+import pytest
+
+from flowgger_amd import GelfDecoder, LTSVDecoder, RFC5424Decoder, synth
+from gpu_util import assert_same, device_path, host_path_blob
+
+pytestmark = pytest.mark.gpu
+
+RFC5424, LTSV, GELF = 0, 1, 2
+IDEO, NBSP = "\u3000", "\u00a0"
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    import oracle_binding
+
+    return oracle_binding.Oracle()
+
+
+def both_paths(dec, oracle, lines, config=None, host=True):
+    data, offsets = synth.pack(lines)
+    oblob, ooffs = oracle.decode_batch(dec.fmt, data, offsets, config)
+    if host:
+        (blob, offs), _ = host_path_blob(dec, data, offsets)
+        assert_same(blob, offs, oblob, ooffs, lines)
+    tables, _, _ = device_path(dec, data, offsets)
+    blob2, offs2 = tables.to_host().serialize(dec.fmt, data, offsets, cfg=dec._cfg)
+    assert_same(blob2, offs2, oblob, ooffs, lines)
+
+
+def mutate_py(lines, rng, alphabet, per_line=(1, 4), lo=0):
+    """byte-level mutations anywhere in the line (insertions, deletions and multi-byte scalars included; UTF-8 stays valid: only
+    ASCII bytes are replaced)"""
+    out = []
+    for ln in lines:
+        b = bytearray(ln)
+        for _ in range(int(rng.integers(*per_line))):
+            if len(b) <= lo:
+                break
+            pos = int(rng.integers(lo, len(b)))
+            if b[pos] >= 0x80:
+                continue
+            b[pos:pos + 1] = alphabet[int(rng.integers(0, len(alphabet)))]
+        out.append(bytes(b))
+    return out
+
+
+SD_ALPHABET = [b" ", b"[", b"]", b'"', b"\\", b"=", b"<", b">", b"-", b"1", b"Z", b":", b".", b"+", b"\t", b"", b"  ", b'""', b"\\\\",
+               b'\\"', b"] ", b"][", b'="', b'" ', "é".encode(), IDEO.encode(), NBSP.encode(), b"\x7f", b"T", b"a"]
+
+
+def test_rfc5424_sd_whole_line_mutation_fuzz(oracle):
+    """Mutations over the WHOLE line -- header, every pair of the structured data, the brackets between elements, the message."""
+    rng = np.random.default_rng(0x5424_4)
+    dec = RFC5424Decoder()
+    base = synth.rfc5424_lines(6000, cfg=4, sd=True, invalid_frac=0)
+    lines = mutate_py(base, rng, SD_ALPHABET)
+    # the same mutations confined to the structured data (from the first '[' to the last ']')
+    for ln in base[:3000]:
+        a, z = ln.find(b"["), ln.rfind(b"]")
+        b = bytearray(ln)
+        for _ in range(int(rng.integers(1, 3))):
+            pos = int(rng.integers(a, z + 1))
+            if pos < len(b) and b[pos] < 0x80:
+                b[pos:pos + 1] = SD_ALPHABET[int(rng.integers(0, len(SD_ALPHABET)))]
+        lines.append(bytes(b))
+    both_paths(dec, oracle, lines)
+    # ... and under the kernel variants the launch options select (head-only staging, few lines per group, small tiles)
+    for opts in ({"force_head": True}, {"lines_per_group": 7, "tile_cap": 6144}, {"tile_cap": 4096}):
+        d2 = RFC5424Decoder()
+        d2.set_launch_opts(**opts)
+        both_paths(d2, oracle, lines[:4000], host=False)
+
+
+LTSV_ALPHABET = [b"\t", b":", b"[", b"]", b"0", b"9", b"-", b"+", b".", b"e", b" ", b"", b"\t\t", b"::", b"time:", b"host:", b"level:", b"\tx",
+                 b"\tlevel:7", b"\tlevel:8", b"\tcounter:18446744073709551616", b"\tdone:TRUE", b"\tmean:1e400", b"\tscore:-0",
+                 "é".encode(), IDEO.encode(), b"T", b"Z", b"/"]
+
+
+def test_ltsv_structural_mutation_fuzz(oracle):
+    """LTSV has no structure but TAB and the first ':' of a part; typed values, the three timestamp spellings and the bracket strip
+    hang off single bytes -- mutate exactly those."""
+    rng = np.random.default_rng(0x175)
+    dec = LTSVDecoder(synth.LTSV_CONFIG)
+    base = synth.ltsv_lines(8000, invalid_frac=0) + synth.ltsv_lines(1500, invalid_frac=0, long_tail=True)
+    lines = mutate_py(base, rng, LTSV_ALPHABET)
+    both_paths(dec, oracle, lines, synth.LTSV_CONFIG)
+    d2 = LTSVDecoder(synth.LTSV_CONFIG)
+    d2.set_launch_opts(lines_per_group=5, tile_cap=4096)
+    both_paths(d2, oracle, lines[:4000], synth.LTSV_CONFIG, host=False)
+
+
+def _mutate_packed(data, offsets, rng, ascii_alphabet, frac=0.85):
+    """vectorised: one to three single-byte replacements in `frac` of the lines (ASCII for ASCII: offsets and UTF-8 validity stay)"""
+    data = data.copy()
+    n = len(offsets) - 1
+    ln = np.diff(offsets.astype(np.int64))
+    alpha = np.frombuffer(ascii_alphabet, np.uint8)
+    for _ in range(3):
+        pick = (rng.random(n) < frac / 2) & (ln > 0)
+        idx = np.nonzero(pick)[0]
+        pos = offsets[idx].astype(np.int64) + (rng.integers(0, 1 << 62, idx.size) % ln[idx])
+        ok = data[pos] < 0x80
+        data[pos[ok]] = alpha[rng.integers(0, alpha.size, int(ok.sum()))]
+    return data
+
+
+def _chunked_compare(dec, oracle, data, offsets, config, chunk=250_000):
+    n = len(offsets) - 1
+    for i0 in range(0, n, chunk):
+        i1 = min(n, i0 + chunk)
+        b0, b1 = int(offsets[i0]), int(offsets[i1])
+        d = np.ascontiguousarray(data[b0:b1])
+        o = (offsets[i0:i1 + 1] - offsets[i0]).astype(np.uint64)
+        oblob, ooffs = oracle.decode_batch(dec.fmt, d, o, config)
+        tables, _, _ = device_path(dec, d, o)
+        blob, offs = tables.to_host().serialize(dec.fmt, d, o, cfg=dec._cfg)
+        if not (np.array_equal(offs, ooffs) and np.array_equal(blob, oblob)):
+            lines = [bytes(d[int(o[k]):int(o[k + 1])]) for k in range(i1 - i0)]
+            assert_same(blob, offs, oblob, ooffs, lines)
+
+
+@pytest.mark.parametrize("fmt", ["rfc5424_sd", "ltsv", "gelf"])
+def test_one_million_mutated_lines_per_format(oracle, fmt):
+    """>= 1 M mutated lines, seeded, generated on the fly: a 125 K-line tile (with lengths that straddle the LDS tile end and the
+    768-byte head threshold mixed in) mutated eight different ways; every chunk == the oracle, Record for Record."""
+    rng = np.random.default_rng({"rfc5424_sd": 41, "ltsv": 42, "gelf": 43}[fmt])
+    if fmt == "rfc5424_sd":
+        dec, config = RFC5424Decoder(), None
+        base = synth.rfc5424_lines(100_000, cfg=4, sd=True, invalid_frac=0.002)
+        # lines around the head-staging threshold (768 B average switches kernels; 1024 B is the staged head) and around the tile end
+        base += synth.rfc5424_lines(15_000, cfg=5, sd=True, invalid_frac=0, long_tail=True)
+        base += [ln + b" pad" * int(k) for ln, k in zip(synth.rfc5424_lines(10_000, cfg=4, sd=True, invalid_frac=0), rng.integers(40, 160, 10_000))]
+        alpha = b' []"\\=<>-1Z:.+a\x7f'
+    elif fmt == "ltsv":
+        dec, config = LTSVDecoder(synth.LTSV_CONFIG), synth.LTSV_CONFIG
+        base = synth.ltsv_lines(110_000, invalid_frac=0.002) + synth.ltsv_lines(15_000, invalid_frac=0, long_tail=True)
+        alpha = b"\t:[]09-+.e TZ/a"
+    else:
+        dec, config = GelfDecoder(), None
+        base = synth.gelf_lines(125_000, invalid_frac=0.002)
+        alpha = b'{}[],:"\\ 019-+.eEtfn a_'
+    order = rng.permutation(len(base))  # (long and short lines interleaved: groups are cut by bytes)
+    base = [base[i] for i in order]
+    data, offsets = synth.pack(base)
+    total = 0
+    for rep in range(8):
+        d = _mutate_packed(data, offsets, rng, alpha)
+        _chunked_compare(dec, oracle, d, offsets, config)
+        total += len(base)
+    assert total >= 1_000_000
