@@ -236,6 +236,7 @@ void fg_destroy(fg_ctx* ctx) {
     if (ctx->d_stash2) (void)hipFree(ctx->d_stash2);
     if (ctx->d_pending) (void)hipFree(ctx->d_pending);
     if (ctx->d_sink) (void)hipFree(ctx->d_sink);
+    if (ctx->d_used) (void)hipFree(ctx->d_used);
     if (ctx->d_frame) (void)hipFree(ctx->d_frame);
     if (ctx->d_bad) (void)hipFree(ctx->d_bad);
     if (ctx->d_enc) (void)hipFree(ctx->d_enc);

@@ -94,6 +94,7 @@ struct fg_ctx {
     uint32_t* d_pending = nullptr;  // ring of kPendingRing hand-over words (DevTables::pending), zeroed once
     uint32_t epoch = 0;             // launch counter of this ctx
     uint32_t* d_sink = nullptr;     // fg_calibrate_device: the word the read-only sweep may write
+    uint64_t* d_used = nullptr;     // fg_decode_batch, zero-copy form: the entry counter (the tables themselves are pinned host memory)
     uint8_t* d_frame = nullptr;  // fg_frame_device scratch (delimiter / UTF-8 masks, block counts)
     uint64_t d_frame_cap = 0;
     uint8_t* d_bad = nullptr;    // fg_frame_decode_batch: per-frame UTF-8 verdicts

@@ -4,6 +4,8 @@
 // what a kernel does (flowgger_amd/build.py source_hash: measured HBM traffic is keyed on the kernels' own sources).
 // Replaces the per-line `decoder.decode(line)` -> `encoder.encode(..)` -> `tx.send(..)` of handle_line for a whole batch
 // (src/flowgger/splitter/line_splitter.rs:44-54).
+#include <cstddef>
+
 #include "fg_ctx.hpp"
 
 extern "C" {
@@ -127,12 +129,91 @@ int fg_measure_link(fg_ctx* ctx, uint64_t nbytes, double gbps[3]) {
     return rc;
 }
 
+// Is [p, p + n) pinned host memory that the device can address (hipHostMalloc / hipHostRegister)?  -> the device's view of p, else null.
+static const void* device_view_of_pinned(const void* p) {
+    if (!p) return nullptr;
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof a);
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();  // (pageable memory: the runtime reports an error and keeps it sticky)
+        return nullptr;
+    }
+    return a.type == hipMemoryTypeHost ? a.devicePointer : nullptr;
+}
+
+// ZERO-COPY form of fg_decode_batch: when the caller's bytes and offsets live in PINNED host memory (where a batching framer
+// accumulates them: fg_alloc_pinned) the decode kernels read them in place over the link and write every table column straight
+// into the ctx's pinned tables -- no hipMemcpy, no slices, no events: ONE launch.  The kernels stream 1 KiB per wave-instruction
+// with a 20 KiB prefetch window per wave, far more in flight than the link's latency-bandwidth product needs, so the launch runs at
+// link speed in BOTH directions at once (tools/probe/zero_copy.py, profiles/r04b_zero_copy_probe.json: GELF 153 vs 134 M lines/s,
+// LTSV 194 vs 170, cfg2 210 vs 196 against the sliced hipMemcpy pipeline below, whose uploads and downloads the runtime of this
+// platform queues on ONE copy engine: profiles/r04a_timeline_*.log, an upload and a download never in flight together).  Only the
+// entry counter stays in HBM (atomics).  Returns FG_ERR_UNSUPPORTED when the buffers do not qualify: the caller falls through.
+static int decode_batch_zero_copy(fg_ctx* ctx, fg_format fmt, const uint8_t* bytes, uint64_t nbytes, const uint64_t* offsets, uint64_t n,
+                                  fg_tables* out) {
+    if (n == 0 || (ctx->lo.flags & FG_LO_NO_ZERO_COPY)) return FG_ERR_UNSUPPORTED;
+    const uint8_t* d_bytes = (const uint8_t*)device_view_of_pinned(bytes);
+    const uint64_t* d_offsets = (const uint64_t*)device_view_of_pinned(offsets);
+    if (!d_bytes || !d_offsets || ((uintptr_t)d_bytes & 15u) != 0 || !device_view_of_pinned(bytes + nbytes - 1) ||
+        !device_view_of_pinned(offsets + n))
+        return FG_ERR_UNSUPPORTED;
+    int rc;
+    if (!ctx->d_used) FG_HIP(ctx, hipMalloc((void**)&ctx->d_used, 256));
+    uint64_t ent_cap = fmt == FG_RFC5424 ? nbytes / 16 + 1024 : nbytes / 8 + 1024;
+    if (fmt == FG_RFC3164) ent_cap = 16;  // RFC3164 produces no entries
+    const hipStream_t s = ctx->stream;
+    for (;;) {
+        if (ent_cap > 0xFFFFFFF0ull) ent_cap = 0xFFFFFFF0ull;
+        uint64_t total = 0;
+        carve(nullptr, n, ent_cap, nullptr, &total);
+        if ((rc = grow_pinned(ctx, (void**)&ctx->h_tab, &ctx->h_tab_cap, total)) != FG_OK) return rc;
+        fg_tables ht;
+        carve(ctx->h_tab, n, ent_cap, &ht, nullptr);
+        fg_tables kt = ht;  // what the kernels see: the pinned columns (their device view) and the counter in HBM
+        {
+            const uint8_t* dv = (const uint8_t*)device_view_of_pinned(ctx->h_tab);
+            if (!dv) return FG_ERR_UNSUPPORTED;
+            const ptrdiff_t delta = dv - ctx->h_tab;  // (0 under unified addressing)
+            kt.meta = (uint32_t*)((uint8_t*)ht.meta + delta);
+            kt.ts = (double*)((uint8_t*)ht.ts + delta);
+            kt.hostname = (fg_span*)((uint8_t*)ht.hostname + delta);
+            kt.appname = (fg_span*)((uint8_t*)ht.appname + delta);
+            kt.procid = (fg_span*)((uint8_t*)ht.procid + delta);
+            kt.msgid = (fg_span*)((uint8_t*)ht.msgid + delta);
+            kt.msg = (fg_span*)((uint8_t*)ht.msg + delta);
+            kt.full_msg = (fg_span*)((uint8_t*)ht.full_msg + delta);
+            kt.ent_first = (uint32_t*)((uint8_t*)ht.ent_first + delta);
+            kt.ent_count = (uint32_t*)((uint8_t*)ht.ent_count + delta);
+            kt.ent_name = (fg_span*)((uint8_t*)ht.ent_name + delta);
+            kt.ent_val = (uint64_t*)((uint8_t*)ht.ent_val + delta);
+            kt.ent_type = (uint8_t*)ht.ent_type + delta;
+            kt.ent_flags = (uint8_t*)ht.ent_flags + delta;
+        }
+        kt.ent_used = ctx->d_used;
+        if ((rc = fg_decode_frames_impl(ctx, fmt, FG_FRAME_NONE, d_bytes, nbytes, d_offsets, n, nullptr, &kt, (void*)s, true,
+                                        offsets[n] - offsets[0])) != FG_OK)
+            return rc;
+        uint64_t used = 0;
+        FG_HIP(ctx, hipMemcpyAsync(&used, ctx->d_used, 8, hipMemcpyDeviceToHost, s));
+        FG_HIP(ctx, hipStreamSynchronize(s));
+        if (used > ent_cap) {
+            if (ent_cap >= 0xFFFFFFF0ull) return FG_ERR_ENT_OVERFLOW;
+            ent_cap = used + used / 8 + 1024;
+            continue;
+        }
+        *ht.ent_used = used;
+        *out = ht;
+        return FG_OK;
+    }
+}
+
 int fg_decode_batch(fg_ctx* ctx, fg_format fmt, const uint8_t* bytes, uint64_t nbytes, const uint64_t* offsets,
                     uint64_t n, fg_tables* out) {
     if (!ctx || !out || (n && !offsets) || (nbytes && !bytes)) return FG_ERR_ARG;
     if (n && (offsets[n] > nbytes || offsets[0] > offsets[n])) return FG_ERR_ARG;
     DeviceGuard g(ctx->device);
     int rc;
+    if ((rc = decode_batch_zero_copy(ctx, fmt, bytes, nbytes, offsets, n, out)) != FG_ERR_UNSUPPORTED) return rc;
     const uint32_t slices = slice_count(nbytes, n);
     if (slices > 1 && (rc = ensure_pipeline(ctx, slices)) != FG_OK) return rc;  // (a small batch stays on the ctx's own stream)
     if (slices > 1 && !ctx->h_cnt) FG_HIP(ctx, hipHostMalloc((void**)&ctx->h_cnt, 65536, hipHostMallocDefault));

@@ -232,6 +232,7 @@ struct GroupCtx {
     uint32_t tbase = 0;     // tile byte of this lane's line
     uint32_t tlen = 0;      // bytes of the line that are in the tile, from its first byte (== its length when it is there whole)
     uint32_t last2 = 0;     // the line's last byte | the byte before it << 8 (the trims look there; 0 where the line has none)
+    uint32_t tile_cap = 0;  // LDS tile bytes of this launch (the bitmaps and a format's extra block lie behind it)
 };
 
 // The entries a wave parked in its stash -> the entry table THROUGH THE TILE: once every lane has parsed its line the tile's
@@ -607,6 +608,7 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
             // Every line of the group lies inside the tile by construction -- except a single line longer than the whole tile,
             // which is a group of its own and is parsed straight from global memory (the decoders look at o1 - a0 <= span).
             GroupCtx c{bytes, smem, bm16, o0, e1, a0, span, valid, li, (ablate & 8u) ? nullptr : stash, ablate, ent_state, PROF ? prof + 6 : nullptr};
+            c.tile_cap = tile_cap;
             if constexpr (HEAD) {
                 const uint32_t al = (uint32_t)(o0 & 15ull), len = (uint32_t)(e1 - o0);
                 c.tbase = tb + al;
@@ -696,7 +698,8 @@ struct LaunchPlan {
 template <class K>
 inline int plan_launch(K kernel, uint64_t n, uint64_t avg_len, uint32_t extra_lds, uint32_t max_tile, uint32_t stash_blocks,
                        LaunchPlan* p, const fg_launch_opts& lo, uint32_t max_lines = 64, uint32_t n_classes = 1,
-                       uint32_t (*extra_for)(uint32_t tile, uint32_t lines) = nullptr) {
+                       uint32_t (*extra_for)(uint32_t tile, uint32_t lines) = nullptr, uint32_t (*extra_tile)(uint32_t tile) = nullptr,
+                       uint32_t default_tile = 0) {
     const uint64_t window = (uint64_t)kWindowKiB * 1024u;
     // (+6.25 % + 256 B over the average group: a few sigma for the corpora at hand; a longer group just takes
     //  another pass over a restaged tile, while every KiB of LDS saved is occupancy)
@@ -711,18 +714,21 @@ inline int plan_launch(K kernel, uint64_t n, uint64_t avg_len, uint32_t extra_ld
         L = lo.lines_per_group;
         tile = clamp(tile_for(L));
     }
+    // (default_tile: a format whose LDS beyond the tile grows with it caps the tile it gets by default)
+    if (default_tile && tile > default_tile && !(lo.lines_per_group >= 1 && lo.lines_per_group <= max_lines)) tile = default_tile;
     if (lo.tile_cap >= 1024 && lo.tile_cap <= max_tile) tile = (lo.tile_cap + 1023u) / 1024u * 1024u;
     // Groups are cut BY BYTES (persistent_loop): L is only the cap on the lines of a group.  A format without per-line LDS arrays
     // takes the full wave width -- however long the lines, a group then holds as many as fit the tile; the tile of long lines
     // (fewer than 16 average lines in the window) is raised to what eight waves per CU leave each other anyway.
     if (!extra_for && !(lo.lines_per_group >= 1 && lo.lines_per_group <= max_lines)) {
-        if (L <= 16u && !(lo.tile_cap >= 1024 && lo.tile_cap <= max_tile) && tile < 18432u && max_tile >= 18432u) tile = 18432u;
+        if (L <= 16u && !(lo.tile_cap >= 1024 && lo.tile_cap <= max_tile) && tile < 18432u && max_tile >= 18432u && !default_tile) tile = 18432u;
         L = max_lines;
     }
     p->L = L;
     p->tile = tile;
     // (extra_for: LDS a format needs as a function of the tile and the lines per group, e.g. per-item arrays)
-    p->lds = tile + 64u + (tile / 16u + 16u) * 2u * (n_classes ? n_classes : 1u) + extra_lds + (extra_for ? extra_for(tile, L) : 0u);
+    p->lds = tile + 64u + (tile / 16u + 16u) * 2u * (n_classes ? n_classes : 1u) + extra_lds + (extra_for ? extra_for(tile, L) : 0u) +
+             (extra_tile ? extra_tile(tile) : 0u);
     {   // an estimate (the waves cut their ranges themselves): by lines and by bytes
         const uint64_t by_lines = (n + L - 1) / L, by_bytes = (n * avg_len + tile - 1) / tile;
         p->groups = by_lines > by_bytes ? by_lines : by_bytes;

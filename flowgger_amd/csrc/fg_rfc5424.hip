@@ -25,6 +25,7 @@
 #include <cstdlib>
 
 #include "fg_pipeline.hpp"
+#include "fg_sd2.hpp"
 #include "fg_tsfast.hpp"
 
 namespace fg {
@@ -678,27 +679,16 @@ __device__ __forceinline__ uint32_t sd_walk_tile(const Tile& T, uint32_t base, u
 // ended there; when it closes the structured data inside them, and the trims are the everyday ones (one ASCII non-blank byte at
 // each end: the line's last byte comes in last2), the result does not depend on the bytes that are not there.  Anything else
 // returns false: the caller parses the line from global memory.
-__device__ __forceinline__ bool parse_tail_sd_tile(const Tile& T, uint32_t base, uint32_t q, uint32_t len, uint32_t walk_len, uint32_t last2, Row& r,
-                                                   const DevTables& t, uint32_t* tile_w, bool* rec_ok, const uint8_t* gbytes, uint64_t o0) {
-    r.data0 = q;
-    uint32_t msg_at = 0;
-    uint32_t st = tile_w ? sd_walk_tile<SD_STASH>(T, base, q, walk_len, &msg_at, &r.n_ent, t, 0, tile_w, rec_ok)
-                         : sd_walk_tile<SD_COUNT>(T, base, q, walk_len, &msg_at, &r.n_ent, t, 0);
-    if (st != E_OK) {
-        r.n_ent = 0;
-        if (walk_len < len) return false;
-        r.status = st;
-        return true;
-    }
+// the trims behind a structured-data walk that ended at msg_at (parse_msg :163-172, full_msg :46); false = the head of the line was
+// not enough (HEAD staging): the caller parses the line from global memory
+__device__ __forceinline__ bool finish_sd_tail(const Tile& T, uint32_t base, uint32_t len, uint32_t walk_len, uint32_t last2, uint32_t msg_at, Row& r,
+                                               const uint8_t* gbytes, uint64_t o0) {
     LdsReader rd(T.w, base);
     if (walk_len < len) {
         // the trims: the message starts in the head (a run of whitespace that reaches its end is not decided here); the line's end is
         // its last byte when that is a plain one, else the few bytes behind it are looked at where they are, in global memory
         const uint32_t s = trim_start(rd, msg_at, walk_len - 8u);
-        if (s + 8u >= walk_len) {
-            r.n_ent = 0;
-            return false;
-        }
+        if (s + 8u >= walk_len) return false;
         const uint32_t last = last2 & 0xFFu;
         uint32_t e = len;
         if (!(last > 0x20u && last < 0x80u)) {
@@ -723,12 +713,33 @@ __device__ __forceinline__ bool parse_tail_sd_tile(const Tile& T, uint32_t base,
     }
     return true;
 }
+__device__ __forceinline__ bool parse_tail_sd_tile(const Tile& T, uint32_t base, uint32_t q, uint32_t len, uint32_t walk_len, uint32_t last2, Row& r,
+                                                   const DevTables& t, uint32_t* tile_w, bool* rec_ok, const uint8_t* gbytes, uint64_t o0) {
+    r.data0 = q;
+    uint32_t msg_at = 0;
+    uint32_t st = tile_w ? sd_walk_tile<SD_STASH>(T, base, q, walk_len, &msg_at, &r.n_ent, t, 0, tile_w, rec_ok)
+                         : sd_walk_tile<SD_COUNT>(T, base, q, walk_len, &msg_at, &r.n_ent, t, 0);
+    if (st != E_OK) {
+        r.n_ent = 0;
+        if (walk_len < len) return false;
+        r.status = st;
+        return true;
+    }
+    if (!finish_sd_tail(T, base, len, walk_len, last2, msg_at, r, gbytes, o0)) {
+        r.n_ent = 0;
+        return false;
+    }
+    return true;
+}
 
 constexpr uint32_t kShortSdTail = 64;  // bytes after the header up to which a lone SD tail is walked byte-wise
 
 // The format policy of the streaming pipeline (fg_pipeline.hpp): stage A builds the SPACE bitmap;
 // decode() = stage B + SD entries + the table row for ONE line group whose tile is in LDS.
-template <bool HEAD>
+// SDX = true: the instantiation for batches of lines long enough to carry structured data (the launcher: average >= 320 bytes): the LDS
+// behind the tile holds a second bitmap and the scratch of the pair-parallel walk (fg_sd2.hpp); structured data takes that walk, and
+// the (rare) lines it hands back are parsed from global memory.  SDX = false is byte for byte the kernel of round 3.
+template <bool HEAD, bool SDX = false>
 struct Rfc5424FormatT {
     // no stage-A bitmap: the fast path classifies the header bytes itself, the SD walker's
     // quote bitmap is built on demand (rebuild_bitmap) for groups that hold SD lines
@@ -787,7 +798,24 @@ struct Rfc5424FormatT {
     const uint64_t sd_ballot = __ballot(sd_any);
     const bool group_has_sd = __any(sd_any && len - f.d0 > kShortSdTail) || __popcll(sd_ballot) > 4;  // wave-uniform
     const bool sd_lane = sd_any && group_has_sd;
-    if (group_has_sd) {
+    sd2::Lds SL{};
+    sd2::LineIn sin{false, 0u, 0u, 0u, false};
+    sd2::LineOut slo{false, E_OK, 0u, 0u, 0u};
+    bool sd2_ran = false;  // wave-uniform
+    if constexpr (SDX) {
+        if (group_has_sd) {
+            const uint32_t stride16 = c.tile_cap / 16u + 16u;
+            SL = sd2::carve(smem, bm16, c.tile_cap, reinterpret_cast<uint8_t*>(bm16 + 2u * stride16));
+            __syncthreads();
+            const bool chain = sd2::classify_tile(SL, span);
+            __syncthreads();
+            sin = sd2::LineIn{sd_lane && (in_tile || head_only), base, f.d0, walk_len, in_tile};
+            if (!chain) {
+                slo = sd2::group_walk(SL, span, sin);
+                sd2_ran = true;
+            }
+        }
+    } else if (group_has_sd) {
         __syncthreads();
         rebuild_bitmap<QuoteClass>(smem, bm16, span >> 4);
         __syncthreads();
@@ -797,7 +825,20 @@ struct Rfc5424FormatT {
     if (valid) {
         if (!(route & R_GENERIC)) {
             if (r.status == E_OK) {
-                if (sd_lane) {
+                if (SDX && sd_lane) {
+                    // the pair-parallel walk has the line's verdict, or hands it back: then the whole line again, from global memory
+                    // (its copy in the tile carries the walk's bookkeeping in the header bytes)
+                    redo = !slo.handled;
+                    if (slo.handled) {
+                        r.data0 = f.d0;
+                        if (slo.status != E_OK) {
+                            r.status = slo.status;
+                        } else {
+                            r.n_ent = slo.n_ent;
+                            redo = !finish_sd_tail(T, base, len, walk_len, c.last2, slo.msg_at, r, bytes, o0);
+                        }
+                    }
+                } else if (sd_lane) {
                     redo = !parse_tail_sd_tile(T, base, f.d0, len, walk_len, c.last2, r, t, stash ? tile_w : nullptr, &rec_ok, bytes, o0);
                 } else if (head_only && (route & R_TAIL)) {
                     redo = true;  // (a short bracketed tail or garbage in a long line)
@@ -839,6 +880,7 @@ struct Rfc5424FormatT {
             }
         }
         if (redo) {
+            slo.handled = false;  // (its entries are written by the global walk below, not by the pair lanes)
             from_global = true;
             r = Row();
 #pragma unroll
@@ -861,7 +903,11 @@ struct Rfc5424FormatT {
             r.n_ent = 0;
         }
         first = r.n_ent != 0 ? mine : 0u;
-        if (r.n_ent != 0 && !(ablate & 4u)) {
+        const bool by_pairs = SDX && sd_lane && slo.handled && !from_global;  // this lane's entries are written by the pair lanes
+        if constexpr (SDX) {
+            if (sd2_ran) sd2::group_emit(SL, t, sin, slo, by_pairs && !ea.overflow && !(ablate & 4u), first);
+        }
+        if (r.n_ent != 0 && !(ablate & 4u) && !by_pairs) {
             uint32_t msg_at, cnt;
             if (sd_lane && !from_global && stash && rec_ok) {
                 // the records sit in the line's own (consumed) bytes: four in flight before the first store
@@ -922,13 +968,13 @@ struct Rfc5424FormatT {
 using Rfc5424Format = Rfc5424FormatT<false>;
 
 // HEAD = true: the instantiation for LONG lines (only the head of every line is staged, fg_pipeline.hpp)
-template <int NB, bool PROF, bool HEAD = false>
+template <int NB, bool PROF, bool HEAD = false, bool SDX = false>
 __global__ __launch_bounds__(kWave, 2) void k_rfc5424(const uint8_t* __restrict__ bytes,
                                                      const uint64_t* __restrict__ offsets, uint64_t n, DevTables t,
                                                      uint32_t tile_cap, uint32_t L, uint64_t groups,
                                                      unsigned long long* prof, uint64_t* stash_base, FrameArgs fr) {
-    Rfc5424FormatT<HEAD> fmt;
-    persistent_loop<NB, PROF, Rfc5424FormatT<HEAD>, HEAD>(bytes, offsets, n, t, tile_cap, L, groups, prof, stash_base, fmt, fr);
+    Rfc5424FormatT<HEAD, SDX> fmt;
+    persistent_loop<NB, PROF, Rfc5424FormatT<HEAD, SDX>, HEAD>(bytes, offsets, n, t, tile_cap, L, groups, prof, stash_base, fmt, fr);
 }
 
 }  // namespace fg
@@ -946,31 +992,50 @@ extern "C" int fg_launch_rfc5424(const uint8_t* d_bytes, const uint64_t* d_offse
     fg::LaunchPlan p;
     // long lines: only the head of every line is staged (persistent_loop<..., HEAD>): the message is never looked into
     const bool head = (lo->flags & FG_LO_FORCE_HEAD) || (avg_len >= 768u && !(lo->flags & FG_LO_NO_HEAD));
-    if (head ? fg::plan_launch(fg::k_rfc5424<fg::kWindowKiB, false, true>, n, avg_len < fg::kHeadCap ? avg_len : fg::kHeadCap, 0u, 57344u,
-                               stash ? stash_blocks : 0u, &p, *lo)
-             : fg::plan_launch(fg::k_rfc5424<fg::kWindowKiB, false>, n, avg_len, 0u, 57344u, stash ? stash_blocks : 0u, &p, *lo))
-        return -1;
+    // lines long enough to carry structured data: the instantiation with the pair-parallel walk (its LDS scratch costs the headline
+    // configuration -- 254-byte lines without structured data -- a wave per CU, so short lines keep the kernel they had)
+    const bool sdx = (lo->flags & FG_LO_SD_PAIRS) || (avg_len >= 320u && !(lo->flags & FG_LO_SD_WALK));
+    const uint64_t plan_len = head ? (avg_len < fg::kHeadCap ? avg_len : fg::kHeadCap) : avg_len;
+    const uint32_t sb = stash ? stash_blocks : 0u;
+    int prc;
+    if (sdx)
+        prc = head ? fg::plan_launch(fg::k_rfc5424<fg::kWindowKiB, false, true, true>, n, plan_len, 0u, 57344u, sb, &p, *lo, 64, 2, nullptr,
+                                     fg::sd2::extra_bytes, 16384u)
+                   : fg::plan_launch(fg::k_rfc5424<fg::kWindowKiB, false, false, true>, n, plan_len, 0u, 57344u, sb, &p, *lo, 64, 2, nullptr,
+                                     fg::sd2::extra_bytes, 16384u);
+    else
+        prc = head ? fg::plan_launch(fg::k_rfc5424<fg::kWindowKiB, false, true>, n, plan_len, 0u, 57344u, sb, &p, *lo)
+                   : fg::plan_launch(fg::k_rfc5424<fg::kWindowKiB, false>, n, plan_len, 0u, 57344u, sb, &p, *lo);
+    if (prc) return -1;
     if (stash_blocks == 0) stash = nullptr;
     dim3 grid(p.blocks), block(fg::kWave);
+    const fg::FrameArgs fr{strip, line_bad};
+    unsigned long long* const no_prof = nullptr;
+#define FG_LAUNCH_5424(PROF_, HEAD_, SDX_, prof_ptr)                                                                                       \
+    hipLaunchKernelGGL((fg::k_rfc5424<fg::kWindowKiB, PROF_, HEAD_, SDX_>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L, \
+                       p.chunk, prof_ptr, stash, fr)
 #if defined(FG_PROF_BUILD)
     if (fg::prof_requested()) {
         fg::ProfRun pr;
         if (!pr.begin(stream)) return -1;
-        if (head)
-            hipLaunchKernelGGL((fg::k_rfc5424<fg::kWindowKiB, true, true>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile,
-                               p.L, p.chunk, pr.d, stash, fg::FrameArgs{strip, line_bad});
-        else
-            hipLaunchKernelGGL((fg::k_rfc5424<fg::kWindowKiB, true>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile,
-                               p.L, p.chunk, pr.d, stash, fg::FrameArgs{strip, line_bad});
-        pr.end(stream, head ? "rfc5424 (head)" : "rfc5424", p);
+        if (sdx) {
+            if (head) FG_LAUNCH_5424(true, true, true, pr.d);
+            else FG_LAUNCH_5424(true, false, true, pr.d);
+        } else {
+            if (head) FG_LAUNCH_5424(true, true, false, pr.d);
+            else FG_LAUNCH_5424(true, false, false, pr.d);
+        }
+        pr.end(stream, head ? (sdx ? "rfc5424 (head, pairs)" : "rfc5424 (head)") : (sdx ? "rfc5424 (pairs)" : "rfc5424"), p);
         return (int)hipGetLastError();
     }
 #endif
-    if (head)
-        hipLaunchKernelGGL((fg::k_rfc5424<fg::kWindowKiB, false, true>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L,
-                           p.chunk, (unsigned long long*)nullptr, stash, fg::FrameArgs{strip, line_bad});
-    else
-        hipLaunchKernelGGL((fg::k_rfc5424<fg::kWindowKiB, false>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L,
-                           p.chunk, (unsigned long long*)nullptr, stash, fg::FrameArgs{strip, line_bad});
+    if (sdx) {
+        if (head) FG_LAUNCH_5424(false, true, true, no_prof);
+        else FG_LAUNCH_5424(false, false, true, no_prof);
+    } else {
+        if (head) FG_LAUNCH_5424(false, true, false, no_prof);
+        else FG_LAUNCH_5424(false, false, false, no_prof);
+    }
+#undef FG_LAUNCH_5424
     return (int)hipGetLastError();
 }

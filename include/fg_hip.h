@@ -197,7 +197,11 @@ enum {
     FG_LO_GELF_GENERIC = 1,        /* GELF: the run-time-geometry kernel even where the constant-geometry instantiation applies */
     FG_LO_TRANSCODE_ONE_PIECE = 2, /* fg_transcode_batch / fg_frame_decode_batch: never slice a large batch over the streams */
     FG_LO_NO_HEAD = 4,             /* RFC5424: stage whole lines even when they are long (the head-only kernel is the default from 768 B) */
-    FG_LO_FORCE_HEAD = 8           /* RFC5424: the head-only kernel for lines of any length (parity sweeps) */
+    FG_LO_FORCE_HEAD = 8,          /* RFC5424: the head-only kernel for lines of any length (parity sweeps) */
+    FG_LO_SD_WALK = 16,            /* RFC5424: the lane-per-line structured-data walker even for long lines (the pair-parallel walk is the
+                                      default from an average of 320 bytes per line) */
+    FG_LO_SD_PAIRS = 32,           /* RFC5424: the pair-parallel structured-data walk for lines of any length (parity sweeps) */
+    FG_LO_NO_ZERO_COPY = 64        /* fg_decode_batch: the sliced hipMemcpy pipeline even when the caller's buffers are pinned (A/B, tests) */
 };
 
 /* Create a decoder context on HIP device `device` (replaces XDecoder::new(&Config),
@@ -254,12 +258,13 @@ int fg_decode_frames_device(fg_ctx* ctx, fg_format fmt, fg_framing framing, cons
                             uint64_t nbytes, const uint64_t* d_offsets, uint64_t n,
                             const uint8_t* d_bad_utf8, const fg_tables* tables, void* stream);
 
-/* HOST-BUFFER decode: copies the batch to the GPU, decodes, copies the tables back into
- * ctx-owned pinned host memory (`out` is filled with host pointers valid until the next call
- * on this ctx or fg_destroy).  Synchronous.  Entry-table capacity grows automatically.
- * The batch is processed as ~32 MiB slices on two streams so that H2D, kernels and D2H overlap;
- * it runs at link speed when `bytes` / `offsets` live in pinned memory (fg_alloc_pinned: the
- * batching framer accumulates lines there), at the runtime's staged-copy speed otherwise. */
+/* HOST-BUFFER decode: the batch is decoded into ctx-owned pinned host memory (`out` is filled with host pointers valid until
+ * the next call on this ctx or fg_destroy).  Synchronous.  Entry-table capacity grows automatically.
+ *   `bytes` AND `offsets` in PINNED memory (fg_alloc_pinned / hipHostRegister: where the batching framer accumulates lines),
+ *   bytes 16-byte aligned: ZERO-COPY -- one launch, the kernels read the lines in place over the link and write the table columns
+ *   straight into the pinned tables, both directions of the link busy at once;
+ *   anything else: the batch goes up as ~32 MiB slices on three streams (H2D, kernels, D2H of the tables), at the runtime's
+ *   staged-copy speed for pageable memory. */
 int fg_decode_batch(fg_ctx* ctx, fg_format fmt, const uint8_t* bytes, uint64_t nbytes,
                     const uint64_t* offsets, uint64_t n, fg_tables* out);
 

@@ -7,6 +7,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <vector>
 
 #define __device__
 #define __host__
@@ -55,12 +56,44 @@ static inline hipError_t hipMalloc(void** p, size_t n) {
     return *p ? hipSuccess : hipErrorOutOfMemory;
 }
 static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+// pinned allocations are remembered: hipPointerGetAttributes tells pinned host memory (the zero-copy host path) from pageable
+namespace fakehip {
+struct Range { const char* p; size_t n; };
+inline std::vector<Range>& pinned() { static std::vector<Range> v; return v; }
+}  // namespace fakehip
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) {
     *p = malloc(n ? n : 1);
-    if (*p) memset(*p, 0xAB, n);
+    if (*p) {
+        memset(*p, 0xAB, n);
+        fakehip::pinned().push_back({(const char*)*p, n ? n : 1});
+    }
     return *p ? hipSuccess : hipErrorOutOfMemory;
 }
-static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipHostFree(void* p) {
+    auto& v = fakehip::pinned();
+    for (size_t i = 0; i < v.size(); ++i)
+        if (v[i].p == (const char*)p) {
+            v.erase(v.begin() + (long)i);
+            break;
+        }
+    free(p);
+    return hipSuccess;
+}
+enum hipMemoryType { hipMemoryTypeUnregistered = 0, hipMemoryTypeHost = 1, hipMemoryTypeDevice = 2 };
+struct hipPointerAttribute_t { hipMemoryType type; int device; void* devicePointer; void* hostPointer; };
+static inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* p) {
+    for (const auto& r : fakehip::pinned())
+        if ((const char*)p >= r.p && (const char*)p < r.p + r.n) {
+            a->type = hipMemoryTypeHost;
+            a->device = 0;
+            a->devicePointer = const_cast<void*>(p);
+            a->hostPointer = const_cast<void*>(p);
+            return hipSuccess;
+        }
+    a->type = hipMemoryTypeUnregistered;
+    a->devicePointer = nullptr;
+    return hipErrorInvalidValue;
+}
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind k) {
     memmove(d, s, n);
     ++fakehip::copies();

@@ -82,6 +82,29 @@ def test_rfc5424_sd_whole_line_mutation_fuzz(oracle):
         both_paths(d2, oracle, lines[:4000], host=False)
 
 
+@pytest.mark.parametrize("opts", [dict(sd_pairs=True), dict(sd_walk=True), dict(sd_pairs=True, tile_cap=6144, lines_per_group=9),
+                                  dict(sd_pairs=True, force_head=True), dict(sd_pairs=True, tile_cap=36864), dict(sd_pairs=True, tile_cap=4096)])
+def test_pair_parallel_sd_walk_variants(oracle, opts):
+    """The pair-parallel structured-data walk (fg_sd2.hpp, the default from 320-byte lines) and the lane-per-line walker it replaced
+    must both give the oracle's Records -- on the structured-data corpus, the short-line corpus (where the walk is forced on), long
+    lines, the hand-written shapes of the CPU suite and mutated lines, under several tile geometries."""
+    from test_sd2_cpu import HDR
+
+    rng = np.random.default_rng(7)
+    dec = RFC5424Decoder()
+    dec.set_launch_opts(**opts)
+    base = synth.rfc5424_lines(20_000, cfg=4, sd=True)
+    lines = base + synth.rfc5424_lines(5000, cfg=2) + synth.rfc5424_lines(3000, cfg=5, sd=True, long_tail=True)
+    bodies = [b'[a b="c"] m', b'[a b="c"][d e="f"] m', b'[a b="c"]', b'[a b="c"]x', b'[a b="c"][d ] m', b'[a b="c"c="d"] m', b'[a "b="c"] m', b'[id ] m',
+              b'[id] m', b'[a b= "c"] m', b'[a b="c" m', b'[a b="c', b'[a b="c\\"] m', b'[a  b="c"] m', b'[a b="c"  ] m', b'[a b="c"] [d e="f"] m',
+              b'[a b="' + b"\\" * 16 + b'"] m', b'[a b="' + b"\\" * 17 + b'" c="d"] m', b'[a ' + b" ".join(b'k%d="v%d"' % (k, k) for k in range(70)) + b'] m',
+              b'[a b="c"] "quoted" message "with" quotes', b'[a b="c" d="e] f"] m', b'[nospace]', b'[a b="c"]]', b'[a \tb="c"] m']
+    lines += [HDR + b for b in bodies] * 3
+    lines += mutate_py(base[:6000], rng, SD_ALPHABET)
+    order = rng.permutation(len(lines))
+    both_paths(dec, oracle, [lines[i] for i in order], host=False)
+
+
 LTSV_ALPHABET = [b"\t", b":", b"[", b"]", b"0", b"9", b"-", b"+", b".", b"e", b" ", b"", b"\t\t", b"::", b"time:", b"host:", b"level:", b"\tx",
                  b"\tlevel:7", b"\tlevel:8", b"\tcounter:18446744073709551616", b"\tdone:TRUE", b"\tmean:1e400", b"\tscore:-0",
                  "é".encode(), IDEO.encode(), b"T", b"Z", b"/"]

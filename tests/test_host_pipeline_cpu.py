@@ -139,6 +139,55 @@ def test_sliced_decode_batch_equals_one_launch(fake):
     c.close()
 
 
+def test_pinned_buffers_take_the_zero_copy_form(fake):
+    """bytes + offsets in pinned memory: ONE launch reads them in place and writes the pinned tables -- no table byte and no line byte
+    crosses the link by hipMemcpy (only the 8-byte entry counter comes back); the result is what the device entry point gives.  A too
+    small entry table is retried with what the counter asked for; FG_LO_NO_ZERO_COPY and pageable buffers take the sliced pipeline."""
+    rng = np.random.default_rng(4)
+    lines = corpus(150_000, rng) + corpus(30_000, rng, 30, 40, 300)  # (the tail needs more entries than one per 16 bytes)
+    data, offsets = pack(lines)
+    n = len(lines)
+    fake.fg_alloc_pinned.argtypes = [u64, C.POINTER(vp)]
+    fake.fg_free_pinned.argtypes = [vp]
+    pb, po = vp(), vp()
+    assert fake.fg_alloc_pinned(data.size + 64, C.byref(pb)) == 0 and fake.fg_alloc_pinned((n + 1) * 8, C.byref(po)) == 0
+    hb = np.ctypeslib.as_array(C.cast(pb, C.POINTER(C.c_uint8)), (data.size + 64,))
+    ho = np.ctypeslib.as_array(C.cast(po, C.POINTER(C.c_uint64)), (n + 1,))
+    hb[:data.size] = data
+    ho[:] = offsets
+    want = device_reference(fake, data, offsets, data.size // 4 + 1024)
+    c = Ctx(fake)
+    st = L.fg_tables()
+    cnt = (C.c_ulonglong * 3)()
+    fake.fgf_launches(1)
+    fake.fgf_counters(cnt, 1)
+    assert fake.fg_decode_batch(c.h, 0, pb, data.size, po, n, C.byref(st)) == 0
+    launches = fake.fgf_launches(1)
+    fake.fgf_counters(cnt, 1)
+    got = snapshot(st, n)
+    assert got["used"] == want["used"] and not (got["meta"] & 0xFF == 0xFE).any()
+    same_lines(got, want, n)
+    assert launches <= 2 and cnt[1] <= 64 and cnt[2] <= 64, (launches, int(cnt[1]), int(cnt[2]))  # (two launches: the entry-table retry)
+    # the same pinned buffers with the flag: the sliced pipeline (bytes cross by hipMemcpy), same result
+    lo = L.fg_launch_opts(0, 0, 0, 0, 0, L.FG_LO_NO_ZERO_COPY, 0)
+    assert fake.fg_set_launch_opts(c.h, C.byref(lo)) == 0
+    fake.fgf_counters(cnt, 1)
+    assert fake.fg_decode_batch(c.h, 0, pb, data.size, po, n, C.byref(st)) == 0
+    fake.fgf_counters(cnt, 1)
+    assert cnt[1] >= data.size
+    same_lines(snapshot(st, n), want, n)
+    # pageable bytes, pinned offsets: not zero-copy
+    assert fake.fg_set_launch_opts(c.h, None) == 0
+    fake.fgf_counters(cnt, 1)
+    assert fake.fg_decode_batch(c.h, 0, data.ctypes.data, data.size, po, n, C.byref(st)) == 0
+    fake.fgf_counters(cnt, 1)
+    assert cnt[1] >= data.size
+    same_lines(snapshot(st, n), want, n)
+    c.close()
+    fake.fg_free_pinned(pb)
+    fake.fg_free_pinned(po)
+
+
 def test_a_few_short_lines_described_inside_a_large_buffer(fake):
     """fg_shard_plan gives EMPTY leading slices when the lines cover fewer bytes than there are slices (a few short
     lines -- or only empty ones -- whose offsets live in a >= 32 MiB buffer): the first slice WITH rows must upload its own start
