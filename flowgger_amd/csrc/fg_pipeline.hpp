@@ -699,7 +699,7 @@ template <class K>
 inline int plan_launch(K kernel, uint64_t n, uint64_t avg_len, uint32_t extra_lds, uint32_t max_tile, uint32_t stash_blocks,
                        LaunchPlan* p, const fg_launch_opts& lo, uint32_t max_lines = 64, uint32_t n_classes = 1,
                        uint32_t (*extra_for)(uint32_t tile, uint32_t lines) = nullptr, uint32_t (*extra_tile)(uint32_t tile) = nullptr,
-                       uint32_t default_tile = 0) {
+                       uint32_t default_tile = 0, uint32_t default_chunk = 0) {
     const uint64_t window = (uint64_t)kWindowKiB * 1024u;
     // (+6.25 % + 256 B over the average group: a few sigma for the corpora at hand; a longer group just takes
     //  another pass over a restaged tile, while every KiB of LDS saved is occupancy)
@@ -748,7 +748,8 @@ inline int plan_launch(K kernel, uint64_t n, uint64_t avg_len, uint32_t extra_ld
     // tools/sweep.py, 4 M lines: cfg4 1058 / 1150 / 974 M lines/s at 256 / 512 / 1024 -- the grid's 1792 waves need a few rounds
     // of chunks each to finish together) -- provided the batch gives every wave at least two chunks; else what spreads the batch
     // over the grid
-    const uint64_t full = (avg_len ? (uint64_t)p->tile / avg_len : p->L) >= p->L ? 256u : 512u;
+    // (default_chunk: a format's own choice -- the pair-parallel structured-data kernel: 1466 vs 1394 M lines/s at 1024 vs 512 lines)
+    const uint64_t full = default_chunk ? default_chunk : (avg_len ? (uint64_t)p->tile / avg_len : p->L) >= p->L ? 256u : 512u;
     uint64_t chunk = lo.chunk_lines >= p->L && lo.chunk_lines <= 65536u ? lo.chunk_lines : full;
     if (n < blocks * 2u * chunk) {
         chunk = (n + blocks - 1) / (blocks ? blocks : 1);

@@ -739,12 +739,13 @@ constexpr uint32_t kShortSdTail = 64;  // bytes after the header up to which a l
 // SDX = true: the instantiation for batches of lines long enough to carry structured data (the launcher: average >= 320 bytes): the LDS
 // behind the tile holds a second bitmap and the scratch of the pair-parallel walk (fg_sd2.hpp); structured data takes that walk, and
 // the (rare) lines it hands back are parsed from global memory.  SDX = false is byte for byte the kernel of round 3.
-template <bool HEAD, bool SDX = false>
+template <bool HEAD, bool SDX = false, bool PROF = false>
 struct Rfc5424FormatT {
     // no stage-A bitmap: the fast path classifies the header bytes itself, the SD walker's
     // quote bitmap is built on demand (rebuild_bitmap) for groups that hold SD lines
     static constexpr uint32_t kClasses = 0;
     static __device__ __forceinline__ void classify_store(const uint4&, uint16_t*, uint32_t, uint32_t, uint32_t) {}
+    unsigned long long* pacc = nullptr;  // measurement build: the wave's phase clocks (LDS), flushed by the kernel at its end
 
     __device__ __forceinline__ RowOut decode(const GroupCtx& c, const DevTables& t) const {
     const uint8_t* __restrict__ bytes = c.bytes;
@@ -771,6 +772,16 @@ struct Rfc5424FormatT {
     uint32_t* tile_w = reinterpret_cast<uint32_t*>(const_cast<uint8_t*>(smem));
     bool rec_ok = false;       // the structured-data walk left the line's entries as records in the line's own tile bytes
     Tile T{reinterpret_cast<const uint32_t*>(smem), reinterpret_cast<const uint32_t*>(bm16)};
+    // measurement build: cycles of  0 header fast path  1 chunk pass  2-5 the pair-parallel walk (fg_sd2.hpp)  6 routes + trims
+    //                               7 entry slots  8 emit / entry stores  9 row
+    uint64_t pc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tk = PROF ? wv::clock() : 0;
+    auto tick = [&](int k) {
+        if (PROF) {
+            const uint64_t now = wv::clock();
+            pc[k] += now - tk;
+            tk = now;
+        }
+    };
     // ---- 1. straight-line fast path for every line of the tile --------------------------------
     uint32_t route = 0;
     Fast f{};
@@ -798,9 +809,10 @@ struct Rfc5424FormatT {
     const uint64_t sd_ballot = __ballot(sd_any);
     const bool group_has_sd = __any(sd_any && len - f.d0 > kShortSdTail) || __popcll(sd_ballot) > 4;  // wave-uniform
     const bool sd_lane = sd_any && group_has_sd;
+    tick(0);
     sd2::Lds SL{};
     sd2::LineIn sin{false, 0u, 0u, 0u, false};
-    sd2::LineOut slo{false, E_OK, 0u, 0u, 0u};
+    sd2::LineOut slo{false, 0u, false, E_OK, 0u, 0u, 0u};
     bool sd2_ran = false;  // wave-uniform
     if constexpr (SDX) {
         if (group_has_sd) {
@@ -809,11 +821,13 @@ struct Rfc5424FormatT {
             __syncthreads();
             const bool chain = sd2::classify_tile(SL, span);
             __syncthreads();
+            tick(1);
             sin = sd2::LineIn{sd_lane && (in_tile || head_only), base, f.d0, walk_len, in_tile};
             if (!chain) {
-                slo = sd2::group_walk(SL, span, sin);
+                slo = sd2::group_walk<PROF>(SL, span, sin, pc);
                 sd2_ran = true;
             }
+            tk = PROF ? wv::clock() : 0;
         }
     } else if (group_has_sd) {
         __syncthreads();
@@ -893,10 +907,12 @@ struct Rfc5424FormatT {
         }
     }
 
+    tick(6);
     // ---- structured-data entries: wave prefix sum + one atomic per wave ---------------------
     uint32_t first = 0;
     {
         const EntAlloc ea = alloc_entries_ex(t, r.n_ent, c.ent_state);
+        tick(7);
         const uint32_t mine = (ea.overflow || ea.total == 0u) ? 0u : ea.s.at(ea.ex);
         if (ea.overflow) {
             r.status = FG_ST_OVERFLOW;
@@ -950,6 +966,7 @@ struct Rfc5424FormatT {
         }
     }
 
+    tick(8);
     // ---- table row (stored by the caller: one coalesced store per column) --------------------
     RowOut o;
     const bool ok = r.status == E_OK;
@@ -959,6 +976,9 @@ struct Rfc5424FormatT {
     for (int k = 0; k < 6; ++k) o.span[k] = ok ? fg_span{r.off[k], r.len[k]} : fg_span{0, FG_NONE};
     o.first = first;
     o.count = r.n_ent;
+    tick(9);
+    if (PROF && pacc && lane == 0)
+        for (int k = 0; k < 10; ++k) pacc[k] += (unsigned long long)pc[k];  // (the wave's own LDS words: a hot global atomic per phase WOULD BE the profile)
     return o;
     }
 };
@@ -973,8 +993,18 @@ __global__ __launch_bounds__(kWave, 2) void k_rfc5424(const uint8_t* __restrict_
                                                      const uint64_t* __restrict__ offsets, uint64_t n, DevTables t,
                                                      uint32_t tile_cap, uint32_t L, uint64_t groups,
                                                      unsigned long long* prof, uint64_t* stash_base, FrameArgs fr) {
-    Rfc5424FormatT<HEAD, SDX> fmt;
-    persistent_loop<NB, PROF, Rfc5424FormatT<HEAD, SDX>, HEAD>(bytes, offsets, n, t, tile_cap, L, groups, prof, stash_base, fmt, fr);
+    Rfc5424FormatT<HEAD, SDX, PROF> fmt;
+    if constexpr (PROF) {
+        __shared__ unsigned long long pacc[10];
+        if (threadIdx.x < 10) pacc[threadIdx.x] = 0ull;
+        fmt.pacc = pacc;
+        __syncthreads();
+        persistent_loop<NB, PROF, Rfc5424FormatT<HEAD, SDX, PROF>, HEAD>(bytes, offsets, n, t, tile_cap, L, groups, prof, stash_base, fmt, fr);
+        __syncthreads();
+        if (prof && threadIdx.x < 10) atomicAdd(&prof[6 + threadIdx.x], pacc[threadIdx.x]);
+    } else {
+        persistent_loop<NB, PROF, Rfc5424FormatT<HEAD, SDX, PROF>, HEAD>(bytes, offsets, n, t, tile_cap, L, groups, prof, stash_base, fmt, fr);
+    }
 }
 
 }  // namespace fg
@@ -999,10 +1029,11 @@ extern "C" int fg_launch_rfc5424(const uint8_t* d_bytes, const uint64_t* d_offse
     const uint32_t sb = stash ? stash_blocks : 0u;
     int prc;
     if (sdx)
+        // (default tile from the same-box sweeps, profiles/r04g_sweep_*: 12 KiB -- eight waves per CU -- for whole lines and for heads)
         prc = head ? fg::plan_launch(fg::k_rfc5424<fg::kWindowKiB, false, true, true>, n, plan_len, 0u, 57344u, sb, &p, *lo, 64, 2, nullptr,
-                                     fg::sd2::extra_bytes, 16384u)
+                                     fg::sd2::extra_bytes, 12288u, 1024u)
                    : fg::plan_launch(fg::k_rfc5424<fg::kWindowKiB, false, false, true>, n, plan_len, 0u, 57344u, sb, &p, *lo, 64, 2, nullptr,
-                                     fg::sd2::extra_bytes, 16384u);
+                                     fg::sd2::extra_bytes, 12288u, 1024u);
     else
         prc = head ? fg::plan_launch(fg::k_rfc5424<fg::kWindowKiB, false, true>, n, plan_len, 0u, 57344u, sb, &p, *lo)
                    : fg::plan_launch(fg::k_rfc5424<fg::kWindowKiB, false>, n, plan_len, 0u, 57344u, sb, &p, *lo);

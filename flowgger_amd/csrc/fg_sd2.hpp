@@ -42,12 +42,6 @@ constexpr uint32_t kNone = 0xFFFFFFFFu;
 // ---------------------------------------------------------------------------------------------
 // LDS beyond the tile and its two bitmaps (real quotes, backslashes): the "extra" block
 // ---------------------------------------------------------------------------------------------
-struct Own {  // one per pair slot of the current trip (P1 / emit): the line that owns the slot
-    uint32_t k_hb;     // line (lane) | tile offset of the line's info block << 16
-    uint32_t cum_i0;   // first pair slot of the line | index of its first quote in items[] << 16
-    uint32_t s0_e;     // tile position of the line's '[' | end of the line's bytes in the tile << 16
-    uint32_t base_np;  // tile position of the line's first byte | pair slots of the line << 16
-};
 struct Lds {
     wv::Bytes T;        // tile bytes
     uint32_t* tile_w;   // ... writable (the lines' info blocks live in their own, already parsed header bytes)
@@ -56,14 +50,13 @@ struct Lds {
     uint16_t* items;    // [item_cap + 2] tile position of every real quote; items[-1] exists (one pad entry in front)
     uint16_t* qcnt;     // [words + 2] real quotes before each 64-byte word
     uint16_t* rec;      // [item_cap / 2 + 4] per pair slot: name_len | esc << 6 | elem << 7 | kind << 8 | payload << 10
-    Own* own;           // [64]
+    uint16_t* owner;    // [item_cap / 2 + 64] per pair slot: tile offset of its line's info block (built once per tile: no
+                        // barrier inside the slot loops)
     uint16_t* slow;     // [slow_cap] P2 list: pair slot (tile-wide)
-    uint8_t* slow_k;    // [slow_cap] ... its line
-    uint32_t* cnt;      // [4] list length, spare
     uint32_t item_cap, slow_cap;
 };
 // info block of a line, six dwords at the line's first 4-byte boundary (the header bytes are dead once the fast path has the row)
-enum { I_TV = 0, I_EL0 = 1, I_EL1 = 2, I_FIRST = 3, I_I0CUM = 4, I_S0E = 5, kInfoWords = 6 };
+enum { I_TV = 0, I_EL0 = 1, I_EL1 = 2, I_FIRST = 3, I_I0CUM = 4, I_S0E = 5, I_BASEW = 6, kInfoWords = 7 };  // (28 bytes: d0 >= 32)
 enum : uint32_t { K_PAIR = 0, K_TERM = 1, K_ERR = 2, K_BAIL = 3 };
 
 FG_WVH uint32_t up8(uint32_t v) { return (v + 7u) & ~7u; }
@@ -71,7 +64,7 @@ FG_WVH uint32_t item_cap_for(uint32_t tile_cap) { return tile_cap / 16u; }  // o
 FG_WVH uint32_t slow_cap_for(uint32_t tile_cap) { return tile_cap / 64u < 128u ? 128u : tile_cap / 64u; }
 FG_WVH uint32_t extra_bytes(uint32_t tile_cap) {
     const uint32_t words = tile_cap / 64u + 2u, ic = item_cap_for(tile_cap), sc = slow_cap_for(tile_cap);
-    return up8((ic + 4u) * 2u) + up8(words * 2u) + up8((ic / 2u + 4u) * 2u) + 64u * 16u + up8(sc * 2u) + up8(sc) + 16u;
+    return up8((ic + 4u) * 2u) + up8(words * 2u) + up8((ic / 2u + 4u) * 2u) + up8((ic / 2u + 64u) * 2u) + up8(sc * 2u);
 }
 FG_WV Lds carve(const uint8_t* tile, uint16_t* bm16, uint32_t tile_cap, uint8_t* extra) {
     Lds L;
@@ -84,13 +77,11 @@ FG_WV Lds carve(const uint8_t* tile, uint16_t* bm16, uint32_t tile_cap, uint8_t*
     L.slow_cap = slow_cap_for(tile_cap);
     const uint32_t words = tile_cap / 64u + 2u;
     uint8_t* p = extra;
-    L.own = reinterpret_cast<Own*>(p); p += 64u * 16u;
-    L.cnt = reinterpret_cast<uint32_t*>(p); p += 16u;
     L.items = reinterpret_cast<uint16_t*>(p) + 1; p += up8((L.item_cap + 4u) * 2u);
     L.qcnt = reinterpret_cast<uint16_t*>(p); p += up8(words * 2u);
     L.rec = reinterpret_cast<uint16_t*>(p); p += up8((L.item_cap / 2u + 4u) * 2u);
     L.slow = reinterpret_cast<uint16_t*>(p); p += up8(L.slow_cap * 2u);
-    L.slow_k = p;
+    L.owner = reinterpret_cast<uint16_t*>(p);
     return L;
 }
 
@@ -278,6 +269,40 @@ FG_WV Event gap_walk(const wv::Bytes& T, uint32_t from, bool at_elem, uint32_t o
     return ev;
 }
 
+// The stretch in front of an opening quote that OPENS AN ELEMENT in the canonical spelling -- `[id name=` (the line's first stretch,
+// from the '[' on) or `][id name=` (behind a closing quote) -- proven from byte-class masks of the 48 bytes before the quote instead
+// of the byte-wise walk (a serial walk of ~18 bytes cost the group a quarter of its time: profiles/r04f_phases_cfg4_pairs_v2.log):
+// the id is whatever stands before the stretch's ONLY space (rfc5424_decoder.rs:175-177: anything but a space), the name a run of
+// name characters up to the '='.  Returns the name's length, 0 = not that shape (the exact walk decides).  gs = the stretch's first
+// byte, first = it is the line's first stretch.
+FG_WV uint32_t elem_start_shape(const wv::Bytes& T, uint32_t gs, uint32_t open, bool first) {
+    const uint32_t g = open - gs;
+    if (g > 48u || g < 4u || open < 48u) return 0u;
+    uint64_t nm = 0, sp = 0;
+    uint32_t last = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 3u; ++k) {
+        uint32_t w[4];
+        T.load16(open - 48u + 16u * k, w);
+        nm |= (uint64_t)wv::gather16(name_flags(w[0]), name_flags(w[1]), name_flags(w[2]), name_flags(w[3])) << (16u * k);
+        sp |= (uint64_t)wv::gather16(wv::eq_flags(w[0], 0x20202020u), wv::eq_flags(w[1], 0x20202020u), wv::eq_flags(w[2], 0x20202020u),
+                                     wv::eq_flags(w[3], 0x20202020u)) << (16u * k);
+        last = w[3];
+    }
+    // bit i <=> byte open - 48 + i; the stretch = bits [48 - g, 48); byte 47 must be the '='
+    const uint64_t not_nm = (~nm << 17) | (1ull << 16);      // bit 63 <=> byte 46 is no name character
+    const uint32_t nl = wv::clz64(not_nm);                   // name characters that end at byte 46 (at most 47)
+    const uint32_t pre = first ? 1u : 2u;                    // `[` / `][`
+    if ((last >> 24) != '=' || nl == 0u || nl > 62u || nl + 2u + pre > g) return 0u;
+    const uint32_t spb = 46u - nl;                           // the byte in front of the name: the ONE space of the stretch
+    const uint64_t in = (~0ull << (48u - g)) & ((1ull << 48) - 1ull);
+    if ((sp & in) != (1ull << spb)) return 0u;
+    const uint64_t head = T.load8(gs);
+    const uint32_t b0 = (uint32_t)head & 0xFFu, b1 = (uint32_t)(head >> 8) & 0xFFu;
+    if (first ? b0 != '[' : (b0 != ']' || b1 != '[')) return 0u;
+    return nl;
+}
+
 // ---------------------------------------------------------------------------------------------
 // What the lane that owns a line hands in and gets back
 // ---------------------------------------------------------------------------------------------
@@ -289,6 +314,8 @@ struct LineIn {
     bool whole;       // the tile holds the whole line
 };
 struct LineOut {
+    bool tracked;     // the line took part in the walk (it has an info block in its header bytes: group_emit looks at it)
+    uint32_t slots;   // wave-uniform: pair slots of the tile
     bool handled;     // false: the caller walks the line byte-wise
     uint32_t status;  // E_OK or the reference's error
     uint32_t n_pairs, n_ent;
@@ -310,30 +337,44 @@ FG_WV void pair_quotes(const Lds& L, uint32_t i0, uint32_t j, uint32_t s0, uint3
 }
 FG_WV uint32_t rec_index(uint32_t i0, uint32_t j) { return ((i0 + (i0 & 1u)) >> 1) + j; }
 
-// The slots of the current trip: every line lane whose slots reach into [p0, p0 + 64) marks the first of them; every slot lane
-// then finds its line.  Returns false for a lane whose slot does not exist.
-FG_WV bool map_slots(const Lds& L, uint32_t p0, uint32_t total, bool line_has, uint32_t cum, uint32_t np, const Own& mine, Own* out, uint32_t* j) {
+// slot -> line, ONCE per tile: every line marks its first pair slot with the tile offset of its info block, then the marks are
+// spread to the right, 64 slots per row (ballot + one cross-lane read per row, the last owner carried from row to row).
+FG_WV void build_owner(const Lds& L, uint32_t total, bool line_has, uint32_t cum, uint32_t np, uint32_t hb) {
     const uint32_t lane = wv::lane();
-    L.own[lane].k_hb = kNone;
+    for (uint32_t p0 = 0; p0 < total; p0 += wv::kLanes) L.owner[p0 + lane] = 0xFFFFu;
     wv::sync();
-    if (line_has && np != 0u && cum < p0 + wv::kLanes && cum + np > p0) L.own[cum > p0 ? cum - p0 : 0u] = mine;
+    if (line_has && np != 0u) L.owner[cum] = (uint16_t)hb;
     wv::sync();
-    const uint64_t marks = wv::ballot(L.own[lane].k_hb != kNone);
-    const bool has = p0 + lane < total;
-    const uint64_t upto = marks & (lane == 63u ? ~0ull : ((2ull << lane) - 1ull));
-    const uint32_t src = upto ? 63u - wv::clz64(upto) : 0u;
-    *out = L.own[src];
-    *j = p0 + lane - (out->cum_i0 & 0xFFFFu);
-    wv::sync();  // (everybody has read before the next trip clears)
-    return has && upto != 0ull;
+    uint32_t carry = 0;
+    for (uint32_t p0 = 0; p0 < total; p0 += wv::kLanes) {
+        const uint32_t v = L.owner[p0 + lane];
+        const uint64_t marks = wv::ballot(v != 0xFFFFu);
+        const uint64_t upto = marks & (lane == 63u ? ~0ull : ((2ull << lane) - 1ull));
+        const uint32_t src = upto ? 63u - wv::clz64(upto) : 0u;
+        const uint32_t got = wv::shfl(v, src);
+        const uint32_t val = upto ? got : carry;
+        L.owner[p0 + lane] = (uint16_t)val;
+        carry = wv::bcast(val, 63u);
+    }
+    wv::sync();
 }
 
 // ---------------------------------------------------------------------------------------------
 // The group step.  Called by all 64 lanes in wave-uniform control flow, after classify_tile().
 // ---------------------------------------------------------------------------------------------
-FG_WV LineOut group_walk(const Lds& L, uint32_t span, const LineIn& in) {
+// (PROF: measurement build -- cycles of  [2] word + line pass + slot table  [3] P1  [4] P2  [5] verdict  are added to pc[])
+template <bool PROF = false>
+FG_WV LineOut group_walk(const Lds& L, uint32_t span, const LineIn& in, uint64_t* pc = nullptr) {
     const uint32_t lane = wv::lane();
-    LineOut out{false, E_OK, 0u, 0u, 0u};
+    uint64_t tk = PROF ? wv::clock() : 0;
+    auto tick = [&](int k) {
+        if (PROF) {
+            const uint64_t now = wv::clock();
+            pc[k] += now - tk;
+            tk = now;
+        }
+    };
+    LineOut out{false, 0u, false, E_OK, 0u, 0u, 0u};
     const uint64_t* Q = reinterpret_cast<const uint64_t*>(L.bmQ);
 
     // ================= word pass: quote counts per word, positions of all real quotes =================
@@ -361,7 +402,6 @@ FG_WV LineOut group_walk(const Lds& L, uint32_t span, const LineIn& in) {
             L.qcnt[nwords] = (uint16_t)n_items;
             L.qcnt[nwords + 1u] = (uint16_t)n_items;
             L.items[-1] = 0;
-            L.cnt[0] = 0u;
         }
     }
     wv::sync();
@@ -388,20 +428,24 @@ FG_WV LineOut group_walk(const Lds& L, uint32_t span, const LineIn& in) {
         info[I_FIRST] = 0u;
         info[I_I0CUM] = i0 | (cum << 16);
         info[I_S0E] = s0 | (e << 16);
+        info[I_BASEW] = in.base | ((in.whole ? 1u : 0u) << 16);
     }
-    const Own mine{lane | (hb << 16), cum | (i0 << 16), s0 | (e << 16), in.base | (np << 16)};
-    wv::sync();
+    out.tracked = line_has;
+    out.slots = total;
+    build_owner(L, total, line_has, cum, np, hb);  // (ends with a barrier: the info blocks are visible too)
 
+    tick(2);
     // ================= P1: every pair slot of the tile, 64 per trip =================
+    uint32_t n_slow_all = 0;  // wave-uniform: the list's length lives in a register (no counter in LDS, no barrier per trip)
     for (uint32_t p0 = 0; p0 < total; p0 += wv::kLanes) {
-        Own o;
-        uint32_t j;
-        const bool act = map_slots(L, p0, total, line_has, cum, np, mine, &o, &j);
+        const bool act = p0 + lane < total;
         bool to_slow = false;
-        uint32_t k = 0;
         if (act) {
-            k = o.k_hb & 0xFFFFu;
-            const uint32_t ohb = o.k_hb >> 16, oi0 = o.cum_i0 >> 16, os0 = o.s0_e & 0xFFFFu, oe = o.s0_e >> 16;
+            const uint32_t ohb = L.owner[p0 + lane];
+            const uint32_t* oinfo = L.tile_w + (ohb >> 2);
+            const uint32_t i0cum = oinfo[I_I0CUM], s0e = oinfo[I_S0E];
+            const uint32_t oi0 = i0cum & 0xFFFFu, os0 = s0e & 0xFFFFu, oe = s0e >> 16;
+            const uint32_t j = p0 + lane - (i0cum >> 16);
             uint32_t prevc, open, close;
             pair_quotes(L, oi0, j, os0, &prevc, &open, &close);
             const uint32_t gs = prevc + 1u, g = open - gs;
@@ -438,43 +482,37 @@ FG_WV LineOut group_walk(const Lds& L, uint32_t span, const LineIn& in) {
         // the slots that need the exact walk, appended to the list
         const uint64_t sm = wv::ballot(to_slow);
         if (sm) {
-            const uint32_t at = L.cnt[0] + wv::mbcnt(sm);
-            if (to_slow) {
-                if (at < L.slow_cap) {  // (a list that overflows gives the whole tile back: list_overflow below)
-                    L.slow[at] = (uint16_t)(p0 + lane);
-                    L.slow_k[at] = (uint8_t)k;
-                }
-            }
-            wv::sync();
-            if (lane == 0u) L.cnt[0] = L.cnt[0] + wv::popc64(sm);
-            wv::sync();
+            const uint32_t at = n_slow_all + wv::mbcnt(sm);
+            if (to_slow && at < L.slow_cap) L.slow[at] = (uint16_t)(p0 + lane);  // (a list that overflows gives the whole tile back)
+            n_slow_all += wv::popc64(sm);
         }
     }
     wv::sync();
 
+    tick(3);
     // ================= P2: the exact state machine over the listed slots =================
     // (the shuffles are executed by all lanes: the per-lane work is written without early exits)
     {
-        const uint32_t n_slow_all = L.cnt[0];
         const bool list_overflow = n_slow_all > L.slow_cap;
         const uint32_t n_slow = list_overflow ? L.slow_cap : n_slow_all;
         for (uint32_t q0 = 0; q0 < n_slow; q0 += wv::kLanes) {
             const uint32_t q = q0 + lane;
             const bool act = q < n_slow;
-            const uint32_t p = act ? L.slow[q] : 0u, k = act ? L.slow_k[q] : 0u;
-            const uint32_t khb = (wv::shfl(in.base, k) + 3u) & ~3u;
-            const bool kwhole = wv::shfl(in.whole ? 1u : 0u, k) != 0u;
             if (act) {
-                uint32_t* info = L.tile_w + (khb >> 2);
+                const uint32_t p = L.slow[q];
+                uint32_t* info = L.tile_w + ((uint32_t)L.owner[p] >> 2);
                 const uint32_t i0cum = info[I_I0CUM], s0e = info[I_S0E];
+                const bool kwhole = (info[I_BASEW] >> 16) & 1u;
                 const uint32_t oi0 = i0cum & 0xFFFFu, ocum = i0cum >> 16, os0 = s0e & 0xFFFFu, oe = s0e >> 16;
                 const uint32_t j = p - ocum;
                 uint32_t prevc, open, close;
                 pair_quotes(L, oi0, j, os0, &prevc, &open, &close);
                 const uint32_t r = rec_index(oi0, j);
                 const uint32_t esc = (L.rec[r] >> 6) & 1u;
-                // (1) the bytes between the closing quote before and this opening quote
-                Event ev = gap_walk(L.T, j ? prevc + 1u : os0, j == 0u, open, oe, kwhole);
+                // (1) the bytes between the closing quote before and this opening quote: the everyday element start from masks, anything
+                //     else by the exact walk
+                Event ev{K_PAIR, E_OK, 0u, elem_start_shape(L.T, j ? prevc + 1u : os0, open, j == 0u), 1u};
+                if (ev.name_len == 0u) ev = gap_walk(L.T, j ? prevc + 1u : os0, j == 0u, open, oe, kwhole);
                 if (ev.kind == K_PAIR) {
                     L.rec[r] = (uint16_t)(ev.name_len | (esc << 6) | (ev.elem << 7) | (K_PAIR << 8));
                     if (ev.elem) wv::lds_or(&info[j < 32u ? I_EL0 : I_EL1], 1u << (j & 31u));
@@ -509,6 +547,7 @@ FG_WV LineOut group_walk(const Lds& L, uint32_t span, const LineIn& in) {
             }
         }
         wv::sync();
+        tick(4);
         // ================= verdict (lane = line) =================
         if (line_has && !list_overflow) {
             uint32_t* info = L.tile_w + (hb >> 2);
@@ -583,6 +622,7 @@ FG_WV LineOut group_walk(const Lds& L, uint32_t span, const LineIn& in) {
         }
     }
     wv::sync();
+    tick(5);
     return out;
 }
 
@@ -592,43 +632,38 @@ FG_WV LineOut group_walk(const Lds& L, uint32_t span, const LineIn& in) {
 // ---------------------------------------------------------------------------------------------
 FG_WV void group_emit(const Lds& L, const DevTables& t, const LineIn& in, const LineOut& lo, bool emit_line, uint32_t first) {
     const uint32_t lane = wv::lane();
-    const bool line_has = in.sd && lo.handled && lo.status == E_OK && emit_line && lo.n_pairs != 0u;
-    const uint32_t hb = (in.base + 3u) & ~3u;
-    uint32_t np = line_has ? lo.n_pairs : 0u, i0 = 0;
-    if (line_has) {
-        uint32_t* info = L.tile_w + (hb >> 2);
+    if (lo.tracked) {  // this lane's line has an info block: the pairs to emit (none unless it was handled, is Ok and got its slots)
+        uint32_t* info = L.tile_w + (((in.base + 3u) & ~3u) >> 2);
         info[I_FIRST] = first;
-        i0 = info[I_I0CUM] & 0xFFFFu;
+        if (!(lo.handled && lo.status == E_OK && emit_line)) info[I_TV] = 0u;
     }
-    uint32_t total = 0;
-    const uint32_t cum = wv::excl_sum(np, &total);
-    const Own mine{lane | (hb << 16), cum | (i0 << 16), (in.base + in.d0) | ((in.base + in.wlen) << 16), in.base | (np << 16)};
     wv::sync();
+    const uint32_t total = lo.slots;  // wave-uniform: the pair slots of the tile, as P1 walked them
     for (uint32_t p0 = 0; p0 < total; p0 += wv::kLanes) {
-        Own o;
-        uint32_t j;
-        const bool act = map_slots(L, p0, total, line_has, cum, np, mine, &o, &j);
-        if (act) {
-            const uint32_t ohb = o.k_hb >> 16, oi0 = o.cum_i0 >> 16, os0 = o.s0_e & 0xFFFFu, obase = o.base_np & 0xFFFFu;
-            const uint32_t* info = L.tile_w + (ohb >> 2);
-            const uint64_t elmask = (uint64_t)info[I_EL0] | ((uint64_t)info[I_EL1] << 32);
-            const uint32_t slot = info[I_FIRST] + j + wv::popc64(elmask & below(j + 1u));
-            uint32_t prevc, open, close;
-            pair_quotes(L, oi0, j, os0, &prevc, &open, &close);
-            const uint32_t r = L.rec[rec_index(oi0, j)];
-            const uint32_t nl = r & 63u, esc = (r >> 6) & 1u, elem = (r >> 7) & 1u;
-            const uint32_t name_s = open - 1u - nl;
-            t.ent_name[slot] = fg_span{name_s - obase, nl};
-            t.ent_val[slot] = (uint64_t)(open + 1u - obase) | ((uint64_t)(close - open - 1u) << 32);
-            t.ent_type[slot] = FG_T_STRING;
-            t.ent_flags[slot] = esc ? FG_EF_VAL_ESC : 0;
-            if (elem) {  // the element this pair opens: `[id name=` (the line's first) or `][id name=`
-                const uint32_t id_s = j ? prevc + 3u : os0 + 1u;
-                t.ent_name[slot - 1u] = fg_span{id_s - obase, name_s - 1u - id_s};
-                t.ent_val[slot - 1u] = 0;
-                t.ent_type[slot - 1u] = FG_T_SDID;
-                t.ent_flags[slot - 1u] = 0;
-            }
+        if (p0 + lane >= total) continue;
+        const uint32_t ohb = L.owner[p0 + lane];
+        const uint32_t* info = L.tile_w + (ohb >> 2);
+        const uint32_t i0cum = info[I_I0CUM];
+        const uint32_t j = p0 + lane - (i0cum >> 16);
+        if (j >= info[I_TV]) continue;  // (I_TV: the line's pairs, 0 for a line that is not emitted)
+        const uint32_t oi0 = i0cum & 0xFFFFu, os0 = info[I_S0E] & 0xFFFFu, obase = info[I_BASEW] & 0xFFFFu;
+        const uint64_t elmask = (uint64_t)info[I_EL0] | ((uint64_t)info[I_EL1] << 32);
+        const uint32_t slot = info[I_FIRST] + j + wv::popc64(elmask & below(j + 1u));
+        uint32_t prevc, open, close;
+        pair_quotes(L, oi0, j, os0, &prevc, &open, &close);
+        const uint32_t r = L.rec[rec_index(oi0, j)];
+        const uint32_t nl = r & 63u, esc = (r >> 6) & 1u, elem = (r >> 7) & 1u;
+        const uint32_t name_s = open - 1u - nl;
+        t.ent_name[slot] = fg_span{name_s - obase, nl};
+        t.ent_val[slot] = (uint64_t)(open + 1u - obase) | ((uint64_t)(close - open - 1u) << 32);
+        t.ent_type[slot] = FG_T_STRING;
+        t.ent_flags[slot] = esc ? FG_EF_VAL_ESC : 0;
+        if (elem) {  // the element this pair opens: `[id name=` (the line's first) or `][id name=`
+            const uint32_t id_s = j ? prevc + 3u : os0 + 1u;
+            t.ent_name[slot - 1u] = fg_span{id_s - obase, name_s - 1u - id_s};
+            t.ent_val[slot - 1u] = 0;
+            t.ent_type[slot - 1u] = FG_T_SDID;
+            t.ent_flags[slot - 1u] = 0;
         }
     }
 }

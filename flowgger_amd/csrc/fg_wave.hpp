@@ -213,12 +213,14 @@ FG_WV Slots wave_alloc(unsigned long long* ent_used, uint64_t ent_cap, uint32_t*
     return r;
 }
 FG_WVH uint32_t alloc_chunk_for(uint64_t ent_cap, uint32_t waves) {
-    // a wave strands what is left of its LAST chunk: keep the worst case (every wave, a whole chunk) below 1/64 of the table.
+    // a wave strands what is left of its LAST chunk: keep the worst case (every wave, a whole chunk) below 1/16 of the table.
+    // (Round 4: 1/64 and at most 1024 slots meant an atomic on ONE word every third group of the structured-data kernel -- 9 per
+    // microsecond chip-wide, each waiting ~10 us in the queue of that word: 16 % of the group's time, profiles/r04g_phases_*.)
     // A table too small for chunks of 256 slots gets EXACT reservations (chunk 0: every request takes what it needs from the
     // global word and nothing is stranded) -- a caller that sized the table tightly must not see FG_ST_OVERFLOW because of
-    // slots parked in 64-slot chunks, and a table that small is not where the counter is contended.
-    uint64_t c = ent_cap / (64ull * (waves ? waves : 1u));
-    if (c > 1024u) c = 1024u;
+    // slots parked in chunks, and a table that small is not where the counter is contended.
+    uint64_t c = ent_cap / (16ull * (waves ? waves : 1u));
+    if (c > 4096u) c = 4096u;
     if (c < 256u) c = 0u;
     return (uint32_t)c;
 }

@@ -128,9 +128,9 @@ typedef struct fg_tables {
                             chunks (one atomic per chunk instead of one per line group), so this is >= the sum of ent_count and
                             the range [0, ent_used) contains slots no row refers to (uninitialised holes): always walk the
                             entries through ent_first / ent_count.  Sizing ent_cap: a table with fewer than 256 slots per
-                            resident wave x 64 (ent_cap < ~34 M on an MI355X) gets exact reservations -- no slack needed
-                            beyond the entries themselves; above that, up to ent_cap / 64 slots plus one line's entries per
-                            1024-slot chunk can be stranded: size from the input bytes (the host-buffer entry points use
+                            resident wave x 16 (ent_cap < ~8 M on an MI355X) gets exact reservations -- no slack needed
+                            beyond the entries themselves; above that, up to ent_cap / 16 slots plus one line's entries per
+                            chunk (at most 4096 slots) can be stranded: size from the input bytes (the host-buffer entry points use
                             nbytes / 16 for RFC5424, nbytes / 8 otherwise) and retry with ent_used + ent_used / 8 on
                             FG_ERR_ENT_OVERFLOW, as they do. */
 } fg_tables;

@@ -156,7 +156,7 @@ extern "C" long fgs2_walk(const uint8_t* bytes, uint64_t nbytes, const uint64_t*
                 }
                 const bool chain = span ? sd2::classify_tile(lds, span) : true;
                 wv::sync();
-                sd2::LineOut o{false, 0u, 0u, 0u, 0u};
+                sd2::LineOut o{false, 0u, false, 0u, 0u, 0u, 0u};
                 if (!chain) o = sd2::group_walk(lds, span, in);
                 if (lane == 0u) bailed = chain;
                 // slots: a plain wave prefix sum over the handled Ok lines
