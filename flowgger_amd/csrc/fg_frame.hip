@@ -242,3 +242,21 @@ extern "C" int fg_launch_frame_slice(const uint8_t* d_bytes, uint64_t nbytes, ui
     *d_total_out = pref + blk1;
     return (int)hipGetLastError();
 }
+
+// One 8-byte word from device memory into ANY device-addressable memory (a pinned host word included) by a kernel: the sliced host
+// paths bring their per-slice counters back this way, because a hipMemcpy of 8 bytes queues on the same copy engine as the 32 MiB
+// uploads that were issued ahead of it and would wait for all of them (profiles/r04a_timeline_*).
+namespace fg {
+__global__ void k_poke64(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst) {
+    if (threadIdx.x == 0) {
+        const uint64_t v = *src;
+        __atomic_store_n(dst, v, __ATOMIC_RELAXED);
+        __threadfence_system();
+    }
+}
+}  // namespace fg
+extern "C" int fg_launch_poke64(const uint64_t* d_src, uint64_t* dst_devview, hipStream_t stream) {
+    hipLaunchKernelGGL(fg::k_poke64, dim3(1), dim3(64), 0, stream, d_src, dst_devview);
+    return (int)hipGetLastError();
+}
+

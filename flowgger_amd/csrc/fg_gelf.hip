@@ -570,7 +570,7 @@ struct GelfFormat {
         const uint32_t base = (uint32_t)(c.o0 - c.a0);
         gelf2::Lds L = gelf2::carve(c.smem, c.bm16, tile_cap, extra, lines);
         L.ent_state = c.ent_state;
-        L.alloc_chunk = wv::alloc_chunk_for(t.ent_cap, gridDim.x);
+        L.alloc_chunk = wv::alloc_chunk_for(t.ent_cap, gridDim.x, t.n);
         const bool tile_lane = c.valid && in_tile && lane < lines && !(c.ablate & 4u);
         const gelf2::LineOut f = c.phase ? gelf2::decode_tile<true>(L, c.span, tile_lane, base, len, t, pacc)
                                          : gelf2::decode_tile<false>(L, c.span, tile_lane, base, len, t);

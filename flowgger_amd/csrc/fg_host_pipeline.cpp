@@ -141,6 +141,8 @@ static const void* device_view_of_pinned(const void* p) {
     return a.type == hipMemoryTypeHost ? a.devicePointer : nullptr;
 }
 
+static int pinned_tables_for_kernels(fg_ctx* ctx, const fg_tables& ht, fg_tables* kt);
+
 // ZERO-COPY form of fg_decode_batch: when the caller's bytes and offsets live in PINNED host memory (where a batching framer
 // accumulates them: fg_alloc_pinned) the decode kernels read them in place over the link and write every table column straight
 // into the ctx's pinned tables -- no hipMemcpy, no slices, no events: ONE launch.  The kernels stream 1 KiB per wave-instruction
@@ -158,7 +160,6 @@ static int decode_batch_zero_copy(fg_ctx* ctx, fg_format fmt, const uint8_t* byt
         !device_view_of_pinned(offsets + n))
         return FG_ERR_UNSUPPORTED;
     int rc;
-    if (!ctx->d_used) FG_HIP(ctx, hipMalloc((void**)&ctx->d_used, 256));
     uint64_t ent_cap = fmt == FG_RFC5424 ? nbytes / 16 + 1024 : nbytes / 8 + 1024;
     if (fmt == FG_RFC3164) ent_cap = 16;  // RFC3164 produces no entries
     const hipStream_t s = ctx->stream;
@@ -169,27 +170,8 @@ static int decode_batch_zero_copy(fg_ctx* ctx, fg_format fmt, const uint8_t* byt
         if ((rc = grow_pinned(ctx, (void**)&ctx->h_tab, &ctx->h_tab_cap, total)) != FG_OK) return rc;
         fg_tables ht;
         carve(ctx->h_tab, n, ent_cap, &ht, nullptr);
-        fg_tables kt = ht;  // what the kernels see: the pinned columns (their device view) and the counter in HBM
-        {
-            const uint8_t* dv = (const uint8_t*)device_view_of_pinned(ctx->h_tab);
-            if (!dv) return FG_ERR_UNSUPPORTED;
-            const ptrdiff_t delta = dv - ctx->h_tab;  // (0 under unified addressing)
-            kt.meta = (uint32_t*)((uint8_t*)ht.meta + delta);
-            kt.ts = (double*)((uint8_t*)ht.ts + delta);
-            kt.hostname = (fg_span*)((uint8_t*)ht.hostname + delta);
-            kt.appname = (fg_span*)((uint8_t*)ht.appname + delta);
-            kt.procid = (fg_span*)((uint8_t*)ht.procid + delta);
-            kt.msgid = (fg_span*)((uint8_t*)ht.msgid + delta);
-            kt.msg = (fg_span*)((uint8_t*)ht.msg + delta);
-            kt.full_msg = (fg_span*)((uint8_t*)ht.full_msg + delta);
-            kt.ent_first = (uint32_t*)((uint8_t*)ht.ent_first + delta);
-            kt.ent_count = (uint32_t*)((uint8_t*)ht.ent_count + delta);
-            kt.ent_name = (fg_span*)((uint8_t*)ht.ent_name + delta);
-            kt.ent_val = (uint64_t*)((uint8_t*)ht.ent_val + delta);
-            kt.ent_type = (uint8_t*)ht.ent_type + delta;
-            kt.ent_flags = (uint8_t*)ht.ent_flags + delta;
-        }
-        kt.ent_used = ctx->d_used;
+        fg_tables kt;  // what the kernels see: the pinned columns (their device view) and the counter in HBM
+        if ((rc = pinned_tables_for_kernels(ctx, ht, &kt)) != FG_OK) return rc;
         if ((rc = fg_decode_frames_impl(ctx, fmt, FG_FRAME_NONE, d_bytes, nbytes, d_offsets, n, nullptr, &kt, (void*)s, true,
                                         offsets[n] - offsets[0])) != FG_OK)
             return rc;
@@ -447,10 +429,40 @@ static int frame_decode_one_piece(fg_ctx* ctx, fg_format fmt, fg_framing framing
     }
 }
 
+// the kernels' view of tables carved from the ctx's PINNED host block (zero-copy output): every column pointer translated to the
+// device's view of that memory, the entry counter in HBM (atomics)
+static int pinned_tables_for_kernels(fg_ctx* ctx, const fg_tables& ht, fg_tables* kt) {
+    const uint8_t* dv = (const uint8_t*)device_view_of_pinned(ctx->h_tab);
+    if (!dv) return FG_ERR_UNSUPPORTED;
+    if (!ctx->d_used) FG_HIP(ctx, hipMalloc((void**)&ctx->d_used, 256));
+    const ptrdiff_t delta = dv - ctx->h_tab;  // (0 under unified addressing)
+    *kt = ht;
+    kt->meta = (uint32_t*)((uint8_t*)ht.meta + delta);
+    kt->ts = (double*)((uint8_t*)ht.ts + delta);
+    kt->hostname = (fg_span*)((uint8_t*)ht.hostname + delta);
+    kt->appname = (fg_span*)((uint8_t*)ht.appname + delta);
+    kt->procid = (fg_span*)((uint8_t*)ht.procid + delta);
+    kt->msgid = (fg_span*)((uint8_t*)ht.msgid + delta);
+    kt->msg = (fg_span*)((uint8_t*)ht.msg + delta);
+    kt->full_msg = (fg_span*)((uint8_t*)ht.full_msg + delta);
+    kt->ent_first = (uint32_t*)((uint8_t*)ht.ent_first + delta);
+    kt->ent_count = (uint32_t*)((uint8_t*)ht.ent_count + delta);
+    kt->ent_name = (fg_span*)((uint8_t*)ht.ent_name + delta);
+    kt->ent_val = (uint64_t*)((uint8_t*)ht.ent_val + delta);
+    kt->ent_type = (uint8_t*)ht.ent_type + delta;
+    kt->ent_flags = (uint8_t*)ht.ent_flags + delta;
+    kt->ent_used = ctx->d_used;
+    return FG_OK;
+}
+
 // fg_frame_decode_batch for a LARGE raw chunk: the chunk crosses the link in slices (multiples of the framing kernels' 16 KiB
 // block) on the upload stream; as soon as a slice is there it is framed (delimiter ranks continue where the slice before stopped),
-// its frame count comes back to the host through a pinned word, the frames that END in it are decoded, and their rows + offsets go
-// back on the download stream -- all while the next slices are still on the link.  The host never frames, never uploads offsets.
+// its frame count comes back to the host through a pinned word, and the frames that END in it are decoded -- all while the next
+// slices are still on the link.  The host never frames, never uploads offsets.  Round 4: the decode kernels write the table
+// columns STRAIGHT INTO THE PINNED HOST TABLES (zero-copy output) and the per-slice counters come back by a one-thread kernel, so
+// the copy engine carries nothing but the uploads -- on this platform a device -> host hipMemcpy queues behind every upload issued
+// before it (profiles/r04a_timeline_*: an upload and a download were never in flight together), which is what held the GELF and
+// LTSV corpora at the SUM of their two directions.  Only the frame offsets (8 bytes per frame) are still copied.
 // Tables are sized from what the ctx's last chunk held; a chunk that outgrows the estimate (or the entry table) returns
 // FG_ERR_UNSUPPORTED and takes the one-piece path, which counts first.
 static int frame_decode_sliced(fg_ctx* ctx, fg_format fmt, fg_framing framing, const uint8_t* bytes, uint64_t nbytes, int final,
@@ -480,15 +492,16 @@ static int frame_decode_sliced(fg_ctx* ctx, fg_format fmt, fg_framing framing, c
     if ((rc = grow_dev(ctx, (void**)&ctx->d_frame, &ctx->d_frame_cap, fg_frame_scratch_bytes(nbytes))) != FG_OK) return rc;
     if ((rc = grow_pinned(ctx, (void**)&ctx->h_off, &ctx->h_off_cap, (cap + 2) * 8)) != FG_OK) return rc;
     if (!ctx->h_cnt) FG_HIP(ctx, hipHostMalloc((void**)&ctx->h_cnt, 65536, hipHostMallocDefault));
-    if (slices + 2 > 4096) return FG_ERR_UNSUPPORTED;  // (h_cnt: frame counts in the first half, entry counters in the second)
+    if (slices + 2 > 4096) return FG_ERR_UNSUPPORTED;
+    uint64_t* const cnt_dv = (uint64_t*)const_cast<void*>(device_view_of_pinned(ctx->h_cnt));
+    if (!cnt_dv) return FG_ERR_UNSUPPORTED;
     uint64_t tab_bytes = 0;
     carve(nullptr, cap, ent_cap, nullptr, &tab_bytes);
-    if ((rc = grow_dev(ctx, (void**)&ctx->d_tab, &ctx->d_tab_cap, tab_bytes)) != FG_OK) return rc;
     if ((rc = grow_pinned(ctx, (void**)&ctx->h_tab, &ctx->h_tab_cap, tab_bytes)) != FG_OK) return rc;
-    fg_tables dt, ht;
-    carve(ctx->d_tab, cap, ent_cap, &dt, nullptr);
+    fg_tables ht, kt;
     carve(ctx->h_tab, cap, ent_cap, &ht, nullptr);
-    FG_HIP(ctx, hipMemsetAsync(dt.ent_used, 0, 8, s_run));
+    if ((rc = pinned_tables_for_kernels(ctx, ht, &kt)) != FG_OK) return rc;
+    FG_HIP(ctx, hipMemsetAsync(kt.ent_used, 0, 8, s_run));
     FG_HIP(ctx, hipMemsetAsync(ctx->d_bad, 0, cap + 1, s_run));
     const uint32_t delim = framing == FG_FRAME_LINE ? 0x0Au : 0x00u;
     std::vector<hipEvent_t>& ev = ctx->ev_slice;
@@ -499,63 +512,35 @@ static int frame_decode_sliced(fg_ctx* ctx, fg_format fmt, fg_framing framing, c
         if (k + 1 == slices) FG_HIP(ctx, hipMemsetAsync(ctx->d_bytes + nbytes, 0, up(nbytes, 16) + 16 - nbytes, s_up));
         FG_HIP(ctx, hipEventRecord(ev[2 * k], s_up));
     }
-    // frame slice k once it is there, bring its cumulative frame count back (all asynchronous)
+    // frame slice k once it is there; its cumulative frame count lands in a pinned word (all asynchronous)
     auto enqueue = [&](uint32_t k) -> int {
         const uint64_t b0 = (uint64_t)k * slice, b1 = k + 1 == slices ? nbytes : b0 + slice;
         FG_HIP(ctx, hipStreamWaitEvent(s_run, ev[2 * k], 0));
         uint64_t* d_total = nullptr;
         const uint64_t blk0 = b0 / blk, blk1 = k + 1 == slices ? nblk_total : b1 / blk;
-        const int lrc = fg_launch_frame_slice(ctx->d_bytes, nbytes, delim, ctx->d_frame, ctx->d_offsets, ctx->d_bad, cap, blk0, blk1, &d_total, s_run);
+        int lrc = fg_launch_frame_slice(ctx->d_bytes, nbytes, delim, ctx->d_frame, ctx->d_offsets, ctx->d_bad, cap, blk0, blk1, &d_total, s_run);
+        if (lrc == 0) lrc = fg_launch_poke64(d_total, cnt_dv + k, s_run);
         if (lrc != 0) {
             ctx->last_hip = lrc;
             return FG_ERR_HIP;
         }
-        FG_HIP(ctx, hipMemcpyAsync(ctx->h_cnt + k, d_total, 8, hipMemcpyDeviceToHost, s_run));
         FG_HIP(ctx, hipEventRecord(ev[2 * k + 1], s_run));
         return FG_OK;
     };
     uint64_t done = 0;  // frames decoded so far
-    // The entry columns come back per slice as well: after a slice's decode the entry counter goes into a pinned word, and two
-    // iterations later -- the frame-count event the host waits for then was queued behind it -- the entries between two counter
-    // values are copied on the download stream, while later slices are still on the link.  RFC5424 only: measured (profiles/
-    // r03y_e2e_*.json, 4 M lines per call) the structured-data corpus goes from 63 to 90 M lines/s with it, while the GELF and LTSV
-    // corpora got SLOWER on this path (78 -> 46, 108 -> 87 M lines/s; not understood yet) -- their entries come back at the end.
-    const bool early = fmt == FG_RFC5424;
-    uint64_t* const ent_cnt = ctx->h_cnt + 4096;
-    uint64_t ent_done = 0;
-    auto count_entries = [&](uint32_t k) -> int {
-        if (early) FG_HIP(ctx, hipMemcpyAsync(ent_cnt + k, dt.ent_used, 8, hipMemcpyDeviceToHost, s_run));
-        return FG_OK;
-    };
-    auto download_entries = [&](uint64_t e1) -> int {  // entries [ent_done, e1)
-        if (e1 <= ent_done) return FG_OK;
-        const uint64_t e0 = ent_done, m = e1 - e0;
-        FG_HIP(ctx, hipMemcpyAsync(ht.ent_name + e0, dt.ent_name + e0, m * 8, hipMemcpyDeviceToHost, s_down));
-        FG_HIP(ctx, hipMemcpyAsync(ht.ent_val + e0, dt.ent_val + e0, m * 8, hipMemcpyDeviceToHost, s_down));
-        FG_HIP(ctx, hipMemcpyAsync(ht.ent_type + e0, dt.ent_type + e0, m, hipMemcpyDeviceToHost, s_down));
-        FG_HIP(ctx, hipMemcpyAsync(ht.ent_flags + e0, dt.ent_flags + e0, m, hipMemcpyDeviceToHost, s_down));
-        ent_done = e1;
-        return FG_OK;
-    };
-    auto decode_rows = [&](uint64_t f0, uint64_t f1, uint64_t span_bytes) -> int {  // frames [f0, f1): decode + download
+    auto decode_rows = [&](uint64_t f0, uint64_t f1, uint64_t span_bytes) -> int {  // frames [f0, f1): decode into the pinned tables
         if (f1 == f0) return FG_OK;
         const uint64_t rows = f1 - f0;
-        fg_tables sl = dt;
+        fg_tables sl = kt;
         sl.n = rows;
         sl.meta += f0; sl.ts += f0; sl.hostname += f0; sl.appname += f0; sl.procid += f0; sl.msgid += f0; sl.msg += f0; sl.full_msg += f0;
         sl.ent_first += f0; sl.ent_count += f0;
         int r = fg_decode_frames_impl(ctx, fmt, framing, ctx->d_bytes, nbytes, ctx->d_offsets + f0, rows, ctx->d_bad + f0, &sl, (void*)s_run, false, span_bytes);
         if (r != FG_OK) return r;
+        // the frames' offsets (8 bytes per frame) are the one thing still copied: behind the uploads on the copy engine, i.e. at the end
         FG_HIP(ctx, hipEventRecord(ctx->ev_ready, s_run));
         FG_HIP(ctx, hipStreamWaitEvent(s_down, ctx->ev_ready, 0));
         FG_HIP(ctx, hipMemcpyAsync(ctx->h_off + f0 + (f0 ? 1 : 0), ctx->d_offsets + f0 + (f0 ? 1 : 0), (rows + (f0 ? 0 : 1)) * 8, hipMemcpyDeviceToHost, s_down));
-        FG_HIP(ctx, hipMemcpyAsync(ht.meta + f0, dt.meta + f0, rows * 4, hipMemcpyDeviceToHost, s_down));
-        FG_HIP(ctx, hipMemcpyAsync(ht.ts + f0, dt.ts + f0, rows * 8, hipMemcpyDeviceToHost, s_down));
-        fg_span* hs[6] = {ht.hostname, ht.appname, ht.procid, ht.msgid, ht.msg, ht.full_msg};
-        fg_span* ds[6] = {dt.hostname, dt.appname, dt.procid, dt.msgid, dt.msg, dt.full_msg};
-        for (int j = 0; j < 6; ++j) FG_HIP(ctx, hipMemcpyAsync(hs[j] + f0, ds[j] + f0, rows * 8, hipMemcpyDeviceToHost, s_down));
-        FG_HIP(ctx, hipMemcpyAsync(ht.ent_first + f0, dt.ent_first + f0, rows * 4, hipMemcpyDeviceToHost, s_down));
-        FG_HIP(ctx, hipMemcpyAsync(ht.ent_count + f0, dt.ent_count + f0, rows * 4, hipMemcpyDeviceToHost, s_down));
         return FG_OK;
     };
     if ((rc = enqueue(0)) != FG_OK) {
@@ -567,19 +552,11 @@ static int frame_decode_sliced(fg_ctx* ctx, fg_format fmt, fg_framing framing, c
             drain();
             return rc;
         }
-        FG_HIP(ctx, hipEventSynchronize(ev[2 * k + 1]));
-        const uint64_t total = ctx->h_cnt[k];  // delimiters up to the end of slice k = frames that are complete
-        if (early && k >= 2) {  // the decode of slice k - 2 and its counter copy were queued before this slice's framing: both are done
-            const uint64_t cnt = ent_cnt[k - 2];
-            if (cnt > ent_cap) {
-                drain();
-                return FG_ERR_UNSUPPORTED;
-            }
-            if ((rc = download_entries(cnt)) != FG_OK) {
-                drain();
-                return rc;
-            }
+        if (hipEventSynchronize(ev[2 * k + 1]) != hipSuccess) {
+            drain();
+            return FG_ERR_HIP;
         }
+        const uint64_t total = ctx->h_cnt[k];  // delimiters up to the end of slice k = frames that are complete
         if (total + 1 > cap) {
             drain();
             ctx->frames_per_byte = (double)(total + 1) / (double)(((uint64_t)k + 1) * slice);
@@ -587,7 +564,7 @@ static int frame_decode_sliced(fg_ctx* ctx, fg_format fmt, fg_framing framing, c
         }
         const uint64_t b1 = k + 1 == slices ? nbytes : ((uint64_t)k + 1) * slice;
         if (k + 1 < slices) {
-            if ((rc = decode_rows(done, total, b1 - (uint64_t)k * slice)) != FG_OK || (rc = count_entries(k)) != FG_OK) {
+            if ((rc = decode_rows(done, total, b1 - (uint64_t)k * slice)) != FG_OK) {
                 drain();
                 return rc;
             }
@@ -613,19 +590,12 @@ static int frame_decode_sliced(fg_ctx* ctx, fg_format fmt, fg_framing framing, c
         done = n;
     }
     uint64_t used = 0;
-    FG_HIP(ctx, hipMemcpyAsync(&used, dt.ent_used, 8, hipMemcpyDeviceToHost, s_run));
+    FG_HIP(ctx, hipMemcpyAsync(&used, kt.ent_used, 8, hipMemcpyDeviceToHost, s_run));
     FG_HIP(ctx, hipStreamSynchronize(s_run));
     if (done) ctx->frames_per_byte = (double)done / (double)nbytes;
-    if (used > ent_cap) {
-        drain();
-        return FG_ERR_UNSUPPORTED;
-    }
-    if ((rc = download_entries(used)) != FG_OK) {  // what the last two slices appended
-        drain();
-        return rc;
-    }
-    *ht.ent_used = used;
     drain();
+    if (used > ent_cap) return FG_ERR_UNSUPPORTED;
+    *ht.ent_used = used;
     ht.n = done;
     *out = ht;
     *out_offsets = ctx->h_off;

@@ -302,7 +302,12 @@ struct SuffixEnt {                      // 16 bytes: the four configured suffixe
 constexpr uint32_t kLtsvTablesAt = 768u + kSchemaLds * sizeof(SchemaEnt) + 4u * sizeof(SuffixEnt);  // fg_numfold.hpp tables (8-byte aligned)
 constexpr uint32_t kLtsvExtraLds = kLtsvTablesAt + ((numfold::kTableBytes + 15u) & ~15u);
 
-struct LtsvFormat {
+// HEAD = true: the instantiation for LONG lines (persistent_loop<..., HEAD>): only the first kHeadCap bytes of every line are staged and
+// tokenised; what lies behind them is only SCANNED for a TAB, wave-cooperatively and without being stored (in practice the long
+// part of a log line is its last one, the message) -- a line with a TAB back there, or whose cut part is not a plain string, is
+// parsed from global memory.  Three to four times the lines per group on the 64 B .. 8 KiB corpus.
+template <bool HEAD = false>
+struct LtsvFormatT {
     static constexpr uint32_t kClasses = 1;
     static constexpr int kTailBatch = 16;  // the whole tile beyond the 2 KiB window in one round trip
     static constexpr bool kDeferRowStore = false;  // (stage A waits for the tail's loads anyway)
@@ -390,9 +395,11 @@ struct LtsvFormat {
     // per line of HBM traffic and 28 % of stage B).  Records start at the line's first 4-byte boundary; a pair whose record would reach
     // into bytes that are still to be read (a line of many tiny parts: `a:1\tb:2\t...`) clears *in_tile_records, and the line's pairs
     // are written by a second walk over the line in GLOBAL memory (its bytes in the tile are no longer intact).
+    // (HEAD: len = the bytes of the line that are in the tile, true_len = its length; rem_clean = no TAB behind the staged bytes;
+    //  *redo = the head was not enough: the caller parses the line from global memory)
     template <bool PROF>
     __device__ __forceinline__ void walk_tile(const Tile& T, uint32_t base, uint32_t len, LRow& r, uint32_t* tile_w, bool* in_tile_records,
-                                              uint64_t* pc) const {
+                                              uint64_t* pc, uint32_t true_len = 0, bool rem_clean = true, bool* redo = nullptr) const {
         uint32_t wpos = (base + 3u) & ~3u;  // tile byte where the next record goes
         bool rec_ok = true;
         uint64_t tk = PROF ? wv::clock() : 0;
@@ -434,6 +441,11 @@ struct LtsvFormat {
         load16(T, base + ps, w);
         for (;;) {  // line.split('\t')
             const bool more = pe < len;
+            const bool cutp = HEAD && !more && len < true_len;  // the line's last staged part runs on behind the head
+            if (HEAD && cutp && !rem_clean) {
+                *redo = true;  // ... and there is a TAB back there: more parts
+                return;
+            }
             const uint32_t nps = pe + 1u;
             const uint32_t npe = more ? next_tab(nps) : len;
             uint32_t nw[4];
@@ -452,8 +464,12 @@ struct LtsvFormat {
                 if (q < pe) colon = q;
             }
             tick(0);
+            if (HEAD && cutp && colon == 0xFFFFFFFFu) {
+                *redo = true;  // (its ':' may lie behind the head)
+                return;
+            }
             if (colon != 0xFFFFFFFFu) {  // else: println!("Missing value for name ...") :99, no effect on the Record
-                const uint32_t nb = ps, ne = colon, nl = colon - ps, vb = colon + 1, ve = pe;
+                const uint32_t nb = ps, ne = colon, nl = colon - ps, vb = colon + 1, ve = (HEAD && cutp) ? true_len : pe;
                 // the name's first 16 bytes, zero padded (for the key matches)
                 uint32_t k[4];
 #pragma unroll
@@ -463,6 +479,10 @@ struct LtsvFormat {
                 }
                 const bool short4 = k[1] == 0u && k[2] == 0u && k[3] == 0u;
                 if (nl == 4u && short4 && k[0] == 0x656D6974u) {           // "time"
+                    if (HEAD && cutp) {
+                        *redo = true;  // (a value that is looked INTO must be there whole)
+                        return;
+                    }
                     uint32_t b = vb, e = ve;
                     if (e > b && wr.byte(b) == '[' && rd.byte(e - 1) == ']' && e - b >= 2) {
                         ++b;
@@ -484,6 +504,10 @@ struct LtsvFormat {
                     r.msg_off = vb;
                     r.msg_len = ve - vb;
                 } else if (nl == 5u && k[0] == 0x6576656Cu && k[1] == 0x0000006Cu && k[2] == 0u && k[3] == 0u) {  // "level"
+                    if (HEAD && cutp) {
+                        *redo = true;
+                        return;
+                    }
                     uint64_t lv;
                     {
                         uint32_t w6[6];
@@ -507,6 +531,10 @@ struct LtsvFormat {
                     tick(3);
                     uint64_t val = (uint64_t)vb | ((uint64_t)(ve - vb) << 32);
                     uint32_t flags = 0;
+                    if (HEAD && cutp && ty != FG_T_STRING) {
+                        *redo = true;
+                        return;
+                    }
                     if (ty != FG_T_STRING) {
                         // the value's first 24 bytes, once; the everyday spellings are decided from them
                         uint32_t w6[6];
@@ -603,25 +631,88 @@ struct LtsvFormat {
         r.n_ent = cnt;
     }
 
+    // HEAD: is there a TAB behind the staged head of this lane's line?  All lines of the group at once, wave-cooperatively: the rows
+    // of 1 KiB behind the heads are dealt out flat, eight loads in flight, nothing is stored (16-byte aligned: a head ends on a 16-byte
+    // boundary of the packed buffer; the buffer descriptor bounds every row at the line's end: lanes beyond fetch zeros).
+    __device__ __forceinline__ bool tab_behind_head(const GroupCtx& c, uint32_t len) const {
+        const uint32_t lane = threadIdx.x;
+        const uint32_t rem = (c.valid && c.tlen != 0u && c.tlen < len) ? len - c.tlen : 0u;
+        const uint32_t rows = (rem + 1023u) >> 10;
+        uint32_t total;
+        const uint32_t first = wv::excl_sum(rows, &total);
+        bool has_tab = false;
+        const uint64_t rem0 = c.o0 + c.tlen;  // (16-byte aligned when rem != 0)
+        for (uint32_t r0 = 0; r0 < total; r0 += 8u) {
+            u32x4 v[8];
+            uint32_t owner[8], left[8];
+#pragma unroll
+            for (uint32_t j = 0; j < 8u; ++j) {
+                const uint32_t row = r0 + j < total ? r0 + j : total - 1u;
+                // the line that owns the row: the last lane whose first row is <= row (rows are dealt out in lane order)
+                const unsigned long long m = __ballot(rows != 0u && first <= row);
+                const uint32_t k = 63u - (uint32_t)__builtin_clzll(m);
+                owner[j] = k;
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rem0, (int)k);
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(rem0 >> 32), (int)k);
+                const uint32_t kfirst = (uint32_t)__builtin_amdgcn_readlane((int)first, (int)k);
+                const uint32_t krem = (uint32_t)__builtin_amdgcn_readlane((int)rem, (int)k);
+                const uint32_t off = (row - kfirst) << 10;
+                const uint64_t a = ((uint64_t)lo | ((uint64_t)hi << 32)) + off;
+                // (the range in whole 16-byte chunks -- a 16-byte load that straddles the end of the range fetches nothing; the packed
+                //  buffer is readable to its size rounded up to 16 -- and the bytes behind the line's end masked out below)
+                left[j] = krem - off;
+                __amdgpu_buffer_rsrc_t rsrc =
+                    __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(c.bytes + a), (short)0, (int)((left[j] + 15u) & ~15u), 0x00020000);
+                v[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(lane * 16u), 0, FG_STREAM_AUX);
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < 8u; ++j) {
+                uint32_t hit = 0;
+#pragma unroll
+                for (uint32_t d = 0; d < 4u; ++d) {
+                    const uint32_t at = lane * 16u + 4u * d;  // this dword's first byte in the row
+                    const uint32_t nb = left[j] > at ? (left[j] - at < 4u ? left[j] - at : 4u) : 0u;
+                    const uint32_t keep = nb == 4u ? 0xFFFFFFFFu : (1u << (8u * nb)) - 1u;
+                    hit |= eq_flags(v[j][d], 0x09090909u) & keep;
+                }
+                const bool any_tab = __ballot(hit != 0u) != 0ull;  // wave-uniform
+                if (any_tab && lane == owner[j]) has_tab = true;
+            }
+        }
+        return has_tab;
+    }
+
     __device__ __forceinline__ RowOut decode(const GroupCtx& c, const DevTables& t) const {
         const uint32_t lane = threadIdx.x;
         const uint32_t len = (uint32_t)(c.o1 - c.o0);
-        const bool in_tile = (c.o1 - c.a0) <= (uint64_t)c.span;
-        const uint32_t base = (uint32_t)(c.o0 - c.a0);
+        // HEAD staging: the tile holds the line's first c.tlen bytes at c.tbase -- the whole line, or its head only
+        const bool whole = HEAD ? c.tlen == len : (c.o1 - c.a0) <= (uint64_t)c.span;
+        const bool head_only = HEAD && !whole && c.tlen >= 256u;
+        const bool in_tile = whole || head_only;  // the tile walk can start; (head_only: it may hand the line back)
+        const uint32_t base = HEAD ? c.tbase : (uint32_t)(c.o0 - c.a0);
+        bool rem_clean = true;
+        if constexpr (HEAD) rem_clean = !tab_behind_head(c, len);
+        const uint32_t slen = HEAD ? c.tlen : len;  // bytes of the line the tile walk may look at
         Tile T{reinterpret_cast<const uint32_t*>(c.smem), reinterpret_cast<const uint32_t*>(c.bm16)};
         LRow r;
         const bool name_fits = len < 65536u;  // the in-tile records keep 16-bit name offsets
         uint32_t* tile_w = reinterpret_cast<uint32_t*>(const_cast<uint8_t*>(c.smem));
         bool in_tile_records = false;
-        const bool tile_lane = c.valid && in_tile && name_fits;
+        bool tile_lane = c.valid && in_tile && name_fits;
         uint64_t pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         uint64_t t6 = c.phase ? wv::clock() : 0;
         if (c.valid) {
             if (tile_lane) {
-                if (c.phase) walk_tile<true>(T, base, len, r, tile_w, &in_tile_records, pc);
-                else walk_tile<false>(T, base, len, r, tile_w, &in_tile_records, pc);
+                bool redo = false;
+                if (c.phase) walk_tile<true>(T, base, slen, r, tile_w, &in_tile_records, pc, len, rem_clean, &redo);
+                else walk_tile<false>(T, base, slen, r, tile_w, &in_tile_records, pc, len, rem_clean, &redo);
                 if (c.phase) t6 = wv::clock();
-            } else {
+                if (HEAD && redo) {  // the head was not enough: the whole line, from global memory (below)
+                    tile_lane = false;
+                    r = LRow();
+                }
+            }
+            if (!tile_lane) {
                 // (rare; a real call: its LRow lives in memory, so it gets its own -- `r` must never have its address taken, or
                 //  the fast path's row would live in scratch memory too)
                 // The same goes for the tables and the configuration: passed by reference from HERE they would be kept in scratch
@@ -629,7 +720,7 @@ struct LtsvFormat {
                 LRow slow;
                 const DevTables t_copy = t;
                 const LtsvDevCfg cfg_copy = cfg;
-                if (in_tile) {
+                if (whole && !HEAD) {
                     LdsReader rd(T.w, base);
                     ltsv_walk<false>(rd, len, cfg_copy, lds_digits, slow, t_copy, 0);
                 } else {
@@ -676,7 +767,7 @@ struct LtsvFormat {
                 LRow scratch = r;
                 const DevTables t_copy = t;  // (see above)
                 const LtsvDevCfg cfg_copy = cfg;
-                if (in_tile && !tile_lane) {
+                if (whole && !HEAD && !tile_lane) {
                     LdsReader rd(T.w, base);
                     ltsv_walk<true>(rd, len, cfg_copy, lds_digits, scratch, t_copy, first);
                 } else {
@@ -712,7 +803,9 @@ struct LtsvFormat {
     }
 };
 
-template <int NB, bool PROF>
+using LtsvFormat = LtsvFormatT<false>;
+
+template <int NB, bool PROF, bool HEAD = false>
 __global__ __launch_bounds__(kWave, 2) void k_ltsv(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets,
                                                   uint64_t n, DevTables t, LtsvDevCfg cfg, uint32_t tile_cap, uint32_t L,
                                                   uint64_t groups, unsigned long long* prof, uint64_t* stash_base, FrameArgs fr) {
@@ -752,8 +845,8 @@ __global__ __launch_bounds__(kWave, 2) void k_ltsv(const uint8_t* __restrict__ b
     uint32_t* dw = reinterpret_cast<uint32_t*>(extra + kLtsvTablesAt + numfold::kP10Words * 8u);
     numfold::init_tables(dw, p10);
     __syncthreads();
-    LtsvFormat fmt{cfg, extra, schema, suffix, p10, dw};
-    persistent_loop<NB, PROF>(bytes, offsets, n, t, tile_cap, L, groups, prof, stash_base, fmt, fr);
+    LtsvFormatT<HEAD> fmt{cfg, extra, schema, suffix, p10, dw};
+    persistent_loop<NB, PROF, LtsvFormatT<HEAD>, HEAD>(bytes, offsets, n, t, tile_cap, L, groups, prof, stash_base, fmt, fr);
 }
 
 }  // namespace fg
@@ -763,21 +856,34 @@ extern "C" int fg_launch_ltsv(const uint8_t* d_bytes, const uint64_t* d_offsets,
                               uint32_t stash_blocks, uint32_t strip, const uint8_t* line_bad, const fg_launch_opts* lo) {
     if (n == 0) return 0;
     fg::LaunchPlan p;
-    if (fg::plan_launch(fg::k_ltsv<fg::kComputeBoundWindow, false>, n, avg_len, fg::kLtsvExtraLds, 57344u, stash ? stash_blocks : 0u, &p, *lo))
+    // long lines: only the head of every line is staged, the rest is scanned for a TAB (LtsvFormatT<true>)
+    const bool head = (lo->flags & FG_LO_FORCE_HEAD) || (avg_len >= 768u && !(lo->flags & FG_LO_NO_HEAD));
+    const uint64_t plan_len = head ? (avg_len < fg::kHeadCap ? avg_len : fg::kHeadCap) : avg_len;
+    if (head ? fg::plan_launch(fg::k_ltsv<fg::kComputeBoundWindow, false, true>, n, plan_len, fg::kLtsvExtraLds, 57344u, stash ? stash_blocks : 0u, &p, *lo)
+             : fg::plan_launch(fg::k_ltsv<fg::kComputeBoundWindow, false>, n, plan_len, fg::kLtsvExtraLds, 57344u, stash ? stash_blocks : 0u, &p, *lo))
         return -1;
     if (stash_blocks == 0) stash = nullptr;
     dim3 grid(p.blocks), block(fg::kWave);
+    const fg::FrameArgs fr{strip, line_bad};
 #if defined(FG_PROF_BUILD)
     if (fg::prof_requested()) {
         fg::ProfRun pr;
         if (!pr.begin(stream)) return -1;
-        hipLaunchKernelGGL((fg::k_ltsv<fg::kComputeBoundWindow, true>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, *cfg, p.tile,
-                           p.L, p.chunk, pr.d, stash, fg::FrameArgs{strip, line_bad});
-        pr.end(stream, "ltsv", p);
+        if (head)
+            hipLaunchKernelGGL((fg::k_ltsv<fg::kComputeBoundWindow, true, true>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, *cfg, p.tile,
+                               p.L, p.chunk, pr.d, stash, fr);
+        else
+            hipLaunchKernelGGL((fg::k_ltsv<fg::kComputeBoundWindow, true>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, *cfg, p.tile,
+                               p.L, p.chunk, pr.d, stash, fr);
+        pr.end(stream, head ? "ltsv (head)" : "ltsv", p);
         return (int)hipGetLastError();
     }
 #endif
-    hipLaunchKernelGGL((fg::k_ltsv<fg::kComputeBoundWindow, false>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, *cfg, p.tile,
-                       p.L, p.chunk, (unsigned long long*)nullptr, stash, fg::FrameArgs{strip, line_bad});
+    if (head)
+        hipLaunchKernelGGL((fg::k_ltsv<fg::kComputeBoundWindow, false, true>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, *cfg, p.tile,
+                           p.L, p.chunk, (unsigned long long*)nullptr, stash, fr);
+    else
+        hipLaunchKernelGGL((fg::k_ltsv<fg::kComputeBoundWindow, false>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, *cfg, p.tile,
+                           p.L, p.chunk, (unsigned long long*)nullptr, stash, fr);
     return (int)hipGetLastError();
 }

@@ -196,7 +196,7 @@ __device__ __forceinline__ EntAlloc alloc_entries_ex(const DevTables& t, uint32_
     const uint32_t left = wv::wave_left(ent_state);
     const unsigned long long nofit = __ballot(n_ent != 0u && a.ex + n_ent > left);
     const uint32_t cut = nofit ? (uint32_t)__shfl((int)a.ex, (int)__builtin_ctzll(nofit), kWave) : a.total;
-    a.s = wv::wave_alloc(t.ent_used, t.ent_cap, ent_state, a.total, cut, wv::alloc_chunk_for(t.ent_cap, gridDim.x));
+    a.s = wv::wave_alloc(t.ent_used, t.ent_cap, ent_state, a.total, cut, wv::alloc_chunk_for(t.ent_cap, gridDim.x, t.n));
     a.overflow = a.s.overflow && n_ent != 0u && a.ex >= a.s.cut;
     return a;
 }
@@ -334,7 +334,7 @@ template <int NB, bool PROF, class F, bool HEAD = false>
 __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets,
                                                 uint64_t n, const DevTables& t, uint32_t tile_cap, uint32_t L, uint64_t chunk_lines,
                                                 unsigned long long* prof, uint64_t* stash_base, F& fmt, FrameArgs fr) {
-    static_assert(!HEAD || F::kClasses == 0, "HEAD staging is for formats without stage-A byte classes");
+    static_assert(!HEAD || F::kClasses <= 1, "HEAD staging classifies one stage-A byte class at most");
     const uint64_t kChunkLines = chunk_lines;  // lines a wave takes at a time (LaunchPlan::chunk)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint16_t* bm16 = reinterpret_cast<uint16_t*>(smem + tile_cap + 64u);
@@ -494,15 +494,20 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
             for (int k = 0; k < NB; ++k) {
                 if ((uint32_t)k < nl) {  // scalar branch
                     const uint32_t tk = (uint32_t)__builtin_amdgcn_readlane((int)tb, k), sk = (uint32_t)__builtin_amdgcn_readlane((int)st, k);
-                    if (lane * 16u < sk) dst[(tk >> 4) + lane] = make_uint4(v[k][0], v[k][1], v[k][2], v[k][3]);
+                    if (lane * 16u < sk) {
+                        const uint4 q = make_uint4(v[k][0], v[k][1], v[k][2], v[k][3]);
+                        dst[(tk >> 4) + lane] = q;
+                        if constexpr (F::kClasses != 0) F::classify_store(q, bm16, (tk >> 4) + lane, bm_stride, term4);
+                    }
                 }
             }
-            // lines beyond the window: four rows in flight
-            for (uint32_t r0 = NB; r0 < nl; r0 += 4u) {
-                uint4 w[4];
-                uint32_t tk[4], sk[4];
+            // lines beyond the window: HB rows in flight (four; a format whose window is small -- kTailBatch -- takes eight)
+            constexpr uint32_t HB = tail_batch<F>::value >= 8 ? 8u : 4u;
+            for (uint32_t r0 = NB; r0 < nl; r0 += HB) {
+                uint4 w[HB];
+                uint32_t tk[HB], sk[HB];
 #pragma unroll
-                for (uint32_t j = 0; j < 4u; ++j) {
+                for (uint32_t j = 0; j < HB; ++j) {
                     const uint32_t r = r0 + j < nl ? r0 + j : nl - 1u;
                     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)o0, (int)r);
                     const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(o0 >> 32), (int)r);
@@ -514,8 +519,11 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
                     w[j] = make_uint4(x[0], x[1], x[2], x[3]);
                 }
 #pragma unroll
-                for (uint32_t j = 0; j < 4u; ++j)
-                    if (lane * 16u < sk[j]) dst[(tk[j] >> 4) + lane] = w[j];  // (a clamped duplicate row writes the same bytes again)
+                for (uint32_t j = 0; j < HB; ++j)
+                    if (lane * 16u < sk[j]) {  // (a clamped duplicate row writes the same bytes again)
+                        dst[(tk[j] >> 4) + lane] = w[j];
+                        if constexpr (F::kClasses != 0) F::classify_store(w[j], bm16, (tk[j] >> 4) + lane, bm_stride, term4);
+                    }
             }
         } else {
 #pragma unroll

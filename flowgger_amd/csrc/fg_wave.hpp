@@ -212,7 +212,7 @@ FG_WV Slots wave_alloc(unsigned long long* ent_used, uint64_t ent_cap, uint32_t*
     sync();
     return r;
 }
-FG_WVH uint32_t alloc_chunk_for(uint64_t ent_cap, uint32_t waves) {
+FG_WVH uint32_t alloc_chunk_for(uint64_t ent_cap, uint32_t waves, uint64_t n_lines = ~0ull) {
     // a wave strands what is left of its LAST chunk: keep the worst case (every wave, a whole chunk) below 1/16 of the table.
     // (Round 4: 1/64 and at most 1024 slots meant an atomic on ONE word every third group of the structured-data kernel -- 9 per
     // microsecond chip-wide, each waiting ~10 us in the queue of that word: 16 % of the group's time, profiles/r04g_phases_*.)
@@ -221,6 +221,10 @@ FG_WVH uint32_t alloc_chunk_for(uint64_t ent_cap, uint32_t waves) {
     // slots parked in chunks, and a table that small is not where the counter is contended.
     uint64_t c = ent_cap / (16ull * (waves ? waves : 1u));
     if (c > 4096u) c = 4096u;
+    // ... and nothing like a whole chunk per wave when the LAUNCH is small: the sliced host paths decode one batch as dozens of
+    // launches of ~60 K lines into one table, and every launch strands its own chunks (eight slots per line the wave will see)
+    const uint64_t per_wave = n_lines / (waves ? waves : 1u) * 8ull;
+    if (n_lines != ~0ull && c > per_wave) c = per_wave;
     if (c < 256u) c = 0u;
     return (uint32_t)c;
 }

@@ -83,6 +83,10 @@ extern "C" void fgf_counters(unsigned long long out[3], int reset) {
 extern "C" void fgf_fail_malloc_after(long long n) { fakehip::fail_malloc_after() = n; }
 
 extern "C" uint64_t fg_stash_bytes(uint32_t blocks) { return 64ull * blocks; }
+extern "C" int fg_launch_poke64(const uint64_t* src, uint64_t* dst, hipStream_t) {
+    *dst = *src;
+    return 0;
+}
 extern "C" int fg_launch_calib(int mode, const uint8_t* src, uint8_t* dst, uint64_t nbytes, uint32_t*, hipStream_t) {
     if (mode == 0) memcpy(dst, src, nbytes / 16 * 16);
     return 0;

@@ -123,6 +123,33 @@ def test_ltsv_structural_mutation_fuzz(oracle):
     both_paths(d2, oracle, lines[:4000], synth.LTSV_CONFIG, host=False)
 
 
+@pytest.mark.parametrize("opts", [dict(), dict(force_head=True), dict(no_head=True), dict(force_head=True, tile_cap=6144, lines_per_group=5)])
+def test_ltsv_long_lines_head_staging(oracle, opts):
+    """LTSV lines of 64 B .. 8 KiB: only the head of a long line is staged, what lies behind it is scanned for a TAB without being
+    stored (fg_ltsv.hip LtsvFormatT<true>).  Lines whose long part is the last one (the corpus), lines with MORE parts behind the
+    first KiB (typed ones, `time` / `host` / `level` back there, parts without ':'), a cut part that is typed, a cut name, TABs exactly
+    at the head's end -- all must give the oracle's Records, with head staging forced on, off, and left to the launcher."""
+    rng = np.random.default_rng(11)
+    dec = LTSVDecoder(synth.LTSV_CONFIG)
+    dec.set_launch_opts(**opts)
+    base = synth.ltsv_lines(6000, invalid_frac=0.005, long_tail=True)
+    pad = lambda k: b"x" * int(k)  # noqa: E731
+    extra = []
+    for i in range(1500):
+        k = int(rng.integers(900, 1200))  # (around the 1 KiB head, every alignment)
+        head = b"time:1.5\thost:h\tmessage:" + pad(k)
+        tails = [b"\tlevel:3", b"\tlevel:9", b"\tcounter:12", b"\tcounter:x", b"\tnovalue", b"\thost:late", b"\ttime:[2015-08-05T15:53:45Z]", b"\t", b"",
+                 b"\tmean:1e3\tdone:true", b"\tk:" + pad(int(rng.integers(1, 3000))), b"\tscore:-" + b"9" * int(rng.integers(1, 30))]
+        extra.append(head + tails[i % len(tails)])
+        # a cut part that is not a plain string: the typed value / the timestamp / the name itself straddles the head's end
+        extra.append(b"host:h\ttime:1\tpad:" + pad(k - 40) + b"\tcounter:" + b"7" * int(rng.integers(1, 19)))
+        extra.append(b"host:h\tpad:" + pad(k - 30) + b"\ttime:" + b"1" * int(rng.integers(1, 15)) + b".5")
+        extra.append(b"host:h\ttime:2\tpad:" + pad(k - 35) + b"\t" + b"n" * int(rng.integers(1, 60)) + b":v")
+    lines = base + mutate_py(base[:2000], rng, LTSV_ALPHABET) + extra
+    order = rng.permutation(len(lines))
+    both_paths(dec, oracle, [lines[i] for i in order], synth.LTSV_CONFIG, host=False)
+
+
 def _mutate_packed(data, offsets, rng, ascii_alphabet, frac=0.85):
     """vectorised: one to three single-byte replacements in `frac` of the lines (ASCII for ASCII: offsets and UTF-8 validity stay)"""
     data = data.copy()
