@@ -57,7 +57,7 @@ extern "C" int fg_launch_frame(const uint8_t* d_bytes, uint64_t nbytes, uint32_t
 extern "C" uint64_t fg_frame_block_bytes(void);
 extern "C" int fg_launch_frame_slice(const uint8_t* d_bytes, uint64_t nbytes, uint32_t delim, uint8_t* scratch, uint64_t* d_offsets,
                                      uint8_t* d_bad, uint64_t cap, uint64_t blk0, uint64_t blk1, uint64_t** d_total_out,
-                                     hipStream_t stream);
+                                     hipStream_t stream, const uint8_t* src);
 extern "C" int fg_launch_ltsv(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
                               const fg::LtsvDevCfg* cfg, uint64_t avg_len, hipStream_t stream, uint64_t* stash,
                               uint32_t stash_blocks, uint32_t strip, const uint8_t* line_bad, const fg_launch_opts* lo);

@@ -67,8 +67,12 @@ __device__ __forceinline__ uint32_t utf8_err_flags(uint32_t b, uint32_t p) {
 // pass 1.  masks[chunk] = delimiter mask | error mask << 16 (chunk = 16 bytes); counts[block].
 // (blk0: first block of the range this launch covers -- a SLICE of the stream whose bytes have arrived; the pipelined host path frames
 //  slice by slice while the next one is still on the link)
+// COPY: the stream is read where the caller has it -- pinned host memory, over the link -- and written to its place in HBM on the
+// way (copy_to + the same offsets): the upload of the raw-stream host path without the copy engine (fg_host_pipeline.cpp).
+template <bool COPY>
 __global__ __launch_bounds__(kWave) void k_frame_scan(const uint8_t* __restrict__ bytes, uint64_t nbytes, uint32_t delim_pat,
-                                                     uint32_t* __restrict__ masks, uint32_t* __restrict__ counts, uint64_t blk0) {
+                                                     uint32_t* __restrict__ masks, uint32_t* __restrict__ counts, uint64_t blk0,
+                                                     uint8_t* __restrict__ copy_to) {
     const uint32_t lane = threadIdx.x;
     const uint64_t blk = blk0 + blockIdx.x;
     const uint64_t base = blk * kFrameBlock;
@@ -78,6 +82,11 @@ __global__ __launch_bounds__(kWave) void k_frame_scan(const uint8_t* __restrict_
     u32x4 v[kFrameRows];
 #pragma unroll
     for (int k = 0; k < (int)kFrameRows; ++k) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(lane * 16u + k * 1024u), 0, 0);
+    if constexpr (COPY) {
+        __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(copy_to + base, (short)0, (int)span, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < (int)kFrameRows; ++k) __builtin_amdgcn_raw_buffer_store_b128(v[k], dst, (int)(lane * 16u + k * 1024u), 0, 0);
+    }
     // the dword just before this block (row 0, lane 0 needs it)
     uint32_t before = 0;
     if (base != 0) before = *reinterpret_cast<const uint32_t*>(bytes + base - 4);
@@ -213,7 +222,8 @@ extern "C" int fg_launch_frame(const uint8_t* d_bytes, uint64_t nbytes, uint32_t
     uint64_t* pref = reinterpret_cast<uint64_t*>(scratch + nblk * 4096u + ((nblk * 4u + 255u) & ~255ull));
     const uint32_t pat = delim * 0x01010101u;
     (void)hipMemsetAsync(d_bad, 0, cap, stream);
-    hipLaunchKernelGGL(fg::k_frame_scan, dim3((uint32_t)nblk), dim3(fg::kWave), 0, stream, d_bytes, nbytes, pat, masks, counts, (uint64_t)0);
+    hipLaunchKernelGGL(fg::k_frame_scan<false>, dim3((uint32_t)nblk), dim3(fg::kWave), 0, stream, d_bytes, nbytes, pat, masks, counts, (uint64_t)0,
+                       (uint8_t*)nullptr);
     hipLaunchKernelGGL(fg::k_frame_prefix, dim3(1), dim3(1024), 0, stream, counts, nblk, pref, 0u);
     hipLaunchKernelGGL(fg::k_frame_emit, dim3((uint32_t)nblk), dim3(fg::kWave), 0, stream, masks, pref, nbytes, nblk, d_offsets,
                        d_bad, cap, (uint64_t)0, 1u);
@@ -226,9 +236,11 @@ extern "C" int fg_launch_frame(const uint8_t* d_bytes, uint64_t nbytes, uint32_t
 // slice before stopped; *d_total_out = the device word that holds the delimiters up to the end of this slice.  d_bad must have
 // been cleared for the whole batch beforehand; offsets[total + 1] of a final unterminated frame is the caller's business.
 extern "C" uint64_t fg_frame_block_bytes(void) { return fg::kFrameBlock; }
+// src != null: the slice's bytes are read from `src` (the device view of the caller's pinned buffer, same offsets) and stored to d_bytes
+// by the scan itself -- no upload has to have happened.
 extern "C" int fg_launch_frame_slice(const uint8_t* d_bytes, uint64_t nbytes, uint32_t delim, uint8_t* scratch, uint64_t* d_offsets,
                                      uint8_t* d_bad, uint64_t cap, uint64_t blk0, uint64_t blk1, uint64_t** d_total_out,
-                                     hipStream_t stream) {
+                                     hipStream_t stream, const uint8_t* src) {
     const uint64_t nblk = frame_blocks(nbytes);
     if (nblk > 0x7FFFFFFFull || blk1 > nblk || blk0 >= blk1) return -1;
     uint32_t* masks = reinterpret_cast<uint32_t*>(scratch);
@@ -236,7 +248,11 @@ extern "C" int fg_launch_frame_slice(const uint8_t* d_bytes, uint64_t nbytes, ui
     uint64_t* pref = reinterpret_cast<uint64_t*>(scratch + nblk * 4096u + ((nblk * 4u + 255u) & ~255ull));
     const uint32_t pat = delim * 0x01010101u;
     const uint32_t nb = (uint32_t)(blk1 - blk0);
-    hipLaunchKernelGGL(fg::k_frame_scan, dim3(nb), dim3(fg::kWave), 0, stream, d_bytes, nbytes, pat, masks, counts, blk0);
+    if (src)
+        hipLaunchKernelGGL(fg::k_frame_scan<true>, dim3(nb), dim3(fg::kWave), 0, stream, src, nbytes, pat, masks, counts, blk0,
+                           const_cast<uint8_t*>(d_bytes));
+    else
+        hipLaunchKernelGGL(fg::k_frame_scan<false>, dim3(nb), dim3(fg::kWave), 0, stream, d_bytes, nbytes, pat, masks, counts, blk0, (uint8_t*)nullptr);
     hipLaunchKernelGGL(fg::k_frame_prefix, dim3(1), dim3(1024), 0, stream, counts + blk0, (uint64_t)nb, pref + blk0, blk0 ? 1u : 0u);
     hipLaunchKernelGGL(fg::k_frame_emit, dim3(nb), dim3(fg::kWave), 0, stream, masks, pref, nbytes, nblk, d_offsets, d_bad, cap, blk0, 0u);
     *d_total_out = pref + blk1;

@@ -503,28 +503,34 @@ static int frame_decode_sliced(fg_ctx* ctx, fg_format fmt, fg_framing framing, c
     if ((rc = pinned_tables_for_kernels(ctx, ht, &kt)) != FG_OK) return rc;
     FG_HIP(ctx, hipMemsetAsync(kt.ent_used, 0, 8, s_run));
     FG_HIP(ctx, hipMemsetAsync(ctx->d_bad, 0, cap + 1, s_run));
+    FG_HIP(ctx, hipEventRecord(ctx->ev_ready, s_run));
+    FG_HIP(ctx, hipStreamWaitEvent(s_up, ctx->ev_ready, 0));  // (the framing kernels below write d_bad on the upload stream)
     const uint32_t delim = framing == FG_FRAME_LINE ? 0x0Au : 0x00u;
     std::vector<hipEvent_t>& ev = ctx->ev_slice;
-    // every upload is queued NOW (they depend on nothing): the link never waits for the host
-    for (uint32_t k = 0; k < slices; ++k) {
-        const uint64_t b0 = (uint64_t)k * slice, b1 = k + 1 == slices ? nbytes : b0 + slice;
-        FG_HIP(ctx, hipMemcpyAsync(ctx->d_bytes + b0, bytes + b0, b1 - b0, hipMemcpyHostToDevice, s_up));
-        if (k + 1 == slices) FG_HIP(ctx, hipMemsetAsync(ctx->d_bytes + nbytes, 0, up(nbytes, 16) + 16 - nbytes, s_up));
-        FG_HIP(ctx, hipEventRecord(ev[2 * k], s_up));
-    }
-    // frame slice k once it is there; its cumulative frame count lands in a pinned word (all asynchronous)
+    // A raw chunk in PINNED memory is not uploaded at all: the framing scan reads it where it is, over the link, and stores it to
+    // HBM on the way (k_frame_scan<COPY>) -- the copy engine stays out of it, and the kernels of slice k + 1 (reads over the link, on
+    // the upload stream) run beside the decode kernels of slice k (writes over the link).  Pageable memory: hipMemcpy per slice.
+    // MEASURED (profiles/r04l_*): slower than the copy engine's uploads on this platform -- cfg2 91 vs 184 M lines/s, GELF 73 vs 96,
+    // LTSV 84 vs 122 -- the framing kernels of slice k + 1 do not run beside the persistent decode grid of slice k, so the two
+    // directions of the link take turns again.  Off by default (FG_LO_FRAME_KERNEL_UPLOAD turns it on for further work).
+    const uint8_t* src_dv = ((ctx->lo.flags & FG_LO_FRAME_KERNEL_UPLOAD) && ((uintptr_t)bytes & 15u) == 0 && device_view_of_pinned(bytes + nbytes - 1))
+                                ? (const uint8_t*)device_view_of_pinned(bytes) : nullptr;
+    // upload (or in-kernel copy) + framing of slice k, all on the upload stream, queued ahead of the decodes: the link never waits for
+    // the host.  The slice's cumulative frame count lands in a pinned word (all asynchronous).
     auto enqueue = [&](uint32_t k) -> int {
         const uint64_t b0 = (uint64_t)k * slice, b1 = k + 1 == slices ? nbytes : b0 + slice;
-        FG_HIP(ctx, hipStreamWaitEvent(s_run, ev[2 * k], 0));
+        if (!src_dv) FG_HIP(ctx, hipMemcpyAsync(ctx->d_bytes + b0, bytes + b0, b1 - b0, hipMemcpyHostToDevice, s_up));
+        if (k + 1 == slices) FG_HIP(ctx, hipMemsetAsync(ctx->d_bytes + (src_dv ? up(nbytes, 16) : nbytes), 0, up(nbytes, 16) + 16 - (src_dv ? up(nbytes, 16) : nbytes), s_up));
         uint64_t* d_total = nullptr;
         const uint64_t blk0 = b0 / blk, blk1 = k + 1 == slices ? nblk_total : b1 / blk;
-        int lrc = fg_launch_frame_slice(ctx->d_bytes, nbytes, delim, ctx->d_frame, ctx->d_offsets, ctx->d_bad, cap, blk0, blk1, &d_total, s_run);
-        if (lrc == 0) lrc = fg_launch_poke64(d_total, cnt_dv + k, s_run);
+        int lrc = fg_launch_frame_slice(ctx->d_bytes, nbytes, delim, ctx->d_frame, ctx->d_offsets, ctx->d_bad, cap, blk0, blk1, &d_total, s_up, src_dv);
+        if (lrc == 0) lrc = fg_launch_poke64(d_total, cnt_dv + k, s_up);
         if (lrc != 0) {
             ctx->last_hip = lrc;
             return FG_ERR_HIP;
         }
-        FG_HIP(ctx, hipEventRecord(ev[2 * k + 1], s_run));
+        FG_HIP(ctx, hipEventRecord(ev[2 * k + 1], s_up));
+        FG_HIP(ctx, hipStreamWaitEvent(s_run, ev[2 * k + 1], 0));
         return FG_OK;
     };
     uint64_t done = 0;  // frames decoded so far
@@ -543,14 +549,14 @@ static int frame_decode_sliced(fg_ctx* ctx, fg_format fmt, fg_framing framing, c
         FG_HIP(ctx, hipMemcpyAsync(ctx->h_off + f0 + (f0 ? 1 : 0), ctx->d_offsets + f0 + (f0 ? 1 : 0), (rows + (f0 ? 0 : 1)) * 8, hipMemcpyDeviceToHost, s_down));
         return FG_OK;
     };
-    if ((rc = enqueue(0)) != FG_OK) {
-        drain();
-        return rc;
-    }
+    uint32_t queued = 0;
     for (uint32_t k = 0; k < slices; ++k) {
-        if (k + 1 < slices && (rc = enqueue(k + 1)) != FG_OK) {
-            drain();
-            return rc;
+        while (queued < slices && queued < k + 4u) {  // four slices of uploads / framing queued ahead of the decode being issued
+            if ((rc = enqueue(queued)) != FG_OK) {
+                drain();
+                return rc;
+            }
+            ++queued;
         }
         if (hipEventSynchronize(ev[2 * k + 1]) != hipSuccess) {
             drain();

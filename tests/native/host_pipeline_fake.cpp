@@ -14,6 +14,7 @@
 
 namespace {
 unsigned long long g_launches = 0;
+unsigned long long g_kernel_uploaded = 0;  // bytes the fake framing scan copied itself (the raw-stream path without the copy engine)
 
 int fake_decode(const uint8_t* bytes, const uint64_t* offsets, uint64_t n, const fg::DevTables* t, uint32_t strip, const uint8_t* line_bad) {
     ++g_launches;
@@ -69,6 +70,11 @@ int fake_decode(const uint8_t* bytes, const uint64_t* offsets, uint64_t n, const
 }
 }  // namespace
 
+extern "C" unsigned long long fgf_kernel_uploaded(int reset) {
+    const unsigned long long v = g_kernel_uploaded;
+    if (reset) g_kernel_uploaded = 0;
+    return v;
+}
 extern "C" unsigned long long fgf_launches(int reset) {
     const unsigned long long v = g_launches;
     if (reset) g_launches = 0;
@@ -176,7 +182,12 @@ extern "C" int fg_launch_frame(const uint8_t* d_bytes, uint64_t nbytes, uint32_t
     return rc;
 }
 extern "C" int fg_launch_frame_slice(const uint8_t* d_bytes, uint64_t nbytes, uint32_t delim, uint8_t* scratch, uint64_t* d_offsets, uint8_t* d_bad,
-                                     uint64_t cap, uint64_t blk0, uint64_t blk1, uint64_t** d_total_out, hipStream_t) {
+                                     uint64_t cap, uint64_t blk0, uint64_t blk1, uint64_t** d_total_out, hipStream_t, const uint8_t* src) {
     if (blk1 > nbytes / 16384 + 1 || blk0 >= blk1) return -1;
+    if (src) {  // the scan uploads its blocks itself (whole 16-byte chunks, as the kernel's bounded buffer stores do)
+        const uint64_t b0 = blk0 * 16384, b1 = blk1 * 16384 < nbytes ? blk1 * 16384 : nbytes;
+        if (b1 > b0) memcpy(const_cast<uint8_t*>(d_bytes) + b0, src + b0, b1 - b0);
+        g_kernel_uploaded += b1 > b0 ? b1 - b0 : 0;
+    }
     return frame_blocks_fake(d_bytes, nbytes, delim, scratch, d_offsets, d_bad, cap, blk0, blk1, d_total_out);
 }

@@ -265,6 +265,50 @@ def test_raw_stream_sliced_equals_one_piece(fake, final, dense):
     assert a["used"] == int(a["ent_count"].sum()) == b["used"]
 
 
+def test_a_pinned_raw_stream_is_uploaded_by_the_framing_scan_itself(fake):
+    """raw chunk in pinned memory: no hipMemcpy of the stream at all -- the framing scan reads it in place and stores it to its place on
+    the device (k_frame_scan<COPY>), the tables are written straight into the pinned host tables; only frame offsets and a few
+    counters are copied.  Same rows, offsets and entries as the pageable chunk through the hipMemcpy uploads."""
+    rng = np.random.default_rng(8)
+    lines = corpus(230_000, rng)
+    raw = np.frombuffer(b"".join(ln + b"\n" for ln in lines) + b"<1>unterminated tail a=1", np.uint8).copy()
+    assert raw.size > (48 << 20)
+    fake.fg_alloc_pinned.argtypes = [u64, C.POINTER(vp)]
+    fake.fg_free_pinned.argtypes = [vp]
+    fake.fgf_kernel_uploaded.restype = C.c_ulonglong
+    pb = vp()
+    assert fake.fg_alloc_pinned(raw.size + 64, C.byref(pb)) == 0
+    hb = np.ctypeslib.as_array(C.cast(pb, C.POINTER(C.c_uint8)), (raw.size + 64,))
+    hb[:raw.size] = raw
+    res = {}
+    cnt = (C.c_ulonglong * 3)()
+    for pinned in (True, False):
+        c = Ctx(fake)
+        lo = L.fg_launch_opts(0, 0, 0, 0, 0, L.FG_LO_FRAME_KERNEL_UPLOAD, 0)  # (off by default: measured slower than the copy engine)
+        assert fake.fg_set_launch_opts(c.h, C.byref(lo)) == 0
+        st, po, nf, cons = L.fg_tables(), vp(), u64(), u64()
+        pad = np.concatenate([raw, np.zeros(64, np.uint8)])
+        fake.fgf_kernel_uploaded(1)
+        fake.fgf_counters(cnt, 1)
+        src = pb if pinned else pad.ctypes.data
+        assert fake.fg_frame_decode_batch(c.h, 0, 1, src, raw.size, 1, C.byref(st), C.byref(po), C.byref(nf), C.byref(cons)) == 0
+        fake.fgf_counters(cnt, 1)
+        n = int(nf.value)
+        offs = np.ctypeslib.as_array(C.cast(po, C.POINTER(C.c_uint64)), (n + 1,)).copy()
+        res[pinned] = (snapshot(st, n), offs, int(cons.value), n)
+        up_by_kernel = fake.fgf_kernel_uploaded(1)
+        if pinned:
+            assert up_by_kernel >= raw.size and cnt[1] < (1 << 16), (up_by_kernel, int(cnt[1]))   # nothing of the stream by hipMemcpy
+            assert cnt[2] <= (n + 1) * 8 + 4096, int(cnt[2])                                       # D2H: frame offsets + counters only
+        else:
+            assert up_by_kernel == 0 and cnt[1] >= raw.size
+        c.close()
+    (a, ao, ac, an), (b, bo, bc, bn) = res[True], res[False]
+    assert an == bn == len(lines) + 1 and ac == bc == raw.size and np.array_equal(ao, bo)
+    same_lines(a, b, an)
+    fake.fg_free_pinned(pb)
+
+
 def test_a_failed_device_allocation_is_an_error_and_the_ctx_stays_usable(fake):
     rng = np.random.default_rng(4)
     data, offsets = pack(corpus(20_000, rng))
