@@ -62,6 +62,13 @@ def parse_args():
                     help="default workload, one GPU: skip the bounded BASELINE configs[2] (GELF) and configs[3] (structured data) legs "
                          "(4 M lines each, in this process; they ride along in the line as `configs2` / `configs3`)")
     ap.add_argument("--no-calib", action="store_true", help="skip the same-process copy / read calibration (roofline.copy_GBps, read_GBps)")
+    ap.add_argument("--dry-run-backend", default=None, choices=["gloo"],
+                    help="NO GPU: walk the N-rank control flow of this script -- process group, every barrier / max / all-gather of the "
+                         "timed region, the validity and calibration exchanges, the PCIe legs' per-leg barriers, cfg5mix's merge and "
+                         "rank gather (fg_merge_tables, shard.gather_distributed, fg_gather_tables on synthetic tables) -- over gloo on "
+                         "the CPU with the decode stubbed out, so that a hang in a collective is found before the first 8-GPU run "
+                         "(tests/test_shard_cpu.py runs it at world size 2).  Prints a line marked \"dry_run\": true; no throughput in it "
+                         "means anything")
     ap.add_argument("--spawn", action="store_true",
                     help="launch the ranks through torch.distributed.run even for --gpus 1 (the path --gpus N>1 takes by itself "
                          "when WORLD_SIZE is not set)")
@@ -139,9 +146,10 @@ def bind_to_gpu_numa_node(local: int):
 
 
 class Dist:
-    """torch.distributed over RCCL when a launcher set WORLD_SIZE (also for one rank: the same code runs at N = 1 and N = 8)."""
+    """torch.distributed over RCCL when a launcher set WORLD_SIZE (also for one rank: the same code runs at N = 1 and N = 8).
+    backend="gloo": the --dry-run-backend walk of the same collectives on the CPU (dev = cpu, nothing to synchronise)."""
 
-    def __init__(self, dev):
+    def __init__(self, dev, backend="nccl"):
         import torch
         import torch.distributed as dist
 
@@ -149,15 +157,20 @@ class Dist:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.on = "WORLD_SIZE" in os.environ
+        self.gpu = backend == "nccl"
         if self.on:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
-            dist.init_process_group("nccl", device_id=dev)
+            if self.gpu:
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(backend)
 
     def barrier(self):
         if self.on:
             self.dist.barrier()
-        self.torch.cuda.synchronize(self.dev)
+        if self.gpu:
+            self.torch.cuda.synchronize(self.dev)
 
     def max(self, v: float) -> float:
         if not self.on:
@@ -194,8 +207,8 @@ def pinned(nbytes, dt):
 def e2e_legs(D: Dist, dec, fmt, data, offsets, n_tile, tile_bytes, want_transcode, want_stream):
     """PCIe-inclusive rates of the host-buffer entry points on a bounded sample (4 tiles from pinned memory), on EVERY rank at
     the same time (barrier, then ITERS calls per rank, wall clock around them; aggregate = all ranks' lines / the slowest rank):
-      fg_decode_batch        H2D of bytes + offsets, kernels, D2H of the tables
-      fg_frame_decode_batch  H2D of the raw "\\n" stream ONLY, framing + UTF-8 + decode on the GPU, D2H of tables + frame offsets
+      fg_decode_batch        pinned buffers: zero-copy (the kernels read the lines over the link and write the pinned tables)
+      fg_frame_decode_batch  H2D of the raw "\\n" stream ONLY, framing + UTF-8 + decode on the GPU, tables written into pinned memory
       fg_transcode_batch     H2D, decode, GELF encode, line merger, D2H of the encoded stream
     with the link's measured peak (fg_measure_link) beside them.  Reported beside `value`, never as `value`."""
     import ctypes as C
@@ -260,7 +273,7 @@ def e2e_legs(D: Dist, dec, fmt, data, offsets, n_tile, tile_bytes, want_transcod
         if leg("decode_batch",
                lambda: L.check(lib.fg_decode_batch(dec._ctx, fmt, pdata.ctypes.data, tile_bytes * reps, poffs.ctypes.data, n, C.byref(st)),
                                "fg_decode_batch"),
-               tile_bytes * reps + 8 * (n + 1), "fg_decode_batch: H2D of bytes + offsets, kernels, D2H of the tables"):
+               tile_bytes * reps + 8 * (n + 1), "fg_decode_batch from pinned buffers: zero-copy -- ONE launch, the kernels read bytes + offsets in place over the link and write the table columns into pinned host memory"):
             out["decode_batch"]["frac_of_link_h2d"] = out["decode_batch"]["GBps_in"] / link[0] if link[0] else None
         if want_stream and not bool((data[:tile_bytes] == 0x0A).any()):
             # the same lines as ONE raw newline-terminated stream: what LineSplitter reads off the socket
@@ -284,7 +297,7 @@ def e2e_legs(D: Dist, dec, fmt, data, offsets, n_tile, tile_bytes, want_transcod
                 assert nf.value == n, (nf.value, n)
 
             if leg("frame_decode_batch", call_stream, stream_bytes * reps,
-                   "fg_frame_decode_batch: H2D of the raw stream only, framing + UTF-8 + decode on the GPU, D2H of tables + frame offsets"):
+                   "fg_frame_decode_batch: H2D of the raw stream only (sliced hipMemcpy), framing + UTF-8 + decode on the GPU, table columns written straight into pinned host memory, frame offsets copied"):
                 out["frame_decode_batch"]["frac_of_link_h2d"] = out["frame_decode_batch"]["GBps_in"] / link[0] if link[0] else None
         if want_transcode:
             enc = GelfEncoder(None, merger="line")
@@ -430,7 +443,7 @@ class Resident:
         return n_ok_tile, used
 
 
-def bounded_leg(desc, fmt, lines, reps, dev, local, steps=5, warmup=2):
+def bounded_leg(desc, fmt, lines, reps, dev, local, steps=5, warmup=2, D=None):
     """One more BASELINE configuration on a bounded resident sample (4 M lines), timed like the main workload (HIP events on the launch
     stream, replicas compared, Ok count returned for the oracle check): rides in the default line as configs2 / configs3 so that the
     driver's run observes every BASELINE configuration, not only configs[1]."""
@@ -458,6 +471,16 @@ def bounded_leg(desc, fmt, lines, reps, dev, local, steps=5, warmup=2):
            "algorithmic_bytes_per_launch": alg_read + alg_written, "entries": used, "ok_lines_per_tile": n_ok_tile,
            "what": "bounded sample of this BASELINE configuration, same timing and replica checks as the main line; full size: "
                    "python bench.py --workload " + ("cfg3" if fmt == 2 else "cfg4 --reps 125")}
+    if D is not None:  # the PCIe-inclusive entry points on this corpus too (pinned buffers: fg_decode_batch takes its zero-copy form)
+        try:
+            e = e2e_legs(D, R.dec, fmt, R.data, R.offsets, R.n_tile, R.tile_bytes, want_transcode=False, want_stream=True)
+            out["e2e"] = {k: {kk: e[k][kk] for kk in ("lines_per_s", "GBps_in", "ms", "frac_of_link_h2d", "what") if kk in e[k]}
+                          for k in ("decode_batch", "frame_decode_batch") if k in e and "lines_per_s" in e[k]}
+            out["e2e"]["sample"] = e.get("sample")
+        except AssertionError:
+            raise
+        except Exception as ex:  # noqa: BLE001
+            out["e2e"] = {"error": repr(ex)[:200]}
     leg = (R.fmt, R.data, R.offsets, R.n_tile, None)
     del R
     torch.cuda.empty_cache()
@@ -490,10 +513,73 @@ def calibrate(dec, d_bytes, nbytes, dev, reps=3):
     return out
 
 
+def dry_run(args):
+    """--dry-run-backend gloo: the collectives of main() in main()'s order, on the CPU, with the decode stubbed out (see parse_args).
+    Kept beside main() on purpose: a collective added there belongs here too (tests/test_shard_cpu.py::test_bench_dry_run_world2)."""
+    import torch
+
+    from flowgger_amd import shard
+
+    D = Dist(torch.device("cpu"), backend=args.dry_run_backend)
+    world, rank = D.world, D.rank
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    wl = args.workload
+    for _ in range(args.warmup):
+        pass
+    D.barrier()                                    # before the timed region
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    D.barrier()                                    # after it
+    elapsed = D.max(time.perf_counter() - t0)      # MAX over ranks
+    rank_ms = [r[0] for r in D.all([0.001 * (rank + 1)])]          # every rank's kernel time
+    calib_all = D.all([5000.0 + rank, 6000.0 + rank])              # calibration exchange
+    gather = None
+    if wl == "cfg5mix":
+        # two synthetic sub-batch tables per rank (one entry per second row), merged by arrival index, then every rank's table to rank 0
+        n = 1000 + 10 * rank
+        parts, index = [], []
+        rng = np.random.default_rng(rank)
+        tag = rng.integers(0, 2, n).astype(np.uint8)
+        for k in (0, 1):
+            m = int((tag == k).sum())
+            t = shard._alloc_tables(m, max(m // 2, 1))
+            t.a["meta"][:m] = np.arange(m, dtype=np.uint32) << 8
+            t.a["ent_count"][:m] = (np.arange(m) % 2 == 0).astype(np.uint32)
+            t.a["ent_first"][:m] = np.cumsum(np.concatenate([[0], t.a["ent_count"][:m - 1]])).astype(np.uint32) if m else 0
+            t.a["ent_used"][0] = int(t.a["ent_count"][:m].sum())
+            parts.append(t)
+            index.append(np.flatnonzero(tag == k).astype(np.uint64))
+        merged, src = shard.merge_tables(parts, index)
+        assert merged.n == n and np.array_equal(src[:n], tag)
+        D.barrier()
+        full = shard.gather_distributed(merged, dst=0)
+        D.barrier()
+        g_ms = D.max(1.0)
+        if rank == 0:
+            assert full.n == sum(1000 + 10 * r for r in range(world))
+        gather = {"ranks_gather_ms": g_ms, "all_ranks_gather_ms": [r[0] for r in D.all([g_ms])], "ranks_rows": int(full.n) if rank == 0 else None}
+    e2e = None
+    if not args.no_e2e and wl in ("cfg2", "cfg1", "cfg3", "cfg4", "ltsv"):
+        e2e = {"link_peak": D.all([57.0, 57.0, 80.0])}
+        for leg in ("decode_batch", "frame_decode_batch") + (("transcode_batch",) if wl in ("cfg2", "cfg1") else ()):
+            D.barrier()                            # every rank starts a leg together ...
+            e2e[leg] = [x[0] for x in D.all([0.01 * (rank + 1)])]   # ... and hands in its time
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "backend": args.dry_run_backend, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "workload": wl, "elapsed_s": elapsed, "ranks": {"n": len(rank_ms), "kernel_ms": rank_ms},
+                          "calibration_ranks": len(calib_all), "gather": gather, "e2e_legs": sorted(e2e) if e2e else None,
+                          "what": "control flow only: process group, barriers, reductions and gathers of bench.py's N-rank run on the CPU; "
+                                  "no decode ran and no number here is a measurement"}), flush=True)
+    D.close()
+
+
 def main():
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
         raise SystemExit(self_launch(args))
+    if args.dry_run_backend:
+        return dry_run(args)
     import torch
 
     from flowgger_amd import synth
@@ -777,7 +863,7 @@ def main():
                     ("configs2", 2, WORKLOADS["cfg3"][1], lambda: synth.gelf_lines(250_000, invalid_frac=args.invalid_frac)),
                     ("configs3", 0, WORKLOADS["cfg4"][1], lambda: synth.rfc5424_lines(250_000, cfg=4, sd=True, invalid_frac=args.invalid_frac))):
                 try:
-                    out[key], leg = bounded_leg(desc, lfmt, gen(), 16, dev, local)
+                    out[key], leg = bounded_leg(desc, lfmt, gen(), 16, dev, local, D=D if not args.no_e2e else None)
                     extra_legs.append((key, leg))
                 except Exception as e:  # noqa: BLE001 -- an extra leg never takes the bench line down (a parity failure does: below)
                     if isinstance(e, AssertionError):

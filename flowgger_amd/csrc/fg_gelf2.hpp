@@ -635,6 +635,28 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
         uint32_t rank_x = 0;  // (the rank among ALL members only orders errors: counted where one is found)
         bool dropped = false;
         member = member && !(L.l_flags[k] & LF_BAIL);
+        // Fast form: the keys' first FOUR bytes (the high dword of the sort key) order the line's members whenever they are pairwise
+        // different -- every GELF producer's field names -- with one 32-bit compare per key; a lane that meets an equal high dword
+        // (the same key twice, or two keys that share four bytes) sends the block through the full 64-bit form below.
+        bool tie = false;
+        if (member) {
+            const uint32_t hi_k = (uint32_t)(key >> 32);
+            for (uint32_t t0 = kfi; t0 < kfe; t0 += 4u) {
+                uint64_t ko[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) ko[u] = L.kblk[(t0 + u) & 63u];  // (past the line: masked out below)
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) {
+                    const uint32_t tt = t0 + u;
+                    const bool in = tt < kfe;
+                    const uint32_t hi_o = (uint32_t)(ko[u] >> 32);
+                    rank_x += (in && hi_o < hi_k && ((uint32_t)ko[u] & 0x80u)) ? 1u : 0u;
+                    tie = tie || (in && tt != jj && hi_o == hi_k);
+                }
+            }
+        }
+        if (wv::any(member && tie)) {  // rare
+        rank_x = 0;
         if (member) {
             bool bail = false, dup = false;
             // (four keys per round trip: the loads of a batch are issued before the first compare)
@@ -662,6 +684,7 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
             }
             if (bail) wv::lds_or(&L.l_flags[k], LF_BAIL);
             else if (dup) wv::lds_or(&L.l_flags[k], LF_DUP);
+        }
         }
         if (wv::any(dropped)) {  // rare: erase the dropped duplicates and recount their lines
             wv::sync();
