@@ -378,6 +378,24 @@ def oracle_ok_count(fmt, data, offsets, cfg):
     return ok
 
 
+def cached_lines(key, gen):
+    """FG_BENCH_CACHE=<dir> (measurement scripts that run this file many times on one box: tools/r04_final.sh): the generated tile is
+    kept as one pickle per (workload, size, share of invalid lines) -- the generators are deterministic (fixed seeds), so this only
+    saves the tens of seconds Python needs to format a million lines.  Unset: generate, as the driver's run does."""
+    d = os.environ.get("FG_BENCH_CACHE")
+    if not d:
+        return gen()
+    import pickle
+
+    f = Path(d) / (key + ".pkl")
+    if f.exists():
+        return pickle.loads(f.read_bytes())
+    lines = gen()
+    f.parent.mkdir(parents=True, exist_ok=True)
+    f.write_bytes(pickle.dumps(lines, protocol=4))
+    return lines
+
+
 def make_decoder(fmt, local, opts):
     from flowgger_amd import GelfDecoder, LTSVDecoder, RFC3164Decoder, RFC5424Decoder, synth
 
@@ -601,26 +619,29 @@ def main():
     fmt, wl_desc = WORKLOADS[wl]
     sd = wl in ("cfg4", "cfg5")
     index = None
+    ckey = f"{wl}_{args.tile_lines}_{args.invalid_frac:g}" + (f"_{args.line_len[0]}_{args.line_len[1]}" if args.line_len else "")
     if wl == "cfg5mix":
-        tag, (la, ia), (lb, ib) = synth.mixed_cfg5(args.tile_lines, invalid_frac=args.invalid_frac)
+        tag, (la, ia), (lb, ib) = cached_lines(ckey, lambda: synth.mixed_cfg5(args.tile_lines, invalid_frac=args.invalid_frac))
         subs = [Resident(0, la, args.reps, dev, local, opts), Resident(1, lb, args.reps, dev, local, opts)]
         # arrival position of row j of replica r of a sub-batch: r * tile + position inside the tile
         index = [np.concatenate([ix + np.uint64(r * args.tile_lines) for r in range(args.reps)]) for ix in (ia, ib)]
         del la, lb
     else:
-        if wl == "cfg3":
-            lines = synth.gelf_lines(args.tile_lines, invalid_frac=args.invalid_frac)
-        elif wl in ("ltsv", "ltsv5"):
-            lines = synth.ltsv_lines(args.tile_lines, invalid_frac=args.invalid_frac, long_tail=wl == "ltsv5")
-        elif wl == "rfc3164":
-            lines = synth.rfc3164_lines(args.tile_lines, invalid_frac=args.invalid_frac)
-        elif wl == "frame":
-            lines = [ln + b"\n" for ln in synth.rfc5424_lines(args.tile_lines, cfg=2, invalid_frac=args.invalid_frac)]
-        elif wl == "cfg5":
-            lines = synth.rfc5424_lines(args.tile_lines, cfg=5, sd=True, invalid_frac=args.invalid_frac, long_tail=True)
-        else:
+        def gen_lines():
+            if wl == "cfg3":
+                return synth.gelf_lines(args.tile_lines, invalid_frac=args.invalid_frac)
+            if wl in ("ltsv", "ltsv5"):
+                return synth.ltsv_lines(args.tile_lines, invalid_frac=args.invalid_frac, long_tail=wl == "ltsv5")
+            if wl == "rfc3164":
+                return synth.rfc3164_lines(args.tile_lines, invalid_frac=args.invalid_frac)
+            if wl == "frame":
+                return [ln + b"\n" for ln in synth.rfc5424_lines(args.tile_lines, cfg=2, invalid_frac=args.invalid_frac)]
+            if wl == "cfg5":
+                return synth.rfc5424_lines(args.tile_lines, cfg=5, sd=True, invalid_frac=args.invalid_frac, long_tail=True)
             kw = {"lo": args.line_len[0], "hi": args.line_len[1]} if (args.line_len and not sd) else {}
-            lines = synth.rfc5424_lines(args.tile_lines, cfg=4 if sd else 2, sd=sd, invalid_frac=args.invalid_frac, **kw)
+            return synth.rfc5424_lines(args.tile_lines, cfg=4 if sd else 2, sd=sd, invalid_frac=args.invalid_frac, **kw)
+
+        lines = cached_lines(ckey if wl != "cfg1" else ckey.replace("cfg1", "cfg2"), gen_lines)
         subs = [Resident(fmt, lines, args.reps, dev, local, opts, entries=wl != "cfg2")]
         del lines
     R = subs[0]
