@@ -517,7 +517,10 @@ def calibrate(dec, d_bytes, nbytes, dev, reps=3):
     nbytes = nbytes // 16 * 16
     dst = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     out = {}
-    for name, mode, traffic in (("copy_GBps", 0, 2 * nbytes), ("read_GBps", 1, nbytes)):
+    # (three spellings of the float4 copy -- grid-stride, non-temporal, one element per thread -- and the BEST is the box's copy rate:
+    #  the ceiling the decoder is priced against must not be an artefact of one spelling)
+    for name, mode, traffic in (("copy_gridstride_GBps", 0, 2 * nbytes), ("copy_nt_GBps", 2, 2 * nbytes), ("copy_flat_GBps", 3, 2 * nbytes),
+                                ("read_GBps", 1, nbytes)):
         L.check(lib.fg_calibrate_device(dec._ctx, mode, d_bytes.data_ptr(), dst.data_ptr(), nbytes, stream.cuda_stream), "fg_calibrate_device")
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
         for a, b in ev:
@@ -526,6 +529,7 @@ def calibrate(dec, d_bytes, nbytes, dev, reps=3):
             b.record(stream)
         torch.cuda.synchronize(dev)
         out[name] = traffic / (min(a.elapsed_time(b) for a, b in ev) * 1e-3) / 1e9
+    out["copy_GBps"] = max(out["copy_gridstride_GBps"], out["copy_nt_GBps"], out["copy_flat_GBps"])
     del dst
     torch.cuda.empty_cache()
     return out
@@ -821,10 +825,12 @@ def main():
         if calib is not None and "copy_GBps" in calib:
             rf = out["roofline"]
             rf["copy_GBps"], rf["read_GBps"] = calib["copy_GBps"], calib["read_GBps"]
+            rf["copy_variants_GBps"] = {k: calib[k] for k in ("copy_gridstride_GBps", "copy_nt_GBps", "copy_flat_GBps")}
             rf["frac_of_copy"] = achieved / calib["copy_GBps"]
             rf["read_only_frac_of_read"] = alg_read / (kernel_ms * 1e-3) / 1e9 / calib["read_GBps"]
-            rf["calibration"] = ("fg_calibrate_device in this process over the decoder's own resident buffer: float4 copy (2 x bytes) and "
-                                 "read-only sweep, best of 3; frac_of_copy = achieved / copy_GBps -- the box-independent figure")
+            rf["calibration"] = ("fg_calibrate_device in this process over the decoder's own resident buffer: the best of three float4 copies "
+                                 "(grid-stride, non-temporal, one element per thread; 2 x bytes of traffic) and a read-only sweep, best of 3 "
+                                 "launches each; frac_of_copy = achieved / copy_GBps -- the box-independent figure")
             if calib_all and len(calib_all) > 1:
                 rf["per_rank_copy_GBps"] = [r[0] for r in calib_all]
         elif calib is not None:

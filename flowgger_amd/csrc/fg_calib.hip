@@ -2,8 +2,11 @@
 // gives a plain streaming kernel, measured in the same process and on the same buffer as the decode kernels, so that a decoder's
 // GB/s can be priced against the box it ran on (bench.py: roofline.copy_GBps / read_GBps, frac_of_copy) instead of against another
 // box's number.  No reference analogue; measurement support, not part of the decode path.
-//   mode 0  float4 copy   src -> dst           (2 x nbytes of traffic; the guide's "float4 copy" figure, ~6.3 TB/s)
+//   mode 0  float4 copy   src -> dst           (2 x nbytes of traffic; the guide's "float4 copy" figure, ~6.3 TB/s), grid-stride
 //   mode 1  read-only     src -> one word      (nbytes of traffic: the roof of a decoder that writes little)
+//   mode 2  float4 copy with non-temporal loads and stores, grid-stride
+//   mode 3  float4 copy, one 16-byte element per thread (no loop: the plain "one thread, one float4" copy)
+// (bench.py takes the BEST of the copies as the box's copy rate: the ceiling must not be an artefact of one spelling)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -23,6 +26,27 @@ __global__ __launch_bounds__(kCalibThreads) void k_calib_copy(const uint4* __res
         for (int k = 0; k < kCalibUnroll; ++k) dst[i + k * stride] = v[k];
     }
     for (; i < n16; i += stride) dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(kCalibThreads) void k_calib_copy_nt(const uint4* __restrict__ src, uint4* __restrict__ dst, uint64_t n16) {
+    typedef uint32_t nt4 __attribute__((ext_vector_type(4)));
+    const nt4* s = reinterpret_cast<const nt4*>(src);
+    nt4* d = reinterpret_cast<nt4*>(dst);
+    const uint64_t stride = (uint64_t)gridDim.x * kCalibThreads;
+    uint64_t i = (uint64_t)blockIdx.x * kCalibThreads + threadIdx.x;
+    for (; i + (kCalibUnroll - 1) * stride < n16; i += kCalibUnroll * stride) {
+        nt4 v[kCalibUnroll];
+#pragma unroll
+        for (int k = 0; k < kCalibUnroll; ++k) v[k] = __builtin_nontemporal_load(s + i + k * stride);
+#pragma unroll
+        for (int k = 0; k < kCalibUnroll; ++k) __builtin_nontemporal_store(v[k], d + i + k * stride);
+    }
+    for (; i < n16; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(s + i), d + i);
+}
+
+__global__ __launch_bounds__(kCalibThreads) void k_calib_copy_flat(const uint4* __restrict__ src, uint4* __restrict__ dst, uint64_t n16) {
+    const uint64_t i = (uint64_t)blockIdx.x * kCalibThreads + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
 }
 
 __global__ __launch_bounds__(kCalibThreads) void k_calib_read(const uint4* __restrict__ src, uint64_t n16, uint32_t* __restrict__ sink) {
@@ -58,7 +82,14 @@ extern "C" int fg_launch_calib(int mode, const uint8_t* d_src, uint8_t* d_dst, u
     if (mode == 0)
         hipLaunchKernelGGL(fg::k_calib_copy, dim3((uint32_t)blocks), dim3(fg::kCalibThreads), 0, stream, reinterpret_cast<const uint4*>(d_src),
                            reinterpret_cast<uint4*>(d_dst), n16);
-    else
+    else if (mode == 2)
+        hipLaunchKernelGGL(fg::k_calib_copy_nt, dim3((uint32_t)blocks), dim3(fg::kCalibThreads), 0, stream, reinterpret_cast<const uint4*>(d_src),
+                           reinterpret_cast<uint4*>(d_dst), n16);
+    else if (mode == 3) {
+        if (need > 0x7FFFFFFFull) return -1;
+        hipLaunchKernelGGL(fg::k_calib_copy_flat, dim3((uint32_t)need), dim3(fg::kCalibThreads), 0, stream, reinterpret_cast<const uint4*>(d_src),
+                           reinterpret_cast<uint4*>(d_dst), n16);
+    } else
         hipLaunchKernelGGL(fg::k_calib_read, dim3((uint32_t)blocks), dim3(fg::kCalibThreads), 0, stream, reinterpret_cast<const uint4*>(d_src), n16,
                            d_sink);
     return (int)hipGetLastError();

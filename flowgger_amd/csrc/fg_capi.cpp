@@ -293,7 +293,7 @@ int fg_last_kernel_ms(fg_ctx* ctx, float* ms) {
 }
 
 int fg_calibrate_device(fg_ctx* ctx, int mode, const uint8_t* d_src, uint8_t* d_dst, uint64_t nbytes, void* stream) {
-    if (!ctx || !d_src || (mode != FG_CALIB_COPY && mode != FG_CALIB_READ) || (mode == FG_CALIB_COPY && !d_dst)) return FG_ERR_ARG;
+    if (!ctx || !d_src || mode < FG_CALIB_COPY || mode > FG_CALIB_COPY_FLAT || (mode != FG_CALIB_READ && !d_dst)) return FG_ERR_ARG;
     if ((((uintptr_t)d_src) | ((uintptr_t)d_dst)) & 15u) return FG_ERR_ARG;
     DeviceGuard g(ctx->device);
     if (!ctx->d_sink) FG_HIP(ctx, hipMalloc((void**)&ctx->d_sink, 256));

@@ -401,7 +401,9 @@ int fg_measure_link(fg_ctx* ctx, uint64_t nbytes, double gbps[3]);
  *   FG_CALIB_READ  read-only sweep (d_dst ignored): nbytes of traffic -- the roof of a decoder that writes little
  * bench.py reports both beside the decoder's achieved GB/s (roofline.copy_GBps / read_GBps) so that box-to-box variance is not
  * mistaken for a code change.  No reference analogue (measurement support). */
-enum { FG_CALIB_COPY = 0, FG_CALIB_READ = 1 };
+enum { FG_CALIB_COPY = 0, FG_CALIB_READ = 1,
+       FG_CALIB_COPY_NT = 2,  /* the copy with non-temporal loads and stores */
+       FG_CALIB_COPY_FLAT = 3 /* the copy as one 16-byte element per thread (no grid-stride loop) */ };
 int fg_calibrate_device(fg_ctx* ctx, int mode, const uint8_t* d_src, uint8_t* d_dst, uint64_t nbytes, void* stream);
 
 /* The reference's exact &'static str for a status code of a format (0 -> "", unknown -> NULL). */

@@ -94,7 +94,7 @@ extern "C" int fg_launch_poke64(const uint64_t* src, uint64_t* dst, hipStream_t)
     return 0;
 }
 extern "C" int fg_launch_calib(int mode, const uint8_t* src, uint8_t* dst, uint64_t nbytes, uint32_t*, hipStream_t) {
-    if (mode == 0) memcpy(dst, src, nbytes / 16 * 16);
+    if (mode != 1) memcpy(dst, src, nbytes / 16 * 16);
     return 0;
 }
 extern "C" int fg_launch_rfc5424(const uint8_t* b, const uint64_t* o, uint64_t n, const fg::DevTables* t, uint64_t, hipStream_t, uint64_t*, uint32_t,

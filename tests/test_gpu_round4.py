@@ -209,3 +209,46 @@ def test_one_million_mutated_lines_per_format(oracle, fmt):
         _chunked_compare(dec, oracle, d, offsets, config)
         total += len(base)
     assert total >= 1_000_000
+
+
+@pytest.mark.parametrize("fmt", ["rfc5424_sd", "ltsv", "gelf"])
+def test_zero_copy_decode_batch_from_pinned_buffers(oracle, fmt):
+    """fg_decode_batch with bytes + offsets in pinned memory takes the ZERO-COPY form (one launch, the kernels read the lines over the
+    link and write the table columns into pinned host memory): the Records must be the oracle's, the same as through the sliced copies
+    (FG_LO_NO_ZERO_COPY) -- also when the first entry-table size is too small and the launch is repeated."""
+    import ctypes as C
+
+    from flowgger_amd import _lib as L
+    from flowgger_amd.tables import HostTables
+
+    if fmt == "rfc5424_sd":
+        dec, config = RFC5424Decoder(), None
+        lines = synth.rfc5424_lines(60_000, cfg=4, sd=True) + synth.rfc5424_lines(4000, cfg=5, sd=True, long_tail=True)
+        lines += [b'<13>1 2015-08-05T15:53:45Z h a p m [x ' + b" ".join(b'k%d="v"' % k for k in range(60)) + b"] dense pairs"] * 3000  # > 1 entry / 16 B
+    elif fmt == "ltsv":
+        dec, config, lines = LTSVDecoder(synth.LTSV_CONFIG), synth.LTSV_CONFIG, synth.ltsv_lines(60_000) + synth.ltsv_lines(3000, long_tail=True)
+    else:
+        dec, config, lines = GelfDecoder(), None, synth.gelf_lines(60_000)
+    data, offsets = synth.pack(lines)
+    n = len(lines)
+    lib = L.lib()
+    pb, po = C.c_void_p(), C.c_void_p()
+    L.check(lib.fg_alloc_pinned(data.size + 64, C.byref(pb)), "fg_alloc_pinned")
+    L.check(lib.fg_alloc_pinned((n + 1) * 8, C.byref(po)), "fg_alloc_pinned")
+    try:
+        hb = np.ctypeslib.as_array(C.cast(pb, C.POINTER(C.c_uint8)), (data.size + 64,))
+        ho = np.ctypeslib.as_array(C.cast(po, C.POINTER(C.c_uint64)), (n + 1,))
+        hb[:data.size] = data
+        hb[data.size:] = 0
+        ho[:] = offsets
+        oblob, ooffs = oracle.decode_batch(dec.fmt, data, offsets, config)
+        for no_zc in (False, True):
+            dec.set_launch_opts(no_zero_copy=no_zc)
+            st = L.fg_tables()
+            L.check(lib.fg_decode_batch(dec._ctx, dec.fmt, pb, data.size, po, n, C.byref(st)), "fg_decode_batch")
+            blob, offs = HostTables.from_struct(st).serialize(dec.fmt, data, offsets, cfg=dec._cfg)
+            assert_same(blob, offs, oblob, ooffs, lines)
+    finally:
+        lib.fg_free_pinned(pb)
+        lib.fg_free_pinned(po)
+

@@ -21,7 +21,10 @@ sys.path.insert(0, str(root))
 from flowgger_amd.build import source_hash  # noqa: E402
 
 measured_all = s.get("src_hash")
-src_hash = source_hash(wl) if measured_all and measured_all == source_hash() else measured_all
+# the summary carries the per-workload hashes as computed ON THE GPU BOX from the manifest that travels with the library
+# (flowgger_amd/kernel_deps.json): that is the identity of what was measured, whatever has happened to this tree's host side since
+measured_wl = (s.get("src_hashes") or {}).get(wl)
+src_hash = measured_wl or (source_hash(wl) if measured_all and measured_all == source_hash() else measured_all)
 tr = root / "profiles" / "traffic.json"
 t = json.loads(tr.read_text()) if tr.exists() else {}
 t[wl] = {"hbm_bytes_per_line": h["total"] / lines, "read": h["read"] / lines, "written": h["written"] / lines, "lines": lines,
