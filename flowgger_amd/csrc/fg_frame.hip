@@ -81,7 +81,8 @@ __global__ __launch_bounds__(kWave) void k_frame_scan(const uint8_t* __restrict_
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(bytes + base), (short)0, (int)span, 0x00020000);
     u32x4 v[kFrameRows];
 #pragma unroll
-    for (int k = 0; k < (int)kFrameRows; ++k) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(lane * 16u + k * 1024u), 0, 0);
+    for (int k = 0; k < (int)kFrameRows; ++k)
+        v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(lane * 16u + k * 1024u), 0, COPY ? FG_STREAM_AUX : 0);  // (COPY: read once, over the link)
     if constexpr (COPY) {
         __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(copy_to + base, (short)0, (int)span, 0x00020000);
 #pragma unroll
