@@ -29,6 +29,31 @@
 
 namespace fg {
 
+// The batch buffers of the framers live in PAGE-LOCKED memory (fg_alloc_pinned): with bytes and offsets there, fg_decode_batch is
+// zero-copy -- one launch, the kernels read the lines over the link and write the table columns into the ctx's pinned tables
+// (include/fg_hip.h) -- and the raw-stream / transcode uploads run at link speed instead of through the runtime's staging buffer.
+// A std::vector with this allocator is all it takes; pinning costs milliseconds per allocation, so the framers reserve their
+// capacity once.
+template <class T>
+struct PinnedAllocator {
+    using value_type = T;
+    PinnedAllocator() = default;
+    template <class U>
+    PinnedAllocator(const PinnedAllocator<U>&) {}
+    T* allocate(size_t n) {
+        void* p = nullptr;
+        if (fg_alloc_pinned((uint64_t)(n * sizeof(T)), &p) != FG_OK || !p) throw std::bad_alloc();
+        return static_cast<T*>(p);
+    }
+    void deallocate(T* p, size_t) { fg_free_pinned(p); }
+    template <class U>
+    bool operator==(const PinnedAllocator<U>&) const { return true; }
+    template <class U>
+    bool operator!=(const PinnedAllocator<U>&) const { return false; }
+};
+using PinnedBytes = std::vector<uint8_t, PinnedAllocator<uint8_t>>;
+using PinnedOffsets = std::vector<uint64_t, PinnedAllocator<uint64_t>>;
+
 struct SDValue {  // record.rs:3-11
     enum Kind : uint8_t { String = 0, Bool = 1, F64 = 2, I64 = 3, U64 = 4, Null = 5 } kind = Null;
     std::string s;
@@ -418,7 +443,8 @@ class BufferedSource {
     }
     // a raw chunk for the GPU framers: appends what is there to `out` (at most room bytes) under the same policy, where the
     // batch in the making is `out` itself.  false = nothing was added and the input has ended.
-    bool read_chunk(std::vector<uint8_t>& out, size_t room) {
+    template <class Vec>
+    bool read_chunk(Vec& out, size_t room) {
         using clock = std::chrono::steady_clock;
         const size_t had = out.size();
         bool started = false;
@@ -522,6 +548,9 @@ class BatchingSplitter {
         max_bytes_ = pol.max_bytes;
         bytes_.clear();
         offsets_.assign(1, 0);
+        // (pinned once: a batch never outgrows max_bytes + one line; a longer line re-pins, once)
+        bytes_.reserve(std::min<size_t>(max_bytes_, (size_t)64 << 20) + (1u << 20));
+        offsets_.reserve(std::min<size_t>(max_lines_, (size_t)1 << 20) + 2);
         BufferedSource in(src, pol);
         in.on_block([&] { return bytes_.size() + (offsets_.size() - 1); }, [&] { flush(decoder, sink, err); });
         std::string line;
@@ -623,8 +652,8 @@ class BatchingSplitter {
     }
     Framing f_;
     size_t max_lines_, max_bytes_;
-    std::vector<uint8_t> bytes_;
-    std::vector<uint64_t> offsets_;
+    PinnedBytes bytes_;       // page-locked: fg_decode_batch reads them in place (zero-copy)
+    PinnedOffsets offsets_;
 };
 
 
@@ -726,7 +755,8 @@ class GpuFramingSplitter {
     void run(ByteSource& src, const FlushPolicy& pol, const Decoder& d, const RecordSink& sink, std::ostream& err) {
         chunk_ = pol.max_bytes;
         BufferedSource in(src, pol);
-        std::vector<uint8_t> buf;  // the unterminated tail of the last chunk + what arrived since
+        PinnedBytes buf;  // the unterminated tail of the last chunk + what arrived since (page-locked: uploads at link speed)
+        buf.reserve(std::min<size_t>(chunk_, (size_t)64 << 20) + (1u << 20) + 64);
         for (;;) {
             const bool got = in.read_chunk(buf, chunk_ > buf.size() ? chunk_ - buf.size() : chunk_);
             const bool eof = in.end() == BufferedSource::Eof;
