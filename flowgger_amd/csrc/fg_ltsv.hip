@@ -314,12 +314,15 @@ struct LtsvFormatT {
     static __device__ __forceinline__ void classify_store(const uint4& q, uint16_t* bm16, uint32_t chunk, uint32_t, uint32_t) {
         bm16[chunk] = (uint16_t)mask16(q);
     }
-    LtsvDevCfg cfg;
+    uint32_t n_schema;          // (= cfg->n_schema, in a register)
+    const LtsvDevCfg* cfg;      // the kernel's LDS copy: indexed dynamically below, an embedded copy would live in scratch memory
     uint8_t* lds_digits;        // 768-byte digit buffer for dec2flt's slow path
     const SchemaEnt* schema;    // LDS mirror of the first kSchemaLds schema entries
     const SuffixEnt* suffix;    // LDS mirror of the four suffixes
     const double* p10;          // fg_numfold.hpp tables (LDS)
     const uint32_t* dw;
+    const DevTables* t_call;    // the tables once more, in LDS: what the byte-wise walk (a real call, rare) is handed -- a reference
+                                // to the kernel's own copy would pin that in scratch memory for every line
 
     // ---- the everyday spellings straight out of registers; false = NOT DECIDED: the byte-wise parser of the grammar runs ----
     // f64::from_str of  -?D+(.D+)?  with a significand below 2^53: Clinger's fast path, w / 10^k is the correctly rounded result
@@ -355,7 +358,7 @@ struct LtsvFormatT {
     // schema lookup (HashMap::get, ltsv_decoder.rs:126): exact byte match of the name [nb, nb+nl)
     // whose first 16 bytes are in w[] (zero padded)
     __device__ __forceinline__ uint32_t lookup(LdsReader& rd, uint32_t nb, uint32_t nl, const uint32_t w[4]) const {
-        const uint32_t ns = cfg.n_schema < kSchemaLds ? cfg.n_schema : kSchemaLds;
+        const uint32_t ns = n_schema < kSchemaLds ? n_schema : kSchemaLds;
         // four entries per LDS round trip (every lane reads the same entry: a broadcast); the loads of a batch are issued
         // before the first compare
         for (uint32_t k0 = 0; k0 < ns; k0 += 4u) {
@@ -368,19 +371,19 @@ struct LtsvFormatT {
                 if (e[j].len == nl && e[j].name[0] == w[0] && e[j].name[1] == w[1] && e[j].name[2] == w[2] && e[j].name[3] == w[3]) {
                     bool eq = true;
                     if (nl > 16u) {
-                        const uint32_t o = cfg.name_off[k0 + j];
-                        for (uint32_t i = 16; i < nl && eq; ++i) eq = rd.byte(nb + i) == cfg.blob[o + i];
+                        const uint32_t o = cfg->name_off[k0 + j];
+                        for (uint32_t i = 16; i < nl && eq; ++i) eq = rd.byte(nb + i) == cfg->blob[o + i];
                     }
                     if (eq) return e[j].type;
                 }
             }
         }
-        for (uint32_t k = kSchemaLds; k < cfg.n_schema; ++k) {
-            uint32_t o = cfg.name_off[k], l = cfg.name_off[k + 1] - o;
+        for (uint32_t k = kSchemaLds; k < n_schema; ++k) {
+            uint32_t o = cfg->name_off[k], l = cfg->name_off[k + 1] - o;
             if (l != nl) continue;
             bool eq = true;
-            for (uint32_t i = 0; i < l && eq; ++i) eq = rd.byte(nb + i) == cfg.blob[o + i];
-            if (eq) return cfg.types[k];
+            for (uint32_t i = 0; i < l && eq; ++i) eq = rd.byte(nb + i) == cfg->blob[o + i];
+            if (eq) return cfg->types[k];
         }
         return FG_T_STRING;
     }
@@ -588,8 +591,8 @@ struct LtsvFormatT {
                                     if (sf.len < 8u) tail &= ~0ull >> (64u - 8u * sf.len);
                                     ends = tail == sf.bytes;
                                 } else {
-                                    const uint32_t so = cfg.suf_off[ty - FG_T_BOOL];
-                                    for (uint32_t i = 0; i < sf.len && ends; ++i) ends = rd.byte(ne - sf.len + i) == cfg.blob[so + i];
+                                    const uint32_t so = cfg->suf_off[ty - FG_T_BOOL];
+                                    for (uint32_t i = 0; i < sf.len && ends; ++i) ends = rd.byte(ne - sf.len + i) == cfg->blob[so + i];
                                 }
                             }
                             if (!ends) flags |= FG_EF_SUFFIX;
@@ -716,10 +719,11 @@ struct LtsvFormatT {
                 // (rare; a real call: its LRow lives in memory, so it gets its own -- `r` must never have its address taken, or
                 //  the fast path's row would live in scratch memory too)
                 // The same goes for the tables and the configuration: passed by reference from HERE they would be kept in scratch
-                // memory for the whole kernel (every table store then reloads its column pointer from there): the call gets copies.
+                // memory for the whole kernel (every table store then reloads its column pointer from there): the call gets the
+                // copies the kernel parked in LDS.
                 LRow slow;
-                const DevTables t_copy = t;
-                const LtsvDevCfg cfg_copy = cfg;
+                const DevTables& t_copy = *t_call;
+                const LtsvDevCfg& cfg_copy = *cfg;
                 if (whole && !HEAD) {
                     LdsReader rd(T.w, base);
                     ltsv_walk<false>(rd, len, cfg_copy, lds_digits, slow, t_copy, 0);
@@ -765,8 +769,8 @@ struct LtsvFormatT {
                 // (a line outside the tile -- or one whose records did not fit its consumed bytes, whose copy in the tile is therefore
                 //  no longer intact: from global memory then)
                 LRow scratch = r;
-                const DevTables t_copy = t;  // (see above)
-                const LtsvDevCfg cfg_copy = cfg;
+                const DevTables& t_copy = *t_call;  // (see above)
+                const LtsvDevCfg& cfg_copy = *cfg;
                 if (whole && !HEAD && !tile_lane) {
                     LdsReader rd(T.w, base);
                     ltsv_walk<true>(rd, len, cfg_copy, lds_digits, scratch, t_copy, first);
@@ -844,8 +848,14 @@ __global__ __launch_bounds__(kWave, 2) void k_ltsv(const uint8_t* __restrict__ b
     double* p10 = reinterpret_cast<double*>(extra + kLtsvTablesAt);
     uint32_t* dw = reinterpret_cast<uint32_t*>(extra + kLtsvTablesAt + numfold::kP10Words * 8u);
     numfold::init_tables(dw, p10);
+    __shared__ DevTables t_call;
+    __shared__ LtsvDevCfg cfg_call;
+    if (threadIdx.x == 0) {
+        t_call = t;
+        cfg_call = cfg;
+    }
     __syncthreads();
-    LtsvFormatT<HEAD> fmt{cfg, extra, schema, suffix, p10, dw};
+    LtsvFormatT<HEAD> fmt{cfg.n_schema, &cfg_call, extra, schema, suffix, p10, dw, &t_call};
     persistent_loop<NB, PROF, LtsvFormatT<HEAD>, HEAD>(bytes, offsets, n, t, tile_cap, L, groups, prof, stash_base, fmt, fr);
 }
 

@@ -1030,9 +1030,10 @@ extern "C" int fg_launch_rfc5424(const uint8_t* d_bytes, const uint64_t* d_offse
     int prc;
     if (sdx)
         // (default tile from the same-box sweeps, profiles/r04g_sweep_*: 12 KiB -- eight waves per CU -- for whole lines and for heads)
-        prc = head ? fg::plan_launch(fg::k_rfc5424<fg::kWindowKiB, false, true, true>, n, plan_len, 0u, 57344u, sb, &p, *lo, 64, 2, nullptr,
+        // (tiles of at most 36 KiB: with the two bitmaps and the walk's scratch -- 0.57 x the tile -- that is 58 KiB of LDS per wave)
+        prc = head ? fg::plan_launch(fg::k_rfc5424<fg::kWindowKiB, false, true, true>, n, plan_len, 0u, 36864u, sb, &p, *lo, 64, 2, nullptr,
                                      fg::sd2::extra_bytes, 12288u, 1024u)
-                   : fg::plan_launch(fg::k_rfc5424<fg::kWindowKiB, false, false, true>, n, plan_len, 0u, 57344u, sb, &p, *lo, 64, 2, nullptr,
+                   : fg::plan_launch(fg::k_rfc5424<fg::kWindowKiB, false, false, true>, n, plan_len, 0u, 36864u, sb, &p, *lo, 64, 2, nullptr,
                                      fg::sd2::extra_bytes, 12288u, 1024u);
     else
         prc = head ? fg::plan_launch(fg::k_rfc5424<fg::kWindowKiB, false, true>, n, plan_len, 0u, 57344u, sb, &p, *lo)
