@@ -446,8 +446,6 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
     }
     const bool fast = valid && clean && !tile_bail && n_items_tile <= L.item_cap && len >= 2u && (fe - fi) >= 2u && (fe - fi) <= kMaxLineItems;
     if (valid) {
-        L.l_se[lane] = s | (e << 16);
-        L.l_fife[lane] = fi | (fe << 16);
         L.l_flags[lane] = fast ? 0u : LF_BAIL;
         L.l_err[lane] = 0xFFFFFFFFu;
         L.l_cnt[lane] = 0u;
@@ -464,46 +462,51 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
     FG_MARK(1);
 
     tick(1);
-    // ================= blocks: whole lines, at most 64 items, one item per lane =================
+    // ================= rows: the next lines of the tile, one line per row of W lanes, one item per lane =================
+    // W = 16 (four lines at a time), 32 or 64: the narrowest row that holds the widest of the lines it would take.  What the lanes of
+    // a row find out about their LINE (a member out of shape, the closing brace, the known keys met, the number of extras) is combined
+    // by row reductions in registers, so every lane of the row knows the line's verdict itself: no LDS flags, no atomics and no
+    // barrier inside the loop on the everyday path.  BTreeMap order among a line's extras: rank = extras of the row with a smaller
+    // key, fifteen DPP rotations of the keys' first four bytes (W = 16); keys those cannot order, the same key twice, and wider
+    // rows take the 64-bit form through LDS.
     const uint64_t valid_m = wv::ballot(valid);
-    uint32_t lb = valid_m ? wv::ctz64(valid_m) : wv::kLanes;
     const uint32_t lend = valid_m ? 64u - wv::clz64(valid_m) : 0u;  // one past the last valid lane
+    uint32_t lb = valid_m ? wv::ctz64(valid_m) : wv::kLanes;
+    const uint32_t cntf = fast ? fe - fi : 0u;  // the items of this lane's line (0: not for the rows)
+    const uint32_t pk_se = s | (e << 16), pk_fc = fi | (cntf << 16);
+    // the wave's entry-slot reservation (wv::wave_alloc): read once per tile, kept in (scalar) registers, written back behind the loop
+    uint32_t a_next = wv::bcast(L.ent_state[0], 0u), a_left = wv::bcast(L.ent_state[1], 0u);
     while (lb < lend) {
-        const uint32_t fi_lb = wv::bcast(fi, lb);
-        const bool over = lane >= lb && lane < lend && (!valid || (fe - fi_lb) > wv::kLanes);
-        const uint64_t over_m = wv::ballot(over);
-        const uint32_t le = over_m ? wv::ctz64(over_m) : lend;
-        if (le == lb) {  // a single line with more than 64 items (not a fast-form line: flagged above), or a hole
-            lb = lb + 1u;
-            continue;
-        }
-        const uint32_t n_items = wv::bcast(fe, le - 1u) - fi_lb;
+        const uint32_t c0 = wv::bcast(cntf, lb);
+        const uint32_t c1 = lb + 1u < lend ? wv::bcast(cntf, lb + 1u) : 0u;
+        const uint32_t c2 = lb + 2u < lend ? wv::bcast(cntf, lb + 2u) : 0u;
+        const uint32_t c3 = lb + 3u < lend ? wv::bcast(cntf, lb + 3u) : 0u;
+        const uint32_t m01 = c0 > c1 ? c0 : c1, m23 = c2 > c3 ? c2 : c3;
+        const uint32_t lg = (m01 <= 16u && m23 <= 16u) ? 4u : (m01 <= 32u ? 5u : 6u);
+        const uint32_t W = 1u << lg, rows = 64u >> lg;
 
         // ---- the item of this lane ----
-        const uint32_t jj = lane;
-        bool act = jj < n_items;
-        uint32_t k = lb;  // the item's line: the last line of the block that starts at or before it
-        for (uint32_t q = lb + 1u; q < le; ++q)
-            if ((L.l_fife[q] & 0xFFFFu) - fi_lb <= jj) k = q;
-        const uint32_t se = L.l_se[k], ff = L.l_fife[k];
+        const uint32_t row = lane >> lg, j = lane & (W - 1u), k = lb + row;
+        const uint32_t kk = k < lend ? k : lend - 1u;
+        const uint32_t se = wv::shfl(pk_se, kk), fc = wv::shfl(pk_fc, kk);
         const uint32_t ls = se & 0xFFFFu, le_ = se >> 16;
-        const uint32_t kfi = (ff & 0xFFFFu) - fi_lb, kfe = (ff >> 16) - fi_lb;  // the line's items: lanes [kfi, kfe)
-        act = act && !(L.l_flags[k] & LF_BAIL);
+        const uint32_t fi_k = fc & 0xFFFFu, n_k = k < lend ? fc >> 16 : 0u;  // the line's items: lanes [row base, row base + n_k)
+        const bool act = j < n_k;
         FG_MARK(7);
         tick(7);
-        bool member = false;
+        bool member = false, closed = false, bad = false;
         uint64_t key = ~0ull, bits = 0;
         uint32_t key_b = 0, kl = 0, which = K_OTHER, kind = V_NULL, v_b = 0, v_len = 0, v_esc = 0;
         if (act) {
-            const uint32_t pos = L.items[fi_lb + jj];
-            const bool first_item = jj == kfi, last_item = jj + 1u == kfe;
-            const uint32_t nxt = last_item ? pos + 1u : (uint32_t)L.items[fi_lb + jj + 1u];
+            const uint32_t pos = L.items[fi_k + j];
+            const bool first_item = j == 0u, last_item = j + 1u == n_k;
+            const uint32_t nxt = last_item ? pos + 1u : (uint32_t)L.items[fi_k + j + 1u];
             const uint32_t c = T.byte(pos), rb = T.byte(nxt);
             bool ok;
             if (c == '}') {
                 // the closing brace: last item, only spaces behind it, and something opened before it
                 ok = last_item && !first_item && wv::find_bit(bmN, pos + 1u, le_) >= le_;
-                if (ok) wv::lds_or(&L.l_flags[k], LF_CLOSED);
+                closed = ok;
             } else {
                 // '{' or ',' owns the member up to the next item, which must be ',' or '}'  ('[' / ']' = nesting, control characters:
                 // not fast-form material).  Straight-line from here: every read below is at a clamped, always readable position and the
@@ -616,95 +619,22 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
                         uint64_t pre = (uint64_t)kw[0] | ((uint64_t)kw[1] << 32);
                         if (kl < 8u) pre &= kl == 0u ? 0ull : (~0ull >> (64u - 8u * kl));
                         const uint64_t be = __builtin_bswap64(pre);
-                        key = (be & ~0xFFull) | (which == K_OTHER ? 0x80ull : 0ull) | (jj - kfi);  // index in line < 64
+                        key = (be & ~0xFFull) | (which == K_OTHER ? 0x80ull : 0ull) | j;  // index in line < 64
                         member = true;
                     }
                 }
                 // "{}": no member at all; "{,", ",,", ",}" are syntax errors
                 ok = ok & (empty ? (m <= 64u && c == '{' && rb == '}') : (okm & okv));
             }
-            if (!ok) wv::lds_or(&L.l_flags[k], LF_BAIL);
+            bad = !ok;
+            member = member && ok;
         }
-        L.kblk[lane] = key;
-        L.kinfo[lane] = key_b | (kl << 16);
-        wv::sync();
         FG_MARK(2);
         tick(2);
 
-        // ---- BTreeMap order inside the line: rank among the members (orders the errors) and among the extras (the slot) ----
-        uint32_t rank_x = 0;  // (the rank among ALL members only orders errors: counted where one is found)
-        bool dropped = false;
-        member = member && !(L.l_flags[k] & LF_BAIL);
-        // Fast form: the keys' first FOUR bytes (the high dword of the sort key) order the line's members whenever they are pairwise
-        // different -- every GELF producer's field names -- with one 32-bit compare per key; a lane that meets an equal high dword
-        // (the same key twice, or two keys that share four bytes) sends the block through the full 64-bit form below.
-        bool tie = false;
+        // ---- gelf_decoder.rs:51-106 for this member: its status, the line flags it sets and what it leaves in the line's row ----
+        uint32_t st = G_OK, fl = 0u, si = 0xFFu, pa = 0u, pb = 0u;
         if (member) {
-            const uint32_t hi_k = (uint32_t)(key >> 32);
-            for (uint32_t t0 = kfi; t0 < kfe; t0 += 4u) {
-                uint64_t ko[4];
-#pragma unroll
-                for (uint32_t u = 0; u < 4u; ++u) ko[u] = L.kblk[(t0 + u) & 63u];  // (past the line: masked out below)
-#pragma unroll
-                for (uint32_t u = 0; u < 4u; ++u) {
-                    const uint32_t tt = t0 + u;
-                    const bool in = tt < kfe;
-                    const uint32_t hi_o = (uint32_t)(ko[u] >> 32);
-                    rank_x += (in && hi_o < hi_k && ((uint32_t)ko[u] & 0x80u)) ? 1u : 0u;
-                    tie = tie || (in && tt != jj && hi_o == hi_k);
-                }
-            }
-        }
-        if (wv::any(member && tie)) {  // rare
-        rank_x = 0;
-        if (member) {
-            bool bail = false, dup = false;
-            // (four keys per round trip: the loads of a batch are issued before the first compare)
-            for (uint32_t t0 = kfi; t0 < kfe; t0 += 4u) {
-                uint64_t ko[4];
-#pragma unroll
-                for (uint32_t u = 0; u < 4u; ++u) ko[u] = L.kblk[(t0 + u) & 63u];  // (past the line: masked out below)
-#pragma unroll
-                for (uint32_t u = 0; u < 4u; ++u) {
-                    const uint32_t tt = t0 + u;
-                    const bool in = tt < kfe;
-                    rank_x += (in && ko[u] < key && (ko[u] & 0x80ull)) ? 1u : 0u;
-                    if (in && tt != jj && (ko[u] >> 8) == (key >> 8)) {
-                        // same 7-byte prefix: the same key twice (the later one wins, BTreeMap::insert), or two keys the prefix
-                        // cannot order (the general form sorts them)
-                        const uint32_t oi = L.kinfo[tt];
-                        const uint32_t ob = oi & 0xFFFFu, ol = oi >> 16;
-                        bool same = ol == kl;
-                        for (uint32_t q = 7; q < kl && same; ++q) same = T.byte(key_b + q) == T.byte(ob + q);
-                        if (!same) bail = true;
-                        else if (tt > jj) dropped = true;
-                        dup = true;
-                    }
-                }
-            }
-            if (bail) wv::lds_or(&L.l_flags[k], LF_BAIL);
-            else if (dup) wv::lds_or(&L.l_flags[k], LF_DUP);
-        }
-        }
-        if (wv::any(dropped)) {  // rare: erase the dropped duplicates and recount their lines
-            wv::sync();
-            if (dropped) L.kblk[lane] = ~0ull;
-            wv::sync();
-            if (member && !dropped && (L.l_flags[k] & LF_DUP)) {
-                rank_x = 0;
-                for (uint32_t tt = kfi; tt < kfe; ++tt) {
-                    const uint64_t ko = L.kblk[tt];
-                    rank_x += (ko < key && (ko & 0x80ull)) ? 1u : 0u;
-                }
-            }
-        }
-        member = member && !dropped;
-        FG_MARK(3);
-        tick(3);
-        // ---- gelf_decoder.rs:51-106 for this member ----
-        if (member && !(L.l_flags[k] & LF_BAIL)) {
-            uint32_t* row = L.l_row + k * 8u;
-            uint32_t st = G_OK;
             switch (which) {
                 case K_TS: {
                     double tsv = 0.0;
@@ -713,34 +643,38 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
                     else if (kind == V_I64) tsv = (double)(int64_t)bits;
                     else st = G_TS;
                     const uint64_t tb = num::f64_to_bits(tsv);
-                    row[0] = (uint32_t)tb;
-                    row[1] = (uint32_t)(tb >> 32);
-                    wv::lds_or(&L.l_flags[k], LF_HAVE_TS);
+                    pa = (uint32_t)tb;
+                    pb = (uint32_t)(tb >> 32);
+                    si = 0u;
+                    fl = LF_HAVE_TS;
                     break;
                 }
                 case K_HOST:
                     if (kind != V_STRING) st = G_HOST;
-                    row[2] = v_b - ls;
-                    row[3] = v_len;
-                    wv::lds_or(&L.l_flags[k], LF_HAVE_HOST | (v_esc ? (uint32_t)FG_F_HOST_ESC << 8 : 0u));
+                    pa = v_b - ls;
+                    pb = v_len;
+                    si = 2u;
+                    fl = LF_HAVE_HOST | (v_esc ? (uint32_t)FG_F_HOST_ESC << 8 : 0u);
                     break;
                 case K_SHORT:
                     if (kind != V_STRING) st = G_SHORT;
-                    row[4] = v_b - ls;
-                    row[5] = v_len;
-                    if (v_esc) wv::lds_or(&L.l_flags[k], (uint32_t)FG_F_MSG_ESC << 8);
+                    pa = v_b - ls;
+                    pb = v_len;
+                    si = 4u;
+                    fl = v_esc ? (uint32_t)FG_F_MSG_ESC << 8 : 0u;
                     break;
                 case K_FULL:
                     if (kind != V_STRING) st = G_FULL;
-                    row[6] = v_b - ls;
-                    row[7] = v_len;
-                    if (v_esc) wv::lds_or(&L.l_flags[k], (uint32_t)FG_F_FULLMSG_ESC << 8);
+                    pa = v_b - ls;
+                    pb = v_len;
+                    si = 6u;
+                    fl = v_esc ? (uint32_t)FG_F_FULLMSG_ESC << 8 : 0u;
                     break;
                 case K_VERSION:
                     if (kind != V_STRING) {
                         st = G_VERSTR;
                     } else if (v_esc) {
-                        wv::lds_or(&L.l_flags[k], LF_BAIL);  // "1.0" / "1.1" by DECODED value: an escaped spelling is for the general form
+                        bad = true;  // "1.0" / "1.1" by DECODED value: an escaped spelling is for the general form
                     } else {
                         const uint32_t three = (uint32_t)T.load8(v_b) & 0xFFFFFFu;
                         if (!(v_len == 3u && (three == 0x302E31u || three == 0x312E31u))) st = G_VER;
@@ -749,66 +683,171 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
                 case K_LEVEL:
                     if (kind != V_U64) st = G_LEVEL;  // Value::as_u64 (NumCast): floats and negatives -> None
                     else if (bits > 7u) st = G_LEVEL7;
-                    else L.l_sev[k] = (uint32_t)bits;
+                    else {
+                        si = 8u;
+                        pa = (uint32_t)bits;
+                    }
                     break;
                 default:
-                    wv::lds_add(&L.l_cnt[k], 1u);  // an extra (nested values never reach the fast form)
+                    break;  // an extra (nested values never reach the fast form)
             }
-            if (st != G_OK) {  // the FIRST error in BTreeMap order is the line's: rank among all members
+        }
+        FG_MARK(4);
+        tick(4);
+
+        // ---- BTreeMap order among the line's extras ----
+        bool extra = member && which == K_OTHER;
+        uint32_t rank_x = 0;
+        const bool wide = lg != 4u;
+        if (!wide) {
+            const uint32_t xk = extra ? (uint32_t)(key >> 32) : 0xFFFFFFFFu;  // (valid UTF-8 holds no 0xFF: nothing ties with a non-extra)
+            rank_x = wv::row16_count_less(xk);
+        }
+        // ---- the line, as every lane of its row sees it ----
+        //   R_or : bit 0 a lane out of shape, 1 closed, 2 / 3 timestamp / host met, 8..15 FG_F_* escapes, 16 a member in error,
+        //          17..22 the known keys met;   R_add: extras | known keys << 8 | sum of the extras' ranks << 16
+        uint32_t R_or, R_add;
+        auto combine = [&]() {
+            const uint32_t known = (member && which != K_OTHER) ? 1u : 0u;
+            const uint32_t w_or = (bad ? (uint32_t)LF_BAIL : 0u) | (closed ? (uint32_t)LF_CLOSED : 0u) | (member ? fl : 0u) |
+                                  ((member && st != G_OK) ? 0x10000u : 0u) | (known ? (0x20000u << which) : 0u);
+            const uint32_t w_add = (extra ? (1u | (rank_x << 16)) : 0u) | (known << 8);
+            R_or = wv::rows_or(w_or, lg);
+            R_add = wv::rows_add(w_add, lg);
+        };
+        combine();
+        // Ranks by four key bytes are a permutation of 0 .. nx-1 exactly when those are pairwise different (a tie takes one from the
+        // sum); a known key met twice shows as more known members than known-key bits.
+        bool redo;
+        {
+            const uint32_t nx = R_add & 0xFFu, nk = (R_add >> 8) & 0xFFu;
+            const bool tie = !wide && (R_add >> 16) != ((nx * (nx - 1u)) >> 1);
+            const bool dupk = nk != wv::popc32((R_or >> 17) & 0x3Fu);
+            redo = wide || wv::any(act && (tie || dupk));
+        }
+        if (redo) {  // rare: the 64-bit keys through LDS (7 key bytes | extra bit | index); duplicates: the last one wins
+            L.kblk[lane] = member ? key : ~0ull;
+            L.kinfo[lane] = key_b | (kl << 16);
+            wv::sync();
+            const uint32_t kfi = lane - j, kfe = kfi + n_k;
+            bool dropped = false;
+            rank_x = 0;
+            if (member) {
+                bool bail = false;
+                for (uint32_t tt = kfi; tt < kfe; ++tt) {
+                    const uint64_t ko = L.kblk[tt];
+                    rank_x += (ko < key && (ko & 0x80ull)) ? 1u : 0u;
+                    if (tt != lane && (ko >> 8) == (key >> 8)) {
+                        // same 7-byte prefix: the same key twice (the later one wins, BTreeMap::insert), or two keys the prefix
+                        // cannot order (the general form sorts them)
+                        const uint32_t oi = L.kinfo[tt];
+                        const uint32_t ob = oi & 0xFFFFu, ol = oi >> 16;
+                        bool same = ol == kl;
+                        for (uint32_t q = 7; q < kl && same; ++q) same = T.byte(key_b + q) == T.byte(ob + q);
+                        if (!same) bail = true;
+                        else if (tt > lane) dropped = true;
+                    }
+                }
+                if (bail) bad = true;
+            }
+            if (wv::any(dropped)) {  // erase the dropped duplicates and recount
+                wv::sync();
+                if (dropped) L.kblk[lane] = ~0ull;
+                wv::sync();
+                if (member && !dropped) {
+                    rank_x = 0;
+                    for (uint32_t tt = kfi; tt < kfe; ++tt) {
+                        const uint64_t ko = L.kblk[tt];
+                        rank_x += (ko < key && (ko & 0x80ull)) ? 1u : 0u;
+                    }
+                }
+            }
+            member = member && !dropped;
+            extra = extra && !dropped;
+            combine();
+        }
+        FG_MARK(3);
+        tick(3);
+        // ---- the line's verdict ----
+        const bool line_ok = (R_or & (LF_BAIL | LF_CLOSED)) == LF_CLOSED;
+        uint32_t status = G_OK;
+        if (wv::any(act && line_ok && (R_or & 0x10000u))) {  // rare: the FIRST error in BTreeMap order is the line's
+            if (!redo) L.kblk[lane] = member ? key : ~0ull;
+            wv::sync();
+            if (member && st != G_OK && line_ok) {
+                const uint32_t kfi = lane - j, kfe = kfi + n_k;
                 uint32_t rank_all = 0;
                 for (uint32_t tt = kfi; tt < kfe; ++tt) rank_all += L.kblk[tt] < key ? 1u : 0u;
                 wv::lds_min(&L.l_err[k], (rank_all << 8) | st);
             }
+            wv::sync();
+            if (act && (R_or & 0x10000u)) status = L.l_err[k] & 0xFFu;
+            wv::sync();  // (read before the row's first lane replaces it with the final status)
         }
-        wv::sync();
-        FG_MARK(4);
-        tick(4);
-        // ---- the line's verdict, by the lane of its first item; entry slots for the block out of the wave's chunk ----
-        uint32_t my_ent = 0;
-        bool done = false;
-        if (jj < n_items && jj == kfi) {
-            const uint32_t lf = L.l_flags[k];
-            if (!(lf & LF_BAIL) && (lf & LF_CLOSED)) {
-                const uint32_t err = L.l_err[k];
-                uint32_t status = err == 0xFFFFFFFFu ? G_OK : (err & 0xFFu);
-                if (status == G_OK && !(lf & LF_HAVE_HOST)) status = G_NOHOST;  // :110
-                my_ent = status == G_OK ? L.l_cnt[k] : 0u;
-                L.l_err[k] = status;  // (reused: the final status)
-                done = true;
-            } else {
-                wv::lds_or(&L.l_flags[k], LF_BAIL);
+        if (status == G_OK && !(R_or & LF_HAVE_HOST)) status = G_NOHOST;  // :110
+        const uint32_t n_ent = (line_ok && status == G_OK) ? (R_add & 0xFFu) : 0u;
+        // ---- entry slots for the rows out of the wave's chunk: what is left of it takes the lines whose slices fit, whole; the
+        //      rest opens the next chunk (the offsets are wave-uniform: scalar arithmetic on the rows' first lanes) ----
+        const uint32_t e0 = wv::bcast(n_ent, 0u);
+        const uint32_t e1 = rows >= 2u ? wv::bcast(n_ent, W) : 0u;
+        const uint32_t e2 = rows == 4u ? wv::bcast(n_ent, 2u * W) : 0u;
+        const uint32_t e3 = rows == 4u ? wv::bcast(n_ent, 3u * W) : 0u;
+        const uint32_t o1 = e0, o2 = o1 + e1, o3 = o2 + e2, total = o3 + e3;
+        wv::Slots es{a_next, total, 0u, false};
+        if (total <= a_left) {  // everyday: out of what is left of the chunk -- scalar arithmetic on the state kept in registers
+            a_next += total;
+            a_left -= total;
+        } else {
+            uint32_t cut_at = total;
+            if (e3 != 0u && o3 + e3 > a_left) cut_at = o3;
+            if (e2 != 0u && o2 + e2 > a_left) cut_at = o2;
+            if (e1 != 0u && o1 + e1 > a_left) cut_at = o1;
+            if (e0 != 0u && e0 > a_left) cut_at = 0u;
+            if (lane == 0u) {
+                L.ent_state[0] = a_next;
+                L.ent_state[1] = a_left;
             }
+            wv::sync();
+            es = wv::wave_alloc(t.ent_used, t.ent_cap, L.ent_state, total, cut_at, L.alloc_chunk);
+            a_next = wv::bcast(L.ent_state[0], 0u);
+            a_left = wv::bcast(L.ent_state[1], 0u);
         }
-        uint32_t bl_total;
-        const uint32_t bl_off = wv::excl_sum(my_ent, &bl_total);  // (lanes that do not own a line contribute 0)
-        // (what is left of the wave's chunk takes the lines whose slices fit, whole; the rest opens the next chunk)
-        const uint32_t left = wv::wave_left(L.ent_state);
-        const uint64_t nofit = wv::ballot(my_ent != 0u && bl_off + my_ent > left);
-        const uint32_t cut_at = nofit ? wv::bcast(bl_off, wv::ctz64(nofit)) : bl_total;
-        const wv::Slots es = wv::wave_alloc(t.ent_used, t.ent_cap, L.ent_state, bl_total, cut_at, L.alloc_chunk);
-        if (done) {
-            const bool ov = es.overflow && my_ent != 0u && bl_off >= es.cut;
-            if (ov) L.l_err[k] = FG_ST_OVERFLOW;
-            L.l_cnt[k] = ov ? 0u : my_ent;
-            L.l_eoff[k] = my_ent ? es.at(bl_off) : 0u;
-            wv::lds_or(&L.l_flags[k], LF_DONE);
-        }
-        wv::sync();
-        // ---- extras -> the entry table, at first(line) + rank among the line's extras (BTreeMap order): the lanes of a block
-        //      write ONE contiguous stretch of slots ----
-        if (member && which == K_OTHER) {
-            const uint32_t lf = L.l_flags[k];
-            if ((lf & (LF_BAIL | LF_DONE)) == LF_DONE && L.l_cnt[k] != 0u) {
-                const uint32_t slot = L.l_eoff[k] + rank_x;
+        const uint32_t bl_off = row == 0u ? 0u : row == 1u ? o1 : row == 2u ? o2 : o3;
+        const bool ov = es.overflow && n_ent != 0u && bl_off >= es.cut;
+        const uint32_t slot0 = es.at(bl_off);
+        if (act && line_ok) {
+            if (j == 0u) {  // for the lane that owns the line (rows, below)
+                L.l_err[k] = ov ? (uint32_t)FG_ST_OVERFLOW : status;
+                L.l_cnt[k] = ov ? 0u : n_ent;
+                L.l_eoff[k] = n_ent ? slot0 : 0u;
+                L.l_flags[k] = LF_DONE | (R_or & (LF_HAVE_TS | 0xFF00u));
+            }
+            if (member && si != 0xFFu) {
+                if (si == 8u) {
+                    L.l_sev[k] = pa;
+                } else {
+                    uint32_t* rowp = L.l_row + k * 8u;
+                    rowp[si] = pa;
+                    rowp[si + 1u] = pb;
+                }
+            }
+            // ---- extras -> the entry table, at first(line) + rank among the line's extras (BTreeMap order): the lanes of a block
+            //      write ONE contiguous stretch of slots ----
+            if (extra && n_ent != 0u && !ov) {
+                const uint32_t slot = slot0 + rank_x;
                 t.ent_name[slot] = fg_span{key_b - ls, kl};
                 t.ent_val[slot] = kind == V_STRING ? ((uint64_t)(v_b - ls) | ((uint64_t)v_len << 32)) : kind == V_NULL ? 0ull : bits;
                 t.ent_type[slot] = (uint8_t)kind;
                 t.ent_flags[slot] = (uint8_t)((kind == V_STRING && v_esc) ? FG_EF_VAL_ESC : 0);
             }
         }
-        lb = le;
+        lb += rows;
         FG_MARK(5);
         tick(5);
+    }
+    if (lane == 0u) {
+        L.ent_state[0] = a_next;
+        L.ent_state[1] = a_left;
     }
     // the dirty bits of this tile have been looked at: clean for the next one
     if (wv::any(valid)) {

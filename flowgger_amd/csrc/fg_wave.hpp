@@ -149,6 +149,77 @@ FG_WV uint32_t excl_sum(uint32_t v, uint32_t* total) {
 }
 #endif
 
+// ---- rows of 16 lanes (the DPP row): rotations and all-to-all reductions without the LDS crossbar.  Every lane of the wave must be
+//      active (a DPP read of a disabled lane returns nothing useful): wave-uniform control flow only.
+#if defined(__HIPCC__)
+template <int N>
+FG_WV uint32_t row_ror(uint32_t v) {  // lane i of a row reads lane (i - N) mod 16 of the same row
+    return dpp_<0x120 + N, 0xf, 0xf, true>(v);
+}
+#else
+template <int N>
+FG_WV uint32_t row_ror(uint32_t v) {
+    const uint32_t l = lane();
+    return shfl(v, (l & ~15u) | ((l - (uint32_t)N) & 15u));
+}
+#endif
+// how many of the other fifteen lanes of this lane's row hold a value below x: the all-pairs count behind a rank inside a row.  The
+// compiler keeps every rotation a separate v_mov_dpp (3 instructions a step; gfx950 has no DPP compare); spelled out, a subtract
+// that reads its operand through DPP leaves "the other one is smaller" as its borrow and an add with carry-in collects it (2 a step).
+#if defined(__HIP_DEVICE_COMPILE__)
+FG_WV uint32_t row16_count_less(uint32_t x) {
+    uint32_t acc = 0, tmp;
+    // (s_nop 4: a VALU write of x, or of EXEC, just before a DPP read needs up to five wait states nobody adds inside an asm block)
+#define FG_STEP_(N) "v_sub_co_u32_dpp %1, vcc, %2, %2 row_ror:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_addc_co_u32_e32 %0, vcc, 0, %0, vcc\n\t"
+    asm volatile("s_nop 4\n\t" FG_STEP_(1) FG_STEP_(2) FG_STEP_(3) FG_STEP_(4) FG_STEP_(5) FG_STEP_(6) FG_STEP_(7) FG_STEP_(8) FG_STEP_(9)
+                     FG_STEP_(10) FG_STEP_(11) FG_STEP_(12) FG_STEP_(13) FG_STEP_(14) FG_STEP_(15)
+                 : "+v"(acc), "=&v"(tmp)
+                 : "v"(x)
+                 : "vcc");
+#undef FG_STEP_
+    return acc;
+}
+#else
+FG_WV uint32_t row16_count_less(uint32_t x) {
+    uint32_t acc = 0;
+    acc += row_ror<1>(x) < x ? 1u : 0u;
+    acc += row_ror<2>(x) < x ? 1u : 0u;
+    acc += row_ror<3>(x) < x ? 1u : 0u;
+    acc += row_ror<4>(x) < x ? 1u : 0u;
+    acc += row_ror<5>(x) < x ? 1u : 0u;
+    acc += row_ror<6>(x) < x ? 1u : 0u;
+    acc += row_ror<7>(x) < x ? 1u : 0u;
+    acc += row_ror<8>(x) < x ? 1u : 0u;
+    acc += row_ror<9>(x) < x ? 1u : 0u;
+    acc += row_ror<10>(x) < x ? 1u : 0u;
+    acc += row_ror<11>(x) < x ? 1u : 0u;
+    acc += row_ror<12>(x) < x ? 1u : 0u;
+    acc += row_ror<13>(x) < x ? 1u : 0u;
+    acc += row_ror<14>(x) < x ? 1u : 0u;
+    acc += row_ror<15>(x) < x ? 1u : 0u;
+    return acc;
+}
+#endif
+// OR / sum over the lanes of a row of (1 << lg) lanes, lg = 4, 5 or 6 (wave-uniform); every lane gets the result
+FG_WV uint32_t rows_or(uint32_t x, uint32_t lg) {
+    x |= row_ror<1>(x);
+    x |= row_ror<2>(x);
+    x |= row_ror<4>(x);
+    x |= row_ror<8>(x);
+    if (lg >= 5u) x |= shfl(x, lane() ^ 16u);
+    if (lg >= 6u) x |= shfl(x, lane() ^ 32u);
+    return x;
+}
+FG_WV uint32_t rows_add(uint32_t x, uint32_t lg) {
+    x += row_ror<1>(x);
+    x += row_ror<2>(x);
+    x += row_ror<4>(x);
+    x += row_ror<8>(x);
+    if (lg >= 5u) x += shfl(x, lane() ^ 16u);
+    if (lg >= 6u) x += shfl(x, lane() ^ 32u);
+    return x;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Entry-table slots, wave-cooperative.  Every allocation used to be one atomic on the SAME global word (ent_used): 250 K atomics
 // per 4 M lines serialise in one L2 channel and hold up everything else routed through it (measured: the loads of unrelated

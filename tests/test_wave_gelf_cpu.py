@@ -142,6 +142,39 @@ def test_semantics(wave, oracle):
         assert not by_line[ln], ln
 
 
+def test_row_widths_ties_and_duplicates(wave, oracle):
+    """The rows of the item pass: lines of up to 16 items share a wave four at a time and rank their extras by the keys' first four
+    bytes (DPP rotations); wider lines get rows of 32 / 64 lanes, and keys the four bytes cannot order, or a key met twice, take
+    the 64-bit form through LDS.  All of these are producers' spelling: the fast form must handle every one itself."""
+    def obj(n, pfx="_k", host_at=0, extra=""):
+        f = [f'"{pfx}{(i * 7) % n:02d}":{i}' for i in range(n)]
+        f.insert(host_at % (n + 1), '"host":"h"')
+        return "{" + ",".join(f) + extra + "}"
+
+    lines = []
+    for n in (0, 1, 2, 12, 13, 14, 15, 16, 17, 29, 30, 31, 32, 33, 47, 61, 62):
+        lines.append(obj(n, host_at=n // 2))
+    # four-byte ties (ordered by bytes 4..6), seven-byte ties with different lengths handed back, duplicates of extras and known keys
+    lines += ['{"_user_name":"n","_user_id":7,"host":"h","_user":1,"_use":2,"_us":3}',
+              '{"host":"h","_user_id":1,"_user_id":2,"_a":3}', '{"host":"a","_z":1,"host":"b","_y":2,"host":"c"}',
+              '{"level":3,"_b":1,"level":"bad","host":"h","_a":2}', '{"level":"bad","_b":1,"level":3,"host":"h","_a":2}',
+              '{"timestamp":"x","_q":1,"level":99,"host":"h","version":"7"}',
+              '{"version":"1.1","host":"h","short_message":"m","full_message":"f","timestamp":1.5,"level":3,"_a":1,"_b":2,"_c":3,'
+              '"_d":4,"_e":5,"_f":6,"_g":7,"_h":8,"_i":9}',  # 16 items exactly: six known keys + nine extras
+              '{"version":"1.1","host":"h","short_message":"m","full_message":"f","timestamp":1.5,"level":3,"_a":1,"_b":2,"_c":3,'
+              '"_d":4,"_e":5,"_f":6,"_g":7,"_h":8,"_i":9,"_j":10}']  # 17: a row of 32
+    rng = np.random.default_rng(4)
+    mixed = [lines[int(i)] for i in rng.integers(0, len(lines), 400)] + synth.gelf_lines(400, invalid_frac=0)
+    order = rng.permutation(len(mixed))
+    mixed = [mixed[int(i)] for i in order]
+    for geom in (dict(), dict(lines_per_group=8, tile_cap=4096), dict(lines_per_group=5, tile_cap=4096),
+                 dict(lines_per_group=64, tile_cap=24576)):
+        handled = check(wave, oracle, lines, must_handle=range(len(lines)), **geom)
+        assert handled.all()
+        handled = check(wave, oracle, mixed, **geom)
+        assert handled.all()
+
+
 def test_odd_quotes_do_not_leak_into_the_next_line(wave, oracle):
     """A line with an unbalanced quote flips the raw string parity of everything behind it in the tile: the in-string state
     must start afresh at every line (the toggle pass)."""
