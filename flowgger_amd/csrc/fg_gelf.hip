@@ -729,7 +729,20 @@ int launch_gelf_fast(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t
 #endif
     if constexpr (NB == 3) {
         if (p.tile == 4096u && p.L == 8u && !fg::prof_requested() && !(lo.flags & FG_LO_GELF_GENERIC)) {
-            // the geometry of ~300-byte GELF (the BASELINE corpus): constants
+            // the geometry of ~300-byte GELF (the BASELINE corpus): constants (every LDS address an immediate)
+            if (!lo.tile_cap && 8u * avg_len * 17u / 16u + 256u <= 3072u) {
+                // ... and when the average group of eight fits 3 KiB, a tile of exactly the register window: 6.3 KiB of LDS and 96
+                // registers (two spilled) let twenty waves share a CU (4 KiB tiles: 8 040 B, and only eighteen fit -- 1481 vs
+                // 1422 M lines/s at sixteen, profiles/r04s_sweep_cfg3.log)
+                fg_launch_opts lo3 = lo;
+                lo3.tile_cap = 3072u;
+                if (fg::plan_launch(fg::k_gelf<NB, false, 5, 3072u, 8u>, n, avg_len, 0u, 40960u, 0u, &p, lo3, max_lines,
+                                    fg::GelfFormat::kClasses, fg::gelf_extra_lds) || p.tile != 3072u || p.L != 8u)
+                    return -1;
+                hipLaunchKernelGGL((fg::k_gelf<NB, false, 5, 3072u, 8u>), dim3(p.blocks), block, p.lds, stream, d_bytes, d_offsets, n, *t,
+                                   p.tile, p.L, p.chunk, (unsigned long long*)nullptr, (uint64_t*)nullptr, fr);
+                return 0;
+            }
             hipLaunchKernelGGL((fg::k_gelf<NB, false, 4, 4096u, 8u>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L,
                                p.chunk, (unsigned long long*)nullptr, (uint64_t*)nullptr, fr);
             return 0;

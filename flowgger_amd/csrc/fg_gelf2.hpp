@@ -114,10 +114,8 @@ struct Lds {
     uint8_t* wpar;           // [words + 1] string parity carried INTO each 64-byte word
     uint16_t* wcnt;          // [words + 1] items before each word
     uint16_t* items;         // [item_cap] tile position of every item of the tile
-    uint64_t* kblk;          // [64] the block's sort keys: 7 key bytes big endian | extra << 7 | index in line;  ~0 = not a member
-    uint32_t* kinfo;         // [64] the block's key spans: key_b | key_len << 16
     uint32_t* dirty;         // [words / 32 + 1] bit w: word w of the tile holds a control character (set by stage A, cleared here)
-    uint32_t *l_se, *l_fife, *l_flags, *l_err, *l_cnt, *l_eoff, *l_sev;  // [lines] per line (l_eoff: the line's first entry slot)
+    uint32_t *l_flags, *l_err, *l_cnt, *l_eoff, *l_sev;  // [lines] per line (l_eoff: the line's first entry slot)
     uint32_t* l_row;         // [lines][8]: ts lo, ts hi, host off, host len, msg off, msg len, full off, full len
     double* p10;             // [23] 10^0 .. 10^22 (exact): the number parser's divisors without a trip to global memory
     uint32_t* dw;            // [16 + 12] digit weights of a dword by its 4-bit digit mask (parse_num24), then 10^0 .. 10^8
@@ -133,8 +131,8 @@ FG_WVH uint32_t dirty_bytes(uint32_t tile_cap) { return up8((tile_cap / 64u / 32
 // bytes of the extra block
 FG_WVH uint32_t extra_bytes(uint32_t tile_cap, uint32_t lines) {
     const uint32_t words = tile_cap / 64u + 2u;
-    return dirty_bytes(tile_cap) + up8(words) + up8(words * 2u) + up8(item_cap_for(tile_cap) * 2u + 16u) + 64u * 8u + 64u * 4u +
-           lines * (7u * 4u + 32u) + 23u * 8u + 28u * 4u + 64u;
+    return dirty_bytes(tile_cap) + up8(words) + up8(words * 2u) + up8(item_cap_for(tile_cap) * 2u + 16u) + lines * (5u * 4u + 32u) +
+           23u * 8u + 28u * 4u + 64u;
 }
 FG_WV Lds carve(const uint8_t* tile, uint16_t* bm16, uint32_t tile_cap, uint8_t* extra, uint32_t lines) {
     Lds L;
@@ -146,11 +144,7 @@ FG_WV Lds carve(const uint8_t* tile, uint16_t* bm16, uint32_t tile_cap, uint8_t*
     uint8_t* p = extra;
     L.dirty = reinterpret_cast<uint32_t*>(p); p += dirty_bytes(tile_cap);  // (first: stage A finds it right behind the bitmaps)
     L.p10 = reinterpret_cast<double*>(p); p += 23u * 8u;
-    L.kblk = reinterpret_cast<uint64_t*>(p); p += 64u * 8u;
     L.l_row = reinterpret_cast<uint32_t*>(p); p += lines * 32u;
-    L.kinfo = reinterpret_cast<uint32_t*>(p); p += 64u * 4u;
-    L.l_se = reinterpret_cast<uint32_t*>(p); p += lines * 4u;
-    L.l_fife = reinterpret_cast<uint32_t*>(p); p += lines * 4u;
     L.l_flags = reinterpret_cast<uint32_t*>(p); p += lines * 4u;
     L.l_err = reinterpret_cast<uint32_t*>(p); p += lines * 4u;
     L.l_cnt = reinterpret_cast<uint32_t*>(p); p += lines * 4u;
@@ -725,45 +719,45 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
             const bool dupk = nk != wv::popc32((R_or >> 17) & 0x3Fu);
             redo = wide || wv::any(act && (tie || dupk));
         }
-        if (redo) {  // rare: the 64-bit keys through LDS (7 key bytes | extra bit | index); duplicates: the last one wins
-            L.kblk[lane] = member ? key : ~0ull;
-            L.kinfo[lane] = key_b | (kl << 16);
-            wv::sync();
-            const uint32_t kfi = lane - j, kfe = kfi + n_k;
-            bool dropped = false;
+        if (redo) {  // rare: 64-bit keys (7 key bytes | extra bit | index), every lane meets the other lanes of its row by shuffle
+            const uint32_t rb = lane - j, kinfo = key_b | (kl << 16);
+            bool dropped = false, bail = false;
             rank_x = 0;
-            if (member) {
-                bool bail = false;
-                for (uint32_t tt = kfi; tt < kfe; ++tt) {
-                    const uint64_t ko = L.kblk[tt];
-                    rank_x += (ko < key && (ko & 0x80ull)) ? 1u : 0u;
-                    if (tt != lane && (ko >> 8) == (key >> 8)) {
-                        // same 7-byte prefix: the same key twice (the later one wins, BTreeMap::insert), or two keys the prefix
-                        // cannot order (the general form sorts them)
-                        const uint32_t oi = L.kinfo[tt];
-                        const uint32_t ob = oi & 0xFFFFu, ol = oi >> 16;
-                        bool same = ol == kl;
-                        for (uint32_t q = 7; q < kl && same; ++q) same = T.byte(key_b + q) == T.byte(ob + q);
-                        if (!same) bail = true;
-                        else if (tt > lane) dropped = true;
-                    }
-                }
-                if (bail) bad = true;
-            }
-            if (wv::any(dropped)) {  // erase the dropped duplicates and recount
-                wv::sync();
-                if (dropped) L.kblk[lane] = ~0ull;
-                wv::sync();
-                if (member && !dropped) {
-                    rank_x = 0;
-                    for (uint32_t tt = kfi; tt < kfe; ++tt) {
-                        const uint64_t ko = L.kblk[tt];
+            {
+                const uint64_t mine = member ? key : ~0ull;
+                const uint32_t klo = (uint32_t)mine, khi = (uint32_t)(mine >> 32);
+                for (uint32_t d = 1; d < W; ++d) {  // (wave-uniform)
+                    const uint32_t src = rb + ((j + d) & (W - 1u));
+                    const uint32_t olo = wv::shfl(klo, src), ohi = wv::shfl(khi, src), oi = wv::shfl(kinfo, src);
+                    const uint64_t ko = ((uint64_t)ohi << 32) | olo;
+                    if (member) {
                         rank_x += (ko < key && (ko & 0x80ull)) ? 1u : 0u;
+                        if ((ko >> 8) == (key >> 8)) {
+                            // same 7-byte prefix: the same key twice (the later one wins, BTreeMap::insert), or two keys the prefix
+                            // cannot order (the general form sorts them)
+                            const uint32_t ob = oi & 0xFFFFu, ol = oi >> 16;
+                            bool same = ol == kl;
+                            for (uint32_t q = 7; q < kl && same; ++q) same = T.byte(key_b + q) == T.byte(ob + q);
+                            if (!same) bail = true;
+                            else if (src > lane) dropped = true;
+                        }
                     }
                 }
             }
+            if (bail) bad = true;
             member = member && !dropped;
             extra = extra && !dropped;
+            if (wv::any(dropped)) {  // recount without the dropped duplicates
+                const uint64_t mine = member ? key : ~0ull;
+                const uint32_t klo = (uint32_t)mine, khi = (uint32_t)(mine >> 32);
+                rank_x = 0;
+                for (uint32_t d = 1; d < W; ++d) {
+                    const uint32_t src = rb + ((j + d) & (W - 1u));
+                    const uint32_t olo = wv::shfl(klo, src), ohi = wv::shfl(khi, src);
+                    const uint64_t ko = ((uint64_t)ohi << 32) | olo;
+                    rank_x += (member && ko < key && (ko & 0x80ull)) ? 1u : 0u;
+                }
+            }
             combine();
         }
         FG_MARK(3);
@@ -772,14 +766,16 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
         const bool line_ok = (R_or & (LF_BAIL | LF_CLOSED)) == LF_CLOSED;
         uint32_t status = G_OK;
         if (wv::any(act && line_ok && (R_or & 0x10000u))) {  // rare: the FIRST error in BTreeMap order is the line's
-            if (!redo) L.kblk[lane] = member ? key : ~0ull;
-            wv::sync();
-            if (member && st != G_OK && line_ok) {
-                const uint32_t kfi = lane - j, kfe = kfi + n_k;
-                uint32_t rank_all = 0;
-                for (uint32_t tt = kfi; tt < kfe; ++tt) rank_all += L.kblk[tt] < key ? 1u : 0u;
-                wv::lds_min(&L.l_err[k], (rank_all << 8) | st);
+            const uint32_t rb = lane - j;
+            const uint64_t mine = member ? key : ~0ull;
+            const uint32_t klo = (uint32_t)mine, khi = (uint32_t)(mine >> 32);
+            uint32_t rank_all = 0;
+            for (uint32_t d = 1; d < W; ++d) {  // (wave-uniform)
+                const uint32_t src = rb + ((j + d) & (W - 1u));
+                const uint32_t olo = wv::shfl(klo, src), ohi = wv::shfl(khi, src);
+                rank_all += (((uint64_t)ohi << 32) | olo) < mine ? 1u : 0u;
             }
+            if (member && st != G_OK && line_ok) wv::lds_min(&L.l_err[k], (rank_all << 8) | st);
             wv::sync();
             if (act && (R_or & 0x10000u)) status = L.l_err[k] & 0xFFu;
             wv::sync();  // (read before the row's first lane replaces it with the final status)
