@@ -86,9 +86,14 @@ extern "C" int fg_launch_calib(int mode, const uint8_t* d_src, uint8_t* d_dst, u
         hipLaunchKernelGGL(fg::k_calib_copy_nt, dim3((uint32_t)blocks), dim3(fg::kCalibThreads), 0, stream, reinterpret_cast<const uint4*>(d_src),
                            reinterpret_cast<uint4*>(d_dst), n16);
     else if (mode == 3) {
-        if (need > 0x7FFFFFFFull) return -1;
-        hipLaunchKernelGGL(fg::k_calib_copy_flat, dim3((uint32_t)need), dim3(fg::kCalibThreads), 0, stream, reinterpret_cast<const uint4*>(d_src),
-                           reinterpret_cast<uint4*>(d_dst), n16);
+        // (a launch holds fewer than 2^32 threads: buffers beyond 64 GiB go in slices of 2^30 elements, back to back on the stream)
+        const uint64_t slice = 1ull << 30;
+        for (uint64_t at = 0; at < n16; at += slice) {
+            const uint64_t m = n16 - at < slice ? n16 - at : slice;
+            hipLaunchKernelGGL(fg::k_calib_copy_flat, dim3((uint32_t)((m + fg::kCalibThreads - 1) / fg::kCalibThreads)), dim3(fg::kCalibThreads), 0,
+                               stream, reinterpret_cast<const uint4*>(d_src) + at, reinterpret_cast<uint4*>(d_dst) + at, m);
+            if (hipGetLastError() != hipSuccess) return -1;
+        }
     } else
         hipLaunchKernelGGL(fg::k_calib_read, dim3((uint32_t)blocks), dim3(fg::kCalibThreads), 0, stream, reinterpret_cast<const uint4*>(d_src), n16,
                            d_sink);

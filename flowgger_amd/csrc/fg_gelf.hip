@@ -579,7 +579,7 @@ struct GelfFormat {
         const bool ok = f.handled && f.status == G_OK;
         o.meta = f.handled ? (f.status | (0xFFu << 8) | ((ok ? f.severity : 0xFFu) << 16) | ((ok ? f.flags : 0u) << 24)) : kPending;
         // (tell the general kernel that this launch left it something: any lane, the same value, idempotent)
-        if (t.pending && c.valid && !f.handled) *t.pending = t.epoch;
+        if (t.pending && c.valid && !f.handled) gstore(t.pending, 0, t.epoch);
         o.ts = (ok && f.have_ts) ? f.ts : 0.0;
         o.span[S_HOST] = ok ? fg_span{f.host_off, f.host_len} : none;
         o.span[S_APP] = none;
@@ -609,7 +609,13 @@ __global__ __launch_bounds__(kWave, MINW) void k_gelf(const uint8_t* __restrict_
         gelf2::init_lds(lds);
         gelf2::clear_dirty(lds, tile_cap);
     }
-    persistent_loop<NB, PROF>(bytes, offsets, n, t, tile_cap, L, groups, prof, stash_base, fmt, fr);
+    // The tables' forty words live in LDS, not in scalar registers: with them the kernel needs more than the 102 it has, and the
+    // compiler parks whole 16-register kernel-argument tuples in VGPR lanes -- every row store and every entry store then began
+    // with sixteen or thirty-two v_readlane (7 % of the kernel's VALU instructions); a column pointer is now one LDS read where used.
+    __shared__ DevTables t_lds;
+    if (threadIdx.x == 0) t_lds = t;
+    __syncthreads();
+    persistent_loop<NB, PROF>(bytes, offsets, n, t_lds, tile_cap, L, groups, prof, stash_base, fmt, fr);
     if (PROF) {
         __syncthreads();
         if (threadIdx.x < 10) atomicAdd(&prof[6 + threadIdx.x], pacc[threadIdx.x]);

@@ -804,7 +804,7 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
                 L.ent_state[1] = a_left;
             }
             wv::sync();
-            es = wv::wave_alloc(t.ent_used, t.ent_cap, L.ent_state, total, cut_at, L.alloc_chunk);
+            es = wv::wave_alloc(glb(t.ent_used), t.ent_cap, L.ent_state, total, cut_at, L.alloc_chunk);
             a_next = wv::bcast(L.ent_state[0], 0u);
             a_left = wv::bcast(L.ent_state[1], 0u);
         }
@@ -831,10 +831,10 @@ FG_WV LineOut decode_tile(const Lds& L, uint32_t span, bool valid, uint32_t base
             //      write ONE contiguous stretch of slots ----
             if (extra && n_ent != 0u && !ov) {
                 const uint32_t slot = slot0 + rank_x;
-                t.ent_name[slot] = fg_span{key_b - ls, kl};
-                t.ent_val[slot] = kind == V_STRING ? ((uint64_t)(v_b - ls) | ((uint64_t)v_len << 32)) : kind == V_NULL ? 0ull : bits;
-                t.ent_type[slot] = (uint8_t)kind;
-                t.ent_flags[slot] = (uint8_t)((kind == V_STRING && v_esc) ? FG_EF_VAL_ESC : 0);
+                gstore(t.ent_name, slot, fg_span{key_b - ls, kl});
+                gstore(t.ent_val, slot, kind == V_STRING ? ((uint64_t)(v_b - ls) | ((uint64_t)v_len << 32)) : kind == V_NULL ? 0ull : bits);
+                gstore(t.ent_type, slot, (uint8_t)kind);
+                gstore(t.ent_flags, slot, (uint8_t)((kind == V_STRING && v_esc) ? FG_EF_VAL_ESC : 0));
             }
         }
         lb += rows;

@@ -167,12 +167,12 @@ struct RowOut {
 };
 __device__ __forceinline__ void store_row(const DevTables& t, uint64_t li, const RowOut& o) {
     if (o.skip) return;
-    t.meta[li] = o.meta;
-    t.ts[li] = o.ts;
+    gstore(t.meta, li, o.meta);
+    gstore(t.ts, li, o.ts);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) t.span[k][li] = o.span[k];
-    t.ent_first[li] = o.first;
-    t.ent_count[li] = o.count;
+    for (int k = 0; k < 6; ++k) gstore(t.span[k], li, o.span[k]);
+    gstore(t.ent_first, li, o.first);
+    gstore(t.ent_count, li, o.count);
 }
 // Entries found while a line is parsed are parked in the wave's scratch (stash[k * 64 + lane],
 // k < kStashEntries, two u64 per entry in the GELF/LTSV kernels, one in the RFC5424 kernel) and

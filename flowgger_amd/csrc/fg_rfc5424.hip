@@ -1002,6 +1002,13 @@ __global__ __launch_bounds__(kWave, 2) void k_rfc5424(const uint8_t* __restrict_
         persistent_loop<NB, PROF, Rfc5424FormatT<HEAD, SDX, PROF>, HEAD>(bytes, offsets, n, t, tile_cap, L, groups, prof, stash_base, fmt, fr);
         __syncthreads();
         if (prof && threadIdx.x < 10) atomicAdd(&prof[6 + threadIdx.x], pacc[threadIdx.x]);
+    } else if constexpr (SDX) {
+        // (the pair-parallel kernel keeps the tables' forty words in LDS: in scalar registers they push the kernel past the 102 it has,
+        //  and the compiler parks whole kernel-argument tuples in VGPR lanes -- see k_gelf)
+        __shared__ DevTables t_lds;
+        if (threadIdx.x == 0) t_lds = t;
+        __syncthreads();
+        persistent_loop<NB, PROF, Rfc5424FormatT<HEAD, SDX, PROF>, HEAD>(bytes, offsets, n, t_lds, tile_cap, L, groups, prof, stash_base, fmt, fr);
     } else {
         persistent_loop<NB, PROF, Rfc5424FormatT<HEAD, SDX, PROF>, HEAD>(bytes, offsets, n, t, tile_cap, L, groups, prof, stash_base, fmt, fr);
     }

@@ -654,16 +654,16 @@ FG_WV void group_emit(const Lds& L, const DevTables& t, const LineIn& in, const 
         const uint32_t r = L.rec[rec_index(oi0, j)];
         const uint32_t nl = r & 63u, esc = (r >> 6) & 1u, elem = (r >> 7) & 1u;
         const uint32_t name_s = open - 1u - nl;
-        t.ent_name[slot] = fg_span{name_s - obase, nl};
-        t.ent_val[slot] = (uint64_t)(open + 1u - obase) | ((uint64_t)(close - open - 1u) << 32);
-        t.ent_type[slot] = FG_T_STRING;
-        t.ent_flags[slot] = esc ? FG_EF_VAL_ESC : 0;
+        gstore(t.ent_name, slot, fg_span{name_s - obase, nl});
+        gstore(t.ent_val, slot, (uint64_t)(open + 1u - obase) | ((uint64_t)(close - open - 1u) << 32));
+        gstore(t.ent_type, slot, (uint8_t)FG_T_STRING);
+        gstore(t.ent_flags, slot, (uint8_t)(esc ? FG_EF_VAL_ESC : 0));
         if (elem) {  // the element this pair opens: `[id name=` (the line's first) or `][id name=`
             const uint32_t id_s = j ? prevc + 3u : os0 + 1u;
-            t.ent_name[slot - 1u] = fg_span{id_s - obase, name_s - 1u - id_s};
-            t.ent_val[slot - 1u] = 0;
-            t.ent_type[slot - 1u] = FG_T_SDID;
-            t.ent_flags[slot - 1u] = 0;
+            gstore(t.ent_name, slot - 1u, fg_span{id_s - obase, name_s - 1u - id_s});
+            gstore(t.ent_val, slot - 1u, 0ull);
+            gstore(t.ent_type, slot - 1u, (uint8_t)FG_T_SDID);
+            gstore(t.ent_flags, slot - 1u, (uint8_t)0);
         }
     }
 }

@@ -28,6 +28,38 @@ struct DevTables {
     uint32_t* pending;
     uint32_t epoch;
 };
+// A table pointer that did not come straight out of the kernel arguments (a kernel that keeps its DevTables in LDS, k_gelf) is a
+// generic pointer to the compiler: stores through it would be flat_ instructions, which also count against the LDS wait counter.
+// gstore() says what every table pointer is -- global memory.  (No effect where the compiler knows already.)
+template <class T> struct SameAs { typedef T type; };  // (a non-deduced context: the pointer alone names the element type)
+template <int N> struct RawOf;
+template <> struct RawOf<1> { typedef uint8_t type; };
+template <> struct RawOf<4> { typedef uint32_t type; };
+template <> struct RawOf<8> { typedef uint64_t type; };
+#if defined(__HIPCC__)
+#define FG_TV_HD __host__ __device__ __forceinline__
+#else
+#define FG_TV_HD inline
+#endif
+template <class T>
+FG_TV_HD void gstore(T* p, uint64_t i, const typename SameAs<T>::type& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef typename RawOf<sizeof(T)>::type U;
+    U u;
+    __builtin_memcpy(&u, &v, sizeof(T));
+    ((U __attribute__((address_space(1)))*)p)[i] = u;
+#else
+    p[i] = v;
+#endif
+}
+template <class T>
+FG_TV_HD T* glb(T* p) {  // (atomics: the builtin takes a generic pointer; the cast chain is what the optimiser sees)
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (T*)(T __attribute__((address_space(1)))*)p;
+#else
+    return p;
+#endif
+}
 enum { S_HOST = 0, S_APP = 1, S_PROC = 2, S_MSGID = 3, S_MSG = 4, S_FULL = 5 };
 
 }  // namespace fg
