@@ -151,9 +151,26 @@ static int pinned_tables_for_kernels(fg_ctx* ctx, const fg_tables& ht, fg_tables
 // LTSV 194 vs 170, cfg2 210 vs 196 against the sliced hipMemcpy pipeline below, whose uploads and downloads the runtime of this
 // platform queues on ONE copy engine: profiles/r04a_timeline_*.log, an upload and a download never in flight together).  Only the
 // entry counter stays in HBM (atomics).  Returns FG_ERR_UNSUPPORTED when the buffers do not qualify: the caller falls through.
+// A decode grid whose tables lie in pinned host memory runs at the LINK's pace: its waves mostly wait for their stores to drain.  At full
+// occupancy (GELF: twenty waves per CU) that costs throughput -- same box, 4 M GELF lines: fg_frame_decode_batch 105 M lines/s with
+// every wave slot taken, 129 M at eight waves per CU; fg_decode_batch 151 -> 161 M (profiles/r04w_frame_overlap.log; the other formats'
+// kernels hold eight waves or fewer anyway).  For the duration of a host pipeline the grid is capped at eight, unless the caller set
+// its own figure (fg_set_launch_opts).
+struct LinkBoundGrid {
+    fg_ctx* ctx;
+    bool set;
+    explicit LinkBoundGrid(fg_ctx* c) : ctx(c), set(c->lo.waves_per_cu == 0) {
+        if (set) ctx->lo.waves_per_cu = 8;
+    }
+    ~LinkBoundGrid() {
+        if (set) ctx->lo.waves_per_cu = 0;
+    }
+};
+
 static int decode_batch_zero_copy(fg_ctx* ctx, fg_format fmt, const uint8_t* bytes, uint64_t nbytes, const uint64_t* offsets, uint64_t n,
                                   fg_tables* out) {
     if (n == 0 || (ctx->lo.flags & FG_LO_NO_ZERO_COPY)) return FG_ERR_UNSUPPORTED;
+    LinkBoundGrid grid(ctx);
     const uint8_t* d_bytes = (const uint8_t*)device_view_of_pinned(bytes);
     const uint64_t* d_offsets = (const uint64_t*)device_view_of_pinned(offsets);
     if (!d_bytes || !d_offsets || ((uintptr_t)d_bytes & 15u) != 0 || !device_view_of_pinned(bytes + nbytes - 1) ||
@@ -468,6 +485,7 @@ static int pinned_tables_for_kernels(fg_ctx* ctx, const fg_tables& ht, fg_tables
 static int frame_decode_sliced(fg_ctx* ctx, fg_format fmt, fg_framing framing, const uint8_t* bytes, uint64_t nbytes, int final,
                                fg_tables* out, const uint64_t** out_offsets, uint64_t* n_frames, uint64_t* consumed) {
     int rc;
+    LinkBoundGrid grid(ctx);
     const uint64_t blk = fg_frame_block_bytes();
     uint64_t slice = nbytes / 8;
     if (slice < (8ull << 20)) slice = 8ull << 20;

@@ -758,10 +758,10 @@ struct LtsvFormatT {
                     for (uint32_t j = 0; j < 4u; ++j) {
                         const uint32_t k = k0 + j;
                         if (k < r.n_ent) {
-                            t.ent_name[first + k] = fg_span{q[j][0] & 0xFFFFu, q[j][0] >> 16};
-                            t.ent_val[first + k] = (uint64_t)q[j][2] | ((uint64_t)q[j][3] << 32);
-                            t.ent_type[first + k] = (uint8_t)(q[j][1] & 0xFFu);
-                            t.ent_flags[first + k] = (uint8_t)((q[j][1] >> 8) & 0xFFu);
+                            gstore(t.ent_name, first + k, fg_span{q[j][0] & 0xFFFFu, q[j][0] >> 16});
+                            gstore(t.ent_val, first + k, (uint64_t)q[j][2] | ((uint64_t)q[j][3] << 32));
+                            gstore(t.ent_type, first + k, (uint8_t)(q[j][1] & 0xFFu));
+                            gstore(t.ent_flags, first + k, (uint8_t)((q[j][1] >> 8) & 0xFFu));
                         }
                     }
                 }
@@ -856,7 +856,8 @@ __global__ __launch_bounds__(kWave, 2) void k_ltsv(const uint8_t* __restrict__ b
     }
     __syncthreads();
     LtsvFormatT<HEAD> fmt{cfg.n_schema, &cfg_call, extra, schema, suffix, p10, dw, &t_call};
-    persistent_loop<NB, PROF, LtsvFormatT<HEAD>, HEAD>(bytes, offsets, n, t, tile_cap, L, groups, prof, stash_base, fmt, fr);
+    // (the pipeline gets the LDS copy of the tables too: see k_gelf -- scalar-register tuples parked in VGPR lanes otherwise)
+    persistent_loop<NB, PROF, LtsvFormatT<HEAD>, HEAD>(bytes, offsets, n, t_call, tile_cap, L, groups, prof, stash_base, fmt, fr);
 }
 
 }  // namespace fg
