@@ -869,7 +869,7 @@ def main():
                 rf["read_only_frac_of_read"] = alg_read / (dms * 1e-3) / 1e9 / rf["read_GBps"]
         if frame_ms is not None:
             out["framing"] = {"ms": frame_ms, "GBps": tile_bytes * reps / (frame_ms * 1e-3) / 1e9,
-                              "note": "fg_frame_device: scan + prefix + emit kernels incl. the host sync that returns the frame count"}
+                              "note": "fg_frame_device: the one-pass framing scan (chained look-back over 128 KiB tiles; the stream is read once) incl. clearing the verdicts and the host sync that returns the frame count"}
         # HBM traffic from the PMC passes (tools/prof.sh -> profiles/traffic.json): only when it was measured on THESE
         # kernel sources -- a figure from older code is not reported
         tr = ROOT / "profiles" / "traffic.json"

@@ -322,17 +322,20 @@ int fg_frame_device(fg_ctx* ctx, fg_framing framing, const uint8_t* d_bytes, uin
     if (nbytes == 0) return FG_OK;
     int rc;
     if ((rc = grow_dev(ctx, (void**)&ctx->d_frame, &ctx->d_frame_cap, fg_frame_scratch_bytes(nbytes))) != FG_OK) return rc;
-    uint64_t* d_total = nullptr;
-    int lrc = fg_launch_frame(d_bytes, nbytes, framing == FG_FRAME_LINE ? 0x0Au : 0x00u, ctx->d_frame, d_offsets, d_bad_utf8,
-                              cap_frames, &d_total, s);
-    if (lrc != 0) {
-        ctx->last_hip = lrc;
-        return FG_ERR_HIP;
-    }
-    // frames = delimiters (+1 when the stream does not end with one)
     uint64_t total = 0;
-    FG_HIP(ctx, hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, s));
-    FG_HIP(ctx, hipStreamSynchronize(s));
+    for (int classic = (ctx->lo.flags & FG_LO_FRAME_CLASSIC) ? 1 : 0;; classic = 1) {
+        uint64_t* d_total = nullptr;
+        int lrc = fg_launch_frame(d_bytes, nbytes, framing == FG_FRAME_LINE ? 0x0Au : 0x00u, ctx->d_frame, d_offsets, d_bad_utf8,
+                                  cap_frames, &d_total, s, classic);
+        if (lrc != 0) {
+            ctx->last_hip = lrc;
+            return FG_ERR_HIP;
+        }
+        // frames = delimiters (+1 when the stream does not end with one)
+        FG_HIP(ctx, hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, s));
+        FG_HIP(ctx, hipStreamSynchronize(s));
+        if (total != FG_FRAME_ABORTED || classic) break;  // (the one-pass scan gave up waiting on a tile: the three-kernel form)
+    }
     if (total + 1 > cap_frames) {
         *n_frames = total + 1;
         return FG_ERR_ENT_OVERFLOW;

@@ -53,11 +53,13 @@ extern "C" int fg_launch_encode_write(const uint8_t* d_bytes, const uint64_t* d_
                                       uint8_t* d_out, hipStream_t stream);
 extern "C" uint64_t fg_frame_scratch_bytes(uint64_t nbytes);
 extern "C" int fg_launch_frame(const uint8_t* d_bytes, uint64_t nbytes, uint32_t delim, uint8_t* scratch, uint64_t* d_offsets,
-                               uint8_t* d_bad, uint64_t cap, uint64_t** d_total_out, hipStream_t stream);
+                               uint8_t* d_bad, uint64_t cap, uint64_t** d_total_out, hipStream_t stream, int classic);
+constexpr uint64_t FG_FRAME_ABORTED = ~0ull;  // *d_total_out after a one-pass launch whose look-back gave up: launch again, classic
 extern "C" uint64_t fg_frame_block_bytes(void);
+extern "C" uint64_t fg_frame_slice_align(void);
 extern "C" int fg_launch_frame_slice(const uint8_t* d_bytes, uint64_t nbytes, uint32_t delim, uint8_t* scratch, uint64_t* d_offsets,
                                      uint8_t* d_bad, uint64_t cap, uint64_t blk0, uint64_t blk1, uint64_t** d_total_out,
-                                     hipStream_t stream, const uint8_t* src);
+                                     hipStream_t stream, const uint8_t* src, int classic);
 extern "C" int fg_launch_ltsv(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
                               const fg::LtsvDevCfg* cfg, uint64_t avg_len, hipStream_t stream, uint64_t* stash,
                               uint32_t stash_blocks, uint32_t strip, const uint8_t* line_bad, const fg_launch_opts* lo);

@@ -13,12 +13,16 @@
 // kernels strip "\n" / "\r\n" / "\0" themselves, fg_decode_frames_device), bad_utf8[i] = 1 when
 // the frame is not valid UTF-8.
 //
-// Two streaming passes, HBM-bound:
-//   scan  every byte once: 16 B per lane, per 16-byte chunk a delimiter mask and a UTF-8 error
-//         mask (both 16 bits, one u32 store), delimiter count per 16 KiB block;
-//   (a one-workgroup exclusive scan of the block counts;)
-//   emit  reads only the masks (1/4 of the input): rank of every delimiter -> offsets[], error
-//         bits -> bad_utf8[frame].
+// ONE streaming pass (k_frame_onepass, round 4): a wave takes a 16 KiB tile -- 16 B per lane and row, per 16-byte chunk a delimiter
+// mask and a UTF-8 error mask -- counts its delimiters, learns how many lie before its tile from the tiles before it (a chained
+// scan with decoupled look-back over one 8-byte descriptor per tile: flag | count), and writes the offsets of ITS delimiters and the
+// bad-UTF-8 flags of ITS error positions from the masks it still holds (transposed through 4 KiB of LDS so that a lane owns 256
+// consecutive bytes).  The stream is read once; nothing but the descriptors is written besides the output.
+// The classic form (k_frame_scan -> k_frame_prefix -> k_frame_emit: masks to HBM, a one-workgroup scan of the tile counts, a second
+// pass over the masks; 39 GB of traffic for a 25.5 GB stream) is kept as the fall-back: a wave that waits on a predecessor's
+// descriptor longer than kSpinLimit polls raises an abort word, every wave leaves, the launcher's caller sees the sentinel total
+// and runs the classic kernels (forward progress of the chain rests on workgroups being dispatched in index order; the bound makes a
+// platform where that ever fails slow, not hung).
 // UTF-8 validity is judged per byte position from the byte and its three predecessors (the
 // table-free form of the well-formedness rules, Unicode 15 Table 3-7), so blocks, waves and
 // lanes need no carried state; an error is always flagged inside the frame it belongs to
@@ -202,6 +206,176 @@ __global__ __launch_bounds__(kWave) void k_frame_emit(const uint32_t* __restrict
     }
 }
 
+
+// ---- the one-pass form ----------------------------------------------------------------------------------------------------
+// desc[tile] = flag << 62 | value: flag 0 nothing yet, 1 the tile's own delimiter count (A), 2 the count of all tiles up to and
+// including this one (P).  Zeroed once per stream (fg_launch_frame / the first slice).
+constexpr uint64_t kDescA = 1ull << 62, kDescP = 2ull << 62, kDescVal = (1ull << 62) - 1ull;
+constexpr uint32_t kSpinLimit = 1u << 22;  // polls of ~100 cycles each: a third of a second
+constexpr uint64_t kFrameAborted = ~0ull;  // what pref[blk1] holds when the chain gave up (the caller runs the classic kernels)
+
+// A workgroup of four waves takes a 64 KiB tile (a wave = one 16 KiB block of it, as in the classic scan); ONE descriptor per tile:
+// the chain moves at most 64 descriptors per look-back step (a trip to L2), so the tile must be large enough for that to outrun
+// the memory system -- with one wave per 16 KiB descriptor the scan ran at 2.9 TB/s, bound by exactly that (profiles/r04x_*).
+constexpr uint32_t kTileWaves = 8;
+template <bool COPY>
+__global__ __launch_bounds__(kWave* kTileWaves) void k_frame_onepass(const uint8_t* __restrict__ bytes, uint64_t nbytes, uint32_t delim_pat,
+                                                                    uint64_t* __restrict__ desc, uint64_t* __restrict__ pref,
+                                                                    uint32_t* __restrict__ abort_w, uint64_t* __restrict__ offsets,
+                                                                    uint8_t* __restrict__ bad, uint64_t cap, uint64_t tile0, uint64_t blk1,
+                                                                    uint64_t nblk, uint32_t whole, uint8_t* __restrict__ copy_to) {
+    __shared__ __attribute__((aligned(16))) uint32_t m_lds[kTileWaves][kFrameBlock / 16u];
+    __shared__ uint32_t s_cnt[kTileWaves];
+    __shared__ uint64_t s_prefix;
+    __shared__ uint32_t s_abort;
+    const uint32_t lane = threadIdx.x & (kWave - 1u), wv = threadIdx.x / kWave;
+    const uint64_t tile = tile0 + blockIdx.x;
+    const uint64_t blk = tile * kTileWaves + wv;  // this wave's 16 KiB block (may lie behind the stream: empty then)
+    const uint64_t base = blk * kFrameBlock;
+    const uint64_t left = base < nbytes ? nbytes - base : 0ull;  // (a block AT the end only carries the "cut off by the end" check)
+    const uint32_t span = left >= kFrameBlock ? kFrameBlock : (uint32_t)((left + 15u) & ~15ull);
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(bytes + (base < nbytes ? base : 0ull)), (short)0, (int)span, 0x00020000);
+    u32x4 v[kFrameRows];
+#pragma unroll
+    for (int k = 0; k < (int)kFrameRows; ++k)
+        v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(lane * 16u + k * 1024u), 0, COPY ? FG_STREAM_AUX : 0);
+    if constexpr (COPY) {
+        __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(copy_to + (base < nbytes ? base : 0ull), (short)0, (int)span, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < (int)kFrameRows; ++k) __builtin_amdgcn_raw_buffer_store_b128(v[k], dst, (int)(lane * 16u + k * 1024u), 0, 0);
+    }
+    uint32_t before = 0;  // the dword just before this block (row 0, lane 0 needs it)
+    if (base != 0 && base <= nbytes) before = *reinterpret_cast<const uint32_t*>(bytes + base - 4);
+    uint32_t count = 0;
+    uint32_t prev_row_last = before;
+#pragma unroll
+    for (int k = 0; k < (int)kFrameRows; ++k) {
+        const uint4 q = make_uint4(v[k][0], v[k][1], v[k][2], v[k][3]);
+        const uint64_t cpos = base + (uint64_t)(k * kWave + lane) * 16u;
+        const uint32_t nv = cpos >= nbytes ? 0u : (nbytes - cpos >= 16u ? 16u : (uint32_t)(nbytes - cpos));
+        const uint32_t dm = mask16_eq(q, delim_pat) & ((1u << nv) - 1u);
+        uint32_t pw = __shfl_up(q.w, 1, kWave);
+        const uint32_t row_last = __shfl(q.w, kWave - 1, kWave);
+        if (lane == 0) pw = prev_row_last;
+        prev_row_last = row_last;
+        uint32_t em = 0;
+        if (((q.x | q.y | q.z | q.w | pw) & 0x80808080u) != 0u) {
+            em = gather16(utf8_err_flags(q.x, pw), utf8_err_flags(q.y, q.x), utf8_err_flags(q.z, q.y), utf8_err_flags(q.w, q.z));
+            em &= nv >= 16u ? 0xFFFFu : ((2u << nv) - 1u);  // keep position nv itself (zero fill = "not a continuation")
+            if (cpos > nbytes) em = 0;
+        }
+        m_lds[wv][k * kWave + lane] = dm | (em << 16);
+        count += (uint32_t)__builtin_popcount(dm);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) count += __shfl_xor(count, d, kWave);
+    if (lane == 0) s_cnt[wv] = count;
+    if (threadIdx.x == 0) s_abort = 0u;
+    __syncthreads();
+    uint32_t tile_count = 0, wave_off = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kTileWaves; ++k) {
+        const uint32_t c = s_cnt[k];
+        wave_off += k < wv ? c : 0u;
+        tile_count += c;
+    }
+    // the tile's own count, for the tiles behind it (the first tile of the stream knows its prefix)
+    if (threadIdx.x == 0) __hip_atomic_store(desc + tile, (tile == 0 ? kDescP : kDescA) | (uint64_t)tile_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // a lane now owns 16 consecutive chunks (256 bytes) of its wave's block: rank of its first delimiter inside the tile
+    uint32_t w[16];
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(m_lds[wv] + lane * 16u);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint4 m = src[k];
+            w[4 * k] = m.x; w[4 * k + 1] = m.y; w[4 * k + 2] = m.z; w[4 * k + 3] = m.w;
+        }
+    }
+    uint32_t mine = 0, any_err = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        mine += (uint32_t)__builtin_popcount(w[j] & 0xFFFFu);
+        any_err |= w[j] >> 16;
+    }
+    uint32_t tot;
+    const uint32_t ex = wave_exclusive_sum(mine, &tot);
+    // ---- look-back (the tile's first wave): the delimiters of all tiles before this one ----
+    if (wv == 0) {
+        uint64_t prefix = 0;
+        bool aborted = false;
+        if (tile != 0) {
+            int64_t idx = (int64_t)tile - 1;
+            uint32_t polls = 0;
+            for (;;) {
+                const int64_t j = idx - (int64_t)lane;  // lane i looks at tile idx - i; before the stream: a prefix of zero
+                uint64_t d = kDescP;
+                if (j >= 0) d = __hip_atomic_load(desc + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t fl = (uint32_t)(d >> 62);
+                const uint64_t mp = __ballot(fl == 2u), mx = __ballot(fl == 0u);
+                const uint32_t p = mp ? (uint32_t)__builtin_ctzll(mp) : 64u;  // the nearest tile that knows its prefix
+                const uint64_t upto = p >= 63u ? ~0ull : ((2ull << p) - 1ull);
+                if (mx & upto) {  // a tile between here and there has not even counted yet: wait for it
+                    ++polls;
+                    if (polls > kSpinLimit) {
+                        if (lane == 0) __hip_atomic_store(abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        aborted = true;
+                    } else if ((polls & 255u) == 0u && __hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                        aborted = true;
+                    }
+                    if (aborted) break;
+                    __builtin_amdgcn_s_sleep(2);
+                    continue;
+                }
+                uint32_t a = lane < p ? (uint32_t)d : 0u;  // (a tile's own count fits 17 bits)
+#pragma unroll
+                for (int s2 = 32; s2 >= 1; s2 >>= 1) a += __shfl_xor(a, s2, kWave);
+                prefix += a;
+                if (mp) {
+                    const uint32_t lo = __shfl((uint32_t)d, (int)p, kWave), hi = __shfl((uint32_t)(d >> 32), (int)p, kWave);
+                    prefix += (((uint64_t)hi << 32) | lo) & kDescVal;
+                    break;
+                }
+                idx -= kWave;
+            }
+            if (!aborted && lane == 0) __hip_atomic_store(desc + tile, kDescP | (prefix + tile_count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) {
+            s_prefix = prefix;
+            s_abort = aborted ? 1u : 0u;
+            const uint64_t incl = prefix + tile_count;
+            if (aborted) {
+                pref[blk1] = kFrameAborted;
+            } else {
+                if (tile == (blk1 - 1u) / kTileWaves) pref[blk1] = incl;  // the delimiters up to the end of this launch's range
+                if (tile == 0) offsets[0] = 0;
+                if (whole && tile == (nblk - 1u) / kTileWaves && incl + 1 <= cap) offsets[incl + 1] = nbytes;  // a final unterminated frame
+            }
+        }
+    }
+    __syncthreads();
+    if (s_abort) return;
+    if (mine == 0 && any_err == 0) return;
+    uint64_t rank = s_prefix + wave_off + ex;  // delimiters before this lane's first byte
+    const uint64_t lane_base = base + (uint64_t)lane * 256u;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        uint32_t dm = w[j] & 0xFFFFu, em = w[j] >> 16;
+        const uint64_t cpos = lane_base + (uint64_t)j * 16u;
+        while (em) {  // rare
+            const uint32_t b = (uint32_t)__builtin_ctz(em);
+            em &= em - 1u;
+            const uint64_t frame = rank + (uint32_t)__builtin_popcount(dm & ((1u << b) - 1u));
+            if (frame < cap) bad[frame] = 1;
+        }
+        while (dm) {
+            const uint32_t b = (uint32_t)__builtin_ctz(dm);
+            dm &= dm - 1u;
+            ++rank;
+            if (rank <= cap) offsets[rank] = cpos + b + 1u;
+        }
+    }
+}
+
 }  // namespace fg
 
 // scratch: masks = ceil(nbytes / 16 KiB) * 1024 u32, counts = nblk u32, pref = (nblk + 1) u64
@@ -214,8 +388,14 @@ extern "C" uint64_t fg_frame_scratch_bytes(uint64_t nbytes) {
     const uint64_t nblk = frame_blocks(nbytes);
     return nblk * 4096u + ((nblk * 4u + 255u) & ~255ull) + (nblk + 1u) * 8u + 256u;
 }
+// classic != 0: the three-kernel form (the fall-back of a one-pass launch that reported kFrameAborted, and FG_LO_FRAME_CLASSIC).
+// *d_total_out: the device word that will hold the delimiter count -- or FG_FRAME_ABORTED (~0), after which the caller launches again
+// with classic = 1 (same arguments; everything is rewritten).
+static inline uint32_t* frame_abort_word(uint8_t* scratch, uint64_t nblk) {
+    return reinterpret_cast<uint32_t*>(scratch + nblk * 4096u + ((nblk * 4u + 255u) & ~255ull) + (nblk + 1u) * 8u + 64u);
+}
 extern "C" int fg_launch_frame(const uint8_t* d_bytes, uint64_t nbytes, uint32_t delim, uint8_t* scratch, uint64_t* d_offsets,
-                               uint8_t* d_bad, uint64_t cap, uint64_t** d_total_out, hipStream_t stream) {
+                               uint8_t* d_bad, uint64_t cap, uint64_t** d_total_out, hipStream_t stream, int classic) {
     const uint64_t nblk = frame_blocks(nbytes);
     if (nblk > 0x7FFFFFFFull) return -1;
     uint32_t* masks = reinterpret_cast<uint32_t*>(scratch);
@@ -223,12 +403,21 @@ extern "C" int fg_launch_frame(const uint8_t* d_bytes, uint64_t nbytes, uint32_t
     uint64_t* pref = reinterpret_cast<uint64_t*>(scratch + nblk * 4096u + ((nblk * 4u + 255u) & ~255ull));
     const uint32_t pat = delim * 0x01010101u;
     (void)hipMemsetAsync(d_bad, 0, cap, stream);
+    *d_total_out = pref + nblk;
+    if (!classic) {
+        uint64_t* desc = reinterpret_cast<uint64_t*>(scratch);  // (where the classic form keeps its masks)
+        (void)hipMemsetAsync(desc, 0, nblk * 8u, stream);
+        (void)hipMemsetAsync(frame_abort_word(scratch, nblk), 0, 4, stream);
+        hipLaunchKernelGGL(fg::k_frame_onepass<false>, dim3((uint32_t)((nblk + fg::kTileWaves - 1) / fg::kTileWaves)), dim3(fg::kWave * fg::kTileWaves), 0,
+                           stream, d_bytes, nbytes, pat, desc, pref, frame_abort_word(scratch, nblk), d_offsets, d_bad, cap, (uint64_t)0, nblk, nblk,
+                           1u, (uint8_t*)nullptr);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(fg::k_frame_scan<false>, dim3((uint32_t)nblk), dim3(fg::kWave), 0, stream, d_bytes, nbytes, pat, masks, counts, (uint64_t)0,
                        (uint8_t*)nullptr);
     hipLaunchKernelGGL(fg::k_frame_prefix, dim3(1), dim3(1024), 0, stream, counts, nblk, pref, 0u);
     hipLaunchKernelGGL(fg::k_frame_emit, dim3((uint32_t)nblk), dim3(fg::kWave), 0, stream, masks, pref, nbytes, nblk, d_offsets,
                        d_bad, cap, (uint64_t)0, 1u);
-    *d_total_out = pref + nblk;
     return (int)hipGetLastError();
 }
 
@@ -236,12 +425,14 @@ extern "C" int fg_launch_frame(const uint8_t* d_bytes, uint64_t nbytes, uint32_t
 // frame_blocks(nbytes)), whose bytes -- and everything before them -- are in d_bytes.  Continues the delimiter ranks where the
 // slice before stopped; *d_total_out = the device word that holds the delimiters up to the end of this slice.  d_bad must have
 // been cleared for the whole batch beforehand; offsets[total + 1] of a final unterminated frame is the caller's business.
+// Slices of one stream are launched in order, all classic or all one-pass (the first slice clears the descriptors of the whole stream).
 extern "C" uint64_t fg_frame_block_bytes(void) { return fg::kFrameBlock; }
+extern "C" uint64_t fg_frame_slice_align(void) { return (uint64_t)fg::kFrameBlock * fg::kTileWaves; }  // slice boundaries: whole tiles
 // src != null: the slice's bytes are read from `src` (the device view of the caller's pinned buffer, same offsets) and stored to d_bytes
 // by the scan itself -- no upload has to have happened.
 extern "C" int fg_launch_frame_slice(const uint8_t* d_bytes, uint64_t nbytes, uint32_t delim, uint8_t* scratch, uint64_t* d_offsets,
                                      uint8_t* d_bad, uint64_t cap, uint64_t blk0, uint64_t blk1, uint64_t** d_total_out,
-                                     hipStream_t stream, const uint8_t* src) {
+                                     hipStream_t stream, const uint8_t* src, int classic) {
     const uint64_t nblk = frame_blocks(nbytes);
     if (nblk > 0x7FFFFFFFull || blk1 > nblk || blk0 >= blk1) return -1;
     uint32_t* masks = reinterpret_cast<uint32_t*>(scratch);
@@ -249,6 +440,25 @@ extern "C" int fg_launch_frame_slice(const uint8_t* d_bytes, uint64_t nbytes, ui
     uint64_t* pref = reinterpret_cast<uint64_t*>(scratch + nblk * 4096u + ((nblk * 4u + 255u) & ~255ull));
     const uint32_t pat = delim * 0x01010101u;
     const uint32_t nb = (uint32_t)(blk1 - blk0);
+    *d_total_out = pref + blk1;
+    if (!classic) {
+        uint64_t* desc = reinterpret_cast<uint64_t*>(scratch);
+        if (blk0 == 0) {
+            (void)hipMemsetAsync(desc, 0, nblk * 8u, stream);
+            (void)hipMemsetAsync(frame_abort_word(scratch, nblk), 0, 4, stream);
+        }
+        // (tiles of four blocks: a slice that is not the stream's first starts at a multiple of fg_frame_slice_align())
+        if (blk0 % fg::kTileWaves) return -1;
+        const uint64_t tile0 = blk0 / fg::kTileWaves;
+        const uint32_t nt = (uint32_t)((blk1 + fg::kTileWaves - 1) / fg::kTileWaves - tile0);
+        if (src)
+            hipLaunchKernelGGL(fg::k_frame_onepass<true>, dim3(nt), dim3(fg::kWave * fg::kTileWaves), 0, stream, src, nbytes, pat, desc, pref,
+                               frame_abort_word(scratch, nblk), d_offsets, d_bad, cap, tile0, blk1, nblk, 0u, const_cast<uint8_t*>(d_bytes));
+        else
+            hipLaunchKernelGGL(fg::k_frame_onepass<false>, dim3(nt), dim3(fg::kWave * fg::kTileWaves), 0, stream, d_bytes, nbytes, pat, desc, pref,
+                               frame_abort_word(scratch, nblk), d_offsets, d_bad, cap, tile0, blk1, nblk, 0u, (uint8_t*)nullptr);
+        return (int)hipGetLastError();
+    }
     if (src)
         hipLaunchKernelGGL(fg::k_frame_scan<true>, dim3(nb), dim3(fg::kWave), 0, stream, src, nbytes, pat, masks, counts, blk0,
                            const_cast<uint8_t*>(d_bytes));
@@ -256,7 +466,6 @@ extern "C" int fg_launch_frame_slice(const uint8_t* d_bytes, uint64_t nbytes, ui
         hipLaunchKernelGGL(fg::k_frame_scan<false>, dim3(nb), dim3(fg::kWave), 0, stream, d_bytes, nbytes, pat, masks, counts, blk0, (uint8_t*)nullptr);
     hipLaunchKernelGGL(fg::k_frame_prefix, dim3(1), dim3(1024), 0, stream, counts + blk0, (uint64_t)nb, pref + blk0, blk0 ? 1u : 0u);
     hipLaunchKernelGGL(fg::k_frame_emit, dim3(nb), dim3(fg::kWave), 0, stream, masks, pref, nbytes, nblk, d_offsets, d_bad, cap, blk0, 0u);
-    *d_total_out = pref + blk1;
     return (int)hipGetLastError();
 }
 

@@ -490,7 +490,7 @@ static int frame_decode_sliced(fg_ctx* ctx, fg_format fmt, fg_framing framing, c
     uint64_t slice = nbytes / 8;
     if (slice < (8ull << 20)) slice = 8ull << 20;
     if (slice > (32ull << 20)) slice = 32ull << 20;
-    slice = slice / blk * blk;
+    slice = slice / fg_frame_slice_align() * fg_frame_slice_align();  // (whole 64 KiB tiles of the one-pass scan)
     const uint32_t slices = (uint32_t)((nbytes + slice - 1) / slice);
     const uint64_t nblk_total = nbytes / blk + 1;
     if ((rc = ensure_pipeline(ctx, slices)) != FG_OK) return rc;
@@ -553,7 +553,8 @@ static int frame_decode_sliced(fg_ctx* ctx, fg_format fmt, fg_framing framing, c
         else if (k + 1 == slices) FG_HIP(ctx, hipMemsetAsync(ctx->d_bytes + up(nbytes, 16), 0, 16, s_up));
         uint64_t* d_total = nullptr;
         const uint64_t blk0 = b0 / blk, blk1 = k + 1 == slices ? nblk_total : b1 / blk;
-        int lrc = fg_launch_frame_slice(ctx->d_bytes, nbytes, delim, ctx->d_frame, ctx->d_offsets, ctx->d_bad, cap, blk0, blk1, &d_total, s_frame, src_dv);
+        int lrc = fg_launch_frame_slice(ctx->d_bytes, nbytes, delim, ctx->d_frame, ctx->d_offsets, ctx->d_bad, cap, blk0, blk1, &d_total, s_frame, src_dv,
+                                        (ctx->lo.flags & FG_LO_FRAME_CLASSIC) ? 1 : 0);
         if (lrc == 0) lrc = fg_launch_poke64(d_total, cnt_dv + k, s_frame);
         if (lrc != 0) {
             ctx->last_hip = lrc;
@@ -593,6 +594,10 @@ static int frame_decode_sliced(fg_ctx* ctx, fg_format fmt, fg_framing framing, c
             return FG_ERR_HIP;
         }
         const uint64_t total = ctx->h_cnt[k];  // delimiters up to the end of slice k = frames that are complete
+        if (total == FG_FRAME_ABORTED) {  // the one-pass scan gave up waiting on a tile (never seen): the one-piece path frames classically
+            drain();
+            return FG_ERR_UNSUPPORTED;
+        }
         if (total + 1 > cap) {
             drain();
             ctx->frames_per_byte = (double)(total + 1) / (double)(((uint64_t)k + 1) * slice);
@@ -669,15 +674,18 @@ static int frame_stage(fg_ctx* ctx, fg_framing framing, uint64_t nbytes, int fin
         if ((rc = grow_dev(ctx, (void**)&ctx->d_offsets, &ctx->d_offsets_cap, (cap + 2) * 8)) != FG_OK) return rc;
         if ((rc = grow_dev(ctx, (void**)&ctx->d_bad, &ctx->d_bad_cap, cap + 1)) != FG_OK) return rc;
         if ((rc = grow_dev(ctx, (void**)&ctx->d_frame, &ctx->d_frame_cap, fg_frame_scratch_bytes(nbytes))) != FG_OK) return rc;
-        uint64_t* d_total = nullptr;
-        int lrc = fg_launch_frame(ctx->d_bytes, nbytes, framing == FG_FRAME_LINE ? 0x0Au : 0x00u, ctx->d_frame, ctx->d_offsets,
-                                  ctx->d_bad, cap, &d_total, s);
-        if (lrc != 0) {
-            ctx->last_hip = lrc;
-            return FG_ERR_HIP;
+        for (int classic = (ctx->lo.flags & FG_LO_FRAME_CLASSIC) ? 1 : 0;; classic = 1) {
+            uint64_t* d_total = nullptr;
+            int lrc = fg_launch_frame(ctx->d_bytes, nbytes, framing == FG_FRAME_LINE ? 0x0Au : 0x00u, ctx->d_frame, ctx->d_offsets,
+                                      ctx->d_bad, cap, &d_total, s, classic);
+            if (lrc != 0) {
+                ctx->last_hip = lrc;
+                return FG_ERR_HIP;
+            }
+            FG_HIP(ctx, hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, s));
+            FG_HIP(ctx, hipStreamSynchronize(s));
+            if (total != FG_FRAME_ABORTED || classic) break;  // (the one-pass scan gave up waiting on a tile: the three-kernel form)
         }
-        FG_HIP(ctx, hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, s));
-        FG_HIP(ctx, hipStreamSynchronize(s));
         if (total + 1 <= cap) break;
         cap = total + 16;
     }

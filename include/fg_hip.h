@@ -202,8 +202,10 @@ enum {
                                       default from an average of 320 bytes per line) */
     FG_LO_SD_PAIRS = 32,           /* RFC5424: the pair-parallel structured-data walk for lines of any length (parity sweeps) */
     FG_LO_NO_ZERO_COPY = 64,       /* fg_decode_batch: the sliced hipMemcpy pipeline even when the caller's buffers are pinned (A/B, tests) */
-    FG_LO_FRAME_KERNEL_UPLOAD = 128 /* fg_frame_decode_batch, pinned chunk: the framing scan reads the chunk in place and stores it to HBM
+    FG_LO_FRAME_KERNEL_UPLOAD = 128, /* fg_frame_decode_batch, pinned chunk: the framing scan reads the chunk in place and stores it to HBM
                                       itself instead of hipMemcpy uploads (measured slower on MI355X / ROCm 7.2: off by default) */
+    FG_LO_FRAME_CLASSIC = 256      /* framing: the three-kernel form (masks to HBM, one-workgroup scan, emit) instead of the one-pass chained
+                                      scan -- which falls back to it by itself should its look-back ever give up (A/B, tests) */
 };
 
 /* Create a decoder context on HIP device `device` (replaces XDecoder::new(&Config),

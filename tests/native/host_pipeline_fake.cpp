@@ -152,6 +152,7 @@ extern "C" int fg_launch_encode_write(const uint8_t* b, const uint64_t* o, uint6
 // ---- framing: offsets[0] = 0, offsets[r + 1] = the byte behind the delimiter of rank r; the word behind block k of `scratch` holds
 //      the delimiters of the blocks before k (so the word at [blk1] is "up to the end of this slice")
 extern "C" uint64_t fg_frame_block_bytes(void) { return 16384; }
+extern "C" uint64_t fg_frame_slice_align(void) { return 131072; }
 extern "C" uint64_t fg_frame_scratch_bytes(uint64_t nbytes) { return (nbytes / 16384 + 3) * 8; }
 static int frame_blocks_fake(const uint8_t* d_bytes, uint64_t nbytes, uint32_t delim, uint8_t* scratch, uint64_t* d_offsets, uint8_t* d_bad, uint64_t cap,
                              uint64_t blk0, uint64_t blk1, uint64_t** d_total_out) {
@@ -173,17 +174,37 @@ static int frame_blocks_fake(const uint8_t* d_bytes, uint64_t nbytes, uint32_t d
     *d_total_out = pref + blk1;
     return 0;
 }
+// The one-pass scan's look-back giving up (FG_FRAME_ABORTED in the total word): g_frame_abort_left one-pass launches report it; the host
+// must come back with classic = 1 (one-piece) or leave the sliced path for the one-piece one.
+int g_frame_abort_left = 0;
+int g_frame_classic_launches = 0;
+extern "C" void fake_frame_abort_next(int n) { g_frame_abort_left = n; g_frame_classic_launches = 0; }
+extern "C" int fake_frame_classic_launches(void) { return g_frame_classic_launches; }
+static bool fake_aborts(int classic, uint8_t* scratch, uint64_t blk1, uint64_t** d_total_out) {
+    if (classic) {
+        ++g_frame_classic_launches;
+        return false;
+    }
+    if (g_frame_abort_left <= 0) return false;
+    --g_frame_abort_left;
+    uint64_t* pref = reinterpret_cast<uint64_t*>(scratch);
+    pref[blk1] = ~0ull;
+    *d_total_out = pref + blk1;
+    return true;
+}
 extern "C" int fg_launch_frame(const uint8_t* d_bytes, uint64_t nbytes, uint32_t delim, uint8_t* scratch, uint64_t* d_offsets, uint8_t* d_bad, uint64_t cap,
-                               uint64_t** d_total_out, hipStream_t) {
+                               uint64_t** d_total_out, hipStream_t, int classic) {
     memset(d_bad, 0, cap);
+    if (fake_aborts(classic, scratch, nbytes / 16384 + 1, d_total_out)) return 0;
     const int rc = frame_blocks_fake(d_bytes, nbytes, delim, scratch, d_offsets, d_bad, cap, 0, nbytes / 16384 + 1, d_total_out);
     const uint64_t total = **d_total_out;  // the whole-stream form also ends an unterminated last frame at nbytes
     if (total + 1 <= cap && d_offsets[total] != nbytes) d_offsets[total + 1] = nbytes;
     return rc;
 }
 extern "C" int fg_launch_frame_slice(const uint8_t* d_bytes, uint64_t nbytes, uint32_t delim, uint8_t* scratch, uint64_t* d_offsets, uint8_t* d_bad,
-                                     uint64_t cap, uint64_t blk0, uint64_t blk1, uint64_t** d_total_out, hipStream_t, const uint8_t* src) {
+                                     uint64_t cap, uint64_t blk0, uint64_t blk1, uint64_t** d_total_out, hipStream_t, const uint8_t* src, int classic) {
     if (blk1 > nbytes / 16384 + 1 || blk0 >= blk1) return -1;
+    if (fake_aborts(classic, scratch, blk1, d_total_out)) return 0;
     if (src) {  // the scan uploads its blocks itself (whole 16-byte chunks, as the kernel's bounded buffer stores do)
         const uint64_t b0 = blk0 * 16384, b1 = blk1 * 16384 < nbytes ? blk1 * 16384 : nbytes;
         if (b1 > b0) memcpy(const_cast<uint8_t*>(d_bytes) + b0, src + b0, b1 - b0);

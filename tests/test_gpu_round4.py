@@ -252,3 +252,76 @@ def test_zero_copy_decode_batch_from_pinned_buffers(oracle, fmt):
         lib.fg_free_pinned(pb)
         lib.fg_free_pinned(po)
 
+
+
+@pytest.mark.parametrize("framing", ["line", "nul"])
+def test_one_pass_framing_equals_the_three_kernel_form_at_scale(framing):
+    """k_frame_onepass (a chained scan with decoupled look-back over one descriptor per 16 KiB tile) against the classic scan -> prefix ->
+    emit (FG_LO_FRAME_CLASSIC) on a stream of ~20 000 tiles with injected UTF-8 damage, empty frames, lines longer than a tile and an
+    unterminated tail: identical offsets and verdicts -- and the oracle's splitter on a sample.  Also through fg_frame_decode_batch
+    (sliced: every slice continues the chain where the one before stopped)."""
+    import ctypes as C
+
+    import torch
+    from flowgger_amd import _lib as L
+
+    rng = np.random.default_rng(0x0F4A)
+    dec = RFC5424Decoder()
+    dev = torch.device("cuda", dec.device)
+    delim = b"\n" if framing == "line" else b"\0"
+    base = synth.rfc5424_lines(120_000, cfg=2)
+    dmg = [b"\xff", b"\xc3", b"\xe2\x82", b"\xf0\x9f\x98", b"\xed\xa0\x80", b"\xc0\xaf", b"caf\xc3\xa9 \xe2\x82\xac ok"]
+    pieces = []
+    for i, ln in enumerate(base):
+        if i % 53 == 7:
+            ln = ln + b" " + dmg[(i // 53) % len(dmg)]
+        if i % 997 == 0:
+            ln = b""
+        if i % 20011 == 5:
+            ln = ln + b" " + b"x" * int(rng.integers(17_000, 70_000))  # longer than a tile (and than four)
+        pieces.append(ln + delim)
+    one = b"".join(pieces)
+    raw = one * 10 + b"unterminated tail \xe2\x82"
+    assert len(raw) > 256 << 20
+    d_bytes = torch.cat([torch.frombuffer(bytearray(raw), dtype=torch.uint8), torch.zeros(32, dtype=torch.uint8)]).to(dev)
+    d_raw = d_bytes[:len(raw)]
+    fr = L.FG_FRAME_LINE if framing == "line" else L.FG_FRAME_NUL
+    res = {}
+    for classic in (False, True):
+        dec.set_launch_opts(frame_classic=classic)
+        d_offsets, d_bad, n = dec.frame_device(d_raw, fr)
+        res[classic] = (d_offsets[:n + 1].cpu().numpy().copy(), d_bad[:n].cpu().numpy().copy(), n)
+    (ao, ab, an), (bo, bb, bn) = res[False], res[True]
+    assert an == bn == len(pieces) * 10 + 1
+    assert np.array_equal(ao, bo) and np.array_equal(ab, bb)
+    assert int(ao[-1]) == len(raw) and int(ab.sum()) > 10 * (len(base) // 53) * 5 // 7
+    # the first copy of the stream against the plain-Python splitter
+    ends = np.cumsum(np.fromiter((len(p) for p in pieces), np.int64, len(pieces)))
+    assert np.array_equal(ao[1:len(pieces) + 1].astype(np.int64), ends)
+    for i in range(0, len(pieces), 37):
+        body = pieces[i][:-1]
+        try:
+            body.decode("utf-8")
+            ok = 1
+        except UnicodeDecodeError:
+            ok = 0
+        assert int(ab[i]) == 1 - ok, i
+    # ... and the sliced host path (pageable chunk: hipMemcpy uploads, every slice framed by one launch of the chain)
+    lib = L.lib()
+    host = np.frombuffer(raw, np.uint8)
+    pad = np.concatenate([host, np.zeros(64, np.uint8)])
+    out = {}
+    for classic in (False, True):
+        dec.set_launch_opts(frame_classic=classic)
+        st, po, nf, cons = L.fg_tables(), C.c_void_p(), C.c_uint64(), C.c_uint64()
+        L.check(lib.fg_frame_decode_batch(dec._ctx, dec.fmt, fr, pad.ctypes.data, host.size, 1, C.byref(st), C.byref(po), C.byref(nf), C.byref(cons)),
+                "fg_frame_decode_batch")
+        n = int(nf.value)
+        offs = np.ctypeslib.as_array(C.cast(po, C.POINTER(C.c_uint64)), (n + 1,)).copy()
+        meta = np.ctypeslib.as_array(C.cast(st.meta, C.POINTER(C.c_uint32)), (n,)).copy()
+        out[classic] = (offs, meta, n)
+    assert out[False][2] == out[True][2] == an
+    assert np.array_equal(out[False][0], out[True][0]) and np.array_equal(out[False][0].astype(np.int64), ao.astype(np.int64))
+    assert np.array_equal(out[False][1], out[True][1])
+    assert np.array_equal((out[False][1] & 0xFF) == L.FG_ST_BAD_UTF8, ab == 1)
+    dec.set_launch_opts()

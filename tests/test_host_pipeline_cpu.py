@@ -265,6 +265,37 @@ def test_raw_stream_sliced_equals_one_piece(fake, final, dense):
     assert a["used"] == int(a["ent_count"].sum()) == b["used"]
 
 
+@pytest.mark.parametrize("one_piece", [False, True])
+def test_a_one_pass_framing_scan_that_gives_up_is_redone_by_the_three_kernel_form(fake, one_piece):
+    """k_frame_onepass's look-back is bounded: a wave that waits too long on a predecessor's descriptor raises the abort word and the total
+    comes back as FG_FRAME_ABORTED.  The sliced path then leaves for the one-piece path, which launches the framing again with
+    classic = 1; the caller sees the same frames as ever."""
+    rng = np.random.default_rng(5)
+    lines = corpus(250_000, rng)
+    raw = np.frombuffer(b"".join(ln + b"\n" for ln in lines) + b"<1>tail a=1", np.uint8).copy()
+    assert raw.size > (48 << 20)
+    pad = np.concatenate([raw, np.zeros(64, np.uint8)])
+    fake.fake_frame_abort_next.argtypes = [C.c_int]
+    res = {}
+    for abort in (0, 3):
+        c = Ctx(fake)
+        lo = L.fg_launch_opts()
+        lo.flags = L.FG_LO_TRANSCODE_ONE_PIECE if one_piece else 0
+        assert fake.fg_set_launch_opts(c.h, C.byref(lo)) == 0
+        fake.fake_frame_abort_next(abort)
+        st, po, nf, cons = L.fg_tables(), vp(), u64(), u64()
+        assert fake.fg_frame_decode_batch(c.h, 0, 1, pad.ctypes.data, raw.size, 1, C.byref(st), C.byref(po), C.byref(nf), C.byref(cons)) == 0
+        n = int(nf.value)
+        offs = np.ctypeslib.as_array(C.cast(po, C.POINTER(C.c_uint64)), (n + 1,)).copy()
+        res[abort] = (snapshot(st, n), offs, int(cons.value), n)
+        assert fake.fake_frame_classic_launches() == (1 if abort else 0)
+        c.close()
+    fake.fake_frame_abort_next(0)
+    (a, ao, ac, an), (b, bo, bc, bn) = res[0], res[3]
+    assert an == bn == len(lines) + 1 and ac == bc == raw.size and np.array_equal(ao, bo)
+    same_lines(a, b, an)
+
+
 def test_a_pinned_raw_stream_is_uploaded_by_the_framing_scan_itself(fake):
     """raw chunk in pinned memory: no hipMemcpy of the stream at all -- the framing scan reads it in place and stores it to its place on
     the device (k_frame_scan<COPY>), the tables are written straight into the pinned host tables; only frame offsets and a few
