@@ -487,7 +487,8 @@ static int frame_decode_sliced(fg_ctx* ctx, fg_format fmt, fg_framing framing, c
     int rc;
     LinkBoundGrid grid(ctx);
     const uint64_t blk = fg_frame_block_bytes();
-    uint64_t slice = nbytes / 8;
+    // (sixteen slices or more: the first upload and the last decode + download run alone -- a sixteenth of the batch each, not an eighth)
+    uint64_t slice = nbytes / 16;
     if (slice < (8ull << 20)) slice = 8ull << 20;
     if (slice > (32ull << 20)) slice = 32ull << 20;
     slice = slice / fg_frame_slice_align() * fg_frame_slice_align();  // (whole 64 KiB tiles of the one-pass scan)

@@ -38,4 +38,6 @@ for w in cfg3 ltsv cfg4; do python bench.py --workload $w --tile-lines 250000 --
 for f in bench_default_100M bench_cfg3_100M bench_cfg4_125M bench_cfg5_40M bench_ltsv_100M bench_ltsv5_20M bench_cfg5mix bench_rfc3164_100M bench_frame bench_cfg1_pipeline e2e_cfg3 e2e_ltsv e2e_cfg4; do python -c "
 import json; d=json.loads(open('gpurun_out/${T}_$f.json').read().strip().splitlines()[-1]); r=d['roofline']; e=d.get('e2e') or {}
 print('$f', round(d['value']/1e6,1), 'M lines/s', round(r['kernel_ms'],3), 'ms frac', round(r['frac'],4), 'of copy', r.get('frac_of_copy'), 'cpu', d.get('cpu_baseline',{}).get('value'), d.get('gather_ms'), d.get('framing',{}).get('GBps'), d.get('encode',{}).get('ms'), {k: round(v/1e6,1) for k,v in (e.get('aggregate') or {}).items()})" 2>&1 | tail -1; done
+# framing: per-kernel times of the one-pass scan and of the classic three kernels
+bash tools/prof_frame_modes.sh 4 2>&1 | tail -12; cp gpurun_out/frame_modes_kernels.log gpurun_out/${T}_frame_modes_kernels.log
 ls gpurun_out | grep -c $T
