@@ -10,17 +10,19 @@
 //                                       prefix-XOR of the real quotes carried across the wave (popcount parity + ballot), reset
 //                                       at every line start; structural characters OUTSIDE strings -> the ITEM bitmap; a wave
 //                                       prefix sum numbers the items
-//   blocks    (lane = one item)         whole lines are packed into blocks of at most 64 items; an item is a '{' or ',' (it owns the
-//                                       member that follows) or the closing '}'.  The lane delimits  ws "key" ws : ws value ws  with
-//                                       bit scans of 64-bit bitmap windows held in registers, checks every byte outside the tokens,
-//                                       parses numbers (serde_json 0.8 algorithm) and literals -- 13 members of 64 lines are 13 full
-//                                       iterations of 64 lanes, whatever the members per line.  BTreeMap order: rank = members of the
-//                                       same line with a smaller key (7-byte prefix + index, 512 bytes of LDS per block); duplicates:
-//                                       the last one wins; gelf_decoder.rs:51-106 is dispatched per member, the FIRST error in sorted
-//                                       order wins through an LDS min.  Member records never leave the registers.
+//   rows      (lane = one item)         the next lines of the tile take one ROW of W lanes each (W = 16: four lines per trip; 32 / 64 for
+//                                       wider lines); an item is a '{' or ',' (it owns the member that follows) or the closing '}'.  The
+//                                       lane delimits  ws "key" ws : ws value ws  with bit scans of 64-bit bitmap windows held in registers,
+//                                       checks every byte outside the tokens, parses numbers (serde_json 0.8 algorithm) and literals.
+//                                       What the lanes of a row find out about their LINE is combined by row reductions in registers
+//                                       (DPP rotations): every lane of the row knows the verdict itself -- no LDS flags, no atomics, no
+//                                       barrier in the loop.  BTreeMap order: rank = extras of the row with a smaller key (fifteen DPP
+//                                       rotations of the keys' first four bytes; ties, duplicate keys and wider rows: the 64-bit keys by
+//                                       shuffle); duplicates: the last one wins; gelf_decoder.rs:51-106 is evaluated per member, the FIRST
+//                                       error in sorted order wins through an LDS min (rare).  Member records never leave the registers.
 //   output                              rows from the lane that owns the line; extras go to first(line) + rank among the line's extras:
-//                                       the lanes of a block store into ONE contiguous stretch of the entry table, reserved out
-//                                       of the wave's chunk (fg_wave.hpp wave_alloc) without a trip to the global counter
+//                                       the lanes of a trip store into ONE contiguous stretch of the entry table, reserved out
+//                                       of the wave's chunk (fg_wave.hpp wave_alloc; the reservation lives in registers across the tile)
 //
 // Exactness: this is a FAST FORM.  It accepts flat objects whose keys hold no escapes, with ' ' as the only whitespace
 // between tokens, at most kMaxLineItems structural characters -- every GELF producer's output -- and proves every byte of

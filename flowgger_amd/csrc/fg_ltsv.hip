@@ -871,7 +871,10 @@ extern "C" int fg_launch_ltsv(const uint8_t* d_bytes, const uint64_t* d_offsets,
     const bool head = (lo->flags & FG_LO_FORCE_HEAD) || (avg_len >= 768u && !(lo->flags & FG_LO_NO_HEAD));
     const uint64_t plan_len = head ? (avg_len < fg::kHeadCap ? avg_len : fg::kHeadCap) : avg_len;
     if (head ? fg::plan_launch(fg::k_ltsv<fg::kComputeBoundWindow, false, true>, n, plan_len, fg::kLtsvExtraLds, 57344u, stash ? stash_blocks : 0u, &p, *lo)
-             : fg::plan_launch(fg::k_ltsv<fg::kComputeBoundWindow, false>, n, plan_len, fg::kLtsvExtraLds, 57344u, stash ? stash_blocks : 0u, &p, *lo))
+             // (whole lines staged: chunks of 128 lines -- 3.78 vs 3.67 G lines/s with the pipeline's 256, alternated on one box,
+             //  profiles/r04z3_sweep_ltsv.log)
+             : fg::plan_launch(fg::k_ltsv<fg::kComputeBoundWindow, false>, n, plan_len, fg::kLtsvExtraLds, 57344u, stash ? stash_blocks : 0u, &p, *lo,
+                               64, 1, nullptr, nullptr, 0u, 128u))
         return -1;
     if (stash_blocks == 0) stash = nullptr;
     dim3 grid(p.blocks), block(fg::kWave);
