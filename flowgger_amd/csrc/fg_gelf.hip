@@ -742,11 +742,10 @@ int launch_gelf_fast(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t
                 // 1422 M lines/s at sixteen, profiles/r04s_sweep_cfg3.log)
                 fg_launch_opts lo3 = lo;
                 lo3.tile_cap = 3072u;
-                // (chunks of 128 lines: 64 / 128 / 512 all measure 2 % above the pipeline's 256 on this corpus, alternated on one box --
-                //  profiles/r04z2_sweep_cfg3.log)
-                if (!lo3.chunk_lines) lo3.chunk_lines = 128u;
+                // (chunks of at most 128 lines: 64 / 128 / 512 all measure 2 % above the pipeline's 256 on this corpus, alternated on one
+                //  box -- profiles/r04z2_sweep_cfg3.log)
                 if (fg::plan_launch(fg::k_gelf<NB, false, 5, 3072u, 8u>, n, avg_len, 0u, 40960u, 0u, &p, lo3, max_lines,
-                                    fg::GelfFormat::kClasses, fg::gelf_extra_lds) || p.tile != 3072u || p.L != 8u)
+                                    fg::GelfFormat::kClasses, fg::gelf_extra_lds, nullptr, 0u, 128u) || p.tile != 3072u || p.L != 8u)
                     return -1;
                 hipLaunchKernelGGL((fg::k_gelf<NB, false, 5, 3072u, 8u>), dim3(p.blocks), block, p.lds, stream, d_bytes, d_offsets, n, *t,
                                    p.tile, p.L, p.chunk, (unsigned long long*)nullptr, (uint64_t*)nullptr, fr);

@@ -758,11 +758,22 @@ inline int plan_launch(K kernel, uint64_t n, uint64_t avg_len, uint32_t extra_ld
     // over the grid
     // (default_chunk: a format's own choice -- the pair-parallel structured-data kernel: 1466 vs 1394 M lines/s at 1024 vs 512 lines)
     const uint64_t full = default_chunk ? default_chunk : (avg_len ? (uint64_t)p->tile / avg_len : p->L) >= p->L ? 256u : 512u;
-    uint64_t chunk = lo.chunk_lines >= p->L && lo.chunk_lines <= 65536u ? lo.chunk_lines : full;
-    if (n < blocks * 2u * chunk) {
-        chunk = (n + blocks - 1) / (blocks ? blocks : 1);
+    uint64_t chunk;
+    if (lo.chunk_lines >= p->L && lo.chunk_lines <= 65536u) {
+        chunk = lo.chunk_lines;  // (tuning: taken as it is, unless the batch is too small for two of them per wave)
+        if (n < blocks * 2u * chunk) {
+            chunk = (n + blocks - 1) / (blocks ? blocks : 1);
+            if (chunk < p->L) chunk = p->L;
+        }
+    } else {
+        // The chunks are dealt out round-robin, so every wave should get the SAME number of them: k = the chunks per wave that keeps a
+        // chunk at or below `full`, chunk = n / (waves * k).  (With chunks of exactly `full` lines a batch of 1.9 chunks per wave left a
+        // tenth of the grid with half the work of the rest: 4 M structured-data lines 1.80 -> 1.89 G lines/s, 4 M long-tail lines
+        // 0.69 -> 0.88 G with one even chunk per wave, profiles/r04z3_sweep_cfg4.log, r04z5_sweep_cfg5.log.)
+        const uint64_t per_wave = (n + blocks - 1) / (blocks ? blocks : 1);
+        const uint64_t k = (per_wave + full - 1) / full;
+        chunk = (per_wave + (k ? k : 1) - 1) / (k ? k : 1);
         if (chunk < p->L) chunk = p->L;
-        if (chunk > full && !lo.chunk_lines) chunk = full;
     }
     const uint64_t chunks = (n + chunk - 1) / chunk;
     if (blocks > chunks) blocks = chunks;
