@@ -20,8 +20,8 @@
 // consecutive bytes).  The stream is read once; nothing but the descriptors is written besides the output.
 // The classic form (k_frame_scan -> k_frame_prefix -> k_frame_emit: masks to HBM, a one-workgroup scan of the tile counts, a second
 // pass over the masks; 39 GB of traffic for a 25.5 GB stream) is kept as the fall-back: a wave that waits on a predecessor's
-// descriptor longer than kSpinLimit polls raises an abort word, every wave leaves, the launcher's caller sees the sentinel total
-// and runs the classic kernels (forward progress of the chain rests on workgroups being dispatched in index order; the bound makes a
+// descriptor longer than kSpinLimit polls raises an abort word and leaves the sentinel as the range's total, the launcher's caller
+// sees it and runs the classic kernels (forward progress of the chain rests on workgroups being dispatched in index order; the bound makes a
 // platform where that ever fails slow, not hung).
 // UTF-8 validity is judged per byte position from the byte and its three predecessors (the
 // table-free form of the well-formedness rules, Unicode 15 Table 3-7), so blocks, waves and
@@ -343,10 +343,13 @@ __global__ __launch_bounds__(kWave* kTileWaves) void k_frame_onepass(const uint8
             s_prefix = prefix;
             s_abort = aborted ? 1u : 0u;
             const uint64_t incl = prefix + tile_count;
+            // (the range's total through an atomic MAX over a word the launcher cleared: a tile that gave up leaves the sentinel -- the
+            //  largest value -- whichever of the two stores lands last; tiles behind a tile that gave up still finish, on its count)
             if (aborted) {
-                pref[blk1] = kFrameAborted;
+                atomicMax(reinterpret_cast<unsigned long long*>(pref + blk1), (unsigned long long)kFrameAborted);
             } else {
-                if (tile == (blk1 - 1u) / kTileWaves) pref[blk1] = incl;  // the delimiters up to the end of this launch's range
+                if (tile == (blk1 - 1u) / kTileWaves)  // the delimiters up to the end of this launch's range
+                    atomicMax(reinterpret_cast<unsigned long long*>(pref + blk1), (unsigned long long)incl);
                 if (tile == 0) offsets[0] = 0;
                 if (whole && tile == (nblk - 1u) / kTileWaves && incl + 1 <= cap) offsets[incl + 1] = nbytes;  // a final unterminated frame
             }
@@ -408,6 +411,7 @@ extern "C" int fg_launch_frame(const uint8_t* d_bytes, uint64_t nbytes, uint32_t
         uint64_t* desc = reinterpret_cast<uint64_t*>(scratch);  // (where the classic form keeps its masks)
         (void)hipMemsetAsync(desc, 0, nblk * 8u, stream);
         (void)hipMemsetAsync(frame_abort_word(scratch, nblk), 0, 4, stream);
+        (void)hipMemsetAsync(pref + nblk, 0, 8, stream);
         hipLaunchKernelGGL(fg::k_frame_onepass<false>, dim3((uint32_t)((nblk + fg::kTileWaves - 1) / fg::kTileWaves)), dim3(fg::kWave * fg::kTileWaves), 0,
                            stream, d_bytes, nbytes, pat, desc, pref, frame_abort_word(scratch, nblk), d_offsets, d_bad, cap, (uint64_t)0, nblk, nblk,
                            1u, (uint8_t*)nullptr);
@@ -449,6 +453,7 @@ extern "C" int fg_launch_frame_slice(const uint8_t* d_bytes, uint64_t nbytes, ui
         }
         // (tiles of four blocks: a slice that is not the stream's first starts at a multiple of fg_frame_slice_align())
         if (blk0 % fg::kTileWaves) return -1;
+        (void)hipMemsetAsync(pref + blk1, 0, 8, stream);
         const uint64_t tile0 = blk0 / fg::kTileWaves;
         const uint32_t nt = (uint32_t)((blk1 + fg::kTileWaves - 1) / fg::kTileWaves - tile0);
         if (src)
