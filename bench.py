@@ -739,25 +739,48 @@ def main():
         from flowgger_amd import shard
 
         side = torch.cuda.Stream(dev)
-        parts = [s.tables.to_host_pinned(side) for s in subs]  # (allocates + pins the staging buffers: a framer keeps them)
+        # round 4: the rows go back to their arrival positions ON THE DEVICE (fg_merge_tables_device: both sub-batches' tables are still in
+        # HBM), and ONE merged table crosses the link.  (Rounds 2-3: D2H of both tables + fg_merge_tables on the host's cores -- 36 of 56 ms;
+        # timed below as `host_merge_ms` for comparison.)
+        d_index = [torch.from_numpy(np.ascontiguousarray(ix).astype(np.int64)).to(dev) for ix in index]
+        d_merged, d_src = shard.merge_tables_device(subs[0].dec, [s.tables for s in subs], d_index)   # allocates the merged table
+        merged = d_merged.to_host_pinned(side)  # (allocates + pins the staging buffer: a framer keeps it)
+        torch.cuda.synchronize(dev)
         D.barrier()
+        mev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         t0 = time.perf_counter()
-        parts = [s.tables.to_host_pinned(side, host=p._pinned) for s, p in zip(subs, parts)]  # D2H of both sub-batches' tables
-        d2h_ms = (time.perf_counter() - t0) * 1e3
-        merged, src = shard.merge_tables(parts, index)       # first call allocates + faults the output in
-        t0 = time.perf_counter()
-        merged, src = shard.merge_tables(parts, index, out=merged, src=src)
+        mev[0].record()
+        d_merged, d_src = shard.merge_tables_device(subs[0].dec, [s.tables for s in subs], d_index, out=d_merged, d_src=d_src)
+        mev[1].record()
+        torch.cuda.synchronize(dev)
         merge_ms = (time.perf_counter() - t0) * 1e3
+        merge_kernel_ms = mev[0].elapsed_time(mev[1])
+        t0 = time.perf_counter()
+        merged = d_merged.to_host_pinned(side, host=merged._pinned)  # D2H of the ONE merged table
+        src = d_src.cpu().numpy()
+        d2h_ms = (time.perf_counter() - t0) * 1e3
         assert merged.n == n and np.array_equal(src[: args.tile_lines], tag), "merge did not restore the arrival order"
+        # the host merge of rounds 2-3, for comparison and as the check of the device merge (same rows at the same places)
+        parts = [s.tables.to_host_pinned(side) for s in subs]
+        hmerged, hsrc = shard.merge_tables(parts, index)
+        t0 = time.perf_counter()
+        hmerged, hsrc = shard.merge_tables(parts, index, out=hmerged, src=hsrc)
+        host_merge_ms = (time.perf_counter() - t0) * 1e3
+        assert np.array_equal(hsrc, src) and np.array_equal(hmerged.a["meta"][:n], merged.a["meta"][:n]) and hmerged.ent_used == merged.ent_used
+        assert np.array_equal(hmerged.a["ent_first"][:n], merged.a["ent_first"][:n])
         # spot check: rows went back where they came from
         for k, s_ in enumerate(subs):
             j = np.array([0, s_.n_tile // 2, s_.n - 1])
             assert np.array_equal(merged.a["meta"][index[k][j].astype(np.int64)], parts[k].a["meta"][j])
-        table_bytes = sum(int(p.n) * 68 + int(p.ent_used) * 18 for p in parts)
-        gather = {"gather_ms": d2h_ms + merge_ms, "d2h_ms": d2h_ms, "merge_ms": merge_ms, "rows": int(merged.n),
+        table_bytes = int(merged.n) * 68 + int(merged.ent_used) * 18
+        gather = {"gather_ms": d2h_ms + merge_ms, "d2h_ms": d2h_ms, "merge_ms": merge_ms, "merge_kernel_ms": merge_kernel_ms,
+                  "host_merge_ms": host_merge_ms, "rows": int(merged.n),
                   "entries": int(merged.ent_used), "table_bytes": table_bytes, "d2h_GBps": table_bytes / (d2h_ms * 1e-3) / 1e9,
                   "lines_per_s": n / ((d2h_ms + merge_ms) * 1e-3),
-                  "what": "D2H of both sub-batches' tables into pinned memory + fg_merge_tables by arrival index (whole resident batch)"}
+                  "what": "fg_merge_tables_device (rows back to their arrival positions, entries rebased, in HBM) + D2H of the ONE merged table "
+                          "into pinned memory (whole resident batch); host_merge_ms = fg_merge_tables on the host's cores, what rounds 2-3 "
+                          "added to a D2H of the same size"}
+        del hmerged
         if D.on:  # N ranks: the ranks' merged tables -> one table on rank 0, in rank (= shard) order
             D.barrier()
             t0 = time.perf_counter()

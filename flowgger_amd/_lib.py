@@ -143,6 +143,7 @@ def lib() -> C.CDLL:
     L.fg_gather_size.argtypes = [C.POINTER(fg_tables), u32, C.POINTER(u64), C.POINTER(u64)]
     L.fg_gather_tables.argtypes = [C.POINTER(fg_tables), u32, C.POINTER(fg_tables)]
     L.fg_merge_tables.argtypes = [C.POINTER(fg_tables), u32, C.POINTER(vp), C.POINTER(fg_tables), vp]
+    L.fg_merge_tables_device.argtypes = [vp, C.POINTER(fg_tables), u32, C.POINTER(vp), C.POINTER(fg_tables), vp, vp]
     L.fg_ordered_merge.argtypes = [u32, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp, u64, vp]
     L.fg_ordered_merge.restype = C.c_int64
     L.fg_set_timing.argtypes = [vp, C.c_int]

@@ -24,7 +24,7 @@ PROF = bool(os.environ.get("FG_BUILD_PROF"))
 LIB = ROOT / ("libfg_hip_prof.so" if PROF else "libfg_hip.so")
 ARCH = "gfx950"
 
-HIP_SOURCES = ["fg_rfc5424.hip", "fg_ltsv.hip", "fg_gelf.hip", "fg_frame.hip", "fg_encode.hip", "fg_rfc3164.hip", "fg_calib.hip"]
+HIP_SOURCES = ["fg_rfc5424.hip", "fg_ltsv.hip", "fg_gelf.hip", "fg_frame.hip", "fg_encode.hip", "fg_rfc3164.hip", "fg_calib.hip", "fg_merge.hip"]
 HIP_HOST_SOURCES = ["fg_capi.cpp", "fg_host_pipeline.cpp"]  # host code that needs the HIP headers / launch syntax
 CXX_SOURCES = ["fg_materialize.cpp", "fg_gather.cpp"]
 

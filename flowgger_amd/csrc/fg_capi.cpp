@@ -306,6 +306,28 @@ int fg_calibrate_device(fg_ctx* ctx, int mode, const uint8_t* d_src, uint8_t* d_
     return FG_OK;
 }
 
+int fg_merge_tables_device(fg_ctx* ctx, const fg_tables* parts, uint32_t g, const uint64_t* const* d_index, const fg_tables* out,
+                           uint8_t* d_src_part, void* stream) {
+    if (!ctx || !parts || !d_index || !out || g == 0 || g > 8) return FG_ERR_ARG;
+    uint64_t rows = 0, cap = 0, max_rows = 0, max_cap = 0;
+    for (uint32_t k = 0; k < g; ++k) {
+        if (parts[k].n && !d_index[k]) return FG_ERR_ARG;
+        rows += parts[k].n;
+        cap += parts[k].ent_cap;
+        if (parts[k].n > max_rows) max_rows = parts[k].n;
+        if (parts[k].ent_cap > max_cap) max_cap = parts[k].ent_cap;
+    }
+    if (out->n != rows || out->ent_cap < cap || cap > 0xFFFFFFFFull) return FG_ERR_ARG;
+    DeviceGuard gd(ctx->device);
+    hipStream_t s = stream == FG_STREAM_OWN ? ctx->stream : (hipStream_t)stream;
+    const int rc = fg_launch_merge_device(parts, g, d_index, out, d_src_part, max_rows, max_cap, s);
+    if (rc != 0) {
+        ctx->last_hip = rc;
+        return FG_ERR_HIP;
+    }
+    return FG_OK;
+}
+
 int fg_decode_batch_device(fg_ctx* ctx, fg_format fmt, const uint8_t* d_bytes, uint64_t nbytes,
                            const uint64_t* d_offsets, uint64_t n, const fg_tables* tables, void* stream) {
     return fg_decode_frames_device(ctx, fmt, FG_FRAME_NONE, d_bytes, nbytes, d_offsets, n, nullptr, tables, stream);

@@ -68,6 +68,8 @@ extern "C" int fg_launch_gelf(const uint8_t* d_bytes, const uint64_t* d_offsets,
                               const uint8_t* line_bad, const fg_launch_opts* lo);
 
 extern "C" int fg_launch_poke64(const uint64_t* d_src, uint64_t* dst_devview, hipStream_t stream);
+extern "C" int fg_launch_merge_device(const fg_tables* parts, uint32_t g, const uint64_t* const* d_index, const fg_tables* out, uint8_t* d_src_part,
+                                      uint64_t max_rows, uint64_t max_entries, hipStream_t stream);
 extern "C" int fg_launch_calib(int mode, const uint8_t* d_src, uint8_t* d_dst, uint64_t nbytes, uint32_t* d_sink, hipStream_t stream);
 
 struct fg_ctx {

@@ -82,6 +82,31 @@ def merge_tables(parts: Sequence[HostTables], index: Sequence[np.ndarray], out: 
     return out, src[: int(n.value)]
 
 
+def merge_tables_device(dec, parts, d_index, out=None, d_src=None, stream=None):
+    """fg_merge_tables_device: the same merge while the sub-batches' tables are still in HBM.  parts: DeviceTables (as the decoders
+    left them); d_index[k]: torch int64 / uint64 tensor on the device, original position of row j of parts[k].  Returns
+    (DeviceTables, src_part uint8 tensor); asynchronous on `stream` (default: torch's current stream).  ONE merged table then crosses the
+    link (DeviceTables.to_host_pinned) instead of every part's plus a pass of the host over all of them."""
+    import torch
+
+    from .tables import DeviceTables
+
+    dev = parts[0].buf.device
+    n = sum(int(p.n) for p in parts)
+    cap = sum(int(p.ent_cap) for p in parts)
+    if out is None or out.n != n or out.ent_cap < cap:
+        out = DeviceTables(n, cap, dev)
+    if d_src is None or d_src.numel() < n:
+        d_src = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
+    if stream is None:
+        stream = torch.cuda.current_stream(dev)
+    arr = (L.fg_tables * len(parts))(*[p.struct for p in parts])
+    ptrs = (C.c_void_p * len(parts))(*[int(i.data_ptr()) for i in d_index])
+    L.check(L.lib().fg_merge_tables_device(dec._ctx, arr, len(parts), ptrs, C.byref(out.struct), int(d_src.data_ptr()),
+                                           C.c_void_p(stream.cuda_stream)), "fg_merge_tables_device")
+    return out, d_src[:n]
+
+
 def decode_sharded(decode: Callable[[np.ndarray, np.ndarray, int], HostTables], data: np.ndarray,
                    offsets: np.ndarray, g: int) -> HostTables:
     """Single-process driver: decode(shard_bytes, shard_offsets, k) for each of g shards (each

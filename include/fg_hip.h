@@ -450,6 +450,14 @@ int fg_shard_plan(const uint64_t* offsets, uint64_t n, uint32_t g, uint64_t* lin
  *                     m[k] records, record j = blobs[k][offs[k][j] .. offs[k][j+1]); out_offs receives rows+1 offsets;
  *                     returns the total bytes (call with out == NULL to size), negative FG_ERR_* on bad arguments */
 int fg_gather_size(const fg_tables* parts, uint32_t g, uint64_t* n_rows, uint64_t* n_entries);
+/* fg_merge_tables ON THE DEVICE (round 4): the parts' tables, index[k] and `out` are device memory (the sub-batches' tables as
+ * fg_decode_batch_device left them, at most 8 parts); the rows go back to their arrival positions and the entry columns behind one
+ * another while everything is still in HBM -- ONE merged table then crosses the link instead of g tables plus a pass of the host's
+ * cores over all of them.  Asynchronous on `stream`; the parts' entry counters are read on the device.  out->n must be the sum of the
+ * parts' rows and out->ent_cap at least the sum of their ent_cap (checked); out->ent_used receives the merged entry count;
+ * d_src_part (device, may be NULL) as src_part of fg_merge_tables.  The indices are the caller's contract (every position once). */
+int fg_merge_tables_device(fg_ctx* ctx, const fg_tables* parts, uint32_t g, const uint64_t* const* d_index, const fg_tables* out,
+                           uint8_t* d_src_part, void* stream);
 int fg_gather_tables(const fg_tables* parts, uint32_t g, fg_tables* out);
 int fg_merge_tables(const fg_tables* parts, uint32_t g, const uint64_t* const* index, fg_tables* out, uint8_t* src_part);
 int64_t fg_ordered_merge(uint32_t g, const uint64_t* m, const uint64_t* const* index, const uint8_t* const* blobs,

@@ -149,6 +149,32 @@ extern "C" int fg_launch_encode_write(const uint8_t* b, const uint64_t* o, uint6
     return 0;
 }
 
+// ---- the device merge (fg_merge.hip), on "device" memory that is host memory here
+extern "C" int fg_launch_merge_device(const fg_tables* parts, uint32_t g, const uint64_t* const* d_index, const fg_tables* out, uint8_t* d_src_part,
+                                      uint64_t, uint64_t, hipStream_t) {
+    uint64_t base = 0;
+    for (uint32_t k = 0; k < g; ++k) {
+        const fg_tables& p = parts[k];
+        const uint64_t used = *p.ent_used < p.ent_cap ? *p.ent_used : p.ent_cap;
+        for (uint64_t j = 0; j < p.n; ++j) {
+            const uint64_t i = d_index[k][j];
+            out->meta[i] = p.meta[j]; out->ts[i] = p.ts[j];
+            out->hostname[i] = p.hostname[j]; out->appname[i] = p.appname[j]; out->procid[i] = p.procid[j];
+            out->msgid[i] = p.msgid[j]; out->msg[i] = p.msg[j]; out->full_msg[i] = p.full_msg[j];
+            out->ent_count[i] = p.ent_count[j];
+            out->ent_first[i] = p.ent_count[j] ? (uint32_t)(p.ent_first[j] + base) : 0u;
+            if (d_src_part) d_src_part[i] = (uint8_t)k;
+        }
+        for (uint64_t e = 0; e < used; ++e) {
+            out->ent_name[base + e] = p.ent_name[e]; out->ent_val[base + e] = p.ent_val[e];
+            out->ent_type[base + e] = p.ent_type[e]; out->ent_flags[base + e] = p.ent_flags[e];
+        }
+        base += used;
+    }
+    *out->ent_used = base;
+    return 0;
+}
+
 // ---- framing: offsets[0] = 0, offsets[r + 1] = the byte behind the delimiter of rank r; the word behind block k of `scratch` holds
 //      the delimiters of the blocks before k (so the word at [blk1] is "up to the end of this slice")
 extern "C" uint64_t fg_frame_block_bytes(void) { return 16384; }

@@ -325,3 +325,38 @@ def test_one_pass_framing_equals_the_three_kernel_form_at_scale(framing):
     assert np.array_equal(out[False][1], out[True][1])
     assert np.array_equal((out[False][1] & 0xFF) == L.FG_ST_BAD_UTF8, ab == 1)
     dec.set_launch_opts()
+
+
+def test_device_merge_of_tagged_sub_batches_equals_the_host_merge():
+    """fg_merge_tables_device: the rows of the two sub-batches of a mixed stream (configs[4]) go back to their arrival positions while the
+    tables are still in HBM -- the merged table, copied out once, must equal what fg_merge_tables makes of the two tables on the host
+    (rows at their positions, entries rebased and behind one another, src_part = the tag)."""
+    import torch
+    from flowgger_amd import shard
+
+    n = 200_000
+    tag, (la, ia), (lb, ib) = synth.mixed_cfg5(n)
+    decs = (RFC5424Decoder(), LTSVDecoder(synth.LTSV_CONFIG))
+    dev = torch.device("cuda", decs[0].device)
+    dparts, hparts, index = [], [], [ia, ib]
+    for dec, lines in zip(decs, (la, lb)):
+        data, offsets = synth.pack(lines)
+        tables, _, _ = device_path(dec, data, offsets, ent_cap=int(offsets[-1]) // 16 + (1 << 20))
+        dparts.append(tables)
+        hparts.append(tables.to_host_pinned())
+    want, wsrc = shard.merge_tables(hparts, index)
+    d_index = [torch.from_numpy(ix.astype(np.int64)).to(dev) for ix in index]
+    out, d_src = shard.merge_tables_device(decs[0], dparts, d_index)
+    torch.cuda.synchronize(dev)
+    got = out.to_host_pinned()
+    assert got.n == want.n == n and got.ent_used == want.ent_used
+    assert np.array_equal(d_src.cpu().numpy(), tag) and np.array_equal(wsrc, tag)
+    for col in ("meta", "ts", "hostname", "appname", "procid", "msgid", "msg", "full_msg", "ent_first", "ent_count"):
+        assert np.array_equal(got.a[col][: n * (2 if got.a[col].size >= 2 * n else 1)], want.a[col][: n * (2 if want.a[col].size >= 2 * n else 1)]), col
+    u = want.ent_used
+    for col, w in (("ent_name", 2), ("ent_val", 1), ("ent_type", 1), ("ent_flags", 1)):
+        assert np.array_equal(got.a[col][: u * w], want.a[col][: u * w]), col
+    # a second merge into the same output (a framer merges batch after batch into the same memory)
+    out2, _ = shard.merge_tables_device(decs[0], dparts, d_index, out=out, d_src=d_src)
+    torch.cuda.synchronize(dev)
+    assert out2 is out and out.to_host_pinned().ent_used == want.ent_used
