@@ -152,7 +152,7 @@ __device__ __forceinline__ bool key_is(R& rd, uint32_t b, uint32_t e, const char
 
 // One forward pass over the line.  EMIT=false: validate + count; EMIT=true: write entries.
 template <bool EMIT, class R>
-__device__ void ltsv_walk(R& rd, uint32_t len, const LtsvDevCfg& cfg, uint8_t* lds_digits, LRow& r,
+__device__ __forceinline__ void ltsv_walk(R& rd, uint32_t len, const LtsvDevCfg& cfg, uint8_t* lds_digits, LRow& r,
                           const DevTables& t, uint32_t slot) {
     uint32_t cnt = 0;
     uint32_t ps = 0;
@@ -284,6 +284,17 @@ __device__ void ltsv_walk(R& rd, uint32_t len, const LtsvDevCfg& cfg, uint8_t* l
         r.n_ent = cnt;
     }
 }
+
+// The call the kernels make (rare lines only).  Reader and row travel BY VALUE -- in registers: a reference to either would be an
+// object in the caller's frame, i.e. scratch memory reserved for every lane of every wave (508 B per lane in round 3, 140 with the
+// row and the reader in the kernel's frame, what is left now is the callees' own).
+template <bool EMIT, class R>
+__device__ __noinline__ LRow ltsv_walk_call(R rd, uint32_t len, const LtsvDevCfg& cfg, uint8_t* lds_digits, const DevTables& t, uint32_t slot) {
+    LRow r;
+    ltsv_walk<EMIT>(rd, len, cfg, lds_digits, r, t, slot);
+    return r;
+}
+
 
 // ---------------------------------------------------------------------------------------------
 // The tile form
@@ -721,17 +732,10 @@ struct LtsvFormatT {
                 // The same goes for the tables and the configuration: passed by reference from HERE they would be kept in scratch
                 // memory for the whole kernel (every table store then reloads its column pointer from there): the call gets the
                 // copies the kernel parked in LDS.
-                LRow slow;
                 const DevTables& t_copy = *t_call;
                 const LtsvDevCfg& cfg_copy = *cfg;
-                if (whole && !HEAD) {
-                    LdsReader rd(T.w, base);
-                    ltsv_walk<false>(rd, len, cfg_copy, lds_digits, slow, t_copy, 0);
-                } else {
-                    GlobalReader rd(reinterpret_cast<const uint32_t*>(c.bytes), c.o0);
-                    ltsv_walk<false>(rd, len, cfg_copy, lds_digits, slow, t_copy, 0);
-                }
-                r = slow;
+                if (whole && !HEAD) r = ltsv_walk_call<false>(LdsReader(T.w, base), len, cfg_copy, lds_digits, t_copy, 0);
+                else r = ltsv_walk_call<false>(GlobalReader(reinterpret_cast<const uint32_t*>(c.bytes), c.o0), len, cfg_copy, lds_digits, t_copy, 0);
             }
             if (r.status != L_OK) r.n_ent = 0;
         }
@@ -768,16 +772,10 @@ struct LtsvFormatT {
             } else {
                 // (a line outside the tile -- or one whose records did not fit its consumed bytes, whose copy in the tile is therefore
                 //  no longer intact: from global memory then)
-                LRow scratch = r;
                 const DevTables& t_copy = *t_call;  // (see above)
                 const LtsvDevCfg& cfg_copy = *cfg;
-                if (whole && !HEAD && !tile_lane) {
-                    LdsReader rd(T.w, base);
-                    ltsv_walk<true>(rd, len, cfg_copy, lds_digits, scratch, t_copy, first);
-                } else {
-                    GlobalReader rd(reinterpret_cast<const uint32_t*>(c.bytes), c.o0);
-                    ltsv_walk<true>(rd, len, cfg_copy, lds_digits, scratch, t_copy, first);
-                }
+                if (whole && !HEAD && !tile_lane) (void)ltsv_walk_call<true>(LdsReader(T.w, base), len, cfg_copy, lds_digits, t_copy, first);
+                else (void)ltsv_walk_call<true>(GlobalReader(reinterpret_cast<const uint32_t*>(c.bytes), c.o0), len, cfg_copy, lds_digits, t_copy, first);
             }
         }
         if (c.phase) {
