@@ -79,6 +79,7 @@ class fg_launch_opts(C.Structure):
 
 FG_LO_GELF_GENERIC, FG_LO_TRANSCODE_ONE_PIECE, FG_LO_NO_HEAD, FG_LO_FORCE_HEAD, FG_LO_SD_WALK, FG_LO_SD_PAIRS, FG_LO_NO_ZERO_COPY, FG_LO_FRAME_KERNEL_UPLOAD = 1, 2, 4, 8, 16, 32, 64, 128
 FG_LO_FRAME_CLASSIC = 256
+FG_LO_RESERVED = 0x40000000  # the library's own (fg_set_launch_opts clears it)
 
 
 class fg_transcoded(C.Structure):

@@ -267,6 +267,7 @@ int fg_set_launch_opts(fg_ctx* ctx, const fg_launch_opts* opts) {
     if (!ctx) return FG_ERR_ARG;
     if (opts && (opts->lines_per_group > 64 || (opts->gelf_window_kib && (opts->gelf_window_kib < 2 || opts->gelf_window_kib > 6)))) return FG_ERR_ARG;
     ctx->lo = opts ? *opts : fg_launch_opts{};
+    ctx->lo.flags &= ~(uint32_t)FG_LO_RESERVED;
     return FG_OK;
 }
 
@@ -410,10 +411,22 @@ int fg_decode_frames_impl(fg_ctx* ctx, fg_format fmt, fg_framing framing, const 
         FG_HIP(ctx, hipMalloc((void**)&ctx->d_pending, kPendingRing * sizeof(uint32_t)));
         FG_HIP(ctx, hipMemset(ctx->d_pending, 0, kPendingRing * sizeof(uint32_t)));
     }
-    ctx->epoch += 1u;
-    if (ctx->epoch == 0u) ctx->epoch = 1u;  // (0 = the ring's initial content: never a valid epoch)
-    dt.epoch = ctx->epoch;
-    dt.pending = ctx->d_pending + (ctx->epoch % kPendingRing);
+    fg_launch_opts lo_call = ctx->lo;
+    if (ctx->defer_general && fmt == FG_GELF) {
+        // the slices of one batch: one hand-over word for all of them, the exact form once behind the last (fg_finish_deferred_general)
+        if (!ctx->batch_epoch) {
+            ctx->epoch += 1u;
+            if (ctx->epoch == 0u) ctx->epoch = 1u;
+            ctx->batch_epoch = ctx->epoch;
+        }
+        dt.epoch = ctx->batch_epoch;
+        lo_call.flags |= (uint32_t)FG_LO_RESERVED;
+    } else {
+        ctx->epoch += 1u;
+        if (ctx->epoch == 0u) ctx->epoch = 1u;  // (0 = the ring's initial content: never a valid epoch)
+        dt.epoch = ctx->epoch;
+    }
+    dt.pending = ctx->d_pending + (dt.epoch % kPendingRing);
     if (ctx->timing) FG_HIP(ctx, hipEventRecord(ctx->ev0, s));
     int rc;
     const uint64_t avg_len = (span_bytes + n - 1) / n;
@@ -428,7 +441,7 @@ int fg_decode_frames_impl(fg_ctx* ctx, fg_format fmt, fg_framing framing, const 
             break;
         case FG_GELF:
             rc = fg_launch_gelf(d_bytes, d_offsets, n, &dt, avg_len, s, stash, ctx->stash_blocks,
-                                (uint32_t)framing, d_bad_utf8, &ctx->lo);
+                                (uint32_t)framing, d_bad_utf8, &lo_call);
             break;
         case FG_RFC3164:
             if (!ctx->r3164_set) return FG_ERR_ARG;  // fg_set_rfc3164 first
@@ -450,6 +463,27 @@ int fg_decode_frames_impl(fg_ctx* ctx, fg_format fmt, fg_framing framing, const 
     return FG_OK;
 }
 
+
+// The exact form of GELF for ALL rows of a batch whose slices were decoded with ctx->defer_general set (a no-op when none was).
+int fg_finish_deferred_general(fg_ctx* ctx, fg_framing framing, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n,
+                               const uint8_t* d_bad_utf8, const fg_tables* tables, void* stream) {
+    const uint32_t epoch = ctx->batch_epoch;
+    ctx->batch_epoch = 0;
+    ctx->defer_general = false;
+    if (!epoch || n == 0) return FG_OK;
+    DeviceGuard g(ctx->device);
+    hipStream_t s = stream == FG_STREAM_OWN ? ctx->stream : (hipStream_t)stream;
+    fg::DevTables dt = to_dev(*tables);
+    dt.n = n;
+    dt.epoch = epoch;
+    dt.pending = ctx->d_pending + (epoch % 1024u);
+    const int rc = fg_launch_gelf_general(d_bytes, d_offsets, n, &dt, s, (uint32_t)framing, d_bad_utf8);
+    if (rc != 0) {
+        ctx->last_hip = rc;
+        return FG_ERR_HIP;
+    }
+    return FG_OK;
+}
 
 namespace {
 // fg_encode_device (total != nullptr: synchronises for the configuration's entry count and for the total) and

@@ -63,6 +63,8 @@ extern "C" int fg_launch_frame_slice(const uint8_t* d_bytes, uint64_t nbytes, ui
 extern "C" int fg_launch_ltsv(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
                               const fg::LtsvDevCfg* cfg, uint64_t avg_len, hipStream_t stream, uint64_t* stash,
                               uint32_t stash_blocks, uint32_t strip, const uint8_t* line_bad, const fg_launch_opts* lo);
+extern "C" int fg_launch_gelf_general(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t, hipStream_t stream,
+                                      uint32_t strip, const uint8_t* line_bad);
 extern "C" int fg_launch_gelf(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
                               uint64_t avg_len, hipStream_t stream, uint64_t* stash, uint32_t stash_blocks, uint32_t strip,
                               const uint8_t* line_bad, const fg_launch_opts* lo);
@@ -98,6 +100,8 @@ struct fg_ctx {
     uint32_t stash_blocks = 0;
     uint32_t* d_pending = nullptr;  // ring of kPendingRing hand-over words (DevTables::pending), zeroed once
     uint32_t epoch = 0;             // launch counter of this ctx
+    bool defer_general = false;     // a sliced host path: GELF's exact form runs once, behind the last slice (fg_finish_deferred_general)
+    uint32_t batch_epoch = 0;       // ... and the slices share one hand-over word: the epoch of the batch's first GELF launch
     uint32_t* d_sink = nullptr;     // fg_calibrate_device: the word the read-only sweep may write
     uint64_t* d_used = nullptr;     // fg_decode_batch, zero-copy form: the entry counter (the tables themselves are pinned host memory)
     uint8_t* d_frame = nullptr;  // fg_frame_device scratch (delimiter / UTF-8 masks, block counts)
@@ -255,6 +259,8 @@ int grow_pinned(fg_ctx* ctx, void** p, uint64_t* cap, uint64_t need) {
 // one decode launch on `stream` (fg_capi.cpp).  reset_counter = false: a further slice of a batch whose entry counter is already live;
 // span_bytes = the bytes the n lines cover (launch geometry is planned from the average line); lane = 1: a second launch that may be in
 // flight at the same time (its own entry stash)
+extern "C" int fg_finish_deferred_general(fg_ctx* ctx, fg_framing framing, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n,
+                               const uint8_t* d_bad_utf8, const fg_tables* tables, void* stream);
 extern "C" int fg_decode_frames_impl(fg_ctx* ctx, fg_format fmt, fg_framing framing, const uint8_t* d_bytes, uint64_t nbytes,
                           const uint64_t* d_offsets, uint64_t n, const uint8_t* d_bad_utf8, const fg_tables* tables,
                           void* stream, bool reset_counter, uint64_t span_bytes, uint32_t lane = 0);

@@ -772,6 +772,8 @@ int launch_gelf_fast(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t
 }
 }  // namespace
 
+extern "C" int fg_launch_gelf_general(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t, hipStream_t stream,
+                                      uint32_t strip, const uint8_t* line_bad);
 extern "C" int fg_launch_gelf(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
                               uint64_t avg_len, hipStream_t stream, uint64_t* stash, uint32_t stash_blocks, uint32_t strip,
                               const uint8_t* line_bad, const fg_launch_opts* lop) {
@@ -813,13 +815,21 @@ extern "C" int fg_launch_gelf(const uint8_t* d_bytes, const uint64_t* d_offsets,
     else rc = launch_gelf_fast<6>(d_bytes, d_offsets, n, t, avg_len, stream, p.L, fr, lo);
     if (rc) return rc;
     if (hipGetLastError() != hipSuccess) return -1;
-    // pending lines (a frame flagged as invalid UTF-8 never is: the pipeline has overwritten its status)
+    // pending lines (a frame flagged as invalid UTF-8 never is: the pipeline has overwritten its status) -- unless the caller runs the
+    // exact form ONCE for all the slices of a batch (fg_launch_gelf_general over all rows: the kernel is a chain of dependent steps,
+    // ~170 us however few lines a slice hands it -- a quarter of the GPU time of a sliced host path, profiles/r04g2_probe_frame_gelf.log)
+    if (lo.flags & FG_LO_RESERVED) return 0;
+    return fg_launch_gelf_general(d_bytes, d_offsets, n, t, stream, strip, line_bad);
+}
+extern "C" int fg_launch_gelf_general(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t, hipStream_t stream,
+                                      uint32_t strip, const uint8_t* line_bad) {
+    if (n == 0) return 0;
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
         return -1;
     uint64_t chunks = (n + fg::kGeneralSpan - 1) / fg::kGeneralSpan;
     uint64_t gblocks = (uint64_t)cus * 8u;
     if (gblocks > chunks) gblocks = chunks;
-    hipLaunchKernelGGL(fg::k_gelf_general, dim3((uint32_t)gblocks), block, 0, stream, d_bytes, d_offsets, n, *t, fg::FrameArgs{strip, line_bad});
+    hipLaunchKernelGGL(fg::k_gelf_general, dim3((uint32_t)gblocks), dim3(fg::kWave), 0, stream, d_bytes, d_offsets, n, *t, fg::FrameArgs{strip, line_bad});
     return (int)hipGetLastError();
 }

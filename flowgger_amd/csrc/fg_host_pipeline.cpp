@@ -486,6 +486,19 @@ static int frame_decode_sliced(fg_ctx* ctx, fg_format fmt, fg_framing framing, c
                                fg_tables* out, const uint64_t** out_offsets, uint64_t* n_frames, uint64_t* consumed) {
     int rc;
     LinkBoundGrid grid(ctx);
+    // GELF's exact form (k_gelf_general: the lines the fast form hands back) runs ONCE, behind the last slice, over all rows -- it is a
+    // chain of dependent steps of ~170 us however few lines it gets, and launched per slice it was a quarter of this path's GPU time
+    struct DeferGeneral {
+        fg_ctx* ctx;
+        explicit DeferGeneral(fg_ctx* c, bool on) : ctx(c) {
+            ctx->defer_general = on;
+            ctx->batch_epoch = 0;
+        }
+        ~DeferGeneral() {  // (also on every error path: nothing of this batch is left pending in the ctx)
+            ctx->defer_general = false;
+            ctx->batch_epoch = 0;
+        }
+    } defer(ctx, fmt == FG_GELF);
     const uint64_t blk = fg_frame_block_bytes();
     // (sixteen slices or more: the first upload and the last decode + download run alone -- a sixteenth of the batch each, not an eighth)
     uint64_t slice = nbytes / 16;
@@ -630,6 +643,14 @@ static int frame_decode_sliced(fg_ctx* ctx, fg_format fmt, fg_framing framing, c
             return rc;
         }
         done = n;
+    }
+    {
+        fg_tables all = kt;
+        all.n = done;
+        if ((rc = fg_finish_deferred_general(ctx, framing, ctx->d_bytes, ctx->d_offsets, done, ctx->d_bad, &all, (void*)s_run)) != FG_OK) {
+            drain();
+            return rc;
+        }
     }
     uint64_t used = 0;
     FG_HIP(ctx, hipMemcpyAsync(&used, kt.ent_used, 8, hipMemcpyDeviceToHost, s_run));

@@ -204,8 +204,9 @@ enum {
     FG_LO_NO_ZERO_COPY = 64,       /* fg_decode_batch: the sliced hipMemcpy pipeline even when the caller's buffers are pinned (A/B, tests) */
     FG_LO_FRAME_KERNEL_UPLOAD = 128, /* fg_frame_decode_batch, pinned chunk: the framing scan reads the chunk in place and stores it to HBM
                                       itself instead of hipMemcpy uploads (measured slower on MI355X / ROCm 7.2: off by default) */
-    FG_LO_FRAME_CLASSIC = 256      /* framing: the three-kernel form (masks to HBM, one-workgroup scan, emit) instead of the one-pass chained
+    FG_LO_FRAME_CLASSIC = 256,     /* framing: the three-kernel form (masks to HBM, one-workgroup scan, emit) instead of the one-pass chained
                                       scan -- which falls back to it by itself should its look-back ever give up (A/B, tests) */
+    FG_LO_RESERVED = 0x40000000    /* the library's own (fg_set_launch_opts clears it) */
 };
 
 /* Create a decoder context on HIP device `device` (replaces XDecoder::new(&Config),
