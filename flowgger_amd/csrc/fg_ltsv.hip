@@ -321,6 +321,9 @@ template <bool HEAD = false>
 struct LtsvFormatT {
     static constexpr uint32_t kClasses = 1;
     static constexpr int kTailBatch = 16;  // the whole tile beyond the 2 KiB window in one round trip
+    // HEAD staging: 512 bytes of every long line (the parts in front of the long one -- in practice the message -- are a few hundred
+    // bytes): at the same tile and occupancy a group holds 46 lines of the 64 B .. 8 KiB corpus instead of 28
+    static constexpr uint32_t kHeadBytes = 512;
     static constexpr bool kDeferRowStore = false;  // (stage A waits for the tail's loads anyway)
     static __device__ __forceinline__ void classify_store(const uint4& q, uint16_t* bm16, uint32_t chunk, uint32_t, uint32_t) {
         bm16[chunk] = (uint16_t)mask16(q);
@@ -867,7 +870,7 @@ extern "C" int fg_launch_ltsv(const uint8_t* d_bytes, const uint64_t* d_offsets,
     fg::LaunchPlan p;
     // long lines: only the head of every line is staged, the rest is scanned for a TAB (LtsvFormatT<true>)
     const bool head = (lo->flags & FG_LO_FORCE_HEAD) || (avg_len >= 768u && !(lo->flags & FG_LO_NO_HEAD));
-    const uint64_t plan_len = head ? (avg_len < fg::kHeadCap ? avg_len : fg::kHeadCap) : avg_len;
+    const uint64_t plan_len = head ? (avg_len < fg::LtsvFormatT<true>::kHeadBytes ? avg_len : fg::LtsvFormatT<true>::kHeadBytes) : avg_len;
     if (head ? fg::plan_launch(fg::k_ltsv<fg::kComputeBoundWindow, false, true>, n, plan_len, fg::kLtsvExtraLds, 57344u, stash ? stash_blocks : 0u, &p, *lo)
              // (whole lines staged: chunks of 128 lines -- 3.78 vs 3.67 G lines/s with the pipeline's 256, alternated on one box,
              //  profiles/r04z3_sweep_ltsv.log)

@@ -329,6 +329,11 @@ struct defer_row_store<F, decltype((void)F::kDeferRowStore)> { static constexpr 
 // the lines per tile on the 64 B .. 8 KiB corpus.  The decoder gets the line's last two bytes beside it (the trims) and takes the
 // rare line whose structured data runs past its head from global memory.
 constexpr uint32_t kHeadCap = 1024;  // bytes of a line staged in HEAD mode, alignment slack included (a multiple of 16)
+// (a format whose head holds less says so -- F::kHeadBytes, a multiple of 16 below kHeadCap: more lines per tile at the same occupancy)
+template <class F, class = void>
+struct head_cap { static constexpr uint32_t value = kHeadCap; };
+template <class F>
+struct head_cap<F, decltype((void)F::kHeadBytes)> { static constexpr uint32_t value = F::kHeadBytes; };
 
 template <int NB, bool PROF, class F, bool HEAD = false>
 __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets,
@@ -403,7 +408,7 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
         const uint64_t left = hi_line - q;
         const uint32_t avail = left < (uint64_t)L ? (uint32_t)left : L;  // >= 1
         const uint64_t want = (o1 - o0) + (o0 & 15ull);
-        uint32_t st = want >= kHeadCap ? kHeadCap : (uint32_t)((want + 15ull) & ~15ull);
+        uint32_t st = want >= head_cap<F>::value ? head_cap<F>::value : (uint32_t)((want + 15ull) & ~15ull);
         if (lane >= avail) st = 0u;
         uint32_t total;
         const uint32_t tb = wv::excl_sum(st, &total);
