@@ -79,6 +79,7 @@ class fg_launch_opts(C.Structure):
 
 FG_LO_GELF_GENERIC, FG_LO_TRANSCODE_ONE_PIECE, FG_LO_NO_HEAD, FG_LO_FORCE_HEAD, FG_LO_SD_WALK, FG_LO_SD_PAIRS, FG_LO_NO_ZERO_COPY, FG_LO_FRAME_KERNEL_UPLOAD = 1, 2, 4, 8, 16, 32, 64, 128
 FG_LO_FRAME_CLASSIC = 256
+FG_LO_STATIC_CHUNKS = 512
 FG_LO_RESERVED = 0x40000000  # the library's own (fg_set_launch_opts clears it)
 
 
@@ -147,6 +148,7 @@ def lib() -> C.CDLL:
     L.fg_merge_tables_device.argtypes = [vp, C.POINTER(fg_tables), u32, C.POINTER(vp), C.POINTER(fg_tables), vp, vp]
     L.fg_ordered_merge.argtypes = [u32, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp, u64, vp]
     L.fg_ordered_merge.restype = C.c_int64
+    L.fg_ticket_ring_check.argtypes = [vp]
     L.fg_set_timing.argtypes = [vp, C.c_int]
     L.fg_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.fg_frame_decode_batch.argtypes = [vp, C.c_int, C.c_int, vp, u64, C.c_int, C.POINTER(fg_tables), C.POINTER(vp),

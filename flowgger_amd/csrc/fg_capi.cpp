@@ -235,6 +235,7 @@ void fg_destroy(fg_ctx* ctx) {
     if (ctx->d_stash) (void)hipFree(ctx->d_stash);
     if (ctx->d_stash2) (void)hipFree(ctx->d_stash2);
     if (ctx->d_pending) (void)hipFree(ctx->d_pending);
+    if (ctx->d_ticket) (void)hipFree(ctx->d_ticket);
     if (ctx->d_sink) (void)hipFree(ctx->d_sink);
     if (ctx->d_used) (void)hipFree(ctx->d_used);
     if (ctx->d_frame) (void)hipFree(ctx->d_frame);
@@ -281,6 +282,18 @@ int fg_set_timing(fg_ctx* ctx, int enabled) {
     ctx->timing = enabled != 0;
     ctx->ev_valid = false;
     return FG_OK;
+}
+
+int fg_ticket_ring_check(fg_ctx* ctx) {
+    if (!ctx) return FG_ERR_ARG;
+    DeviceGuard g(ctx->device);
+    if (!ctx->d_ticket) return 0;  // no decode launch yet
+    FG_HIP(ctx, hipDeviceSynchronize());  // (launches may have gone to any stream the caller passed)
+    std::vector<uint32_t> dev(ctx->h_ticket.size());
+    FG_HIP(ctx, hipMemcpy(dev.data(), ctx->d_ticket, dev.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    int bad = 0;
+    for (size_t k = 0; k < dev.size(); ++k) bad += dev[k] != ctx->h_ticket[k] ? 1 : 0;
+    return bad;
 }
 
 int fg_last_kernel_ms(fg_ctx* ctx, float* ms) {
@@ -427,21 +440,32 @@ int fg_decode_frames_impl(fg_ctx* ctx, fg_format fmt, fg_framing framing, const 
         dt.epoch = ctx->epoch;
     }
     dt.pending = ctx->d_pending + (dt.epoch % kPendingRing);
+    // the launch's ticket counter (dynamic chunk dispatch, fg_pipeline.hpp): one word of a ring per LAUNCH -- the slices of a batch may be
+    // in flight on two streams at once and must not draw from one counter -- never reset: the host knows what every launch adds
+    constexpr uint32_t kTicketRing = 1024;
+    if (!ctx->d_ticket) {
+        FG_HIP(ctx, hipMalloc((void**)&ctx->d_ticket, kTicketRing * sizeof(uint32_t)));
+        FG_HIP(ctx, hipMemset(ctx->d_ticket, 0, kTicketRing * sizeof(uint32_t)));
+        ctx->h_ticket.assign(kTicketRing, 0u);
+    }
+    const uint32_t tslot = ctx->ticket_seq++ % kTicketRing;
+    fg::TicketSlot tk_slot{ctx->d_ticket + tslot, &ctx->h_ticket[tslot]};
+    fg::TicketSlot* const tk = (ctx->lo.flags & FG_LO_STATIC_CHUNKS) ? nullptr : &tk_slot;
     if (ctx->timing) FG_HIP(ctx, hipEventRecord(ctx->ev0, s));
     int rc;
     const uint64_t avg_len = (span_bytes + n - 1) / n;
     switch (fmt) {
         case FG_RFC5424:
             rc = fg_launch_rfc5424(d_bytes, d_offsets, n, &dt, avg_len, s, stash, ctx->stash_blocks, (uint32_t)framing,
-                                   d_bad_utf8, &ctx->lo);
+                                   d_bad_utf8, &ctx->lo, tk);
             break;
         case FG_LTSV:
             rc = fg_launch_ltsv(d_bytes, d_offsets, n, &dt, &ctx->ltsv, avg_len, s, stash, ctx->stash_blocks,
-                                (uint32_t)framing, d_bad_utf8, &ctx->lo);
+                                (uint32_t)framing, d_bad_utf8, &ctx->lo, tk);
             break;
         case FG_GELF:
             rc = fg_launch_gelf(d_bytes, d_offsets, n, &dt, avg_len, s, stash, ctx->stash_blocks,
-                                (uint32_t)framing, d_bad_utf8, &lo_call);
+                                (uint32_t)framing, d_bad_utf8, &lo_call, tk);
             break;
         case FG_RFC3164:
             if (!ctx->r3164_set) return FG_ERR_ARG;  // fg_set_rfc3164 first

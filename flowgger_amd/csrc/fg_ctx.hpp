@@ -35,7 +35,7 @@ struct LtsvDevCfg {
 
 extern "C" int fg_launch_rfc5424(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
                                  uint64_t avg_len, hipStream_t stream, uint64_t* stash, uint32_t stash_blocks, uint32_t strip,
-                                 const uint8_t* line_bad, const fg_launch_opts* lo);
+                                 const uint8_t* line_bad, const fg_launch_opts* lo, fg::TicketSlot* tk);
 extern "C" uint64_t fg_stash_bytes(uint32_t blocks);
 extern "C" int fg_launch_rfc3164(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
                                  const fg::r3164::Cfg* cfg, uint32_t tile_cap, hipStream_t stream, uint32_t strip,
@@ -62,12 +62,12 @@ extern "C" int fg_launch_frame_slice(const uint8_t* d_bytes, uint64_t nbytes, ui
                                      hipStream_t stream, const uint8_t* src, int classic);
 extern "C" int fg_launch_ltsv(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
                               const fg::LtsvDevCfg* cfg, uint64_t avg_len, hipStream_t stream, uint64_t* stash,
-                              uint32_t stash_blocks, uint32_t strip, const uint8_t* line_bad, const fg_launch_opts* lo);
+                              uint32_t stash_blocks, uint32_t strip, const uint8_t* line_bad, const fg_launch_opts* lo, fg::TicketSlot* tk);
 extern "C" int fg_launch_gelf_general(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t, hipStream_t stream,
                                       uint32_t strip, const uint8_t* line_bad);
 extern "C" int fg_launch_gelf(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
                               uint64_t avg_len, hipStream_t stream, uint64_t* stash, uint32_t stash_blocks, uint32_t strip,
-                              const uint8_t* line_bad, const fg_launch_opts* lo);
+                              const uint8_t* line_bad, const fg_launch_opts* lo, fg::TicketSlot* tk);
 
 extern "C" int fg_launch_poke64(const uint64_t* d_src, uint64_t* dst_devview, hipStream_t stream);
 extern "C" int fg_launch_merge_device(const fg_tables* parts, uint32_t g, const uint64_t* const* d_index, const fg_tables* out, uint8_t* d_src_part,
@@ -99,6 +99,9 @@ struct fg_ctx {
     uint64_t* d_stash2 = nullptr;  // the second lane's (fg_transcode_batch)
     uint32_t stash_blocks = 0;
     uint32_t* d_pending = nullptr;  // ring of kPendingRing hand-over words (DevTables::pending), zeroed once
+    uint32_t* d_ticket = nullptr;   // ring of ticket counters, one per decode launch (fg::TicketSlot); zeroed once
+    std::vector<uint32_t> h_ticket; // ... what each word holds once the launches issued so far have run
+    uint32_t ticket_seq = 0;        // ... the next launch's slot
     uint32_t epoch = 0;             // launch counter of this ctx
     bool defer_general = false;     // a sliced host path: GELF's exact form runs once, behind the last slice (fg_finish_deferred_general)
     uint32_t batch_epoch = 0;       // ... and the slices share one hand-over word: the epoch of the batch's first GELF launch

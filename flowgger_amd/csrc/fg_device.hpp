@@ -64,34 +64,48 @@ struct LdsReader {
     }
 };
 struct GlobalReader {
+    // Round 5: the reader keeps the ALIGNED 16 bytes around its position (one dwordx4 load) instead of one dword: a byte-wise walk
+    // through global memory -- a line longer than the tile, a structured-data block that runs past its staged head -- pays one trip
+    // to memory per 16 bytes, not per 4.  (That walk is the floor of a small batch's kernel time: a 1 KiB walk by ONE lane was ~0.3 ms
+    // at ~1 us per dependent load, whatever the other 130 000 lanes of the grid did.)  The packed buffer is 16-byte aligned and
+    // readable up to its size rounded up to 16 (include/fg_hip.h), so the aligned chunk around any byte of a line is readable.
     const uint32_t* words;  // packed buffer viewed as dwords (base is 16-byte aligned)
     uint64_t base;          // byte offset of the line inside the packed buffer
-    uint64_t cur_idx = ~0ull;
-    uint32_t cur = 0;
+    uint64_t cur_idx = ~0ull;  // index of the 16-byte chunk held
+    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
     __device__ __forceinline__ GlobalReader(const uint32_t* w, uint64_t b) : words(w), base(b) {}
-    __device__ __forceinline__ uint32_t byte(uint32_t i) {
-        uint64_t a = base + i;
-        uint64_t w = a >> 2;
-        if (w != cur_idx) {
-            cur = words[w];
-            cur_idx = w;
-        }
-        return __builtin_amdgcn_ubfe(cur, ((uint32_t)a & 3u) * 8u, 8u);
+    __device__ __forceinline__ void fill(uint64_t chunk) {
+        // (four dwords of one aligned chunk: the compiler makes it one global_load_dwordx4)
+        const uint32_t* q = static_cast<const uint32_t*>(__builtin_assume_aligned(words + chunk * 4u, 16));
+        c0 = q[0];
+        c1 = q[1];
+        c2 = q[2];
+        c3 = q[3];
+        cur_idx = chunk;
     }
-    // 4 bytes starting at byte i; the dword behind is only touched when the nb wanted bytes reach into it (the
+    // dword k (0..3) of the chunk held -- by selects: a dynamically indexed register array would live in scratch memory
+    __device__ __forceinline__ uint32_t dw(uint32_t k) const { return k == 0u ? c0 : k == 1u ? c1 : k == 2u ? c2 : c3; }
+    __device__ __forceinline__ uint32_t byte(uint32_t i) {
+        const uint64_t a = base + i;
+        if ((a >> 4) != cur_idx) fill(a >> 4);
+        return __builtin_amdgcn_ubfe(dw(((uint32_t)a >> 2) & 3u), ((uint32_t)a & 3u) * 8u, 8u);
+    }
+    // 4 bytes starting at byte i; the chunk behind is only touched when the nb wanted bytes reach into it (the
     // packed buffer is readable up to nbytes rounded up to 16, not beyond)
     __device__ __forceinline__ uint32_t load4(uint32_t i, uint32_t nb) {
         const uint64_t a = base + i;
-        const uint64_t w = a >> 2;
-        if (w != cur_idx) {
-            cur = words[w];
-            cur_idx = w;
-        }
-        const uint32_t lo = cur, sh = (uint32_t)a & 3u;
+        if ((a >> 4) != cur_idx) fill(a >> 4);
+        const uint32_t k = ((uint32_t)a >> 2) & 3u, sh = (uint32_t)a & 3u;
+        const uint32_t lo = dw(k);
         if (sh + nb <= 4u) return lo >> (8u * sh);
-        cur = words[w + 1u];
-        cur_idx = w + 1u;
-        return __builtin_amdgcn_alignbyte(cur, lo, sh);
+        uint32_t hi;
+        if (k < 3u) {
+            hi = dw(k + 1u);
+        } else {
+            fill((a >> 4) + 1u);
+            hi = c0;
+        }
+        return __builtin_amdgcn_alignbyte(hi, lo, sh);
     }
     // 16 wanted bytes starting at byte i (see LdsReader::load16); never reads a dword without wanted bytes
     __device__ __forceinline__ void load16(uint32_t i, uint32_t* q) {

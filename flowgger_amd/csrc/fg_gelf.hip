@@ -725,7 +725,7 @@ namespace {
 // the fast-form kernel with a register window of NB KiB (the bytes of the NEXT group, prefetched while this one is decoded)
 template <int NB>
 int launch_gelf_fast(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t, uint64_t avg_len,
-                     hipStream_t stream, uint32_t max_lines, fg::FrameArgs fr, const fg_launch_opts& lo) {
+                     hipStream_t stream, uint32_t max_lines, fg::FrameArgs fr, const fg_launch_opts& lo, fg::TicketSlot* tk) {
     fg::LaunchPlan p;
     if (fg::plan_launch(fg::k_gelf<NB, false>, n, avg_len, 0u, 40960u, 0u, &p, lo, max_lines, fg::GelfFormat::kClasses, fg::gelf_extra_lds))
         return -1;
@@ -747,10 +747,12 @@ int launch_gelf_fast(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t
                 if (fg::plan_launch(fg::k_gelf<NB, false, 5, 3072u, 8u>, n, avg_len, 0u, 40960u, 0u, &p, lo3, max_lines,
                                     fg::GelfFormat::kClasses, fg::gelf_extra_lds, nullptr, 0u, 128u) || p.tile != 3072u || p.L != 8u)
                     return -1;
+                fg::take_tickets(&fr, tk, p);
                 hipLaunchKernelGGL((fg::k_gelf<NB, false, 5, 3072u, 8u>), dim3(p.blocks), block, p.lds, stream, d_bytes, d_offsets, n, *t,
                                    p.tile, p.L, p.chunk, (unsigned long long*)nullptr, (uint64_t*)nullptr, fr);
                 return 0;
             }
+            fg::take_tickets(&fr, tk, p);
             hipLaunchKernelGGL((fg::k_gelf<NB, false, 4, 4096u, 8u>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L,
                                p.chunk, (unsigned long long*)nullptr, (uint64_t*)nullptr, fr);
             return 0;
@@ -766,6 +768,7 @@ int launch_gelf_fast(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t
         return 0;
     }
 #endif
+    fg::take_tickets(&fr, tk, p);
     hipLaunchKernelGGL((fg::k_gelf<NB, false>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L, p.chunk,
                        (unsigned long long*)nullptr, (uint64_t*)nullptr, fr);
     return 0;
@@ -776,7 +779,7 @@ extern "C" int fg_launch_gelf_general(const uint8_t* d_bytes, const uint64_t* d_
                                       uint32_t strip, const uint8_t* line_bad);
 extern "C" int fg_launch_gelf(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
                               uint64_t avg_len, hipStream_t stream, uint64_t* stash, uint32_t stash_blocks, uint32_t strip,
-                              const uint8_t* line_bad, const fg_launch_opts* lop) {
+                              const uint8_t* line_bad, const fg_launch_opts* lop, fg::TicketSlot* tk) {
     const fg_launch_opts& lo = *lop;
     (void)stash;
     (void)stash_blocks;
@@ -808,11 +811,11 @@ extern "C" int fg_launch_gelf(const uint8_t* d_bytes, const uint64_t* d_offsets,
     const fg::FrameArgs fr{strip, line_bad};
     const dim3 block(fg::kWave);
     int rc;
-    if (want <= 2) rc = launch_gelf_fast<2>(d_bytes, d_offsets, n, t, avg_len, stream, p.L, fr, lo);
-    else if (want == 3) rc = launch_gelf_fast<3>(d_bytes, d_offsets, n, t, avg_len, stream, p.L, fr, lo);
-    else if (want == 4) rc = launch_gelf_fast<4>(d_bytes, d_offsets, n, t, avg_len, stream, p.L, fr, lo);
-    else if (want == 5) rc = launch_gelf_fast<5>(d_bytes, d_offsets, n, t, avg_len, stream, p.L, fr, lo);
-    else rc = launch_gelf_fast<6>(d_bytes, d_offsets, n, t, avg_len, stream, p.L, fr, lo);
+    if (want <= 2) rc = launch_gelf_fast<2>(d_bytes, d_offsets, n, t, avg_len, stream, p.L, fr, lo, tk);
+    else if (want == 3) rc = launch_gelf_fast<3>(d_bytes, d_offsets, n, t, avg_len, stream, p.L, fr, lo, tk);
+    else if (want == 4) rc = launch_gelf_fast<4>(d_bytes, d_offsets, n, t, avg_len, stream, p.L, fr, lo, tk);
+    else if (want == 5) rc = launch_gelf_fast<5>(d_bytes, d_offsets, n, t, avg_len, stream, p.L, fr, lo, tk);
+    else rc = launch_gelf_fast<6>(d_bytes, d_offsets, n, t, avg_len, stream, p.L, fr, lo, tk);
     if (rc) return rc;
     if (hipGetLastError() != hipSuccess) return -1;
     // pending lines (a frame flagged as invalid UTF-8 never is: the pipeline has overwritten its status) -- unless the caller runs the

@@ -865,7 +865,7 @@ __global__ __launch_bounds__(kWave, 2) void k_ltsv(const uint8_t* __restrict__ b
 
 extern "C" int fg_launch_ltsv(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
                               const fg::LtsvDevCfg* cfg, uint64_t avg_len, hipStream_t stream, uint64_t* stash,
-                              uint32_t stash_blocks, uint32_t strip, const uint8_t* line_bad, const fg_launch_opts* lo) {
+                              uint32_t stash_blocks, uint32_t strip, const uint8_t* line_bad, const fg_launch_opts* lo, fg::TicketSlot* tk) {
     if (n == 0) return 0;
     fg::LaunchPlan p;
     // long lines: only the head of every line is staged, the rest is scanned for a TAB (LtsvFormatT<true>)
@@ -879,7 +879,8 @@ extern "C" int fg_launch_ltsv(const uint8_t* d_bytes, const uint64_t* d_offsets,
         return -1;
     if (stash_blocks == 0) stash = nullptr;
     dim3 grid(p.blocks), block(fg::kWave);
-    const fg::FrameArgs fr{strip, line_bad};
+    fg::FrameArgs fr{strip, line_bad};
+    fg::take_tickets(&fr, tk, p);
 #if defined(FG_PROF_BUILD)
     if (fg::prof_requested()) {
         fg::ProfRun pr;

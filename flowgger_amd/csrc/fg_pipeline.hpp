@@ -292,7 +292,12 @@ __device__ __forceinline__ bool stash_to_table(const GroupCtx& c, const DevTable
 struct FrameArgs {
     uint32_t strip;           // FG_FRAME_NONE / _LINE ("\n", then one "\r") / _NUL ("\0")
     const uint8_t* line_bad;  // [n] 1 = not valid UTF-8 (or null)
+    // Dynamic chunk dispatch (round 5): the launch's ticket counter (one word of a ctx-owned ring) and the value it holds when the
+    // launch starts; null = chunks are dealt out round-robin (the form of rounds 3-4, kept for A/B: FG_LO_STATIC_CHUNKS).
+    uint32_t* ticket = nullptr;
+    uint32_t ticket_base = 0;
 };
+// (host side of the ticket: fg::TicketSlot, fg_tables_view.hpp)
 
 // The input is read ONCE: its loads carry the non-temporal hint (aux bit 1 = nt on gfx950) so that the stream does not push the
 // wave's stash, scratch and table lines out of the XCD's L2 between two uses.
@@ -359,9 +364,24 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
     // configuration 10 %: DRAM pages and TLB entries want neighbours in time to be neighbours in memory.)  The last group of a
     // chunk may be short: 256 lines = 4 full groups of 64 short lines, a dozen or more groups of long ones (small batches get
     // smaller chunks, so that every wave of the grid has one).
+    // Round 5: only a wave's FIRST chunk is its block index; every further one is DRAWN from the launch's ticket counter (one atomic
+    // per chunk, by lane 0, requested one group before the chunk in hand runs out so that its round trip hides behind that group).
+    // Tickets are handed out in order, so the sweep stays front to back -- and a wave that meets a slow line (a walk through global
+    // memory), a slow XCD or a chunk of long lines simply draws fewer tickets instead of keeping the whole grid waiting at the end:
+    // what a batch of 10^5 .. 10^6 lines, one or two chunks per wave, needs.  Every wave draws until its first
+    // ticket beyond the last chunk, so a launch advances the counter by EXACTLY the number of chunks: the host keeps the count and
+    // hands the next launch of the slot its base -- no reset, no memset between launches.
+    const bool dyn = fr.ticket != nullptr;  // wave-uniform
+    uint32_t tk_raw = 0;      // the ticket drawn ahead (lane 0's return value; read when the chunk in hand runs out)
+    bool tk_pending = false;  // wave-uniform
+    auto draw_ticket = [&]() {
+        if (lane == 0u) tk_raw = __hip_atomic_fetch_add(fr.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tk_pending = true;
+    };
     uint64_t chunk = blockIdx.x;
     uint64_t hi_line = (chunk + 1u) * kChunkLines < n ? (chunk + 1u) * kChunkLines : n;
     uint64_t p = chunk * kChunkLines;
+    if (dyn && kChunkLines <= 2u * L && p < n) draw_ticket();
 
     // the L offsets from line q on (clamped to the wave's range), as o0 = start / o1 = end of lane's line
     auto load_offsets = [&](uint64_t q, uint64_t* o0, uint64_t* o1) {
@@ -477,9 +497,20 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
         // needed only after stage A, when the next window is issued)
         uint64_t pn = p + nl;
         if (pn >= hi_line) {  // this chunk is done: on to the wave's next one
-            chunk += G;
+            if (dyn) {
+                if (!tk_pending) draw_ticket();  // (a chunk of one group: drawn and waited for here)
+                const uint32_t tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk_raw);
+                chunk = (uint64_t)(uint32_t)(tk - fr.ticket_base) + G;  // (beyond the last chunk: pn >= n, the wave is done)
+                tk_pending = false;
+                // (chunks of one or two groups -- a small batch: the successor's ticket right away, or its trip would be waited for)
+                if (kChunkLines <= 2u * L && chunk * kChunkLines < n) draw_ticket();
+            } else {
+                chunk += G;
+            }
             pn = chunk * kChunkLines;
             hi_line = (chunk + 1u) * kChunkLines < n ? (chunk + 1u) * kChunkLines : n;
+        } else if (dyn && !tk_pending && pn + L >= hi_line) {
+            draw_ticket();  // the group after this one ends the chunk: its successor's ticket is under way
         }
         const bool more = pn < n;  // wave-uniform
         uint64_t no0 = 0, no1 = 0;
@@ -698,9 +729,19 @@ struct LaunchPlan {
     uint32_t tile = 0;    // LDS tile bytes (multiple of 1024)
     uint32_t lds = 0;     // dynamic LDS bytes per workgroup = tile + 64 + bitmap + extra
     uint64_t groups = 0;  // an estimate (the waves cut their ranges into groups themselves)
-    uint64_t chunk = 256; // lines a wave takes at a time, dealt out round-robin
+    uint64_t chunk = 256; // lines a wave takes at a time (the first by block index, the rest by ticket)
+    uint64_t chunks = 0;  // ceil(n / chunk) >= blocks
     uint32_t blocks = 0;  // persistent grid
 };
+
+// The launch's ticket counter into the kernel's arguments; the host's copy of the counter moves on by what the launch will draw
+// (every wave draws until its first ticket beyond the last chunk: chunks - blocks good ones + blocks bad ones = chunks).
+inline void take_tickets(FrameArgs* fr, TicketSlot* tk, const LaunchPlan& p) {
+    if (!tk || !tk->d_word || !tk->h_val || p.chunks + p.blocks >= 0xFFFFFFFFull || p.blocks > p.chunks) return;  // (static round-robin)
+    fr->ticket = tk->d_word;
+    fr->ticket_base = *tk->h_val;
+    *tk->h_val += (uint32_t)p.chunks;
+}
 
 // Lines per group L and the LDS tile: the largest power of two L <= 64 whose average group
 // (+6.25 % + 256 B) fits the register prefetch window, so that a whole group is prefetched.
@@ -763,12 +804,33 @@ inline int plan_launch(K kernel, uint64_t n, uint64_t avg_len, uint32_t extra_ld
     // over the grid
     // (default_chunk: a format's own choice -- the pair-parallel structured-data kernel: 1466 vs 1394 M lines/s at 1024 vs 512 lines)
     const uint64_t full = default_chunk ? default_chunk : (avg_len ? (uint64_t)p->tile / avg_len : p->L) >= p->L ? 256u : 512u;
+    // lines an average group holds (groups are cut by bytes): the unit chunks are made of
+    uint64_t g = avg_len ? ((uint64_t)p->tile * 16u) / (avg_len * 17u) : p->L;
+    g = g < 1u ? 1u : g > p->L ? p->L : g;
+    const bool dynamic = !(lo.flags & FG_LO_STATIC_CHUNKS);
     uint64_t chunk;
-    if (lo.chunk_lines >= p->L && lo.chunk_lines <= 65536u) {
+    if (lo.chunk_lines >= (dynamic ? 1u : p->L) && lo.chunk_lines <= 65536u) {
         chunk = lo.chunk_lines;  // (tuning: taken as it is, unless the batch is too small for two of them per wave)
         if (n < blocks * 2u * chunk) {
             chunk = (n + blocks - 1) / (blocks ? blocks : 1);
-            if (chunk < p->L) chunk = p->L;
+            if (chunk < (dynamic ? g : p->L)) chunk = dynamic ? g : p->L;
+        }
+    } else if (dynamic) {
+        // Chunks are DRAWN (persistent_loop's ticket): balance is the dispatch's business, the chunk only has to be small against a
+        // wave's share of the batch and a whole number of groups, because the group a chunk ends on is as short as it comes out and
+        // costs these latency-bound kernels what a full one does.  Large batch: `full` lines.  Small batch (what a framer hands over:
+        // 10^4 .. 10^6 lines): a quarter of the wave's share, in units of an average group less a sixteenth (so that a unit USUALLY is
+        // one group) -- down to ONE group per chunk.  (Rounds 3-4 never cut a chunk below 64 lines: 16 K structured-data lines, 21 to
+        // the group, ran as 256 waves of three groups each on a grid of 2048 -- 84 us where 30 would do, profiles/r05a_small.log.)
+        const uint64_t per_wave = (n + blocks - 1) / (blocks ? blocks : 1);
+        if (per_wave >= 4u * full) {
+            chunk = full;
+        } else {
+            const uint64_t unit = g >= p->L ? g : (g * 15u / 16u ? g * 15u / 16u : 1u);
+            uint64_t units = per_wave / 4u / unit;
+            if (units < 1u) units = 1u;
+            chunk = units * unit;
+            if (chunk > full) chunk = full;
         }
     } else {
         // The chunks are dealt out round-robin, so every wave should get the SAME number of them: k = the chunks per wave that keeps a
@@ -783,6 +845,7 @@ inline int plan_launch(K kernel, uint64_t n, uint64_t avg_len, uint32_t extra_ld
     const uint64_t chunks = (n + chunk - 1) / chunk;
     if (blocks > chunks) blocks = chunks;
     p->chunk = chunk;
+    p->chunks = chunks;
     p->blocks = (uint32_t)blocks;
     return 0;
 }

@@ -836,6 +836,7 @@ struct Rfc5424FormatT {
     }
     // ---- 3. the rare / heavy routes ------------------------------------------------------------
     bool redo = false;  // (HEAD) the head of the line was not enough: the whole line again, from global memory
+    bool coop = false;  // (HEAD) ... by the whole wave, once this group is done (the line fits the tile)
     if (valid) {
         if (!(route & R_GENERIC)) {
             if (r.status == E_OK) {
@@ -891,6 +892,19 @@ struct Rfc5424FormatT {
                 }
                 LdsReader rd(T.w, base);
                 parse_line_generic(rd, len, r, t);
+            }
+        }
+        if (HEAD && redo && (o1 - (o0 & ~15ull)) <= (uint64_t)c.tile_cap) {
+            // (round 5) the line fits the tile WHOLE: it is decoded again at the end of this group, by the whole wave, out of a
+            // restaged tile (coop_redo below) -- not by this one lane byte for byte through global memory
+            coop = true;
+            redo = false;
+            slo.handled = false;
+            r = Row();
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                r.off[k] = 0;
+                r.len[k] = FG_NONE;
             }
         }
         if (redo) {
@@ -976,6 +990,64 @@ struct Rfc5424FormatT {
     for (int k = 0; k < 6; ++k) o.span[k] = ok ? fg_span{r.off[k], r.len[k]} : fg_span{0, FG_NONE};
     o.first = first;
     o.count = r.n_ent;
+    if constexpr (HEAD) {
+        // ---- lines whose head was not enough (structured data that runs past it, a bracketed tail behind it ...): one in five hundred
+        // of the 64 B .. 8 KiB corpus.  Rounds 3-4 sent the lane through the byte-wise parser over global memory, a dword per trip:
+        // ~0.65 ms for a 1 KiB structured-data block while the other 63 lanes waited -- THE floor of a small batch's kernel time (64 K
+        // lines: 781 us with those lines, 124 us without, profiles/r05a_small*.log) and a third of a large one's.  Now the wave takes
+        // such a line as a group of its own: the WHOLE line is staged (coalesced, as stage A would) and decoded by the instantiation
+        // for whole lines -- pair-parallel walk included -- and the row goes back to the lane that owns the line.
+        unsigned long long todo = __ballot(coop);
+        while (todo) {  // wave-uniform, rare
+            const int src = (int)__builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            auto rl64 = [&](uint64_t x) -> uint64_t {
+                return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, src) |
+                       ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), src) << 32);
+            };
+            const uint64_t ro0 = rl64(o0), ro1 = rl64(o1), rli = rl64(c.li);
+            const uint64_t ra0 = ro0 & ~15ull;
+            const uint32_t rspan = (uint32_t)((ro1 - ra0 + 15ull) & ~15ull);  // <= tile_cap (a multiple of 1024)
+            __syncthreads();  // every lane is done with the tile
+            {
+                __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(bytes + ra0), (short)0, (int)rspan, 0x00020000);
+                uint4* dst = reinterpret_cast<uint4*>(const_cast<uint8_t*>(smem));
+                const uint32_t nrow = (rspan + 1023u) >> 10;
+                for (uint32_t r0 = 0; r0 < nrow; r0 += 4u) {  // (rows past the span fetch nothing and store zeros, as in stage A)
+                    u32x4 w[4];
+#pragma unroll
+                    for (uint32_t j = 0; j < 4u; ++j) w[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(lane * 16u + (r0 + j) * 1024u), 0, FG_STREAM_AUX);
+#pragma unroll
+                    for (uint32_t j = 0; j < 4u; ++j)
+                        if (r0 + j < nrow) dst[(r0 + j) * kWave + lane] = make_uint4(w[j][0], w[j][1], w[j][2], w[j][3]);
+                }
+            }
+            __syncthreads();
+            GroupCtx c2{bytes, smem, bm16, ro0, ro1, ra0, rspan, lane == 0u, rli, c.stash, ablate, c.ent_state, nullptr};
+            c2.tile_cap = c.tile_cap;
+            Rfc5424FormatT<false, SDX, false> whole;
+            const RowOut w = whole.decode(c2, t);
+            // lane 0's row -> the lane that owns the line
+            auto b32 = [&](uint32_t x) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); };
+            const uint32_t g_meta = b32(w.meta), g_first = b32(w.first), g_count = b32(w.count);
+            const uint64_t tsb = (uint64_t)__builtin_bit_cast(unsigned long long, w.ts);
+            const uint32_t g_ts0 = b32((uint32_t)tsb), g_ts1 = b32((uint32_t)(tsb >> 32));
+            uint32_t g_off[6], g_len[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                g_off[k] = b32(w.span[k].off);
+                g_len[k] = b32(w.span[k].len);
+            }
+            if ((int)lane == src) {
+                o.meta = g_meta;
+                o.ts = __builtin_bit_cast(double, (unsigned long long)((uint64_t)g_ts0 | ((uint64_t)g_ts1 << 32)));
+#pragma unroll
+                for (int k = 0; k < 6; ++k) o.span[k] = fg_span{g_off[k], g_len[k]};
+                o.first = g_first;
+                o.count = g_count;
+            }
+        }
+    }
     tick(9);
     if (PROF && pacc && lane == 0)
         for (int k = 0; k < 10; ++k) pacc[k] += (unsigned long long)pc[k];  // (the wave's own LDS words: a hot global atomic per phase WOULD BE the profile)
@@ -1024,7 +1096,7 @@ extern "C" uint64_t fg_stash_bytes(uint32_t blocks) {
 // bytes (or NULL: SD lines are then parsed twice); the persistent grid is capped at stash_blocks.
 extern "C" int fg_launch_rfc5424(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
                                  uint64_t avg_len, hipStream_t stream, uint64_t* stash, uint32_t stash_blocks, uint32_t strip,
-                                 const uint8_t* line_bad, const fg_launch_opts* lo) {
+                                 const uint8_t* line_bad, const fg_launch_opts* lo, fg::TicketSlot* tk) {
     if (n == 0) return 0;
     fg::LaunchPlan p;
     // long lines: only the head of every line is staged (persistent_loop<..., HEAD>): the message is never looked into
@@ -1048,7 +1120,8 @@ extern "C" int fg_launch_rfc5424(const uint8_t* d_bytes, const uint64_t* d_offse
     if (prc) return -1;
     if (stash_blocks == 0) stash = nullptr;
     dim3 grid(p.blocks), block(fg::kWave);
-    const fg::FrameArgs fr{strip, line_bad};
+    fg::FrameArgs fr{strip, line_bad};
+    fg::take_tickets(&fr, tk, p);
     unsigned long long* const no_prof = nullptr;
 #define FG_LAUNCH_5424(PROF_, HEAD_, SDX_, prof_ptr)                                                                                       \
     hipLaunchKernelGGL((fg::k_rfc5424<fg::kWindowKiB, PROF_, HEAD_, SDX_>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L, \

@@ -28,6 +28,13 @@ struct DevTables {
     uint32_t* pending;
     uint32_t epoch;
 };
+// Dynamic chunk dispatch of the streaming decoders (fg_pipeline.hpp persistent_loop): the ticket counter of ONE launch -- a word of
+// a ctx-owned ring in device memory -- and the host's copy of what it holds; the launcher hands the kernel the word + that value and
+// adds the tickets the launch will draw (exactly its number of chunks), so the word is never reset between launches.
+struct TicketSlot {
+    uint32_t* d_word;
+    uint32_t* h_val;
+};
 // A table pointer that did not come straight out of the kernel arguments (a kernel that keeps its DevTables in LDS, k_gelf) is a
 // generic pointer to the compiler: stores through it would be flat_ instructions, which also count against the LDS wait counter.
 // gstore() says what every table pointer is -- global memory.  (No effect where the compiler knows already.)

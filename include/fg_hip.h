@@ -206,6 +206,8 @@ enum {
                                       itself instead of hipMemcpy uploads (measured slower on MI355X / ROCm 7.2: off by default) */
     FG_LO_FRAME_CLASSIC = 256,     /* framing: the three-kernel form (masks to HBM, one-workgroup scan, emit) instead of the one-pass chained
                                       scan -- which falls back to it by itself should its look-back ever give up (A/B, tests) */
+    FG_LO_STATIC_CHUNKS = 512,     /* decode kernels: deal the chunks of a batch out round-robin over the waves (rounds 3-4) instead of by
+                                      ticket -- every wave draws its next chunk from a per-launch counter when it needs one (A/B, tests) */
     FG_LO_RESERVED = 0x40000000    /* the library's own (fg_set_launch_opts clears it) */
 };
 
@@ -469,6 +471,13 @@ int64_t fg_ordered_merge(uint32_t g, const uint64_t* m, const uint64_t* const* i
  * enables event recording around every launch. */
 int fg_set_timing(fg_ctx* ctx, int enabled);
 int fg_last_kernel_ms(fg_ctx* ctx, float* ms);
+
+/* Self-check of the dynamic chunk dispatch (round 5): the streaming decode kernels draw their chunks from a per-launch ticket counter
+ * -- a word of a ctx-owned ring in device memory that is never reset: the host keeps what every word holds once the launches issued so
+ * far have run (a launch adds exactly its number of chunks).  waits for the device, reads the ring back
+ * and returns the number of words that differ from the host's books (0 = consistent; negative = an FG_ERR_* code).  A diagnostic
+ * for tests and for a shim's debug builds; the decode path never calls it. */
+int fg_ticket_ring_check(fg_ctx* ctx);
 
 #ifdef __cplusplus
 }

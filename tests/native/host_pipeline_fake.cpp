@@ -98,14 +98,14 @@ extern "C" int fg_launch_calib(int mode, const uint8_t* src, uint8_t* dst, uint6
     return 0;
 }
 extern "C" int fg_launch_rfc5424(const uint8_t* b, const uint64_t* o, uint64_t n, const fg::DevTables* t, uint64_t, hipStream_t, uint64_t*, uint32_t,
-                                 uint32_t strip, const uint8_t* bad, const fg_launch_opts*) { return fake_decode(b, o, n, t, strip, bad); }
+                                 uint32_t strip, const uint8_t* bad, const fg_launch_opts*, fg::TicketSlot*) { return fake_decode(b, o, n, t, strip, bad); }
 extern "C" int fg_launch_ltsv(const uint8_t* b, const uint64_t* o, uint64_t n, const fg::DevTables* t, const fg::LtsvDevCfg*, uint64_t, hipStream_t,
-                              uint64_t*, uint32_t, uint32_t strip, const uint8_t* bad, const fg_launch_opts*) { return fake_decode(b, o, n, t, strip, bad); }
+                              uint64_t*, uint32_t, uint32_t strip, const uint8_t* bad, const fg_launch_opts*, fg::TicketSlot*) { return fake_decode(b, o, n, t, strip, bad); }
 extern "C" int fg_launch_gelf_general(const uint8_t*, const uint64_t*, uint64_t, const fg::DevTables*, hipStream_t, uint32_t, const uint8_t*) {
     return 0;  // (the fake fast form leaves nothing pending)
 }
 extern "C" int fg_launch_gelf(const uint8_t* b, const uint64_t* o, uint64_t n, const fg::DevTables* t, uint64_t, hipStream_t, uint64_t*, uint32_t,
-                              uint32_t strip, const uint8_t* bad, const fg_launch_opts*) { return fake_decode(b, o, n, t, strip, bad); }
+                              uint32_t strip, const uint8_t* bad, const fg_launch_opts*, fg::TicketSlot*) { return fake_decode(b, o, n, t, strip, bad); }
 extern "C" int fg_launch_rfc3164(const uint8_t* b, const uint64_t* o, uint64_t n, const fg::DevTables* t, const fg::r3164::Cfg*, uint32_t, hipStream_t,
                                  uint32_t strip, const uint8_t* bad) { return fake_decode(b, o, n, t, strip, bad); }
 // ---- the fake encoder: an Ok row's message = its line + one '#' per entry + '\n' (so rows AND entry counts of the right slice matter);

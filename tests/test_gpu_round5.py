@@ -1,0 +1,160 @@
+"""-m gpu, round 5: the dynamic chunk dispatch (tickets), small batches, and the wave-cooperative second look at lines whose head was
+not enough.
+
+* every format at the batch sizes a framer really hands over (1 .. 70 000 lines), under both dispatch forms and chunk sizes down
+  to ONE line, several launches on one ctx (the ticket counter is never reset: the host's bookkeeping must agree with the device);
+* RFC5424 lines whose structured data runs past the 1 KiB head (valid and broken behind the head), lines longer than the tile;
+* chunk boundaries inside long lines are impossible by construction (chunks are line ranges) -- long-tail corpora at tiny chunk
+  sizes exercise the ragged last group of every chunk instead.
+The oracle is the checker (tests/oracle_binding.py); the product path is the C ABI.
+"""
+import numpy as np
+import pytest
+
+from flowgger_amd import GelfDecoder, LTSVDecoder, RFC3164Decoder, RFC5424Decoder, synth
+from flowgger_amd import _lib as L
+from gpu_util import assert_same, device_path
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    import oracle_binding
+
+    return oracle_binding.Oracle()
+
+
+def check_device(dec, oracle, lines, config=None):
+    data, offsets = synth.pack(lines)
+    oblob, ooffs = oracle.decode_batch(dec.fmt, data, offsets, config)
+    tables, _, _ = device_path(dec, data, offsets)
+    blob, offs = tables.to_host().serialize(dec.fmt, data, offsets, cfg=dec._cfg)
+    assert_same(blob, offs, oblob, ooffs, lines)
+
+
+def ticket_ring_ok(dec):
+    """the device's ticket counters == what the host's bookkeeping says they hold (fg_ticket_ring_check: 0 = all equal)"""
+    return L.lib().fg_ticket_ring_check(dec._ctx)
+
+
+def corpora():
+    return {
+        "rfc5424": (lambda: RFC5424Decoder(), None, synth.rfc5424_lines(70_000, cfg=2)),
+        "rfc5424_sd": (lambda: RFC5424Decoder(), None, synth.rfc5424_lines(20_000, cfg=4, sd=True)),
+        "rfc5424_long": (lambda: RFC5424Decoder(), None, synth.rfc5424_lines(6_000, cfg=5, sd=True, long_tail=True)),
+        "ltsv": (lambda: LTSVDecoder(synth.LTSV_CONFIG), synth.LTSV_CONFIG, synth.ltsv_lines(40_000)),
+        "ltsv_long": (lambda: LTSVDecoder(synth.LTSV_CONFIG), synth.LTSV_CONFIG, synth.ltsv_lines(6_000, long_tail=True)),
+        "gelf": (lambda: GelfDecoder(), None, synth.gelf_lines(30_000)),
+    }
+
+
+@pytest.mark.parametrize("name", ["rfc5424", "rfc5424_sd", "rfc5424_long", "ltsv", "ltsv_long", "gelf"])
+def test_small_batches_under_both_dispatch_forms(oracle, name):
+    make, cfg, lines = corpora()[name]
+    sizes = [1, 2, 63, 64, 65, 127, 1000, 5000, len(lines)]
+    for opts in (dict(), dict(static_chunks=True), dict(chunk_lines=1), dict(chunk_lines=3, waves_per_cu=1),
+                 dict(chunk_lines=100, waves_per_cu=2), dict(chunk_lines=64, static_chunks=True)):
+        dec = make()
+        dec.set_launch_opts(**opts)
+        for n in sizes:
+            if n > len(lines):
+                continue
+            # (a window that moves through the corpus: the invalid lines and the long ones land in different lanes and chunks)
+            start = (n * 7) % max(1, len(lines) - n + 1)
+            check_device(dec, oracle, lines[start:start + n], cfg)
+        # the same ctx again, sizes interleaved: every launch draws from its own word of the ring, never reset
+        for n in (5000, 1, 65, 1000):
+            if n <= len(lines):
+                check_device(dec, oracle, lines[:n], cfg)
+        assert ticket_ring_ok(dec) == 0, f"{name} {opts}: ticket counters and host bookkeeping disagree"
+        dec.close()
+
+
+def test_ticket_ring_wraps(oracle):
+    """more launches on one ctx than the ring has words: the slots are reused with their counters where earlier launches left them"""
+    dec = RFC5424Decoder()
+    lines = synth.rfc5424_lines(3000, cfg=2)
+    data, offsets = synth.pack(lines)
+    oblob, ooffs = oracle.decode_batch(dec.fmt, data, offsets, None)
+    import torch
+
+    from flowgger_amd.tables import DeviceTables
+
+    dev = torch.device("cuda", dec.device)
+    d_bytes = torch.cat([torch.from_numpy(data[: int(offsets[-1])]).to(dev), torch.zeros(32, dtype=torch.uint8, device=dev)])
+    d_offsets = torch.from_numpy(offsets.astype(np.int64)).to(dev)
+    tables = DeviceTables(len(lines), 4096, dev)
+    for k in range(2100):
+        dec.decode_device(d_bytes, d_offsets, tables)
+    torch.cuda.synchronize(dev)
+    blob, offs = tables.to_host().serialize(dec.fmt, data, offsets, cfg=dec._cfg)
+    assert_same(blob, offs, oblob, ooffs, lines)
+    assert ticket_ring_ok(dec) == 0
+
+
+def long_sd_lines(rng, n=400):
+    """RFC5424 lines whose structured data ends well behind byte 1024 (the staged head), with long messages behind it: valid ones,
+    and ones that are broken BEHIND the head (so that the verdict needs bytes the head does not hold)."""
+    pool = synth._text_pool(rng, 1 << 16)
+    out = []
+    for i in range(n):
+        npairs = int(rng.integers(28, 70))
+        pairs = []
+        for k in range(npairs):
+            o = int(rng.integers(0, len(pool) - 64))
+            val = pool[o:o + int(rng.integers(1, 48))].replace('"', "'").replace("\\", "/").replace("]", ")")
+            if rng.random() < 0.1:
+                val += '\\"x\\\\y\\]z'
+            pairs.append(f'key{k}_{"abcdefgh"[k % 8]}="{val}"')
+        sd = "[sd@1 " + " ".join(pairs) + "]"
+        if rng.random() < 0.4:
+            sd += "[e2@9 a=\"b\" c=\"d\"]"
+        kind = i % 8
+        if kind == 5:
+            sd = sd[:-1]                      # the closing bracket is missing: "Missing ] after structured data"
+        elif kind == 6:
+            cut = sd.rfind(' key')
+            sd = sd[:cut] + " =" + sd[cut + 1:]  # a format error far behind the head
+        elif kind == 7:
+            sd = sd + "x"                      # garbage behind the last ']': "Malformated RFC5424 message"
+        msg_len = int(np.exp(rng.uniform(np.log(8.0), np.log(9000.0))))
+        o = int(rng.integers(0, len(pool) - 9100))
+        tail = (" " + pool[o:o + msg_len]) if kind != 4 else ""  # kind 4: no message behind the structured data
+        out.append(f"<{int(rng.integers(0, 192))}>1 2021-03-04T05:06:07.{int(rng.integers(0, 999999)):06d}Z host{i} app {i} ID{i} {sd}{tail}".encode())
+    return out
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(force_head=True), dict(force_head=True, tile_cap=6144), dict(force_head=True, sd_walk=True),
+                                  dict(force_head=True, chunk_lines=1), dict(no_head=True)])
+def test_structured_data_that_runs_past_the_staged_head(oracle, opts):
+    rng = np.random.default_rng(0x5424_55)
+    special = long_sd_lines(rng)
+    # among ordinary long-tail lines, so that a group holds both kinds
+    filler = synth.rfc5424_lines(4000, cfg=5, sd=True, long_tail=True)
+    lines = []
+    for i, ln in enumerate(filler):
+        lines.append(ln)
+        if i % 10 == 3 and special:
+            lines.append(special.pop())
+    lines.extend(special)
+    # lines longer than any tile (the byte-wise walk through global memory stays the last resort)
+    lines.append(lines[5][:200] + b"x" * 70_000)
+    lines.append(long_sd_lines(rng, 1)[0] + b" " + b"y" * 50_000)
+    dec = RFC5424Decoder()
+    dec.set_launch_opts(**opts)
+    check_device(dec, oracle, lines)
+    # a batch of ONLY such lines, and one line alone
+    sp = long_sd_lines(np.random.default_rng(7), 130)
+    check_device(dec, oracle, sp)
+    check_device(dec, oracle, sp[:1])
+
+
+def test_rfc3164_is_untouched_by_the_dispatch_flag(oracle):
+    """RFC3164 has its own launcher (no persistent loop): the flag must be a no-op there"""
+    from flowgger_amd import tzdb
+
+    oracle.set_rfc3164(2026, tzdb.default_table())
+    dec = RFC3164Decoder({"rfc3164": {"current_year": 2026}})
+    dec.set_launch_opts(static_chunks=True)
+    check_device(dec, oracle, synth.rfc3164_lines(3000))
