@@ -324,8 +324,17 @@ int fg_merge_tables_device(fg_ctx* ctx, const fg_tables* parts, uint32_t g, cons
                            uint8_t* d_src_part, void* stream) {
     if (!ctx || !parts || !d_index || !out || g == 0 || g > 8) return FG_ERR_ARG;
     uint64_t rows = 0, cap = 0, max_rows = 0, max_cap = 0;
+    // every column the merge kernels read or write must be there (a table without its entry counter was a device fault)
+    auto complete = [](const fg_tables& t, bool entries) {
+        const bool rows_ok = t.n == 0 || (t.meta && t.ts && t.hostname && t.appname && t.procid && t.msgid && t.msg && t.full_msg && t.ent_first &&
+                                          t.ent_count);
+        const bool ent_ok = !entries || (t.ent_name && t.ent_val && t.ent_type && t.ent_flags);
+        return rows_ok && ent_ok && t.ent_used != nullptr;
+    };
+    if (!complete(*out, out->ent_cap != 0)) return FG_ERR_ARG;
     for (uint32_t k = 0; k < g; ++k) {
         if (parts[k].n && !d_index[k]) return FG_ERR_ARG;
+        if (!complete(parts[k], parts[k].ent_cap != 0)) return FG_ERR_ARG;
         rows += parts[k].n;
         cap += parts[k].ent_cap;
         if (parts[k].n > max_rows) max_rows = parts[k].n;
@@ -359,7 +368,7 @@ int fg_frame_device(fg_ctx* ctx, fg_framing framing, const uint8_t* d_bytes, uin
     int rc;
     if ((rc = grow_dev(ctx, (void**)&ctx->d_frame, &ctx->d_frame_cap, fg_frame_scratch_bytes(nbytes))) != FG_OK) return rc;
     uint64_t total = 0;
-    for (int classic = (ctx->lo.flags & FG_LO_FRAME_CLASSIC) ? 1 : 0;; classic = 1) {
+    for (int classic = (ctx->lo.flags & FG_LO_FRAME_CLASSIC) ? 1 : (ctx->lo.flags & FG_LO_FRAME_SELFTEST_STALL) ? 2 : 0;; classic = 1) {
         uint64_t* d_total = nullptr;
         int lrc = fg_launch_frame(d_bytes, nbytes, framing == FG_FRAME_LINE ? 0x0Au : 0x00u, ctx->d_frame, d_offsets, d_bad_utf8,
                                   cap_frames, &d_total, s, classic);
@@ -370,7 +379,7 @@ int fg_frame_device(fg_ctx* ctx, fg_framing framing, const uint8_t* d_bytes, uin
         // frames = delimiters (+1 when the stream does not end with one)
         FG_HIP(ctx, hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, s));
         FG_HIP(ctx, hipStreamSynchronize(s));
-        if (total != FG_FRAME_ABORTED || classic) break;  // (the one-pass scan gave up waiting on a tile: the three-kernel form)
+        if (total != FG_FRAME_ABORTED || classic == 1) break;  // (the one-pass scan gave up waiting on a tile: the three-kernel form)
     }
     if (total + 1 > cap_frames) {
         *n_frames = total + 1;

@@ -228,6 +228,7 @@ fg::DevTables to_dev(const fg_tables& t) {
     d.ent_used = (unsigned long long*)t.ent_used;
     d.pending = nullptr;
     d.epoch = 0;
+    d.alloc_chunk = 0;
     return d;
 }
 

@@ -211,10 +211,13 @@ __global__ __launch_bounds__(kWave) void k_frame_emit(const uint32_t* __restrict
 // desc[tile] = flag << 62 | value: flag 0 nothing yet, 1 the tile's own delimiter count (A), 2 the count of all tiles up to and
 // including this one (P).  Zeroed once per stream (fg_launch_frame / the first slice).
 constexpr uint64_t kDescA = 1ull << 62, kDescP = 2ull << 62, kDescVal = (1ull << 62) - 1ull;
-constexpr uint32_t kSpinLimit = 1u << 22;  // polls of ~100 cycles each: a third of a second
+// polls before a waiting tile gives up: a poll is an s_sleep(2) plus an agent-scope load that goes to L2, ~0.5-1 us, so 2^18 polls are
+// a fifth of a second -- against a look-back that normally resolves within a few polls.  (2^22 were SECONDS per waiting tile)
+constexpr uint32_t kSpinLimit = 1u << 18;
+constexpr uint32_t kWholeStream = 1u, kSelfTestStall = 2u;  // bits of the kernel's `whole` argument
 constexpr uint64_t kFrameAborted = ~0ull;  // what pref[blk1] holds when the chain gave up (the caller runs the classic kernels)
 
-// A workgroup of four waves takes a 64 KiB tile (a wave = one 16 KiB block of it, as in the classic scan); ONE descriptor per tile:
+// A workgroup of kTileWaves = eight waves takes a 128 KiB tile (a wave = one 16 KiB block of it, as in the classic scan); ONE descriptor per tile:
 // the chain moves at most 64 descriptors per look-back step (a trip to L2), so the tile must be large enough for that to outrun
 // the memory system -- with one wave per 16 KiB descriptor the scan ran at 2.9 TB/s, bound by exactly that (profiles/r04x_*).
 constexpr uint32_t kTileWaves = 8;
@@ -280,7 +283,10 @@ __global__ __launch_bounds__(kWave* kTileWaves) void k_frame_onepass(const uint8
         tile_count += c;
     }
     // the tile's own count, for the tiles behind it (the first tile of the stream knows its prefix)
-    if (threadIdx.x == 0) __hip_atomic_store(desc + tile, (tile == 0 ? kDescP : kDescA) | (uint64_t)tile_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (self-test, FG_LO_FRAME_SELFTEST_STALL: the second tile of the launch never publishes anything -- every tile behind it must give up
+    //  within the spin bound and the caller must fall back to the classic kernels)
+    const bool stall = (whole & kSelfTestStall) != 0u && blockIdx.x == 1u;
+    if (threadIdx.x == 0 && !stall) __hip_atomic_store(desc + tile, (tile == 0 ? kDescP : kDescA) | (uint64_t)tile_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // a lane now owns 16 consecutive chunks (256 bytes) of its wave's block: rank of its first delimiter inside the tile
     uint32_t w[16];
     {
@@ -319,7 +325,7 @@ __global__ __launch_bounds__(kWave* kTileWaves) void k_frame_onepass(const uint8
                     if (polls > kSpinLimit) {
                         if (lane == 0) __hip_atomic_store(abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         aborted = true;
-                    } else if ((polls & 255u) == 0u && __hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                    } else if ((polls & 15u) == 0u && __hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
                         aborted = true;
                     }
                     if (aborted) break;
@@ -337,7 +343,7 @@ __global__ __launch_bounds__(kWave* kTileWaves) void k_frame_onepass(const uint8
                 }
                 idx -= kWave;
             }
-            if (!aborted && lane == 0) __hip_atomic_store(desc + tile, kDescP | (prefix + tile_count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!aborted && !stall && lane == 0) __hip_atomic_store(desc + tile, kDescP | (prefix + tile_count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (lane == 0) {
             s_prefix = prefix;
@@ -351,7 +357,7 @@ __global__ __launch_bounds__(kWave* kTileWaves) void k_frame_onepass(const uint8
                 if (tile == (blk1 - 1u) / kTileWaves)  // the delimiters up to the end of this launch's range
                     atomicMax(reinterpret_cast<unsigned long long*>(pref + blk1), (unsigned long long)incl);
                 if (tile == 0) offsets[0] = 0;
-                if (whole && tile == (nblk - 1u) / kTileWaves && incl + 1 <= cap) offsets[incl + 1] = nbytes;  // a final unterminated frame
+                if ((whole & kWholeStream) && tile == (nblk - 1u) / kTileWaves && incl + 1 <= cap) offsets[incl + 1] = nbytes;  // a final unterminated frame
             }
         }
     }
@@ -407,14 +413,14 @@ extern "C" int fg_launch_frame(const uint8_t* d_bytes, uint64_t nbytes, uint32_t
     const uint32_t pat = delim * 0x01010101u;
     (void)hipMemsetAsync(d_bad, 0, cap, stream);
     *d_total_out = pref + nblk;
-    if (!classic) {
+    if (classic != 1) {  // (classic == 2: the one-pass form with its self-test stall -- it WILL report FG_FRAME_ABORTED on a stream of three tiles or more)
         uint64_t* desc = reinterpret_cast<uint64_t*>(scratch);  // (where the classic form keeps its masks)
         (void)hipMemsetAsync(desc, 0, nblk * 8u, stream);
         (void)hipMemsetAsync(frame_abort_word(scratch, nblk), 0, 4, stream);
         (void)hipMemsetAsync(pref + nblk, 0, 8, stream);
         hipLaunchKernelGGL(fg::k_frame_onepass<false>, dim3((uint32_t)((nblk + fg::kTileWaves - 1) / fg::kTileWaves)), dim3(fg::kWave * fg::kTileWaves), 0,
                            stream, d_bytes, nbytes, pat, desc, pref, frame_abort_word(scratch, nblk), d_offsets, d_bad, cap, (uint64_t)0, nblk, nblk,
-                           1u, (uint8_t*)nullptr);
+                           fg::kWholeStream | (classic == 2 ? fg::kSelfTestStall : 0u), (uint8_t*)nullptr);
         return (int)hipGetLastError();
     }
     hipLaunchKernelGGL(fg::k_frame_scan<false>, dim3((uint32_t)nblk), dim3(fg::kWave), 0, stream, d_bytes, nbytes, pat, masks, counts, (uint64_t)0,
@@ -445,23 +451,24 @@ extern "C" int fg_launch_frame_slice(const uint8_t* d_bytes, uint64_t nbytes, ui
     const uint32_t pat = delim * 0x01010101u;
     const uint32_t nb = (uint32_t)(blk1 - blk0);
     *d_total_out = pref + blk1;
-    if (!classic) {
+    if (classic != 1) {
+        const uint32_t stall = (classic == 2 && blk0 == 0) ? fg::kSelfTestStall : 0u;  // (self-test: the stream's first slice stalls)
         uint64_t* desc = reinterpret_cast<uint64_t*>(scratch);
         if (blk0 == 0) {
             (void)hipMemsetAsync(desc, 0, nblk * 8u, stream);
             (void)hipMemsetAsync(frame_abort_word(scratch, nblk), 0, 4, stream);
         }
-        // (tiles of four blocks: a slice that is not the stream's first starts at a multiple of fg_frame_slice_align())
+        // (tiles of kTileWaves blocks: a slice that is not the stream's first starts at a multiple of fg_frame_slice_align())
         if (blk0 % fg::kTileWaves) return -1;
         (void)hipMemsetAsync(pref + blk1, 0, 8, stream);
         const uint64_t tile0 = blk0 / fg::kTileWaves;
         const uint32_t nt = (uint32_t)((blk1 + fg::kTileWaves - 1) / fg::kTileWaves - tile0);
         if (src)
             hipLaunchKernelGGL(fg::k_frame_onepass<true>, dim3(nt), dim3(fg::kWave * fg::kTileWaves), 0, stream, src, nbytes, pat, desc, pref,
-                               frame_abort_word(scratch, nblk), d_offsets, d_bad, cap, tile0, blk1, nblk, 0u, const_cast<uint8_t*>(d_bytes));
+                               frame_abort_word(scratch, nblk), d_offsets, d_bad, cap, tile0, blk1, nblk, stall, const_cast<uint8_t*>(d_bytes));
         else
             hipLaunchKernelGGL(fg::k_frame_onepass<false>, dim3(nt), dim3(fg::kWave * fg::kTileWaves), 0, stream, d_bytes, nbytes, pat, desc, pref,
-                               frame_abort_word(scratch, nblk), d_offsets, d_bad, cap, tile0, blk1, nblk, 0u, (uint8_t*)nullptr);
+                               frame_abort_word(scratch, nblk), d_offsets, d_bad, cap, tile0, blk1, nblk, stall, (uint8_t*)nullptr);
         return (int)hipGetLastError();
     }
     if (src)

@@ -570,7 +570,7 @@ struct GelfFormat {
         const uint32_t base = (uint32_t)(c.o0 - c.a0);
         gelf2::Lds L = gelf2::carve(c.smem, c.bm16, tile_cap, extra, lines);
         L.ent_state = c.ent_state;
-        L.alloc_chunk = wv::alloc_chunk_for(t.ent_cap, gridDim.x, t.n);
+        L.alloc_chunk = t.alloc_chunk;
         const bool tile_lane = c.valid && in_tile && lane < lines && !(c.ablate & 4u);
         const gelf2::LineOut f = c.phase ? gelf2::decode_tile<true>(L, c.span, tile_lane, base, len, t, pacc)
                                          : gelf2::decode_tile<false>(L, c.span, tile_lane, base, len, t);
@@ -730,6 +730,7 @@ int launch_gelf_fast(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t
     if (fg::plan_launch(fg::k_gelf<NB, false>, n, avg_len, 0u, 40960u, 0u, &p, lo, max_lines, fg::GelfFormat::kClasses, fg::gelf_extra_lds))
         return -1;
     dim3 grid(p.blocks), block(fg::kWave);
+    fg::DevTables tt = *t;
 #if defined(FG_PROF_BUILD)
     if (getenv("FG_PLAN")) fprintf(stderr, "gelf plan: L %u tile %u lds %u blocks %u window %d KiB\n", p.L, p.tile, p.lds, p.blocks, NB);
 #endif
@@ -748,12 +749,14 @@ int launch_gelf_fast(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t
                                     fg::GelfFormat::kClasses, fg::gelf_extra_lds, nullptr, 0u, 128u) || p.tile != 3072u || p.L != 8u)
                     return -1;
                 fg::take_tickets(&fr, tk, p);
-                hipLaunchKernelGGL((fg::k_gelf<NB, false, 5, 3072u, 8u>), dim3(p.blocks), block, p.lds, stream, d_bytes, d_offsets, n, *t,
+    tt.alloc_chunk = fg::entry_chunk(tt.ent_cap, p.blocks, n, lo);
+                hipLaunchKernelGGL((fg::k_gelf<NB, false, 5, 3072u, 8u>), dim3(p.blocks), block, p.lds, stream, d_bytes, d_offsets, n, tt,
                                    p.tile, p.L, p.chunk, (unsigned long long*)nullptr, (uint64_t*)nullptr, fr);
                 return 0;
             }
             fg::take_tickets(&fr, tk, p);
-            hipLaunchKernelGGL((fg::k_gelf<NB, false, 4, 4096u, 8u>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L,
+    tt.alloc_chunk = fg::entry_chunk(tt.ent_cap, p.blocks, n, lo);
+            hipLaunchKernelGGL((fg::k_gelf<NB, false, 4, 4096u, 8u>), grid, block, p.lds, stream, d_bytes, d_offsets, n, tt, p.tile, p.L,
                                p.chunk, (unsigned long long*)nullptr, (uint64_t*)nullptr, fr);
             return 0;
         }
@@ -762,14 +765,16 @@ int launch_gelf_fast(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t
     if (fg::prof_requested()) {
         fg::ProfRun pr;
         if (!pr.begin(stream)) return -1;
-        hipLaunchKernelGGL((fg::k_gelf<NB, true>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L, p.chunk, pr.d,
+        tt.alloc_chunk = fg::entry_chunk(tt.ent_cap, p.blocks, n, lo);
+        hipLaunchKernelGGL((fg::k_gelf<NB, true>), grid, block, p.lds, stream, d_bytes, d_offsets, n, tt, p.tile, p.L, p.chunk, pr.d,
                            (uint64_t*)nullptr, fr);
         pr.end(stream, "gelf", p);
         return 0;
     }
 #endif
     fg::take_tickets(&fr, tk, p);
-    hipLaunchKernelGGL((fg::k_gelf<NB, false>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L, p.chunk,
+    tt.alloc_chunk = fg::entry_chunk(tt.ent_cap, p.blocks, n, lo);
+    hipLaunchKernelGGL((fg::k_gelf<NB, false>), grid, block, p.lds, stream, d_bytes, d_offsets, n, tt, p.tile, p.L, p.chunk,
                        (unsigned long long*)nullptr, (uint64_t*)nullptr, fr);
     return 0;
 }

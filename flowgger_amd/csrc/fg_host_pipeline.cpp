@@ -568,7 +568,7 @@ static int frame_decode_sliced(fg_ctx* ctx, fg_format fmt, fg_framing framing, c
         uint64_t* d_total = nullptr;
         const uint64_t blk0 = b0 / blk, blk1 = k + 1 == slices ? nblk_total : b1 / blk;
         int lrc = fg_launch_frame_slice(ctx->d_bytes, nbytes, delim, ctx->d_frame, ctx->d_offsets, ctx->d_bad, cap, blk0, blk1, &d_total, s_frame, src_dv,
-                                        (ctx->lo.flags & FG_LO_FRAME_CLASSIC) ? 1 : 0);
+                                        (ctx->lo.flags & FG_LO_FRAME_CLASSIC) ? 1 : (ctx->lo.flags & FG_LO_FRAME_SELFTEST_STALL) ? 2 : 0);
         if (lrc == 0) lrc = fg_launch_poke64(d_total, cnt_dv + k, s_frame);
         if (lrc != 0) {
             ctx->last_hip = lrc;
@@ -696,7 +696,7 @@ static int frame_stage(fg_ctx* ctx, fg_framing framing, uint64_t nbytes, int fin
         if ((rc = grow_dev(ctx, (void**)&ctx->d_offsets, &ctx->d_offsets_cap, (cap + 2) * 8)) != FG_OK) return rc;
         if ((rc = grow_dev(ctx, (void**)&ctx->d_bad, &ctx->d_bad_cap, cap + 1)) != FG_OK) return rc;
         if ((rc = grow_dev(ctx, (void**)&ctx->d_frame, &ctx->d_frame_cap, fg_frame_scratch_bytes(nbytes))) != FG_OK) return rc;
-        for (int classic = (ctx->lo.flags & FG_LO_FRAME_CLASSIC) ? 1 : 0;; classic = 1) {
+        for (int classic = (ctx->lo.flags & FG_LO_FRAME_CLASSIC) ? 1 : (ctx->lo.flags & FG_LO_FRAME_SELFTEST_STALL) ? 2 : 0;; classic = 1) {
             uint64_t* d_total = nullptr;
             int lrc = fg_launch_frame(ctx->d_bytes, nbytes, framing == FG_FRAME_LINE ? 0x0Au : 0x00u, ctx->d_frame, ctx->d_offsets,
                                       ctx->d_bad, cap, &d_total, s, classic);
@@ -706,7 +706,7 @@ static int frame_stage(fg_ctx* ctx, fg_framing framing, uint64_t nbytes, int fin
             }
             FG_HIP(ctx, hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, s));
             FG_HIP(ctx, hipStreamSynchronize(s));
-            if (total != FG_FRAME_ABORTED || classic) break;  // (the one-pass scan gave up waiting on a tile: the three-kernel form)
+            if (total != FG_FRAME_ABORTED || classic == 1) break;  // (the one-pass scan gave up waiting on a tile: the three-kernel form)
         }
         if (total + 1 <= cap) break;
         cap = total + 16;

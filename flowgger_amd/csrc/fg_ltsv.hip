@@ -881,25 +881,27 @@ extern "C" int fg_launch_ltsv(const uint8_t* d_bytes, const uint64_t* d_offsets,
     dim3 grid(p.blocks), block(fg::kWave);
     fg::FrameArgs fr{strip, line_bad};
     fg::take_tickets(&fr, tk, p);
+    fg::DevTables tt = *t;
+    tt.alloc_chunk = fg::entry_chunk(tt.ent_cap, p.blocks, n, *lo);
 #if defined(FG_PROF_BUILD)
     if (fg::prof_requested()) {
         fg::ProfRun pr;
         if (!pr.begin(stream)) return -1;
         if (head)
-            hipLaunchKernelGGL((fg::k_ltsv<fg::kComputeBoundWindow, true, true>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, *cfg, p.tile,
+            hipLaunchKernelGGL((fg::k_ltsv<fg::kComputeBoundWindow, true, true>), grid, block, p.lds, stream, d_bytes, d_offsets, n, tt, *cfg, p.tile,
                                p.L, p.chunk, pr.d, stash, fr);
         else
-            hipLaunchKernelGGL((fg::k_ltsv<fg::kComputeBoundWindow, true>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, *cfg, p.tile,
+            hipLaunchKernelGGL((fg::k_ltsv<fg::kComputeBoundWindow, true>), grid, block, p.lds, stream, d_bytes, d_offsets, n, tt, *cfg, p.tile,
                                p.L, p.chunk, pr.d, stash, fr);
         pr.end(stream, head ? "ltsv (head)" : "ltsv", p);
         return (int)hipGetLastError();
     }
 #endif
     if (head)
-        hipLaunchKernelGGL((fg::k_ltsv<fg::kComputeBoundWindow, false, true>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, *cfg, p.tile,
+        hipLaunchKernelGGL((fg::k_ltsv<fg::kComputeBoundWindow, false, true>), grid, block, p.lds, stream, d_bytes, d_offsets, n, tt, *cfg, p.tile,
                            p.L, p.chunk, (unsigned long long*)nullptr, stash, fr);
     else
-        hipLaunchKernelGGL((fg::k_ltsv<fg::kComputeBoundWindow, false>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, *cfg, p.tile,
+        hipLaunchKernelGGL((fg::k_ltsv<fg::kComputeBoundWindow, false>), grid, block, p.lds, stream, d_bytes, d_offsets, n, tt, *cfg, p.tile,
                            p.L, p.chunk, (unsigned long long*)nullptr, stash, fr);
     return (int)hipGetLastError();
 }

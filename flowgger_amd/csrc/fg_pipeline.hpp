@@ -196,7 +196,7 @@ __device__ __forceinline__ EntAlloc alloc_entries_ex(const DevTables& t, uint32_
     const uint32_t left = wv::wave_left(ent_state);
     const unsigned long long nofit = __ballot(n_ent != 0u && a.ex + n_ent > left);
     const uint32_t cut = nofit ? (uint32_t)__shfl((int)a.ex, (int)__builtin_ctzll(nofit), kWave) : a.total;
-    a.s = wv::wave_alloc(t.ent_used, t.ent_cap, ent_state, a.total, cut, wv::alloc_chunk_for(t.ent_cap, gridDim.x, t.n));
+    a.s = wv::wave_alloc(t.ent_used, t.ent_cap, ent_state, a.total, cut, t.alloc_chunk);
     a.overflow = a.s.overflow && n_ent != 0u && a.ex >= a.s.cut;
     return a;
 }
@@ -731,13 +731,36 @@ struct LaunchPlan {
     uint64_t groups = 0;  // an estimate (the waves cut their ranges into groups themselves)
     uint64_t chunk = 256; // lines a wave takes at a time (the first by block index, the rest by ticket)
     uint64_t chunks = 0;  // ceil(n / chunk) >= blocks
+    bool tickets = false; // chunks beyond a wave's first are drawn from the launch's ticket counter (else: round-robin)
     uint32_t blocks = 0;  // persistent grid
 };
+
+// Entry slots a wave reserves from the table's counter at a time (DevTables::alloc_chunk; wv::wave_alloc).  Every reservation is an
+// atomic on ONE word, and that word's channel serves only a few dozen of them per microsecond (rounds 3-4 and profiles/r05b_*: GELF,
+// one request per 8-line tile, took 290 us for 64 K lines and 915 us for 256 K where 512 K take 400 us -- small launches fell under
+// the 256-slot floor of wv::alloc_chunk_for into EXACT reservations).  So: the table's share per wave (1/16 of it over all waves, at
+// most 4096 slots) capped by eight slots per line the wave will see in this launch -- but never below 64 slots; exact reservations
+// only for a table too small for 256-slot chunks (a caller that sized it tightly must not see FG_ST_OVERFLOW because of slots parked
+// in chunks).  What a wave strands is the rest of its last chunk: half a chunk on average, never written and -- on the
+// zero-copy host paths, which write the tables across the link themselves -- never moved.
+inline uint32_t entry_chunk(uint64_t ent_cap, uint32_t blocks, uint64_t n, const fg_launch_opts& lo) {
+    if (lo.ent_chunk == 1u) return 0u;
+    if (lo.ent_chunk >= 2u) return lo.ent_chunk;
+    const uint64_t waves = blocks ? blocks : 1u;
+    uint64_t c = ent_cap / (16ull * waves);
+    if (c > 4096u) c = 4096u;
+    if (c < 256u) return 0u;
+    const uint64_t per_wave = (n + waves - 1u) / waves * 8ull;
+    if (c > per_wave) c = per_wave;
+    if (c < 64u) c = 64u;
+    return (uint32_t)c;
+}
 
 // The launch's ticket counter into the kernel's arguments; the host's copy of the counter moves on by what the launch will draw
 // (every wave draws until its first ticket beyond the last chunk: chunks - blocks good ones + blocks bad ones = chunks).
 inline void take_tickets(FrameArgs* fr, TicketSlot* tk, const LaunchPlan& p) {
     if (!tk || !tk->d_word || !tk->h_val || p.chunks + p.blocks >= 0xFFFFFFFFull || p.blocks > p.chunks) return;  // (static round-robin)
+    if (!p.tickets) return;  // (equal shares: nothing to draw)
     fr->ticket = tk->d_word;
     fr->ticket_base = *tk->h_val;
     *tk->h_val += (uint32_t)p.chunks;
@@ -815,37 +838,40 @@ inline int plan_launch(K kernel, uint64_t n, uint64_t avg_len, uint32_t extra_ld
             chunk = (n + blocks - 1) / (blocks ? blocks : 1);
             if (chunk < (dynamic ? g : p->L)) chunk = dynamic ? g : p->L;
         }
-    } else if (dynamic) {
-        // Chunks are DRAWN (persistent_loop's ticket): balance is the dispatch's business, the chunk only has to be small against a
-        // wave's share of the batch and a whole number of groups, because the group a chunk ends on is as short as it comes out and
-        // costs these latency-bound kernels what a full one does.  Large batch: `full` lines.  Small batch (what a framer hands over:
-        // 10^4 .. 10^6 lines): a quarter of the wave's share, in units of an average group less a sixteenth (so that a unit USUALLY is
-        // one group) -- down to ONE group per chunk.  (Rounds 3-4 never cut a chunk below 64 lines: 16 K structured-data lines, 21 to
-        // the group, ran as 256 waves of three groups each on a grid of 2048 -- 84 us where 30 would do, profiles/r05a_small.log.)
-        const uint64_t per_wave = (n + blocks - 1) / (blocks ? blocks : 1);
-        if (per_wave >= 4u * full) {
-            chunk = full;
-        } else {
-            const uint64_t unit = g >= p->L ? g : (g * 15u / 16u ? g * 15u / 16u : 1u);
-            uint64_t units = per_wave / 4u / unit;
-            if (units < 1u) units = 1u;
-            chunk = units * unit;
-            if (chunk > full) chunk = full;
-        }
+    } else if (dynamic && (n + blocks - 1) / (blocks ? blocks : 1) >= 2u * full) {
+        // Chunks are DRAWN (persistent_loop's ticket): a wave that meets slow lines or sits on a slow XCD draws fewer -- the balance is
+        // the dispatch's business, so the chunk is simply `full` lines: its last group is as short as it comes out and costs these
+        // latency-bound kernels what a full one does (1 group in 4 .. 50), and every ticket is an atomic on one word, of which the
+        // chip serves a few dozen per microsecond -- chunks of ONE group (8192 tickets for 512 K lines of the headline corpus) doubled
+        // the kernel's time (profiles/r05b_small_ab.log: 123 vs 65 us).  A batch with fewer than two such chunks per wave takes the
+        // equal shares below and draws nothing.
+        chunk = full;
     } else {
         // The chunks are dealt out round-robin, so every wave should get the SAME number of them: k = the chunks per wave that keeps a
         // chunk at or below `full`, chunk = n / (waves * k).  (With chunks of exactly `full` lines a batch of 1.9 chunks per wave left a
         // tenth of the grid with half the work of the rest: 4 M structured-data lines 1.80 -> 1.89 G lines/s, 4 M long-tail lines
         // 0.69 -> 0.88 G with one even chunk per wave, profiles/r04z3_sweep_cfg4.log, r04z5_sweep_cfg5.log.)
         const uint64_t per_wave = (n + blocks - 1) / (blocks ? blocks : 1);
-        const uint64_t k = (per_wave + full - 1) / full;
-        chunk = (per_wave + (k ? k : 1) - 1) / (k ? k : 1);
-        if (chunk < p->L) chunk = p->L;
+        if (dynamic) {
+            // (round 5) equal shares of [full, 2 full) lines -- one or two ragged groups per wave instead of up to k -- and no floor of
+            // L lines: a small batch is cut down to ONE average group per wave (16 K structured-data lines, 21 to the group, ran as 256
+            // waves of three groups each on a grid of 2048: 84 us where 65 do, profiles/r05a_small.log / r05b_small_ab.log)
+            const uint64_t k = per_wave / full ? per_wave / full : 1u;
+            chunk = (per_wave + k - 1) / k;
+            const uint64_t unit = g >= p->L ? g : (g * 15u / 16u ? g * 15u / 16u : 1u);
+            if (chunk < unit) chunk = unit;
+        } else {
+            const uint64_t k = (per_wave + full - 1) / full;
+            chunk = (per_wave + (k ? k : 1) - 1) / (k ? k : 1);
+            if (chunk < p->L) chunk = p->L;
+        }
     }
     const uint64_t chunks = (n + chunk - 1) / chunk;
     if (blocks > chunks) blocks = chunks;
     p->chunk = chunk;
     p->chunks = chunks;
+    // (tickets: large batches -- or whenever the caller names a chunk size while dispatch is dynamic: tests, tuning)
+    p->tickets = dynamic && ((n + blocks - 1) / (blocks ? blocks : 1) >= 2u * full || (lo.chunk_lines >= 1u && lo.chunk_lines <= 65536u));
     p->blocks = (uint32_t)blocks;
     return 0;
 }

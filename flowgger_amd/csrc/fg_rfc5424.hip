@@ -1122,9 +1122,11 @@ extern "C" int fg_launch_rfc5424(const uint8_t* d_bytes, const uint64_t* d_offse
     dim3 grid(p.blocks), block(fg::kWave);
     fg::FrameArgs fr{strip, line_bad};
     fg::take_tickets(&fr, tk, p);
+    fg::DevTables tt = *t;
+    tt.alloc_chunk = fg::entry_chunk(tt.ent_cap, p.blocks, n, *lo);
     unsigned long long* const no_prof = nullptr;
 #define FG_LAUNCH_5424(PROF_, HEAD_, SDX_, prof_ptr)                                                                                       \
-    hipLaunchKernelGGL((fg::k_rfc5424<fg::kWindowKiB, PROF_, HEAD_, SDX_>), grid, block, p.lds, stream, d_bytes, d_offsets, n, *t, p.tile, p.L, \
+    hipLaunchKernelGGL((fg::k_rfc5424<fg::kWindowKiB, PROF_, HEAD_, SDX_>), grid, block, p.lds, stream, d_bytes, d_offsets, n, tt, p.tile, p.L, \
                        p.chunk, prof_ptr, stash, fr)
 #if defined(FG_PROF_BUILD)
     if (fg::prof_requested()) {

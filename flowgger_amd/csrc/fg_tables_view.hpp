@@ -27,6 +27,9 @@ struct DevTables {
     // else.  One word of a ctx-owned ring per launch (epoch = the ctx's launch counter), so launches in flight never share one.
     uint32_t* pending;
     uint32_t epoch;
+    // entry slots a wave reserves from ent_used at a time (wv::wave_alloc): 0 = exactly what each request needs.  Set by the kernel
+    // launchers from the table, the grid and the lines of THIS launch (fg::entry_chunk, fg_pipeline.hpp).
+    uint32_t alloc_chunk;
 };
 // Dynamic chunk dispatch of the streaming decoders (fg_pipeline.hpp persistent_loop): the ticket counter of ONE launch -- a word of
 // a ctx-owned ring in device memory -- and the host's copy of what it holds; the launcher hands the kernel the word + that value and

@@ -191,7 +191,10 @@ typedef struct fg_launch_opts {
     uint32_t gelf_lds_budget; /* GELF: LDS bytes per wave the lines per group are fitted to */
     uint32_t gelf_window_kib; /* GELF: register prefetch window in KiB (2..6) */
     uint32_t flags;           /* FG_LO_* */
-    uint32_t chunk_lines;     /* lines a wave takes at a time (dealt out round-robin over the grid), 64..65536 */
+    uint32_t chunk_lines;     /* lines a wave takes at a time (the first chunk by block index, further ones drawn by ticket), 1..65536 */
+    uint32_t ent_chunk;       /* entry slots a wave reserves from the table's counter at a time: 1 = exactly what each request needs,
+                                 >= 2 = that many (tuning: fewer atomics on the one counter word against slots stranded at the end of
+                                 every wave's last reservation) */
 } fg_launch_opts;
 enum {
     FG_LO_GELF_GENERIC = 1,        /* GELF: the run-time-geometry kernel even where the constant-geometry instantiation applies */
@@ -208,6 +211,9 @@ enum {
                                       scan -- which falls back to it by itself should its look-back ever give up (A/B, tests) */
     FG_LO_STATIC_CHUNKS = 512,     /* decode kernels: deal the chunks of a batch out round-robin over the waves (rounds 3-4) instead of by
                                       ticket -- every wave draws its next chunk from a per-launch counter when it needs one (A/B, tests) */
+    FG_LO_FRAME_SELFTEST_STALL = 1024, /* framing self-test: the one-pass scan's second tile never publishes its descriptor, so the tiles behind
+                                      it must give up within the spin bound and the call must come back through the classic kernels with
+                                      the same result (tests; never set in production: it costs the spin bound, ~0.2 s) */
     FG_LO_RESERVED = 0x40000000    /* the library's own (fg_set_launch_opts clears it) */
 };
 

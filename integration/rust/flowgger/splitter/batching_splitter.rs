@@ -25,6 +25,21 @@ use crate::flowgger::encoder::Encoder;
 
 /// A batch never grows beyond this (the GPU path runs at link speed long before).
 const MAX_BYTES: usize = 8 << 20;
+/// Capacity of the reader the splitter reads through.  `fill()` never blocks while complete frames are buffered, so under sustained
+/// load a batch is what ONE read returns: with the 8 KiB `BufReader` the reference's inputs build (`tcp_input.rs:77`,
+/// `stdin_input.rs:57`) that is ~32 lines per GPU call, each paying the call's fixed cost.  The splitter therefore
+/// re-wraps the source: whatever the input's reader has buffered is taken over, the source itself moves into a reader of this size.
+const READER_CAPACITY: usize = 1 << 20;
+
+/// The input's `BufReader` (8 KiB by default) -> one of READER_CAPACITY over the same source; bytes it had already buffered go
+/// to `carry` (they are the first bytes of the first batch).  A reader that is already large enough is kept.
+fn widen<T: Read>(reader: BufReader<T>, carry: &mut Vec<u8>) -> BufReader<T> {
+    if reader.capacity() >= READER_CAPACITY {
+        return reader;
+    }
+    carry.extend_from_slice(reader.buffer());
+    BufReader::with_capacity(READER_CAPACITY, reader.into_inner())
+}
 
 pub struct GpuSplitter {
     pub framing: fg_framing, // FG_FRAME_LINE (lines()) or FG_FRAME_NUL (split(0))
@@ -50,13 +65,17 @@ impl<T: Read> Splitter<T> for GpuSplitter {
 }
 
 impl GpuSplitter {
-    pub fn run_decode<T: Read>(&self, mut reader: BufReader<T>, tx: SyncSender<Vec<u8>>, decoder: &GpuDecoder, encoder: Box<dyn Encoder>) {
+    pub fn run_decode<T: Read>(&self, reader: BufReader<T>, tx: SyncSender<Vec<u8>>, decoder: &GpuDecoder, encoder: Box<dyn Encoder>) {
         let mut buf: Vec<u8> = Vec::with_capacity(2 * MAX_BYTES);
+        let mut reader = widen(reader, &mut buf);
+        // does `buf` hold a complete frame?  Kept as a flag: what a decode leaves behind is an unterminated tail (no frame), and
+        // `fill` looks only at the bytes it adds -- the buffer is never rescanned (a long unterminated frame was quadratic)
+        let mut framed = has_frame(&buf, self.framing);
         loop {
-            let how = fill(&mut reader, &mut buf, MAX_BYTES, self.framing);
+            let how = fill(&mut reader, &mut buf, MAX_BYTES, self.framing, &mut framed);
             let last = how != Fill::Data;
             let eof = how == Fill::Eof;
-            if !buf.is_empty() && (eof || has_frame(&buf, self.framing)) {
+            if !buf.is_empty() && (eof || framed) {
                 let nbytes = buf.len();
                 buf.resize(nbytes + 16, 0); // readable slack
                 let mut t: fg_tables = unsafe { std::mem::zeroed() };
@@ -89,6 +108,7 @@ impl GpuSplitter {
                 }
                 buf.truncate(nbytes);
                 buf.drain(..used as usize); // an unterminated tail waits for more bytes
+                framed = false;
             }
             if last {
                 if how == Fill::Idle {
@@ -100,13 +120,15 @@ impl GpuSplitter {
         }
     }
 
-    pub fn run_transcode<T: Read>(&self, mut reader: BufReader<T>, tx: SyncSender<Vec<u8>>, decoder: &GpuDecoder, enc: &fg_encode_cfg) {
+    pub fn run_transcode<T: Read>(&self, reader: BufReader<T>, tx: SyncSender<Vec<u8>>, decoder: &GpuDecoder, enc: &fg_encode_cfg) {
         let mut buf: Vec<u8> = Vec::with_capacity(2 * MAX_BYTES);
+        let mut reader = widen(reader, &mut buf);
+        let mut framed = has_frame(&buf, self.framing);
         loop {
-            let how = fill(&mut reader, &mut buf, MAX_BYTES, self.framing);
+            let how = fill(&mut reader, &mut buf, MAX_BYTES, self.framing, &mut framed);
             let last = how != Fill::Data;
             let eof = how == Fill::Eof;
-            if !buf.is_empty() && (eof || has_frame(&buf, self.framing)) {
+            if !buf.is_empty() && (eof || framed) {
                 let nbytes = buf.len();
                 buf.resize(nbytes + 16, 0);
                 let mut r: fg_transcoded = unsafe { std::mem::zeroed() };
@@ -144,6 +166,7 @@ impl GpuSplitter {
                 }
                 buf.truncate(nbytes);
                 buf.drain(..r.consumed as usize);
+                framed = false;
             }
             if last {
                 if how == Fill::Idle {
@@ -182,10 +205,10 @@ fn has_frame(buf: &[u8], framing: fg_framing) -> bool {
 /// quiet), and the next `fill_buf()` would block on the socket for up to `input.timeout` with complete lines sitting undecoded:
 /// so a full read only reads on while `buf` holds NO complete frame yet -- never block while there is something to decode
 /// (the reference hands every line to the decoder as soon as `lines()` yields it, line_splitter.rs:17).  The batch
-/// size under sustained load is therefore the reader's capacity: construct the input's reader as
-/// `BufReader::with_capacity(1 << 20, ..)` (4000 lines of 256 bytes per GPU call); the reference's 8 KiB default works and
-/// gives 32-line batches.
-fn fill<T: Read>(reader: &mut BufReader<T>, buf: &mut Vec<u8>, max_bytes: usize, framing: fg_framing) -> Fill {
+/// size under sustained load is therefore the reader's capacity -- READER_CAPACITY, 1 MiB = 4000 lines of 256 bytes per GPU call:
+/// `widen()` sees to it whatever reader the input built.
+/// `framed`: in / out, "buf holds a complete frame".  Only the bytes added here are searched for a terminator.
+fn fill<T: Read>(reader: &mut BufReader<T>, buf: &mut Vec<u8>, max_bytes: usize, framing: fg_framing, framed: &mut bool) -> Fill {
     let cap = reader.capacity();
     let mut added = 0usize;
     loop {
@@ -199,13 +222,13 @@ fn fill<T: Read>(reader: &mut BufReader<T>, buf: &mut Vec<u8>, max_bytes: usize,
         if k == 0 {
             return Fill::Eof;
         }
-        let fresh_has_frame = has_frame(chunk, framing);
+        *framed = *framed || has_frame(chunk, framing);
         buf.extend_from_slice(chunk);
         reader.consume(k);
         added += k;
         // a short read: nothing more is pending -- or the batch is full -- or there is a complete frame to decode and the next
-        // read might block (the frame may also have been completed by these bytes: look at the whole buffer then)
-        if k < cap || added >= max_bytes || fresh_has_frame || has_frame(buf, framing) {
+        // read might block
+        if k < cap || added >= max_bytes || *framed {
             return Fill::Data;
         }
     }
@@ -240,7 +263,9 @@ mod tests {
         piece[cap - 1] = b'\n';
         let mut reader = BufReader::with_capacity(cap, Pieces { pieces: vec![piece], next: 0 });
         let mut buf = Vec::new();
-        assert!(fill(&mut reader, &mut buf, 1 << 20, FG_FRAME_LINE) == Fill::Data);
+        let mut framed = false;
+        assert!(fill(&mut reader, &mut buf, 1 << 20, FG_FRAME_LINE, &mut framed) == Fill::Data);
+        assert!(framed);
         assert_eq!(buf.len(), cap);
     }
 
@@ -252,7 +277,25 @@ mod tests {
         second[19] = b'\n';
         let mut reader = BufReader::with_capacity(cap, Pieces { pieces: vec![first, second], next: 0 });
         let mut buf = Vec::new();
-        assert!(fill(&mut reader, &mut buf, 1 << 20, FG_FRAME_LINE) == Fill::Data);
+        let mut framed = false;
+        assert!(fill(&mut reader, &mut buf, 1 << 20, FG_FRAME_LINE, &mut framed) == Fill::Data);
+        assert!(framed);
         assert_eq!(buf.len(), cap + 20);
+    }
+
+    #[test]
+    fn the_inputs_small_reader_is_widened_and_its_buffered_bytes_are_kept() {
+        let mut piece = vec![b'z'; 40];
+        piece[39] = b'\n';
+        let mut small = BufReader::with_capacity(64, Pieces { pieces: vec![piece.clone(), b"tail\n".to_vec()], next: 0 });
+        assert_eq!(small.fill_buf().unwrap().len(), 40); // the input's reader has read ahead
+        let mut carry = Vec::new();
+        let mut wide = widen(small, &mut carry);
+        assert_eq!(carry, piece);
+        assert!(wide.capacity() >= READER_CAPACITY);
+        let mut framed = has_frame(&carry, FG_FRAME_LINE);
+        assert!(framed);
+        assert!(fill(&mut wide, &mut carry, 1 << 20, FG_FRAME_LINE, &mut framed) == Fill::Data);
+        assert_eq!(carry.len(), 45);
     }
 }

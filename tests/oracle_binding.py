@@ -214,6 +214,18 @@ class Oracle:
                            vp(be.ctypes.data), vp(valid.ctypes.data), C.c_uint64(int(n)))
         return [(int(starts[i]), int(ends[i]), raw[int(starts[i]):int(be[i])], bool(valid[i])) for i in range(int(n))]
 
+    def frame_arrays(self, data: np.ndarray, framing: str):
+        """fgo_frame over a large stream without Python objects per frame -> (starts u64[n], ends_with_terminator u64[n], valid u8[n])"""
+        self.lib.fgo_frame.restype = C.c_int64
+        fr = 1 if framing == "line" else 2
+        vp = C.c_void_p
+        n = int(self.lib.fgo_frame(C.c_int(fr), vp(data.ctypes.data), C.c_uint64(data.size), None, None, None, None, C.c_uint64(0)))
+        starts, ends, be = (np.zeros(max(n, 1), np.uint64) for _ in range(3))
+        valid = np.zeros(max(n, 1), np.uint8)
+        self.lib.fgo_frame(C.c_int(fr), vp(data.ctypes.data), C.c_uint64(data.size), vp(starts.ctypes.data), vp(ends.ctypes.data),
+                           vp(be.ctypes.data), vp(valid.ctypes.data), C.c_uint64(n))
+        return starts[:n], ends[:n], valid[:n]
+
     def decode_stdout(self, fmt: int, line: bytes, config=None) -> bytes:
         """what Decoder::decode(line) prints to stdout (ltsv_decoder.rs:99)"""
         cfg, keep = self.make_cfg(config)
