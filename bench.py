@@ -505,6 +505,39 @@ def bounded_leg(desc, fmt, lines, reps, dev, local, steps=5, warmup=2, D=None):
     return out, leg
 
 
+def small_batch_leg(dev, local, invalid_frac):
+    """Kernel-only rate at the batch sizes a framer really hands over (the kernels were tuned at 4 M .. 100 M
+    lines): 64 K / 256 K / 1 M lines of the headline corpus and of the long-tail structured-data corpus (64 B .. 8 KiB), resident in
+    HBM, median of 9 launches after 3 warm-ups, HIP events on the launch stream.  One 64 K-line tile per corpus, replicated."""
+    import torch
+
+    from flowgger_amd import synth
+
+    stream = torch.cuda.current_stream(dev)
+    out = {"what": "fg_decode_batch_device on a resident batch of n lines (a 65 536-line tile x 1 / 4 / 16), kernel-only lines/s, median of 9"}
+    for key, gen, entries in (("cfg2", lambda: synth.rfc5424_lines(65_536, cfg=2, invalid_frac=invalid_frac), False),
+                              ("long_tail", lambda: synth.rfc5424_lines(65_536, cfg=5, sd=True, invalid_frac=invalid_frac, long_tail=True), True)):
+        lines = gen()
+        res = {}
+        for reps in (1, 4, 16):
+            R = Resident(0, lines, reps, dev, local, {}, entries=entries)
+            for _ in range(3):
+                R.decode(stream)
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(9)]
+            for a, b in ev:
+                a.record(stream)
+                R.decode(stream)
+                b.record(stream)
+            torch.cuda.synchronize(dev)
+            ms = sorted(a.elapsed_time(b) for a, b in ev)[4]
+            R.check_replicas()
+            res[str(R.n)] = {"lines_per_s": R.n / (ms * 1e-3), "kernel_us": ms * 1e3, "avg_line_bytes": R.tile_bytes / R.n_tile}
+            del R
+            torch.cuda.empty_cache()
+        out[key] = res
+    return out
+
+
 def calibrate(dec, d_bytes, nbytes, dev, reps=3):
     """What THIS box's memory system gives a plain streaming kernel over the very buffer the decoder reads (fg_calibrate_device):
     a float4 copy (2 x nbytes of traffic) and a read-only sweep.  Three boxes of this pool differ by 8 % on the same code."""
@@ -923,6 +956,13 @@ def main():
                     if isinstance(e, AssertionError):
                         raise
                     out[key] = {"error": repr(e)[:200]}
+        if wl == "cfg2" and world == 1 and not args.no_legs:
+            try:
+                out["small_batch"] = small_batch_leg(dev, local, args.invalid_frac)
+            except Exception as e:  # noqa: BLE001 -- an extra leg never takes the bench line down
+                if isinstance(e, AssertionError):
+                    raise
+                out["small_batch"] = {"error": repr(e)[:200]}
         if wl == "cfg2" and world == 1 and "WORLD_SIZE" not in os.environ and not args.no_mix:
             # BASELINE configs[4] (mixed RFC5424 + LTSV long-tail stream, host-side ordered gather) on a bounded sample, so that the
             # driver's default run carries its rate and gather time too: this very script, --workload cfg5mix, as a child process

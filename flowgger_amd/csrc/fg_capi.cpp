@@ -585,6 +585,26 @@ int encode_device_impl(fg_ctx* ctx, fg_format src_fmt, const fg_encode_cfg* ecfg
     // the tile is what limits the waves per CU (the emitters are latency-bound: occupancy is throughput)
     const uint32_t tile_cap = pick_tile_cap(ctx, nbytes, n, 40 * 1024, 1);
     if (ctx->timing) FG_HIP(ctx, hipEventRecord(ctx->ev0, s));
+    if (d_out && !(ctx->lo.flags & FG_LO_ENCODE_THREE_PASS)) {
+        // ONE launch: count -> chained look-back -> write (fg_encode.hip k_encode_fused).  A workgroup whose messages would end behind
+        // out_cap writes nothing, so the capacity is safe before the host has seen the total.
+        fg::EncCfg fcfg = cfg;
+        fcfg.out_cap = out_cap ? out_cap : 1;
+        int frc = fg_launch_encode_fused(d_bytes, d_offsets, n, &dt, &fcfg, tile_cap, cfg_lds, d_enc_status, d_block_sums, 0ull, d_out_offsets, d_out, s);
+        if (frc != 0) {
+            ctx->last_hip = frc;
+            return FG_ERR_HIP;
+        }
+        if (ctx->timing) {
+            FG_HIP(ctx, hipEventRecord(ctx->ev1, s));
+            ctx->ev_valid = true;
+        }
+        if (async) return FG_OK;  // (a look-back that gave up shows as out_offsets[n] == ~0: larger than any capacity)
+        FG_HIP(ctx, hipMemcpyAsync(total, d_out_offsets + n, 8, hipMemcpyDeviceToHost, s));
+        FG_HIP(ctx, hipStreamSynchronize(s));
+        if (*total != FG_ENCODE_ABORTED) return *total > out_cap ? FG_ERR_ENT_OVERFLOW : FG_OK;
+        *total = 0;  // never seen: the three launches below do the batch again
+    }
     int lrc = fg_launch_encode_sizes(d_bytes, d_offsets, n, &dt, &cfg, tile_cap, cfg_lds, d_sizes, d_block_sums, d_enc_status, d_out_offsets, s);
     if (lrc != 0) {
         ctx->last_hip = lrc;

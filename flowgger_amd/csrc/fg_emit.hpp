@@ -190,45 +190,95 @@ struct CountSink {
     FGE_HD void add(uint32_t k) { n += k; }
     FGE_HD void finish() {}
 };
-// Packs the byte stream into ALIGNED dword stores.  Messages of neighbouring lines are adjacent in the output and are
-// written by other lanes at the same time, so nothing outside [q, q + length) may be touched: the bytes of the first
-// dword before q and of the last dword after the end are never stored (byte stores there).
+// Packs the byte stream into ALIGNED 16-BYTE stores (round 5; rounds 1-4: aligned dword stores).  A lane streams its own message, so
+// one store instruction of the wave touches 64 different cache lines whatever its width -- the store path handles those one line per
+// cycle: per-lane dword stores ran the write kernel at 0.9 TB/s of output (2.6 ms for the 2.4 GB of the 4 M-line corpus, the whole
+// difference between the count pass and the write pass), per-lane 16-byte stores move the same bytes in a quarter of the store
+// instructions: 3.0 TB/s (tools/probe/store_patterns.cpp, profiles/r05c_store_patterns.log; staging the bytes through LDS for
+// wave-cooperative flushes measured SLOWER than that: 2.5 TB/s).  Messages of neighbouring lines are adjacent in the output and are
+// written by other lanes at the same time, so nothing outside [q, q + length) may be touched: the first and the last 16-byte block of
+// a message are stored by dwords and bytes, only over bytes that are the message's own.
 struct PackSink {
     static constexpr bool kCount = false;
-    uint8_t* p;     // aligned address of the dword being assembled
-    uint32_t acc;   // pending bytes: the low k (< 4) bytes are valid (the first `head` of them are placeholders)
-    uint32_t k;
-    uint32_t head;  // bytes of the first dword that belong to the previous message
+    struct alignas(16) Block { uint32_t x, y, z, w; };
+    uint8_t* p;     // 16-byte aligned address of the block being assembled (after finish(): the end of the message)
+    uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;  // its completed dwords
+    uint32_t acc = 0;  // the dword being assembled: its low (k & 3) bytes are valid (placeholders where `head` says so)
+    uint32_t k;        // bytes of the block that are filled, 0..15
+    uint32_t head;     // bytes at the start of the FIRST block that belong to the previous message (0 once that block is out)
     FGE_HD explicit PackSink(uint8_t* q) {
-        head = (uint32_t)((uintptr_t)q & 3u);
+        head = (uint32_t)((uintptr_t)q & 15u);
         p = q - head;
-        acc = 0;
         k = head;
+    }
+    FGE_HD uint32_t dword_of(uint32_t d) const { return d == 0u ? b0 : d == 1u ? b1 : d == 2u ? b2 : b3; }
+    // (the output lies in global memory: said explicitly, or the kernels' stores are flat_ instructions -- a slower address path that
+    //  also counts against the LDS wait counter)
+    template <class T>
+    static FGE_HD void st(uint8_t* q, const T& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        *reinterpret_cast<T __attribute__((address_space(1)))*>((uint8_t __attribute__((address_space(1)))*)q) = v;
+#else
+        *reinterpret_cast<T*>(q) = v;
+#endif
+    }
+    // bytes [lo, hi) of the block, from the completed dwords (index < full) and `acc` (index == full): whole dwords as dwords
+    FGE_HD void store_part(uint32_t lo, uint32_t hi, uint32_t full) {
+#ifdef __HIP_DEVICE_COMPILE__
+#pragma unroll
+#endif
+        for (uint32_t d = 0; d < 4u; ++d) {
+            const uint32_t a = d * 4u > lo ? d * 4u : lo, e = d * 4u + 4u < hi ? d * 4u + 4u : hi;
+            if (a >= e) continue;
+            const uint32_t v = d < full ? dword_of(d) : acc;
+            if (e - a == 4u) {
+                st<uint32_t>(p + d * 4u, v);
+            } else {
+                for (uint32_t i = a; i < e; ++i) st<uint8_t>(p + i, (uint8_t)(v >> (8u * (i & 3u))));
+            }
+        }
+    }
+    static FGE_HD void st16(uint8_t* q, uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef uint32_t v4u __attribute__((ext_vector_type(4)));  // (a vector, not a struct: an aggregate copy forgets the address space)
+        const v4u v = {x, y, z, w};
+        *reinterpret_cast<v4u __attribute__((address_space(1)))*>((uint8_t __attribute__((address_space(1)))*)q) = v;
+#else
+        *reinterpret_cast<Block*>(q) = Block{x, y, z, w};
+#endif
     }
     // 32-bit arithmetic only (64-bit shifts are slow on the vector ALU): w's low bytes complete the dword, its high
     // bytes start the next one
     FGE_HD void put_word(uint32_t w, uint32_t nb) {
-        const uint32_t sh = 8u * k;
+        const uint32_t kb = k & 3u, sh = 8u * kb;
         const uint32_t lo = acc | (w << sh);
-        k += nb;
-        if (k >= 4u) {
-            if (head) {
-                for (uint32_t i = head; i < 4u; ++i) p[i] = (uint8_t)(lo >> (8u * i));
-                head = 0;
-            } else {
-                *reinterpret_cast<uint32_t*>(p) = lo;
-            }
-            p += 4;
+        if (kb + nb >= 4u) {
+            const uint32_t d = k >> 2;  // (selects, not an array: a dynamically indexed local array lives in scratch memory)
+            b0 = d == 0u ? lo : b0;
+            b1 = d == 1u ? lo : b1;
+            b2 = d == 2u ? lo : b2;
+            b3 = d == 3u ? lo : b3;
             acc = sh ? w >> (32u - sh) : 0u;
-            k -= 4u;
+            k += nb;
+            if (k >= 16u) {  // the block is complete
+                if (head) {
+                    store_part(head, 16u, 4u);
+                    head = 0;
+                } else {
+                    st16(p, b0, b1, b2, b3);
+                }
+                p += 16;
+                k -= 16u;
+            }
         } else {
             acc = lo;
+            k += nb;
         }
     }
     FGE_HD void put(uint32_t c) { put_word(c & 0xFFu, 1u); }
     FGE_HD void add(uint32_t) {}
     FGE_HD void finish() {
-        for (uint32_t i = head; i < k; ++i) p[i] = (uint8_t)(acc >> (8u * i));
+        if (k > head) store_part(head, k, k >> 2);
         p += k;
         head = 0;
         k = 0;

@@ -365,7 +365,7 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
     // chunk may be short: 256 lines = 4 full groups of 64 short lines, a dozen or more groups of long ones (small batches get
     // smaller chunks, so that every wave of the grid has one).
     // Round 5: only a wave's FIRST chunk is its block index; every further one is DRAWN from the launch's ticket counter (one atomic
-    // per chunk, by lane 0, requested one group before the chunk in hand runs out so that its round trip hides behind that group).
+    // per chunk, by lane 0, requested when the chunk BEFORE it is entered, so that a whole chunk hides its round trip).
     // Tickets are handed out in order, so the sweep stays front to back -- and a wave that meets a slow line (a walk through global
     // memory), a slow XCD or a chunk of long lines simply draws fewer tickets instead of keeping the whole grid waiting at the end:
     // what a batch of 10^5 .. 10^6 lines, one or two chunks per wave, needs.  Every wave draws until its first
@@ -381,7 +381,7 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
     uint64_t chunk = blockIdx.x;
     uint64_t hi_line = (chunk + 1u) * kChunkLines < n ? (chunk + 1u) * kChunkLines : n;
     uint64_t p = chunk * kChunkLines;
-    if (dyn && kChunkLines <= 2u * L && p < n) draw_ticket();
+    if (dyn && p < n) draw_ticket();
 
     // the L offsets from line q on (clamped to the wave's range), as o0 = start / o1 = end of lane's line
     auto load_offsets = [&](uint64_t q, uint64_t* o0, uint64_t* o1) {
@@ -502,15 +502,15 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
                 const uint32_t tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk_raw);
                 chunk = (uint64_t)(uint32_t)(tk - fr.ticket_base) + G;  // (beyond the last chunk: pn >= n, the wave is done)
                 tk_pending = false;
-                // (chunks of one or two groups -- a small batch: the successor's ticket right away, or its trip would be waited for)
-                if (kChunkLines <= 2u * L && chunk * kChunkLines < n) draw_ticket();
+                // the successor's ticket right away: a whole chunk hides its trip.  (Drawn one group before the end, as the first cut
+                // did, the tickets of a batch's FIRST round -- every wave starts at the same moment -- arrived in a burst of 1792 on one
+                // word and were waited for: 1 M lines 122 us with tickets, 104 without, profiles/r05c_small_ab.log.)
+                if (chunk * kChunkLines < n) draw_ticket();
             } else {
                 chunk += G;
             }
             pn = chunk * kChunkLines;
             hi_line = (chunk + 1u) * kChunkLines < n ? (chunk + 1u) * kChunkLines : n;
-        } else if (dyn && !tk_pending && pn + L >= hi_line) {
-            draw_ticket();  // the group after this one ends the chunk: its successor's ticket is under way
         }
         const bool more = pn < n;  // wave-uniform
         uint64_t no0 = 0, no1 = 0;
@@ -739,7 +739,9 @@ struct LaunchPlan {
 // atomic on ONE word, and that word's channel serves only a few dozen of them per microsecond (rounds 3-4 and profiles/r05b_*: GELF,
 // one request per 8-line tile, took 290 us for 64 K lines and 915 us for 256 K where 512 K take 400 us -- small launches fell under
 // the 256-slot floor of wv::alloc_chunk_for into EXACT reservations).  So: the table's share per wave (1/16 of it over all waves, at
-// most 4096 slots) capped by eight slots per line the wave will see in this launch -- but never below 64 slots; exact reservations
+// most 4096 slots) capped by eight slots per line the wave will see in this launch -- but never below 256 slots (a floor of 64 is one
+// 8-line GELF tile's worth: still an atomic per tile; 256: 340 -> 184 us for 64 K lines, 896 -> 303 us for 256 K,
+// profiles/r05c_small_gelf_opts.log); exact reservations
 // only for a table too small for 256-slot chunks (a caller that sized it tightly must not see FG_ST_OVERFLOW because of slots parked
 // in chunks).  What a wave strands is the rest of its last chunk: half a chunk on average, never written and -- on the
 // zero-copy host paths, which write the tables across the link themselves -- never moved.
@@ -752,7 +754,7 @@ inline uint32_t entry_chunk(uint64_t ent_cap, uint32_t blocks, uint64_t n, const
     if (c < 256u) return 0u;
     const uint64_t per_wave = (n + waves - 1u) / waves * 8ull;
     if (c > per_wave) c = per_wave;
-    if (c < 64u) c = 64u;
+    if (c < 256u) c = 256u;
     return (uint32_t)c;
 }
 

@@ -741,10 +741,18 @@ constexpr uint32_t kShortSdTail = 64;  // bytes after the header up to which a l
 // the (rare) lines it hands back are parsed from global memory.  SDX = false is byte for byte the kernel of round 3.
 template <bool HEAD, bool SDX = false, bool PROF = false>
 struct Rfc5424FormatT {
-    // no stage-A bitmap: the fast path classifies the header bytes itself, the SD walker's
-    // quote bitmap is built on demand (rebuild_bitmap) for groups that hold SD lines
-    static constexpr uint32_t kClasses = 0;
-    static __device__ __forceinline__ void classify_store(const uint4&, uint16_t*, uint32_t, uint32_t, uint32_t) {}
+    // no stage-A bitmap for the fast path (it classifies the header bytes itself); the lane-per-line SD walker's quote bitmap is built
+    // on demand (rebuild_bitmap) for groups that hold SD lines.  The pair-parallel instantiation for WHOLE lines (SDX, not HEAD)
+    // classifies in stage A, while the tile's bytes sit in registers: raw quote and backslash masks straight into the walk's two
+    // bitmaps (sd2::resolve_escapes finishes them) -- the chunk pass no longer reads the tile back out of LDS.
+    static constexpr bool kStageAClasses = SDX && !HEAD;
+    static constexpr uint32_t kClasses = kStageAClasses ? 2u : 0u;
+    static __device__ __forceinline__ void classify_store(const uint4& q, uint16_t* bm16, uint32_t chunk, uint32_t stride, uint32_t) {
+        if constexpr (kStageAClasses) {
+            bm16[chunk] = (uint16_t)mask16_eq(q, 0x22222222u);
+            bm16[stride + chunk] = (uint16_t)mask16_eq(q, 0x5C5C5C5Cu);
+        }
+    }
     unsigned long long* pacc = nullptr;  // measurement build: the wave's phase clocks (LDS), flushed by the kernel at its end
 
     __device__ __forceinline__ RowOut decode(const GroupCtx& c, const DevTables& t) const {
@@ -819,7 +827,7 @@ struct Rfc5424FormatT {
             const uint32_t stride16 = c.tile_cap / 16u + 16u;
             SL = sd2::carve(smem, bm16, c.tile_cap, reinterpret_cast<uint8_t*>(bm16 + 2u * stride16));
             __syncthreads();
-            const bool chain = sd2::classify_tile(SL, span);
+            const bool chain = kStageAClasses ? sd2::resolve_escapes(SL, span) : sd2::classify_tile(SL, span);
             __syncthreads();
             tick(1);
             sin = sd2::LineIn{sd_lane && (in_tile || head_only), base, f.d0, walk_len, in_tile};
@@ -1019,7 +1027,12 @@ struct Rfc5424FormatT {
                     for (uint32_t j = 0; j < 4u; ++j) w[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(lane * 16u + (r0 + j) * 1024u), 0, FG_STREAM_AUX);
 #pragma unroll
                     for (uint32_t j = 0; j < 4u; ++j)
-                        if (r0 + j < nrow) dst[(r0 + j) * kWave + lane] = make_uint4(w[j][0], w[j][1], w[j][2], w[j][3]);
+                        if (r0 + j < nrow) {
+                            const uint4 q = make_uint4(w[j][0], w[j][1], w[j][2], w[j][3]);
+                            dst[(r0 + j) * kWave + lane] = q;
+                            // (the whole-line instantiation expects what its stage A leaves: the raw class masks of every chunk)
+                            Rfc5424FormatT<false, SDX, false>::classify_store(q, bm16, (r0 + j) * kWave + lane, c.tile_cap / 16u + 16u, wv::kNoTerm);
+                        }
                 }
             }
             __syncthreads();

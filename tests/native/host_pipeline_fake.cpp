@@ -151,6 +151,27 @@ extern "C" int fg_launch_encode_write(const uint8_t* b, const uint64_t* o, uint6
     }
     return 0;
 }
+// the fused form (count -> look-back -> write in one launch): offsets absolute from `base`; a message that would end behind cfg->out_cap
+// is not written (the real kernel skips the whole 64-line workgroup; here: the line)
+extern "C" int fg_launch_encode_fused(const uint8_t* b, const uint64_t* o, uint64_t n, const fg::DevTables* t, const fg::EncCfg* c, uint32_t, uint32_t,
+                                      uint8_t* d_status, uint64_t*, uint64_t base, uint64_t* d_out_offsets, uint8_t* d_out, hipStream_t) {
+    uint64_t at = base;
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint32_t sz = fake_size(o, t, i);
+        if (d_status) d_status[i] = (t->meta[i] & 0xFFu) == 0u ? 0 : 1;
+        d_out_offsets[i] = at;
+        if (sz && d_out && (c->out_cap == 0 || at + sz <= c->out_cap)) {
+            uint8_t* w = d_out + at;
+            const uint32_t len = (uint32_t)(o[i + 1] - o[i]);
+            memcpy(w, b + o[i], len);
+            memset(w + len, '#', t->ent_count[i]);
+            w[len + t->ent_count[i]] = '\n';
+        }
+        at += sz;
+    }
+    d_out_offsets[n] = at;
+    return 0;
+}
 
 // ---- the device merge (fg_merge.hip), on "device" memory that is host memory here
 extern "C" int fg_launch_merge_device(const fg_tables* parts, uint32_t g, const uint64_t* const* d_index, const fg_tables* out, uint8_t* d_src_part,
