@@ -19,7 +19,7 @@ if _ALT and (Path(_ALT).name != _ALT or not _ALT.startswith("libfg_hip") or not 
     raise RuntimeError(f"FLOWGGER_AMD_LIB={_ALT!r}: only a bare libfg_hip*.so file name beside flowgger_amd/_lib.py is accepted")
 LIB_PATH = _HERE / (_ALT or ("libfg_hip_prof.so" if os.environ.get("FLOWGGER_AMD_PROF_LIB") else "libfg_hip.so"))
 
-FG_ABI_VERSION = 2  # include/fg_hip.h
+FG_ABI_VERSION = 3  # include/fg_hip.h
 FG_RFC5424, FG_LTSV, FG_GELF, FG_RFC3164 = 0, 1, 2, 3
 FG_FRAME_NONE, FG_FRAME_LINE, FG_FRAME_NUL = 0, 1, 2
 FG_ST_OVERFLOW, FG_ST_BAD_UTF8 = 0xFE, 0xFD

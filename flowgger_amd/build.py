@@ -21,7 +21,11 @@ CSRC = ROOT / "csrc"
 # environment -- csrc/fg_pipeline.hpp) as libfg_hip_prof.so from its own object directory.  tools/ load it with
 # FLOWGGER_AMD_PROF_LIB=1; the product library has none of it.
 PROF = bool(os.environ.get("FG_BUILD_PROF"))
-LIB = ROOT / ("libfg_hip_prof.so" if PROF else "libfg_hip.so")
+# FG_BUILD_VARIANT=<name> FG_BUILD_DEFS="-DX -DY": a same-box A/B of COMPILE-TIME choices -- libfg_hip_<name>.so from build_<name>/ with the
+# extra defines; tools/ load it with FLOWGGER_AMD_LIB=libfg_hip_<name>.so (flowgger_amd/_lib.py).  Never the product library.
+VARIANT = os.environ.get("FG_BUILD_VARIANT", "")
+VARIANT_DEFS = os.environ.get("FG_BUILD_DEFS", "").split()
+LIB = ROOT / (f"libfg_hip_{VARIANT}.so" if VARIANT else "libfg_hip_prof.so" if PROF else "libfg_hip.so")
 ARCH = "gfx950"
 
 HIP_SOURCES = ["fg_rfc5424.hip", "fg_ltsv.hip", "fg_gelf.hip", "fg_frame.hip", "fg_encode.hip", "fg_rfc3164.hip", "fg_calib.hip", "fg_merge.hip"]
@@ -170,7 +174,7 @@ def source_hashes() -> dict:
 
 def build(force: bool = False, verbose: bool = False) -> Path:
     hipcc = _hipcc()
-    objdir = ROOT / ("build_prof" if PROF else "build")
+    objdir = ROOT / (f"build_{VARIANT}" if VARIANT else "build_prof" if PROF else "build")
     objdir.mkdir(exist_ok=True)
     headers = list(CSRC.glob("*.hpp")) + [ROOT.parent / "include" / "fg_hip.h", Path(__file__)]
     common = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-fast-math",
@@ -180,6 +184,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     common.append(f"-I{ROOT.parent / 'tests' / 'native'}")
     if PROF:
         common.append("-DFG_PROF_BUILD")
+    common.extend(VARIANT_DEFS)
     # (source, object, extra defines); fg_encode.hip is compiled once per (encoder, pass) -- its emitters are large
     # force-inlined templates (one object took 18 minutes) -- plus once for the dispatcher
     units: list[tuple[str, Path, list[str]]] = []
@@ -229,7 +234,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         if verbose:
             print(" ".join(cmd))
         _run(cmd)
-    if not PROF:
+    if not PROF and not VARIANT:
         _write_deps_manifest()
     return LIB
 

@@ -745,7 +745,11 @@ struct Rfc5424FormatT {
     // on demand (rebuild_bitmap) for groups that hold SD lines.  The pair-parallel instantiation for WHOLE lines (SDX, not HEAD)
     // classifies in stage A, while the tile's bytes sit in registers: raw quote and backslash masks straight into the walk's two
     // bitmaps (sd2::resolve_escapes finishes them) -- the chunk pass no longer reads the tile back out of LDS.
+#if defined(FG_AB_NO_STAGEA_CLASSES)  // (A/B build only: the chunk pass of round 4, flowgger_amd/build.py FG_BUILD_VARIANT)
+    static constexpr bool kStageAClasses = false;
+#else
     static constexpr bool kStageAClasses = SDX && !HEAD;
+#endif
     static constexpr uint32_t kClasses = kStageAClasses ? 2u : 0u;
     static __device__ __forceinline__ void classify_store(const uint4& q, uint16_t* bm16, uint32_t chunk, uint32_t stride, uint32_t) {
         if constexpr (kStageAClasses) {

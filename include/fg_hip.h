@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FG_ABI_VERSION 2 /* 2 (round 4): FG_YEAR_NOW = INT32_MIN, FG_F_LTSV_NOVALUE and the failed-LTSV-row count, ent_used = RESERVED slots, fg_calibrate_device */
+#define FG_ABI_VERSION 3 /* 3 (round 5): fg_launch_opts.ent_chunk (the struct grew), FG_LO_STATIC_CHUNKS / _FRAME_SELFTEST_STALL / _ENCODE_THREE_PASS, fg_ticket_ring_check, fg_encode_device_async leaves an undersized buffer UNDEFINED (not untouched); 2 (round 4): FG_YEAR_NOW = INT32_MIN, FG_F_LTSV_NOVALUE and the failed-LTSV-row count, ent_used = RESERVED slots, fg_calibrate_device */
 
 typedef enum fg_format { FG_RFC5424 = 0, FG_LTSV = 1, FG_GELF = 2, FG_RFC3164 = 3 } fg_format;
 

@@ -103,7 +103,7 @@ def generate() -> str:
     known = {it[2][0] for it in items if it[1] in ("struct", "enum") and it[2][0]} | {it[2] for it in items if it[1] == "opaque"}
     out = []
     w = out.append
-    w("// fg-hip-sys: raw FFI declarations of libfg_hip.so (include/fg_hip.h, FG_ABI_VERSION 2).")
+    w("// fg-hip-sys: raw FFI declarations of libfg_hip.so (include/fg_hip.h, FG_ABI_VERSION 3).")
     w("// GENERATED by tools/gen_rust_ffi.py from the header -- do not edit; `python tools/gen_rust_ffi.py` rewrites it and")
     w("// tests/test_rust_ffi_cpu.py fails when this file and the header disagree.")
     w("//")
