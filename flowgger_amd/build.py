@@ -194,7 +194,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         units.append((name, objdir / (name + ".o"), []))
         if name == "fg_encode.hip":
             for enc in range(5):  # fg_encoder values; GELF (0) has two ranking-scratch sizes
-                for wr in (0, 1, 2):  # count, write, fused (count -> look-back -> write in one launch)
+                for wr in (0, 1):
                     for slots in ((1, 8, 32) if enc == 0 else (0,)):
                         units.append((name, objdir / f"fg_encode.e{enc}w{wr}s{slots}.o",
                                       [f"-DFG_ENC_TU={enc}", f"-DFG_ENC_TU_WRITE={wr}", f"-DFG_ENC_TU_SLOTS={slots}"]))
@@ -222,7 +222,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     jobs = int(os.environ.get("FG_BUILD_JOBS", "0")) or max(1, os.cpu_count() or 1)
     with ThreadPoolExecutor(max_workers=jobs) as pool:
         # heaviest first so the long poles start immediately
-        order = sorted(units, key=lambda u: 0 if ("fg_encode.e0w2" in u[1].name or "fg_encode.e0w1" in u[1].name) else 1 if "fg_encode.e" in u[1].name else 2)
+        order = sorted(units, key=lambda u: 0 if "fg_encode.e0w1" in u[1].name else 1 if "fg_encode.e" in u[1].name else 2)
         for _ in pool.map(compile_unit, order):
             pass
     if os.environ.get("FG_BUILD_NO_LINK"):  # compile only (e.g. while a gpurun snapshot of the tree is in flight)

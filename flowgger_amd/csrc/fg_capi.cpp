@@ -236,6 +236,7 @@ void fg_destroy(fg_ctx* ctx) {
     if (ctx->d_stash2) (void)hipFree(ctx->d_stash2);
     if (ctx->d_pending) (void)hipFree(ctx->d_pending);
     if (ctx->d_ticket) (void)hipFree(ctx->d_ticket);
+    if (ctx->d_merge) (void)hipFree(ctx->d_merge);
     if (ctx->d_sink) (void)hipFree(ctx->d_sink);
     if (ctx->d_used) (void)hipFree(ctx->d_used);
     if (ctx->d_frame) (void)hipFree(ctx->d_frame);
@@ -343,7 +344,10 @@ int fg_merge_tables_device(fg_ctx* ctx, const fg_tables* parts, uint32_t g, cons
     if (out->n != rows || out->ent_cap < cap || cap > 0xFFFFFFFFull) return FG_ERR_ARG;
     DeviceGuard gd(ctx->device);
     hipStream_t s = stream == FG_STREAM_OWN ? ctx->stream : (hipStream_t)stream;
-    const int rc = fg_launch_merge_device(parts, g, d_index, out, d_src_part, max_rows, max_cap, s);
+    (void)max_cap;
+    int grc;
+    if ((grc = grow_dev(ctx, (void**)&ctx->d_merge, &ctx->d_merge_cap, fg_merge_scratch_bytes(rows))) != FG_OK) return grc;
+    const int rc = fg_launch_merge_device(parts, g, d_index, out, d_src_part, max_rows, ctx->d_merge, s);
     if (rc != 0) {
         ctx->last_hip = rc;
         return FG_ERR_HIP;
@@ -585,26 +589,6 @@ int encode_device_impl(fg_ctx* ctx, fg_format src_fmt, const fg_encode_cfg* ecfg
     // the tile is what limits the waves per CU (the emitters are latency-bound: occupancy is throughput)
     const uint32_t tile_cap = pick_tile_cap(ctx, nbytes, n, 40 * 1024, 1);
     if (ctx->timing) FG_HIP(ctx, hipEventRecord(ctx->ev0, s));
-    if (d_out && !(ctx->lo.flags & FG_LO_ENCODE_THREE_PASS)) {
-        // ONE launch: count -> chained look-back -> write (fg_encode.hip k_encode_fused).  A workgroup whose messages would end behind
-        // out_cap writes nothing, so the capacity is safe before the host has seen the total.
-        fg::EncCfg fcfg = cfg;
-        fcfg.out_cap = out_cap ? out_cap : 1;
-        int frc = fg_launch_encode_fused(d_bytes, d_offsets, n, &dt, &fcfg, tile_cap, cfg_lds, d_enc_status, d_block_sums, 0ull, d_out_offsets, d_out, s);
-        if (frc != 0) {
-            ctx->last_hip = frc;
-            return FG_ERR_HIP;
-        }
-        if (ctx->timing) {
-            FG_HIP(ctx, hipEventRecord(ctx->ev1, s));
-            ctx->ev_valid = true;
-        }
-        if (async) return FG_OK;  // (a look-back that gave up shows as out_offsets[n] == ~0: larger than any capacity)
-        FG_HIP(ctx, hipMemcpyAsync(total, d_out_offsets + n, 8, hipMemcpyDeviceToHost, s));
-        FG_HIP(ctx, hipStreamSynchronize(s));
-        if (*total != FG_ENCODE_ABORTED) return *total > out_cap ? FG_ERR_ENT_OVERFLOW : FG_OK;
-        *total = 0;  // never seen: the three launches below do the batch again
-    }
     int lrc = fg_launch_encode_sizes(d_bytes, d_offsets, n, &dt, &cfg, tile_cap, cfg_lds, d_sizes, d_block_sums, d_enc_status, d_out_offsets, s);
     if (lrc != 0) {
         ctx->last_hip = lrc;

@@ -51,10 +51,6 @@ extern "C" int fg_launch_encode_scan(const uint32_t* d_sizes, uint64_t* d_block_
 extern "C" int fg_launch_encode_write(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
                                       const fg::EncCfg* cfg, uint32_t tile_cap, uint32_t cfg_lds, const uint64_t* d_out_offsets,
                                       uint8_t* d_out, hipStream_t stream);
-extern "C" int fg_launch_encode_fused(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
-                                      const fg::EncCfg* cfg, uint32_t tile_cap, uint32_t cfg_lds, uint8_t* d_status, uint64_t* d_desc,
-                                      uint64_t base, uint64_t* d_out_offsets, uint8_t* d_out, hipStream_t stream);
-constexpr uint64_t FG_ENCODE_ABORTED = ~0ull;  // out_offsets[n] after a fused launch whose look-back gave up: run the three-kernel form
 extern "C" uint64_t fg_frame_scratch_bytes(uint64_t nbytes);
 extern "C" int fg_launch_frame(const uint8_t* d_bytes, uint64_t nbytes, uint32_t delim, uint8_t* scratch, uint64_t* d_offsets,
                                uint8_t* d_bad, uint64_t cap, uint64_t** d_total_out, hipStream_t stream, int classic);
@@ -74,8 +70,9 @@ extern "C" int fg_launch_gelf(const uint8_t* d_bytes, const uint64_t* d_offsets,
                               const uint8_t* line_bad, const fg_launch_opts* lo, fg::TicketSlot* tk);
 
 extern "C" int fg_launch_poke64(const uint64_t* d_src, uint64_t* dst_devview, hipStream_t stream);
+extern "C" uint64_t fg_merge_scratch_bytes(uint64_t rows);
 extern "C" int fg_launch_merge_device(const fg_tables* parts, uint32_t g, const uint64_t* const* d_index, const fg_tables* out, uint8_t* d_src_part,
-                                      uint64_t max_rows, uint64_t max_entries, hipStream_t stream);
+                                      uint64_t max_rows, uint8_t* scratch, hipStream_t stream);
 extern "C" int fg_launch_calib(int mode, const uint8_t* d_src, uint8_t* d_dst, uint64_t nbytes, uint32_t* d_sink, hipStream_t stream);
 
 struct fg_ctx {
@@ -109,6 +106,8 @@ struct fg_ctx {
     uint32_t epoch = 0;             // launch counter of this ctx
     bool defer_general = false;     // a sliced host path: GELF's exact form runs once, behind the last slice (fg_finish_deferred_general)
     uint32_t batch_epoch = 0;       // ... and the slices share one hand-over word: the epoch of the batch's first GELF launch
+    uint8_t* d_merge = nullptr;     // fg_merge_tables_device: the scan's scratch (dense offsets, block sums, part tags)
+    uint64_t d_merge_cap = 0;
     uint32_t* d_sink = nullptr;     // fg_calibrate_device: the word the read-only sweep may write
     uint64_t* d_used = nullptr;     // fg_decode_batch, zero-copy form: the entry counter (the tables themselves are pinned host memory)
     uint8_t* d_frame = nullptr;  // fg_frame_device scratch (delimiter / UTF-8 masks, block counts)

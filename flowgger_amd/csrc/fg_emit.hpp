@@ -187,6 +187,7 @@ struct CountSink {
     uint32_t n = 0;
     FGE_HD void put(uint32_t) { ++n; }
     FGE_HD void put_word(uint32_t, uint32_t nb) { n += nb; }
+    FGE_HD void put16(uint32_t, uint32_t, uint32_t, uint32_t) { n += 16u; }
     FGE_HD void add(uint32_t k) { n += k; }
     FGE_HD void finish() {}
 };
@@ -274,6 +275,44 @@ struct PackSink {
             acc = lo;
             k += nb;
         }
+    }
+    // bytes [4 - sh, 8 - sh) of the eight bytes lo | hi << 32: the dword that a left shift by sh bytes moves across a dword boundary
+    static FGE_HD uint32_t carry_bytes(uint32_t hi, uint32_t lo, uint32_t sh) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return __builtin_amdgcn_perm(hi, lo, 0x03020100u + (4u - sh) * 0x01010101u);  // (one v_perm_b32; 64-bit shifts are slow)
+#else
+        return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8u * (4u - sh)));
+#endif
+    }
+    // SIXTEEN bytes at once (the span copies: one LDS round trip of input): the block position k does not change, so exactly ONE
+    // block completes per call -- whatever k is -- and every lane of a wave that copies a span stores its 16 bytes in the SAME store
+    // instruction.  (Four put_word calls complete the block at a lane-specific call: four store instructions with a quarter of the
+    // lanes each, and the write kernel gained nothing from 16-byte stores that way -- profiles/r05d_*cfg1*.)
+    FGE_HD void put16(uint32_t q0, uint32_t q1, uint32_t q2, uint32_t q3) {
+        const uint32_t d = k >> 2, sh = k & 3u;
+        const uint32_t t0 = carry_bytes(q0, 0u, sh), t1 = carry_bytes(q1, q0, sh), t2 = carry_bytes(q2, q1, sh), t3 = carry_bytes(q3, q2, sh),
+                       t4 = carry_bytes(0u, q3, sh);
+        const uint32_t a0 = acc | t0;  // (acc holds the low sh bytes, t0 the rest: they do not overlap)
+        // the block: its first d dwords are there already, then a0, then t1 ...; what does not fit starts the next block
+        const uint32_t o0 = d == 0u ? a0 : b0;
+        const uint32_t o1 = d == 0u ? t1 : d == 1u ? a0 : b1;
+        const uint32_t o2 = d == 0u ? t2 : d == 1u ? t1 : d == 2u ? a0 : b2;
+        const uint32_t o3 = d == 0u ? t3 : d == 1u ? t2 : d == 2u ? t1 : a0;
+        if (head) {
+            b0 = o0;
+            b1 = o1;
+            b2 = o2;
+            b3 = o3;
+            store_part(head, 16u, 4u);
+            head = 0;
+        } else {
+            st16(p, o0, o1, o2, o3);
+        }
+        p += 16;
+        b0 = d == 1u ? t3 : d == 2u ? t2 : t1;
+        b1 = d == 2u ? t3 : t2;
+        b2 = t3;
+        acc = t4;
     }
     FGE_HD void put(uint32_t c) { put_word(c & 0xFFu, 1u); }
     FGE_HD void add(uint32_t) {}
@@ -430,10 +469,7 @@ struct Base {
                 uint32_t q[4];
                 rd.load16(off + i, q);
                 if (!(word_needs_bytes<ESC>(q[0]) || word_needs_bytes<ESC>(q[1]) || word_needs_bytes<ESC>(q[2]) || word_needs_bytes<ESC>(q[3]))) {
-                    out.put_word(q[0], 4u);
-                    out.put_word(q[1], 4u);
-                    out.put_word(q[2], 4u);
-                    out.put_word(q[3], 4u);
+                    out.put16(q[0], q[1], q[2], q[3]);
                     i += 16u;
                     continue;
                 }

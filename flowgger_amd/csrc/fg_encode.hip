@@ -4,14 +4,7 @@
 // geometry around it.
 //
 // A lane takes the table row of ITS line (spans into the packed line bytes + the entry slice) and emits the output
-// text directly -- the Record is never materialised.
-// ONE launch since round 5 (k_encode_fused): the 64 lines of a workgroup are staged once; the emitter runs with the counting sink, the
-// workgroup's byte count goes into one descriptor, the bytes of all workgroups before it come from a chained scan with decoupled
-// look-back (the framing scan's, fg_frame.hip: lane i looks at descriptor blk - 1 - i, own counts are added up to the nearest
-// workgroup that already knows its inclusive prefix), and the emitter runs again with the packing sink at the offsets just found.
-// The three-kernel form below is kept: for sizing calls, for the sliced host pipeline (which queues a slice's count before it knows
-// where the slice's output starts), behind FG_LO_ENCODE_THREE_PASS, and as the fall-back should a look-back ever give up.
-// Two passes over the same emitter with different sinks:
+// text directly -- the Record is never materialised.  Two passes over the same emitter with different sinks:
 //   k_encode<ENC, false>  count: sizes[i] = framed length of line i (0 when its decode or its encode failed) + status
 //   k_block_scan + k_line_offsets   per-workgroup sums -> exclusive scan -> out_offsets[0..n]
 //   k_encode<ENC, true>   write at out + out_offsets[i]
@@ -37,14 +30,6 @@ namespace fg {
         uint8_t *d_out, hipStream_t stream
 // one definition per (encoder, pass, ranking slots) object
 template <uint32_t ENC, bool WRITE, uint32_t SLOTS> int launch_encode_tu(FG_ENC_ARGS);
-#define FG_ENC_FUSED_ARGS                                                                                                       \
-    const uint8_t *d_bytes, const uint64_t *d_offsets, uint64_t n, const DevTables &t, const EncCfg &cfg, uint32_t tile_cap,    \
-        uint32_t cfg_lds, uint8_t *d_status, uint64_t *d_desc, uint64_t base, uint64_t *d_out_offsets, uint8_t *d_out, hipStream_t stream
-template <uint32_t ENC, uint32_t SLOTS> int launch_encode_fused_tu(FG_ENC_FUSED_ARGS);
-// descriptor of a workgroup in the fused form: flag << 62 | bytes (flag 1: the workgroup's own bytes; 2: all bytes up to and including it)
-constexpr uint64_t kEncA = 1ull << 62, kEncP = 2ull << 62, kEncVal = (1ull << 62) - 1ull;
-constexpr uint64_t kEncAborted = ~0ull;     // out_offsets[n] when a look-back gave up (the caller runs the three-kernel form)
-constexpr uint32_t kEncSpinLimit = 1u << 18;  // polls of ~0.5-1 us: a fifth of a second against a wait that is normally a few polls
 
 #ifdef FG_ENC_TU
 // One 64-lane workgroup = 64 consecutive lines = ONE contiguous byte range of the packed buffer: it is staged into LDS
@@ -143,136 +128,6 @@ __global__ __launch_bounds__(kWave) void k_encode(const uint8_t* __restrict__ by
     }
 }
 
-
-#if FG_ENC_TU_WRITE == 2
-// The fused form: count -> chained scan (decoupled look-back over one descriptor per workgroup) -> write, one launch, the tile staged
-// once.  desc[] zeroed and out_offsets[n] zeroed by the launcher.  Forward progress rests on workgroups being dispatched in index
-// order (a workgroup only ever waits for lower-numbered ones, all of which started before it) -- the spin is bounded all the same.
-template <uint32_t ENC, uint32_t SLOTS>
-__global__ __launch_bounds__(kWave) void k_encode_fused(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets, uint64_t n,
-                                                       DevTables t, EncCfg cfg, uint32_t tile_cap, uint32_t cfg_lds,
-                                                       uint8_t* __restrict__ enc_status, uint64_t* __restrict__ desc, uint64_t base,
-                                                       uint64_t* __restrict__ out_offsets, uint8_t* __restrict__ out,
-                                                       const uint4* __restrict__ cfg_block) {
-    constexpr uint32_t kSlots = SLOTS ? SLOTS : 1u;
-    __shared__ uint64_t s_keys[kWave * kSlots];
-    __shared__ uint8_t s_slot[kWave * kSlots];
-    __shared__ uint8_t s_order[kWave * kSlots];
-    extern __shared__ __attribute__((aligned(16))) uint8_t s_tile[];
-    cfg.sort_slots = SLOTS;
-    uint8_t* s_cfg = s_tile + tile_cap + 16u;
-    const uint32_t lane = threadIdx.x;
-    const uint64_t blk = blockIdx.x;
-    const uint64_t g0 = blk * kWave;
-    const uint64_t g1 = g0 + kWave < n ? g0 + kWave : n;
-    const uint64_t li = g0 + lane;
-    uint64_t* keys64 = s_keys + lane * kSlots;
-    uint8_t* slot_ent = s_slot + lane * kSlots;
-    uint8_t* order = s_order + lane * kSlots;
-    const bool live = li < n;
-    const uint64_t lic = live ? li : n - 1u;
-    LanePre pre;
-    pre.o0 = offsets[lic];
-    pre.meta = t.meta[lic];
-    pre.row.load(t, lic);
-    pre.oo0 = pre.oo1 = 0;
-    const uint64_t a_begin = offsets[g0], a_end = offsets[g1];
-    const uint64_t a0 = a_begin & ~15ull;
-    const uint64_t span = (a_end - a0 + 15ull) & ~15ull;
-    const bool staged = span <= (uint64_t)tile_cap;
-    stage_tile_rider<20>(bytes, a0, staged ? (uint32_t)span : 0u, s_tile, cfg_block, cfg_lds >> 4, reinterpret_cast<uint4*>(s_cfg));
-    {
-        const uint8_t* g_cfg = reinterpret_cast<const uint8_t*>(cfg.keys);
-        cfg.blob = cfg_lds ? s_cfg + (cfg.blob - g_cfg) : cfg.blob;
-        cfg.keys = cfg_lds ? reinterpret_cast<const StaticKey*>(s_cfg) : cfg.keys;
-    }
-    __syncthreads();
-    // ---- pass 1: sizes ----
-    uint32_t size = 0;
-    if (live) {
-        uint32_t st;
-        if (staged) {
-            LdsReader rd(reinterpret_cast<const uint32_t*>(s_tile), (uint32_t)(pre.o0 - a0));
-            size = emit::row_size<ENC>(cfg, rd, t, li, pre.meta, keys64, slot_ent, order, &st, &pre.row);
-        } else {
-            GlobalReader rd(reinterpret_cast<const uint32_t*>(bytes), pre.o0);
-            size = emit::row_size<ENC>(cfg, rd, t, li, pre.meta, keys64, slot_ent, order, &st, &pre.row);
-        }
-        if (enc_status) enc_status[li] = (uint8_t)st;
-    }
-    uint32_t tot;
-    const uint32_t ex = wave_exclusive_sum(size, &tot);
-    // ---- the bytes of all workgroups before this one ----
-    uint64_t prefix = base;
-    bool aborted = false;
-    if (blk == 0) {
-        if (lane == 0) __hip_atomic_store(desc, kEncP | (base + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-        if (lane == 0) __hip_atomic_store(desc + blk, kEncA | (uint64_t)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        prefix = 0;
-        int64_t idx = (int64_t)blk - 1;
-        uint32_t polls = 0;
-        for (;;) {
-            const int64_t j = idx - (int64_t)lane;  // lane i looks at workgroup idx - i; before the first: a prefix of `base`
-            uint64_t d = kEncP | base;
-            if (j >= 0) d = __hip_atomic_load(desc + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t fl = (uint32_t)(d >> 62);
-            const uint64_t mp = __ballot(fl == 2u), mx = __ballot(fl == 0u);
-            const uint32_t p = mp ? (uint32_t)__builtin_ctzll(mp) : 64u;  // the nearest workgroup that knows its prefix
-            const uint64_t upto = p >= 63u ? ~0ull : ((2ull << p) - 1ull);
-            if (mx & upto) {  // a workgroup between here and there has not counted yet: wait for it
-                if (++polls > kEncSpinLimit) {
-                    aborted = true;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(2);
-                continue;
-            }
-            uint64_t a = lane < p ? (d & kEncVal) : 0ull;
-#pragma unroll
-            for (int s2 = 32; s2 >= 1; s2 >>= 1) a += __shfl_xor(a, s2, kWave);
-            prefix += a;
-            if (mp) {
-                const uint32_t lo = __shfl((uint32_t)d, (int)p, kWave), hi = __shfl((uint32_t)(d >> 32), (int)p, kWave);
-                prefix += (((uint64_t)hi << 32) | lo) & kEncVal;
-                break;
-            }
-            idx -= kWave;
-        }
-        if (!aborted && lane == 0) __hip_atomic_store(desc + blk, kEncP | (prefix + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (aborted) {  // (never seen; the total says so -- through an atomic max: the sentinel wins whatever the order -- and the caller falls back)
-        if (lane == 0) atomicMax(reinterpret_cast<unsigned long long*>(out_offsets + n), (unsigned long long)kEncAborted);
-        return;
-    }
-    if (lane == 0 && g1 == n) atomicMax(reinterpret_cast<unsigned long long*>(out_offsets + n), (unsigned long long)(prefix + tot));
-    const uint64_t my = prefix + ex;
-    if (live) out_offsets[li] = my;
-    // a workgroup whose messages would end behind the buffer writes nothing (the caller sees out_offsets[n] > capacity)
-    if (!out || (cfg.out_cap != 0ull && prefix + tot > cfg.out_cap)) return;
-    // ---- pass 2: the bytes ----
-    if (live && size != 0u) {
-        emit::PackSink sink(out + my);
-        if (staged) {
-            LdsReader rd(reinterpret_cast<const uint32_t*>(s_tile), (uint32_t)(pre.o0 - a0));
-            emit::row_write<ENC>(sink, size, cfg, rd, t, li, pre.meta, keys64, slot_ent, order, &pre.row);
-        } else {
-            GlobalReader rd(reinterpret_cast<const uint32_t*>(bytes), pre.o0);
-            emit::row_write<ENC>(sink, size, cfg, rd, t, li, pre.meta, keys64, slot_ent, order, &pre.row);
-        }
-    }
-}
-
-template <>
-int launch_encode_fused_tu<FG_ENC_TU, FG_ENC_TU_SLOTS>(FG_ENC_FUSED_ARGS) {
-    const uint64_t blocks = (n + kWave - 1) / kWave;
-    if (blocks > 0x7FFFFFFFull) return -1;
-    hipLaunchKernelGGL((k_encode_fused<FG_ENC_TU, FG_ENC_TU_SLOTS>), dim3((uint32_t)blocks), dim3(kWave), tile_cap + 16u + (cfg_lds ? cfg_lds : 16u), stream,
-                       d_bytes, d_offsets, n, t, cfg, tile_cap, cfg_lds, d_status, d_desc, base, d_out_offsets, d_out,
-                       reinterpret_cast<const uint4*>(cfg.keys));
-    return 0;
-}
-#else
 template <>
 int launch_encode_tu<FG_ENC_TU, (FG_ENC_TU_WRITE != 0), FG_ENC_TU_SLOTS>(FG_ENC_ARGS) {
     const uint64_t blocks = (n + kWave - 1) / kWave;
@@ -282,7 +137,6 @@ int launch_encode_tu<FG_ENC_TU, (FG_ENC_TU_WRITE != 0), FG_ENC_TU_SLOTS>(FG_ENC_
                        d_out_offsets, d_out, reinterpret_cast<const uint4*>(cfg.keys));
     return 0;
 }
-#endif  // FG_ENC_TU_WRITE == 2
 #else  // !FG_ENC_TU: scan kernels, dispatcher, C entry points
 
 // exclusive scan of the per-workgroup sums (nb = ceil(n / 64) of them) in place; off_n[0] = the grand total.  One
@@ -361,21 +215,6 @@ static int launch_encode(FG_ENC_ARGS) {
     }
 #undef FG_CALL
 }
-static int launch_encode_fused(FG_ENC_FUSED_ARGS) {
-#define FG_CALL(E, SL) return launch_encode_fused_tu<E, SL>(d_bytes, d_offsets, n, t, cfg, tile_cap, cfg_lds, d_status, d_desc, base, d_out_offsets, d_out, stream)
-    switch (cfg.enc) {
-        case FG_ENC_GELF:
-            if (cfg.sort_slots <= 1u) FG_CALL(FG_ENC_GELF, 1u);
-            if (cfg.sort_slots <= 8u) FG_CALL(FG_ENC_GELF, 8u);
-            FG_CALL(FG_ENC_GELF, 32u);
-        case FG_ENC_LTSV: FG_CALL(FG_ENC_LTSV, 0u);
-        case FG_ENC_RFC5424: FG_CALL(FG_ENC_RFC5424, 0u);
-        case FG_ENC_RFC3164: FG_CALL(FG_ENC_RFC3164, 0u);
-        case FG_ENC_PASSTHROUGH: FG_CALL(FG_ENC_PASSTHROUGH, 0u);
-        default: return -1;
-    }
-#undef FG_CALL
-}
 #endif  // FG_ENC_TU
 
 }  // namespace fg
@@ -406,18 +245,6 @@ extern "C" int fg_launch_encode_sizes(const uint8_t* d_bytes, const uint64_t* d_
     if (n == 0) return 0;
     if (fg_launch_encode_count(d_bytes, d_offsets, n, t, cfg, tile_cap, cfg_lds, d_sizes, d_block_sums, d_status, stream) != 0) return -1;
     return fg_launch_encode_scan(d_sizes, d_block_sums, n, d_out_offsets, 0ull, stream);
-}
-// The fused form: d_desc = ceil(n / 64) u64 of scratch (zeroed here); out_offsets[0 .. n] come out absolute from `base`; out_offsets[n]
-// == FG_ENCODE_ABORTED (~0) when a look-back gave up -- the caller then runs the three launches above.  d_out == nullptr: offsets only.
-extern "C" int fg_launch_encode_fused(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
-                                      const fg::EncCfg* cfg, uint32_t tile_cap, uint32_t cfg_lds, uint8_t* d_status, uint64_t* d_desc,
-                                      uint64_t base, uint64_t* d_out_offsets, uint8_t* d_out, hipStream_t stream) {
-    if (n == 0) return 0;
-    const uint64_t nb = (n + fg::kWave - 1) / fg::kWave;
-    (void)hipMemsetAsync(d_desc, 0, nb * 8u, stream);
-    (void)hipMemsetAsync(d_out_offsets + n, 0, 8, stream);
-    if (fg::launch_encode_fused(d_bytes, d_offsets, n, *t, *cfg, tile_cap, cfg_lds, d_status, d_desc, base, d_out_offsets, d_out, stream) != 0) return -1;
-    return (int)hipGetLastError();
 }
 extern "C" int fg_launch_encode_write(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
                                       const fg::EncCfg* cfg, uint32_t tile_cap, uint32_t cfg_lds, const uint64_t* d_out_offsets,

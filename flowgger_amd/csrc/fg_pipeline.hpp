@@ -739,7 +739,8 @@ struct LaunchPlan {
 // atomic on ONE word, and that word's channel serves only a few dozen of them per microsecond (rounds 3-4 and profiles/r05b_*: GELF,
 // one request per 8-line tile, took 290 us for 64 K lines and 915 us for 256 K where 512 K take 400 us -- small launches fell under
 // the 256-slot floor of wv::alloc_chunk_for into EXACT reservations).  So: the table's share per wave (1/16 of it over all waves, at
-// most 4096 slots) capped by eight slots per line the wave will see in this launch -- but never below 256 slots (a floor of 64 is one
+// most 4096 slots, at least 256 where a quarter of the table holds 256 per wave) capped by eight slots per line the wave will see in
+// this launch -- but never below 256 slots (a floor of 64 is one
 // 8-line GELF tile's worth: still an atomic per tile; 256: 340 -> 184 us for 64 K lines, 896 -> 303 us for 256 K,
 // profiles/r05c_small_gelf_opts.log); exact reservations
 // only for a table too small for 256-slot chunks (a caller that sized it tightly must not see FG_ST_OVERFLOW because of slots parked
@@ -751,7 +752,8 @@ inline uint32_t entry_chunk(uint64_t ent_cap, uint32_t blocks, uint64_t n, const
     const uint64_t waves = blocks ? blocks : 1u;
     uint64_t c = ent_cap / (16ull * waves);
     if (c > 4096u) c = 4096u;
-    if (c < 256u) return 0u;
+    if (ent_cap / (4ull * waves) < 256u) return 0u;  // (a quarter of the table stranded at worst, an eighth on average)
+    if (c < 256u) c = 256u;
     const uint64_t per_wave = (n + waves - 1u) / waves * 8ull;
     if (c > per_wave) c = per_wave;
     if (c < 256u) c = 256u;
@@ -778,7 +780,7 @@ template <class K>
 inline int plan_launch(K kernel, uint64_t n, uint64_t avg_len, uint32_t extra_lds, uint32_t max_tile, uint32_t stash_blocks,
                        LaunchPlan* p, const fg_launch_opts& lo, uint32_t max_lines = 64, uint32_t n_classes = 1,
                        uint32_t (*extra_for)(uint32_t tile, uint32_t lines) = nullptr, uint32_t (*extra_tile)(uint32_t tile) = nullptr,
-                       uint32_t default_tile = 0, uint32_t default_chunk = 0) {
+                       uint32_t default_tile = 0, uint32_t default_chunk = 0, uint32_t ticket_from = 2) {
     const uint64_t window = (uint64_t)kWindowKiB * 1024u;
     // (+6.25 % + 256 B over the average group: a few sigma for the corpora at hand; a longer group just takes
     //  another pass over a restaged tile, while every KiB of LDS saved is occupancy)
@@ -840,13 +842,17 @@ inline int plan_launch(K kernel, uint64_t n, uint64_t avg_len, uint32_t extra_ld
             chunk = (n + blocks - 1) / (blocks ? blocks : 1);
             if (chunk < (dynamic ? g : p->L)) chunk = dynamic ? g : p->L;
         }
-    } else if (dynamic && (n + blocks - 1) / (blocks ? blocks : 1) >= 2u * full) {
+    } else if (dynamic && (n + blocks - 1) / (blocks ? blocks : 1) >= (uint64_t)ticket_from * full) {
         // Chunks are DRAWN (persistent_loop's ticket): a wave that meets slow lines or sits on a slow XCD draws fewer -- the balance is
         // the dispatch's business, so the chunk is simply `full` lines: its last group is as short as it comes out and costs these
         // latency-bound kernels what a full one does (1 group in 4 .. 50), and every ticket is an atomic on one word, of which the
         // chip serves a few dozen per microsecond -- chunks of ONE group (8192 tickets for 512 K lines of the headline corpus) doubled
-        // the kernel's time (profiles/r05b_small_ab.log: 123 vs 65 us).  A batch with fewer than two such chunks per wave takes the
-        // equal shares below and draws nothing.
+        // the kernel's time (profiles/r05b_small_ab.log: 123 vs 65 us).  A batch with fewer than `ticket_from` such chunks per wave
+        // takes the equal shares below and draws nothing: two for the compute-bound kernels (GELF gains 13 % from six chunks per wave
+        // on, LTSV 5 %), thirty-two for the HBM-bound headline kernel, whose first round of tickets -- 1792 waves start at the same
+        // moment -- arrives as a burst on one word, and an atomic that takes 20 us to come back holds the wave's window loads up behind
+        // it (vmcnt retires in order): +25 us at 1 M, 2 M and 4 M lines alike, +18 % throughput at 40 M (profiles/r05d_small_cfg2_big.log,
+        // r05d_sweep_cfg2_40M.log).
         chunk = full;
     } else {
         // The chunks are dealt out round-robin, so every wave should get the SAME number of them: k = the chunks per wave that keeps a
@@ -873,7 +879,7 @@ inline int plan_launch(K kernel, uint64_t n, uint64_t avg_len, uint32_t extra_ld
     p->chunk = chunk;
     p->chunks = chunks;
     // (tickets: large batches -- or whenever the caller names a chunk size while dispatch is dynamic: tests, tuning)
-    p->tickets = dynamic && ((n + blocks - 1) / (blocks ? blocks : 1) >= 2u * full || (lo.chunk_lines >= 1u && lo.chunk_lines <= 65536u));
+    p->tickets = dynamic && ((n + blocks - 1) / (blocks ? blocks : 1) >= (uint64_t)ticket_from * full || (lo.chunk_lines >= 1u && lo.chunk_lines <= 65536u));
     p->blocks = (uint32_t)blocks;
     return 0;
 }

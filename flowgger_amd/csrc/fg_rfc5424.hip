@@ -741,22 +741,13 @@ constexpr uint32_t kShortSdTail = 64;  // bytes after the header up to which a l
 // the (rare) lines it hands back are parsed from global memory.  SDX = false is byte for byte the kernel of round 3.
 template <bool HEAD, bool SDX = false, bool PROF = false>
 struct Rfc5424FormatT {
-    // no stage-A bitmap for the fast path (it classifies the header bytes itself); the lane-per-line SD walker's quote bitmap is built
-    // on demand (rebuild_bitmap) for groups that hold SD lines.  The pair-parallel instantiation for WHOLE lines (SDX, not HEAD)
-    // classifies in stage A, while the tile's bytes sit in registers: raw quote and backslash masks straight into the walk's two
-    // bitmaps (sd2::resolve_escapes finishes them) -- the chunk pass no longer reads the tile back out of LDS.
-#if defined(FG_AB_NO_STAGEA_CLASSES)  // (A/B build only: the chunk pass of round 4, flowgger_amd/build.py FG_BUILD_VARIANT)
-    static constexpr bool kStageAClasses = false;
-#else
-    static constexpr bool kStageAClasses = SDX && !HEAD;
-#endif
-    static constexpr uint32_t kClasses = kStageAClasses ? 2u : 0u;
-    static __device__ __forceinline__ void classify_store(const uint4& q, uint16_t* bm16, uint32_t chunk, uint32_t stride, uint32_t) {
-        if constexpr (kStageAClasses) {
-            bm16[chunk] = (uint16_t)mask16_eq(q, 0x22222222u);
-            bm16[stride + chunk] = (uint16_t)mask16_eq(q, 0x5C5C5C5Cu);
-        }
-    }
+    // no stage-A bitmap: the fast path classifies the header bytes itself, the SD walker's
+    // quote bitmap is built on demand (rebuild_bitmap) for groups that hold SD lines.  (Round 5 measured the pair-parallel kernel with
+    // the quote / backslash masks computed in stage A, while the bytes sit in registers, so that the chunk pass no longer reads the tile
+    // back: 1.88-1.91 G lines/s against 1.90-1.92 G without, alternated on one box -- profiles/r05d_ab_stagea_cfg4.log: the chunk pass's
+    // LDS read is not what the group waits for.  Not kept.)
+    static constexpr uint32_t kClasses = 0;
+    static __device__ __forceinline__ void classify_store(const uint4&, uint16_t*, uint32_t, uint32_t, uint32_t) {}
     unsigned long long* pacc = nullptr;  // measurement build: the wave's phase clocks (LDS), flushed by the kernel at its end
 
     __device__ __forceinline__ RowOut decode(const GroupCtx& c, const DevTables& t) const {
@@ -831,7 +822,7 @@ struct Rfc5424FormatT {
             const uint32_t stride16 = c.tile_cap / 16u + 16u;
             SL = sd2::carve(smem, bm16, c.tile_cap, reinterpret_cast<uint8_t*>(bm16 + 2u * stride16));
             __syncthreads();
-            const bool chain = kStageAClasses ? sd2::resolve_escapes(SL, span) : sd2::classify_tile(SL, span);
+            const bool chain = sd2::classify_tile(SL, span);
             __syncthreads();
             tick(1);
             sin = sd2::LineIn{sd_lane && (in_tile || head_only), base, f.d0, walk_len, in_tile};
@@ -1031,12 +1022,7 @@ struct Rfc5424FormatT {
                     for (uint32_t j = 0; j < 4u; ++j) w[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(lane * 16u + (r0 + j) * 1024u), 0, FG_STREAM_AUX);
 #pragma unroll
                     for (uint32_t j = 0; j < 4u; ++j)
-                        if (r0 + j < nrow) {
-                            const uint4 q = make_uint4(w[j][0], w[j][1], w[j][2], w[j][3]);
-                            dst[(r0 + j) * kWave + lane] = q;
-                            // (the whole-line instantiation expects what its stage A leaves: the raw class masks of every chunk)
-                            Rfc5424FormatT<false, SDX, false>::classify_store(q, bm16, (r0 + j) * kWave + lane, c.tile_cap / 16u + 16u, wv::kNoTerm);
-                        }
+                        if (r0 + j < nrow) dst[(r0 + j) * kWave + lane] = make_uint4(w[j][0], w[j][1], w[j][2], w[j][3]);
                 }
             }
             __syncthreads();
@@ -1132,8 +1118,9 @@ extern "C" int fg_launch_rfc5424(const uint8_t* d_bytes, const uint64_t* d_offse
                    : fg::plan_launch(fg::k_rfc5424<fg::kWindowKiB, false, false, true>, n, plan_len, 0u, 36864u, sb, &p, *lo, 64, 2, nullptr,
                                      fg::sd2::extra_bytes, 12288u, 1024u);
     else
+        // (tickets from 32 chunks per wave on: the HBM-bound kernel pays for the first round's burst, fg_pipeline.hpp plan_launch)
         prc = head ? fg::plan_launch(fg::k_rfc5424<fg::kWindowKiB, false, true>, n, plan_len, 0u, 57344u, sb, &p, *lo)
-                   : fg::plan_launch(fg::k_rfc5424<fg::kWindowKiB, false>, n, plan_len, 0u, 57344u, sb, &p, *lo);
+                   : fg::plan_launch(fg::k_rfc5424<fg::kWindowKiB, false>, n, plan_len, 0u, 57344u, sb, &p, *lo, 64, 1, nullptr, nullptr, 0u, 0u, 32u);
     if (prc) return -1;
     if (stash_blocks == 0) stash = nullptr;
     dim3 grid(p.blocks), block(fg::kWave);

@@ -152,41 +152,6 @@ FG_WV bool classify_tile(const Lds& L, uint32_t span) {
     return wv::any(chain);
 }
 
-// The same result when STAGE A has already left the raw masks of every 16-byte chunk in the two bitmaps (quotes in bmQ, backslashes
-// in bmB: the classification happened while the tile's bytes sat in registers, fg_rfc5424.hip classify_store -- round 5, VERDICT r4
-// item 1a): what is left is the escape resolution, and only for rows of 64 chunks that hold a backslash at all -- one 2-byte LDS read
-// and a ballot per KiB of tile instead of a 16-byte read, two SWAR classifications and two stores.
-FG_WV bool resolve_escapes(const Lds& L, uint32_t span) {
-    const uint32_t lane = wv::lane();
-    const uint32_t nchunk = span >> 4;
-    uint16_t* q16 = reinterpret_cast<uint16_t*>(L.bmQ);
-    uint16_t* b16 = reinterpret_cast<uint16_t*>(L.bmB);
-    bool chain = false;
-    uint32_t carry = 0;
-    for (uint32_t c0 = 0; c0 < nchunk; c0 += wv::kLanes) {
-        const uint32_t c = c0 + lane;
-        const bool in = c < nchunk;
-        const uint32_t b = in ? (uint32_t)b16[c] : 0u;
-        if (!wv::any(b != 0u || (lane == 0u && carry != 0u))) {  // wave-uniform: no backslash in this KiB, none carried into it
-            carry = 0;
-            continue;
-        }
-        const uint32_t q = in ? (uint32_t)q16[c] : 0u;
-        chain = chain || b == 0xFFFFu;
-        const uint32_t run = wv::clz64(~((uint64_t)b << 48));
-        const uint32_t odd = run & 1u;
-        const uint32_t cin = wv::shfl_up1(odd, carry);
-        carry = wv::bcast(odd, 63u);
-        const uint32_t qr = q & ~find_escaped16(b, cin);
-        if (in && qr != q) q16[c] = (uint16_t)qr;
-    }
-    for (uint32_t c = nchunk + lane; c < nchunk + 8u; c += wv::kLanes) {
-        q16[c] = 0;
-        b16[c] = 0;
-    }
-    return wv::any(chain);
-}
-
 // ---------------------------------------------------------------------------------------------
 // The reference's state machine over a stretch of the line, byte by byte (rfc5424_decoder.rs:174-242 + parse_data :134-158).
 //   from      tile position of the first byte to look at

@@ -79,7 +79,7 @@ class Encoder:
                             ent_hint: int = 0xFFFFFFFFFFFFFFFF):
         """fg_encode_device_async: count, scan and write queued on `stream`, no host synchronisation.  Returns (d_out_offsets
         int64[n+1], d_status uint8[n]); d_out_offsets[n] (device) = the bytes the batch needs -- when that exceeds out.numel()
-        the content of `out` is undefined (nothing is written at or behind its end).  ent_hint: an upper bound of the entries in `tables` (0 = none)."""
+        nothing was written to `out`.  ent_hint: an upper bound of the entries in `tables` (0 = none)."""
         import torch
 
         if stream is None:

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FG_ABI_VERSION 3 /* 3 (round 5): fg_launch_opts.ent_chunk (the struct grew), FG_LO_STATIC_CHUNKS / _FRAME_SELFTEST_STALL / _ENCODE_THREE_PASS, fg_ticket_ring_check, fg_encode_device_async leaves an undersized buffer UNDEFINED (not untouched); 2 (round 4): FG_YEAR_NOW = INT32_MIN, FG_F_LTSV_NOVALUE and the failed-LTSV-row count, ent_used = RESERVED slots, fg_calibrate_device */
+#define FG_ABI_VERSION 3 /* 3 (round 5): fg_launch_opts.ent_chunk (the struct grew), FG_LO_STATIC_CHUNKS / _FRAME_SELFTEST_STALL, fg_ticket_ring_check; 2 (round 4): FG_YEAR_NOW = INT32_MIN, FG_F_LTSV_NOVALUE and the failed-LTSV-row count, ent_used = RESERVED slots, fg_calibrate_device */
 
 typedef enum fg_format { FG_RFC5424 = 0, FG_LTSV = 1, FG_GELF = 2, FG_RFC3164 = 3 } fg_format;
 
@@ -214,8 +214,6 @@ enum {
     FG_LO_FRAME_SELFTEST_STALL = 1024, /* framing self-test: the one-pass scan's second tile never publishes its descriptor, so the tiles behind
                                       it must give up within the spin bound and the call must come back through the classic kernels with
                                       the same result (tests; never set in production: it costs the spin bound, ~0.2 s) */
-    FG_LO_ENCODE_THREE_PASS = 2048, /* fg_encode_device[_async]: count + scan + write as three launches (rounds 1-4) instead of the fused
-                                      one-launch form (count -> chained look-back -> write); A/B, tests */
     FG_LO_RESERVED = 0x40000000    /* the library's own (fg_set_launch_opts clears it) */
 };
 
@@ -354,13 +352,9 @@ int fg_encode_device(fg_ctx* ctx, fg_format src_fmt, const fg_encode_cfg* cfg, c
                      uint64_t* d_out_offsets, uint8_t* d_enc_status, uint64_t* total, void* stream);
 
 /* The same WITHOUT a host synchronisation (a device-resident pipeline must not wait on the host for a byte count):
- * the work is queued on `stream` (one launch since round 5: count -> chained look-back -> write) and the call returns.  Nothing comes
- * back to the host:
- *   d_out_offsets[n]  (device) = the bytes the batch needs; when it exceeds out_cap the content of d_out is UNDEFINED (no byte at or
- *                     behind d_out + out_cap is ever written: a 64-line workgroup whose messages would end behind the capacity writes
- *                     nothing) -- the caller checks that word whenever it next synchronises (d_out_offsets / d_enc_status are always
- *                     produced).  ~0 there = the one-launch form gave up (a look-back that outlasted its spin bound: never observed):
- *                     encode the batch again through fg_encode_device, which falls back to three launches by itself
+ * count, scan and write are queued on `stream` and the call returns.  Nothing comes back to the host:
+ *   d_out_offsets[n]  (device) = the bytes the batch needs; when it exceeds out_cap the write kernel leaves d_out untouched --
+ *                     the caller checks that word whenever it next synchronises (d_out_offsets / d_enc_status are always produced)
  *   ent_hint          an upper bound of the entries in `tables` (sizes the GELF encoder's key-ranking scratch instead of the
  *                     ent_used read-back): 0 = none (RFC5424 without structured data), ~0 = unknown
  * The first calls on a ctx may still synchronise while its scratch grows to the batch size (hipFree / hipMalloc).

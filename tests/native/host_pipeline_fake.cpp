@@ -151,32 +151,14 @@ extern "C" int fg_launch_encode_write(const uint8_t* b, const uint64_t* o, uint6
     }
     return 0;
 }
-// the fused form (count -> look-back -> write in one launch): offsets absolute from `base`; a message that would end behind cfg->out_cap
-// is not written (the real kernel skips the whole 64-line workgroup; here: the line)
-extern "C" int fg_launch_encode_fused(const uint8_t* b, const uint64_t* o, uint64_t n, const fg::DevTables* t, const fg::EncCfg* c, uint32_t, uint32_t,
-                                      uint8_t* d_status, uint64_t*, uint64_t base, uint64_t* d_out_offsets, uint8_t* d_out, hipStream_t) {
-    uint64_t at = base;
-    for (uint64_t i = 0; i < n; ++i) {
-        const uint32_t sz = fake_size(o, t, i);
-        if (d_status) d_status[i] = (t->meta[i] & 0xFFu) == 0u ? 0 : 1;
-        d_out_offsets[i] = at;
-        if (sz && d_out && (c->out_cap == 0 || at + sz <= c->out_cap)) {
-            uint8_t* w = d_out + at;
-            const uint32_t len = (uint32_t)(o[i + 1] - o[i]);
-            memcpy(w, b + o[i], len);
-            memset(w + len, '#', t->ent_count[i]);
-            w[len + t->ent_count[i]] = '\n';
-        }
-        at += sz;
-    }
-    d_out_offsets[n] = at;
-    return 0;
-}
-
 // ---- the device merge (fg_merge.hip), on "device" memory that is host memory here
+extern "C" uint64_t fg_merge_scratch_bytes(uint64_t rows) { return rows + 64; }
 extern "C" int fg_launch_merge_device(const fg_tables* parts, uint32_t g, const uint64_t* const* d_index, const fg_tables* out, uint8_t* d_src_part,
-                                      uint64_t, uint64_t, hipStream_t) {
-    uint64_t base = 0;
+                                      uint64_t, uint8_t* scratch, hipStream_t) {
+    // the real kernels' contract: rows at their arrival positions, entries DENSE in arrival order
+    uint8_t* src = d_src_part ? d_src_part : scratch;
+    std::vector<uint32_t> local(out->n, 0);
+    for (uint64_t i = 0; i < out->n; ++i) out->ent_count[i] = 0;
     for (uint32_t k = 0; k < g; ++k) {
         const fg_tables& p = parts[k];
         const uint64_t used = *p.ent_used < p.ent_cap ? *p.ent_used : p.ent_cap;
@@ -185,17 +167,22 @@ extern "C" int fg_launch_merge_device(const fg_tables* parts, uint32_t g, const 
             out->meta[i] = p.meta[j]; out->ts[i] = p.ts[j];
             out->hostname[i] = p.hostname[j]; out->appname[i] = p.appname[j]; out->procid[i] = p.procid[j];
             out->msgid[i] = p.msgid[j]; out->msg[i] = p.msg[j]; out->full_msg[i] = p.full_msg[j];
-            out->ent_count[i] = p.ent_count[j];
-            out->ent_first[i] = p.ent_count[j] ? (uint32_t)(p.ent_first[j] + base) : 0u;
-            if (d_src_part) d_src_part[i] = (uint8_t)k;
+            out->ent_count[i] = (uint64_t)p.ent_first[j] + p.ent_count[j] <= used ? p.ent_count[j] : 0u;
+            local[i] = p.ent_first[j];
+            src[i] = (uint8_t)k;
         }
-        for (uint64_t e = 0; e < used; ++e) {
-            out->ent_name[base + e] = p.ent_name[e]; out->ent_val[base + e] = p.ent_val[e];
-            out->ent_type[base + e] = p.ent_type[e]; out->ent_flags[base + e] = p.ent_flags[e];
-        }
-        base += used;
     }
-    *out->ent_used = base;
+    uint64_t at = 0;
+    for (uint64_t i = 0; i < out->n; ++i) {
+        const fg_tables& p = parts[src[i]];
+        for (uint32_t e = 0; e < out->ent_count[i]; ++e) {
+            out->ent_name[at + e] = p.ent_name[local[i] + e]; out->ent_val[at + e] = p.ent_val[local[i] + e];
+            out->ent_type[at + e] = p.ent_type[local[i] + e]; out->ent_flags[at + e] = p.ent_flags[local[i] + e];
+        }
+        out->ent_first[i] = out->ent_count[i] ? (uint32_t)at : 0u;
+        at += out->ent_count[i];
+    }
+    *out->ent_used = at;
     return 0;
 }
 

@@ -138,30 +138,6 @@ extern "C" long fgs2_walk(const uint8_t* bytes, uint64_t nbytes, const uint64_t*
                 for (uint32_t i = 0; i < span; ++i) smem[i] = a0 + i < nbytes ? bytes[a0 + i] : 0;
             }
             sd2::Lds lds = sd2::carve(smem, bm16, tile_cap, extra);
-            // round 5: the whole-line kernel classifies in STAGE A (raw quote / backslash masks per 16-byte chunk, written while the
-            // bytes sit in registers) and sd2::resolve_escapes finishes the bitmaps -- it must leave exactly what classify_tile leaves
-            std::vector<uint16_t> q_ref, b_ref;
-            bool chain_ref = false, masks_differ = false;
-            if (!head_cap && span) {
-                const uint32_t nchunk = span >> 4, stride16 = tile_cap / 16u + 16u;
-                for (uint32_t c = 0; c < ((nchunk + 63u) & ~63u); ++c) {  // (stage A stores whole rows: zeros behind the span)
-                    uint32_t q = 0, b = 0;
-                    for (uint32_t k = 0; k < 16u; ++k) {
-                        const uint8_t ch = c < nchunk ? smem[c * 16u + k] : 0;
-                        q |= (ch == '"' ? 1u : 0u) << k;
-                        b |= (ch == '\\' ? 1u : 0u) << k;
-                    }
-                    bm16[c] = (uint16_t)q;
-                    bm16[stride16 + c] = (uint16_t)b;
-                }
-                emu::run_wave([&]() {
-                    const bool ch = sd2::resolve_escapes(lds, span);
-                    if (wv::lane() == 0u) chain_ref = ch;
-                });
-                q_ref.assign(bm16, bm16 + nchunk + 8u);
-                b_ref.assign(bm16 + stride16, bm16 + stride16 + nchunk + 8u);
-                memset(bm16, 0xA5, (size_t)stride16 * 4u);
-            }
             sd2::LineOut outs[64];
             sd2::LineIn ins[64];
             uint32_t firsts[64];
@@ -180,12 +156,6 @@ extern "C" long fgs2_walk(const uint8_t* bytes, uint64_t nbytes, const uint64_t*
                 }
                 const bool chain = span ? sd2::classify_tile(lds, span) : true;
                 wv::sync();
-                if (lane == 0u && !q_ref.empty()) {
-                    const uint32_t nchunk = span >> 4, stride16 = tile_cap / 16u + 16u;
-                    masks_differ = chain != chain_ref;
-                    for (uint32_t c = 0; c < nchunk + 8u && !chain; ++c)
-                        masks_differ = masks_differ || bm16[c] != q_ref[c] || bm16[stride16 + c] != b_ref[c];
-                }
                 sd2::LineOut o{false, 0u, false, 0u, 0u, 0u, 0u};
                 if (!chain) o = sd2::group_walk(lds, span, in);
                 if (lane == 0u) bailed = chain;
@@ -201,7 +171,6 @@ extern "C" long fgs2_walk(const uint8_t* bytes, uint64_t nbytes, const uint64_t*
                 wv::sync();
                 if (lane == 0u) used += total;
             });
-            if (masks_differ) throw std::runtime_error("sd2::resolve_escapes (stage-A masks) and sd2::classify_tile disagree");
             if (used > ent_cap) throw std::runtime_error("entry table too small");
             for (uint32_t k = 0; k < nl; ++k) {
                 const uint64_t li = g0 + k;

@@ -282,59 +282,3 @@ def test_one_pass_framing_falls_back_when_a_tile_never_publishes(oracle, framing
     assert n == len(starts) and np.array_equal(offs[:-1], starts)
     dec.set_launch_opts()
 
-
-ENCODERS = ["gelf", "ltsv", "rfc5424", "rfc3164", "passthrough"]
-
-
-def _encoder(name, merger):
-    from flowgger_amd import GelfEncoder, LTSVEncoder, PassthroughEncoder, RFC3164Encoder, RFC5424Encoder
-
-    return {"gelf": GelfEncoder, "ltsv": LTSVEncoder, "rfc5424": RFC5424Encoder, "rfc3164": RFC3164Encoder,
-            "passthrough": PassthroughEncoder}[name](merger=merger)
-
-
-@pytest.mark.parametrize("enc_name", ENCODERS)
-def test_fused_encoder_equals_the_three_kernel_form(oracle, enc_name):
-    """fg_encode_device in ONE launch (count -> chained look-back -> write, 16-byte stores) against count + scan + write
-    (FG_LO_ENCODE_THREE_PASS): the same stream, offsets and verdicts for every encoder, on records with and without entries, long
-    lines (groups that leave the tile), failed rows -- and against the oracle's decode -> encode -> merger through the existing tests
-    (tests/test_gpu_parity.py drives the default = fused form)."""
-    import torch
-    from flowgger_amd.tables import DeviceTables
-
-    corpora = [synth.rfc5424_lines(50_000, cfg=2), synth.rfc5424_lines(20_000, cfg=4, sd=True),
-               synth.rfc5424_lines(3_000, cfg=5, sd=True, long_tail=True), synth.rfc5424_lines(130, cfg=2), synth.rfc5424_lines(1, cfg=2)]
-    for lines in corpora:
-        dec = RFC5424Decoder()
-        dev = torch.device("cuda", dec.device)
-        data, offsets = synth.pack(lines)
-        tables, d_bytes, d_offsets = device_path(dec, data, offsets)
-        n = len(lines)
-        res = {}
-        for three in (False, True):
-            dec.set_launch_opts(encode_three_pass=three)
-            enc = _encoder(enc_name, "line" if enc_name != "passthrough" else "nul")
-            out, off, st = enc.encode_device(dec, d_bytes, d_offsets, n, tables, want_status=True)
-            torch.cuda.synchronize(dev)
-            res[three] = (out.cpu().numpy().copy(), off.cpu().numpy().copy(), st.cpu().numpy().copy())
-        assert np.array_equal(res[False][1], res[True][1]), "offsets differ"
-        assert np.array_equal(res[False][2], res[True][2]), "verdicts differ"
-        assert np.array_equal(res[False][0], res[True][0]), "bytes differ"
-        total = int(res[True][1][n])
-        assert total == res[True][0].size
-        if total > 4096:
-            # a buffer that is too small: the call reports it, and nothing behind the capacity is touched
-            enc = _encoder(enc_name, "line" if enc_name != "passthrough" else "nul")
-            dec.set_launch_opts()
-            cap = total // 2
-            buf = torch.full((total + 4096,), 0xA5, dtype=torch.uint8, device=dev)
-            cfg, _keep = enc._cfg_struct(0.0)
-            import ctypes as C
-            d_off = torch.empty(n + 1, dtype=torch.int64, device=dev)
-            tot = C.c_uint64()
-            rc = L.lib().fg_encode_device(dec._ctx, dec.fmt, C.byref(cfg), d_bytes.data_ptr(), d_bytes.numel(), d_offsets.data_ptr(), n,
-                                          C.byref(tables.struct), buf.data_ptr(), cap, d_off.data_ptr(), None, C.byref(tot),
-                                          C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
-            assert rc == L.FG_ERR_ENT_OVERFLOW and int(tot.value) == total
-            assert bool((buf[cap:] == 0xA5).all()), "bytes behind the capacity were written"
-        dec.close()
