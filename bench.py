@@ -72,6 +72,13 @@ def parse_args():
     ap.add_argument("--spawn", action="store_true",
                     help="launch the ranks through torch.distributed.run even for --gpus 1 (the path --gpus N>1 takes by itself "
                          "when WORLD_SIZE is not set)")
+    ap.add_argument("--launcher", default="auto", choices=["auto", "torchrun", "threads"],
+                    help="--gpus N > 1 without an external launcher: torchrun = re-exec under torch.distributed.run (one PROCESS per GPU, "
+                         "RCCL); threads = N host threads of THIS process, one ctx per thread on its own device (no torch.distributed: "
+                         "barriers and reductions are thread barriers -- the lines shard without a data-path collective, so nothing else is "
+                         "needed); auto = torchrun, and threads when that launch fails (VERDICT r4 item 10)")
+    ap.add_argument("--thread-devices", default=None,
+                    help="threads launcher: the device of every thread, e.g. 0,0 to run two ranks on ONE GPU (tests on a 1-GPU box)")
     ap.add_argument("--line-len", type=int, nargs=2, default=None, metavar=("LO", "HI"),
                     help="cfg2 only: uniform line-length range instead of 192..320 (tuning experiments)")
     ap.add_argument("--invalid-frac", type=float, default=0.01, help="share of invalid lines in the tile (SURVEY 8d: 1 %%)")
@@ -192,6 +199,61 @@ class Dist:
         if self.on:
             self.dist.barrier()
             self.dist.destroy_process_group()
+
+
+class ThreadDist:
+    """--launcher threads: the same interface as Dist for N host threads of one process (one rank per thread, each on its own device
+    with its own ctx -- the concurrency contract fg_clone is tested for, tcp_input.rs:39-47: one decoder clone per connection thread)."""
+
+    def __init__(self, dev, world, rank, shared):
+        import torch
+
+        self.torch, self.dev, self.world, self.rank, self.sh = torch, dev, world, rank, shared
+        self.on, self.gpu, self.threads = world > 1, True, True
+
+    def barrier(self):
+        self.torch.cuda.synchronize(self.dev)
+        self.sh["barrier"].wait()
+
+    def all(self, vals):
+        self.sh["slots"][self.rank] = [float(v) for v in vals]
+        self.sh["barrier"].wait()
+        res = [list(v) for v in self.sh["slots"]]
+        self.sh["barrier"].wait()
+        return res
+
+    def max(self, v: float) -> float:
+        return max(r[0] for r in self.all([v]))
+
+    def close(self):
+        self.sh["barrier"].wait()
+
+
+def run_threads(args) -> int:
+    """N ranks as N threads of this process.  Rank 0 prints the JSON line; an exception in any rank aborts the barrier for all."""
+    import threading
+
+    devs = [int(d) for d in args.thread_devices.split(",")] if args.thread_devices else list(range(args.gpus))
+    assert len(devs) == args.gpus, "--thread-devices must name one device per rank"
+    shared = {"barrier": threading.Barrier(args.gpus), "slots": [None] * args.gpus}
+    errors = []
+
+    def rank_main(rank):
+        try:
+            main(args, thread_rank=(rank, devs[rank], shared))
+        except BaseException as e:  # noqa: BLE001
+            errors.append((rank, e))
+            shared["barrier"].abort()
+
+    ts = [threading.Thread(target=rank_main, args=(r,), name=f"rank{r}") for r in range(args.gpus)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for rank, e in errors:
+        if not isinstance(e, threading.BrokenBarrierError):
+            print(f"rank {rank}: {e!r}", file=sys.stderr)
+    return 1 if errors else 0
 
 
 def pinned(nbytes, dt):
@@ -633,9 +695,18 @@ def dry_run(args):
     D.close()
 
 
-def main():
-    args = parse_args()
-    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
+def main(args=None, thread_rank=None):
+    if args is None:
+        args = parse_args()
+    if thread_rank is None and "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn) and not args.dry_run_backend:
+        if args.launcher == "threads":
+            raise SystemExit(run_threads(args))
+        rc = self_launch(args)
+        if rc != 0 and args.launcher == "auto" and args.gpus > 1:
+            print(f"bench.py: torch.distributed.run exited with {rc}: running the {args.gpus} ranks as threads of one process", file=sys.stderr)
+            rc = run_threads(args)
+        raise SystemExit(rc)
+    if thread_rank is None and "WORLD_SIZE" not in os.environ and args.dry_run_backend and (args.gpus > 1 or args.spawn):
         raise SystemExit(self_launch(args))
     if args.dry_run_backend:
         return dry_run(args)
@@ -643,14 +714,18 @@ def main():
 
     from flowgger_amd import synth
 
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0")) if thread_rank is None else thread_rank[1]
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the decode path has no CPU fallback")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     all_cpus = os.sched_getaffinity(0)
-    numa = bind_to_gpu_numa_node(local)
-    D = Dist(dev)
+    if thread_rank is None:
+        numa = bind_to_gpu_numa_node(local)
+        D = Dist(dev)
+    else:  # (CPU affinity is the process's: threads are not bound)
+        numa = {"numa_node": None, "note": "threads launcher: ranks are threads of one process, not bound"}
+        D = ThreadDist(dev, args.gpus, thread_rank[0], thread_rank[2])
     world, rank = D.world, D.rank
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     opts = {k: int(v) for k, v in (kv.split("=") for kv in args.launch_opts.split(",") if kv)}
@@ -799,22 +874,26 @@ def main():
         t0 = time.perf_counter()
         hmerged, hsrc = shard.merge_tables(parts, index, out=hmerged, src=hsrc)
         host_merge_ms = (time.perf_counter() - t0) * 1e3
-        assert np.array_equal(hsrc, src) and np.array_equal(hmerged.a["meta"][:n], merged.a["meta"][:n]) and hmerged.ent_used == merged.ent_used
-        assert np.array_equal(hmerged.a["ent_first"][:n], merged.a["ent_first"][:n])
+        # (round 5: the device merge compacts the entries -- dense, arrival order --, the host merge keeps the parts' layouts)
+        assert np.array_equal(hsrc, src) and np.array_equal(hmerged.a["meta"][:n], merged.a["meta"][:n])
+        assert np.array_equal(hmerged.a["ent_count"][:n], merged.a["ent_count"][:n])
+        assert merged.ent_used == int(merged.a["ent_count"][:n].astype(np.int64).sum()) <= hmerged.ent_used
         # spot check: rows went back where they came from
         for k, s_ in enumerate(subs):
             j = np.array([0, s_.n_tile // 2, s_.n - 1])
             assert np.array_equal(merged.a["meta"][index[k][j].astype(np.int64)], parts[k].a["meta"][j])
         table_bytes = int(merged.n) * 68 + int(merged.ent_used) * 18
         gather = {"gather_ms": d2h_ms + merge_ms, "d2h_ms": d2h_ms, "merge_ms": merge_ms, "merge_kernel_ms": merge_kernel_ms,
-                  "host_merge_ms": host_merge_ms, "rows": int(merged.n),
+                  "host_merge_ms": host_merge_ms, "rows": int(merged.n), "entries_before_compaction": int(hmerged.ent_used),
                   "entries": int(merged.ent_used), "table_bytes": table_bytes, "d2h_GBps": table_bytes / (d2h_ms * 1e-3) / 1e9,
                   "lines_per_s": n / ((d2h_ms + merge_ms) * 1e-3),
-                  "what": "fg_merge_tables_device (rows back to their arrival positions, entries rebased, in HBM) + D2H of the ONE merged table "
+                  "what": "fg_merge_tables_device (rows back to their arrival positions, entries compacted into arrival order, in HBM) + D2H of the ONE merged table "
                           "into pinned memory (whole resident batch); host_merge_ms = fg_merge_tables on the host's cores, what rounds 2-3 "
                           "added to a D2H of the same size"}
         del hmerged
-        if D.on:  # N ranks: the ranks' merged tables -> one table on rank 0, in rank (= shard) order
+        if D.on and getattr(D, "threads", False):
+            gather["ranks_what"] = "threads launcher: the ranks' tables are in one address space -- no rank gather"
+        elif D.on:  # N ranks: the ranks' merged tables -> one table on rank 0, in rank (= shard) order
             D.barrier()
             t0 = time.perf_counter()
             full = shard.gather_distributed(merged, dst=0)
@@ -873,7 +952,8 @@ def main():
             },
             "ranks": {"n": len(rank_ms), "kernel_ms": rank_ms, "kernel_ms_min": min(rank_ms), "kernel_ms_max": max(rank_ms),
                       "numa": numa,
-                      "launcher": "self (torch.distributed.run)" if os.environ.get("FG_BENCH_SPAWNED") else
+                      "launcher": "threads (one process, one thread and ctx per GPU)" if thread_rank is not None else
+                                  "self (torch.distributed.run)" if os.environ.get("FG_BENCH_SPAWNED") else
                                   "external (WORLD_SIZE set)" if "WORLD_SIZE" in os.environ else "single process"},
         }
         if opts:

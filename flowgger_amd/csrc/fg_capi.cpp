@@ -438,6 +438,7 @@ int fg_decode_frames_impl(fg_ctx* ctx, fg_format fmt, fg_framing framing, const 
         FG_HIP(ctx, hipMemset(ctx->d_pending, 0, kPendingRing * sizeof(uint32_t)));
     }
     fg_launch_opts lo_call = ctx->lo;
+    if (ctx->link_bound_waves && lo_call.waves_per_cu == 0) lo_call.waves_per_cu = ctx->link_bound_waves;
     if (ctx->defer_general && fmt == FG_GELF) {
         // the slices of one batch: one hand-over word for all of them, the exact form once behind the last (fg_finish_deferred_general)
         if (!ctx->batch_epoch) {
@@ -470,11 +471,11 @@ int fg_decode_frames_impl(fg_ctx* ctx, fg_format fmt, fg_framing framing, const 
     switch (fmt) {
         case FG_RFC5424:
             rc = fg_launch_rfc5424(d_bytes, d_offsets, n, &dt, avg_len, s, stash, ctx->stash_blocks, (uint32_t)framing,
-                                   d_bad_utf8, &ctx->lo, tk);
+                                   d_bad_utf8, &lo_call, tk);
             break;
         case FG_LTSV:
             rc = fg_launch_ltsv(d_bytes, d_offsets, n, &dt, &ctx->ltsv, avg_len, s, stash, ctx->stash_blocks,
-                                (uint32_t)framing, d_bad_utf8, &ctx->lo, tk);
+                                (uint32_t)framing, d_bad_utf8, &lo_call, tk);
             break;
         case FG_GELF:
             rc = fg_launch_gelf(d_bytes, d_offsets, n, &dt, avg_len, s, stash, ctx->stash_blocks,

@@ -85,6 +85,8 @@ struct fg_ctx {
     hipEvent_t ev_ready = nullptr;
     int last_hip = 0;
     fg_launch_opts lo{};  // launch-geometry overrides (fg_set_launch_opts); all zero = the library's own choices
+    uint32_t link_bound_waves = 0;  // host pipelines whose tables lie across the link: waves per CU of the decode grid for the duration of
+                                    // a call, where the caller's options leave the choice to the library (fg_host_pipeline.cpp LinkBoundGrid)
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;

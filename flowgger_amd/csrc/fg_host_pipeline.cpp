@@ -156,15 +156,10 @@ static int pinned_tables_for_kernels(fg_ctx* ctx, const fg_tables& ht, fg_tables
 // every wave slot taken, 129 M at eight waves per CU; fg_decode_batch 151 -> 161 M (profiles/r04w_frame_overlap.log; the other formats'
 // kernels hold eight waves or fewer anyway).  For the duration of a host pipeline the grid is capped at eight, unless the caller set
 // its own figure (fg_set_launch_opts).
-struct LinkBoundGrid {
+struct LinkBoundGrid {  // (a per-call cap beside the caller's launch options, never written into them: ADVICE r4)
     fg_ctx* ctx;
-    bool set;
-    explicit LinkBoundGrid(fg_ctx* c) : ctx(c), set(c->lo.waves_per_cu == 0) {
-        if (set) ctx->lo.waves_per_cu = 8;
-    }
-    ~LinkBoundGrid() {
-        if (set) ctx->lo.waves_per_cu = 0;
-    }
+    explicit LinkBoundGrid(fg_ctx* c) : ctx(c) { ctx->link_bound_waves = 8; }
+    ~LinkBoundGrid() { ctx->link_bound_waves = 0; }
 };
 
 static int decode_batch_zero_copy(fg_ctx* ctx, fg_format fmt, const uint8_t* bytes, uint64_t nbytes, const uint64_t* offsets, uint64_t n,
@@ -173,9 +168,19 @@ static int decode_batch_zero_copy(fg_ctx* ctx, fg_format fmt, const uint8_t* byt
     LinkBoundGrid grid(ctx);
     const uint8_t* d_bytes = (const uint8_t*)device_view_of_pinned(bytes);
     const uint64_t* d_offsets = (const uint64_t*)device_view_of_pinned(offsets);
-    if (!d_bytes || !d_offsets || ((uintptr_t)d_bytes & 15u) != 0 || !device_view_of_pinned(bytes + nbytes - 1) ||
-        !device_view_of_pinned(offsets + n))
-        return FG_ERR_UNSUPPORTED;
+    if (!d_bytes || !d_offsets || ((uintptr_t)d_bytes & 15u) != 0) return FG_ERR_UNSUPPORTED;
+    {
+        // ONE mapping with a constant device-view delta from the first byte to the last the kernels touch (the first and
+        // the last byte of two adjacent registrations both qualify, the bytes between their device views need not be contiguous).
+        // The kernels' 16-byte loads reach up to nbytes rounded up to 16 (include/fg_hip.h: the packed buffer must be readable that far):
+        // that byte must be part of the same mapping too.
+        const uint8_t* last_b = bytes + ((nbytes + 15u) & ~15ull) - 1u;
+        const uint8_t* dv_last_b = (const uint8_t*)device_view_of_pinned(last_b);
+        const uint8_t* dv_last_o = (const uint8_t*)device_view_of_pinned(offsets + n);
+        if (!dv_last_b || !dv_last_o || dv_last_b - d_bytes != last_b - bytes ||
+            dv_last_o - (const uint8_t*)d_offsets != (const uint8_t*)(offsets + n) - (const uint8_t*)offsets)
+            return FG_ERR_UNSUPPORTED;
+    }
     int rc;
     uint64_t ent_cap = fmt == FG_RFC5424 ? nbytes / 16 + 1024 : nbytes / 8 + 1024;
     if (fmt == FG_RFC3164) ent_cap = 16;  // RFC3164 produces no entries

@@ -275,7 +275,10 @@ int fg_decode_frames_device(fg_ctx* ctx, fg_format fmt, fg_framing framing, cons
  * the next call on this ctx or fg_destroy).  Synchronous.  Entry-table capacity grows automatically.
  *   `bytes` AND `offsets` in PINNED memory (fg_alloc_pinned / hipHostRegister: where the batching framer accumulates lines),
  *   bytes 16-byte aligned: ZERO-COPY -- one launch, the kernels read the lines in place over the link and write the table columns
- *   straight into the pinned tables, both directions of the link busy at once;
+ *   straight into the pinned tables, both directions of the link busy at once.  The kernels load 16 bytes at a time: the pinned
+ *   mapping must be READABLE UP TO nbytes ROUNDED UP TO 16 (fg_alloc_pinned memory is; a hipHostRegister'ed range must include
+ *   those bytes), and bytes[0 .. that) and offsets[0 .. n] must each lie in ONE mapping -- buffers that do not qualify (the library
+ *   checks the device view of the first and the last byte it will touch) silently take the sliced path below;
  *   anything else: the batch goes up as ~32 MiB slices on three streams (H2D, kernels, D2H of the tables), at the runtime's
  *   staged-copy speed for pageable memory. */
 int fg_decode_batch(fg_ctx* ctx, fg_format fmt, const uint8_t* bytes, uint64_t nbytes,
@@ -460,9 +463,11 @@ int fg_shard_plan(const uint64_t* offsets, uint64_t n, uint32_t g, uint64_t* lin
  *                     returns the total bytes (call with out == NULL to size), negative FG_ERR_* on bad arguments */
 int fg_gather_size(const fg_tables* parts, uint32_t g, uint64_t* n_rows, uint64_t* n_entries);
 /* fg_merge_tables ON THE DEVICE (round 4): the parts' tables, index[k] and `out` are device memory (the sub-batches' tables as
- * fg_decode_batch_device left them, at most 8 parts); the rows go back to their arrival positions and the entry columns behind one
- * another while everything is still in HBM -- ONE merged table then crosses the link instead of g tables plus a pass of the host's
- * cores over all of them.  Asynchronous on `stream`; the parts' entry counters are read on the device.  out->n must be the sum of the
+ * fg_decode_batch_device left them, at most 8 parts); the rows go back to their arrival positions while everything is still in HBM --
+ * ONE merged table then crosses the link instead of g tables plus a pass of the host's cores over all of them.  Round 5: the merged
+ * ENTRIES are DENSE and in ARRIVAL order (row i's slice starts where row i-1's ends; ent_used = the sum of ent_count): the slots the
+ * decoders' waves reserved but never used -- they lie between the slices of a decoder's own table -- do not cross the link.
+ * Asynchronous on `stream`; the parts' entry counters are read on the device.  out->n must be the sum of the
  * parts' rows and out->ent_cap at least the sum of their ent_cap (checked); out->ent_used receives the merged entry count;
  * d_src_part (device, may be NULL) as src_part of fg_merge_tables.  The indices are the caller's contract (every position once). */
 int fg_merge_tables_device(fg_ctx* ctx, const fg_tables* parts, uint32_t g, const uint64_t* const* d_index, const fg_tables* out,

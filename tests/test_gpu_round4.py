@@ -349,14 +349,22 @@ def test_device_merge_of_tagged_sub_batches_equals_the_host_merge():
     out, d_src = shard.merge_tables_device(decs[0], dparts, d_index)
     torch.cuda.synchronize(dev)
     got = out.to_host_pinned()
-    assert got.n == want.n == n and got.ent_used == want.ent_used
+    assert got.n == want.n == n
     assert np.array_equal(d_src.cpu().numpy(), tag) and np.array_equal(wsrc, tag)
-    for col in ("meta", "ts", "hostname", "appname", "procid", "msgid", "msg", "full_msg", "ent_first", "ent_count"):
+    for col in ("meta", "ts", "hostname", "appname", "procid", "msgid", "msg", "full_msg", "ent_count"):
         assert np.array_equal(got.a[col][: n * (2 if got.a[col].size >= 2 * n else 1)], want.a[col][: n * (2 if want.a[col].size >= 2 * n else 1)]), col
-    u = want.ent_used
+    # round 5: the device merge lays the entries out DENSE and in arrival order (the host merge keeps each part's layout, stranded
+    # reservations included): same entries per row, different places
+    cnt = want.a["ent_count"][:n].astype(np.int64)
+    assert got.ent_used == int(cnt.sum()) <= want.ent_used
+    dense = np.concatenate([[0], np.cumsum(cnt)[:-1]])
+    assert np.array_equal(got.a["ent_first"][:n][cnt > 0].astype(np.int64), dense[cnt > 0])
+    take = np.repeat(want.a["ent_first"][:n].astype(np.int64) - dense, cnt) + np.arange(int(cnt.sum()))
     for col, w in (("ent_name", 2), ("ent_val", 1), ("ent_type", 1), ("ent_flags", 1)):
-        assert np.array_equal(got.a[col][: u * w], want.a[col][: u * w]), col
+        g_ = got.a[col][: got.ent_used * w].reshape(-1, w)
+        w_ = want.a[col][: want.ent_used * w].reshape(-1, w)[take]
+        assert np.array_equal(g_, w_), col
     # a second merge into the same output (a framer merges batch after batch into the same memory)
     out2, _ = shard.merge_tables_device(decs[0], dparts, d_index, out=out, d_src=d_src)
     torch.cuda.synchronize(dev)
-    assert out2 is out and out.to_host_pinned().ent_used == want.ent_used
+    assert out2 is out and out.to_host_pinned().ent_used == int(cnt.sum())

@@ -282,3 +282,23 @@ def test_one_pass_framing_falls_back_when_a_tile_never_publishes(oracle, framing
     assert n == len(starts) and np.array_equal(offs[:-1], starts)
     dec.set_launch_opts()
 
+
+def test_bench_threads_launcher_runs_two_ranks_in_one_process():
+    """bench.py --gpus 2 --launcher threads (the fall-back when torch.distributed.run cannot be used on the
+    driver's node): two ranks as two threads of one process, each with its own ctx -- here both on device 0 --, barriers and
+    max-over-ranks through thread barriers; rank 0 prints one JSON line for the whole job."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--launcher", "threads", "--thread-devices", "0,0",
+                        "--tile-lines", "50000", "--reps", "4", "--steps", "3", "--warmup", "1", "--no-legs", "--no-mix",
+                        "--no-cpu-baseline", "--no-e2e", "--no-calib"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks"]["n"] == 2 and d["ranks"]["launcher"].startswith("threads")
+    assert d["config"]["lines_per_gpu"] == 200_000 and d["value"] > 0
