@@ -58,10 +58,26 @@ __device__ __forceinline__ void encode_lane(R rd, uint64_t li, const DevTables& 
     }
 }
 
+// A group whose bytes exceed the tile (long lines: rare) reads from global memory.  ITS OWN FUNCTION, NOT INLINED, everything BY VALUE
+// (round 5): inlined, this instantiation of the emitters kept the emitter, the sink and -- through the references the emitter holds --
+// the kernel's DevTables and EncCfg arguments in scratch memory for the WHOLE kernel (four allocas survive in the optimised IR;
+// 1489 of the write kernel's 1939 scratch instructions belong to this path), and the hot path then fetched every table column
+// pointer and configuration field from the stack copy: ~60 extra VMEM reads per wave, each of which waits behind the wave's
+// outstanding output stores (vmcnt counts both) -- profiles/r05f_pmc_encode_*.json: the write kernel spent half its wave-cycles waiting.
+template <uint32_t ENC, bool WRITE>
+__device__ __attribute__((noinline)) uint32_t encode_lane_global(const uint8_t* bytes, uint64_t li, DevTables t, EncCfg cfg, uint64_t* keys64,
+                                                                 uint8_t* slot_ent, uint8_t* order, uint32_t* sizes, uint8_t* enc_status,
+                                                                 LanePre pre, uint8_t* out) {
+    uint32_t size = 0;
+    GlobalReader rd(reinterpret_cast<const uint32_t*>(bytes), pre.o0);
+    encode_lane<ENC, WRITE>(rd, li, t, cfg, keys64, slot_ent, order, sizes, enc_status, pre, out, &size);
+    return size;
+}
+
 // SLOTS = per-lane entries of the GELF key-ranking scratch (0 for the other encoders); cfg_lds = bytes of the
 // configuration block [static keys | blob] to mirror in LDS (0: read it from global memory).
 template <uint32_t ENC, bool WRITE, uint32_t SLOTS>
-__global__ __launch_bounds__(kWave) void k_encode(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets, uint64_t n,
+__global__ __launch_bounds__(kWave, 2) void k_encode(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets, uint64_t n,
                                                  DevTables t, EncCfg cfg, uint32_t tile_cap, uint32_t cfg_lds, uint32_t* __restrict__ sizes,
                                                  uint8_t* __restrict__ enc_status, uint64_t* __restrict__ block_sums,
                                                  const uint64_t* __restrict__ out_offsets, uint8_t* __restrict__ out,
@@ -117,8 +133,7 @@ __global__ __launch_bounds__(kWave) void k_encode(const uint8_t* __restrict__ by
             encode_lane<ENC, WRITE>(rd, li, t, cfg, keys64, slot_ent, order, sizes, enc_status, pre, out, &size);
         }
     } else if (live) {
-        GlobalReader rd(reinterpret_cast<const uint32_t*>(bytes), pre.o0);
-        encode_lane<ENC, WRITE>(rd, li, t, cfg, keys64, slot_ent, order, sizes, enc_status, pre, out, &size);
+        size = encode_lane_global<ENC, WRITE>(bytes, li, t, cfg, keys64, slot_ent, order, sizes, enc_status, pre, out);
     }
     if (!WRITE) {  // the 64 lines of this workgroup: one partial sum for the offset scan
         uint64_t sum = size;

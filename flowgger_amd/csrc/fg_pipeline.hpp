@@ -849,10 +849,10 @@ inline int plan_launch(K kernel, uint64_t n, uint64_t avg_len, uint32_t extra_ld
         // chip serves a few dozen per microsecond -- chunks of ONE group (8192 tickets for 512 K lines of the headline corpus) doubled
         // the kernel's time (profiles/r05b_small_ab.log: 123 vs 65 us).  A batch with fewer than `ticket_from` such chunks per wave
         // takes the equal shares below and draws nothing: two for the compute-bound kernels (GELF gains 13 % from six chunks per wave
-        // on, LTSV 5 %), thirty-two for the HBM-bound headline kernel, whose first round of tickets -- 1792 waves start at the same
+        // on, LTSV 5 %), twenty for the HBM-bound headline kernel, whose first round of tickets -- 1792 waves start at the same
         // moment -- arrives as a burst on one word, and an atomic that takes 20 us to come back holds the wave's window loads up behind
-        // it (vmcnt retires in order): +25 us at 1 M, 2 M and 4 M lines alike, +18 % throughput at 40 M (profiles/r05d_small_cfg2_big.log,
-        // r05d_sweep_cfg2_40M.log).
+        // it (vmcnt retires in order): +25 us at 1 M, 2 M and 4 M lines alike, +12 % throughput at 16 M, +18 % at 40 M
+        // (profiles/r05d_small_cfg2_big.log, r05e_small.log, r05d_sweep_cfg2_40M.log).
         chunk = full;
     } else {
         // The chunks are dealt out round-robin, so every wave should get the SAME number of them: k = the chunks per wave that keeps a
@@ -861,11 +861,13 @@ inline int plan_launch(K kernel, uint64_t n, uint64_t avg_len, uint32_t extra_ld
         // 0.69 -> 0.88 G with one even chunk per wave, profiles/r04z3_sweep_cfg4.log, r04z5_sweep_cfg5.log.)
         const uint64_t per_wave = (n + blocks - 1) / (blocks ? blocks : 1);
         if (dynamic) {
-            // (round 5) equal shares of [full, 2 full) lines -- one or two ragged groups per wave instead of up to k -- and no floor of
-            // L lines: a small batch is cut down to ONE average group per wave (16 K structured-data lines, 21 to the group, ran as 256
-            // waves of three groups each on a grid of 2048: 84 us where 65 do, profiles/r05a_small.log / r05b_small_ab.log)
-            const uint64_t k = per_wave / full ? per_wave / full : 1u;
-            chunk = (per_wave + k - 1) / k;
+            // (round 5) ONE chunk per wave, the wave's whole share: a single ragged group per wave, and no floor of L lines -- a small
+            // batch is cut down to one average group per wave (16 K structured-data lines, 21 to the group, ran as 256 waves of three
+            // groups each on a grid of 2048: 84 us where 47 do).  Same box, alternated, against the k equal chunks of <= `full` lines
+            // of rounds 3-4 (profiles/r05f_small_cfg2_chunks.log, r05f_sweep_4M_chunks.log): headline corpus 1 M lines 97 vs 104 us,
+            // 4 M 340 vs 335; structured data 256 K / 512 K / 4 M lines 194 / 328 us / 1.91 G against 195 / 330 us / 1.89 G; GELF and LTSV
+            // alike.  (The sweep-front-to-back argument for many chunks per wave is a large batch's: that regime draws tickets.)
+            chunk = per_wave;
             const uint64_t unit = g >= p->L ? g : (g * 15u / 16u ? g * 15u / 16u : 1u);
             if (chunk < unit) chunk = unit;
         } else {
