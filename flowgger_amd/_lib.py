@@ -150,6 +150,8 @@ def lib() -> C.CDLL:
     L.fg_ordered_merge.argtypes = [u32, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp, u64, vp]
     L.fg_ordered_merge.restype = C.c_int64
     L.fg_ticket_ring_check.argtypes = [vp]
+    L.fg_set_pinned_limits.argtypes = [u64, u64]
+    L.fg_pinned_stats.argtypes = [C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     L.fg_set_timing.argtypes = [vp, C.c_int]
     L.fg_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.fg_frame_decode_batch.argtypes = [vp, C.c_int, C.c_int, vp, u64, C.c_int, C.POINTER(fg_tables), C.POINTER(vp),

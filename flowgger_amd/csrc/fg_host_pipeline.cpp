@@ -10,13 +10,123 @@
 
 extern "C" {
 
+// ---- the batch buffers' allocator: page-locked memory through a process-wide POOL (a framer pinned max_bytes + 1 MiB per
+// run(), i.e. per connection -- a thread-per-connection server with hundreds of clients pinned gigabytes and paid milliseconds of
+// pin / unpin per connect).  A freed block is kept (up to `idle_limit` bytes in total) and handed to the next request it fits; the
+// bytes pinned through this allocator are capped (`limit`): beyond the cap a request gets PAGEABLE memory -- fg_decode_batch and the
+// raw-stream paths take either (pinned: zero-copy / link-speed uploads; pageable: the runtime's staged copies).
+}  // extern "C"
+#include <map>
+#include <mutex>
+namespace {
+struct PinnedPool {
+    std::mutex mu;
+    std::map<void*, std::pair<uint64_t, bool>> live;  // block -> (capacity, pinned?)
+    std::multimap<uint64_t, void*> idle;              // pinned blocks nobody holds, by capacity
+    uint64_t pinned_bytes = 0, idle_bytes = 0;
+    uint64_t limit = 1ull << 30, idle_limit = 256ull << 20;
+};
+PinnedPool& pinned_pool() {
+    static PinnedPool* p = new PinnedPool();  // (never destroyed: no HIP calls from static destructors at process exit)
+    return *p;
+}
+}  // namespace
+extern "C" {
+
 int fg_alloc_pinned(uint64_t bytes, void** out) {
     if (!out) return FG_ERR_ARG;
     *out = nullptr;
-    return hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? FG_OK : FG_ERR_HIP;
+    const uint64_t need = up(bytes ? bytes : 1, 64u << 10);
+    PinnedPool& P = pinned_pool();
+    {
+        std::lock_guard<std::mutex> g(P.mu);
+        auto it = P.idle.lower_bound(need);
+        if (it != P.idle.end() && it->first <= 2u * need + (1u << 20)) {  // (a block of at most twice the size: no 64 MiB block for a 64 KiB request)
+            void* p = it->second;
+            const uint64_t cap = it->first;
+            P.idle.erase(it);
+            P.idle_bytes -= cap;
+            P.live[p] = {cap, true};
+            *out = p;
+            return FG_OK;
+        }
+        if (P.pinned_bytes + need > P.limit) {
+            // over the cap: what is idle goes first, then pageable memory
+            while (!P.idle.empty() && P.pinned_bytes + need > P.limit) {
+                auto last = std::prev(P.idle.end());
+                (void)hipHostFree(last->second);
+                P.pinned_bytes -= last->first;
+                P.idle_bytes -= last->first;
+                P.idle.erase(last);
+            }
+            if (P.pinned_bytes + need > P.limit) {
+                void* p = aligned_alloc(4096, (size_t)need);
+                if (!p) return FG_ERR_NOMEM;
+                P.live[p] = {need, false};
+                *out = p;
+                return FG_OK;
+            }
+        }
+        P.pinned_bytes += need;  // (reserved before the slow call, outside the lock)
+    }
+    void* p = nullptr;
+    if (hipHostMalloc(&p, need, hipHostMallocDefault) != hipSuccess || !p) {
+        (void)hipGetLastError();
+        std::lock_guard<std::mutex> g(P.mu);
+        P.pinned_bytes -= need;
+        return FG_ERR_HIP;
+    }
+    std::lock_guard<std::mutex> g(P.mu);
+    P.live[p] = {need, true};
+    *out = p;
+    return FG_OK;
 }
 void fg_free_pinned(void* p) {
-    if (p) (void)hipHostFree(p);
+    if (!p) return;
+    PinnedPool& P = pinned_pool();
+    bool unpin = false;
+    {
+        std::lock_guard<std::mutex> g(P.mu);
+        auto it = P.live.find(p);
+        if (it == P.live.end()) return;  // (not ours)
+        const uint64_t cap = it->second.first;
+        const bool pinned = it->second.second;
+        P.live.erase(it);
+        if (!pinned) {
+            free(p);
+            return;
+        }
+        if (P.idle_bytes + cap <= P.idle_limit) {
+            P.idle.emplace(cap, p);
+            P.idle_bytes += cap;
+        } else {
+            P.pinned_bytes -= cap;
+            unpin = true;
+        }
+    }
+    if (unpin) (void)hipHostFree(p);
+}
+int fg_set_pinned_limits(uint64_t total_bytes, uint64_t idle_bytes) {
+    PinnedPool& P = pinned_pool();
+    std::lock_guard<std::mutex> g(P.mu);
+    P.limit = total_bytes;
+    P.idle_limit = idle_bytes;
+    while (!P.idle.empty() && P.idle_bytes > P.idle_limit) {
+        auto last = std::prev(P.idle.end());
+        (void)hipHostFree(last->second);
+        P.pinned_bytes -= last->first;
+        P.idle_bytes -= last->first;
+        P.idle.erase(last);
+    }
+    return FG_OK;
+}
+int fg_pinned_stats(uint64_t* pinned_bytes, uint64_t* idle_bytes, uint64_t* live_blocks) {
+    PinnedPool& P = pinned_pool();
+    std::lock_guard<std::mutex> g(P.mu);
+    if (pinned_bytes) *pinned_bytes = P.pinned_bytes;
+    if (idle_bytes) *idle_bytes = P.idle_bytes;
+    if (live_blocks) *live_blocks = P.live.size();
+    return FG_OK;
 }
 
 // Streams and events of the pipelined host paths (created on first use).  Three roles, each its own stream, chained by events per slice:

@@ -399,9 +399,15 @@ typedef struct fg_transcoded {
 int fg_transcode_batch(fg_ctx* ctx, fg_format fmt, fg_framing framing, const fg_encode_cfg* cfg, const uint8_t* bytes,
                        uint64_t nbytes, const uint64_t* offsets, uint64_t n, int final, fg_transcoded* out);
 
-/* Page-locked host memory for the framer's batch buffers (bytes, offsets). */
+/* Host memory for the framer's batch buffers (bytes, offsets): PAGE-LOCKED, through a process-wide pool -- a freed block is kept
+ * (up to idle_bytes in total) and handed to the next request it fits, so a framer per connection does not pin and unpin megabytes per
+ * connect; the bytes pinned through this allocator are capped at total_bytes, beyond which a request gets PAGEABLE memory (every
+ * host-buffer entry point takes either: pinned = zero-copy / link-speed uploads, pageable = the runtime's staged copies).
+ * Defaults: 1 GiB in total, 256 MiB idle.  Thread-safe.  fg_pinned_stats: what is pinned / idle / handed out right now. */
 int fg_alloc_pinned(uint64_t bytes, void** out);
 void fg_free_pinned(void* p);
+int fg_set_pinned_limits(uint64_t total_bytes, uint64_t idle_bytes);
+int fg_pinned_stats(uint64_t* pinned_bytes, uint64_t* idle_bytes, uint64_t* live_blocks);
 
 /* The host <-> device link of ctx's GPU, MEASURED: hipMemcpyAsync of a pinned buffer of `nbytes` (>= 64 MiB for a steady figure;
  * bench.py uses 1 GiB), best of three, in GB/s: gbps[0] host -> device, gbps[1] device -> host, gbps[2] both directions at once

@@ -425,3 +425,43 @@ def test_the_timeline_probe_runs_against_the_fake_runtime(fake, tmp_path):
         r = subprocess.run([str(exe), "rfc5424", str(corpus_file), mib, mode], capture_output=True, text=True, timeout=120)
         assert r.returncode == 0, r.stderr[-500:]
         assert "total" in r.stdout.splitlines()[-1] and f"mode {mode}" in r.stdout.splitlines()[0]
+
+
+def test_pinned_pool_reuses_blocks_and_falls_back_to_pageable_memory(fake):
+    """fg_alloc_pinned / fg_free_pinned: a freed block is handed to the next request it fits (no pin / unpin per
+    connection), idle blocks are bounded, and beyond the cap of pinned bytes a request gets pageable memory that the same free takes."""
+    lib = fake
+    lib.fg_alloc_pinned.argtypes = [u64, C.POINTER(vp)]
+    lib.fg_free_pinned.argtypes = [vp]
+    lib.fg_free_pinned.restype = None
+    lib.fg_set_pinned_limits.argtypes = [u64, u64]
+    lib.fg_pinned_stats.argtypes = [C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
+
+    def stats():
+        a, b, c = u64(), u64(), u64()
+        lib.fg_pinned_stats(C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
+
+    lib.fg_set_pinned_limits(1 << 30, 0)  # (earlier tests left idle blocks: unpinned here, so that the books start clean)
+    p0, i0, l0 = stats()
+    assert i0 == 0
+    lib.fg_set_pinned_limits(p0 + (8 << 20), 4 << 20)
+    a = vp()
+    assert lib.fg_alloc_pinned(3 << 20, C.byref(a)) == 0 and a.value
+    C.memset(a, 0x5A, 3 << 20)
+    assert stats()[0] == p0 + (3 << 20) and stats()[2] == l0 + 1
+    lib.fg_free_pinned(a)
+    assert stats() == (p0 + (3 << 20), i0 + (3 << 20), l0)          # kept, idle
+    b = vp()
+    assert lib.fg_alloc_pinned((2 << 20) + 5, C.byref(b)) == 0 and b.value == a.value   # the idle block fits: reused
+    c = vp()
+    assert lib.fg_alloc_pinned(4 << 20, C.byref(c)) == 0 and c.value                    # a second pinned block: 7 of 8 MiB
+    d = vp()
+    assert lib.fg_alloc_pinned(4 << 20, C.byref(d)) == 0 and d.value                    # over the cap: pageable, still usable
+    C.memset(d, 0x11, 4 << 20)
+    assert stats()[0] == p0 + (7 << 20)
+    for q in (b, c, d):
+        lib.fg_free_pinned(q)
+    pinned, idle, live = stats()
+    assert live == l0 and idle <= i0 + (4 << 20) and pinned <= p0 + (7 << 20)   # the second free exceeded the idle bound: unpinned
+    lib.fg_set_pinned_limits(1 << 30, 256 << 20)

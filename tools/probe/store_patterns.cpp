@@ -7,6 +7,9 @@
 //   2  lane-per-message through a 64-byte LDS slot per lane, flushed by the wave: 4 lanes per slot, 16 slots per instruction
 //   3  lane-per-message through a 256-byte LDS slot per lane, flushed by the wave: 16 lanes per slot
 //   4  fully coalesced (the wave's whole range, 1 KiB per instruction): the ceiling
+//   5  as 1, but every store instruction executes with a QUARTER of the lanes (lane & 3 == step & 3) -- four times the instructions
+//      for the same bytes: what a sink does whose lanes complete their 16-byte blocks at different put_word calls
+//   6  as 5 with an EIGHTH of the lanes
 // build: hipcc --offload-arch=gfx950 -O3 -o tools/probe/store_patterns tools/probe/store_patterns.cpp
 #include <hip/hip_runtime.h>
 
@@ -48,6 +51,19 @@ __global__ __launch_bounds__(64) void k_store(const uint64_t* __restrict__ off, 
             u32x4 q = {v, v + 1u, v + 2u, v + 3u};
             *reinterpret_cast<u32x4*>(out + a) = q;
             v = v * 1664525u + 1013904223u;
+        }
+    } else if (MODE == 5 || MODE == 6) {
+        constexpr uint32_t PARTS = MODE == 5 ? 4u : 8u;
+        uint64_t a = (o0 + 15u) & ~15ull;
+        const uint64_t e = o1 & ~15ull;
+        uint32_t v = (uint32_t)o0;
+        for (uint32_t step = 0; __any(a < e); ++step) {
+            if ((lane % PARTS) == (step % PARTS) && a < e) {
+                u32x4 q = {v, v + 1u, v + 2u, v + 3u};
+                *reinterpret_cast<u32x4*>(out + a) = q;
+                v = v * 1664525u + 1013904223u;
+                a += 16u;
+            }
         }
     } else if (MODE == 2 || MODE == 3) {
         constexpr uint32_t SLOT = MODE == 2 ? 64u : 256u;   // bytes per lane and round
@@ -118,7 +134,7 @@ int main(int argc, char** argv) {
     CHECK(hipEventCreate(&e1));
     const uint32_t blocks = (uint32_t)((n + 63) / 64);
     printf("%llu messages, %.1f MB of output, %u B of LDS per wave\n", (unsigned long long)n, s / 1e6, lds);
-    for (int mode = 0; mode < 5; ++mode) {
+    for (int mode = 0; mode < 7; ++mode) {
         float best = 1e9f;
         for (int rep = 0; rep < 4; ++rep) {
             CHECK(hipEventRecord(e0));
@@ -127,7 +143,9 @@ int main(int argc, char** argv) {
                 case 1: hipLaunchKernelGGL(k_store<1>, dim3(blocks), dim3(64), lds, 0, d_off, n, d_out); break;
                 case 2: hipLaunchKernelGGL(k_store<2>, dim3(blocks), dim3(64), lds, 0, d_off, n, d_out); break;
                 case 3: hipLaunchKernelGGL(k_store<3>, dim3(blocks), dim3(64), lds < 16384u ? 16384u : lds, 0, d_off, n, d_out); break;
-                default: hipLaunchKernelGGL(k_store<4>, dim3(blocks), dim3(64), lds, 0, d_off, n, d_out); break;
+                case 4: hipLaunchKernelGGL(k_store<4>, dim3(blocks), dim3(64), lds, 0, d_off, n, d_out); break;
+                case 5: hipLaunchKernelGGL(k_store<5>, dim3(blocks), dim3(64), lds, 0, d_off, n, d_out); break;
+                default: hipLaunchKernelGGL(k_store<6>, dim3(blocks), dim3(64), lds, 0, d_off, n, d_out); break;
             }
             CHECK(hipEventRecord(e1));
             CHECK(hipEventSynchronize(e1));
