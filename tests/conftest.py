@@ -8,6 +8,34 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
 
+# The CPU suite builds its native helpers (tests/native/lib*_host.so, the fake-runtime host pipeline ...) on first use, each from the
+# fixture of the module that needs it.  Under pytest-xdist several workers reach the same fixture at the same moment and compiled INTO
+# THE SAME FILE -- a worker then loaded a half-written library ("file too short").  Every g++ / gcc build whose output lies under
+# tests/native therefore compiles to a private name and is renamed into place (atomic on one filesystem).
+import os
+import subprocess
+
+_real_run = subprocess.run
+
+
+def _atomic_native_build(cmd, *args, **kwargs):
+    if isinstance(cmd, (list, tuple)) and cmd and cmd[0] in ("g++", "gcc") and "-o" in cmd:
+        i = list(cmd).index("-o")
+        out = Path(cmd[i + 1])
+        if str(out.resolve()).startswith(str(ROOT / "tests" / "native")):
+            tmp = out.with_name(f".{out.name}.{os.getpid()}.tmp")
+            c2 = list(cmd)
+            c2[i + 1] = str(tmp)
+            r = _real_run(c2, *args, **kwargs)
+            if r.returncode == 0:
+                os.replace(tmp, out)
+            return r
+    return _real_run(cmd, *args, **kwargs)
+
+
+subprocess.run = _atomic_native_build
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` through gpurun)")
 
