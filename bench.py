@@ -261,6 +261,10 @@ def pinned(nbytes, dt):
 
     from flowgger_amd import _lib as L
 
+    # (the harness keeps whole multi-GB batches page-locked: beyond the allocator's cap -- 8 GiB by default -- it would hand out PAGEABLE
+    #  memory, and the legs would measure the runtime's staged copies instead of the link)
+    L.check(L.lib().fg_set_pinned_limits(1 << 40, 256 << 20), "fg_set_pinned_limits")
+
     p = C.c_void_p()
     L.check(L.lib().fg_alloc_pinned(nbytes, C.byref(p)), "fg_alloc_pinned")
     return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (nbytes,)).view(dt), p

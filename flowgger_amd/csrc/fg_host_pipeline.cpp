@@ -24,7 +24,7 @@ struct PinnedPool {
     std::map<void*, std::pair<uint64_t, bool>> live;  // block -> (capacity, pinned?)
     std::multimap<uint64_t, void*> idle;              // pinned blocks nobody holds, by capacity
     uint64_t pinned_bytes = 0, idle_bytes = 0;
-    uint64_t limit = 1ull << 30, idle_limit = 256ull << 20;
+    uint64_t limit = 8ull << 30, idle_limit = 256ull << 20;
 };
 PinnedPool& pinned_pool() {
     static PinnedPool* p = new PinnedPool();  // (never destroyed: no HIP calls from static destructors at process exit)

@@ -464,4 +464,4 @@ def test_pinned_pool_reuses_blocks_and_falls_back_to_pageable_memory(fake):
         lib.fg_free_pinned(q)
     pinned, idle, live = stats()
     assert live == l0 and idle <= i0 + (4 << 20) and pinned <= p0 + (7 << 20)   # the second free exceeded the idle bound: unpinned
-    lib.fg_set_pinned_limits(1 << 30, 256 << 20)
+    lib.fg_set_pinned_limits(8 << 30, 256 << 20)
