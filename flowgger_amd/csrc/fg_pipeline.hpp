@@ -14,6 +14,7 @@
 // HBM sees only coalesced 1 KiB-per-wave-instruction reads, each byte once.
 #pragma once
 #include "fg_device.hpp"
+#include "fg_plan_policy.hpp"
 #include "fg_wave.hpp"
 
 namespace fg {
@@ -735,31 +736,6 @@ struct LaunchPlan {
     uint32_t blocks = 0;  // persistent grid
 };
 
-// Entry slots a wave reserves from the table's counter at a time (DevTables::alloc_chunk; wv::wave_alloc).  Every reservation is an
-// atomic on ONE word, and that word's channel serves only a few dozen of them per microsecond (rounds 3-4 and profiles/r05b_*: GELF,
-// one request per 8-line tile, took 290 us for 64 K lines and 915 us for 256 K where 512 K take 400 us -- small launches fell under
-// the 256-slot floor of wv::alloc_chunk_for into EXACT reservations).  So: the table's share per wave (1/16 of it over all waves, at
-// most 4096 slots, at least 256 where a quarter of the table holds 256 per wave) capped by eight slots per line the wave will see in
-// this launch -- but never below 256 slots (a floor of 64 is one
-// 8-line GELF tile's worth: still an atomic per tile; 256: 340 -> 184 us for 64 K lines, 896 -> 303 us for 256 K,
-// profiles/r05c_small_gelf_opts.log); exact reservations
-// only for a table too small for 256-slot chunks (a caller that sized it tightly must not see FG_ST_OVERFLOW because of slots parked
-// in chunks).  What a wave strands is the rest of its last chunk: half a chunk on average, never written and -- on the
-// zero-copy host paths, which write the tables across the link themselves -- never moved.
-inline uint32_t entry_chunk(uint64_t ent_cap, uint32_t blocks, uint64_t n, const fg_launch_opts& lo) {
-    if (lo.ent_chunk == 1u) return 0u;
-    if (lo.ent_chunk >= 2u) return lo.ent_chunk;
-    const uint64_t waves = blocks ? blocks : 1u;
-    uint64_t c = ent_cap / (16ull * waves);
-    if (c > 4096u) c = 4096u;
-    if (ent_cap / (4ull * waves) < 256u) return 0u;  // (a quarter of the table stranded at worst, an eighth on average)
-    if (c < 256u) c = 256u;
-    const uint64_t per_wave = (n + waves - 1u) / waves * 8ull;
-    if (c > per_wave) c = per_wave;
-    if (c < 256u) c = 256u;
-    return (uint32_t)c;
-}
-
 // The launch's ticket counter into the kernel's arguments; the host's copy of the counter moves on by what the launch will draw
 // (every wave draws until its first ticket beyond the last chunk: chunks - blocks good ones + blocks bad ones = chunks).
 inline void take_tickets(FrameArgs* fr, TicketSlot* tk, const LaunchPlan& p) {
@@ -827,62 +803,17 @@ inline int plan_launch(K kernel, uint64_t n, uint64_t avg_len, uint32_t extra_ld
     // 256 lines per chunk (four groups of 64 short lines: the HBM-bound configuration keeps its sweep tight) -- 512 when a group
     // holds fewer than L average lines, so that the short group at the end of every chunk stays a few per cent (same-box sweep,
     // tools/sweep.py, 4 M lines: cfg4 1058 / 1150 / 974 M lines/s at 256 / 512 / 1024 -- the grid's 1792 waves need a few rounds
-    // of chunks each to finish together) -- provided the batch gives every wave at least two chunks; else what spreads the batch
-    // over the grid
+    // of chunks each to finish together)
     // (default_chunk: a format's own choice -- the pair-parallel structured-data kernel: 1466 vs 1394 M lines/s at 1024 vs 512 lines)
     const uint64_t full = default_chunk ? default_chunk : (avg_len ? (uint64_t)p->tile / avg_len : p->L) >= p->L ? 256u : 512u;
     // lines an average group holds (groups are cut by bytes): the unit chunks are made of
-    uint64_t g = avg_len ? ((uint64_t)p->tile * 16u) / (avg_len * 17u) : p->L;
-    g = g < 1u ? 1u : g > p->L ? p->L : g;
-    const bool dynamic = !(lo.flags & FG_LO_STATIC_CHUNKS);
-    uint64_t chunk;
-    if (lo.chunk_lines >= (dynamic ? 1u : p->L) && lo.chunk_lines <= 65536u) {
-        chunk = lo.chunk_lines;  // (tuning: taken as it is, unless the batch is too small for two of them per wave)
-        if (n < blocks * 2u * chunk) {
-            chunk = (n + blocks - 1) / (blocks ? blocks : 1);
-            if (chunk < (dynamic ? g : p->L)) chunk = dynamic ? g : p->L;
-        }
-    } else if (dynamic && (n + blocks - 1) / (blocks ? blocks : 1) >= (uint64_t)ticket_from * full) {
-        // Chunks are DRAWN (persistent_loop's ticket): a wave that meets slow lines or sits on a slow XCD draws fewer -- the balance is
-        // the dispatch's business, so the chunk is simply `full` lines: its last group is as short as it comes out and costs these
-        // latency-bound kernels what a full one does (1 group in 4 .. 50), and every ticket is an atomic on one word, of which the
-        // chip serves a few dozen per microsecond -- chunks of ONE group (8192 tickets for 512 K lines of the headline corpus) doubled
-        // the kernel's time (profiles/r05b_small_ab.log: 123 vs 65 us).  A batch with fewer than `ticket_from` such chunks per wave
-        // takes the equal shares below and draws nothing: two for the compute-bound kernels (GELF gains 13 % from six chunks per wave
-        // on, LTSV 5 %), twenty for the HBM-bound headline kernel, whose first round of tickets -- 1792 waves start at the same
-        // moment -- arrives as a burst on one word, and an atomic that takes 20 us to come back holds the wave's window loads up behind
-        // it (vmcnt retires in order): +25 us at 1 M, 2 M and 4 M lines alike, +12 % throughput at 16 M, +18 % at 40 M
-        // (profiles/r05d_small_cfg2_big.log, r05e_small.log, r05d_sweep_cfg2_40M.log).
-        chunk = full;
-    } else {
-        // The chunks are dealt out round-robin, so every wave should get the SAME number of them: k = the chunks per wave that keeps a
-        // chunk at or below `full`, chunk = n / (waves * k).  (With chunks of exactly `full` lines a batch of 1.9 chunks per wave left a
-        // tenth of the grid with half the work of the rest: 4 M structured-data lines 1.80 -> 1.89 G lines/s, 4 M long-tail lines
-        // 0.69 -> 0.88 G with one even chunk per wave, profiles/r04z3_sweep_cfg4.log, r04z5_sweep_cfg5.log.)
-        const uint64_t per_wave = (n + blocks - 1) / (blocks ? blocks : 1);
-        if (dynamic) {
-            // (round 5) ONE chunk per wave, the wave's whole share: a single ragged group per wave, and no floor of L lines -- a small
-            // batch is cut down to one average group per wave (16 K structured-data lines, 21 to the group, ran as 256 waves of three
-            // groups each on a grid of 2048: 84 us where 47 do).  Same box, alternated, against the k equal chunks of <= `full` lines
-            // of rounds 3-4 (profiles/r05f_small_cfg2_chunks.log, r05f_sweep_4M_chunks.log): headline corpus 1 M lines 97 vs 104 us,
-            // 4 M 340 vs 335; structured data 256 K / 512 K / 4 M lines 194 / 328 us / 1.91 G against 195 / 330 us / 1.89 G; GELF and LTSV
-            // alike.  (The sweep-front-to-back argument for many chunks per wave is a large batch's: that regime draws tickets.)
-            chunk = per_wave;
-            const uint64_t unit = g >= p->L ? g : (g * 15u / 16u ? g * 15u / 16u : 1u);
-            if (chunk < unit) chunk = unit;
-        } else {
-            const uint64_t k = (per_wave + full - 1) / full;
-            chunk = (per_wave + (k ? k : 1) - 1) / (k ? k : 1);
-            if (chunk < p->L) chunk = p->L;
-        }
-    }
-    const uint64_t chunks = (n + chunk - 1) / chunk;
-    if (blocks > chunks) blocks = chunks;
-    p->chunk = chunk;
-    p->chunks = chunks;
-    // (tickets: large batches -- or whenever the caller names a chunk size while dispatch is dynamic: tests, tuning)
-    p->tickets = dynamic && ((n + blocks - 1) / (blocks ? blocks : 1) >= (uint64_t)ticket_from * full || (lo.chunk_lines >= 1u && lo.chunk_lines <= 65536u));
-    p->blocks = (uint32_t)blocks;
+    const uint64_t g = avg_len ? ((uint64_t)p->tile * 16u) / (avg_len * 17u) : p->L;
+    // how the batch is cut into chunks, and whether chunks are drawn by ticket: pure arithmetic, fg_plan_policy.hpp (CPU-tested)
+    const ChunkPlan cp = plan_chunks(n, blocks, p->L, g, full, ticket_from, lo);
+    p->chunk = cp.chunk;
+    p->chunks = cp.chunks;
+    p->tickets = cp.tickets;
+    p->blocks = cp.blocks;
     return 0;
 }
 
