@@ -445,7 +445,7 @@ def oracle_ok_count(fmt, data, offsets, cfg):
 
 
 def cached_lines(key, gen):
-    """FG_BENCH_CACHE=<dir> (measurement scripts that run this file many times on one box: tools/r04_final.sh): the generated tile is
+    """FG_BENCH_CACHE=<dir> (measurement scripts that run this file many times on one box: tools/r05_final.sh): the generated tile is
     kept as one pickle per (workload, size, share of invalid lines) -- the generators are deterministic (fixed seeds), so this only
     saves the tens of seconds Python needs to format a million lines.  Unset: generate, as the driver's run does."""
     d = os.environ.get("FG_BENCH_CACHE")
