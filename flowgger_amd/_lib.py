@@ -81,6 +81,9 @@ FG_LO_GELF_GENERIC, FG_LO_TRANSCODE_ONE_PIECE, FG_LO_NO_HEAD, FG_LO_FORCE_HEAD, 
 FG_LO_FRAME_CLASSIC = 256
 FG_LO_STATIC_CHUNKS = 512
 FG_LO_FRAME_SELFTEST_STALL = 1024
+FG_LO_NO_TAPER = 2048
+FG_LO_TAPER_1 = 4096
+FG_LO_TAPER_2 = 8192
 FG_LO_RESERVED = 0x40000000  # the library's own (fg_set_launch_opts clears it)
 
 

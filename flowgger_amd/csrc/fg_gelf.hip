@@ -350,7 +350,7 @@ struct GRow {
 // gelf_decoder.rs:51-106 for ONE member (already the winner among duplicates).  EMIT writes
 // extras to slot+*cnt.  Returns a G_* status (G_OK to continue).
 template <bool EMIT, class R>
-__device__ uint32_t gelf_dispatch(const Gelf<R>& g, const Member& m, GRow& r, const DevTables& t, uint32_t slot,
+__device__ __forceinline__ uint32_t gelf_dispatch(const Gelf<R>& g, const Member& m, GRow& r, const DevTables& t, uint32_t slot,
                                   uint32_t* cnt) {
     const uint32_t kb = m.key_b, ke = m.key_e, kx = m.key_esc;
     if (g.key_is(kb, ke, kx, "timestamp", 9)) {
@@ -404,7 +404,7 @@ __device__ uint32_t gelf_dispatch(const Gelf<R>& g, const Member& m, GRow& r, co
 
 // pass 1: validate the document, count top-level members, remember key positions.
 template <class R>
-__device__ uint32_t gelf_validate(const Gelf<R>& g, uint32_t* keypos, GRow& r, bool* is_object) {
+__device__ __forceinline__ uint32_t gelf_validate(const Gelf<R>& g, uint32_t* keypos, GRow& r, bool* is_object) {
     uint32_t p = g.skip_ws(0);
     if (p >= g.len) return J_SYNTAX;  // EOFWhileParsingValue
     *is_object = g.rd.byte(p) == '{';
@@ -446,7 +446,7 @@ __device__ uint32_t gelf_validate(const Gelf<R>& g, uint32_t* keypos, GRow& r, b
 
 // Visit the members in sorted decoded-key order, last duplicate wins; dispatch each.
 template <bool EMIT, class R>
-__device__ void gelf_sorted_dispatch(const Gelf<R>& g, uint32_t* keypos, GRow& r, const DevTables& t, uint32_t slot) {
+__device__ __forceinline__ void gelf_sorted_dispatch(const Gelf<R>& g, uint32_t* keypos, GRow& r, const DevTables& t, uint32_t slot) {
     uint32_t cnt = 0;
     const uint32_t n = r.n_members;
     if (r.stored) {
@@ -517,7 +517,7 @@ __device__ void gelf_sorted_dispatch(const Gelf<R>& g, uint32_t* keypos, GRow& r
 }
 
 template <class R>
-__device__ void gelf_line(R& rd, uint32_t len, uint32_t* keypos, uint32_t* stack, GRow& r, const DevTables& t) {
+__device__ __forceinline__ void gelf_line(R& rd, uint32_t len, uint32_t* keypos, uint32_t* stack, GRow& r, const DevTables& t) {
     Gelf<R> g{rd, len, false, stack};
     bool is_object = false;
     uint32_t e = gelf_validate(g, keypos, r, &is_object);
@@ -743,10 +743,11 @@ int launch_gelf_fast(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t
                 // 1422 M lines/s at sixteen, profiles/r04s_sweep_cfg3.log)
                 fg_launch_opts lo3 = lo;
                 lo3.tile_cap = 3072u;
-                // (chunks of at most 128 lines: 64 / 128 / 512 all measure 2 % above the pipeline's 256 on this corpus, alternated on one
-                //  box -- profiles/r04z2_sweep_cfg3.log)
+                // (chunks of 64 lines = eight tiles, drawn by ticket: 4 M lines 1878-1886 M lines/s against 1805-1813 at 128, 1866-1870 at 48 / 96;
+                //  16 M lines 2051 against 2012 at 128 and 2003 at 256 -- one box, alternated, profiles/r05u_chunk_taper_sweep.log;
+                //  tickets from four chunks per wave on: at three -- 1 M lines -- one share per wave is as fast, profiles/r05v_policy_ab.log)
                 if (fg::plan_launch(fg::k_gelf<NB, false, 5, 3072u, 8u>, n, avg_len, 0u, 40960u, 0u, &p, lo3, max_lines,
-                                    fg::GelfFormat::kClasses, fg::gelf_extra_lds, nullptr, 0u, 128u) || p.tile != 3072u || p.L != 8u)
+                                    fg::GelfFormat::kClasses, fg::gelf_extra_lds, nullptr, 0u, 64u, 4u) || p.tile != 3072u || p.L != 8u)
                     return -1;
                 fg::take_tickets(&fr, tk, p);
     tt.alloc_chunk = fg::entry_chunk(tt.ent_cap, p.blocks, n, lo);

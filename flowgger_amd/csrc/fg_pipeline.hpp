@@ -297,6 +297,8 @@ struct FrameArgs {
     // launch starts; null = chunks are dealt out round-robin (the form of rounds 3-4, kept for A/B: FG_LO_STATIC_CHUNKS).
     uint32_t* ticket = nullptr;
     uint32_t ticket_base = 0;
+    // ... and the chunk indices from which the chunks of a ticket launch shrink (fg_plan_policy.hpp: the taper)
+    uint32_t taper0 = kNoTaper, taper1 = kNoTaper, taper2 = kNoTaper;
 };
 // (host side of the ticket: fg::TicketSlot, fg_tables_view.hpp)
 
@@ -380,8 +382,8 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
         tk_pending = true;
     };
     uint64_t chunk = blockIdx.x;
-    uint64_t hi_line = (chunk + 1u) * kChunkLines < n ? (chunk + 1u) * kChunkLines : n;
-    uint64_t p = chunk * kChunkLines;
+    uint64_t p, hi_line;
+    chunk_range(chunk, kChunkLines, fr.taper0, fr.taper1, fr.taper2, n, &p, &hi_line);
     if (dyn && p < n) draw_ticket();
 
     // the L offsets from line q on (clamped to the wave's range), as o0 = start / o1 = end of lane's line
@@ -506,12 +508,12 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
                 // the successor's ticket right away: a whole chunk hides its trip.  (Drawn one group before the end, as the first cut
                 // did, the tickets of a batch's FIRST round -- every wave starts at the same moment -- arrived in a burst of 1792 on one
                 // word and were waited for: 1 M lines 122 us with tickets, 104 without, profiles/r05c_small_ab.log.)
-                if (chunk * kChunkLines < n) draw_ticket();
+                chunk_range(chunk, kChunkLines, fr.taper0, fr.taper1, fr.taper2, n, &pn, &hi_line);
+                if (pn < n) draw_ticket();
             } else {
                 chunk += G;
+                chunk_range(chunk, kChunkLines, kNoTaper, kNoTaper, kNoTaper, n, &pn, &hi_line);
             }
-            pn = chunk * kChunkLines;
-            hi_line = (chunk + 1u) * kChunkLines < n ? (chunk + 1u) * kChunkLines : n;
         }
         const bool more = pn < n;  // wave-uniform
         uint64_t no0 = 0, no1 = 0;
@@ -733,6 +735,7 @@ struct LaunchPlan {
     uint64_t chunk = 256; // lines a wave takes at a time (the first by block index, the rest by ticket)
     uint64_t chunks = 0;  // ceil(n / chunk) >= blocks
     bool tickets = false; // chunks beyond a wave's first are drawn from the launch's ticket counter (else: round-robin)
+    uint32_t taper[3] = {kNoTaper, kNoTaper, kNoTaper};  // ticket launches: where the chunks shrink (fg_plan_policy.hpp)
     uint32_t blocks = 0;  // persistent grid
 };
 
@@ -743,6 +746,7 @@ inline void take_tickets(FrameArgs* fr, TicketSlot* tk, const LaunchPlan& p) {
     if (!p.tickets) return;  // (equal shares: nothing to draw)
     fr->ticket = tk->d_word;
     fr->ticket_base = *tk->h_val;
+    fr->taper0 = p.taper[0], fr->taper1 = p.taper[1], fr->taper2 = p.taper[2];
     *tk->h_val += (uint32_t)p.chunks;
 }
 
@@ -756,7 +760,7 @@ template <class K>
 inline int plan_launch(K kernel, uint64_t n, uint64_t avg_len, uint32_t extra_lds, uint32_t max_tile, uint32_t stash_blocks,
                        LaunchPlan* p, const fg_launch_opts& lo, uint32_t max_lines = 64, uint32_t n_classes = 1,
                        uint32_t (*extra_for)(uint32_t tile, uint32_t lines) = nullptr, uint32_t (*extra_tile)(uint32_t tile) = nullptr,
-                       uint32_t default_tile = 0, uint32_t default_chunk = 0, uint32_t ticket_from = 2) {
+                       uint32_t default_tile = 0, uint32_t default_chunk = 0, uint32_t ticket_from = 2, uint32_t taper = 1) {
     const uint64_t window = (uint64_t)kWindowKiB * 1024u;
     // (+6.25 % + 256 B over the average group: a few sigma for the corpora at hand; a longer group just takes
     //  another pass over a restaged tile, while every KiB of LDS saved is occupancy)
@@ -804,15 +808,16 @@ inline int plan_launch(K kernel, uint64_t n, uint64_t avg_len, uint32_t extra_ld
     // holds fewer than L average lines, so that the short group at the end of every chunk stays a few per cent (same-box sweep,
     // tools/sweep.py, 4 M lines: cfg4 1058 / 1150 / 974 M lines/s at 256 / 512 / 1024 -- the grid's 1792 waves need a few rounds
     // of chunks each to finish together)
-    // (default_chunk: a format's own choice -- the pair-parallel structured-data kernel: 1466 vs 1394 M lines/s at 1024 vs 512 lines)
+    // (default_chunk: a format's own choice -- fg_rfc5424.hip, fg_gelf.hip, fg_ltsv.hip: each from a same-box sweep under ticket dispatch)
     const uint64_t full = default_chunk ? default_chunk : (avg_len ? (uint64_t)p->tile / avg_len : p->L) >= p->L ? 256u : 512u;
     // lines an average group holds (groups are cut by bytes): the unit chunks are made of
     const uint64_t g = avg_len ? ((uint64_t)p->tile * 16u) / (avg_len * 17u) : p->L;
     // how the batch is cut into chunks, and whether chunks are drawn by ticket: pure arithmetic, fg_plan_policy.hpp (CPU-tested)
-    const ChunkPlan cp = plan_chunks(n, blocks, p->L, g, full, ticket_from, lo);
+    const ChunkPlan cp = plan_chunks(n, blocks, p->L, g, full, ticket_from, lo, taper);
     p->chunk = cp.chunk;
     p->chunks = cp.chunks;
     p->tickets = cp.tickets;
+    for (int j = 0; j < 3; ++j) p->taper[j] = cp.taper[j];
     p->blocks = cp.blocks;
     return 0;
 }

@@ -6,13 +6,59 @@
 
 #include "../../include/fg_hip.h"
 
+#if defined(__HIPCC__)
+#define FG_POLICY_HD __host__ __device__
+#else
+#define FG_POLICY_HD
+#endif
+
 namespace fg {
+
+// The TAPER of a ticket launch: chunks are `chunk` lines up to chunk index taper[0], half that up to taper[1], a quarter up to
+// taper[2], an eighth from there to the end of the batch (kNoTaper = that level is not used; taper[0] <= taper[1] <= taper[2]).
+// Waves that draw chunks of C lines finish up to one chunk's time apart, so the LAST chunk per wave's worth of lines is dealt out in
+// smaller pieces (guided self-scheduling, at most three levels).  Measured, one box, every setting alternated
+// (profiles/r05u_chunk_taper_sweep.log): ONE level is what pays -- structured data 4 M lines, chunks of 128: 1956 M lines/s without,
+// 1990 with one level, 1981 / 1979 with two / three; 16 M lines, chunks of 512: 2042 -> 2080; LTSV 4 M lines 3813 -> 3941; the
+// long-tail corpus 1366 -> 1396 -- and the HBM-bound headline kernel gains nothing from it (14.75-14.88 G without, 14.86-14.88 with
+// one level, 14.63 with two: its last level would be chunks of ONE group, which that kernel cannot afford).  Deeper levels are a
+// tuning option (FG_LO_TAPER_1 / _2).
+constexpr uint32_t kNoTaper = 0xFFFFFFFFu;
+
+// chunk index -> its lines [lo, hi) (lo == hi == n: beyond the batch).  Shared by the kernels (persistent_loop) and the host's count.
+FG_POLICY_HD inline void chunk_range(uint64_t c, uint64_t chunk, uint32_t t0, uint32_t t1, uint32_t t2, uint64_t n, uint64_t* lo,
+                                     uint64_t* hi) {
+    uint64_t base = 0, first = 0, sz = chunk;
+    if (c >= t0) {
+        base = (uint64_t)t0 * sz, first = t0, sz >>= 1;
+        if (c >= t1) {
+            base += (uint64_t)(t1 - t0) * sz, first = t1, sz >>= 1;
+            if (c >= t2) base += (uint64_t)(t2 - t1) * sz, first = t2, sz >>= 1;
+        }
+    }
+    const uint64_t l = base + (c - first) * sz;
+    *lo = l < n ? l : n;
+    *hi = l + sz < n ? l + sz : n;
+}
+
+// chunks a batch of n lines makes under a taper (the first index whose range is empty)
+inline uint64_t count_chunks(uint64_t chunk, const uint32_t t[3], uint64_t n) {
+    uint64_t base = 0, first = 0, sz = chunk;
+    for (int j = 0; j < 3; ++j) {
+        if (t[j] == kNoTaper) break;
+        const uint64_t upto = base + (uint64_t)(t[j] - first) * sz;
+        if (upto >= n) break;
+        base = upto, first = t[j], sz >>= 1;
+    }
+    return first + (n - base + sz - 1) / sz;
+}
 
 struct ChunkPlan {
     uint64_t chunk = 1;    // lines per chunk
-    uint64_t chunks = 0;   // ceil(n / chunk)
+    uint64_t chunks = 0;   // chunks of the batch (ceil(n / chunk) without a taper)
     uint32_t blocks = 0;   // persistent waves (<= chunks)
     bool tickets = false;  // chunks beyond a wave's first are drawn from the launch's ticket counter (else: round-robin)
+    uint32_t taper[3] = {kNoTaper, kNoTaper, kNoTaper};  // (ticket launches only)
 };
 
 //   n           lines of the launch (>= 1)
@@ -21,8 +67,10 @@ struct ChunkPlan {
 //   g           lines an AVERAGE group holds (groups are cut by bytes), 1 .. L
 //   full        the format's chunk for large batches (256 / 512 / its own choice)
 //   ticket_from chunks of `full` lines per wave from which tickets are drawn
-//   lo          the caller's launch options (chunk_lines, FG_LO_STATIC_CHUNKS)
-inline ChunkPlan plan_chunks(uint64_t n, uint64_t blocks, uint32_t L, uint64_t g, uint64_t full, uint32_t ticket_from, const fg_launch_opts& lo) {
+//   lo          the caller's launch options (chunk_lines, FG_LO_STATIC_CHUNKS, FG_LO_NO_TAPER / _TAPER_1 / _TAPER_2)
+//   taper       levels of the taper at the end of a ticket launch, 0 .. 3 (the format's choice)
+inline ChunkPlan plan_chunks(uint64_t n, uint64_t blocks, uint32_t L, uint64_t g, uint64_t full, uint32_t ticket_from, const fg_launch_opts& lo,
+                             uint32_t taper = 1) {
     ChunkPlan p;
     if (blocks < 1u) blocks = 1u;
     if (g < 1u) g = 1u;
@@ -46,8 +94,9 @@ inline ChunkPlan plan_chunks(uint64_t n, uint64_t blocks, uint32_t L, uint64_t g
         // latency-bound kernels what a full one does (1 group in 4 .. 50), and every ticket is an atomic on one word, of which the
         // chip serves a few dozen per microsecond -- chunks of ONE group (8192 tickets for 512 K lines of the headline corpus) doubled
         // the kernel's time (profiles/r05b_small_ab.log: 123 vs 65 us).  A batch with fewer than `ticket_from` such chunks per wave
-        // takes the equal shares below and draws nothing: two for the compute-bound kernels (GELF gains 13 % from six chunks per wave
-        // on, LTSV 5 %), twenty for the HBM-bound headline kernel, whose first round of tickets -- 1792 waves start at the same
+        // takes the equal shares below and draws nothing: two to four for the compute-bound kernels (GELF gains 13 % from six chunks per
+        // wave on, LTSV 5 %; structured data and GELF lose 1-4 % at three: profiles/r05v_policy_ab.log), twenty for the HBM-bound
+        // headline kernel, whose first round of tickets -- 1792 waves start at the same
         // moment -- arrives as a burst on one word, and an atomic that takes 20 us to come back holds the wave's window loads up behind
         // it (vmcnt retires in order): +25 us at 1 M, 2 M and 4 M lines alike, +12 % throughput at 16 M, +18 % at 40 M
         // (profiles/r05d_small_cfg2_big.log, r05e_small.log, r05d_sweep_cfg2_40M.log).
@@ -74,6 +123,23 @@ inline ChunkPlan plan_chunks(uint64_t n, uint64_t blocks, uint32_t L, uint64_t g
     if (chunk < 1u) chunk = 1u;
     p.chunk = chunk;
     p.chunks = (n + chunk - 1) / chunk;
+    if (lo.flags & (FG_LO_TAPER_1 | FG_LO_TAPER_2)) taper = ((lo.flags & FG_LO_TAPER_1) ? 1u : 0u) + ((lo.flags & FG_LO_TAPER_2) ? 2u : 0u);
+    if (taper > 3u) taper = 3u;
+    if (tickets && taper && !(lo.flags & FG_LO_NO_TAPER)) {
+        // the tail: one chunk per wave's worth of lines, at most half the batch; levels down to one average group (a chunk below
+        // that is a group short of lines at a full group's latency)
+        uint64_t m = n / (2u * chunk);
+        if (m > blocks) m = blocks;
+        uint32_t levels = 0;
+        while (levels < taper && (chunk >> (levels + 1u)) >= g) ++levels;
+        if (m >= 1u && levels >= 1u && p.chunks + 4u * m < 0xFFFFFFF0ull) {
+            const uint64_t t0 = (n - m * chunk) / chunk;  // full chunks before the tail
+            p.taper[0] = (uint32_t)t0;
+            if (levels >= 2u) p.taper[1] = (uint32_t)(t0 + m);
+            if (levels >= 3u) p.taper[2] = (uint32_t)(t0 + 2u * m);
+            p.chunks = count_chunks(chunk, p.taper, n);
+        }
+    }
     p.blocks = (uint32_t)(blocks > p.chunks ? p.chunks : blocks);
     p.tickets = tickets;
     return p;

@@ -1113,14 +1113,19 @@ extern "C" int fg_launch_rfc5424(const uint8_t* d_bytes, const uint64_t* d_offse
     if (sdx)
         // (default tile from the same-box sweeps, profiles/r04g_sweep_*: 12 KiB -- eight waves per CU -- for whole lines and for heads)
         // (tiles of at most 36 KiB: with the two bitmaps and the walk's scratch -- 0.57 x the tile -- that is 58 KiB of LDS per wave)
+        // (chunks of 128 lines, drawn by ticket from two per wave on: round 4's 1024 was the round-robin form's optimum; under tickets,
+        //  one box, alternated -- profiles/r05u_chunk_taper_sweep.log -- 4 M lines: 1879-1905 M lines/s as one share per wave, 1990 in
+        //  chunks of 128, 1938-1967 at 256 / 512; 16 M lines: 2008-2013 at 1024, 2074-2082 at 128 .. 512; the long-tail corpus 1349 -> 1396.
+        //  From FOUR chunks per wave on: at 1 M lines -- 3.8 per wave -- one share per wave measured 1716-1743 M lines/s, tickets
+        //  1638-1663; at 2 M lines 1804-1844 against 1845-1873, at 16 M 1880 against 2075: profiles/r05v_policy_ab.log)
         prc = head ? fg::plan_launch(fg::k_rfc5424<fg::kWindowKiB, false, true, true>, n, plan_len, 0u, 36864u, sb, &p, *lo, 64, 2, nullptr,
-                                     fg::sd2::extra_bytes, 12288u, 1024u)
+                                     fg::sd2::extra_bytes, 12288u, 128u, 4u)
                    : fg::plan_launch(fg::k_rfc5424<fg::kWindowKiB, false, false, true>, n, plan_len, 0u, 36864u, sb, &p, *lo, 64, 2, nullptr,
-                                     fg::sd2::extra_bytes, 12288u, 1024u);
+                                     fg::sd2::extra_bytes, 12288u, 128u, 4u);
     else
         // (tickets from 20 chunks per wave on: the HBM-bound kernel pays for the first round's burst, fg_pipeline.hpp plan_launch)
         prc = head ? fg::plan_launch(fg::k_rfc5424<fg::kWindowKiB, false, true>, n, plan_len, 0u, 57344u, sb, &p, *lo)
-                   : fg::plan_launch(fg::k_rfc5424<fg::kWindowKiB, false>, n, plan_len, 0u, 57344u, sb, &p, *lo, 64, 1, nullptr, nullptr, 0u, 0u, 20u);
+                   : fg::plan_launch(fg::k_rfc5424<fg::kWindowKiB, false>, n, plan_len, 0u, 57344u, sb, &p, *lo, 64, 1, nullptr, nullptr, 0u, 0u, 20u, 0u);
     if (prc) return -1;
     if (stash_blocks == 0) stash = nullptr;
     dim3 grid(p.blocks), block(fg::kWave);

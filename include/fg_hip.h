@@ -214,6 +214,11 @@ enum {
     FG_LO_FRAME_SELFTEST_STALL = 1024, /* framing self-test: the one-pass scan's second tile never publishes its descriptor, so the tiles behind
                                       it must give up within the spin bound and the call must come back through the classic kernels with
                                       the same result (tests; never set in production: it costs the spin bound, ~0.2 s) */
+    FG_LO_NO_TAPER = 2048,         /* ticket launches: every chunk of the batch the same size -- by default the last chunk per wave's worth of
+                                      lines is dealt out in halves, quarters and eighths of a chunk, so that the grid finishes together
+                                      (fg_plan_policy.hpp; A/B, tests) */
+    FG_LO_TAPER_1 = 4096,          /* ... at most one such level (halves) instead of the format's own depth; */
+    FG_LO_TAPER_2 = 8192,          /* ... at most two (halves, quarters); both bits: three (tuning) */
     FG_LO_RESERVED = 0x40000000    /* the library's own (fg_set_launch_opts clears it) */
 };
 

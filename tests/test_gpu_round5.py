@@ -54,7 +54,9 @@ def test_small_batches_under_both_dispatch_forms(oracle, name):
     make, cfg, lines = corpora()[name]
     sizes = [1, 2, 63, 64, 65, 127, 1000, 5000, len(lines)]
     for opts in (dict(), dict(static_chunks=True), dict(chunk_lines=1), dict(chunk_lines=3, waves_per_cu=1),
-                 dict(chunk_lines=100, waves_per_cu=2), dict(chunk_lines=64, static_chunks=True)):
+                 dict(chunk_lines=100, waves_per_cu=2), dict(chunk_lines=64, static_chunks=True),
+                 # (named chunks with room for a taper -- halves, quarters, eighths of a chunk at the end of the batch -- and without)
+                 dict(chunk_lines=64, waves_per_cu=1), dict(chunk_lines=100, waves_per_cu=2, no_taper=True)):
         dec = make()
         dec.set_launch_opts(**opts)
         for n in sizes:

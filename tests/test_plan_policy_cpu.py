@@ -22,20 +22,31 @@ def plan():
     if not LIB.exists() or LIB.stat().st_mtime < max(p.stat().st_mtime for p in DEPS):
         subprocess.run(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-Wall", "-o", str(LIB), str(SRC)], check=True)
     lib = C.CDLL(str(LIB))
-    lib.fgp_plan_chunks.argtypes = [u64, u64, u32, u64, u64, u32, u32, u32, C.POINTER(u64)]
+    lib.fgp_plan_chunks.argtypes = [u64, u64, u32, u64, u64, u32, u32, u32, u32, C.POINTER(u64)]
     lib.fgp_entry_chunk.argtypes = [u64, u32, u64, u32]
     lib.fgp_entry_chunk.restype = u32
 
-    def chunks(n, blocks, L_=64, g=64, full=256, ticket_from=2, flags=0, chunk_lines=0):
-        out = (u64 * 4)()
-        lib.fgp_plan_chunks(n, blocks, L_, g, full, ticket_from, flags, chunk_lines, out)
-        return int(out[0]), int(out[1]), int(out[2]), bool(out[3])
+    lib.fgp_chunk_range.argtypes = [u64, u64, u32, u32, u32, u64, C.POINTER(u64)]
 
+    def chunks(n, blocks, L_=64, g=64, full=256, ticket_from=2, flags=0, chunk_lines=0, taper=False, levels=1):
+        out = (u64 * 7)()
+        lib.fgp_plan_chunks(n, blocks, L_, g, full, ticket_from, flags, chunk_lines, levels, out)
+        r = int(out[0]), int(out[1]), int(out[2]), bool(out[3])
+        return r + (tuple(int(out[4 + j]) for j in range(3)),) if taper else r
+
+    def chunk_range(c, chunk, taper, n):
+        out = (u64 * 2)()
+        lib.fgp_chunk_range(c, chunk, taper[0], taper[1], taper[2], n, out)
+        return int(out[0]), int(out[1])
+
+    chunks.range = chunk_range
     return chunks, lib.fgp_entry_chunk
 
 
-GEOMETRIES = [  # (L, g, full, ticket_from, blocks): headline, structured data, GELF, LTSV long lines
-    (64, 64, 256, 20, 1792), (64, 20, 1024, 2, 2048), (8, 8, 128, 2, 5120), (64, 30, 512, 2, 1792), (64, 1, 512, 2, 1792)]
+NO_TAPER = 0xFFFFFFFF
+GEOMETRIES = [  # (L, g, full, ticket_from, blocks, taper levels): headline, structured data, GELF, LTSV long lines
+    (64, 64, 256, 20, 1792, 0), (64, 20, 128, 2, 2048, 1), (8, 8, 64, 2, 5120, 1), (64, 30, 512, 2, 1792, 1), (64, 1, 512, 2, 1792, 3),
+    (64, 20, 1024, 2, 2048, 3), (8, 8, 128, 2, 5120, 2)]
 
 
 def test_every_plan_covers_the_batch_and_fits_the_grid(plan):
@@ -43,12 +54,19 @@ def test_every_plan_covers_the_batch_and_fits_the_grid(plan):
     rng = np.random.default_rng(5)
     sizes = [1, 2, 7, 63, 64, 65, 1000, 16_384, 65_536, 262_144, 1 << 20, 4 << 20, 16 << 20, 100_000_000, 1 << 32] + \
         [int(x) for x in np.exp(rng.uniform(0, np.log(2e9), 300))]
-    for L_, g, full, tf, blocks in GEOMETRIES:
-        for flags in (0, L.FG_LO_STATIC_CHUNKS):
+    for L_, g, full, tf, blocks, lv in GEOMETRIES:
+        for flags in (0, L.FG_LO_STATIC_CHUNKS, L.FG_LO_TAPER_1 | L.FG_LO_TAPER_2):
             for cl in (0, 1, 3, 64, 100, 65536):
                 for n in sizes:
-                    chunk, nch, blk, tickets = chunks(n, blocks, L_, g, full, tf, flags, cl)
-                    assert chunk >= 1 and nch == -(-n // chunk), (n, L_, g, full, flags, cl)
+                    chunk, nch, blk, tickets, taper = chunks(n, blocks, L_, g, full, tf, flags, cl, taper=True, levels=lv)
+                    assert chunk >= 1 and nch >= -(-n // chunk), (n, L_, g, full, flags, cl)
+                    if lv == 0 and not flags & (L.FG_LO_TAPER_1 | L.FG_LO_TAPER_2):
+                        assert taper[0] == NO_TAPER, "the headline kernel never tapers by itself"
+                    if taper[0] == NO_TAPER:
+                        assert nch == -(-n // chunk) and taper == (NO_TAPER,) * 3
+                    else:  # the tail is at most one chunk per wave's worth of lines, in at most 4 x as many chunks
+                        assert tickets and nch <= -(-n // chunk) + 7 * min(blocks, n // (2 * chunk)) + 8
+                        assert chunks(n, blocks, L_, g, full, tf, flags | L.FG_LO_NO_TAPER, cl, levels=lv) == (chunk, -(-n // chunk), min(blocks, -(-n // chunk)), True)
                     assert 1 <= blk <= min(blocks, nch)
                     assert not (tickets and flags & L.FG_LO_STATIC_CHUNKS)
                     if not tickets and not flags and not cl:
@@ -60,7 +78,11 @@ def test_every_plan_covers_the_batch_and_fits_the_grid(plan):
 def test_the_documented_cases(plan):
     chunks, _ = plan
     # headline kernel (64 lines to the group, 1792 waves, tickets from 20 chunks of 256 per wave)
-    assert chunks(100_000_000, 1792, 64, 64, 256, 20) == (256, 390_625, 1792, True)
+    assert chunks(100_000_000, 1792, 64, 64, 256, 20, levels=0) == (256, 390_625, 1792, True)
+    # ... under FG_LO_TAPER_1 | _2 (tuning): the last chunk per wave's worth of lines in halves and quarters (a chunk never falls below
+    # one average group: 64 lines)
+    assert chunks(100_000_000, 1792, 64, 64, 256, 20, L.FG_LO_TAPER_1 | L.FG_LO_TAPER_2, taper=True, levels=0) == \
+        (256, 388_833 + 1792 + 2 * 1792, 1792, True, (388_833, 390_625, NO_TAPER))
     assert chunks(16 << 20, 1792, 64, 64, 256, 20)[3] is True           # 9363 lines per wave >= 5120
     c = chunks(4 << 20, 1792, 64, 64, 256, 20)
     assert c == (2341, 1792, 1792, False)                                # one chunk per wave, no tickets
@@ -71,9 +93,12 @@ def test_the_documented_cases(plan):
     assert (chunk, tickets) == (20, False) and nch == blk == 820
     # ... and the round-robin form of rounds 3-4 kept its 64-line floor
     assert chunks(16_384, 820, 64, 20, 1024, 2, L.FG_LO_STATIC_CHUNKS)[0] == 64
-    # GELF: tickets from two chunks of 128 lines per wave on
-    assert chunks(4_000_000, 5120, 8, 8, 128, 2) == (128, 31_250, 5120, True)
-    assert chunks(524_288, 5120, 8, 8, 128, 2)[3] is False
+    # GELF: tickets from two chunks of 64 lines per wave on; the last 5120 chunks' worth of lines go out as 10 240 chunks of 32
+    assert chunks(4_000_000, 5120, 8, 8, 64, 2, L.FG_LO_NO_TAPER) == (64, 62_500, 5120, True)
+    assert chunks(4_000_000, 5120, 8, 8, 64, 2, taper=True) == (64, 57_380 + 10_240, 5120, True, (57_380, NO_TAPER, NO_TAPER))
+    # ... three levels (tuning): 5120 chunks of 64, 5120 of 32 and 10 240 of 16 lines behind 26 130 of 128
+    assert chunks(4_000_000, 5120, 8, 8, 128, 2, taper=True, levels=3) == (128, 26_130 + 5120 + 5120 + 10_240, 5120, True, (26_130, 31_250, 36_370))
+    assert chunks(524_288, 5120, 8, 8, 64, 2)[3] is False
     # a named chunk size under dynamic dispatch always draws (tests, tuning)
     assert chunks(70_000, 1792, 64, 64, 256, 20, 0, 3) == (40, 1750, 1750, True) or chunks(70_000, 1792, 64, 64, 256, 20, 0, 3)[3] is True
 
@@ -97,3 +122,35 @@ def test_entry_reservations(plan):
         assert c == 0 or (256 <= c <= 4096 and c * waves <= cap // 4 + 4096 * waves // 16 + 256 * waves)
         if c:
             assert cap // (4 * waves) >= 256
+
+
+def test_tapered_chunks_tile_the_batch_exactly(plan):
+    """chunk index -> lines (fg::chunk_range, the function the kernels call): consecutive, non-empty, in order, covering [0, n) with
+    exactly the number of chunks the host books on the ticket counter."""
+    chunks, _ = plan
+    rng = np.random.default_rng(11)
+    cases = [(4_000_000, 5120, 8, 8, 128, 2, 0), (70_000, 5120, 8, 8, 128, 2, 64), (70_000, 5120, 8, 8, 128, 2, 16), (4_194_304, 2048, 64, 20, 1024, 2, 512),
+             (1_000_003, 1792, 64, 64, 256, 2, 0), (999, 1792, 64, 1, 512, 2, 8), (100_000, 7, 64, 5, 512, 2, 0)]
+    for _ in range(60):
+        L_ = int(rng.choice([8, 64]))
+        cases.append((int(rng.integers(1, 3_000_000)), int(rng.integers(1, 6000)), L_, int(rng.integers(1, L_ + 1)),
+                      int(rng.choice([128, 256, 512, 1024])), 2, int(rng.choice([0, 0, 5, 64, 100, 777]))))
+    tapered = 0
+    for idx, (n, blocks, L_, g, full, tf, cl) in enumerate(cases):
+        chunk, nch, blk, tickets, taper = chunks(n, blocks, L_, g, full, tf, 0, cl, taper=True, levels=1 + idx % 3)
+        tapered += taper[0] != NO_TAPER
+        if nch > 400_000:
+            continue
+        at = 0
+        sizes = []
+        for c in range(nch):
+            lo, hi = chunks.range(c, chunk, taper, n)
+            assert lo == at and hi > lo, (n, blocks, chunk, taper, c)
+            sizes.append(hi - lo)
+            at = hi
+        assert at == n
+        assert chunks.range(nch, chunk, taper, n) == (n, n) and chunks.range(nch + 12345, chunk, taper, n) == (n, n)
+        assert all(a >= b for a, b in zip(sizes[:-1], sizes[1:-1])), "chunk sizes never grow (but for the batch's last, ragged one)"
+        if taper[0] != NO_TAPER:
+            assert min(sizes[:-1] or [g]) >= min(g, chunk), "no chunk below one average group"
+    assert tapered >= 20

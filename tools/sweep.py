@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One corpus, many launch geometries: tools/sweep.py <workload> [--lines N] [--reps R] opts;opts;...   (opts = k=v,k=v; empty = defaults)
+"""One corpus, many launch geometries: tools/sweep.py <workload> [--lines N] [--reps R[,R...]] opts;opts;...   (opts = k=v,k=v; empty = defaults)
 Generates the workload's tile ONCE, keeps it resident, and times fg_decode_batch_device under each fg_set_launch_opts setting (HIP
 events, 5 launches after 2 warm-ups) -- an A/B on the SAME box in seconds instead of one bench.py process per point."""
 import sys
@@ -17,24 +17,31 @@ from flowgger_amd import synth  # noqa: E402
 def main():
     wl = sys.argv[1]
     args = sys.argv[2:]
-    lines_n, reps = 1_000_000, 4
+    lines_n, reps_list = 1_000_000, [4]
     while args and args[0].startswith("--"):
         if args[0] == "--lines":
             lines_n = int(args[1])
         elif args[0] == "--reps":
-            reps = int(args[1])
+            reps_list = [int(x) for x in args[1].split(",")]
         args = args[2:]
     settings = (args[0] if args else "").split(";")
     fmt = bench.WORKLOADS[wl][0]
-    if wl == "cfg3":
-        lines = synth.gelf_lines(lines_n)
-    elif wl in ("ltsv", "ltsv5"):
-        lines = synth.ltsv_lines(lines_n, long_tail=wl == "ltsv5")
-    elif wl == "cfg5":
-        lines = synth.rfc5424_lines(lines_n, cfg=5, sd=True, long_tail=True)
-    else:
-        lines = synth.rfc5424_lines(lines_n, cfg=4 if wl == "cfg4" else 2, sd=wl == "cfg4")
+    def gen():
+        if wl == "cfg3":
+            return synth.gelf_lines(lines_n)
+        if wl in ("ltsv", "ltsv5"):
+            return synth.ltsv_lines(lines_n, long_tail=wl == "ltsv5")
+        if wl == "cfg5":
+            return synth.rfc5424_lines(lines_n, cfg=5, sd=True, long_tail=True)
+        return synth.rfc5424_lines(lines_n, cfg=4 if wl == "cfg4" else 2, sd=wl == "cfg4")
+
+    lines = bench.cached_lines(f"sweep_{wl}_{lines_n}", gen)  # (FG_BENCH_CACHE=<dir>: one pickle per corpus, for scripts that call this file repeatedly)
     dev = torch.device("cuda", 0)
+    for reps in reps_list:
+        sweep(wl, fmt, lines, reps, dev, settings)
+
+
+def sweep(wl, fmt, lines, reps, dev, settings):
     R = bench.Resident(fmt, lines, reps, dev, 0, {}, entries=wl != "cfg2")
     stream = torch.cuda.current_stream(dev)
     for s in settings:
@@ -50,7 +57,9 @@ def main():
         torch.cuda.synchronize(dev)
         ms = float(np.median([a.elapsed_time(b) for a, b in ev]))
         n_ok, used = R.check_replicas()
-        print(f"{wl:6s} {s or 'defaults':40s} {R.n / ms / 1e3:9.1f} M lines/s  {ms:8.3f} ms  ok/tile {n_ok}", flush=True)
+        print(f"{wl:6s} n={R.n:10d} {s or 'defaults':40s} {R.n / ms / 1e3:9.1f} M lines/s  {ms:8.3f} ms  ok/tile {n_ok}", flush=True)
+    del R
+    torch.cuda.empty_cache()
 
 
 main()
