@@ -62,6 +62,9 @@ struct LdsReader {
         q[2] = __builtin_amdgcn_alignbyte(d3, d2, sh);
         q[3] = __builtin_amdgcn_alignbyte(d4, d3, sh);
     }
+    // 16 bytes starting at byte i of which only the first nb (1 .. 15) are wanted; the others come back unspecified.  The tile is
+    // followed by 16 bytes of padding and the launch's configuration mirror: the reads stay inside the workgroup's LDS.
+    __device__ __forceinline__ void load16p(uint32_t i, uint32_t, uint32_t* q) { load16(i, q); }
 };
 struct GlobalReader {
     // Round 5: the reader keeps the ALIGNED 16 bytes around its position (one dwordx4 load) instead of one dword: a byte-wise walk
@@ -116,6 +119,12 @@ struct GlobalReader {
         q[1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
         q[2] = __builtin_amdgcn_alignbyte(d3, d2, sh);
         q[3] = __builtin_amdgcn_alignbyte(d4, d3, sh);
+    }
+    // the first nb (1 .. 15) of 16 bytes starting at byte i, dword by dword: never reads a chunk without wanted bytes (this reader
+    // serves the rare group that does not fit its tile)
+    __device__ __forceinline__ void load16p(uint32_t i, uint32_t nb, uint32_t* q) {
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) q[j] = nb > 4u * j ? load4(i + 4u * j, nb - 4u * j < 4u ? nb - 4u * j : 4u) : 0u;
     }
 };
 

@@ -349,28 +349,13 @@ struct Bcd17 {
     }
 };
 
-// value must be finite.  Streams at most 26 characters into sink.put(char code).
+// The digits dg * 10^k as rapidjson's Prettify prints them, streamed into sink.put(char code): at most 25 characters.
 template <class Sink>
-FGD_HD void write_to(double value, Sink& sink) {
-    uint64_t u;
-    memcpy(&u, &value, 8);
-    if (u >> 63) {
-        sink.put((uint32_t)'-');
-        value = -value;
-    }
-    if ((u << 1) == 0) {  // +-0.0
-        sink.put((uint32_t)'0');
-        sink.put((uint32_t)'.');
-        sink.put((uint32_t)'0');
-        return;
-    }
-    Digits dg;
-    int k = 0;
-    grisu2(value, dg, &k);
+FGD_HD void stream_digits(const Digits& dg, int k, Sink& sink) {
     const int len = dg.len;
     const Bcd17 bcd(dg);
     const int kk = len + k;  // 10^(kk-1) <= v < 10^kk
-    // rapidjson's Prettify as ONE stream: `lead` zeros ("0." + zeros for 1234e-6 -> 0.001234), the digits with a '.'
+    // ONE stream: `lead` zeros ("0." + zeros for 1234e-6 -> 0.001234), the digits with a '.'
     // after digit `dot` (0: none), `trail` zeros and ".0" (1234e7 -> 12340000000.0), or an exponent
     int dot = 0, trail = 0, lead = 0;
     bool exp = false, point_zero = false;
@@ -409,14 +394,100 @@ FGD_HD void write_to(double value, Sink& sink) {
         sink.put((uint32_t)'0' + (uint32_t)(K % 10));
     }
 }
-// Buffer form (host tests): writes at most 26 characters into out, returns the count.
+// the sign and the zeros; false = the text is complete
+template <class Sink>
+FGD_HD bool write_sign_zero(double& value, Sink& sink) {
+    uint64_t u;
+    memcpy(&u, &value, 8);
+    if (u >> 63) {
+        sink.put((uint32_t)'-');
+        value = -value;
+    }
+    if ((u << 1) == 0) {  // +-0.0
+        sink.put((uint32_t)'0');
+        sink.put((uint32_t)'.');
+        sink.put((uint32_t)'0');
+        return false;
+    }
+    return true;
+}
+// value must be finite.  Streams at most 26 characters into sink.put(char code).
+template <class Sink>
+FGD_HD void write_to(double value, Sink& sink) {
+    if (!write_sign_zero(value, sink)) return;
+    Digits dg;
+    int k = 0;
+    grisu2(value, dg, &k);
+    stream_digits(dg, k, sink);
+}
+
+// four BCD digits (the low 16 bits of y, the first digit in the highest nibble) as four ASCII bytes, the first digit in byte 0
+FGD_HD uint32_t ascii4(uint32_t y) {
+    uint32_t z = (y | (y << 8)) & 0x00FF00FFu;
+    z = (z | (z << 4)) & 0x0F0F0F0Fu;  // (the first digit in byte 3)
+    return __builtin_bswap32(z) + 0x30303030u;
+}
+// The same text for a sink that takes PIECES (fg_emit.hpp: put16 / put_part / add, kCount): a timestamp -- seconds with a fraction, or
+// whole seconds: the decimal point falls inside the first 17 positions -- is assembled in registers and handed over as one piece or
+// two instead of seventeen to twenty put() calls (what a put costs the write pass: PackSink::put_part).  Everything else streams.
+template <class Sink>
+FGD_HD void write_pieces(double value, Sink& sink) {
+    if (!write_sign_zero(value, sink)) return;
+    Digits dg;
+    int k = 0;
+    grisu2(value, dg, &k);
+    const int len = dg.len, kk = len + k;
+    if (!(0 < kk && kk <= 16)) {
+        stream_digits(dg, k, sink);
+        return;
+    }
+    // digits [0, kk) '.' digits [kk, len)   (k < 0: len + 1 characters)   or   digits, k zeros, ".0"   (k >= 0: kk + 2 characters) --
+    // the 17 BCD digits are zero beyond len, so the string S of their ASCII codes holds the trailing zeros already
+    const uint32_t L = (uint32_t)(k < 0 ? len + 1 : kk + 2), dot = (uint32_t)kk;
+    if (Sink::kCount) {
+        sink.add(L);
+        return;
+    }
+    const Bcd17 bcd(dg);
+    const uint32_t u0 = ascii4(bcd.a >> 16), u1 = ascii4(bcd.a & 0xFFFFu), u2 = ascii4(bcd.b >> 16), u3 = ascii4(bcd.b & 0xFFFFu);
+    const uint32_t S[5] = {((uint32_t)'0' + bcd.top) | u0 << 8, u0 >> 24 | u1 << 8, u1 >> 24 | u2 << 8, u2 >> 24 | u3 << 8, u3 >> 24};
+    uint32_t R[5];
+#ifdef __HIP_DEVICE_COMPILE__
+#pragma unroll
+#endif
+    for (uint32_t j = 0; j < 5u; ++j) {
+        const uint32_t shifted = (j ? S[j - 1u] >> 24 : 0u) | S[j] << 8;        // the string moved up by the '.'
+        const uint32_t v = dot > 4u * j ? dot - 4u * j : 0u;                    // this dword's bytes in front of the '.'
+        const uint32_t m = v >= 4u ? 0xFFFFFFFFu : (1u << (8u * v)) - 1u;
+        uint32_t r = (S[j] & m) | (shifted & ~m);
+        if (v < 4u && dot >= 4u * j) r = (r & ~(0xFFu << (8u * v))) | (uint32_t)'.' << (8u * v);
+        const uint32_t keep = L > 4u * j ? L - 4u * j : 0u;                     // ... and of the text at all
+        R[j] = keep >= 4u ? r : (r & ((1u << (8u * keep)) - 1u));
+    }
+    if (L >= 16u) {
+        sink.put16(R[0], R[1], R[2], R[3]);
+        if (L > 16u) sink.put_part(R[4], 0u, 0u, 0u, L - 16u);
+    } else {
+        sink.put_part(R[0], R[1], R[2], R[3], L);
+    }
+}
+// Buffer form (host tests): writes at most 26 characters into out, returns the count.  Through write_pieces, so that the tests of
+// this function cover the assembled form as well as the streamed one.
+struct BufSink {
+    static constexpr bool kCount = false;
+    char* p;
+    int n;
+    FGD_HD void put(uint32_t c) { p[n++] = (char)c; }
+    FGD_HD void add(uint32_t) {}
+    FGD_HD void put_part(uint32_t q0, uint32_t q1, uint32_t q2, uint32_t q3, uint32_t nb) {
+        const uint32_t q[4] = {q0, q1, q2, q3};
+        for (uint32_t i = 0; i < nb; ++i) p[n++] = (char)(q[i >> 2] >> (8u * (i & 3u)));
+    }
+    FGD_HD void put16(uint32_t q0, uint32_t q1, uint32_t q2, uint32_t q3) { put_part(q0, q1, q2, q3, 16u); }
+};
 FGD_HD int write(double value, char* out) {
-    struct BufSink {
-        char* p;
-        int n;
-        FGD_HD void put(uint32_t c) { p[n++] = (char)c; }
-    } bs{out, 0};
-    write_to(value, bs);
+    BufSink bs{out, 0};
+    write_pieces(value, bs);
     return bs.n;
 }
 

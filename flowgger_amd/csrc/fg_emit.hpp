@@ -41,8 +41,11 @@ enum : uint32_t { SK_APP = 0, SK_FULL = 1, SK_HOST = 2, SK_LEVEL = 3, SK_PROC = 
 struct StaticKey {
     uint32_t key_off, key_len;    // the raw key bytes (for the merge with the record's own keys), into the blob
     uint32_t kind;                // SK_*
-    uint32_t text_off, text_len;  // the member text up to the value: `"key":` with the key JSON-escaped; SK_EXTRA:
-                                  // the whole member `"key":"value"` (4-byte aligned in the blob)
+    // The member text up to the value's first own byte, TWICE (both 4-byte aligned in the blob, text_len bytes each): at text_off
+    // behind a ',' -- `,"key":` with the key JSON-escaped --, at text1_off behind the '{' of an object it opens.  The kinds whose value
+    // is always a string carry its opening quote (`,"host":"`), SK_VERSION and SK_EXTRA the whole member (`,"version":"1.1"`,
+    // `,"key":"value"`): every byte that does not depend on the record is part of ONE piece (what a piece costs: PackSink::put_part).
+    uint32_t text_off, text1_off, text_len;
 };
 struct EncCfg {
     const uint8_t* blob;       // GELF keys + extra values, LTSV suffixes, the LTSV extras text, the prepend header
@@ -188,6 +191,7 @@ struct CountSink {
     FGE_HD void put(uint32_t) { ++n; }
     FGE_HD void put_word(uint32_t, uint32_t nb) { n += nb; }
     FGE_HD void put16(uint32_t, uint32_t, uint32_t, uint32_t) { n += 16u; }
+    FGE_HD void put_part(uint32_t, uint32_t, uint32_t, uint32_t, uint32_t nb) { n += nb; }
     FGE_HD void add(uint32_t k) { n += k; }
     FGE_HD void finish() {}
 };
@@ -313,6 +317,48 @@ struct PackSink {
         b1 = d == 2u ? t3 : t2;
         b2 = t3;
         acc = t4;
+    }
+    // ONE TO SIXTEEN bytes at once, nb of them, in q0 .. q3 (little-endian; the bytes beyond nb must be ZERO): the tail of a span, a
+    // key's text, a number's digits.  Branch-free but for the store: a message is ~85 short pieces (puts of one to four bytes) around
+    // its two dozen 16-byte copies, the lanes of a wave hold their blocks at 64 different fill levels, so some lane completes a block
+    // at EVERY short put and the wave runs both sides of put_word's branches every time -- fewer, larger pieces are what the write
+    // pass's instruction count is made of.
+    FGE_HD void put_part(uint32_t q0, uint32_t q1, uint32_t q2, uint32_t q3, uint32_t nb) {
+        const uint32_t d = k >> 2, sh = k & 3u;
+        const uint32_t t0 = carry_bytes(q0, 0u, sh), t1 = carry_bytes(q1, q0, sh), t2 = carry_bytes(q2, q1, sh), t3 = carry_bytes(q3, q2, sh),
+                       t4 = carry_bytes(0u, q3, sh);
+        const uint32_t a0 = acc | t0;
+        // the stream's dwords 0 .. 7 from the block's start: the d complete ones, a0, t1 .. t4, zeros
+        const uint32_t o0 = d == 0u ? a0 : b0;
+        const uint32_t o1 = d == 0u ? t1 : d == 1u ? a0 : b1;
+        const uint32_t o2 = d == 0u ? t2 : d == 1u ? t1 : d == 2u ? a0 : b2;
+        const uint32_t o3 = d == 0u ? t3 : d == 1u ? t2 : d == 2u ? t1 : a0;
+        const uint32_t n0 = d == 0u ? t4 : d == 1u ? t3 : d == 2u ? t2 : t1;
+        const uint32_t n1 = d == 1u ? t4 : d == 2u ? t3 : d == 3u ? t2 : 0u;
+        const uint32_t n2 = d == 2u ? t4 : d == 3u ? t3 : 0u;
+        const uint32_t n3 = d == 3u ? t4 : 0u;
+        const uint32_t k2 = k + nb;
+        const bool full = k2 >= 16u;
+        if (full) {
+            if (head) {
+                b0 = o0;
+                b1 = o1;
+                b2 = o2;
+                b3 = o3;
+                store_part(head, 16u, 4u);
+                head = 0;
+            } else {
+                st16(p, o0, o1, o2, o3);
+            }
+            p += 16;
+        }
+        b0 = full ? n0 : o0;
+        b1 = full ? n1 : o1;
+        b2 = full ? n2 : o2;
+        b3 = full ? n3 : o3;
+        k = full ? k2 - 16u : k2;
+        const uint32_t dn = k >> 2;  // (the dword being assembled: its bytes beyond k are zero because q's beyond nb are)
+        acc = dn == 0u ? b0 : dn == 1u ? b1 : dn == 2u ? b2 : b3;
     }
     FGE_HD void put(uint32_t c) { put_word(c & 0xFFu, 1u); }
     FGE_HD void add(uint32_t) {}
@@ -452,40 +498,82 @@ struct Base {
         }
         const uint32_t* w = reinterpret_cast<const uint32_t*>(cfg.blob + off);
         uint32_t i = 0;
-        for (; i + 4u <= len; i += 4u) out.put_word(w[i >> 2], 4u);
-        if (i < len) out.put_word(w[i >> 2] & (0xFFFFFFFFu >> (8u * (4u - (len - i)))), len - i);
+        for (; i + 16u <= len; i += 16u) out.put16(w[i >> 2], w[(i >> 2) + 1u], w[(i >> 2) + 2u], w[(i >> 2) + 3u]);
+        if (i < len) {  // (the blob ends in sixteen bytes of padding: fg_enc_cfg.hpp)
+            uint32_t q[4] = {w[i >> 2], w[(i >> 2) + 1u], w[(i >> 2) + 2u], w[(i >> 2) + 3u]};
+            keep_low(q, len - i);
+            out.put_part(q[0], q[1], q[2], q[3], len - i);
+        }
     }
     // rd[off .. off+len) copied through the per-byte functor `fb` only where a dword holds a byte that needs it
     // (ESC): everything else moves four bytes at a time
+    // the low nb (0 .. 16) of the sixteen bytes q[0 .. 3]; the rest zero
+    static FGE_HD void keep_low(uint32_t* q, uint32_t nb) {
+#ifdef __HIP_DEVICE_COMPILE__
+#pragma unroll
+#endif
+        for (uint32_t j = 0; j < 4u; ++j) {
+            const uint32_t v = nb > 4u * j ? nb - 4u * j : 0u;  // this dword's bytes
+            q[j] = v >= 4u ? q[j] : (q[j] & ((1u << (8u * v)) - 1u));
+        }
+    }
+    // byte c becomes byte `at` (0 .. 15) of the sixteen bytes q[0 .. 3] (which is zero there)
+    static FGE_HD void set_byte(uint32_t* q, uint32_t at, uint32_t c) {
+        const uint32_t w = c << (8u * (at & 3u)), j = at >> 2;
+        q[0] |= j == 0u ? w : 0u;
+        q[1] |= j == 1u ? w : 0u;
+        q[2] |= j == 2u ? w : 0u;
+        q[3] |= j == 3u ? w : 0u;
+    }
+    // rd[off .. off+len) copied through the per-byte functor `fb` only where a dword holds a byte that needs it
+    // (ESC): everything else moves sixteen bytes at a time, the span's last 1 .. 15 bytes as ONE piece -- with the byte `sfx` behind
+    // them when the caller has one (a string's closing quote: a put of its own costs what a whole piece does, PackSink::put_part)
     template <uint32_t ESC, class FB>
-    FGE_HD void copy_raw(uint32_t off, uint32_t len, FB&& fb) {
+    FGE_HD void copy_raw(uint32_t off, uint32_t len, FB&& fb, uint32_t sfx = 0u) {
         if (ESC == ESC_NONE && S::kCount) {
-            out.add(len);
+            out.add(len + (sfx ? 1u : 0u));
             return;
         }
-        for (uint32_t i = 0; i < len;) {
-            uint32_t nb = len - i;
-            if (nb >= 16u) {  // 16 bytes per LDS round trip (the copy is latency-bound: one wave or two per SIMD)
-                uint32_t q[4];
-                rd.load16(off + i, q);
-                if (!(word_needs_bytes<ESC>(q[0]) || word_needs_bytes<ESC>(q[1]) || word_needs_bytes<ESC>(q[2]) || word_needs_bytes<ESC>(q[3]))) {
-                    out.put16(q[0], q[1], q[2], q[3]);
-                    i += 16u;
-                    continue;
-                }
+        uint32_t i = 0;
+        for (; i + 16u <= len; i += 16u) {  // 16 bytes per LDS round trip (the copy is latency-bound: one wave or two per SIMD)
+            uint32_t q[4];
+            rd.load16(off + i, q);
+            if (!(word_needs_bytes<ESC>(q[0]) || word_needs_bytes<ESC>(q[1]) || word_needs_bytes<ESC>(q[2]) || word_needs_bytes<ESC>(q[3]))) {
+                out.put16(q[0], q[1], q[2], q[3]);
+                continue;
             }
-            // the tail, or a dword with a byte that needs fb: byte-wise through ONE fb call site
-            if (nb >= 4u) {
-                const uint32_t w = rd.load4(off + i, 4u);
-                if (!word_needs_bytes<ESC>(w)) {
-                    out.put_word(w, 4u);
-                    i += 4u;
-                    continue;
-                }
-                nb = 4u;
+            slow16<ESC>(q, 16u, fb);
+        }
+        const uint32_t nb = len - i;  // 0 .. 15
+        if (nb == 0u && !sfx) return;
+        uint32_t q[4] = {0u, 0u, 0u, 0u};
+        if (nb) {
+            rd.load16p(off + i, nb, q);
+            keep_low(q, nb);
+            // (the bytes beyond nb are zero: for the escape test they read as plain letters)
+            const uint32_t fill = 0x61616161u;
+            const uint32_t f0 = nb >= 4u ? 0u : fill << (8u * nb), f1 = nb >= 8u ? 0u : nb <= 4u ? fill : fill << (8u * (nb - 4u)),
+                           f2 = nb >= 12u ? 0u : nb <= 8u ? fill : fill << (8u * (nb - 8u)), f3 = nb <= 12u ? fill : fill << (8u * (nb - 12u));
+            if (word_needs_bytes<ESC>(q[0] | f0) || word_needs_bytes<ESC>(q[1] | f1) || word_needs_bytes<ESC>(q[2] | f2) || word_needs_bytes<ESC>(q[3] | f3)) {
+                slow16<ESC>(q, nb, fb);
+                if (sfx) out.put(sfx);
+                return;
             }
-            for (uint32_t j = 0; j < nb; ++j) fb(rd.byte(off + i + j));
-            i += nb;
+        }
+        if (sfx) set_byte(q, nb, sfx);
+        out.put_part(q[0], q[1], q[2], q[3], nb + (sfx ? 1u : 0u));
+    }
+    // nb (1 .. 16) bytes in q with a byte that needs fb among them: dword by dword, byte-wise only where it is
+    template <uint32_t ESC, class FB>
+    FGE_HD void slow16(const uint32_t* q, uint32_t nb, FB&& fb) {
+        for (uint32_t j = 0; j < 4u && 4u * j < nb; ++j) {
+            const uint32_t w = j == 0u ? q[0] : j == 1u ? q[1] : j == 2u ? q[2] : q[3];
+            const uint32_t m = nb - 4u * j < 4u ? nb - 4u * j : 4u;
+            if (m == 4u && !word_needs_bytes<ESC>(w)) {
+                out.put_word(w, 4u);
+                continue;
+            }
+            for (uint32_t b = 0; b < m; ++b) fb((w >> (8u * b)) & 0xFFu);
         }
     }
     FGE_HD void raw_field(int col) {  // a top-level field, decoded, unmodified
@@ -688,23 +776,26 @@ struct GelfEmitter : Base<S, R> {
         }
         out.put_word(w, nb);
     }
-    FGE_HD void member_start() {
-        if (!first_member) out.put(',');
+    FGE_HD void member_start() {  // (the object's '{' comes with its first member)
+        out.put(first_member ? (uint32_t)'{' : (uint32_t)',');
         first_member = false;
     }
-    FGE_HD void key_static(const StaticKey& k) {  // `"key":` (escaped by the host), SK_EXTRA: `"key":"value"`
-        member_start();
-        this->blob(k.text_off, k.text_len);
+    FGE_HD void key_static(const StaticKey& k) {  // `,"key":` / `{"key":` (StaticKey: with everything behind it that is constant)
+        this->blob(first_member ? k.text1_off : k.text_off, k.text_len);
+        first_member = false;
     }
-    FGE_HD void str_span(uint32_t off, uint32_t len, uint32_t mode) {
-        out.put('"');
-        if (mode == M_RAW) this->template copy_raw<ESC_JSON>(off, len, [&](uint32_t c) { esc_byte(c); });
-        else for_each_decoded(rd, off, len, mode, [&](uint32_t c) { esc_byte(c); });
+    FGE_HD void str_span(uint32_t off, uint32_t len, uint32_t mode, bool open_quote = true) {
+        if (open_quote) out.put('"');
+        if (mode == M_RAW) {  // (the closing quote rides on the span's last piece)
+            this->template copy_raw<ESC_JSON>(off, len, [&](uint32_t c) { esc_byte(c); }, (uint32_t)'"');
+            return;
+        }
+        for_each_decoded(rd, off, len, mode, [&](uint32_t c) { esc_byte(c); });
         out.put('"');
     }
-    FGE_HD void str_field(int col) {
+    FGE_HD void str_field(int col) {  // (a static key's value: the key's text ends in the opening quote)
         const fg_span s = this->span(col);
-        str_span(s.off, s.len, this->field_mode(col));
+        str_span(s.off, s.len, this->field_mode(col), false);
     }
     FGE_HD void f64_text(double d) {
         uint64_t b;
@@ -713,7 +804,7 @@ struct GelfEmitter : Base<S, R> {
             this->lit("null", 4);
             return;
         }
-        dtoa::write_to(d, out);  // digits in registers, streamed (no char buffer: that would be scratch memory)
+        dtoa::write_pieces(d, out);  // digits in registers, as one piece or two where the shape allows (no char buffer: that would be scratch memory)
     }
     FGE_HD int cmp_dyn(const Dyn& a, const Dyn& b) {
         const uint32_t la = a.dlen + a.sl, lb = b.dlen + b.sl, n = la < lb ? la : lb;
@@ -780,9 +871,7 @@ struct GelfEmitter : Base<S, R> {
             case SK_HOST: {
                 const fg_span s = this->span(S_HOST);
                 if (s.len == 0u || s.len == FG_NONE) {
-                    out.put('"');
-                    this->lit("unknown", 7);
-                    out.put('"');
+                    this->lit("unknown\"", 8);
                 } else {
                     col = S_HOST;
                 }
@@ -791,14 +880,12 @@ struct GelfEmitter : Base<S, R> {
             case SK_LEVEL: out.put('0' + FG_META_SEVERITY(meta)); break;
             case SK_SDID: {
                 const fg_span id = t.ent_name[sdid_entry];
-                out.put('"');
                 for (uint32_t i = 0; i < id.len; ++i) esc_byte(rd.byte(id.off + i));
                 out.put('"');
                 break;
             }
             case SK_SHORT: {
                 if (!this->some(S_MSG)) {
-                    out.put('"');
                     out.put('-');
                     out.put('"');
                 } else {
@@ -807,12 +894,7 @@ struct GelfEmitter : Base<S, R> {
                 break;
             }
             case SK_TS: f64_text(this->record_ts()); break;
-            case SK_VERSION:
-                out.put('"');
-                this->lit("1.1", 3);
-                out.put('"');
-                break;
-            default: break;  // SK_EXTRA: the value is part of the precomputed member text
+            default: break;  // SK_VERSION, SK_EXTRA: the value is part of the precomputed member text
         }
         if (col >= 0) str_field(col);
     }
@@ -859,7 +941,6 @@ struct GelfEmitter : Base<S, R> {
                 else ranked = false;  // two different names share 7 bytes: exact selection below
             }
         }
-        out.put('{');
         // ONE member loop for both orders (one emit_static / emit_dyn call site each: code size): the next entry in
         // key order comes from the ranking or, when that is not available, from an exact selection -- repeatedly the
         // smallest key greater than the previous one, among equal keys the LAST entry (the later insert)
@@ -897,6 +978,7 @@ struct GelfEmitter : Base<S, R> {
             if (e == kNone) break;
             if (!shadowed) emit_dyn(e);
         }
+        if (first_member) out.put('{');  // (no member at all)
         out.put('}');
         return ES_OK;
     }

@@ -73,13 +73,20 @@ inline bool build_enc_cfg(fg_format src_fmt, const fg_encode_cfg* ec, const std:
             k.key_len = (uint32_t)kv.first.size();
             blob.insert(blob.end(), kv.first.begin(), kv.first.end());
             k.kind = kv.second.kind;
-            std::string text;
+            // (StaticKey: the member's text with everything that is constant, behind ',' and behind '{')
+            std::string text = ",";
             json_text(kv.first, &text);
             text.push_back(':');
             if (kv.second.kind == SK_EXTRA) json_text(kv.second.val, &text);
+            else if (kv.second.kind == SK_VERSION) text += "\"1.1\"";
+            else if (kv.second.kind != SK_LEVEL && kv.second.kind != SK_TS) text.push_back('"');  // a string: its opening quote
+            k.text_len = (uint32_t)text.size();
             align4(&blob);
             k.text_off = (uint32_t)blob.size();
-            k.text_len = (uint32_t)text.size();
+            blob.insert(blob.end(), text.begin(), text.end());
+            text[0] = '{';
+            align4(&blob);
+            k.text1_off = (uint32_t)blob.size();
             blob.insert(blob.end(), text.begin(), text.end());
             out->keys.push_back(k);
         }
@@ -111,7 +118,7 @@ inline bool build_enc_cfg(fg_format src_fmt, const fg_encode_cfg* ec, const std:
         blob.insert(blob.end(), p.begin(), p.end());
         cfg.prepend_len = (uint32_t)p.size();
     }
-    blob.resize(blob.size() + 8, 0);  // readable padding behind the last piece
+    blob.resize(blob.size() + 16, 0);  // readable padding behind the last piece (Base::blob reads sixteen bytes at a piece's tail)
     cfg.src_fmt = (uint32_t)src_fmt;
     cfg.enc = (uint32_t)ec->encoder;
     cfg.merger = (uint32_t)ec->merger;

@@ -20,6 +20,10 @@ struct HostReader {
         return w;
     }
     void load16(uint32_t i, uint32_t* q) { memcpy(q, p + i, 16); }  // all 16 bytes are wanted by contract
+    void load16p(uint32_t i, uint32_t nb, uint32_t* q) {  // the first nb wanted, the rest unspecified: garbage, so that a missing mask shows
+        memset(q, 0xEE, 16);
+        memcpy(q, p + i, nb);
+    }
 };
 struct Cur {
     const uint8_t* p;

@@ -125,7 +125,10 @@ def test_kernel_dtoa_header_equals_oracle_dtoa(oracle):
         rng.integers(-10 ** 6, 10 ** 6, 20000) / 10.0 ** rng.integers(0, 8, 20000),
         10.0 ** rng.integers(-320, 308, 20000) * rng.random(20000),
         np.frombuffer(rng.bytes(8 * 60000), np.float64),
-        np.array([0.0, -0.0, 1.0, 1e21, 1e-7, 5e-324, 1.7976931348623157e308, 123.456, 1385053862.3072, 2.0 ** 63, 2.0 ** 64])])
+        # (whole seconds, and the edges of the form that is assembled in registers: the point within the first 17 positions)
+        rng.integers(0, 4102444800, 7000).astype(np.float64), 10.0 ** rng.integers(0, 18, 700), rng.integers(1, 10 ** 17, 7000).astype(np.float64),
+        rng.integers(1, 10 ** 17, 7000) / 10.0 ** rng.integers(0, 18, 7000),
+        np.array([0.0, -0.0, 1.0, 1e21, 1e-7, 5e-324, 0.5, 9.5, 1e15, 1e16, 1e17, 9999999999999998.0, 99999999999999984.0, 1234567890123456.7, 0.1, 16.0, 1.7976931348623157e308, 123.456, 1385053862.3072, 2.0 ** 63, 2.0 ** 64])])
     vals = np.ascontiguousarray(vals[np.isfinite(vals)], np.float64)
     buf = C.create_string_buffer(32 * len(vals))
     L.fgd_write_batch(vals.ctypes.data_as(C.POINTER(C.c_double)), C.c_uint64(len(vals)), buf)
