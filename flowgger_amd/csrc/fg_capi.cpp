@@ -603,7 +603,7 @@ int encode_device_impl(fg_ctx* ctx, fg_format src_fmt, const fg_encode_cfg* ecfg
     } else {
         cfg.out_cap = out_cap ? out_cap : 1;  // the write kernel reads out_offsets[n] itself and leaves d_out alone when it exceeds this
     }
-    lrc = fg_launch_encode_write(d_bytes, d_offsets, n, &dt, &cfg, tile_cap, cfg_lds, d_out_offsets, d_out, s);
+    lrc = fg_launch_encode_write(d_bytes, d_offsets, n, &dt, &cfg, tile_cap, cfg_lds, d_out_offsets, d_out, d_sizes, s);
     if (lrc != 0) {
         ctx->last_hip = lrc;
         return FG_ERR_HIP;

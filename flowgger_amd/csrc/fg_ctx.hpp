@@ -50,7 +50,7 @@ extern "C" int fg_launch_encode_scan(const uint32_t* d_sizes, uint64_t* d_block_
                                      hipStream_t stream);
 extern "C" int fg_launch_encode_write(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
                                       const fg::EncCfg* cfg, uint32_t tile_cap, uint32_t cfg_lds, const uint64_t* d_out_offsets,
-                                      uint8_t* d_out, hipStream_t stream);
+                                      uint8_t* d_out, const uint32_t* d_sizes, hipStream_t stream);
 extern "C" uint64_t fg_frame_scratch_bytes(uint64_t nbytes);
 extern "C" int fg_launch_frame(const uint8_t* d_bytes, uint64_t nbytes, uint32_t delim, uint8_t* scratch, uint64_t* d_offsets,
                                uint8_t* d_bad, uint64_t cap, uint64_t** d_total_out, hipStream_t stream, int classic);

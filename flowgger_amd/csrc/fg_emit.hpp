@@ -188,6 +188,8 @@ FGE_HD void for_each_decoded(R& rd, uint32_t off, uint32_t len, uint32_t mode, F
 struct CountSink {
     static constexpr bool kCount = true;
     uint32_t n = 0;
+    uint32_t slow = 0;  // spans that held a byte to escape (Base::copy_raw): 0 = the write pass may copy this row's spans untested
+    FGE_HD void mark_slow() { slow = 1u; }
     FGE_HD void put(uint32_t) { ++n; }
     FGE_HD void put_word(uint32_t, uint32_t nb) { n += nb; }
     FGE_HD void put16(uint32_t, uint32_t, uint32_t, uint32_t) { n += 16u; }
@@ -227,22 +229,32 @@ struct PackSink {
         *reinterpret_cast<T*>(q) = v;
 #endif
     }
-    // bytes [lo, hi) of the block, from the completed dwords (index < full) and `acc` (index == full): whole dwords as dwords
-    FGE_HD void store_part(uint32_t lo, uint32_t hi, uint32_t full) {
+    // bytes [lo, hi) of the block at q, from its completed dwords (index < full) and `ac` (index == full): whole dwords as dwords.
+    // A message's first and last block only -- ONE copy of the code per kernel, by value (inlined at each of the emitters' ~150 sink
+    // calls it was most of the write kernel's 74 000 vector instructions).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FG_EMIT_INLINE_STORE_PART)  // (the macro: an A/B build)
+    static __device__ __attribute__((noinline))
+#elif defined(__HIP_DEVICE_COMPILE__)
+    static __device__ __forceinline__
+#else
+    static inline
+#endif
+    void store_part_at(uint8_t* q, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t ac, uint32_t lo, uint32_t hi, uint32_t full) {
 #ifdef __HIP_DEVICE_COMPILE__
 #pragma unroll
 #endif
         for (uint32_t d = 0; d < 4u; ++d) {
             const uint32_t a = d * 4u > lo ? d * 4u : lo, e = d * 4u + 4u < hi ? d * 4u + 4u : hi;
             if (a >= e) continue;
-            const uint32_t v = d < full ? dword_of(d) : acc;
+            const uint32_t v = d < full ? (d == 0u ? w0 : d == 1u ? w1 : d == 2u ? w2 : w3) : ac;
             if (e - a == 4u) {
-                st<uint32_t>(p + d * 4u, v);
+                st<uint32_t>(q + d * 4u, v);
             } else {
-                for (uint32_t i = a; i < e; ++i) st<uint8_t>(p + i, (uint8_t)(v >> (8u * (i & 3u))));
+                for (uint32_t i = a; i < e; ++i) st<uint8_t>(q + i, (uint8_t)(v >> (8u * (i & 3u))));
             }
         }
     }
+    FGE_HD void store_part(uint32_t lo, uint32_t hi, uint32_t full) { store_part_at(p, b0, b1, b2, b3, acc, lo, hi, full); }
     static FGE_HD void st16(uint8_t* q, uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
 #if defined(__HIP_DEVICE_COMPILE__)
         typedef uint32_t v4u __attribute__((ext_vector_type(4)));  // (a vector, not a struct: an aggregate copy forgets the address space)
@@ -362,6 +374,7 @@ struct PackSink {
     }
     FGE_HD void put(uint32_t c) { put_word(c & 0xFFu, 1u); }
     FGE_HD void add(uint32_t) {}
+    FGE_HD void mark_slow() {}
     FGE_HD void finish() {
         if (k > head) store_part(head, k, k >> 2);
         p += k;
@@ -381,6 +394,19 @@ FGE_HD bool word_needs_bytes(uint32_t w) {
     if (ESC == ESC_JSON) return (swar_lt20(w) | swar_has(w, '"') | swar_has(w, '\\')) != 0;
     if (ESC == ESC_LTSV_VAL) return (swar_has(w, '\t') | swar_has(w, '\n')) != 0;
     return false;
+}
+// the same tests without their final mask (bit 7 of a byte set = candidate): the terms of several dwords are OR-ed and masked ONCE --
+// one compare and one branch per sixteen bytes instead of four short-circuit tests
+FGE_HD uint32_t swar_zero_raw(uint32_t v) { return (v - 0x01010101u) & ~v; }
+template <uint32_t ESC>
+FGE_HD uint32_t word_needs_raw(uint32_t w) {
+    if (ESC == ESC_JSON) return ((w - 0x20202020u) & ~w) | swar_zero_raw(w ^ 0x22222222u) | swar_zero_raw(w ^ 0x5C5C5C5Cu);
+    if (ESC == ESC_LTSV_VAL) return swar_zero_raw(w ^ 0x09090909u) | swar_zero_raw(w ^ 0x0A0A0A0Au);
+    return 0u;
+}
+template <uint32_t ESC>
+FGE_HD bool any16_needs_bytes(uint32_t q0, uint32_t q1, uint32_t q2, uint32_t q3) {
+    return ((word_needs_raw<ESC>(q0) | word_needs_raw<ESC>(q1) | word_needs_raw<ESC>(q2) | word_needs_raw<ESC>(q3)) & 0x80808080u) != 0u;
 }
 
 // decimal text of v through f(char code), without a digit buffer (a dynamically indexed local array is scratch
@@ -409,6 +435,7 @@ struct RowRegs {
     fg_span s0, s1, s2, s3, s4, s5;
     double ts;
     uint32_t ef, ec;
+    uint32_t plain = 0;  // write pass: the count pass found no byte to escape in any span it tested (row_size's *plain)
     FGE_HD void load(const DevTables& t, uint64_t li) {
         s0 = t.span[0][li];
         s1 = t.span[1][li];
@@ -436,8 +463,12 @@ struct Base {
     fg_span s0{}, s1{}, s2{}, s3{}, s4{}, s5{};
     double row_ts = 0.0;
     uint32_t row_ef = 0, row_ec = 0;
+    // The count pass has tested every span copy_raw moves and found no byte that needs escaping: the write pass copies them untested
+    // (the three SWAR tests are 52 of the ~95 instructions a 16-byte step costs).  False = test, as the count pass itself does.
+    bool plain = false;
     FGE_HD void load_row(const RowRegs* pre) {
         if (pre) {
+            plain = pre->plain != 0u;
             s0 = pre->s0;
             s1 = pre->s1;
             s2 = pre->s2;
@@ -538,10 +569,11 @@ struct Base {
         for (; i + 16u <= len; i += 16u) {  // 16 bytes per LDS round trip (the copy is latency-bound: one wave or two per SIMD)
             uint32_t q[4];
             rd.load16(off + i, q);
-            if (!(word_needs_bytes<ESC>(q[0]) || word_needs_bytes<ESC>(q[1]) || word_needs_bytes<ESC>(q[2]) || word_needs_bytes<ESC>(q[3]))) {
+            if (plain || !any16_needs_bytes<ESC>(q[0], q[1], q[2], q[3])) {
                 out.put16(q[0], q[1], q[2], q[3]);
                 continue;
             }
+            out.mark_slow();
             slow16<ESC>(q, 16u, fb);
         }
         const uint32_t nb = len - i;  // 0 .. 15
@@ -554,7 +586,8 @@ struct Base {
             const uint32_t fill = 0x61616161u;
             const uint32_t f0 = nb >= 4u ? 0u : fill << (8u * nb), f1 = nb >= 8u ? 0u : nb <= 4u ? fill : fill << (8u * (nb - 4u)),
                            f2 = nb >= 12u ? 0u : nb <= 8u ? fill : fill << (8u * (nb - 8u)), f3 = nb <= 12u ? fill : fill << (8u * (nb - 12u));
-            if (word_needs_bytes<ESC>(q[0] | f0) || word_needs_bytes<ESC>(q[1] | f1) || word_needs_bytes<ESC>(q[2] | f2) || word_needs_bytes<ESC>(q[3] | f3)) {
+            if (!plain && any16_needs_bytes<ESC>(q[0] | f0, q[1] | f1, q[2] | f2, q[3] | f3)) {
+                out.mark_slow();
                 slow16<ESC>(q, nb, fb);
                 if (sfx) out.put(sfx);
                 return;
@@ -1342,7 +1375,8 @@ FGE_HD uint32_t encode_row(S& sink, const EncCfg& cfg, R rd, const DevTables& t,
 // count pass: the framed size of row li (0 when nothing is produced) and its encode status
 template <uint32_t ENC, class R>
 FGE_HD uint32_t row_size(const EncCfg& cfg, R rd, const DevTables& t, uint64_t li, uint32_t meta, uint64_t* keys64, uint8_t* slot_ent,
-                         uint8_t* order, uint32_t* status, const RowRegs* pre = nullptr) {
+                         uint8_t* order, uint32_t* status, const RowRegs* pre = nullptr, uint32_t* plain = nullptr) {
+    if (plain) *plain = 0u;
     if (FG_META_STATUS(meta) != 0u) {
         *status = ES_DECODE_FAILED;
         return 0;
@@ -1350,6 +1384,7 @@ FGE_HD uint32_t row_size(const EncCfg& cfg, R rd, const DevTables& t, uint64_t l
     CountSink cs;
     const uint32_t st = encode_row<ENC>(cs, cfg, rd, t, li, meta, keys64, slot_ent, order, pre);
     *status = st;
+    if (plain) *plain = cs.slow ? 0u : 1u;  // (RowRegs::plain of the write pass)
     return st == ES_OK ? (uint32_t)framed_size(cfg.merger, cs.n) : 0u;
 }
 // write pass: `total` = the framed size the count pass returned for this row (the sink starts at the row's offset)

@@ -5,7 +5,8 @@
 //
 // A lane takes the table row of ITS line (spans into the packed line bytes + the entry slice) and emits the output
 // text directly -- the Record is never materialised.  Two passes over the same emitter with different sinks:
-//   k_encode<ENC, false>  count: sizes[i] = framed length of line i (0 when its decode or its encode failed) + status
+//   k_encode<ENC, false>  count: sizes[i] = framed length of line i (0 when its decode or its encode failed; bit 31: no span
+//                         holds a byte to escape) + status
 //   k_block_scan + k_line_offsets   per-workgroup sums -> exclusive scan -> out_offsets[0..n]
 //   k_encode<ENC, true>   write at out + out_offsets[i]
 // so that the output is ONE contiguous, already framed byte stream in input order (what the outputs write).
@@ -50,9 +51,9 @@ __device__ __forceinline__ void encode_lane(R rd, uint64_t li, const DevTables& 
         emit::PackSink sink(out + pre.oo0);
         emit::row_write<ENC>(sink, pre.oo1 - pre.oo0, cfg, rd, t, li, pre.meta, keys64, slot_ent, order, &pre.row);
     } else {
-        uint32_t st;
-        const uint32_t size = emit::row_size<ENC>(cfg, rd, t, li, pre.meta, keys64, slot_ent, order, &st, &pre.row);
-        sizes[li] = size;
+        uint32_t st, plain;
+        const uint32_t size = emit::row_size<ENC>(cfg, rd, t, li, pre.meta, keys64, slot_ent, order, &st, &pre.row, &plain);
+        sizes[li] = size | plain << 31;  // (bit 31: no span of this row holds a byte to escape -- the write pass copies untested)
         if (enc_status) enc_status[li] = (uint8_t)st;
         *size_out = size;
     }
@@ -111,6 +112,7 @@ __global__ __launch_bounds__(kWave, 2) void k_encode(const uint8_t* __restrict__
     if (WRITE) {
         pre.oo0 = out_offsets[lic];
         pre.oo1 = out_offsets[lic + 1u];
+        pre.row.plain = sizes ? sizes[lic] >> 31 : 0u;  // (the count pass's verdict on this row's spans; no sizes: test again)
     }
     // the group's byte range (wave-uniform)
     const uint64_t a_begin = offsets[g0], a_end = offsets[g1];
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(1024) void k_block_scan(uint64_t* __restrict__ bloc
 __global__ __launch_bounds__(kWave) void k_line_offsets(const uint32_t* __restrict__ sizes, const uint64_t* __restrict__ block_off, uint64_t n,
                                                        uint64_t* __restrict__ off) {
     const uint64_t li = (uint64_t)blockIdx.x * kWave + threadIdx.x;
-    const uint32_t x = li < n ? sizes[li] : 0u;
+    const uint32_t x = li < n ? sizes[li] & 0x7FFFFFFFu : 0u;  // (bit 31 is the count pass's note for the write pass: k_encode)
     uint32_t tot;
     const uint32_t ex = wave_exclusive_sum(x, &tot);
     if (li < n) off[li] = block_off[blockIdx.x] + ex;
@@ -263,9 +265,10 @@ extern "C" int fg_launch_encode_sizes(const uint8_t* d_bytes, const uint64_t* d_
 }
 extern "C" int fg_launch_encode_write(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
                                       const fg::EncCfg* cfg, uint32_t tile_cap, uint32_t cfg_lds, const uint64_t* d_out_offsets,
-                                      uint8_t* d_out, hipStream_t stream) {
+                                      uint8_t* d_out, const uint32_t* d_sizes, hipStream_t stream) {
     if (n == 0) return 0;
-    if (fg::launch_encode<true>(d_bytes, d_offsets, n, *t, *cfg, tile_cap, cfg_lds, nullptr, nullptr, nullptr, d_out_offsets, d_out, stream) != 0) return -1;
+    // (d_sizes: what fg_launch_encode_count left for these n rows -- read for its bit 31 only; null = every span is tested again)
+    if (fg::launch_encode<true>(d_bytes, d_offsets, n, *t, *cfg, tile_cap, cfg_lds, const_cast<uint32_t*>(d_sizes), nullptr, nullptr, d_out_offsets, d_out, stream) != 0) return -1;
     return (int)hipGetLastError();
 }
 #endif  // !FG_ENC_TU

@@ -626,6 +626,10 @@ __global__ __launch_bounds__(kWave, MINW) void k_gelf(const uint8_t* __restrict_
 constexpr uint32_t kGeneralSpan = 4096;  // lines a wave of the general kernel collects pending lines from at a time
 constexpr uint32_t kLaneBlock = kMaxStored * 4u + kMaxDepth / 8u;  // per lane: keypos[32] + the nesting stack (kMaxDepth bits)
 
+// (Round 5, measured and dropped: the pending lines of a trip staged into LDS by the wave and walked from there -- 4 K .. 64 K-line
+//  launches 105 / 109 / 173 us against 115 / 119 / 185 us, 16 M lines 2.00 against 2.05 G lines/s because 40 KiB of slots leave two
+//  waves per CU: profiles/r05aa_gelf_general_lds_ab.log.  The ~70 us a trip takes however few lines it holds are not memory: a lane
+//  walks its line three times -- validation, the sorted dispatch's count, its emission -- at ~20 dependent instructions per byte.)
 __global__ __launch_bounds__(kWave, 2) void k_gelf_general(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets,
                                                           uint64_t n, DevTables t, FrameArgs fr) {
     __shared__ __attribute__((aligned(16))) uint8_t scratch[kWave * kLaneBlock];

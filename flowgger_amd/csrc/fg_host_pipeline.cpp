@@ -992,7 +992,7 @@ static int transcode_sliced(fg_ctx* ctx, fg_format fmt, const fg_encode_cfg* ecf
         const fg_tables sl = sl_tables(l0, l1);
         fg::DevTables sdt = to_dev(sl);
         sdt.ent_cap = ddt.ent_cap;
-        if (fg_launch_encode_write(ctx->d_bytes, ctx->d_offsets + l0, rows, &sdt, &cfg, tile_cap, cfg_lds, d_out_offsets + l0, ctx->d_tout, s) != 0) {
+        if (fg_launch_encode_write(ctx->d_bytes, ctx->d_offsets + l0, rows, &sdt, &cfg, tile_cap, cfg_lds, d_out_offsets + l0, ctx->d_tout, d_sizes + l0, s) != 0) {
             drain();
             return FG_ERR_HIP;
         }

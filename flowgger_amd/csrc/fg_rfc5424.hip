@@ -1063,18 +1063,8 @@ struct Rfc5424FormatT {
 using Rfc5424Format = Rfc5424FormatT<false>;
 
 // HEAD = true: the instantiation for LONG lines (only the head of every line is staged, fg_pipeline.hpp)
-// (tuning builds: -DFG_SDX_WIN=<KiB> -DFG_SDX_MINW=<waves per SIMD> -DFG_SDX_TILE=<bytes> for the pair-parallel instantiations)
-#ifndef FG_SDX_WIN
-#define FG_SDX_WIN fg::kWindowKiB
-#endif
-#ifndef FG_SDX_MINW
-#define FG_SDX_MINW 2
-#endif
-#ifndef FG_SDX_TILE
-#define FG_SDX_TILE 12288u
-#endif
 template <int NB, bool PROF, bool HEAD = false, bool SDX = false>
-__global__ __launch_bounds__(kWave, SDX ? FG_SDX_MINW : 2) void k_rfc5424(const uint8_t* __restrict__ bytes,
+__global__ __launch_bounds__(kWave, 2) void k_rfc5424(const uint8_t* __restrict__ bytes,
                                                      const uint64_t* __restrict__ offsets, uint64_t n, DevTables t,
                                                      uint32_t tile_cap, uint32_t L, uint64_t groups,
                                                      unsigned long long* prof, uint64_t* stash_base, FrameArgs fr) {
@@ -1123,15 +1113,19 @@ extern "C" int fg_launch_rfc5424(const uint8_t* d_bytes, const uint64_t* d_offse
     if (sdx)
         // (default tile from the same-box sweeps, profiles/r04g_sweep_*: 12 KiB -- eight waves per CU -- for whole lines and for heads)
         // (tiles of at most 36 KiB: with the two bitmaps and the walk's scratch -- 0.57 x the tile -- that is 58 KiB of LDS per wave)
+        // (THREE waves per SIMD -- the compiler fits the whole-line instantiation into 168 registers without a spill under
+        //  __launch_bounds__(64, 3) -- with the 8 KiB tile and window that twelve waves per CU leave each other: 1.64-1.71 G lines/s
+        //  against 1.98-2.08 at 4-16 M lines, 9 KiB / eleven waves 1.71-1.78: fourteen lines to the group instead of twenty-one, and a
+        //  group's cost is mostly fixed -- profiles/r05x_sd_three_waves_ab.log)
         // (chunks of 128 lines, drawn by ticket from two per wave on: round 4's 1024 was the round-robin form's optimum; under tickets,
         //  one box, alternated -- profiles/r05u_chunk_taper_sweep.log -- 4 M lines: 1879-1905 M lines/s as one share per wave, 1990 in
         //  chunks of 128, 1938-1967 at 256 / 512; 16 M lines: 2008-2013 at 1024, 2074-2082 at 128 .. 512; the long-tail corpus 1349 -> 1396.
         //  From FOUR chunks per wave on: at 1 M lines -- 3.8 per wave -- one share per wave measured 1716-1743 M lines/s, tickets
         //  1638-1663; at 2 M lines 1804-1844 against 1845-1873, at 16 M 1880 against 2075: profiles/r05v_policy_ab.log)
-        prc = head ? fg::plan_launch(fg::k_rfc5424<FG_SDX_WIN, false, true, true>, n, plan_len, 0u, 36864u, sb, &p, *lo, 64, 2, nullptr,
-                                     fg::sd2::extra_bytes, FG_SDX_TILE, 128u, 4u)
-                   : fg::plan_launch(fg::k_rfc5424<FG_SDX_WIN, false, false, true>, n, plan_len, 0u, 36864u, sb, &p, *lo, 64, 2, nullptr,
-                                     fg::sd2::extra_bytes, FG_SDX_TILE, 128u, 4u);
+        prc = head ? fg::plan_launch(fg::k_rfc5424<fg::kWindowKiB, false, true, true>, n, plan_len, 0u, 36864u, sb, &p, *lo, 64, 2, nullptr,
+                                     fg::sd2::extra_bytes, 12288u, 128u, 4u)
+                   : fg::plan_launch(fg::k_rfc5424<fg::kWindowKiB, false, false, true>, n, plan_len, 0u, 36864u, sb, &p, *lo, 64, 2, nullptr,
+                                     fg::sd2::extra_bytes, 12288u, 128u, 4u);
     else
         // (tickets from 20 chunks per wave on: the HBM-bound kernel pays for the first round's burst, fg_pipeline.hpp plan_launch)
         prc = head ? fg::plan_launch(fg::k_rfc5424<fg::kWindowKiB, false, true>, n, plan_len, 0u, 57344u, sb, &p, *lo)
@@ -1145,7 +1139,7 @@ extern "C" int fg_launch_rfc5424(const uint8_t* d_bytes, const uint64_t* d_offse
     tt.alloc_chunk = fg::entry_chunk(tt.ent_cap, p.blocks, n, *lo);
     unsigned long long* const no_prof = nullptr;
 #define FG_LAUNCH_5424(PROF_, HEAD_, SDX_, prof_ptr)                                                                                       \
-    hipLaunchKernelGGL((fg::k_rfc5424<(SDX_ ? FG_SDX_WIN : fg::kWindowKiB), PROF_, HEAD_, SDX_>), grid, block, p.lds, stream, d_bytes, d_offsets, n, tt, p.tile, p.L, \
+    hipLaunchKernelGGL((fg::k_rfc5424<fg::kWindowKiB, PROF_, HEAD_, SDX_>), grid, block, p.lds, stream, d_bytes, d_offsets, n, tt, p.tile, p.L, \
                        p.chunk, prof_ptr, stash, fr)
 #if defined(FG_PROF_BUILD)
     if (fg::prof_requested()) {

@@ -36,6 +36,7 @@ struct Cur {
 };
 uint64_t rng_state;
 uint32_t g_sort_slots = fg::emit::kSortSlots;
+uint32_t g_last_plain = 0;
 uint32_t rnd() {
     rng_state = rng_state * 6364136223846793005ull + 1442695040888963407ull;
     return (uint32_t)(rng_state >> 33);
@@ -104,6 +105,8 @@ std::string json_escape_src(const std::string& s, bool* esc) {
 
 // the GELF ranking scratch size the kernels pick per batch (8 or 32)
 extern "C" void fge_set_sort_slots(uint32_t n) { g_sort_slots = n; }
+// the count pass's note for the write pass on the last record encoded: 1 = no span held a byte to escape
+extern "C" uint32_t fge_last_plain() { return g_last_plain; }
 
 // enc / merger: fg_encoder / fg_merger.  src_fmt: which decoder the synthetic row pretends to come from (escape style).
 // gelf_key_variant (src_fmt == FG_GELF): 0 = key spans include the leading '_', 1 = they do not (the decoder adds it).
@@ -247,12 +250,18 @@ extern "C" int64_t fge_encode_canonical(int enc, int merger, int src_fmt, int ge
         std::vector<uint8_t> buf;
 #define RUN(E)                                                                                                  \
     case E: {                                                                                                   \
-        size = fg::emit::row_size<E>(h.cfg, rd, t, li, meta[li], keys64, slot_ent, order, &st);               \
+        uint32_t plain = 0;                                                                                     \
+        size = fg::emit::row_size<E>(h.cfg, rd, t, li, meta[li], keys64, slot_ent, order, &st, nullptr, &plain); \
+        g_last_plain = plain;                                                                                   \
         buf.assign((size_t)size + 96, 0xA5);                                                                    \
         uint8_t* start = buf.data() + 32;                                                                       \
         start += (al - ((uintptr_t)start & 15u)) & 15u;                                                          \
         fg::emit::PackSink sink(start);                                                                         \
-        fg::emit::row_write<E>(sink, size, h.cfg, rd, t, li, meta[li], keys64, slot_ent, order);              \
+        /* odd alignments: with the row in registers and the count pass's "no byte to escape" note, as the write kernel runs */ \
+        fg::emit::RowRegs pre;                                                                                  \
+        pre.load(t, li);                                                                                        \
+        pre.plain = plain;                                                                                      \
+        fg::emit::row_write<E>(sink, size, h.cfg, rd, t, li, meta[li], keys64, slot_ent, order, (al & 1u) ? &pre : nullptr); \
         for (uint8_t* q = buf.data(); q < buf.data() + buf.size(); ++q)                                         \
             if ((q < start || q >= start + size) && *q != 0xA5) return -4;                                      \
         if (size && sink.p != start + size) return -3; /* count and write passes disagree */                   \

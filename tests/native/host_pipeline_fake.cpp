@@ -140,9 +140,10 @@ extern "C" int fg_launch_encode_sizes(const uint8_t* b, const uint64_t* o, uint6
     return rc ? rc : fg_launch_encode_scan(d_sizes, d_block_sums, n, d_out_offsets, 0, s);
 }
 extern "C" int fg_launch_encode_write(const uint8_t* b, const uint64_t* o, uint64_t n, const fg::DevTables* t, const fg::EncCfg*, uint32_t, uint32_t,
-                                      const uint64_t* d_out_offsets, uint8_t* d_out, hipStream_t) {
+                                      const uint64_t* d_out_offsets, uint8_t* d_out, const uint32_t* d_sizes, hipStream_t) {
     for (uint64_t i = 0; i < n; ++i) {
         if ((t->meta[i] & 0xFFu) != 0u) continue;
+        if (!d_sizes || (d_sizes[i] & 0x7FFFFFFFu) != fake_size(o, t, i)) return -8;  // (the write step is handed the count step's sizes of ITS slice)
         uint8_t* w = d_out + d_out_offsets[i];
         const uint32_t len = (uint32_t)(o[i + 1] - o[i]);
         memcpy(w, b + o[i], len);

@@ -45,6 +45,8 @@ def emit():
         assert n <= len(buf)
         return (buf.raw[:n] if st.value == 0 else ES[st.value])
     run.set_sort_slots = L.fge_set_sort_slots
+    L.fge_last_plain.restype = C.c_uint32
+    run.last_plain = L.fge_last_plain
     return run
 
 
@@ -183,3 +185,37 @@ def test_integer_text_at_the_chunk_boundaries(emit, oracle):
     for n in (1, 5, 6, 7, 95, 96, 97, 98, 995, 996, 997, 998, 9996, 9997, 9998):  # framed length crosses 10 / 100 / 1000 / 10000
         cb = canonical(ts=1.5, hostname="h", msg="m", full_msg="x" * n)
         assert emit(OB.ENC_PASSTHROUGH, 3, RFC5424, cb) == oracle.encode(OB.ENC_PASSTHROUGH, cb, 3), n
+
+
+@pytest.mark.parametrize("enc", [OB.ENC_GELF, OB.ENC_LTSV, OB.ENC_RFC5424, OB.ENC_RFC3164, OB.ENC_PASSTHROUGH],
+                         ids=["gelf", "ltsv", "rfc5424", "rfc3164", "passthrough"])
+def test_long_spans_every_tail_length_and_the_plain_note(emit, oracle, enc):
+    """Spans of 0 .. 70 bytes at every length (full 16-byte steps + every tail of 0 .. 15 bytes: the tail is ONE piece, a string's
+    closing quote rides on it), plain and with a byte to escape at the start, at the end, in the tail and across a 16-byte boundary;
+    timestamps that are assembled in registers (seconds with and without a fraction) and ones that stream.  The count pass's note
+    for the write pass -- no span holds a byte to escape -- must be set for the plain records (the write pass then copies untested;
+    the harness runs it both ways) and clear whenever the GELF encoder had to escape."""
+    r = random.Random(77 + enc)
+    text = "The quick brown fox jumps over the lazy dog 0123456789 +-*/=()<>{}|~^%$#@!?;,.'`&_"
+    seen = [0, 0]
+    for n in range(0, 71):
+        for kind in range(6):
+            body = (text * 2)[n % 7: n % 7 + n]
+            if kind and n:
+                at = {1: 0, 2: n - 1, 3: max(0, n - 1 - (n % 16) // 2), 4: min(n - 1, 15), 5: r.randrange(n)}[kind]
+                body = body[:at] + r.choice(['"', "\\", "\n", "\t", "\x01", "\x1f"]) + body[at + 1:]
+            ts = [1438790025.637824, 1438859724.0, 0.5, 1e15, 1234567.125, 1e22, 1e-9][(n + kind) % 7]
+            rec = dict(ts=ts, hostname=body[: 1 + n % 40] or "h", severity=n % 8, facility=n % 24, appname="app" if n % 3 else None,
+                       procid=str(n) if n % 4 else None, msgid="ID" if n % 5 else None, msg=body if n % 11 else None,
+                       full_msg=("<13>1 - " + body) if n % 13 else None)
+            cb = canonical(**rec)
+            for merger in (0, 1, 3):
+                got = emit(enc, merger, RFC5424, cb, now_ts=1.5)
+                want = oracle.encode(enc, cb, merger, now_ts=1.5)
+                assert got == want, (n, kind, merger, rec)
+                if isinstance(want, bytes) and enc == OB.ENC_GELF:
+                    escaped = b"\\" in want
+                    seen[emit.last_plain()] += 1
+                    assert emit.last_plain() == (0 if escaped else 1), (n, kind, rec)
+    if enc == OB.ENC_GELF:
+        assert seen[0] > 100 and seen[1] > 100
