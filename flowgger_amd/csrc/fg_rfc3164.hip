@@ -7,6 +7,11 @@
 // arrays: the stores of a wave are coalesced per column).  A group whose bytes exceed the tile (long lines) reads
 // from global memory.  RFC3164 produces no structured data: no entry table traffic.
 // Roofline: HBM -- line bytes + 8 B offset read once, 68 B written per line.
+// (Round 5, measured and dropped: this kernel as a format of the shared streaming pipeline -- persistent waves, the next group
+//  prefetched into the register window, chunks by ticket: 3.70 against 3.84 G lines/s at 100 M lines, 47 / 49 / 96 / 357 us against
+//  46 / 48 / 101 / 311 us at 16 K .. 1 M lines, profiles/r05ab_rfc3164_pipeline_ab.log.  A group takes ~46 us however it is staged:
+//  the time is the lane-serial parser -- three line shapes in one wave, zone names resolved through dependent loads from global
+//  memory -- and the one-workgroup form keeps nine to ten such waves on a CU where the pipeline's window leaves seven or eight.)
 #include "fg_device.hpp"
 #include "fg_rfc3164_parse.hpp"
 
