@@ -1,7 +1,7 @@
 #!/bin/bash
 # The encoders of several builds of this tree on one box (cfg1: decode -> GELF encode -> line merger), alternated; then the encoder
 # tests of the GPU suite and the counters of the product's encode kernels.
-# usage (through gpurun): bash tools/r05_encode_ab.sh <tag> "<libs: product libfg_hip_x.so ...>" [bench args, default 100 M lines]
+# usage (through gpurun): bash tools/encode_ab.sh <tag> "<libs: product libfg_hip_x.so ...>" [bench args, default 100 M lines]
 tag=${1:-r05w}
 libs=${2:-product libfg_hip_r05z.so}
 shift 2

@@ -1,6 +1,6 @@
 #!/bin/bash
-# Builds of this tree against each other on one box (FG_BUILD_VARIANT libraries): tools/r05_lib_ab.sh <tag> "<workloads>" "<libs>" [reps]
-# usage (through gpurun): bash tools/r05_lib_ab.sh r05x "cfg4 cfg5" "product libfg_hip_sd3.so" 16,64
+# Builds of this tree against each other on one box (FG_BUILD_VARIANT libraries): tools/lib_ab.sh <tag> "<workloads>" "<libs>" [reps]
+# usage (through gpurun): bash tools/lib_ab.sh r05x "cfg4 cfg5" "product libfg_hip_sd3.so" 16,64
 tag=${1:-r05x}
 wls=${2:-cfg4}
 libs=${3:-product}
