@@ -13,7 +13,7 @@ rocprofv3 --kernel-trace --output-format csv --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/pmc3 -o pmc3 -- $BENCH > $OUT/pmc3.log 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/pmc4 -o pmc4 -- $BENCH > $OUT/pmc4.log 2>&1
 cd $ROOT
-python tools/prof_summary.py $OUT ${PAT:-k_} > gpurun_out/prof_$TAG.json
+python tools/prof_summary.py $OUT "${PAT:-k_}" > gpurun_out/prof_$TAG.json
 grep -h '"metric"' $OUT/kt.log > gpurun_out/prof_${TAG}_bench.json
 tail -2 $OUT/pmc1.log | cut -c1-300
 cat gpurun_out/prof_$TAG.json | head -80

@@ -10,7 +10,7 @@ BENCH="python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e $@"
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/pmc3 -o pmc3 -- $BENCH > $OUT/pmc3.log 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/pmc4 -o pmc4 -- $BENCH > $OUT/pmc4.log 2>&1
 cd $ROOT
-python tools/prof_summary.py $OUT $PAT > gpurun_out/traffic_$TAG.json
+python tools/prof_summary.py $OUT "$PAT" > gpurun_out/traffic_$TAG.json
 grep -h '"metric"' $OUT/pmc3.log | tail -1 > gpurun_out/traffic_${TAG}_bench.json
 python -c "
 import json; d=json.load(open('gpurun_out/traffic_$TAG.json')); print('$TAG', d.get('hbm_bytes_per_dispatch'), d.get('pmc_per_dispatch_mean'))"
