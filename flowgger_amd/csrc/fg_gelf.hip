@@ -623,7 +623,12 @@ __global__ __launch_bounds__(kWave, MINW) void k_gelf(const uint8_t* __restrict_
 }
 
 // ---- kernel 2: pending lines -> the general form, straight from global memory --------------------------------------
-constexpr uint32_t kGeneralSpan = 4096;  // lines a wave of the general kernel collects pending lines from at a time
+// lines a wave of the general kernel collects pending lines from at a time -- at most; a small batch takes shorter spans (the
+// launcher's `span`: a multiple of 64).  A wave runs the SHAPES of its pending lines one after the other (each a chain of dependent
+// loads: DESIGN 3.3), so the work-efficient span is a long one -- full trips -- and the latency-efficient one is short: few shapes
+// share a wave.  A batch that cannot fill the grid anyway takes the short ones: launches of 4 K / 16 K / 64 K / 256 K lines 118 / 120 /
+// 185 / 307 -> 85 / 89 / 155 / 277 us, 4 M lines and more unchanged (profiles/r05ak_small_gelf_span.log).
+constexpr uint32_t kGeneralSpan = 4096;
 constexpr uint32_t kLaneBlock = kMaxStored * 4u + kMaxDepth / 8u;  // per lane: keypos[32] + the nesting stack (kMaxDepth bits)
 
 // (Round 5, measured and dropped: the pending lines of a trip staged into LDS by the wave and walked from there -- 4 K .. 64 K-line
@@ -631,7 +636,7 @@ constexpr uint32_t kLaneBlock = kMaxStored * 4u + kMaxDepth / 8u;  // per lane: 
 //  waves per CU: profiles/r05aa_gelf_general_lds_ab.log.  The ~70 us a trip takes however few lines it holds are not memory: a lane
 //  walks its line three times -- validation, the sorted dispatch's count, its emission -- at ~20 dependent instructions per byte.)
 __global__ __launch_bounds__(kWave, 2) void k_gelf_general(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets,
-                                                          uint64_t n, DevTables t, FrameArgs fr) {
+                                                          uint64_t n, DevTables t, FrameArgs fr, uint32_t span) {
     __shared__ __attribute__((aligned(16))) uint8_t scratch[kWave * kLaneBlock];
     __shared__ uint32_t ent_state[2];
     const uint32_t lane = threadIdx.x;
@@ -644,16 +649,16 @@ __global__ __launch_bounds__(kWave, 2) void k_gelf_general(const uint8_t* __rest
     // Pending lines are rare (~1 per 100): a wave first COLLECTS the pending lines of a 4096-line span into an LDS list, then
     // takes them 64 at a time -- lane per pending line instead of one busy lane per 64-line chunk.
     __shared__ uint16_t s_list[kGeneralSpan];
-    const uint64_t spans = (n + kGeneralSpan - 1) / kGeneralSpan;
+    const uint64_t spans = (n + span - 1) / span;  // (span: 64 .. kGeneralSpan, a multiple of 64)
     for (uint64_t sp = blockIdx.x; sp < spans; sp += gridDim.x) {
-      const uint64_t l0 = sp * kGeneralSpan;
+      const uint64_t l0 = sp * span;
       uint32_t cnt = 0;  // wave-uniform
-      for (uint32_t k0 = 0; k0 < kGeneralSpan / kWave; k0 += 8u) {
+      for (uint32_t k0 = 0; k0 < span / kWave; k0 += 8u) {
           uint32_t m8[8];
 #pragma unroll
-          for (uint32_t j = 0; j < 8u; ++j) {  // (eight loads in flight)
+          for (uint32_t j = 0; j < 8u; ++j) {  // (eight loads in flight; rows beyond the span read as "not pending")
               const uint64_t q = l0 + (uint64_t)(k0 + j) * kWave + lane;
-              m8[j] = q < n ? t.meta[q] : 0u;
+              m8[j] = (k0 + j) * kWave < span && q < n ? t.meta[q] : 0u;
           }
 #pragma unroll
           for (uint32_t j = 0; j < 8u; ++j) {
@@ -840,9 +845,13 @@ extern "C" int fg_launch_gelf_general(const uint8_t* d_bytes, const uint64_t* d_
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
         return -1;
-    uint64_t chunks = (n + fg::kGeneralSpan - 1) / fg::kGeneralSpan;
+    // the span: as long as it can be with a span for every wave of the grid (n / 1024 lines, a multiple of 64 in 64 .. 4096)
     uint64_t gblocks = (uint64_t)cus * 8u;
+    uint32_t span = fg::kGeneralSpan;
+    while (span > fg::kWave && n < (uint64_t)span * 1024u) span >>= 1;
+    const uint64_t chunks = (n + span - 1) / span;
     if (gblocks > chunks) gblocks = chunks;
-    hipLaunchKernelGGL(fg::k_gelf_general, dim3((uint32_t)gblocks), dim3(fg::kWave), 0, stream, d_bytes, d_offsets, n, *t, fg::FrameArgs{strip, line_bad});
+    hipLaunchKernelGGL(fg::k_gelf_general, dim3((uint32_t)gblocks), dim3(fg::kWave), 0, stream, d_bytes, d_offsets, n, *t, fg::FrameArgs{strip, line_bad},
+                       span);
     return (int)hipGetLastError();
 }
