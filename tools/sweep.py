@@ -2,6 +2,7 @@
 """One corpus, many launch geometries: tools/sweep.py <workload> [--lines N] [--reps R[,R...]] opts;opts;...   (opts = k=v,k=v; empty = defaults)
 Generates the workload's tile ONCE, keeps it resident, and times fg_decode_batch_device under each fg_set_launch_opts setting (HIP
 events, 5 launches after 2 warm-ups) -- an A/B on the SAME box in seconds instead of one bench.py process per point."""
+import os
 import sys
 from pathlib import Path
 
@@ -26,16 +27,18 @@ def main():
         args = args[2:]
     settings = (args[0] if args else "").split(";")
     fmt = bench.WORKLOADS[wl][0]
+    inv = float(os.environ.get("FG_SWEEP_INVALID", "0.01"))  # share of invalid lines in the corpus (the BASELINE corpora: 1 %)
+
     def gen():
         if wl == "cfg3":
-            return synth.gelf_lines(lines_n)
+            return synth.gelf_lines(lines_n, invalid_frac=inv)
         if wl in ("ltsv", "ltsv5"):
-            return synth.ltsv_lines(lines_n, long_tail=wl == "ltsv5")
+            return synth.ltsv_lines(lines_n, invalid_frac=inv, long_tail=wl == "ltsv5")
         if wl == "cfg5":
-            return synth.rfc5424_lines(lines_n, cfg=5, sd=True, long_tail=True)
-        return synth.rfc5424_lines(lines_n, cfg=4 if wl == "cfg4" else 2, sd=wl == "cfg4")
+            return synth.rfc5424_lines(lines_n, cfg=5, sd=True, invalid_frac=inv, long_tail=True)
+        return synth.rfc5424_lines(lines_n, cfg=4 if wl == "cfg4" else 2, sd=wl == "cfg4", invalid_frac=inv)
 
-    lines = bench.cached_lines(f"sweep_{wl}_{lines_n}", gen)  # (FG_BENCH_CACHE=<dir>: one pickle per corpus, for scripts that call this file repeatedly)
+    lines = bench.cached_lines(f"sweep_{wl}_{lines_n}_{inv:g}", gen)  # (FG_BENCH_CACHE=<dir>: one pickle per corpus, for scripts that call this file repeatedly)
     dev = torch.device("cuda", 0)
     for reps in reps_list:
         sweep(wl, fmt, lines, reps, dev, settings)
