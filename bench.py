@@ -54,6 +54,9 @@ def parse_args():
                     help="cfg2 = the BASELINE metric's configuration (default); the others time the remaining "
                          "kernels on their parity-test corpora (not bench lines, see DESIGN.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--encoder", default="gelf", choices=["gelf", "ltsv", "rfc5424", "rfc3164"],
+                    help="cfg1 only: the encoder of the pipeline leg (BASELINE configs[0] is GELF; the others for the encoders' own A/Bs -- "
+                         "the CPU baseline is GELF's: pass --no-cpu-baseline with them)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive host-buffer legs (fg_decode_batch / fg_transcode_batch)")
     ap.add_argument("--no-mix", action="store_true",
                     help="default workload, one GPU, no launcher: skip the bounded BASELINE configs[4] leg (a cfg5mix sample run as a child "
@@ -787,9 +790,9 @@ def main(args=None, thread_rank=None):
 
     encode_ms = []
     if wl == "cfg1":
-        from flowgger_amd import GelfEncoder
+        import flowgger_amd as FA
 
-        enc = GelfEncoder(merger="line")
+        enc = {"gelf": FA.GelfEncoder, "ltsv": FA.LTSVEncoder, "rfc5424": FA.RFC5424Encoder, "rfc3164": FA.RFC3164Encoder}[args.encoder](merger="line")
         dec.decode_device(d_bytes, d_offsets, tables, stream)
         e_out, e_off = enc.encode_device(dec, d_bytes, d_offsets, n, tables, stream=stream)  # sizes the output buffer
         enc_bytes = int(e_out.numel())

@@ -427,28 +427,10 @@ FGD_HD uint32_t ascii4(uint32_t y) {
     z = (z | (z << 4)) & 0x0F0F0F0Fu;  // (the first digit in byte 3)
     return __builtin_bswap32(z) + 0x30303030u;
 }
-// The same text for a sink that takes PIECES (fg_emit.hpp: put16 / put_part / add, kCount): a timestamp -- seconds with a fraction, or
-// whole seconds: the decimal point falls inside the first 17 positions -- is assembled in registers and handed over as one piece or
-// two instead of seventeen to twenty put() calls (what a put costs the write pass: PackSink::put_part).  Everything else streams.
+// The 17 digits of `bcd` as text with a '.' in front of digit `dot` (1 .. 16; >= 20: none), cut to L characters (<= 18), as one piece
+// or two: put16 / put_part of the sink.  (The digits beyond the generated ones are zeros: trailing zeros of an integer come for free.)
 template <class Sink>
-FGD_HD void write_pieces(double value, Sink& sink) {
-    if (!write_sign_zero(value, sink)) return;
-    Digits dg;
-    int k = 0;
-    grisu2(value, dg, &k);
-    const int len = dg.len, kk = len + k;
-    if (!(0 < kk && kk <= 16)) {
-        stream_digits(dg, k, sink);
-        return;
-    }
-    // digits [0, kk) '.' digits [kk, len)   (k < 0: len + 1 characters)   or   digits, k zeros, ".0"   (k >= 0: kk + 2 characters) --
-    // the 17 BCD digits are zero beyond len, so the string S of their ASCII codes holds the trailing zeros already
-    const uint32_t L = (uint32_t)(k < 0 ? len + 1 : kk + 2), dot = (uint32_t)kk;
-    if (Sink::kCount) {
-        sink.add(L);
-        return;
-    }
-    const Bcd17 bcd(dg);
+FGD_HD void put_text17(const Bcd17& bcd, uint32_t dot, uint32_t L, Sink& sink) {
     const uint32_t u0 = ascii4(bcd.a >> 16), u1 = ascii4(bcd.a & 0xFFFFu), u2 = ascii4(bcd.b >> 16), u3 = ascii4(bcd.b & 0xFFFFu);
     const uint32_t S[5] = {((uint32_t)'0' + bcd.top) | u0 << 8, u0 >> 24 | u1 << 8, u1 >> 24 | u2 << 8, u2 >> 24 | u3 << 8, u3 >> 24};
     uint32_t R[5];
@@ -470,6 +452,29 @@ FGD_HD void write_pieces(double value, Sink& sink) {
     } else {
         sink.put_part(R[0], R[1], R[2], R[3], L);
     }
+}
+// The same text for a sink that takes PIECES (fg_emit.hpp: put16 / put_part / add, kCount): a timestamp -- seconds with a fraction, or
+// whole seconds: the decimal point falls inside the first 17 positions -- is assembled in registers and handed over as one piece or
+// two instead of seventeen to twenty put() calls (what a put costs the write pass: PackSink::put_part).  Everything else streams.
+template <class Sink>
+FGD_HD void write_pieces(double value, Sink& sink) {
+    if (!write_sign_zero(value, sink)) return;
+    Digits dg;
+    int k = 0;
+    grisu2(value, dg, &k);
+    const int len = dg.len, kk = len + k;
+    if (!(0 < kk && kk <= 16)) {
+        stream_digits(dg, k, sink);
+        return;
+    }
+    // digits [0, kk) '.' digits [kk, len)   (k < 0: len + 1 characters)   or   digits, k zeros, ".0"   (k >= 0: kk + 2 characters) --
+    // the 17 BCD digits are zero beyond len, so the string S of their ASCII codes holds the trailing zeros already
+    const uint32_t L = (uint32_t)(k < 0 ? len + 1 : kk + 2), dot = (uint32_t)kk;
+    if (Sink::kCount) {
+        sink.add(L);
+        return;
+    }
+    put_text17(Bcd17(dg), dot, L, sink);
 }
 // Buffer form (host tests): writes at most 26 characters into out, returns the count.  Through write_pieces, so that the tests of
 // this function cover the assembled form as well as the streamed one.

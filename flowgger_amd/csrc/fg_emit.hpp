@@ -449,6 +449,19 @@ struct RowRegs {
     }
 };
 
+// a sink over a per-byte functor (a pair's value on its way through an escaper): pieces are taken apart again
+template <class F>
+struct FnSinkT {
+    static constexpr bool kCount = false;
+    F& f;
+    FGE_HD void put(uint32_t c) { f(c); }
+    FGE_HD void add(uint32_t) {}
+    FGE_HD void put_part(uint32_t q0, uint32_t q1, uint32_t q2, uint32_t q3, uint32_t nb) {
+        for (uint32_t i = 0; i < nb; ++i) f(((i < 4u ? q0 : i < 8u ? q1 : i < 12u ? q2 : q3) >> (8u * (i & 3u))) & 0xFFu);
+    }
+    FGE_HD void put16(uint32_t q0, uint32_t q1, uint32_t q2, uint32_t q3) { put_part(q0, q1, q2, q3, 16u); }
+};
+
 // Everything the emitters share: the row, the field views, the number formats.
 template <class S, class R>
 struct Base {
@@ -512,14 +525,27 @@ struct Base {
     }
     FGE_HD double record_ts() const { return (flags() & FG_F_TS_NOW) ? cfg.now_ts : row_ts; }
 
-    FGE_HD void lit(const char* s, uint32_t n) {
-        uint32_t i = 0;
-        for (; i + 4u <= n; i += 4u) {
-            uint32_t w;
-            memcpy(&w, s + i, 4);
-            out.put_word(w, 4u);
+    // a literal (n <= 32 bytes, known at the call site: the words below fold into constants), as ONE piece per sixteen bytes -- and
+    // with the byte `lead` in front of it when the caller has one (a separator: a put of its own costs what a piece does)
+    FGE_HD void lit(const char* s, uint32_t n, uint32_t lead = 0u) {
+        if (S::kCount) {
+            out.add(n + (lead ? 1u : 0u));
+            return;
         }
-        for (; i < n; ++i) out.put((uint32_t)(uint8_t)s[i]);
+        uint32_t q[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, p[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};  // without / behind the lead byte
+        for (uint32_t i = 0; i < n && i < 31u; ++i) {
+            q[i >> 2] |= (uint32_t)(uint8_t)s[i] << (8u * (i & 3u));
+            p[(i + 1u) >> 2] |= (uint32_t)(uint8_t)s[i] << (8u * ((i + 1u) & 3u));
+        }
+        const bool ld = lead != 0u;
+        const uint32_t m = n + (ld ? 1u : 0u);
+        const uint32_t w0 = ld ? (p[0] | lead) : q[0], w1 = ld ? p[1] : q[1], w2 = ld ? p[2] : q[2], w3 = ld ? p[3] : q[3];
+        if (m <= 16u) {
+            out.put_part(w0, w1, w2, w3, m);
+        } else {
+            out.put16(w0, w1, w2, w3);
+            out.put_part(ld ? p[4] : q[4], ld ? p[5] : q[5], ld ? p[6] : q[6], ld ? p[7] : q[7], m - 16u);
+        }
     }
     // a piece of the configuration blob; every piece starts 4-byte aligned and is followed by readable padding
     FGE_HD void blob(uint32_t off, uint32_t len) {
@@ -609,18 +635,23 @@ struct Base {
             for (uint32_t b = 0; b < m; ++b) fb((w >> (8u * b)) & 0xFFu);
         }
     }
-    FGE_HD void raw_field(int col) {  // a top-level field, decoded, unmodified
+    FGE_HD void raw_field(int col, uint32_t sfx = 0u) {  // a top-level field, decoded, unmodified [+ the separator behind it]
         const fg_span s = this->span(col);
         const uint32_t mode = field_mode(col);
-        if (mode == M_RAW) copy_raw<ESC_NONE>(s.off, s.len, [&](uint32_t c) { out.put(c); });
-        else for_each_decoded(rd, s.off, s.len, mode, [&](uint32_t c) { out.put(c); });
+        if (mode == M_RAW) {
+            copy_raw<ESC_NONE>(s.off, s.len, [&](uint32_t c) { out.put(c); }, sfx);
+            return;
+        }
+        for_each_decoded(rd, s.off, s.len, mode, [&](uint32_t c) { out.put(c); });
+        if (sfx) out.put(sfx);
     }
+    // two decimal digits as two ASCII bytes (the tens in the low byte), v < 100
+    static FGE_HD uint32_t d2(uint32_t v) { return ((uint32_t)'0' + v / 10u) | ((uint32_t)'0' + v % 10u) << 8; }
     FGE_HD void u64_text(uint64_t v) {
-        if (v < 1000u) {  // <pri>, level, facility: the common case
-            const uint32_t x = (uint32_t)v;
-            if (x >= 100u) out.put('0' + x / 100u);
-            if (x >= 10u) out.put('0' + x / 10u % 10u);
-            out.put('0' + x % 10u);
+        if (v < 1000u) {  // level, facility, small typed values: the common case, one piece
+            const uint32_t x = (uint32_t)v, nd = x >= 100u ? 3u : x >= 10u ? 2u : 1u;
+            const uint32_t h = (uint32_t)'0' + x / 100u, m = (uint32_t)'0' + x / 10u % 10u, l = (uint32_t)'0' + x % 10u;
+            out.put_part(nd == 3u ? (h | m << 8 | l << 16) : nd == 2u ? (m | l << 8) : l, 0u, 0u, 0u, nd);
             return;
         }
         u64_digits(v, [&](uint32_t c) { out.put(c); });
@@ -638,11 +669,16 @@ struct Base {
         out.put('0' + v % 10u);
     }
     // <pri>: ((facility << 3) & 0xF8) + (severity & 7) in u8 arithmetic
-    FGE_HD void pri() {
+    FGE_HD void pri() {  // "<" + 1..3 digits + ">": one piece
         const uint32_t npri = (((FG_META_FACILITY(meta) << 3) & 0xF8u) + (FG_META_SEVERITY(meta) & 7u)) & 0xFFu;
-        out.put('<');
-        u64_text(npri);
-        out.put('>');
+        const uint32_t nd = npri >= 100u ? 3u : npri >= 10u ? 2u : 1u;
+        const uint32_t h = npri / 100u, m = npri / 10u % 10u, l = npri % 10u;
+        // bytes: '<' d.. '>'
+        const uint32_t digits = nd == 3u ? (('0' + h) | ('0' + m) << 8 | ('0' + l) << 16) : nd == 2u ? (('0' + m) | ('0' + l) << 8) : ('0' + l);
+        const uint32_t w0 = (uint32_t)'<' | digits << 8;                 // '<' + up to three digits
+        const uint32_t gt = (uint32_t)'>';
+        // '>' lands at byte 1 + nd: in w0 for nd <= 2, in w1 for nd == 3
+        out.put_part(nd == 3u ? w0 : (w0 | gt << (8u * (1u + nd))), nd == 3u ? gt : 0u, 0u, 0u, nd + 2u);
     }
     FGE_HD bool has_pri() const { return FG_META_FACILITY(meta) != 0xFFu && FG_META_SEVERITY(meta) != 0xFFu; }
 
@@ -712,10 +748,7 @@ struct Base {
     FGE_HD void value_display(uint32_t e, F&& f) {
         const uint32_t ty = t.ent_type[e];
         const uint64_t v = t.ent_val[e];
-        struct FnSink {
-            F& f;
-            FGE_HD void put(uint32_t c) { f(c); }
-        } fs{f};
+        FnSinkT<F> fs{f};
         if (ty == FG_T_STRING) {
             for_each_decoded(rd, (uint32_t)v, (uint32_t)(v >> 32), value_mode(e), f);
         } else if (ty == FG_T_BOOL) {
@@ -1034,11 +1067,10 @@ struct LtsvEmitter : Base<S, R> {
 
     FGE_HD void key_byte(uint32_t c) { out.put(c == '\n' || c == '\t' ? (uint32_t)' ' : c == ':' ? (uint32_t)'_' : c); }
     FGE_HD void val_byte(uint32_t c) { out.put(c == '\n' || c == '\t' ? (uint32_t)' ' : c); }
-    FGE_HD void start(const char* key, uint32_t n) {  // LTSVString::insert up to and including ':'
-        if (!first) out.put('\t');
+    // LTSVString::insert up to and including ':' -- `key` includes its ':' -- behind the TAB of every entry but the first: one piece
+    FGE_HD void start(const char* key, uint32_t n) {
+        this->lit(key, n, first ? 0u : (uint32_t)'\t');
         first = false;
-        this->lit(key, n);
-        out.put(':');
     }
     FGE_HD void val_span(uint32_t off, uint32_t len, uint32_t mode) {
         if (mode == M_RAW) this->template copy_raw<ESC_LTSV_VAL>(off, len, [&](uint32_t c) { val_byte(c); });
@@ -1070,26 +1102,26 @@ struct LtsvEmitter : Base<S, R> {
             first = false;
             this->blob(cfg.ltsv_extra_off, cfg.ltsv_extra_len);
         }
-        start("host", 4);
+        start("host:", 5);
         if (this->some(S_HOST)) {
             const fg_span s = this->span(S_HOST);
             val_span(s.off, s.len, this->field_mode(S_HOST));
         }
-        start("time", 4);
+        start("time:", 5);
         shortest::display_f64(this->record_ts(), out);
-        if (this->some(S_MSG)) field("message", 7, S_MSG);
-        if (this->some(S_FULL)) field("full_message", 12, S_FULL);
+        if (this->some(S_MSG)) field("message:", 8, S_MSG);
+        if (this->some(S_FULL)) field("full_message:", 13, S_FULL);
         if (FG_META_SEVERITY(meta) != 0xFFu) {
-            start("level", 5);
+            start("level:", 6);
             this->u64_text(FG_META_SEVERITY(meta));
         }
         if (FG_META_FACILITY(meta) != 0xFFu) {
-            start("facility", 8);
+            start("facility:", 9);
             this->u64_text(FG_META_FACILITY(meta));
         }
-        if (this->some(S_APP)) field("appname", 7, S_APP);
-        if (this->some(S_PROC)) field("procid", 6, S_PROC);
-        if (this->some(S_MSGID)) field("msgid", 5, S_MSGID);
+        if (this->some(S_APP)) field("appname:", 8, S_APP);
+        if (this->some(S_PROC)) field("procid:", 7, S_PROC);
+        if (this->some(S_MSGID)) field("msgid:", 6, S_MSGID);
         return ES_OK;
     }
 };
@@ -1209,51 +1241,48 @@ struct Rfc5424Emitter : Base<S, R> {
         if (c.y < 0 || c.y > 9999) return ES_5424_FORMAT;
         if (this->has_pri()) this->pri();
         else this->lit("<13>", 4);
-        out.put('1');
-        out.put(' ');
-        this->pad2((uint32_t)c.y / 100u);
-        this->pad2((uint32_t)c.y % 100u);
-        out.put('-');
-        this->pad2((uint32_t)c.m);
-        out.put('-');
-        this->pad2((uint32_t)c.d);
-        out.put('T');
-        this->pad2(c.hh);
-        out.put(':');
-        this->pad2(c.mm);
-        out.put(':');
-        this->pad2(c.ss);
-        if (nanos) {  // time 0.3 Rfc3339: '.' + the nanoseconds without trailing zeros
-            out.put('.');
-            uint32_t digs = 9, v = nanos;
-            while (v % 10u == 0) {
-                v /= 10u;
-                --digs;
+        // "1 YYYY-MM-DDTHH:" (sixteen bytes) + "MM:SS" [+ "." + the nanoseconds without trailing zeros: time 0.3 Rfc3339] + "Z ": three
+        // pieces (two without a fraction) instead of ~thirty one-byte puts
+        {
+            const uint32_t yh = B::d2((uint32_t)c.y / 100u), yl = B::d2((uint32_t)c.y % 100u), mo = B::d2((uint32_t)c.m), dd = B::d2((uint32_t)c.d);
+            const uint32_t hh = B::d2(c.hh), mi = B::d2(c.mm), ss = B::d2(c.ss);
+            out.put16((uint32_t)'1' | (uint32_t)' ' << 8 | yh << 16, yl | (uint32_t)'-' << 16 | (mo & 0xFFu) << 24,
+                      (mo >> 8) | (uint32_t)'-' << 8 | dd << 16, (uint32_t)'T' | hh << 8 | (uint32_t)':' << 24);
+            const uint32_t t0 = mi | (uint32_t)':' << 16 | (ss & 0xFFu) << 24, t1 = ss >> 8;  // "MM:SS"
+            if (!nanos) {
+                out.put_part(t0, t1 | (uint32_t)'Z' << 8 | (uint32_t)' ' << 16, 0u, 0u, 7u);
+            } else {
+                out.put_part(t0, t1, 0u, 0u, 5u);
+                uint32_t digs = 9, v = nanos;
+                while (v % 10u == 0) {
+                    v /= 10u;
+                    --digs;
+                }
+                // '.' + nine digits, cut behind `digs` of them, "Z " behind the cut
+                const uint32_t lo8 = dtoa::Bcd17::bcd8(nanos % 100000000u);
+                uint32_t q[4] = {(uint32_t)'.' | ((uint32_t)'0' + nanos / 100000000u) << 8, 0u, 0u, 0u};
+                const uint32_t a = dtoa::ascii4(lo8 >> 16), b = dtoa::ascii4(lo8 & 0xFFFFu);  // digits 2..5, 6..9
+                q[0] |= a << 16;
+                q[1] = a >> 16 | b << 16;
+                q[2] = b >> 16;
+                B::keep_low(q, 1u + digs);
+                B::set_byte(q, 1u + digs, (uint32_t)'Z');
+                B::set_byte(q, 2u + digs, (uint32_t)' ');
+                out.put_part(q[0], q[1], q[2], q[3], 3u + digs);
             }
-            uint32_t p = 1;
-            for (uint32_t i = 1; i < digs; ++i) p *= 10u;
-            for (; p; p /= 10u) out.put('0' + v / p % 10u);
         }
-        out.put('Z');
-        out.put(' ');
-        if (this->some(S_HOST)) this->raw_field(S_HOST);
-        out.put(' ');
-        if (this->some(S_APP)) {
-            this->raw_field(S_APP);
-            out.put(' ');
-        }
-        if (this->some(S_PROC)) this->raw_field(S_PROC);
-        else out.put('-');
-        out.put(' ');
-        if (this->some(S_MSGID)) this->raw_field(S_MSGID);
-        else out.put('-');
-        out.put(' ');
+        if (this->some(S_HOST)) this->raw_field(S_HOST, (uint32_t)' ');
+        else out.put(' ');
+        if (this->some(S_APP)) this->raw_field(S_APP, (uint32_t)' ');
+        if (this->some(S_PROC)) this->raw_field(S_PROC, (uint32_t)' ');
+        else this->lit("- ", 2);
+        if (this->some(S_MSGID)) this->raw_field(S_MSGID, (uint32_t)' ');
+        else this->lit("- ", 2);
         if (this->has_sd()) {
             this->sd_display();
             out.put(' ');
         } else {
-            out.put('-');
-            out.put(' ');
+            this->lit("- ", 2);
         }
         if (this->some(S_MSG)) this->raw_field(S_MSG);
         return ES_OK;
@@ -1273,32 +1302,24 @@ struct Rfc3164Emitter : Base<S, R> {
         if (this->has_pri()) this->pri();
         const Civil c = civil_of(secs);
         // "[month repr:short]  [day padding:none] [hour]:[minute]:[second] "
-        const char* mon = "JanFebMarAprMayJunJulAugSepOctNovDec";
-        this->lit(mon + 3 * (c.m - 1), 3);
-        out.put(' ');
-        out.put(' ');
-        this->u64_text((uint64_t)c.d);
-        out.put(' ');
-        this->pad2(c.hh);
-        out.put(':');
-        this->pad2(c.mm);
-        out.put(':');
-        this->pad2(c.ss);
-        out.put(' ');
-        if (this->some(S_HOST)) this->raw_field(S_HOST);
-        out.put(' ');
+        const char* mon = "JanFebMarAprMayJunJulAugSepOctNovDec" + 3 * (c.m - 1);
+        {   // "Mon  " (two spaces) + the day without padding + " ", then "hh:mm:ss ": two pieces
+            const uint32_t day = (uint32_t)c.d, nd = day >= 10u ? 2u : 1u;
+            const uint32_t m4 = (uint32_t)(uint8_t)mon[0] | (uint32_t)(uint8_t)mon[1] << 8 | (uint32_t)(uint8_t)mon[2] << 16 | (uint32_t)' ' << 24;
+            out.put_part(m4, nd == 2u ? ((uint32_t)' ' | B::d2(day) << 8 | (uint32_t)' ' << 24) : ((uint32_t)' ' | ((uint32_t)'0' + day) << 8 | (uint32_t)' ' << 16),
+                         0u, 0u, 6u + nd);
+            const uint32_t hh = B::d2(c.hh), mi = B::d2(c.mm), ss = B::d2(c.ss);
+            out.put_part(hh | (uint32_t)':' << 16 | (mi & 0xFFu) << 24, (mi >> 8) | (uint32_t)':' << 8 | ss << 16, (uint32_t)' ', 0u, 9u);
+        }
+        if (this->some(S_HOST)) this->raw_field(S_HOST, (uint32_t)' ');
+        else out.put(' ');
         if (this->some(S_APP)) this->raw_field(S_APP);
         if (this->some(S_PROC)) {
             out.put('[');
-            this->raw_field(S_PROC);
-            out.put(']');
-            out.put(':');
-            out.put(' ');
+            this->raw_field(S_PROC, (uint32_t)']');
+            this->lit(": ", 2);
         }
-        if (this->some(S_MSGID)) {
-            this->raw_field(S_MSGID);
-            out.put(' ');
-        }
+        if (this->some(S_MSGID)) this->raw_field(S_MSGID, (uint32_t)' ');
         if (this->has_sd()) {
             this->sd_display();
             out.put(' ');

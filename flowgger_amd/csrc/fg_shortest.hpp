@@ -161,6 +161,14 @@ FGS_HD void display_f64(double v, S& out) {
     const dtoa::Bcd17 bcd(dg);
     // value = 0.d1d2... * 10^e10
     const int e10 = d.exp + nd;
+    if (e10 > 0 && e10 <= 16 && nd <= 17) {
+        // the point inside the first 17 positions (seconds with a fraction), or an integer of up to 16 digits (whole seconds, typed
+        // values): assembled in registers, one piece or two (dtoa::put_text17) instead of a put per character
+        const uint32_t L = nd > e10 ? (uint32_t)nd + 1u : (uint32_t)e10;
+        if (S::kCount) out.add(L);
+        else dtoa::put_text17(bcd, nd > e10 ? (uint32_t)e10 : 32u, L, out);
+        return;
+    }
     if (e10 <= 0) {
         out.put('0');
         out.put('.');

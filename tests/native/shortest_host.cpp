@@ -11,9 +11,16 @@
 #include "../../flowgger_amd/csrc/fg_shortest.hpp"
 
 namespace {
-struct StrSink {
+struct StrSink {  // the emitters' sink protocol: bytes, and pieces of up to sixteen (display_f64 assembles the common shapes in registers)
+    static constexpr bool kCount = false;
     std::string s;
     void put(uint32_t c) { s.push_back((char)c); }
+    void add(uint32_t) {}
+    void put_part(uint32_t q0, uint32_t q1, uint32_t q2, uint32_t q3, uint32_t nb) {
+        const uint32_t q[4] = {q0, q1, q2, q3};
+        for (uint32_t i = 0; i < nb; ++i) s.push_back((char)(q[i >> 2] >> (8u * (i & 3u))));
+    }
+    void put16(uint32_t q0, uint32_t q1, uint32_t q2, uint32_t q3) { put_part(q0, q1, q2, q3, 16u); }
 };
 std::string reference_display(double v) {
     if (std::isnan(v)) return "NaN";
