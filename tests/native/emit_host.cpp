@@ -284,3 +284,42 @@ extern "C" int64_t fge_encode_canonical(int enc, int merger, int src_fmt, int ge
     if (out && res.size() <= cap) memcpy(out, res.data(), res.size());
     return (int64_t)res.size();
 }
+
+// PackSink alone: a random sequence of put / put_word / put16 / put_part calls at a random start alignment into a guarded buffer
+// must leave exactly the concatenation of the bytes it was handed, and nothing outside.  Returns 0, or the failing step + 1.
+extern "C" int fge_sink_fuzz(uint64_t seed, uint32_t steps) {
+    rng_state = seed * 0x9E3779B97F4A7C15ull + 777u;
+    std::vector<uint8_t> want;
+    std::vector<uint8_t> buf(steps * 16u + 128u, 0xA5);
+    uint8_t* start = buf.data() + 48;
+    start += (rnd() & 15u) - ((uintptr_t)start & 15u) & 15u;
+    fg::emit::PackSink sink(start);
+    for (uint32_t i = 0; i < steps; ++i) {
+        uint32_t q[4];
+        for (int k = 0; k < 4; ++k) q[k] = rnd() * 2654435761u + rnd();
+        const uint32_t kind = rnd() % 4u;
+        if (kind == 0u) {
+            sink.put(q[0] & 0xFFu);
+            want.push_back((uint8_t)q[0]);
+        } else if (kind == 1u) {
+            const uint32_t nb = 1u + rnd() % 4u;
+            const uint32_t w = nb == 4u ? q[0] : (q[0] & ((1u << (8u * nb)) - 1u));
+            sink.put_word(w, nb);
+            for (uint32_t b = 0; b < nb; ++b) want.push_back((uint8_t)(w >> (8u * b)));
+        } else if (kind == 2u) {
+            sink.put16(q[0], q[1], q[2], q[3]);
+            for (uint32_t b = 0; b < 16u; ++b) want.push_back((uint8_t)(q[b >> 2] >> (8u * (b & 3u))));
+        } else {
+            const uint32_t nb = 1u + rnd() % 16u;
+            for (uint32_t b = nb; b < 16u; ++b) q[b >> 2] &= ~(0xFFu << (8u * (b & 3u)));  // (the contract: zero beyond nb)
+            sink.put_part(q[0], q[1], q[2], q[3], nb);
+            for (uint32_t b = 0; b < nb; ++b) want.push_back((uint8_t)(q[b >> 2] >> (8u * (b & 3u))));
+        }
+    }
+    sink.finish();
+    if (sink.p != start + want.size()) return -1;
+    if (memcmp(start, want.data(), want.size()) != 0) return -2;
+    for (uint8_t* p = buf.data(); p < buf.data() + buf.size(); ++p)
+        if ((p < start || p >= start + want.size()) && *p != 0xA5) return -3;
+    return 0;
+}

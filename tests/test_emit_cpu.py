@@ -47,6 +47,8 @@ def emit():
     run.set_sort_slots = L.fge_set_sort_slots
     L.fge_last_plain.restype = C.c_uint32
     run.last_plain = L.fge_last_plain
+    L.fge_sink_fuzz.argtypes = [C.c_uint64, C.c_uint32]
+    run.sink_fuzz = L.fge_sink_fuzz
     return run
 
 
@@ -219,3 +221,12 @@ def test_long_spans_every_tail_length_and_the_plain_note(emit, oracle, enc):
                     assert emit.last_plain() == (0 if escaped else 1), (n, kind, rec)
     if enc == OB.ENC_GELF:
         assert seen[0] > 100 and seen[1] > 100
+
+
+def test_pack_sink_alone_any_sequence_of_pieces(emit):
+    """PackSink (the write pass's sink) on its own: random sequences of one-byte puts, 1-4-byte words, sixteen-byte copies and pieces of
+    1-16 bytes at random start alignments leave exactly the bytes they were handed -- nothing before, nothing behind (guard bytes)."""
+    for seed in range(400):
+        assert emit.sink_fuzz(seed, 1 + seed % 97) == 0, seed
+    for seed in range(40):
+        assert emit.sink_fuzz(10_000 + seed, 5000) == 0, seed
