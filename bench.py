@@ -365,9 +365,21 @@ def e2e_legs(D: Dist, dec, fmt, data, offsets, n_tile, tile_bytes, want_transcod
                                                   C.byref(po), C.byref(nf), C.byref(cons)), "fg_frame_decode_batch")
                 assert nf.value == n, (nf.value, n)
 
+            PATHS = {0: "none", 1: "decode zero-copy", 2: "decode sliced", 3: "frame + decode in ONE launch (the decode kernel frames the pinned chunk itself)",
+                     4: "upload slices + framing scan + decode per slice", 5: "upload, frame, count on the host, decode"}
             if leg("frame_decode_batch", call_stream, stream_bytes * reps,
-                   "fg_frame_decode_batch: H2D of the raw stream only (sliced hipMemcpy), framing + UTF-8 + decode on the GPU, table columns written straight into pinned host memory, frame offsets copied"):
+                   "fg_frame_decode_batch from a pinned raw stream: ONE launch since round 6 -- the decode kernel reads the chunk in place over the link, frames its tiles itself (UTF-8 check included) and writes rows, entries and frame offsets straight into pinned host memory",
+                   extra=lambda: {"path": PATHS.get(int(lib.fg_last_host_path(dec._ctx)), "?")}):
                 out["frame_decode_batch"]["frac_of_link_h2d"] = out["frame_decode_batch"]["GBps_in"] / link[0] if link[0] else None
+            # the same leg the way rounds 3-5 ran it (upload slices, a framing scan, a capped decode grid per slice): same box, same buffers
+            try:
+                dec.set_launch_opts(**dict(getattr(dec, "_bench_opts", {}), no_fused_framing=True))
+                if leg("frame_decode_batch_two_step", call_stream, stream_bytes * reps,
+                       "the same call with FG_LO_NO_FUSED_FRAMING: H2D of the raw stream by sliced hipMemcpy, framing scan + decode per slice (rounds 3-5)",
+                       extra=lambda: {"path": PATHS.get(int(lib.fg_last_host_path(dec._ctx)), "?")}):
+                    out["frame_decode_batch_two_step"]["frac_of_link_h2d"] = out["frame_decode_batch_two_step"]["GBps_in"] / link[0] if link[0] else None
+            finally:
+                dec.set_launch_opts(**getattr(dec, "_bench_opts", {}))
         if want_transcode:
             enc = GelfEncoder(None, merger="line")
             cfg, _keep = enc._cfg_struct(0.0)
@@ -475,6 +487,7 @@ def make_decoder(fmt, local, opts):
                else RFC5424Decoder(device=local))
     if opts:
         dec.set_launch_opts(**opts)
+    dec._bench_opts = dict(opts or {})
     return dec
 
 

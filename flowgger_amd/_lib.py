@@ -19,7 +19,7 @@ if _ALT and (Path(_ALT).name != _ALT or not _ALT.startswith("libfg_hip") or not 
     raise RuntimeError(f"FLOWGGER_AMD_LIB={_ALT!r}: only a bare libfg_hip*.so file name beside flowgger_amd/_lib.py is accepted")
 LIB_PATH = _HERE / (_ALT or ("libfg_hip_prof.so" if os.environ.get("FLOWGGER_AMD_PROF_LIB") else "libfg_hip.so"))
 
-FG_ABI_VERSION = 3  # include/fg_hip.h
+FG_ABI_VERSION = 4  # include/fg_hip.h
 FG_RFC5424, FG_LTSV, FG_GELF, FG_RFC3164 = 0, 1, 2, 3
 FG_FRAME_NONE, FG_FRAME_LINE, FG_FRAME_NUL = 0, 1, 2
 FG_ST_OVERFLOW, FG_ST_BAD_UTF8 = 0xFE, 0xFD
@@ -84,6 +84,8 @@ FG_LO_FRAME_SELFTEST_STALL = 1024
 FG_LO_NO_TAPER = 2048
 FG_LO_TAPER_1 = 4096
 FG_LO_TAPER_2 = 8192
+FG_LO_NO_FUSED_FRAMING = 16384
+FG_PATH_DECODE_ZERO_COPY, FG_PATH_DECODE_SLICED, FG_PATH_FRAME_FUSED, FG_PATH_FRAME_SLICED, FG_PATH_FRAME_ONE_PIECE = 1, 2, 3, 4, 5
 FG_LO_RESERVED = 0x40000000  # the library's own (fg_set_launch_opts clears it)
 
 
@@ -176,6 +178,8 @@ def lib() -> C.CDLL:
     L.fg_free_pinned.restype = None
     L.fg_frame_device.argtypes = [vp, C.c_int, vp, u64, vp, vp, u64, C.POINTER(u64), vp]
     L.fg_decode_frames_device.argtypes = [vp, C.c_int, C.c_int, vp, u64, vp, u64, vp, C.POINTER(fg_tables), vp]
+    L.fg_last_host_path.argtypes = [vp]
+    L.fg_frame_decode_device.argtypes = [vp, C.c_int, C.c_int, vp, u64, C.c_int, vp, u64, C.POINTER(fg_tables), u64, vp, vp]
     if L.fg_abi_version() != FG_ABI_VERSION:
         raise RuntimeError("libfg_hip.so ABI version mismatch")
     _lib = L

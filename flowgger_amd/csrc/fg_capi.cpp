@@ -93,6 +93,7 @@ int upload_ltsv_cfg(fg_ctx* ctx) {
 extern "C" {
 
 int fg_abi_version(void) { return FG_ABI_VERSION; }
+int fg_last_host_path(const fg_ctx* ctx) { return ctx ? ctx->last_host_path : 0; }
 
 int fg_tables_layout(uint64_t n, uint64_t ent_cap, uint64_t sizes[FG_TABLE_ARRAYS]) {
     if (!sizes) return FG_ERR_ARG;
@@ -240,6 +241,7 @@ void fg_destroy(fg_ctx* ctx) {
     if (ctx->d_sink) (void)hipFree(ctx->d_sink);
     if (ctx->d_used) (void)hipFree(ctx->d_used);
     if (ctx->d_frame) (void)hipFree(ctx->d_frame);
+    if (ctx->d_fused) (void)hipFree(ctx->d_fused);
     if (ctx->d_bad) (void)hipFree(ctx->d_bad);
     if (ctx->d_enc) (void)hipFree(ctx->d_enc);
     if (ctx->h_enc_ring) (void)hipHostFree(ctx->h_enc_ring);
@@ -501,6 +503,98 @@ int fg_decode_frames_impl(fg_ctx* ctx, fg_format fmt, fg_framing framing, const 
     return FG_OK;
 }
 
+
+// FRAME + DECODE IN ONE KERNEL (fg_fused.hpp): the raw stream chunk d_bytes[0 .. nbytes) is framed by the decode kernel itself --
+// rows into `tables` (tables->n = the rows it holds), frame starts into d_offsets (tables->n + 2 entries), and two result words in the
+// ctx's scratch: (*d_total)[0] = the frames of the chunk (beyond tables->n: those rows were not written), (*d_total)[1] != 0 = a wave
+// gave up waiting on the look-back (nothing is valid: run the separate framing + decode kernels).  Asynchronous on `stream`; nothing
+// visits the host.  avg_line = the average frame length to plan for (0: the ctx's experience).  FG_ERR_UNSUPPORTED = this format /
+// line length keeps the separate framing pass (RFC3164; long lines, whose kernels stage heads only): nothing was launched.
+int fg_frame_decode_impl(fg_ctx* ctx, fg_format fmt, fg_framing framing, const uint8_t* d_bytes, uint64_t nbytes, int final, uint64_t* d_offsets,
+                         uint64_t cap, const fg_tables* tables, uint64_t avg_line, void* stream, unsigned long long** d_total) {
+    if (!ctx || !tables || !d_offsets || !d_total || (nbytes && !d_bytes)) return FG_ERR_ARG;
+    if (framing != FG_FRAME_LINE && framing != FG_FRAME_NUL) return FG_ERR_ARG;
+    if (((uintptr_t)d_bytes & 15u) != 0 || tables->n < cap || (cap && !tables->meta) || tables->ent_cap > 0xFFFFFFFFull) return FG_ERR_ARG;
+    if (fmt != FG_RFC5424 && fmt != FG_LTSV && fmt != FG_GELF) return FG_ERR_UNSUPPORTED;
+    if (nbytes == 0 || cap == 0) return FG_ERR_UNSUPPORTED;
+    if (avg_line == 0) avg_line = ctx->frames_per_byte > 0.0 ? (uint64_t)(1.0 / ctx->frames_per_byte + 0.5) : 200u;
+    fg_launch_opts lo_call = ctx->lo;
+    if (ctx->link_bound_waves && lo_call.waves_per_cu == 0) lo_call.waves_per_cu = ctx->link_bound_waves;
+    const fg::FusedGeom g = fg::fused_geometry(fmt, avg_line, lo_call, ctx->link_bound_waves != 0);
+    if (!g.ok) return FG_ERR_UNSUPPORTED;
+    DeviceGuard guard(ctx->device);
+    hipStream_t s = stream == FG_STREAM_OWN ? ctx->stream : (hipStream_t)stream;
+    int rc;
+    if ((rc = grow_dev(ctx, (void**)&ctx->d_fused, &ctx->d_fused_cap, fg::fused_scratch_bytes(nbytes, g.S))) != FG_OK) return rc;
+    fg::DevTables dt = to_dev(*tables);
+    if (dt.ent_used) FG_HIP(ctx, hipMemsetAsync(dt.ent_used, 0, 8, s));
+    if (!ctx->d_stash) {
+        hipDeviceProp_t prop;
+        FG_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+        uint32_t blocks = 8u * (uint32_t)prop.multiProcessorCount;
+        FG_HIP(ctx, hipMalloc((void**)&ctx->d_stash, fg_stash_bytes(blocks)));
+        ctx->stash_blocks = blocks;
+    }
+    constexpr uint32_t kPendingRing = 1024;
+    if (!ctx->d_pending) {
+        FG_HIP(ctx, hipMalloc((void**)&ctx->d_pending, kPendingRing * sizeof(uint32_t)));
+        FG_HIP(ctx, hipMemset(ctx->d_pending, 0, kPendingRing * sizeof(uint32_t)));
+    }
+    ctx->epoch += 1u;
+    if (ctx->epoch == 0u) ctx->epoch = 1u;
+    dt.epoch = ctx->epoch;
+    dt.pending = ctx->d_pending + (dt.epoch % kPendingRing);
+    dt.n = cap;
+    if (ctx->timing) FG_HIP(ctx, hipEventRecord(ctx->ev0, s));
+    int lrc;
+    switch (fmt) {
+        case FG_RFC5424:
+            lrc = fg_launch_rfc5424_fused(d_bytes, nbytes, &dt, &g, s, ctx->d_stash, ctx->stash_blocks, (uint32_t)framing, final, d_offsets, cap, ctx->d_fused,
+                                          &lo_call, d_total);
+            break;
+        case FG_LTSV:
+            lrc = fg_launch_ltsv_fused(d_bytes, nbytes, &dt, &ctx->ltsv, &g, s, ctx->d_stash, ctx->stash_blocks, (uint32_t)framing, final, d_offsets, cap,
+                                       ctx->d_fused, &lo_call, d_total);
+            break;
+        default:
+            lrc = fg_launch_gelf_fused(d_bytes, nbytes, &dt, &g, s, (uint32_t)framing, final, d_offsets, cap, ctx->d_fused, &lo_call, d_total);
+            // the lines the fast form handed back: the exact form over the offsets the launch wrote (rows = its frame count, read on the device)
+            if (lrc == 0) lrc = fg_launch_gelf_general_dev(d_bytes, d_offsets, cap, &dt, s, (uint32_t)framing, nullptr, *d_total);
+            break;
+    }
+    if (lrc != 0) {
+        ctx->last_hip = lrc;
+        return FG_ERR_HIP;
+    }
+    if (ctx->timing) {
+        FG_HIP(ctx, hipEventRecord(ctx->ev1, s));
+        ctx->ev_valid = true;
+    }
+    return FG_OK;
+}
+
+int fg_frame_decode_device(fg_ctx* ctx, fg_format fmt, fg_framing framing, const uint8_t* d_bytes, uint64_t nbytes, int final, uint64_t* d_offsets,
+                           uint64_t cap_frames, const fg_tables* tables, uint64_t avg_line_hint, uint64_t* d_result, void* stream) {
+    if (!d_result) return FG_ERR_ARG;
+    unsigned long long* d_total = nullptr;
+    const int rc = fg_frame_decode_impl(ctx, fmt, framing, d_bytes, nbytes, final, d_offsets, cap_frames, tables, avg_line_hint, stream, &d_total);
+    if (rc != FG_OK) return rc;
+    DeviceGuard guard(ctx->device);
+    hipStream_t s = stream == FG_STREAM_OWN ? ctx->stream : (hipStream_t)stream;
+    FG_HIP(ctx, hipMemcpyAsync(d_result, d_total, 16, hipMemcpyDeviceToDevice, s));
+    return FG_OK;
+}
+
+#if defined(FG_FUSED_STATS)
+// measurement variant only (FG_BUILD_VARIANT=stats): the counters / phase clocks the last fused launch of this ctx left (fg_fused.hpp)
+extern "C" int fg_debug_fused_stats(fg_ctx* ctx, uint64_t out[16]) {
+    if (!ctx || !ctx->d_fused) return FG_ERR_ARG;
+    DeviceGuard guard(ctx->device);
+    FG_HIP(ctx, hipDeviceSynchronize());
+    FG_HIP(ctx, hipMemcpy(out, ctx->d_fused + fg::kFusedCounters * fg::kFusedCounterStride * 4u, 128, hipMemcpyDeviceToHost));
+    return FG_OK;
+}
+#endif
 
 // The exact form of GELF for ALL rows of a batch whose slices were decoded with ctx->defer_general set (a no-op when none was).
 int fg_finish_deferred_general(fg_ctx* ctx, fg_framing framing, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n,

@@ -15,6 +15,7 @@
 #include "../../include/fg_hip.h"
 #include "fg_device.hpp"
 #include "fg_enc_cfg.hpp"
+#include "fg_fused_plan.hpp"
 #include <time.h>
 
 #include "fg_rfc3164_parse.hpp"
@@ -69,6 +70,19 @@ extern "C" int fg_launch_gelf(const uint8_t* d_bytes, const uint64_t* d_offsets,
                               uint64_t avg_len, hipStream_t stream, uint64_t* stash, uint32_t stash_blocks, uint32_t strip,
                               const uint8_t* line_bad, const fg_launch_opts* lo, fg::TicketSlot* tk);
 
+extern "C" int fg_launch_gelf_general_dev(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t, hipStream_t stream,
+                                          uint32_t strip, const uint8_t* line_bad, const unsigned long long* n_dev);
+// the fused launches (fg_fused.hpp): frame + decode of a raw stream chunk in ONE kernel; g from fg::fused_geometry, scratch of
+// fg::fused_scratch_bytes(nbytes, g->S) bytes; *d_total = the launch's two result words (lines, abort flag), device memory
+extern "C" int fg_launch_rfc5424_fused(const uint8_t* d_bytes, uint64_t nbytes, const fg::DevTables* t, const fg::FusedGeom* g, hipStream_t stream,
+                                       uint64_t* stash, uint32_t stash_blocks, uint32_t strip, int final_, uint64_t* d_offsets, uint64_t cap,
+                                       uint8_t* scratch, const fg_launch_opts* lo, unsigned long long** d_total);
+extern "C" int fg_launch_ltsv_fused(const uint8_t* d_bytes, uint64_t nbytes, const fg::DevTables* t, const fg::LtsvDevCfg* cfg, const fg::FusedGeom* g,
+                                    hipStream_t stream, uint64_t* stash, uint32_t stash_blocks, uint32_t strip, int final_, uint64_t* d_offsets,
+                                    uint64_t cap, uint8_t* scratch, const fg_launch_opts* lo, unsigned long long** d_total);
+extern "C" int fg_launch_gelf_fused(const uint8_t* d_bytes, uint64_t nbytes, const fg::DevTables* t, const fg::FusedGeom* g, hipStream_t stream,
+                                    uint32_t strip, int final_, uint64_t* d_offsets, uint64_t cap, uint8_t* scratch, const fg_launch_opts* lo,
+                                    unsigned long long** d_total);
 extern "C" int fg_launch_poke64(const uint64_t* d_src, uint64_t* dst_devview, hipStream_t stream);
 extern "C" uint64_t fg_merge_scratch_bytes(uint64_t rows);
 extern "C" int fg_launch_merge_device(const fg_tables* parts, uint32_t g, const uint64_t* const* d_index, const fg_tables* out, uint8_t* d_src_part,
@@ -87,6 +101,7 @@ struct fg_ctx {
     fg_launch_opts lo{};  // launch-geometry overrides (fg_set_launch_opts); all zero = the library's own choices
     uint32_t link_bound_waves = 0;  // host pipelines whose tables lie across the link: waves per CU of the decode grid for the duration of
                                     // a call, where the caller's options leave the choice to the library (fg_host_pipeline.cpp LinkBoundGrid)
+    int last_host_path = 0;  // fg_last_host_path: which form the last host-buffer decode call took (FG_PATH_*)
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
@@ -114,6 +129,8 @@ struct fg_ctx {
     uint64_t* d_used = nullptr;     // fg_decode_batch, zero-copy form: the entry counter (the tables themselves are pinned host memory)
     uint8_t* d_frame = nullptr;  // fg_frame_device scratch (delimiter / UTF-8 masks, block counts)
     uint64_t d_frame_cap = 0;
+    uint8_t* d_fused = nullptr;  // fg_frame_decode_device: the fused launch's scratch (ticket counters, tile counts, block prefixes)
+    uint64_t d_fused_cap = 0;
     uint8_t* d_bad = nullptr;    // fg_frame_decode_batch: per-frame UTF-8 verdicts
     uint64_t d_bad_cap = 0;
     uint64_t* h_off = nullptr;   // fg_frame_decode_batch: pinned host copy of the frame offsets
@@ -270,6 +287,10 @@ int grow_pinned(fg_ctx* ctx, void** p, uint64_t* cap, uint64_t need) {
 // flight at the same time (its own entry stash)
 extern "C" int fg_finish_deferred_general(fg_ctx* ctx, fg_framing framing, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n,
                                const uint8_t* d_bad_utf8, const fg_tables* tables, void* stream);
+// one fused launch on `stream` (fg_capi.cpp): *d_total = its result words in ctx scratch.  FG_ERR_UNSUPPORTED: nothing was launched
+extern "C" int fg_frame_decode_impl(fg_ctx* ctx, fg_format fmt, fg_framing framing, const uint8_t* d_bytes, uint64_t nbytes, int final,
+                                    uint64_t* d_offsets, uint64_t cap, const fg_tables* tables, uint64_t avg_line, void* stream,
+                                    unsigned long long** d_total);
 extern "C" int fg_decode_frames_impl(fg_ctx* ctx, fg_format fmt, fg_framing framing, const uint8_t* d_bytes, uint64_t nbytes,
                           const uint64_t* d_offsets, uint64_t n, const uint8_t* d_bad_utf8, const fg_tables* tables,
                           void* stream, bool reset_counter, uint64_t span_bytes, uint32_t lane = 0);

@@ -23,12 +23,13 @@
 // device only).  Everything HERE is written against fg_wave.hpp and runs lane for lane on the CPU emulation of a wave
 // (tests/native/fuse_host.cpp, tests/test_fuse_cpu.py) against the oracle's restatement of the two splitters (fgo_frame).
 #pragma once
+#include "fg_fused_plan.hpp"
 #include "fg_wave.hpp"
 
 namespace fg {
 namespace fuse {
 
-constexpr uint32_t kPre = 16;    // bytes staged in front of the tile
+constexpr uint32_t kPre = kPreBytes;  // bytes staged in front of the tile
 constexpr uint32_t kList = 256;  // line starts listed at a time (list[0 .. kList] : kList lines and the end of the last)
 constexpr uint32_t kUnresolved = 0xFFFFFFFFu;
 
@@ -64,10 +65,15 @@ FG_WV uint32_t utf8_err_flags(uint32_t b, uint32_t p) {
 }
 // delimiter mask (low 16 bits) | UTF-8 error mask (high 16 bits) of the chunk q0..q3 whose predecessor dword is pw.
 //   rem = stream bytes from the chunk's first byte to the end of the stream, clamped to [-1, 16]: 16 = a full chunk, 0 .. 15 = the
-//   chunk that holds position `nbytes` (the error bit AT that position stays: a sequence cut off by the end of the stream -- the
-//   bytes behind the end read as "not a continuation"), -1 = a chunk behind it (nothing).
+//   chunk that holds position `nbytes` -- what lies behind the stream's end is the caller's memory, anything: it is read as zeros, so
+//   that the error bit AT position nbytes says "a sequence cut off by the end of the stream" --, -1 = a chunk behind it (nothing).
 FG_WV uint32_t chunk_masks(uint32_t q0, uint32_t q1, uint32_t q2, uint32_t q3, uint32_t pw, uint32_t delim4, int32_t rem) {
     if (rem < 0) return 0u;
+    if (rem < 16) {  // (rare: one chunk per stream)
+        const uint32_t r = (uint32_t)rem;
+        auto keep = [&](uint32_t d) -> uint32_t { return r >= 4u * d + 4u ? 0xFFFFFFFFu : r <= 4u * d ? 0u : (1u << (8u * (r - 4u * d))) - 1u; };
+        q0 &= keep(0u), q1 &= keep(1u), q2 &= keep(2u), q3 &= keep(3u);
+    }
     uint32_t dm = wv::gather16(wv::eq_flags(q0, delim4), wv::eq_flags(q1, delim4), wv::eq_flags(q2, delim4), wv::eq_flags(q3, delim4));
     uint32_t em = 0;
     if (((q0 | q1 | q2 | q3 | pw) & 0x80808080u) != 0u)
@@ -80,23 +86,23 @@ FG_WV uint32_t chunk_masks(uint32_t q0, uint32_t q1, uint32_t q2, uint32_t q3, u
 }
 
 // ---- the tile ---------------------------------------------------------------------------------------------------------------------
-// chunks a lane owns in the count / list passes: the tile's chunks dealt out in runs, a multiple of four (16-byte LDS reads)
+// chunks a lane owns in the count / list passes: the tile's chunks dealt out in runs, a multiple of four (8-byte LDS reads)
 FG_WVH uint32_t chunks_per_lane(uint32_t tile_cap) { return ((tile_cap / 16u + 63u) / 64u + 3u) & ~3u; }
-// LDS of the fused part: m32[64 * R] + list[kList + 2] (u16) + eight words of state
-FG_WVH uint32_t lds_bytes(uint32_t tile_cap) { return 64u * chunks_per_lane(tile_cap) * 4u + (((kList + 2u) * 2u + 15u) & ~15u) + 32u; }
+// LDS of the fused part: dm16[64 * R] + list[kList + 2] (u16).  (The UTF-8 error masks are NOT kept: a tile without an error bit --
+// every tile of a healthy stream -- never looks at them, and a tile with one re-derives them from the tile's own bytes, line_bad.  One
+// word per chunk, both masks, cost the structured-data kernel a wave per CU.)
+FG_WVH uint32_t lds_bytes(uint32_t tile_cap) { return 64u * chunks_per_lane(tile_cap) * 2u + (((kList + 2u) * 2u + 15u) & ~15u); }
 
 struct Lds {
-    uint32_t* m32;   // [64 * R]: per chunk of the staged range, delimiter mask | error mask << 16; zero behind the staged chunks
+    uint16_t* dm16;  // [64 * R]: the delimiter mask of every 16-byte chunk of the staged range; zero behind the staged chunks
     uint16_t* list;  // [kList + 2]
-    uint32_t* state; // [8]
     uint32_t R;
 };
 FG_WVH Lds carve(uint8_t* base, uint32_t tile_cap) {
     Lds L;
     L.R = chunks_per_lane(tile_cap);
-    L.m32 = reinterpret_cast<uint32_t*>(base);
-    L.list = reinterpret_cast<uint16_t*>(base + 64u * L.R * 4u);
-    L.state = reinterpret_cast<uint32_t*>(base + 64u * L.R * 4u + (((kList + 2u) * 2u + 15u) & ~15u));
+    L.dm16 = reinterpret_cast<uint16_t*>(base);
+    L.list = reinterpret_cast<uint16_t*>(base + 64u * L.R * 2u);
     return L;
 }
 
@@ -137,37 +143,28 @@ struct Count {
     uint32_t n_own;  // lines that start in the tile
     uint32_t n_all;  // delimiters of the staged range (the pre-chunk's last byte included)
     uint32_t ex;     // this lane: delimiters before its run
-    bool any_err;    // an error bit anywhere in the staged range (wave-uniform)
 };
 // All 64 lanes.  The masks must be in LDS (and visible: wv::sync() before).
 FG_WV Count count_tile(const Lds& L, const Geo& g) {
     const uint32_t lane = wv::lane();
-    const uint32_t c0 = lane * L.R;
-    uint32_t all = 0, own = 0, err = 0;
-    for (uint32_t j = 0; j < L.R; j += 4u) {
-        uint32_t m[4];
-#if defined(__HIPCC__)
-        const uint4 q = *reinterpret_cast<const uint4*>(L.m32 + c0 + j);
-        m[0] = q.x, m[1] = q.y, m[2] = q.z, m[3] = q.w;
-#else
-        for (uint32_t k = 0; k < 4u; ++k) m[k] = L.m32[c0 + j + k];
-#endif
-#pragma unroll
-        for (uint32_t k = 0; k < 4u; ++k) {
-            const uint32_t dm = m[k] & 0xFFFFu, x0 = (c0 + j + k) * 16u;
-            err |= m[k] >> 16;
-            all += wv::popc32(dm);
-            // the part of the chunk in front of own_end
-            const uint32_t keep = x0 + 16u <= g.own_end ? 0xFFFFu : x0 >= g.own_end ? 0u : (1u << (g.own_end - x0)) - 1u;
-            own += wv::popc32(dm & keep);
+    const uint32_t c0 = lane * L.R, x0 = c0 * 16u, x1 = x0 + L.R * 16u;
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(L.dm16 + c0);  // two masks to the dword
+    uint32_t all = 0;
+    for (uint32_t j = 0; j < L.R / 2u; j += 2u) all += wv::popc32(w[j]) + wv::popc32(w[j + 1u]);
+    // the delimiters in front of own_end: everything, nothing -- or, for the one lane whose run holds own_end, chunk by chunk
+    uint32_t own = x1 <= g.own_end ? all : 0u;
+    if (x0 < g.own_end && g.own_end < x1) {
+        for (uint32_t j = 0; j < L.R; ++j) {
+            const uint32_t c = x0 + j * 16u;
+            if (c >= g.own_end) break;
+            const uint32_t keep = c + 16u <= g.own_end ? 0xFFFFu : (1u << (g.own_end - c)) - 1u;
+            own += wv::popc32((uint32_t)L.dm16[c0 + j] & keep);
         }
     }
     Count r;
     r.ex = wv::excl_sum(all, &r.n_all);
-    uint32_t n_own;
-    (void)wv::excl_sum(own, &n_own);
-    r.n_own = n_own;
-    r.any_err = wv::any(err != 0u);
+    const uint32_t lb = g.own_end / (L.R * 16u);  // the lane whose run holds own_end (beyond the last lane: every delimiter counts)
+    r.n_own = wv::bcast(r.ex + own, lb < 63u ? lb : 63u);
     return r;
 }
 // list[r - w0] = tile position of the byte BEHIND the delimiter of rank r, for w0 <= r <= w0 + kList.  All 64 lanes; wv::sync() after.
@@ -177,7 +174,7 @@ FG_WV void build_list(const Lds& L, const Count& cn, uint32_t w0) {
     uint32_t r = cn.ex;
     if (r > w0 + kList) return;
     for (uint32_t j = 0; j < L.R; ++j) {
-        uint32_t dm = L.m32[c0 + j] & 0xFFFFu;
+        uint32_t dm = L.dm16[c0 + j];
         while (dm) {
             const uint32_t b = wv::ctz32(dm);
             dm &= dm - 1u;
@@ -193,10 +190,12 @@ FG_WV void line_at(const Lds& L, const Count& cn, uint32_t w0, uint32_t k, uint3
     *s = L.list[k - w0];
     *e = k + 1u < cn.n_all ? (uint32_t)L.list[k + 1u - w0] : kUnresolved;
 }
-// any UTF-8 error bit at tile positions [a, b)?  (b <= span + 1)
-FG_WV bool line_bad(const Lds& L, uint32_t a, uint32_t b) {
+// any UTF-8 error at tile positions [a, b) (a >= kPre, b <= span + 1)?  Re-derived from the tile's bytes (tile = the staged range as
+// dwords): only a tile in which stage A saw an error bit ever asks.
+FG_WV bool line_bad(const uint32_t* tile, const Geo& g, uint32_t a, uint32_t b) {
     for (uint32_t c = a >> 4; c * 16u < b; ++c) {
-        uint32_t em = L.m32[c] >> 16;
+        const uint32_t* q = tile + c * 4u;
+        uint32_t em = chunk_masks(q[0], q[1], q[2], q[3], q[-1], 0x01010101u, chunk_rem(g, c)) >> 16;
         const uint32_t x0 = c * 16u;
         if (x0 < a) em &= ~((1u << (a - x0)) - 1u);
         if (x0 + 16u > b) em &= (1u << (b - x0)) - 1u;
@@ -262,28 +261,6 @@ FG_WV void resolve_tail(const Geo& g, Count* cn, Load ld, uint64_t nbytes, uint3
         }
     }
     *tail_end = e;
-}
-
-// ---- host side: the tile size of a fused launch --------------------------------------------------------------------------------------
-// S: as many bytes as `lines` average lines hold, less an eighth (a tile that holds more lines than the group takes costs a second
-// pass of stage B over the same tile), a multiple of 256; look: one average line rounded up to 64, 64 .. 2048 -- the tile's last line
-// ends within it three times out of four, else the wave reads on (forward_scan) and the line is parsed from global memory.
-// Both bounded by the LDS tile: kPre + S + look + 16 <= tile_cap.
-struct TilePlan { uint32_t S, look; };
-FG_WVH TilePlan plan_tile(uint64_t avg_len, uint32_t lines, uint32_t tile_cap) {
-    if (avg_len < 16u) avg_len = 16u;
-    uint64_t look = (avg_len + 63u) & ~63ull;
-    if (look > 2048u) look = 2048u;
-    if (look + 1024u > tile_cap) look = 64u;
-    const uint64_t room = tile_cap - kPre - 16u - look;  // what the tile may hold besides
-    uint64_t S = (uint64_t)lines * avg_len * 7u / 8u;
-    if (S > room) S = room;
-    S &= ~255ull;
-    if (S < 256u) S = room < 256u ? (room & ~15ull) : 256u;
-    TilePlan p;
-    p.S = (uint32_t)S;
-    p.look = (uint32_t)look;
-    return p;
 }
 
 }  // namespace fuse

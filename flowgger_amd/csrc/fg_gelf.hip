@@ -24,7 +24,7 @@
 //   pass 3  extras are written to the entry table in sorted order (count -> wave-aggregated
 //           atomic -> fill).
 // Numbers use serde_json 0.8's own (not correctly rounded) algorithm, see fg_numparse.hpp.
-#include "fg_pipeline.hpp"
+#include "fg_fused.hpp"
 #include "fg_numparse.hpp"
 #include "fg_gelf2.hpp"
 
@@ -622,6 +622,29 @@ __global__ __launch_bounds__(kWave, MINW) void k_gelf(const uint8_t* __restrict_
     }
 }
 
+// The fast form over a RAW stream: the kernel frames its tiles itself (fg_fused.hpp); the lines it hands back get kPending as ever,
+// and k_gelf_general finds them through the offsets this kernel wrote.
+template <int NB, int MINW = 4, uint32_t TILE = 0, uint32_t LINES = 0>
+__global__ __launch_bounds__(kWave, MINW) void k_gelf_fused(const uint8_t* __restrict__ bytes, DevTables t, uint32_t tile_cap_, uint32_t L_,
+                                                         FusedArgs fa, uint32_t strip) {
+    const uint32_t tile_cap = TILE ? TILE : tile_cap_, L = LINES ? LINES : L_;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    GelfFormat fmt{smem + tile_cap + 64u + (tile_cap / 16u + 16u) * 2u * GelfFormat::kClasses, tile_cap, L, nullptr};
+    {
+        const gelf2::Lds lds = gelf2::carve(smem, reinterpret_cast<uint16_t*>(smem + tile_cap + 64u), tile_cap, fmt.extra, L);
+        gelf2::init_lds(lds);
+        gelf2::clear_dirty(lds, tile_cap);
+    }
+    __shared__ DevTables t_lds;  // (see k_gelf)
+    __shared__ FusedArgs fa_lds;
+    if (threadIdx.x == 0) {
+        t_lds = t;
+        fa_lds = fa;
+    }
+    __syncthreads();
+    fused_loop<NB>(bytes, t_lds, tile_cap, L, fmt, fa_lds, strip, nullptr);
+}
+
 // ---- kernel 2: pending lines -> the general form, straight from global memory --------------------------------------
 // lines a wave of the general kernel collects pending lines from at a time -- at most; a small batch takes shorter spans (the
 // launcher's `span`: a multiple of 64).  A wave runs the SHAPES of its pending lines one after the other (each a chain of dependent
@@ -636,7 +659,12 @@ constexpr uint32_t kLaneBlock = kMaxStored * 4u + kMaxDepth / 8u;  // per lane: 
 //  waves per CU: profiles/r05aa_gelf_general_lds_ab.log.  The ~70 us a trip takes however few lines it holds are not memory: a lane
 //  walks its line three times -- validation, the sorted dispatch's count, its emission -- at ~20 dependent instructions per byte.)
 __global__ __launch_bounds__(kWave, 2) void k_gelf_general(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets,
-                                                          uint64_t n, DevTables t, FrameArgs fr, uint32_t span) {
+                                                          uint64_t n, DevTables t, FrameArgs fr, uint32_t span, const unsigned long long* n_dev) {
+    // (behind a fused launch -- fg_fused.hpp -- the number of frames is known on the device only: n is then the tables' capacity)
+    if (n_dev) {
+        const unsigned long long nd = *n_dev;
+        if (nd < n) n = nd;
+    }
     __shared__ __attribute__((aligned(16))) uint8_t scratch[kWave * kLaneBlock];
     __shared__ uint32_t ent_state[2];
     const uint32_t lane = threadIdx.x;
@@ -839,8 +867,15 @@ extern "C" int fg_launch_gelf(const uint8_t* d_bytes, const uint64_t* d_offsets,
     if (lo.flags & FG_LO_RESERVED) return 0;
     return fg_launch_gelf_general(d_bytes, d_offsets, n, t, stream, strip, line_bad);
 }
+extern "C" int fg_launch_gelf_general_dev(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t, hipStream_t stream,
+                                          uint32_t strip, const uint8_t* line_bad, const unsigned long long* n_dev);
 extern "C" int fg_launch_gelf_general(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t, hipStream_t stream,
                                       uint32_t strip, const uint8_t* line_bad) {
+    return fg_launch_gelf_general_dev(d_bytes, d_offsets, n, t, stream, strip, line_bad, nullptr);
+}
+// n_dev != null: the rows are min(n, *n_dev), read on the device (the exact form behind a fused launch)
+extern "C" int fg_launch_gelf_general_dev(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t, hipStream_t stream,
+                                          uint32_t strip, const uint8_t* line_bad, const unsigned long long* n_dev) {
     if (n == 0) return 0;
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
@@ -852,6 +887,32 @@ extern "C" int fg_launch_gelf_general(const uint8_t* d_bytes, const uint64_t* d_
     const uint64_t chunks = (n + span - 1) / span;
     if (gblocks > chunks) gblocks = chunks;
     hipLaunchKernelGGL(fg::k_gelf_general, dim3((uint32_t)gblocks), dim3(fg::kWave), 0, stream, d_bytes, d_offsets, n, *t, fg::FrameArgs{strip, line_bad},
-                       span);
+                       span, n_dev);
+    return (int)hipGetLastError();
+}
+
+// The fused launch (fg_fused.hpp): frame + the fast form of a raw stream chunk in one kernel (see fg_launch_rfc5424_fused).  The lines
+// the fast form hands back are finished by fg_launch_gelf_general_dev over the offsets this launch writes (n read on the device).
+extern "C" int fg_launch_gelf_fused(const uint8_t* d_bytes, uint64_t nbytes, const fg::DevTables* t, const fg::FusedGeom* g, hipStream_t stream,
+                                    uint32_t strip, int final_, uint64_t* d_offsets, uint64_t cap, uint8_t* scratch, const fg_launch_opts* lo,
+                                    unsigned long long** d_total) {
+    if (nbytes == 0 || !g->ok) return -1;
+    const uint32_t base_lds = g->tile + 64u + (g->tile / 16u + 16u) * 2u * fg::GelfFormat::kClasses + fg::gelf_extra_lds(g->tile, g->L);
+    fg::FusedArgs fa{};
+    uint32_t lds = 0, blocks = 0;
+    const uint32_t delim = strip == FG_FRAME_LINE ? 0x0Au : 0u;
+    const bool konst = g->variant == 1u && g->tile == 3072u && g->L == 8u;
+    const int prc = konst ? fg::fused_prepare(fg::k_gelf_fused<3, 4, 3072u, 8u>, *g, base_lds, nbytes, final_, delim, d_offsets, cap, scratch, 0u, *lo, stream,
+                                              &fa, &lds, &blocks)
+                          : fg::fused_prepare(fg::k_gelf_fused<6, 4>, *g, base_lds, nbytes, final_, delim, d_offsets, cap, scratch, 0u, *lo, stream, &fa, &lds,
+                                              &blocks);
+    if (prc) return -1;
+    fg::DevTables tt = *t;
+    tt.alloc_chunk = fg::entry_chunk(tt.ent_cap, blocks, nbytes / (g->S / g->L ? g->S / g->L : 1u) + 1u, *lo);
+    *d_total = fa.total;
+    if (konst)
+        hipLaunchKernelGGL((fg::k_gelf_fused<3, 4, 3072u, 8u>), dim3(blocks), dim3(fg::kWave), lds, stream, d_bytes, tt, g->tile, g->L, fa, strip);
+    else
+        hipLaunchKernelGGL((fg::k_gelf_fused<6, 4>), dim3(blocks), dim3(fg::kWave), lds, stream, d_bytes, tt, g->tile, g->L, fa, strip);
     return (int)hipGetLastError();
 }

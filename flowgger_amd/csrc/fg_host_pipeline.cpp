@@ -317,6 +317,7 @@ static int decode_batch_zero_copy(fg_ctx* ctx, fg_format fmt, const uint8_t* byt
         }
         *ht.ent_used = used;
         *out = ht;
+        ctx->last_host_path = FG_PATH_DECODE_ZERO_COPY;
         return FG_OK;
     }
 }
@@ -477,6 +478,7 @@ int fg_decode_batch(fg_ctx* ctx, fg_format fmt, const uint8_t* bytes, uint64_t n
         FG_HIP(ctx, hipStreamSynchronize(s_down));
         FG_HIP(ctx, hipStreamSynchronize(s_run));
         *out = ht;
+        ctx->last_host_path = FG_PATH_DECODE_SLICED;
         return FG_OK;
     }
 }
@@ -785,19 +787,96 @@ static int frame_decode_sliced(fg_ctx* ctx, fg_format fmt, fg_framing framing, c
     return FG_OK;
 }
 
+// fg_frame_decode_batch as ONE LAUNCH (round 6): a raw chunk in PINNED memory is neither uploaded nor framed by a pass of its own -- the
+// decode kernel reads it in place over the link, frames its tiles itself (fg_fused.hpp) and writes rows, entries AND the frame offsets
+// straight into the ctx's pinned tables: what fg_decode_batch's zero-copy form does for framed lines, now for the raw stream -- the path a
+// flowgger input really has (LineSplitter::run over a socket's bytes).  Until round 5 this path was an upload + a framing scan + a capped
+// decode grid per slice and ran at 0.55-0.87 of the link where the zero-copy form did 0.80-0.97.
+// FG_ERR_UNSUPPORTED: the chunk does not qualify (pageable memory, long lines, a table estimate that turned out too small, the
+// look-back's bounded wait ran out): the caller takes the paths below.
+static int frame_decode_fused(fg_ctx* ctx, fg_format fmt, fg_framing framing, const uint8_t* bytes, uint64_t nbytes, int final, fg_tables* out,
+                              const uint64_t** out_offsets, uint64_t* n_frames, uint64_t* consumed) {
+    if (nbytes == 0 || (ctx->lo.flags & (FG_LO_NO_FUSED_FRAMING | FG_LO_NO_ZERO_COPY | FG_LO_FRAME_CLASSIC | FG_LO_FRAME_SELFTEST_STALL))) return FG_ERR_UNSUPPORTED;
+    if (fmt != FG_RFC5424 && fmt != FG_LTSV && fmt != FG_GELF) return FG_ERR_UNSUPPORTED;
+    const uint8_t* d_bytes = (const uint8_t*)device_view_of_pinned(bytes);
+    if (!d_bytes || ((uintptr_t)d_bytes & 15u) != 0) return FG_ERR_UNSUPPORTED;
+    {
+        const uint8_t* last_b = bytes + ((nbytes + 15u) & ~15ull) - 1u;
+        const uint8_t* dv_last = (const uint8_t*)device_view_of_pinned(last_b);
+        if (!dv_last || dv_last - d_bytes != last_b - bytes) return FG_ERR_UNSUPPORTED;  // (ONE mapping up to the last byte the kernels load)
+    }
+    LinkBoundGrid grid(ctx);
+    int rc;
+    const uint64_t cap = (uint64_t)((double)nbytes * ctx->frames_per_byte * 1.25) + 4096;
+    const uint64_t ent_cap0 = fmt == FG_RFC5424 ? nbytes / 16 + 1024 : nbytes / 8 + 1024;
+    const uint64_t ent_cap = ent_cap0 > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : ent_cap0;
+    uint64_t tab_bytes = 0;
+    carve(nullptr, cap, ent_cap, nullptr, &tab_bytes);
+    if ((rc = grow_pinned(ctx, (void**)&ctx->h_tab, &ctx->h_tab_cap, tab_bytes)) != FG_OK) return rc;
+    if ((rc = grow_pinned(ctx, (void**)&ctx->h_off, &ctx->h_off_cap, (cap + 2) * 8)) != FG_OK) return rc;
+    if (!ctx->h_cnt) FG_HIP(ctx, hipHostMalloc((void**)&ctx->h_cnt, 65536, hipHostMallocDefault));
+    fg_tables ht, kt;
+    carve(ctx->h_tab, cap, ent_cap, &ht, nullptr);
+    if ((rc = pinned_tables_for_kernels(ctx, ht, &kt)) != FG_OK) return rc;
+    uint64_t* const off_dv = (uint64_t*)const_cast<void*>(device_view_of_pinned(ctx->h_off));
+    if (!off_dv) return FG_ERR_UNSUPPORTED;
+    const hipStream_t s = ctx->stream;
+    unsigned long long* d_total = nullptr;
+    if ((rc = fg_frame_decode_impl(ctx, fmt, framing, d_bytes, nbytes, final, off_dv, cap, &kt, 0, (void*)s, &d_total)) != FG_OK) return rc;
+    uint64_t* const res = ctx->h_cnt + 2048;  // [0] frames [1] abort [2] entries
+    FG_HIP(ctx, hipMemcpyAsync(res, d_total, 16, hipMemcpyDeviceToHost, s));
+    FG_HIP(ctx, hipMemcpyAsync(res + 2, kt.ent_used, 8, hipMemcpyDeviceToHost, s));
+    FG_HIP(ctx, hipStreamSynchronize(s));
+    const uint64_t total = res[0], used = res[2];
+    if (res[1] != 0) return FG_ERR_UNSUPPORTED;  // (the look-back's bounded wait ran out: never seen)
+    if (total > cap) {                          // more frames than the ctx's experience said: the next chunk is sized from this one
+        ctx->frames_per_byte = (double)(total + 1) / (double)nbytes;
+        return FG_ERR_UNSUPPORTED;
+    }
+    if (used > ent_cap) return FG_ERR_UNSUPPORTED;
+    if (total && nbytes >= (1u << 20)) ctx->frames_per_byte = (double)total / (double)nbytes;
+    *n_frames = total;
+    ctx->last_host_path = FG_PATH_FRAME_FUSED;
+    if (total == 0) {
+        fg_tables empty{};
+        *out = empty;
+        ctx->h_off[0] = 0;
+        *out_offsets = ctx->h_off;
+        *consumed = 0;
+        return FG_OK;
+    }
+    *ht.ent_used = used;
+    ht.n = total;
+    *out = ht;
+    *out_offsets = ctx->h_off;
+    *consumed = ctx->h_off[total];
+    return FG_OK;
+}
+
 int fg_frame_decode_batch(fg_ctx* ctx, fg_format fmt, fg_framing framing, const uint8_t* bytes, uint64_t nbytes, int final,
                           fg_tables* out, const uint64_t** out_offsets, uint64_t* n_frames, uint64_t* consumed) {
     if (!ctx || !out || !out_offsets || !n_frames || !consumed || (nbytes && !bytes)) return FG_ERR_ARG;
     if (framing != FG_FRAME_LINE && framing != FG_FRAME_NUL) return FG_ERR_UNSUPPORTED;
+    {
+        DeviceGuard g(ctx->device);
+        *n_frames = 0;
+        *consumed = 0;
+        *out_offsets = nullptr;
+        const int rc = frame_decode_fused(ctx, fmt, framing, bytes, nbytes, final, out, out_offsets, n_frames, consumed);
+        if (rc != FG_ERR_UNSUPPORTED) return rc;
+    }
     if (nbytes >= (48ull << 20) && !(ctx->lo.flags & FG_LO_TRANSCODE_ONE_PIECE)) {
         DeviceGuard g(ctx->device);
         *n_frames = 0;
         *consumed = 0;
         *out_offsets = nullptr;
         const int rc = frame_decode_sliced(ctx, fmt, framing, bytes, nbytes, final, out, out_offsets, n_frames, consumed);
+        if (rc == FG_OK) ctx->last_host_path = FG_PATH_FRAME_SLICED;
         if (rc != FG_ERR_UNSUPPORTED) return rc;
     }
-    return frame_decode_one_piece(ctx, fmt, framing, bytes, nbytes, final, out, out_offsets, n_frames, consumed);
+    const int rc1 = frame_decode_one_piece(ctx, fmt, framing, bytes, nbytes, final, out, out_offsets, n_frames, consumed);
+    if (rc1 == FG_OK) ctx->last_host_path = FG_PATH_FRAME_ONE_PIECE;
+    return rc1;
 }
 
 // Framing stage shared by fg_frame_decode_batch and fg_transcode_batch: the raw chunk is already in ctx->d_bytes

@@ -11,7 +11,7 @@
 // Pairs are parked in the wave's stash while the line is parsed and copied to the entry table
 // once the wave has its slots (single parse); the byte-walking two-pass form below stays for
 // lines outside the tile and lines with more than kStashEntries pairs.
-#include "fg_pipeline.hpp"
+#include "fg_fused.hpp"
 #include "fg_numfold.hpp"
 #include "fg_numparse.hpp"
 #include "fg_tsfast.hpp"
@@ -810,10 +810,10 @@ struct LtsvFormatT {
 
 using LtsvFormat = LtsvFormatT<false>;
 
-template <int NB, bool PROF, bool HEAD = false>
-__global__ __launch_bounds__(kWave, 2) void k_ltsv(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets,
-                                                  uint64_t n, DevTables t, LtsvDevCfg cfg, uint32_t tile_cap, uint32_t L,
-                                                  uint64_t groups, unsigned long long* prof, uint64_t* stash_base, FrameArgs fr) {
+// The per-wave setup both streaming skeletons share (schema / suffix mirrors, the digit-fold tables, the LDS copies of the tables and
+// the configuration), then `run(fmt, tables)`.
+template <bool HEAD, class Run>
+__device__ __forceinline__ void ltsv_body(const DevTables& t, const LtsvDevCfg& cfg, uint32_t tile_cap, Run run) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t* extra = smem + tile_cap + 64u + (tile_cap / 16u + 16u) * 2u;
     SchemaEnt* schema = reinterpret_cast<SchemaEnt*>(extra + 768u);
@@ -857,8 +857,28 @@ __global__ __launch_bounds__(kWave, 2) void k_ltsv(const uint8_t* __restrict__ b
     }
     __syncthreads();
     LtsvFormatT<HEAD> fmt{cfg.n_schema, &cfg_call, extra, schema, suffix, p10, dw, &t_call};
+    run(fmt, t_call);
+}
+
+template <int NB, bool PROF, bool HEAD = false>
+__global__ __launch_bounds__(kWave, 2) void k_ltsv(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets,
+                                                  uint64_t n, DevTables t, LtsvDevCfg cfg, uint32_t tile_cap, uint32_t L,
+                                                  uint64_t groups, unsigned long long* prof, uint64_t* stash_base, FrameArgs fr) {
     // (the pipeline gets the LDS copy of the tables too: see k_gelf -- scalar-register tuples parked in VGPR lanes otherwise)
-    persistent_loop<NB, PROF, LtsvFormatT<HEAD>, HEAD>(bytes, offsets, n, t_call, tile_cap, L, groups, prof, stash_base, fmt, fr);
+    ltsv_body<HEAD>(t, cfg, tile_cap, [&](LtsvFormatT<HEAD>& fmt, DevTables& t_call) {
+        persistent_loop<NB, PROF, LtsvFormatT<HEAD>, HEAD>(bytes, offsets, n, t_call, tile_cap, L, groups, prof, stash_base, fmt, fr);
+    });
+}
+
+// The same decoder over a RAW stream: the kernel frames its tiles itself (fg_fused.hpp)
+template <int NB>
+__global__ __launch_bounds__(kWave, 2) void k_ltsv_fused(const uint8_t* __restrict__ bytes, DevTables t, LtsvDevCfg cfg, uint32_t tile_cap,
+                                                        uint32_t L, uint64_t* stash_base, FusedArgs fa, uint32_t strip) {
+    __shared__ FusedArgs fa_lds;  // (see k_rfc5424_fused)
+    if (threadIdx.x == 0) fa_lds = fa;
+    ltsv_body<false>(t, cfg, tile_cap, [&](LtsvFormatT<false>& fmt, DevTables& t_call) {
+        fused_loop<NB>(bytes, t_call, tile_cap, L, fmt, fa_lds, strip, stash_base);
+    });
 }
 
 }  // namespace fg
@@ -903,5 +923,25 @@ extern "C" int fg_launch_ltsv(const uint8_t* d_bytes, const uint64_t* d_offsets,
     else
         hipLaunchKernelGGL((fg::k_ltsv<fg::kComputeBoundWindow, false>), grid, block, p.lds, stream, d_bytes, d_offsets, n, tt, *cfg, p.tile,
                            p.L, p.chunk, (unsigned long long*)nullptr, stash, fr);
+    return (int)hipGetLastError();
+}
+
+// The fused launch (fg_fused.hpp): frame + decode of a raw stream chunk in one kernel (see fg_launch_rfc5424_fused).
+extern "C" int fg_launch_ltsv_fused(const uint8_t* d_bytes, uint64_t nbytes, const fg::DevTables* t, const fg::LtsvDevCfg* cfg, const fg::FusedGeom* g,
+                                    hipStream_t stream, uint64_t* stash, uint32_t stash_blocks, uint32_t strip, int final_, uint64_t* d_offsets,
+                                    uint64_t cap, uint8_t* scratch, const fg_launch_opts* lo, unsigned long long** d_total) {
+    if (nbytes == 0 || !g->ok) return -1;
+    const uint32_t base_lds = g->tile + 64u + (g->tile / 16u + 16u) * 2u + fg::kLtsvExtraLds;
+    fg::FusedArgs fa{};
+    uint32_t lds = 0, blocks = 0;
+    if (stash_blocks == 0) stash = nullptr;
+    const uint32_t delim = strip == FG_FRAME_LINE ? 0x0Au : 0u;
+    if (fg::fused_prepare(fg::k_ltsv_fused<fg::kComputeBoundWindow>, *g, base_lds, nbytes, final_, delim, d_offsets, cap, scratch, stash ? stash_blocks : 0u, *lo,
+                          stream, &fa, &lds, &blocks))
+        return -1;
+    fg::DevTables tt = *t;
+    tt.alloc_chunk = fg::entry_chunk(tt.ent_cap, blocks, nbytes / (g->S / g->L ? g->S / g->L : 1u) + 1u, *lo);
+    *d_total = fa.total;
+    hipLaunchKernelGGL((fg::k_ltsv_fused<fg::kComputeBoundWindow>), dim3(blocks), dim3(fg::kWave), lds, stream, d_bytes, tt, *cfg, g->tile, g->L, stash, fa, strip);
     return (int)hipGetLastError();
 }

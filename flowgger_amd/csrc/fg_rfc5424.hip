@@ -24,7 +24,7 @@
 #include <cstdio>
 #include <cstdlib>
 
-#include "fg_pipeline.hpp"
+#include "fg_fused.hpp"
 #include "fg_sd2.hpp"
 #include "fg_tsfast.hpp"
 
@@ -1089,6 +1089,24 @@ __global__ __launch_bounds__(kWave, 2) void k_rfc5424(const uint8_t* __restrict_
     }
 }
 
+// The same decoder over a RAW stream: the kernel frames its tiles itself (fg_fused.hpp).  Whole lines only (a stream of long lines
+// -- head staging -- keeps the separate framing pass).
+template <int NB, bool SDX>
+__global__ __launch_bounds__(kWave, 2) void k_rfc5424_fused(const uint8_t* __restrict__ bytes, DevTables t, uint32_t tile_cap, uint32_t L,
+                                                           uint64_t* stash_base, FusedArgs fa, uint32_t strip) {
+    Rfc5424FormatT<false, SDX, false> fmt;
+    // (the tables AND the launch's arguments live in LDS: in scalar registers the loop's own wave-uniform state pushes the kernel past
+    //  the 102 it has, whole tuples get parked in VGPR lanes, the VGPRs spill -- and a scratch reload waits for EVERY load in flight)
+    __shared__ DevTables t_lds;
+    __shared__ FusedArgs fa_lds;
+    if (threadIdx.x == 0) {
+        t_lds = t;
+        fa_lds = fa;
+    }
+    __syncthreads();
+    fused_loop<NB>(bytes, t_lds, tile_cap, L, fmt, fa_lds, strip, stash_base);
+}
+
 }  // namespace fg
 
 extern "C" uint64_t fg_stash_bytes(uint32_t blocks) {
@@ -1164,5 +1182,32 @@ extern "C" int fg_launch_rfc5424(const uint8_t* d_bytes, const uint64_t* d_offse
         else FG_LAUNCH_5424(false, false, false, no_prof);
     }
 #undef FG_LAUNCH_5424
+    return (int)hipGetLastError();
+}
+
+// The fused launch (fg_fused.hpp): frame + decode of a raw stream chunk in one kernel.  g from fg::fused_geometry (the caller sized
+// `scratch` from it: fg::fused_scratch_bytes).  *d_total = the two device words the launch leaves: lines, abort flag.
+extern "C" int fg_launch_rfc5424_fused(const uint8_t* d_bytes, uint64_t nbytes, const fg::DevTables* t, const fg::FusedGeom* g, hipStream_t stream,
+                                       uint64_t* stash, uint32_t stash_blocks, uint32_t strip, int final_, uint64_t* d_offsets, uint64_t cap,
+                                       uint8_t* scratch, const fg_launch_opts* lo, unsigned long long** d_total) {
+    if (nbytes == 0 || !g->ok) return -1;
+    const bool sdx = g->variant == 1u;
+    const uint32_t base_lds = g->tile + 64u + (g->tile / 16u + 16u) * 2u * (sdx ? 2u : 1u) + (sdx ? fg::sd2::extra_bytes(g->tile) : 0u);
+    fg::FusedArgs fa{};
+    uint32_t lds = 0, blocks = 0;
+    if (stash_blocks == 0) stash = nullptr;
+    const uint32_t delim = strip == FG_FRAME_LINE ? 0x0Au : 0u;
+    const int prc = sdx ? fg::fused_prepare(fg::k_rfc5424_fused<fg::kWindowKiB, true>, *g, base_lds, nbytes, final_, delim, d_offsets, cap, scratch,
+                                            stash ? stash_blocks : 0u, *lo, stream, &fa, &lds, &blocks)
+                        : fg::fused_prepare(fg::k_rfc5424_fused<fg::kWindowKiB, false>, *g, base_lds, nbytes, final_, delim, d_offsets, cap, scratch,
+                                            stash ? stash_blocks : 0u, *lo, stream, &fa, &lds, &blocks);
+    if (prc) return -1;
+    fg::DevTables tt = *t;
+    tt.alloc_chunk = fg::entry_chunk(tt.ent_cap, blocks, nbytes / (g->S / g->L ? g->S / g->L : 1u) + 1u, *lo);
+    *d_total = fa.total;
+    if (sdx)
+        hipLaunchKernelGGL((fg::k_rfc5424_fused<fg::kWindowKiB, true>), dim3(blocks), dim3(fg::kWave), lds, stream, d_bytes, tt, g->tile, g->L, stash, fa, strip);
+    else
+        hipLaunchKernelGGL((fg::k_rfc5424_fused<fg::kWindowKiB, false>), dim3(blocks), dim3(fg::kWave), lds, stream, d_bytes, tt, g->tile, g->L, stash, fa, strip);
     return (int)hipGetLastError();
 }

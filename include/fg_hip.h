@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FG_ABI_VERSION 3 /* 3 (round 5): fg_launch_opts.ent_chunk (the struct grew), FG_LO_STATIC_CHUNKS / _FRAME_SELFTEST_STALL, fg_ticket_ring_check; 2 (round 4): FG_YEAR_NOW = INT32_MIN, FG_F_LTSV_NOVALUE and the failed-LTSV-row count, ent_used = RESERVED slots, fg_calibrate_device */
+#define FG_ABI_VERSION 4 /* 4 (round 6): fg_frame_decode_device (framing inside the decode kernels), FG_LO_NO_FUSED_FRAMING; 3 (round 5): fg_launch_opts.ent_chunk (the struct grew), FG_LO_STATIC_CHUNKS / _FRAME_SELFTEST_STALL, fg_ticket_ring_check; 2 (round 4): FG_YEAR_NOW = INT32_MIN, FG_F_LTSV_NOVALUE and the failed-LTSV-row count, ent_used = RESERVED slots, fg_calibrate_device */
 
 typedef enum fg_format { FG_RFC5424 = 0, FG_LTSV = 1, FG_GELF = 2, FG_RFC3164 = 3 } fg_format;
 
@@ -219,6 +219,8 @@ enum {
                                       (fg_plan_policy.hpp; A/B, tests) */
     FG_LO_TAPER_1 = 4096,          /* ... at most one such level (halves) instead of the format's own depth; */
     FG_LO_TAPER_2 = 8192,          /* ... at most two (halves, quarters); both bits: three (tuning) */
+    FG_LO_NO_FUSED_FRAMING = 16384, /* fg_frame_decode_batch / fg_transcode_batch: the separate framing pass (rounds 1-5) even where the decode kernels
+                                      can frame a pinned chunk themselves (A/B, tests) */
     FG_LO_RESERVED = 0x40000000    /* the library's own (fg_set_launch_opts clears it) */
 };
 
@@ -276,6 +278,26 @@ int fg_decode_frames_device(fg_ctx* ctx, fg_format fmt, fg_framing framing, cons
                             uint64_t nbytes, const uint64_t* d_offsets, uint64_t n,
                             const uint8_t* d_bad_utf8, const fg_tables* tables, void* stream);
 
+/* FRAME + DECODE IN ONE KERNEL (round 6; ABI 4): the decode kernel frames the raw stream chunk itself -- one read of the stream, no
+ * framing pass, no frame count that visits the host between two kernels.  Replaces, for a chunk of the stream, the whole loop of
+ * LineSplitter::run / NulSplitter::run (splitter/line_splitter.rs:17-54, nul_splitter.rs:18-60): `lines()` / `split(0)`, the UTF-8
+ * check and decoder.decode(line) for every frame.
+ *   d_bytes      raw stream chunk (device-addressable: HBM, or the device view of pinned host memory), 16-byte aligned, readable
+ *                up to nbytes rounded up to 16
+ *   final        nonzero: the stream ends with this chunk (an unterminated last piece is a frame); zero: it is not a frame, and
+ *                d_offsets[frames] says where it starts (carry it over)
+ *   d_offsets    out, cap_frames + 2 entries: frame i = [d_offsets[i], d_offsets[i + 1]) INCLUDING its terminator
+ *   tables       device arrays for cap_frames rows (tables->n >= cap_frames); a frame that is not valid UTF-8 gets FG_ST_BAD_UTF8
+ *   avg_line_hint  the average frame length to plan the launch for (0 = what this ctx last saw); only the speed depends on it
+ *   d_result     out (device), two words: [0] the frames of the chunk -- when it exceeds cap_frames the rows beyond were not
+ *                written: run again with more; [1] nonzero: the kernel's look-back gave up (never seen; bounded spin) -- nothing is
+ *                valid, use fg_frame_device + fg_decode_frames_device
+ * Asynchronous on `stream`.  FG_ERR_UNSUPPORTED (nothing launched): FG_RFC3164, or lines so long (average >= 768 bytes) that the
+ * decoders stage heads only -- those keep the separate framing pass. */
+int fg_frame_decode_device(fg_ctx* ctx, fg_format fmt, fg_framing framing, const uint8_t* d_bytes, uint64_t nbytes, int final,
+                           uint64_t* d_offsets, uint64_t cap_frames, const fg_tables* tables, uint64_t avg_line_hint,
+                           uint64_t* d_result, void* stream);
+
 /* HOST-BUFFER decode: the batch is decoded into ctx-owned pinned host memory (`out` is filled with host pointers valid until
  * the next call on this ctx or fg_destroy).  Synchronous.  Entry-table capacity grows automatically.
  *   `bytes` AND `offsets` in PINNED memory (fg_alloc_pinned / hipHostRegister: where the batching framer accumulates lines),
@@ -303,6 +325,17 @@ int fg_decode_batch(fg_ctx* ctx, fg_format fmt, const uint8_t* bytes, uint64_t n
 int fg_frame_decode_batch(fg_ctx* ctx, fg_format fmt, fg_framing framing, const uint8_t* bytes,
                           uint64_t nbytes, int final, fg_tables* out, const uint64_t** out_offsets,
                           uint64_t* n_frames, uint64_t* consumed);
+
+/* Which form the last fg_decode_batch / fg_frame_decode_batch call on this ctx took (0 = none yet): the library picks by what the
+ * caller's buffers allow, silently -- a harness that prices a leg against the link, or a test of one form, asks afterwards. */
+enum {
+    FG_PATH_DECODE_ZERO_COPY = 1,  /* fg_decode_batch: one launch, lines read over the link, tables written into pinned memory */
+    FG_PATH_DECODE_SLICED = 2,     /* fg_decode_batch: hipMemcpy slices on three streams */
+    FG_PATH_FRAME_FUSED = 3,       /* fg_frame_decode_batch: ONE launch -- the decode kernel frames the pinned chunk itself (round 6) */
+    FG_PATH_FRAME_SLICED = 4,      /* fg_frame_decode_batch: upload slices + framing scan + decode per slice (rounds 3-5) */
+    FG_PATH_FRAME_ONE_PIECE = 5    /* fg_frame_decode_batch: upload, frame, count on the host, decode */
+};
+int fg_last_host_path(const fg_ctx* ctx);
 
 /* GELF ENCODER FROM THE TABLES: replaces GelfEncoder::encode (src/flowgger/encoder/
  * gelf_encoder.rs:59-115, serde_json 0.8 serialisation of the BTreeMap it builds) for a whole

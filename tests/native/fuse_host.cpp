@@ -54,20 +54,22 @@ extern "C" long fgf_frame(const uint8_t* bytes, uint64_t nbytes, uint32_t delim,
             const fuse::Geo g = fuse::tile_geo(T, S, look, nbytes);
             if (g.span > tile_cap) throw std::runtime_error("span exceeds the tile");
             const uint32_t nchunk = g.span / 16u;
-            // ---- stage A: bytes -> tile, masks -> m32 (the kernels do this from the register window) ----
-            uint32_t pw = 0;
+            // ---- stage A: bytes -> tile, masks -> dm16 (the kernels do this from the register window) ----
+            uint32_t pw = 0, err_acc = 0;
             for (uint32_t c = 0; c < nchunk; ++c) {
                 fuse::U4 q{0, 0, 0, 0};
                 if (!(T == 0 && c == 0)) q = ld(g.base + (uint64_t)c * 16u);
                 memcpy(tile + c * 16u, &q, 16);
                 uint32_t m = fuse::chunk_masks(q.x, q.y, q.z, q.w, pw, delim4, fuse::chunk_rem(g, c));
                 if (c == 0) m = fuse::pre_chunk_mask(m, T == 0);
-                L.m32[c] = m;
+                L.dm16[c] = (uint16_t)m;
+                err_acc |= m >> 16;
                 pw = q.w;
             }
-            for (uint32_t c = nchunk; c < prev_chunks; ++c) L.m32[c] = 0u;  // (stale words of a longer tile before)
+            for (uint32_t c = nchunk; c < prev_chunks; ++c) L.dm16[c] = 0u;  // (stale masks of a longer tile before)
             prev_chunks = nchunk;
             const uint32_t pw_last = pw;
+            const bool any_err = err_acc != 0u;
             // ---- the wave-level part ----
             struct Out { uint64_t s, e; bool bad, valid; };
             std::vector<Out> out;
@@ -98,10 +100,10 @@ extern "C" long fgf_frame(const uint8_t* bytes, uint64_t nbytes, uint32_t delim,
                             if (e == fuse::kUnresolved) {
                                 o1 = tail_end;
                                 const uint32_t lim = g.end_x != fuse::kUnresolved ? g.end_x + 1u : g.span;
-                                b = tail_bad || (cn.any_err && fuse::line_bad(L, s, lim));
+                                b = tail_bad || (any_err && fuse::line_bad(tile32.data(), g, s, lim));
                             } else {
                                 o1 = g.base + e;
-                                b = cn.any_err && fuse::line_bad(L, s, e);
+                                b = any_err && fuse::line_bad(tile32.data(), g, s, e);
                             }
                         }
                         slot[lane] = Out{o0, o1, b, valid};

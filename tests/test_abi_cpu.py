@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 12
     for name in names:
         assert hasattr(lib, name), f"{name} declared in include/fg_hip.h but not exported"
-    assert lib.fg_abi_version() == 3
+    assert lib.fg_abi_version() == 4
 
 
 def test_product_never_touches_the_oracle():

@@ -35,7 +35,7 @@ def expect(oracle, raw: bytes, framing: str, final: bool):
 
 def check(host, oracle, raw: bytes, framing: str, final: bool, S: int, look: int, tile_cap: int, lines: int = 64):
     delim = 0x0A if framing == "line" else 0
-    for garbage in (delim, 0xC3):
+    for garbage in (delim, 0xC3, 0x80):
         gs, ge, gb, consumed, passes, scans = host.frame(raw, delim, final, S, look, tile_cap, lines, garbage)
         ws, we, wb = expect(oracle, raw, framing, final)
         ctx = f"S={S} look={look} lines={lines} final={final} framing={framing} len={len(raw)}"

@@ -1,0 +1,218 @@
+"""Round 6 GPU tests: FRAMING INSIDE THE DECODE KERNELS (flowgger_amd/csrc/fg_fused.hpp, fg_fuse.hpp; fg_frame_decode_device and the
+one-launch form of fg_frame_decode_batch) against the oracle -- its restatement of the splitters (fgo_frame; src/flowgger/splitter/
+line_splitter.rs:17-25, nul_splitter.rs:18-40) for the frames and the UTF-8 verdicts, its decoders for every frame's Record."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from flowgger_amd import GelfDecoder, LTSVDecoder, RFC5424Decoder, synth
+from flowgger_amd import _lib as L
+from flowgger_amd.tables import DeviceTables, HostTables
+from oracle_binding import Oracle
+
+pytestmark = pytest.mark.gpu
+
+RFC5424, LTSV, GELF = 0, 1, 2
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    return Oracle()
+
+
+def make_decoder(fmt):
+    if fmt == RFC5424:
+        return RFC5424Decoder(), None
+    if fmt == LTSV:
+        return LTSVDecoder(synth.LTSV_CONFIG), synth.LTSV_CONFIG
+    return GelfDecoder(), None
+
+
+def corpus(fmt, n, sd=False):
+    if fmt == RFC5424:
+        return synth.rfc5424_lines(n, cfg=4, sd=True) if sd else synth.rfc5424_lines(n, cfg=2)
+    if fmt == LTSV:
+        return synth.ltsv_lines(n)
+    return synth.gelf_lines(n)
+
+
+def stream_of(lines, framing, crlf_every=0, empty_every=0, damage_every=0, tail=b""):
+    term = b"\n" if framing == L.FG_FRAME_LINE else b"\0"
+    out = bytearray()
+    for i, ln in enumerate(lines):
+        if framing == L.FG_FRAME_NUL:
+            ln = ln.replace(b"\0", b" ")
+        if damage_every and i % damage_every == damage_every - 1:
+            ln = ln[: len(ln) // 2] + bytes([(0x80, 0xC3, 0xE2, 0xF0, 0xFF)[i % 5]]) + ln[len(ln) // 2:]
+        out += ln
+        if crlf_every and framing == L.FG_FRAME_LINE and i % crlf_every == 0:
+            out += b"\r"
+        out += term
+        if empty_every and i % empty_every == 0:
+            out += term
+    return bytes(out + tail)
+
+
+def expected_frames(oracle, raw, framing, final):
+    starts, ends, valid = oracle.frame_arrays(np.frombuffer(raw + b"\0", np.uint8)[: len(raw)], "line" if framing == L.FG_FRAME_LINE else "nul")
+    term = 0x0A if framing == L.FG_FRAME_LINE else 0
+    if not final and len(ends) and int(ends[-1]) == len(raw) and (len(raw) == 0 or raw[-1] != term):
+        starts, ends, valid = starts[:-1], ends[:-1], valid[:-1]
+    return starts, ends, valid
+
+
+def strip(raw, s, e, framing):
+    body = raw[s:e]
+    if framing == L.FG_FRAME_LINE:
+        if body.endswith(b"\n"):
+            body = body[:-1]
+            if body.endswith(b"\r"):
+                body = body[:-1]
+    elif body.endswith(b"\0"):
+        body = body[:-1]
+    return body
+
+
+def check_rows(oracle, fmt, cfg, dec_cfg, raw, framing, starts, ends, valid, tab: HostTables, offs, i0=0):
+    """rows [i0, n) of `tab` (frame i = raw[offs[i] .. offs[i + 1])) against the oracle's decode of every valid frame"""
+    n = len(starts)
+    assert np.array_equal(offs[:n].astype(np.uint64), starts), f"frame starts differ at {int(np.flatnonzero(offs[:n] != starts)[0])}"
+    assert n == 0 or int(offs[n]) == int(ends[-1])
+    if n == i0:
+        return
+    data = np.frombuffer(raw + b"\0" * 32, np.uint8)
+    blob, boffs = tab.serialize(fmt, data, np.ascontiguousarray(offs[: n + 1], np.uint64), i0, n, cfg=dec_cfg)
+    st = tab.status[i0:n]
+    assert np.array_equal(st == L.FG_ST_BAD_UTF8, valid[i0:] == 0), "UTF-8 verdicts differ"
+    good = [strip(raw, int(starts[i]), int(ends[i]), framing) for i in range(i0, n) if valid[i]]
+    if not good:
+        return
+    gdata, goffs = synth.pack(good)
+    oblob, ooffs = oracle.decode_batch(fmt, gdata, goffs, cfg)
+    j = 0
+    for i in range(i0, n):
+        if not valid[i]:
+            continue
+        got = blob[int(boffs[i - i0]):int(boffs[i - i0 + 1])].tobytes()
+        want = oblob[int(ooffs[j]):int(ooffs[j + 1])].tobytes()
+        assert got == want, f"frame {i}: {good[j][:80]!r}\n  gpu    {got[:120]!r}\n  oracle {want[:120]!r}"
+        j += 1
+
+
+def run_device(dec, raw, framing, final, avg_line=0, cap=None):
+    import torch
+
+    dev = torch.device("cuda", dec.device)
+    padded = (len(raw) + 15) & ~15
+    host = np.full(padded + 16, 0x0A if framing == L.FG_FRAME_LINE else 0, np.uint8)  # what lies behind the stream is terminators on purpose
+    host[: len(raw)] = np.frombuffer(raw, np.uint8)
+    d_bytes = torch.from_numpy(host).to(dev)[: len(raw)]
+    cap = cap if cap is not None else len(raw) // 2 + 16
+    tables = DeviceTables(cap, len(raw) // 4 + 4096, dev)
+    d_off, d_res = dec.frame_decode_device(d_bytes, framing, tables, cap, final=final, avg_line=avg_line)
+    torch.cuda.synchronize(dev)
+    res = d_res.cpu().numpy()
+    assert int(res[1]) == 0, "the fused launch gave up"
+    n = int(res[0])
+    return tables, d_off.cpu().numpy().astype(np.uint64), n
+
+
+@pytest.mark.parametrize("fmt,sd", [(RFC5424, False), (RFC5424, True), (LTSV, False), (GELF, False)])
+@pytest.mark.parametrize("framing", [L.FG_FRAME_LINE, L.FG_FRAME_NUL])
+def test_fused_frame_decode_matches_the_oracle(oracle, fmt, sd, framing):
+    dec, cfg = make_decoder(fmt)
+    lines = corpus(fmt, 6000, sd)
+    for final, tail in ((True, b""), (True, b"an unterminated last piece"), (False, b"carried over \xe2\x82")):
+        raw = stream_of(lines, framing, crlf_every=7, empty_every=501, damage_every=97, tail=tail)
+        starts, ends, valid = expected_frames(oracle, raw, framing, final)
+        tables, offs, n = run_device(dec, raw, framing, final)
+        assert n == len(starts)
+        check_rows(oracle, fmt, cfg, dec._cfg, raw, framing, starts, ends, valid, tables.to_host(), offs)
+
+
+@pytest.mark.parametrize("fmt", [RFC5424, LTSV, GELF])
+def test_fused_geometries_that_do_not_fit_the_corpus(oracle, fmt):
+    """the launch planned for the wrong line length (tiles of many short lines: several lists and passes; tiles shorter than a line:
+    the forward scan and lines parsed from global memory), explicit tile / group overrides, tiny streams"""
+    dec, cfg = make_decoder(fmt)
+    lines = corpus(fmt, 3000)
+    raw = stream_of(lines, L.FG_FRAME_LINE, crlf_every=5, empty_every=3, damage_every=61)
+    starts, ends, valid = expected_frames(oracle, raw, L.FG_FRAME_LINE, True)
+    for avg in (16, 40, 700):
+        tables, offs, n = run_device(dec, raw, L.FG_FRAME_LINE, True, avg_line=avg)
+        assert n == len(starts), f"avg_line {avg}"
+        check_rows(oracle, fmt, cfg, dec._cfg, raw, L.FG_FRAME_LINE, starts, ends, valid, tables.to_host(), offs)
+    for opts in (dict(lines_per_group=3), dict(tile_cap=4096), dict(waves_per_cu=1), dict(lines_per_group=64, tile_cap=32768)):
+        dec.set_launch_opts(**opts)
+        tables, offs, n = run_device(dec, raw, L.FG_FRAME_LINE, True)
+        assert n == len(starts), str(opts)
+        check_rows(oracle, fmt, cfg, dec._cfg, raw, L.FG_FRAME_LINE, starts, ends, valid, tables.to_host(), offs)
+    dec.set_launch_opts()
+    for small in (lines[0] + b"\n", lines[0], b"\n", b"\n\n\n", lines[1] + b"\n" + lines[2]):
+        for final in (True, False):
+            starts, ends, valid = expected_frames(oracle, small, L.FG_FRAME_LINE, final)
+            tables, offs, n = run_device(dec, small, L.FG_FRAME_LINE, final)
+            assert n == len(starts), (small[:20], final)
+            check_rows(oracle, fmt, cfg, dec._cfg, small, L.FG_FRAME_LINE, starts, ends, valid, tables.to_host(), offs)
+
+
+def test_fused_many_tiles_row_indices(oracle):
+    """64 MB = several thousand tiles and dozens of look-back blocks: every frame start against the oracle's, the Ok count, and the rows
+    of a sample of the stream's far end record for record"""
+    dec, cfg = make_decoder(RFC5424)
+    lines = synth.rfc5424_lines(40_000, cfg=2)
+    raw = stream_of(lines, L.FG_FRAME_LINE, crlf_every=11) * 6
+    starts, ends, valid = expected_frames(oracle, raw, L.FG_FRAME_LINE, True)
+    tables, offs, n = run_device(dec, raw, L.FG_FRAME_LINE, True, cap=len(starts) + 64)
+    assert n == len(starts)
+    assert np.array_equal(offs[:n], starts) and int(offs[n]) == len(raw)
+    host = tables.to_host()
+    one = len(lines)
+    st = host.status[:n]
+    assert np.array_equal(st[:one], st[n - one:n])  # the replicas decode alike
+    check_rows(oracle, RFC5424, cfg, dec._cfg, raw, L.FG_FRAME_LINE, starts, ends, valid, host, offs, i0=n - 3000)
+
+
+def test_fused_table_too_small_reports_the_frame_count(oracle):
+    dec, cfg = make_decoder(RFC5424)
+    raw = stream_of(synth.rfc5424_lines(5000, cfg=2), L.FG_FRAME_LINE)
+    tables, offs, n = run_device(dec, raw, L.FG_FRAME_LINE, True, cap=1000)
+    assert n == 5000  # the rows beyond the capacity were not written; the caller runs again with more
+    starts, ends, valid = expected_frames(oracle, raw, L.FG_FRAME_LINE, True)
+    assert np.array_equal(offs[:1000], starts[:1000])
+
+
+@pytest.mark.parametrize("fmt", [RFC5424, LTSV, GELF])
+def test_frame_decode_batch_one_launch_from_pinned_memory(oracle, fmt):
+    """fg_frame_decode_batch with the raw chunk in PINNED memory: the one-launch form (the kernels read the chunk over the link and
+    write tables and offsets into pinned memory) against the oracle and against the sliced path of rounds 3-5"""
+    dec, cfg = make_decoder(fmt)
+    lib = L.lib()
+    lines = corpus(fmt, 20_000)
+    raw = stream_of(lines, L.FG_FRAME_LINE, crlf_every=9, empty_every=1001, damage_every=89, tail=b"tail without a terminator")
+    p = C.c_void_p()
+    L.check(lib.fg_alloc_pinned(len(raw) + 64, C.byref(p)), "fg_alloc_pinned")
+    try:
+        buf = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (len(raw) + 64,))
+        buf[:] = 0x0A
+        buf[: len(raw)] = np.frombuffer(raw, np.uint8)
+        for final in (True, False):
+            starts, ends, valid = expected_frames(oracle, raw, L.FG_FRAME_LINE, final)
+            for fused in (True, False):
+                dec.set_launch_opts(no_fused_framing=not fused)
+                st = L.fg_tables()
+                off = C.c_void_p()
+                nf, used = C.c_uint64(), C.c_uint64()
+                L.check(lib.fg_frame_decode_batch(dec._ctx, fmt, L.FG_FRAME_LINE, p, len(raw), int(final), C.byref(st), C.byref(off), C.byref(nf),
+                                                  C.byref(used)), "fg_frame_decode_batch")
+                n = int(nf.value)
+                assert n == len(starts), (final, fused)
+                assert int(used.value) == (int(ends[-1]) if n else 0)
+                offs = np.ctypeslib.as_array(C.cast(off, C.POINTER(C.c_uint64)), (n + 1,)).copy()
+                check_rows(oracle, fmt, cfg, dec._cfg, raw, L.FG_FRAME_LINE, starts, ends, valid, HostTables.from_struct(st), offs)
+    finally:
+        dec.set_launch_opts()
+        lib.fg_free_pinned(p)
