@@ -574,8 +574,8 @@ def bounded_leg(desc, fmt, lines, reps, dev, local, steps=5, warmup=2, D=None):
     if D is not None:  # the PCIe-inclusive entry points on this corpus too (pinned buffers: fg_decode_batch takes its zero-copy form)
         try:
             e = e2e_legs(D, R.dec, fmt, R.data, R.offsets, R.n_tile, R.tile_bytes, want_transcode=False, want_stream=True)
-            out["e2e"] = {k: {kk: e[k][kk] for kk in ("lines_per_s", "GBps_in", "ms", "frac_of_link_h2d", "what") if kk in e[k]}
-                          for k in ("decode_batch", "frame_decode_batch") if k in e and "lines_per_s" in e[k]}
+            out["e2e"] = {k: {kk: e[k][kk] for kk in ("lines_per_s", "GBps_in", "ms", "frac_of_link_h2d", "path", "what") if kk in e[k]}
+                          for k in ("decode_batch", "frame_decode_batch", "frame_decode_batch_two_step") if k in e and "lines_per_s" in e[k]}
             out["e2e"]["sample"] = e.get("sample")
         except AssertionError:
             raise

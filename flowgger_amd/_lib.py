@@ -74,7 +74,7 @@ class fg_encode_cfg(C.Structure):
 
 class fg_launch_opts(C.Structure):
     _fields_ = [("lines_per_group", C.c_uint32), ("tile_cap", C.c_uint32), ("waves_per_cu", C.c_uint32),
-                ("gelf_lds_budget", C.c_uint32), ("gelf_window_kib", C.c_uint32), ("flags", C.c_uint32), ("chunk_lines", C.c_uint32), ("ent_chunk", C.c_uint32)]
+                ("gelf_lds_budget", C.c_uint32), ("gelf_window_kib", C.c_uint32), ("flags", C.c_uint32), ("chunk_lines", C.c_uint32), ("ent_chunk", C.c_uint32), ("fused_look", C.c_uint32), ("fused_ext", C.c_uint32)]
 
 
 FG_LO_GELF_GENERIC, FG_LO_TRANSCODE_ONE_PIECE, FG_LO_NO_HEAD, FG_LO_FORCE_HEAD, FG_LO_SD_WALK, FG_LO_SD_PAIRS, FG_LO_NO_ZERO_COPY, FG_LO_FRAME_KERNEL_UPLOAD = 1, 2, 4, 8, 16, 32, 64, 128

@@ -42,6 +42,7 @@ struct FusedArgs {
     uint32_t delim4;            // the terminator byte in all four bytes of a dword
     uint32_t final_;            // nonzero: the stream ends with this chunk (an unterminated last piece is a frame)
     uint32_t lds_off;           // dynamic-LDS offset of the fused block (fuse::carve)
+    uint32_t ext;               // bytes staged on at a time behind the look-ahead (FusedGeom::ext)
     uint32_t counters;          // K (<= kFusedCounters, <= the grid)
     uint64_t cap;               // rows the tables hold; offsets holds cap + 2
     uint64_t* offsets;          // out: offsets[i] = start of frame i, offsets[total] = end of the last frame
@@ -409,7 +410,7 @@ __device__ __forceinline__ void fused_loop(const uint8_t* __restrict__ bytes, co
             FG_ST(4, 1);
             uint32_t carry = reinterpret_cast<const uint32_t*>(smem)[(g.span >> 2) - 1u];
             while (g.end_x == fuse::kUnresolved && g.span + 16u <= tile_cap) {
-                const uint32_t ext = tile_cap - g.span < 1024u ? tile_cap - g.span : 1024u;  // bytes of this row (a multiple of 16)
+                const uint32_t ext = tile_cap - g.span < fa.ext ? tile_cap - g.span : fa.ext;  // bytes of this row (a multiple of 16, <= 1024)
                 const uint64_t pos = g.base + g.span;                                        // (16-byte aligned, <= nbytes)
                 if (pos + ext > fa.nbytes) g.end_x = (uint32_t)(fa.nbytes - g.base);         // the stream ends inside this row
                 const uint32_t idx = (g.span >> 4) + lane;
@@ -597,6 +598,7 @@ inline int fused_prepare(K kernel, const FusedGeom& g, uint32_t base_lds, uint64
     fa->look = g.look;
     fa->delim4 = delim * 0x01010101u;
     fa->final_ = final_ ? 1u : 0u;
+    fa->ext = g.ext >= 16u && g.ext <= 1024u ? g.ext & ~15u : 1024u;
     fa->cap = cap;
     fa->offsets = d_offsets;
     fused_carve(scratch, nbytes, g.S, fa);

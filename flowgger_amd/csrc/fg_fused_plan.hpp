@@ -16,10 +16,11 @@ constexpr uint32_t kPreBytes = 16;  // (= fuse::kPre)
 // the tile's last line ends within it most of the time, else the wave reads on (fuse::forward_scan) and the line is parsed from global
 // memory.  Both bounded by the LDS tile: kPre + S + look + 16 <= tile_cap.
 struct TilePlan { uint32_t S, look; };
-inline TilePlan plan_tile(uint64_t avg_len, uint32_t lines, uint32_t tile_cap) {
+inline TilePlan plan_tile(uint64_t avg_len, uint32_t lines, uint32_t tile_cap, uint32_t look_override = 0) {
     if (avg_len < 16u) avg_len = 16u;
     uint64_t look = (avg_len + 63u) & ~63ull;
     if (look > 2048u) look = 2048u;
+    if (look_override) look = (look_override + 15u) & ~15u;  // (tuning: fg_launch_opts.fused_look)
     if (look + 1024u > tile_cap) look = 64u;
     // ... and room to stage ON when the last line runs past the look-ahead (fused_loop: a KiB at a time while the tile has room -- a line
     // that is not in the tile is parsed from global memory by one lane): a KiB, or another average line in a small tile
@@ -43,6 +44,7 @@ inline TilePlan plan_tile(uint64_t avg_len, uint32_t lines, uint32_t tile_cap) {
 struct FusedGeom {
     uint32_t S = 0, look = 0;  // tile bytes, look-ahead bytes
     uint32_t tile = 0;         // LDS tile bytes (a multiple of 1024, >= 16 + S + look + 16)
+    uint32_t ext = 1024;       // bytes staged on at a time when the tile's last line runs past the look-ahead (a multiple of 16, <= 1024)
     uint32_t L = 64;           // lines a pass of stage B takes
     uint32_t variant = 0;      // the format's kernel instantiation (RFC5424: 1 = pair-parallel structured data; GELF: 1 = the constant 3 KiB geometry)
     bool ok = false;           // false: this stream keeps the separate framing pass (long lines: head staging)
@@ -57,7 +59,9 @@ inline FusedGeom fused_geometry(fg_format fmt, uint64_t avg_len, const fg_launch
             if (head) return g;
             g.variant = ((lo.flags & FG_LO_SD_PAIRS) || (avg_len >= 320u && !(lo.flags & FG_LO_SD_WALK))) ? 1u : 0u;
             g.L = 64u;
-            bound = g.variant ? 12288u : 20480u;  // (the pair-parallel kernel's tile; else the register window)
+            // (the pair-parallel kernel's tile -- twice that across the link, where the grid is capped anyway and every byte of look-ahead
+            //  is read twice over the link: the input side of the link is the ceiling there, 48 GB/s --; else the register window)
+            bound = g.variant ? (link_bound ? 24576u : 12288u) : 20480u;
             break;
         case FG_LTSV:
             if (head) return g;
@@ -67,7 +71,7 @@ inline FusedGeom fused_geometry(fg_format fmt, uint64_t avg_len, const fg_launch
         case FG_GELF:
             // resident: eight lines to the pass (the row loop's geometry: more lines cost LDS, i.e. waves); across the link
             // the grid is capped anyway and the look-ahead is re-read over the link: thirty-two lines to the tile
-            g.L = link_bound ? 32u : 8u;
+            g.L = link_bound ? 48u : 8u;
             bound = link_bound ? 16384u : 8u * avg_len * 17u / 16u + 256u <= 3072u ? 3072u : 8192u;
             if (!link_bound && bound == 3072u && !lo.tile_cap && !lo.lines_per_group && !(lo.flags & FG_LO_GELF_GENERIC)) g.variant = 1u;
             break;
@@ -77,7 +81,9 @@ inline FusedGeom fused_geometry(fg_format fmt, uint64_t avg_len, const fg_launch
     if (lo.lines_per_group >= 1u && lo.lines_per_group <= 64u) g.L = lo.lines_per_group;
     if (lo.tile_cap >= 1024u && lo.tile_cap <= 57344u) bound = (lo.tile_cap + 1023u) / 1024u * 1024u;
     if (bound < 2048u) bound = 2048u;
-    const fuse::TilePlan tp = fuse::plan_tile(avg_len, g.L, bound);
+    if (link_bound) g.ext = 256u;  // (a KiB read on for a line that needed 150 bytes more is look-ahead too)
+    if (lo.fused_ext >= 16u && lo.fused_ext <= 1024u) g.ext = lo.fused_ext & ~15u;
+    const fuse::TilePlan tp = fuse::plan_tile(avg_len, g.L, bound, lo.fused_look <= 4096u ? lo.fused_look : 0u);
     g.S = tp.S;
     g.look = tp.look;
     // (the tile keeps the room plan_tile left for staging on: the LDS tile is the bound it planned with unless the lines are short)

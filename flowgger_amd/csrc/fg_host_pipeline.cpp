@@ -796,7 +796,7 @@ static int frame_decode_sliced(fg_ctx* ctx, fg_format fmt, fg_framing framing, c
 // look-back's bounded wait ran out): the caller takes the paths below.
 static int frame_decode_fused(fg_ctx* ctx, fg_format fmt, fg_framing framing, const uint8_t* bytes, uint64_t nbytes, int final, fg_tables* out,
                               const uint64_t** out_offsets, uint64_t* n_frames, uint64_t* consumed) {
-    if (nbytes == 0 || (ctx->lo.flags & (FG_LO_NO_FUSED_FRAMING | FG_LO_NO_ZERO_COPY | FG_LO_FRAME_CLASSIC | FG_LO_FRAME_SELFTEST_STALL))) return FG_ERR_UNSUPPORTED;
+    if (nbytes == 0 || (ctx->lo.flags & (FG_LO_NO_FUSED_FRAMING | FG_LO_NO_ZERO_COPY | FG_LO_FRAME_CLASSIC | FG_LO_FRAME_SELFTEST_STALL | FG_LO_FRAME_KERNEL_UPLOAD))) return FG_ERR_UNSUPPORTED;
     if (fmt != FG_RFC5424 && fmt != FG_LTSV && fmt != FG_GELF) return FG_ERR_UNSUPPORTED;
     const uint8_t* d_bytes = (const uint8_t*)device_view_of_pinned(bytes);
     if (!d_bytes || ((uintptr_t)d_bytes & 15u) != 0) return FG_ERR_UNSUPPORTED;
@@ -807,33 +807,41 @@ static int frame_decode_fused(fg_ctx* ctx, fg_format fmt, fg_framing framing, co
     }
     LinkBoundGrid grid(ctx);
     int rc;
-    const uint64_t cap = (uint64_t)((double)nbytes * ctx->frames_per_byte * 1.25) + 4096;
-    const uint64_t ent_cap0 = fmt == FG_RFC5424 ? nbytes / 16 + 1024 : nbytes / 8 + 1024;
-    const uint64_t ent_cap = ent_cap0 > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : ent_cap0;
-    uint64_t tab_bytes = 0;
-    carve(nullptr, cap, ent_cap, nullptr, &tab_bytes);
-    if ((rc = grow_pinned(ctx, (void**)&ctx->h_tab, &ctx->h_tab_cap, tab_bytes)) != FG_OK) return rc;
-    if ((rc = grow_pinned(ctx, (void**)&ctx->h_off, &ctx->h_off_cap, (cap + 2) * 8)) != FG_OK) return rc;
+    // tables from the ctx's experience (frames per byte of its last chunk) and one entry per 16 / 8 input bytes; a chunk that holds more
+    // of either says how many, and the launch is repeated ONCE PER TABLE with what it needs (another pass over the link -- the price
+    // of the older forms' count-first as well -- and the next chunk is sized from this one)
+    uint64_t cap = (uint64_t)((double)nbytes * ctx->frames_per_byte * 1.25) + 4096;
+    uint64_t ent_cap = fmt == FG_RFC5424 ? nbytes / 16 + 1024 : nbytes / 8 + 1024;
     if (!ctx->h_cnt) FG_HIP(ctx, hipHostMalloc((void**)&ctx->h_cnt, 65536, hipHostMallocDefault));
-    fg_tables ht, kt;
-    carve(ctx->h_tab, cap, ent_cap, &ht, nullptr);
-    if ((rc = pinned_tables_for_kernels(ctx, ht, &kt)) != FG_OK) return rc;
-    uint64_t* const off_dv = (uint64_t*)const_cast<void*>(device_view_of_pinned(ctx->h_off));
-    if (!off_dv) return FG_ERR_UNSUPPORTED;
     const hipStream_t s = ctx->stream;
-    unsigned long long* d_total = nullptr;
-    if ((rc = fg_frame_decode_impl(ctx, fmt, framing, d_bytes, nbytes, final, off_dv, cap, &kt, 0, (void*)s, &d_total)) != FG_OK) return rc;
-    uint64_t* const res = ctx->h_cnt + 2048;  // [0] frames [1] abort [2] entries
-    FG_HIP(ctx, hipMemcpyAsync(res, d_total, 16, hipMemcpyDeviceToHost, s));
-    FG_HIP(ctx, hipMemcpyAsync(res + 2, kt.ent_used, 8, hipMemcpyDeviceToHost, s));
-    FG_HIP(ctx, hipStreamSynchronize(s));
-    const uint64_t total = res[0], used = res[2];
-    if (res[1] != 0) return FG_ERR_UNSUPPORTED;  // (the look-back's bounded wait ran out: never seen)
-    if (total > cap) {                          // more frames than the ctx's experience said: the next chunk is sized from this one
-        ctx->frames_per_byte = (double)(total + 1) / (double)nbytes;
-        return FG_ERR_UNSUPPORTED;
+    fg_tables ht;
+    uint64_t total = 0, used = 0;
+    for (int attempt = 0;; ++attempt) {
+        if (ent_cap > 0xFFFFFFF0ull) ent_cap = 0xFFFFFFF0ull;
+        uint64_t tab_bytes = 0;
+        carve(nullptr, cap, ent_cap, nullptr, &tab_bytes);
+        if ((rc = grow_pinned(ctx, (void**)&ctx->h_tab, &ctx->h_tab_cap, tab_bytes)) != FG_OK) return rc;
+        if ((rc = grow_pinned(ctx, (void**)&ctx->h_off, &ctx->h_off_cap, (cap + 2) * 8)) != FG_OK) return rc;
+        fg_tables kt;
+        carve(ctx->h_tab, cap, ent_cap, &ht, nullptr);
+        if ((rc = pinned_tables_for_kernels(ctx, ht, &kt)) != FG_OK) return rc;
+        uint64_t* const off_dv = (uint64_t*)const_cast<void*>(device_view_of_pinned(ctx->h_off));
+        if (!off_dv) return FG_ERR_UNSUPPORTED;
+        unsigned long long* d_total = nullptr;
+        if ((rc = fg_frame_decode_impl(ctx, fmt, framing, d_bytes, nbytes, final, off_dv, cap, &kt, 0, (void*)s, &d_total)) != FG_OK) return rc;
+        uint64_t* const res = ctx->h_cnt + 2048;  // [0] frames [1] abort [2] entries
+        FG_HIP(ctx, hipMemcpyAsync(res, d_total, 16, hipMemcpyDeviceToHost, s));
+        FG_HIP(ctx, hipMemcpyAsync(res + 2, kt.ent_used, 8, hipMemcpyDeviceToHost, s));
+        FG_HIP(ctx, hipStreamSynchronize(s));
+        total = res[0], used = res[2];
+        if (res[1] != 0) return FG_ERR_UNSUPPORTED;  // (the look-back's bounded wait ran out: never seen)
+        const bool rows_short = total > cap, ents_short = used > ent_cap;
+        if (!rows_short && !ents_short) break;
+        if (rows_short) ctx->frames_per_byte = (double)(total + 1) / (double)nbytes;
+        if (attempt >= 2 || (ents_short && ent_cap >= 0xFFFFFFF0ull)) return FG_ERR_UNSUPPORTED;
+        if (rows_short) cap = total + total / 16 + 1024;
+        if (ents_short) ent_cap = used + used / 8 + 1024;  // (rows beyond the old capacity had no entries yet: a third launch may follow)
     }
-    if (used > ent_cap) return FG_ERR_UNSUPPORTED;
     if (total && nbytes >= (1u << 20)) ctx->frames_per_byte = (double)total / (double)nbytes;
     *n_frames = total;
     ctx->last_host_path = FG_PATH_FRAME_FUSED;

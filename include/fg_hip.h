@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FG_ABI_VERSION 4 /* 4 (round 6): fg_frame_decode_device (framing inside the decode kernels), FG_LO_NO_FUSED_FRAMING; 3 (round 5): fg_launch_opts.ent_chunk (the struct grew), FG_LO_STATIC_CHUNKS / _FRAME_SELFTEST_STALL, fg_ticket_ring_check; 2 (round 4): FG_YEAR_NOW = INT32_MIN, FG_F_LTSV_NOVALUE and the failed-LTSV-row count, ent_used = RESERVED slots, fg_calibrate_device */
+#define FG_ABI_VERSION 4 /* 4 (round 6): fg_frame_decode_device (framing inside the decode kernels), FG_LO_NO_FUSED_FRAMING, fg_launch_opts.fused_look / fused_ext (the struct grew), fg_last_host_path; 3 (round 5): fg_launch_opts.ent_chunk (the struct grew), FG_LO_STATIC_CHUNKS / _FRAME_SELFTEST_STALL, fg_ticket_ring_check; 2 (round 4): FG_YEAR_NOW = INT32_MIN, FG_F_LTSV_NOVALUE and the failed-LTSV-row count, ent_used = RESERVED slots, fg_calibrate_device */
 
 typedef enum fg_format { FG_RFC5424 = 0, FG_LTSV = 1, FG_GELF = 2, FG_RFC3164 = 3 } fg_format;
 
@@ -195,6 +195,9 @@ typedef struct fg_launch_opts {
     uint32_t ent_chunk;       /* entry slots a wave reserves from the table's counter at a time: 1 = exactly what each request needs,
                                  >= 2 = that many (tuning: fewer atomics on the one counter word against slots stranded at the end of
                                  every wave's last reservation) */
+    uint32_t fused_look;      /* fused frame + decode launches (fg_frame_decode_device): bytes staged behind a tile, where its last line ends
+                                 (a multiple of 16; the library's own choice: one average line) */
+    uint32_t fused_ext;       /* ... bytes staged ON at a time when that line runs past them (a multiple of 16, at most 1024) */
 } fg_launch_opts;
 enum {
     FG_LO_GELF_GENERIC = 1,        /* GELF: the run-time-geometry kernel even where the constant-geometry instantiation applies */

@@ -250,3 +250,46 @@ extern "C" int fg_launch_frame_slice(const uint8_t* d_bytes, uint64_t nbytes, ui
     }
     return frame_blocks_fake(d_bytes, nbytes, delim, scratch, d_offsets, d_bad, cap, blk0, blk1, d_total_out);
 }
+
+// ---- the fused launches (fg_fused.hpp): frame + decode of a raw chunk in one "kernel".  The real contract: offsets[i] = start of frame
+//      i, offsets[frames] = end of the last frame; rows and offsets only below `cap`; an unterminated tail is a frame iff `final`;
+//      the two result words = frames (may exceed cap), abort flag.
+int g_fused_abort_left = 0;
+extern "C" void fake_fused_abort_next(int n) { g_fused_abort_left = n; }
+static int fake_fused(const uint8_t* b, uint64_t nbytes, const fg::DevTables* t, uint32_t strip, int final_, uint64_t* d_offsets, uint64_t cap,
+                      uint8_t* scratch, unsigned long long** d_total) {
+    unsigned long long* total = reinterpret_cast<unsigned long long*>(scratch);
+    *d_total = total;
+    total[0] = total[1] = 0;
+    if (g_fused_abort_left > 0) {
+        --g_fused_abort_left;
+        total[1] = 1;
+        return 0;
+    }
+    const uint8_t delim = strip == FG_FRAME_LINE ? 0x0A : 0x00;
+    std::vector<uint64_t> offs{0};
+    for (uint64_t p = 0; p < nbytes; ++p)
+        if (b[p] == delim) offs.push_back(p + 1);
+    if (offs.back() != nbytes && final_) offs.push_back(nbytes);
+    const uint64_t n = offs.size() - 1;
+    total[0] = n;
+    const uint64_t rows = n < cap ? n : cap;
+    std::vector<uint8_t> bad(rows + 1, 0);
+    for (uint64_t i = 0; i < rows; ++i)
+        for (uint64_t p = offs[i]; p < offs[i + 1]; ++p) bad[i] |= b[p] >= 0xF8u;
+    for (uint64_t i = 0; i <= n && i <= cap + 1; ++i) d_offsets[i] = offs[i];
+    fg::DevTables tt = *t;
+    return fake_decode(b, offs.data(), rows, &tt, strip, bad.data());
+}
+extern "C" int fg_launch_rfc5424_fused(const uint8_t* b, uint64_t nbytes, const fg::DevTables* t, const fg::FusedGeom*, hipStream_t, uint64_t*, uint32_t,
+                                       uint32_t strip, int final_, uint64_t* d_offsets, uint64_t cap, uint8_t* scratch, const fg_launch_opts*,
+                                       unsigned long long** d_total) { return fake_fused(b, nbytes, t, strip, final_, d_offsets, cap, scratch, d_total); }
+extern "C" int fg_launch_ltsv_fused(const uint8_t* b, uint64_t nbytes, const fg::DevTables* t, const fg::LtsvDevCfg*, const fg::FusedGeom*, hipStream_t, uint64_t*,
+                                    uint32_t, uint32_t strip, int final_, uint64_t* d_offsets, uint64_t cap, uint8_t* scratch, const fg_launch_opts*,
+                                    unsigned long long** d_total) { return fake_fused(b, nbytes, t, strip, final_, d_offsets, cap, scratch, d_total); }
+extern "C" int fg_launch_gelf_fused(const uint8_t* b, uint64_t nbytes, const fg::DevTables* t, const fg::FusedGeom*, hipStream_t, uint32_t strip, int final_,
+                                    uint64_t* d_offsets, uint64_t cap, uint8_t* scratch, const fg_launch_opts*, unsigned long long** d_total) {
+    return fake_fused(b, nbytes, t, strip, final_, d_offsets, cap, scratch, d_total);
+}
+extern "C" int fg_launch_gelf_general_dev(const uint8_t*, const uint64_t*, uint64_t, const fg::DevTables*, hipStream_t, uint32_t, const uint8_t*,
+                                          const unsigned long long*) { return 0; }

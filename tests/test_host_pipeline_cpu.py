@@ -17,7 +17,7 @@ ROOT = Path(__file__).resolve().parent.parent
 HERE = ROOT / "tests" / "native"
 LIB = HERE / "libhost_pipeline_fake.so"
 SRC = [HERE / "host_pipeline_fake.cpp", HERE / "fakehip/hip/hip_runtime.h"] + [ROOT / "flowgger_amd/csrc" / f for f in
-                                                                                ("fg_capi.cpp", "fg_host_pipeline.cpp", "fg_ctx.hpp", "fg_tile_cap.hpp", "fg_gather.cpp", "fg_materialize.cpp")] + [ROOT / "include/fg_hip.h"]
+                                                                                ("fg_capi.cpp", "fg_host_pipeline.cpp", "fg_ctx.hpp", "fg_fused_plan.hpp", "fg_tile_cap.hpp", "fg_gather.cpp", "fg_materialize.cpp")] + [ROOT / "include/fg_hip.h"]
 u64, vp = C.c_uint64, C.c_void_p
 COLS = ["meta", "ts", "hostname", "appname", "procid", "msgid", "msg", "full_msg", "ent_count"]
 
@@ -337,6 +337,70 @@ def test_a_pinned_raw_stream_is_uploaded_by_the_framing_scan_itself(fake):
     (a, ao, ac, an), (b, bo, bc, bn) = res[True], res[False]
     assert an == bn == len(lines) + 1 and ac == bc == raw.size and np.array_equal(ao, bo)
     same_lines(a, b, an)
+    fake.fg_free_pinned(pb)
+
+
+def test_a_pinned_raw_stream_is_framed_and_decoded_by_one_launch(fake):
+    """round 6: a raw chunk in pinned memory is ONE launch -- the decode kernel frames it itself (fg_fused.hpp) and writes rows, entries
+    and frame offsets into pinned memory: no byte of the stream and no table byte crosses by hipMemcpy.  Same result as the pageable
+    chunk through the older forms, final or not; a table estimate that was too small and a look-back that gave up both fall back,
+    and the next chunk is sized from the first."""
+    rng = np.random.default_rng(9)
+    lines = corpus(60_000, rng)
+    raw = np.frombuffer(b"".join(ln + b"\n" for ln in lines) + b"<1>unterminated tail a=1", np.uint8).copy()
+    fake.fg_alloc_pinned.argtypes = [u64, C.POINTER(vp)]
+    fake.fg_free_pinned.argtypes = [vp]
+    fake.fg_last_host_path.argtypes = [vp]
+    pb = vp()
+    assert fake.fg_alloc_pinned(raw.size + 64, C.byref(pb)) == 0
+    hb = np.ctypeslib.as_array(C.cast(pb, C.POINTER(C.c_uint8)), (raw.size + 64,))
+    hb[:] = 0x0A  # (what lies behind the chunk is the caller's: terminators, on purpose)
+    hb[:raw.size] = raw
+    pad = np.concatenate([raw, np.zeros(64, np.uint8)])
+    cnt = (C.c_ulonglong * 3)()
+
+    def call(c, src, final):
+        st, po, nf, cons = L.fg_tables(), vp(), u64(), u64()
+        fake.fgf_launches(1)
+        fake.fgf_counters(cnt, 1)
+        assert fake.fg_frame_decode_batch(c.h, 0, 1, src, raw.size, final, C.byref(st), C.byref(po), C.byref(nf), C.byref(cons)) == 0
+        fake.fgf_counters(cnt, 1)
+        n = int(nf.value)
+        offs = np.ctypeslib.as_array(C.cast(po, C.POINTER(C.c_uint64)), (n + 1,)).copy()
+        return snapshot(st, n), offs, int(cons.value), n, int(fake.fgf_launches(1)), int(fake.fg_last_host_path(c.h)), int(cnt[1]), int(cnt[2])
+
+    for final in (1, 0):
+        c = Ctx(fake)
+        a, ao, ac, an, launches, path, h2d, d2h = call(c, pb, final)   # one launch, nothing copied but a few counters
+        assert path == L.FG_PATH_FRAME_FUSED and launches == 1 and h2d < 4096 and d2h < 4096, (path, launches, h2d, d2h)
+        b, bo, bc, bn, _, pathb, h2d_b, _ = call(c, pad.ctypes.data, final)   # pageable: the older forms
+        assert pathb != L.FG_PATH_FRAME_FUSED and h2d_b >= raw.size
+        assert an == bn == len(lines) + (1 if final else 0) and ac == bc and np.array_equal(ao, bo)
+        assert ac == (raw.size if final else raw.size - len(b"<1>unterminated tail a=1"))
+        same_lines(a, b, an)
+        # a look-back that gives up (bounded wait): the call comes back through the older form with the same result
+        fake.fake_fused_abort_next(1)
+        d, do, dc, dn, _, pathd, _, _ = call(c, pb, final)
+        assert pathd != L.FG_PATH_FRAME_FUSED and dn == an and np.array_equal(do, ao)
+        same_lines(a, d, an)
+        c.close()
+    # a ctx that has seen no chunk sizes its tables for one frame per 200 bytes and one entry per 16: a chunk of three-byte lines with an
+    # entry each fits neither -> the launch says what it holds and is repeated with that (once per table); the NEXT chunk is sized from
+    # this one: one launch
+    short = np.frombuffer(b"a=\n" * 700_000, np.uint8)
+    hb[:short.size] = short
+    c = Ctx(fake)
+    got = []
+    for _ in range(2):
+        st, po, nf, cons = L.fg_tables(), vp(), u64(), u64()
+        fake.fgf_launches(1)
+        assert fake.fg_frame_decode_batch(c.h, 0, 1, pb, short.size, 1, C.byref(st), C.byref(po), C.byref(nf), C.byref(cons)) == 0
+        got.append((int(nf.value), int(cons.value), int(fake.fg_last_host_path(c.h)), snapshot(st, int(nf.value)), int(fake.fgf_launches(1))))
+    assert got[0][:3] == got[1][:3] == (700_000, short.size, L.FG_PATH_FRAME_FUSED)
+    assert got[0][4] == 3 and got[1][4] == 2, (got[0][4], got[1][4])  # rows, then entries; then only the entries (one per 3 bytes, not per 16)
+    same_lines(got[0][3], got[1][3], 700_000)
+    assert got[1][3]["used"] == 700_000
+    c.close()
     fake.fg_free_pinned(pb)
 
 
