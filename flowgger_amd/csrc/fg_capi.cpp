@@ -439,6 +439,7 @@ int fg_decode_frames_impl(fg_ctx* ctx, fg_format fmt, fg_framing framing, const 
         FG_HIP(ctx, hipMalloc((void**)&ctx->d_pending, kPendingRing * sizeof(uint32_t)));
         FG_HIP(ctx, hipMemset(ctx->d_pending, 0, kPendingRing * sizeof(uint32_t)));
     }
+    dt.shares = ctx->table_shares ? ctx->table_shares : 1u;
     fg_launch_opts lo_call = ctx->lo;
     if (ctx->link_bound_waves && lo_call.waves_per_cu == 0) lo_call.waves_per_cu = ctx->link_bound_waves;
     if (ctx->defer_general && fmt == FG_GELF) {
@@ -493,6 +494,11 @@ int fg_decode_frames_impl(fg_ctx* ctx, fg_format fmt, fg_framing framing, const 
             return FG_ERR_UNSUPPORTED;
     }
     if (rc != 0) {
+        // The launcher has already moved the host's copy of the launch's ticket word on (take_tickets) and the kernel that would have drawn
+        // those tickets did not run: word and copy would differ for good, and every later launch on this slot of the ring would compute
+        // chunk indices from a wrong base -- rows silently left undecoded.  Both go back to zero, behind whatever is queued.
+        (void)hipMemsetAsync(ctx->d_ticket + tslot, 0, sizeof(uint32_t), s);
+        ctx->h_ticket[tslot] = 0u;
         ctx->last_hip = rc;
         return FG_ERR_HIP;
     }
@@ -628,6 +634,7 @@ int encode_device_impl(fg_ctx* ctx, fg_format src_fmt, const fg_encode_cfg* ecfg
     if (async && !d_out) return FG_ERR_ARG;
     if ((int)src_fmt < 0 || (int)src_fmt > (int)FG_RFC3164) return FG_ERR_ARG;
     if (tables->n < n) return FG_ERR_ARG;
+    if (((uintptr_t)d_bytes & 15u) != 0) return FG_ERR_ARG;  // (the emitters' global reader loads aligned 16-byte chunks: as the decoders require)
     DeviceGuard g(ctx->device);
     hipStream_t s = stream == FG_STREAM_OWN ? ctx->stream : (hipStream_t)stream;
     if (total) *total = 0;

@@ -101,6 +101,7 @@ struct fg_ctx {
     fg_launch_opts lo{};  // launch-geometry overrides (fg_set_launch_opts); all zero = the library's own choices
     uint32_t link_bound_waves = 0;  // host pipelines whose tables lie across the link: waves per CU of the decode grid for the duration of
                                     // a call, where the caller's options leave the choice to the library (fg_host_pipeline.cpp LinkBoundGrid)
+    uint32_t table_shares = 0;  // a sliced host path: the launches of the batch that share one entry table (fg::entry_chunk), else 0
     int last_host_path = 0;  // fg_last_host_path: which form the last host-buffer decode call took (FG_PATH_*)
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -251,6 +252,7 @@ fg::DevTables to_dev(const fg_tables& t) {
     d.pending = nullptr;
     d.epoch = 0;
     d.alloc_chunk = 0;
+    d.shares = 1;
     return d;
 }
 

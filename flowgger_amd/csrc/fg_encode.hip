@@ -13,10 +13,14 @@
 // Input: the 64 lines of a workgroup are one contiguous byte range, staged into LDS with coalesced 16-byte loads; every
 // HBM input of a lane (its offsets, its table row, its output slot) and the configuration mirror are requested BEFORE
 // the tile so that one round trip covers them all (stage_tile_rider).  Spans without bytes that need escaping move
-// sixteen bytes per LDS round trip (SWAR test per dword, fg_emit.hpp); the write sink packs the byte stream into
-// aligned dword stores (emit::PackSink).  Output stores are per lane (each lane streams into its own message).
-// Measured: the kernels are latency-bound at two waves per SIMD (the LDS tile is the occupancy
-// limit); 16-byte output stores were slower than dword stores, a cheaper sink accumulator changed nothing.
+// sixteen bytes per LDS round trip (SWAR test per dword, fg_emit.hpp); the write sink assembles the byte stream into
+// aligned SIXTEEN-byte blocks (emit::PackSink, round 5: a message's first and last block go out by dwords and bytes so that
+// nothing outside the message is touched; rounds 1-4 packed dwords).  Output stores are per lane (each lane streams into its
+// own message): per-lane 16-byte stores run at 3.0 TB/s against 0.92 TB/s for per-lane dword stores and 4.9 TB/s fully
+// coalesced (tools/probe/store_patterns.cpp, profiles/r05c_store_patterns.log).  Measured (DESIGN.md sections 3.5, 4.0): the
+// kernels run at two waves per SIMD (the LDS tile is the occupancy limit); a message goes out as ~45 pieces of up to sixteen
+// bytes (round 5; 108 before), and what reaches HBM is 1.68x the message's bytes -- emitting once, wave-cooperatively, is what
+// is left.
 #include "fg_device.hpp"
 #include "fg_emit.hpp"
 

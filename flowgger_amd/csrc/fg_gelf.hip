@@ -764,7 +764,7 @@ template <int NB>
 int launch_gelf_fast(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t, uint64_t avg_len,
                      hipStream_t stream, uint32_t max_lines, fg::FrameArgs fr, const fg_launch_opts& lo, fg::TicketSlot* tk) {
     fg::LaunchPlan p;
-    if (fg::plan_launch(fg::k_gelf<NB, false>, n, avg_len, 0u, 40960u, 0u, &p, lo, max_lines, fg::GelfFormat::kClasses, fg::gelf_extra_lds))
+    if (fg::plan_launch(fg::k_gelf<NB, false>, n, avg_len, 0u, 40960u, 0u, &p, lo, fg::PlanFormat().lines(max_lines).classes(fg::GelfFormat::kClasses).lds_for(fg::gelf_extra_lds)))
         return -1;
     dim3 grid(p.blocks), block(fg::kWave);
     fg::DevTables tt = *t;
@@ -783,17 +783,18 @@ int launch_gelf_fast(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t
                 // (chunks of 64 lines = eight tiles, drawn by ticket: 4 M lines 1878-1886 M lines/s against 1805-1813 at 128, 1866-1870 at 48 / 96;
                 //  16 M lines 2051 against 2012 at 128 and 2003 at 256 -- one box, alternated, profiles/r05u_chunk_taper_sweep.log;
                 //  tickets from four chunks per wave on: at three -- 1 M lines -- one share per wave is as fast, profiles/r05v_policy_ab.log)
-                if (fg::plan_launch(fg::k_gelf<NB, false, 5, 3072u, 8u>, n, avg_len, 0u, 40960u, 0u, &p, lo3, max_lines,
-                                    fg::GelfFormat::kClasses, fg::gelf_extra_lds, nullptr, 0u, 64u, 4u) || p.tile != 3072u || p.L != 8u)
+                if (fg::plan_launch(fg::k_gelf<NB, false, 5, 3072u, 8u>, n, avg_len, 0u, 40960u, 0u, &p, lo3,
+                                    fg::PlanFormat().lines(max_lines).classes(fg::GelfFormat::kClasses).lds_for(fg::gelf_extra_lds).chunk(64u).tickets_from(4u)) ||
+                    p.tile != 3072u || p.L != 8u)
                     return -1;
                 fg::take_tickets(&fr, tk, p);
-    tt.alloc_chunk = fg::entry_chunk(tt.ent_cap, p.blocks, n, lo);
+    tt.alloc_chunk = fg::entry_chunk(tt.ent_cap, p.blocks, n, lo, tt.shares);
                 hipLaunchKernelGGL((fg::k_gelf<NB, false, 5, 3072u, 8u>), dim3(p.blocks), block, p.lds, stream, d_bytes, d_offsets, n, tt,
                                    p.tile, p.L, p.chunk, (unsigned long long*)nullptr, (uint64_t*)nullptr, fr);
                 return 0;
             }
             fg::take_tickets(&fr, tk, p);
-    tt.alloc_chunk = fg::entry_chunk(tt.ent_cap, p.blocks, n, lo);
+    tt.alloc_chunk = fg::entry_chunk(tt.ent_cap, p.blocks, n, lo, tt.shares);
             hipLaunchKernelGGL((fg::k_gelf<NB, false, 4, 4096u, 8u>), grid, block, p.lds, stream, d_bytes, d_offsets, n, tt, p.tile, p.L,
                                p.chunk, (unsigned long long*)nullptr, (uint64_t*)nullptr, fr);
             return 0;
@@ -803,7 +804,7 @@ int launch_gelf_fast(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t
     if (fg::prof_requested()) {
         fg::ProfRun pr;
         if (!pr.begin(stream)) return -1;
-        tt.alloc_chunk = fg::entry_chunk(tt.ent_cap, p.blocks, n, lo);
+        tt.alloc_chunk = fg::entry_chunk(tt.ent_cap, p.blocks, n, lo, tt.shares);
         hipLaunchKernelGGL((fg::k_gelf<NB, true>), grid, block, p.lds, stream, d_bytes, d_offsets, n, tt, p.tile, p.L, p.chunk, pr.d,
                            (uint64_t*)nullptr, fr);
         pr.end(stream, "gelf", p);
@@ -811,7 +812,7 @@ int launch_gelf_fast(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t
     }
 #endif
     fg::take_tickets(&fr, tk, p);
-    tt.alloc_chunk = fg::entry_chunk(tt.ent_cap, p.blocks, n, lo);
+    tt.alloc_chunk = fg::entry_chunk(tt.ent_cap, p.blocks, n, lo, tt.shares);
     hipLaunchKernelGGL((fg::k_gelf<NB, false>), grid, block, p.lds, stream, d_bytes, d_offsets, n, tt, p.tile, p.L, p.chunk,
                        (unsigned long long*)nullptr, (uint64_t*)nullptr, fr);
     return 0;
@@ -838,14 +839,14 @@ extern "C" int fg_launch_gelf(const uint8_t* d_bytes, const uint64_t* d_offsets,
     if (lo.lines_per_group) max_lines = lo.lines_per_group;
     else {
         while (max_lines > 4u) {
-            if (fg::plan_launch(fg::k_gelf<2, false>, n, avg_len, 0u, 40960u, 0u, &p, lo, max_lines, fg::GelfFormat::kClasses, fg::gelf_extra_lds))
+            if (fg::plan_launch(fg::k_gelf<2, false>, n, avg_len, 0u, 40960u, 0u, &p, lo, fg::PlanFormat().lines(max_lines).classes(fg::GelfFormat::kClasses).lds_for(fg::gelf_extra_lds)))
                 return -1;
             if (p.L < max_lines) max_lines = p.L;  // (the geometry already settled on fewer lines)
             if (p.lds <= lds_budget) break;
             max_lines >>= 1;
         }
     }
-    if (fg::plan_launch(fg::k_gelf<2, false>, n, avg_len, 0u, 40960u, 0u, &p, lo, max_lines, fg::GelfFormat::kClasses, fg::gelf_extra_lds))
+    if (fg::plan_launch(fg::k_gelf<2, false>, n, avg_len, 0u, 40960u, 0u, &p, lo, fg::PlanFormat().lines(max_lines).classes(fg::GelfFormat::kClasses).lds_for(fg::gelf_extra_lds)))
         return -1;
     // The register window should hold the whole average group: what lies beyond it is staged by plain loads whose latency
     // nothing hides (and four chunks at a time).  1 KiB of window = 4 registers.
@@ -908,7 +909,7 @@ extern "C" int fg_launch_gelf_fused(const uint8_t* d_bytes, uint64_t nbytes, con
                                               &blocks);
     if (prc) return -1;
     fg::DevTables tt = *t;
-    tt.alloc_chunk = fg::entry_chunk(tt.ent_cap, blocks, nbytes / (g->S / g->L ? g->S / g->L : 1u) + 1u, *lo);
+    tt.alloc_chunk = fg::entry_chunk(tt.ent_cap, blocks, nbytes / (g->S / g->L ? g->S / g->L : 1u) + 1u, *lo, tt.shares);
     *d_total = fa.total;
     if (konst)
         hipLaunchKernelGGL((fg::k_gelf_fused<3, 4, 3072u, 8u>), dim3(blocks), dim3(fg::kWave), lds, stream, d_bytes, tt, g->tile, g->L, fa, strip);

@@ -38,6 +38,8 @@ int fg_alloc_pinned(uint64_t bytes, void** out) {
     *out = nullptr;
     const uint64_t need = up(bytes ? bytes : 1, 64u << 10);
     PinnedPool& P = pinned_pool();
+    std::vector<void*> evict;  // idle blocks to unpin, once the lock is released
+    bool pageable = false;
     {
         std::lock_guard<std::mutex> g(P.mu);
         auto it = P.idle.lower_bound(need);
@@ -51,24 +53,28 @@ int fg_alloc_pinned(uint64_t bytes, void** out) {
             return FG_OK;
         }
         if (P.pinned_bytes + need > P.limit) {
-            // over the cap: what is idle goes first, then pageable memory
+            // over the cap: what is idle goes first (unpinned BEHIND the lock: hipHostFree is a millisecond-scale call, and every connection
+            // thread's alloc / free waits on this mutex -- ADVICE r5), then pageable memory
             while (!P.idle.empty() && P.pinned_bytes + need > P.limit) {
                 auto last = std::prev(P.idle.end());
-                (void)hipHostFree(last->second);
+                evict.push_back(last->second);
                 P.pinned_bytes -= last->first;
                 P.idle_bytes -= last->first;
                 P.idle.erase(last);
             }
             if (P.pinned_bytes + need > P.limit) {
                 void* p = aligned_alloc(4096, (size_t)need);
-                if (!p) return FG_ERR_NOMEM;
-                P.live[p] = {need, false};
-                *out = p;
-                return FG_OK;
+                if (p) {
+                    P.live[p] = {need, false};
+                    *out = p;
+                }
+                pageable = true;
             }
         }
-        P.pinned_bytes += need;  // (reserved before the slow call, outside the lock)
+        if (!pageable) P.pinned_bytes += need;  // (reserved before the slow call, outside the lock)
     }
+    for (void* e : evict) (void)hipHostFree(e);
+    if (pageable) return *out ? FG_OK : FG_ERR_NOMEM;
     void* p = nullptr;
     if (hipHostMalloc(&p, need, hipHostMallocDefault) != hipSuccess || !p) {
         (void)hipGetLastError();
@@ -108,17 +114,29 @@ void fg_free_pinned(void* p) {
 }
 int fg_set_pinned_limits(uint64_t total_bytes, uint64_t idle_bytes) {
     PinnedPool& P = pinned_pool();
-    std::lock_guard<std::mutex> g(P.mu);
-    P.limit = total_bytes;
-    P.idle_limit = idle_bytes;
-    while (!P.idle.empty() && P.idle_bytes > P.idle_limit) {
-        auto last = std::prev(P.idle.end());
-        (void)hipHostFree(last->second);
-        P.pinned_bytes -= last->first;
-        P.idle_bytes -= last->first;
-        P.idle.erase(last);
+    std::vector<void*> evict;
+    {
+        std::lock_guard<std::mutex> g(P.mu);
+        P.limit = total_bytes;
+        P.idle_limit = idle_bytes;
+        while (!P.idle.empty() && P.idle_bytes > P.idle_limit) {
+            auto last = std::prev(P.idle.end());
+            evict.push_back(last->second);
+            P.pinned_bytes -= last->first;
+            P.idle_bytes -= last->first;
+            P.idle.erase(last);
+        }
     }
+    for (void* e : evict) (void)hipHostFree(e);  // (behind the lock)
     return FG_OK;
+}
+// 1: p is a block of this allocator that is page-locked; 0: one that fell back to pageable memory (the cap was reached: zero-copy and
+// link-speed uploads do not apply to it); -1: not a block of this allocator
+int fg_is_pinned(const void* p) {
+    PinnedPool& P = pinned_pool();
+    std::lock_guard<std::mutex> g(P.mu);
+    auto it = P.live.find(const_cast<void*>(p));
+    return it == P.live.end() ? -1 : it->second.second ? 1 : 0;
 }
 int fg_pinned_stats(uint64_t* pinned_bytes, uint64_t* idle_bytes, uint64_t* live_blocks) {
     PinnedPool& P = pinned_pool();
@@ -266,6 +284,12 @@ static int pinned_tables_for_kernels(fg_ctx* ctx, const fg_tables& ht, fg_tables
 // every wave slot taken, 129 M at eight waves per CU; fg_decode_batch 151 -> 161 M (profiles/r04w_frame_overlap.log; the other formats'
 // kernels hold eight waves or fewer anyway).  For the duration of a host pipeline the grid is capped at eight, unless the caller set
 // its own figure (fg_set_launch_opts).
+// the launches of a sliced batch share ONE entry table: fg::entry_chunk gives each of them a 1 / shares part of the table's budget
+struct TableShares {
+    fg_ctx* ctx;
+    TableShares(fg_ctx* c, uint32_t launches) : ctx(c) { ctx->table_shares = launches; }
+    ~TableShares() { ctx->table_shares = 0; }
+};
 struct LinkBoundGrid {  // (a per-call cap beside the caller's launch options, never written into them: ADVICE r4)
     fg_ctx* ctx;
     explicit LinkBoundGrid(fg_ctx* c) : ctx(c) { ctx->link_bound_waves = 8; }
@@ -330,6 +354,7 @@ int fg_decode_batch(fg_ctx* ctx, fg_format fmt, const uint8_t* bytes, uint64_t n
     int rc;
     if ((rc = decode_batch_zero_copy(ctx, fmt, bytes, nbytes, offsets, n, out)) != FG_ERR_UNSUPPORTED) return rc;
     const uint32_t slices = slice_count(nbytes, n);
+    TableShares shares(ctx, slices);
     if (slices > 1 && (rc = ensure_pipeline(ctx, slices)) != FG_OK) return rc;  // (a small batch stays on the ctx's own stream)
     if (slices > 1 && !ctx->h_cnt) FG_HIP(ctx, hipHostMalloc((void**)&ctx->h_cnt, 65536, hipHostMallocDefault));
     if ((rc = grow_dev(ctx, (void**)&ctx->d_bytes, &ctx->d_bytes_cap, up(nbytes, 16) + 16)) != FG_OK) return rc;
@@ -623,6 +648,7 @@ static int frame_decode_sliced(fg_ctx* ctx, fg_format fmt, fg_framing framing, c
     if (slice > (32ull << 20)) slice = 32ull << 20;
     slice = slice / fg_frame_slice_align() * fg_frame_slice_align();  // (whole 64 KiB tiles of the one-pass scan)
     const uint32_t slices = (uint32_t)((nbytes + slice - 1) / slice);
+    TableShares shares(ctx, slices);
     const uint64_t nblk_total = nbytes / blk + 1;
     if ((rc = ensure_pipeline(ctx, slices)) != FG_OK) return rc;
     const hipStream_t s_up = ctx->s_up, s_run = ctx->s_run, s_down = ctx->s_down;
@@ -964,6 +990,7 @@ static int transcode_sliced(fg_ctx* ctx, fg_format fmt, const fg_encode_cfg* ecf
     if (slices < 2) slices = 2;
     if (slices > 64) slices = 64;
     if (n < slices) return FG_ERR_UNSUPPORTED;
+    TableShares shares(ctx, slices);
     std::vector<uint64_t> cut(slices + 1);
     if (fg_shard_plan(offsets, n, slices, cut.data()) != FG_OK) return FG_ERR_ARG;
     // ---- device buffers: input, tables (whole batch), out_offsets / enc_status, encoder scratch ----

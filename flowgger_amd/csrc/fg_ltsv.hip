@@ -895,14 +895,14 @@ extern "C" int fg_launch_ltsv(const uint8_t* d_bytes, const uint64_t* d_offsets,
              // (whole lines staged: chunks of 128 lines -- 3.78 vs 3.67 G lines/s with the pipeline's 256, alternated on one box,
              //  profiles/r04z3_sweep_ltsv.log)
              : fg::plan_launch(fg::k_ltsv<fg::kComputeBoundWindow, false>, n, plan_len, fg::kLtsvExtraLds, 57344u, stash ? stash_blocks : 0u, &p, *lo,
-                               64, 1, nullptr, nullptr, 0u, 128u))
+                               fg::PlanFormat().chunk(128u)))
         return -1;
     if (stash_blocks == 0) stash = nullptr;
     dim3 grid(p.blocks), block(fg::kWave);
     fg::FrameArgs fr{strip, line_bad};
     fg::take_tickets(&fr, tk, p);
     fg::DevTables tt = *t;
-    tt.alloc_chunk = fg::entry_chunk(tt.ent_cap, p.blocks, n, *lo);
+    tt.alloc_chunk = fg::entry_chunk(tt.ent_cap, p.blocks, n, *lo, tt.shares);
 #if defined(FG_PROF_BUILD)
     if (fg::prof_requested()) {
         fg::ProfRun pr;
@@ -940,7 +940,7 @@ extern "C" int fg_launch_ltsv_fused(const uint8_t* d_bytes, uint64_t nbytes, con
                           stream, &fa, &lds, &blocks))
         return -1;
     fg::DevTables tt = *t;
-    tt.alloc_chunk = fg::entry_chunk(tt.ent_cap, blocks, nbytes / (g->S / g->L ? g->S / g->L : 1u) + 1u, *lo);
+    tt.alloc_chunk = fg::entry_chunk(tt.ent_cap, blocks, nbytes / (g->S / g->L ? g->S / g->L : 1u) + 1u, *lo, tt.shares);
     *d_total = fa.total;
     hipLaunchKernelGGL((fg::k_ltsv_fused<fg::kComputeBoundWindow>), dim3(blocks), dim3(fg::kWave), lds, stream, d_bytes, tt, *cfg, g->tile, g->L, stash, fa, strip);
     return (int)hipGetLastError();

@@ -98,6 +98,7 @@ __global__ __launch_bounds__(64) void k_merge_entries(MergeArgs a) {
         a.out.ent_first[i] = a.out.ent_count[i] ? (uint32_t)ds : 0u;
     }
     if (lane == 0) s_ds[rows] = a.dense[g0 + rows];
+    // (ent_used = what the merged rows need; above ent_cap -- or above what ent_first can address -- the caller sees the overflow there)
     if (blockIdx.x == 0 && lane == 0) *reinterpret_cast<unsigned long long*>(a.out.ent_used) = a.dense[a.out.n];
     __syncthreads();
     const uint64_t d0 = s_ds[0];
@@ -112,6 +113,9 @@ __global__ __launch_bounds__(64) void k_merge_entries(MergeArgs a) {
         }
         const uint32_t k = s_k[lo];
         const uint64_t src = (uint64_t)s_src[lo] + (t - s_ds[lo]);
+        // (the dense total is bounded by the parts' used counts only while the index is the caller's contract -- every position once, no two
+        //  rows sharing a slice; an index that repeats a row must not become a write past the table: ADVICE r5)
+        if (t >= a.out.ent_cap) continue;
         a.out.ent_name[t] = s_name[k][src];
         a.out.ent_val[t] = s_val[k][src];
         a.out.ent_type[t] = s_type[k][src];

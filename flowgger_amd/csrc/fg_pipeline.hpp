@@ -756,11 +756,33 @@ inline void take_tickets(FrameArgs* fr, TicketSlot* tk, const LaunchPlan& p) {
 // window is staged by the tail loop); anything that still does not fit is parsed from global
 // memory.  fg_launch_opts (fg_set_launch_opts: tuning, parity sweeps) overrides tile / lines per group / waves per CU; the
 // library itself reads no environment variable.
+// What a format says about its own launch, by NAME (twelve positional arguments ending `64, 1, nullptr, nullptr, 0u, 0u, 20u, 0u`
+// were one swapped literal away from a silent performance regression): PlanFormat().classes(2).extra_tile(f).tile(12288).chunk(128) ...
+struct PlanFormat {
+    uint32_t max_lines = 64;        // lines a group holds at most (the wave width, or the format's cap)
+    uint32_t n_classes = 1;         // stage-A class bitmaps kept in LDS
+    uint32_t (*extra_for)(uint32_t tile, uint32_t lines) = nullptr;  // LDS that grows with the tile and the lines per group (per-item arrays)
+    uint32_t (*extra_tile)(uint32_t tile) = nullptr;                 // LDS that grows with the tile only
+    uint32_t default_tile = 0;      // a cap on the tile the format gets by default (its LDS beyond the tile grows with it)
+    uint32_t default_chunk = 0;     // lines a wave takes at a time under ticket dispatch (0: 256 / 512 by the lines a tile holds)
+    uint32_t ticket_from = 2;       // chunks of that size per wave from which chunks are drawn by ticket
+    uint32_t taper = 1;             // levels of the taper at the end of a ticket launch
+    PlanFormat& lines(uint32_t v) { max_lines = v; return *this; }
+    PlanFormat& classes(uint32_t v) { n_classes = v; return *this; }
+    PlanFormat& lds_for(uint32_t (*f)(uint32_t, uint32_t)) { extra_for = f; return *this; }
+    PlanFormat& lds_tile(uint32_t (*f)(uint32_t)) { extra_tile = f; return *this; }
+    PlanFormat& tile(uint32_t v) { default_tile = v; return *this; }
+    PlanFormat& chunk(uint32_t v) { default_chunk = v; return *this; }
+    PlanFormat& tickets_from(uint32_t v) { ticket_from = v; return *this; }
+    PlanFormat& taper_levels(uint32_t v) { taper = v; return *this; }
+};
 template <class K>
-inline int plan_launch(K kernel, uint64_t n, uint64_t avg_len, uint32_t extra_lds, uint32_t max_tile, uint32_t stash_blocks,
-                       LaunchPlan* p, const fg_launch_opts& lo, uint32_t max_lines = 64, uint32_t n_classes = 1,
-                       uint32_t (*extra_for)(uint32_t tile, uint32_t lines) = nullptr, uint32_t (*extra_tile)(uint32_t tile) = nullptr,
-                       uint32_t default_tile = 0, uint32_t default_chunk = 0, uint32_t ticket_from = 2, uint32_t taper = 1) {
+inline int plan_launch(K kernel, uint64_t n, uint64_t avg_len, uint32_t extra_lds, uint32_t max_tile, uint32_t stash_blocks, LaunchPlan* p,
+                       const fg_launch_opts& lo, const PlanFormat& pf = PlanFormat()) {
+    const uint32_t max_lines = pf.max_lines, n_classes = pf.n_classes, default_tile = pf.default_tile, default_chunk = pf.default_chunk;
+    const uint32_t ticket_from = pf.ticket_from, taper = pf.taper;
+    uint32_t (*const extra_for)(uint32_t, uint32_t) = pf.extra_for;
+    uint32_t (*const extra_tile)(uint32_t) = pf.extra_tile;
     const uint64_t window = (uint64_t)kWindowKiB * 1024u;
     // (+6.25 % + 256 B over the average group: a few sigma for the corpora at hand; a longer group just takes
     //  another pass over a restaged tile, while every KiB of LDS saved is occupancy)

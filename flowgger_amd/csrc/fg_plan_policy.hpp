@@ -155,13 +155,18 @@ inline ChunkPlan plan_chunks(uint64_t n, uint64_t blocks, uint32_t L, uint64_t g
 // caller that sized the table tightly must not see FG_ST_OVERFLOW because of slots parked in chunks).  What a wave strands
 // is the rest of its last chunk: half a chunk on average, never written and -- on the zero-copy host paths, which write the tables
 // across the link themselves -- never moved.
-inline uint32_t entry_chunk(uint64_t ent_cap, uint32_t blocks, uint64_t n, const fg_launch_opts& lo) {
+// shares: launches that reserve from the SAME table (the sliced host paths decode one batch as 6 .. 64 launches into one table sized
+// from the input bytes): the per-launch rule above bounds what ONE launch strands, so the table's share per wave is that of a
+// 1 / shares part of it -- else the slices' stranded chunks add up past the capacity, the batch reports FG_ERR_UNSUPPORTED and is decoded
+// again on the one-piece path: a cliff on structured-data-heavy batches.
+inline uint32_t entry_chunk(uint64_t ent_cap, uint32_t blocks, uint64_t n, const fg_launch_opts& lo, uint32_t shares = 1) {
     if (lo.ent_chunk == 1u) return 0u;
     if (lo.ent_chunk >= 2u) return lo.ent_chunk;
     const uint64_t waves = blocks ? blocks : 1u;
-    uint64_t c = ent_cap / (16ull * waves);
+    const uint64_t budget = ent_cap / (shares ? shares : 1u);
+    uint64_t c = budget / (16ull * waves);
     if (c > 4096u) c = 4096u;
-    if (ent_cap / (4ull * waves) < 256u) return 0u;  // (a quarter of the table stranded at worst, an eighth on average)
+    if (budget / (4ull * waves) < 256u) return 0u;  // (a quarter of the table's share stranded at worst, an eighth on average)
     if (c < 256u) c = 256u;
     const uint64_t per_wave = (n + waves - 1u) / waves * 8ull;
     if (c > per_wave) c = per_wave;

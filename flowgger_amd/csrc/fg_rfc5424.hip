@@ -1140,21 +1140,21 @@ extern "C" int fg_launch_rfc5424(const uint8_t* d_bytes, const uint64_t* d_offse
         //  chunks of 128, 1938-1967 at 256 / 512; 16 M lines: 2008-2013 at 1024, 2074-2082 at 128 .. 512; the long-tail corpus 1349 -> 1396.
         //  From FOUR chunks per wave on: at 1 M lines -- 3.8 per wave -- one share per wave measured 1716-1743 M lines/s, tickets
         //  1638-1663; at 2 M lines 1804-1844 against 1845-1873, at 16 M 1880 against 2075: profiles/r05v_policy_ab.log)
-        prc = head ? fg::plan_launch(fg::k_rfc5424<fg::kWindowKiB, false, true, true>, n, plan_len, 0u, 36864u, sb, &p, *lo, 64, 2, nullptr,
-                                     fg::sd2::extra_bytes, 12288u, 128u, 4u)
-                   : fg::plan_launch(fg::k_rfc5424<fg::kWindowKiB, false, false, true>, n, plan_len, 0u, 36864u, sb, &p, *lo, 64, 2, nullptr,
-                                     fg::sd2::extra_bytes, 12288u, 128u, 4u);
+        prc = head ? fg::plan_launch(fg::k_rfc5424<fg::kWindowKiB, false, true, true>, n, plan_len, 0u, 36864u, sb, &p, *lo,
+                                     fg::PlanFormat().classes(2u).lds_tile(fg::sd2::extra_bytes).tile(12288u).chunk(128u).tickets_from(4u))
+                   : fg::plan_launch(fg::k_rfc5424<fg::kWindowKiB, false, false, true>, n, plan_len, 0u, 36864u, sb, &p, *lo,
+                                     fg::PlanFormat().classes(2u).lds_tile(fg::sd2::extra_bytes).tile(12288u).chunk(128u).tickets_from(4u));
     else
         // (tickets from 20 chunks per wave on: the HBM-bound kernel pays for the first round's burst, fg_pipeline.hpp plan_launch)
         prc = head ? fg::plan_launch(fg::k_rfc5424<fg::kWindowKiB, false, true>, n, plan_len, 0u, 57344u, sb, &p, *lo)
-                   : fg::plan_launch(fg::k_rfc5424<fg::kWindowKiB, false>, n, plan_len, 0u, 57344u, sb, &p, *lo, 64, 1, nullptr, nullptr, 0u, 0u, 20u, 0u);
+                   : fg::plan_launch(fg::k_rfc5424<fg::kWindowKiB, false>, n, plan_len, 0u, 57344u, sb, &p, *lo, fg::PlanFormat().tickets_from(20u).taper_levels(0u));
     if (prc) return -1;
     if (stash_blocks == 0) stash = nullptr;
     dim3 grid(p.blocks), block(fg::kWave);
     fg::FrameArgs fr{strip, line_bad};
     fg::take_tickets(&fr, tk, p);
     fg::DevTables tt = *t;
-    tt.alloc_chunk = fg::entry_chunk(tt.ent_cap, p.blocks, n, *lo);
+    tt.alloc_chunk = fg::entry_chunk(tt.ent_cap, p.blocks, n, *lo, tt.shares);
     unsigned long long* const no_prof = nullptr;
 #define FG_LAUNCH_5424(PROF_, HEAD_, SDX_, prof_ptr)                                                                                       \
     hipLaunchKernelGGL((fg::k_rfc5424<fg::kWindowKiB, PROF_, HEAD_, SDX_>), grid, block, p.lds, stream, d_bytes, d_offsets, n, tt, p.tile, p.L, \
@@ -1203,7 +1203,7 @@ extern "C" int fg_launch_rfc5424_fused(const uint8_t* d_bytes, uint64_t nbytes, 
                                             stash ? stash_blocks : 0u, *lo, stream, &fa, &lds, &blocks);
     if (prc) return -1;
     fg::DevTables tt = *t;
-    tt.alloc_chunk = fg::entry_chunk(tt.ent_cap, blocks, nbytes / (g->S / g->L ? g->S / g->L : 1u) + 1u, *lo);
+    tt.alloc_chunk = fg::entry_chunk(tt.ent_cap, blocks, nbytes / (g->S / g->L ? g->S / g->L : 1u) + 1u, *lo, tt.shares);
     *d_total = fa.total;
     if (sdx)
         hipLaunchKernelGGL((fg::k_rfc5424_fused<fg::kWindowKiB, true>), dim3(blocks), dim3(fg::kWave), lds, stream, d_bytes, tt, g->tile, g->L, stash, fa, strip);

@@ -30,6 +30,9 @@ struct DevTables {
     // entry slots a wave reserves from ent_used at a time (wv::wave_alloc): 0 = exactly what each request needs.  Set by the kernel
     // launchers from the table, the grid and the lines of THIS launch (fg::entry_chunk, fg_pipeline.hpp).
     uint32_t alloc_chunk;
+    // launches that reserve entry slots from this table (host side only: the sliced host paths decode one batch as many launches;
+    // fg::entry_chunk divides the table's budget by it).  0 / 1 = this launch alone.
+    uint32_t shares;
 };
 // Dynamic chunk dispatch of the streaming decoders (fg_pipeline.hpp persistent_loop): the ticket counter of ONE launch -- a word of
 // a ctx-owned ring in device memory -- and the host's copy of what it holds; the launcher hands the kernel the word + that value and

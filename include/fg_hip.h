@@ -449,6 +449,10 @@ int fg_alloc_pinned(uint64_t bytes, void** out);
 void fg_free_pinned(void* p);
 int fg_set_pinned_limits(uint64_t total_bytes, uint64_t idle_bytes);
 int fg_pinned_stats(uint64_t* pinned_bytes, uint64_t* idle_bytes, uint64_t* live_blocks);
+/* 1: `p` (a pointer fg_alloc_pinned returned) is page-locked; 0: the cap was reached and the block is PAGEABLE memory -- the host-buffer
+ * entry points then take their staged-copy forms, silently; -1: not a block of this allocator (fg_free_pinned ignores such a pointer:
+ * it is the caller's to free). */
+int fg_is_pinned(const void* p);
 
 /* The host <-> device link of ctx's GPU, MEASURED: hipMemcpyAsync of a pinned buffer of `nbytes` (>= 64 MiB for a steady figure;
  * bench.py uses 1 GiB), best of three, in GB/s: gbps[0] host -> device, gbps[1] device -> host, gbps[2] both directions at once

@@ -71,8 +71,12 @@ impl GpuSplitter {
         // does `buf` hold a complete frame?  Kept as a flag: what a decode leaves behind is an unterminated tail (no frame), and
         // `fill` looks only at the bytes it adds -- the buffer is never rescanned (a long unterminated frame was quadratic)
         let mut framed = has_frame(&buf, self.framing);
+        // what the input's reader had buffered may already hold complete frames: they are decoded BEFORE the source is read again -- `fill`
+        // blocks in `fill_buf` up to the socket's read timeout, and nothing decodable may wait behind that
+        let mut carried = framed;
         loop {
-            let how = fill(&mut reader, &mut buf, MAX_BYTES, self.framing, &mut framed);
+            let how = if carried { Fill::Data } else { fill(&mut reader, &mut buf, MAX_BYTES, self.framing, &mut framed) };
+            carried = false;
             let last = how != Fill::Data;
             let eof = how == Fill::Eof;
             if !buf.is_empty() && (eof || framed) {
@@ -108,7 +112,8 @@ impl GpuSplitter {
                 }
                 buf.truncate(nbytes);
                 buf.drain(..used as usize); // an unterminated tail waits for more bytes
-                framed = false;
+                framed = false; // (the library consumes up to the last terminator: what is left holds no frame)
+                debug_assert!(!has_frame(&buf, self.framing));
             }
             if last {
                 if how == Fill::Idle {
@@ -124,8 +129,12 @@ impl GpuSplitter {
         let mut buf: Vec<u8> = Vec::with_capacity(2 * MAX_BYTES);
         let mut reader = widen(reader, &mut buf);
         let mut framed = has_frame(&buf, self.framing);
+        // what the input's reader had buffered may already hold complete frames: they are decoded BEFORE the source is read again -- `fill`
+        // blocks in `fill_buf` up to the socket's read timeout, and nothing decodable may wait behind that
+        let mut carried = framed;
         loop {
-            let how = fill(&mut reader, &mut buf, MAX_BYTES, self.framing, &mut framed);
+            let how = if carried { Fill::Data } else { fill(&mut reader, &mut buf, MAX_BYTES, self.framing, &mut framed) };
+            carried = false;
             let last = how != Fill::Data;
             let eof = how == Fill::Eof;
             if !buf.is_empty() && (eof || framed) {
@@ -166,7 +175,8 @@ impl GpuSplitter {
                 }
                 buf.truncate(nbytes);
                 buf.drain(..r.consumed as usize);
-                framed = false;
+                framed = false; // (see run_decode)
+                debug_assert!(!has_frame(&buf, self.framing));
             }
             if last {
                 if how == Fill::Idle {

@@ -23,4 +23,9 @@ uint32_t fgp_entry_chunk(uint64_t ent_cap, uint32_t blocks, uint64_t n, uint32_t
     lo.ent_chunk = ent_chunk;
     return fg::entry_chunk(ent_cap, blocks, n, lo);
 }
+uint32_t fgp_entry_chunk_shared(uint64_t ent_cap, uint32_t blocks, uint64_t n, uint32_t ent_chunk, uint32_t shares) {
+    fg_launch_opts lo{};
+    lo.ent_chunk = ent_chunk;
+    return fg::entry_chunk(ent_cap, blocks, n, lo, shares);
+}
 }

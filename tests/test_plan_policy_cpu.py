@@ -15,6 +15,7 @@ SRC = ROOT / "tests/native/plan_host.cpp"
 LIB = ROOT / "tests/native/libplan_host.so"
 DEPS = [SRC, ROOT / "flowgger_amd/csrc/fg_plan_policy.hpp", ROOT / "include/fg_hip.h"]
 u64, u32 = C.c_uint64, C.c_uint32
+lib_holder = []
 
 
 @pytest.fixture(scope="module")
@@ -25,7 +26,9 @@ def plan():
     lib.fgp_plan_chunks.argtypes = [u64, u64, u32, u64, u64, u32, u32, u32, u32, C.POINTER(u64)]
     lib.fgp_entry_chunk.argtypes = [u64, u32, u64, u32]
     lib.fgp_entry_chunk.restype = u32
-
+    lib.fgp_entry_chunk_shared.argtypes = [u64, u32, u64, u32, u32]
+    lib.fgp_entry_chunk_shared.restype = u32
+    lib_holder.append(lib)
     lib.fgp_chunk_range.argtypes = [u64, u64, u32, u32, u32, u64, C.POINTER(u64)]
 
     def chunks(n, blocks, L_=64, g=64, full=256, ticket_from=2, flags=0, chunk_lines=0, taper=False, levels=1):
@@ -154,3 +157,22 @@ def test_tapered_chunks_tile_the_batch_exactly(plan):
         if taper[0] != NO_TAPER:
             assert min(sizes[:-1] or [g]) >= min(g, chunk), "no chunk below one average group"
     assert tapered >= 20
+
+
+def test_slices_that_share_a_table_never_strand_more_than_a_quarter_of_it(plan):
+    """the sliced host paths decode ONE batch as 6 .. 64 launches into ONE entry table (nbytes / 16 or / 8 slots); every launch
+    strands at most waves x chunk slots.  With the table's budget divided by the launches that share it, what ALL slices strand stays
+    below a quarter of the table -- the floor of 256 slots per reservation included -- for every batch size and grid the paths use."""
+    shared = lib_holder[0].fgp_entry_chunk_shared
+    for nbytes in (48 << 20, 256 << 20, 1 << 30, 4 << 30):
+        for per_byte in (16, 8):
+            ent_cap = nbytes // per_byte + 1024
+            for slices in (6, 16, 32, 64):
+                for blocks in (1792, 2048, 4096, 5120):
+                    lines = nbytes // 300 // slices
+                    c = shared(ent_cap, blocks, lines, 0, slices)
+                    stranded = slices * min(blocks, max(lines, 1)) * c  # every wave of every slice, a whole reservation
+                    assert stranded <= ent_cap // 4 + blocks, (nbytes, per_byte, slices, blocks, c)
+                    assert c == 0 or c >= 256
+    # ... and a launch alone keeps the round-5 rule
+    assert shared(400_000_000, 2048, 125_000_000, 0, 1) == 4096
