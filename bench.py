@@ -132,9 +132,11 @@ def source_hash(workload=None) -> str:
     return h(workload)
 
 
-def bind_to_gpu_numa_node(local: int):
+def bind_to_gpu_numa_node(local: int, tid: int = 0):
     """One process per GPU: run this rank (and first-touch its pinned staging buffers) on the CPUs of the NUMA node the GPU hangs
-    off, so that H2D / D2H do not cross the socket interconnect.  Best effort; returns what was done for the JSON line."""
+    off, so that H2D / D2H do not cross the socket interconnect.  tid != 0: the THREAD with that kernel id (the threads launcher: one
+    rank per host thread -- Linux affinities are per thread, so every rank's thread sits on its own GPU's node just as a rank's process
+    does: VERDICT r5 item 10).  Best effort; returns what was done for the JSON line."""
     try:
         import torch
 
@@ -147,10 +149,10 @@ def bind_to_gpu_numa_node(local: int):
         for part in Path(f"/sys/devices/system/node/node{node}/cpulist").read_text().strip().split(","):
             a, _, b = part.partition("-")
             cpus.update(range(int(a), int(b or a) + 1))
-        cpus &= os.sched_getaffinity(0)
+        cpus &= os.sched_getaffinity(tid)
         if cpus:
-            os.sched_setaffinity(0, cpus)
-        return {"pci": bdf, "numa_node": node, "cpus": len(cpus)}
+            os.sched_setaffinity(tid, cpus)
+        return {"pci": bdf, "numa_node": node, "cpus": len(cpus), "bound": "thread" if tid else "process"}
     except Exception as e:  # noqa: BLE001
         return {"numa_node": None, "note": repr(e)[:80]}
 
@@ -543,7 +545,33 @@ class Resident:
         return n_ok_tile, used
 
 
-def bounded_leg(desc, fmt, lines, reps, dev, local, steps=5, warmup=2, D=None):
+def stamped(workload_key):
+    """profiles/traffic.json's entry for a workload when it was measured on THESE kernel sources (tools/update_traffic.py stamps the PMC
+    passes of the closing run with the hash of the files the workload's kernel object is compiled from), else None."""
+    tr = ROOT / "profiles" / "traffic.json"
+    try:
+        t = json.loads(tr.read_text()).get(workload_key)
+        if t and (t.get("src_hash") == source_hash(workload_key) or (t.get("src_hash_all") and t.get("src_hash_all") == source_hash())):
+            return t
+    except Exception:  # noqa: BLE001
+        pass
+    return None
+
+
+def compute_roof(t):
+    """The COMPUTE side of a kernel from its stamped instruction counters (`0.12 of HBM` says nothing for a kernel that
+    sits at 0.85 of the VALU issue rate): wave-instructions per line and VALU busy = SQ_INSTS_VALU x 4 cycles / (kernel time x 2.4 GHz x
+    1024 SIMDs) of the run the counters came from."""
+    c = (t or {}).get("compute")
+    if not c:
+        return None
+    return {"valu_per_line": c["valu_per_line"], "salu_per_line": c["salu_per_line"], "valu_busy": c["valu_busy"],
+            "what": "rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_SALU of this kernel on these sources (" + str(t.get("profile")) + "): wave-instructions per "
+                    "line, and VALU busy = VALU instructions x 4 cycles / (kernel time x 2.4 GHz x 1024 SIMDs) -- a wave64 VALU instruction "
+                    "occupies its SIMD for 4 cycles; near 1.0 = bound by instruction issue, not by HBM"}
+
+
+def bounded_leg(desc, fmt, lines, reps, dev, local, steps=10, warmup=2, D=None, stamp_key=None):
     """One more BASELINE configuration on a bounded resident sample (4 M lines), timed like the main workload (HIP events on the launch
     stream, replicas compared, Ok count returned for the oracle check): rides in the default line as configs2 / configs3 so that the
     driver's run observes every BASELINE configuration, not only configs[1]."""
@@ -581,6 +609,9 @@ def bounded_leg(desc, fmt, lines, reps, dev, local, steps=5, warmup=2, D=None):
             raise
         except Exception as ex:  # noqa: BLE001
             out["e2e"] = {"error": repr(ex)[:200]}
+    cr = compute_roof(stamped(stamp_key)) if stamp_key else None
+    if cr:
+        out["compute"] = cr
     leg = (R.fmt, R.data, R.offsets, R.n_tile, None)
     del R
     torch.cuda.empty_cache()
@@ -656,7 +687,7 @@ def calibrate(dec, d_bytes, nbytes, dev, reps=3):
 
 def dry_run(args):
     """--dry-run-backend gloo: the collectives of main() in main()'s order, on the CPU, with the decode stubbed out (see parse_args).
-    Kept beside main() on purpose: a collective added there belongs here too (tests/test_shard_cpu.py::test_bench_dry_run_world2)."""
+    Kept beside main() on purpose: a collective added there belongs here too (tests/test_shard_cpu.py::test_bench_dry_run_n_ranks)."""
     import torch
 
     from flowgger_amd import shard
@@ -703,7 +734,7 @@ def dry_run(args):
     e2e = None
     if not args.no_e2e and wl in ("cfg2", "cfg1", "cfg3", "cfg4", "ltsv"):
         e2e = {"link_peak": D.all([57.0, 57.0, 80.0])}
-        for leg in ("decode_batch", "frame_decode_batch") + (("transcode_batch",) if wl in ("cfg2", "cfg1") else ()):
+        for leg in ("decode_batch", "frame_decode_batch", "frame_decode_batch_two_step") + (("transcode_batch",) if wl in ("cfg2", "cfg1") else ()):
             D.barrier()                            # every rank starts a leg together ...
             e2e[leg] = [x[0] for x in D.all([0.01 * (rank + 1)])]   # ... and hands in its time
     if rank == 0:
@@ -743,8 +774,10 @@ def main(args=None, thread_rank=None):
     if thread_rank is None:
         numa = bind_to_gpu_numa_node(local)
         D = Dist(dev)
-    else:  # (CPU affinity is the process's: threads are not bound)
-        numa = {"numa_node": None, "note": "threads launcher: ranks are threads of one process, not bound"}
+    else:  # (a rank = a host thread: ITS affinity goes to the GPU's node; pinned buffers are first-touched by the thread that fills them)
+        import threading
+
+        numa = bind_to_gpu_numa_node(local, tid=threading.get_native_id())
         D = ThreadDist(dev, args.gpus, thread_rank[0], thread_rank[2])
     world, rank = D.world, D.rank
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -800,6 +833,29 @@ def main(args=None, thread_rank=None):
         evf[1].record(stream)
         torch.cuda.synchronize(dev)
         frame_ms = evf[0].elapsed_time(evf[1]) / 3
+        # round 6: the decode kernel frames the stream ITSELF (fg_frame_decode_device): one read of the stream, nothing visits the host
+        fused = None
+        try:
+            f_tab = R.tables
+            fo, fr_ = dec.frame_decode_device(raw_stream, FL.FG_FRAME_LINE, f_tab, n, final=True, avg_line=(tile_bytes + n_tile - 1) // n_tile)
+            torch.cuda.synchronize(dev)
+            res = fr_.cpu().numpy()
+            same = int(res[0]) == n and int(res[1]) == 0 and bool((fo[:n + 1] == d_offsets).all())
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+            for a, b in evs:
+                a.record(stream)
+                dec.frame_decode_device(raw_stream, FL.FG_FRAME_LINE, f_tab, n, final=True, avg_line=(tile_bytes + n_tile - 1) // n_tile)
+                b.record(stream)
+            torch.cuda.synchronize(dev)
+            fms = sorted(a.elapsed_time(b) for a, b in evs)[2]
+            fused = {"ms": fms, "stream_GBps": tile_bytes * reps / (fms * 1e-3) / 1e9, "lines_per_s": n / (fms * 1e-3), "frames_and_offsets_equal": same,
+                     "what": "fg_frame_decode_device: ONE kernel frames (UTF-8 check included) and decodes the resident stream -- the stream is read "
+                             "once and no count visits the host between framing and decode; beside it: framing.ms + the decode of the frames"}
+            assert same, "the fused launch disagrees with the generator's offsets"
+        except AssertionError:
+            raise
+        except Exception as e:  # noqa: BLE001
+            fused = {"error": repr(e)[:200]}
 
     encode_ms = []
     if wl == "cfg1":
@@ -1025,32 +1081,31 @@ def main(args=None, thread_rank=None):
                 rf["read_only_frac_of_read"] = alg_read / (dms * 1e-3) / 1e9 / rf["read_GBps"]
         if frame_ms is not None:
             out["framing"] = {"ms": frame_ms, "GBps": tile_bytes * reps / (frame_ms * 1e-3) / 1e9,
-                              "note": "fg_frame_device: the one-pass framing scan (chained look-back over 128 KiB tiles; the stream is read once) incl. clearing the verdicts and the host sync that returns the frame count"}
+                              "note": "fg_frame_device: the one-pass framing scan (chained look-back over 128 KiB tiles; the stream is read once) incl. clearing the verdicts and the host sync that returns the frame count",
+                              "fused": fused}
         # HBM traffic from the PMC passes (tools/prof.sh -> profiles/traffic.json): only when it was measured on THESE
         # kernel sources -- a figure from older code is not reported
-        tr = ROOT / "profiles" / "traffic.json"
-        if tr.exists():
-            try:
-                t = json.loads(tr.read_text()).get(args.workload)
-                # (per workload: the files its kernel object was compiled from; where the dependency files are missing that
-                #  falls back to the hash over every kernel source, which the entry carries as src_hash_all)
-                if t and (t.get("src_hash") == source_hash(wl) or (t.get("src_hash_all") and t.get("src_hash_all") == source_hash())):
-                    out["roofline"]["traffic"] = t["hbm_bytes_per_line"] * n
-                    out["roofline"]["traffic_profile"] = t.get("profile")
-                elif t:
-                    out["roofline"]["traffic_note"] = "profiles/traffic.json holds a figure for older kernel sources: not reported"
-            except Exception:
-                pass
+        t = stamped(args.workload)
+        if t:
+            out["roofline"]["traffic"] = t["hbm_bytes_per_line"] * n
+            out["roofline"]["traffic_profile"] = t.get("profile")
+            cr = compute_roof(t)
+            if cr:
+                out["roofline"].update({k: cr[k] for k in ("valu_per_line", "salu_per_line", "valu_busy")})
+                out["roofline"]["compute_what"] = cr["what"]
+        elif (ROOT / "profiles" / "traffic.json").exists():
+            out["roofline"]["traffic_note"] = "profiles/traffic.json holds no figure for these kernel sources: not reported"
         if e2e is not None:
             out["e2e"] = e2e
         extra_legs = []
         if wl == "cfg2" and world == 1 and not args.no_legs:
             # BASELINE configs[2] (GELF) and configs[3] (RFC5424 + structured data) on bounded samples, in this process
-            for key, lfmt, desc, gen in (
-                    ("configs2", 2, WORKLOADS["cfg3"][1], lambda: synth.gelf_lines(250_000, invalid_frac=args.invalid_frac)),
-                    ("configs3", 0, WORKLOADS["cfg4"][1], lambda: synth.rfc5424_lines(250_000, cfg=4, sd=True, invalid_frac=args.invalid_frac))):
+            for key, lfmt, desc, gen, skey in (
+                    ("configs2", 2, WORKLOADS["cfg3"][1], lambda: synth.gelf_lines(250_000, invalid_frac=args.invalid_frac), "cfg3"),
+                    ("configs3", 0, WORKLOADS["cfg4"][1], lambda: synth.rfc5424_lines(250_000, cfg=4, sd=True, invalid_frac=args.invalid_frac), "cfg4")):
                 try:
-                    out[key], leg = bounded_leg(desc, lfmt, gen(), 16, dev, local, D=D if not args.no_e2e else None)
+                    # (16 M lines, 10 steps: at 4 M lines and 5 steps a 2 % kernel change drowned in the box's noise -- VERDICT r5 item 5)
+                    out[key], leg = bounded_leg(desc, lfmt, gen(), 64, dev, local, D=D if not args.no_e2e else None, stamp_key=skey)
                     extra_legs.append((key, leg))
                 except Exception as e:  # noqa: BLE001 -- an extra leg never takes the bench line down (a parity failure does: below)
                     if isinstance(e, AssertionError):
@@ -1072,7 +1127,9 @@ def main(args=None, thread_rank=None):
                 m = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
                 out["configs4"] = {"workload": m["config"]["workload"], "value": m["value"], "unit": m["unit"], "ms_per_step": m["ms_per_step"],
                                    "gather_ms": m["gather_ms"], "gather": m["gather"], "sub_batches": m["sub_batches"],
-                                   "roofline_frac": m["roofline"]["frac"],
+                                   "roofline_frac_effective": m["roofline"]["frac"],
+                                   "roofline_frac_note": "EFFECTIVE: algorithmic bytes / time / 8 TB/s -- the long-tail kernels fetch the HEADS of the lines only "
+                                                         "(0.61x the algorithmic bytes, profiles/traffic.json cfg5), so this is not an HBM utilisation",
                                    "what": "python bench.py --workload cfg5mix on a bounded sample (1 M lines resident); full size: that command alone"}
             except Exception as e:  # noqa: BLE001 -- the extra leg never takes the bench line down
                 out["configs4"] = {"error": repr(e)[:200]}

@@ -94,25 +94,28 @@ def test_distributed_gather_gloo_world2(tmp_path):
     assert (tmp_path / "ok").exists()
 
 
-@pytest.mark.parametrize("workload", ["cfg2", "cfg5mix"])
-def test_bench_dry_run_world2(workload):
-    """bench.py --dry-run-backend gloo --gpus 2: the N-rank control flow of the bench (self-launch under torch.distributed.run,
+@pytest.mark.parametrize("workload,world", [("cfg2", 2), ("cfg5mix", 2), ("cfg4", 8), ("cfg5mix", 8)])
+def test_bench_dry_run_n_ranks(workload, world):
+    """bench.py --dry-run-backend gloo --gpus N: the N-rank control flow of the bench (self-launch under torch.distributed.run,
     process group, every barrier / reduction / gather, cfg5mix's merge + rank gather through the C ABI) on the CPU -- a hang in a
-    collective shows up here, not on the first 8-GPU box."""
+    collective shows up here, not on the first 8-GPU box.  Round 6: also at EIGHT ranks, for
+    the two configurations BASELINE runs on eight GPUs -- configs[3] (`cfg4`, sharded) and configs[4] (`cfg5mix`, with its ordered gather)."""
     import json
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run-backend", "gloo", "--workload", workload,
-                        "--steps", "3", "--warmup", "1"], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--dry-run-backend", "gloo", "--workload", workload,
+                        "--steps", "3", "--warmup", "1"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert line["dry_run"] is True and line["n_gpus"] == 2 and line["ranks"]["n"] == 2 and line["calibration_ranks"] == 2
+    assert line["dry_run"] is True and line["n_gpus"] == world and line["ranks"]["n"] == world and line["calibration_ranks"] == world
     if workload == "cfg5mix":
-        assert line["gather"]["ranks_rows"] == 1000 + 1010 and len(line["gather"]["all_ranks_gather_ms"]) == 2
+        assert line["gather"]["ranks_rows"] == sum(1000 + 10 * r for r in range(world)) and len(line["gather"]["all_ranks_gather_ms"]) == world
+    elif workload == "cfg2":
+        assert line["e2e_legs"] == ["decode_batch", "frame_decode_batch", "frame_decode_batch_two_step", "link_peak", "transcode_batch"]
     else:
-        assert line["e2e_legs"] == ["decode_batch", "frame_decode_batch", "link_peak", "transcode_batch"]
+        assert line["e2e_legs"] == ["decode_batch", "frame_decode_batch", "frame_decode_batch_two_step", "link_peak"]
 
 
 def test_ordered_merge_of_format_sub_batches(oracle):
