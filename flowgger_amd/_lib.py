@@ -85,6 +85,7 @@ FG_LO_NO_TAPER = 2048
 FG_LO_TAPER_1 = 4096
 FG_LO_TAPER_2 = 8192
 FG_LO_NO_FUSED_FRAMING = 16384
+FG_LO_RFC3164_REGROUP, FG_LO_RFC3164_NO_REGROUP = 32768, 65536
 FG_PATH_DECODE_ZERO_COPY, FG_PATH_DECODE_SLICED, FG_PATH_FRAME_FUSED, FG_PATH_FRAME_SLICED, FG_PATH_FRAME_ONE_PIECE = 1, 2, 3, 4, 5
 FG_LO_RESERVED = 0x40000000  # the library's own (fg_set_launch_opts clears it)
 

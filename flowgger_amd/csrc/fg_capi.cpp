@@ -242,6 +242,7 @@ void fg_destroy(fg_ctx* ctx) {
     if (ctx->d_used) (void)hipFree(ctx->d_used);
     if (ctx->d_frame) (void)hipFree(ctx->d_frame);
     if (ctx->d_fused) (void)hipFree(ctx->d_fused);
+    if (ctx->d_r3164) (void)hipFree(ctx->d_r3164);
     if (ctx->d_bad) (void)hipFree(ctx->d_bad);
     if (ctx->d_enc) (void)hipFree(ctx->d_enc);
     if (ctx->h_enc_ring) (void)hipHostFree(ctx->h_enc_ring);
@@ -487,8 +488,17 @@ int fg_decode_frames_impl(fg_ctx* ctx, fg_format fmt, fg_framing framing, const 
         case FG_RFC3164:
             if (!ctx->r3164_set) return FG_ERR_ARG;  // fg_set_rfc3164 first
             if ((rc = refresh_year(ctx)) != FG_OK) return rc;
-            rc = fg_launch_rfc3164(d_bytes, d_offsets, n, &dt, &ctx->r3164, pick_tile_cap(ctx, span_bytes, n, 56 * 1024), s, (uint32_t)framing,
-                                   d_bad_utf8);
+{
+                // (large batches: lines regrouped by shape -- fg_rfc3164.hip; the scratch is 16 bytes per line: the slow shapes' lists)
+                const int regroup = (ctx->lo.flags & FG_LO_RFC3164_NO_REGROUP) ? 2 : (ctx->lo.flags & FG_LO_RFC3164_REGROUP) ? 1 : 0;
+                uint8_t* scratch = nullptr;
+                if (regroup != 2 && n < 0xFFFFFFFFull && (regroup == 1 || n >= fg_rfc3164_regroup_from()) && lane == 0u) {
+                    if ((rc = grow_dev(ctx, (void**)&ctx->d_r3164, &ctx->d_r3164_cap, fg_rfc3164_scratch_bytes(n))) != FG_OK) return rc;
+                    scratch = ctx->d_r3164;
+                }
+                rc = fg_launch_rfc3164(d_bytes, d_offsets, n, &dt, &ctx->r3164, pick_tile_cap(ctx, span_bytes, n, 56 * 1024), s, (uint32_t)framing,
+                                       d_bad_utf8, scratch, regroup);
+            }
             break;
         default:
             return FG_ERR_UNSUPPORTED;

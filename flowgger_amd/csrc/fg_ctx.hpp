@@ -40,7 +40,9 @@ extern "C" int fg_launch_rfc5424(const uint8_t* d_bytes, const uint64_t* d_offse
 extern "C" uint64_t fg_stash_bytes(uint32_t blocks);
 extern "C" int fg_launch_rfc3164(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
                                  const fg::r3164::Cfg* cfg, uint32_t tile_cap, hipStream_t stream, uint32_t strip,
-                                 const uint8_t* line_bad);
+                                 const uint8_t* line_bad, uint8_t* scratch, int regroup);
+extern "C" uint64_t fg_rfc3164_scratch_bytes(uint64_t n);
+extern "C" uint64_t fg_rfc3164_regroup_from(void);   // lines from which the library regroups by itself  // the regrouped form's scratch: shape keys, block counts, the line permutation
 extern "C" int fg_launch_encode_sizes(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const fg::DevTables* t,
                                       const fg::EncCfg* cfg, uint32_t tile_cap, uint32_t cfg_lds, uint32_t* d_sizes,
                                       uint64_t* d_block_sums, uint8_t* d_status, uint64_t* d_out_offsets, hipStream_t stream);
@@ -130,6 +132,8 @@ struct fg_ctx {
     uint64_t* d_used = nullptr;     // fg_decode_batch, zero-copy form: the entry counter (the tables themselves are pinned host memory)
     uint8_t* d_frame = nullptr;  // fg_frame_device scratch (delimiter / UTF-8 masks, block counts)
     uint64_t d_frame_cap = 0;
+    uint8_t* d_r3164 = nullptr;  // FG_RFC3164, lines regrouped by shape: keys, block counts, permutation (fg_rfc3164.hip)
+    uint64_t d_r3164_cap = 0;
     uint8_t* d_fused = nullptr;  // fg_frame_decode_device: the fused launch's scratch (ticket counters, tile counts, block prefixes)
     uint64_t d_fused_cap = 0;
     uint8_t* d_bad = nullptr;    // fg_frame_decode_batch: per-frame UTF-8 verdicts

@@ -65,13 +65,13 @@ class Decoder:
 
     def set_launch_opts(self, lines_per_group: int = 0, tile_cap: int = 0, waves_per_cu: int = 0, gelf_lds_budget: int = 0,
                         gelf_window_kib: int = 0, gelf_generic: bool = False, transcode_one_piece: bool = False, chunk_lines: int = 0,
-                        no_head: bool = False, force_head: bool = False, sd_walk: bool = False, sd_pairs: bool = False, no_zero_copy: bool = False, frame_kernel_upload: bool = False, frame_classic: bool = False, static_chunks: bool = False, frame_selftest_stall: bool = False, ent_chunk: int = 0, no_taper: bool = False, taper_levels: int = 0, no_fused_framing: bool = False, fused_look: int = 0, fused_ext: int = 0) -> None:
+                        no_head: bool = False, force_head: bool = False, sd_walk: bool = False, sd_pairs: bool = False, no_zero_copy: bool = False, frame_kernel_upload: bool = False, frame_classic: bool = False, static_chunks: bool = False, frame_selftest_stall: bool = False, ent_chunk: int = 0, no_taper: bool = False, taper_levels: int = 0, no_fused_framing: bool = False, fused_look: int = 0, fused_ext: int = 0, rfc3164_regroup: int = 0) -> None:
         """fg_set_launch_opts: launch-geometry overrides of this ctx (parity sweeps over the kernel variants, tuning); 0 = the
         library's own choice.  Results are identical for every setting.  (The library reads no environment variables.)"""
         lo = L.fg_launch_opts(lines_per_group, tile_cap, waves_per_cu, gelf_lds_budget, gelf_window_kib,
                               (L.FG_LO_GELF_GENERIC if gelf_generic else 0) | (L.FG_LO_TRANSCODE_ONE_PIECE if transcode_one_piece else 0) |
                               (L.FG_LO_NO_HEAD if no_head else 0) | (L.FG_LO_FORCE_HEAD if force_head else 0) |
-                              (L.FG_LO_SD_WALK if sd_walk else 0) | (L.FG_LO_SD_PAIRS if sd_pairs else 0) | (L.FG_LO_NO_ZERO_COPY if no_zero_copy else 0) | (L.FG_LO_FRAME_KERNEL_UPLOAD if frame_kernel_upload else 0) | (L.FG_LO_FRAME_CLASSIC if frame_classic else 0) | (L.FG_LO_STATIC_CHUNKS if static_chunks else 0) | (L.FG_LO_FRAME_SELFTEST_STALL if frame_selftest_stall else 0) | (L.FG_LO_NO_TAPER if no_taper else 0) | (L.FG_LO_TAPER_1 if taper_levels & 1 else 0) | (L.FG_LO_TAPER_2 if taper_levels & 2 else 0) | (L.FG_LO_NO_FUSED_FRAMING if no_fused_framing else 0),
+                              (L.FG_LO_SD_WALK if sd_walk else 0) | (L.FG_LO_SD_PAIRS if sd_pairs else 0) | (L.FG_LO_NO_ZERO_COPY if no_zero_copy else 0) | (L.FG_LO_FRAME_KERNEL_UPLOAD if frame_kernel_upload else 0) | (L.FG_LO_FRAME_CLASSIC if frame_classic else 0) | (L.FG_LO_STATIC_CHUNKS if static_chunks else 0) | (L.FG_LO_FRAME_SELFTEST_STALL if frame_selftest_stall else 0) | (L.FG_LO_NO_TAPER if no_taper else 0) | (L.FG_LO_TAPER_1 if taper_levels & 1 else 0) | (L.FG_LO_TAPER_2 if taper_levels & 2 else 0) | (L.FG_LO_NO_FUSED_FRAMING if no_fused_framing else 0) | (L.FG_LO_RFC3164_REGROUP if rfc3164_regroup == 1 else L.FG_LO_RFC3164_NO_REGROUP if rfc3164_regroup == 2 else 0),
                               chunk_lines, ent_chunk, fused_look, fused_ext)
         L.check(L.lib().fg_set_launch_opts(self._ctx, C.byref(lo)), "fg_set_launch_opts")
 

@@ -224,6 +224,9 @@ enum {
     FG_LO_TAPER_2 = 8192,          /* ... at most two (halves, quarters); both bits: three (tuning) */
     FG_LO_NO_FUSED_FRAMING = 16384, /* fg_frame_decode_batch / fg_transcode_batch: the separate framing pass (rounds 1-5) even where the decode kernels
                                       can frame a pinned chunk themselves (A/B, tests) */
+    FG_LO_RFC3164_REGROUP = 32768, /* FG_RFC3164: hand the lines of the slow shapes (zone names, the custom form) to a second kernel, 64 of a kind to the workgroup,
+                                      for batches of any size -- the library does so from 1 M lines on (tests) */
+    FG_LO_RFC3164_NO_REGROUP = 65536, /* ... never: lines in arrival order, a wave runs the union of its lines' shapes (rounds 1-5; A/B) */
     FG_LO_RESERVED = 0x40000000    /* the library's own (fg_set_launch_opts clears it) */
 };
 

@@ -107,7 +107,9 @@ extern "C" int fg_launch_gelf_general(const uint8_t*, const uint64_t*, uint64_t,
 extern "C" int fg_launch_gelf(const uint8_t* b, const uint64_t* o, uint64_t n, const fg::DevTables* t, uint64_t, hipStream_t, uint64_t*, uint32_t,
                               uint32_t strip, const uint8_t* bad, const fg_launch_opts*, fg::TicketSlot*) { return fake_decode(b, o, n, t, strip, bad); }
 extern "C" int fg_launch_rfc3164(const uint8_t* b, const uint64_t* o, uint64_t n, const fg::DevTables* t, const fg::r3164::Cfg*, uint32_t, hipStream_t,
-                                 uint32_t strip, const uint8_t* bad) { return fake_decode(b, o, n, t, strip, bad); }
+                                 uint32_t strip, const uint8_t* bad, uint8_t*, int) { return fake_decode(b, o, n, t, strip, bad); }
+extern "C" uint64_t fg_rfc3164_scratch_bytes(uint64_t n) { return n * 17 + 4096; }
+extern "C" uint64_t fg_rfc3164_regroup_from(void) { return 1u << 20; }
 // ---- the fake encoder: an Ok row's message = its line + one '#' per entry + '\n' (so rows AND entry counts of the right slice matter);
 //      other rows encode to nothing with enc_status 1.  Contracts of the real launchers (fg_encode.hip): count -> sizes per line +
 //      sums per 64 lines; scan -> out_offsets[0 .. n] absolute from `base`; sizes = both with base 0; write -> the bytes.

@@ -216,3 +216,78 @@ def test_frame_decode_batch_one_launch_from_pinned_memory(oracle, fmt):
     finally:
         dec.set_launch_opts()
         lib.fg_free_pinned(p)
+
+
+# ---------------------------------------------------------------------------------------------
+# RFC3164: lines regrouped by shape (fg_rfc3164.hip; rfc3164_decoder.rs:31-213)
+# ---------------------------------------------------------------------------------------------
+def test_rfc3164_regrouped_by_shape_matches_the_oracle(oracle):
+    """the slow shapes handed to the second kernel (shape key from a line's first bytes, per-class lists, rows staged line by line): every
+    Record against the oracle, at batch sizes that do and do not fill a workgroup and a list, with empty / one-byte / very long lines, lines whose
+    first bytes lie at every alignment, and the shape key's own edge cases (a capital after the time that is no zone, a year that is
+    none); and against the plain kernel on the same batch"""
+    from flowgger_amd import RFC3164Decoder, tzdb
+    from test_gpu_parity import RFC3164_CONFIG, RFC3164_YEAR
+    from test_rfc3164_cpu import fuzz_lines
+    from gpu_util import assert_same, device_path
+
+    oracle.set_rfc3164(RFC3164_YEAR, tzdb.default_table())
+    dec = RFC3164Decoder(RFC3164_CONFIG)
+    base = synth.rfc3164_lines(20_000) + fuzz_lines(6_000, 31)
+    base += [b"", b"<", b"<1", b"<12>", b"A", b"Aug", b"Aug 6 11:15:24 Host-With-Capital app: m", b"<34>2019 Aug 6 11:15:24 UTC h a: m", b"<5>1234x", b"a: b: ",
+             b"Aug 6 11:15:24 " + b"h" * 9000 + b" long hostname token", b"<190>Oct  1 00:00:00 Europe/Paris h app[1]: " + b"x" * 70_000]
+    for n in (1, 63, 64, 65, 1023, 1025, len(base)):
+        lines = base[-n:] if n <= 65 else base[:n]
+        data, offsets = synth.pack(lines)
+        oblob, ooffs = oracle.decode_batch(dec.fmt, data, offsets, None)
+        got = {}
+        for mode in (1, 2):  # regrouped, plain
+            dec.set_launch_opts(rfc3164_regroup=mode)
+            tables, _, _ = device_path(dec, data, offsets)
+            blob, offs = tables.to_host().serialize(dec.fmt, data, offsets, cfg=dec._cfg)
+            assert_same(blob, offs, oblob, ooffs, lines)
+            got[mode] = tables.to_host().a["meta"][:len(lines)].copy()
+        assert np.array_equal(got[1], got[2])
+    dec.set_launch_opts()
+
+
+def test_rfc3164_regrouped_frames_and_large_batch(oracle):
+    """the library's own choice (regrouping from 1 M lines on) on a 1.2 M-line stream of FRAMES (terminators stripped in-kernel, a
+    frame that is not valid UTF-8): the Ok verdicts of every row against the plain kernel, a sample of Records against the oracle"""
+    import torch
+
+    from flowgger_amd import RFC3164Decoder, tzdb
+    from test_gpu_parity import RFC3164_CONFIG, RFC3164_YEAR
+
+    oracle.set_rfc3164(RFC3164_YEAR, tzdb.default_table())
+    dec = RFC3164Decoder(RFC3164_CONFIG)
+    lines = synth.rfc3164_lines(100_000) * 12
+    lines[7] = lines[7] + b"\r"
+    lines[9] = b"Aug  6 11:15:24 h \xff\xfe not utf-8"
+    stream = b"".join(ln + b"\n" for ln in lines)
+    raw = torch.frombuffer(bytearray(stream + b"\0" * 32), dtype=torch.uint8).cuda()[:len(stream)]
+    d_off, d_bad, nf = dec.frame_device(raw, L.FG_FRAME_LINE)
+    assert nf == len(lines)
+    metas = {}
+    for mode in (0, 2):
+        dec.set_launch_opts(rfc3164_regroup=mode)
+        tables = DeviceTables(nf, 16, raw.device)
+        dec.decode_frames_device(raw, d_off, nf, tables, L.FG_FRAME_LINE, d_bad)
+        torch.cuda.synchronize()
+        host = tables.to_host()
+        metas[mode] = (host.a["meta"][:nf].copy(), host.a["ts"][:nf].copy(), host.a["hostname"][: 2 * nf].copy(), host.a["msg"][: 2 * nf].copy())
+        if mode == 0:
+            off = d_off[:nf + 1].cpu().numpy().astype(np.uint64)
+            data = np.frombuffer(stream + b"\0" * 32, np.uint8)
+            blob, offs = host.serialize(dec.fmt, data, off, 0, 3000)
+            good = [ln[:-1] if ln.endswith(b"\r") else ln for ln in lines[:3000]]
+            gdata, goffs = synth.pack(good)
+            oblob, ooffs = oracle.decode_batch(dec.fmt, gdata, goffs)
+            for i in range(3000):
+                if i == 9:
+                    assert host.status[i] == L.FG_ST_BAD_UTF8
+                    continue
+                assert blob[int(offs[i]):int(offs[i + 1])].tobytes() == oblob[int(ooffs[i]):int(ooffs[i + 1])].tobytes(), i
+    dec.set_launch_opts()
+    for a, b in zip(metas[0], metas[2]):
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
