@@ -66,7 +66,7 @@ inline void fused_carve(uint8_t* scratch, uint64_t nbytes, uint32_t S, FusedArgs
 // -DFG_FUSED_STATS (a measurement variant, FG_BUILD_VARIANT=stats; never the product): event counts and shader-clock phases of the fused loop,
 // accumulated per wave and added to total[2 ..] at the wave's end: [2] tiles [3] slow look-backs [4] tiles that staged on [5] tail scans
 // [6] passes of stage B [7] tiles with a UTF-8 error bit; cycles: [8] wait for the window [9] stage A [10] count + tail [11] prefetch issue +
-// publish [12] look-back + row stores [13] list + stage B
+// publish [12] look-back + row stores [13] list + stage B [14] slow look-backs because a tile of the block had not published [15] ... because no prefix / an incomplete block lay in the 64 blocks
 #if defined(FG_FUSED_STATS)
 #define FG_ST(k, v) (st_acc[k] += (v))
 #define FG_CLK(k)                                              \
@@ -212,7 +212,11 @@ __device__ __forceinline__ uint64_t lookback_finish(const FusedArgs& fa, uint64_
     const bool ready = __ballot(lb.v == 0u) == 0ull && mp != 0ull && __ballot(part && (lb.agg >> 40) != 64ull) == 0ull;  // wave-uniform
     if (!ready) {
 #if defined(FG_FUSED_STATS)
-        if (lane == 0u) atomicAdd(fa.total + 3, 1ull);
+        if (lane == 0u) {
+            atomicAdd(fa.total + 3, 1ull);
+            if (__ballot(lb.v == 0u) != 0ull) atomicAdd(fa.total + 14, 1ull);
+            else atomicAdd(fa.total + 15, 1ull);
+        }
 #endif
         const uint64_t r = lookback_slow(fa.tcount, fa.bagg, fa.bpre, fa.total, fa.ntiles, T, n_own);
         if (r == ~0ull) *aborted = true;
@@ -462,30 +466,34 @@ __device__ __forceinline__ void fused_loop(const uint8_t* __restrict__ bytes, co
             }
         }
         FG_CLK(10);
-        // ---- prefetch: the next tile's bytes into the register window (nothing below needs a global load of this wave back sooner) ----
-        const uint64_t Tn = drawn();
-        const bool more = Tn < fa.ntiles;  // wave-uniform
-        if (more) {
-            draw();
-            load_window(Tn, fuse::tile_geo(Tn, fa.S, fa.look, fa.nbytes), v);
-        }
         const bool any_err = __ballot((err_acc >> 16) != 0u) != 0ull;  // wave-uniform; a healthy stream: never
         if (lane == 0u) {
             __hip_atomic_store(fa.tcount + T, cn.n_own + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             (void)__hip_atomic_fetch_add(fa.bagg + (T >> 6), (1ull << 40) | (unsigned long long)cn.n_own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        FG_CLK(11);
         if (any_err) FG_ST(7, 1);
-        // ---- the tile before: its row index, then its rows ----
+        // ---- the tile before: its row index, then its rows.  BEFORE the prefetch is issued: vmcnt retires in order, so anything this
+        // wave loads behind the window -- a poll of the look-back's slow path, a spilled register coming back -- waits for the whole
+        // window (the first cut looked back behind the prefetch: 14 k of a tile's 68 k cycles sat right there, profiles/r06f_fused_stats.log).
+        // (Measured and not kept: the next tile's ticket drawn at the top of the iteration instead of an iteration ahead -- fewer tiles wait on a
+        // straggler, but the atomic sits in front of the look-back's loads: 0.98 -> 1.32 ms per GB, profiles/r06u_fused_frame.log.)
         if (pend_any) {
             const uint64_t base = lookback_finish(fa, pend_T, pend_nown, lbk, &aborted);
             if (aborted) return;
             store_rows(base, pend, pend_valid, pend_k, pend_o0, pend_o1);
             pend_any = false;
         }
+        FG_CLK(12);
+        // ---- prefetch: the next tile's bytes into the register window ----
+        const uint64_t Tn = drawn();
+        const bool more = Tn < fa.ntiles;  // wave-uniform
+        if (more) {
+            draw();
+            load_window(Tn, fuse::tile_geo(Tn, fa.S, fa.look, fa.nbytes), v);
+        }
+        FG_CLK(11);
         __builtin_amdgcn_sched_barrier(0);
         FG_MARK(B);
-        FG_CLK(12);
         // ---- stage B: the tile's lines, L to the pass ----
         bool have_base = false;
         uint64_t base = 0;
@@ -512,19 +520,23 @@ __device__ __forceinline__ void fused_loop(const uint8_t* __restrict__ bytes, co
                 }
                 const uint32_t k = p0 + lane;
                 const bool valid = lane < L && k < w1;
+                // the lane's frame [o0, o1) (terminator included) from the list: asked for twice, before and BEHIND decode(), so that
+                // nothing of it stays alive across the decoder (which runs at the register limit: a value kept there is a spill, and a
+                // spilled register coming back is a wait for every load in flight)
+                auto frame_of = [&](uint64_t* f0, uint64_t* f1, uint32_t* sx, uint32_t* ex) {
+                    uint32_t s2, e2;
+                    fuse::line_at(FL, cn, w0, k, &s2, &e2);
+                    *f0 = g.base + s2;
+                    *f1 = e2 == fuse::kUnresolved ? tail_end : g.base + e2;
+                    *sx = s2, *ex = e2;
+                };
                 uint64_t o0 = 0, o1 = 0;
                 bool bad = false;
                 if (valid) {
                     uint32_t s, e;
-                    fuse::line_at(FL, cn, w0, k, &s, &e);
-                    o0 = g.base + s;
-                    if (e == fuse::kUnresolved) {
-                        o1 = tail_end;
-                        bad = tail_bad || (any_err && fused_line_bad(tile32, g.base, g.span, g.own_end, g.end_x, s, g.end_x != fuse::kUnresolved ? g.end_x + 1u : g.span));
-                    } else {
-                        o1 = g.base + e;
-                        bad = any_err && fused_line_bad(tile32, g.base, g.span, g.own_end, g.end_x, s, e);
-                    }
+                    frame_of(&o0, &o1, &s, &e);
+                    if (e == fuse::kUnresolved) bad = tail_bad || (any_err && fused_line_bad(tile32, g.base, g.span, g.own_end, g.end_x, s, g.end_x != fuse::kUnresolved ? g.end_x + 1u : g.span));
+                    else bad = any_err && fused_line_bad(tile32, g.base, g.span, g.own_end, g.end_x, s, e);
                 }
                 // terminator stripping (BufRead::lines / split(0), as persistent_loop)
                 uint64_t e1 = o1;
@@ -553,7 +565,13 @@ __device__ __forceinline__ void fused_loop(const uint8_t* __restrict__ bytes, co
                     for (int q = 0; q < 6; ++q) row.span[q] = fg_span{0, FG_NONE};
                     row.count = 0;
                 }
-                row_o0 = o0, row_o1 = o1, row_k = k, row_valid = valid;
+                row_k = p0 + lane;
+                row_valid = lane < L && row_k < w1;
+                row_o0 = row_o1 = 0;
+                if (row_valid) {
+                    uint32_t s3, e3;
+                    frame_of(&row_o0, &row_o1, &s3, &e3);
+                }
             }
         }
         // the rows of the tile's last pass wait for the tile's look-back, one iteration: by then every tile before has published

@@ -61,7 +61,7 @@ inline FusedGeom fused_geometry(fg_format fmt, uint64_t avg_len, const fg_launch
             g.L = 64u;
             // (the pair-parallel kernel's tile -- twice that across the link, where the grid is capped anyway and every byte of look-ahead
             //  is read twice over the link: the input side of the link is the ceiling there, 48 GB/s --; else the register window)
-            bound = g.variant ? (link_bound ? 24576u : 12288u) : 20480u;
+            bound = g.variant ? (link_bound ? 24576u : 12288u) : 16384u;
             break;
         case FG_LTSV:
             if (head) return g;

@@ -1185,6 +1185,8 @@ extern "C" int fg_launch_rfc5424(const uint8_t* d_bytes, const uint64_t* d_offse
     return (int)hipGetLastError();
 }
 
+// (register windows of exactly the tile's rows -- 16 KiB, 12 KiB for the pair-parallel kernel --: the 20 KiB of the plain kernels would
+//  hold rows that are never fetched, and the fused loop needs those registers: a spill there is a wait for every load in flight)
 // The fused launch (fg_fused.hpp): frame + decode of a raw stream chunk in one kernel.  g from fg::fused_geometry (the caller sized
 // `scratch` from it: fg::fused_scratch_bytes).  *d_total = the two device words the launch leaves: lines, abort flag.
 extern "C" int fg_launch_rfc5424_fused(const uint8_t* d_bytes, uint64_t nbytes, const fg::DevTables* t, const fg::FusedGeom* g, hipStream_t stream,
@@ -1197,17 +1199,17 @@ extern "C" int fg_launch_rfc5424_fused(const uint8_t* d_bytes, uint64_t nbytes, 
     uint32_t lds = 0, blocks = 0;
     if (stash_blocks == 0) stash = nullptr;
     const uint32_t delim = strip == FG_FRAME_LINE ? 0x0Au : 0u;
-    const int prc = sdx ? fg::fused_prepare(fg::k_rfc5424_fused<fg::kWindowKiB, true>, *g, base_lds, nbytes, final_, delim, d_offsets, cap, scratch,
+    const int prc = sdx ? fg::fused_prepare(fg::k_rfc5424_fused<12, true>, *g, base_lds, nbytes, final_, delim, d_offsets, cap, scratch,
                                             stash ? stash_blocks : 0u, *lo, stream, &fa, &lds, &blocks)
-                        : fg::fused_prepare(fg::k_rfc5424_fused<fg::kWindowKiB, false>, *g, base_lds, nbytes, final_, delim, d_offsets, cap, scratch,
+                        : fg::fused_prepare(fg::k_rfc5424_fused<16, false>, *g, base_lds, nbytes, final_, delim, d_offsets, cap, scratch,
                                             stash ? stash_blocks : 0u, *lo, stream, &fa, &lds, &blocks);
     if (prc) return -1;
     fg::DevTables tt = *t;
     tt.alloc_chunk = fg::entry_chunk(tt.ent_cap, blocks, nbytes / (g->S / g->L ? g->S / g->L : 1u) + 1u, *lo, tt.shares);
     *d_total = fa.total;
     if (sdx)
-        hipLaunchKernelGGL((fg::k_rfc5424_fused<fg::kWindowKiB, true>), dim3(blocks), dim3(fg::kWave), lds, stream, d_bytes, tt, g->tile, g->L, stash, fa, strip);
+        hipLaunchKernelGGL((fg::k_rfc5424_fused<12, true>), dim3(blocks), dim3(fg::kWave), lds, stream, d_bytes, tt, g->tile, g->L, stash, fa, strip);
     else
-        hipLaunchKernelGGL((fg::k_rfc5424_fused<fg::kWindowKiB, false>), dim3(blocks), dim3(fg::kWave), lds, stream, d_bytes, tt, g->tile, g->L, stash, fa, strip);
+        hipLaunchKernelGGL((fg::k_rfc5424_fused<16, false>), dim3(blocks), dim3(fg::kWave), lds, stream, d_bytes, tt, g->tile, g->L, stash, fa, strip);
     return (int)hipGetLastError();
 }

@@ -92,8 +92,8 @@ def main():
                 L.lib().fg_debug_fused_stats(dec._ctx, st)
                 tiles = max(int(st[2]), 1)
                 names = ["frames", "abort", "tiles", "slow_lookbacks", "staged_on", "tail_scans", "passes", "err_tiles", "cyc_wait_window", "cyc_stage_a",
-                         "cyc_count_tail", "cyc_prefetch_publish", "cyc_lookback_rows", "cyc_list_stage_b"]
-                row["stats" + (":" + v if v else "")] = {nm: (int(st[i]) if i < 8 else round(int(st[i]) / tiles)) for i, nm in enumerate(names)}
+                         "cyc_count_tail", "cyc_prefetch_publish", "cyc_lookback_rows", "cyc_list_stage_b", "slow_tcount", "slow_blocks"]
+                row["stats" + (":" + v if v else "")] = {nm: (int(st[i]) if (i < 8 or i >= 14) else round(int(st[i]) / tiles)) for i, nm in enumerate(names)}
             row["fused" + (":" + v if v else "")] = {"ms": round(t[0], 3), "best_ms": round(t[1], 3), "same_result": ok,
                                                      "G_lines_s": round(n / t[0] / 1e6, 3), "stream_TBps": round(nbytes / t[0] / 1e9, 3)}
         dec.set_launch_opts()
