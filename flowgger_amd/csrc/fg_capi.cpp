@@ -535,7 +535,12 @@ int fg_frame_decode_impl(fg_ctx* ctx, fg_format fmt, fg_framing framing, const u
     if (nbytes == 0 || cap == 0) return FG_ERR_UNSUPPORTED;
     if (avg_line == 0) avg_line = ctx->frames_per_byte > 0.0 ? (uint64_t)(1.0 / ctx->frames_per_byte + 0.5) : 200u;
     fg_launch_opts lo_call = ctx->lo;
-    if (ctx->link_bound_waves && lo_call.waves_per_cu == 0) lo_call.waves_per_cu = ctx->link_bound_waves;
+    // Across the link the queue of outstanding reads IS the latency of every dependent one (a tile staged on, a tail scan, the exact
+    // GELF form): 2048 waves x a 15 KiB window are 30 MB = half a millisecond at 57 GB/s, and a wave that waits that long holds the
+    // look-back of every tile behind it.  Two waves per CU keep the link as full (a few hundred KB in flight do) with a sixteenth of
+    // the queue: cfg2 0.864 -> 0.900 of the link, structured data 0.870 -> 0.878 (profiles/r06y_fused_host.log); GELF needs the
+    // waves for its arithmetic (one per CU: 0.63) and keeps the link-bound grid of the other zero-copy launches.
+    if (ctx->link_bound_waves && lo_call.waves_per_cu == 0) lo_call.waves_per_cu = fmt == FG_GELF ? ctx->link_bound_waves : 2u;
     const fg::FusedGeom g = fg::fused_geometry(fmt, avg_line, lo_call, ctx->link_bound_waves != 0);
     if (!g.ok) return FG_ERR_UNSUPPORTED;
     DeviceGuard guard(ctx->device);

@@ -73,9 +73,20 @@ def main():
             return ts
 
         ts = timed(lambda: L.check(lib.fg_decode_batch(dec._ctx, dec.fmt, pdata.ctypes.data, tb * reps, poffs.ctypes.data, nl, C.byref(st)), "fg_decode_batch"))
-        row["decode_batch_zero_copy"] = {"M_lines_s": round(nl / min(ts) / 1e6, 1), "of_link": round((tb * reps + 8 * nl) / min(ts) / 1e9 / gb[0], 3)}
+        row["decode_batch_zero_copy"] = {"M_lines_s": round(nl / min(ts) / 1e6, 1), "of_link": round((tb * reps + 8 * nl) / min(ts) / 1e9 / gb[0], 3),
+                                         "wall_ms": round(min(ts) * 1e3, 3)}
+
+        def kernel_ms(call):  # (HIP events around the launch on the ctx's stream: what of the call is the kernel)
+            lib.fg_set_timing(dec._ctx, 1)
+            call()
+            ms = C.c_float()
+            lib.fg_last_kernel_ms(dec._ctx, C.byref(ms))
+            lib.fg_set_timing(dec._ctx, 0)
+            return round(float(ms.value), 3)
+
+        row["decode_batch_zero_copy"]["kernel_ms"] = kernel_ms(lambda: L.check(lib.fg_decode_batch(dec._ctx, dec.fmt, pdata.ctypes.data, tb * reps, poffs.ctypes.data, nl, C.byref(st)), "fg_decode_batch"))
         res = {v: [] for v in variants}
-        paths = {}
+        paths, kms = {}, {}
         for _round in range(2):
             for v in variants:
                 opts = {k: int(x) for k, x in (kv.split("=") for kv in v.split(",") if kv)}
@@ -89,11 +100,13 @@ def main():
 
                 res[v] += timed(call)
                 paths[v] = int(lib.fg_last_host_path(dec._ctx))
+                kms[v] = kernel_ms(call)
         dec.set_launch_opts()
         for v in variants:
             ts = sorted(res[v])
             row["frame_decode_batch" + (":" + v if v else "")] = {"best_M_lines_s": round(nl / ts[0] / 1e6, 1), "median_M_lines_s": round(nl / ts[len(ts) // 2] / 1e6, 1),
-                                                                 "best_of_link": round(nbytes / ts[0] / 1e9 / gb[0], 3), "path": paths[v]}
+                                                                 "best_of_link": round(nbytes / ts[0] / 1e9 / gb[0], 3), "path": paths[v],
+                                                                 "wall_ms": round(ts[0] * 1e3, 3), "kernel_ms": kms[v]}
         print(json.dumps(row), flush=True)
         for h in (hraw, hd, ho):
             lib.fg_free_pinned(h)
