@@ -85,6 +85,11 @@ def main():
             return round(float(ms.value), 3)
 
         row["decode_batch_zero_copy"]["kernel_ms"] = kernel_ms(lambda: L.check(lib.fg_decode_batch(dec._ctx, dec.fmt, pdata.ctypes.data, tb * reps, poffs.ctypes.data, nl, C.byref(st)), "fg_decode_batch"))
+        for v in [x for x in os.environ.get("FG_PROBE_DB_OPTS", "").split(";") if x]:  # (the zero-copy launch under launch options of its own)
+            dec.set_launch_opts(**{k: int(x) for k, x in (kv.split("=") for kv in v.split(",") if kv)})
+            ts = timed(lambda: L.check(lib.fg_decode_batch(dec._ctx, dec.fmt, pdata.ctypes.data, tb * reps, poffs.ctypes.data, nl, C.byref(st)), "fg_decode_batch"))
+            row["decode_batch_zero_copy:" + v] = {"M_lines_s": round(nl / min(ts) / 1e6, 1), "of_link": round((tb * reps + 8 * nl) / min(ts) / 1e9 / gb[0], 3), "wall_ms": round(min(ts) * 1e3, 3)}
+        dec.set_launch_opts()
         res = {v: [] for v in variants}
         paths, kms = {}, {}
         for _round in range(2):
