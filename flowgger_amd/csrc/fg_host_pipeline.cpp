@@ -986,16 +986,44 @@ static int decode_stage(fg_ctx* ctx, fg_format fmt, fg_framing framing, uint64_t
 static int transcode_sliced(fg_ctx* ctx, fg_format fmt, const fg_encode_cfg* ecfg, const uint8_t* bytes, uint64_t nbytes,
                             const uint64_t* offsets, uint64_t n, fg_transcoded* out) {
     int rc;
-    if (!ctx->stream2) FG_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-    if (!ctx->ev_ready) FG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming));
-    hipStream_t lanes[2] = {ctx->stream, ctx->stream2};
-    uint32_t slices = (uint32_t)(nbytes / (32ull << 20));
-    if (slices < 2) slices = 2;
-    if (slices > 64) slices = 64;
-    if (n < slices) return FG_ERR_UNSUPPORTED;
+    if (n < 64) return FG_ERR_UNSUPPORTED;
+    // Slices that GROW: 4, 8, 16, 32 MiB, then 64 MiB each (a sixtieth of the batch beyond 4 GiB).  The download direction is the bound (the
+    // GELF text is 2.4x the input) and it cannot start before the first slice is uploaded, decoded, counted, scanned and written:
+    // 1.7 ms of a 13 ms call with a 32 MiB first slice, a quarter of a millisecond with 4 MiB.
+    std::vector<uint64_t> cut{0};
+    {
+        const uint64_t steady = nbytes / 60u > (64ull << 20) ? nbytes / 60u : (64ull << 20);
+        uint64_t piece = 4ull << 20, at = offsets[0];
+        while (cut.back() < n) {
+            at += piece;
+            uint64_t line = (uint64_t)(std::upper_bound(offsets, offsets + n + 1, at) - offsets);
+            line = line ? line - 1 : 0;  // the last line that starts at or before `at`
+            if (line <= cut.back()) line = cut.back() + 1;
+            if (line >= n || offsets[n] - offsets[line] < piece / 2u) line = n;
+            cut.push_back(line);
+            at = offsets[line];
+            if (piece < steady) piece = piece * 2u < steady ? piece * 2u : steady;
+        }
+    }
+    const uint32_t slices = (uint32_t)(cut.size() - 1);
+    // One stream per direction of the link (round 6; rounds 3-5 ran two lanes, each with its own upload, kernels and download).  The
+    // timeline of one call (profiles/r06ae_transcode_timeline.json) showed what two lanes cost: whenever both lanes had a copy of the
+    // SAME direction in flight the runtime moved the second with a blit KERNEL, copies and kernels of a lane waited for each other, and
+    // the two directions were never busy together.  Now:
+    //   s_up    upload k, decode k, count k, upload k + 1, ... -- all queued at once, nothing on it waits for the host; the upload
+    //           direction has time to spare (the text is 2.4x the input), so the kernels may sit between two uploads
+    //   s_run   what hangs on the host's one number per slice: scan k -> the slice's size -> write k.  A write never queues behind the
+    //           decode of a later slice: kernels crawl while a download saturates the link's write queue (k_rfc5424 0.03 -> 0.6-1.0 ms
+    //           per slice), and only the write is on the download's critical path
+    //   s_down  every download, in slice order
+    // (three streams, not four: with a fourth the runtime put it on the hardware queue of s_down and every download waited for the
+    //  last upload -- profiles/r06ai_transcode_timeline.json)
+    if ((rc = ensure_pipeline(ctx, slices * 2u)) != FG_OK) return rc;  // (four events per slice)
+    const hipStream_t s_up = ctx->s_up, s_run = ctx->s_run, s_down = ctx->s_down, s_ahead = ctx->s_up;
+    hipStream_t lanes[1] = {s_run};
+    if (!ctx->h_cnt) FG_HIP(ctx, hipHostMalloc((void**)&ctx->h_cnt, 65536, hipHostMallocDefault));
+    std::vector<hipEvent_t>& ev = ctx->ev_slice;  // [4k + 1] slice k is decoded and counted, [4k + 2] its messages are written
     TableShares shares(ctx, slices);
-    std::vector<uint64_t> cut(slices + 1);
-    if (fg_shard_plan(offsets, n, slices, cut.data()) != FG_OK) return FG_ERR_ARG;
     // ---- device buffers: input, tables (whole batch), out_offsets / enc_status, encoder scratch ----
     if ((rc = grow_dev(ctx, (void**)&ctx->d_bytes, &ctx->d_bytes_cap, up(nbytes, 16) + 16)) != FG_OK) return rc;
     if ((rc = grow_dev(ctx, (void**)&ctx->d_offsets, &ctx->d_offsets_cap, (n + 1) * 8)) != FG_OK) return rc;
@@ -1044,12 +1072,13 @@ static int transcode_sliced(fg_ctx* ctx, fg_format fmt, const fg_encode_cfg* ecf
     };
     auto blocks_before = [&](uint32_t k) { return cut[k] / 64 + k; };  // first scratch sum of slice k (disjoint per slice)
     auto drain = [&]() {
-        (void)hipStreamSynchronize(lanes[0]);
-        (void)hipStreamSynchronize(lanes[1]);
+        (void)hipStreamSynchronize(s_up);
+        (void)hipStreamSynchronize(s_run);
+        (void)hipStreamSynchronize(s_down);
     };
-    // queue a slice's upload, decode and count kernel
+    // queue a slice's upload, decode and count kernel (sixteen-byte aligned cuts: a slice starts with the sixteen bytes its first line begins in)
     auto enqueue = [&](uint32_t k) -> int {
-        hipStream_t s = lanes[k & 1u];
+        hipStream_t s = s_ahead;
         const uint64_t l0 = cut[k], l1 = cut[k + 1];
         if (l1 == l0) return FG_OK;
         const uint64_t b0 = offsets[l0] & ~15ull, b1 = offsets[l1];
@@ -1071,28 +1100,43 @@ static int transcode_sliced(fg_ctx* ctx, fg_format fmt, const fg_encode_cfg* ecf
         if (fg_launch_encode_count(ctx->d_bytes, ctx->d_offsets + l0, l1 - l0, &sdt, &cfg, tile_cap, cfg_lds, d_sizes + l0,
                                    d_block_sums + blocks_before(k), d_enc_status + l0, s) != 0)
             return FG_ERR_HIP;
+        FG_HIP(ctx, hipEventRecord(ev[4 * k + 1], s));
         return FG_OK;
     };
+    // (a few slices ahead of the one being finished, not all at once: the forty API calls of a slice take the host a tenth of a
+    //  millisecond, and thirty slices queued before the first scan kept the first download waiting for four)
+    uint32_t queued = 0;
     for (uint32_t k = 0; k < slices; ++k) {
-        if (k == 0 && (rc = enqueue(0)) != FG_OK) {
-            drain();
-            return rc;
+        while (queued < slices && queued < k + 3u) {
+            if ((rc = enqueue(queued)) != FG_OK) {
+                drain();
+                return rc;
+            }
+            ++queued;
         }
-        if (k + 1 < slices && (rc = enqueue(k + 1)) != FG_OK) {
-            drain();
-            return rc;
-        }
-        // ---- finish slice k: offsets from `base`, its size, the write kernel, the download ----
-        hipStream_t s = lanes[k & 1u];
+
+        // ---- finish slice k: offsets from `base`, its size (the host waits for that one number), the write kernel, the download ----
+        hipStream_t s = s_run;
         const uint64_t l0 = cut[k], l1 = cut[k + 1], rows = l1 - l0;
         if (rows == 0) continue;
+        if (hipStreamWaitEvent(s, ev[4 * k + 1], 0) != hipSuccess) {
+            drain();
+            return FG_ERR_HIP;
+        }
         if (fg_launch_encode_scan(d_sizes + l0, d_block_sums + blocks_before(k), rows, d_out_offsets + l0, base, s) != 0) {
             drain();
             return FG_ERR_HIP;
         }
-        uint64_t end = 0;
-        FG_HIP(ctx, hipMemcpyAsync(&end, d_out_offsets + l1, 8, hipMemcpyDeviceToHost, s));
-        FG_HIP(ctx, hipStreamSynchronize(s));
+        uint64_t* const h_end = ctx->h_cnt + 4096;
+        if (hipMemcpyAsync(h_end, d_out_offsets + l1, 8, hipMemcpyDeviceToHost, s) != hipSuccess || hipEventRecord(ctx->ev_ready, s) != hipSuccess) {
+            drain();
+            return FG_ERR_HIP;
+        }
+        if (hipEventSynchronize(ctx->ev_ready) != hipSuccess) {
+            drain();
+            return FG_ERR_HIP;
+        }
+        const uint64_t end = *h_end;
         if (k == 0) {
             // size the output buffers from the first slice (+ 12 %); a batch that outgrows the estimate takes the one-piece path
             const uint64_t in0 = offsets[l1] - offsets[l0];
@@ -1114,11 +1158,33 @@ static int transcode_sliced(fg_ctx* ctx, fg_format fmt, const fg_encode_cfg* ecf
             return FG_ERR_HIP;
         }
         uint8_t* hh = ctx->h_tout;
-        if (end > base) FG_HIP(ctx, hipMemcpyAsync(hh + o_msgs + base, ctx->d_tout + base, end - base, hipMemcpyDeviceToHost, s));
-        FG_HIP(ctx, hipMemcpyAsync(hh + o_offs + l0 * 8, d_out_offsets + l0, (rows + 1) * 8, hipMemcpyDeviceToHost, s));
-        FG_HIP(ctx, hipMemcpyAsync(hh + o_meta + l0 * 4, dt.meta + l0, rows * 4, hipMemcpyDeviceToHost, s));
-        FG_HIP(ctx, hipMemcpyAsync(hh + o_st + l0, d_enc_status + l0, rows, hipMemcpyDeviceToHost, s));
+        // (the downloads stay with hipMemcpyAsync: a copy kernel of the library's own through the buffer's device view -- one wave per
+        //  CU, eight 16-byte accesses in flight per lane -- moved a slice no faster than the runtime's blit kernel, 50 vs 52 GB/s, and
+        //  slowed the kernels beside it just the same: it is the link's write queue that holds them up, not the CUs the copy takes)
+        // at most three downloads queued: a stream's packets share a hardware queue with another stream's, and two dozen downloads
+        // queued ahead held the uploads behind them up for 45 ms (4 M lines, profiles/r06al_transcode_host_trace.log)
+        bool ok = k < 3u || hipEventSynchronize(ev[4 * (k - 3u) + 3]) == hipSuccess;
+        ok = ok && hipEventRecord(ev[4 * k + 2], s) == hipSuccess && hipStreamWaitEvent(s_down, ev[4 * k + 2], 0) == hipSuccess;
+        if (ok && end > base) ok = hipMemcpyAsync(hh + o_msgs + base, ctx->d_tout + base, end - base, hipMemcpyDeviceToHost, s_down) == hipSuccess;
+        ok = ok && hipEventRecord(ev[4 * k + 3], s_down) == hipSuccess;
+        if (!ok) {
+            drain();
+            return FG_ERR_HIP;
+        }
         base = end;
+    }
+    // the fixed-size arrays -- offsets, meta, status of every line -- in three copies behind the last slice's messages (per slice they
+    // were three more launches between two downloads: a tenth of a millisecond of an idle link per slice)
+    {
+        uint8_t* hh = ctx->h_tout;
+        bool ok = hipStreamWaitEvent(s_down, ev[4 * (slices - 1u) + 2], 0) == hipSuccess;
+        ok = ok && hipMemcpyAsync(hh + o_offs, d_out_offsets, (n + 1) * 8, hipMemcpyDeviceToHost, s_down) == hipSuccess;
+        ok = ok && hipMemcpyAsync(hh + o_meta, dt.meta, n * 4, hipMemcpyDeviceToHost, s_down) == hipSuccess;
+        ok = ok && hipMemcpyAsync(hh + o_st, d_enc_status, n, hipMemcpyDeviceToHost, s_down) == hipSuccess;
+        if (!ok) {
+            drain();
+            return FG_ERR_HIP;
+        }
     }
     drain();
     // an entry table that was too small shows up as FG_ST_OVERFLOW rows: the one-piece path sizes it exactly
@@ -1152,7 +1218,9 @@ int fg_transcode_batch(fg_ctx* ctx, fg_format fmt, fg_framing framing, const fg_
     DeviceGuard g(ctx->device);
     hipStream_t s = ctx->stream;
     int rc;
-    if (framing == FG_FRAME_NONE && nbytes >= (64ull << 20) && n >= 4096 && !(ctx->lo.flags & FG_LO_TRANSCODE_ONE_PIECE)) {
+    // (from 16 MiB: the slices start at 4 MiB, so a 25 MB batch already has its first download in flight while the rest uploads --
+    //  100 000 lines 1.65 vs 1.81 ms in one piece, 250 000 lines 3.35 vs 4.2; at 13 MB the two forms are level)
+    if (framing == FG_FRAME_NONE && nbytes >= (16ull << 20) && n >= 4096 && !(ctx->lo.flags & FG_LO_TRANSCODE_ONE_PIECE)) {
         rc = transcode_sliced(ctx, fmt, ecfg, bytes, nbytes, offsets, n, out);
         if (rc != FG_ERR_UNSUPPORTED) return rc;
         *out = fg_transcoded{};
