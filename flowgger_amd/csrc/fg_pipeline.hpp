@@ -175,6 +175,28 @@ __device__ __forceinline__ void store_row(const DevTables& t, uint64_t li, const
     gstore(t.ent_first, li, o.first);
     gstore(t.ent_count, li, o.count);
 }
+#if defined(FG_ROW64_AB)
+// MEASUREMENT VARIANT ONLY (FG_BUILD_VARIANT=row64a / row64b, tools/probe/row64_ab.py): the fixed part of a line as
+// ONE 64-byte record (meta, ts, six spans, entry count -- the entry index folded away) at (uint4*)t.meta + 4 * line, instead of nine
+// column stores.  The tables of this build are NOT the ABI's: nothing but the timing of the decode launch means anything.
+//   FG_ROW64_AB == 1  each lane stores its own record: four 16-byte stores at a 64-byte stride
+//   FG_ROW64_AB == 2  the wave's 64 records transposed through the (free) head of the LDS tile: four stores of 1 KiB contiguous each
+__device__ __forceinline__ void pack_row64(const RowOut& o, uint4 w[4]) {
+    const uint64_t tsb = (uint64_t)__double_as_longlong(o.ts);
+    w[0] = make_uint4(o.meta, (uint32_t)tsb, (uint32_t)(tsb >> 32), o.span[0].off);
+    w[1] = make_uint4(o.span[0].len, o.span[1].off, o.span[1].len, o.span[2].off);
+    w[2] = make_uint4(o.span[2].len, o.span[3].off, o.span[3].len, o.span[4].off);
+    w[3] = make_uint4(o.span[4].len, o.span[5].off, o.span[5].len, o.count);
+}
+__device__ __forceinline__ void store_row64_lane(const DevTables& t, uint64_t li, const RowOut& o) {
+    if (o.skip) return;
+    uint4 w[4];
+    pack_row64(o, w);
+    uint4* g = reinterpret_cast<uint4*>(t.meta) + li * 4u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g[j] = w[j];
+}
+#endif
 // Entries found while a line is parsed are parked in the wave's scratch (stash[k * 64 + lane],
 // k < kStashEntries, two u64 per entry in the GELF/LTSV kernels, one in the RFC5424 kernel) and
 // copied into the entry table once the wave has its slots -- instead of parsing every line twice.
@@ -488,6 +510,14 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
     RowOut pend{};
     uint64_t pend_li = 0;
     bool pend_valid = false;
+#if defined(FG_ROW64_AB) && FG_ROW64_AB == 2
+    // the pending group's records: transposed (on their way to memory) / as each lane packed its own (scalars, not arrays: the arrays stayed in scratch)
+    uint4 rq0 = {}, rq1 = {}, rq2 = {}, rq3 = {}, pw0 = {}, pw1 = {}, pw2 = {}, pw3 = {};
+    uint64_t rq_p = 0;    // first line of the pending group (wave-uniform)
+    uint32_t rq_nl = 0;   // its lines; 0 = nothing pending
+    uint64_t pend_p = 0;
+    uint32_t pend_nl = 0;
+#endif
     uint64_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0, iters = 0, tm0 = 0, tm1 = 0, tm2 = 0, tm3 = 0;
     // measurement build only: prof[5] = ablation flags (1 = no table stores, 2 = no stage B,
     // 4 / 8 = format-specific, see the decoders)
@@ -523,6 +553,27 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the window has landed
             tm1 = __builtin_amdgcn_s_memtime();
         }
+#if defined(FG_ROW64_AB) && FG_ROW64_AB == 2
+        rq_nl = 0;
+        if (!HEAD && defer_row_store<F>::value) {  // the tile is free: stage B of the last group is done (unconditional: `pend` dies here)
+            uint4* rb = reinterpret_cast<uint4*>(smem);
+            const uint32_t sw = (lane >> 1) & 3u;  // (16-byte chunks of a record swizzled: lanes two apart would share their banks)
+            rb[lane * 4u + (0u ^ sw)] = pw0;
+            rb[lane * 4u + (1u ^ sw)] = pw1;
+            rb[lane * 4u + (2u ^ sw)] = pw2;
+            rb[lane * 4u + (3u ^ sw)] = pw3;
+            __syncthreads();
+            rq0 = rb[lane];
+            rq1 = rb[64u + lane];
+            rq2 = rb[128u + lane];
+            rq3 = rb[192u + lane];
+            __syncthreads();  // (before stage A overwrites the tile)
+            rq_p = pend_p;
+            rq_nl = pend_nl;
+            pend_nl = 0;
+            pend_valid = false;
+        }
+#endif
         // ---- stage A for this group: registers -> LDS, classify on the way ----------------------
         FG_MARK(A);
         const uint32_t nchunk = span >> 4;
@@ -607,7 +658,19 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
             __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): LDS writes retired
             tm2 = __builtin_amdgcn_s_memtime();
         }
+#if defined(FG_ROW64_AB) && FG_ROW64_AB == 2
+        if (rq_nl != 0u && !(ablate & 1u)) {
+            uint4* g = reinterpret_cast<uint4*>(t.meta) + rq_p * 4u;
+            if (lane < rq_nl * 4u) g[lane] = rq0;
+            if (64u + lane < rq_nl * 4u) g[64u + lane] = rq1;
+            if (128u + lane < rq_nl * 4u) g[128u + lane] = rq2;
+            if (192u + lane < rq_nl * 4u) g[192u + lane] = rq3;
+        }
+#elif defined(FG_ROW64_AB)
+        if (pend_valid && !(ablate & 1u)) store_row64_lane(t, pend_li, pend);
+#else
         if (pend_valid && !(ablate & 1u)) store_row(t, pend_li, pend);
+#endif
         // ---- prefetch: the next group's geometry from its offsets, then its bytes into the register window ----
         uint64_t pa0 = 0;
         uint32_t pspan = 0, pnl = 0, pst = 0, ptb = 0, plast2 = 0;
@@ -672,8 +735,21 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
             }
             pend_li = li;
             pend_valid = valid;
+#if defined(FG_ROW64_AB) && FG_ROW64_AB == 2
+            pend_p = p;
+            pend_nl = nl;
+            if (!HEAD && defer_row_store<F>::value) {
+                uint4 w[4];
+                pack_row64(pend, w);
+                pw0 = w[0], pw1 = w[1], pw2 = w[2], pw3 = w[3];
+            }
+#endif
             if (!defer_row_store<F>::value) {  // (a format whose stage A waits for its own loads anyway: nothing to hide behind)
+#if defined(FG_ROW64_AB)
+                if (pend_valid && !(ablate & 1u)) store_row64_lane(t, pend_li, pend);
+#else
                 if (pend_valid && !(ablate & 1u)) store_row(t, pend_li, pend);
+#endif
                 pend_valid = false;
             }
         }
@@ -702,7 +778,20 @@ __device__ __forceinline__ void persistent_loop(const uint8_t* __restrict__ byte
             last2 = plast2;
         }
     }
+#if defined(FG_ROW64_AB) && FG_ROW64_AB == 2
+    if (!HEAD && defer_row_store<F>::value) {
+        if (pend_valid && !(ablate & 1u)) {
+            uint4* g = reinterpret_cast<uint4*>(t.meta) + pend_li * 4u;
+            g[0] = pw0, g[1] = pw1, g[2] = pw2, g[3] = pw3;
+        }
+    } else if (pend_valid && !(ablate & 1u)) {
+        store_row64_lane(t, pend_li, pend);
+    }
+#elif defined(FG_ROW64_AB)
+    if (pend_valid && !(ablate & 1u)) store_row64_lane(t, pend_li, pend);
+#else
     if (pend_valid && !(ablate & 1u)) store_row(t, pend_li, pend);
+#endif
     if (PROF && lane == 0) {
         atomicAdd(&prof[0], (unsigned long long)acc0);
         atomicAdd(&prof[1], (unsigned long long)acc1);
