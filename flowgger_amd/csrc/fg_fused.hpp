@@ -260,7 +260,10 @@ __device__ __forceinline__ void fused_loop(const uint8_t* __restrict__ bytes, co
     if (lane < 2u) ent_state[lane] = 0u;
     for (uint32_t c = lane; c < dm_cap; c += kWave) FL.dm16[c] = 0u;
     const uint32_t K = fa.counters;
-    const uint32_t cq = K ? blockIdx.x % K : 0u;
+    // (workgroups go round the eight XCDs: with `blockIdx.x % K` a counter's waves all sat on ONE XCD, the XCDs do not run at one pace,
+    //  and every tile waited for the slowest counter's; `(blockIdx.x / 8) % K` gives each counter an eighth of every XCD's waves.  A grid
+    //  of fewer than 8 K workgroups keeps the plain residue: every counter must have a wave)
+    const uint32_t cq = K ? (gridDim.x >= 8u * K ? (blockIdx.x >> 3) % K : blockIdx.x % K) : 0u;
     uint32_t* const counter = fa.tickets + cq * kFusedCounterStride;
     const uint32_t term4 = fa.delim4;
     const uint64_t padded = (fa.nbytes + 15ull) & ~15ull;
