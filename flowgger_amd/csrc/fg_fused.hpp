@@ -634,7 +634,12 @@ inline int fused_prepare(K kernel, const FusedGeom& g, uint32_t base_lds, uint64
     if (b > fa->ntiles) b = fa->ntiles;
     if (b < 1u) b = 1u;
     *blocks = (uint32_t)b;
-    fa->counters = (lo.flags & FG_LO_STATIC_CHUNKS) ? 0u : b < kFusedCounters ? (uint32_t)b : kFusedCounters;
+#if defined(FG_FUSED_K)  // (A/B builds: fewer counters than the scratch has room for)
+    constexpr uint32_t kUse = FG_FUSED_K < kFusedCounters ? FG_FUSED_K : kFusedCounters;
+#else
+    constexpr uint32_t kUse = kFusedCounters;
+#endif
+    fa->counters = (lo.flags & FG_LO_STATIC_CHUNKS) ? 0u : b < kUse ? (uint32_t)b : kUse;
     if (hipMemsetAsync(scratch, 0, fused_scratch_bytes(nbytes, g.S), stream) != hipSuccess) return -1;
     return 0;
 }

@@ -894,6 +894,13 @@ extern "C" int fg_launch_gelf_general_dev(const uint8_t* d_bytes, const uint64_t
 
 // The fused launch (fg_fused.hpp): frame + the fast form of a raw stream chunk in one kernel (see fg_launch_rfc5424_fused).  The lines
 // the fast form hands back are finished by fg_launch_gelf_general_dev over the offsets this launch writes (n read on the device).
+// waves per SIMD the resident fused instantiation is compiled for (A/B builds: -DFG_GELF_FUSED_MINW=2 / 4).  Measured on one box
+// (profiles/r06ar_gelf_fused_minw.log, 4 M lines): two waves (228 VGPRs, no scratch) 5.39 ms, three (168, 144 bytes of scratch) 5.12,
+// four (128, 272 bytes) 5.35 -- the spills are not what holds this kernel back; across the link four waves (384 bytes) gave 0.82 of the
+// link and two (no scratch) 0.79, so that instantiation stays at four.
+#ifndef FG_GELF_FUSED_MINW
+#define FG_GELF_FUSED_MINW 3
+#endif
 extern "C" int fg_launch_gelf_fused(const uint8_t* d_bytes, uint64_t nbytes, const fg::DevTables* t, const fg::FusedGeom* g, hipStream_t stream,
                                     uint32_t strip, int final_, uint64_t* d_offsets, uint64_t cap, uint8_t* scratch, const fg_launch_opts* lo,
                                     unsigned long long** d_total) {
@@ -903,7 +910,7 @@ extern "C" int fg_launch_gelf_fused(const uint8_t* d_bytes, uint64_t nbytes, con
     uint32_t lds = 0, blocks = 0;
     const uint32_t delim = strip == FG_FRAME_LINE ? 0x0Au : 0u;
     const bool konst = g->variant == 1u && g->tile == 3072u && g->L == 8u;
-    const int prc = konst ? fg::fused_prepare(fg::k_gelf_fused<3, 4, 3072u, 8u>, *g, base_lds, nbytes, final_, delim, d_offsets, cap, scratch, 0u, *lo, stream,
+    const int prc = konst ? fg::fused_prepare(fg::k_gelf_fused<3, FG_GELF_FUSED_MINW, 3072u, 8u>, *g, base_lds, nbytes, final_, delim, d_offsets, cap, scratch, 0u, *lo, stream,
                                               &fa, &lds, &blocks)
                           : fg::fused_prepare(fg::k_gelf_fused<6, 4>, *g, base_lds, nbytes, final_, delim, d_offsets, cap, scratch, 0u, *lo, stream, &fa, &lds,
                                               &blocks);
@@ -912,7 +919,7 @@ extern "C" int fg_launch_gelf_fused(const uint8_t* d_bytes, uint64_t nbytes, con
     tt.alloc_chunk = fg::entry_chunk(tt.ent_cap, blocks, nbytes / (g->S / g->L ? g->S / g->L : 1u) + 1u, *lo, tt.shares);
     *d_total = fa.total;
     if (konst)
-        hipLaunchKernelGGL((fg::k_gelf_fused<3, 4, 3072u, 8u>), dim3(blocks), dim3(fg::kWave), lds, stream, d_bytes, tt, g->tile, g->L, fa, strip);
+        hipLaunchKernelGGL((fg::k_gelf_fused<3, FG_GELF_FUSED_MINW, 3072u, 8u>), dim3(blocks), dim3(fg::kWave), lds, stream, d_bytes, tt, g->tile, g->L, fa, strip);
     else
         hipLaunchKernelGGL((fg::k_gelf_fused<6, 4>), dim3(blocks), dim3(fg::kWave), lds, stream, d_bytes, tt, g->tile, g->L, fa, strip);
     return (int)hipGetLastError();
