@@ -121,9 +121,13 @@ __global__ __launch_bounds__(kWave) void k_rfc3164(const uint8_t* __restrict__ b
                 rd.load16(16u, w + 4);  // (what lies behind a line's end is masked by its length; the tile is followed by 48 spare bytes)
                 key = r3164_key(w, len64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)len64);
             }
+            // a group that is MOSTLY slow shapes parses them where they are: the wave is full enough as it stands, and a corpus of one slow
+            // shape would otherwise go through the lists line by line for nothing (16.7 M zone-tagged lines: 7.2 G lines/s in place, 4.9 G
+            // through the lists; the custom form 5.3 vs 3.9 -- profiles/r06fin_rfc3164_shapes.log)
+            const bool regroup = __popcll(__ballot(live && key >= kSlowKey)) < 32;  // wave-uniform
 #pragma unroll
             for (uint32_t c = 0; c < 2u; ++c) {
-                const bool mine = live && len64 <= 0xFFFFFFFFull && (c == 0u ? (key == 2u || key == 3u) : key == 4u);
+                const bool mine = regroup && live && len64 <= 0xFFFFFFFFull && (c == 0u ? (key == 2u || key == 3u) : key == 4u);
                 const unsigned long long m = __ballot(mine);
                 if (m) {  // wave-uniform
                     const uint32_t s = c * kSubLists + (blockIdx.x & (kSubLists - 1u));
