@@ -17,7 +17,7 @@
 // aligned SIXTEEN-byte blocks (emit::PackSink, round 5: a message's first and last block go out by dwords and bytes so that
 // nothing outside the message is touched; rounds 1-4 packed dwords).  Output stores are per lane (each lane streams into its
 // own message): per-lane 16-byte stores run at 3.0 TB/s against 0.92 TB/s for per-lane dword stores and 4.9 TB/s fully
-// coalesced (tools/probe/store_patterns.cpp, profiles/r05c_store_patterns.log).  Measured (DESIGN.md sections 3.5, 4.0): the
+// coalesced (tools/probe/store_patterns.cpp, profiles/r05c_store_patterns.log).  Measured (DESIGN.md sections 3.5, 4.1): the
 // kernels run at two waves per SIMD (the LDS tile is the occupancy limit); a message goes out as ~45 pieces of up to sixteen
 // bytes (round 5; 108 before), and what reaches HBM is 1.68x the message's bytes -- emitting once, wave-cooperatively, is what
 // is left.
