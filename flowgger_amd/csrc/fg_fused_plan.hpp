@@ -46,6 +46,7 @@ struct FusedGeom {
     uint32_t tile = 0;         // LDS tile bytes (a multiple of 1024, >= 16 + S + look + 16)
     uint32_t ext = 1024;       // bytes staged on at a time when the tile's last line runs past the look-ahead (a multiple of 16, <= 1024)
     uint32_t L = 64;           // lines a pass of stage B takes
+    uint32_t plan = 0;         // lines the tile is planned to hold (0: L -- one pass per tile); more than L: several passes per tile
     uint32_t variant = 0;      // the format's kernel instantiation (RFC5424: 1 = pair-parallel structured data; GELF: 1 = the constant 3 KiB geometry)
     bool ok = false;           // false: this stream keeps the separate framing pass (long lines: head staging)
 };
@@ -74,6 +75,15 @@ inline FusedGeom fused_geometry(fg_format fmt, uint64_t avg_len, const fg_launch
             g.L = link_bound ? 48u : 8u;
             bound = link_bound ? 16384u : 8u * avg_len * 17u / 16u + 256u <= 3072u ? 3072u : 8192u;
             if (!link_bound && bound == 3072u && !lo.tile_cap && !lo.lines_per_group && !(lo.flags & FG_LO_GELF_GENERIC)) g.variant = 1u;
+#if defined(FG_GELF_FUSED_PLAN)  // (A/B builds: resident tiles of that many lines, eight to the pass -- a quarter of the look-backs at 32.
+                                 //  MEASURED, 4 M lines on one box: 5.14 ms as shipped, 7.46 with 16 lines, 7.18 with 32: profiles/r06at_gelf_fused_plan.log)
+            if (!link_bound) {
+                g.plan = FG_GELF_FUSED_PLAN;
+                g.variant = 0u;
+                bound = (uint32_t)((uint64_t)g.plan * avg_len + 2048u + 1023u) / 1024u * 1024u;
+                if (bound > 16384u) bound = 16384u;
+            }
+#endif
             break;
         default:
             return g;
@@ -83,7 +93,7 @@ inline FusedGeom fused_geometry(fg_format fmt, uint64_t avg_len, const fg_launch
     if (bound < 2048u) bound = 2048u;
     if (link_bound) g.ext = 256u;  // (a KiB read on for a line that needed 150 bytes more is look-ahead too)
     if (lo.fused_ext >= 16u && lo.fused_ext <= 1024u) g.ext = lo.fused_ext & ~15u;
-    const fuse::TilePlan tp = fuse::plan_tile(avg_len, g.L, bound, lo.fused_look <= 4096u ? lo.fused_look : 0u);
+    const fuse::TilePlan tp = fuse::plan_tile(avg_len, g.plan ? g.plan : g.L, bound, lo.fused_look <= 4096u ? lo.fused_look : 0u);
     g.S = tp.S;
     g.look = tp.look;
     // (the tile keeps the room plan_tile left for staging on: the LDS tile is the bound it planned with unless the lines are short)

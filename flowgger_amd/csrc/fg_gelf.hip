@@ -916,7 +916,7 @@ extern "C" int fg_launch_gelf_fused(const uint8_t* d_bytes, uint64_t nbytes, con
                                               &blocks);
     if (prc) return -1;
     fg::DevTables tt = *t;
-    tt.alloc_chunk = fg::entry_chunk(tt.ent_cap, blocks, nbytes / (g->S / g->L ? g->S / g->L : 1u) + 1u, *lo, tt.shares);
+    tt.alloc_chunk = fg::entry_chunk(tt.ent_cap, blocks, nbytes / (g->S / (g->plan ? g->plan : g->L) ? g->S / (g->plan ? g->plan : g->L) : 1u) + 1u, *lo, tt.shares);
     *d_total = fa.total;
     if (konst)
         hipLaunchKernelGGL((fg::k_gelf_fused<3, FG_GELF_FUSED_MINW, 3072u, 8u>), dim3(blocks), dim3(fg::kWave), lds, stream, d_bytes, tt, g->tile, g->L, fa, strip);
