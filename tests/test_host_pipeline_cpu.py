@@ -435,8 +435,9 @@ def test_argument_errors(fake):
 
 @pytest.mark.parametrize("dense", [False, True])
 def test_transcode_sliced_equals_one_piece(fake, dense):
-    """fg_transcode_batch above 64 MiB: slices alternate between two lanes (upload, decode, count; then scan from the running base,
-    write, download), output buffers sized from the first slice; same stream, offsets, row meta and encoder status as the one-piece
+    """fg_transcode_batch from 16 MiB: slices that grow from 4 MiB, one stream per direction of the link (upload, decode, count /
+    scan from the running base, write / downloads, the fixed-size arrays once at the end), output buffers sized from the first
+    slice; same stream, offsets, row meta and encoder status as the one-piece
     form -- also when the entry table is too small for the sliced form (it then hands the batch to the one-piece form)."""
     fake.fg_transcode_batch.argtypes = [vp, C.c_int, C.c_int, C.POINTER(L.fg_encode_cfg), vp, u64, vp, u64, C.c_int, C.POINTER(L.fg_transcoded)]
     rng = np.random.default_rng(6)
