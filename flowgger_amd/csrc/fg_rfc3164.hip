@@ -166,7 +166,11 @@ __global__ __launch_bounds__(kWave) void k_rfc3164(const uint8_t* __restrict__ b
 // group in flight (the permuted decode is ~40 % slower per line than the contiguous one, and the pre-pass reads 58 % of the stream again);
 // the everyday lines in place and only the slow ones permuted 4.45 G; then the key computed IN the decode kernel from the staged tile --
 // no pre-pass at all -- (below).  Round 5's two forms for comparison: the streaming pipeline -4 %, the two-kernel form that parsed every
-// line the standard way first +5 %.  Small batches (below kRegroupFrom lines: one M) keep the plain kernel -- the second launch and its part-filled workgroups cost more than the union does.
+// line the standard way first +5 %.  MEASURED AND REMOVED at the end of round 6 (profiles/r06au_rfc3164_shapes.log, "library choice" there):
+// the regrouping done INSIDE a workgroup of four waves (four tiles, the 256 lines dealt out again in key order through LDS, no lists, no
+// second kernel) -- 3.49 G lines/s on the mix against 4.10 plain and 5.18 with the lists, and 8.8 against 11.5 G on the everyday shape
+// alone: the workgroup holds its four tiles until its slowest (custom-shape) wave is done, and two workgroups per CU overlap their
+// staging and their parsing far worse than nine independent waves do.  Small batches (below kRegroupFrom lines: one M) keep the plain kernel -- the second launch and its part-filled workgroups cost more than the union does.
 // ---------------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kWave) void k_rfc3164_perm(const uint8_t* __restrict__ bytes, DevTables t, R3164Args a, uint32_t tile_cap, R3164Lists lists) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_tile[];  // tile_cap + 16 bytes

@@ -32,7 +32,7 @@ def main():
     for ln in lines:
         groups.setdefault(shape(ln), []).append(ln)
     for name, ls in groups.items():
-        for n, mode in ((65536, 2), (1 << 20, 2), (1 << 24, 2), (1 << 24, 0)):
+        for n, mode in ((65536, 2), (65536, 0), (1 << 20, 2), (1 << 20, 0), (1 << 24, 2), (1 << 24, 1), (1 << 24, 0)):
             tile = ls[: min(len(ls), 65536)]
             reps = max(1, n // len(tile))
             R = bench.Resident(3, tile, reps, dev, 0, {"rfc3164_regroup": mode}, entries=False)
@@ -45,7 +45,7 @@ def main():
                 b.record(stream)
             torch.cuda.synchronize(dev)
             ts = sorted(a.elapsed_time(b) for a, b in ev)
-            print(f"rfc3164 {name:7s} share {len(ls) / len(lines):5.2f}  n={R.n:8d}  {'plain kernel' if mode == 2 else 'library choice'}  {ts[3] * 1e3:8.1f} us  {R.n / ts[3] / 1e3:8.1f} M lines/s", flush=True)
+            print(f"rfc3164 {name:7s} share {len(ls) / len(lines):5.2f}  n={R.n:8d}  {'plain kernel' if mode == 2 else 'global lists' if mode == 1 else 'library choice'}  {ts[3] * 1e3:8.1f} us  {R.n / ts[3] / 1e3:8.1f} M lines/s", flush=True)
             del R
             torch.cuda.empty_cache()
 
