@@ -91,8 +91,8 @@ def test_bench_launches_its_own_ranks():
 
 @pytest.mark.parametrize("src,enc,merger", [("rfc5424", "gelf", "line"), ("sd", "rfc5424", "syslen"), ("gelf", "gelf", "nul")])
 def test_transcode_large_batch_is_sliced_over_two_streams(oracle, src, enc, merger):
-    """fg_transcode_batch above 64 MiB: the batch goes through upload -> decode -> encode -> download as ~32 MiB slices on two
-    streams.  Same bytes as the one-piece path (fg_launch_opts: FG_LO_TRANSCODE_ONE_PIECE) and as the oracle's decode -> encode -> merger."""
+    """fg_transcode_batch on a large batch: upload -> decode -> encode -> download in slices (rounds 2-5: ~32 MiB slices on two lanes;
+    round 6: slices that grow from 4 MiB, one stream per direction of the link).  Same bytes as the one-piece path (fg_launch_opts: FG_LO_TRANSCODE_ONE_PIECE) and as the oracle's decode -> encode -> merger."""
     import oracle_binding as OB
     from flowgger_amd import GelfEncoder, Pipeline, RFC5424Encoder
 

@@ -291,3 +291,35 @@ def test_rfc3164_regrouped_frames_and_large_batch(oracle):
     dec.set_launch_opts()
     for a, b in zip(metas[0], metas[2]):
         assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_lines", [70_000, 101_003, 170_000])
+def test_transcode_growing_slices_equal_one_piece_and_the_oracle(oracle, n_lines):
+    """fg_transcode_batch from 16 MiB (round 6): slices of 4, 8, 16 ... MiB on one stream per direction of the link, a short last slice
+    merged into the one before, the fixed-size arrays downloaded once at the end.  18 / 26 / 43 MB of cfg2 lines: the same bytes,
+    offsets and statuses as the one-piece path, twice (buffers at size the second time), and as the oracle's decode -> encode -> merger
+    on a prefix."""
+    import oracle_binding as OB
+    from flowgger_amd import GelfEncoder, Pipeline
+
+    dec = RFC5424Decoder()
+    lines = synth.rfc5424_lines(n_lines, cfg=2, invalid_frac=0.01)
+    data, offsets = synth.pack(lines)
+    assert data.size > (16 << 20)
+    data = np.concatenate([data, np.zeros(64, np.uint8)])
+    now_ts = 1438859724.638
+    pipe = Pipeline(dec, GelfEncoder(None, merger="line"))
+    sliced = pipe.run_packed(data, offsets, now_ts=now_ts)
+    again = pipe.run_packed(data, offsets, now_ts=now_ts)
+    dec.set_launch_opts(transcode_one_piece=True)
+    whole = pipe.run_packed(data, offsets, now_ts=now_ts)
+    dec.set_launch_opts()
+    for r in (sliced, again):
+        assert r.n == len(lines) and r.consumed == int(offsets[-1])
+        assert np.array_equal(r.out_offsets, whole.out_offsets) and np.array_equal(r.out, whole.out)
+        assert np.array_equal(r.enc_status, whole.enc_status) and np.array_equal(r.dec_status, whole.dec_status)
+    m = 20_000
+    oblob, ooffs, ost = oracle.decode_encode_batch(RFC5424, OB.ENC_GELF, OB.MERGE_LINE, data, offsets[: m + 1], None, extra=None, prepend=None, now_ts=now_ts)
+    assert np.array_equal(sliced.out_offsets[: m + 1], ooffs) and np.array_equal(sliced.out[: int(ooffs[-1])], oblob)
+    assert np.array_equal(np.minimum(sliced.enc_status[:m], 2), ost)
